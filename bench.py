@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+metric: poly-mults/sec (NTT + pointwise + INTT), n = 4096, 4 x 62-bit moduli.
+One "step" = one pass of the hot path over one batch of synthetic input:
+    c = INTT( NTT(a) (.) NTT(b) )   for every poly of the per-GPU batch
+i.e. the reference sequence a.ntt_pow_phi(); b.ntt_pow_phi(); c = a*b;
+c.invntt_pow_invphi() (poly.hpp:167-168, 350) as ONE fused HIP kernel.
+Inputs are generated on the device (seeded counter stream) and are resident in
+HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+N>1 is launched by torch.distributed.run, one rank per GPU: batch split with no
+data-path collective (weak scaling: per-GPU batch fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x4E464C6C6962
+WORKLOADS = {
+    # name: (limb_bits, degree, nmoduli, default per-GPU batch)
+    "B": (64, 4096, 4, 16384),   # BASELINE.json configs[1] -- the metric is quoted on this
+    "C": (64, 16384, 8, 1024),   # configs[2]
+    "E": (64, 65536, 30, 32),    # configs[4]
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0):
+    """Time the CPU path on this host on a bounded sample of the same workload.
+    kind "reference": the REAL NFLlib (oracle/_ref/libnflref.so, prebuilt in the
+    build container from /root/reference's own sources) when it loads here;
+    otherwise kind "port": oracle/nfl_oracle.c, rebuilt -march=native on this host."""
+    import numpy as np
+    from nfllib_amd.params import params
+    from oracle import oracle as O
+    out = {}
+    native_dir = os.path.join(ROOT, "gpurun_out")
+    libpath = None
+    try:
+        os.makedirs(native_dir, exist_ok=True)
+        O.build(native_out=native_dir)
+        libpath = os.path.join(native_dir, "libnfloracle_native.so")
+    except Exception:
+        libpath = None
+    o = O.Oracle(limb_bits, degree, nmoduli, params(limb_bits), libpath=libpath)
+    gen = o.fill_uniform
+
+    def run(fn, label):
+        a, b = gen(8, SEED, 0), gen(8, SEED, 1)
+        t0 = time.perf_counter(); fn(a, b); dt = time.perf_counter() - t0
+        chunk = max(8, min(512, int(8 * 1.0 / max(dt, 1e-6))))
+        a, b = gen(chunk, SEED, 0), gen(chunk, SEED, 1)
+        done, t_used = 0, 0.0
+        while t_used < budget_s:
+            t0 = time.perf_counter(); fn(a, b); t_used += time.perf_counter() - t0
+            done += chunk
+        return {"value": done / t_used, "sample": "%d polymuls (%s) in %.1f s, 1 thread" % (done, label, t_used)}
+
+    port = run(o.polymul, "oracle/nfl_oracle.c -O3 -march=native" if libpath else "oracle/nfl_oracle.c -O3 x86-64-v3")
+    ref = None
+    try:
+        if O.ref_available():
+            r = O.Reference(limb_bits, degree, nmoduli)
+            ref = run(r.polymul, "real NFLlib via oracle/_ref, NFL_OPTIMIZED+NTT_AVX2 x86-64-v3")
+    except Exception:
+        ref = None
+    best = ref or port
+    out = {"value": round(best["value"], 2), "unit": "polymul/s", "cores": 1, "kind": "reference" if ref else "port",
+           "sample": best["sample"], "port_value": round(port["value"], 2)}
+    try:
+        with open("/proc/cpuinfo") as f:
+            models = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+        out["cpu"] = models[0] if models else "unknown"
+        out["host_cores"] = len(models)
+    except Exception:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=0, help="polys per GPU (default: workload default)")
+    ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nfllib_amd import Engine
+    from nfllib_amd import sharding
+
+    rank, world, local_rank = sharding.env_rank_world()
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+
+    lb, n, nm, dflt = WORKLOADS[args.workload]
+    batch = args.batch or dflt
+    eng = Engine(lb, n, nm, device=dev)
+    first_poly = rank * batch  # shard of the logical global batch; no data-path collective
+    a = eng.fill_uniform(eng.empty(batch), SEED, 0, first_poly=first_poly)
+    b = eng.fill_uniform(eng.empty(batch), SEED, 1, first_poly=first_poly)
+    c = eng.empty(batch)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.polymul(a, b, out=c)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # on the current stream == the stream the kernels are launched on
+    for _ in range(args.steps):
+        eng.polymul(a, b, out=c)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        dt = sharding.allreduce_max(dt, dist, device=torch.device("cuda", dev))
+        kernel_ms = sharding.allreduce_max(kernel_ms, dist, device=torch.device("cuda", dev))
+
+    # cheap in-run sanity: one sampled poly against nothing but itself commuting (parity lives in tests/)
+    ok = not eng.any_neq(c, eng.polymul(b, a))
+
+    alg_bytes_per_poly = 3 * nm * n * (lb // 8)       # read a, read b, write c
+    launch_bytes = alg_bytes_per_poly * batch
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    value = world * batch * args.steps / dt
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload:
+                traffic = tj["hbm_bytes_per_poly"] * batch
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli" if args.workload == "B"
+                  else "poly-mults/sec (NTT+pointwise+INTT), n=%d, %dx62-bit moduli" % (n, nm),
+        "value": round(value, 1), "unit": "polymul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "nfl::poly<uint64_t,%d,%d> batched polymul (BASELINE configs %s)" % (n, nm, args.workload),
+                   "degree": n, "nmoduli": nm, "limb_bits": lb, "batch_per_gpu": batch, "global_batch": batch * world,
+                   "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "k_polymul4096<false>" if args.workload == "B" else "composed",
+                     "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(lb, n, nm, args.cpu_budget)
+        except Exception as e:  # the checker must never take the bench down
+            result["cpu_baseline"] = {"value": None, "unit": "polymul/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

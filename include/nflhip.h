@@ -1,0 +1,178 @@
+/* nflhip.h -- C ABI of the MI355X-native NTT polynomial-ring engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of quarkslab/NFLlib that
+ * this project accelerates: whole-polynomial / whole-batch
+ * operations on the dense modulus-major coefficient block of
+ * nfl::poly<T, Degree, NbModuli> (reference include/nfl/poly.hpp:82-88:
+ * `T _data[NbModuli*Degree]`, element (cm,i) at `_data[cm*Degree+i]`).  A batch
+ * is an array of polys, i.e. a dense [batch][NbModuli][Degree] tensor (how the
+ * reference's tests allocate: tests/tools.h:6-17).
+ *
+ * Every entry point names the reference interface it replaces (file:line under
+ * /root/reference).  All results are bit-identical to the reference's on the
+ * same inputs.  Plain C types only; no exceptions cross this boundary: every
+ * call returns an int status (0 = NFLHIP_OK) and nflhip_last_error() gives the
+ * text.  The library is implemented in hand-written HIP for gfx950 and there
+ * is NO CPU fallback: without a usable GPU every compute call fails with
+ * NFLHIP_ERR_NO_DEVICE.
+ *
+ * Pointer conventions
+ *   *_dev entry points take DEVICE pointers and a hipStream_t (passed as
+ *   void*; NULL = the null stream) and are asynchronous on that stream.
+ *   The un-suffixed entry points take HOST pointers, stage through
+ *   context-owned device buffers and return after the result is in host
+ *   memory (the per-poly calls of the header-only nfl::poly surface use them).
+ *   `out` may alias any input of an element-wise op (the reference's
+ *   evaluation loop is strictly element-wise: core.hpp:24-37).
+ */
+#ifndef NFLHIP_H
+#define NFLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFLHIP_ABI_VERSION 1
+
+typedef struct nflhip_ctx nflhip_ctx;
+
+/* status codes */
+enum {
+  NFLHIP_OK = 0,
+  NFLHIP_ERR_INVALID = 1,    /* bad argument (std::runtime_error / static_assert in the reference) */
+  NFLHIP_ERR_NO_DEVICE = 2,  /* no usable HIP device: there is no CPU fallback */
+  NFLHIP_ERR_HIP = 3,        /* a HIP runtime call failed */
+  NFLHIP_ERR_UNSUPPORTED = 4,/* shape outside what the engine implements */
+  NFLHIP_ERR_NOMEM = 5
+};
+
+/* element-wise operations (the functors poly::operator=(expr) evaluates) */
+enum {
+  NFLHIP_OP_ADD = 0,           /* ops::addmod        ops.hpp:124-135; operator+  poly.hpp:347 */
+  NFLHIP_OP_SUB = 1,           /* ops::submod        ops.hpp:141-151; operator-  poly.hpp:346 */
+  NFLHIP_OP_MUL = 2,           /* ops::mulmod        ops.hpp:183-219; operator*  poly.hpp:350 */
+  NFLHIP_OP_MUL_SHOUP = 3,     /* ops::mulmod_shoup  ops.hpp:225-242; shoup(a*b,b') ops.hpp:267-277 */
+  NFLHIP_OP_COMPUTE_SHOUP = 4  /* ops::compute_shoup ops.hpp:165-177; poly.hpp:352 */
+};
+
+/* tables readable through nflhip_get_table (reference-format views, for parity tests) */
+enum {
+  NFLHIP_TAB_PSI = 0,       /* engine layout: n pairs (psi^bitrev(k), Shoup companion), k=0..n-1 */
+  NFLHIP_TAB_MODULUS = 1,   /* 1 word: params<T>::P[cm]                       params.hpp:21,55,97 */
+  NFLHIP_TAB_INVDEGREE = 2  /* 1 word: core::invpolyDegree[cm]                core.hpp:664-665 */
+};
+
+int nflhip_abi_version(void);
+/* Text of the last error on this context (or, with ctx == NULL, of the last
+ * failed nflhip_ctx_create on the calling thread). Never NULL. */
+const char *nflhip_last_error(const nflhip_ctx *ctx);
+int nflhip_device_count(int *count);
+
+/* ---- context: replaces the static tables of poly::core / poly::GMP ----------
+ * core::initialize (core.hpp:625-686), core::prep_wtab (core.hpp:564-581) and
+ * GMP::GMP (gmp.hpp:113-155).  Built lazily by the caller (never at static-init
+ * time, unlike poly.hpp:247).  limb_bits in {16,32,64}; P / primitive_roots /
+ * invkmax point at nmoduli words of that width taken from params<T>
+ * (params.hpp:21-36, 55-76, 97-113); kmax_log2 = log2(params<T>::kMaxPolyDegree).
+ * The context is immutable after creation: entry points may be called from
+ * several host threads with distinct streams.  One context per device. */
+int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree, size_t nmoduli,
+                      const void *P, const void *primitive_roots, const void *invkmax, int kmax_log2);
+int nflhip_ctx_destroy(nflhip_ctx *ctx);
+
+size_t nflhip_degree(const nflhip_ctx *ctx);
+size_t nflhip_nmoduli(const nflhip_ctx *ctx);
+int nflhip_limb_bits(const nflhip_ctx *ctx);
+/* L = ceil(bits(prod p_cm)/64): 64-bit limbs per lifted coefficient (gmp.hpp:121-122) */
+size_t nflhip_crt_limbs(const nflhip_ctx *ctx);
+int nflhip_get_table(const nflhip_ctx *ctx, int which, size_t cm, void *host_out, size_t host_bytes);
+/* CRT constants as little-endian 64-bit limbs; what: 0 = moduli_product, 1 = lifting_integers[cm]
+ * (gmp.hpp:115-151). Returns the number of significant limbs through *nlimbs. */
+int nflhip_get_crt_constant(const nflhip_ctx *ctx, int what, size_t cm, uint64_t *host_out, size_t cap,
+                            size_t *nlimbs);
+
+/* ---- transforms ------------------------------------------------------------
+ * poly::ntt_pow_phi()       poly.hpp:167 -> core::ntt_pow_phi        core.hpp:594-600
+ * poly::invntt_pow_invphi() poly.hpp:168 -> core::invntt_pow_invphi  core.hpp:608-614
+ * In place on [batch][nmoduli][degree]; forward output is in the reference's
+ * order (out[cm][bitrev(k)] = a_cm(phi^(2k+1))) and every output word is the
+ * canonical representative in [0,p) (core.hpp:523-529, ops.hpp:240). */
+int nflhip_ntt_fwd_dev(nflhip_ctx *ctx, void *d_data, size_t batch, void *stream);
+int nflhip_ntt_inv_dev(nflhip_ctx *ctx, void *d_data, size_t batch, void *stream);
+int nflhip_ntt_fwd(nflhip_ctx *ctx, void *h_data, size_t batch);
+int nflhip_ntt_inv(nflhip_ctx *ctx, void *h_data, size_t batch);
+
+/* ---- element-wise ops: poly::operator=(expr) core.hpp:24-37 ------------------
+ * op in NFLHIP_OP_*; b is ignored for COMPUTE_SHOUP, bprime only used by
+ * MUL_SHOUP.  Input contract as the reference's (operands < p; ops.hpp:131,148,211). */
+int nflhip_pointwise_dev(nflhip_ctx *ctx, int op, void *d_out, const void *d_a, const void *d_b,
+                         const void *d_bprime, size_t batch, void *stream);
+int nflhip_pointwise(nflhip_ctx *ctx, int op, void *h_out, const void *h_a, const void *h_b,
+                     const void *h_bprime, size_t batch);
+
+/* ---- the metric path ---------------------------------------------------------
+ * c = INTT( NTT(a) (.) NTT(b) ): the reference sequence
+ *   a.ntt_pow_phi(); b.ntt_pow_phi(); c = a*b; c.invntt_pow_invphi();
+ * (poly.hpp:167-168, 350) as one fused device pass.  a, b, c in coefficient
+ * form; a and b are not modified; c may alias a or b. */
+int nflhip_polymul_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const void *d_b, size_t batch,
+                       void *stream);
+int nflhip_polymul(nflhip_ctx *ctx, void *h_c, const void *h_a, const void *h_b, size_t batch);
+/* "one operand pre-transformed": c = INTT( NTT(a) (.) b_ntt ), b_ntt already in
+ * NTT form (keys kept in NTT form as in tests/nfllib_demo_main_op.cpp:26-46). */
+int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const void *d_bntt, size_t batch,
+                           void *stream);
+
+/* ---- comparisons: expr::operator bool over eqmod / neqmod (ops.hpp:81-117) ----
+ * *result = 1 iff ANY word of a equals (any_eq) / differs from (any_neq) the
+ * matching word of b -- the reference's semantics for `a == b` / `a != b`.
+ * These synchronise the stream. */
+int nflhip_any_eq_dev(nflhip_ctx *ctx, const void *d_a, const void *d_b, size_t batch, int *result,
+                      void *stream);
+int nflhip_any_neq_dev(nflhip_ctx *ctx, const void *d_a, const void *d_b, size_t batch, int *result,
+                       void *stream);
+int nflhip_any_eq(nflhip_ctx *ctx, const void *h_a, const void *h_b, size_t batch, int *result);
+int nflhip_any_neq(nflhip_ctx *ctx, const void *h_a, const void *h_b, size_t batch, int *result);
+
+/* ---- CRT ---------------------------------------------------------------------
+ * lift:    GMP::poly2mpz gmp.hpp:183-209 -- limbs[b][i][0..L) = little-endian
+ *          64-bit limbs (the mpz_export(order=-1) image) of
+ *          X_i = sum_cm lifting[cm]*x(cm,i) mod Q, in [0,Q).
+ * project: GMP::mpz2poly gmp.hpp:211-219 / poly::set_mpz gmp.hpp:73-108 --
+ *          x(cm,i) = X_i mod p_cm for non-negative X_i given as L_in limbs. */
+int nflhip_crt_lift_dev(nflhip_ctx *ctx, uint64_t *d_limbs, const void *d_data, size_t batch, void *stream);
+int nflhip_crt_project_dev(nflhip_ctx *ctx, void *d_data, const uint64_t *d_limbs, size_t L_in, size_t batch,
+                           void *stream);
+int nflhip_crt_lift(nflhip_ctx *ctx, uint64_t *h_limbs, const void *h_data, size_t batch);
+int nflhip_crt_project(nflhip_ctx *ctx, void *h_data, const uint64_t *h_limbs, size_t L_in, size_t batch);
+
+/* ---- harness helpers ---------------------------------------------------------
+ * Seeded synthetic operands generated in place on the device: word (b,cm,i) of
+ * operand s = splitmix64 counter stream masked to floor(log2 p)+1 bits with one
+ * conditional subtract of p -- the distribution rule of nfl::uniform
+ * (core.hpp:165-176).  first_poly offsets the counter so shards of one logical
+ * batch can be generated independently on several GPUs. */
+int nflhip_fill_uniform_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, size_t batch, uint64_t seed,
+                            int operand, void *stream);
+
+/* plain device-memory helpers so a C caller needs no HIP headers */
+int nflhip_malloc(nflhip_ctx *ctx, void **d_ptr, size_t bytes);
+int nflhip_free(nflhip_ctx *ctx, void *d_ptr);
+int nflhip_memcpy_h2d(nflhip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int nflhip_memcpy_d2h(nflhip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int nflhip_stream_sync(nflhip_ctx *ctx, void *stream);
+
+/* ---- in-library timing of the metric kernel (HIP events on `stream`) -----------
+ * Runs `iters` back-to-back polymul passes over the batch and returns the mean
+ * milliseconds per pass measured with hipEvents recorded on the same stream the
+ * kernels are launched on (bench.py's roofline leg). */
+int nflhip_time_polymul_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const void *d_b, size_t batch,
+                            int iters, void *stream, float *ms_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFLHIP_H */

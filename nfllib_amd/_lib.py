@@ -1,0 +1,82 @@
+"""ctypes binding of libnflhip.so (the C ABI declared in include/nflhip.h).
+
+The library is hand-written HIP for gfx950 and is the ONLY compute path of this
+package: if it cannot be loaded, importing fails loudly -- there is no CPU or
+PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnflhip.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = range(6)
+OP_ADD, OP_SUB, OP_MUL, OP_MUL_SHOUP, OP_COMPUTE_SHOUP = range(5)
+TAB_PSI, TAB_MODULUS, TAB_INVDEGREE = range(3)
+
+# every symbol include/nflhip.h declares: (name, restype, argtypes)
+_vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+SYMBOLS = [
+    ("nflhip_abi_version", _i, []),
+    ("nflhip_last_error", C.c_char_p, [_vp]),
+    ("nflhip_device_count", _i, [C.POINTER(_i)]),
+    ("nflhip_ctx_create", _i, [C.POINTER(_vp), _i, _i, _sz, _sz, _vp, _vp, _vp, _i]),
+    ("nflhip_ctx_destroy", _i, [_vp]),
+    ("nflhip_degree", _sz, [_vp]),
+    ("nflhip_nmoduli", _sz, [_vp]),
+    ("nflhip_limb_bits", _i, [_vp]),
+    ("nflhip_crt_limbs", _sz, [_vp]),
+    ("nflhip_get_table", _i, [_vp, _i, _sz, _vp, _sz]),
+    ("nflhip_get_crt_constant", _i, [_vp, _i, _sz, _vp, _sz, C.POINTER(_sz)]),
+    ("nflhip_ntt_fwd_dev", _i, [_vp, _vp, _sz, _vp]),
+    ("nflhip_ntt_inv_dev", _i, [_vp, _vp, _sz, _vp]),
+    ("nflhip_ntt_fwd", _i, [_vp, _vp, _sz]),
+    ("nflhip_ntt_inv", _i, [_vp, _vp, _sz]),
+    ("nflhip_pointwise_dev", _i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_pointwise", _i, [_vp, _i, _vp, _vp, _vp, _vp, _sz]),
+    ("nflhip_polymul_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_polymul", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("nflhip_polymul_ntt_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_any_eq_dev", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i), _vp]),
+    ("nflhip_any_neq_dev", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i), _vp]),
+    ("nflhip_any_eq", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i)]),
+    ("nflhip_any_neq", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i)]),
+    ("nflhip_crt_lift_dev", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_crt_project_dev", _i, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    ("nflhip_crt_lift", _i, [_vp, _vp, _vp, _sz]),
+    ("nflhip_crt_project", _i, [_vp, _vp, _vp, _sz, _sz]),
+    ("nflhip_fill_uniform_dev", _i, [_vp, _vp, _sz, _sz, _u64, _i, _vp]),
+    ("nflhip_malloc", _i, [_vp, C.POINTER(_vp), _sz]),
+    ("nflhip_free", _i, [_vp, _vp]),
+    ("nflhip_memcpy_h2d", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_memcpy_d2h", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_stream_sync", _i, [_vp, _vp]),
+    ("nflhip_time_polymul_dev", _i, [_vp, _vp, _vp, _vp, _sz, _i, _vp, C.POINTER(C.c_float)]),
+]
+
+
+class NflHipError(RuntimeError):
+    """Non-zero status from the C ABI (the header-only C++ surface throws
+    std::runtime_error in the same situations: core.hpp:111-115, gmp.hpp:83-87)."""
+
+    def __init__(self, code, msg):
+        super().__init__("nflhip status %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "nfllib_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nflhip_abi_version() != 1:
+        raise ImportError("nfllib_amd: libnflhip.so ABI version mismatch")
+    return lib
+
+
+lib = load()

@@ -1,0 +1,728 @@
+// api.hip -- the C ABI of include/nflhip.h: context + device-table provisioning
+// and the host/device entry points.  No CPU compute path exists here: every
+// operation is a launch of a gfx950 kernel (kernels_generic.hip / kernels_fast.hip).
+#include "../../include/nflhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace nflhip;
+
+typedef unsigned __int128 u128;
+
+static thread_local std::string g_create_error = "";
+
+struct nflhip_ctx {
+  int device = 0;
+  Shape shape{};
+  DevTables tabs{};
+  size_t word = 8;  // bytes per limb
+  mutable std::string err;
+  // host-pointer path: staging buffers + private stream, serialised by a mutex
+  std::mutex mu;
+  hipStream_t hstream = nullptr;
+  void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[4] = {0, 0, 0, 0};
+  // scratch for the composed (non-fused) polymul path, per stream use is serialised by the caller
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  std::mutex scratch_mu;
+  // host copies for introspection
+  std::vector<uint64_t> h_Q;                     // moduli_product limbs
+  std::vector<std::vector<uint64_t>> h_lifting;  // lifting_integers[cm]
+  std::vector<uint64_t> h_P;
+};
+
+static int fail(const nflhip_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+static int hipfail(const nflhip_ctx *ctx, hipError_t e, const char *where) {
+  return fail(ctx, e == hipErrorNoDevice || e == hipErrorInvalidDevice ? NFLHIP_ERR_NO_DEVICE : NFLHIP_ERR_HIP,
+              std::string(where) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(ctx, call)                                   \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return hipfail(ctx, _e, #call);   \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// host-side modular helpers used only to BUILD tables (once per context)
+// ---------------------------------------------------------------------------
+static inline uint64_t mulmod_h(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((u128)a * b % p); }
+static uint64_t powmod_h(uint64_t a, uint64_t e, uint64_t p) {
+  uint64_t r = 1 % p;
+  a %= p;
+  while (e) {
+    if (e & 1) r = mulmod_h(r, a, p);
+    a = mulmod_h(a, a, p);
+    e >>= 1;
+  }
+  return r;
+}
+static inline uint64_t shoup_h(uint64_t w, uint64_t p, int wb) { return (uint64_t)((((u128)w) << wb) / p); }
+static unsigned bitrev_h(unsigned k, int bits) {
+  unsigned r = 0;
+  for (int i = 0; i < bits; ++i) {
+    r = (r << 1) | (k & 1u);
+    k >>= 1;
+  }
+  return r;
+}
+
+// little-endian multi-limb helpers for the CRT constants (gmp.hpp:113-155)
+typedef std::vector<uint64_t> Big;
+static void big_trim(Big &a) { while (!a.empty() && a.back() == 0) a.pop_back(); }
+static Big big_mul_u64(const Big &a, uint64_t w) {
+  Big r(a.size() + 1, 0);
+  u128 c = 0;
+  for (size_t i = 0; i < a.size(); ++i) {
+    c += (u128)a[i] * w;
+    r[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  r[a.size()] = (uint64_t)c;
+  big_trim(r);
+  return r;
+}
+static uint64_t big_divrem_u64(const Big &a, uint64_t d, Big *q) {
+  Big out(a.size(), 0);
+  u128 r = 0;
+  for (size_t k = a.size(); k-- > 0;) {
+    r = (r << 64) | a[k];
+    out[k] = (uint64_t)(r / d);
+    r %= d;
+  }
+  big_trim(out);
+  if (q) *q = out;
+  return (uint64_t)r;
+}
+static size_t big_bits(const Big &a) {
+  if (a.empty()) return 0;
+  size_t b = 0;
+  uint64_t t = a.back();
+  while (t) { ++b; t >>= 1; }
+  return (a.size() - 1) * 64 + b;
+}
+static Big big_shl(const Big &a, int k, size_t limbs) {
+  Big r(limbs, 0);
+  for (size_t i = 0; i < a.size() && i < limbs; ++i) {
+    r[i] |= a[i] << k;
+    if (k && i + 1 < limbs) r[i + 1] |= a[i] >> (64 - k);
+  }
+  return r;
+}
+
+template <typename T>
+static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const void *invkv, int kmax_log2) {
+  const T *P = (const T *)Pv, *roots = (const T *)rootsv, *invk = (const T *)invkv;
+  const Shape &s = c->shape;
+  const int wb = s.limb_bits, logn = s.logn;
+  const size_t n = s.n, nm = s.nm;
+  // moduli sanity: the engine relies on p being 2 bits below the word (params.hpp:27-28,61-62,104-105)
+  for (size_t cm = 0; cm < nm; ++cm) {
+    const uint64_t p = P[cm];
+    if (p < 3 || (p >> (wb - 2)) != 0 || (p >> (wb - 3)) == 0)
+      return fail(nullptr, NFLHIP_ERR_INVALID, "modulus is not (word-2) bits long");
+    c->h_P.push_back(p);
+  }
+  // CRT constants
+  Big Q(1, 1);
+  for (size_t cm = 0; cm < nm; ++cm) Q = big_mul_u64(Q, P[cm]);
+  const size_t bitsQ = big_bits(Q);
+  c->shape.crt_L = (bitsQ + 63) / 64;
+  c->shape.crt_Lacc = c->shape.crt_L + 1;
+  const size_t Lacc = c->shape.crt_Lacc;
+  c->h_Q = Q;
+  c->h_Q.resize(c->shape.crt_L, 0);
+  std::vector<uint64_t> qhat(nm * Lacc, 0), qsh(6 * Lacc, 0);
+  std::vector<uint64_t> yinv(nm, 0);
+  c->h_lifting.resize(nm);
+  for (size_t cm = 0; cm < nm; ++cm) {
+    Big quot;
+    big_divrem_u64(Q, P[cm], &quot);                       // Q / p_cm            (mpz_divexact)
+    const uint64_t qmod = big_divrem_u64(quot, P[cm], nullptr);
+    yinv[cm] = powmod_h(qmod, P[cm] - 2, P[cm]);           // (Q/p_cm)^-1 mod p_cm (mpz_invert)
+    for (size_t k = 0; k < quot.size(); ++k) qhat[cm * Lacc + k] = quot[k];
+    c->h_lifting[cm] = big_mul_u64(quot, yinv[cm]);        // lifting_integers[cm] (gmp.hpp:149-150)
+  }
+  for (int k = 0; k < 6; ++k) {
+    Big sh = big_shl(Q, k, Lacc);
+    for (size_t i = 0; i < Lacc; ++i) qsh[k * Lacc + i] = sh[i];
+  }
+
+  // twiddles + per-modulus constants
+  std::vector<Tw<T>> psi(nm * n);
+  std::vector<ModConst<T>> mc(nm);
+  for (size_t cm = 0; cm < nm; ++cm) {
+    const uint64_t p = P[cm];
+    // phi: primitive 2n-th root from the primitive 2*kMax-th root (core.hpp:640-645)
+    uint64_t phi = roots[cm];
+    for (int i = 0; i < kmax_log2 - logn; ++i) phi = mulmod_h(phi, phi, p);
+    if (powmod_h(phi, n, p) != p - 1) return fail(nullptr, NFLHIP_ERR_INVALID, "primitive root has the wrong order");
+    std::vector<uint64_t> pw(n);
+    uint64_t cur = 1;
+    for (size_t i = 0; i < n; ++i) {
+      pw[i] = cur;
+      cur = mulmod_h(cur, phi, p);
+    }
+    Tw<T> *tw = psi.data() + cm * n;
+    for (size_t k = 0; k < n; ++k) {
+      const uint64_t w = pw[bitrev_h((unsigned)k, logn)];
+      tw[k].w = (T)w;
+      tw[k].wp = (T)shoup_h(w, p, wb);
+    }
+    ModConst<T> &m = mc[cm];
+    m.p = (T)p;
+    m.p2 = (T)(2 * p);
+    m.mu = (T)((((u128)1) << (2 * wb - 4)) / p);
+    // n^-1 = kMax^-1 * (kMax/n) (core.hpp:664-665)
+    const uint64_t ninv = mulmod_h(invk[cm], (((uint64_t)1) << kmax_log2) / n, p);
+    if (mulmod_h(ninv, n % p, p) != 1 % p) return fail(nullptr, NFLHIP_ERR_INVALID, "invkMaxPolyDegree is not the inverse");
+    m.ninv = (T)ninv;
+    m.ninv_sh = (T)shoup_h(ninv, p, wb);
+    const uint64_t w1 = n >= 2 ? (uint64_t)tw[1].w : 1;
+    const uint64_t w1n = mulmod_h(w1, ninv, p);
+    m.w1ninv = (T)w1n;
+    m.w1ninv_sh = (T)shoup_h(w1n, p, wb);
+    const uint64_t beta = (uint64_t)((((u128)1) << 64) % p);
+    m.beta = (T)beta;
+    m.beta_sh = (T)shoup_h(beta, p, wb);
+    m.yinv = (T)yinv[cm];
+    m.yinv_sh = (T)shoup_h(yinv[cm], p, wb);
+    int bits = 0;
+    while (bits < wb && (((u128)1) << bits) <= (u128)p) ++bits;
+    m.mask = (T)(bits >= 64 ? ~(uint64_t)0 : ((((uint64_t)1) << bits) - 1));
+  }
+
+  HIPCHK(nullptr, hipMalloc(&c->tabs.psi, psi.size() * sizeof(Tw<T>)));
+  HIPCHK(nullptr, hipMemcpy(c->tabs.psi, psi.data(), psi.size() * sizeof(Tw<T>), hipMemcpyHostToDevice));
+  HIPCHK(nullptr, hipMalloc(&c->tabs.mc, mc.size() * sizeof(ModConst<T>)));
+  HIPCHK(nullptr, hipMemcpy(c->tabs.mc, mc.data(), mc.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
+  HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qhat, qhat.size() * sizeof(uint64_t)));
+  HIPCHK(nullptr, hipMemcpy(c->tabs.qhat, qhat.data(), qhat.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qsh, qsh.size() * sizeof(uint64_t)));
+  HIPCHK(nullptr, hipMemcpy(c->tabs.qsh, qsh.data(), qsh.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIPCHK(nullptr, hipMalloc((void **)&c->tabs.flag, sizeof(int)));
+  return NFLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dispatch on the limb type
+// ---------------------------------------------------------------------------
+#define DISPATCH_T(ctx, EXPR16, EXPR32, EXPR64) \
+  ((ctx)->shape.limb_bits == 16 ? (EXPR16) : (ctx)->shape.limb_bits == 32 ? (EXPR32) : (EXPR64))
+
+static int set_device(const nflhip_ctx *ctx) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return NFLHIP_OK;
+}
+static size_t poly_bytes(const nflhip_ctx *ctx, size_t batch) { return batch * ctx->shape.nm * ctx->shape.n * ctx->word; }
+
+static int ensure_stage(nflhip_ctx *ctx, int slot, size_t bytes) {
+  if (ctx->stage_bytes[slot] >= bytes) return NFLHIP_OK;
+  if (ctx->stage[slot]) HIPCHK(ctx, hipFree(ctx->stage[slot]));
+  ctx->stage[slot] = nullptr;
+  ctx->stage_bytes[slot] = 0;
+  HIPCHK(ctx, hipMalloc(&ctx->stage[slot], bytes));
+  ctx->stage_bytes[slot] = bytes;
+  return NFLHIP_OK;
+}
+static int ensure_scratch(nflhip_ctx *ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return NFLHIP_OK;
+  if (ctx->scratch) HIPCHK(ctx, hipFree(ctx->scratch));
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return NFLHIP_OK;
+}
+
+// composed path: NTT(a)->c, NTT(b)->scratch, inverse with the product fused into its load
+template <typename T>
+static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b_is_ntt, size_t batch, hipStream_t st) {
+  hipError_t e;
+  const T *bn = b;
+  std::unique_lock<std::mutex> lk(ctx->scratch_mu, std::defer_lock);
+  T *acopy = nullptr;
+  // c may alias a or b: transform a into c first only when that does not clobber b
+  const size_t bytes = poly_bytes(ctx, batch);
+  lk.lock();
+  int rc = ensure_scratch(ctx, 2 * bytes);
+  if (rc) return rc;
+  T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
+  (void)acopy;
+  e = launch_ntt_fwd<T>(ctx->shape, ctx->tabs, a, s0, batch, st);
+  if (e != hipSuccess) return hipfail(ctx, e, "polymul: ntt(a)");
+  if (!b_is_ntt) {
+    e = launch_ntt_fwd<T>(ctx->shape, ctx->tabs, b, s1, batch, st);
+    if (e != hipSuccess) return hipfail(ctx, e, "polymul: ntt(b)");
+    bn = s1;
+  }
+  e = launch_ntt_inv<T>(ctx->shape, ctx->tabs, s0, bn, c, batch, st);
+  if (e != hipSuccess) return hipfail(ctx, e, "polymul: intt");
+  // the scratch is reused by the next call on any stream: make that safe
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hipfail(ctx, e, "polymul: sync");
+  return NFLHIP_OK;
+}
+
+extern "C" {
+
+int nflhip_abi_version(void) { return NFLHIP_ABI_VERSION; }
+
+const char *nflhip_last_error(const nflhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int nflhip_device_count(int *count) {
+  if (!count) return fail(nullptr, NFLHIP_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return hipfail(nullptr, e, "hipGetDeviceCount");
+  }
+  *count = n;
+  return NFLHIP_OK;
+}
+
+int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree, size_t nmoduli, const void *P,
+                      const void *primitive_roots, const void *invkmax, int kmax_log2) {
+  if (!out) return fail(nullptr, NFLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (limb_bits != 16 && limb_bits != 32 && limb_bits != 64)
+    return fail(nullptr, NFLHIP_ERR_INVALID, "limb_bits must be 16, 32 or 64");
+  if (!P || !primitive_roots || !invkmax) return fail(nullptr, NFLHIP_ERR_INVALID, "NULL parameter table");
+  if (degree == 0 || (degree & (degree - 1)) != 0) return fail(nullptr, NFLHIP_ERR_INVALID, "degree must be a power of two");
+  if (kmax_log2 < 1 || kmax_log2 > 30 || degree > (((size_t)1) << kmax_log2))
+    return fail(nullptr, NFLHIP_ERR_INVALID, "degree exceeds kMaxPolyDegree (core.hpp:59-60)");
+  if (degree < 4) return fail(nullptr, NFLHIP_ERR_UNSUPPORTED, "degree < 4 is not supported by the device engine");
+  if (nmoduli == 0 || nmoduli > 1024) return fail(nullptr, NFLHIP_ERR_INVALID, "nmoduli out of range");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, NFLHIP_ERR_NO_DEVICE, "no HIP device available (this engine has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, NFLHIP_ERR_INVALID, "device index out of range");
+  HIPCHK(nullptr, hipSetDevice(device));
+  nflhip_ctx *c = new (std::nothrow) nflhip_ctx();
+  if (!c) return fail(nullptr, NFLHIP_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  c->word = (size_t)limb_bits / 8;
+  c->shape.limb_bits = limb_bits;
+  c->shape.n = degree;
+  c->shape.nm = nmoduli;
+  c->shape.logn = 0;
+  while ((((size_t)1) << c->shape.logn) < degree) c->shape.logn++;
+  int rc = limb_bits == 16   ? build_tables<uint16_t>(c, P, primitive_roots, invkmax, kmax_log2)
+           : limb_bits == 32 ? build_tables<uint32_t>(c, P, primitive_roots, invkmax, kmax_log2)
+                             : build_tables<uint64_t>(c, P, primitive_roots, invkmax, kmax_log2);
+  if (rc == NFLHIP_OK) {
+    hipError_t se = hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking);
+    if (se != hipSuccess) rc = hipfail(nullptr, se, "hipStreamCreate");
+  }
+  if (rc != NFLHIP_OK) {
+    nflhip_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return NFLHIP_OK;
+}
+
+int nflhip_ctx_destroy(nflhip_ctx *ctx) {
+  if (!ctx) return NFLHIP_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->hstream) (void)hipStreamDestroy(ctx->hstream);
+  for (int i = 0; i < 4; ++i)
+    if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->tabs.psi) (void)hipFree(ctx->tabs.psi);
+  if (ctx->tabs.mc) (void)hipFree(ctx->tabs.mc);
+  if (ctx->tabs.qhat) (void)hipFree(ctx->tabs.qhat);
+  if (ctx->tabs.qsh) (void)hipFree(ctx->tabs.qsh);
+  if (ctx->tabs.flag) (void)hipFree(ctx->tabs.flag);
+  delete ctx;
+  return NFLHIP_OK;
+}
+
+size_t nflhip_degree(const nflhip_ctx *ctx) { return ctx ? ctx->shape.n : 0; }
+size_t nflhip_nmoduli(const nflhip_ctx *ctx) { return ctx ? ctx->shape.nm : 0; }
+int nflhip_limb_bits(const nflhip_ctx *ctx) { return ctx ? ctx->shape.limb_bits : 0; }
+size_t nflhip_crt_limbs(const nflhip_ctx *ctx) { return ctx ? ctx->shape.crt_L : 0; }
+
+int nflhip_get_table(const nflhip_ctx *ctx, int which, size_t cm, void *host_out, size_t host_bytes) {
+  if (!ctx || !host_out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (cm >= ctx->shape.nm) return fail(ctx, NFLHIP_ERR_INVALID, "modulus index out of range");
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  const size_t w = ctx->word;
+  const size_t mcsz = 12 * w;  // sizeof(ModConst<T>)
+  switch (which) {
+    case NFLHIP_TAB_PSI: {
+      const size_t bytes = ctx->shape.n * 2 * w;
+      if (host_bytes < bytes) return fail(ctx, NFLHIP_ERR_INVALID, "output buffer too small");
+      HIPCHK(ctx, hipMemcpy(host_out, (const char *)ctx->tabs.psi + cm * bytes, bytes, hipMemcpyDeviceToHost));
+      return NFLHIP_OK;
+    }
+    case NFLHIP_TAB_MODULUS:
+    case NFLHIP_TAB_INVDEGREE: {
+      if (host_bytes < w) return fail(ctx, NFLHIP_ERR_INVALID, "output buffer too small");
+      const size_t off = cm * mcsz + (which == NFLHIP_TAB_MODULUS ? 0 : 3 * w);
+      HIPCHK(ctx, hipMemcpy(host_out, (const char *)ctx->tabs.mc + off, w, hipMemcpyDeviceToHost));
+      return NFLHIP_OK;
+    }
+    default: return fail(ctx, NFLHIP_ERR_INVALID, "unknown table id");
+  }
+}
+
+int nflhip_get_crt_constant(const nflhip_ctx *ctx, int what, size_t cm, uint64_t *host_out, size_t cap, size_t *nlimbs) {
+  if (!ctx || !host_out || !nlimbs) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  const std::vector<uint64_t> *src = nullptr;
+  if (what == 0) src = &ctx->h_Q;
+  else if (what == 1 && cm < ctx->shape.nm) src = &ctx->h_lifting[cm];
+  else return fail(ctx, NFLHIP_ERR_INVALID, "unknown CRT constant");
+  size_t n = src->size();
+  while (n > 0 && (*src)[n - 1] == 0) --n;
+  *nlimbs = n;
+  if (cap < n) return fail(ctx, NFLHIP_ERR_INVALID, "output buffer too small");
+  memset(host_out, 0, cap * sizeof(uint64_t));
+  memcpy(host_out, src->data(), n * sizeof(uint64_t));
+  return NFLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device-pointer entry points
+// ---------------------------------------------------------------------------
+#define CHECK_CTX(ctx)                                                \
+  do {                                                                \
+    if (!(ctx)) return fail(nullptr, NFLHIP_ERR_INVALID, "ctx is NULL"); \
+    int _rc = set_device(ctx);                                        \
+    if (_rc) return _rc;                                              \
+  } while (0)
+
+int nflhip_ntt_fwd_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (!d && batch) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (ctx->shape.limb_bits == 64) {
+    e = launch_ntt_fwd_fast_u64(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(fast)");
+  }
+  e = DISPATCH_T(ctx, launch_ntt_fwd<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d, (uint16_t *)d, batch, st),
+                 launch_ntt_fwd<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)d, (uint32_t *)d, batch, st),
+                 launch_ntt_fwd<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "ntt_fwd");
+  return NFLHIP_OK;
+}
+
+int nflhip_ntt_inv_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (!d && batch) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (ctx->shape.limb_bits == 64) {
+    e = launch_ntt_inv_fast_u64(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(fast)");
+  }
+  e = DISPATCH_T(ctx,
+                 launch_ntt_inv<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d, nullptr, (uint16_t *)d, batch, st),
+                 launch_ntt_inv<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)d, nullptr, (uint32_t *)d, batch, st),
+                 launch_ntt_inv<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)d, nullptr, (uint64_t *)d, batch, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "ntt_inv");
+  return NFLHIP_OK;
+}
+
+int nflhip_pointwise_dev(nflhip_ctx *ctx, int op, void *o, const void *a, const void *b, const void *bp, size_t batch,
+                         void *stream) {
+  CHECK_CTX(ctx);
+  if (op < 0 || op > 4) return fail(ctx, NFLHIP_ERR_INVALID, "unknown element-wise op");
+  if (batch && (!o || !a || (op != NFLHIP_OP_COMPUTE_SHOUP && !b) || (op == NFLHIP_OP_MUL_SHOUP && !bp)))
+    return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(
+      ctx,
+      launch_pointwise<uint16_t>(ctx->shape, ctx->tabs, op, (uint16_t *)o, (const uint16_t *)a, (const uint16_t *)b,
+                                 (const uint16_t *)bp, batch, st),
+      launch_pointwise<uint32_t>(ctx->shape, ctx->tabs, op, (uint32_t *)o, (const uint32_t *)a, (const uint32_t *)b,
+                                 (const uint32_t *)bp, batch, st),
+      launch_pointwise<uint64_t>(ctx->shape, ctx->tabs, op, (uint64_t *)o, (const uint64_t *)a, (const uint64_t *)b,
+                                 (const uint64_t *)bp, batch, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "pointwise");
+  return NFLHIP_OK;
+}
+
+static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, int b_is_ntt, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (batch && (!c || !a || !b)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  if (batch == 0) return NFLHIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (ctx->shape.limb_bits == 64) {
+    hipError_t e = launch_polymul_fast_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b,
+                                           b_is_ntt, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(fast)");
+  }
+  return DISPATCH_T(ctx, polymul_composed<uint16_t>(ctx, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, b_is_ntt, batch, st),
+                    polymul_composed<uint32_t>(ctx, (uint32_t *)c, (const uint32_t *)a, (const uint32_t *)b, b_is_ntt, batch, st),
+                    polymul_composed<uint64_t>(ctx, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b, b_is_ntt, batch, st));
+}
+
+int nflhip_polymul_dev(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_t batch, void *stream) {
+  return polymul_any(ctx, c, a, b, 0, batch, stream);
+}
+int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *c, const void *a, const void *bntt, size_t batch, void *stream) {
+  return polymul_any(ctx, c, a, bntt, 1, batch, stream);
+}
+
+static int any_cmp_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int want_eq, int *result, void *stream) {
+  CHECK_CTX(ctx);
+  if (!result || (batch && (!a || !b))) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(
+      ctx, launch_any_cmp<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)a, (const uint16_t *)b, batch, want_eq, st),
+      launch_any_cmp<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)a, (const uint32_t *)b, batch, want_eq, st),
+      launch_any_cmp<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)a, (const uint64_t *)b, batch, want_eq, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "any_cmp");
+  int flag = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->tabs.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  *result = flag ? 1 : 0;
+  return NFLHIP_OK;
+}
+int nflhip_any_eq_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int *result, void *stream) {
+  return any_cmp_dev(ctx, a, b, batch, 1, result, stream);
+}
+int nflhip_any_neq_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int *result, void *stream) {
+  return any_cmp_dev(ctx, a, b, batch, 0, result, stream);
+}
+
+int nflhip_crt_lift_dev(nflhip_ctx *ctx, uint64_t *limbs, const void *d, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (batch && (!limbs || !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(ctx, launch_crt_lift<uint16_t>(ctx->shape, ctx->tabs, limbs, (const uint16_t *)d, batch, st),
+                            launch_crt_lift<uint32_t>(ctx->shape, ctx->tabs, limbs, (const uint32_t *)d, batch, st),
+                            launch_crt_lift<uint64_t>(ctx->shape, ctx->tabs, limbs, (const uint64_t *)d, batch, st));
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "crt_lift: more than 32 moduli");
+  if (e != hipSuccess) return hipfail(ctx, e, "crt_lift");
+  return NFLHIP_OK;
+}
+
+int nflhip_crt_project_dev(nflhip_ctx *ctx, void *d, const uint64_t *limbs, size_t L_in, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (batch && (!limbs || !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (L_in == 0 || L_in > (1u << 20)) return fail(ctx, NFLHIP_ERR_INVALID, "L_in out of range");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(ctx, launch_crt_project<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, limbs, L_in, batch, st),
+                            launch_crt_project<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, limbs, L_in, batch, st),
+                            launch_crt_project<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, limbs, L_in, batch, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "crt_project");
+  return NFLHIP_OK;
+}
+
+int nflhip_fill_uniform_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t batch, uint64_t seed, int operand,
+                            void *stream) {
+  CHECK_CTX(ctx);
+  if (batch && !d) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(ctx, launch_fill_uniform<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, seed, operand, st),
+                            launch_fill_uniform<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, seed, operand, st),
+                            launch_fill_uniform<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, seed, operand, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "fill_uniform");
+  return NFLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// memory helpers
+// ---------------------------------------------------------------------------
+int nflhip_malloc(nflhip_ctx *ctx, void **p, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (!p) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return fail(ctx, NFLHIP_ERR_NOMEM, "hipMalloc: out of device memory");
+  if (e != hipSuccess) return hipfail(ctx, e, "hipMalloc");
+  return NFLHIP_OK;
+}
+int nflhip_free(nflhip_ctx *ctx, void *p) {
+  CHECK_CTX(ctx);
+  if (p) HIPCHK(ctx, hipFree(p));
+  return NFLHIP_OK;
+}
+int nflhip_memcpy_h2d(nflhip_ctx *ctx, void *d, const void *h, size_t bytes, void *stream) {
+  CHECK_CTX(ctx);
+  HIPCHK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return NFLHIP_OK;
+}
+int nflhip_memcpy_d2h(nflhip_ctx *ctx, void *h, const void *d, size_t bytes, void *stream) {
+  CHECK_CTX(ctx);
+  HIPCHK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return NFLHIP_OK;
+}
+int nflhip_stream_sync(nflhip_ctx *ctx, void *stream) {
+  CHECK_CTX(ctx);
+  HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+  return NFLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-pointer entry points: stage through context-owned device buffers
+// ---------------------------------------------------------------------------
+struct Staged {
+  nflhip_ctx *ctx;
+  std::unique_lock<std::mutex> lk;
+  explicit Staged(nflhip_ctx *c) : ctx(c), lk(c->mu) {}
+  int in(int slot, const void *h, size_t bytes) {
+    int rc = ensure_stage(ctx, slot, bytes);
+    if (rc) return rc;
+    if (h) HIPCHK(ctx, hipMemcpyAsync(ctx->stage[slot], h, bytes, hipMemcpyHostToDevice, ctx->hstream));
+    return NFLHIP_OK;
+  }
+  int out(void *h, int slot, size_t bytes) {
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->stage[slot], bytes, hipMemcpyDeviceToHost, ctx->hstream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->hstream));
+    return NFLHIP_OK;
+  }
+};
+
+int nflhip_ntt_fwd(nflhip_ctx *ctx, void *h, size_t batch) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return NFLHIP_OK;
+  if (!h) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  int rc = s.in(0, h, bytes);
+  if (rc) return rc;
+  rc = nflhip_ntt_fwd_dev(ctx, ctx->stage[0], batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(h, 0, bytes);
+}
+int nflhip_ntt_inv(nflhip_ctx *ctx, void *h, size_t batch) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return NFLHIP_OK;
+  if (!h) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  int rc = s.in(0, h, bytes);
+  if (rc) return rc;
+  rc = nflhip_ntt_inv_dev(ctx, ctx->stage[0], batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(h, 0, bytes);
+}
+int nflhip_pointwise(nflhip_ctx *ctx, int op, void *o, const void *a, const void *b, const void *bp, size_t batch) {
+  CHECK_CTX(ctx);
+  if (op < 0 || op > 4) return fail(ctx, NFLHIP_ERR_INVALID, "unknown element-wise op");
+  if (batch == 0) return NFLHIP_OK;
+  if (!o || !a || (op != NFLHIP_OP_COMPUTE_SHOUP && !b) || (op == NFLHIP_OP_MUL_SHOUP && !bp))
+    return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  int rc = s.in(0, a, bytes);
+  if (rc) return rc;
+  if (op != NFLHIP_OP_COMPUTE_SHOUP && (rc = s.in(1, b, bytes))) return rc;
+  if (op == NFLHIP_OP_MUL_SHOUP && (rc = s.in(2, bp, bytes))) return rc;
+  rc = nflhip_pointwise_dev(ctx, op, ctx->stage[0], ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(o, 0, bytes);
+}
+int nflhip_polymul(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_t batch) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return NFLHIP_OK;
+  if (!c || !a || !b) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  int rc = s.in(0, a, bytes);
+  if (rc) return rc;
+  if ((rc = s.in(1, b, bytes))) return rc;
+  rc = nflhip_polymul_dev(ctx, ctx->stage[0], ctx->stage[0], ctx->stage[1], batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(c, 0, bytes);
+}
+static int any_cmp_host(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int want_eq, int *result) {
+  CHECK_CTX(ctx);
+  if (!result) return fail(ctx, NFLHIP_ERR_INVALID, "NULL result");
+  if (batch == 0) { *result = 0; return NFLHIP_OK; }
+  if (!a || !b) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  int rc = s.in(0, a, bytes);
+  if (rc) return rc;
+  if ((rc = s.in(1, b, bytes))) return rc;
+  return any_cmp_dev(ctx, ctx->stage[0], ctx->stage[1], batch, want_eq, result, ctx->hstream);
+}
+int nflhip_any_eq(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int *result) {
+  return any_cmp_host(ctx, a, b, batch, 1, result);
+}
+int nflhip_any_neq(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int *result) {
+  return any_cmp_host(ctx, a, b, batch, 0, result);
+}
+int nflhip_crt_lift(nflhip_ctx *ctx, uint64_t *limbs, const void *d, size_t batch) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return NFLHIP_OK;
+  if (!limbs || !d) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  const size_t lbytes = batch * ctx->shape.n * ctx->shape.crt_L * sizeof(uint64_t);
+  int rc = s.in(0, d, bytes);
+  if (rc) return rc;
+  if ((rc = s.in(1, nullptr, lbytes))) return rc;
+  rc = nflhip_crt_lift_dev(ctx, (uint64_t *)ctx->stage[1], ctx->stage[0], batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(limbs, 1, lbytes);
+}
+int nflhip_crt_project(nflhip_ctx *ctx, void *d, const uint64_t *limbs, size_t L_in, size_t batch) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return NFLHIP_OK;
+  if (!limbs || !d) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (L_in == 0) return fail(ctx, NFLHIP_ERR_INVALID, "L_in must be positive");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  const size_t lbytes = batch * ctx->shape.n * L_in * sizeof(uint64_t);
+  int rc = s.in(1, limbs, lbytes);
+  if (rc) return rc;
+  if ((rc = s.in(0, nullptr, bytes))) return rc;
+  rc = nflhip_crt_project_dev(ctx, ctx->stage[0], (const uint64_t *)ctx->stage[1], L_in, batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(d, 0, bytes);
+}
+
+// ---------------------------------------------------------------------------
+// in-library timing of the metric kernel: HIP events on the launch stream
+// ---------------------------------------------------------------------------
+int nflhip_time_polymul_dev(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_t batch, int iters, void *stream,
+                            float *ms_per_pass) {
+  CHECK_CTX(ctx);
+  if (!ms_per_pass || iters <= 0) return fail(ctx, NFLHIP_ERR_INVALID, "bad timing arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  HIPCHK(ctx, hipEventCreate(&e0));
+  HIPCHK(ctx, hipEventCreate(&e1));
+  HIPCHK(ctx, hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) {
+    int rc = nflhip_polymul_dev(ctx, c, a, b, batch, stream);
+    if (rc) {
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      return rc;
+    }
+  }
+  HIPCHK(ctx, hipEventRecord(e1, st));
+  HIPCHK(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_pass = ms / (float)iters;
+  return NFLHIP_OK;
+}
+
+}  // extern "C"

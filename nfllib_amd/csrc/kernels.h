@@ -1,0 +1,79 @@
+// kernels.h -- internal launch interface between the C-ABI layer (api.hip) and
+// the gfx950 kernels.  Not installed; the public boundary is include/nflhip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nflhip {
+
+// Per-modulus device constants (engine layout; derived from params<T>::P,
+// primitive_roots, invkMaxPolyDegree -- reference params.hpp -- by tables.cpp).
+template <typename T> struct ModConst {
+  T p;          // modulus
+  T p2;         // 2p
+  T mu;         // floor(2^(2W-4)/p): Barrett constant for exact x*y mod p
+  T ninv;       // n^-1 mod p                       (core.hpp:664-665)
+  T ninv_sh;    // Shoup companion of ninv
+  T w1ninv;     // psi_br[1] * n^-1 mod p (last inverse stage, merged scale)
+  T w1ninv_sh;  // its Shoup companion
+  T beta;       // 2^64 mod p (CRT project, Horner step)
+  T beta_sh;    // its Shoup companion
+  T yinv;       // (Q/p)^-1 mod p (CRT lift)         (gmp.hpp:141-147)
+  T yinv_sh;    // its Shoup companion
+  T mask;       // 2^(floor(log2 p)+1) - 1           (core.hpp:165-166)
+};
+
+// Twiddle pair as stored on the device: psi^bitrev(k) and its Shoup companion.
+template <typename T> struct alignas(2 * sizeof(T)) Tw {
+  T w, wp;
+};
+
+struct Shape {
+  int limb_bits;
+  int logn;
+  size_t n, nm;
+  size_t crt_L;      // limbs of a lifted coefficient
+  size_t crt_Lacc;   // limbs of the accumulator (L+1)
+};
+
+// Device-resident tables of one context.
+struct DevTables {
+  void *psi;        // [nm][n] Tw<T>
+  void *mc;         // [nm] ModConst<T>
+  uint64_t *qhat;   // [nm][crt_Lacc]  Q/p_cm, little-endian limbs
+  uint64_t *qsh;    // [6][crt_Lacc]   Q << k, k = 0..5
+  int *flag;        // 1 int, result of any_eq / any_neq
+};
+
+// ---- launchers (kernels_generic.hip) ----
+template <typename T>
+hipError_t launch_ntt_fwd(const Shape &s, const DevTables &t, const T *src, T *dst, size_t batch, hipStream_t st);
+// inverse of (src (.) mul) when mul != nullptr (fused point-wise product), else of src
+template <typename T>
+hipError_t launch_ntt_inv(const Shape &s, const DevTables &t, const T *src, const T *mul, T *dst, size_t batch,
+                          hipStream_t st);
+template <typename T>
+hipError_t launch_pointwise(const Shape &s, const DevTables &t, int op, T *out, const T *a, const T *b, const T *bp,
+                            size_t batch, hipStream_t st);
+template <typename T>
+hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
+                          hipStream_t st);
+template <typename T>
+hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, uint64_t seed,
+                               int operand, hipStream_t st);
+template <typename T>
+hipError_t launch_crt_lift(const Shape &s, const DevTables &t, uint64_t *limbs, const T *d, size_t batch, hipStream_t st);
+template <typename T>
+hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const uint64_t *limbs, size_t L_in, size_t batch,
+                              hipStream_t st);
+
+// ---- fast paths (kernels_fast.hip); return hipErrorNotSupported when the shape has none ----
+hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
+                                   int b_is_ntt, size_t batch, hipStream_t st);
+hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
+                                   hipStream_t st);
+hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
+                                   hipStream_t st);
+
+}  // namespace nflhip

@@ -1,0 +1,513 @@
+// kernels_generic.hip -- shape-generic gfx950 kernels of the NTT polynomial-ring
+// engine: negacyclic NTT (any power-of-two degree, any limb width), element-wise
+// modular ops, comparisons, seeded input generation and CRT lift/project.
+//
+// These are the correctness-first paths every shape can take; the tuned
+// register-tiled kernels for the headline shape live in kernels_fast.hip.
+//
+// Algorithm (NOT the reference's loop structure): the reference computes
+//   phi-twist (core.hpp:596) -> cyclic Harvey DIF NTT (core.hpp:455-532) and, for
+//   the inverse, bit-reverse -> NTT -> bit-reverse -> scale/untwist (core.hpp:539-557, 613).
+// Its forward output is out[bitrev(k)] = a(phi^(2k+1)) in [0,p), which is exactly
+// what a merged-twiddle Cooley-Tukey negacyclic transform over the table
+// psi_br[k] = phi^bitrev(k) produces in place; the inverse is the mirrored
+// Gentleman-Sande network over the SAME table, using
+//   psi_br[m+j]^-1 = -psi_br[m + (m-1-j)]   and   (u-v)*(-W) = (v-u)*W,
+// with n^-1 folded into the last stage.  Every public word is the canonical
+// representative, so results are bit-identical to the reference's.
+#include "kernels.h"
+#include "modarith.h"
+
+namespace nflhip {
+
+static constexpr int kInnerLogMax = 12;  // rows up to 4096 words are transformed inside LDS
+
+// ---------------------------------------------------------------------------
+// forward, LDS-resident stages [logn-logi, logn)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_ntt_fwd_lds(const T *src, T *dst, const Tw<T> *__restrict__ psi,
+                              const ModConst<T> *__restrict__ mc, int logn, int logi, int nm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *sm = reinterpret_cast<T *>(smem_raw);
+  const int s0 = logn - logi;
+  const size_t row = (size_t)blockIdx.x >> s0;
+  const unsigned blk = blockIdx.x & ((1u << s0) - 1u);
+  const int cm = (int)(row % (size_t)nm);
+  const T p = mc[cm].p, p2 = mc[cm].p2;
+  const Tw<T> *tw = psi + ((size_t)cm << logn);
+  const unsigned I = 1u << logi;
+  const size_t base = (row << logn) + ((size_t)blk << logi);
+  for (unsigned i = threadIdx.x; i < I; i += blockDim.x) sm[i] = src[base + i];
+  for (int s = s0; s < logn; ++s) {
+    const int lt = logn - s - 1;  // log2 of the half-block length t
+    const unsigned t = 1u << lt;
+    const unsigned jbase = (1u << s) + (blk << (s - s0));
+    __syncthreads();
+    for (unsigned q = threadIdx.x; q < (I >> 1); q += blockDim.x) {
+      const unsigned jl = q >> lt, o = q & (t - 1u);
+      const unsigned i = (jl << (lt + 1)) + o;
+      const Tw<T> w = tw[jbase + jl];
+      T x = sm[i];
+      const T y = sm[i + t];
+      x = csub<T>(x, p2);                                     // [0,4p) -> [0,2p)
+      const T m = mul_shoup_lazy<T>(y, w.w, w.wp, p);         // [0,2p)
+      sm[i] = (T)(x + m);                                     // [0,4p)
+      sm[i + t] = (T)(x - m + p2);                            // [0,4p)
+    }
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < I; i += blockDim.x) dst[base + i] = reduce4<T>(sm[i], p);
+}
+
+// forward, streaming radix-2^R pass over global stages [done, done+R): strides >= 4096 words
+template <typename T, int R>
+__global__ void k_ntt_fwd_outer(const T *src, T *dst, const Tw<T> *__restrict__ psi,
+                                const ModConst<T> *__restrict__ mc, int logn, int done, int nm) {
+  constexpr int E = 1 << R;
+  const int lstride = logn - done - R;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per E-point column
+  const size_t row = gid >> (logn - R);
+  const unsigned q = (unsigned)(gid & ((((size_t)1) << (logn - R)) - 1));
+  const unsigned j = q >> lstride, o = q & ((1u << lstride) - 1u);
+  const int cm = (int)(row % (size_t)nm);
+  const T p = mc[cm].p, p2 = mc[cm].p2;
+  const Tw<T> *tw = psi + ((size_t)cm << logn);
+  const size_t base = (row << logn) + ((size_t)j << (lstride + R)) + o;
+  T v[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k] = src[base + ((size_t)k << lstride)];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int half = 1 << (R - 1 - r);
+#pragma unroll
+    for (int g = 0; g < (1 << r); ++g) {
+      const Tw<T> w = tw[(1u << (done + r)) + (j << r) + (unsigned)g];
+#pragma unroll
+      for (int h = 0; h < half; ++h) {
+        const int i0 = g * 2 * half + h, i1 = i0 + half;
+        const T x = csub<T>(v[i0], p2);
+        const T m = mul_shoup_lazy<T>(v[i1], w.w, w.wp, p);
+        v[i0] = (T)(x + m);
+        v[i1] = (T)(x - m + p2);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) dst[base + ((size_t)k << lstride)] = v[k];  // stays lazy in [0,4p)
+}
+
+// ---------------------------------------------------------------------------
+// inverse, LDS-resident stages logn-1 down to logn-logi (Gentleman-Sande)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_ntt_inv_lds(const T *src, const T *mul, T *dst, const Tw<T> *__restrict__ psi,
+                              const ModConst<T> *__restrict__ mc, int logn, int logi, int nm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *sm = reinterpret_cast<T *>(smem_raw);
+  const int s0 = logn - logi;
+  const size_t row = (size_t)blockIdx.x >> s0;
+  const unsigned blk = blockIdx.x & ((1u << s0) - 1u);
+  const int cm = (int)(row % (size_t)nm);
+  const ModConst<T> c = mc[cm];
+  const T p = c.p, p2 = c.p2;
+  const Tw<T> *tw = psi + ((size_t)cm << logn);
+  const unsigned I = 1u << logi;
+  const size_t base = (row << logn) + ((size_t)blk << logi);
+  if (mul != nullptr) {
+    for (unsigned i = threadIdx.x; i < I; i += blockDim.x)
+      sm[i] = barrett<T>::mul(src[base + i], mul[base + i], p, c.mu);  // fused point-wise product
+  } else {
+    for (unsigned i = threadIdx.x; i < I; i += blockDim.x) sm[i] = src[base + i];
+  }
+  for (int s = logn - 1; s >= s0; --s) {
+    const int lt = logn - s - 1;
+    const unsigned t = 1u << lt;
+    const unsigned m = 1u << s;
+    const unsigned jg0 = blk << (s - s0);
+    __syncthreads();
+    if (s > 0) {
+      for (unsigned q = threadIdx.x; q < (I >> 1); q += blockDim.x) {
+        const unsigned jl = q >> lt, o = q & (t - 1u);
+        const unsigned i = (jl << (lt + 1)) + o;
+        const Tw<T> w = tw[m + (m - 1u - (jg0 + jl))];  // -(psi_br[m+j])^-1
+        const T u = sm[i], v = sm[i + t];
+        sm[i] = csub<T>((T)(u + v), p2);
+        sm[i + t] = mul_shoup_lazy<T>((T)(v - u + p2), w.w, w.wp, p);
+      }
+    } else {  // last stage: fold n^-1, emit canonical words
+      for (unsigned q = threadIdx.x; q < (I >> 1); q += blockDim.x) {
+        const T u = sm[q], v = sm[q + t];
+        sm[q] = mul_shoup<T>((T)(u + v), c.ninv, c.ninv_sh, p);
+        sm[q + t] = mul_shoup<T>((T)(v - u + p2), c.w1ninv, c.w1ninv_sh, p);
+      }
+    }
+  }
+  __syncthreads();
+  // when outer passes follow, words stay lazy in [0,2p); otherwise they are canonical already
+  for (unsigned i = threadIdx.x; i < I; i += blockDim.x) dst[base + i] = sm[i];
+}
+
+// inverse, streaming radix-2^R pass over global stages [sa, sa+R), processed high to low
+template <typename T, int R>
+__global__ void k_ntt_inv_outer(const T *src, T *dst, const Tw<T> *__restrict__ psi,
+                                const ModConst<T> *__restrict__ mc, int logn, int sa, int nm) {
+  constexpr int E = 1 << R;
+  const int lstride = logn - sa - R;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = gid >> (logn - R);
+  const unsigned q = (unsigned)(gid & ((((size_t)1) << (logn - R)) - 1));
+  const unsigned j = q >> lstride, o = q & ((1u << lstride) - 1u);
+  const int cm = (int)(row % (size_t)nm);
+  const ModConst<T> c = mc[cm];
+  const T p = c.p, p2 = c.p2;
+  const Tw<T> *tw = psi + ((size_t)cm << logn);
+  const size_t base = (row << logn) + ((size_t)j << (lstride + R)) + o;
+  T v[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k] = src[base + ((size_t)k << lstride)];
+#pragma unroll
+  for (int r = R - 1; r >= 0; --r) {
+    const int half = 1 << (R - 1 - r);
+    const unsigned m = 1u << (sa + r);
+#pragma unroll
+    for (int g = 0; g < (1 << r); ++g) {
+      if (sa + r > 0) {
+        const Tw<T> w = tw[m + (m - 1u - ((j << r) + (unsigned)g))];
+#pragma unroll
+        for (int h = 0; h < half; ++h) {
+          const int i0 = g * 2 * half + h, i1 = i0 + half;
+          const T u = v[i0], x = v[i1];
+          v[i0] = csub<T>((T)(u + x), p2);
+          v[i1] = mul_shoup_lazy<T>((T)(x - u + p2), w.w, w.wp, p);
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < half; ++h) {
+          const int i0 = g * 2 * half + h, i1 = i0 + half;
+          const T u = v[i0], x = v[i1];
+          v[i0] = mul_shoup<T>((T)(u + x), c.ninv, c.ninv_sh, p);
+          v[i1] = mul_shoup<T>((T)(x - u + p2), c.w1ninv, c.w1ninv_sh, p);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) dst[base + ((size_t)k << lstride)] = v[k];
+}
+
+// ---------------------------------------------------------------------------
+// launch plans
+// ---------------------------------------------------------------------------
+static inline int inner_log(const Shape &s) { return s.logn < kInnerLogMax ? s.logn : kInnerLogMax; }
+static inline unsigned lds_threads(int logi) {
+  const unsigned half = 1u << (logi > 0 ? logi - 1 : 0);
+  return half < 64u ? 64u : (half > 256u ? 256u : half);
+}
+
+template <typename T>
+static hipError_t outer_fwd(const Shape &s, const DevTables &t, const T *src, T *dst, size_t rows, int done, int R,
+                            hipStream_t st) {
+  const size_t threads = rows << (s.logn - R);
+  const dim3 block(256), grid((unsigned)(threads / 256));
+  const Tw<T> *psi = (const Tw<T> *)t.psi;
+  const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+  switch (R) {
+    case 1: hipLaunchKernelGGL((k_ntt_fwd_outer<T, 1>), grid, block, 0, st, src, dst, psi, mc, s.logn, done, (int)s.nm); break;
+    case 2: hipLaunchKernelGGL((k_ntt_fwd_outer<T, 2>), grid, block, 0, st, src, dst, psi, mc, s.logn, done, (int)s.nm); break;
+    case 3: hipLaunchKernelGGL((k_ntt_fwd_outer<T, 3>), grid, block, 0, st, src, dst, psi, mc, s.logn, done, (int)s.nm); break;
+    default: hipLaunchKernelGGL((k_ntt_fwd_outer<T, 4>), grid, block, 0, st, src, dst, psi, mc, s.logn, done, (int)s.nm); break;
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t outer_inv(const Shape &s, const DevTables &t, const T *src, T *dst, size_t rows, int sa, int R,
+                            hipStream_t st) {
+  const size_t threads = rows << (s.logn - R);
+  const dim3 block(256), grid((unsigned)(threads / 256));
+  const Tw<T> *psi = (const Tw<T> *)t.psi;
+  const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+  switch (R) {
+    case 1: hipLaunchKernelGGL((k_ntt_inv_outer<T, 1>), grid, block, 0, st, src, dst, psi, mc, s.logn, sa, (int)s.nm); break;
+    case 2: hipLaunchKernelGGL((k_ntt_inv_outer<T, 2>), grid, block, 0, st, src, dst, psi, mc, s.logn, sa, (int)s.nm); break;
+    case 3: hipLaunchKernelGGL((k_ntt_inv_outer<T, 3>), grid, block, 0, st, src, dst, psi, mc, s.logn, sa, (int)s.nm); break;
+    default: hipLaunchKernelGGL((k_ntt_inv_outer<T, 4>), grid, block, 0, st, src, dst, psi, mc, s.logn, sa, (int)s.nm); break;
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_ntt_fwd(const Shape &s, const DevTables &t, const T *src, T *dst, size_t batch, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const size_t rows = batch * s.nm;
+  const int logi = inner_log(s);
+  int done = 0;
+  const T *cur = src;
+  while (done < s.logn - logi) {  // streaming passes over the large strides
+    const int rem = s.logn - logi - done;
+    const int R = rem >= 4 ? 4 : rem;
+    hipError_t e = outer_fwd<T>(s, t, cur, dst, rows, done, R, st);
+    if (e != hipSuccess) return e;
+    cur = dst;
+    done += R;
+  }
+  const unsigned nblk = (unsigned)(rows << (s.logn - logi));
+  hipLaunchKernelGGL((k_ntt_fwd_lds<T>), dim3(nblk), dim3(lds_threads(logi)), sizeof(T) << logi, st, cur, dst,
+                     (const Tw<T> *)t.psi, (const ModConst<T> *)t.mc, s.logn, logi, (int)s.nm);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_ntt_inv(const Shape &s, const DevTables &t, const T *src, const T *mul, T *dst, size_t batch,
+                          hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const size_t rows = batch * s.nm;
+  const int logi = inner_log(s);
+  const unsigned nblk = (unsigned)(rows << (s.logn - logi));
+  hipLaunchKernelGGL((k_ntt_inv_lds<T>), dim3(nblk), dim3(lds_threads(logi)), sizeof(T) << logi, st, src, mul, dst,
+                     (const Tw<T> *)t.psi, (const ModConst<T> *)t.mc, s.logn, logi, (int)s.nm);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  int top = s.logn - logi;  // global stages [0, top) remain, processed high to low
+  while (top > 0) {
+    const int R = top >= 4 ? 4 : top;
+    e = outer_inv<T>(s, t, dst, dst, rows, top - R, R, st);
+    if (e != hipSuccess) return e;
+    top -= R;
+  }
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------
+// element-wise ops (the functors of poly::operator=(expr), core.hpp:24-37)
+// ---------------------------------------------------------------------------
+template <typename T, int OP>
+__global__ void k_pointwise(T *out, const T *a, const T *b, const T *bp, const ModConst<T> *__restrict__ mc, int logn,
+                            int nm, size_t total) {
+  constexpr int V = 16 / sizeof(T);
+  struct alignas(16) Vec { T e[V]; };
+  const size_t nvec = total / V;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const Vec va = reinterpret_cast<const Vec *>(a)[v];
+    Vec vb = va, vp = va, vo;
+    if (OP != 4) vb = reinterpret_cast<const Vec *>(b)[v];
+    if (OP == 3) vp = reinterpret_cast<const Vec *>(bp)[v];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int cm = (int)((((v * V + k) >> logn)) % (size_t)nm);
+      const T p = mc[cm].p;
+      T r;
+      if (OP == 0) r = csub<T>((T)(va.e[k] + vb.e[k]), p);                       // addmod
+      else if (OP == 1) r = csub<T>((T)(va.e[k] + (T)(p - vb.e[k])), p);           // submod = addmod(x, p-y)
+      else if (OP == 2) r = barrett<T>::mul(va.e[k], vb.e[k], p, mc[cm].mu);       // mulmod
+      else if (OP == 3) r = mul_shoup<T>(va.e[k], vb.e[k], vp.e[k], p);            // mulmod_shoup
+      else {                                                                       // compute_shoup
+        T x = va.e[k];
+        x = csub<T>(x, (T)(4 * p)); x = csub<T>(x, (T)(2 * p)); x = csub<T>(x, p);
+        if (sizeof(T) < 8) { while (x >= p) x -= p; }
+        r = shoup_of<T>::get(x, p, mc[cm].mu);
+      }
+      vo.e[k] = r;
+    }
+    reinterpret_cast<Vec *>(out)[v] = vo;
+  }
+}
+
+template <typename T>
+hipError_t launch_pointwise(const Shape &s, const DevTables &t, int op, T *out, const T *a, const T *b, const T *bp,
+                            size_t batch, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const size_t total = batch * s.nm * s.n;
+  constexpr size_t V = 16 / sizeof(T);
+  if (total % V) return hipErrorInvalidValue;
+  const size_t nvec = total / V;
+  size_t blocks = (nvec + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+  const dim3 g((unsigned)blocks), bl(256);
+  switch (op) {
+    case 0: hipLaunchKernelGGL((k_pointwise<T, 0>), g, bl, 0, st, out, a, b, bp, mc, s.logn, (int)s.nm, total); break;
+    case 1: hipLaunchKernelGGL((k_pointwise<T, 1>), g, bl, 0, st, out, a, b, bp, mc, s.logn, (int)s.nm, total); break;
+    case 2: hipLaunchKernelGGL((k_pointwise<T, 2>), g, bl, 0, st, out, a, b, bp, mc, s.logn, (int)s.nm, total); break;
+    case 3: hipLaunchKernelGGL((k_pointwise<T, 3>), g, bl, 0, st, out, a, b, bp, mc, s.logn, (int)s.nm, total); break;
+    case 4: hipLaunchKernelGGL((k_pointwise<T, 4>), g, bl, 0, st, out, a, b, bp, mc, s.logn, (int)s.nm, total); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// expr::operator bool over eqmod / neqmod (ops.hpp:81-117): "any word" semantics
+template <typename T>
+__global__ void k_any_cmp(const T *a, const T *b, size_t total, int want_eq, int *flag) {
+  int hit = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    hit |= ((a[i] == b[i]) == (want_eq != 0)) ? 1 : 0;
+  if (__any(hit)) {
+    if ((threadIdx.x & 63) == 0) atomicOr(flag, 1);
+  }
+}
+
+template <typename T>
+hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
+                          hipStream_t st) {
+  hipError_t e = hipMemsetAsync(t.flag, 0, sizeof(int), st);
+  if (e != hipSuccess || batch == 0) return e;
+  const size_t total = batch * s.nm * s.n;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((k_any_cmp<T>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, total, want_eq, t.flag);
+  return hipGetLastError();
+}
+
+// seeded synthetic operands: mask-then-subtract rule of nfl::uniform (core.hpp:165-176)
+template <typename T>
+__global__ void k_fill_uniform(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t first_word,
+                               size_t total, uint64_t seed, int operand) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = first_word + i;
+    const int cm = (int)((g >> logn) % (size_t)nm);
+    const uint64_t p = mc[cm].p;
+    uint64_t v = splitmix64_at(seed, operand, g) & (uint64_t)mc[cm].mask;
+    if (v >= p) v -= p;
+    d[i] = (T)v;
+  }
+}
+
+template <typename T>
+hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, uint64_t seed,
+                               int operand, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const size_t total = batch * s.nm * s.n;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL((k_fill_uniform<T>), dim3((unsigned)blocks), dim3(256), 0, st, d, (const ModConst<T> *)t.mc, s.logn,
+                     (int)s.nm, first_poly * s.nm * s.n, total, seed, operand);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// CRT lift (GMP::poly2mpz, gmp.hpp:183-209).  The reference accumulates
+// sum_cm lifting[cm]*x(cm,i) and Barrett-reduces mod Q; the value in [0,Q) is
+// unique, so we use the equivalent small-quotient form
+//   X = sum_cm (Q/p_cm) * ((x(cm,i) * (Q/p_cm)^-1) mod p_cm)   (< nm*Q)
+// followed by conditional subtractions of Q<<k.  One thread per coefficient.
+// ---------------------------------------------------------------------------
+static constexpr int kCrtMaxLimbs = 36;
+
+template <typename T>
+__global__ void k_crt_lift(uint64_t *out, const T *d, const ModConst<T> *__restrict__ mc,
+                           const uint64_t *__restrict__ qhat, const uint64_t *__restrict__ qsh, int logn, int nm, int L,
+                           int Lacc, size_t ncoef) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncoef) return;
+  const size_t b = gid >> logn, i = gid & ((((size_t)1) << logn) - 1);
+  uint64_t acc[kCrtMaxLimbs];
+  for (int k = 0; k < Lacc; ++k) acc[k] = 0;
+  for (int cm = 0; cm < nm; ++cm) {
+    const ModConst<T> c = mc[cm];
+    const T x = d[((b * nm + cm) << logn) + i];
+    const uint64_t y = (uint64_t)mul_shoup<T>(x, c.yinv, c.yinv_sh, c.p);
+    const uint64_t *qh = qhat + (size_t)cm * Lacc;
+    uint64_t carry = 0;
+    for (int k = 0; k < Lacc; ++k) {  // acc += qhat[cm] * y
+      const uint64_t lo = qh[k] * y, hi = __umul64hi(qh[k], y);
+      uint64_t s = acc[k] + lo;
+      uint64_t c1 = s < lo ? 1 : 0;
+      s += carry;
+      c1 += s < carry ? 1 : 0;
+      acc[k] = s;
+      carry = hi + c1;
+    }
+  }
+  for (int sft = 5; sft >= 0; --sft) {  // acc < 32*Q: subtract Q<<5 .. Q<<0 when possible
+    const uint64_t *qs = qsh + (size_t)sft * Lacc;
+    bool ge = true;
+    for (int k = Lacc - 1; k >= 0; --k) {
+      if (acc[k] != qs[k]) { ge = acc[k] > qs[k]; break; }
+    }
+    if (ge) {
+      uint64_t borrow = 0;
+      for (int k = 0; k < Lacc; ++k) {
+        const uint64_t a = acc[k], q = qs[k];
+        const uint64_t dd = a - q - borrow;
+        borrow = (a < q || (a == q && borrow)) ? 1 : 0;
+        acc[k] = dd;
+      }
+    }
+  }
+  uint64_t *o = out + gid * (size_t)L;
+  for (int k = 0; k < L; ++k) o[k] = acc[k];
+}
+
+template <typename T>
+hipError_t launch_crt_lift(const Shape &s, const DevTables &t, uint64_t *limbs, const T *d, size_t batch, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  if ((int)s.crt_Lacc > kCrtMaxLimbs || s.nm > 32) return hipErrorNotSupported;
+  const size_t ncoef = batch * s.n;
+  hipLaunchKernelGGL((k_crt_lift<T>), dim3((unsigned)((ncoef + 127) / 128)), dim3(128), 0, st, limbs, d,
+                     (const ModConst<T> *)t.mc, t.qhat, t.qsh, s.logn, (int)s.nm, (int)s.crt_L, (int)s.crt_Lacc, ncoef);
+  return hipGetLastError();
+}
+
+// CRT project (GMP::mpz2poly gmp.hpp:211-219): x(cm,i) = X_i mod p_cm by Horner
+// over the 64-bit limbs with beta = 2^64 mod p.
+template <typename T>
+__global__ void k_crt_project(T *d, const uint64_t *limbs, const ModConst<T> *__restrict__ mc, int logn, int nm, int Lin,
+                              size_t total) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const size_t i = gid & ((((size_t)1) << logn) - 1);
+  const size_t rowi = gid >> logn;
+  const size_t b = rowi / (size_t)nm;
+  const int cm = (int)(rowi % (size_t)nm);
+  const ModConst<T> c = mc[cm];
+  const uint64_t p = c.p;
+  const uint64_t *x = limbs + ((b << logn) + i) * (size_t)Lin;
+  uint64_t r = 0;
+  for (int k = Lin - 1; k >= 0; --k) {
+    uint64_t l = x[k];
+    if (sizeof(T) == 8) {
+      l = csub<uint64_t>(l, 4 * p); l = csub<uint64_t>(l, 2 * p); l = csub<uint64_t>(l, p);
+      // r < 4p: r*beta mod p lazily in [0,2p), plus l < p  -> < 3p
+      r = mul_shoup_lazy<uint64_t>(r, (uint64_t)c.beta, (uint64_t)c.beta_sh, p) + l;
+    } else {
+      l %= p;
+      r = ((r * (uint64_t)c.beta) % p + l);  // p < 2^30: no overflow
+      r = r >= p ? r - p : r;
+    }
+  }
+  if (sizeof(T) == 8) r = reduce4<uint64_t>(r, p);
+  d[gid] = (T)r;
+}
+
+template <typename T>
+hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const uint64_t *limbs, size_t L_in, size_t batch,
+                              hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const size_t total = batch * s.nm * s.n;
+  hipLaunchKernelGGL((k_crt_project<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, limbs,
+                     (const ModConst<T> *)t.mc, s.logn, (int)s.nm, (int)L_in, total);
+  return hipGetLastError();
+}
+
+// ---- explicit instantiations ----
+#define NFLHIP_INST(T)                                                                                              \
+  template hipError_t launch_ntt_fwd<T>(const Shape &, const DevTables &, const T *, T *, size_t, hipStream_t);      \
+  template hipError_t launch_ntt_inv<T>(const Shape &, const DevTables &, const T *, const T *, T *, size_t,         \
+                                        hipStream_t);                                                                \
+  template hipError_t launch_pointwise<T>(const Shape &, const DevTables &, int, T *, const T *, const T *,          \
+                                          const T *, size_t, hipStream_t);                                           \
+  template hipError_t launch_any_cmp<T>(const Shape &, const DevTables &, const T *, const T *, size_t, int,         \
+                                        hipStream_t);                                                                \
+  template hipError_t launch_fill_uniform<T>(const Shape &, const DevTables &, T *, size_t, size_t, uint64_t, int,   \
+                                             hipStream_t);                                                           \
+  template hipError_t launch_crt_lift<T>(const Shape &, const DevTables &, uint64_t *, const T *, size_t,            \
+                                         hipStream_t);                                                               \
+  template hipError_t launch_crt_project<T>(const Shape &, const DevTables &, T *, const uint64_t *, size_t, size_t, \
+                                            hipStream_t);
+NFLHIP_INST(uint16_t)
+NFLHIP_INST(uint32_t)
+NFLHIP_INST(uint64_t)
+
+}  // namespace nflhip

@@ -1,0 +1,217 @@
+"""Host-side driver of the HIP engine for tests, bench.py and the multi-GPU
+batch split.  This is plumbing over the C ABI (include/nflhip.h): device
+memory and streams come from PyTorch, all arithmetic happens in libnflhip.so.
+
+Data layout is the reference's: a batch of nfl::poly<T,Degree,NbModuli> is a
+dense [batch][NbModuli][Degree] tensor of T (poly.hpp:82-88, tests/tools.h:6-17).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (NflHipError, OP_ADD, OP_COMPUTE_SHOUP, OP_MUL, OP_MUL_SHOUP, OP_SUB,  # noqa: F401
+                   TAB_INVDEGREE, TAB_MODULUS, TAB_PSI)
+from .params import params as limb_params
+
+_NP = {16: np.uint16, 32: np.uint32, 64: np.uint64}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _vp(x):
+    """void* of a numpy array, a torch tensor, an int or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.data_ptr())
+
+
+class Engine:
+    """One (T, Degree, NbModuli) context on one GPU -- the device-side
+    counterpart of poly<T,Degree,NbModuli>::base / ::gmp (poly.hpp:247, 275)."""
+
+    def __init__(self, limb_bits, degree, nmoduli, device=0):
+        self.lib = _lib.lib
+        self.limb_bits, self.degree, self.nmoduli, self.device = limb_bits, degree, nmoduli, device
+        self.np_dtype = np.dtype(_NP[limb_bits])
+        pr = self.params = limb_params(limb_bits)
+        if nmoduli > pr.max_moduli:
+            raise ValueError("only %d moduli are mirrored for %d-bit limbs" % (pr.max_moduli, limb_bits))
+        self._keep = [np.ascontiguousarray(x[:nmoduli]) for x in (pr.P, pr.primitive_roots, pr.invkmax)]
+        h = C.c_void_p()
+        rc = self.lib.nflhip_ctx_create(C.byref(h), device, limb_bits, degree, nmoduli,
+                                        *[_vp(x) for x in self._keep], pr.kmax_log2)
+        if rc != 0:
+            raise NflHipError(rc, self.lib.nflhip_last_error(None).decode())
+        self.ctx = h
+        self.P = [int(v) for v in self._keep[0]]
+        self.crt_limbs = self.lib.nflhip_crt_limbs(self.ctx)
+        self.words_per_poly = degree * nmoduli
+        self.bytes_per_poly = self.words_per_poly * self.np_dtype.itemsize
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nflhip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NflHipError(rc, self.lib.nflhip_last_error(self.ctx).decode())
+
+    # ---- device tensors (torch is only the allocator / stream provider) ----
+    @property
+    def torch_dtype(self):
+        t = _torch()
+        return {16: t.int16, 32: t.int32, 64: t.int64}[self.limb_bits]
+
+    def empty(self, batch):
+        t = _torch()
+        return t.empty((batch, self.nmoduli, self.degree), dtype=self.torch_dtype, device="cuda:%d" % self.device)
+
+    def to_device(self, arr):
+        t = _torch()
+        arr = np.ascontiguousarray(arr, dtype=self.np_dtype)
+        signed = arr.view({16: np.int16, 32: np.int32, 64: np.int64}[self.limb_bits])
+        return t.from_numpy(signed.copy()).to("cuda:%d" % self.device)
+
+    def to_host(self, ten):
+        return ten.detach().cpu().contiguous().numpy().view(self.np_dtype)
+
+    def _stream(self, stream=None):
+        t = _torch()
+        s = stream if stream is not None else t.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
+
+    def _batch(self, ten):
+        n = ten.numel()
+        assert n % self.words_per_poly == 0 and ten.is_contiguous()
+        return n // self.words_per_poly
+
+    def ntt_(self, d, stream=None):
+        self._chk(self.lib.nflhip_ntt_fwd_dev(self.ctx, _vp(d), self._batch(d), self._stream(stream)))
+        return d
+
+    def intt_(self, d, stream=None):
+        self._chk(self.lib.nflhip_ntt_inv_dev(self.ctx, _vp(d), self._batch(d), self._stream(stream)))
+        return d
+
+    def pointwise(self, op, a, b=None, bprime=None, out=None, stream=None):
+        out = out if out is not None else _torch().empty_like(a)
+        self._chk(self.lib.nflhip_pointwise_dev(self.ctx, op, _vp(out), _vp(a), _vp(b), _vp(bprime), self._batch(a),
+                                                self._stream(stream)))
+        return out
+
+    def polymul(self, a, b, out=None, b_is_ntt=False, stream=None):
+        out = out if out is not None else _torch().empty_like(a)
+        fn = self.lib.nflhip_polymul_ntt_dev if b_is_ntt else self.lib.nflhip_polymul_dev
+        self._chk(fn(self.ctx, _vp(out), _vp(a), _vp(b), self._batch(a), self._stream(stream)))
+        return out
+
+    def any_eq(self, a, b, stream=None):
+        r = C.c_int(0)
+        self._chk(self.lib.nflhip_any_eq_dev(self.ctx, _vp(a), _vp(b), self._batch(a), C.byref(r), self._stream(stream)))
+        return bool(r.value)
+
+    def any_neq(self, a, b, stream=None):
+        r = C.c_int(0)
+        self._chk(self.lib.nflhip_any_neq_dev(self.ctx, _vp(a), _vp(b), self._batch(a), C.byref(r), self._stream(stream)))
+        return bool(r.value)
+
+    def fill_uniform(self, d, seed, operand=0, first_poly=0, stream=None):
+        self._chk(self.lib.nflhip_fill_uniform_dev(self.ctx, _vp(d), first_poly, self._batch(d), seed, operand,
+                                                   self._stream(stream)))
+        return d
+
+    def crt_lift(self, d, stream=None):
+        t = _torch()
+        batch = self._batch(d)
+        out = t.empty((batch, self.degree, self.crt_limbs), dtype=t.int64, device=d.device)
+        self._chk(self.lib.nflhip_crt_lift_dev(self.ctx, _vp(out), _vp(d), batch, self._stream(stream)))
+        return out
+
+    def crt_project(self, limbs, stream=None):
+        batch, deg, L = limbs.shape
+        assert deg == self.degree and limbs.is_contiguous()
+        out = self.empty(batch)
+        self._chk(self.lib.nflhip_crt_project_dev(self.ctx, _vp(out), _vp(limbs), L, batch, self._stream(stream)))
+        return out
+
+    def time_polymul(self, c, a, b, iters, stream=None):
+        ms = C.c_float(0)
+        self._chk(self.lib.nflhip_time_polymul_dev(self.ctx, _vp(c), _vp(a), _vp(b), self._batch(a), iters,
+                                                   self._stream(stream), C.byref(ms)))
+        return ms.value
+
+    # ---- host-pointer path (numpy in, numpy out): what the per-poly C++ surface calls ----
+    def _hb(self, a):
+        assert isinstance(a, np.ndarray) and a.dtype == self.np_dtype and a.flags.c_contiguous
+        assert a.size % self.words_per_poly == 0
+        return a.size // self.words_per_poly
+
+    def h_ntt(self, a):
+        out = a.copy()
+        self._chk(self.lib.nflhip_ntt_fwd(self.ctx, _vp(out), self._hb(out)))
+        return out
+
+    def h_intt(self, a):
+        out = a.copy()
+        self._chk(self.lib.nflhip_ntt_inv(self.ctx, _vp(out), self._hb(out)))
+        return out
+
+    def h_pointwise(self, op, a, b=None, bprime=None):
+        out = np.empty_like(a)
+        self._chk(self.lib.nflhip_pointwise(self.ctx, op, _vp(out), _vp(a), _vp(b), _vp(bprime), self._hb(a)))
+        return out
+
+    def h_polymul(self, a, b):
+        out = np.empty_like(a)
+        self._chk(self.lib.nflhip_polymul(self.ctx, _vp(out), _vp(a), _vp(b), self._hb(a)))
+        return out
+
+    def h_any_eq(self, a, b):
+        r = C.c_int(0)
+        self._chk(self.lib.nflhip_any_eq(self.ctx, _vp(a), _vp(b), self._hb(a), C.byref(r)))
+        return bool(r.value)
+
+    def h_any_neq(self, a, b):
+        r = C.c_int(0)
+        self._chk(self.lib.nflhip_any_neq(self.ctx, _vp(a), _vp(b), self._hb(a), C.byref(r)))
+        return bool(r.value)
+
+    def h_crt_lift(self, a):
+        batch = self._hb(a)
+        out = np.zeros((batch, self.degree, self.crt_limbs), dtype=np.uint64)
+        self._chk(self.lib.nflhip_crt_lift(self.ctx, _vp(out), _vp(a), batch))
+        return out
+
+    def h_crt_project(self, limbs):
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        batch, deg, L = limbs.shape
+        out = np.empty((batch, self.nmoduli, self.degree), dtype=self.np_dtype)
+        self._chk(self.lib.nflhip_crt_project(self.ctx, _vp(out), _vp(limbs), L, batch))
+        return out
+
+    def table(self, which, cm):
+        n = 2 * self.degree if which == TAB_PSI else 1
+        out = np.zeros(n, dtype=self.np_dtype)
+        self._chk(self.lib.nflhip_get_table(self.ctx, which, cm, _vp(out), out.nbytes))
+        return out
+
+    def crt_constant(self, what, cm=0):
+        buf = np.zeros(self.crt_limbs + 2, dtype=np.uint64)
+        n = C.c_size_t(0)
+        self._chk(self.lib.nflhip_get_crt_constant(self.ctx, what, cm, _vp(buf), buf.size, C.byref(n)))
+        return int.from_bytes(buf[:n.value].tobytes(), "little")

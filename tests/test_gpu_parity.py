@@ -1,0 +1,237 @@
+"""-m gpu: the HIP engine (through the C ABI) against the CPU oracle, bit-exact.
+
+Mirrors what the reference's own tests pin -- scalar-formula agreement of + - *
+(tests/test_binary_op.h:9-32), shoup-mul (tests/nfllib_demo_main_op.cpp:76-84),
+NTT/INTT (tests/poly_p.cpp:51-58), CRT round trip (tests/poly_mpz.cpp:19-64) --
+but with memcmp equality instead of the reference's "any lane" operator==
+(ops.hpp:81-95), over the reference's test configs (tests/CMakeLists.txt:19-48)
+and the BASELINE.json shapes.
+"""
+import numpy as np
+import pytest
+
+from conftest import SEED
+
+pytestmark = pytest.mark.gpu
+
+# (limb_bits, degree, nmoduli, batch)
+SHAPES = [
+    (16, 128, 1, 5),      # reference CONFIG (128,14,uint16_t)
+    (16, 512, 2, 2),
+    (32, 8, 2, 9),        # reference CONFIG (8,60,uint32_t)
+    (32, 1024, 1, 3),     # BASELINE configs[0]
+    (32, 1024, 2, 3),     # reference CONFIG (1024,60,uint32_t)
+    (32, 32768, 1, 1),    # u32 kMaxPolyDegree
+    (64, 4, 1, 7),
+    (64, 8, 2, 5),
+    (64, 64, 3, 4),
+    (64, 1024, 2, 3),     # tests/ntt_perfs.cpp shape
+    (64, 2048, 1, 2),
+    (64, 4096, 4, 6),     # BASELINE configs[1] -- the metric shape
+    (64, 8192, 2, 2),     # reference CONFIG (8192,124,uint64_t)
+    (64, 16384, 8, 2),    # BASELINE configs[2]
+    (64, 32768, 2, 1),    # reference CONFIG (32768,124,uint64_t)
+    (64, 65536, 30, 1),   # BASELINE configs[4]
+]
+IDS = ["u%d-n%d-m%d" % s[:3] for s in SHAPES]
+
+
+def _inputs(o, batch, seed=SEED):
+    return o.fill_uniform(batch, seed, 0), o.fill_uniform(batch, seed, 1)
+
+
+@pytest.mark.parametrize("lb,n,m,batch", SHAPES, ids=IDS)
+def test_fill_uniform_matches_oracle(lb, n, m, batch, oracle_factory, engine_factory):
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    for operand in (0, 1):
+        d = e.fill_uniform(e.empty(batch), SEED, operand, first_poly=3)
+        assert np.array_equal(e.to_host(d), o.fill_uniform(batch, SEED, operand, first_poly=3))
+
+
+@pytest.mark.parametrize("lb,n,m,batch", SHAPES, ids=IDS)
+def test_ntt_forward_inverse(lb, n, m, batch, oracle_factory, engine_factory):
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a, _ = _inputs(o, batch)
+    fa = e.to_host(e.ntt_(e.to_device(a)))
+    assert np.array_equal(fa, o.ntt(a)), "ntt_pow_phi differs from the reference algorithm"
+    ia = e.to_host(e.intt_(e.to_device(a)))
+    assert np.array_equal(ia, o.intt(a)), "invntt_pow_invphi differs from the reference algorithm"
+    rt = e.to_host(e.intt_(e.ntt_(e.to_device(a))))
+    assert np.array_equal(rt, a), "INTT(NTT(a)) != a"
+
+
+@pytest.mark.parametrize("lb,n,m,batch", SHAPES, ids=IDS)
+def test_pointwise_ops(lb, n, m, batch, oracle_factory, engine_factory):
+    from nfllib_amd import OP_ADD, OP_COMPUTE_SHOUP, OP_MUL, OP_MUL_SHOUP, OP_SUB
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a, b = _inputs(o, batch)
+    da, db = e.to_device(a), e.to_device(b)
+    for op in (OP_ADD, OP_SUB, OP_MUL):
+        assert np.array_equal(e.to_host(e.pointwise(op, da, db)), o.pointwise(op, a, b)), op
+    bp = o.pointwise(OP_COMPUTE_SHOUP, b)
+    dbp = e.pointwise(OP_COMPUTE_SHOUP, db)
+    assert np.array_equal(e.to_host(dbp), bp)
+    assert np.array_equal(e.to_host(e.pointwise(OP_MUL_SHOUP, da, db, dbp)), o.pointwise(OP_MUL_SHOUP, a, b, bp))
+    # aliasing: a = a + b is legal in the reference (core.hpp:24-37)
+    dc = da.clone()
+    e.pointwise(OP_ADD, dc, db, out=dc)
+    assert np.array_equal(e.to_host(dc), o.pointwise(OP_ADD, a, b))
+
+
+@pytest.mark.parametrize("lb,n,m,batch", SHAPES, ids=IDS)
+def test_polymul(lb, n, m, batch, oracle_factory, engine_factory):
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a, b = _inputs(o, batch)
+    want = o.polymul(a, b)
+    da, db = e.to_device(a), e.to_device(b)
+    assert np.array_equal(e.to_host(e.polymul(da, db)), want)
+    # inputs untouched
+    assert np.array_equal(e.to_host(da), a) and np.array_equal(e.to_host(db), b)
+    # one operand pre-transformed
+    dbn = e.ntt_(db.clone())
+    assert np.array_equal(e.to_host(e.polymul(da, dbn, b_is_ntt=True)), want)
+    # c aliasing a
+    dc = da.clone()
+    e.polymul(dc, db, out=dc)
+    assert np.array_equal(e.to_host(dc), want)
+
+
+def test_polymul_is_negacyclic_convolution(oracle_factory, engine_factory):
+    """Independent second oracle: schoolbook product mod (X^n + 1, p)."""
+    for lb, n, m in [(64, 64, 3), (32, 8, 2), (16, 128, 1)]:
+        o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+        a, b = _inputs(o, 2, seed=7)
+        got = e.to_host(e.polymul(e.to_device(a), e.to_device(b)))
+        for bi in range(2):
+            for cm in range(m):
+                p = o.P[cm]
+                x = [int(v) for v in a[bi, cm]]
+                y = [int(v) for v in b[bi, cm]]
+                z = [0] * n
+                for i in range(n):
+                    for j in range(n):
+                        k = i + j
+                        if k < n:
+                            z[k] = (z[k] + x[i] * y[j]) % p
+                        else:
+                            z[k - n] = (z[k - n] - x[i] * y[j]) % p
+                assert [int(v) for v in got[bi, cm]] == z
+
+
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (32, 1024, 2), (16, 128, 1)])
+def test_edge_vectors(lb, n, m, oracle_factory, engine_factory):
+    """all-zero, all-(p-1), unit impulses, X^(n-1)*X wrap (negacyclic sign)."""
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    dt = o.dtype
+    zero = np.zeros((1, m, n), dtype=dt)
+    pm1 = np.stack([np.full(n, o.P[cm] - 1, dtype=dt) for cm in range(m)])[None]
+    imp0 = zero.copy(); imp0[0, :, 0] = 1
+    impl = zero.copy(); impl[0, :, n - 1] = 1
+    x1 = zero.copy(); x1[0, :, 1] = 1
+    for v in (zero, pm1, imp0, impl, x1):
+        assert np.array_equal(e.to_host(e.ntt_(e.to_device(v))), o.ntt(v))
+        assert np.array_equal(e.to_host(e.intt_(e.to_device(v))), o.intt(v))
+    # X^(n-1) * X = X^n = -1
+    got = e.to_host(e.polymul(e.to_device(impl), e.to_device(x1)))
+    want = zero.copy()
+    for cm in range(m):
+        want[0, cm, 0] = o.P[cm] - 1
+    assert np.array_equal(got, want)
+    assert np.array_equal(e.to_host(e.polymul(e.to_device(pm1), e.to_device(pm1))), o.polymul(pm1, pm1))
+
+
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (32, 1024, 2)])
+def test_any_eq_neq_reference_semantics(lb, n, m, oracle_factory, engine_factory):
+    """`a == b` in the reference is "ANY lane equal" (ops.hpp:81-107)."""
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a, b = _inputs(o, 2)
+    b[b == a] += 1  # make every lane differ
+    da, db = e.to_device(a), e.to_device(b)
+    assert e.any_eq(da, da) and not e.any_neq(da, da)
+    assert not e.any_eq(da, db) and e.any_neq(da, db)
+    b2 = b.copy(); b2[1, m - 1, n - 1] = a[1, m - 1, n - 1]
+    db2 = e.to_device(b2)
+    assert e.any_eq(da, db2) and e.any_neq(da, db2)
+    assert e.any_eq(da, db2) == o.any_eq(a, b2) and e.any_neq(da, db2) == o.any_neq(a, b2)
+
+
+@pytest.mark.parametrize("lb,n,m,batch", [(64, 4096, 4, 2), (64, 16384, 8, 1), (64, 65536, 30, 1), (32, 1024, 2, 2),
+                                           (16, 128, 1, 3), (64, 64, 3, 3)])
+def test_crt_lift_project(lb, n, m, batch, oracle_factory, engine_factory):
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    assert e.crt_limbs == o.crt_limbs
+    assert e.crt_constant(0) == o.crt_modulus()
+    for cm in range(m):
+        assert e.crt_constant(1, cm) == o.crt_lifting(cm)
+    a, _ = _inputs(o, batch)
+    a[0, :, 0] = 0  # the reference skips zero residues (gmp.hpp:193)
+    da = e.to_device(a)
+    limbs = e.crt_lift(da)
+    got = limbs.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, o.crt_lift(a)), "poly2mpz differs"
+    back = e.crt_project(limbs)
+    assert np.array_equal(e.to_host(back), a), "mpz2poly(poly2mpz(a)) != a (tests/poly_mpz.cpp:19-29)"
+    # reduction of wide non-negative integers (tests/poly_mpz.cpp:44-64): 4 limbs of noise
+    rng = np.random.default_rng(0)
+    wide = rng.integers(0, 2**63, size=(batch, n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(
+        0, 2, size=(batch, n, 4), dtype=np.uint64)
+    import torch
+    dw = torch.from_numpy(wide.view(np.int64)).to(da.device)
+    assert np.array_equal(e.to_host(e.crt_project(dw)), o.crt_project(wide))
+
+
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (32, 1024, 1), (64, 8, 2)])
+def test_host_pointer_entry_points(lb, n, m, oracle_factory, engine_factory):
+    """The un-suffixed C entry points (host buffers in/out) used by the per-poly nfl::poly surface."""
+    from nfllib_amd import OP_ADD, OP_MUL
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a, b = _inputs(o, 2)
+    assert np.array_equal(e.h_ntt(a), o.ntt(a))
+    assert np.array_equal(e.h_intt(a), o.intt(a))
+    assert np.array_equal(e.h_pointwise(OP_ADD, a, b), o.pointwise(OP_ADD, a, b))
+    assert np.array_equal(e.h_pointwise(OP_MUL, a, b), o.pointwise(OP_MUL, a, b))
+    assert np.array_equal(e.h_polymul(a, b), o.polymul(a, b))
+    assert e.h_any_eq(a, a) and not e.h_any_neq(a, a)
+    assert np.array_equal(e.h_crt_project(e.h_crt_lift(a)), a)
+
+
+def test_device_tables_match_reference_tables(oracle_factory, engine_factory):
+    """psi_br[k] = phi^bitrev(k): cross-check against the reference's phis table (core.hpp:649-656)."""
+    from nfllib_amd import TAB_INVDEGREE, TAB_MODULUS, TAB_PSI
+    from oracle import oracle as O
+    for lb, n, m in [(64, 4096, 4), (32, 1024, 2), (16, 128, 1)]:
+        o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+        logn = n.bit_length() - 1
+        br = np.array([int(format(k, "0%db" % logn)[::-1], 2) for k in range(n)])
+        for cm in range(m):
+            psi = e.table(TAB_PSI, cm).reshape(n, 2)
+            assert np.array_equal(psi[:, 0], o.table(O.TAB_PHIS, cm)[br])
+            assert np.array_equal(psi[:, 1], o.table(O.TAB_SHOUPPHIS, cm)[br])
+            assert int(e.table(TAB_MODULUS, cm)[0]) == o.P[cm]
+            assert int(e.table(TAB_INVDEGREE, cm)[0]) == int(o.table(O.TAB_INVPOLYDEGREE, cm)[0])
+
+
+def test_full_size_properties_metric_shape(oracle_factory, engine_factory):
+    """BASELINE configs[1] at a bench-sized batch: size-independent properties +
+    sampled compare against the oracle."""
+    lb, n, m, batch = 64, 4096, 4, 4096
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a = e.fill_uniform(e.empty(batch), SEED, 0)
+    b = e.fill_uniform(e.empty(batch), SEED, 1)
+    c = e.polymul(a, b)
+    # commutativity, and INTT(NTT(a)) == a over the whole batch
+    assert not e.any_neq(c, e.polymul(b, a))
+    rt = e.intt_(e.ntt_(a.clone()))
+    assert not e.any_neq(rt, a)
+    # linearity: (a+b)*b == a*b + b*b
+    from nfllib_amd import OP_ADD
+    lhs = e.polymul(e.pointwise(OP_ADD, a, b), b)
+    rhs = e.pointwise(OP_ADD, c, e.polymul(b, b))
+    assert not e.any_neq(lhs, rhs)
+    # sampled polys regenerated on the CPU from the same counter stream
+    rng = np.random.default_rng(1)
+    hc = e.to_host(c)
+    for idx in rng.choice(batch, size=8, replace=False):
+        ha = o.fill_uniform(1, SEED, 0, first_poly=int(idx))
+        hb = o.fill_uniform(1, SEED, 1, first_poly=int(idx))
+        assert np.array_equal(hc[idx:idx + 1], o.polymul(ha, hb))
