@@ -134,6 +134,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     if (p < 3 || (p >> (wb - 2)) != 0 || (p >> (wb - 3)) == 0)
       return fail(nullptr, NFLHIP_ERR_INVALID, "modulus is not (word-2) bits long");
     c->h_P.push_back(p);
+    if (((((uint64_t)1) << (wb - 2)) - p) >> 31) c->shape.small_delta = 0;
   }
   // CRT constants
   Big Q(1, 1);
@@ -202,6 +203,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     int bits = 0;
     while (bits < wb && (((u128)1) << bits) <= (u128)p) ++bits;
     m.mask = (T)(bits >= 64 ? ~(uint64_t)0 : ((((uint64_t)1) << bits) - 1));
+    m.delta = (T)((((uint64_t)1) << (wb - 2)) - p);
   }
 
   HIPCHK(nullptr, hipMalloc(&c->tabs.psi, psi.size() * sizeof(Tw<T>)));
@@ -319,6 +321,7 @@ int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree
   c->shape.limb_bits = limb_bits;
   c->shape.n = degree;
   c->shape.nm = nmoduli;
+  c->shape.small_delta = 1;
   c->shape.logn = 0;
   while ((((size_t)1) << c->shape.logn) < degree) c->shape.logn++;
   int rc = limb_bits == 16   ? build_tables<uint16_t>(c, P, primitive_roots, invkmax, kmax_log2)
@@ -363,7 +366,7 @@ int nflhip_get_table(const nflhip_ctx *ctx, int which, size_t cm, void *host_out
   int rc = set_device(ctx);
   if (rc) return rc;
   const size_t w = ctx->word;
-  const size_t mcsz = 12 * w;  // sizeof(ModConst<T>)
+  const size_t mcsz = sizeof(ModConst<uint64_t>) / 8 * w;  // sizeof(ModConst<T>)
   switch (which) {
     case NFLHIP_TAB_PSI: {
       const size_t bytes = ctx->shape.n * 2 * w;

@@ -22,6 +22,7 @@ template <typename T> struct ModConst {
   T yinv;       // (Q/p)^-1 mod p (CRT lift)         (gmp.hpp:141-147)
   T yinv_sh;    // its Shoup companion
   T mask;       // 2^(floor(log2 p)+1) - 1           (core.hpp:165-166)
+  T delta;      // 2^(W-2) - p: the primes are 2^(W-2) - c*2*kMax + 1 (params.hpp:20,54,96)
 };
 
 // Twiddle pair as stored on the device: psi^bitrev(k) and its Shoup companion.
@@ -35,6 +36,7 @@ struct Shape {
   size_t n, nm;
   size_t crt_L;      // limbs of a lifted coefficient
   size_t crt_Lacc;   // limbs of the accumulator (L+1)
+  int small_delta;   // every modulus is 2^(W-2) - delta with 2*delta < 2^32 (delta-form butterflies)
 };
 
 // Device-resident tables of one context.

@@ -25,6 +25,7 @@
 // core::invntt_pow_invphi (core.hpp:608-614).
 #include "kernels.h"
 #include "modarith.h"
+#include <cstdlib>
 
 namespace nflhip {
 
@@ -39,25 +40,75 @@ static constexpr int kLdsWords = kN + (kN >> 4);  // padded slab
 
 __device__ __forceinline__ int pad(int e) { return e + (e >> 4); }
 
+// ---- modulus in the form the butterflies want it ------------------------------------
+// The reference's 62-bit primes are p = 2^62 - delta with delta = c*2^21 - 1 < 2^31
+// (params.hpp:94-97), so q*p = (q << 62) - q*delta costs one 32x32 multiply-add.
+struct Mod {
+  u64 p, p2;
+  uint32_t d, d2;  // delta, 2*delta
+};
+typedef uint32_t u32;
+
+// exact floor(y*wp / 2^64) phrased so that hipcc emits v_mad_u64_u32 chains
+__device__ __forceinline__ u64 mulhi_x(const u64 y, const u64 wp) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wp, a1 = (u32)(wp >> 32);
+  const u64 t0 = (u64)y0 * a0;
+  const u64 t1 = (u64)y1 * a0 + (t0 >> 32);
+  const u64 t2 = (u64)y0 * a1 + (u32)t1;
+  return (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);
+}
+// seed + (y*w mod p, lazily in [0,2p)) for ANY 64-bit y: Shoup quotient, then
+// y*w - q*p = y*w + q*delta - (q << 62), all modulo 2^64, accumulated onto the seed.
+__device__ __forceinline__ u64 shoup_acc(const u64 y, const Tw64 w, const u64 seed, const Mod &k) {
+  const u64 q = mulhi_x(y, w.wp);
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w.w, w1 = (u32)(w.w >> 32);
+  const u32 q0 = (u32)q, q1 = (u32)(q >> 32);
+  u64 acc = (u64)y0 * w0 + seed;
+  acc = (u64)q0 * k.d + acc;
+  const u32 hi = (u32)(acc >> 32) + y0 * w1 + y1 * w0 + q1 * k.d - (q0 << 30);
+  return ((u64)hi << 32) | (u32)acc;
+}
+
 // ---- one lazy butterfly each way -------------------------------------------------
-// Cooley-Tukey: x,y in [0,4p) -> x' = x + w*y, y' = x - w*y, both in [0,4p)
-__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const u64 p, const u64 p2) {
-  const u64 u = csub<u64>(x, p2);
-  const u64 m = mul_shoup_lazy<u64>(y, w.w, w.wp, p);
-  x = u + m;
-  y = u - m + p2;
+// Cooley-Tukey, x' = x + w*y, y' = x - w*y.
+//  ARITH 0: Harvey's ranges, x,y in [0,4p) -> [0,4p).
+//  ARITH 1: x,y ANY 64-bit word -> any 64-bit word: the conditional subtraction of
+//           2p = 2^63 - 2*delta is keyed on bit 63 (U = x - [x >= 2^63]*2p < 2^63 + 2*delta),
+//           m < 2p exactly, so U + m < 2^64 and U - m + 2p < 2^64; the x-path sum is
+//           folded into the multiply-add chain and y' = (2U + 2p) - x'.
+template <int ARITH>
+__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod &k) {
+  if (ARITH == 0) {
+    const u64 u = csub<u64>(x, k.p2);
+    const u64 m = mul_shoup_lazy<u64>(y, w.w, w.wp, k.p);
+    x = u + m;
+    y = u - m + k.p2;
+  } else {
+    const u32 b = (u32)(x >> 63);
+    const u64 U = (x & 0x7fffffffffffffffull) + (u64)b * k.d2;
+    const u64 xn = shoup_acc(y, w, U, k);
+    y = ((U << 1) + k.p2) - xn;
+    x = xn;
+  }
 }
 // Gentleman-Sande with the negated mirrored twiddle: u,v in [0,2p) ->
 // u' = u + v, v' = (v - u) * w, both in [0,2p)
-__device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, const Tw64 w, const u64 p, const u64 p2) {
-  const u64 s = csub<u64>(x + y, p2);
-  const u64 d = y - x + p2;
+template <int ARITH>
+__device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, const Tw64 w, const Mod &k) {
+  const u64 s = csub<u64>(x + y, k.p2);
+  const u64 d = y - x + k.p2;
   x = s;
-  y = mul_shoup_lazy<u64>(d, w.w, w.wp, p);
+  y = ARITH == 0 ? mul_shoup_lazy<u64>(d, w.w, w.wp, k.p) : shoup_acc(d, w, 0, k);
+}
+// any 64-bit word (ARITH 1) or [0,4p) (ARITH 0) -> [0,p)
+template <int ARITH> __device__ __forceinline__ u64 canon(u64 x, const Mod &k) {
+  if (ARITH == 1) x = (x & 0x7fffffffffffffffull) + (u64)(u32)(x >> 63) * k.d2;  // < 2p + 4*delta
+  x = csub<u64>(x, k.p2);
+  return csub<u64>(x, k.p);
 }
 
 // radix-16 register passes; TW(s, g) yields the twiddle of sub-stage s (0..3), group g
-template <class TW> __device__ __forceinline__ void ct16(u64 (&v)[16], TW tw, const u64 p, const u64 p2) {
+template <int ARITH, class TW> __device__ __forceinline__ void ct16(u64 (&v)[16], TW tw, const Mod &k) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int half = 8 >> s;
@@ -65,11 +116,11 @@ template <class TW> __device__ __forceinline__ void ct16(u64 (&v)[16], TW tw, co
     for (int g = 0; g < (1 << s); ++g) {
       const Tw64 w = tw(s, g);
 #pragma unroll
-      for (int h = 0; h < half; ++h) ct_bfly(v[g * 2 * half + h], v[g * 2 * half + h + half], w, p, p2);
+      for (int h = 0; h < half; ++h) ct_bfly<ARITH>(v[g * 2 * half + h], v[g * 2 * half + h + half], w, k);
     }
   }
 }
-template <class TW> __device__ __forceinline__ void gs16(u64 (&v)[16], TW tw, const u64 p, const u64 p2) {
+template <int ARITH, class TW> __device__ __forceinline__ void gs16(u64 (&v)[16], TW tw, const Mod &k) {
 #pragma unroll
   for (int s = 3; s >= 0; --s) {
     const int half = 8 >> s;
@@ -77,17 +128,18 @@ template <class TW> __device__ __forceinline__ void gs16(u64 (&v)[16], TW tw, co
     for (int g = 0; g < (1 << s); ++g) {
       const Tw64 w = tw(s, g);
 #pragma unroll
-      for (int h = 0; h < half; ++h) gs_bfly(v[g * 2 * half + h], v[g * 2 * half + h + half], w, p, p2);
+      for (int h = 0; h < half; ++h) gs_bfly<ARITH>(v[g * 2 * half + h], v[g * 2 * half + h + half], w, k);
     }
   }
 }
 
 // ---- forward transform of the 16 words a thread loaded as x[t + 256k] ---------------
 // On return thread q = t holds X[16q + k] (bit-reversed order positions), lazy in [0,4p).
-__device__ __forceinline__ void fwd_core(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const u64 p, const u64 p2,
-                                         const int t, const bool war_barrier) {
+template <int ARITH>
+__device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const Mod &k, const int t,
+                                         const bool war_barrier) {
   // F1: stages 0-3, block index of sub-stage s is the group g: psi[2^s + g] (wave-uniform)
-  ct16(v, [&](int s, int g) { return tw[(1 << s) + g]; }, p, p2);
+  ct16<ARITH>(v, [&](int s, int g) { return tw[(1 << s) + g]; }, k);
   if (war_barrier) __syncthreads();  // the slab may still be read by slower waves (previous transform)
   {
     const int base = t + (t >> 4);
@@ -102,7 +154,7 @@ __device__ __forceinline__ void fwd_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 17 * k];
   }
   // F2: stages 4-7 inside 256-word block B: psi[2^(4+s) + B*2^s + g]
-  ct16(v, [&](int s, int g) { return tw[(16 << s) + (B << s) + g]; }, p, p2);
+  ct16<ARITH>(v, [&](int s, int g) { return tw[(16 << s) + (B << s) + g]; }, k);
   // E2: 16-lane transpose through this wave's own LDS region (LDS is in-order per wave)
   {
     const int base = 272 * B + r;
@@ -117,16 +169,27 @@ __device__ __forceinline__ void fwd_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = sm[base + k];
   }
-  // F3: stages 8-11 inside 16-word block q = t: psi[2^(8+s) + q*2^s + g]
-  ct16(v, [&](int s, int g) { return tw[(256 << s) + (t << s) + g]; }, p, p2);
+}
+// F3: stages 8-11 inside 16-word block q = t: psi[2^(8+s) + q*2^s + g]
+template <int ARITH>
+__device__ __forceinline__ void fwd_tail(u64 (&v)[16], const Tw64 *__restrict__ tw, const Mod &k, const int t) {
+  ct16<ARITH>(v, [&](int s, int g) { return tw[(256 << s) + (t << s) + g]; }, k);
+}
+template <int ARITH>
+__device__ __forceinline__ void fwd_core(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const Mod &k, const int t,
+                                         const bool war_barrier) {
+  fwd_head<ARITH>(v, sm, tw, k, t, war_barrier);
+  fwd_tail<ARITH>(v, tw, k, t);
 }
 
 // ---- inverse transform of the 16 words a thread holds as X[16q + k], in [0,2p) -------
 // On return thread t holds x[t + 256k], canonical in [0,p).
-__device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const MC64 &c, const int t) {
+template <int ARITH>
+__device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const MC64 &c, const Mod &k,
+                                         const int t) {
   const u64 p = c.p, p2 = c.p2;
   // I1: stages 11..8; mirrored index 2m-1-j with m = 2^(8+s), j = q*2^s + g
-  gs16(v, [&](int s, int g) { return tw[(512 << s) - 1 - ((t << s) + g)]; }, p, p2);
+  gs16<ARITH>(v, [&](int s, int g) { return tw[(512 << s) - 1 - ((t << s) + g)]; }, k);
   const int B = t >> 4, r = t & 15;
   {
     const int base = 17 * t;
@@ -142,7 +205,7 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 17 * k];
   }
   // I2: stages 7..4; m = 2^(4+s), j = B*2^s + g
-  gs16(v, [&](int s, int g) { return tw[(32 << s) - 1 - ((B << s) + g)]; }, p, p2);
+  gs16<ARITH>(v, [&](int s, int g) { return tw[(32 << s) - 1 - ((B << s) + g)]; }, k);
   {
     const int base = 272 * B + r;
 #pragma unroll
@@ -162,80 +225,106 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int g = 0; g < (1 << s); ++g) {
       const Tw64 w = tw[(2 << s) - 1 - g];
 #pragma unroll
-      for (int h = 0; h < half; ++h) gs_bfly(v[g * 2 * half + h], v[g * 2 * half + h + half], w, p, p2);
+      for (int h = 0; h < half; ++h) gs_bfly<ARITH>(v[g * 2 * half + h], v[g * 2 * half + h + half], w, k);
     }
   }
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
     const u64 x = v[h], y = v[h + 8];
-    v[h] = mul_shoup<u64>(x + y, c.ninv, c.ninv_sh, p);
-    v[h + 8] = mul_shoup<u64>(y - x + p2, c.w1ninv, c.w1ninv_sh, p);
+    if (ARITH == 0) {
+      v[h] = mul_shoup<u64>(x + y, c.ninv, c.ninv_sh, p);
+      v[h + 8] = mul_shoup<u64>(y - x + p2, c.w1ninv, c.w1ninv_sh, p);
+    } else {
+      v[h] = csub<u64>(shoup_acc(x + y, Tw64{c.ninv, c.ninv_sh}, 0, k), p);
+      v[h + 8] = csub<u64>(shoup_acc(y - x + p2, Tw64{c.w1ninv, c.w1ninv_sh}, 0, k), p);
+    }
   }
 }
 
 // ---- the metric kernel: c = INTT( NTT(a) (.) NTT(b) ), one row per workgroup ---------
-template <bool B_IS_NTT>
-__global__ __launch_bounds__(kThreads) void k_polymul4096(u64 *c, const u64 *a, const u64 *b,
-                                                          const Tw64 *__restrict__ psi, const MC64 *__restrict__ mc,
-                                                          int nm) {
-  __shared__ u64 sm[kLdsWords];
+__device__ __forceinline__ Mod make_mod(const MC64 &c) {
+  Mod k;
+  k.p = c.p;
+  k.p2 = c.p2;
+  k.d = (u32)c.delta;
+  k.d2 = 2u * (u32)c.delta;
+  return k;
+}
+
+template <bool B_IS_NTT, int ARITH>
+__device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, const u64 *b, const Tw64 *__restrict__ psi,
+                                             const MC64 *__restrict__ mc, int nm) {
   const int t = threadIdx.x;
   const size_t row = blockIdx.x;
   const int cm = (int)(row % (size_t)nm);
   const MC64 mcc = mc[cm];
-  const u64 p = mcc.p, p2 = mcc.p2;
+  const Mod k = make_mod(mcc);
   const Tw64 *tw = psi + ((size_t)cm << kLogN);
   const size_t off = row << kLogN;
 
   u64 va[16], vb[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) va[k] = a[off + t + 256 * k];
+  for (int i = 0; i < 16; ++i) va[i] = a[off + t + 256 * i];
+  fwd_head<ARITH>(va, sm, tw, k, t, false);
+  // b's HBM loads are issued here so their latency hides under F3(a) without
+  // holding 32 more VGPRs through the first two passes
+  asm volatile("" ::: "memory");
   if (!B_IS_NTT) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) vb[k] = b[off + t + 256 * k];
+    for (int i = 0; i < 16; ++i) vb[i] = b[off + t + 256 * i];
   } else {
     // b already in NTT form: thread q needs B[16q + k]
     const ulonglong2 *b2 = reinterpret_cast<const ulonglong2 *>(b + off + 16 * t);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const ulonglong2 x = b2[k];
-      vb[2 * k] = x.x;
-      vb[2 * k + 1] = x.y;
+    for (int i = 0; i < 8; ++i) {
+      const ulonglong2 x = b2[i];
+      vb[2 * i] = x.x;
+      vb[2 * i + 1] = x.y;
     }
   }
-  fwd_core(va, sm, tw, p, p2, t, false);
-  if (!B_IS_NTT) fwd_core(vb, sm, tw, p, p2, t, true);
+  asm volatile("" ::: "memory");
+  fwd_tail<ARITH>(va, tw, k, t);
+  if (!B_IS_NTT) fwd_core<ARITH>(vb, sm, tw, k, t, true);
   // point-wise product on canonical representatives (operator*, ops.hpp:201-219)
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const u64 x = reduce4<u64>(va[k], p);
-    const u64 y = B_IS_NTT ? vb[k] : reduce4<u64>(vb[k], p);
-    va[k] = barrett<u64>::mul(x, y, p, mcc.mu);
+  for (int i = 0; i < 16; ++i) {
+    const u64 x = canon<ARITH>(va[i], k);
+    const u64 y = B_IS_NTT ? vb[i] : canon<ARITH>(vb[i], k);
+    va[i] = barrett<u64>::mul(x, y, k.p, mcc.mu);
   }
-  inv_core(va, sm, tw, mcc, t);
+  inv_core<ARITH>(va, sm, tw, mcc, k, t);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) c[off + t + 256 * k] = va[k];
+  for (int i = 0; i < 16; ++i) c[off + t + 256 * i] = va[i];
+}
+
+template <bool B_IS_NTT, int ARITH, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_polymul4096(u64 *c, const u64 *a, const u64 *b,
+                                                                const Tw64 *__restrict__ psi,
+                                                                const MC64 *__restrict__ mc, int nm) {
+  __shared__ u64 sm[kLdsWords];
+  polymul_body<B_IS_NTT, ARITH>(sm, c, a, b, psi, mc, nm);
 }
 
 // ---- stand-alone transforms (in place or out of place) --------------------------------
+template <int ARITH>
 __global__ __launch_bounds__(kThreads) void k_ntt_fwd4096(const u64 *src, u64 *dst, const Tw64 *__restrict__ psi,
                                                           const MC64 *__restrict__ mc, int nm) {
   __shared__ u64 sm[kLdsWords];
   const int t = threadIdx.x;
   const size_t row = blockIdx.x;
   const int cm = (int)(row % (size_t)nm);
-  const u64 p = mc[cm].p, p2 = mc[cm].p2;
+  const Mod k = make_mod(mc[cm]);
   const Tw64 *tw = psi + ((size_t)cm << kLogN);
   const size_t off = row << kLogN;
   u64 v[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = src[off + t + 256 * k];
-  fwd_core(v, sm, tw, p, p2, t, false);
+  for (int i = 0; i < 16; ++i) v[i] = src[off + t + 256 * i];
+  fwd_core<ARITH>(v, sm, tw, k, t, false);
   // thread q holds X[16q+k]: transpose inside the wave's LDS region for coalesced stores
   {
     const int base = 17 * t;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sm[base + k] = reduce4<u64>(v[k], p);
+    for (int i = 0; i < 16; ++i) sm[base + i] = canon<ARITH>(v[i], k);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -248,6 +337,7 @@ __global__ __launch_bounds__(kThreads) void k_ntt_fwd4096(const u64 *src, u64 *d
   }
 }
 
+template <int ARITH>
 __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, u64 *dst, const Tw64 *__restrict__ psi,
                                                           const MC64 *__restrict__ mc, int nm) {
   __shared__ u64 sm[kLdsWords];
@@ -255,6 +345,7 @@ __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, u64 *d
   const size_t row = blockIdx.x;
   const int cm = (int)(row % (size_t)nm);
   const MC64 mcc = mc[cm];
+  const Mod k = make_mod(mcc);
   const Tw64 *tw = psi + ((size_t)cm << kLogN);
   const size_t off = row << kLogN;
   const int w = t >> 6, l = t & 63;
@@ -270,15 +361,52 @@ __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, u64 *d
   {
     const int base = 17 * t;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = sm[base + k];
+    for (int i = 0; i < 16; ++i) v[i] = sm[base + i];
   }
-  inv_core(v, sm, tw, mcc, t);
+  inv_core<ARITH>(v, sm, tw, mcc, k, t);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) dst[off + t + 256 * k] = v[k];
+  for (int i = 0; i < 16; ++i) dst[off + t + 256 * i] = v[i];
 }
 
 // ---- launchers --------------------------------------------------------------------------
+// The delta-form arithmetic needs 2*delta < 2^32; every prime of the mirrored table
+// qualifies (c <= 587), Shape::small_delta records it per context.
 static inline bool fast_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN; }
+
+// Experiment switch (tools/ and profiling only): NFLHIP_VARIANT="<arith><minw>", e.g. "12".
+static int variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("NFLHIP_VARIANT");
+    v = e ? atoi(e) : 12;
+  }
+  return v;
+}
+
+template <bool B_IS_NTT>
+static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
+                                   unsigned rows, hipStream_t st) {
+  const Tw64 *psi = (const Tw64 *)t.psi;
+  const MC64 *mc = (const MC64 *)t.mc;
+  const int nm = (int)s.nm;
+  int v = variant();
+  if (!s.small_delta) v = v % 10;  // arithmetic 0 only
+#define NFLHIP_LAUNCH(A, W)                                                                                         \
+  hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, A, W>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);     \
+  break;
+  switch (v) {
+    case 1: NFLHIP_LAUNCH(0, 1)
+    case 2: NFLHIP_LAUNCH(0, 2)
+    case 3: NFLHIP_LAUNCH(0, 3)
+    case 4: NFLHIP_LAUNCH(0, 4)
+    case 11: NFLHIP_LAUNCH(1, 1)
+    case 13: NFLHIP_LAUNCH(1, 3)
+    case 14: NFLHIP_LAUNCH(1, 4)
+    default: NFLHIP_LAUNCH(1, 2)
+  }
+#undef NFLHIP_LAUNCH
+  return hipGetLastError();
+}
 
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                    int b_is_ntt, size_t batch, hipStream_t st) {
@@ -286,13 +414,8 @@ hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t 
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  if (b_is_ntt)
-    hipLaunchKernelGGL((k_polymul4096<true>), dim3((unsigned)rows), dim3(kThreads), 0, st, c, a, b, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  else
-    hipLaunchKernelGGL((k_polymul4096<false>), dim3((unsigned)rows), dim3(kThreads), 0, st, c, a, b, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  return hipGetLastError();
+  return b_is_ntt ? launch_polymul_v<true>(s, t, c, a, b, (unsigned)rows, st)
+                  : launch_polymul_v<false>(s, t, c, a, b, (unsigned)rows, st);
 }
 
 hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
@@ -301,8 +424,12 @@ hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uin
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_ntt_fwd4096, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                     (const MC64 *)t.mc, (int)s.nm);
+  if (s.small_delta && variant() >= 10)
+    hipLaunchKernelGGL(k_ntt_fwd4096<1>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
+                       (const MC64 *)t.mc, (int)s.nm);
+  else
+    hipLaunchKernelGGL(k_ntt_fwd4096<0>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
+                       (const MC64 *)t.mc, (int)s.nm);
   return hipGetLastError();
 }
 
@@ -312,8 +439,12 @@ hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uin
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_ntt_inv4096, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                     (const MC64 *)t.mc, (int)s.nm);
+  if (s.small_delta && variant() >= 10)
+    hipLaunchKernelGGL(k_ntt_inv4096<1>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
+                       (const MC64 *)t.mc, (int)s.nm);
+  else
+    hipLaunchKernelGGL(k_ntt_inv4096<0>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
+                       (const MC64 *)t.mc, (int)s.nm);
   return hipGetLastError();
 }
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Experiment driver (GPU box): time kernel variants of the metric kernel and
+check that every variant produces the same words as variant 2 (the plain
+Harvey-range arithmetic).  One subprocess per variant because the variant is
+latched from the NFLHIP_VARIANT environment variable at first launch.
+
+  python tools/quick_bench.py 2 3 4 12 13 14 [--batch 16384] [--iters 10]
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(batch, iters, workload):
+    import torch
+    from nfllib_amd import Engine
+    from nfllib_amd.sharding import digest_words
+    lb, n, nm = {"B": (64, 4096, 4), "C": (64, 16384, 8), "E": (64, 65536, 30)}[workload]
+    e = Engine(lb, n, nm)
+    a = e.fill_uniform(e.empty(batch), 0x4E464C6C6962, 0)
+    b = e.fill_uniform(e.empty(batch), 0x4E464C6C6962, 1)
+    c = e.empty(batch)
+    for _ in range(3):
+        e.polymul(a, b, out=c)
+    torch.cuda.synchronize()
+    best = min(e.time_polymul(c, a, b, iters) for _ in range(3))
+    small = e.to_host(c[:64])
+    fa = e.ntt_(a[:64].clone())
+    rt = e.intt_(fa.clone())
+    ok = not e.any_neq(rt, a[:64].contiguous())
+    print(json.dumps({"ms": best, "polymul_per_s": batch / best * 1e3, "digest": digest_words(small),
+                      "ntt_digest": digest_words(e.to_host(fa)), "roundtrip_ok": ok}))
+
+
+def main():
+    if sys.argv[1] == "--child":
+        return child(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    batch = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--batch=")), 16384))
+    iters = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--iters=")), 10))
+    workload = next((a.split("=")[1] for a in sys.argv if a.startswith("--workload=")), "B")
+    ref = None
+    for v in args:
+        env = dict(os.environ, NFLHIP_VARIANT=v)
+        out = subprocess.run([sys.executable, __file__, "--child", str(batch), str(iters), workload], env=env,
+                             capture_output=True, text=True)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print("variant", v, "FAILED", out.stderr[-400:])
+            continue
+        r = json.loads(line[-1])
+        if ref is None:
+            ref = r
+        same = r["digest"] == ref["digest"] and r["ntt_digest"] == ref["ntt_digest"]
+        print("variant %4s  %8.3f ms  %10.0f polymul/s  %5.1f%% of 8TB/s  same_as_first=%s roundtrip=%s" % (
+            v, r["ms"], r["polymul_per_s"], r["polymul_per_s"] * 393216 / 8e12 * 100, same, r["roundtrip_ok"]))
+
+
+if __name__ == "__main__":
+    main()
