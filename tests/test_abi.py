@@ -1,0 +1,90 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nflhip.h declares;
+without a GPU it fails loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "nflhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nflhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from nfllib_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libnflhip.so does not export %s" % n
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert bound == set(names), (bound ^ set(names))
+    assert lib.nflhip_abi_version() == 1
+
+
+def test_no_torch_types_in_the_boundary():
+    txt = open(os.path.join(ROOT, "include", "nflhip.h")).read()
+    assert "torch" not in txt.lower() and "at::" not in txt and "#include <hip" not in txt
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_have_gpu(), reason="CPU-only behaviour")
+def test_fails_loudly_without_gpu():
+    from nfllib_amd import Engine, NflHipError
+    with pytest.raises(NflHipError) as ei:
+        Engine(64, 4096, 4)
+    assert ei.value.code == 2 and "no CPU fallback" in str(ei.value)
+
+
+def test_argument_validation_precedes_device_use():
+    from nfllib_amd import _lib
+    from nfllib_amd.params import params
+    lib = _lib.lib
+    pr = params(64)
+    h = C.c_void_p()
+    P, R, K = [np.ascontiguousarray(x[:4]) for x in (pr.P, pr.primitive_roots, pr.invkmax)]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    # degree not a power of two, bad limb width, NULL tables, degree > kMaxPolyDegree (core.hpp:59-60)
+    assert lib.nflhip_ctx_create(C.byref(h), 0, 64, 4095, 4, vp(P), vp(R), vp(K), pr.kmax_log2) == 1
+    assert lib.nflhip_ctx_create(C.byref(h), 0, 48, 4096, 4, vp(P), vp(R), vp(K), pr.kmax_log2) == 1
+    assert lib.nflhip_ctx_create(C.byref(h), 0, 64, 4096, 4, None, vp(R), vp(K), pr.kmax_log2) == 1
+    assert lib.nflhip_ctx_create(C.byref(h), 0, 64, 1 << 21, 4, vp(P), vp(R), vp(K), pr.kmax_log2) == 1
+    assert b"kMaxPolyDegree" in lib.nflhip_last_error(None)
+    assert lib.nflhip_ntt_fwd_dev(None, None, 1, None) == 1  # NULL ctx
+
+
+def test_params_mirror_is_consistent():
+    from nfllib_amd.params import params
+    for lb in (16, 32, 64):
+        pr = params(lb)
+        for j in range(pr.max_moduli):
+            p, r = int(pr.P[j]), int(pr.primitive_roots[j])
+            assert p % (2 * pr.kmax) == 1 and p.bit_length() == pr.modulus_bits
+            assert pow(r, pr.kmax, p) == p - 1
+            assert int(pr.invkmax[j]) * pr.kmax % p == 1
+            assert int(pr.Pn[j]) == ((1 << (2 * lb)) // p) % (1 << lb)
+    hdr = open(os.path.join(ROOT, "include", "nflhip_params.h")).read()
+    assert str(int(params(64).P[0])) in hdr and str(int(params(32).primitive_roots[3])) in hdr
+
+
+def test_product_path_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under nfllib_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("nfllib_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"nfl_oracle|from oracle|import oracle|oracle/", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

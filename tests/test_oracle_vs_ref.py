@@ -1,0 +1,55 @@
+"""CPU, build container only: oracle/nfl_oracle.c against the REAL reference
+(oracle/_ref/libnflref.so) bit-for-bit, on fresh seeds (not the fixture seed)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (no /root/reference here)")
+
+SHAPES = [(16, 128, 1), (32, 8, 2), (32, 1024, 1), (32, 1024, 2), (64, 8, 2), (64, 64, 3), (64, 1024, 2), (64, 4096, 4),
+          (64, 8192, 2), (64, 16384, 8), (64, 32768, 2)]
+
+
+@pytest.mark.parametrize("lb,n,m", SHAPES)
+def test_oracle_equals_real_reference(lb, n, m, oracle_factory):
+    o, r = oracle_factory(lb, n, m), O.Reference(lb, n, m)
+    for which in range(7):
+        for cm in range(m):
+            assert np.array_equal(o.table(which, cm), r.table(which, cm)), (which, cm)
+    for seed in (11, 12):
+        a, b = o.fill_uniform(2, seed, 0), o.fill_uniform(2, seed, 1)
+        assert np.array_equal(o.ntt(a), r.ntt(a))
+        assert np.array_equal(o.intt(a), r.intt(a))
+        for op in (O.OP_ADD, O.OP_SUB, O.OP_MUL):
+            assert np.array_equal(o.pointwise(op, a, b), r.pointwise(op, a, b)), op
+        bp = o.pointwise(O.OP_COMPUTE_SHOUP, b)
+        assert np.array_equal(bp, r.pointwise(O.OP_COMPUTE_SHOUP, b))
+        assert np.array_equal(o.pointwise(O.OP_MUL_SHOUP, a, b, bp), r.pointwise(O.OP_MUL_SHOUP, a, b, bp))
+        assert np.array_equal(o.polymul(a, b), r.polymul(a, b))
+        # the cyclic core alone, both table sets (core::ntt through the friend proxy, poly.hpp:69-76)
+        row = a[0, 0]
+        assert np.array_equal(o.ntt_row(row, 0), r.ntt_row(row, 0))
+        assert np.array_equal(o.ntt_row(row, 0, True), r.ntt_row(row, 0, True))
+        assert o.any_eq(a[0], b[0]) == r.any_eq(a[0], b[0]) and o.any_neq(a[0], a[0]) == r.any_neq(a[0], a[0])
+    assert o.crt_bits == r.crt_bits and o.crt_shift == r.crt_shift
+    assert o.crt_modulus() == r.crt_modulus() and o.crt_modulus_shoup() == r.crt_modulus_shoup()
+    assert all(o.crt_lifting(c) == r.crt_lifting(c) for c in range(m))
+    a = o.fill_uniform(1, 13, 0)
+    assert np.array_equal(o.crt_lift(a), r.crt_lift(a, o.crt_limbs))
+
+
+def test_cpu_port_not_slower_than_reference(oracle_factory):
+    """The same-run CPU baseline must not be sand-bagged: the port's polymul
+    time is within 25% of the real reference's on the metric shape."""
+    import time
+    o, r = oracle_factory(64, 4096, 4), O.Reference(64, 4096, 4)
+    a, b = o.fill_uniform(16, 1, 0), o.fill_uniform(16, 1, 1)
+
+    def best(fn):
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); fn(a, b); ts.append(time.perf_counter() - t0)
+        return min(ts)
+    tp, tr = best(o.polymul), best(r.polymul)
+    assert tp < 1.25 * tr, (tp, tr)
