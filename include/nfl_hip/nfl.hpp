@@ -1,0 +1,454 @@
+// nfl_hip/nfl.hpp -- header-only host surface of the MI355X NTT polynomial-ring engine.
+//
+// Keeps the template surface of the reference's nfl::poly<T, Degree, NbModuli>
+// (include/nfl/poly.hpp:82-352) and its expression-template operators
+// (include/nfl/ops.hpp:18-97, 249-277) so existing callers compile unchanged,
+// but every whole-polynomial operation is forwarded through the C ABI of
+// include/nflhip.h to hand-written HIP kernels.  There is no CPU arithmetic in
+// this header: without libnflhip.so + a GPU every operation throws
+// std::runtime_error (the reference's error convention: core.hpp:111-115).
+//
+// What is kept (same names, argument meaning, error behaviour):
+//   storage layout T _data[NbModuli*Degree], 32-byte aligned, modulus-major  poly.hpp:87-88,156-157
+//   ctors / set(): value, initializer_list, iterator range (+reduce_coeffs)   core.hpp:64-137
+//   operator()(cm,i), begin/end, data(), get_modulus, degree/nmoduli/nbits    poly.hpp:142-162
+//   ntt_pow_phi(), invntt_pow_invphi()                                        poly.hpp:167-168
+//   operator+ - * == !=, shoup(a*b,b'), compute_shoup(b), nested expressions  poly.hpp:346-352
+//   explicit operator bool on polys and on == / != expressions                core.hpp:39-43, ops.hpp:81-95
+//   serialize_manually / deserialize_manually                                 poly.hpp:180-185
+//   nfl::add / sub / mul                                                      poly.hpp:314-332
+// What differs, on purpose:
+//   * tables live in a lazily created per-(T,Degree,NbModuli) device context,
+//     never at static-init time (the reference's `static core base`, poly.hpp:247);
+//   * CRT lift/project exchange little-endian 64-bit limb vectors
+//     (poly2limbs / limbs2poly == the mpz_export/mpz_import image of
+//     poly2mpz / mpz2poly, gmp.hpp:183-219); GMP-typed overloads are available
+//     when NFL_HIP_WITH_GMP is defined before inclusion;
+//   * nfl::batch::* operate on contiguous arrays of polys (dense
+//     [batch][NbModuli][Degree], as tests/tools.h:6-17 allocates) in ONE device
+//     pass -- the per-poly members stay for source compatibility;
+//   * nfl::uniform is a seeded counter-based generator with the reference's
+//     mask-then-subtract rule (core.hpp:165-176), not a CSPRNG.
+#ifndef NFL_HIP_NFL_HPP
+#define NFL_HIP_NFL_HPP
+
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <initializer_list>
+#include <iostream>
+#include <iterator>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <vector>
+
+#include "../nflhip.h"
+#include "../nflhip_params.h"
+
+#ifdef NFL_HIP_WITH_GMP
+#include <gmp.h>
+#endif
+
+namespace nfl {
+
+// ---------------------------------------------------------------- params<T> (params.hpp:11-119)
+template <class T> struct params;
+template <> struct params<uint16_t> {
+  typedef uint16_t value_type;
+  typedef int16_t signed_value_type;
+  typedef uint32_t greater_value_type;
+  static constexpr unsigned int kMaxNbModuli = NFLHIP_U16_NMODULI;
+  static constexpr unsigned int kModulusBitsize = NFLHIP_U16_MODULUS_BITS;
+  static constexpr unsigned int kModulusRepresentationBitsize = 16;
+  static constexpr unsigned int kMaxPolyDegree = 1u << NFLHIP_U16_KMAX_LOG2;
+  static constexpr int kMaxLog2 = NFLHIP_U16_KMAX_LOG2;
+  static const value_type *P() { return NFLHIP_U16_P; }
+  static const value_type *roots() { return NFLHIP_U16_ROOTS; }
+  static const value_type *invkmax() { return NFLHIP_U16_INVKMAX; }
+};
+template <> struct params<uint32_t> {
+  typedef uint32_t value_type;
+  typedef int32_t signed_value_type;
+  typedef uint64_t greater_value_type;
+  static constexpr unsigned int kMaxNbModuli = NFLHIP_U32_NMODULI;
+  static constexpr unsigned int kModulusBitsize = NFLHIP_U32_MODULUS_BITS;
+  static constexpr unsigned int kModulusRepresentationBitsize = 32;
+  static constexpr unsigned int kMaxPolyDegree = 1u << NFLHIP_U32_KMAX_LOG2;
+  static constexpr int kMaxLog2 = NFLHIP_U32_KMAX_LOG2;
+  static const value_type *P() { return NFLHIP_U32_P; }
+  static const value_type *roots() { return NFLHIP_U32_ROOTS; }
+  static const value_type *invkmax() { return NFLHIP_U32_INVKMAX; }
+};
+template <> struct params<uint64_t> {
+  typedef uint64_t value_type;
+  typedef int64_t signed_value_type;
+  typedef unsigned __int128 greater_value_type;
+  static constexpr unsigned int kMaxNbModuli = NFLHIP_U64_NMODULI;
+  static constexpr unsigned int kModulusBitsize = NFLHIP_U64_MODULUS_BITS;
+  static constexpr unsigned int kModulusRepresentationBitsize = 64;
+  static constexpr unsigned int kMaxPolyDegree = 1u << NFLHIP_U64_KMAX_LOG2;
+  static constexpr int kMaxLog2 = NFLHIP_U64_KMAX_LOG2;
+  static const value_type *P() { return NFLHIP_U64_P; }
+  static const value_type *roots() { return NFLHIP_U64_ROOTS; }
+  static const value_type *invkmax() { return NFLHIP_U64_INVKMAX; }
+};
+
+// seeded stand-in for the reference's sampler tag (poly.hpp:42)
+struct uniform {
+  uint64_t seed;
+  explicit uniform(uint64_t s = 0x4E464C6C6962ull) : seed(s) {}
+};
+
+namespace detail {
+
+inline void check(nflhip_ctx *ctx, int rc, const char *what) {
+  if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): ") + what + ": " + nflhip_last_error(ctx));
+}
+
+// One device context per (T, Degree, NbModuli): the replacement of the
+// reference's static `core base` / `GMP gmp` members (poly.hpp:247, 275), created
+// on first use (function-local static => thread-safe, never before main()).
+template <class T, size_t Degree, size_t NbModuli> struct context {
+  nflhip_ctx *ctx;
+  context() : ctx(nullptr) {
+    static_assert(NbModuli <= params<T>::kMaxNbModuli, "not enough moduli of this size (see nflhip_params.h)");
+    static_assert(Degree <= params<T>::kMaxPolyDegree, "degree is not lower or equal than kMaxPolyDegree");
+    int rc = nflhip_ctx_create(&ctx, 0, int(sizeof(T) * 8), Degree, NbModuli, params<T>::P(), params<T>::roots(),
+                               params<T>::invkmax(), params<T>::kMaxLog2);
+    if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): context: ") + nflhip_last_error(nullptr));
+  }
+  ~context() { nflhip_ctx_destroy(ctx); }
+  context(const context &) = delete;
+  context &operator=(const context &) = delete;
+  static nflhip_ctx *get() {
+    static context c;
+    return c.ctx;
+  }
+};
+
+inline uint64_t splitmix64_at(uint64_t seed, int operand, uint64_t g) {
+  uint64_t z = (seed ^ (uint64_t(operand) << 62)) + (g + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+}  // namespace detail
+
+template <class T, size_t Degree, size_t NbModuli> class poly;
+
+// ---------------------------------------------------------------- expression templates (ops.hpp:52-97)
+namespace ops {
+
+struct addmod { static constexpr int code = NFLHIP_OP_ADD; };
+struct submod { static constexpr int code = NFLHIP_OP_SUB; };
+struct mulmod { static constexpr int code = NFLHIP_OP_MUL; };
+struct mulmod_shoup { static constexpr int code = NFLHIP_OP_MUL_SHOUP; };
+struct compute_shoup { static constexpr int code = NFLHIP_OP_COMPUTE_SHOUP; };
+struct eqmod {};
+struct neqmod {};
+struct shoup_marker {};
+
+template <class Op, class... Args> struct expr;
+
+template <class Op, class... Args> struct expr {
+  std::tuple<Args const &...> args;
+  explicit expr(Args const &... a) : args(a...) {}
+  typedef typename std::remove_cv<typename std::remove_reference<
+      decltype(std::get<0>(std::declval<std::tuple<Args const &...>>()))>::type>::type first_type;
+  typedef typename first_type::value_type value_type;
+  typedef typename first_type::poly_type poly_type;
+  static constexpr size_t degree = first_type::degree;
+  static constexpr size_t nmoduli = first_type::nmoduli;
+
+  // evaluate this node into `out` (one device pass per node; children first)
+  void eval(poly_type &out) const { eval_impl(out, std::integral_constant<size_t, sizeof...(Args)>()); }
+
+  // expr::operator bool (ops.hpp:81-95): true as soon as ONE lane of the value is non-zero
+  explicit operator bool() const { return truth(Op()); }
+
+ private:
+  template <class A> static const poly_type &materialise(const A &a, poly_type &tmp, std::true_type) { (void)tmp; return a; }
+  template <class A> static const poly_type &materialise(const A &a, poly_type &tmp, std::false_type) {
+    a.eval(tmp);
+    return tmp;
+  }
+  template <class A> static const poly_type &mat(const A &a, poly_type &tmp) {
+    return materialise(a, tmp, std::is_same<A, poly_type>());
+  }
+  void eval_impl(poly_type &out, std::integral_constant<size_t, 1>) const {
+    poly_type *t0 = poly_type::make_temp();
+    const poly_type &a = mat(std::get<0>(args), *t0);
+    out.apply(Op::code, a, a, a);
+    poly_type::drop_temp(t0);
+  }
+  void eval_impl(poly_type &out, std::integral_constant<size_t, 2>) const {
+    poly_type *t0 = poly_type::make_temp(), *t1 = poly_type::make_temp();
+    const poly_type &a = mat(std::get<0>(args), *t0);
+    const poly_type &b = mat(std::get<1>(args), *t1);
+    out.apply(Op::code, a, b, b);
+    poly_type::drop_temp(t0);
+    poly_type::drop_temp(t1);
+  }
+  void eval_impl(poly_type &out, std::integral_constant<size_t, 3>) const {
+    poly_type *t0 = poly_type::make_temp(), *t1 = poly_type::make_temp(), *t2 = poly_type::make_temp();
+    const poly_type &a = mat(std::get<0>(args), *t0);
+    const poly_type &b = mat(std::get<1>(args), *t1);
+    const poly_type &c = mat(std::get<2>(args), *t2);
+    out.apply(Op::code, a, b, c);
+    poly_type::drop_temp(t0);
+    poly_type::drop_temp(t1);
+    poly_type::drop_temp(t2);
+  }
+  template <class O> bool truth(O) const {  // arithmetic expression: any non-zero word
+    poly_type *t = poly_type::make_temp();
+    eval(*t);
+    const bool r = bool(*t);
+    poly_type::drop_temp(t);
+    return r;
+  }
+  bool cmp(bool want_eq) const {
+    poly_type *t0 = poly_type::make_temp(), *t1 = poly_type::make_temp();
+    const poly_type &a = mat(std::get<0>(args), *t0);
+    const poly_type &b = mat(std::get<1>(args), *t1);
+    const bool r = poly_type::any_cmp(a, b, want_eq);
+    poly_type::drop_temp(t0);
+    poly_type::drop_temp(t1);
+    return r;
+  }
+  bool truth(eqmod) const { return cmp(true); }    // "any lane equal"  (the reference's quirk)
+  bool truth(neqmod) const { return cmp(false); }  // "any lane differs"
+};
+
+}  // namespace ops
+
+// ---------------------------------------------------------------- poly (poly.hpp:82-310)
+template <class T, size_t Degree, size_t NbModuli> class poly {
+  static constexpr size_t N = Degree * NbModuli;
+  T _data[N] __attribute__((aligned(32)));
+
+ public:
+  typedef typename params<T>::value_type value_type;
+  typedef typename params<T>::greater_value_type greater_value_type;
+  typedef typename params<T>::signed_value_type signed_value_type;
+  typedef T *pointer_type;
+  typedef T const *const_pointer_type;
+  typedef pointer_type iterator;
+  typedef const_pointer_type const_iterator;
+  typedef poly poly_type;
+  static constexpr size_t degree = Degree;
+  static constexpr size_t nmoduli = NbModuli;
+  static constexpr size_t nbits = params<T>::kModulusBitsize;
+  static constexpr size_t aggregated_modulus_bit_size = NbModuli * nbits;
+
+  /* constructors (core.hpp:64-84) */
+  poly() { set(value_type(0)); }
+  poly(uniform const &u) { set(u); }
+  poly(value_type v, bool reduce_coeffs = true) { set(v, reduce_coeffs); }
+  poly(std::initializer_list<value_type> values, bool reduce_coeffs = true) { set(values, reduce_coeffs); }
+  template <class It> poly(It first, It last, bool reduce_coeffs = true) { set(first, last, reduce_coeffs); }
+  template <class Op, class... Args> poly(ops::expr<Op, Args...> const &e) { *this = e; }
+
+  void set(value_type v, bool reduce_coeffs = true) {
+    if (v == 0) std::fill(begin(), end(), value_type(0));
+    else set({v}, reduce_coeffs);
+  }
+  void set(std::initializer_list<value_type> values, bool reduce_coeffs = true) { set(values.begin(), values.end(), reduce_coeffs); }
+  // same contract as core.hpp:101-137: fewer than `degree` values are zero-padded and
+  // replicated across moduli; otherwise exactly degree*nmoduli values are required
+  template <class It> void set(It first, It last, bool reduce_coeffs = true) {
+    const size_t size = size_t(std::distance(first, last));
+    if (size > degree && size != degree * nmoduli)
+      throw std::runtime_error("core: CRITICAL, initializer of size above degree but not equal to nmoduli*degree");
+    T *iter = begin();
+    It viter = first;
+    for (size_t cm = 0; cm < nmoduli; cm++) {
+      const value_type p = get_modulus(cm);
+      if (size != degree * nmoduli) viter = first;
+      size_t i = 0;
+      for (; i < degree && viter != last; ++i, ++viter, ++iter) *iter = reduce_coeffs ? value_type((*viter) % p) : value_type(*viter);
+      for (; i < degree; ++i, ++iter) *iter = 0;
+    }
+  }
+  // mask-then-subtract rule of core.hpp:165-176 on a seeded counter stream
+  void set(uniform const &u) {
+    for (size_t cm = 0; cm < nmoduli; cm++) {
+      const uint64_t p = get_modulus(cm);
+      int bits = 0;  // floor(log2 p) + 1 (core.hpp:165-166)
+      while (bits < 63 && (uint64_t(1) << bits) <= p) ++bits;
+      const uint64_t mask = (uint64_t(1) << bits) - 1;
+      for (size_t i = 0; i < degree; i++) {
+        uint64_t v = detail::splitmix64_at(u.seed, 0, cm * degree + i) & mask;
+        if (v >= p) v -= p;
+        _data[cm * degree + i] = T(v);
+      }
+    }
+  }
+
+  poly &operator=(value_type v) { set(v); return *this; }
+  poly &operator=(uniform const &u) { set(u); return *this; }
+  poly &operator=(std::initializer_list<value_type> values) { set(values); return *this; }
+  // THE evaluation point of an expression tree (core.hpp:24-37)
+  template <class Op, class... Args> poly &operator=(ops::expr<Op, Args...> const &e) {
+    e.eval(*this);
+    return *this;
+  }
+
+  explicit operator bool() const {  // core.hpp:39-43
+    return std::find_if(begin(), end(), [](value_type v) { return v != 0; }) != end();
+  }
+
+  iterator begin() { return _data; }
+  iterator end() { return _data + N; }
+  const_iterator begin() const { return _data; }
+  const_iterator end() const { return _data + N; }
+  const_iterator cbegin() const { return _data; }
+  const_iterator cend() const { return _data + N; }
+  value_type const &operator()(size_t cm, size_t i) const { return _data[cm * degree + i]; }
+  value_type &operator()(size_t cm, size_t i) { return _data[cm * degree + i]; }
+  pointer_type data() { return _data; }
+  const_pointer_type cdata() const { return _data; }
+  static value_type get_modulus(size_t n) { return params<T>::P()[n]; }
+
+  /* ntt stuff - public API (poly.hpp:167-168) */
+  void ntt_pow_phi() { detail::check(ctx(), nflhip_ntt_fwd(ctx(), _data, 1), "ntt_pow_phi"); }
+  void invntt_pow_invphi() { detail::check(ctx(), nflhip_ntt_inv(ctx(), _data, 1), "invntt_pow_invphi"); }
+
+  /* manual serializers (poly.hpp:180-185): raw little-endian words */
+  void serialize_manually(std::ostream &os) { os.write(reinterpret_cast<char *>(_data), N * sizeof(T)); }
+  void deserialize_manually(std::istream &is) { is.read(reinterpret_cast<char *>(_data), N * sizeof(T)); }
+
+  /* CRT (gmp.hpp:183-219) on little-endian 64-bit limb vectors */
+  static size_t crt_limbs() { return nflhip_crt_limbs(ctx()); }
+  // out[i*L .. i*L+L) = limbs of X_i in [0, Q): the mpz_export image of poly2mpz()
+  void poly2limbs(std::vector<uint64_t> &out) const {
+    out.assign(degree * crt_limbs(), 0);
+    detail::check(ctx(), nflhip_crt_lift(ctx(), out.data(), _data, 1), "poly2mpz");
+  }
+  // mpz2poly: x(cm,i) = X_i mod p_cm for non-negative X_i given as L_in limbs each
+  void limbs2poly(const uint64_t *limbs, size_t L_in) {
+    detail::check(ctx(), nflhip_crt_project(ctx(), _data, limbs, L_in, 1), "mpz2poly");
+  }
+#ifdef NFL_HIP_WITH_GMP
+  void poly2mpz(std::array<mpz_t, Degree> &rop) const {
+    std::vector<uint64_t> limbs;
+    poly2limbs(limbs);
+    const size_t L = crt_limbs();
+    for (size_t i = 0; i < degree; i++) mpz_import(rop[i], L, -1, sizeof(uint64_t), 0, 0, limbs.data() + i * L);
+  }
+  void mpz2poly(std::array<mpz_t, Degree> const &v) {
+    size_t L = 1;
+    for (size_t i = 0; i < degree; i++) L = std::max(L, (mpz_sizeinbase(v[i], 2) + 63) / 64);
+    std::vector<uint64_t> limbs(degree * L, 0);
+    for (size_t i = 0; i < degree; i++) {
+      if (mpz_sgn(v[i]) < 0) throw std::runtime_error("gmp: negative coefficient");
+      mpz_export(limbs.data() + i * L, nullptr, -1, sizeof(uint64_t), 0, 0, v[i]);
+    }
+    limbs2poly(limbs.data(), L);
+  }
+#endif
+
+  // ---- plumbing used by the expression templates (not part of the reference surface) ----
+  static nflhip_ctx *ctx() { return detail::context<T, Degree, NbModuli>::get(); }
+  void apply(int op, const poly &a, const poly &b, const poly &bp) {
+    detail::check(ctx(), nflhip_pointwise(ctx(), op, _data, a._data, b._data, bp._data, 1), "operator=(expr)");
+  }
+  static bool any_cmp(const poly &a, const poly &b, bool want_eq) {
+    int r = 0;
+    detail::check(ctx(), want_eq ? nflhip_any_eq(ctx(), a._data, b._data, 1, &r) : nflhip_any_neq(ctx(), a._data, b._data, 1, &r),
+                  "operator== / !=");
+    return r != 0;
+  }
+  static poly *make_temp() {  // polys can be MBs: temporaries of nested expressions live on the heap
+    void *mem = nullptr;
+    if (posix_memalign(&mem, 32, sizeof(poly)) != 0) throw std::bad_alloc();
+    return new (mem) poly();
+  }
+  static void drop_temp(poly *p) {
+    p->~poly();
+    free(p);
+  }
+} __attribute__((aligned(32)));
+
+// ---------------------------------------------------------------- operators (poly.hpp:346-352, ops.hpp:18-45)
+namespace ops {
+template <class X> struct is_node : std::false_type {};
+template <class T, size_t D, size_t M> struct is_node<poly<T, D, M>> : std::true_type {};
+template <class Op, class... A> struct is_node<expr<Op, A...>> : std::true_type {};
+}  // namespace ops
+
+#define NFL_HIP_BINARY(SYM, NAME)                                                                          \
+  template <class A, class B>                                                                              \
+  typename std::enable_if<ops::is_node<A>::value && ops::is_node<B>::value, ops::expr<ops::NAME, A, B>>::type SYM( \
+      A const &a, B const &b) {                                                                            \
+    static_assert(std::is_same<typename A::poly_type, typename B::poly_type>::value, "correct type combination"); \
+    return ops::expr<ops::NAME, A, B>(a, b);                                                               \
+  }
+NFL_HIP_BINARY(operator-, submod)
+NFL_HIP_BINARY(operator+, addmod)
+NFL_HIP_BINARY(operator*, mulmod)
+NFL_HIP_BINARY(operator==, eqmod)
+NFL_HIP_BINARY(operator!=, neqmod)
+#undef NFL_HIP_BINARY
+
+template <class A> typename std::enable_if<ops::is_node<A>::value, ops::expr<ops::compute_shoup, A>>::type compute_shoup(A const &a) {
+  return ops::expr<ops::compute_shoup, A>(a);
+}
+// shoup(a*b, b') is rewritten into mulmod_shoup(a, b, b') (ops.hpp:267-277); anything else
+// is a compile-time error, as in the reference (ops.hpp:153-163)
+template <class A0, class A1, class B>
+ops::expr<ops::mulmod_shoup, A0, A1, B> shoup(ops::expr<ops::mulmod, A0, A1> const &prod, B const &bprime) {
+  return ops::expr<ops::mulmod_shoup, A0, A1, B>(std::get<0>(prod.args), std::get<1>(prod.args), bprime);
+}
+
+/* high level wrappers (poly.hpp:314-332) */
+template <class T, size_t D, size_t M> void sub(poly<T, D, M> &out, poly<T, D, M> const &a, poly<T, D, M> const &b) { out = a - b; }
+template <class T, size_t D, size_t M> void add(poly<T, D, M> &out, poly<T, D, M> const &a, poly<T, D, M> const &b) { out = a + b; }
+template <class T, size_t D, size_t M> void mul(poly<T, D, M> &out, poly<T, D, M> const &a, poly<T, D, M> const &b) { out = a * b; }
+
+template <class T, size_t Degree, size_t AggregatedModulusBitSize>
+using poly_from_modulus = poly<T, Degree, AggregatedModulusBitSize / params<T>::kModulusBitsize>;
+
+// same text format as the reference's stream operator (core.hpp:398-421)
+template <class T, size_t D, size_t M> std::ostream &operator<<(std::ostream &os, poly<T, D, M> const &p) {
+  const char *term = sizeof(T) == 8 ? "ULL" : (sizeof(T) == 4 ? "UL" : "U");
+  bool first = true;
+  os << "{ ";
+  for (auto v : p) {
+    if (first) { first = false; os << uint64_t(v); }
+    else os << term << ", " << uint64_t(v);
+  }
+  return os << term << " }";
+}
+
+// ---------------------------------------------------------------- batch entry points
+// A contiguous array of polys is the dense [batch][NbModuli][Degree] tensor the
+// device wants (sizeof(poly) == N*sizeof(T)): one H2D, one kernel pass, one D2H.
+namespace batch {
+template <class P> void ntt_pow_phi(P *first, size_t count) {
+  static_assert(sizeof(P) == P::degree * P::nmoduli * sizeof(typename P::value_type), "dense poly array");
+  detail::check(P::ctx(), nflhip_ntt_fwd(P::ctx(), first->data(), count), "batch::ntt_pow_phi");
+}
+template <class P> void invntt_pow_invphi(P *first, size_t count) {
+  detail::check(P::ctx(), nflhip_ntt_inv(P::ctx(), first->data(), count), "batch::invntt_pow_invphi");
+}
+// c[k] = INTT(NTT(a[k]) (.) NTT(b[k])): the fused metric path
+template <class P> void polymul(P *c, P const *a, P const *b, size_t count) {
+  detail::check(P::ctx(), nflhip_polymul(P::ctx(), c->data(), a->cdata(), b->cdata(), count), "batch::polymul");
+}
+template <class P> void pointwise(int op, P *out, P const *a, P const *b, P const *bprime, size_t count) {
+  detail::check(P::ctx(), nflhip_pointwise(P::ctx(), op, out->data(), a->cdata(), b ? b->cdata() : nullptr,
+                                           bprime ? bprime->cdata() : nullptr, count), "batch::pointwise");
+}
+}  // namespace batch
+
+}  // namespace nfl
+
+#endif  // NFL_HIP_NFL_HPP

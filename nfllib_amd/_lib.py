@@ -65,6 +65,14 @@ class NflHipError(RuntimeError):
 
 
 def load():
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 pair; the dynamic
+    # loader shares ONE HIP runtime per process by soname, so when torch is going to be
+    # used (it is our device allocator / stream provider) it must get there first --
+    # otherwise torch would run on the system runtime with its bundled HSA and see no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "nfllib_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,0 +1,178 @@
+// tests/cpp/surface_main.cpp -- the reference's own test strategy restated against
+// the header-only nfl::poly surface of include/nfl_hip/nfl.hpp:
+//   scalar-formula agreement of + - * (tests/test_binary_op.h:9-32, nfl_add/sub/mul.cpp),
+//   a == a, a != a + b (tests/nfl_eq.cpp, nfl_neq.cpp),
+//   compute_shoup / shoup(a*b,b'), NTT / INTT, nested expression (tests/poly_p.cpp:29-66),
+//   CRT round trip (tests/poly_mpz.cpp:19-29), ctor/set semantics (tests/poly_set.cpp),
+//   serialisation round trip (tests/poly_serialize_manually.cpp), stream prefix (tests/nfl_stream.cpp),
+// with memcmp-strength comparisons (the reference's operator== is "any lane equal").
+// Exit code 0 = all good; prints the failing check otherwise.  Needs a GPU.
+#include <nfl_hip/nfl.hpp>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <sstream>
+
+int other_tu_selftest();  // surface_tu2.cpp: second translation unit including the header (tests/multi0.cpp, multi1.cpp)
+
+template <class P> struct Heap {
+  P *p;
+  template <class... A> explicit Heap(A &&... a) {
+    void *mem = nullptr;
+    if (posix_memalign(&mem, 32, sizeof(P)) != 0) throw std::bad_alloc();
+    p = new (mem) P(std::forward<A>(a)...);
+  }
+  ~Heap() { p->~P(); free(p); }
+  P &operator*() { return *p; }
+  P *operator->() { return p; }
+};
+
+template <class P> static bool same(const P &a, const P &b) {
+  return std::memcmp(a.cdata(), b.cdata(), sizeof(typename P::value_type) * P::degree * P::nmoduli) == 0;
+}
+
+#define CHECK(cond)                                                      \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);        \
+      return false;                                                      \
+    }                                                                    \
+  } while (0)
+
+template <class T, size_t Degree, size_t NbModuli> static bool run() {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  using W = typename poly_t::greater_value_type;
+  Heap<poly_t> a(nfl::uniform(1)), b(nfl::uniform(2)), add(nfl::uniform(3)), tmp, res;
+  // test_binary_op: per-coefficient scalar oracles
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) (*tmp)(cm, j) = T((W((*a)(cm, j)) + (*b)(cm, j)) % poly_t::get_modulus(cm));
+  *res = *a + *b;
+  CHECK(same(*res, *tmp));
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) {
+      const T p = poly_t::get_modulus(cm), x = (*a)(cm, j), y = (*b)(cm, j);
+      (*tmp)(cm, j) = x >= y ? T(x - y) : T(x - y + p);
+    }
+  *res = *a - *b;
+  CHECK(same(*res, *tmp));
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) (*tmp)(cm, j) = T((W((*a)(cm, j)) * (*b)(cm, j)) % poly_t::get_modulus(cm));
+  *res = *a * *b;
+  CHECK(same(*res, *tmp));
+  nfl::mul(*res, *a, *b);
+  CHECK(same(*res, *tmp));
+  // eq / neq with the reference's semantics
+  CHECK(bool(*a == *a));
+  CHECK(!bool(*a != *a));
+  CHECK(bool(*a != *a + *b));
+  // shoup path == plain product
+  Heap<poly_t> bp(nfl::compute_shoup(*b));
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++)
+      CHECK((*bp)(cm, j) == T((W((*b)(cm, j)) << (sizeof(T) * 8)) / poly_t::get_modulus(cm)));
+  *res = nfl::shoup(*a * *b, *bp);
+  CHECK(same(*res, *tmp));
+  // nested expression a + b*add, aliasing a = a + b
+  *res = *a + *b * *add;
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) {
+      const T p = poly_t::get_modulus(cm);
+      (*tmp)(cm, j) = T((W((*a)(cm, j)) + (W((*b)(cm, j)) * (*add)(cm, j)) % p) % p);
+    }
+  CHECK(same(*res, *tmp));
+  Heap<poly_t> al(*a);
+  *al = *al + *b;
+  *tmp = *a + *b;
+  CHECK(same(*al, *tmp));
+  // NTT / INTT round trip and the ring product against schoolbook for small degrees
+  Heap<poly_t> fa(*a), fb(*b);
+  fa->ntt_pow_phi();
+  CHECK(!same(*fa, *a));
+  Heap<poly_t> back(*fa);
+  back->invntt_pow_invphi();
+  CHECK(same(*back, *a));
+  fb->ntt_pow_phi();
+  *res = *fa * *fb;
+  res->invntt_pow_invphi();
+  Heap<poly_t> fused;
+  nfl::batch::polymul(fused.p, a.p, b.p, 1);
+  CHECK(same(*fused, *res));
+  if (Degree <= 256) {
+    for (size_t cm = 0; cm < NbModuli; cm++) {
+      const W p = poly_t::get_modulus(cm);
+      std::vector<W> z(Degree, 0);
+      for (size_t i = 0; i < Degree; i++)
+        for (size_t j = 0; j < Degree; j++) {
+          const W t = (W((*a)(cm, i)) * (*b)(cm, j)) % p;
+          if (i + j < Degree) z[i + j] = (z[i + j] + t) % p;
+          else z[i + j - Degree] = (z[i + j - Degree] + p - t) % p;
+        }
+      for (size_t i = 0; i < Degree; i++) CHECK((*res)(cm, i) == T(z[i]));
+    }
+  }
+  // CRT round trip (poly2mpz -> mpz2poly == identity)
+  std::vector<uint64_t> limbs;
+  a->poly2limbs(limbs);
+  Heap<poly_t> prj;
+  prj->limbs2poly(limbs.data(), poly_t::crt_limbs());
+  CHECK(same(*prj, *a));
+  // set semantics (tests/poly_set.cpp): zero-pad + replicate; wrong size throws
+  Heap<poly_t> s1(std::initializer_list<T>{1, 2, 3});
+  for (size_t cm = 0; cm < NbModuli; cm++) {
+    CHECK((*s1)(cm, 0) == 1 && (*s1)(cm, 1) == 2 && (*s1)(cm, 2) == 3);
+    for (size_t j = 3; j < Degree; j++) CHECK((*s1)(cm, j) == 0);
+  }
+  bool threw = false;
+  try {
+    std::vector<T> bad(Degree + 1, 1);
+    if (NbModuli > 1 || true) { Heap<poly_t> s2(bad.begin(), bad.end()); (void)s2; }
+  } catch (std::runtime_error const &) { threw = true; }
+  CHECK(threw || (Degree + 1 == Degree * NbModuli));
+  Heap<poly_t> one(T(1));
+  CHECK(bool(*one));
+  Heap<poly_t> zero;
+  CHECK(!bool(*zero));
+  // serialisation + stream
+  std::stringstream ss(std::ios::in | std::ios::out | std::ios::binary);
+  a->serialize_manually(ss);
+  Heap<poly_t> de;
+  de->deserialize_manually(ss);
+  CHECK(same(*de, *a));
+  std::ostringstream oss;
+  oss << *one;
+  CHECK(oss.str().substr(0, 4) == "{ 1U");
+  // batch entry points on a dense array
+  const size_t B = 3;
+  void *mem = nullptr;
+  CHECK(posix_memalign(&mem, 32, sizeof(poly_t) * B) == 0);
+  poly_t *arr = static_cast<poly_t *>(mem);
+  for (size_t k = 0; k < B; k++) new (&arr[k]) poly_t(nfl::uniform(100 + k));
+  Heap<poly_t> single(arr[1]);
+  nfl::batch::ntt_pow_phi(arr, B);
+  single->ntt_pow_phi();
+  CHECK(same(arr[1], *single));
+  nfl::batch::invntt_pow_invphi(arr, B);
+  single->invntt_pow_invphi();
+  CHECK(same(arr[1], *single));
+  free(mem);
+  return true;
+}
+
+int main() {
+  try {
+    bool ok = true;
+    ok &= run<uint32_t, 8, 2>();        // reference CONFIG 8,60,uint32_t
+    ok &= run<uint16_t, 128, 1>();      // 128,14,uint16_t
+    ok &= run<uint32_t, 1024, 2>();     // 1024,60,uint32_t
+    ok &= run<uint64_t, 64, 3>();
+    ok &= run<uint64_t, 4096, 4>();     // BASELINE configs[1]
+    ok &= run<uint64_t, 8192, 2>();     // 8192,124,uint64_t
+    ok &= other_tu_selftest() == 0;
+    std::printf(ok ? "surface: all checks passed\n" : "surface: FAILED\n");
+    return ok ? 0 : 1;
+  } catch (std::exception const &e) {
+    std::printf("surface: exception: %s\n", e.what());
+    return 2;
+  }
+}

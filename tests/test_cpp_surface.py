@@ -1,0 +1,42 @@
+"""The header-only nfl::poly surface (include/nfl_hip/nfl.hpp) -- compiled with the
+HOST compiler only, two translation units (the reference's multi0/multi1 hygiene
+test), linked against libnflhip.so.  On the GPU box the binary re-runs the
+reference's own unit-test strategy through the C ABI; on a CPU-only host it must
+fail loudly with the reference's exception type instead of computing anything."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+BIN = os.path.join(CPP, "surface_test")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", CPP])
+    assert os.path.exists(BIN)
+
+
+def _gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_header_compiles_as_cxx11_in_two_tus_and_links():
+    _build()
+
+
+@pytest.mark.skipif(_gpu(), reason="CPU-only behaviour")
+def test_surface_throws_runtime_error_without_gpu():
+    _build()
+    r = subprocess.run([BIN], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+def test_surface_reference_style_checks_on_gpu():
+    _build()
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout
