@@ -204,6 +204,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     while (bits < wb && (((u128)1) << bits) <= (u128)p) ++bits;
     m.mask = (T)(bits >= 64 ? ~(uint64_t)0 : ((((uint64_t)1) << bits) - 1));
     m.delta = (T)((((uint64_t)1) << (wb - 2)) - p);
+    m.mu2 = (T)((((u128)1) << (2 * wb - 3)) / p);
   }
 
   HIPCHK(nullptr, hipMalloc(&c->tabs.psi, psi.size() * sizeof(Tw<T>)));

@@ -23,6 +23,7 @@ template <typename T> struct ModConst {
   T yinv_sh;    // its Shoup companion
   T mask;       // 2^(floor(log2 p)+1) - 1           (core.hpp:165-166)
   T delta;      // 2^(W-2) - p: the primes are 2^(W-2) - c*2*kMax + 1 (params.hpp:20,54,96)
+  T mu2;        // floor(2^(2W-3)/p): Barrett constant for lazily reduced operands (< 2^(W-2) + 3*delta)
 };
 
 // Twiddle pair as stored on the device: psi^bitrev(k) and its Shoup companion.

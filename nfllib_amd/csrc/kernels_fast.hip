@@ -69,6 +69,12 @@ __device__ __forceinline__ u64 shoup_acc(const u64 y, const Tw64 w, const u64 se
   return ((u64)hi << 32) | (u32)acc;
 }
 
+// z -> z mod-ish p in [0, 2^62 + 3*delta) for ANY 64-bit z: 2^62 == delta (mod p), so the
+// top two bits fold down with one multiply-add (v_lshrrev, v_and, v_mad_u64_u32).
+__device__ __forceinline__ u64 fold2(const u64 z, const Mod &k) {
+  return (z & 0x3fffffffffffffffull) + (u64)(u32)(z >> 62) * k.d;
+}
+
 // ---- one lazy butterfly each way -------------------------------------------------
 // Cooley-Tukey, x' = x + w*y, y' = x - w*y.
 //  ARITH 0: Harvey's ranges, x,y in [0,4p) -> [0,4p).
@@ -83,9 +89,15 @@ __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod 
     const u64 m = mul_shoup_lazy<u64>(y, w.w, w.wp, k.p);
     x = u + m;
     y = u - m + k.p2;
-  } else {
+  } else if (ARITH == 1) {
     const u32 b = (u32)(x >> 63);
     const u64 U = (x & 0x7fffffffffffffffull) + (u64)b * k.d2;
+    const u64 xn = shoup_acc(y, w, U, k);
+    y = ((U << 1) + k.p2) - xn;
+    x = xn;
+  } else {
+    //  ARITH 2: as 1 with the two-bit fold (U < 2^62 + 3*delta): same cost, tighter range
+    const u64 U = fold2(x, k);
     const u64 xn = shoup_acc(y, w, U, k);
     y = ((U << 1) + k.p2) - xn;
     x = xn;
@@ -93,18 +105,31 @@ __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod 
 }
 // Gentleman-Sande with the negated mirrored twiddle: u,v in [0,2p) ->
 // u' = u + v, v' = (v - u) * w, both in [0,2p)
+//  ARITH 2: inputs < 2p; the sum is folded to < 2^62 + 3*delta (< 2p) with no compare.
 template <int ARITH>
 __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, const Tw64 w, const Mod &k) {
-  const u64 s = csub<u64>(x + y, k.p2);
+  const u64 s = ARITH == 2 ? fold2(x + y, k) : csub<u64>(x + y, k.p2);
   const u64 d = y - x + k.p2;
   x = s;
   y = ARITH == 0 ? mul_shoup_lazy<u64>(d, w.w, w.wp, k.p) : shoup_acc(d, w, 0, k);
 }
 // any 64-bit word (ARITH 1) or [0,4p) (ARITH 0) -> [0,p)
 template <int ARITH> __device__ __forceinline__ u64 canon(u64 x, const Mod &k) {
+  if (ARITH == 2) return csub<u64>(fold2(x, k), k.p);  // < p + 4*delta, one subtract left
   if (ARITH == 1) x = (x & 0x7fffffffffffffffull) + (u64)(u32)(x >> 63) * k.d2;  // < 2p + 4*delta
   x = csub<u64>(x, k.p2);
   return csub<u64>(x, k.p);
+}
+// x*y mod p for lazily reduced x, y (< 2^62 + 3*delta): T < 2^125, q = mulhi(T >> 61, mu2)
+// is within 3 of floor(T/p), r = T - q*p < 4p, folded to < p + 4*delta.
+__device__ __forceinline__ u64 mul_lazy(const u64 x, const u64 y, const u64 mu2, const Mod &k) {
+  const u64 lo = x * y, hi = __umul64hi(x, y);
+  const u64 th = (hi << 3) | (lo >> 61);
+  const u64 q = __umul64hi(th, mu2);
+  const u32 q0 = (u32)q, q1 = (u32)(q >> 32);
+  u64 r = (u64)q0 * k.d + lo;                                   // lo - q*p = lo + q*delta - (q << 62)
+  r += (u64)(q1 * k.d - (q0 << 30)) << 32;
+  return fold2(r, k);
 }
 
 // radix-16 register passes; TW(s, g) yields the twiddle of sub-stage s (0..3), group g
@@ -288,9 +313,13 @@ __device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, cons
   // point-wise product on canonical representatives (operator*, ops.hpp:201-219)
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const u64 x = canon<ARITH>(va[i], k);
-    const u64 y = B_IS_NTT ? vb[i] : canon<ARITH>(vb[i], k);
-    va[i] = barrett<u64>::mul(x, y, k.p, mcc.mu);
+    if (ARITH == 2) {
+      va[i] = mul_lazy(fold2(va[i], k), B_IS_NTT ? vb[i] : fold2(vb[i], k), mcc.mu2, k);
+    } else {
+      const u64 x = canon<ARITH>(va[i], k);
+      const u64 y = B_IS_NTT ? vb[i] : canon<ARITH>(vb[i], k);
+      va[i] = barrett<u64>::mul(x, y, k.p, mcc.mu);
+    }
   }
   inv_core<ARITH>(va, sm, tw, mcc, k, t);
 #pragma unroll
@@ -378,7 +407,7 @@ static int variant() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("NFLHIP_VARIANT");
-    v = e ? atoi(e) : 12;
+    v = e ? atoi(e) : 22;
   }
   return v;
 }
@@ -400,9 +429,9 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
     case 3: NFLHIP_LAUNCH(0, 3)
     case 4: NFLHIP_LAUNCH(0, 4)
     case 11: NFLHIP_LAUNCH(1, 1)
-    case 13: NFLHIP_LAUNCH(1, 3)
-    case 14: NFLHIP_LAUNCH(1, 4)
-    default: NFLHIP_LAUNCH(1, 2)
+    case 12: NFLHIP_LAUNCH(1, 2)
+    case 21: NFLHIP_LAUNCH(2, 1)
+    default: NFLHIP_LAUNCH(2, 2)
   }
 #undef NFLHIP_LAUNCH
   return hipGetLastError();
@@ -424,7 +453,10 @@ hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uin
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  if (s.small_delta && variant() >= 10)
+  if (s.small_delta && variant() >= 20)
+    hipLaunchKernelGGL(k_ntt_fwd4096<2>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
+                       (const MC64 *)t.mc, (int)s.nm);
+  else if (s.small_delta && variant() >= 10)
     hipLaunchKernelGGL(k_ntt_fwd4096<1>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
                        (const MC64 *)t.mc, (int)s.nm);
   else
@@ -439,7 +471,10 @@ hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uin
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  if (s.small_delta && variant() >= 10)
+  if (s.small_delta && variant() >= 20)
+    hipLaunchKernelGGL(k_ntt_inv4096<2>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
+                       (const MC64 *)t.mc, (int)s.nm);
+  else if (s.small_delta && variant() >= 10)
     hipLaunchKernelGGL(k_ntt_inv4096<1>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
                        (const MC64 *)t.mc, (int)s.nm);
   else
