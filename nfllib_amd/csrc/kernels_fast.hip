@@ -44,7 +44,7 @@ __device__ __forceinline__ int pad(int e) { return e + (e >> 4); }
 // The reference's 62-bit primes are p = 2^62 - delta with delta = c*2^21 - 1 < 2^31
 // (params.hpp:94-97), so q*p = (q << 62) - q*delta costs one 32x32 multiply-add.
 struct Mod {
-  u64 p, p2;
+  u64 p, p2, p3;
   uint32_t d, d2;  // delta, 2*delta
 };
 typedef uint32_t u32;
@@ -57,10 +57,19 @@ __device__ __forceinline__ u64 mulhi_x(const u64 y, const u64 wp) {
   const u64 t2 = (u64)y0 * a1 + (u32)t1;
   return (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);
 }
+// floor(y*wp / 2^64) - e with e in {0,1}: the hi32(y0*a0) term of the exact quotient is
+// dropped, which removes the zero-extension register shuffles of the exact chain.
+__device__ __forceinline__ u64 mulhi_a(const u64 y, const u64 wp) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wp, a1 = (u32)(wp >> 32);
+  const u64 A = (u64)y1 * a0, B = (u64)y0 * a1;
+  const unsigned __int128 S = (unsigned __int128)A + B;
+  return (u64)y1 * a1 + (u64)(S >> 32);
+}
 // seed + (y*w mod p, lazily in [0,2p)) for ANY 64-bit y: Shoup quotient, then
 // y*w - q*p = y*w + q*delta - (q << 62), all modulo 2^64, accumulated onto the seed.
+template <bool APPROX = false>
 __device__ __forceinline__ u64 shoup_acc(const u64 y, const Tw64 w, const u64 seed, const Mod &k) {
-  const u64 q = mulhi_x(y, w.wp);
+  const u64 q = APPROX ? mulhi_a(y, w.wp) : mulhi_x(y, w.wp);  // APPROX: result in [0,3p) instead of [0,2p)
   const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w.w, w1 = (u32)(w.w >> 32);
   const u32 q0 = (u32)q, q1 = (u32)(q >> 32);
   u64 acc = (u64)y0 * w0 + seed;
@@ -95,11 +104,18 @@ __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod 
     const u64 xn = shoup_acc(y, w, U, k);
     y = ((U << 1) + k.p2) - xn;
     x = xn;
-  } else {
+  } else if (ARITH == 2) {
     //  ARITH 2: as 1 with the two-bit fold (U < 2^62 + 3*delta): same cost, tighter range
     const u64 U = fold2(x, k);
     const u64 xn = shoup_acc(y, w, U, k);
     y = ((U << 1) + k.p2) - xn;
+    x = xn;
+  } else {
+    //  ARITH 3: U < p + 4*delta and the product is reduced with the one-off quotient, m < 3p:
+    //           x' = U + m < 4p + 4*delta = 2^64 and y' = U + 3p - m < 2^64 still fit the word.
+    const u64 U = fold2(x, k);
+    const u64 xn = shoup_acc<true>(y, w, U, k);
+    y = ((U << 1) + k.p3) - xn;
     x = xn;
   }
 }
@@ -108,14 +124,14 @@ __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod 
 //  ARITH 2: inputs < 2p; the sum is folded to < 2^62 + 3*delta (< 2p) with no compare.
 template <int ARITH>
 __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, const Tw64 w, const Mod &k) {
-  const u64 s = ARITH == 2 ? fold2(x + y, k) : csub<u64>(x + y, k.p2);
+  const u64 s = ARITH >= 2 ? fold2(x + y, k) : csub<u64>(x + y, k.p2);
   const u64 d = y - x + k.p2;
   x = s;
   y = ARITH == 0 ? mul_shoup_lazy<u64>(d, w.w, w.wp, k.p) : shoup_acc(d, w, 0, k);
 }
 // any 64-bit word (ARITH 1) or [0,4p) (ARITH 0) -> [0,p)
 template <int ARITH> __device__ __forceinline__ u64 canon(u64 x, const Mod &k) {
-  if (ARITH == 2) return csub<u64>(fold2(x, k), k.p);  // < p + 4*delta, one subtract left
+  if (ARITH >= 2) return csub<u64>(fold2(x, k), k.p);  // < p + 4*delta, one subtract left
   if (ARITH == 1) x = (x & 0x7fffffffffffffffull) + (u64)(u32)(x >> 63) * k.d2;  // < 2p + 4*delta
   x = csub<u64>(x, k.p2);
   return csub<u64>(x, k.p);
@@ -271,6 +287,7 @@ __device__ __forceinline__ Mod make_mod(const MC64 &c) {
   Mod k;
   k.p = c.p;
   k.p2 = c.p2;
+  k.p3 = c.p2 + c.p;
   k.d = (u32)c.delta;
   k.d2 = 2u * (u32)c.delta;
   return k;
@@ -313,7 +330,7 @@ __device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, cons
   // point-wise product on canonical representatives (operator*, ops.hpp:201-219)
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    if (ARITH == 2) {
+    if (ARITH >= 2) {
       va[i] = mul_lazy(fold2(va[i], k), B_IS_NTT ? vb[i] : fold2(vb[i], k), mcc.mu2, k);
     } else {
       const u64 x = canon<ARITH>(va[i], k);
@@ -407,7 +424,7 @@ static int variant() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("NFLHIP_VARIANT");
-    v = e ? atoi(e) : 22;
+    v = e ? atoi(e) : 32;
   }
   return v;
 }
@@ -431,7 +448,9 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
     case 11: NFLHIP_LAUNCH(1, 1)
     case 12: NFLHIP_LAUNCH(1, 2)
     case 21: NFLHIP_LAUNCH(2, 1)
-    default: NFLHIP_LAUNCH(2, 2)
+    case 22: NFLHIP_LAUNCH(2, 2)
+    case 31: NFLHIP_LAUNCH(3, 1)
+    default: NFLHIP_LAUNCH(3, 2)
   }
 #undef NFLHIP_LAUNCH
   return hipGetLastError();
@@ -453,7 +472,10 @@ hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uin
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  if (s.small_delta && variant() >= 20)
+  if (s.small_delta && variant() >= 30)
+    hipLaunchKernelGGL(k_ntt_fwd4096<3>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
+                       (const MC64 *)t.mc, (int)s.nm);
+  else if (s.small_delta && variant() >= 20)
     hipLaunchKernelGGL(k_ntt_fwd4096<2>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
                        (const MC64 *)t.mc, (int)s.nm);
   else if (s.small_delta && variant() >= 10)
