@@ -49,21 +49,34 @@ struct Mod {
 };
 typedef uint32_t u32;
 
-// exact floor(y*wp / 2^64) phrased so that hipcc emits v_mad_u64_u32 chains
+// S = a*b + c with the carry-out of the 64-bit accumulate materialised as 0/1 in `carry`.
+// v_mad_u64_u32's SGPR carry has no C spelling; both instructions sit in ONE asm statement
+// because gfx950 needs 2 wait states between a VALU SGPR write and a VALU read of that SGPR
+// and hipcc pads nothing inside (or around the operands of) an asm string.
+__device__ __forceinline__ u64 mad_carry(const u32 a, const u32 b, const u64 c, u32 &carry) {
+  u64 S, cy;
+  asm("v_mad_u64_u32 %0, %2, %3, %4, %5\n\ts_nop 1\n\tv_addc_co_u32 %1, %2, 0, 0, %2"
+      : "=v"(S), "=v"(carry), "=&s"(cy)
+      : "v"(a), "v"(b), "v"(c));
+  return S;
+}
+// exact floor(y*wp / 2^64): y0*a1 + hi32(y0*a0) cannot overflow, the second cross product is
+// accumulated with its carry, and (sum >> 32 | carry << 32) is the addend of the top product.
 __device__ __forceinline__ u64 mulhi_x(const u64 y, const u64 wp) {
   const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wp, a1 = (u32)(wp >> 32);
-  const u64 t0 = (u64)y0 * a0;
-  const u64 t1 = (u64)y1 * a0 + (t0 >> 32);
-  const u64 t2 = (u64)y0 * a1 + (u32)t1;
-  return (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);
+  const u64 X = (u64)y0 * a1 + (u64)__umulhi(y0, a0);
+  u32 c;
+  const u64 S = mad_carry(y1, a0, X, c);
+  return (u64)y1 * a1 + (((u64)c << 32) | (u32)(S >> 32));
 }
 // floor(y*wp / 2^64) - e with e in {0,1}: the hi32(y0*a0) term of the exact quotient is
 // dropped, which removes the zero-extension register shuffles of the exact chain.
 __device__ __forceinline__ u64 mulhi_a(const u64 y, const u64 wp) {
   const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wp, a1 = (u32)(wp >> 32);
-  const u64 A = (u64)y1 * a0, B = (u64)y0 * a1;
-  const unsigned __int128 S = (unsigned __int128)A + B;
-  return (u64)y1 * a1 + (u64)(S >> 32);
+  const u64 A = (u64)y1 * a0;
+  u32 c;
+  const u64 S = mad_carry(y0, a1, A, c);
+  return (u64)y1 * a1 + (((u64)c << 32) | (u32)(S >> 32));
 }
 // seed + (y*w mod p, lazily in [0,2p)) for ANY 64-bit y: Shoup quotient, then
 // y*w - q*p = y*w + q*delta - (q << 62), all modulo 2^64, accumulated onto the seed.
