@@ -151,13 +151,14 @@ def main():
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     value = world * batch * args.steps / dt
 
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == args.workload:
                 traffic = tj["hbm_bytes_per_poly"] * batch
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes, %s, calibrated)" % tj.get("round", "")
         except Exception:
             traffic = None
 
@@ -171,7 +172,7 @@ def main():
                    "degree": n, "nmoduli": nm, "limb_bits": lb, "batch_per_gpu": batch, "global_batch": batch * world,
                    "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "k_polymul4096<false>" if args.workload == "B" else "composed",
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }

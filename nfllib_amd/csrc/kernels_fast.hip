@@ -208,6 +208,7 @@ __device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 17 * k];
   }
   // F2: stages 4-7 inside 256-word block B: psi[2^(4+s) + B*2^s + g]
+  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   ct16<ARITH>(v, [&](int s, int g) { return tw[(16 << s) + (B << s) + g]; }, k);
   // E2: 16-lane transpose through this wave's own LDS region (LDS is in-order per wave)
   {
@@ -227,6 +228,7 @@ __device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__re
 // F3: stages 8-11 inside 16-word block q = t: psi[2^(8+s) + q*2^s + g]
 template <int ARITH>
 __device__ __forceinline__ void fwd_tail(u64 (&v)[16], const Tw64 *__restrict__ tw, const Mod &k, const int t) {
+  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   ct16<ARITH>(v, [&](int s, int g) { return tw[(256 << s) + (t << s) + g]; }, k);
 }
 template <int ARITH>
@@ -243,6 +245,7 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
                                          const int t) {
   const u64 p = c.p, p2 = c.p2;
   // I1: stages 11..8; mirrored index 2m-1-j with m = 2^(8+s), j = q*2^s + g
+  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   gs16<ARITH>(v, [&](int s, int g) { return tw[(512 << s) - 1 - ((t << s) + g)]; }, k);
   const int B = t >> 4, r = t & 15;
   {
@@ -259,6 +262,7 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 17 * k];
   }
   // I2: stages 7..4; m = 2^(4+s), j = B*2^s + g
+  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   gs16<ARITH>(v, [&](int s, int g) { return tw[(32 << s) - 1 - ((B << s) + g)]; }, k);
   {
     const int base = 272 * B + r;
@@ -271,6 +275,7 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 272 * k];
   }
+  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   // I3: stages 3..1 (uniform twiddles), then stage 0 with n^-1 folded in
 #pragma unroll
   for (int s = 3; s >= 1; --s) {
@@ -463,6 +468,10 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
     case 21: NFLHIP_LAUNCH(2, 1)
     case 22: NFLHIP_LAUNCH(2, 2)
     case 31: NFLHIP_LAUNCH(3, 1)
+    case 42: NFLHIP_LAUNCH(4, 2)
+    case 43: NFLHIP_LAUNCH(4, 3)
+    case 44: NFLHIP_LAUNCH(4, 4)
+    case 33: NFLHIP_LAUNCH(3, 3)
     default: NFLHIP_LAUNCH(3, 2)
   }
 #undef NFLHIP_LAUNCH
