@@ -79,4 +79,11 @@ hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uin
 hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
                                    hipStream_t st);
 
+// 4096-word inner blocks of rows with logn >= 12 on the register-tiled kernels (rows = batch * nm);
+// `mul` != nullptr fuses the point-wise product into the inverse's load.
+hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t rows,
+                                     hipStream_t st);
+hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, const uint64_t *mul,
+                                     uint64_t *dst, size_t rows, hipStream_t st);
+
 }  // namespace nflhip

@@ -187,13 +187,22 @@ template <int ARITH, class TW> __device__ __forceinline__ void gs16(u64 (&v)[16]
   }
 }
 
+// Position of the 4096-word block this workgroup transforms inside a longer row of
+// n = 4096 * 2^r words (r = 0: the row itself).  The streaming outer passes of
+// kernels_generic.hip handle global stages [0, r); the passes below then cover global
+// stages r .. r+11 with block index offsets folded into the twiddle indices.
+struct Blk {
+  int r;
+  unsigned blk;
+};
+
 // ---- forward transform of the 16 words a thread loaded as x[t + 256k] ---------------
 // On return thread q = t holds X[16q + k] (bit-reversed order positions), lazy in [0,4p).
 template <int ARITH>
 __device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const Mod &k, const int t,
-                                         const bool war_barrier) {
-  // F1: stages 0-3, block index of sub-stage s is the group g: psi[2^s + g] (wave-uniform)
-  ct16<ARITH>(v, [&](int s, int g) { return tw[(1 << s) + g]; }, k);
+                                         const bool war_barrier, const Blk bk) {
+  // F1: stages r..r+3, block index of sub-stage s is blk*2^s + g: psi[2^(r+s) + ...] (wave-uniform)
+  ct16<ARITH>(v, [&](int s, int g) { return tw[(1u << (bk.r + s)) + (bk.blk << s) + g]; }, k);
   if (war_barrier) __syncthreads();  // the slab may still be read by slower waves (previous transform)
   {
     const int base = t + (t >> 4);
@@ -209,7 +218,7 @@ __device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__re
   }
   // F2: stages 4-7 inside 256-word block B: psi[2^(4+s) + B*2^s + g]
   if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
-  ct16<ARITH>(v, [&](int s, int g) { return tw[(16 << s) + (B << s) + g]; }, k);
+  ct16<ARITH>(v, [&](int s, int g) { return tw[(16u << (bk.r + s)) + ((bk.blk * 16u + B) << s) + g]; }, k);
   // E2: 16-lane transpose through this wave's own LDS region (LDS is in-order per wave)
   {
     const int base = 272 * B + r;
@@ -227,26 +236,28 @@ __device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__re
 }
 // F3: stages 8-11 inside 16-word block q = t: psi[2^(8+s) + q*2^s + g]
 template <int ARITH>
-__device__ __forceinline__ void fwd_tail(u64 (&v)[16], const Tw64 *__restrict__ tw, const Mod &k, const int t) {
+__device__ __forceinline__ void fwd_tail(u64 (&v)[16], const Tw64 *__restrict__ tw, const Mod &k, const int t,
+                                         const Blk bk) {
   if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
-  ct16<ARITH>(v, [&](int s, int g) { return tw[(256 << s) + (t << s) + g]; }, k);
+  ct16<ARITH>(v, [&](int s, int g) { return tw[(256u << (bk.r + s)) + ((bk.blk * 256u + t) << s) + g]; }, k);
 }
 template <int ARITH>
 __device__ __forceinline__ void fwd_core(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const Mod &k, const int t,
-                                         const bool war_barrier) {
-  fwd_head<ARITH>(v, sm, tw, k, t, war_barrier);
-  fwd_tail<ARITH>(v, tw, k, t);
+                                         const bool war_barrier, const Blk bk) {
+  fwd_head<ARITH>(v, sm, tw, k, t, war_barrier, bk);
+  fwd_tail<ARITH>(v, tw, k, t, bk);
 }
 
 // ---- inverse transform of the 16 words a thread holds as X[16q + k], in [0,2p) -------
-// On return thread t holds x[t + 256k], canonical in [0,p).
+// On return thread t holds x[t + 256k]: canonical in [0,p) when r == 0 (n^-1 folded into
+// global stage 0), lazy in [0,2p) when outer inverse passes follow (r > 0).
 template <int ARITH>
 __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__restrict__ tw, const MC64 &c, const Mod &k,
-                                         const int t) {
+                                         const int t, const Blk bk) {
   const u64 p = c.p, p2 = c.p2;
   // I1: stages 11..8; mirrored index 2m-1-j with m = 2^(8+s), j = q*2^s + g
   if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
-  gs16<ARITH>(v, [&](int s, int g) { return tw[(512 << s) - 1 - ((t << s) + g)]; }, k);
+  gs16<ARITH>(v, [&](int s, int g) { return tw[(512u << (bk.r + s)) - 1u - (((bk.blk * 256u + t) << s) + g)]; }, k);
   const int B = t >> 4, r = t & 15;
   {
     const int base = 17 * t;
@@ -263,7 +274,7 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
   }
   // I2: stages 7..4; m = 2^(4+s), j = B*2^s + g
   if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
-  gs16<ARITH>(v, [&](int s, int g) { return tw[(32 << s) - 1 - ((B << s) + g)]; }, k);
+  gs16<ARITH>(v, [&](int s, int g) { return tw[(32u << (bk.r + s)) - 1u - (((bk.blk * 16u + B) << s) + g)]; }, k);
   {
     const int base = 272 * B + r;
 #pragma unroll
@@ -276,16 +287,22 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 272 * k];
   }
   if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
-  // I3: stages 3..1 (uniform twiddles), then stage 0 with n^-1 folded in
+  // I3: stages r+3..r+1 (uniform twiddles), then stage r (with n^-1 folded in when r == 0)
 #pragma unroll
   for (int s = 3; s >= 1; --s) {
     const int half = 8 >> s;
 #pragma unroll
     for (int g = 0; g < (1 << s); ++g) {
-      const Tw64 w = tw[(2 << s) - 1 - g];
+      const Tw64 w = tw[(2u << (bk.r + s)) - 1u - ((bk.blk << s) + g)];
 #pragma unroll
       for (int h = 0; h < half; ++h) gs_bfly<ARITH>(v[g * 2 * half + h], v[g * 2 * half + h + half], w, k);
     }
+  }
+  if (bk.r > 0) {  // plain last stage: the merged scale happens in the outer pass that owns global stage 0
+    const Tw64 w = tw[(2u << bk.r) - 1u - bk.blk];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) gs_bfly<ARITH>(v[h], v[h + 8], w, k);
+    return;
   }
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
@@ -325,7 +342,8 @@ __device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, cons
   u64 va[16], vb[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) va[i] = a[off + t + 256 * i];
-  fwd_head<ARITH>(va, sm, tw, k, t, false);
+  const Blk bk{0, 0u};
+  fwd_head<ARITH>(va, sm, tw, k, t, false, bk);
   // b's HBM loads are issued here so their latency hides under F3(a) without
   // holding 32 more VGPRs through the first two passes
   asm volatile("" ::: "memory");
@@ -343,8 +361,8 @@ __device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, cons
     }
   }
   asm volatile("" ::: "memory");
-  fwd_tail<ARITH>(va, tw, k, t);
-  if (!B_IS_NTT) fwd_core<ARITH>(vb, sm, tw, k, t, true);
+  fwd_tail<ARITH>(va, tw, k, t, bk);
+  if (!B_IS_NTT) fwd_core<ARITH>(vb, sm, tw, k, t, true, bk);
   // point-wise product on canonical representatives (operator*, ops.hpp:201-219)
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -356,7 +374,7 @@ __device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, cons
       va[i] = barrett<u64>::mul(x, y, k.p, mcc.mu);
     }
   }
-  inv_core<ARITH>(va, sm, tw, mcc, k, t);
+  inv_core<ARITH>(va, sm, tw, mcc, k, t, bk);
 #pragma unroll
   for (int i = 0; i < 16; ++i) c[off + t + 256 * i] = va[i];
 }
@@ -370,20 +388,24 @@ __global__ __launch_bounds__(kThreads, MINW) void k_polymul4096(u64 *c, const u6
 }
 
 // ---- stand-alone transforms (in place or out of place) --------------------------------
+// One workgroup per 4096-word block of a row of n = 2^logn words (logn >= 12); for
+// logn > 12 the streaming outer passes run before (forward) / after (inverse) these.
 template <int ARITH>
 __global__ __launch_bounds__(kThreads) void k_ntt_fwd4096(const u64 *src, u64 *dst, const Tw64 *__restrict__ psi,
-                                                          const MC64 *__restrict__ mc, int nm) {
+                                                          const MC64 *__restrict__ mc, int nm, int logn) {
   __shared__ u64 sm[kLdsWords];
   const int t = threadIdx.x;
-  const size_t row = blockIdx.x;
+  const int r = logn - kLogN;
+  const size_t row = (size_t)blockIdx.x >> r;
+  const Blk bk{r, blockIdx.x & ((1u << r) - 1u)};
   const int cm = (int)(row % (size_t)nm);
   const Mod k = make_mod(mc[cm]);
-  const Tw64 *tw = psi + ((size_t)cm << kLogN);
-  const size_t off = row << kLogN;
+  const Tw64 *tw = psi + ((size_t)cm << logn);
+  const size_t off = (size_t)blockIdx.x << kLogN;
   u64 v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = src[off + t + 256 * i];
-  fwd_core<ARITH>(v, sm, tw, k, t, false);
+  fwd_core<ARITH>(v, sm, tw, k, t, false, bk);
   // thread q holds X[16q+k]: transpose inside the wave's LDS region for coalesced stores
   {
     const int base = 17 * t;
@@ -401,22 +423,28 @@ __global__ __launch_bounds__(kThreads) void k_ntt_fwd4096(const u64 *src, u64 *d
   }
 }
 
-template <int ARITH>
-__global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, u64 *dst, const Tw64 *__restrict__ psi,
-                                                          const MC64 *__restrict__ mc, int nm) {
+// MUL: the point-wise product src (.) mul (both canonical, NTT order) is fused into the load.
+template <int ARITH, bool MUL>
+__global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, const u64 *mul, u64 *dst,
+                                                          const Tw64 *__restrict__ psi, const MC64 *__restrict__ mc,
+                                                          int nm, int logn) {
   __shared__ u64 sm[kLdsWords];
   const int t = threadIdx.x;
-  const size_t row = blockIdx.x;
+  const int r = logn - kLogN;
+  const size_t row = (size_t)blockIdx.x >> r;
+  const Blk bk{r, blockIdx.x & ((1u << r) - 1u)};
   const int cm = (int)(row % (size_t)nm);
   const MC64 mcc = mc[cm];
   const Mod k = make_mod(mcc);
-  const Tw64 *tw = psi + ((size_t)cm << kLogN);
-  const size_t off = row << kLogN;
+  const Tw64 *tw = psi + ((size_t)cm << logn);
+  const size_t off = (size_t)blockIdx.x << kLogN;
   const int w = t >> 6, l = t & 63;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int e = 1024 * w + 64 * j + l;
-    sm[pad(e)] = src[off + e];
+    u64 x = src[off + e];
+    if (MUL) x = ARITH >= 2 ? mul_lazy(x, mul[off + e], mcc.mu2, k) : barrett<u64>::mul(x, mul[off + e], k.p, mcc.mu);
+    sm[pad(e)] = x;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -427,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, u64 *d
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = sm[base + i];
   }
-  inv_core<ARITH>(v, sm, tw, mcc, k, t);
+  inv_core<ARITH>(v, sm, tw, mcc, k, t, bk);
 #pragma unroll
   for (int i = 0; i < 16; ++i) dst[off + t + 256 * i] = v[i];
 }
@@ -488,43 +516,55 @@ hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t 
                   : launch_polymul_v<false>(s, t, c, a, b, (unsigned)rows, st);
 }
 
+// inner 4096-word blocks of rows with logn >= 12 (used directly for n = 4096 and by the
+// generic launch plans of kernels_generic.hip after / before their streaming outer passes)
+hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t rows,
+                                     hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn < kLogN) return hipErrorNotSupported;
+  const size_t blocks = rows << (s.logn - kLogN);
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const Tw64 *psi = (const Tw64 *)t.psi;
+  const MC64 *mc = (const MC64 *)t.mc;
+  const dim3 g((unsigned)blocks), b(kThreads);
+  const int v = s.small_delta ? variant() : variant() % 10;
+  if (v >= 30) hipLaunchKernelGGL(k_ntt_fwd4096<3>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
+  else if (v >= 20) hipLaunchKernelGGL(k_ntt_fwd4096<2>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
+  else if (v >= 10) hipLaunchKernelGGL(k_ntt_fwd4096<1>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
+  else hipLaunchKernelGGL(k_ntt_fwd4096<0>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
+  return hipGetLastError();
+}
+
+hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, const uint64_t *mul,
+                                     uint64_t *dst, size_t rows, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn < kLogN) return hipErrorNotSupported;
+  const size_t blocks = rows << (s.logn - kLogN);
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const Tw64 *psi = (const Tw64 *)t.psi;
+  const MC64 *mc = (const MC64 *)t.mc;
+  const dim3 g((unsigned)blocks), b(kThreads);
+  const int v = s.small_delta ? variant() : variant() % 10;
+#define NFLHIP_INV(A)                                                                                                  \
+  if (mul) hipLaunchKernelGGL((k_ntt_inv4096<A, true>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);      \
+  else hipLaunchKernelGGL((k_ntt_inv4096<A, false>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);
+  if (v >= 20) { NFLHIP_INV(2) }
+  else if (v >= 10) { NFLHIP_INV(1) }
+  else { NFLHIP_INV(0) }
+#undef NFLHIP_INV
+  return hipGetLastError();
+}
+
 hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
                                    hipStream_t st) {
   if (!fast_shape(s)) return hipErrorNotSupported;
-  const size_t rows = batch * s.nm;
-  if (rows == 0) return hipSuccess;
-  if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  if (s.small_delta && variant() >= 30)
-    hipLaunchKernelGGL(k_ntt_fwd4096<3>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  else if (s.small_delta && variant() >= 20)
-    hipLaunchKernelGGL(k_ntt_fwd4096<2>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  else if (s.small_delta && variant() >= 10)
-    hipLaunchKernelGGL(k_ntt_fwd4096<1>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  else
-    hipLaunchKernelGGL(k_ntt_fwd4096<0>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  return hipGetLastError();
+  return launch_inner_fwd_fast_u64(s, t, src, dst, batch * s.nm, st);
 }
 
 hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
                                    hipStream_t st) {
   if (!fast_shape(s)) return hipErrorNotSupported;
-  const size_t rows = batch * s.nm;
-  if (rows == 0) return hipSuccess;
-  if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  if (s.small_delta && variant() >= 20)
-    hipLaunchKernelGGL(k_ntt_inv4096<2>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  else if (s.small_delta && variant() >= 10)
-    hipLaunchKernelGGL(k_ntt_inv4096<1>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  else
-    hipLaunchKernelGGL(k_ntt_inv4096<0>, dim3((unsigned)rows), dim3(kThreads), 0, st, src, dst, (const Tw64 *)t.psi,
-                       (const MC64 *)t.mc, (int)s.nm);
-  return hipGetLastError();
+  return launch_inner_inv_fast_u64(s, t, src, nullptr, dst, batch * s.nm, st);
 }
 
 }  // namespace nflhip

@@ -18,6 +18,8 @@
 #include "kernels.h"
 #include "modarith.h"
 
+#include <type_traits>
+
 namespace nflhip {
 
 static constexpr int kInnerLogMax = 12;  // rows up to 4096 words are transformed inside LDS
@@ -252,6 +254,10 @@ hipError_t launch_ntt_fwd(const Shape &s, const DevTables &t, const T *src, T *d
     cur = dst;
     done += R;
   }
+  if (std::is_same<T, uint64_t>::value && logi == kInnerLogMax) {  // register-tiled 4096-word blocks
+    hipError_t e = launch_inner_fwd_fast_u64(s, t, (const uint64_t *)cur, (uint64_t *)dst, rows, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   const unsigned nblk = (unsigned)(rows << (s.logn - logi));
   hipLaunchKernelGGL((k_ntt_fwd_lds<T>), dim3(nblk), dim3(lds_threads(logi)), sizeof(T) << logi, st, cur, dst,
                      (const Tw<T> *)t.psi, (const ModConst<T> *)t.mc, s.logn, logi, (int)s.nm);
@@ -264,10 +270,15 @@ hipError_t launch_ntt_inv(const Shape &s, const DevTables &t, const T *src, cons
   if (batch == 0) return hipSuccess;
   const size_t rows = batch * s.nm;
   const int logi = inner_log(s);
-  const unsigned nblk = (unsigned)(rows << (s.logn - logi));
-  hipLaunchKernelGGL((k_ntt_inv_lds<T>), dim3(nblk), dim3(lds_threads(logi)), sizeof(T) << logi, st, src, mul, dst,
-                     (const Tw<T> *)t.psi, (const ModConst<T> *)t.mc, s.logn, logi, (int)s.nm);
-  hipError_t e = hipGetLastError();
+  hipError_t e = hipErrorNotSupported;
+  if (std::is_same<T, uint64_t>::value && logi == kInnerLogMax)  // register-tiled 4096-word blocks
+    e = launch_inner_inv_fast_u64(s, t, (const uint64_t *)src, (const uint64_t *)mul, (uint64_t *)dst, rows, st);
+  if (e == hipErrorNotSupported) {
+    const unsigned nblk = (unsigned)(rows << (s.logn - logi));
+    hipLaunchKernelGGL((k_ntt_inv_lds<T>), dim3(nblk), dim3(lds_threads(logi)), sizeof(T) << logi, st, src, mul, dst,
+                       (const Tw<T> *)t.psi, (const ModConst<T> *)t.mc, s.logn, logi, (int)s.nm);
+    e = hipGetLastError();
+  }
   if (e != hipSuccess) return e;
   int top = s.logn - logi;  // global stages [0, top) remain, processed high to low
   while (top > 0) {
