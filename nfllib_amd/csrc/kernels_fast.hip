@@ -475,6 +475,46 @@ static int variant() {
   return v;
 }
 
+// ---- hand-scheduled assembly version (tools/gen_polymul_asm.py) ----------------------------
+static const unsigned char kPolymulHsaco[] = {
+#include "polymul4096_hsaco.inc"
+};
+struct AsmKernel {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  bool tried = false;
+};
+static AsmKernel g_asm[16];  // per device
+
+static hipFunction_t asm_polymul_fn() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  AsmKernel &k = g_asm[dev];
+  if (!k.tried) {
+    k.tried = true;
+    if (hipModuleLoadData(&k.mod, kPolymulHsaco) != hipSuccess ||
+        hipModuleGetFunction(&k.fn, k.mod, "nflhip_polymul4096_asm") != hipSuccess) {
+      k.fn = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  return k.fn;
+}
+
+static hipError_t launch_polymul_asm(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
+                                     size_t batch, hipStream_t st) {
+  hipFunction_t fn = asm_polymul_fn();
+  if (!fn) return hipErrorNotSupported;
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    int nm, pad;
+  } args = {c, a, b, t.psi, t.mc, (int)s.nm, 0};
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+}
+
 template <bool B_IS_NTT>
 static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                    unsigned rows, hipStream_t st) {
@@ -512,6 +552,10 @@ hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t 
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
+  if (!b_is_ntt && s.small_delta && variant() >= 50 && s.nm <= 65535) {
+    const hipError_t e = launch_polymul_asm(s, t, c, a, b, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   return b_is_ntt ? launch_polymul_v<true>(s, t, c, a, b, (unsigned)rows, st)
                   : launch_polymul_v<false>(s, t, c, a, b, (unsigned)rows, st);
 }

@@ -1,0 +1,582 @@
+#!/usr/bin/env python3
+"""Generate nfllib_amd/csrc/polymul4096_gfx950.s -- the hand-scheduled gfx950 assembly
+version of the metric kernel (fused c = INTT(NTT(a) (.) NTT(b)), u64, n = 4096).
+
+Same algorithm, thread mapping, LDS layout and device tables as k_polymul4096 in
+kernels_fast.hip (read that file's header first); what the generator adds over hipcc:
+
+  * every v_mad_u64_u32 addend pair is placed by construction (even-aligned VGPR pairs,
+    a persistent zero register behind the one zero-extended operand), so the ~1000
+    v_mov copies per wave that hipcc needs to build those pairs disappear;
+  * the 64-bit accumulate chains write straight into the coefficient registers
+    (no result moves), the Shoup low word and the "- (q << 62)" term are one
+    four-instruction v_mad_u64_u32 chain + one v_add_u32;
+  * two independent butterflies are interleaved instruction by instruction, which
+    covers the 2 wait states gfx950 needs between a VALU SGPR write (carry / borrow)
+    and the VALU that consumes it; a hazard tracker inserts s_nop where it does not;
+  * a's and b's forward passes share each pass's twiddle registers.
+
+Run:  python tools/gen_polymul_asm.py   (writes the .s; nfllib_amd/csrc/Makefile assembles it
+with clang -x assembler -mcpu=gfx950, links it with ld.lld and embeds the code object).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "nfllib_amd", "csrc", "polymul4096_gfx950.s")
+KNAME = "nflhip_polymul4096_asm"
+
+# ------------------------------------------------------------------ register map
+# SGPRs
+S_KARG = "s[0:1]"
+S_WGX, S_WGY = "s2", "s3"           # workgroup ids: x = poly index, y = modulus index
+S_C, S_A, S_B, S_PSI, S_MC = "s[4:5]", "s[6:7]", "s[8:9]", "s[10:11]", "s[12:13]"
+S_NM = "s14"
+S_AROW, S_BROW, S_CROW, S_TW = "s[16:17]", "s[18:19]", "s[20:21]", "s[22:23]"
+S_P, S_P2, S_P3 = "s[24:25]", "s[26:27]", "s[28:29]"
+S_DELTA, S_MASK, S_C0 = "s30", "s31", "s15"      # delta, 0x3fffffff, 0xC0000000
+S_MU2 = (32, 33)
+S_NINV, S_NINVSH, S_W1N, S_W1NSH = (34, 35), (36, 37), (38, 39), (40, 41)
+S_TMP = "s[42:43]"                   # scalar address scratch
+S_CARRY = ["s[44:45]", "s[46:47]"]   # v_mad_u64_u32 carry-out, per stream
+S_DUMMY = "s[48:49]"                 # dead carry-outs
+S_BORROW = ["s[50:51]", "s[52:53]"]  # v_sub_co borrow, per stream
+S_MCBUF = 56                         # s[56:83]: the ModConst record (28 dwords)
+S_BASE2 = "s[84:85]"                 # scalar base for twiddle loads with large constant offsets
+NEXT_SGPR = 96
+
+# VGPRs
+V_TID = 0
+V_OFF8 = 1        # tid*8 (global row offset)
+V_L1W = 2         # LDS byte address, E1 write / E1' read : (t + (t>>4))*8
+V_L1R = 3         # LDS byte address, E1 read / E2 write / E2' read / E1' write : (272*B + r)*8
+V_L2R = 4         # LDS byte address, E2 read / E2' write : 17*t*8
+V_TWA = 6         # v[6:7]: 64-bit per-lane twiddle address scratch
+V_TWO = 8         # 32-bit per-lane twiddle offset scratch
+V_A = 16          # v[16:47]  : a  (16 even-aligned pairs)
+V_B = 48          # v[48:79]  : b
+V_TW = 80         # v[80:139] : 15 twiddle records (w lo, w hi, w' lo, w' hi)
+V_T = [140, 160]  # per-stream temporaries (20 regs each)
+NEXT_VGPR = 180
+
+LDS_BYTES = (4096 + 256) * 8
+
+
+def vp(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def sp(pair):
+    return "s[%d:%d]" % pair
+
+
+class Emitter:
+    """Collects instructions, counts VALU work and pads the gfx950
+    'VALU writes SGPR -> VALU reads that SGPR: 2 wait states' hazard."""
+
+    def __init__(self):
+        self.lines = []
+        self.pos = 0
+        self.last_swrite = {}
+        self.n_valu = 0
+        self.n_nop = 0
+
+    def raw(self, text):
+        self.lines.append("\t" + text)
+        self.pos += 1
+
+    def comment(self, text):
+        self.lines.append("\t; " + text)
+
+    def valu(self, text, wr=None, rd=None):
+        if rd is not None and rd in self.last_swrite:
+            gap = self.pos - self.last_swrite[rd]
+            if gap < 3:
+                need = 3 - gap
+                self.lines.append("\ts_nop %d" % (need - 1))
+                self.pos += need
+                self.n_nop += 1
+        self.lines.append("\t" + text)
+        if wr is not None:
+            self.last_swrite[wr] = self.pos
+        self.pos += 1
+        self.n_valu += 1
+
+
+def interleave(em, gens):
+    """Round-robin the instruction streams of independent butterflies."""
+    gens = list(gens)
+    while gens:
+        for g in list(gens):
+            try:
+                text, wr, rd = next(g)
+                em.valu(text, wr, rd)
+            except StopIteration:
+                gens.remove(g)
+
+
+def run_pairs(em, jobs):
+    """jobs: list of callables(stream) -> generator; executed two at a time, interleaved."""
+    for i in range(0, len(jobs), 2):
+        gens = [jobs[i](0)]
+        if i + 1 < len(jobs):
+            gens.append(jobs[i + 1](1))
+        interleave(em, gens)
+
+
+# ------------------------------------------------------------------ arithmetic building blocks
+# temporaries of stream s (base T = V_T[s], all pairs even-aligned):
+#   T+0       t      scratch dword
+#   T+2,+3    P      (sum >> 32 | carry << 32) addend pair
+#   T+4,+5    U      folded x / 2U+3p
+#   T+6,+7    A      cross-product accumulator
+#   T+8,+9    Q      quotient
+#   T+10,+11  H      high-word accumulator (low dword used)
+#   T+12,+13  E      sum / 2p+y
+#   T+14,+15  D      difference
+#   T+16,+17  ZP     [mul_hi result, 0]  (T+17 is zeroed once and never written again)
+#   T+18,+19  L      point-wise low product
+
+def T(s, k):
+    return V_T[s] + k
+
+
+def quotient(s, y, tw, exact):
+    """Q = floor(y*w'/2^64) (exact) or that minus e, e in {0,1} (not exact). y = VGPR pair base of
+    the multiplicand; tw = (w0, w1, a0, a1) operand strings (VGPR or SGPR)."""
+    w0, w1, a0, a1 = tw
+    A, P, Q, ZP = T(s, 6), T(s, 2), T(s, 8), T(s, 16)
+    if exact:
+        yield "v_mul_hi_u32 v%d, v%d, %s" % (ZP, y, a0), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(A), S_DUMMY, y, a1, vp(ZP)), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(A), S_CARRY[s], y + 1, a0, vp(A)), S_CARRY[s], None
+    else:
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, 0" % (vp(A), S_DUMMY, y + 1, a0), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(A), S_CARRY[s], y, a1, vp(A)), S_CARRY[s], None
+    yield "v_mov_b32_e32 v%d, v%d" % (P, A + 1), None, None
+    yield "v_addc_co_u32_e64 v%d, %s, 0, 0, %s" % (P + 1, S_DUMMY, S_CARRY[s]), None, S_CARRY[s]
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(Q), S_DUMMY, y + 1, a1, vp(P)), None, None
+
+
+def lowchain(s, y, tw, acc, seed):
+    """acc = seed + y*w - Q*p (mod 2^64) using p = 2^62 - delta: y*w + Q*delta - (Q << 62)."""
+    w0, w1, a0, a1 = tw
+    Q, H = T(s, 8), T(s, 10)
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(acc), S_DUMMY, y, w0, seed), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(acc), S_DUMMY, Q, S_DELTA, vp(acc)), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, 0" % (vp(H), S_DUMMY, y, w1), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_DUMMY, y + 1, w0, vp(H)), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_DUMMY, Q + 1, S_DELTA, vp(H)), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_DUMMY, Q, S_C0, vp(H)), None, None
+    yield "v_add_u32_e32 v%d, v%d, v%d" % (acc + 1, acc + 1, H), None, None
+
+
+def fold2(s, dst, src):
+    """dst = (src & (2^62-1)) + (src >> 62)*delta  (< 2^62 + 3*delta); clobbers src's high dword."""
+    t = T(s, 0)
+    yield "v_lshrrev_b32_e32 v%d, 30, v%d" % (t, src + 1), None, None
+    yield "v_and_b32_e32 v%d, %s, v%d" % (src + 1, S_MASK, src + 1), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(dst), S_DUMMY, t, S_DELTA, vp(src)), None, None
+
+
+def ct_bfly(x, y, tw):
+    """Cooley-Tukey: x' = x + w*y, y' = x - w*y (any 64-bit words in, any 64-bit words out)."""
+    def gen(s):
+        U = T(s, 4)
+        yield from fold2(s, U, x)
+        yield from quotient(s, y, tw, exact=False)
+        yield from lowchain(s, y, tw, x, vp(U))                      # x' = U + m, m < 3p
+        yield "v_lshl_add_u64 %s, %s, 1, %s" % (vp(U), vp(U), S_P3), None, None
+        yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (y, S_BORROW[s], U, x), S_BORROW[s], None
+        yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (y + 1, S_DUMMY, U + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
+    return gen
+
+
+def gs_bfly(x, y, tw):
+    """Gentleman-Sande with the negated mirrored twiddle: x' = fold(x + y), y' = (y - x)*w; inputs < 2p."""
+    def gen(s):
+        E, D = T(s, 12), T(s, 14)
+        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(y), S_P2), None, None
+        yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (D, S_BORROW[s], E, x), S_BORROW[s], None
+        yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (D + 1, S_DUMMY, E + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
+        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(x), vp(y)), None, None
+        yield from fold2(s, x, E)
+        yield from quotient(s, D, tw, exact=True)
+        yield from lowchain(s, D, tw, y, "0")
+    return gen
+
+
+def csub_p(s, reg):
+    """reg = reg >= p ? reg - p : reg  (borrow trick)."""
+    E = T(s, 12)
+    yield "v_sub_co_u32_e64 v%d, %s, v%d, %s" % (E, S_BORROW[s], reg, "s24"), S_BORROW[s], None
+    # subb with an SGPR subtrahend needs it in src0 of the *rev* form: use a VGPR copy of p's high dword
+    yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (E + 1, S_BORROW[s], reg + 1, V_PHI, S_BORROW[s]), S_BORROW[s], S_BORROW[s]
+    yield "v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (reg, E, reg, S_BORROW[s]), None, S_BORROW[s]
+    yield "v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (reg + 1, E + 1, reg + 1, S_BORROW[s]), None, S_BORROW[s]
+
+
+V_PHI = 10  # VGPR copy of the high dword of p (set once)
+
+
+def final_bfly(x, y):
+    """Last inverse stage with n^-1 folded in; canonical outputs."""
+    tw_n = ("s%d" % S_NINV[0], "s%d" % S_NINV[1], "s%d" % S_NINVSH[0], "s%d" % S_NINVSH[1])
+    tw_w = ("s%d" % S_W1N[0], "s%d" % S_W1N[1], "s%d" % S_W1NSH[0], "s%d" % S_W1NSH[1])
+
+    def gen(s):
+        E, D = T(s, 12), T(s, 14)
+        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(y), S_P2), None, None
+        yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (D, S_BORROW[s], E, x), S_BORROW[s], None
+        yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (D + 1, S_DUMMY, E + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
+        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(x), vp(y)), None, None
+        yield from quotient(s, E, tw_n, exact=True)
+        yield from lowchain(s, E, tw_n, x, "0")
+        yield from csub_p(s, x)
+        yield from quotient(s, D, tw_w, exact=True)
+        yield from lowchain(s, D, tw_w, y, "0")
+        yield from csub_p(s, y)
+    return gen
+
+
+def pointwise(xa, xb):
+    """xa = fold2(xa*xb mod p) with lazily reduced operands (mul_lazy of kernels_fast.hip)."""
+    mu0, mu1 = "s%d" % S_MU2[0], "s%d" % S_MU2[1]
+
+    def gen(s):
+        L, A, P, Q, H, E, ZP = T(s, 18), T(s, 6), T(s, 2), T(s, 8), T(s, 10), T(s, 12), T(s, 16)
+        yield from fold2(s, xa, xa)
+        yield from fold2(s, xb, xb)
+        # T = xa*xb as four dwords: T0 = L.lo, T1 = A.lo, T2 = E.lo, T3 = E.hi
+        yield "v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(L), S_DUMMY, xa, xb), None, None
+        yield "v_mov_b32_e32 v%d, v%d" % (ZP, L + 1), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(A), S_DUMMY, xa, xb + 1, vp(ZP)), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(A), S_CARRY[s], xa + 1, xb, vp(A)), S_CARRY[s], None
+        yield "v_mov_b32_e32 v%d, v%d" % (P, A + 1), None, None
+        yield "v_addc_co_u32_e64 v%d, %s, 0, 0, %s" % (P + 1, S_DUMMY, S_CARRY[s]), None, S_CARRY[s]
+        yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(E), S_DUMMY, xa + 1, xb + 1, vp(P)), None, None
+        # th = T >> 61 -> D pair
+        D = T(s, 14)
+        yield "v_alignbit_b32 v%d, v%d, v%d, 29" % (D, E, A), None, None
+        yield "v_alignbit_b32 v%d, v%d, v%d, 29" % (D + 1, E + 1, E), None, None
+        # q ~ floor(th*mu2/2^64), one-off allowed (r < 4p, folded below)
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, 0" % (vp(H), S_DUMMY, D + 1, mu0), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_CARRY[s], D, mu1, vp(H)), S_CARRY[s], None
+        yield "v_mov_b32_e32 v%d, v%d" % (P, H + 1), None, None
+        yield "v_addc_co_u32_e64 v%d, %s, 0, 0, %s" % (P + 1, S_DUMMY, S_CARRY[s]), None, S_CARRY[s]
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(Q), S_DUMMY, D + 1, mu1, vp(P)), None, None
+        # r = lo64(T) + q*delta - (q << 62)
+        yield "v_mov_b32_e32 v%d, v%d" % (L + 1, A), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(L), S_DUMMY, Q, S_DELTA, vp(L)), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, 0" % (vp(H), S_DUMMY, Q + 1, S_DELTA), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_DUMMY, Q, S_C0, vp(H)), None, None
+        yield "v_add_u32_e32 v%d, v%d, v%d" % (L + 1, L + 1, H), None, None
+        yield from fold2(s, xa, L)
+    return gen
+
+
+# ------------------------------------------------------------------ passes
+def twreg(i):
+    b = V_TW + 4 * i
+    return ("v%d" % b, "v%d" % (b + 1), "v%d" % (b + 2), "v%d" % (b + 3))
+
+
+def tw_slot(s, g):
+    return (1 << s) - 1 + g          # 15 records: sub-stage s (0..3), group g (0..2^s-1)
+
+
+def ct16(em, base_regs, both):
+    """Radix-16 forward register pass over the 16 pairs at base (+ the same for b when both)."""
+    for s in range(4):
+        half = 8 >> s
+        jobs = []
+        for g in range(1 << s):
+            tw = twreg(tw_slot(s, g))
+            for h in range(half):
+                i0 = g * 2 * half + h
+                for base in base_regs:
+                    jobs.append(ct_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
+        run_pairs(em, jobs)
+
+
+def gs16(em, base, last_plain=True, stages=(3, 2, 1, 0)):
+    for s in stages:
+        half = 8 >> s
+        jobs = []
+        for g in range(1 << s):
+            tw = twreg(tw_slot(s, g))
+            for h in range(half):
+                i0 = g * 2 * half + h
+                jobs.append(gs_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
+        run_pairs(em, jobs)
+
+
+def load_tw_uniform(em, first_index_of_stage):
+    """15 twiddle records at wave-uniform indices first_index_of_stage(s) + g (s = 0..3)."""
+    for s in range(4):
+        idx0 = first_index_of_stage(s)
+        for g in range(1 << s):
+            off = (idx0 + g) * 16
+            assert 0 <= off < 4096
+            em.raw("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
+                                                                         V_ZERO, S_TW, off))
+
+
+V_ZERO = 11   # a VGPR holding 0 (uniform twiddle loads use it as the per-lane offset)
+
+
+def load_tw_lane(em, vidx, scale_shift, const_of_stage, descending):
+    """Per-lane twiddle records.  Ascending (forward):  index = const(s) + (vidx << s) + g.
+    Descending (inverse, mirrored): index = const(s) - (vidx << s) - g.
+    vidx is a VGPR holding the lane's block index (B or t)."""
+    for s in range(4):
+        cbytes = const_of_stage(s) * 16
+        # scalar base = tw + cbytes
+        em.raw("s_add_u32 s84, s22, 0x%x" % (cbytes & 0xffffffff))
+        em.raw("s_addc_u32 s85, s23, 0")
+        em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
+        if not descending:
+            for g in range(1 << s):
+                em.raw("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
+                                                                             V_TWO, S_BASE2, g * 16))
+        else:
+            # 64-bit per-lane address = base - offset
+            em.valu("v_mov_b32_e32 v%d, s84" % (V_TWA,))
+            em.valu("v_mov_b32_e32 v%d, s85" % (V_TWA + 1,))
+            em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (V_TWA, V_TWA, V_TWO), "vcc", None)
+            em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (V_TWA + 1, V_TWA + 1), "vcc", "vcc")
+            for g in range(1 << s):
+                em.raw("global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
+                                                                            vp(V_TWA), -g * 16))
+
+
+def lds_write(em, addr, base, stride):
+    for k in range(16):
+        em.raw("ds_write_b64 v%d, %s offset:%d" % (addr, vp(base + 2 * k), stride * k))
+
+
+def lds_read(em, addr, base, stride):
+    for k in range(16):
+        em.raw("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), addr, stride * k))
+
+
+def build():
+    em = Emitter()
+    R = em.raw
+    # ---------------- prologue
+    R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
+    R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
+    R("s_load_dword s14, s[0:1], 0x28")                  # nm
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_TWO, V_TID))                      # B = t >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_TWO))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
+    em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
+    em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_TWO, V_L2R, V_L1R))      # 272*B + r
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
+    em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
+    em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
+    em.valu("v_mov_b32_e32 v%d, 0" % (V_ZERO,))
+    em.valu("v_mov_b32_e32 v12, v%d" % (V_TWO,))                                    # keep B in v12
+    for s in (0, 1):
+        em.valu("v_mov_b32_e32 v%d, 0" % (T(s, 17),))                               # the persistent zero of ZP
+    R("s_waitcnt lgkmcnt(0)")
+    # row = wgx*nm + wgy ; byte offset = row << 15
+    R("s_mul_i32 s42, s2, s14")
+    R("s_add_u32 s42, s42, s3")
+    R("s_lshr_b32 s43, s42, 17")
+    R("s_lshl_b32 s42, s42, 15")
+    for base, row in ((6, 16), (8, 18), (4, 20)):
+        R("s_add_u32 s%d, s%d, s42" % (row, base))
+        R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    # tw = psi + (cm << 16) ; mc record = mc + cm*112
+    R("s_lshl_b32 s42, s3, 16")
+    R("s_add_u32 s22, s10, s42")
+    R("s_addc_u32 s23, s11, 0")
+    R("s_mul_i32 s42, s3, 112")
+    R("s_add_u32 s42, s12, s42")
+    R("s_addc_u32 s43, s13, 0")
+    R("s_load_dwordx16 s[56:71], s[42:43], 0x0")          # p p2 mu ninv ninv_sh w1ninv w1ninv_sh beta
+    R("s_load_dwordx8 s[72:79], s[42:43], 0x40")          # beta_sh yinv yinv_sh mask
+    R("s_load_dwordx4 s[80:83], s[42:43], 0x60")          # delta mu2
+    # global loads: a, F1 twiddles, b
+    def row_loads(dst_base, srow):
+        R("s_mov_b64 %s, %s" % (S_TMP, srow))
+        for k in range(16):
+            R("global_load_dwordx2 %s, v%d, %s offset:%d" % (vp(dst_base + 2 * k), V_OFF8, S_TMP, (k & 1) * 2048))
+            if k & 1:
+                R("s_add_u32 s42, s42, 0x1000")
+                R("s_addc_u32 s43, s43, 0")
+    row_loads(V_A, S_AROW)
+    load_tw_uniform(em, lambda s: (1 << s))
+    row_loads(V_B, S_BROW)
+    R("s_waitcnt lgkmcnt(0)")
+    # constants from the ModConst record
+    R("s_mov_b64 s[24:25], s[56:57]")                    # p
+    R("s_mov_b64 s[26:27], s[58:59]")                    # 2p
+    R("s_add_u32 s28, s58, s56")                         # 3p
+    R("s_addc_u32 s29, s59, s57")
+    R("s_mov_b32 s30, s80")                              # delta
+    R("s_mov_b32 s31, 0x3fffffff")
+    R("s_mov_b32 s15, 0xc0000000")
+    R("s_mov_b64 s[32:33], s[82:83]")                    # mu2
+    R("s_mov_b64 s[34:35], s[62:63]")                    # ninv
+    R("s_mov_b64 s[36:37], s[64:65]")                    # ninv_sh
+    R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
+    R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
+    em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+    R("s_waitcnt vmcnt(0)")
+
+    # ---------------- forward: a and b share each pass's twiddles
+    em.comment("F1: stages 0-3 (wave-uniform twiddles)")
+    ct16(em, [V_A, V_B], both=True)
+    em.comment("prefetch F2 twiddles: psi[(16<<s) + (B<<s) + g]")
+    load_tw_lane(em, 12, 0, lambda s: (16 << s), descending=False)
+    em.comment("E1(a)")
+    lds_write(em, V_L1W, V_A, 2176)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    lds_read(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    em.comment("E1(b)")
+    lds_write(em, V_L1W, V_B, 2176)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    lds_read(em, V_L1R, V_B, 136)
+    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    em.comment("F2: stages 4-7")
+    ct16(em, [V_A, V_B], both=True)
+    em.comment("prefetch F3 twiddles: psi[(256<<s) + (t<<s) + g]")
+    load_tw_lane(em, V_TID, 0, lambda s: (256 << s), descending=False)
+    em.comment("E2(a), E2(b): wave-local 16-lane transposes (LDS is in order per wave)")
+    lds_write(em, V_L1R, V_A, 136)
+    lds_read(em, V_L2R, V_A, 8)
+    R("s_waitcnt lgkmcnt(0)")
+    lds_write(em, V_L1R, V_B, 136)
+    lds_read(em, V_L2R, V_B, 8)
+    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    em.comment("F3: stages 8-11")
+    ct16(em, [V_A, V_B], both=True)
+    em.comment("prefetch I1 twiddles: psi[(512<<s) - 1 - ((t<<s) + g)]")
+    load_tw_lane(em, V_TID, 0, lambda s: (512 << s) - 1, descending=True)
+
+    # ---------------- point-wise product into a
+    em.comment("point-wise product")
+    run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i) for i in range(16)])
+    R("s_waitcnt vmcnt(0)")
+
+    # ---------------- inverse
+    em.comment("I1: stages 11..8")
+    gs16(em, V_A)
+    em.comment("prefetch I2 twiddles: psi[(32<<s) - 1 - ((B<<s) + g)]")
+    load_tw_lane(em, 12, 0, lambda s: (32 << s) - 1, descending=True)
+    em.comment("E2'")
+    lds_write(em, V_L2R, V_A, 8)
+    lds_read(em, V_L1R, V_A, 136)
+    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    em.comment("I2: stages 7..4")
+    gs16(em, V_A)
+    em.comment("prefetch I3 twiddles (uniform): psi[(2<<s) - 1 - g]")
+    for s in range(4):
+        for g in range(1 << s):
+            idx = (2 << s) - 1 - g
+            R("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
+                                                                    V_ZERO, S_TW, idx * 16))
+    em.comment("E1'")
+    lds_write(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    lds_read(em, V_L1W, V_A, 2176)
+    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    em.comment("I3: stages 3..1, then stage 0 with n^-1 folded in")
+    gs16(em, V_A, stages=(3, 2, 1))
+    run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
+    # ---------------- store c
+    R("s_mov_b64 %s, %s" % (S_TMP, S_CROW))
+    for k in range(16):
+        R("global_store_dwordx2 v%d, %s, %s offset:%d" % (V_OFF8, vp(V_A + 2 * k), S_TMP, (k & 1) * 2048))
+        if k & 1:
+            R("s_add_u32 s42, s42, 0x1000")
+            R("s_addc_u32 s43, s43, 0")
+    R("s_endpgm")
+    return em
+
+
+HEADER = """\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.amdhsa_code_object_version 6
+\t.text
+\t.globl\t%(k)s
+\t.p2align\t8
+\t.type\t%(k)s,@function
+%(k)s:
+"""
+
+FOOTER = """.Lfunc_end0:
+\t.size\t%(k)s, .Lfunc_end0-%(k)s
+\t.rodata
+\t.p2align\t6
+\t.amdhsa_kernel %(k)s
+\t\t.amdhsa_group_segment_fixed_size %(lds)d
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size 48
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 1
+\t\t.amdhsa_system_sgpr_workgroup_id_z 0
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr %(vgpr)d
+\t\t.amdhsa_next_free_sgpr %(sgpr)d
+\t\t.amdhsa_accum_offset %(accum)d
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+\t.amdgpu_metadata
+---
+amdhsa.kernels:
+  - .args:
+      - {.address_space: global, .offset: 0, .size: 8, .value_kind: global_buffer}
+      - {.address_space: global, .offset: 8, .size: 8, .value_kind: global_buffer}
+      - {.address_space: global, .offset: 16, .size: 8, .value_kind: global_buffer}
+      - {.address_space: global, .offset: 24, .size: 8, .value_kind: global_buffer}
+      - {.address_space: global, .offset: 32, .size: 8, .value_kind: global_buffer}
+      - {.offset: 40, .size: 4, .value_kind: by_value}
+      - {.offset: 44, .size: 4, .value_kind: by_value}
+    .group_segment_fixed_size: %(lds)d
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 48
+    .max_flat_workgroup_size: 256
+    .name:           %(k)s
+    .private_segment_fixed_size: 0
+    .sgpr_count:     %(sgprc)d
+    .symbol:         %(k)s.kd
+    .vgpr_count:     %(vgpr)d
+    .wavefront_size: 64
+amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+\t.end_amdgpu_metadata
+"""
+
+
+def main():
+    em = build()
+    accum = (NEXT_VGPR + 3) // 4 * 4
+    params = dict(k=KNAME, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6)
+    with open(OUT, "w") as f:
+        f.write("; GENERATED by tools/gen_polymul_asm.py -- do not edit.\n")
+        f.write(HEADER % params)
+        f.write("\n".join(em.lines) + "\n")
+        f.write(FOOTER % params)
+    print("wrote %s: %d VALU instructions per wave, %d hazard nops, %d lines" % (OUT, em.n_valu, em.n_nop, len(em.lines)))
+
+
+if __name__ == "__main__":
+    main()
