@@ -470,7 +470,7 @@ static int variant() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("NFLHIP_VARIANT");
-    v = e ? atoi(e) : 32;
+    v = e ? atoi(e) : 52;
   }
   return v;
 }
