@@ -193,7 +193,7 @@ def main():
                    "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "k_polymul4096<false>" if args.workload == "B" else "composed",
+                     "kernel": "nflhip_polymul4096_asm" if args.workload == "B" else "composed",
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

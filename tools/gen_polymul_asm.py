@@ -51,13 +51,17 @@ V_OFF8 = 1        # tid*8 (global row offset)
 V_L1W = 2         # LDS byte address, E1 write / E1' read : (t + (t>>4))*8
 V_L1R = 3         # LDS byte address, E1 read / E2 write / E2' read / E1' write : (272*B + r)*8
 V_L2R = 4         # LDS byte address, E2 read / E2' write : 17*t*8
-V_TWA = 6         # v[6:7]: 64-bit per-lane twiddle address scratch
-V_TWO = 8         # 32-bit per-lane twiddle offset scratch
-V_A = 16          # v[16:47]  : a  (16 even-aligned pairs)
-V_B = 48          # v[48:79]  : b
-V_TW = 80         # v[80:139] : 15 twiddle records (w lo, w hi, w' lo, w' hi)
-V_T = [140, 160]  # per-stream temporaries (20 regs each)
-NEXT_VGPR = 180
+V_BIDX = 5        # B = t >> 4
+V_PHI = 6         # high dword of p (v_subb needs it in a VGPR)
+V_A = 8           # v[8:39]    : a  (16 even-aligned pairs)
+V_B = 40          # v[40:71]   : b
+V_TW = 72         # v[72:131]  : 15 twiddle records (w lo, w hi, w' lo, w' hi)
+V_T = [132, 150]  # per-stream temporaries (18 regs each)
+NEXT_VGPR = 168   # 3 waves per SIMD
+# address scratch lives in stream 1's temporaries (idle between butterflies)
+V_TWO = V_T[1] + 1      # 32-bit per-lane twiddle offset
+V_TWA = V_T[1] + 4      # 64-bit per-lane twiddle address
+V_ZERO = V_T[0] + 15    # a persistent zero (the high half of stream 0's ZP pair)
 
 LDS_BYTES = (4096 + 256) * 8
 
@@ -128,14 +132,13 @@ def run_pairs(em, jobs):
 # temporaries of stream s (base T = V_T[s], all pairs even-aligned):
 #   T+0       t      scratch dword
 #   T+2,+3    P      (sum >> 32 | carry << 32) addend pair
-#   T+4,+5    U      folded x / 2U+3p
+#   T+4,+5    U / D  folded x, 2U+3p (CT)  /  difference (GS, final, point-wise)
 #   T+6,+7    A      cross-product accumulator
 #   T+8,+9    Q      quotient
 #   T+10,+11  H      high-word accumulator (low dword used)
 #   T+12,+13  E      sum / 2p+y
-#   T+14,+15  D      difference
-#   T+16,+17  ZP     [mul_hi result, 0]  (T+17 is zeroed once and never written again)
-#   T+18,+19  L      point-wise low product
+#   T+14,+15  ZP     [mul_hi result, 0]  (T+15 is zeroed once and never written again)
+#   T+16,+17  L      point-wise low product
 
 def T(s, k):
     return V_T[s] + k
@@ -145,7 +148,7 @@ def quotient(s, y, tw, exact):
     """Q = floor(y*w'/2^64) (exact) or that minus e, e in {0,1} (not exact). y = VGPR pair base of
     the multiplicand; tw = (w0, w1, a0, a1) operand strings (VGPR or SGPR)."""
     w0, w1, a0, a1 = tw
-    A, P, Q, ZP = T(s, 6), T(s, 2), T(s, 8), T(s, 16)
+    A, P, Q, ZP = T(s, 6), T(s, 2), T(s, 8), T(s, 14)
     if exact:
         yield "v_mul_hi_u32 v%d, v%d, %s" % (ZP, y, a0), None, None
         yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(A), S_DUMMY, y, a1, vp(ZP)), None, None
@@ -195,7 +198,7 @@ def ct_bfly(x, y, tw):
 def gs_bfly(x, y, tw):
     """Gentleman-Sande with the negated mirrored twiddle: x' = fold(x + y), y' = (y - x)*w; inputs < 2p."""
     def gen(s):
-        E, D = T(s, 12), T(s, 14)
+        E, D = T(s, 12), T(s, 4)
         yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(y), S_P2), None, None
         yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (D, S_BORROW[s], E, x), S_BORROW[s], None
         yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (D + 1, S_DUMMY, E + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
@@ -216,7 +219,6 @@ def csub_p(s, reg):
     yield "v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (reg + 1, E + 1, reg + 1, S_BORROW[s]), None, S_BORROW[s]
 
 
-V_PHI = 10  # VGPR copy of the high dword of p (set once)
 
 
 def final_bfly(x, y):
@@ -225,7 +227,7 @@ def final_bfly(x, y):
     tw_w = ("s%d" % S_W1N[0], "s%d" % S_W1N[1], "s%d" % S_W1NSH[0], "s%d" % S_W1NSH[1])
 
     def gen(s):
-        E, D = T(s, 12), T(s, 14)
+        E, D = T(s, 12), T(s, 4)
         yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(y), S_P2), None, None
         yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (D, S_BORROW[s], E, x), S_BORROW[s], None
         yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (D + 1, S_DUMMY, E + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
@@ -244,7 +246,7 @@ def pointwise(xa, xb):
     mu0, mu1 = "s%d" % S_MU2[0], "s%d" % S_MU2[1]
 
     def gen(s):
-        L, A, P, Q, H, E, ZP = T(s, 18), T(s, 6), T(s, 2), T(s, 8), T(s, 10), T(s, 12), T(s, 16)
+        L, A, P, Q, H, E, ZP = T(s, 16), T(s, 6), T(s, 2), T(s, 8), T(s, 10), T(s, 12), T(s, 14)
         yield from fold2(s, xa, xa)
         yield from fold2(s, xb, xb)
         # T = xa*xb as four dwords: T0 = L.lo, T1 = A.lo, T2 = E.lo, T3 = E.hi
@@ -256,7 +258,7 @@ def pointwise(xa, xb):
         yield "v_addc_co_u32_e64 v%d, %s, 0, 0, %s" % (P + 1, S_DUMMY, S_CARRY[s]), None, S_CARRY[s]
         yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(E), S_DUMMY, xa + 1, xb + 1, vp(P)), None, None
         # th = T >> 61 -> D pair
-        D = T(s, 14)
+        D = T(s, 4)
         yield "v_alignbit_b32 v%d, v%d, v%d, 29" % (D, E, A), None, None
         yield "v_alignbit_b32 v%d, v%d, v%d, 29" % (D + 1, E + 1, E), None, None
         # q ~ floor(th*mu2/2^64), one-off allowed (r < 4p, folded below)
@@ -285,69 +287,80 @@ def tw_slot(s, g):
     return (1 << s) - 1 + g          # 15 records: sub-stage s (0..3), group g (0..2^s-1)
 
 
-def ct16(em, base_regs, both):
-    """Radix-16 forward register pass over the 16 pairs at base (+ the same for b when both)."""
-    for s in range(4):
-        half = 8 >> s
-        jobs = []
+class VmCounter:
+    """In-order VMEM load bookkeeping for counted s_waitcnt vmcnt(N)."""
+
+    def __init__(self, em):
+        self.em = em
+        self.issued = 0
+
+    def load(self, text):
+        self.em.raw(text)
+        self.issued += 1
+        return self.issued
+
+    def wait(self, seq):
+        """Block until load number `seq` (and every earlier one) has landed."""
+        n = self.issued - seq
+        assert 0 <= n
+        self.em.raw("s_waitcnt vmcnt(%d)" % min(n, 63))
+
+
+def ct_stage(em, bases, s):
+    half = 8 >> s
+    jobs = []
+    for g in range(1 << s):
+        tw = twreg(tw_slot(s, g))
+        for h in range(half):
+            i0 = g * 2 * half + h
+            for base in bases:
+                jobs.append(ct_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
+    run_pairs(em, jobs)
+
+
+def gs_stage(em, base, s):
+    half = 8 >> s
+    jobs = []
+    for g in range(1 << s):
+        tw = twreg(tw_slot(s, g))
+        for h in range(half):
+            i0 = g * 2 * half + h
+            jobs.append(gs_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
+    run_pairs(em, jobs)
+
+
+def tw_uniform_stage(em, vm, s, idx_of_g):
+    """Twiddle records of sub-stage s at wave-uniform indices idx_of_g(g)."""
+    seq = 0
+    for g in range(1 << s):
+        off = idx_of_g(g) * 16
+        assert 0 <= off < 4096
+        r = V_TW + 4 * tw_slot(s, g)
+        seq = vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_ZERO, S_TW, off))
+    return seq
+
+
+def tw_lane_stage(em, vm, s, vidx, const, descending):
+    """Per-lane twiddle records of sub-stage s.  Ascending (forward): index = const + (vidx << s) + g.
+    Descending (inverse, mirrored): index = const - (vidx << s) - g.  vidx: VGPR with B or t."""
+    cbytes = const * 16
+    em.raw("s_add_u32 s84, s22, 0x%x" % (cbytes & 0xffffffff))
+    em.raw("s_addc_u32 s85, s23, 0")
+    em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
+    seq = 0
+    if not descending:
         for g in range(1 << s):
-            tw = twreg(tw_slot(s, g))
-            for h in range(half):
-                i0 = g * 2 * half + h
-                for base in base_regs:
-                    jobs.append(ct_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
-        run_pairs(em, jobs)
-
-
-def gs16(em, base, last_plain=True, stages=(3, 2, 1, 0)):
-    for s in stages:
-        half = 8 >> s
-        jobs = []
+            r = V_TW + 4 * tw_slot(s, g)
+            seq = vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_TWO, S_BASE2, g * 16))
+    else:
+        em.valu("v_mov_b32_e32 v%d, s84" % (V_TWA,))
+        em.valu("v_mov_b32_e32 v%d, s85" % (V_TWA + 1,))
+        em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (V_TWA, V_TWA, V_TWO), "vcc", None)
+        em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (V_TWA + 1, V_TWA + 1), "vcc", "vcc")
         for g in range(1 << s):
-            tw = twreg(tw_slot(s, g))
-            for h in range(half):
-                i0 = g * 2 * half + h
-                jobs.append(gs_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
-        run_pairs(em, jobs)
-
-
-def load_tw_uniform(em, first_index_of_stage):
-    """15 twiddle records at wave-uniform indices first_index_of_stage(s) + g (s = 0..3)."""
-    for s in range(4):
-        idx0 = first_index_of_stage(s)
-        for g in range(1 << s):
-            off = (idx0 + g) * 16
-            assert 0 <= off < 4096
-            em.raw("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
-                                                                         V_ZERO, S_TW, off))
-
-
-V_ZERO = 11   # a VGPR holding 0 (uniform twiddle loads use it as the per-lane offset)
-
-
-def load_tw_lane(em, vidx, scale_shift, const_of_stage, descending):
-    """Per-lane twiddle records.  Ascending (forward):  index = const(s) + (vidx << s) + g.
-    Descending (inverse, mirrored): index = const(s) - (vidx << s) - g.
-    vidx is a VGPR holding the lane's block index (B or t)."""
-    for s in range(4):
-        cbytes = const_of_stage(s) * 16
-        # scalar base = tw + cbytes
-        em.raw("s_add_u32 s84, s22, 0x%x" % (cbytes & 0xffffffff))
-        em.raw("s_addc_u32 s85, s23, 0")
-        em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
-        if not descending:
-            for g in range(1 << s):
-                em.raw("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
-                                                                             V_TWO, S_BASE2, g * 16))
-        else:
-            # 64-bit per-lane address = base - offset
-            em.valu("v_mov_b32_e32 v%d, s84" % (V_TWA,))
-            em.valu("v_mov_b32_e32 v%d, s85" % (V_TWA + 1,))
-            em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (V_TWA, V_TWA, V_TWO), "vcc", None)
-            em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (V_TWA + 1, V_TWA + 1), "vcc", "vcc")
-            for g in range(1 << s):
-                em.raw("global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
-                                                                            vp(V_TWA), -g * 16))
+            r = V_TW + 4 * tw_slot(s, g)
+            seq = vm.load("global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (r, r + 3, vp(V_TWA), -g * 16))
+    return seq
 
 
 def lds_write(em, addr, base, stride):
@@ -360,27 +373,37 @@ def lds_read(em, addr, base, stride):
         em.raw("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), addr, stride * k))
 
 
+# twiddle index of (pass, sub-stage s, group g); see fwd_head / fwd_tail / inv_core of kernels_fast.hip
+PASS_TW = {
+    "F1": lambda em, vm, s: tw_uniform_stage(em, vm, s, lambda g: (1 << s) + g),
+    "F2": lambda em, vm, s: tw_lane_stage(em, vm, s, V_BIDX, 16 << s, False),
+    "F3": lambda em, vm, s: tw_lane_stage(em, vm, s, V_TID, 256 << s, False),
+    "I1": lambda em, vm, s: tw_lane_stage(em, vm, s, V_TID, (512 << s) - 1, True),
+    "I2": lambda em, vm, s: tw_lane_stage(em, vm, s, V_BIDX, (32 << s) - 1, True),
+    "I3": lambda em, vm, s: tw_uniform_stage(em, vm, s, lambda g: (2 << s) - 1 - g),
+}
+
+
 def build():
     em = Emitter()
+    vm = VmCounter(em)
     R = em.raw
     # ---------------- prologue
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
     R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
     R("s_load_dword s14, s[0:1], 0x28")                  # nm
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
-    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_TWO, V_TID))                      # B = t >> 4
-    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_TWO))
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                     # B = t >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
     em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
     em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
-    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_TWO, V_L2R, V_L1R))      # 272*B + r
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_BIDX, V_L2R, V_L1R))     # 272*B + r
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
     em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
     em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
-    em.valu("v_mov_b32_e32 v%d, 0" % (V_ZERO,))
-    em.valu("v_mov_b32_e32 v12, v%d" % (V_TWO,))                                    # keep B in v12
     for s in (0, 1):
-        em.valu("v_mov_b32_e32 v%d, 0" % (T(s, 17),))                               # the persistent zero of ZP
+        em.valu("v_mov_b32_e32 v%d, 0" % (T(s, 15),))                               # the persistent zero of ZP
     R("s_waitcnt lgkmcnt(0)")
     # row = wgx*nm + wgy ; byte offset = row << 15
     R("s_mul_i32 s42, s2, s14")
@@ -394,23 +417,27 @@ def build():
     R("s_lshl_b32 s42, s3, 16")
     R("s_add_u32 s22, s10, s42")
     R("s_addc_u32 s23, s11, 0")
-    R("s_mul_i32 s42, s3, 112")
+    R("s_mul_i32 s42, s3, 0x70")
     R("s_add_u32 s42, s12, s42")
     R("s_addc_u32 s43, s13, 0")
     R("s_load_dwordx16 s[56:71], s[42:43], 0x0")          # p p2 mu ninv ninv_sh w1ninv w1ninv_sh beta
     R("s_load_dwordx8 s[72:79], s[42:43], 0x40")          # beta_sh yinv yinv_sh mask
     R("s_load_dwordx4 s[80:83], s[42:43], 0x60")          # delta mu2
-    # global loads: a, F1 twiddles, b
+
     def row_loads(dst_base, srow):
-        R("s_mov_b64 %s, %s" % (S_TMP, srow))
+        seq = 0
+        R("s_mov_b64 s[86:87], %s" % (srow,))
         for k in range(16):
-            R("global_load_dwordx2 %s, v%d, %s offset:%d" % (vp(dst_base + 2 * k), V_OFF8, S_TMP, (k & 1) * 2048))
+            seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d" % (vp(dst_base + 2 * k), V_OFF8, (k & 1) * 2048))
             if k & 1:
-                R("s_add_u32 s42, s42, 0x1000")
-                R("s_addc_u32 s43, s43, 0")
-    row_loads(V_A, S_AROW)
-    load_tw_uniform(em, lambda s: (1 << s))
-    row_loads(V_B, S_BROW)
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+        return seq
+    seq_a = row_loads(V_A, S_AROW)
+    seq_b = row_loads(V_B, S_BROW)
+    tw_seq = {}
+    for s in range(4):
+        tw_seq[("F1", s)] = PASS_TW["F1"](em, vm, s)
     R("s_waitcnt lgkmcnt(0)")
     # constants from the ModConst record
     R("s_mov_b64 s[24:25], s[56:57]")                    # p
@@ -426,13 +453,24 @@ def build():
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
-    R("s_waitcnt vmcnt(0)")
 
-    # ---------------- forward: a and b share each pass's twiddles
-    em.comment("F1: stages 0-3 (wave-uniform twiddles)")
-    ct16(em, [V_A, V_B], both=True)
-    em.comment("prefetch F2 twiddles: psi[(16<<s) + (B<<s) + g]")
-    load_tw_lane(em, 12, 0, lambda s: (16 << s), descending=False)
+    def fwd_pass(name, nxt):
+        em.comment("%s (a and b share the twiddles); prefetching %s" % (name, nxt))
+        for s in range(4):
+            vm.wait(tw_seq[(name, s)])
+            ct_stage(em, [V_A, V_B], s)
+            tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
+
+    def inv_pass(name, nxt, stages=(3, 2, 1, 0)):
+        em.comment("%s; prefetching %s" % (name, nxt))
+        for s in stages:
+            vm.wait(tw_seq[(name, s)])
+            gs_stage(em, V_A, s)
+            if nxt is not None and not (nxt == "I3" and s == 0):
+                tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
+
+    # ---------------- forward
+    fwd_pass("F1", "F2")
     em.comment("E1(a)")
     lds_write(em, V_L1W, V_A, 2176)
     R("s_waitcnt lgkmcnt(0)")
@@ -445,61 +483,43 @@ def build():
     R("s_waitcnt lgkmcnt(0)")
     R("s_barrier")
     lds_read(em, V_L1R, V_B, 136)
-    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    em.comment("F2: stages 4-7")
-    ct16(em, [V_A, V_B], both=True)
-    em.comment("prefetch F3 twiddles: psi[(256<<s) + (t<<s) + g]")
-    load_tw_lane(em, V_TID, 0, lambda s: (256 << s), descending=False)
+    R("s_waitcnt lgkmcnt(0)")
+    fwd_pass("F2", "F3")
     em.comment("E2(a), E2(b): wave-local 16-lane transposes (LDS is in order per wave)")
     lds_write(em, V_L1R, V_A, 136)
     lds_read(em, V_L2R, V_A, 8)
-    R("s_waitcnt lgkmcnt(0)")
     lds_write(em, V_L1R, V_B, 136)
     lds_read(em, V_L2R, V_B, 8)
-    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    em.comment("F3: stages 8-11")
-    ct16(em, [V_A, V_B], both=True)
-    em.comment("prefetch I1 twiddles: psi[(512<<s) - 1 - ((t<<s) + g)]")
-    load_tw_lane(em, V_TID, 0, lambda s: (512 << s) - 1, descending=True)
+    R("s_waitcnt lgkmcnt(0)")
+    fwd_pass("F3", "I1")
 
     # ---------------- point-wise product into a
     em.comment("point-wise product")
     run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i) for i in range(16)])
-    R("s_waitcnt vmcnt(0)")
 
     # ---------------- inverse
-    em.comment("I1: stages 11..8")
-    gs16(em, V_A)
-    em.comment("prefetch I2 twiddles: psi[(32<<s) - 1 - ((B<<s) + g)]")
-    load_tw_lane(em, 12, 0, lambda s: (32 << s) - 1, descending=True)
+    inv_pass("I1", "I2")
     em.comment("E2'")
     lds_write(em, V_L2R, V_A, 8)
     lds_read(em, V_L1R, V_A, 136)
-    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    em.comment("I2: stages 7..4")
-    gs16(em, V_A)
-    em.comment("prefetch I3 twiddles (uniform): psi[(2<<s) - 1 - g]")
-    for s in range(4):
-        for g in range(1 << s):
-            idx = (2 << s) - 1 - g
-            R("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (V_TW + 4 * tw_slot(s, g), V_TW + 4 * tw_slot(s, g) + 3,
-                                                                    V_ZERO, S_TW, idx * 16))
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I2", "I3")
     em.comment("E1'")
     lds_write(em, V_L1R, V_A, 136)
     R("s_waitcnt lgkmcnt(0)")
     R("s_barrier")
     lds_read(em, V_L1W, V_A, 2176)
-    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    em.comment("I3: stages 3..1, then stage 0 with n^-1 folded in")
-    gs16(em, V_A, stages=(3, 2, 1))
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I3", None, stages=(3, 2, 1))
+    em.comment("stage 0 with n^-1 folded in")
     run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
     # ---------------- store c
-    R("s_mov_b64 %s, %s" % (S_TMP, S_CROW))
+    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
     for k in range(16):
-        R("global_store_dwordx2 v%d, %s, %s offset:%d" % (V_OFF8, vp(V_A + 2 * k), S_TMP, (k & 1) * 2048))
+        R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (V_OFF8, vp(V_A + 2 * k), (k & 1) * 2048))
         if k & 1:
-            R("s_add_u32 s42, s42, 0x1000")
-            R("s_addc_u32 s43, s43, 0")
+            R("s_add_u32 s86, s86, 0x1000")
+            R("s_addc_u32 s87, s87, 0")
     R("s_endpgm")
     return em
 
