@@ -221,6 +221,9 @@ def test_full_size_properties_metric_shape(oracle_factory, engine_factory):
     c = e.polymul(a, b)
     # commutativity, and INTT(NTT(a)) == a over the whole batch
     assert not e.any_neq(c, e.polymul(b, a))
+    # two independent device code paths must agree word for word on the whole batch: the
+    # hand-scheduled assembly kernel (polymul) vs the hipcc-compiled kernel (b already in NTT form)
+    assert not e.any_neq(c, e.polymul(a, e.ntt_(b.clone()), b_is_ntt=True))
     rt = e.intt_(e.ntt_(a.clone()))
     assert not e.any_neq(rt, a)
     # linearity: (a+b)*b == a*b + b*b
