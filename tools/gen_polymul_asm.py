@@ -161,16 +161,20 @@ def quotient(s, y, tw, exact):
     yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(Q), S_DUMMY, y + 1, a1, vp(P)), None, None
 
 
-def lowchain(s, y, tw, acc, seed):
-    """acc = seed + y*w - Q*p (mod 2^64) using p = 2^62 - delta: y*w + Q*delta - (Q << 62)."""
+def lowchain(s, y, tw, acc, seed, after_low=None):
+    """acc = seed + y*w - Q*p (mod 2^64) using p = 2^62 - delta: y*w + Q*delta - (Q << 62).
+    The high-dword terms are accumulated first; after_low is an instruction that needs only
+    acc's LOW dword and may overwrite y's low dword (slotted in once both are settled)."""
     w0, w1, a0, a1 = tw
     Q, H = T(s, 8), T(s, 10)
-    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(acc), S_DUMMY, y, w0, seed), None, None
-    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(acc), S_DUMMY, Q, S_DELTA, vp(acc)), None, None
     yield "v_mad_u64_u32 %s, %s, v%d, %s, 0" % (vp(H), S_DUMMY, y, w1), None, None
     yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_DUMMY, y + 1, w0, vp(H)), None, None
     yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_DUMMY, Q + 1, S_DELTA, vp(H)), None, None
     yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), S_DUMMY, Q, S_C0, vp(H)), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(acc), S_DUMMY, y, w0, seed), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(acc), S_DUMMY, Q, S_DELTA, vp(acc)), None, None
+    if after_low is not None:
+        yield after_low
     yield "v_add_u32_e32 v%d, v%d, v%d" % (acc + 1, acc + 1, H), None, None
 
 
@@ -185,25 +189,27 @@ def fold2(s, dst, src):
 def ct_bfly(x, y, tw):
     """Cooley-Tukey: x' = x + w*y, y' = x - w*y (any 64-bit words in, any 64-bit words out)."""
     def gen(s):
-        U = T(s, 4)
+        U, Y2 = T(s, 4), T(s, 12)
         yield from fold2(s, U, x)
         yield from quotient(s, y, tw, exact=False)
-        yield from lowchain(s, y, tw, x, vp(U))                      # x' = U + m, m < 3p
-        yield "v_lshl_add_u64 %s, %s, 1, %s" % (vp(U), vp(U), S_P3), None, None
-        yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (y, S_BORROW[s], U, x), S_BORROW[s], None
-        yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (y + 1, S_DUMMY, U + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
+        yield "v_lshl_add_u64 %s, %s, 1, %s" % (vp(Y2), vp(U), S_P3), None, None
+        # x' = U + m (m < 3p) lands in x; y' = (2U + 3p) - x'.  The low-dword subtract is issued as soon as
+        # x' low is final, so its borrow is old enough when v_subb consumes it (no hazard nop).
+        sub_lo = ("v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (y, S_BORROW[s], Y2, x), S_BORROW[s], None)
+        yield from lowchain(s, y, tw, x, vp(U), after_low=sub_lo)
+        yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (y + 1, S_DUMMY, Y2 + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
     return gen
 
 
 def gs_bfly(x, y, tw):
     """Gentleman-Sande with the negated mirrored twiddle: x' = fold(x + y), y' = (y - x)*w; inputs < 2p."""
     def gen(s):
-        E, D = T(s, 12), T(s, 4)
+        E, D, SUM = T(s, 12), T(s, 4), T(s, 16)
         yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(y), S_P2), None, None
         yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (D, S_BORROW[s], E, x), S_BORROW[s], None
+        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(SUM), vp(x), vp(y)), None, None
         yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (D + 1, S_DUMMY, E + 1, x + 1, S_BORROW[s]), None, S_BORROW[s]
-        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(x), vp(y)), None, None
-        yield from fold2(s, x, E)
+        yield from fold2(s, x, SUM)
         yield from quotient(s, D, tw, exact=True)
         yield from lowchain(s, D, tw, y, "0")
     return gen
