@@ -264,6 +264,23 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn > 12) {
+    // large rows: streaming outer passes, then the fused assembly kernel over the 4096-word blocks,
+    // then the outer inverse passes (9 operand streams of HBM traffic instead of 13)
+    const size_t rows = batch * ctx->shape.nm;
+    e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, (const uint64_t *)a, (uint64_t *)s0, rows, st);
+    if (e == hipSuccess) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, (const uint64_t *)b, (uint64_t *)s1, rows, st);
+    if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer forward");
+    e = launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)s0, (const uint64_t *)s1, batch, st);
+    if (e == hipSuccess) {
+      e = launch_outer_inv_u64(ctx->shape, ctx->tabs, (uint64_t *)c, rows, st);
+      if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer inverse");
+      e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return hipfail(ctx, e, "polymul: sync");
+      return NFLHIP_OK;
+    }
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul: fused blocks");
+  }
   e = launch_ntt_fwd<T>(ctx->shape, ctx->tabs, a, s0, batch, st);
   if (e != hipSuccess) return hipfail(ctx, e, "polymul: ntt(a)");
   if (!b_is_ntt) {

@@ -86,4 +86,14 @@ hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const u
 hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, const uint64_t *mul,
                                      uint64_t *dst, size_t rows, hipStream_t st);
 
+// streaming outer passes alone (rows with logn > 12): forward src -> dst, inverse in place
+hipError_t launch_outer_fwd_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t rows,
+                                hipStream_t st);
+hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *data, size_t rows, hipStream_t st);
+// fused NTT,NTT,(.),INTT over the 4096-word blocks of rows whose outer forward passes already ran
+// (a_in, b_in) and whose outer inverse passes still have to run on c (logn > 12), or the whole
+// polymul for logn == 12.  hipErrorNotSupported when the assembly code object is unavailable.
+hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
+                                         const uint64_t *b_in, size_t batch, hipStream_t st);
+
 }  // namespace nflhip

@@ -508,11 +508,20 @@ static hipError_t launch_polymul_asm(const Shape &s, const DevTables &t, uint64_
   struct {
     void *c;
     const void *a, *b, *psi, *mc;
-    int nm, pad;
-  } args = {c, a, b, t.psi, t.mc, (int)s.nm, 0};
+    int nm, logn;
+  } args = {c, a, b, t.psi, t.mc, (int)s.nm, s.logn};
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+  const size_t gx = batch << (s.logn - kLogN);  // one workgroup per 4096-word block
+  if (gx > 0x7fffffffull) return hipErrorInvalidValue;
+  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+}
+
+hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
+                                         const uint64_t *b_in, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn < kLogN || !s.small_delta || s.nm > 65535 || variant() < 50) return hipErrorNotSupported;
+  if (batch == 0) return hipSuccess;
+  return launch_polymul_asm(s, t, c, a_in, b_in, batch, st);
 }
 
 template <bool B_IS_NTT>

@@ -239,14 +239,13 @@ static hipError_t outer_inv(const Shape &s, const DevTables &t, const T *src, T 
   return hipGetLastError();
 }
 
+// all streaming forward passes (global stages [0, logn - logi)): src -> dst, then in place on dst
 template <typename T>
-hipError_t launch_ntt_fwd(const Shape &s, const DevTables &t, const T *src, T *dst, size_t batch, hipStream_t st) {
-  if (batch == 0) return hipSuccess;
-  const size_t rows = batch * s.nm;
+static hipError_t outer_fwd_all(const Shape &s, const DevTables &t, const T *src, T *dst, size_t rows, hipStream_t st) {
   const int logi = inner_log(s);
   int done = 0;
   const T *cur = src;
-  while (done < s.logn - logi) {  // streaming passes over the large strides
+  while (done < s.logn - logi) {
     const int rem = s.logn - logi - done;
     const int R = rem >= 4 ? 4 : rem;
     hipError_t e = outer_fwd<T>(s, t, cur, dst, rows, done, R, st);
@@ -254,6 +253,36 @@ hipError_t launch_ntt_fwd(const Shape &s, const DevTables &t, const T *src, T *d
     cur = dst;
     done += R;
   }
+  return hipSuccess;
+}
+// all streaming inverse passes (global stages logn - logi - 1 .. 0), in place
+template <typename T>
+static hipError_t outer_inv_all(const Shape &s, const DevTables &t, T *data, size_t rows, hipStream_t st) {
+  int top = s.logn - inner_log(s);
+  while (top > 0) {
+    const int R = top >= 4 ? 4 : top;
+    hipError_t e = outer_inv<T>(s, t, data, data, rows, top - R, R, st);
+    if (e != hipSuccess) return e;
+    top -= R;
+  }
+  return hipSuccess;
+}
+hipError_t launch_outer_fwd_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t rows,
+                                hipStream_t st) {
+  return outer_fwd_all<uint64_t>(s, t, src, dst, rows, st);
+}
+hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *data, size_t rows, hipStream_t st) {
+  return outer_inv_all<uint64_t>(s, t, data, rows, st);
+}
+
+template <typename T>
+hipError_t launch_ntt_fwd(const Shape &s, const DevTables &t, const T *src, T *dst, size_t batch, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const size_t rows = batch * s.nm;
+  const int logi = inner_log(s);
+  hipError_t oe = outer_fwd_all<T>(s, t, src, dst, rows, st);
+  if (oe != hipSuccess) return oe;
+  const T *cur = s.logn > logi ? dst : src;
   if (std::is_same<T, uint64_t>::value && logi == kInnerLogMax) {  // register-tiled 4096-word blocks
     hipError_t e = launch_inner_fwd_fast_u64(s, t, (const uint64_t *)cur, (uint64_t *)dst, rows, st);
     if (e != hipErrorNotSupported) return e;
@@ -280,14 +309,7 @@ hipError_t launch_ntt_inv(const Shape &s, const DevTables &t, const T *src, cons
     e = hipGetLastError();
   }
   if (e != hipSuccess) return e;
-  int top = s.logn - logi;  // global stages [0, top) remain, processed high to low
-  while (top > 0) {
-    const int R = top >= 4 ? 4 : top;
-    e = outer_inv<T>(s, t, dst, dst, rows, top - R, R, st);
-    if (e != hipSuccess) return e;
-    top -= R;
-  }
-  return hipSuccess;
+  return outer_inv_all<T>(s, t, dst, rows, st);  // global stages [0, logn - logi) remain, high to low
 }
 
 // ---------------------------------------------------------------------------

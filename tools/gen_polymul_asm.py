@@ -42,7 +42,10 @@ S_CARRY = ["s[44:45]", "s[46:47]"]   # v_mad_u64_u32 carry-out, per stream
 S_DUMMY = "s[48:49]"                 # dead carry-outs
 S_BORROW = ["s[50:51]", "s[52:53]"]  # v_sub_co borrow, per stream
 S_MCBUF = 56                         # s[56:83]: the ModConst record (28 dwords)
-S_BASE2 = "s[84:85]"                 # scalar base for twiddle loads with large constant offsets
+S_BASE2 = "s[84:85]"                 # scalar base of the current twiddle loads
+S_R, S_BLK = "s88", "s89"            # r = logn - 12, blk = index of this 4096-word block inside its row
+# K of each pass: twiddle index = (K << s) + (lane << s) + g (forward) / (K << s) - 1 - (lane << s) - g (inverse)
+S_K = {"F1": "s90", "F2": "s91", "F3": "s92", "I1": "s93", "I2": "s94", "I3": "s95"}
 NEXT_SGPR = 96
 
 # VGPRs
@@ -335,23 +338,31 @@ def gs_stage(em, base, s):
     run_pairs(em, jobs)
 
 
-def tw_uniform_stage(em, vm, s, idx_of_g):
-    """Twiddle records of sub-stage s at wave-uniform indices idx_of_g(g)."""
+def tw_base(em, kreg, s, descending):
+    """s[84:85] = tw + 16 * ((K << s) [- 1])"""
+    em.raw("s_lshl_b32 s86, %s, %d" % (kreg, s))
+    if descending:
+        em.raw("s_sub_u32 s86, s86, 1")
+    em.raw("s_lshl_b32 s86, s86, 4")
+    em.raw("s_add_u32 s84, s22, s86")
+    em.raw("s_addc_u32 s85, s23, 0")
+
+
+def tw_uniform_stage(em, vm, s, kreg, descending):
+    """Twiddle records of sub-stage s at wave-uniform indices (K << s) + g  /  (K << s) - 1 - g."""
+    tw_base(em, kreg, s, descending)
     seq = 0
     for g in range(1 << s):
-        off = idx_of_g(g) * 16
-        assert 0 <= off < 4096
         r = V_TW + 4 * tw_slot(s, g)
-        seq = vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_ZERO, S_TW, off))
+        off = -g * 16 if descending else g * 16
+        seq = vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_ZERO, S_BASE2, off))
     return seq
 
 
-def tw_lane_stage(em, vm, s, vidx, const, descending):
-    """Per-lane twiddle records of sub-stage s.  Ascending (forward): index = const + (vidx << s) + g.
-    Descending (inverse, mirrored): index = const - (vidx << s) - g.  vidx: VGPR with B or t."""
-    cbytes = const * 16
-    em.raw("s_add_u32 s84, s22, 0x%x" % (cbytes & 0xffffffff))
-    em.raw("s_addc_u32 s85, s23, 0")
+def tw_lane_stage(em, vm, s, vidx, kreg, descending):
+    """Per-lane twiddle records of sub-stage s.  Ascending (forward): index = (K << s) + (vidx << s) + g.
+    Descending (inverse, mirrored): index = (K << s) - 1 - (vidx << s) - g.  vidx: VGPR with B or t."""
+    tw_base(em, kreg, s, descending)
     em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
     seq = 0
     if not descending:
@@ -379,14 +390,16 @@ def lds_read(em, addr, base, stride):
         em.raw("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), addr, stride * k))
 
 
-# twiddle index of (pass, sub-stage s, group g); see fwd_head / fwd_tail / inv_core of kernels_fast.hip
+# twiddle index of (pass, sub-stage s, group g); see fwd_head / fwd_tail / inv_core of kernels_fast.hip:
+# with Kf = 2^r + blk the forward passes use K = Kf, 16*Kf, 256*Kf; the mirrored inverse passes use
+# K = (512<<r) - 256*blk, (32<<r) - 16*blk, (2<<r) - blk.
 PASS_TW = {
-    "F1": lambda em, vm, s: tw_uniform_stage(em, vm, s, lambda g: (1 << s) + g),
-    "F2": lambda em, vm, s: tw_lane_stage(em, vm, s, V_BIDX, 16 << s, False),
-    "F3": lambda em, vm, s: tw_lane_stage(em, vm, s, V_TID, 256 << s, False),
-    "I1": lambda em, vm, s: tw_lane_stage(em, vm, s, V_TID, (512 << s) - 1, True),
-    "I2": lambda em, vm, s: tw_lane_stage(em, vm, s, V_BIDX, (32 << s) - 1, True),
-    "I3": lambda em, vm, s: tw_uniform_stage(em, vm, s, lambda g: (2 << s) - 1 - g),
+    "F1": lambda em, vm, s: tw_uniform_stage(em, vm, s, S_K["F1"], False),
+    "F2": lambda em, vm, s: tw_lane_stage(em, vm, s, V_BIDX, S_K["F2"], False),
+    "F3": lambda em, vm, s: tw_lane_stage(em, vm, s, V_TID, S_K["F3"], False),
+    "I1": lambda em, vm, s: tw_lane_stage(em, vm, s, V_TID, S_K["I1"], True),
+    "I2": lambda em, vm, s: tw_lane_stage(em, vm, s, V_BIDX, S_K["I2"], True),
+    "I3": lambda em, vm, s: tw_uniform_stage(em, vm, s, S_K["I3"], True),
 }
 
 
@@ -398,6 +411,7 @@ def build():
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
     R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
     R("s_load_dword s14, s[0:1], 0x28")                  # nm
+    R("s_load_dword s88, s[0:1], 0x2c")                  # logn
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
     em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                     # B = t >> 4
     em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
@@ -411,18 +425,38 @@ def build():
     for s in (0, 1):
         em.valu("v_mov_b32_e32 v%d, 0" % (T(s, 15),))                               # the persistent zero of ZP
     R("s_waitcnt lgkmcnt(0)")
-    # row = wgx*nm + wgy ; byte offset = row << 15
-    R("s_mul_i32 s42, s2, s14")
-    R("s_add_u32 s42, s42, s3")
+    # r = logn - 12; wgx = poly * 2^r + blk; block = ((poly*nm + cm) << r) + blk; byte offset = block << 15
+    R("s_sub_u32 s88, s88, 12")
+    R("s_lshr_b32 s42, s2, s88")                         # poly
+    R("s_lshl_b32 s43, s42, s88")
+    R("s_sub_u32 s89, s2, s43")                          # blk
+    R("s_mul_i32 s42, s42, s14")
+    R("s_add_u32 s42, s42, s3")                          # row
+    R("s_lshl_b32 s42, s42, s88")
+    R("s_add_u32 s42, s42, s89")                         # block index
     R("s_lshr_b32 s43, s42, 17")
     R("s_lshl_b32 s42, s42, 15")
     for base, row in ((6, 16), (8, 18), (4, 20)):
         R("s_add_u32 s%d, s%d, s42" % (row, base))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
-    # tw = psi + (cm << 16) ; mc record = mc + cm*112
-    R("s_lshl_b32 s42, s3, 16")
+    # tw = psi + (cm << (logn + 4)) ; mc record = mc + cm*112
+    R("s_add_u32 s43, s88, 16")
+    R("s_lshl_b32 s42, s3, s43")
     R("s_add_u32 s22, s10, s42")
     R("s_addc_u32 s23, s11, 0")
+    # pass constants K
+    R("s_lshl_b32 s90, 1, s88")
+    R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
+    R("s_lshl_b32 s91, s90, 4")
+    R("s_lshl_b32 s92, s90, 8")
+    R("s_lshl_b32 s93, 0x200, s88")
+    R("s_lshl_b32 s42, s89, 8")
+    R("s_sub_u32 s93, s93, s42")                         # (512<<r) - 256*blk
+    R("s_lshl_b32 s94, 32, s88")
+    R("s_lshl_b32 s42, s89, 4")
+    R("s_sub_u32 s94, s94, s42")                         # (32<<r) - 16*blk
+    R("s_lshl_b32 s95, 2, s88")
+    R("s_sub_u32 s95, s95, s89")                         # (2<<r) - blk
     R("s_mul_i32 s42, s3, 0x70")
     R("s_add_u32 s42, s12, s42")
     R("s_addc_u32 s43, s13, 0")
@@ -472,7 +506,7 @@ def build():
         for s in stages:
             vm.wait(tw_seq[(name, s)])
             gs_stage(em, V_A, s)
-            if nxt is not None and not (nxt == "I3" and s == 0):
+            if nxt is not None:
                 tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
 
     # ---------------- forward
@@ -517,8 +551,17 @@ def build():
     lds_read(em, V_L1W, V_A, 2176)
     R("s_waitcnt lgkmcnt(0)")
     inv_pass("I3", None, stages=(3, 2, 1))
-    em.comment("stage 0 with n^-1 folded in")
+    R("s_cmp_eq_u32 s88, 0")
+    R("s_cbranch_scc1 .Lmerged_last_stage")
+    em.comment("r > 0: plain stage r (uniform twiddle psi[(2<<r) - 1 - blk]); lazy output for the outer passes")
+    vm.wait(tw_seq[("I3", 0)])
+    gs_stage(em, V_A, 0)
+    R("s_branch .Lstore")
+    em.lines.append(".Lmerged_last_stage:")
+    em.comment("r == 0: stage 0 with n^-1 folded in")
+    R("s_waitcnt vmcnt(0)")
     run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
+    em.lines.append(".Lstore:")
     # ---------------- store c
     R("s_mov_b64 s[86:87], %s" % (S_CROW,))
     for k in range(16):
