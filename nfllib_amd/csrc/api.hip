@@ -145,7 +145,9 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   const size_t Lacc = c->shape.crt_Lacc;
   c->h_Q = Q;
   c->h_Q.resize(c->shape.crt_L, 0);
-  std::vector<uint64_t> qhat(nm * Lacc, 0), qsh(6 * Lacc, 0);
+  const size_t kStride = 36;  // fixed, zero-padded row stride of the device CRT tables
+  const bool crt_ok = Lacc <= kStride;  // beyond that crt_lift reports NFLHIP_ERR_UNSUPPORTED, the transforms still work
+  std::vector<uint64_t> qhat(nm * kStride, 0), qsh(6 * kStride, 0);
   std::vector<uint64_t> yinv(nm, 0);
   c->h_lifting.resize(nm);
   for (size_t cm = 0; cm < nm; ++cm) {
@@ -153,12 +155,12 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     big_divrem_u64(Q, P[cm], &quot);                       // Q / p_cm            (mpz_divexact)
     const uint64_t qmod = big_divrem_u64(quot, P[cm], nullptr);
     yinv[cm] = powmod_h(qmod, P[cm] - 2, P[cm]);           // (Q/p_cm)^-1 mod p_cm (mpz_invert)
-    for (size_t k = 0; k < quot.size(); ++k) qhat[cm * Lacc + k] = quot[k];
+    for (size_t k = 0; crt_ok && k < quot.size(); ++k) qhat[cm * kStride + k] = quot[k];
     c->h_lifting[cm] = big_mul_u64(quot, yinv[cm]);        // lifting_integers[cm] (gmp.hpp:149-150)
   }
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; crt_ok && k < 6; ++k) {
     Big sh = big_shl(Q, k, Lacc);
-    for (size_t i = 0; i < Lacc; ++i) qsh[k * Lacc + i] = sh[i];
+    for (size_t i = 0; i < Lacc; ++i) qsh[k * kStride + i] = sh[i];
   }
 
   // twiddles + per-modulus constants

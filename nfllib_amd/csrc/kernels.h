@@ -96,4 +96,10 @@ hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *da
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                          const uint64_t *b_in, size_t batch, hipStream_t st);
 
+// register-resident CRT kernels for 64-bit limbs (kernels_crt.hip); hipErrorNotSupported otherwise
+hipError_t launch_crt_lift_fast_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,
+                                    hipStream_t st);
+hipError_t launch_crt_project_fast_u64(const Shape &s, const DevTables &t, uint64_t *d, const uint64_t *limbs, size_t L_in,
+                                       size_t batch, hipStream_t st);
+
 }  // namespace nflhip

@@ -426,7 +426,7 @@ hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t 
 //   X = sum_cm (Q/p_cm) * ((x(cm,i) * (Q/p_cm)^-1) mod p_cm)   (< nm*Q)
 // followed by conditional subtractions of Q<<k.  One thread per coefficient.
 // ---------------------------------------------------------------------------
-static constexpr int kCrtMaxLimbs = 36;
+static constexpr int kCrtMaxLimbs = 36;  // also the row stride of the qhat / qsh tables
 
 template <typename T>
 __global__ void k_crt_lift(uint64_t *out, const T *d, const ModConst<T> *__restrict__ mc,
@@ -441,7 +441,7 @@ __global__ void k_crt_lift(uint64_t *out, const T *d, const ModConst<T> *__restr
     const ModConst<T> c = mc[cm];
     const T x = d[((b * nm + cm) << logn) + i];
     const uint64_t y = (uint64_t)mul_shoup<T>(x, c.yinv, c.yinv_sh, c.p);
-    const uint64_t *qh = qhat + (size_t)cm * Lacc;
+    const uint64_t *qh = qhat + (size_t)cm * kCrtMaxLimbs;
     uint64_t carry = 0;
     for (int k = 0; k < Lacc; ++k) {  // acc += qhat[cm] * y
       const uint64_t lo = qh[k] * y, hi = __umul64hi(qh[k], y);
@@ -454,7 +454,7 @@ __global__ void k_crt_lift(uint64_t *out, const T *d, const ModConst<T> *__restr
     }
   }
   for (int sft = 5; sft >= 0; --sft) {  // acc < 32*Q: subtract Q<<5 .. Q<<0 when possible
-    const uint64_t *qs = qsh + (size_t)sft * Lacc;
+    const uint64_t *qs = qsh + (size_t)sft * kCrtMaxLimbs;
     bool ge = true;
     for (int k = Lacc - 1; k >= 0; --k) {
       if (acc[k] != qs[k]) { ge = acc[k] > qs[k]; break; }
@@ -476,6 +476,10 @@ __global__ void k_crt_lift(uint64_t *out, const T *d, const ModConst<T> *__restr
 template <typename T>
 hipError_t launch_crt_lift(const Shape &s, const DevTables &t, uint64_t *limbs, const T *d, size_t batch, hipStream_t st) {
   if (batch == 0) return hipSuccess;
+  if (std::is_same<T, uint64_t>::value) {
+    hipError_t e = launch_crt_lift_fast_u64(s, t, limbs, (const uint64_t *)d, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if ((int)s.crt_Lacc > kCrtMaxLimbs || s.nm > 32) return hipErrorNotSupported;
   const size_t ncoef = batch * s.n;
   hipLaunchKernelGGL((k_crt_lift<T>), dim3((unsigned)((ncoef + 127) / 128)), dim3(128), 0, st, limbs, d,
@@ -518,6 +522,10 @@ template <typename T>
 hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const uint64_t *limbs, size_t L_in, size_t batch,
                               hipStream_t st) {
   if (batch == 0) return hipSuccess;
+  if (std::is_same<T, uint64_t>::value) {
+    hipError_t e = launch_crt_project_fast_u64(s, t, (uint64_t *)d, limbs, L_in, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   const size_t total = batch * s.nm * s.n;
   hipLaunchKernelGGL((k_crt_project<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, limbs,
                      (const ModConst<T> *)t.mc, s.logn, (int)s.nm, (int)L_in, total);
