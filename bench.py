@@ -74,24 +74,19 @@ def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0):
     best = ref or port
     out = {"value": round(best["value"], 2), "unit": "polymul/s", "cores": 1, "kind": "reference" if ref else "port",
            "sample": best["sample"], "port_value": round(port["value"], 2)}
-    # socket-level figure for an honest comparison: the same port on every
-    # host thread, polys are independent (ctypes releases the GIL around the C call)
+    # socket-level figure for an honest comparison: the same port with the batch split
+    # over every host thread (native pthreads inside the oracle library; polys are independent)
     try:
-        from concurrent.futures import ThreadPoolExecutor
         nthreads = os.cpu_count() or 1
-        a, b = gen(16, SEED, 0), gen(16, SEED, 1)
-        reps = max(1, int(budget_s * 0.5 * port["value"] / 16))
-
-        def work(_):
-            for _ in range(reps):
-                o.polymul(a, b)
-            return 16 * reps
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(nthreads) as ex:
-            total = sum(ex.map(work, range(nthreads)))
-        dt = time.perf_counter() - t0
-        out["all_cores"] = {"value": round(total / dt, 1), "cores": nthreads, "kind": "port",
-                            "sample": "%d polymuls on %d threads in %.1f s" % (total, nthreads, dt)}
+        nb = max(nthreads * 4, 256)
+        a, b = gen(nb, SEED, 0), gen(nb, SEED, 1)
+        o.polymul_mt(a, b, nthreads)
+        done, t_used = 0, 0.0
+        while t_used < max(2.0, budget_s * 0.4):
+            t0 = time.perf_counter(); o.polymul_mt(a, b, nthreads); t_used += time.perf_counter() - t0
+            done += nb
+        out["all_cores"] = {"value": round(done / t_used, 1), "cores": nthreads, "kind": "port",
+                            "sample": "%d polymuls on %d pthreads in %.1f s" % (done, nthreads, t_used)}
     except Exception as e:
         out["all_cores"] = {"value": None, "cores": 0, "sample": "failed: %r" % (e,)}
     try:
@@ -112,6 +107,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="polys per GPU (default: workload default)")
     ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel secondary rates")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -182,6 +178,41 @@ def main():
         except Exception:
             traffic = None
 
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # secondary rates of SURVEY.md 8(d): per-kernel transforms, point-wise ops, the
+        # "one operand pre-transformed" product and CRT lift/project (same batch, same stream)
+        from nfllib_amd import OP_ADD, OP_MUL
+
+        def rate(fn, reps=10):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3
+        w = lb // 8
+        tr_bytes, pw_bytes = 2 * nm * n * w * batch, 3 * nm * n * w * batch
+        bn = eng.ntt_(b.clone())
+        t_f = rate(lambda: eng.ntt_(c)); t_i = rate(lambda: eng.intt_(c))
+        t_add = rate(lambda: eng.pointwise(OP_ADD, a, b, out=c)); t_mul = rate(lambda: eng.pointwise(OP_MUL, a, b, out=c))
+        t_pn = rate(lambda: eng.polymul(a, bn, out=c, b_is_ntt=True))
+        sub = min(batch, 2048)
+        limbs = eng.crt_lift(a[:sub])
+        t_l = rate(lambda: eng.crt_lift(a[:sub]), 5); t_p = rate(lambda: eng.crt_project(limbs), 5)
+        crt_bytes = sub * (nm * n * w + n * eng.crt_limbs * 8)
+        extras = {
+            "ntt_fwd_per_s": round(batch / t_f, 1), "ntt_fwd_GBs": round(tr_bytes / t_f / 1e9, 1),
+            "ntt_inv_per_s": round(batch / t_i, 1), "ntt_inv_GBs": round(tr_bytes / t_i / 1e9, 1),
+            "pointwise_add_GBs": round(pw_bytes / t_add / 1e9, 1), "pointwise_mul_GBs": round(pw_bytes / t_mul / 1e9, 1),
+            "polymul_b_pretransformed_per_s": round(batch / t_pn, 1),
+            "crt_lift_per_s": round(sub / t_l, 1), "crt_lift_GBs": round(crt_bytes / t_l / 1e9, 1),
+            "crt_project_per_s": round(sub / t_p, 1), "crt_project_GBs": round(crt_bytes / t_p / 1e9, 1),
+            "note": "GB/s are algorithmic bytes (SURVEY.md 8(d)) / event time; polys per second over the same batch",
+        }
+        del bn, limbs
+
     result = {
         "metric": "poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli" if args.workload == "B"
                   else "poly-mults/sec (NTT+pointwise+INTT), n=%d, %dx62-bit moduli" % (n, nm),
@@ -196,6 +227,8 @@ def main():
                      "kernel": "nflhip_polymul4096_asm" if args.workload == "B" else "composed",
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
+    if extras is not None:
+        result["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(lb, n, nm, args.cpu_budget)

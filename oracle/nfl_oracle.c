@@ -7,6 +7,7 @@
  */
 #include "nfl_oracle.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -356,6 +357,42 @@ void nfl_oracle_polymul(const nfl_oracle_ctx *c, void *out, const void *a, const
   nfl_oracle_invntt_pow_invphi(c, out, batch);
   free(ta);
   free(tb);
+}
+
+/* the same polymul over a batch split across host threads (polys are independent); used only by
+ * bench.py's socket-level CPU figure */
+typedef struct {
+  const nfl_oracle_ctx *c;
+  char *out;
+  const char *a, *b;
+  size_t batch;
+} mt_job;
+static void *mt_worker(void *arg) {
+  mt_job *j = (mt_job *)arg;
+  if (j->batch) nfl_oracle_polymul(j->c, j->out, j->a, j->b, j->batch);
+  return NULL;
+}
+void nfl_oracle_polymul_mt(const nfl_oracle_ctx *c, void *out, const void *a, const void *b, size_t batch,
+                           int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if ((size_t)nthreads > batch) nthreads = (int)(batch ? batch : 1);
+  const size_t pbytes = c->nm * c->n * (size_t)(c->limb_bits / 8);
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)nthreads);
+  size_t start = 0;
+  for (int t = 0; t < nthreads; t++) {
+    size_t cnt = batch / (size_t)nthreads + ((size_t)t < batch % (size_t)nthreads ? 1 : 0);
+    jobs[t].c = c;
+    jobs[t].out = (char *)out + start * pbytes;
+    jobs[t].a = (const char *)a + start * pbytes;
+    jobs[t].b = (const char *)b + start * pbytes;
+    jobs[t].batch = cnt;
+    start += cnt;
+    pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  free(th);
+  free(jobs);
 }
 
 int nfl_oracle_any_eq(const nfl_oracle_ctx *c, const void *a, const void *b, size_t batch) {

@@ -66,6 +66,8 @@ void nfl_oracle_pointwise(const nfl_oracle_ctx *ctx, int op, void *out, const vo
                           const void *b, const void *bprime, size_t batch);
 /* a.ntt_pow_phi(); b.ntt_pow_phi(); c = a*b; c.invntt_pow_invphi()  (poly.hpp:167-168,350) */
 void nfl_oracle_polymul(const nfl_oracle_ctx *ctx, void *c, const void *a, const void *b, size_t batch);
+/* nfl_oracle_polymul with the batch split over `nthreads` host threads (bench.py's socket-level figure) */
+void nfl_oracle_polymul_mt(const nfl_oracle_ctx *ctx, void *c, const void *a, const void *b, size_t batch, int nthreads);
 /* expr::operator bool over eqmod / neqmod (ops.hpp:81-117): "any lane" semantics */
 int nfl_oracle_any_eq(const nfl_oracle_ctx *ctx, const void *a, const void *b, size_t batch);
 int nfl_oracle_any_neq(const nfl_oracle_ctx *ctx, const void *a, const void *b, size_t batch);

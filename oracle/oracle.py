@@ -57,6 +57,8 @@ class Oracle:
         L.nfl_oracle_pointwise.restype = None
         L.nfl_oracle_polymul.argtypes = [C.c_void_p] * 4 + [C.c_size_t]
         L.nfl_oracle_polymul.restype = None
+        L.nfl_oracle_polymul_mt.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_int]
+        L.nfl_oracle_polymul_mt.restype = None
         for name in ("nfl_oracle_any_eq", "nfl_oracle_any_neq"):
             getattr(L, name).argtypes = [C.c_void_p] * 3 + [C.c_size_t]
             getattr(L, name).restype = C.c_int
@@ -128,6 +130,11 @@ class Oracle:
     def polymul(self, a, b):
         out = np.empty_like(a)
         self.lib.nfl_oracle_polymul(self.ctx, _vp(out), _vp(a), _vp(b), self._chk(a))
+        return out
+
+    def polymul_mt(self, a, b, nthreads):
+        out = np.empty_like(a)
+        self.lib.nfl_oracle_polymul_mt(self.ctx, _vp(out), _vp(a), _vp(b), self._chk(a), nthreads)
         return out
 
     def any_eq(self, a, b):
