@@ -158,6 +158,38 @@ struct shoup_marker {};
 
 template <class Op, class... Args> struct expr;
 
+// postfix program of one expression tree (include/nflhip.h, NFLHIP_EXPR_*), built when the tree is
+// assigned: distinct leaf polys become operands 0..2, every node appends its opcode.
+struct program {
+  unsigned char code[NFLHIP_EXPR_MAX_LEN];
+  size_t len = 0;
+  const void *operand[3] = {nullptr, nullptr, nullptr};
+  size_t noperands = 0;
+  int depth = 0;
+  bool ok = true;
+  void push_leaf(const void *p) {
+    size_t k = 0;
+    while (k < noperands && operand[k] != p) ++k;
+    if (k == noperands) {
+      if (noperands == 3) { ok = false; return; }
+      operand[noperands++] = p;
+    }
+    emit((unsigned char)k, +1);
+  }
+  void emit(unsigned char c, int delta) {
+    if (len == NFLHIP_EXPR_MAX_LEN) { ok = false; return; }
+    code[len++] = c;
+    depth += delta;
+    if (depth > 4) ok = false;
+  }
+};
+template <class Op> struct opcode { static constexpr int value = -1; static constexpr int delta = 0; };
+template <> struct opcode<addmod> { static constexpr int value = NFLHIP_EXPR_ADD; static constexpr int delta = -1; };
+template <> struct opcode<submod> { static constexpr int value = NFLHIP_EXPR_SUB; static constexpr int delta = -1; };
+template <> struct opcode<mulmod> { static constexpr int value = NFLHIP_EXPR_MUL; static constexpr int delta = -1; };
+template <> struct opcode<mulmod_shoup> { static constexpr int value = NFLHIP_EXPR_MUL_SHOUP; static constexpr int delta = -2; };
+template <> struct opcode<compute_shoup> { static constexpr int value = NFLHIP_EXPR_COMPUTE_SHOUP; static constexpr int delta = 0; };
+
 template <class Op, class... Args> struct expr {
   std::tuple<Args const &...> args;
   explicit expr(Args const &... a) : args(a...) {}
@@ -168,13 +200,33 @@ template <class Op, class... Args> struct expr {
   static constexpr size_t degree = first_type::degree;
   static constexpr size_t nmoduli = first_type::nmoduli;
 
-  // evaluate this node into `out` (one device pass per node; children first)
-  void eval(poly_type &out) const { eval_impl(out, std::integral_constant<size_t, sizeof...(Args)>()); }
+  // evaluate this node into `out`: the whole tree in ONE fused device pass when it fits the
+  // postfix program limits (<= 3 distinct polys, stack depth <= 4), else one pass per node
+  void eval(poly_type &out) const {
+    program pr;
+    lower(pr);
+    if (pr.ok && opcode<Op>::value >= 0 && out.apply_program(pr)) return;
+    eval_impl(out, std::integral_constant<size_t, sizeof...(Args)>());
+  }
+  // append this subtree to a postfix program
+  void lower(program &pr) const {
+    lower_args(pr, std::integral_constant<size_t, 0>());
+    if (opcode<Op>::value < 0) pr.ok = false;
+    else pr.emit((unsigned char)opcode<Op>::value, opcode<Op>::delta);
+  }
 
   // expr::operator bool (ops.hpp:81-95): true as soon as ONE lane of the value is non-zero
   explicit operator bool() const { return truth(Op()); }
 
  private:
+  template <class A> static void lower_one(const A &a, program &pr, std::true_type) { pr.push_leaf(a.cdata()); }
+  template <class A> static void lower_one(const A &a, program &pr, std::false_type) { a.lower(pr); }
+  template <size_t I> void lower_args(program &pr, std::integral_constant<size_t, I>) const {
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(std::get<I>(args))>::type>::type A;
+    lower_one(std::get<I>(args), pr, std::is_same<A, poly_type>());
+    lower_args(pr, std::integral_constant<size_t, I + 1>());
+  }
+  void lower_args(program &, std::integral_constant<size_t, sizeof...(Args)>) const {}
   template <class A> static const poly_type &materialise(const A &a, poly_type &tmp, std::true_type) { (void)tmp; return a; }
   template <class A> static const poly_type &materialise(const A &a, poly_type &tmp, std::false_type) {
     a.eval(tmp);
@@ -359,6 +411,13 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   static nflhip_ctx *ctx() { return detail::context<T, Degree, NbModuli>::get(); }
   void apply(int op, const poly &a, const poly &b, const poly &bp) {
     detail::check(ctx(), nflhip_pointwise(ctx(), op, _data, a._data, b._data, bp._data, 1), "operator=(expr)");
+  }
+  // fused tree evaluation; false = the engine declined (tiny rows): the caller goes node by node
+  bool apply_program(const ops::program &pr) {
+    const int rc = nflhip_eval(ctx(), _data, pr.operand, pr.noperands, pr.code, pr.len, 1);
+    if (rc == NFLHIP_ERR_UNSUPPORTED) return false;
+    detail::check(ctx(), rc, "operator=(expr)");
+    return true;
   }
   static bool any_cmp(const poly &a, const poly &b, bool want_eq) {
     int r = 0;

@@ -113,6 +113,27 @@ int nflhip_pointwise_dev(nflhip_ctx *ctx, int op, void *d_out, const void *d_a, 
 int nflhip_pointwise(nflhip_ctx *ctx, int op, void *h_out, const void *h_a, const void *h_b,
                      const void *h_bprime, size_t batch);
 
+/* ---- fused expression trees -------------------------------------------------------
+ * poly::operator=(expr) evaluates a whole expression tree (e.g. `a + b*add`, tests/poly_p.cpp:62-66;
+ * `resb - resa*s`, tests/nfllib_demo_main_op.cpp:51) in one pass without temporaries
+ * (core.hpp:24-37, ops.hpp:52-79).  Here the tree is a postfix program executed per word on the
+ * device: byte k < 8 pushes operand k; NFLHIP_EXPR_ADD/SUB/MUL pop two values and push the result
+ * (`x op y` with y on top); NFLHIP_EXPR_MUL_SHOUP pops b', b, a and pushes mulmod_shoup(a,b,b');
+ * NFLHIP_EXPR_COMPUTE_SHOUP replaces the top.  At most 8 operands, 24 program bytes, stack depth 4;
+ * exactly one value must remain.  `out` may alias any operand.  The host-pointer variant stages at
+ * most 3 distinct operands. */
+#define NFLHIP_EXPR_ADD 0x10
+#define NFLHIP_EXPR_SUB 0x11
+#define NFLHIP_EXPR_MUL 0x12
+#define NFLHIP_EXPR_MUL_SHOUP 0x13
+#define NFLHIP_EXPR_COMPUTE_SHOUP 0x14
+#define NFLHIP_EXPR_MAX_OPERANDS 8
+#define NFLHIP_EXPR_MAX_LEN 24
+int nflhip_eval_dev(nflhip_ctx *ctx, void *d_out, const void *const *d_operands, size_t noperands,
+                    const unsigned char *program, size_t proglen, size_t batch, void *stream);
+int nflhip_eval(nflhip_ctx *ctx, void *h_out, const void *const *h_operands, size_t noperands,
+                const unsigned char *program, size_t proglen, size_t batch);
+
 /* ---- the metric path ---------------------------------------------------------
  * c = INTT( NTT(a) (.) NTT(b) ): the reference sequence
  *   a.ntt_pow_phi(); b.ntt_pow_phi(); c = a*b; c.invntt_pow_invphi();

@@ -34,6 +34,8 @@ SYMBOLS = [
     ("nflhip_ntt_inv", _i, [_vp, _vp, _sz]),
     ("nflhip_pointwise_dev", _i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     ("nflhip_pointwise", _i, [_vp, _i, _vp, _vp, _vp, _vp, _sz]),
+    ("nflhip_eval_dev", _i, [_vp, _vp, _vp, _sz, _vp, _sz, _sz, _vp]),
+    ("nflhip_eval", _i, [_vp, _vp, _vp, _sz, _vp, _sz, _sz]),
     ("nflhip_polymul_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     ("nflhip_polymul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("nflhip_polymul_ntt_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),

@@ -484,6 +484,19 @@ int nflhip_pointwise_dev(nflhip_ctx *ctx, int op, void *o, const void *a, const 
   return NFLHIP_OK;
 }
 
+static int eval_dev(nflhip_ctx *ctx, void *out, const void *const *ops, size_t nops, const unsigned char *prog, size_t len,
+                    size_t batch, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(
+      ctx, launch_eval_expr<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)out, ops, (int)nops, prog, (int)len, batch, st),
+      launch_eval_expr<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)out, ops, (int)nops, prog, (int)len, batch, st),
+      launch_eval_expr<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)out, ops, (int)nops, prog, (int)len, batch, st));
+  if (e == hipErrorInvalidValue) return fail(ctx, NFLHIP_ERR_INVALID, "malformed expression program");
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "row shorter than one 16-byte vector");
+  if (e != hipSuccess) return hipfail(ctx, e, "eval");
+  return NFLHIP_OK;
+}
+
 static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, int b_is_ntt, size_t batch, void *stream) {
   CHECK_CTX(ctx);
   if (batch && (!c || !a || !b)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
@@ -498,6 +511,17 @@ static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, i
   return DISPATCH_T(ctx, polymul_composed<uint16_t>(ctx, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, b_is_ntt, batch, st),
                     polymul_composed<uint32_t>(ctx, (uint32_t *)c, (const uint32_t *)a, (const uint32_t *)b, b_is_ntt, batch, st),
                     polymul_composed<uint64_t>(ctx, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b, b_is_ntt, batch, st));
+}
+
+int nflhip_eval_dev(nflhip_ctx *ctx, void *d_out, const void *const *d_operands, size_t noperands,
+                    const unsigned char *program, size_t proglen, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (!program || !d_operands || (batch && !d_out)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (noperands == 0 || noperands > NFLHIP_EXPR_MAX_OPERANDS || proglen == 0 || proglen > NFLHIP_EXPR_MAX_LEN)
+    return fail(ctx, NFLHIP_ERR_INVALID, "expression program too large");
+  for (size_t i = 0; i < noperands; ++i)
+    if (batch && !d_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  return eval_dev(ctx, d_out, d_operands, noperands, program, proglen, batch, stream);
 }
 
 int nflhip_polymul_dev(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_t batch, void *stream) {
@@ -657,6 +681,30 @@ int nflhip_pointwise(nflhip_ctx *ctx, int op, void *o, const void *a, const void
   if (rc) return rc;
   return s.out(o, 0, bytes);
 }
+int nflhip_eval(nflhip_ctx *ctx, void *h_out, const void *const *h_operands, size_t noperands, const unsigned char *program,
+                size_t proglen, size_t batch) {
+  CHECK_CTX(ctx);
+  if (!program || !h_operands) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (noperands == 0 || noperands > 3 || proglen == 0 || proglen > NFLHIP_EXPR_MAX_LEN)
+    return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "host-pointer eval takes at most 3 distinct operands");
+  if (batch == 0) return NFLHIP_OK;
+  if (!h_out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL output");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  const void *dops[3] = {nullptr, nullptr, nullptr};
+  for (size_t i = 0; i < noperands; ++i) {
+    if (!h_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+    int rc = s.in((int)i, h_operands[i], bytes);
+    if (rc) return rc;
+    dops[i] = ctx->stage[i];
+  }
+  int rc = s.in(3, nullptr, bytes);
+  if (rc) return rc;
+  rc = eval_dev(ctx, ctx->stage[3], dops, noperands, program, proglen, batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(h_out, 3, bytes);
+}
+
 int nflhip_polymul(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_t batch) {
   CHECK_CTX(ctx);
   if (batch == 0) return NFLHIP_OK;

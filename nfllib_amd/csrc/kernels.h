@@ -59,6 +59,10 @@ hipError_t launch_ntt_inv(const Shape &s, const DevTables &t, const T *src, cons
 template <typename T>
 hipError_t launch_pointwise(const Shape &s, const DevTables &t, int op, T *out, const T *a, const T *b, const T *bp,
                             size_t batch, hipStream_t st);
+// postfix expression program (include/nflhip.h NFLHIP_EXPR_*) over up to 8 operands, one fused pass
+template <typename T>
+hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const void *const *operands, int noperands,
+                            const unsigned char *program, int len, size_t batch, hipStream_t st);
 template <typename T>
 hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
                           hipStream_t st);

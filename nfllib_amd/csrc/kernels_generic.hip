@@ -370,6 +370,96 @@ hipError_t launch_pointwise(const Shape &s, const DevTables &t, int op, T *out, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// fused expression trees: poly::operator=(expr) evaluates an arbitrary tree of the
+// element-wise functors in ONE pass with no temporaries (core.hpp:24-37, ops.hpp:52-79).
+// The tree arrives in postfix form (include/nflhip.h: NFLHIP_EXPR_*); every lane runs
+// the same tiny program over a 4-deep register stack.
+// ---------------------------------------------------------------------------
+struct ExprProgram {
+  unsigned char code[24];
+  int len;
+  const void *operand[8];
+};
+
+template <typename T> struct ExprStack {
+  T s0, s1, s2, s3;
+  __device__ __forceinline__ void push(T v) { s3 = s2; s2 = s1; s1 = s0; s0 = v; }
+  __device__ __forceinline__ void drop() { s0 = s1; s1 = s2; s2 = s3; }
+};
+
+template <typename T>
+__global__ void k_eval_expr(T *out, ExprProgram prog, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t total) {
+  constexpr int V = 16 / sizeof(T);
+  struct alignas(16) Vec { T e[V]; };
+  const size_t nvec = total / V;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cm = (int)(((v * V) >> logn) % (size_t)nm);  // n >= V words: a vector never straddles moduli
+    const T p = mc[cm].p, mu = mc[cm].mu;
+    ExprStack<T> st[V];
+    for (int pc = 0; pc < prog.len; ++pc) {
+      const unsigned c = prog.code[pc];
+      if (c < 8) {
+        const Vec x = reinterpret_cast<const Vec *>(prog.operand[c])[v];
+#pragma unroll
+        for (int k = 0; k < V; ++k) st[k].push(x.e[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          ExprStack<T> &s = st[k];
+          switch (c) {
+            case 0x10: { const T r = csub<T>((T)(s.s1 + s.s0), p); s.drop(); s.s0 = r; } break;            // addmod
+            case 0x11: { const T r = csub<T>((T)(s.s1 + (T)(p - s.s0)), p); s.drop(); s.s0 = r; } break;    // submod
+            case 0x12: { const T r = barrett<T>::mul(s.s1, s.s0, p, mu); s.drop(); s.s0 = r; } break;       // mulmod
+            case 0x13: { const T r = mul_shoup<T>(s.s2, s.s1, s.s0, p); s.drop(); s.drop(); s.s0 = r; } break;  // a b b' -> mulmod_shoup
+            default: {                                                                                        // compute_shoup
+              T x = s.s0;
+              x = csub<T>(x, (T)(4 * p)); x = csub<T>(x, (T)(2 * p)); x = csub<T>(x, p);
+              if (sizeof(T) < 8) { while (x >= p) x -= p; }
+              s.s0 = shoup_of<T>::get(x, p, mu);
+            } break;
+          }
+        }
+      }
+    }
+    Vec o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o.e[k] = st[k].s0;
+    reinterpret_cast<Vec *>(out)[v] = o;
+  }
+}
+
+template <typename T>
+hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const void *const *operands, int noperands,
+                            const unsigned char *program, int len, size_t batch, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  if (len <= 0 || len > 24 || noperands < 1 || noperands > 8) return hipErrorInvalidValue;
+  const size_t total = batch * s.nm * s.n;
+  constexpr size_t V = 16 / sizeof(T);
+  if (total % V || s.n < V) return hipErrorNotSupported;  // tiny rows: the caller evaluates node by node
+  ExprProgram prog;
+  int depth = 0;
+  for (int i = 0; i < len; ++i) {  // validate: operands in range, stack depth 1..4, exactly one result
+    const unsigned c = program[i];
+    prog.code[i] = (unsigned char)c;
+    if (c < 8) { if ((int)c >= noperands) return hipErrorInvalidValue; ++depth; }
+    else if (c == 0x10 || c == 0x11 || c == 0x12) { if (depth < 2) return hipErrorInvalidValue; --depth; }
+    else if (c == 0x13) { if (depth < 3) return hipErrorInvalidValue; depth -= 2; }
+    else if (c == 0x14) { if (depth < 1) return hipErrorInvalidValue; }
+    else return hipErrorInvalidValue;
+    if (depth > 4) return hipErrorInvalidValue;
+  }
+  if (depth != 1) return hipErrorInvalidValue;
+  prog.len = len;
+  for (int i = 0; i < 8; ++i) prog.operand[i] = i < noperands ? operands[i] : nullptr;
+  const size_t nvec = total / V;
+  size_t blocks = (nvec + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL((k_eval_expr<T>), dim3((unsigned)blocks), dim3(256), 0, st, out, prog, (const ModConst<T> *)t.mc, s.logn,
+                     (int)s.nm, total);
+  return hipGetLastError();
+}
+
 // expr::operator bool over eqmod / neqmod (ops.hpp:81-117): "any word" semantics
 template <typename T>
 __global__ void k_any_cmp(const T *a, const T *b, size_t total, int want_eq, int *flag) {
@@ -539,6 +629,8 @@ hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const ui
                                         hipStream_t);                                                                \
   template hipError_t launch_pointwise<T>(const Shape &, const DevTables &, int, T *, const T *, const T *,          \
                                           const T *, size_t, hipStream_t);                                           \
+  template hipError_t launch_eval_expr<T>(const Shape &, const DevTables &, T *, const void *const *, int,           \
+                                          const unsigned char *, int, size_t, hipStream_t);                          \
   template hipError_t launch_any_cmp<T>(const Shape &, const DevTables &, const T *, const T *, size_t, int,         \
                                         hipStream_t);                                                                \
   template hipError_t launch_fill_uniform<T>(const Shape &, const DevTables &, T *, size_t, size_t, uint64_t, int,   \

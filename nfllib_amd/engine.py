@@ -114,6 +114,25 @@ class Engine:
                                                 self._stream(stream)))
         return out
 
+    def eval(self, program, operands, out=None, stream=None):
+        """Fused expression tree: `program` = postfix bytes (k<8 push operand k, 0x10 add, 0x11 sub,
+        0x12 mul, 0x13 mul_shoup, 0x14 compute_shoup), one device pass (nflhip_eval_dev)."""
+        out = out if out is not None else _torch().empty_like(operands[0])
+        ptrs = (C.c_void_p * len(operands))(*[o.data_ptr() for o in operands])
+        prog = (C.c_ubyte * len(program))(*program)
+        self._chk(self.lib.nflhip_eval_dev(self.ctx, _vp(out), C.cast(ptrs, C.c_void_p), len(operands),
+                                           C.cast(prog, C.c_void_p), len(program), self._batch(operands[0]),
+                                           self._stream(stream)))
+        return out
+
+    def h_eval(self, program, operands):
+        out = np.empty_like(operands[0])
+        ptrs = (C.c_void_p * len(operands))(*[o.ctypes.data for o in operands])
+        prog = (C.c_ubyte * len(program))(*program)
+        self._chk(self.lib.nflhip_eval(self.ctx, _vp(out), C.cast(ptrs, C.c_void_p), len(operands),
+                                       C.cast(prog, C.c_void_p), len(program), self._hb(operands[0])))
+        return out
+
     def polymul(self, a, b, out=None, b_is_ntt=False, stream=None):
         out = out if out is not None else _torch().empty_like(a)
         fn = self.lib.nflhip_polymul_ntt_dev if b_is_ntt else self.lib.nflhip_polymul_dev

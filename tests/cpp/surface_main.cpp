@@ -81,6 +81,30 @@ template <class T, size_t Degree, size_t NbModuli> static bool run() {
       (*tmp)(cm, j) = T((W((*a)(cm, j)) + (W((*b)(cm, j)) * (*add)(cm, j)) % p) % p);
     }
   CHECK(same(*res, *tmp));
+  // deeper trees: fused in one device pass (<= 3 distinct polys) ...
+  *res = (*a + *b) * (*a - *add) + *b * *add;
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) {
+      const W p = poly_t::get_modulus(cm), x = (*a)(cm, j), y = (*b)(cm, j), z = (*add)(cm, j);
+      (*tmp)(cm, j) = T((((x + y) % p) * ((x + p - z) % p) % p + (y * z) % p) % p);
+    }
+  CHECK(same(*res, *tmp));
+  // ... and node by node when the tree has more leaves than the fused program takes
+  Heap<poly_t> d4(nfl::uniform(4));
+  *res = (*a + *b) + (*add + *d4);
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) {
+      const W p = poly_t::get_modulus(cm);
+      (*tmp)(cm, j) = T((W((*a)(cm, j)) + (*b)(cm, j) + (*add)(cm, j) + (*d4)(cm, j)) % p);
+    }
+  CHECK(same(*res, *tmp));
+  *res = nfl::shoup(*a * *b, nfl::compute_shoup(*b)) + *add;
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) {
+      const W p = poly_t::get_modulus(cm);
+      (*tmp)(cm, j) = T(((W((*a)(cm, j)) * (*b)(cm, j)) % p + (*add)(cm, j)) % p);
+    }
+  CHECK(same(*res, *tmp));
   Heap<poly_t> al(*a);
   *al = *al + *b;
   *tmp = *a + *b;

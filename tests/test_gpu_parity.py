@@ -238,3 +238,34 @@ def test_full_size_properties_metric_shape(oracle_factory, engine_factory):
         ha = o.fill_uniform(1, SEED, 0, first_poly=int(idx))
         hb = o.fill_uniform(1, SEED, 1, first_poly=int(idx))
         assert np.array_equal(hc[idx:idx + 1], o.polymul(ha, hb))
+
+
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (32, 1024, 2), (16, 128, 1), (64, 8, 2)])
+def test_fused_expression_trees(lb, n, m, oracle_factory, engine_factory):
+    """nflhip_eval: whole expression trees in one pass (core.hpp:24-37), vs the oracle's op-by-op result."""
+    from nfllib_amd import NflHipError, OP_ADD, OP_COMPUTE_SHOUP, OP_MUL, OP_MUL_SHOUP, OP_SUB
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a, b = _inputs(o, 3)
+    c = o.fill_uniform(3, 77, 0)
+    da, db, dc = e.to_device(a), e.to_device(b), e.to_device(c)
+    ADD, SUB, MUL, MSH, CSH = 0x10, 0x11, 0x12, 0x13, 0x14
+    # a + b*c  (tests/poly_p.cpp:62-66)
+    want = o.pointwise(OP_ADD, a, o.pointwise(OP_MUL, b, c))
+    assert np.array_equal(e.to_host(e.eval([0, 1, 2, MUL, ADD], [da, db, dc])), want)
+    # b - a*c  (tests/nfllib_demo_main_op.cpp:51)
+    want = o.pointwise(OP_SUB, b, o.pointwise(OP_MUL, a, c))
+    assert np.array_equal(e.to_host(e.eval([1, 0, 2, MUL, SUB], [da, db, dc])), want)
+    # (a+b)*(a-c) + b*c, result aliasing an operand
+    want = o.pointwise(OP_ADD, o.pointwise(OP_MUL, o.pointwise(OP_ADD, a, b), o.pointwise(OP_SUB, a, c)), o.pointwise(OP_MUL, b, c))
+    out = da.clone()
+    e.eval([0, 1, ADD, 0, 2, SUB, MUL, 1, 2, MUL, ADD], [out, db, dc], out=out)
+    assert np.array_equal(e.to_host(out), want)
+    # shoup(a*b, compute_shoup(b)) + c
+    want = o.pointwise(OP_ADD, o.pointwise(OP_MUL, a, b), c)
+    assert np.array_equal(e.to_host(e.eval([0, 1, 1, CSH, MSH, 2, ADD], [da, db, dc])), want)
+    # host-pointer variant
+    assert np.array_equal(e.h_eval([0, 1, 2, MUL, ADD], [a, b, c]), o.pointwise(OP_ADD, a, o.pointwise(OP_MUL, b, c)))
+    # malformed programs are rejected, not executed
+    for bad in ([0, ADD], [0, 1], [0, 1, 2, 0, 1, ADD], [9, 0, ADD], [0, 1, 0x7f]):
+        with pytest.raises(NflHipError):
+            e.eval(bad, [da, db, dc])
