@@ -508,6 +508,87 @@ template <class P> void pointwise(int op, P *out, P const *a, P const *b, P cons
 }
 }  // namespace batch
 
+// ---------------------------------------------------------------- device-resident batches
+// The reference's poly stores its words inline on the host (poly.hpp:87-88), so every per-poly call
+// above crosses PCIe twice.  device_batch<P> keeps a dense [count][NbModuli][Degree] tensor resident
+// in HBM (the role poly_p's shared payload plays on the host, poly_p.hpp:11-204) and runs the same
+// operations through the *_dev entry points on one stream: upload once, compute, download once.
+template <class P> class device_batch {
+ public:
+  typedef typename P::value_type value_type;
+  explicit device_batch(size_t count) : n_(count), d_(nullptr) {
+    static_assert(sizeof(P) == P::degree * P::nmoduli * sizeof(value_type), "dense poly array");
+    detail::check(P::ctx(), nflhip_malloc(P::ctx(), &d_, bytes()), "device_batch");
+  }
+  device_batch(const P *host, size_t count) : device_batch(count) { upload(host); }
+  ~device_batch() { if (d_) nflhip_free(P::ctx(), d_); }
+  device_batch(const device_batch &) = delete;
+  device_batch &operator=(const device_batch &) = delete;
+  device_batch(device_batch &&o) noexcept : n_(o.n_), d_(o.d_) { o.d_ = nullptr; }
+
+  size_t size() const { return n_; }
+  size_t bytes() const { return n_ * sizeof(P); }
+  void *data() { return d_; }
+  const void *data() const { return d_; }
+
+  void upload(const P *host) {
+    detail::check(P::ctx(), nflhip_memcpy_h2d(P::ctx(), d_, host->cdata(), bytes(), nullptr), "upload");
+    sync();
+  }
+  void download(P *host) const {
+    detail::check(P::ctx(), nflhip_memcpy_d2h(P::ctx(), host->data(), d_, bytes(), nullptr), "download");
+    sync();
+  }
+  void sync() const { detail::check(P::ctx(), nflhip_stream_sync(P::ctx(), nullptr), "sync"); }
+
+  // same names and meaning as the poly members (poly.hpp:167-168), over the whole batch
+  void ntt_pow_phi() { detail::check(P::ctx(), nflhip_ntt_fwd_dev(P::ctx(), d_, n_, nullptr), "ntt_pow_phi"); }
+  void invntt_pow_invphi() { detail::check(P::ctx(), nflhip_ntt_inv_dev(P::ctx(), d_, n_, nullptr), "invntt_pow_invphi"); }
+  // *this = op(a, b[, b'])  (NFLHIP_OP_*); aliasing allowed
+  void assign(int op, const device_batch &a, const device_batch &b) {
+    same_size(a); same_size(b);
+    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), op, d_, a.d_, b.d_, nullptr, n_, nullptr), "pointwise");
+  }
+  void assign_mul_shoup(const device_batch &a, const device_batch &b, const device_batch &bprime) {
+    same_size(a); same_size(b); same_size(bprime);
+    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_MUL_SHOUP, d_, a.d_, b.d_, bprime.d_, n_, nullptr),
+                  "mulmod_shoup");
+  }
+  void assign_compute_shoup(const device_batch &b) {
+    same_size(b);
+    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_COMPUTE_SHOUP, d_, b.d_, nullptr, nullptr, n_, nullptr),
+                  "compute_shoup");
+  }
+  // *this = INTT(NTT(a) (.) NTT(b)), the fused metric path
+  void assign_polymul(const device_batch &a, const device_batch &b) {
+    same_size(a); same_size(b);
+    detail::check(P::ctx(), nflhip_polymul_dev(P::ctx(), d_, a.d_, b.d_, n_, nullptr), "polymul");
+  }
+  // fused postfix expression over up to NFLHIP_EXPR_MAX_OPERANDS resident batches
+  void assign_program(const unsigned char *program, size_t len, const device_batch *const *operands, size_t count) {
+    const void *ptr[NFLHIP_EXPR_MAX_OPERANDS];
+    if (count > NFLHIP_EXPR_MAX_OPERANDS) throw std::runtime_error("nfl(hip): too many operands");
+    for (size_t i = 0; i < count; ++i) { same_size(*operands[i]); ptr[i] = operands[i]->d_; }
+    detail::check(P::ctx(), nflhip_eval_dev(P::ctx(), d_, ptr, count, program, len, n_, nullptr), "eval");
+  }
+  bool any_equal(const device_batch &o) const { return cmp(o, true); }    // the reference's `a == b`
+  bool any_differs(const device_batch &o) const { return cmp(o, false); } // the reference's `a != b`
+
+ private:
+  void same_size(const device_batch &o) const {
+    if (o.n_ != n_) throw std::runtime_error("nfl(hip): batch size mismatch");
+  }
+  bool cmp(const device_batch &o, bool want_eq) const {
+    same_size(o);
+    int r = 0;
+    detail::check(P::ctx(), want_eq ? nflhip_any_eq_dev(P::ctx(), d_, o.d_, n_, &r, nullptr)
+                                    : nflhip_any_neq_dev(P::ctx(), d_, o.d_, n_, &r, nullptr), "compare");
+    return r != 0;
+  }
+  size_t n_;
+  void *d_;
+};
+
 }  // namespace nfl
 
 #endif  // NFL_HIP_NFL_HPP

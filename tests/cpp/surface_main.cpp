@@ -179,6 +179,35 @@ template <class T, size_t Degree, size_t NbModuli> static bool run() {
   nfl::batch::invntt_pow_invphi(arr, B);
   single->invntt_pow_invphi();
   CHECK(same(arr[1], *single));
+  // device-resident batch: upload once, run the whole pipeline in HBM, download once
+  {
+    for (size_t k = 0; k < B; k++) new (&arr[k]) poly_t(nfl::uniform(200 + k));
+    void *mem2 = nullptr, *mem3 = nullptr;
+    CHECK(posix_memalign(&mem2, 32, sizeof(poly_t) * B) == 0);
+    CHECK(posix_memalign(&mem3, 32, sizeof(poly_t) * B) == 0);
+    poly_t *brr = static_cast<poly_t *>(mem2), *out = static_cast<poly_t *>(mem3);
+    for (size_t k = 0; k < B; k++) { new (&brr[k]) poly_t(nfl::uniform(300 + k)); new (&out[k]) poly_t(); }
+    nfl::device_batch<poly_t> da(arr, B), db(brr, B), dc(B), dd(B);
+    dc.assign_polymul(da, db);
+    dc.download(out);
+    Heap<poly_t> ref;
+    nfl::batch::polymul(ref.p, &arr[2], &brr[2], 1);
+    CHECK(same(out[2], *ref));
+    dd.assign(NFLHIP_OP_ADD, da, db);                       // dd = a + b
+    const unsigned char prog[] = {0, 1, NFLHIP_EXPR_MUL, 2, NFLHIP_EXPR_ADD};   // a*b + (a+b)
+    const nfl::device_batch<poly_t> *ops3[] = {&da, &db, &dd};
+    dc.assign_program(prog, sizeof(prog), ops3, 3);
+    dc.download(out);
+    *ref = arr[1] * brr[1] + (arr[1] + brr[1]);
+    CHECK(same(out[1], *ref));
+    da.ntt_pow_phi();
+    da.invntt_pow_invphi();
+    da.download(out);
+    CHECK(same(out[0], arr[0]));
+    CHECK(da.any_equal(da) && !da.any_differs(da) && da.any_differs(db));
+    free(mem2);
+    free(mem3);
+  }
   free(mem);
   return true;
 }
