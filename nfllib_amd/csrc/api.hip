@@ -35,6 +35,11 @@ struct nflhip_ctx {
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
   std::mutex scratch_mu;
+  // large-row polymul pipeline: two helper streams so that the HBM-bound streaming passes of one
+  // chunk overlap the VALU-bound fused kernel of another; ev_prev orders successive calls on the scratch
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
+  bool ev_prev_valid = false;
   // host copies for introspection
   std::vector<uint64_t> h_Q;                     // moduli_product limbs
   std::vector<std::vector<uint64_t>> h_lifting;  // lifting_integers[cm]
@@ -266,22 +271,41 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn > 12) {
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn > 12 && ctx->aux[0]) {
     // large rows: streaming outer passes, then the fused assembly kernel over the 4096-word blocks,
-    // then the outer inverse passes (9 operand streams of HBM traffic instead of 13)
-    const size_t rows = batch * ctx->shape.nm;
-    e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, (const uint64_t *)a, (uint64_t *)s0, rows, st);
-    if (e == hipSuccess) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, (const uint64_t *)b, (uint64_t *)s1, rows, st);
-    if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer forward");
-    e = launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)s0, (const uint64_t *)s1, batch, st);
-    if (e == hipSuccess) {
-      e = launch_outer_inv_u64(ctx->shape, ctx->tabs, (uint64_t *)c, rows, st);
-      if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer inverse");
-      e = hipStreamSynchronize(st);
-      if (e != hipSuccess) return hipfail(ctx, e, "polymul: sync");
-      return NFLHIP_OK;
+    // then the outer inverse passes (9 operand streams of HBM traffic instead of 13).  The batch is cut
+    // into chunks that alternate between two helper streams: one chunk's HBM-bound streaming passes
+    // overlap another chunk's VALU-bound fused kernel.  Fully asynchronous w.r.t. the host.
+    const size_t nm = ctx->shape.nm, pw = nm * ctx->shape.n;  // words per poly
+    const size_t nchunk = batch >= 8 ? 8 : batch;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_start, st));
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_start, 0));
+      if (ctx->ev_prev_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_done[1 - k], 0));  // previous call's scratch use
     }
-    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul: fused blocks");
+    bool unsupported = false;
+    for (size_t ch = 0; ch < nchunk && !unsupported; ++ch) {
+      const size_t lo = batch * ch / nchunk, hi = batch * (ch + 1) / nchunk, cnt = hi - lo;
+      if (cnt == 0) continue;
+      hipStream_t s = ctx->aux[ch & 1];
+      const uint64_t *ak = (const uint64_t *)a + lo * pw, *bk = (const uint64_t *)b + lo * pw;
+      uint64_t *ck = (uint64_t *)c + lo * pw, *s0k = (uint64_t *)s0 + lo * pw, *s1k = (uint64_t *)s1 + lo * pw;
+      e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, ak, s0k, cnt * nm, s);
+      if (e == hipSuccess) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, bk, s1k, cnt * nm, s);
+      if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer forward");
+      e = launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, ck, s0k, s1k, cnt, s);
+      if (e == hipErrorNotSupported) { unsupported = true; break; }
+      if (e != hipSuccess) return hipfail(ctx, e, "polymul: fused blocks");
+      e = launch_outer_inv_u64(ctx->shape, ctx->tabs, ck, cnt * nm, s);
+      if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer inverse");
+    }
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev_done[k], ctx->aux[k]));
+      HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
+    }
+    ctx->ev_prev_valid = true;
+    if (!unsupported) return NFLHIP_OK;
+    // (assembly kernel unavailable: fall through to the composed plan, ordered after the helper streams)
   }
   e = launch_ntt_fwd<T>(ctx->shape, ctx->tabs, a, s0, batch, st);
   if (e != hipSuccess) return hipfail(ctx, e, "polymul: ntt(a)");
@@ -349,6 +373,11 @@ int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree
                              : build_tables<uint64_t>(c, P, primitive_roots, invkmax, kmax_log2);
   if (rc == NFLHIP_OK) {
     hipError_t se = hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && se == hipSuccess; ++k) {
+      se = hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking);
+      if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming);
+    }
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
     if (se != hipSuccess) rc = hipfail(nullptr, se, "hipStreamCreate");
   }
   if (rc != NFLHIP_OK) {
@@ -363,6 +392,11 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (!ctx) return NFLHIP_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->hstream) (void)hipStreamDestroy(ctx->hstream);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->aux[k]) { (void)hipStreamSynchronize(ctx->aux[k]); (void)hipStreamDestroy(ctx->aux[k]); }
+    if (ctx->ev_done[k]) (void)hipEventDestroy(ctx->ev_done[k]);
+  }
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   for (int i = 0; i < 4; ++i)
     if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
