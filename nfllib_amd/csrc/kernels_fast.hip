@@ -39,10 +39,9 @@ __device__ __forceinline__ int pad(int e) { return e + (e >> 4); }
 // ---- one lazy butterfly each way -------------------------------------------------
 // Cooley-Tukey, x' = x + w*y, y' = x - w*y.
 //  ARITH 0: Harvey's ranges, x,y in [0,4p) -> [0,4p).
-//  ARITH 1: x,y ANY 64-bit word -> any 64-bit word: the conditional subtraction of
-//           2p = 2^63 - 2*delta is keyed on bit 63 (U = x - [x >= 2^63]*2p < 2^63 + 2*delta),
-//           m < 2p exactly, so U + m < 2^64 and U - m + 2p < 2^64; the x-path sum is
-//           folded into the multiply-add chain and y' = (2U + 2p) - x'.
+//  ARITH 2: x,y ANY 64-bit word -> any 64-bit word: U = fold2(x) < p + 4*delta, m < 2p exactly, so
+//           U + m and U - m + 2p stay below 2^64; the x-path sum is folded into the multiply-add
+//           chain and y' = (2U + 2p) - x'.
 template <int ARITH>
 __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod &k) {
   if (ARITH == 0) {
@@ -50,14 +49,7 @@ __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod 
     const u64 m = mul_shoup_lazy<u64>(y, w.w, w.wp, k.p);
     x = u + m;
     y = u - m + k.p2;
-  } else if (ARITH == 1) {
-    const u32 b = (u32)(x >> 63);
-    const u64 U = (x & 0x7fffffffffffffffull) + (u64)b * k.d2;
-    const u64 xn = shoup_acc(y, w, U, k);
-    y = ((U << 1) + k.p2) - xn;
-    x = xn;
   } else if (ARITH == 2) {
-    //  ARITH 2: as 1 with the two-bit fold (U < 2^62 + 3*delta): same cost, tighter range
     const u64 U = fold2(x, k);
     const u64 xn = shoup_acc(y, w, U, k);
     y = ((U << 1) + k.p2) - xn;
@@ -84,7 +76,6 @@ __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, const Tw64 w, const Mod 
 // any 64-bit word (ARITH 1) or [0,4p) (ARITH 0) -> [0,p)
 template <int ARITH> __device__ __forceinline__ u64 canon(u64 x, const Mod &k) {
   if (ARITH >= 2) return csub<u64>(fold2(x, k), k.p);  // < p + 4*delta, one subtract left
-  if (ARITH == 1) x = (x & 0x7fffffffffffffffull) + (u64)(u32)(x >> 63) * k.d2;  // < 2p + 4*delta
   x = csub<u64>(x, k.p2);
   return csub<u64>(x, k.p);
 }
@@ -156,7 +147,6 @@ __device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 17 * k];
   }
   // F2: stages 4-7 inside 256-word block B: psi[2^(4+s) + B*2^s + g]
-  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   ct16<ARITH>(v, [&](int s, int g) { return tw[(16u << (bk.r + s)) + ((bk.blk * 16u + B) << s) + g]; }, k);
   // E2: 16-lane transpose through this wave's own LDS region (LDS is in-order per wave)
   {
@@ -177,7 +167,6 @@ __device__ __forceinline__ void fwd_head(u64 (&v)[16], u64 *sm, const Tw64 *__re
 template <int ARITH>
 __device__ __forceinline__ void fwd_tail(u64 (&v)[16], const Tw64 *__restrict__ tw, const Mod &k, const int t,
                                          const Blk bk) {
-  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   ct16<ARITH>(v, [&](int s, int g) { return tw[(256u << (bk.r + s)) + ((bk.blk * 256u + t) << s) + g]; }, k);
 }
 template <int ARITH>
@@ -195,7 +184,6 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
                                          const int t, const Blk bk) {
   const u64 p = c.p, p2 = c.p2;
   // I1: stages 11..8; mirrored index 2m-1-j with m = 2^(8+s), j = q*2^s + g
-  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   gs16<ARITH>(v, [&](int s, int g) { return tw[(512u << (bk.r + s)) - 1u - (((bk.blk * 256u + t) << s) + g)]; }, k);
   const int B = t >> 4, r = t & 15;
   {
@@ -212,7 +200,6 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 17 * k];
   }
   // I2: stages 7..4; m = 2^(4+s), j = B*2^s + g
-  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   gs16<ARITH>(v, [&](int s, int g) { return tw[(32u << (bk.r + s)) - 1u - (((bk.blk * 16u + B) << s) + g)]; }, k);
   {
     const int base = 272 * B + r;
@@ -225,7 +212,6 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = sm[base + 272 * k];
   }
-  if (ARITH >= 4) asm volatile("" ::: "memory");  // keep this pass's twiddle loads below the previous pass
   // I3: stages r+3..r+1 (uniform twiddles), then stage r (with n^-1 folded in when r == 0)
 #pragma unroll
   for (int s = 3; s >= 1; --s) {
@@ -395,7 +381,9 @@ __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, const 
 // qualifies (c <= 587), Shape::small_delta records it per context.
 static inline bool fast_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN; }
 
-// Experiment switch (tools/ and profiling only): NFLHIP_VARIANT="<arith><minw>", e.g. "12".
+// A/B switch for tools/quick_bench.py and profiling (never needed in production):
+//   NFLHIP_VARIANT = 0x hipcc kernel with Harvey ranges | 2x two-bit fold | 3x + one-off quotient |
+//                    5x (default) the generated assembly kernel, hipcc 3x for everything it does not cover.
 static int variant() {
   static int v = -1;
   if (v < 0) {
@@ -461,25 +449,14 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
   const MC64 *mc = (const MC64 *)t.mc;
   const int nm = (int)s.nm;
   int v = variant();
-  if (!s.small_delta) v = v % 10;  // arithmetic 0 only
+  if (!s.small_delta) v = 0;  // delta-form arithmetic needs 2*delta < 2^32
 #define NFLHIP_LAUNCH(A, W)                                                                                         \
   hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, A, W>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);     \
   break;
-  switch (v) {
-    case 1: NFLHIP_LAUNCH(0, 1)
-    case 2: NFLHIP_LAUNCH(0, 2)
-    case 3: NFLHIP_LAUNCH(0, 3)
-    case 4: NFLHIP_LAUNCH(0, 4)
-    case 11: NFLHIP_LAUNCH(1, 1)
-    case 12: NFLHIP_LAUNCH(1, 2)
-    case 21: NFLHIP_LAUNCH(2, 1)
-    case 22: NFLHIP_LAUNCH(2, 2)
-    case 31: NFLHIP_LAUNCH(3, 1)
-    case 42: NFLHIP_LAUNCH(4, 2)
-    case 43: NFLHIP_LAUNCH(4, 3)
-    case 44: NFLHIP_LAUNCH(4, 4)
-    case 33: NFLHIP_LAUNCH(3, 3)
-    default: NFLHIP_LAUNCH(3, 2)
+  switch (v / 10) {
+    case 0: NFLHIP_LAUNCH(0, 2)   // Harvey ranges, generic Shoup (any modulus)
+    case 2: NFLHIP_LAUNCH(2, 2)   // two-bit fold, exact quotient
+    default: NFLHIP_LAUNCH(3, 2)  // + one-off quotient in the forward butterflies
   }
 #undef NFLHIP_LAUNCH
   return hipGetLastError();
@@ -510,10 +487,9 @@ hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const u
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const dim3 g((unsigned)blocks), b(kThreads);
-  const int v = s.small_delta ? variant() : variant() % 10;
+  const int v = s.small_delta ? variant() : 0;
   if (v >= 30) hipLaunchKernelGGL(k_ntt_fwd4096<3>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
   else if (v >= 20) hipLaunchKernelGGL(k_ntt_fwd4096<2>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
-  else if (v >= 10) hipLaunchKernelGGL(k_ntt_fwd4096<1>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
   else hipLaunchKernelGGL(k_ntt_fwd4096<0>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
   return hipGetLastError();
 }
@@ -527,12 +503,11 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const dim3 g((unsigned)blocks), b(kThreads);
-  const int v = s.small_delta ? variant() : variant() % 10;
+  const int v = s.small_delta ? variant() : 0;
 #define NFLHIP_INV(A)                                                                                                  \
   if (mul) hipLaunchKernelGGL((k_ntt_inv4096<A, true>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);      \
   else hipLaunchKernelGGL((k_ntt_inv4096<A, false>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);
   if (v >= 20) { NFLHIP_INV(2) }
-  else if (v >= 10) { NFLHIP_INV(1) }
   else { NFLHIP_INV(0) }
 #undef NFLHIP_INV
   return hipGetLastError();

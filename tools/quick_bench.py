@@ -4,7 +4,7 @@ check that every variant produces the same words as variant 2 (the plain
 Harvey-range arithmetic).  One subprocess per variant because the variant is
 latched from the NFLHIP_VARIANT environment variable at first launch.
 
-  python tools/quick_bench.py 2 3 4 12 13 14 [--batch 16384] [--iters 10]
+  python tools/quick_bench.py 2 22 32 52 [--batch 16384] [--iters 10]
 """
 import json
 import os
