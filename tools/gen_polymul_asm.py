@@ -122,8 +122,15 @@ def interleave(em, gens):
                 gens.remove(g)
 
 
+SINGLE_STREAM = False   # ring mode: one butterfly at a time (18 temporaries instead of 36)
+
+
 def run_pairs(em, jobs):
     """jobs: list of callables(stream) -> generator; executed two at a time, interleaved."""
+    if SINGLE_STREAM:
+        for j in jobs:
+            interleave(em, [j(0)])
+        return
     for i in range(0, len(jobs), 2):
         gens = [jobs[i](0)]
         if i + 1 < len(jobs):
@@ -403,9 +410,7 @@ PASS_TW = {
 }
 
 
-def build():
-    em = Emitter()
-    vm = VmCounter(em)
+def prologue(em, vm, ring=None):
     R = em.raw
     # ---------------- prologue
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
@@ -422,8 +427,8 @@ def build():
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
     em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
     em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
-    for s in (0, 1):
-        em.valu("v_mov_b32_e32 v%d, 0" % (T(s, 15),))                               # the persistent zero of ZP
+    for s in sorted(set(V_T)):
+        em.valu("v_mov_b32_e32 v%d, 0" % (s + 15,))                                 # the persistent zero of ZP
     R("s_waitcnt lgkmcnt(0)")
     # r = logn - 12; wgx = poly * 2^r + blk; block = ((poly*nm + cm) << r) + blk; byte offset = block << 15
     R("s_sub_u32 s88, s88, 12")
@@ -476,8 +481,11 @@ def build():
     seq_a = row_loads(V_A, S_AROW)
     seq_b = row_loads(V_B, S_BROW)
     tw_seq = {}
-    for s in range(4):
-        tw_seq[("F1", s)] = PASS_TW["F1"](em, vm, s)
+    if ring is None:
+        for s in range(4):
+            tw_seq[("F1", s)] = PASS_TW["F1"](em, vm, s)
+    else:
+        ring.prime()
     R("s_waitcnt lgkmcnt(0)")
     # constants from the ModConst record
     R("s_mov_b64 s[24:25], s[56:57]")                    # p
@@ -493,6 +501,39 @@ def build():
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+
+    return tw_seq
+
+
+def epilogue(em, vm, last_plain_stage):
+    R = em.raw
+    R("s_cmp_eq_u32 s88, 0")
+    R("s_cbranch_scc1 .Lmerged_last_stage")
+    em.comment("r > 0: plain stage r (uniform twiddle psi[(2<<r) - 1 - blk]); lazy output for the outer passes")
+    last_plain_stage()
+    R("s_branch .Lstore")
+    em.lines.append(".Lmerged_last_stage:")
+    em.comment("r == 0: stage 0 with n^-1 folded in")
+    R("s_waitcnt vmcnt(0)")
+    run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
+    em.lines.append(".Lstore:")
+    # ---------------- store c
+    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
+    for k in range(16):
+        R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (V_OFF8, vp(V_A + 2 * k), (k & 1) * 2048))
+        if k & 1:
+            R("s_add_u32 s86, s86, 0x1000")
+            R("s_addc_u32 s87, s87, 0")
+    R("s_endpgm")
+
+
+
+
+def build():
+    em = Emitter()
+    vm = VmCounter(em)
+    R = em.raw
+    tw_seq = prologue(em, vm)
 
     def fwd_pass(name, nxt):
         em.comment("%s (a and b share the twiddles); prefetching %s" % (name, nxt))
@@ -551,25 +592,11 @@ def build():
     lds_read(em, V_L1W, V_A, 2176)
     R("s_waitcnt lgkmcnt(0)")
     inv_pass("I3", None, stages=(3, 2, 1))
-    R("s_cmp_eq_u32 s88, 0")
-    R("s_cbranch_scc1 .Lmerged_last_stage")
-    em.comment("r > 0: plain stage r (uniform twiddle psi[(2<<r) - 1 - blk]); lazy output for the outer passes")
-    vm.wait(tw_seq[("I3", 0)])
-    gs_stage(em, V_A, 0)
-    R("s_branch .Lstore")
-    em.lines.append(".Lmerged_last_stage:")
-    em.comment("r == 0: stage 0 with n^-1 folded in")
-    R("s_waitcnt vmcnt(0)")
-    run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
-    em.lines.append(".Lstore:")
-    # ---------------- store c
-    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
-    for k in range(16):
-        R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (V_OFF8, vp(V_A + 2 * k), (k & 1) * 2048))
-        if k & 1:
-            R("s_add_u32 s86, s86, 0x1000")
-            R("s_addc_u32 s87, s87, 0")
-    R("s_endpgm")
+
+    def last_plain():
+        vm.wait(tw_seq[("I3", 0)])
+        gs_stage(em, V_A, 0)
+    epilogue(em, vm, last_plain)
     return em
 
 
