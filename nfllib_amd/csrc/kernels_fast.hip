@@ -397,31 +397,41 @@ static int variant() {
 static const unsigned char kPolymulHsaco[] = {
 #include "polymul4096_hsaco.inc"
 };
+enum AsmKind { kAsmPolymul = 0, kAsmPolymulNtt, kAsmFwd, kAsmInv, kAsmInvMul, kAsmCount };
+static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm", "nflhip_polymul_ntt4096_asm", "nflhip_ntt_fwd4096_asm",
+                                                 "nflhip_ntt_inv4096_asm", "nflhip_ntt_inv_mul4096_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
+  hipFunction_t fn[kAsmCount] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool tried = false;
 };
 static AsmKernel g_asm[16];  // per device
 
-static hipFunction_t asm_polymul_fn() {
+static hipFunction_t asm_fn(AsmKind kind) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   AsmKernel &k = g_asm[dev];
   if (!k.tried) {
     k.tried = true;
-    if (hipModuleLoadData(&k.mod, kPolymulHsaco) != hipSuccess ||
-        hipModuleGetFunction(&k.fn, k.mod, "nflhip_polymul4096_asm") != hipSuccess) {
-      k.fn = nullptr;
+    if (hipModuleLoadData(&k.mod, kPolymulHsaco) != hipSuccess) {
+      k.mod = nullptr;
       (void)hipGetLastError();
+    } else {
+      for (int i = 0; i < kAsmCount; ++i)
+        if (hipModuleGetFunction(&k.fn[i], k.mod, kAsmNames[i]) != hipSuccess) {
+          k.fn[i] = nullptr;
+          (void)hipGetLastError();
+        }
     }
   }
-  return k.fn;
+  return k.fn[kind];
 }
 
-static hipError_t launch_polymul_asm(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
-                                     size_t batch, hipStream_t st) {
-  hipFunction_t fn = asm_polymul_fn();
+// every generated kernel takes (dst, src_a, src_b, psi, mc, nm, logn) and one workgroup per 4096-word block
+static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a,
+                             const uint64_t *b, size_t batch, hipStream_t st) {
+  if (variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+  hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
   struct {
     void *c;
@@ -437,9 +447,9 @@ static hipError_t launch_polymul_asm(const Shape &s, const DevTables &t, uint64_
 
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                          const uint64_t *b_in, size_t batch, hipStream_t st) {
-  if (s.limb_bits != 64 || s.logn < kLogN || !s.small_delta || s.nm > 65535 || variant() < 50) return hipErrorNotSupported;
+  if (s.limb_bits != 64 || s.logn < kLogN) return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
-  return launch_polymul_asm(s, t, c, a_in, b_in, batch, st);
+  return launch_asm(kAsmPolymul, s, t, c, a_in, b_in, batch, st);
 }
 
 template <bool B_IS_NTT>
@@ -468,8 +478,8 @@ hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t 
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
-  if (!b_is_ntt && s.small_delta && variant() >= 50 && s.nm <= 65535) {
-    const hipError_t e = launch_polymul_asm(s, t, c, a, b, batch, st);
+  {
+    const hipError_t e = launch_asm(b_is_ntt ? kAsmPolymulNtt : kAsmPolymul, s, t, c, a, b, batch, st);
     if (e != hipErrorNotSupported) return e;
   }
   return b_is_ntt ? launch_polymul_v<true>(s, t, c, a, b, (unsigned)rows, st)
@@ -484,6 +494,10 @@ hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const u
   const size_t blocks = rows << (s.logn - kLogN);
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  if (rows % s.nm == 0) {  // the generated kernels index rows as (poly, modulus)
+    const hipError_t e = launch_asm(kAsmFwd, s, t, dst, src, nullptr, rows / s.nm, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const dim3 g((unsigned)blocks), b(kThreads);
@@ -500,6 +514,10 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
   const size_t blocks = rows << (s.logn - kLogN);
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  if (rows % s.nm == 0) {
+    const hipError_t e = launch_asm(mul ? kAsmInvMul : kAsmInv, s, t, dst, src, mul, rows / s.nm, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const dim3 g((unsigned)blocks), b(kThreads);

@@ -221,8 +221,7 @@ def test_full_size_properties_metric_shape(oracle_factory, engine_factory):
     c = e.polymul(a, b)
     # commutativity, and INTT(NTT(a)) == a over the whole batch
     assert not e.any_neq(c, e.polymul(b, a))
-    # two independent device code paths must agree word for word on the whole batch: the
-    # hand-scheduled assembly kernel (polymul) vs the hipcc-compiled kernel (b already in NTT form)
+    # the "b already transformed" kernel must agree word for word with the fused one on the whole batch
     assert not e.any_neq(c, e.polymul(a, e.ntt_(b.clone()), b_is_ntt=True))
     rt = e.intt_(e.ntt_(a.clone()))
     assert not e.any_neq(rt, a)
@@ -269,3 +268,43 @@ def test_fused_expression_trees(lb, n, m, oracle_factory, engine_factory):
     for bad in ([0, ADD], [0, 1], [0, 1, 2, 0, 1, ADD], [9, 0, ADD], [0, 1, 0x7f]):
         with pytest.raises(NflHipError):
             e.eval(bad, [da, db, dc])
+
+
+_VARIANT_CHILD = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from nfllib_amd import Engine
+from nfllib_amd.sharding import digest_words
+out = {}
+for n, m, batch in ((4096, 4, 512), (16384, 8, 4)):
+    e = Engine(64, n, m)
+    a = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 0)
+    b = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 1)
+    fb = e.ntt_(b.clone())
+    d = {"ntt": digest_words(e.to_host(fb)),
+         "intt": digest_words(e.to_host(e.intt_(a.clone()))),
+         "polymul": digest_words(e.to_host(e.polymul(a, b))),
+         "polymul_ntt": digest_words(e.to_host(e.polymul(a, fb, b_is_ntt=True)))}
+    out["%d_%d" % (n, m)] = d
+print(json.dumps(out))
+"""
+
+
+def test_assembly_and_compiled_kernels_agree():
+    """Two independently produced device programs for the 4096-word blocks -- the generated assembly
+    (tools/gen_polymul_asm.py, default) and the hipcc-compiled templates (NFLHIP_VARIANT=32) -- must give the
+    same words for every entry point they serve, over whole batches.  The variant is latched per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for v in ("52", "32", "2"):
+        env = dict(os.environ, NFLHIP_VARIANT=v)
+        r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, root, str(SEED)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[v] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["52"] == got["32"] == got["2"]

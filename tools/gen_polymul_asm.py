@@ -237,6 +237,14 @@ def csub_p(s, reg):
 
 
 
+def canon(reg):
+    """any 64-bit word -> canonical [0,p): two-bit fold (< p + 4*delta) then one conditional subtract."""
+    def gen(s):
+        yield from fold2(s, reg, reg)
+        yield from csub_p(s, reg)
+    return gen
+
+
 def final_bfly(x, y):
     """Last inverse stage with n^-1 folded in; canonical outputs."""
     tw_n = ("s%d" % S_NINV[0], "s%d" % S_NINV[1], "s%d" % S_NINVSH[0], "s%d" % S_NINVSH[1])
@@ -257,14 +265,17 @@ def final_bfly(x, y):
     return gen
 
 
-def pointwise(xa, xb):
-    """xa = fold2(xa*xb mod p) with lazily reduced operands (mul_lazy of kernels_fast.hip)."""
+def pointwise(xa, xb, fold_a=True, fold_b=True):
+    """xa = fold2(xa*xb mod p) with lazily reduced operands (mul_lazy of kernels_fast.hip);
+    an operand known to be canonical (< p) skips its fold."""
     mu0, mu1 = "s%d" % S_MU2[0], "s%d" % S_MU2[1]
 
     def gen(s):
         L, A, P, Q, H, E, ZP = T(s, 16), T(s, 6), T(s, 2), T(s, 8), T(s, 10), T(s, 12), T(s, 14)
-        yield from fold2(s, xa, xa)
-        yield from fold2(s, xb, xb)
+        if fold_a:
+            yield from fold2(s, xa, xa)
+        if fold_b:
+            yield from fold2(s, xb, xb)
         # T = xa*xb as four dwords: T0 = L.lo, T1 = A.lo, T2 = E.lo, T3 = E.hi
         yield "v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(L), S_DUMMY, xa, xb), None, None
         yield "v_mov_b32_e32 v%d, v%d" % (ZP, L + 1), None, None
@@ -410,7 +421,25 @@ PASS_TW = {
 }
 
 
-def prologue(em, vm, ring=None):
+def lane_contig_setup(em):
+    """T(1,0) = byte offset of element 1024*w + l inside a 4096-word block (w = t>>6, l = t&63);
+    T(1,1) = padded LDS byte address of the same element.  Per j the element 1024w + 64j + l sits at
+    +512*j bytes in global memory and +544*j bytes in the padded slab."""
+    g, l = T(1, 0), T(1, 1)
+    em.valu("v_lshrrev_b32_e32 v%d, 6, v%d" % (g, V_TID))                 # w
+    em.valu("v_and_b32_e32 v%d, 63, v%d" % (l, V_TID))                    # l
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (T(1, 2), l))               # l >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (T(1, 2), T(1, 2), l))        # l + (l>>4)
+    em.valu("v_mov_b32_e32 v%d, 0x440" % (T(1, 3),))                      # 1088 = 1024 + 64
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (T(1, 2), g, T(1, 3), T(1, 2)))
+    em.valu("v_lshlrev_b32_e32 v%d, 10, v%d" % (g, g))
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (g, g, l))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (g, g))                      # global byte offset
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (l, T(1, 2)))                # LDS byte address
+    return g, l
+
+
+def prologue(em, vm, kind="polymul"):
     R = em.raw
     # ---------------- prologue
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
@@ -478,14 +507,39 @@ def prologue(em, vm, ring=None):
                 R("s_add_u32 s86, s86, 0x1000")
                 R("s_addc_u32 s87, s87, 0")
         return seq
-    seq_a = row_loads(V_A, S_AROW)
-    seq_b = row_loads(V_B, S_BROW)
+    def lane_loads(dst_base, srow):
+        """element 1024w + 64j + l -> register pair j (fully coalesced 512 B per wave instruction)"""
+        g, _ = lane_contig_setup(em)
+        R("s_mov_b64 s[86:87], %s" % (srow,))
+        for j in range(16):
+            vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d" % (vp(dst_base + 2 * j), g, (j & 7) * 512))
+            if j == 7:
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+
+    def thread16_loads(dst_base, srow):
+        """words 16t .. 16t+15 (the layout NTT-form data has after F3) as 8 x 16-byte loads"""
+        em.valu("v_lshlrev_b32_e32 v%d, 7, v%d" % (T(1, 0), V_TID))
+        for i in range(8):
+            vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (dst_base + 4 * i, dst_base + 4 * i + 3, T(1, 0), srow, 16 * i))
+
+    if kind == "polymul":
+        row_loads(V_A, S_AROW)
+        row_loads(V_B, S_BROW)
+    elif kind == "polymul_ntt":
+        row_loads(V_A, S_AROW)
+        thread16_loads(V_B, S_BROW)
+    elif kind == "fwd":
+        row_loads(V_A, S_AROW)
+    elif kind == "inv":
+        lane_loads(V_A, S_AROW)
+    elif kind == "inv_mul":
+        lane_loads(V_A, S_AROW)
+        lane_loads(V_B, S_BROW)
+    first = "I1" if kind in ("inv", "inv_mul") else "F1"
     tw_seq = {}
-    if ring is None:
-        for s in range(4):
-            tw_seq[("F1", s)] = PASS_TW["F1"](em, vm, s)
-    else:
-        ring.prime()
+    for s in ((3, 2, 1, 0) if first == "I1" else (0, 1, 2, 3)):
+        tw_seq[(first, s)] = PASS_TW[first](em, vm, s)
     R("s_waitcnt lgkmcnt(0)")
     # constants from the ModConst record
     R("s_mov_b64 s[24:25], s[56:57]")                    # p
@@ -505,7 +559,7 @@ def prologue(em, vm, ring=None):
     return tw_seq
 
 
-def epilogue(em, vm, last_plain_stage):
+def epilogue_inverse(em, vm, last_plain_stage):
     R = em.raw
     R("s_cmp_eq_u32 s88, 0")
     R("s_cbranch_scc1 .Lmerged_last_stage")
@@ -517,7 +571,7 @@ def epilogue(em, vm, last_plain_stage):
     R("s_waitcnt vmcnt(0)")
     run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
     em.lines.append(".Lstore:")
-    # ---------------- store c
+    # ---------------- store c (x[t + 256k])
     R("s_mov_b64 s[86:87], %s" % (S_CROW,))
     for k in range(16):
         R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (V_OFF8, vp(V_A + 2 * k), (k & 1) * 2048))
@@ -527,22 +581,50 @@ def epilogue(em, vm, last_plain_stage):
     R("s_endpgm")
 
 
+def epilogue_forward(em, vm):
+    """canonical words, then a wave-local LDS transpose so the stores are fully coalesced"""
+    R = em.raw
+    run_pairs(em, [canon(V_A + 2 * i) for i in range(16)])
+    lds_write(em, V_L2R, V_A, 8)
+    g, l = lane_contig_setup(em)
+    for j in range(16):
+        R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * j), l, 544 * j))
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
+    for j in range(16):
+        R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (g, vp(V_A + 2 * j), (j & 7) * 512))
+        if j == 7:
+            R("s_add_u32 s86, s86, 0x1000")
+            R("s_addc_u32 s87, s87, 0")
+    R("s_endpgm")
 
 
-def build():
+def build(kind="polymul"):
+    """kind: polymul | polymul_ntt (b already in NTT form) | fwd | inv | inv_mul (inverse of src (.) mul)"""
     em = Emitter()
     vm = VmCounter(em)
     R = em.raw
-    tw_seq = prologue(em, vm)
+    tw_seq = prologue(em, vm, kind)
+    has_fwd = kind in ("polymul", "polymul_ntt", "fwd")
+    has_inv = kind != "fwd"
+    fwd_bases = [V_A, V_B] if kind == "polymul" else [V_A]
+    passes = (["F1", "F2", "F3"] if has_fwd else []) + (["I1", "I2", "I3"] if has_inv else [])
 
-    def fwd_pass(name, nxt):
-        em.comment("%s (a and b share the twiddles); prefetching %s" % (name, nxt))
+    def nxt_of(name):
+        i = passes.index(name)
+        return passes[i + 1] if i + 1 < len(passes) else None
+
+    def fwd_pass(name):
+        nxt = nxt_of(name)
+        em.comment("%s; prefetching %s" % (name, nxt))
         for s in range(4):
             vm.wait(tw_seq[(name, s)])
-            ct_stage(em, [V_A, V_B], s)
-            tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
+            ct_stage(em, fwd_bases, s)
+            if nxt is not None:
+                tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
 
-    def inv_pass(name, nxt, stages=(3, 2, 1, 0)):
+    def inv_pass(name, stages=(3, 2, 1, 0)):
+        nxt = nxt_of(name)
         em.comment("%s; prefetching %s" % (name, nxt))
         for s in stages:
             vm.wait(tw_seq[(name, s)])
@@ -550,53 +632,64 @@ def build():
             if nxt is not None:
                 tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
 
-    # ---------------- forward
-    fwd_pass("F1", "F2")
-    em.comment("E1(a)")
-    lds_write(em, V_L1W, V_A, 2176)
-    R("s_waitcnt lgkmcnt(0)")
-    R("s_barrier")
-    lds_read(em, V_L1R, V_A, 136)
-    R("s_waitcnt lgkmcnt(0)")
-    R("s_barrier")
-    em.comment("E1(b)")
-    lds_write(em, V_L1W, V_B, 2176)
-    R("s_waitcnt lgkmcnt(0)")
-    R("s_barrier")
-    lds_read(em, V_L1R, V_B, 136)
-    R("s_waitcnt lgkmcnt(0)")
-    fwd_pass("F2", "F3")
-    em.comment("E2(a), E2(b): wave-local 16-lane transposes (LDS is in order per wave)")
-    lds_write(em, V_L1R, V_A, 136)
-    lds_read(em, V_L2R, V_A, 8)
-    lds_write(em, V_L1R, V_B, 136)
-    lds_read(em, V_L2R, V_B, 8)
-    R("s_waitcnt lgkmcnt(0)")
-    fwd_pass("F3", "I1")
+    if has_fwd:
+        fwd_pass("F1")
+        for i, base in enumerate(fwd_bases):
+            em.comment("E1")
+            if i:
+                R("s_barrier")       # WAR: the slab is still being read for the previous operand
+            lds_write(em, V_L1W, base, 2176)
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            lds_read(em, V_L1R, base, 136)
+            R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F2")
+        em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+        for base in fwd_bases:
+            lds_write(em, V_L1R, base, 136)
+            lds_read(em, V_L2R, base, 8)
+        R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F3")
+    if kind == "fwd":
+        epilogue_forward(em, vm)
+        return em
 
-    # ---------------- point-wise product into a
-    em.comment("point-wise product")
-    run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i) for i in range(16)])
+    if kind in ("polymul", "polymul_ntt"):
+        em.comment("point-wise product (thread q holds words 16q..16q+15 of both operands)")
+        run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i, True, kind == "polymul") for i in range(16)])
+    else:
+        R("s_waitcnt vmcnt(%d)" % (vm.issued - (32 if kind == "inv_mul" else 16)))   # the row loads have landed
+        if kind == "inv_mul":
+            em.comment("point-wise product of canonical NTT-form operands (any common layout works)")
+            run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i, False, False) for i in range(16)])
+        em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
+        _, l = lane_contig_setup(em)
+        for j in range(16):
+            R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
+        lds_read(em, V_L2R, V_A, 8)
+        R("s_waitcnt lgkmcnt(0)")
 
-    # ---------------- inverse
-    inv_pass("I1", "I2")
+    inv_pass("I1")
     em.comment("E2'")
     lds_write(em, V_L2R, V_A, 8)
     lds_read(em, V_L1R, V_A, 136)
     R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I2", "I3")
+    inv_pass("I2")
     em.comment("E1'")
     lds_write(em, V_L1R, V_A, 136)
     R("s_waitcnt lgkmcnt(0)")
     R("s_barrier")
     lds_read(em, V_L1W, V_A, 2176)
     R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I3", None, stages=(3, 2, 1))
+    inv_pass("I3", stages=(3, 2, 1))
 
     def last_plain():
         vm.wait(tw_seq[("I3", 0)])
         gs_stage(em, V_A, 0)
-    epilogue(em, vm, last_plain)
+    # I3's sub-stage-0 record is only used by the r > 0 tail; make sure it was requested
+    if ("I3", 0) not in tw_seq:
+        tw_seq[("I3", 0)] = PASS_TW["I3"](em, vm, 0)
+    epilogue_inverse(em, vm, last_plain)
     return em
 
 
@@ -662,16 +755,28 @@ amdhsa.version:
 """
 
 
+KERNELS = {   # kind -> (file suffix, kernel symbol)
+    "polymul": ("polymul4096", "nflhip_polymul4096_asm"),
+    "polymul_ntt": ("polymul_ntt4096", "nflhip_polymul_ntt4096_asm"),
+    "fwd": ("ntt_fwd4096", "nflhip_ntt_fwd4096_asm"),
+    "inv": ("ntt_inv4096", "nflhip_ntt_inv4096_asm"),
+    "inv_mul": ("ntt_inv_mul4096", "nflhip_ntt_inv_mul4096_asm"),
+}
+
+
 def main():
-    em = build()
-    accum = (NEXT_VGPR + 3) // 4 * 4
-    params = dict(k=KNAME, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6)
-    with open(OUT, "w") as f:
-        f.write("; GENERATED by tools/gen_polymul_asm.py -- do not edit.\n")
-        f.write(HEADER % params)
-        f.write("\n".join(em.lines) + "\n")
-        f.write(FOOTER % params)
-    print("wrote %s: %d VALU instructions per wave, %d hazard nops, %d lines" % (OUT, em.n_valu, em.n_nop, len(em.lines)))
+    outdir = os.path.dirname(OUT)
+    for kind, (stem, kname) in KERNELS.items():
+        em = build(kind)
+        accum = (NEXT_VGPR + 3) // 4 * 4
+        params = dict(k=kname, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6)
+        path = os.path.join(outdir, stem + "_gfx950.s")
+        with open(path, "w") as f:
+            f.write("; GENERATED by tools/gen_polymul_asm.py -- do not edit.\n")
+            f.write(HEADER % params)
+            f.write("\n".join(em.lines) + "\n")
+            f.write(FOOTER % params)
+        print("wrote %s: %d VALU instructions (static), %d hazard nops, %d lines" % (path, em.n_valu, em.n_nop, len(em.lines)))
 
 
 if __name__ == "__main__":
