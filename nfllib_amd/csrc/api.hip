@@ -167,6 +167,38 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     Big sh = big_shl(Q, k, Lacc);
     for (size_t i = 0; i < Lacc; ++i) qsh[k * kStride + i] = sh[i];
   }
+  // carry-free multiply-accumulate tables for 64-bit limbs (kernels_crt.hip)
+  std::vector<uint32_t> qparts, bparts;
+  int proj_K = 0;
+  if (wb == 64 && crt_ok && nm <= 32) {
+    const size_t L = c->shape.crt_L, S32 = 2 * kStride;
+    qparts.assign(nm * 3 * S32, 0);
+    for (size_t cm = 0; cm < nm; ++cm) {
+      Big quot;
+      big_divrem_u64(Q, P[cm], &quot);
+      for (int j = 0; j < 3; ++j) {
+        const Big sh = big_shl(quot, 21 * j, L);  // (Q/p) << 42 < Q: fits L words
+        for (size_t i = 0; i < L; ++i) {
+          qparts[(cm * 3 + j) * S32 + 2 * i] = (uint32_t)sh[i];
+          qparts[(cm * 3 + j) * S32 + 2 * i + 1] = (uint32_t)(sh[i] >> 32);
+        }
+      }
+    }
+    proj_K = (int)(2 * L + 2);
+    const size_t nmS = (nm + 3) & ~(size_t)3;  // row stride: zero padded, the kernel runs without guards
+    bparts.assign((size_t)proj_K * 2 * 3 * nmS, 0);
+    for (size_t cm = 0; cm < nm; ++cm) {
+      const uint64_t p = P[cm], two32 = (((uint64_t)1) << 32) % p;
+      uint64_t cur = 1 % p;  // 2^(32 t) mod p, t = 2k + half
+      for (size_t t = 0; t < (size_t)proj_K * 2; ++t) {
+        uint32_t *e = &bparts[t * 3 * nmS + cm];
+        e[0] = (uint32_t)(cur & 0x1fffff);
+        e[nmS] = (uint32_t)((cur >> 21) & 0x1fffff);
+        e[2 * nmS] = (uint32_t)(cur >> 42);
+        cur = mulmod_h(cur, two32, p);
+      }
+    }
+  }
 
   // twiddles + per-modulus constants
   std::vector<Tw<T>> psi(nm * n);
@@ -222,6 +254,22 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   HIPCHK(nullptr, hipMemcpy(c->tabs.qhat, qhat.data(), qhat.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qsh, qsh.size() * sizeof(uint64_t)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.qsh, qsh.data(), qsh.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  c->tabs.qparts = nullptr;
+  c->tabs.bparts = nullptr;
+  c->tabs.proj_K = 0;
+  if (!qparts.empty()) {
+    HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qparts, qparts.size() * sizeof(uint32_t)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.qparts, qparts.data(), qparts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMalloc((void **)&c->tabs.bparts, bparts.size() * sizeof(uint32_t)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.bparts, bparts.data(), bparts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->tabs.proj_K = proj_K;
+    // Q / 2^(32 max(2L - 3, 0)) from its top words (the kernel divides the top five 32-bit digits of the sum by it)
+    const size_t L = c->shape.crt_L;
+    long double qt = 0.0L;
+    for (size_t k = L; k-- > 0;) qt = qt * 18446744073709551616.0L + (long double)Q[k];
+    for (long w = 0; w < 2 * (long)L - 3; ++w) qt /= 4294967296.0L;
+    c->tabs.inv_qtop = (double)(1.0L / qt);
+  }
   HIPCHK(nullptr, hipMalloc((void **)&c->tabs.flag, sizeof(int)));
   return NFLHIP_OK;
 }
@@ -404,6 +452,8 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->tabs.mc) (void)hipFree(ctx->tabs.mc);
   if (ctx->tabs.qhat) (void)hipFree(ctx->tabs.qhat);
   if (ctx->tabs.qsh) (void)hipFree(ctx->tabs.qsh);
+  if (ctx->tabs.qparts) (void)hipFree(ctx->tabs.qparts);
+  if (ctx->tabs.bparts) (void)hipFree(ctx->tabs.bparts);
   if (ctx->tabs.flag) (void)hipFree(ctx->tabs.flag);
   delete ctx;
   return NFLHIP_OK;

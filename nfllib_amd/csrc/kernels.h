@@ -46,6 +46,10 @@ struct DevTables {
   void *mc;         // [nm] ModConst<T>
   uint64_t *qhat;   // [nm][crt_Lacc]  Q/p_cm, little-endian limbs
   uint64_t *qsh;    // [6][crt_Lacc]   Q << k, k = 0..5
+  uint32_t *qparts; // [nm][3][72]     32-bit digits of (Q/p_cm) << 21 j   (carry-free lift), or nullptr
+  uint32_t *bparts; // [proj_K][2][3][nm rounded up to 4] 21-bit parts of 2^(64k+32h) mod p_cm (project), or nullptr
+  int proj_K;       // input words the project table covers
+  double inv_qtop;  // 2^(32 (2 crt_L - 3)) / Q in double precision (quotient estimate of the lift)
   int *flag;        // 1 int, result of any_eq / any_neq
 };
 

@@ -156,7 +156,8 @@ def test_any_eq_neq_reference_semantics(lb, n, m, oracle_factory, engine_factory
 
 
 @pytest.mark.parametrize("lb,n,m,batch", [(64, 4096, 4, 2), (64, 16384, 8, 1), (64, 65536, 30, 1), (32, 1024, 2, 2),
-                                           (16, 128, 1, 3), (64, 64, 3, 3)])
+                                           (16, 128, 1, 3), (64, 64, 3, 3), (64, 256, 5, 2), (64, 128, 13, 2),
+                                           (64, 64, 21, 1), (64, 32, 32, 2), (64, 16, 1, 3)])
 def test_crt_lift_project(lb, n, m, batch, oracle_factory, engine_factory):
     o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
     assert e.crt_limbs == o.crt_limbs
@@ -165,19 +166,25 @@ def test_crt_lift_project(lb, n, m, batch, oracle_factory, engine_factory):
         assert e.crt_constant(1, cm) == o.crt_lifting(cm)
     a, _ = _inputs(o, batch)
     a[0, :, 0] = 0  # the reference skips zero residues (gmp.hpp:193)
+    if n > 1:
+        a[0, :, 1] = np.asarray(o.P[:m], dtype=a.dtype) - 1  # all residues p-1: X = Q-1, the largest lift
     da = e.to_device(a)
     limbs = e.crt_lift(da)
     got = limbs.cpu().numpy().view(np.uint64)
     assert np.array_equal(got, o.crt_lift(a)), "poly2mpz differs"
     back = e.crt_project(limbs)
     assert np.array_equal(e.to_host(back), a), "mpz2poly(poly2mpz(a)) != a (tests/poly_mpz.cpp:19-29)"
-    # reduction of wide non-negative integers (tests/poly_mpz.cpp:44-64): 4 limbs of noise
-    rng = np.random.default_rng(0)
-    wide = rng.integers(0, 2**63, size=(batch, n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(
-        0, 2, size=(batch, n, 4), dtype=np.uint64)
+    # reduction of wide non-negative integers (tests/poly_mpz.cpp:44-64): noise of 4 limbs, of the widest input
+    # the multiply-accumulate table covers (2L+2), and of one beyond it (the Horner kernel)
     import torch
-    dw = torch.from_numpy(wide.view(np.int64)).to(da.device)
-    assert np.array_equal(e.to_host(e.crt_project(dw)), o.crt_project(wide))
+    rng = np.random.default_rng(0)
+    L = e.crt_limbs
+    for lin in ((4, 2 * L + 2, 2 * L + 5) if n <= 4096 else (4,)):
+        wide = rng.integers(0, 2**63, size=(batch, n, lin), dtype=np.uint64) * np.uint64(2) + rng.integers(
+            0, 2, size=(batch, n, lin), dtype=np.uint64)
+        wide[0, 0, :] = np.uint64(0xFFFFFFFFFFFFFFFF)  # all-ones words: the accumulators' worst case
+        dw = torch.from_numpy(wide.view(np.int64)).to(da.device)
+        assert np.array_equal(e.to_host(e.crt_project(dw)), o.crt_project(wide)), "L_in = %d" % lin
 
 
 @pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (32, 1024, 1), (64, 8, 2)])

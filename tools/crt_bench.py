@@ -15,10 +15,10 @@ for lb, n, nm, batch in [(64, 4096, 4, 4096), (64, 16384, 8, 256), (64, 65536, 3
     for name, fn in (("lift", lambda: e.crt_lift(a)), ("project", lambda: e.crt_project(limbs))):
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(20):
             fn()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 5
+        dt = (time.perf_counter() - t0) / 20
         L = e.crt_limbs
         alg = batch * (nm * n * 8 + n * L * 8)
         print("u%d/%d/%d batch %d  %-8s %8.3f ms  %10.1f polys/s  %6.1f GB/s algorithmic (L=%d)" % (lb, n, nm, batch, name, dt * 1e3, batch / dt, alg / dt / 1e9, L))
