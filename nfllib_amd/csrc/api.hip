@@ -319,6 +319,13 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 14) {
+    // a 16384-word row fits one CU: the whole product is a single launch, 3 operand streams of HBM traffic
+    e = launch_polymul_blocks16k_asm_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b,
+                                         batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul: 16384-word rows");
+  }
   if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn > 12 && ctx->aux[0]) {
     // large rows: streaming outer passes, then the fused assembly kernel over the 4096-word blocks,
     // then the outer inverse passes (9 operand streams of HBM traffic instead of 13).  The batch is cut
@@ -332,19 +339,26 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       if (ctx->ev_prev_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_done[1 - k], 0));  // previous call's scratch use
     }
     bool unsupported = false;
+    int logi = (ctx->shape.logn > 14 && row16k_level() >= 2) ? 14 : 12;  // words (log2) per block of the fused kernel
     for (size_t ch = 0; ch < nchunk && !unsupported; ++ch) {
       const size_t lo = batch * ch / nchunk, hi = batch * (ch + 1) / nchunk, cnt = hi - lo;
       if (cnt == 0) continue;
       hipStream_t s = ctx->aux[ch & 1];
       const uint64_t *ak = (const uint64_t *)a + lo * pw, *bk = (const uint64_t *)b + lo * pw;
       uint64_t *ck = (uint64_t *)c + lo * pw, *s0k = (uint64_t *)s0 + lo * pw, *s1k = (uint64_t *)s1 + lo * pw;
-      e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, ak, s0k, cnt * nm, s);
-      if (e == hipSuccess) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, bk, s1k, cnt * nm, s);
+      e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, ak, s0k, cnt * nm, s, logi);
+      if (e == hipSuccess) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, bk, s1k, cnt * nm, s, logi);
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer forward");
-      e = launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, ck, s0k, s1k, cnt, s);
+      e = logi == 14 ? launch_polymul_blocks16k_asm_u64(ctx->shape, ctx->tabs, ck, s0k, s1k, cnt, s)
+                     : launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, ck, s0k, s1k, cnt, s);
+      if (e == hipErrorNotSupported && logi == 14 && ch == 0) {  // no 16384-word kernel: redo this chunk on 4096-word blocks
+        logi = 12;
+        --ch;
+        continue;
+      }
       if (e == hipErrorNotSupported) { unsupported = true; break; }
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: fused blocks");
-      e = launch_outer_inv_u64(ctx->shape, ctx->tabs, ck, cnt * nm, s);
+      e = launch_outer_inv_u64(ctx->shape, ctx->tabs, ck, cnt * nm, s, logi);
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer inverse");
     }
     for (int k = 0; k < 2; ++k) {

@@ -95,14 +95,22 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
                                      uint64_t *dst, size_t rows, hipStream_t st);
 
 // streaming outer passes alone (rows with logn > 12): forward src -> dst, inverse in place
+// (`logi` = log2 of the block the following fused kernel owns: global stages [0, logn - logi) run here)
 hipError_t launch_outer_fwd_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t rows,
-                                hipStream_t st);
-hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *data, size_t rows, hipStream_t st);
+                                hipStream_t st, int logi = 12);
+hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *data, size_t rows, hipStream_t st,
+                                int logi = 12);
 // fused NTT,NTT,(.),INTT over the 4096-word blocks of rows whose outer forward passes already ran
 // (a_in, b_in) and whose outer inverse passes still have to run on c (logn > 12), or the whole
 // polymul for logn == 12.  hipErrorNotSupported when the assembly code object is unavailable.
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                          const uint64_t *b_in, size_t batch, hipStream_t st);
+
+// the same over 16384-word blocks (logn >= 14): one 1024-thread workgroup keeps a block on its CU for global stages
+// logn-14 .. logn-1 of both operands, the product and the way back.
+hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
+                                            const uint64_t *b_in, size_t batch, hipStream_t st);
+int row16k_level();  // NFLHIP_ROW16K: 0 off, 1 rows of 16384 words only (default), 2 also as block kernel of longer rows
 
 // register-resident CRT kernels for 64-bit limbs (kernels_crt.hip); hipErrorNotSupported otherwise
 hipError_t launch_crt_lift_fast_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,

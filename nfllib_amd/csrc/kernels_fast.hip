@@ -397,12 +397,13 @@ static int variant() {
 static const unsigned char kPolymulHsaco[] = {
 #include "polymul4096_hsaco.inc"
 };
-enum AsmKind { kAsmPolymul = 0, kAsmPolymulNtt, kAsmFwd, kAsmInv, kAsmInvMul, kAsmCount };
-static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm", "nflhip_polymul_ntt4096_asm", "nflhip_ntt_fwd4096_asm",
-                                                 "nflhip_ntt_inv4096_asm", "nflhip_ntt_inv_mul4096_asm"};
+enum AsmKind { kAsmPolymul = 0, kAsmPolymulNtt, kAsmFwd, kAsmInv, kAsmInvMul, kAsmPolymul16k, kAsmCount };
+static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "nflhip_polymul_ntt4096_asm",
+                                                 "nflhip_ntt_fwd4096_asm",     "nflhip_ntt_inv4096_asm",
+                                                 "nflhip_ntt_inv_mul4096_asm", "nflhip_polymul16384_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
-  hipFunction_t fn[kAsmCount] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipFunction_t fn[kAsmCount] = {};
   bool tried = false;
 };
 static AsmKernel g_asm[16];  // per device
@@ -440,9 +441,32 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   } args = {c, a, b, t.psi, t.mc, (int)s.nm, s.logn};
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  const size_t gx = batch << (s.logn - kLogN);  // one workgroup per 4096-word block
+  // one 256-thread workgroup per 4096-word block, or one 1024-thread workgroup per 16384-word block
+  const int blog = kind == kAsmPolymul16k ? kLogN + 2 : kLogN;
+  if (s.logn < blog) return hipErrorNotSupported;
+  const size_t gx = batch << (s.logn - blog);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
-  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kind == kAsmPolymul16k ? 1024 : kThreads, 1, 1, 0, st,
+                               nullptr, extra);
+}
+
+// rows of >= 16384 words: whole 16384-word blocks stay on one CU (global stages logn-14 .. logn-1 and back).
+// NFLHIP_ROW16K = 0 never | 1 (default) rows of exactly 16384 words, where it removes both streaming passes
+// (measured +29 %) | 2 also as the block kernel of longer rows (measured 9 % slower than 4096-word blocks at
+// n = 65536: same HBM traffic, and the single-stream 128-VGPR schedule issues less densely).
+int row16k_level() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("NFLHIP_ROW16K");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
+                                            const uint64_t *b_in, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn < kLogN + 2 || row16k_level() < (s.logn == kLogN + 2 ? 1 : 2)) return hipErrorNotSupported;
+  if (batch == 0) return hipSuccess;
+  return launch_asm(kAsmPolymul16k, s, t, c, a_in, b_in, batch, st);
 }
 
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,

@@ -241,8 +241,9 @@ static hipError_t outer_inv(const Shape &s, const DevTables &t, const T *src, T 
 
 // all streaming forward passes (global stages [0, logn - logi)): src -> dst, then in place on dst
 template <typename T>
-static hipError_t outer_fwd_all(const Shape &s, const DevTables &t, const T *src, T *dst, size_t rows, hipStream_t st) {
-  const int logi = inner_log(s);
+static hipError_t outer_fwd_all(const Shape &s, const DevTables &t, const T *src, T *dst, size_t rows, hipStream_t st,
+                                int logi_override = 0) {
+  const int logi = logi_override ? logi_override : inner_log(s);
   int done = 0;
   const T *cur = src;
   while (done < s.logn - logi) {
@@ -257,8 +258,9 @@ static hipError_t outer_fwd_all(const Shape &s, const DevTables &t, const T *src
 }
 // all streaming inverse passes (global stages logn - logi - 1 .. 0), in place
 template <typename T>
-static hipError_t outer_inv_all(const Shape &s, const DevTables &t, T *data, size_t rows, hipStream_t st) {
-  int top = s.logn - inner_log(s);
+static hipError_t outer_inv_all(const Shape &s, const DevTables &t, T *data, size_t rows, hipStream_t st,
+                                int logi_override = 0) {
+  int top = s.logn - (logi_override ? logi_override : inner_log(s));
   while (top > 0) {
     const int R = top >= 4 ? 4 : top;
     hipError_t e = outer_inv<T>(s, t, data, data, rows, top - R, R, st);
@@ -268,11 +270,11 @@ static hipError_t outer_inv_all(const Shape &s, const DevTables &t, T *data, siz
   return hipSuccess;
 }
 hipError_t launch_outer_fwd_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t rows,
-                                hipStream_t st) {
-  return outer_fwd_all<uint64_t>(s, t, src, dst, rows, st);
+                                hipStream_t st, int logi) {
+  return outer_fwd_all<uint64_t>(s, t, src, dst, rows, st, logi);
 }
-hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *data, size_t rows, hipStream_t st) {
-  return outer_inv_all<uint64_t>(s, t, data, rows, st);
+hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *data, size_t rows, hipStream_t st, int logi) {
+  return outer_inv_all<uint64_t>(s, t, data, rows, st, logi);
 }
 
 template <typename T>

@@ -309,9 +309,48 @@ def test_assembly_and_compiled_kernels_agree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
     for v in ("52", "32", "2"):
-        env = dict(os.environ, NFLHIP_VARIANT=v)
+        # 52: also without the 16384-word row kernel, so both plans for n = 16384 are compared
+        env = dict(os.environ, NFLHIP_VARIANT=v, NFLHIP_ROW16K="1" if v == "52" else "0")
         r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, root, str(SEED)], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         got[v] = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["52"] == got["32"] == got["2"]
+
+
+_ROW16K_CHILD = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from nfllib_amd import Engine
+from nfllib_amd.sharding import digest_words
+out = {}
+for n, m, batch in ((16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (65536, 3, 2)):
+    e = Engine(64, n, m)
+    a = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 0)
+    b = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 1)
+    c = e.polymul(a, b)
+    e.polymul(a, b, out=a)          # in place on an operand
+    assert not e.any_neq(a, c)
+    out["%d_%d" % (n, m)] = digest_words(e.to_host(c))
+print(json.dumps(out))
+"""
+
+
+def test_row_resident_16384_kernel_matches_block_plan():
+    """The 1024-thread kernel that keeps 16384-word blocks on one CU (NFLHIP_ROW16K: 1 = rows of exactly 16384
+    words, 2 = also as the block kernel of longer rows, exercising its plain-last-stage tail) against the
+    4096-word-block plan (0); test_polymul compares the default against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for v in ("0", "1", "2"):
+        env = dict(os.environ, NFLHIP_ROW16K=v)
+        r = subprocess.run([sys.executable, "-c", _ROW16K_CHILD, root, str(SEED)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[v] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["0"] == got["1"] == got["2"]

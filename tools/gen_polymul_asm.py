@@ -693,6 +693,333 @@ def build(kind="polymul"):
     return em
 
 
+# ------------------------------------------------------------------ 16384-word rows: one 1024-thread workgroup
+# A row of 16384 words (or a 16384-word block of a longer row) stays on one CU for the whole product:
+# 16 waves x 16 words per thread, 128 VGPRs (4 waves per SIMD).  Sub-group q = tid >> 8 (4 waves) runs the
+# 4096-word passes F1..F3 / I1..I3 above on block q in its own LDS slab; one extra radix-4 pass F0 / I0
+# (global stages r-2, r-1) in front / behind couples the four blocks through a workgroup-wide exchange X0.
+# Register budget: one butterfly at a time (18 temporaries) and the twiddle records stream through a
+# 9-slot ring in the static order the kernel consumes them.
+class Ring:
+    """Twiddle records stream through a small ring of register slots: the order in which the
+    whole kernel consumes its records is static, so each slot is refilled with the record
+    that is NSLOTS uses ahead as soon as its last butterfly has been issued."""
+
+    def __init__(self, em, vm, nslots, uses, passes):
+        self.em, self.vm, self.uses, self.passes = em, vm, uses, passes
+        self.free = list(range(nslots))
+        self.slot_of, self.seq_of = {}, {}
+        self.next = 0
+        self.cur = None   # (pass, s) whose scalar base / lane offset registers are currently set up
+
+    def regs(self, use):
+        b = V_TW + 4 * self.slot_of[use]
+        return ("v%d" % b, "v%d" % (b + 1), "v%d" % (b + 2), "v%d" % (b + 3))
+
+    def _issue(self):
+        use = self.uses[self.next]
+        self.next += 1
+        slot = self.free.pop(0)
+        self.slot_of[use] = slot
+        name, s, g = use
+        kreg, vidx, desc = self.passes[name]
+        em, r = self.em, V_TW + 4 * slot
+        if self.cur != (name, s):
+            tw_base(em, kreg, s, desc)
+            if vidx is not None:
+                em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
+                if desc:
+                    em.valu("v_mov_b32_e32 v%d, s84" % (V_TWA,))
+                    em.valu("v_mov_b32_e32 v%d, s85" % (V_TWA + 1,))
+                    em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (V_TWA, V_TWA, V_TWO), "vcc", None)
+                    em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (V_TWA + 1, V_TWA + 1), "vcc", "vcc")
+            self.cur = (name, s)
+        off = -g * 16 if desc else g * 16
+        if vidx is None:
+            text = "global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_ZERO, S_BASE2, off)
+        elif not desc:
+            text = "global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_TWO, S_BASE2, off)
+        else:
+            text = "global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (r, r + 3, vp(V_TWA), off)
+        self.seq_of[use] = self.vm.load(text)
+
+    def prime(self):
+        while self.free and self.next < len(self.uses):
+            self._issue()
+
+    def get(self, use):
+        self.vm.wait(self.seq_of[use])
+        return self.regs(use)
+
+    def done(self, use):
+        self.free.append(self.slot_of[use])
+        if self.next < len(self.uses):
+            self._issue()
+
+
+# (SGPRs of the second butterfly stream, idle in single-stream mode; s54/s55 are unused by the 4096-word map)
+S_Q, S_SLAB = "s54", "s55"                  # sub-group index, byte offset of its LDS slab
+S_K0 = {"F0": "s46", "I0": "s47"}
+SLAB_BYTES = (4096 + 256) * 8
+
+
+def configure(mode):
+    """Select the register map: "pair" = two interleaved butterflies, 15 twiddle records resident,
+    168 VGPRs (3 waves/SIMD); "ring" = one butterfly at a time, 9-slot twiddle ring, 128 VGPRs (4 waves/SIMD)."""
+    g = globals()
+    if mode == "pair":
+        g.update(SINGLE_STREAM=False, V_BIDX=5, V_PHI=6, V_A=8, V_B=40, V_TW=72, V_T=[132, 150], NEXT_VGPR=168,
+                 NEXT_SGPR=96, LDS_BYTES=SLAB_BYTES, WG_SIZE=256)
+        g.update(V_TWO=g["V_T"][1] + 1, V_TWA=g["V_T"][1] + 4, V_ZERO=g["V_T"][0] + 15)
+    else:
+        g.update(SINGLE_STREAM=True, V_BIDX=5, V_PHI=6, V_TWO=7, V_TWA=8, V_A=10, V_B=42, V_TW=74, V_T=[110, 110],
+                 NEXT_VGPR=128, NEXT_SGPR=96, RING_SLOTS=9, LDS_BYTES=4 * SLAB_BYTES, WG_SIZE=1024)
+        g.update(V_ZERO=g["V_T"][0] + 15)
+
+
+def prologue16k(em, vm, stop=None):
+    """1024 threads; v0 = tid on entry.  Leaves V_TID = tid & 255 (the thread's index inside its sub-group),
+    V_OFF8 = tid*8, the LDS addresses of the sub-group's slab, all pass constants, and the row loads issued."""
+    R = em.raw
+    if stop == -3:
+        R("s_endpgm")
+    R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
+    R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
+    R("s_load_dword s14, s[0:1], 0x28")                  # nm
+    R("s_load_dword s88, s[0:1], 0x2c")                  # logn
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))                      # tid*8
+    em.valu("v_lshrrev_b32_e32 v%d, 8, v%d" % (V_BIDX, V_TID))                      # q (wave-uniform)
+    R("s_nop 1")                 # gfx950: a VALU VGPR write needs a wait state before v_readfirstlane reads it
+    R("v_readfirstlane_b32 %s, v%d" % (S_Q, V_BIDX))
+    R("s_nop 1")                 # ... and the SGPR it writes two before an SALU read
+    em.valu("v_and_b32_e32 v%d, 0xff, v%d" % (V_TID, V_TID))                        # t = tid & 255
+    R("s_mul_i32 %s, %s, 0x%x" % (S_SLAB, S_Q, SLAB_BYTES))
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                      # B = t >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
+    em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
+    em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_BIDX, V_L2R, V_L1R))     # 272*B + r
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
+    em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
+    em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
+    for reg in (V_L1W, V_L1R, V_L2R):
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (reg, S_SLAB, reg))                  # inside the sub-group's slab
+    em.valu("v_mov_b32_e32 v%d, 0" % (V_ZERO,))
+    R("s_waitcnt lgkmcnt(0)")
+    # r = logn - 12 (>= 2); wgx = poly * 2^(r-2) + blk16; 16384-word block = ((poly*nm + cm) << (r-2)) + blk16
+    R("s_sub_u32 s88, s88, 12")
+    R("s_sub_u32 s86, s88, 2")                           # r - 2
+    R("s_lshr_b32 s42, s2, s86")                         # poly
+    R("s_lshl_b32 s43, s42, s86")
+    R("s_sub_u32 s87, s2, s43")                          # blk16
+    R("s_mul_i32 s42, s42, s14")
+    R("s_add_u32 s42, s42, s3")                          # row
+    R("s_lshl_b32 s42, s42, s86")
+    R("s_add_u32 s42, s42, s87")                         # 16384-word block index
+    R("s_lshr_b32 s43, s42, 15")
+    R("s_lshl_b32 s42, s42, 17")                         # * 131072 bytes
+    for base, row in ((6, 16), (8, 18), (4, 20)):
+        R("s_add_u32 s%d, s%d, s42" % (row, base))
+        R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    # tw = psi + (cm << (logn + 4))
+    R("s_add_u32 s43, s88, 16")
+    R("s_lshl_b32 s42, s3, s43")
+    R("s_add_u32 s22, s10, s42")
+    R("s_addc_u32 s23, s11, 0")
+    # outer pass constants: K_F0 = 2^(r-2) + blk16, K_I0 = 2^(r-1) - blk16
+    R("s_lshl_b32 %s, 1, s86" % (S_K0["F0"],))
+    R("s_add_u32 %s, %s, s87" % (S_K0["F0"], S_K0["F0"]))
+    R("s_lshl_b32 %s, 2, s86" % (S_K0["I0"],))
+    R("s_sub_u32 %s, %s, s87" % (S_K0["I0"], S_K0["I0"]))
+    # inner pass constants of block blk = 4*blk16 + q
+    R("s_lshl_b32 s89, s87, 2")
+    R("s_add_u32 s89, s89, %s" % (S_Q,))
+    R("s_lshl_b32 s90, 1, s88")
+    R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
+    R("s_lshl_b32 s91, s90, 4")
+    R("s_lshl_b32 s92, s90, 8")
+    R("s_lshl_b32 s93, 0x200, s88")
+    R("s_lshl_b32 s42, s89, 8")
+    R("s_sub_u32 s93, s93, s42")                         # (512<<r) - 256*blk
+    R("s_lshl_b32 s94, 32, s88")
+    R("s_lshl_b32 s42, s89, 4")
+    R("s_sub_u32 s94, s94, s42")                         # (32<<r) - 16*blk
+    R("s_lshl_b32 s95, 2, s88")
+    R("s_sub_u32 s95, s95, s89")                         # (2<<r) - blk
+    R("s_mul_i32 s42, s3, 0x70")
+    R("s_add_u32 s42, s12, s42")
+    R("s_addc_u32 s43, s13, 0")
+    R("s_load_dwordx16 s[56:71], s[42:43], 0x0")          # p p2 mu ninv ninv_sh w1ninv w1ninv_sh beta
+    R("s_load_dwordx8 s[72:79], s[42:43], 0x40")          # beta_sh yinv yinv_sh mask
+    R("s_load_dwordx4 s[80:83], s[42:43], 0x60")          # delta mu2
+    if stop == -2:
+        R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        R("s_endpgm")
+    for dst, srow in ((V_A, S_AROW), (V_B, S_BROW)):      # x[tid + 1024 k]
+        R("s_mov_b64 s[86:87], %s" % (srow,))
+        for k in range(16):
+            vm.load("global_load_dwordx2 %s, v%d, s[86:87]" % (vp(dst + 2 * k), V_OFF8))
+            if k < 15:
+                R("s_add_u32 s86, s86, 0x2000")
+                R("s_addc_u32 s87, s87, 0")
+    if stop == -1:
+        R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        R("s_endpgm")
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b64 s[24:25], s[56:57]")                    # p
+    R("s_mov_b64 s[26:27], s[58:59]")                    # 2p
+    R("s_add_u32 s28, s58, s56")                         # 3p
+    R("s_addc_u32 s29, s59, s57")
+    R("s_mov_b32 s30, s80")                              # delta
+    R("s_mov_b32 s31, 0x3fffffff")
+    R("s_mov_b32 s15, 0xc0000000")
+    R("s_mov_b64 s[32:33], s[82:83]")                    # mu2
+    R("s_mov_b64 s[34:35], s[62:63]")                    # ninv
+    R("s_mov_b64 s[36:37], s[64:65]")                    # ninv_sh
+    R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
+    R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
+    em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+
+
+def build_row16k(stop=None):
+    em = Emitter()
+    vm = VmCounter(em)
+    R = em.raw
+    passes = {"F0": (S_K0["F0"], None, False), "F1": (S_K["F1"], None, False), "F2": (S_K["F2"], V_BIDX, False),
+              "F3": (S_K["F3"], V_TID, False), "I1": (S_K["I1"], V_TID, True), "I2": (S_K["I2"], V_BIDX, True),
+              "I3": (S_K["I3"], None, True), "I0": (S_K0["I0"], None, True)}
+    order = {"F0": (0, 1), "F1": (0, 1, 2, 3), "F2": (0, 1, 2, 3), "F3": (0, 1, 2, 3), "I1": (3, 2, 1, 0),
+             "I2": (3, 2, 1, 0), "I3": (3, 2, 1, 0), "I0": (1, 0)}
+    uses = [(name, s, g) for name in ("F0", "F1", "F2", "F3", "I1", "I2", "I3", "I0") for s in order[name]
+            for g in range(1 << s)]
+    ring = Ring(em, vm, RING_SLOTS, uses, passes)
+    prologue16k(em, vm, stop)
+    ring.prime()
+
+    def ck(n):   # debugging aid: build_row16k(stop=n) ends the kernel at checkpoint n
+        if stop == n:
+            R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+            R("s_endpgm")
+    ck(0)
+
+    def fwd_pass(name):
+        em.comment("%s (a and b share the twiddles)" % name)
+        for s in order[name]:
+            half = 8 >> s
+            for g in range(1 << s):
+                tw = ring.get((name, s, g))
+                jobs = []
+                for h in range(half):
+                    i0 = g * 2 * half + h
+                    for base in (V_A, V_B):
+                        jobs.append(ct_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
+                run_pairs(em, jobs)
+                ring.done((name, s, g))
+
+    def inv_pass(name, stages):
+        em.comment(name)
+        for s in stages:
+            half = 8 >> s
+            for g in range(1 << s):
+                tw = ring.get((name, s, g))
+                run_pairs(em, [gs_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw)
+                               for h in range(half)])
+                ring.done((name, s, g))
+
+    AX = T(0, 0)   # exchange address scratch (the butterfly temporaries are idle during exchanges)
+    fwd_pass("F0")
+    ck(1)
+    for i, base in enumerate((V_A, V_B)):
+        em.comment("X0: thread (q, t) slot 4*qq + j  ->  sub-group qq, thread t, slot q + 4*j")
+        if i:
+            R("s_barrier")       # WAR: the slabs are still being read for the previous operand
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+        for k in range(16):
+            qq, j = k >> 2, k & 3
+            R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+        for k in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+        R("s_waitcnt lgkmcnt(0)")
+    ck(2)
+    fwd_pass("F1")
+    ck(3)
+    for base in (V_A, V_B):
+        em.comment("E1")
+        R("s_barrier")           # WAR against the previous exchange through this slab
+        lds_write(em, V_L1W, base, 2176)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        lds_read(em, V_L1R, base, 136)
+        R("s_waitcnt lgkmcnt(0)")
+    fwd_pass("F2")
+    ck(4)
+    em.comment("E2(a), E2(b): wave-local 16-lane transposes (LDS is in order per wave)")
+    for base in (V_A, V_B):
+        lds_write(em, V_L1R, base, 136)
+        lds_read(em, V_L2R, base, 8)
+    R("s_waitcnt lgkmcnt(0)")
+    fwd_pass("F3")
+    ck(5)
+    em.comment("point-wise product")
+    run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i) for i in range(16)])
+    inv_pass("I1", (3, 2, 1, 0))
+    ck(6)
+    em.comment("E2'")
+    lds_write(em, V_L2R, V_A, 8)
+    lds_read(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I2", (3, 2, 1, 0))
+    ck(7)
+    em.comment("E1'")
+    lds_write(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    lds_read(em, V_L1W, V_A, 2176)
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I3", (3, 2, 1, 0))
+    ck(8)
+    em.comment("X0': thread (q, t) slot g + 4*j  ->  thread (g, t) slot 4*q + j, reader-major layout [slot][tid]")
+    R("s_barrier")               # every wave is done reading E1'
+    R("s_lshl_b32 s86, %s, 15" % (S_Q,))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+    em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                              # q*32768 + t*8
+    for k in range(16):
+        g_, j = k & 3, k >> 2
+        R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(V_A + 2 * k), j * 8192 + g_ * 2048))
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    em.valu("v_add_u32_e32 v%d, 0x10000, v%d" % (AX, V_OFF8))
+    for k in range(16):
+        R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * 8192))
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I0", (1,))
+    ck(9)
+    R("s_cmp_eq_u32 s88, 2")
+    R("s_cbranch_scc1 .Lmerged_last_stage")
+    em.comment("r > 2: plain global stage r-2; lazy output for the outer inverse passes")
+    tw = ring.get(("I0", 0, 0))
+    run_pairs(em, [gs_bfly(V_A + 2 * h, V_A + 2 * (h + 8), tw) for h in range(8)])
+    R("s_branch .Lstore")
+    em.lines.append(".Lmerged_last_stage:")
+    em.comment("n == 16384: stage 0 with n^-1 folded in")
+    R("s_waitcnt vmcnt(0)")
+    run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
+    em.lines.append(".Lstore:")
+    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
+    for k in range(16):
+        R("global_store_dwordx2 v%d, %s, s[86:87]" % (V_OFF8, vp(V_A + 2 * k)))
+        if k < 15:
+            R("s_add_u32 s86, s86, 0x2000")
+            R("s_addc_u32 s87, s87, 0")
+    R("s_endpgm")
+    return em
+
+
 HEADER = """\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
 \t.amdhsa_code_object_version 6
 \t.text
@@ -739,7 +1066,7 @@ amdhsa.kernels:
     .group_segment_fixed_size: %(lds)d
     .kernarg_segment_align: 8
     .kernarg_segment_size: 48
-    .max_flat_workgroup_size: 256
+    .max_flat_workgroup_size: %(wg)d
     .name:           %(k)s
     .private_segment_fixed_size: 0
     .sgpr_count:     %(sgprc)d
@@ -764,19 +1091,27 @@ KERNELS = {   # kind -> (file suffix, kernel symbol)
 }
 
 
+def emit_file(path, kname, em):
+    accum = (NEXT_VGPR + 3) // 4 * 4
+    params = dict(k=kname, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=WG_SIZE)
+    with open(path, "w") as f:
+        f.write("; GENERATED by tools/gen_polymul_asm.py -- do not edit.\n")
+        f.write(HEADER % params)
+        f.write("\n".join(em.lines) + "\n")
+        f.write(FOOTER % params)
+    print("wrote %s: %d VALU instructions (static), %d hazard nops, %d lines" % (path, em.n_valu, em.n_nop, len(em.lines)))
+
+
 def main():
     outdir = os.path.dirname(OUT)
+    configure("pair")
     for kind, (stem, kname) in KERNELS.items():
-        em = build(kind)
-        accum = (NEXT_VGPR + 3) // 4 * 4
-        params = dict(k=kname, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6)
-        path = os.path.join(outdir, stem + "_gfx950.s")
-        with open(path, "w") as f:
-            f.write("; GENERATED by tools/gen_polymul_asm.py -- do not edit.\n")
-            f.write(HEADER % params)
-            f.write("\n".join(em.lines) + "\n")
-            f.write(FOOTER % params)
-        print("wrote %s: %d VALU instructions (static), %d hazard nops, %d lines" % (path, em.n_valu, em.n_nop, len(em.lines)))
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind))
+    configure("ring")
+    emit_file(os.path.join(outdir, "polymul16384_gfx950.s"), "nflhip_polymul16384_asm", build_row16k())
+    if os.environ.get("NFL_DEBUG16K"):   # checkpoint variants for bisecting a fault: kernel ends after phase n
+        for n in range(-3, 10):
+            emit_file("/tmp/dbg16k_p%d.s" % (n + 3), "nflhip_polymul16384_dbg%d" % (n + 3), build_row16k(stop=n))
 
 
 if __name__ == "__main__":
