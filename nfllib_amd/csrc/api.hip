@@ -319,13 +319,6 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 14) {
-    // a 16384-word row fits one CU: the whole product is a single launch, 3 operand streams of HBM traffic
-    e = launch_polymul_blocks16k_asm_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b,
-                                         batch, st);
-    if (e == hipSuccess) return NFLHIP_OK;
-    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul: 16384-word rows");
-  }
   if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn > 12 && ctx->aux[0]) {
     // large rows: streaming outer passes, then the fused assembly kernel over the 4096-word blocks,
     // then the outer inverse passes (9 operand streams of HBM traffic instead of 13).  The batch is cut

@@ -330,9 +330,14 @@ for n, m, batch in ((16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (65536, 3, 2)):
     a = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 0)
     b = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 1)
     c = e.polymul(a, b)
+    fb = e.ntt_(b.clone())
+    d = {"polymul": digest_words(e.to_host(c)), "ntt": digest_words(e.to_host(fb)),
+         "intt": digest_words(e.to_host(e.intt_(a.clone()))),
+         "polymul_ntt": digest_words(e.to_host(e.polymul(a, fb, b_is_ntt=True)))}
+    assert not e.any_neq(e.intt_(fb.clone()), b)
     e.polymul(a, b, out=a)          # in place on an operand
     assert not e.any_neq(a, c)
-    out["%d_%d" % (n, m)] = digest_words(e.to_host(c))
+    out["%d_%d" % (n, m)] = d
 print(json.dumps(out))
 """
 

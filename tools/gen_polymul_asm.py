@@ -777,7 +777,7 @@ def configure(mode):
         g.update(V_ZERO=g["V_T"][0] + 15)
 
 
-def prologue16k(em, vm, stop=None):
+def prologue16k(em, vm, stop=None, kind="polymul"):
     """1024 threads; v0 = tid on entry.  Leaves V_TID = tid & 255 (the thread's index inside its sub-group),
     V_OFF8 = tid*8, the LDS addresses of the sub-group's slab, all pass constants, and the row loads issued."""
     R = em.raw
@@ -856,13 +856,44 @@ def prologue16k(em, vm, stop=None):
     if stop == -2:
         R("s_waitcnt vmcnt(0) lgkmcnt(0)")
         R("s_endpgm")
-    for dst, srow in ((V_A, S_AROW), (V_B, S_BROW)):      # x[tid + 1024 k]
+    def row_loads(dst, srow):                             # x[tid + 1024 k]: the layout F0 starts from
         R("s_mov_b64 s[86:87], %s" % (srow,))
         for k in range(16):
             vm.load("global_load_dwordx2 %s, v%d, s[86:87]" % (vp(dst + 2 * k), V_OFF8))
             if k < 15:
                 R("s_add_u32 s86, s86, 0x2000")
                 R("s_addc_u32 s87, s87, 0")
+
+    def block_base(srow):                                 # s[86:87] = first word of this sub-group's 4096-word block
+        R("s_lshl_b32 s42, %s, 15" % (S_Q,))
+        R("s_add_u32 s86, s%s, s42" % (srow[2:].split(":")[0],))
+        R("s_addc_u32 s87, s%s, 0" % (srow.split(":")[1][:-1],))
+
+    def thread16_loads(dst, srow):                        # words 16t .. 16t+15 of the block (NTT-form data, after F3)
+        block_base(srow)
+        em.valu("v_lshlrev_b32_e32 v%d, 7, v%d" % (T(0, 0), V_TID))
+        for i in range(8):
+            vm.load("global_load_dwordx4 v[%d:%d], v%d, s[86:87] offset:%d" % (dst + 4 * i, dst + 4 * i + 3, T(0, 0), 16 * i))
+
+    def lane_loads(dst, srow):                            # block element 1024w + 64j + l -> pair j (512 B per wave load)
+        block_base(srow)
+        g, _ = lane_contig_setup(em)
+        for j in range(16):
+            vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d" % (vp(dst + 2 * j), g, (j & 7) * 512))
+            if j == 7:
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+
+    if kind == "polymul":
+        row_loads(V_A, S_AROW)
+        row_loads(V_B, S_BROW)
+    elif kind == "polymul_ntt":
+        row_loads(V_A, S_AROW)
+        thread16_loads(V_B, S_BROW)
+    elif kind == "fwd":
+        row_loads(V_A, S_AROW)
+    else:
+        lane_loads(V_A, S_AROW)
     if stop == -1:
         R("s_waitcnt vmcnt(0) lgkmcnt(0)")
         R("s_endpgm")
@@ -882,7 +913,8 @@ def prologue16k(em, vm, stop=None):
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
 
 
-def build_row16k(stop=None):
+def build_row16k(kind="polymul", stop=None):
+    """kind: polymul | polymul_ntt (b already in NTT form) | fwd | inv -- over one 16384-word block per workgroup"""
     em = Emitter()
     vm = VmCounter(em)
     R = em.raw
@@ -891,10 +923,14 @@ def build_row16k(stop=None):
               "I3": (S_K["I3"], None, True), "I0": (S_K0["I0"], None, True)}
     order = {"F0": (0, 1), "F1": (0, 1, 2, 3), "F2": (0, 1, 2, 3), "F3": (0, 1, 2, 3), "I1": (3, 2, 1, 0),
              "I2": (3, 2, 1, 0), "I3": (3, 2, 1, 0), "I0": (1, 0)}
-    uses = [(name, s, g) for name in ("F0", "F1", "F2", "F3", "I1", "I2", "I3", "I0") for s in order[name]
-            for g in range(1 << s)]
+    has_fwd = kind != "inv"
+    has_inv = kind != "fwd"
+    names = (["F0", "F1", "F2", "F3"] if has_fwd else []) + (["I1", "I2", "I3", "I0"] if has_inv else [])
+    uses = [(name, s, g) for name in names for s in order[name] for g in range(1 << s)]
     ring = Ring(em, vm, RING_SLOTS, uses, passes)
-    prologue16k(em, vm, stop)
+    fwd_bases = (V_A, V_B) if kind == "polymul" else (V_A,)
+    prologue16k(em, vm, stop, kind)
+    n_before_ring = vm.issued
     ring.prime()
 
     def ck(n):   # debugging aid: build_row16k(stop=n) ends the kernel at checkpoint n
@@ -904,7 +940,7 @@ def build_row16k(stop=None):
     ck(0)
 
     def fwd_pass(name):
-        em.comment("%s (a and b share the twiddles)" % name)
+        em.comment("%s (operands share the twiddles)" % name)
         for s in order[name]:
             half = 8 >> s
             for g in range(1 << s):
@@ -912,7 +948,7 @@ def build_row16k(stop=None):
                 jobs = []
                 for h in range(half):
                     i0 = g * 2 * half + h
-                    for base in (V_A, V_B):
+                    for base in fwd_bases:
                         jobs.append(ct_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
                 run_pairs(em, jobs)
                 ring.done((name, s, g))
@@ -928,45 +964,78 @@ def build_row16k(stop=None):
                 ring.done((name, s, g))
 
     AX = T(0, 0)   # exchange address scratch (the butterfly temporaries are idle during exchanges)
-    fwd_pass("F0")
-    ck(1)
-    for i, base in enumerate((V_A, V_B)):
-        em.comment("X0: thread (q, t) slot 4*qq + j  ->  sub-group qq, thread t, slot q + 4*j")
-        if i:
-            R("s_barrier")       # WAR: the slabs are still being read for the previous operand
-        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
-        for k in range(16):
-            qq, j = k >> 2, k & 3
-            R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
+    if has_fwd:
+        fwd_pass("F0")
+        ck(1)
+        for i, base in enumerate(fwd_bases):
+            em.comment("X0: thread (q, t) slot 4*qq + j  ->  sub-group qq, thread t, slot q + 4*j")
+            if i:
+                R("s_barrier")       # WAR: the slabs are still being read for the previous operand
+            em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+            for k in range(16):
+                qq, j = k >> 2, k & 3
+                R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+            em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+            for k in range(16):
+                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+            R("s_waitcnt lgkmcnt(0)")
+        ck(2)
+        fwd_pass("F1")
+        ck(3)
+        for base in fwd_bases:
+            em.comment("E1")
+            R("s_barrier")           # WAR against the previous exchange through this slab
+            lds_write(em, V_L1W, base, 2176)
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            lds_read(em, V_L1R, base, 136)
+            R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F2")
+        ck(4)
+        em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+        for base in fwd_bases:
+            lds_write(em, V_L1R, base, 136)
+            lds_read(em, V_L2R, base, 8)
         R("s_waitcnt lgkmcnt(0)")
-        R("s_barrier")
-        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
-        em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
-        for k in range(16):
-            R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+        fwd_pass("F3")
+        ck(5)
+    if kind == "fwd":
+        em.comment("canonical words, then a wave-local LDS transpose so the stores are fully coalesced")
+        run_pairs(em, [canon(V_A + 2 * i) for i in range(16)])
+        lds_write(em, V_L2R, V_A, 8)
+        g, l = lane_contig_setup(em)
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (l, S_SLAB, l))
+        for j in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * j), l, 544 * j))
         R("s_waitcnt lgkmcnt(0)")
-    ck(2)
-    fwd_pass("F1")
-    ck(3)
-    for base in (V_A, V_B):
-        em.comment("E1")
-        R("s_barrier")           # WAR against the previous exchange through this slab
-        lds_write(em, V_L1W, base, 2176)
+        R("s_lshl_b32 s42, %s, 15" % (S_Q,))
+        R("s_add_u32 s86, s20, s42")
+        R("s_addc_u32 s87, s21, 0")
+        for j in range(16):
+            R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (g, vp(V_A + 2 * j), (j & 7) * 512))
+            if j == 7:
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+        R("s_endpgm")
+        return em
+
+    if kind in ("polymul", "polymul_ntt"):
+        em.comment("point-wise product (thread t of sub-group q holds words 16t..16t+15 of block q of both operands)")
+        if kind == "polymul_ntt":
+            R("s_waitcnt vmcnt(%d)" % (vm.issued - n_before_ring))    # b's loads (issued before the ring's) have landed
+        run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i, True, kind == "polymul") for i in range(16)])
+    else:
+        R("s_waitcnt vmcnt(%d)" % (vm.issued - n_before_ring))        # the block loads have landed
+        em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
+        _, l = lane_contig_setup(em)
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (l, S_SLAB, l))
+        for j in range(16):
+            R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
+        lds_read(em, V_L2R, V_A, 8)
         R("s_waitcnt lgkmcnt(0)")
-        R("s_barrier")
-        lds_read(em, V_L1R, base, 136)
-        R("s_waitcnt lgkmcnt(0)")
-    fwd_pass("F2")
-    ck(4)
-    em.comment("E2(a), E2(b): wave-local 16-lane transposes (LDS is in order per wave)")
-    for base in (V_A, V_B):
-        lds_write(em, V_L1R, base, 136)
-        lds_read(em, V_L2R, base, 8)
-    R("s_waitcnt lgkmcnt(0)")
-    fwd_pass("F3")
-    ck(5)
-    em.comment("point-wise product")
-    run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i) for i in range(16)])
     inv_pass("I1", (3, 2, 1, 0))
     ck(6)
     em.comment("E2'")
@@ -1102,16 +1171,26 @@ def emit_file(path, kname, em):
     print("wrote %s: %d VALU instructions (static), %d hazard nops, %d lines" % (path, em.n_valu, em.n_nop, len(em.lines)))
 
 
+KERNELS16K = {
+    "polymul": ("polymul16384", "nflhip_polymul16384_asm"),
+    "polymul_ntt": ("polymul_ntt16384", "nflhip_polymul_ntt16384_asm"),
+    "fwd": ("ntt_fwd16384", "nflhip_ntt_fwd16384_asm"),
+    "inv": ("ntt_inv16384", "nflhip_ntt_inv16384_asm"),
+}
+
+
 def main():
     outdir = os.path.dirname(OUT)
     configure("pair")
     for kind, (stem, kname) in KERNELS.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind))
     configure("ring")
-    emit_file(os.path.join(outdir, "polymul16384_gfx950.s"), "nflhip_polymul16384_asm", build_row16k())
+    for kind, (stem, kname) in KERNELS16K.items():
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
     if os.environ.get("NFL_DEBUG16K"):   # checkpoint variants for bisecting a fault: kernel ends after phase n
+        kind = os.environ["NFL_DEBUG16K"]
         for n in range(-3, 10):
-            emit_file("/tmp/dbg16k_p%d.s" % (n + 3), "nflhip_polymul16384_dbg%d" % (n + 3), build_row16k(stop=n))
+            emit_file("/tmp/dbg16k_p%d.s" % (n + 3), "nflhip_dbg16k_%d" % (n + 3), build_row16k(kind, stop=n))
 
 
 if __name__ == "__main__":
