@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cassert>
 #include <cstddef>
 #include <cstdint>
@@ -42,7 +43,10 @@
 #include <initializer_list>
 #include <iostream>
 #include <iterator>
+#include <map>
+#include <mutex>
 #include <new>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -100,10 +104,28 @@ template <> struct params<uint64_t> {
   static const value_type *invkmax() { return NFLHIP_U64_INVKMAX; }
 };
 
-// seeded stand-in for the reference's sampler tag (poly.hpp:42)
+// ---- sampler tags (poly.hpp:42-67).  `uniform()` and the other tags draw fresh randomness on every use, like the
+// reference (process-wide key from the OS, one new keystream per call -- see detail::sampler below);
+// `uniform(seed)` is this header's addition: a seeded, reproducible operand (what benches and tests use).
 struct uniform {
   uint64_t seed;
-  explicit uniform(uint64_t s = 0x4E464C6C6962ull) : seed(s) {}
+  bool seeded;
+  uniform() : seed(0), seeded(false) {}
+  explicit uniform(uint64_t s) : seed(s), seeded(true) {}
+};
+struct non_uniform {
+  uint64_t upper_bound;
+  uint64_t amplifier;
+  non_uniform(uint64_t ub) : upper_bound{ub}, amplifier{1} {}
+  non_uniform(uint64_t ub, uint64_t amp) : upper_bound{ub}, amplifier{amp} {}
+};
+struct hwt_dist {  // hamming weight distribution
+  uint32_t hwt;
+  hwt_dist(uint32_t hwt_) : hwt(hwt_) {}
+};
+struct ZO_dist {  // P(1) = P(-1) = ((rho + 1) / 256) / 2
+  uint8_t rho;
+  ZO_dist(uint8_t rho_ = 0x7F) : rho(rho_) {}
 };
 
 namespace detail {
@@ -111,6 +133,25 @@ namespace detail {
 inline void check(nflhip_ctx *ctx, int rc, const char *what) {
   if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): ") + what + ": " + nflhip_last_error(ctx));
 }
+
+// The process-wide sampler state: the counterpart of fastrandombytes' static key and nonce
+// (lib/prng/fastrandombytes.cpp:17-37).  The key is drawn from the OS once; every sampling call takes the next
+// 64-bit stream id.  nfl::set_sampler_key() pins both for reproducible runs.
+struct sampler {
+  unsigned char key[32];
+  std::atomic<uint64_t> next;
+  sampler() : next(0) {
+    std::random_device rd;
+    for (int i = 0; i < 32; i += 4) {
+      const uint32_t v = rd();
+      std::memcpy(key + i, &v, 4);
+    }
+  }
+  static sampler &get() {
+    static sampler s;
+    return s;
+  }
+};
 
 // One device context per (T, Degree, NbModuli): the replacement of the
 // reference's static `core base` / `GMP gmp` members (poly.hpp:247, 275), created
@@ -141,6 +182,55 @@ inline uint64_t splitmix64_at(uint64_t seed, int operand, uint64_t g) {
 }
 
 }  // namespace detail
+
+/* pin the sampler state: `key` (32 bytes) and the id of the next keystream -- reproducible runs */
+inline void set_sampler_key(const unsigned char key[32], uint64_t next_stream = 0) {
+  detail::sampler &s = detail::sampler::get();
+  std::memcpy(s.key, key, 32);
+  s.next.store(next_stream);
+}
+
+/* FastGaussianNoise<in_class, out_class, _lu_depth>(sigma, security, samples, center) -- same constructor as
+ * FastGaussianNoise.hpp:163-204.  The reference builds byte-indexed lookup tables over MPFR barriers; here the object
+ * only carries the parameters and owns one cumulative table per device context (built on first use with the
+ * reference's tail bound and bit precision, sampled by inversion on the GPU).  in_class / _lu_depth only tuned the
+ * reference's lookup and are accepted for source compatibility. */
+template <class in_class, class out_class, unsigned _lu_depth> class FastGaussianNoise {
+ public:
+  FastGaussianNoise(double sigma, unsigned int security, unsigned int samples, double center_d = 0, bool /*verbose*/ = false)
+      : sigma_(sigma), security_(security), samples_(samples), center_(center_d) {
+    static_assert(_lu_depth == 1 || _lu_depth == 2, "_lu_depth must be 1 or 2 (FastGaussianNoise.hpp:214)");
+  }
+  FastGaussianNoise(FastGaussianNoise const &) = delete;
+  FastGaussianNoise &operator=(FastGaussianNoise const &) = delete;
+  ~FastGaussianNoise() {
+    for (auto &kv : tables_) nflhip_gauss_destroy(kv.first, kv.second);
+  }
+  const nflhip_gauss *table(nflhip_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = tables_.find(ctx);
+    if (it != tables_.end()) return it->second;
+    nflhip_gauss *g = nullptr;
+    detail::check(ctx, nflhip_gauss_create(ctx, &g, sigma_, security_, samples_, center_), "FastGaussianNoise");
+    tables_[ctx] = g;
+    return g;
+  }
+  double sigma() const { return sigma_; }
+
+ private:
+  double sigma_;
+  unsigned security_, samples_;
+  double center_;
+  std::mutex mu_;
+  std::map<nflhip_ctx *, nflhip_gauss *> tables_;
+};
+
+template <class in_class, class out_class, unsigned _lu_depth> struct gaussian {
+  FastGaussianNoise<in_class, out_class, _lu_depth> *fg_prng;
+  uint64_t amplifier;
+  gaussian(FastGaussianNoise<in_class, out_class, _lu_depth> *prng) : fg_prng{prng}, amplifier{1} {}
+  gaussian(FastGaussianNoise<in_class, out_class, _lu_depth> *prng, uint64_t amp) : fg_prng{prng}, amplifier{amp} {}
+};
 
 template <class T, size_t Degree, size_t NbModuli> class poly;
 
@@ -303,6 +393,10 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   /* constructors (core.hpp:64-84) */
   poly() { set(value_type(0)); }
   poly(uniform const &u) { set(u); }
+  poly(non_uniform const &m) { set(m); }
+  poly(hwt_dist const &m) { set(m); }
+  poly(ZO_dist const &m) { set(m); }
+  template <class in_class, unsigned _lu_depth> poly(gaussian<in_class, T, _lu_depth> const &m) { set(m); }
   poly(value_type v, bool reduce_coeffs = true) { set(v, reduce_coeffs); }
   poly(std::initializer_list<value_type> values, bool reduce_coeffs = true) { set(values, reduce_coeffs); }
   template <class It> poly(It first, It last, bool reduce_coeffs = true) { set(first, last, reduce_coeffs); }
@@ -329,8 +423,13 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
       for (; i < degree; ++i, ++iter) *iter = 0;
     }
   }
-  // mask-then-subtract rule of core.hpp:165-176 on a seeded counter stream
+  // mask-then-subtract rule of core.hpp:165-176: on the device's keystream (fresh per call), or on a seeded
+  // counter stream for `uniform(seed)`
   void set(uniform const &u) {
+    if (!u.seeded) {
+      sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+      return;
+    }
     for (size_t cm = 0; cm < nmoduli; cm++) {
       const uint64_t p = get_modulus(cm);
       int bits = 0;  // floor(log2 p) + 1 (core.hpp:165-166)
@@ -343,9 +442,23 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
       }
     }
   }
+  // bounded / zero-one / hamming-weight / Gaussian noise, one small integer per coefficient replicated over the
+  // moduli (core.hpp:195-391); misuse throws std::runtime_error like the reference (core.hpp:205-210)
+  void set(non_uniform const &m) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
+  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO, m.rho, 1, "set(ZO_dist)"); }
+  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT, m.hwt, 1, "set(hwt_dist)"); }
+  template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, T, _lu_depth> const &m) {
+    detail::sampler &s = detail::sampler::get();
+    detail::check(ctx(), nflhip_sample_gauss(ctx(), _data, 1, m.fg_prng->table(ctx()), m.amplifier, s.key, s.next++),
+                  "set(gaussian)");
+  }
 
   poly &operator=(value_type v) { set(v); return *this; }
   poly &operator=(uniform const &u) { set(u); return *this; }
+  poly &operator=(non_uniform const &m) { set(m); return *this; }
+  poly &operator=(hwt_dist const &m) { set(m); return *this; }
+  poly &operator=(ZO_dist const &m) { set(m); return *this; }
+  template <class in_class, unsigned _lu_depth> poly &operator=(gaussian<in_class, T, _lu_depth> const &m) { set(m); return *this; }
   poly &operator=(std::initializer_list<value_type> values) { set(values); return *this; }
   // THE evaluation point of an expression tree (core.hpp:24-37)
   template <class Op, class... Args> poly &operator=(ops::expr<Op, Args...> const &e) {
@@ -409,6 +522,10 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
 
   // ---- plumbing used by the expression templates (not part of the reference surface) ----
   static nflhip_ctx *ctx() { return detail::context<T, Degree, NbModuli>::get(); }
+  void sample(int dist, uint64_t p0, uint64_t p1, const char *what) {
+    detail::sampler &s = detail::sampler::get();
+    detail::check(ctx(), nflhip_sample(ctx(), _data, 1, dist, p0, p1, s.key, s.next++), what);
+  }
   void apply(int op, const poly &a, const poly &b, const poly &bp) {
     detail::check(ctx(), nflhip_pointwise(ctx(), op, _data, a._data, b._data, bp._data, 1), "operator=(expr)");
   }

@@ -179,6 +179,48 @@ int nflhip_crt_project(nflhip_ctx *ctx, void *h_data, const uint64_t *h_limbs, s
 int nflhip_fill_uniform_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, size_t batch, uint64_t seed,
                             int operand, void *stream);
 
+/* ---- samplers ------------------------------------------------------------------
+ * Device versions of the reference's random constructors (core.hpp:146-391):
+ *   poly(uniform) / poly(non_uniform(ub[,amp])) / poly(ZO_dist(rho)) / poly(hwt_dist(h)) /
+ *   poly(gaussian(&fg_prng[,amp])).
+ * The reference draws from a process-global Salsa20 stream keyed from /dev/urandom
+ * (lib/prng/fastrandombytes.cpp:17-37); here every call names its stream: a 32-byte key
+ * and a 64-bit stream id select a ChaCha20 keystream that is read by position (word w of
+ * the stream belongs to one fixed coefficient), so a call is reproducible and a batch can
+ * be generated in shards (first_poly) with the same result.  Callers that want the
+ * reference's behaviour draw the key from the OS once and increment stream_id per call
+ * (what include/nfl_hip/nfl.hpp does).  The map from random words to coefficients is the
+ * reference's (mask-and-subtract, no rejection), so the distributions are identical. */
+enum {
+  NFLHIP_DIST_UNIFORM = 0, /* core.hpp:152-188   one word per residue word */
+  NFLHIP_DIST_BOUNDED = 1, /* core.hpp:195-277   param0 = upper_bound, param1 = amplifier; one word per coefficient */
+  NFLHIP_DIST_ZO = 2,      /* core.hpp:330-340   param0 = rho (0..255) */
+  NFLHIP_DIST_HWT = 3      /* core.hpp:347-391   param0 = hamming weight (1..degree) */
+};
+int nflhip_sample_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, size_t batch, int dist, uint64_t param0,
+                      uint64_t param1, const unsigned char key[32], uint64_t stream_id, void *stream);
+int nflhip_sample(nflhip_ctx *ctx, void *h_data, size_t batch, int dist, uint64_t param0, uint64_t param1,
+                  const unsigned char key[32], uint64_t stream_id);
+/* raw keystream words [first_word, first_word + nwords) of (key, stream_id) -- what the samplers consume */
+int nflhip_random_words_dev(nflhip_ctx *ctx, uint64_t *d_out, uint64_t first_word, size_t nwords,
+                            const unsigned char key[32], uint64_t stream_id, void *stream);
+
+/* Discrete Gaussian (FastGaussianNoise<in,out,lu>(sigma, security, samples, center),
+ * FastGaussianNoise.hpp:163-290): cumulative table with the reference's tail bound and bit precision
+ * (<= 192 bits), sampled by inversion.  The table lives on the context's device. */
+typedef struct nflhip_gauss nflhip_gauss;
+int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsigned security, unsigned samples,
+                        double center);
+int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g);
+/* introspection: support [x_min, x_min + entries), words per entry, the reference's bit_precision and tail bound;
+ * h_table (may be NULL) receives entries*words 64-bit words, most significant word of an entry first */
+int nflhip_gauss_info(const nflhip_gauss *g, long long *x_min, size_t *entries, int *words, unsigned *bit_precision,
+                      double *tail, uint64_t *h_table);
+int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, size_t batch, const nflhip_gauss *g,
+                            uint64_t amplifier, const unsigned char key[32], uint64_t stream_id, void *stream);
+int nflhip_sample_gauss(nflhip_ctx *ctx, void *h_data, size_t batch, const nflhip_gauss *g, uint64_t amplifier,
+                        const unsigned char key[32], uint64_t stream_id);
+
 /* plain device-memory helpers so a C caller needs no HIP headers */
 int nflhip_malloc(nflhip_ctx *ctx, void **d_ptr, size_t bytes);
 int nflhip_free(nflhip_ctx *ctx, void *d_ptr);

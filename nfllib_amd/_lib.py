@@ -48,6 +48,15 @@ SYMBOLS = [
     ("nflhip_crt_lift", _i, [_vp, _vp, _vp, _sz]),
     ("nflhip_crt_project", _i, [_vp, _vp, _vp, _sz, _sz]),
     ("nflhip_fill_uniform_dev", _i, [_vp, _vp, _sz, _sz, _u64, _i, _vp]),
+    ("nflhip_sample_dev", _i, [_vp, _vp, _sz, _sz, _i, _u64, _u64, _vp, _u64, _vp]),
+    ("nflhip_sample", _i, [_vp, _vp, _sz, _i, _u64, _u64, _vp, _u64]),
+    ("nflhip_random_words_dev", _i, [_vp, _vp, _u64, _sz, _vp, _u64, _vp]),
+    ("nflhip_gauss_create", _i, [_vp, C.POINTER(_vp), C.c_double, C.c_uint, C.c_uint, C.c_double]),
+    ("nflhip_gauss_destroy", _i, [_vp, _vp]),
+    ("nflhip_gauss_info", _i, [_vp, C.POINTER(C.c_longlong), C.POINTER(_sz), C.POINTER(_i), C.POINTER(C.c_uint),
+                               C.POINTER(C.c_double), _vp]),
+    ("nflhip_sample_gauss_dev", _i, [_vp, _vp, _sz, _sz, _vp, _u64, _vp, _u64, _vp]),
+    ("nflhip_sample_gauss", _i, [_vp, _vp, _sz, _vp, _u64, _vp, _u64]),
     ("nflhip_malloc", _i, [_vp, C.POINTER(_vp), _sz]),
     ("nflhip_free", _i, [_vp, _vp]),
     ("nflhip_memcpy_h2d", _i, [_vp, _vp, _vp, _sz, _vp]),

@@ -7,11 +7,13 @@
 
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
+#include "gauss_table.h"
 #include "kernels.h"
 
 using namespace nflhip;
@@ -681,6 +683,105 @@ int nflhip_fill_uniform_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t 
 }
 
 // ---------------------------------------------------------------------------
+// samplers
+// ---------------------------------------------------------------------------
+struct nflhip_gauss {
+  GaussTable tab;
+  uint64_t *d_cdt = nullptr;
+  int device = 0;
+};
+
+int nflhip_random_words_dev(nflhip_ctx *ctx, uint64_t *d_out, uint64_t first_word, size_t nwords, const unsigned char *key,
+                            uint64_t stream_id, void *stream) {
+  CHECK_CTX(ctx);
+  if (!key || (nwords && !d_out)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipError_t e = launch_random_words(d_out, first_word, nwords, key, stream_id, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(ctx, e, "random_words");
+  return NFLHIP_OK;
+}
+
+int nflhip_sample_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t batch, int dist, uint64_t p0, uint64_t p1,
+                      const unsigned char *key, uint64_t stream_id, void *stream) {
+  CHECK_CTX(ctx);
+  if (!key || (batch && !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (dist < NFLHIP_DIST_UNIFORM || dist > NFLHIP_DIST_HWT) return fail(ctx, NFLHIP_ERR_INVALID, "unknown distribution");
+  if (dist == NFLHIP_DIST_BOUNDED) {
+    if (p0 == 0 || p0 >= (((uint64_t)1) << 62)) return fail(ctx, NFLHIP_ERR_INVALID, "upper_bound out of range");
+    for (uint64_t p : ctx->h_P)  // core.hpp:205-210
+      if (p0 >= p) return fail(ctx, NFLHIP_ERR_INVALID, "core: upper_bound is larger than the modulus");
+    if (p1 == 0) return fail(ctx, NFLHIP_ERR_INVALID, "amplifier must be positive");
+  }
+  if (dist == NFLHIP_DIST_ZO && p0 > 255) return fail(ctx, NFLHIP_ERR_INVALID, "rho is a byte");
+  if (dist == NFLHIP_DIST_HWT && (p0 == 0 || p0 > ctx->shape.n))  // assert at core.hpp:349
+    return fail(ctx, NFLHIP_ERR_INVALID, "hamming weight must be in [1, degree]");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(
+      ctx, launch_sample<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, dist, p0, p1, key, stream_id, st),
+      launch_sample<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, dist, p0, p1, key, stream_id, st),
+      launch_sample<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, dist, p0, p1, key, stream_id, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "sample");
+  return NFLHIP_OK;
+}
+
+int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsigned security, unsigned samples,
+                        double center) {
+  CHECK_CTX(ctx);
+  if (!out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  std::unique_ptr<nflhip_gauss> g(new (std::nothrow) nflhip_gauss());
+  if (!g) return fail(ctx, NFLHIP_ERR_NOMEM, "out of host memory");
+  std::string err;
+  if (build_gauss_table(sigma, security, samples, center, &g->tab, &err)) return fail(ctx, NFLHIP_ERR_INVALID, err);
+  g->device = ctx->device;
+  const size_t bytes = g->tab.cdt.size() * sizeof(uint64_t);
+  HIPCHK(ctx, hipMalloc((void **)&g->d_cdt, bytes));
+  hipError_t e = hipMemcpy(g->d_cdt, g->tab.cdt.data(), bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(g->d_cdt);
+    return hipfail(ctx, e, "gauss table upload");
+  }
+  *out = g.release();
+  return NFLHIP_OK;
+}
+
+int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g) {
+  if (!g) return NFLHIP_OK;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (g->d_cdt) (void)hipFree(g->d_cdt);
+  delete g;
+  return NFLHIP_OK;
+}
+
+int nflhip_gauss_info(const nflhip_gauss *g, long long *x_min, size_t *entries, int *words, unsigned *bit_precision,
+                      double *tail, uint64_t *h_table) {
+  if (!g) return NFLHIP_ERR_INVALID;
+  if (x_min) *x_min = g->tab.x_min;
+  if (entries) *entries = g->tab.entries;
+  if (words) *words = g->tab.words;
+  if (bit_precision) *bit_precision = g->tab.bit_precision;
+  if (tail) *tail = g->tab.tail;
+  if (h_table) std::memcpy(h_table, g->tab.cdt.data(), g->tab.cdt.size() * sizeof(uint64_t));
+  return NFLHIP_OK;
+}
+
+int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t batch, const nflhip_gauss *g,
+                            uint64_t amplifier, const unsigned char *key, uint64_t stream_id, void *stream) {
+  CHECK_CTX(ctx);
+  if (!key || !g || (batch && !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (g->device != ctx->device) return fail(ctx, NFLHIP_ERR_INVALID, "gaussian table lives on another device");
+  if (amplifier == 0) return fail(ctx, NFLHIP_ERR_INVALID, "amplifier must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const int w = g->tab.words, en = (int)g->tab.entries;
+  const long long x0 = g->tab.x_min;
+  hipError_t e = DISPATCH_T(
+      ctx,
+      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st),
+      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st),
+      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss");
+  return NFLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // memory helpers
 // ---------------------------------------------------------------------------
 int nflhip_malloc(nflhip_ctx *ctx, void **p, size_t bytes) {
@@ -853,6 +954,34 @@ int nflhip_crt_project(nflhip_ctx *ctx, void *d, const uint64_t *limbs, size_t L
   if (rc) return rc;
   if ((rc = s.in(0, nullptr, bytes))) return rc;
   rc = nflhip_crt_project_dev(ctx, ctx->stage[0], (const uint64_t *)ctx->stage[1], L_in, batch, ctx->hstream);
+  if (rc) return rc;
+  return s.out(d, 0, bytes);
+}
+
+int nflhip_sample(nflhip_ctx *ctx, void *d, size_t batch, int dist, uint64_t p0, uint64_t p1, const unsigned char *key,
+                  uint64_t stream_id) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return NFLHIP_OK;
+  if (!d) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  int rc = s.in(0, nullptr, bytes);
+  if (rc) return rc;
+  rc = nflhip_sample_dev(ctx, ctx->stage[0], 0, batch, dist, p0, p1, key, stream_id, ctx->hstream);
+  if (rc) return rc;
+  return s.out(d, 0, bytes);
+}
+
+int nflhip_sample_gauss(nflhip_ctx *ctx, void *d, size_t batch, const nflhip_gauss *g, uint64_t amplifier,
+                        const unsigned char *key, uint64_t stream_id) {
+  CHECK_CTX(ctx);
+  if (batch == 0) return NFLHIP_OK;
+  if (!d) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  Staged s(ctx);
+  const size_t bytes = poly_bytes(ctx, batch);
+  int rc = s.in(0, nullptr, bytes);
+  if (rc) return rc;
+  rc = nflhip_sample_gauss_dev(ctx, ctx->stage[0], 0, batch, g, amplifier, key, stream_id, ctx->hstream);
   if (rc) return rc;
   return s.out(d, 0, bytes);
 }

@@ -79,6 +79,18 @@ template <typename T>
 hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const uint64_t *limbs, size_t L_in, size_t batch,
                               hipStream_t st);
 
+// ---- samplers (kernels_sample.hip): ChaCha20 counter streams keyed by (key32, stream_id) ----
+hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords, const unsigned char *key32,
+                               uint64_t stream_id, hipStream_t st);
+// dist: 0 uniform | 1 bounded (p0 = upper bound, p1 = amplifier) | 2 zero/one (p0 = rho) | 3 hamming weight (p0 = h)
+template <typename T>
+hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, int dist, uint64_t p0,
+                         uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st);
+template <typename T>
+hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
+                               const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
+                               const unsigned char *key32, uint64_t stream_id, hipStream_t st);
+
 // ---- fast paths (kernels_fast.hip); return hipErrorNotSupported when the shape has none ----
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                    int b_is_ntt, size_t batch, hipStream_t st);

@@ -1,0 +1,310 @@
+// kernels_sample.hip -- on-device samplers (the poly(uniform / non_uniform / ZO_dist / hwt_dist / gaussian)
+// constructors of the reference, core.hpp:146-391).
+//
+// Randomness: the reference streams Salsa20 from a process-global key (lib/prng/fastrandombytes.cpp:17-37); here the
+// stream is ChaCha20 (D. J. Bernstein's original layout: 64-bit block counter, 64-bit nonce) keyed per call, and it is
+// COUNTER-BASED: 64-bit word w of stream (key, stream_id) is word (w mod 8) of block (w div 8).  Every coefficient reads
+// a fixed word of its stream, so the output does not depend on the launch geometry or on how a batch is sharded.
+// The map from random words to values is the reference's, statement for statement (cited per kernel); the tests feed
+// the same words through a numpy restatement that is pinned against the real reference.
+#include "kernels.h"
+#include "modarith.h"
+
+namespace nflhip {
+
+struct ChaChaKey {
+  uint32_t k[8];
+};
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+#define NFLHIP_QR(a, b, c, d) \
+  a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7)
+
+// one 64-byte block as eight little-endian 64-bit words
+__device__ __forceinline__ void chacha20_block(const ChaChaKey &key, uint64_t counter, uint64_t nonce, uint64_t out[8]) {
+  uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                    key.k[4],    key.k[5],    key.k[6],    key.k[7],    (uint32_t)counter, (uint32_t)(counter >> 32),
+                    (uint32_t)nonce, (uint32_t)(nonce >> 32)};
+  uint32_t x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = s[i];
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    NFLHIP_QR(x[0], x[4], x[8], x[12]);
+    NFLHIP_QR(x[1], x[5], x[9], x[13]);
+    NFLHIP_QR(x[2], x[6], x[10], x[14]);
+    NFLHIP_QR(x[3], x[7], x[11], x[15]);
+    NFLHIP_QR(x[0], x[5], x[10], x[15]);
+    NFLHIP_QR(x[1], x[6], x[11], x[12]);
+    NFLHIP_QR(x[2], x[7], x[8], x[13]);
+    NFLHIP_QR(x[3], x[4], x[9], x[14]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (uint64_t)(x[2 * i] + s[2 * i]) | ((uint64_t)(x[2 * i + 1] + s[2 * i + 1]) << 32);
+}
+#undef NFLHIP_QR
+
+// raw stream words [first_word, first_word + nwords)
+__global__ void k_random_words(uint64_t *out, uint64_t first_word, size_t nwords, ChaChaKey key, uint64_t nonce) {
+  const uint64_t fb = first_word >> 3, nb = ((first_word + nwords + 7) >> 3) - fb;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t w[8];
+    chacha20_block(key, fb + b, nonce, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t g = ((fb + b) << 3) + j;
+      if (g >= first_word && g < first_word + nwords) out[g - first_word] = w[j];
+    }
+  }
+}
+
+// v * amp mod p for a small signed value (|v| below the modulus in every sensible use; reduced anyway)
+template <typename T> __device__ __forceinline__ T signed_residue(bool neg, uint64_t mag, uint64_t amp, uint64_t p) {
+  const uint64_t m = (uint64_t)(((unsigned __int128)(mag % p) * (amp % p)) % p);
+  return (T)(neg ? (m ? p - m : 0) : m);
+}
+
+// ---- poly(uniform) (core.hpp:152-188): one stream word per residue word, mask to floor(log2 p)+1 bits, one
+// conditional subtraction.  Word index = ((poly*nm + cm)*n + i).
+template <typename T>
+__global__ void k_sample_uniform(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_word,
+                                 size_t total, ChaChaKey key, uint64_t nonce) {
+  const uint64_t fb = first_word >> 3, nb = ((first_word + total + 7) >> 3) - fb;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t w[8];
+    chacha20_block(key, fb + b, nonce, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t g = ((fb + b) << 3) + j;
+      if (g >= first_word && g < first_word + total) {
+        const ModConst<T> c = mc[(int)((g >> logn) % (uint64_t)nm)];
+        T v = (T)((T)w[j] & c.mask);
+        if (v >= c.p) v = (T)(v - c.p);
+        d[g - first_word] = v;
+      }
+    }
+  }
+}
+
+// ---- one small signed integer per coefficient, replicated over the moduli.  Stream word index = poly*n + i.
+//   dist 1  poly(non_uniform(ub[, amp]))  core.hpp:195-277: mask to floor(log2(2ub-1))+1 bits, one conditional
+//           subtraction of 2ub-1, values >= ub are the negatives tmp - (2ub-1); times the amplifier.
+//   dist 2  poly(ZO_dist(rho))            core.hpp:330-340: byte b = word & 0xff; b <= rho ? (b & 2 ? +1 : -1) : 0.
+//           (The reference stores +1 as p+1; this engine stores the canonical 1 -- its own operators require < p,
+//            ops.hpp:131,148.)
+template <typename T>
+__global__ void k_sample_small(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_coef,
+                               size_t ncoef, int dist, uint64_t p0, uint64_t p1, ChaChaKey key, uint64_t nonce) {
+  const uint64_t fb = first_coef >> 3, nb = ((first_coef + ncoef + 7) >> 3) - fb;
+  const uint64_t n = ((uint64_t)1) << logn;
+  uint64_t mask = 0;
+  if (dist == 1) {
+    const uint64_t t = 2 * p0 - 1;  // >= 1
+    int bits = 0;
+    while (bits < 64 && (t >> bits) != 0) ++bits;  // floor(log2 t) + 1
+    mask = bits >= 64 ? ~(uint64_t)0 : ((((uint64_t)1) << bits) - 1);
+  }
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t w[8];
+    chacha20_block(key, fb + b, nonce, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t g = ((fb + b) << 3) + j;
+      if (g < first_coef || g >= first_coef + ncoef) continue;
+      bool neg = false, zero = false;
+      uint64_t mag = 0, amp = 1;
+      if (dist == 1) {
+        uint64_t tmp = w[j] & mask;
+        if (tmp >= 2 * p0 - 1) tmp -= 2 * p0 - 1;
+        neg = tmp >= p0;
+        mag = neg ? (2 * p0 - 1) - tmp : tmp;
+        amp = p1;
+      } else {
+        const unsigned byte = (unsigned)(w[j] & 0xff);
+        zero = byte > (unsigned)p0;
+        neg = (byte & 2u) == 0;
+        mag = 1;
+      }
+      const uint64_t local = g - first_coef, poly = local >> logn, i = local & (n - 1);
+      T *col = d + ((poly * (uint64_t)nm) << logn) + i;
+      for (int cm = 0; cm < nm; ++cm)
+        col[(uint64_t)cm << logn] = zero ? (T)0 : signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+    }
+  }
+}
+
+// ---- poly(gaussian(&fg, amp)) (core.hpp:284-322; FastGaussianNoise.hpp): inversion sampling from a cumulative table
+// of W 64-bit words per entry (most significant first), entry k = floor(2^(64W) * P(X <= x_min + k)); the uniform
+// W-word number r comes from stream words W*(poly*n+i) .. +W-1 (most significant first); x = x_min + #{k : cdt[k] <= r}.
+template <typename T, int W>
+__global__ void k_sample_gauss(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_coef,
+                               size_t ncoef, const uint64_t *__restrict__ cdt, int entries, long long x_min, uint64_t amp,
+                               ChaChaKey key, uint64_t nonce) {
+  const uint64_t n = ((uint64_t)1) << logn;
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t g = first_coef + idx;
+    uint64_t r[W], blk[8];
+    uint64_t have = ~(uint64_t)0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const uint64_t wi = g * W + k;
+      if ((wi >> 3) != have) {
+        have = wi >> 3;
+        chacha20_block(key, have, nonce, blk);
+      }
+      r[k] = blk[wi & 7];
+    }
+    int lo = 0, hi = entries - 1;  // smallest k in [0, entries-1] with r < cdt[k]  (cdt[entries-1] = all ones)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const uint64_t *e = cdt + (size_t)mid * W;
+      bool less = false, decided = false;  // r < e ?
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if (!decided && r[k] != e[k]) {
+          less = r[k] < e[k];
+          decided = true;
+        }
+      }
+      if (less) hi = mid; else lo = mid + 1;
+    }
+    const long long x = x_min + lo;
+    const bool neg = x < 0;
+    const uint64_t mag = (uint64_t)(neg ? -x : x);
+    const uint64_t poly = idx >> logn, i = idx & (n - 1);
+    T *col = d + ((poly * (uint64_t)nm) << logn) + i;
+    for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+  }
+}
+
+// ---- poly(hwt_dist(h)) (core.hpp:347-391): exactly h coefficients are +-1, uniformly among the C(n,h) supports.
+// The reference draws them by reservoir sampling with rejection-sampled indices; here Floyd's algorithm (the same
+// distribution, h draws instead of n) runs one thread per polynomial over the zero-initialised row 0 as the
+// membership set (marks 1 = +1, 2 = -1), then a spread pass writes every modulus row.
+// Sub-stream of polynomial P: words [P*4n, P*4n + 2n) for the index draws (rejections are rarer than 2^-40),
+// word P*4n + 2n + t for the sign of draw t (bit 1, as the reference's `& 2`).
+template <typename T>
+__global__ void k_hwt_select(T *d, int logn, int nm, uint64_t first_poly, size_t batch, uint64_t h, ChaChaKey key,
+                             uint64_t nonce) {
+  const size_t P = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (P >= batch) return;
+  const uint64_t n = ((uint64_t)1) << logn, base = (first_poly + P) * 4 * n;
+  T *row0 = d + ((P * (uint64_t)nm) << logn);
+  uint64_t blk[8], have = ~(uint64_t)0, ctr = 0;
+  auto word = [&](uint64_t wi) {
+    if ((wi >> 3) != have) {
+      have = wi >> 3;
+      chacha20_block(key, have, nonce, blk);
+    }
+    return blk[wi & 7];
+  };
+  for (uint64_t t = 0; t < h; ++t) {
+    const uint64_t j = n - h + t, bound = j + 1;  // draw uniformly from [0, j]
+    const uint64_t lim = (~(uint64_t)0 / bound) * bound;
+    uint64_t pos;
+    for (;;) {
+      pos = word(base + (ctr < 2 * n ? ctr : 2 * n - 1));
+      ++ctr;
+      if (pos <= lim - 1 || ctr >= 2 * n) break;  // accept pos < lim
+    }
+    pos %= bound;
+    if (row0[pos] != 0) pos = j;
+    const uint64_t sgn = word(base + 2 * n + t);
+    row0[pos] = (T)((sgn & 2) ? 1 : 2);
+  }
+}
+template <typename T>
+__global__ void k_hwt_spread(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t ncoef) {
+  const uint64_t n = ((uint64_t)1) << logn;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t poly = idx >> logn, i = idx & (n - 1);
+    T *col = d + ((poly * (uint64_t)nm) << logn) + i;
+    const T m = col[0];
+    if (m == 0) continue;
+    for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = m == 1 ? (T)1 : (T)(mc[cm].p - 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static inline ChaChaKey load_key(const unsigned char *key32) {
+  ChaChaKey k;
+  for (int i = 0; i < 8; ++i)
+    k.k[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) |
+             ((uint32_t)key32[4 * i + 3] << 24);
+  return k;
+}
+static inline unsigned grid_for(size_t items) {
+  size_t b = (items + 255) / 256;
+  return (unsigned)(b > 256 * 64 ? 256 * 64 : (b ? b : 1));
+}
+
+hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords, const unsigned char *key32,
+                               uint64_t stream_id, hipStream_t st) {
+  if (nwords == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_random_words, dim3(grid_for(nwords / 8 + 2)), dim3(256), 0, st, out, first_word, nwords,
+                     load_key(key32), stream_id);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, int dist, uint64_t p0,
+                         uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+  const ChaChaKey key = load_key(key32);
+  const size_t ncoef = batch * s.n, total = ncoef * s.nm;
+  switch (dist) {
+    case 0:
+      hipLaunchKernelGGL((k_sample_uniform<T>), dim3(grid_for(total / 8 + 2)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
+                         (uint64_t)first_poly * s.nm * s.n, total, key, stream_id);
+      break;
+    case 1:
+    case 2:
+      hipLaunchKernelGGL((k_sample_small<T>), dim3(grid_for(ncoef / 8 + 2)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
+                         (uint64_t)first_poly * s.n, ncoef, dist, p0, p1, key, stream_id);
+      break;
+    case 3: {
+      hipError_t e = hipMemsetAsync(d, 0, total * sizeof(T), st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_hwt_select<T>), dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, d, s.logn, (int)s.nm,
+                         (uint64_t)first_poly, batch, p0, key, stream_id);
+      hipLaunchKernelGGL((k_hwt_spread<T>), dim3(grid_for(ncoef)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm, ncoef);
+      break;
+    }
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
+                               const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
+                               const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+  const ChaChaKey key = load_key(key32);
+  const size_t ncoef = batch * s.n;
+  const dim3 g(grid_for(ncoef)), b(256);
+  const uint64_t fc = (uint64_t)first_poly * s.n;
+  switch (words) {
+    case 1: hipLaunchKernelGGL((k_sample_gauss<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+    case 2: hipLaunchKernelGGL((k_sample_gauss<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+    case 3: hipLaunchKernelGGL((k_sample_gauss<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+#define NFLHIP_INST(T)                                                                                                   \
+  template hipError_t launch_sample<T>(const Shape &, const DevTables &, T *, size_t, size_t, int, uint64_t, uint64_t,   \
+                                       const unsigned char *, uint64_t, hipStream_t);                                    \
+  template hipError_t launch_sample_gauss<T>(const Shape &, const DevTables &, T *, size_t, size_t, const uint64_t *, int, \
+                                             int, long long, uint64_t, const unsigned char *, uint64_t, hipStream_t);
+NFLHIP_INST(uint16_t)
+NFLHIP_INST(uint32_t)
+NFLHIP_INST(uint64_t)
+#undef NFLHIP_INST
+
+}  // namespace nflhip

@@ -33,6 +33,9 @@ def _vp(x):
     return C.c_void_p(x.data_ptr())
 
 
+DIST_UNIFORM, DIST_BOUNDED, DIST_ZO, DIST_HWT = 0, 1, 2, 3   # NFLHIP_DIST_* (include/nflhip.h)
+
+
 class Engine:
     """One (T, Degree, NbModuli) context on one GPU -- the device-side
     counterpart of poly<T,Degree,NbModuli>::base / ::gmp (poly.hpp:247, 275)."""
@@ -152,6 +155,52 @@ class Engine:
     def fill_uniform(self, d, seed, operand=0, first_poly=0, stream=None):
         self._chk(self.lib.nflhip_fill_uniform_dev(self.ctx, _vp(d), first_poly, self._batch(d), seed, operand,
                                                    self._stream(stream)))
+        return d
+
+    # ---- samplers (include/nflhip.h "samplers"): key = 32 bytes, stream_id selects the keystream ----
+    @staticmethod
+    def _key(key):
+        key = bytes(key)
+        assert len(key) == 32, "the sampler key is 32 bytes"
+        return C.create_string_buffer(key, 32)
+
+    def sample(self, d, dist, key, stream_id=0, param0=0, param1=1, first_poly=0, stream=None):
+        """dist: DIST_UNIFORM | DIST_BOUNDED (param0 = upper bound, param1 = amplifier) | DIST_ZO (param0 = rho)
+        | DIST_HWT (param0 = hamming weight)"""
+        self._chk(self.lib.nflhip_sample_dev(self.ctx, _vp(d), first_poly, self._batch(d), dist, param0, param1,
+                                             self._key(key), stream_id, self._stream(stream)))
+        return d
+
+    def random_words(self, nwords, key, stream_id=0, first_word=0, stream=None):
+        t = _torch()
+        out = t.empty((nwords,), dtype=t.int64, device="cuda:%d" % self.device)
+        self._chk(self.lib.nflhip_random_words_dev(self.ctx, _vp(out), first_word, nwords, self._key(key), stream_id,
+                                                   self._stream(stream)))
+        return out
+
+    def gauss_create(self, sigma, security=128, samples=None, center=0.0):
+        """FastGaussianNoise(sigma, security, samples, center): returns a handle for sample_gauss / gauss_info"""
+        h = C.c_void_p()
+        self._chk(self.lib.nflhip_gauss_create(self.ctx, C.byref(h), float(sigma), int(security),
+                                               int(samples if samples is not None else self.degree), float(center)))
+        return h
+
+    def gauss_destroy(self, g):
+        self._chk(self.lib.nflhip_gauss_destroy(self.ctx, g))
+
+    def gauss_info(self, g):
+        import numpy as np
+        x_min, entries, words, bits, tail = C.c_longlong(), C.c_size_t(), C.c_int(), C.c_uint(), C.c_double()
+        self._chk(self.lib.nflhip_gauss_info(g, C.byref(x_min), C.byref(entries), C.byref(words), C.byref(bits),
+                                             C.byref(tail), None))
+        tab = np.zeros((entries.value, words.value), dtype=np.uint64)
+        self._chk(self.lib.nflhip_gauss_info(g, None, None, None, None, None, tab.ctypes.data_as(C.c_void_p)))
+        return {"x_min": x_min.value, "entries": entries.value, "words": words.value, "bit_precision": bits.value,
+                "tail": tail.value, "table": tab}
+
+    def sample_gauss(self, d, g, key, stream_id=0, amplifier=1, first_poly=0, stream=None):
+        self._chk(self.lib.nflhip_sample_gauss_dev(self.ctx, _vp(d), first_poly, self._batch(d), g, amplifier,
+                                                   self._key(key), stream_id, self._stream(stream)))
         return d
 
     def crt_lift(self, d, stream=None):

@@ -223,12 +223,27 @@ class Reference:
             L.nflref_ntt_row.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int]
             L.nflref_crt_lift.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
             L.nflref_crt_project.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+            if hasattr(L, "nflref_sample_replay"):
+                L.nflref_sample_replay.restype = C.c_long
+                L.nflref_sample_replay.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p,
+                                                   C.c_void_p, C.c_size_t]
         self.lib = Reference._lib
         self.id = self.lib.nflref_find(limb_bits, degree, nmoduli)
         if self.id < 0:
             raise KeyError("shape not instantiated in ref_shim.cpp")
         self.limb_bits, self.degree, self.nmoduli = limb_bits, degree, nmoduli
         self.dtype = np.dtype(_DT[limb_bits])
+
+    def sample_replay(self, kind, p0=0, p1=1, sigma=0.0):
+        """One random constructor of the real reference (core.hpp:146-391): kind 0 uniform | 1 non_uniform(p0 = ub,
+        p1 = amplifier) | 2 ZO_dist(p0 = rho) | 3 hwt_dist(p0 = h) | 4 gaussian(sigma, p0 = security, p1 = amplifier).
+        Returns (poly [nm, n], raw bytes the constructor consumed -- empty for kinds 3 and 4)."""
+        out = np.zeros((self.nmoduli, self.degree), dtype=self.dtype)
+        raw = np.zeros(self.nmoduli * self.degree * self.dtype.itemsize, dtype=np.uint8)
+        got = self.lib.nflref_sample_replay(self.id, kind, p0, p1, float(sigma), out.ctypes.data, raw.ctypes.data, raw.size)
+        if got < 0:
+            raise RuntimeError("nflref_sample_replay failed")
+        return out, raw[:got].copy()
 
     def _each(self, a, fn):
         out = np.ascontiguousarray(a).copy().reshape(-1, self.nmoduli, self.degree)

@@ -15,6 +15,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <new>
 
 namespace nfl {
@@ -69,6 +72,7 @@ struct shape_vtbl {
   size_t (*crt_const)(int, size_t, uint64_t *, size_t);
   void (*lift)(const void *, uint64_t *, size_t);
   void (*project)(void *, const uint64_t *, size_t);
+  long (*sample)(int, uint64_t, uint64_t, double, void *, unsigned char *, size_t);
 };
 
 template <class P>
@@ -176,9 +180,70 @@ struct ops_for {
     store(d, p);
     drop_poly(p);
   }
+  // The random constructors (core.hpp:146-391).  For the kinds that make ONE fastrandombytes call
+  // (uniform / non_uniform / ZO_dist) the bytes that call will return are captured first: the Salsa20 key and nonce
+  // are process state (lib/prng/fastrandombytes.cpp:17-37), so a forked child that asks for the same number of bytes
+  // sees exactly what the parent's constructor is about to consume.  Returns the number of raw bytes captured
+  // (0 for hwt_dist / gaussian, whose procedures are not one replayable call), or -1 on error.
+  static long sample(int kind, uint64_t p0, uint64_t p1, double sigma, void *out, unsigned char *raw, size_t raw_cap) {
+    unsigned char dummy;
+    nfl::fastrandombytes(&dummy, 1);  // make sure the key exists before the state is duplicated
+    size_t want = 0;
+    if (kind == 0) want = sizeof(T) * P::degree * P::nmoduli;
+    else if (kind == 1) want = sizeof(T) * P::degree;
+    else if (kind == 2) want = P::degree;
+    if (want) {
+      if (!raw || raw_cap < want) return -1;
+      int fd[2];
+      if (pipe(fd) != 0) return -1;
+      const pid_t pid = fork();
+      if (pid < 0) return -1;
+      if (pid == 0) {
+        close(fd[0]);
+        unsigned char *buf = static_cast<unsigned char *>(malloc(want));
+        nfl::fastrandombytes(buf, want);
+        size_t off = 0;
+        while (off < want) {
+          const ssize_t w = write(fd[1], buf + off, want - off);
+          if (w <= 0) _exit(1);
+          off += size_t(w);
+        }
+        _exit(0);
+      }
+      close(fd[1]);
+      size_t off = 0;
+      while (off < want) {
+        const ssize_t r = read(fd[0], raw + off, want - off);
+        if (r <= 0) break;
+        off += size_t(r);
+      }
+      close(fd[0]);
+      int status = 0;
+      waitpid(pid, &status, 0);
+      if (off != want) return -1;
+    }
+    P *p = nullptr;
+    void *mem = nullptr;
+    if (posix_memalign(&mem, 32, sizeof(P)) != 0) throw std::bad_alloc();
+    switch (kind) {
+      case 0: p = new (mem) P(nfl::uniform()); break;
+      case 1: p = new (mem) P(nfl::non_uniform(p0, p1)); break;
+      case 2: p = new (mem) P(nfl::ZO_dist(uint8_t(p0))); break;
+      case 3: p = new (mem) P(nfl::hwt_dist(uint32_t(p0))); break;
+      case 4: {
+        nfl::FastGaussianNoise<uint8_t, T, 2> fg(sigma, unsigned(p0), P::degree);
+        p = new (mem) P(nfl::gaussian<uint8_t, T, 2>(&fg, p1));
+        break;
+      }
+      default: free(mem); return -1;
+    }
+    store(out, p);
+    drop_poly(p);
+    return long(want);
+  }
   static shape_vtbl vt() {
     return shape_vtbl{int(sizeof(T) * 8), P::degree, P::nmoduli, &ntt, &intt, &pointwise, &any, &table,
-                      &ntt_row, &crt_info, &crt_const, &lift, &project};
+                      &ntt_row, &crt_info, &crt_const, &lift, &project, &sample};
   }
 };
 
@@ -236,4 +301,10 @@ size_t nflref_crt_modulus_shoup(int id, uint64_t *out, size_t cap) { return g_sh
 size_t nflref_crt_lifting(int id, size_t cm, uint64_t *out, size_t cap) { return g_shapes[id].crt_const(2, cm, out, cap); }
 void nflref_crt_lift(int id, const void *poly, uint64_t *out, size_t L) { g_shapes[id].lift(poly, out, L); }
 void nflref_crt_project(int id, void *poly, const uint64_t *limbs, size_t L) { g_shapes[id].project(poly, limbs, L); }
+// kind: 0 uniform | 1 non_uniform(p0 = upper bound, p1 = amplifier) | 2 ZO_dist(p0 = rho) | 3 hwt_dist(p0 = weight) |
+//       4 gaussian(sigma, p0 = security, p1 = amplifier; FastGaussianNoise<uint8_t,T,2>(sigma, security, degree))
+long nflref_sample_replay(int id, int kind, uint64_t p0, uint64_t p1, double sigma, void *poly, unsigned char *raw,
+                          size_t raw_cap) {
+  return g_shapes[id].sample(kind, p0, p1, sigma, poly, raw, raw_cap);
+}
 }

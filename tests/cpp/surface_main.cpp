@@ -5,6 +5,7 @@
 //   compute_shoup / shoup(a*b,b'), NTT / INTT, nested expression (tests/poly_p.cpp:29-66),
 //   CRT round trip (tests/poly_mpz.cpp:19-29), ctor/set semantics (tests/poly_set.cpp),
 //   serialisation round trip (tests/poly_serialize_manually.cpp), stream prefix (tests/nfl_stream.cpp),
+//   the random constructors and the LWE round trip (tests/nfllib_demo_main_op.cpp:26-58, 313-332),
 // with memcmp-strength comparisons (the reference's operator== is "any lane equal").
 // Exit code 0 = all good; prints the failing check otherwise.  Needs a GPU.
 #include <nfl_hip/nfl.hpp>
@@ -212,6 +213,62 @@ template <class T, size_t Degree, size_t NbModuli> static bool run() {
   return true;
 }
 
+// The random constructors (core.hpp:146-391) and the reference's LWE round trip
+// (tests/nfllib_demo_main_op.cpp:26-58, 313-332: b = a*s + e in NTT form, b - a*s must be the small noise).
+template <class T, size_t Degree, size_t NbModuli> static bool run_samplers() {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  auto centered = [](const poly_t &p, size_t cm, size_t i) -> long long {
+    const T q = poly_t::get_modulus(cm), v = p(cm, i);
+    return v > q / 2 ? (long long)v - (long long)q : (long long)v;
+  };
+  Heap<poly_t> u1{nfl::uniform()}, u2{nfl::uniform()};
+  CHECK(!same(*u1, *u2));                                        // fresh randomness per call, like the reference
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t i = 0; i < Degree; i++) CHECK((*u1)(cm, i) < poly_t::get_modulus(cm));
+  Heap<poly_t> nb{nfl::non_uniform(5)}, na{nfl::non_uniform(5, 3)};
+  for (size_t i = 0; i < Degree; i++) {
+    const long long v = centered(*nb, 0, i), w = centered(*na, 0, i);
+    CHECK(v > -5 && v < 5 && w % 3 == 0 && w > -15 && w < 15);
+    for (size_t cm = 1; cm < NbModuli; cm++) CHECK(centered(*nb, cm, i) == v);
+  }
+  Heap<poly_t> zo{nfl::ZO_dist()}, hw{nfl::hwt_dist(Degree / 4)};
+  size_t weight = 0, nonzero = 0;
+  for (size_t i = 0; i < Degree; i++) {
+    const long long z = centered(*zo, 0, i), h = centered(*hw, 0, i);
+    CHECK(z >= -1 && z <= 1 && h >= -1 && h <= 1);
+    nonzero += z != 0;
+    weight += h != 0;
+    for (size_t cm = 1; cm < NbModuli; cm++) CHECK(centered(*hw, cm, i) == h);
+  }
+  CHECK(weight == Degree / 4);
+  if (Degree >= 1024) CHECK(nonzero > Degree / 3 && nonzero < 2 * Degree / 3);
+  bool threw = false;
+  try {
+    Heap<poly_t> bad{nfl::non_uniform(poly_t::get_modulus(0))};   // core.hpp:205-210
+  } catch (std::runtime_error const &) {
+    threw = true;
+  }
+  CHECK(threw);
+  // Gaussian noise + LWE: s, e small; a uniform; everything in NTT form
+  nfl::FastGaussianNoise<uint8_t, T, 2> fg(3.19, 128, Degree);
+  Heap<poly_t> sk{nfl::gaussian<uint8_t, T, 2>(&fg)}, e{nfl::gaussian<uint8_t, T, 2>(&fg, 2)}, a{nfl::uniform()}, b, chk;
+  double m2 = 0;
+  for (size_t i = 0; i < Degree; i++) {
+    const long long v = centered(*sk, 0, i);
+    CHECK(v > -60 && v < 60 && centered(*e, 0, i) % 2 == 0);
+    m2 += double(v) * double(v);
+  }
+  if (Degree >= 1024) CHECK(m2 / Degree > 0.8 * 3.19 * 3.19 && m2 / Degree < 1.2 * 3.19 * 3.19);
+  Heap<poly_t> e_coef(*e);
+  sk->ntt_pow_phi();
+  e->ntt_pow_phi();
+  *b = *a * *sk + *e;
+  *chk = *b - *a * *sk;
+  chk->invntt_pow_invphi();
+  CHECK(same(*chk, *e_coef));
+  return true;
+}
+
 int main() {
   try {
     bool ok = true;
@@ -221,6 +278,9 @@ int main() {
     ok &= run<uint64_t, 64, 3>();
     ok &= run<uint64_t, 4096, 4>();     // BASELINE configs[1]
     ok &= run<uint64_t, 8192, 2>();     // 8192,124,uint64_t
+    ok &= run_samplers<uint64_t, 4096, 4>();
+    ok &= run_samplers<uint32_t, 1024, 2>();
+    ok &= run_samplers<uint16_t, 128, 1>();
     ok &= other_tu_selftest() == 0;
     std::printf(ok ? "surface: all checks passed\n" : "surface: FAILED\n");
     return ok ? 0 : 1;

@@ -1,0 +1,159 @@
+"""-m gpu: the device samplers (nflhip_sample*_dev) through the C ABI.
+
+uniform / non_uniform / ZO_dist are checked EXACTLY: the device output must equal the reference's rule
+(oracle/samplers.py, pinned against the real reference by tests/test_samplers_cpu.py) applied to the very keystream
+words the device consumed (ChaCha20, restated in numpy).  hwt_dist and gaussian are checked structurally, exactly
+against the cumulative table, and statistically against histograms of the real reference's samples."""
+import os
+
+import numpy as np
+import pytest
+
+from nfllib_amd import DIST_BOUNDED, DIST_HWT, DIST_UNIFORM, DIST_ZO, NflHipError
+from oracle import samplers as S
+
+pytestmark = pytest.mark.gpu
+KEY = bytes((7 * i + 3) & 0xFF for i in range(32))
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "samplers.npz"))
+SHAPES = [(64, 4096, 4, 3), (64, 64, 3, 5), (32, 1024, 2, 3), (16, 128, 1, 4)]
+IDS = ["u%d-n%d-m%d" % s[:3] for s in SHAPES]
+_MASK = {16: 0xFFFF, 32: 0xFFFFFFFF, 64: 0xFFFFFFFFFFFFFFFF}
+
+
+def _P(e):
+    from nfllib_amd.params import params
+    return [int(x) for x in params(e.limb_bits).P[:e.nmoduli]]
+
+
+def test_keystream_matches_chacha20(engine_factory):
+    e = engine_factory(64, 64, 3)
+    for first, count in ((0, 64), (5, 100), (8, 8), (1023, 3), (0, 1)):
+        got = e.random_words(count, KEY, stream_id=11, first_word=first).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, S.chacha20_words(KEY, 11, first, count)), (first, count)
+    zero = e.random_words(8, bytes(32), 0).cpu().numpy().view(np.uint64)
+    assert zero[0] == 0x903DF1A0ADE0B876  # first word of the all-zero ChaCha20 test vector
+
+
+@pytest.mark.parametrize("lb,n,m,batch", SHAPES, ids=IDS)
+def test_uniform_bounded_zo_are_the_reference_rules(lb, n, m, batch, engine_factory):
+    e = engine_factory(lb, n, m)
+    P, dt = _P(e), e.np_dtype
+    d = e.sample(e.empty(batch), DIST_UNIFORM, KEY, stream_id=1)
+    words = (S.chacha20_words(KEY, 1, 0, batch * m * n) & np.uint64(_MASK[lb])).astype(dt).reshape(batch, m, n)
+    got = e.to_host(d)
+    assert np.array_equal(got, S.uniform(words, P))
+    assert all((got[:, cm] < P[cm]).all() for cm in range(m))
+    # sharded generation: any split of the batch gives the same words
+    lo = e.sample(e.empty(1), DIST_UNIFORM, KEY, stream_id=1, first_poly=0)
+    hi = e.sample(e.empty(batch - 1), DIST_UNIFORM, KEY, stream_id=1, first_poly=1)
+    assert np.array_equal(np.concatenate([e.to_host(lo), e.to_host(hi)]), got)
+    cw = S.chacha20_words(KEY, 2, 0, batch * n).reshape(batch, n)
+    for ub, amp in ((1, 1), (2, 1), (5, 3), (1000, 1), (1 << 12, 1)):
+        if ub * amp >= min(P) // 2:
+            continue
+        d = e.sample(e.empty(batch), DIST_BOUNDED, KEY, stream_id=2, param0=ub, param1=amp)
+        assert np.array_equal(e.to_host(d), S.non_uniform(cw, P, ub, amp, dtype=dt)), (ub, amp)
+    for rho in (0x7F, 0, 255, 10):
+        d = e.sample(e.empty(batch), DIST_ZO, KEY, stream_id=2, param0=rho)
+        assert np.array_equal(e.to_host(d), S.zo_dist(cw & np.uint64(0xFF), P, rho, canonical=True, dtype=dt)), rho
+    # a different stream id is a different polynomial
+    assert not np.array_equal(e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, KEY, stream_id=3)), got)
+
+
+def test_argument_errors_follow_the_reference(engine_factory):
+    e = engine_factory(32, 1024, 2)
+    d = e.empty(1)
+    with pytest.raises(NflHipError, match="upper_bound is larger than the modulus"):   # core.hpp:205-210
+        e.sample(d, DIST_BOUNDED, KEY, param0=min(_P(e)), param1=1)
+    for bad in (dict(dist=DIST_HWT, param0=0), dict(dist=DIST_HWT, param0=1025), dict(dist=DIST_ZO, param0=256),
+                dict(dist=9)):
+        with pytest.raises(NflHipError):
+            e.sample(d, bad.pop("dist"), KEY, **bad)
+    with pytest.raises(NflHipError):
+        e.gauss_create(-1.0)
+
+
+def _chi2_two_sample(a, b):
+    """chi-square statistic / dof for two histograms over the same bins (bins with few counts pooled)"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    keep = (a + b) >= 20
+    a2, b2 = np.append(a[keep], a[~keep].sum()), np.append(b[keep], b[~keep].sum())
+    k1, k2 = np.sqrt(b2.sum() / a2.sum()), np.sqrt(a2.sum() / b2.sum())
+    nz = (a2 + b2) > 0
+    stat = (((k1 * a2 - k2 * b2) ** 2)[nz] / (a2 + b2)[nz]).sum()
+    return stat / max(int(nz.sum()) - 1, 1)
+
+
+def test_hamming_weight_distribution(engine_factory):
+    e = engine_factory(64, 1024, 2)
+    P = _P(e)
+    h, batch = 64, 400
+    d = e.to_host(e.sample(e.empty(batch), DIST_HWT, KEY, stream_id=5, param0=h))
+    nz = d[:, 0] != 0
+    assert (nz.sum(axis=1) == h).all(), "exactly h non-zero coefficients per polynomial (core.hpp:347-391)"
+    assert np.array_equal(nz, d[:, 1] != 0), "the same support in every residue row"
+    c = S.centered(d, P)
+    assert np.array_equal(c[:, 0], c[:, 1]) and set(np.unique(c).tolist()) == {-1, 0, 1}
+    plus = int((c[:, 0] == 1).sum())
+    assert abs(plus - batch * h / 2) < 5 * np.sqrt(batch * h / 4), "signs are fair"
+    # supports are uniform: position histogram against the real reference's (two-sample) and against flat
+    pos = nz.sum(axis=0)
+    assert _chi2_two_sample(pos, GOLD["hwt_64/pos_hist"]) < 1.35
+    assert abs(int(GOLD["hwt_64/plus"]) - int(GOLD["hwt_64/reps"]) * h / 2) < 5 * np.sqrt(int(GOLD["hwt_64/reps"]) * h / 4)
+    # deterministic, shardable, full-weight edge
+    again = e.to_host(e.sample(e.empty(batch), DIST_HWT, KEY, stream_id=5, param0=h))
+    assert np.array_equal(again, d)
+    part = e.to_host(e.sample(e.empty(10), DIST_HWT, KEY, stream_id=5, param0=h, first_poly=100))
+    assert np.array_equal(part, d[100:110])
+    full = e.to_host(e.sample(e.empty(2), DIST_HWT, KEY, stream_id=6, param0=1024))
+    assert (full[:, 0] != 0).all()
+
+
+@pytest.mark.parametrize("sigma", [3.2, 20.0])
+def test_gaussian(sigma, engine_factory):
+    e = engine_factory(64, 1024, 2)
+    P = _P(e)
+    g = e.gauss_create(sigma, security=128, samples=1024)
+    info = e.gauss_info(g)
+    # the reference's parameters for these arguments (FastGaussianNoise.hpp:239-272): k = 128 + 1 + 10
+    k = 139.0
+    assert abs(info["tail"] ** 2 - 2 * np.log(info["tail"]) - 1 - 2 * k * np.log(2)) < 0.2
+    assert info["entries"] == 2 * int(np.ceil(info["tail"] * sigma)) + 1 and info["x_min"] == -(info["entries"] // 2)
+    assert info["bit_precision"] == int(np.ceil(k + np.log2(2 * info["tail"] * sigma))) and info["words"] == 3
+    tab = info["table"]
+    top = tab[:, 0].astype(np.float64) / 2.0 ** 64
+    pmf = S.gaussian_pmf(sigma, 0.0, info["x_min"], info["entries"])
+    assert np.abs(np.diff(np.concatenate([[0.0], top])) - pmf).max() < 1e-15, "table = cumulative discrete Gaussian"
+    assert (tab[-1] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    flat = [int.from_bytes(b"".join(int(v).to_bytes(8, "big") for v in row), "big") for row in tab]
+    assert all(x <= y for x, y in zip(flat, flat[1:]))
+    batch = 200
+    d = e.to_host(e.sample_gauss(e.empty(batch), g, KEY, stream_id=9))
+    c = S.centered(d, P)
+    assert np.array_equal(c[:, 0], c[:, 1]), "one integer per coefficient, replicated over the moduli"
+    v = c[:, 0]
+    # exact: inversion of the very keystream words through the table
+    r = S.chacha20_words(KEY, 9, 0, 3 * 4 * 1024).reshape(4 * 1024, 3)
+    assert np.array_equal(S.gaussian_from_table(r, tab, info["x_min"]), v[:4].reshape(-1))
+    # statistics: moments, tail, and a two-sample test against the real reference's samples
+    flatv = v.reshape(-1)
+    assert abs(flatv.mean()) < 5 * sigma / np.sqrt(flatv.size) and abs(flatv.var() / sigma ** 2 - 1) < 0.02
+    assert np.abs(flatv).max() <= np.ceil(info["tail"] * sigma)
+    rh, rlo = GOLD["gauss_%g/hist" % sigma], int(GOLD["gauss_%g/lo" % sigma])
+    lo, hi = min(rlo, int(flatv.min())), max(rlo + rh.size - 1, int(flatv.max()))
+    a = np.bincount(flatv - lo, minlength=hi - lo + 1)
+    b = np.zeros(hi - lo + 1, dtype=np.int64)
+    b[rlo - lo:rlo - lo + rh.size] = rh
+    assert _chi2_two_sample(a, b) < 1.5
+    # amplifier and sharding
+    amp = e.to_host(e.sample_gauss(e.empty(2), g, KEY, stream_id=9, amplifier=5))
+    assert np.array_equal(S.centered(amp, P)[:, 0], 5 * v[:2])
+    part = e.to_host(e.sample_gauss(e.empty(3), g, KEY, stream_id=9, first_poly=50))
+    assert np.array_equal(part, d[50:53])
+    e.gauss_destroy(g)
+    # off-centre table
+    g2 = e.gauss_create(sigma, security=64, samples=1024, center=2.5)
+    i2 = e.gauss_info(g2)
+    v2 = S.centered(e.to_host(e.sample_gauss(e.empty(100), g2, KEY, stream_id=4)), P)[:, 0].reshape(-1)
+    assert abs(v2.mean() - 2.5) < 5 * sigma / np.sqrt(v2.size) and i2["words"] == 2
+    e.gauss_destroy(g2)

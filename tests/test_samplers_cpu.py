@@ -1,0 +1,86 @@
+"""CPU: the restated sampler rules (oracle/samplers.py) against fixtures captured from the REAL reference's random
+constructors (tests/golden/samplers.npz, made by tools/gen_golden_samplers.py through the fork-replay of
+oracle/ref_shim.cpp), the ChaCha20 restatement against its known-answer vector, and -- when the real reference is
+available (build container) -- a fresh replay."""
+import os
+
+import numpy as np
+import pytest
+
+from nfllib_amd.params import params
+from oracle import oracle as O
+from oracle import samplers as S
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "samplers.npz"))
+_DT = {16: np.uint16, 32: np.uint32, 64: np.uint64}
+
+
+def _shapes():
+    return sorted({k.split("/")[0] for k in GOLD.files if k.startswith("u")})
+
+
+def _moduli(tag):
+    lb, n, m = (int(x) for x in tag[1:].split("_"))
+    return lb, n, m, [int(x) for x in params(lb).P[:m]]
+
+
+@pytest.mark.parametrize("tag", _shapes())
+def test_rules_match_reference_fixtures(tag):
+    lb, n, m, P = _moduli(tag)
+    dt = _DT[lb]
+    seen = 0
+    for key in GOLD.files:
+        if not key.startswith(tag + "/") or not key.endswith("/raw"):
+            continue
+        kind = key.split("/")[1]
+        raw, want = GOLD[key], GOLD[key[:-3] + "out"]
+        if kind == "uniform":
+            got = S.uniform(raw.view(dt).reshape(m, n), P)              # core.hpp:152-188
+        elif kind.startswith("bounded_"):
+            ub, amp = (int(x) for x in kind.split("_")[1:])
+            got = S.non_uniform(raw.view(dt), P, ub, amp, dtype=dt)     # core.hpp:195-277
+        else:
+            rho = int(kind.split("_")[1])
+            got = S.zo_dist(raw, P, rho, canonical=False, dtype=dt)     # core.hpp:330-340 (p+1 for +1, as stored)
+            can = S.zo_dist(raw, P, rho, canonical=True, dtype=dt)
+            assert np.array_equal(S.centered(can[None], P), S.centered((want.astype(object) % np.array(P, dtype=object)[:, None]).astype(dt)[None], P))
+        assert np.array_equal(got, want), key
+        seen += 1
+    assert seen >= 6
+
+
+def test_chacha20_known_answer():
+    # D. J. Bernstein's ChaCha20, all-zero key and nonce, block 0 (the classic test vector)
+    w = S.chacha20_words(bytes(32), 0, 0, 8)
+    ks = b"".join(int(v).to_bytes(8, "little") for v in w).hex()
+    assert ks == ("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                  "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    # random access: any window equals the corresponding slice of a long run, and streams differ
+    key = bytes(range(32))
+    long = S.chacha20_words(key, 7, 0, 100)
+    assert np.array_equal(S.chacha20_words(key, 7, 13, 50), long[13:63])
+    assert not np.array_equal(S.chacha20_words(key, 8, 0, 100), long)
+
+
+def test_distribution_fixtures_are_sane():
+    for sigma in (3.2, 20.0):
+        hist, lo = GOLD["gauss_%g/hist" % sigma], int(GOLD["gauss_%g/lo" % sigma])
+        x = np.arange(lo, lo + hist.size)
+        mean = (hist * x).sum() / hist.sum()
+        var = (hist * (x - mean) ** 2).sum() / hist.sum()
+        assert abs(mean) < 4 * sigma / np.sqrt(hist.sum()) and abs(var / sigma ** 2 - 1) < 0.02
+    assert int(GOLD["hwt_64/pos_hist"].sum()) == 64 * int(GOLD["hwt_64/reps"])
+
+
+@pytest.mark.skipif(not O.ref_available() or not hasattr(O.Reference(64, 64, 3).lib, "nflref_sample_replay"),
+                    reason="real reference not built here")
+def test_rules_match_live_reference():
+    ref = O.Reference(64, 64, 3)
+    P = [int(x) for x in params(64).P[:3]]
+    for _ in range(3):
+        out, raw = ref.sample_replay(0)
+        assert np.array_equal(S.uniform(raw.view(np.uint64).reshape(3, 64), P), out)
+        out, raw = ref.sample_replay(1, 37, 5)
+        assert np.array_equal(S.non_uniform(raw.view(np.uint64), P, 37, 5), out)
+        out, raw = ref.sample_replay(2, 0x7F)
+        assert np.array_equal(S.zo_dist(raw, P, 0x7F, canonical=False), out)
