@@ -202,6 +202,12 @@ def main():
         limbs = eng.crt_lift(a[:sub])
         t_l = rate(lambda: eng.crt_lift(a[:sub]), 5); t_p = rate(lambda: eng.crt_project(limbs), 5)
         crt_bytes = sub * (nm * n * w + n * eng.crt_limbs * 8)
+        # samplers: polys per second written (bytes = one write of the batch)
+        skey = bytes(range(32))
+        gs = eng.gauss_create(3.19, 128, n)
+        t_su = rate(lambda: eng.sample(c, 0, skey, stream_id=1), 5)
+        t_sg = rate(lambda: eng.sample_gauss(c, gs, skey, stream_id=2), 5)
+        eng.gauss_destroy(gs)
         extras = {
             "ntt_fwd_per_s": round(batch / t_f, 1), "ntt_fwd_GBs": round(tr_bytes / t_f / 1e9, 1),
             "ntt_inv_per_s": round(batch / t_i, 1), "ntt_inv_GBs": round(tr_bytes / t_i / 1e9, 1),
@@ -209,6 +215,8 @@ def main():
             "polymul_b_pretransformed_per_s": round(batch / t_pn, 1),
             "crt_lift_per_s": round(sub / t_l, 1), "crt_lift_GBs": round(crt_bytes / t_l / 1e9, 1),
             "crt_project_per_s": round(sub / t_p, 1), "crt_project_GBs": round(crt_bytes / t_p / 1e9, 1),
+            "sample_uniform_per_s": round(batch / t_su, 1), "sample_uniform_GBs": round(batch * nm * n * w / t_su / 1e9, 1),
+            "sample_gaussian_per_s": round(batch / t_sg, 1),
             "note": "GB/s are algorithmic bytes (SURVEY.md 8(d)) / event time; polys per second over the same batch",
         }
         del bn, limbs
