@@ -28,6 +28,7 @@ WORKLOADS = {
     "B": (64, 4096, 4, 16384),   # BASELINE.json configs[1] -- the metric is quoted on this
     "C": (64, 16384, 8, 1024),   # configs[2]
     "E": (64, 65536, 30, 32),    # configs[4]
+    "A": (32, 1024, 1, 1 << 19), # configs[0]'s shape (30-bit moduli) on the device -- secondary
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
@@ -223,10 +224,10 @@ def main():
 
     result = {
         "metric": "poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli" if args.workload == "B"
-                  else "poly-mults/sec (NTT+pointwise+INTT), n=%d, %dx62-bit moduli" % (n, nm),
+                  else "poly-mults/sec (NTT+pointwise+INTT), n=%d, %dx%d-bit moduli" % (n, nm, lb - 2),
         "value": round(value, 1), "unit": "polymul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u%d" % lb, "data": "synthetic",
         "config": {"workload": "nfl::poly<uint64_t,%d,%d> batched polymul (BASELINE configs %s)" % (n, nm, args.workload),
                    "degree": n, "nmoduli": nm, "limb_bits": lb, "batch_per_gpu": batch, "global_batch": batch * world,
                    "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},

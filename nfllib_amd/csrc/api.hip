@@ -533,6 +533,11 @@ int nflhip_ntt_fwd_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(fast)");
   }
+  if (ctx->shape.limb_bits == 32) {
+    e = launch_row1024_u32(ctx->shape, ctx->tabs, 2, (uint32_t *)d, (const uint32_t *)d, nullptr, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(u32)");
+  }
   e = DISPATCH_T(ctx, launch_ntt_fwd<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d, (uint16_t *)d, batch, st),
                  launch_ntt_fwd<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)d, (uint32_t *)d, batch, st),
                  launch_ntt_fwd<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st));
@@ -549,6 +554,11 @@ int nflhip_ntt_inv_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
     e = launch_ntt_inv_fast_u64(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(fast)");
+  }
+  if (ctx->shape.limb_bits == 32) {
+    e = launch_row1024_u32(ctx->shape, ctx->tabs, 3, (uint32_t *)d, (const uint32_t *)d, nullptr, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(u32)");
   }
   e = DISPATCH_T(ctx,
                  launch_ntt_inv<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d, nullptr, (uint16_t *)d, batch, st),
@@ -600,6 +610,12 @@ static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, i
                                            b_is_ntt, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(fast)");
+  }
+  if (ctx->shape.limb_bits == 32) {
+    hipError_t e = launch_row1024_u32(ctx->shape, ctx->tabs, b_is_ntt ? 1 : 0, (uint32_t *)c, (const uint32_t *)a,
+                                      (const uint32_t *)b, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u32)");
   }
   return DISPATCH_T(ctx, polymul_composed<uint16_t>(ctx, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, b_is_ntt, batch, st),
                     polymul_composed<uint32_t>(ctx, (uint32_t *)c, (const uint32_t *)a, (const uint32_t *)b, b_is_ntt, batch, st),

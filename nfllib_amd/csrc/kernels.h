@@ -124,6 +124,11 @@ hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, 
                                             const uint64_t *b_in, size_t batch, hipStream_t st);
 int row16k_level();  // NFLHIP_ROW16K: 0 off, 1 rows of 16384 words only (default), 2 also as block kernel of longer rows
 
+// 32-bit limbs, n = 1024: one wave per row (kernels_u32.hip).  mode 0: c = INTT(NTT(a)(.)NTT(b)); 1: b already in
+// NTT form; 2: c = NTT(a); 3: c = INTT(a).  hipErrorNotSupported for other shapes.
+hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
+                              const uint32_t *b, size_t batch, hipStream_t st);
+
 // register-resident CRT kernels for 64-bit limbs (kernels_crt.hip); hipErrorNotSupported otherwise
 hipError_t launch_crt_lift_fast_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,
                                     hipStream_t st);

@@ -19,7 +19,8 @@ def child(batch, iters, workload):
     import torch
     from nfllib_amd import Engine
     from nfllib_amd.sharding import digest_words
-    lb, n, nm = {"B": (64, 4096, 4), "C": (64, 16384, 8), "E": (64, 65536, 30)}[workload]
+    lb, n, nm = {"B": (64, 4096, 4), "C": (64, 16384, 8), "E": (64, 65536, 30), "A": (32, 1024, 1), "A2": (32, 1024, 2),
+                  "H": (16, 128, 1)}[workload]
     e = Engine(lb, n, nm)
     a = e.fill_uniform(e.empty(batch), 0x4E464C6C6962, 0)
     b = e.fill_uniform(e.empty(batch), 0x4E464C6C6962, 1)
