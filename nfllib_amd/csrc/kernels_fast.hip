@@ -23,6 +23,8 @@
 // Reference behaviour replaced: core::ntt_pow_phi (core.hpp:594-600), the
 // point-wise mulmod loop (core.hpp:24-37 with ops.hpp:201-219) and
 // core::invntt_pow_invphi (core.hpp:608-614).
+#include <mutex>
+
 #include "kernels.h"
 #include "modarith64.h"
 #include <cstdlib>
@@ -411,7 +413,7 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
-  bool tried = false;
+  std::once_flag once;
 };
 static AsmKernel g_asm[16];  // per device
 
@@ -419,19 +421,18 @@ static hipFunction_t asm_fn(AsmKind kind) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   AsmKernel &k = g_asm[dev];
-  if (!k.tried) {
-    k.tried = true;
+  std::call_once(k.once, [&k] {  // contexts may be used from several host threads
     if (hipModuleLoadData(&k.mod, kPolymulHsaco) != hipSuccess) {
       k.mod = nullptr;
       (void)hipGetLastError();
-    } else {
-      for (int i = 0; i < kAsmCount; ++i)
-        if (hipModuleGetFunction(&k.fn[i], k.mod, kAsmNames[i]) != hipSuccess) {
-          k.fn[i] = nullptr;
-          (void)hipGetLastError();
-        }
+      return;
     }
-  }
+    for (int i = 0; i < kAsmCount; ++i)
+      if (hipModuleGetFunction(&k.fn[i], k.mod, kAsmNames[i]) != hipSuccess) {
+        k.fn[i] = nullptr;
+        (void)hipGetLastError();
+      }
+  });
   return k.fn[kind];
 }
 

@@ -359,3 +359,39 @@ def test_row_resident_16384_kernel_matches_block_plan():
         assert r.returncode == 0, r.stderr[-2000:]
         got[v] = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["0"] == got["1"] == got["2"]
+
+
+def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_factory):
+    """The threading contract of include/nflhip.h: a context is immutable after creation, so host threads may call
+    the *_dev entry points concurrently on distinct streams (SURVEY.md 8(b) "Threading")."""
+    import threading
+    import torch
+    for lb, n, m, batch in ((64, 4096, 4, 64), (64, 16384, 2, 8), (32, 1024, 2, 64)):
+        e = engine_factory(lb, n, m)
+        a = e.fill_uniform(e.empty(batch), SEED, 0)
+        b = e.fill_uniform(e.empty(batch), SEED, 1)
+        want = e.to_host(e.polymul(a, b))
+        torch.cuda.synchronize()
+        results, errors = {}, []
+
+        def work(tid):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    aa, bb = a.clone(), b.clone()
+                    out = None
+                    for _ in range(10):
+                        out = e.polymul(aa, bb, stream=st)
+                        f = e.ntt_(aa.clone(), stream=st)
+                        aa = e.intt_(f, stream=st)
+                    st.synchronize()
+                    results[tid] = e.to_host(out)
+            except Exception as ex:  # noqa: BLE001
+                errors.append(ex)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert not errors, errors
+        for tid in range(4):
+            assert np.array_equal(results[tid], want), (lb, n, m, tid)
