@@ -172,8 +172,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload:
+            tj = json.load(open(tpath)).get("workloads", {}).get(args.workload)
+            if tj:
                 traffic = tj["hbm_bytes_per_poly"] * batch
                 traffic_src = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes, %s, calibrated)" % tj.get("round", "")
         except Exception:
