@@ -42,6 +42,8 @@ struct nflhip_ctx {
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
   bool ev_prev_valid = false;
+  hipEvent_t ev_scratch = nullptr;  // end of the last single-stream pipeline that used the scratch
+  bool ev_scratch_valid = false;
   // host copies for introspection
   std::vector<uint64_t> h_Q;                     // moduli_product limbs
   std::vector<std::vector<uint64_t>> h_lifting;  // lifting_integers[cm]
@@ -307,6 +309,17 @@ static int ensure_scratch(nflhip_ctx *ctx, size_t bytes) {
   return NFLHIP_OK;
 }
 
+// NFLHIP_PIPE_CHUNKS: chunks of a batch in the n = 65536 pipeline (0 = use the three-kernel plan instead)
+static int pipe64k_chunks() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("NFLHIP_PIPE_CHUNKS");
+    v = e ? atoi(e) : 4;
+    if (v < 0) v = 0;
+  }
+  return v;
+}
+
 // composed path: NTT(a)->c, NTT(b)->scratch, inverse with the product fused into its load
 template <typename T>
 static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b_is_ntt, size_t batch, hipStream_t st) {
@@ -321,6 +334,34 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 16 && pipe64k_chunks() > 0) {
+    // n = 65536: the streaming passes (HBM-bound) and the fused block kernel (VALU-bound) of neighbouring chunks share
+    // every CU inside ONE kernel whose workgroups take three roles; consecutive launches on the caller's stream form the
+    // pipeline: launch L = forward pass of chunk L, block products of chunk L-1, inverse pass of chunk L-2.
+    const size_t pw = ctx->shape.nm * ctx->shape.n;
+    size_t nchunk = (size_t)pipe64k_chunks();  // fill + drain cost ~0.7 chunk; small grids lose efficiency: 4 measured best
+    if (nchunk * 2 > batch) nchunk = batch >= 2 ? batch / 2 : 1;
+    auto lo_of = [&](size_t ch) { return batch * ch / nchunk; };
+    bool supported = true;
+    if (ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));  // a previous call on another stream
+    for (size_t L = 0; L < nchunk + 2 && supported; ++L) {
+      const bool hf = L < nchunk, hv = L >= 1 && L - 1 < nchunk, hi = L >= 2 && L - 2 < nchunk;
+      const size_t f0 = hf ? lo_of(L) : 0, v0 = hv ? lo_of(L - 1) : 0, i0 = hi ? lo_of(L - 2) : 0;
+      const int cf = hf ? (int)(lo_of(L + 1) - f0) : 0, cv = hv ? (int)(lo_of(L) - v0) : 0, ci = hi ? (int)(lo_of(L - 1) - i0) : 0;
+      e = launch_polymul_pipe64k_u64(ctx->shape, ctx->tabs, (uint64_t *)c + v0 * pw, (const uint64_t *)s0 + v0 * pw,
+                                     (const uint64_t *)s1 + v0 * pw, cv, (const uint64_t *)a + f0 * pw, (uint64_t *)s0 + f0 * pw,
+                                     (const uint64_t *)b + f0 * pw, (uint64_t *)s1 + f0 * pw, cf, (uint64_t *)c + i0 * pw, ci, st);
+      if (e == hipErrorNotSupported && L == 0) { supported = false; break; }
+      if (e != hipSuccess) return hipfail(ctx, e, "polymul: pipeline kernel");
+    }
+    if (supported) {
+      // the scratch is reused by the next call on any stream: order it after this one
+      HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
+      ctx->ev_scratch_valid = true;
+      for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_scratch, 0));
+      return NFLHIP_OK;
+    }
+  }
   if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn > 12 && ctx->aux[0]) {
     // large rows: streaming outer passes, then the fused assembly kernel over the 4096-word blocks,
     // then the outer inverse passes (9 operand streams of HBM traffic instead of 13).  The batch is cut
@@ -435,6 +476,7 @@ int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree
       if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming);
     }
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming);
     if (se != hipSuccess) rc = hipfail(nullptr, se, "hipStreamCreate");
   }
   if (rc != NFLHIP_OK) {
@@ -454,6 +496,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
     if (ctx->ev_done[k]) (void)hipEventDestroy(ctx->ev_done[k]);
   }
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_scratch) (void)hipEventDestroy(ctx->ev_scratch);
   for (int i = 0; i < 4; ++i)
     if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
   if (ctx->scratch) (void)hipFree(ctx->scratch);

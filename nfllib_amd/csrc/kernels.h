@@ -122,7 +122,13 @@ hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uin
 // logn-14 .. logn-1 of both operands, the product and the way back.
 hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                             const uint64_t *b_in, size_t batch, hipStream_t st);
-int row16k_level();  // NFLHIP_ROW16K: 0 off, 1 rows of 16384 words only (default), 2 also as block kernel of longer rows
+int row16k_level();
+// n = 65536: one launch of the three-role pipeline kernel (block products of chunk j-1, forward streaming pass of
+// chunk j, inverse streaming pass of chunk j-2); hipErrorNotSupported for other shapes
+hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
+                                      const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
+                                      const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
+                                      hipStream_t st);  // NFLHIP_ROW16K: 0 off, 1 rows of 16384 words only (default), 2 also as block kernel of longer rows
 
 // 32-bit limbs, n = 1024: one wave per row (kernels_u32.hip).  mode 0: c = INTT(NTT(a)(.)NTT(b)); 1: b already in
 // NTT form; 2: c = NTT(a); 3: c = INTT(a).  hipErrorNotSupported for other shapes.

@@ -402,14 +402,15 @@ static const unsigned char kPolymulHsaco[] = {
 enum AsmKind {
   kAsmPolymul = 0, kAsmPolymulNtt, kAsmFwd, kAsmInv, kAsmInvMul,   // 4096-word blocks, 256 threads
   kAsmPolymul16k, kAsmPolymulNtt16k, kAsmFwd16k, kAsmInv16k,        // 16384-word blocks, 1024 threads
+  kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
   kAsmCount
 };
-static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k; }
+static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
 static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "nflhip_polymul_ntt4096_asm",
                                                  "nflhip_ntt_fwd4096_asm",     "nflhip_ntt_inv4096_asm",
                                                  "nflhip_ntt_inv_mul4096_asm", "nflhip_polymul16384_asm",
                                                  "nflhip_polymul_ntt16384_asm", "nflhip_ntt_fwd16384_asm",
-                                                 "nflhip_ntt_inv16384_asm"};
+                                                 "nflhip_ntt_inv16384_asm",    "nflhip_polymul_pipe65536_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -470,6 +471,37 @@ int row16k_level() {
   }
   return v;
 }
+// n = 65536: one launch of the three-role kernel (tools/gen_polymul_asm.py build_pipe): fused block products of `cnt_v`
+// polynomials whose operands already went through the forward streaming pass (a_v, b_v -> c_v), the forward streaming
+// pass of `cnt_f` polynomials (fa_src -> fa_dst, fb_src -> fb_dst) and the inverse streaming pass of `cnt_i`
+// polynomials in place (inv).  Counts may be zero.
+hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
+                                      const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
+                                      const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
+                                      hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn != 16 || variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+  hipFunction_t fn = asm_fn(kAsmPipe64k);
+  if (!fn) return hipErrorNotSupported;
+  const int mx = cnt_v > cnt_f ? (cnt_v > cnt_i ? cnt_v : cnt_i) : (cnt_f > cnt_i ? cnt_f : cnt_i);
+  if (mx <= 0) return hipSuccess;
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    int nm, logn;
+    int cnt_v, cnt_f, cnt_i, pad;
+    const void *fa_src;
+    void *fa_dst;
+    const void *fb_src;
+    void *fb_dst, *inv, *pad2;
+  } args = {c_v, a_v, b_v, t.psi, t.mc, (int)s.nm, s.logn, cnt_v, cnt_f, cnt_i, 0, fa_src, fa_dst, fb_src, fb_dst, inv, nullptr};
+  static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_pipe65536_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  const size_t gx = (size_t)mx * 28;  // per polynomial row: 16 block products + 3 x 4 streaming workgroups
+  if (gx > 0x7fffffffull) return hipErrorInvalidValue;
+  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+}
+
 hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                             const uint64_t *b_in, size_t batch, hipStream_t st) {
   if (s.limb_bits != 64 || s.logn < kLogN + 2 || row16k_level() < (s.logn == kLogN + 2 ? 1 : 2)) return hipErrorNotSupported;

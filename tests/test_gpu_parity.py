@@ -325,7 +325,7 @@ import torch
 from nfllib_amd import Engine
 from nfllib_amd.sharding import digest_words
 out = {}
-for n, m, batch in ((16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (65536, 3, 2)):
+for n, m, batch in ((16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (65536, 3, 2), (65536, 2, 5), (65536, 1, 1)):
     e = Engine(64, n, m)
     a = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 0)
     b = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 1)
@@ -352,13 +352,15 @@ def test_row_resident_16384_kernel_matches_block_plan():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for v in ("0", "1", "2"):
-        env = dict(os.environ, NFLHIP_ROW16K=v)
+    # NFLHIP_PIPE_CHUNKS: the n = 65536 three-role pipeline kernel (default 4 chunks; 0 = the three-kernel plan;
+    # 3 with the child's batch of 2 or 5 exercises uneven and single-polynomial chunks)
+    for v, pipe in (("0", "0"), ("1", "4"), ("2", "0"), ("1", "3")):
+        env = dict(os.environ, NFLHIP_ROW16K=v, NFLHIP_PIPE_CHUNKS=pipe)
         r = subprocess.run([sys.executable, "-c", _ROW16K_CHILD, root, str(SEED)], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        got[v] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert got["0"] == got["1"] == got["2"]
+        got[v + pipe] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["00"] == got["14"] == got["20"] == got["13"]
 
 
 def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_factory):

@@ -559,25 +559,54 @@ def prologue(em, vm, kind="polymul"):
     return tw_seq
 
 
-def epilogue_inverse(em, vm, last_plain_stage):
+def strided_rows(em, vm, base, srow, stride, store=False, offset=0):
+    """16 words x[t + k*stride/8] of the row at srow (+ offset bytes) <-> register pairs base+2k; returns the number
+    of the last memory instruction issued (stores are counted too when a VmCounter is given)"""
+    R = em.raw
+    seq = 0
+    R("s_mov_b64 s[86:87], %s" % (srow,))
+    if offset:
+        R("s_add_u32 s86, s86, 0x%x" % offset)
+        R("s_addc_u32 s87, s87, 0")
+    for k in range(16):
+        if stride == 2048:
+            off = (k & 1) * 2048
+        else:
+            off = 0
+        if store:
+            text = "global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (V_OFF8, vp(base + 2 * k), off)
+            if vm is None:
+                R(text)
+            else:
+                seq = vm.load(text)
+        else:
+            seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d" % (vp(base + 2 * k), V_OFF8, off))
+        if stride == 2048:
+            if k & 1:
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+        elif k < 15:
+            R("s_add_u32 s86, s86, 0x%x" % stride)
+            R("s_addc_u32 s87, s87, 0")
+    return seq
+
+
+def epilogue_inverse(em, vm, last_plain_stage, suffix="", stride=2048):
+    """stride: bytes between a thread's consecutive words x[t + 256k] (2048 inside a 4096-word block; n/16 words for
+    the streaming passes of long rows)"""
     R = em.raw
     R("s_cmp_eq_u32 s88, 0")
-    R("s_cbranch_scc1 .Lmerged_last_stage")
+    R("s_cbranch_scc1 .Lmerged_last_stage%s" % suffix)
     em.comment("r > 0: plain stage r (uniform twiddle psi[(2<<r) - 1 - blk]); lazy output for the outer passes")
     last_plain_stage()
-    R("s_branch .Lstore")
-    em.lines.append(".Lmerged_last_stage:")
+    R("s_branch .Lstore%s" % suffix)
+    em.lines.append(".Lmerged_last_stage%s:" % suffix)
     em.comment("r == 0: stage 0 with n^-1 folded in")
     R("s_waitcnt vmcnt(0)")
     run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
-    em.lines.append(".Lstore:")
+    em.lines.append(".Lstore%s:" % suffix)
     # ---------------- store c (x[t + 256k])
-    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
-    for k in range(16):
-        R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (V_OFF8, vp(V_A + 2 * k), (k & 1) * 2048))
-        if k & 1:
-            R("s_add_u32 s86, s86, 0x1000")
-            R("s_addc_u32 s87, s87, 0")
+    strided_rows(em, None, V_A, S_CROW, stride, store=True)
     R("s_endpgm")
 
 
@@ -603,8 +632,12 @@ def build(kind="polymul"):
     """kind: polymul | polymul_ntt (b already in NTT form) | fwd | inv | inv_mul (inverse of src (.) mul)"""
     em = Emitter()
     vm = VmCounter(em)
-    R = em.raw
     tw_seq = prologue(em, vm, kind)
+    return build_body(em, vm, kind, tw_seq)
+
+
+def build_body(em, vm, kind, tw_seq, suffix=""):
+    R = em.raw
     has_fwd = kind in ("polymul", "polymul_ntt", "fwd")
     has_inv = kind != "fwd"
     fwd_bases = [V_A, V_B] if kind == "polymul" else [V_A]
@@ -1089,6 +1122,194 @@ def build_row16k(kind="polymul", stop=None):
     return em
 
 
+# ------------------------------------------------------------------ n = 65536: the three-role pipeline kernel
+# Long rows need streaming radix-16 passes around the fused 4096-word block kernel, and the two kinds of work bound
+# different resources (HBM vs integer VALU).  Kernels from different streams do not interleave on a CU in practice
+# (DESIGN.md), so ONE launch carries all three kinds of workgroups, interleaved by workgroup index:
+#   role 0  V   fused product of one 4096-word block of chunk j-1   (operands already passed through role 1/2)
+#   role 1,2 F  forward radix-16 pass (global stages 0-3) of 256 columns of operand a / b of chunk j   (src -> dst)
+#   role 3  I   inverse radix-16 pass (global stages 3-0, n^-1 folded in) of 256 columns of c of chunk j-2, in place
+# Consecutive launches on one stream form the pipeline; inside a launch the roles are independent.
+# kernarg: c_v a_v b_v psi mc | nm (logn unused) | cntV cntF cntI pad | fa_src fa_dst fb_src fb_dst inv_data pad
+# grid: (28 * max(cnt), nm): wgx = 28*poly + w.
+PIPE_LOGN = 16
+
+
+def emit_mc_load(em):
+    R = em.raw
+    R("s_mul_i32 s42, s3, 0x70")
+    R("s_add_u32 s42, s12, s42")
+    R("s_addc_u32 s43, s13, 0")
+    R("s_load_dwordx16 s[56:71], s[42:43], 0x0")          # p p2 mu ninv ninv_sh w1ninv w1ninv_sh beta
+    R("s_load_dwordx8 s[72:79], s[42:43], 0x40")          # beta_sh yinv yinv_sh mask
+    R("s_load_dwordx4 s[80:83], s[42:43], 0x60")          # delta mu2
+
+
+def emit_consts(em):
+    R = em.raw
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b64 s[24:25], s[56:57]")                    # p
+    R("s_mov_b64 s[26:27], s[58:59]")                    # 2p
+    R("s_add_u32 s28, s58, s56")                         # 3p
+    R("s_addc_u32 s29, s59, s57")
+    R("s_mov_b32 s30, s80")                              # delta
+    R("s_mov_b32 s31, 0x3fffffff")
+    R("s_mov_b32 s15, 0xc0000000")
+    R("s_mov_b64 s[32:33], s[82:83]")                    # mu2
+    R("s_mov_b64 s[34:35], s[62:63]")                    # ninv
+    R("s_mov_b64 s[36:37], s[64:65]")                    # ninv_sh
+    R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
+    R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
+    em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+
+
+def build_pipe():
+    em = Emitter()
+    R = em.raw
+    n_words = 1 << PIPE_LOGN
+    stride = n_words // 16 * 8                            # bytes between x[o + k n/16]
+    R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c_v, a_v, b_v, psi
+    R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
+    R("s_load_dword s14, s[0:1], 0x28")                  # nm
+    R("s_load_dwordx16 s[56:71], s[0:1], 0x30")          # cntV cntF cntI pad | fa_src fa_dst fb_src fb_dst inv pad
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                     # B = t >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
+    em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
+    em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_BIDX, V_L2R, V_L1R))     # 272*B + r
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
+    em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
+    em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
+    for t0 in sorted(set(V_T)):
+        em.valu("v_mov_b32_e32 v%d, 0" % (t0 + 15,))                                # the persistent zero of ZP
+    R("s_waitcnt lgkmcnt(0)")
+    # Dense role map, no idle workgroups (a workgroup launch costs ~35 ns of dispatcher time chip-wide, measured):
+    # 28 workgroups per polynomial row -- w = wgx mod 28: 0..15 block products, 16..19 / 20..23 forward streaming of
+    # a / b (four column groups each), 24..27 inverse streaming.  28 = 4 mod 8, so the XCD of a role rotates with the
+    # polynomial index and every role is spread over all XCDs.
+    R("s_mul_hi_u32 s86, s2, 0x%x" % ((1 << 32) // 28 + 1,))   # poly = wgx / 28 (exact below 1.7e8)
+    R("s_mul_i32 s43, s86, 28")
+    R("s_sub_u32 s89, s2, s43")                          # w
+    R("s_mov_b32 s42, 0")                                # role 0: block product, blk = w
+    R("s_cmp_lt_u32 s89, 16")
+    R("s_cbranch_scc1 .Lrole_known")
+    R("s_sub_u32 s89, s89, 16")
+    R("s_lshr_b32 s42, s89, 2")
+    R("s_add_u32 s42, s42, 1")                           # role 1, 2, 3
+    R("s_and_b32 s89, s89, 3")                           # q: column groups q, q+4, q+8, q+12
+    em.lines.append(".Lrole_known:")
+    R("s_mul_i32 s87, s86, s14")
+    R("s_add_u32 s87, s87, s3")                          # row = poly*nm + cm
+    R("s_lshl_b32 s43, s3, %d" % (PIPE_LOGN + 4,))       # tw = psi + cm * n * 16
+    R("s_add_u32 s22, s10, s43")
+    R("s_addc_u32 s23, s11, 0")
+    R("s_cmp_eq_u32 s42, 0")
+    R("s_cbranch_scc1 .Lrole_v")
+    R("s_cmp_eq_u32 s42, 3")
+    R("s_cbranch_scc1 .Lrole_i")
+
+    # ---------------------------------------------------------------- streaming roles
+    # A streaming workgroup owns the four column groups sub, sub+4, sub+8, sub+12 of its row (sub < 4; the others
+    # exit at once) and double-buffers them through the a / b register files: the loads of group g+1 are in flight
+    # while group g is transformed, and the 15 twiddle records of the pass are loaded once.
+    GROUPS, GSTEP = 4, 4 * 2048
+
+    def stream_role(kind):
+        vm = VmCounter(em)
+        bufs = [V_A, V_B]
+        seq_of = {0: strided_rows(em, vm, bufs[0], S_AROW, stride)}
+        tw_last = 0
+        for st in ((0, 1, 2, 3) if kind == "F" else (3, 2, 1, 0)):
+            tw_last = PASS_TW["F1" if kind == "F" else "I3"](em, vm, st)
+        emit_consts(em)
+        for gi in range(GROUPS):
+            buf = bufs[gi & 1]
+            if gi + 1 < GROUPS:
+                seq_of[gi + 1] = strided_rows(em, vm, bufs[(gi + 1) & 1], S_AROW, stride, offset=(gi + 1) * GSTEP)
+            vm.wait(max(seq_of[gi], tw_last))
+            if kind == "F":
+                for st in range(4):
+                    ct_stage(em, [buf], st)
+            else:
+                for st in (3, 2, 1):
+                    gs_stage(em, buf, st)
+                run_pairs(em, [final_bfly(buf + 2 * h, buf + 2 * (h + 8)) for h in range(8)])
+            strided_rows(em, vm, buf, S_CROW, stride, store=True, offset=gi * GSTEP)
+        R("s_endpgm")
+
+    em.comment("role F: x[o + k n/16] -> radix-16 over global stages 0..3 -> lazy words (the block kernel takes any word)")
+    R("s_cmp_ge_u32 s86, s57")
+    R("s_cbranch_scc1 .Lidle")
+    R("s_cmp_eq_u32 s42, 1")
+    R("s_cselect_b64 s[16:17], s[60:61], s[64:65]")      # src
+    R("s_cselect_b64 s[20:21], s[62:63], s[66:67]")      # dst
+    R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
+    R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))      # row * n * 8
+    R("s_lshl_b32 s86, s89, 11")
+    R("s_add_u32 s42, s42, s86")                         # + 256 columns * 8 B * group (no carry: low 19 bits were zero)
+    for row in (16, 20):
+        R("s_add_u32 s%d, s%d, s42" % (row, row))
+        R("s_addc_u32 s%d, s%d, s43" % (row + 1, row + 1))
+    R("s_mov_b32 s90, 1")                                # K_F1 of the row's first four stages
+    emit_mc_load(em)
+    stream_role("F")
+
+    em.lines.append(".Lrole_i:")
+    em.comment("role I: lazy words of the block kernel -> global stages 3..0 with n^-1 -> canonical x[o + k n/16]")
+    R("s_cmp_ge_u32 s86, s58")
+    R("s_cbranch_scc1 .Lidle")
+    R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
+    R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))
+    R("s_lshl_b32 s86, s89, 11")
+    R("s_add_u32 s42, s42, s86")
+    R("s_add_u32 s16, s68, s42")
+    R("s_addc_u32 s17, s69, s43")
+    R("s_mov_b64 s[20:21], s[16:17]")
+    R("s_mov_b32 s95, 2")                                # K_I3 of the row's last four stages
+    emit_mc_load(em)
+    stream_role("I")
+
+    # ---------------------------------------------------------------- role 0: the fused block product
+    em.lines.append(".Lrole_v:")
+    em.comment("role V: one 4096-word block, exactly the stand-alone block kernel (r = 4, blk = s89)")
+    R("s_cmp_ge_u32 s86, s56")
+    R("s_cbranch_scc1 .Lidle")
+    R("s_lshl_b32 s42, s87, 4")
+    R("s_add_u32 s42, s42, s89")                         # block index = row * 16 + blk
+    R("s_lshr_b32 s43, s42, 17")
+    R("s_lshl_b32 s42, s42, 15")
+    for base, row in ((6, 16), (8, 18), (4, 20)):
+        R("s_add_u32 s%d, s%d, s42" % (row, base))
+        R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    R("s_mov_b32 s88, %d" % (PIPE_LOGN - 12,))
+    R("s_lshl_b32 s90, 1, s88")
+    R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
+    R("s_lshl_b32 s91, s90, 4")
+    R("s_lshl_b32 s92, s90, 8")
+    R("s_lshl_b32 s93, 0x200, s88")
+    R("s_lshl_b32 s42, s89, 8")
+    R("s_sub_u32 s93, s93, s42")                         # (512<<r) - 256*blk
+    R("s_lshl_b32 s94, 32, s88")
+    R("s_lshl_b32 s42, s89, 4")
+    R("s_sub_u32 s94, s94, s42")                         # (32<<r) - 16*blk
+    R("s_lshl_b32 s95, 2, s88")
+    R("s_sub_u32 s95, s95, s89")                         # (2<<r) - blk
+    emit_mc_load(em)
+    vm = VmCounter(em)
+    strided_rows(em, vm, V_A, S_AROW, 2048)
+    strided_rows(em, vm, V_B, S_BROW, 2048)
+    tw_seq = {}
+    for st in range(4):
+        tw_seq[("F1", st)] = PASS_TW["F1"](em, vm, st)
+    emit_consts(em)
+    build_body(em, vm, "polymul", tw_seq, "_v")
+    em.lines.append(".Lidle:")
+    R("s_endpgm")
+    return em
+
+
 HEADER = """\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
 \t.amdhsa_code_object_version 6
 \t.text
@@ -1105,7 +1326,7 @@ FOOTER = """.Lfunc_end0:
 \t.amdhsa_kernel %(k)s
 \t\t.amdhsa_group_segment_fixed_size %(lds)d
 \t\t.amdhsa_private_segment_fixed_size 0
-\t\t.amdhsa_kernarg_size 48
+\t\t.amdhsa_kernarg_size %(karg)d
 \t\t.amdhsa_user_sgpr_count 2
 \t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
 \t\t.amdhsa_system_sgpr_workgroup_id_x 1
@@ -1125,16 +1346,9 @@ FOOTER = """.Lfunc_end0:
 ---
 amdhsa.kernels:
   - .args:
-      - {.address_space: global, .offset: 0, .size: 8, .value_kind: global_buffer}
-      - {.address_space: global, .offset: 8, .size: 8, .value_kind: global_buffer}
-      - {.address_space: global, .offset: 16, .size: 8, .value_kind: global_buffer}
-      - {.address_space: global, .offset: 24, .size: 8, .value_kind: global_buffer}
-      - {.address_space: global, .offset: 32, .size: 8, .value_kind: global_buffer}
-      - {.offset: 40, .size: 4, .value_kind: by_value}
-      - {.offset: 44, .size: 4, .value_kind: by_value}
-    .group_segment_fixed_size: %(lds)d
+%(args)s    .group_segment_fixed_size: %(lds)d
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 48
+    .kernarg_segment_size: %(karg)d
     .max_flat_workgroup_size: %(wg)d
     .name:           %(k)s
     .private_segment_fixed_size: 0
@@ -1160,9 +1374,27 @@ KERNELS = {   # kind -> (file suffix, kernel symbol)
 }
 
 
-def emit_file(path, kname, em):
+ARGS_STD = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 40), ("i32", 44)]
+ARGS_PIPE = ARGS_STD + [("i32", 48), ("i32", 52), ("i32", 56), ("i32", 60), ("ptr", 64), ("ptr", 72), ("ptr", 80), ("ptr", 88),
+                        ("ptr", 96), ("ptr", 104)]
+
+
+def args_yaml(spec):
+    out = []
+    for kind, off in spec:
+        if kind == "ptr":
+            out.append("      - {.address_space: global, .offset: %d, .size: 8, .value_kind: global_buffer}" % off)
+        else:
+            out.append("      - {.offset: %d, .size: 4, .value_kind: by_value}" % off)
+    return "\n".join(out) + "\n"
+
+
+def emit_file(path, kname, em, args=None):
     accum = (NEXT_VGPR + 3) // 4 * 4
-    params = dict(k=kname, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=WG_SIZE)
+    args = ARGS_STD if args is None else args
+    karg = args[-1][1] + (8 if args[-1][0] == "ptr" else 4)
+    params = dict(k=kname, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=WG_SIZE,
+                  karg=karg, args=args_yaml(args))
     with open(path, "w") as f:
         f.write("; GENERATED by tools/gen_polymul_asm.py -- do not edit.\n")
         f.write(HEADER % params)
@@ -1184,6 +1416,7 @@ def main():
     configure("pair")
     for kind, (stem, kname) in KERNELS.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind))
+    emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
     configure("ring")
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
