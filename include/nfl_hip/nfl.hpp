@@ -14,7 +14,7 @@
 //   operator()(cm,i), begin/end, data(), get_modulus, degree/nmoduli/nbits    poly.hpp:142-162
 //   ntt_pow_phi(), invntt_pow_invphi()                                        poly.hpp:167-168
 //   operator+ - * == !=, shoup(a*b,b'), compute_shoup(b), nested expressions  poly.hpp:346-352
-//   explicit operator bool on polys and on == / != expressions                core.hpp:39-43, ops.hpp:81-95
+//   explicit operator bool on polys, implicit on == / != expressions         core.hpp:39-43, ops.hpp:81-95
 //   serialize_manually / deserialize_manually                                 poly.hpp:180-185
 //   nfl::add / sub / mul                                                      poly.hpp:314-332
 // What differs, on purpose:
@@ -44,6 +44,7 @@
 #include <iostream>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <random>
@@ -235,6 +236,9 @@ template <class in_class, class out_class, unsigned _lu_depth> struct gaussian {
 template <class T, size_t Degree, size_t NbModuli> class poly;
 
 // ---------------------------------------------------------------- expression templates (ops.hpp:52-97)
+template <class T, size_t Degree, size_t NbModuli> class poly;
+template <class T, size_t Degree, size_t NbModuli> class poly_p;
+
 namespace ops {
 
 struct addmod { static constexpr int code = NFLHIP_OP_ADD; };
@@ -247,6 +251,12 @@ struct neqmod {};
 struct shoup_marker {};
 
 template <class Op, class... Args> struct expr;
+
+// leaves of an expression tree: a poly, or a poly_p handle (poly_p.hpp:11-204) standing for its polynomial
+template <class A, class Poly> struct is_leaf : std::is_same<A, Poly> {};
+template <class T, size_t D, size_t M> struct is_leaf<poly_p<T, D, M>, poly<T, D, M>> : std::true_type {};
+template <class T, size_t D, size_t M> inline const poly<T, D, M> &leaf(const poly<T, D, M> &p) { return p; }
+template <class T, size_t D, size_t M> inline const poly<T, D, M> &leaf(const poly_p<T, D, M> &p) { return p.poly_obj(); }
 
 // postfix program of one expression tree (include/nflhip.h, NFLHIP_EXPR_*), built when the tree is
 // assigned: distinct leaf polys become operands 0..2, every node appends its opcode.
@@ -306,24 +316,24 @@ template <class Op, class... Args> struct expr {
   }
 
   // expr::operator bool (ops.hpp:81-95): true as soon as ONE lane of the value is non-zero
-  explicit operator bool() const { return truth(Op()); }
+  operator bool() const { return truth(Op()); }  // (implicit, as in the reference: `ok &= (a == b);` compiles)
 
  private:
-  template <class A> static void lower_one(const A &a, program &pr, std::true_type) { pr.push_leaf(a.cdata()); }
+  template <class A> static void lower_one(const A &a, program &pr, std::true_type) { pr.push_leaf(leaf(a).cdata()); }
   template <class A> static void lower_one(const A &a, program &pr, std::false_type) { a.lower(pr); }
   template <size_t I> void lower_args(program &pr, std::integral_constant<size_t, I>) const {
     typedef typename std::remove_cv<typename std::remove_reference<decltype(std::get<I>(args))>::type>::type A;
-    lower_one(std::get<I>(args), pr, std::is_same<A, poly_type>());
+    lower_one(std::get<I>(args), pr, is_leaf<A, poly_type>());
     lower_args(pr, std::integral_constant<size_t, I + 1>());
   }
   void lower_args(program &, std::integral_constant<size_t, sizeof...(Args)>) const {}
-  template <class A> static const poly_type &materialise(const A &a, poly_type &tmp, std::true_type) { (void)tmp; return a; }
+  template <class A> static const poly_type &materialise(const A &a, poly_type &tmp, std::true_type) { (void)tmp; return leaf(a); }
   template <class A> static const poly_type &materialise(const A &a, poly_type &tmp, std::false_type) {
     a.eval(tmp);
     return tmp;
   }
   template <class A> static const poly_type &mat(const A &a, poly_type &tmp) {
-    return materialise(a, tmp, std::is_same<A, poly_type>());
+    return materialise(a, tmp, is_leaf<A, poly_type>());
   }
   void eval_impl(poly_type &out, std::integral_constant<size_t, 1>) const {
     poly_type *t0 = poly_type::make_temp();
@@ -557,7 +567,11 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
 namespace ops {
 template <class X> struct is_node : std::false_type {};
 template <class T, size_t D, size_t M> struct is_node<poly<T, D, M>> : std::true_type {};
+template <class T, size_t D, size_t M> struct is_node<poly_p<T, D, M>> : std::true_type {};
 template <class Op, class... A> struct is_node<expr<Op, A...>> : std::true_type {};
+// == and != on a poly_p are its own members (poly_p.hpp:112-140); everything else is generic
+template <class X> struct is_cmp_node : is_node<X> {};
+template <class T, size_t D, size_t M> struct is_cmp_node<poly_p<T, D, M>> : std::false_type {};
 }  // namespace ops
 
 #define NFL_HIP_BINARY(SYM, NAME)                                                                          \
@@ -570,9 +584,17 @@ template <class Op, class... A> struct is_node<expr<Op, A...>> : std::true_type 
 NFL_HIP_BINARY(operator-, submod)
 NFL_HIP_BINARY(operator+, addmod)
 NFL_HIP_BINARY(operator*, mulmod)
-NFL_HIP_BINARY(operator==, eqmod)
-NFL_HIP_BINARY(operator!=, neqmod)
 #undef NFL_HIP_BINARY
+#define NFL_HIP_COMPARE(SYM, NAME)                                                                               \
+  template <class A, class B>                                                                                    \
+  typename std::enable_if<ops::is_cmp_node<A>::value && ops::is_node<B>::value, ops::expr<ops::NAME, A, B>>::type SYM( \
+      A const &a, B const &b) {                                                                                  \
+    static_assert(std::is_same<typename A::poly_type, typename B::poly_type>::value, "correct type combination"); \
+    return ops::expr<ops::NAME, A, B>(a, b);                                                                     \
+  }
+NFL_HIP_COMPARE(operator==, eqmod)
+NFL_HIP_COMPARE(operator!=, neqmod)
+#undef NFL_HIP_COMPARE
 
 template <class A> typename std::enable_if<ops::is_node<A>::value, ops::expr<ops::compute_shoup, A>>::type compute_shoup(A const &a) {
   return ops::expr<ops::compute_shoup, A>(a);
@@ -582,6 +604,100 @@ template <class A> typename std::enable_if<ops::is_node<A>::value, ops::expr<ops
 template <class A0, class A1, class B>
 ops::expr<ops::mulmod_shoup, A0, A1, B> shoup(ops::expr<ops::mulmod, A0, A1> const &prod, B const &bprime) {
   return ops::expr<ops::mulmod_shoup, A0, A1, B>(std::get<0>(prod.args), std::get<1>(prod.args), bprime);
+}
+
+// ---------------------------------------------------------------- poly_p (poly_p.hpp:11-204)
+// Copy-on-write handle to a heap-allocated, 32-byte aligned poly: same members as the reference's class.
+template <class T, size_t Degree, size_t NbModuli> class poly_p {
+ public:
+  typedef poly<T, Degree, NbModuli> poly_type;
+  using value_type = typename poly_type::value_type;
+  using greater_value_type = typename poly_type::greater_value_type;
+  static constexpr size_t nmoduli = poly_type::nmoduli;
+  static constexpr size_t degree = poly_type::degree;
+  static constexpr size_t nbits = poly_type::nbits;
+  static constexpr size_t aggregated_modulus_bit_size = poly_type::aggregated_modulus_bit_size;
+
+ private:
+  typedef std::shared_ptr<poly_type> ptr_type;
+  template <class... Args> static ptr_type make_pointer(Args &&... args) {
+    void *mem = nullptr;
+    if (posix_memalign(&mem, 32, sizeof(poly_type)) != 0) throw std::bad_alloc();
+    poly_type *p = nullptr;
+    try {
+      p = new (mem) poly_type(std::forward<Args>(args)...);
+    } catch (...) {
+      free(mem);
+      throw;
+    }
+    return ptr_type(p, [](poly_type *q) { q->~poly_type(); free(q); });
+  }
+  void detach() {
+    if (!_p.unique()) _p = make_pointer(*_p);
+  }
+  ptr_type _p;
+
+ public:
+  poly_p(poly_p const &o) : _p(o._p) {}
+  poly_p(poly_p &o) : _p(const_cast<poly_p const &>(o)._p) {}
+  poly_p(poly_p &&o) : _p(std::move(o._p)) {}
+  template <class... Args> poly_p(Args &&... args) : _p(make_pointer(std::forward<Args>(args)...)) {}
+  poly_p(poly_type const &) = delete;
+  poly_p(poly_type &&) = delete;
+
+  poly_type &poly_obj() {
+    detach();
+    return *_p;
+  }
+  poly_type const &poly_obj() const { return *_p; }
+
+  template <class O> poly_p &operator=(O &&o) {
+    poly_obj() = std::forward<O>(o);
+    return *this;
+  }
+  poly_p &operator=(std::initializer_list<T> values) {
+    poly_obj() = values;
+    return *this;
+  }
+  poly_p &operator=(poly_p const &o) {
+    if (this != &o) _p = o._p;
+    return *this;
+  }
+  poly_p &operator=(poly_p &o) { return *this = const_cast<poly_p const &>(o); }
+  poly_p &operator=(poly_p &&o) {
+    if (this != &o) _p = std::move(o._p);
+    return *this;
+  }
+
+  bool operator==(poly_p const &o) const { return _p.get() == o._p.get() ? true : bool(poly_obj() == o.poly_obj()); }
+  bool operator!=(poly_p const &o) const { return _p.get() == o._p.get() ? false : bool(poly_obj() != o.poly_obj()); }
+  template <class O> bool operator==(O const &o) const { return bool(poly_obj() == o); }
+  template <class O> bool operator!=(O const &o) const { return bool(poly_obj() != o); }
+
+  value_type &operator()(size_t cm, size_t i) { return poly_obj()(cm, i); }
+  value_type const &operator()(size_t cm, size_t i) const { return poly_obj()(cm, i); }
+  static constexpr value_type get_modulus(size_t n) { return poly_type::get_modulus(n); }
+
+  void ntt_pow_phi() { poly_obj().ntt_pow_phi(); }
+  void invntt_pow_invphi() { poly_obj().invntt_pow_invphi(); }
+  void serialize_manually(std::ostream &os) { poly_obj().serialize_manually(os); }
+  void deserialize_manually(std::istream &is) { poly_obj().deserialize_manually(is); }
+
+  void set(value_type v, bool reduce_coeffs = true) { poly_obj().set(v, reduce_coeffs); }
+  void set(uniform const &m) { poly_obj().set(m); }
+  void set(non_uniform const &m) { poly_obj().set(m); }
+  void set(ZO_dist const &m) { poly_obj().set(m); }
+  void set(hwt_dist const &m) { poly_obj().set(m); }
+  template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, T, _lu_depth> const &m) { poly_obj().set(m); }
+  void set(std::initializer_list<value_type> values, bool reduce_coeffs = true) { poly_obj().set(values, reduce_coeffs); }
+  template <class It> void set(It first, It last, bool reduce_coeffs = true) { poly_obj().set(first, last, reduce_coeffs); }
+};
+
+template <class T, size_t Degree, size_t AggregatedModulusBitSize>
+using poly_p_from_modulus = poly_p<T, Degree, AggregatedModulusBitSize / params<T>::kModulusBitsize>;
+
+template <class T, size_t D, size_t M> std::ostream &operator<<(std::ostream &os, poly_p<T, D, M> const &p) {
+  return os << p.poly_obj();
 }
 
 /* high level wrappers (poly.hpp:314-332) */

@@ -5,6 +5,7 @@
 //   compute_shoup / shoup(a*b,b'), NTT / INTT, nested expression (tests/poly_p.cpp:29-66),
 //   CRT round trip (tests/poly_mpz.cpp:19-29), ctor/set semantics (tests/poly_set.cpp),
 //   serialisation round trip (tests/poly_serialize_manually.cpp), stream prefix (tests/nfl_stream.cpp),
+//   the copy-on-write poly_p handle (tests/poly_p.cpp),
 //   the random constructors and the LWE round trip (tests/nfllib_demo_main_op.cpp:26-58, 313-332),
 // with memcmp-strength comparisons (the reference's operator== is "any lane equal").
 // Exit code 0 = all good; prints the failing check otherwise.  Needs a GPU.
@@ -269,6 +270,58 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_samplers() {
   return true;
 }
 
+// tests/poly_p.cpp:7-80 restated: the copy-on-write handle agrees with plain polys on every operation, in both
+// operand orders, including nested expressions
+template <class T, size_t Degree, size_t NbModuli> static bool run_poly_p() {
+  using poly_p = nfl::poly_p<T, Degree, NbModuli>;
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  bool ret = true;
+  poly_p a{nfl::uniform()}, b{nfl::uniform()};
+  Heap<poly_t> A(a.poly_obj()), B(b.poly_obj());
+  Heap<poly_t> add(*A + *B);
+  poly_p add_p{a + b};
+  ret &= (add_p == *add);
+  CHECK(same(add_p.poly_obj(), *add));
+  Heap<poly_t> sub(*A - *B);
+  poly_p sub_p{a - b};
+  ret &= (sub_p == *sub);
+  CHECK(same(sub_p.poly_obj(), *sub));
+  Heap<poly_t> mul(*A * *B);
+  poly_p mul_p{a * b};
+  ret &= (mul_p == *mul);
+  CHECK(same(mul_p.poly_obj(), *mul));
+  poly_p c{b};                      // shares b's storage until written
+  ret &= (c == b);
+  CHECK(&const_cast<const poly_p &>(c).poly_obj() == &const_cast<const poly_p &>(b).poly_obj());
+  c = {1};                          // detach
+  ret &= (c != b);
+  CHECK(&const_cast<const poly_p &>(c).poly_obj() != &const_cast<const poly_p &>(b).poly_obj());
+  CHECK(same(const_cast<const poly_p &>(b).poly_obj(), *B));
+  poly_p bshoup = nfl::compute_shoup(b);
+  Heap<poly_t> Bshoup(nfl::compute_shoup(*B));
+  ret &= (bshoup == *Bshoup);
+  CHECK(same(bshoup.poly_obj(), *Bshoup));
+  poly_p mul2_p = nfl::shoup(a * b, bshoup);
+  Heap<poly_t> mul2(nfl::shoup(*A * *B, *Bshoup));
+  ret &= (mul2_p == *mul2);
+  CHECK(same(mul2_p.poly_obj(), *mul2));
+  a.ntt_pow_phi();
+  A->ntt_pow_phi();
+  ret &= (a == *A);
+  CHECK(same(a.poly_obj(), *A));
+  b.invntt_pow_invphi();
+  B->invntt_pow_invphi();
+  ret &= (b == *B);
+  CHECK(same(b.poly_obj(), *B));
+  poly_p tmp_p = a + b * add_p;
+  ret &= (tmp_p == *A + *B * *add);
+  Heap<poly_t> tmp(*A + *B * *add);
+  ret &= (*tmp == a + b * add_p);
+  CHECK(same(tmp_p.poly_obj(), *tmp));
+  CHECK(ret);
+  return true;
+}
+
 int main() {
   try {
     bool ok = true;
@@ -281,6 +334,9 @@ int main() {
     ok &= run_samplers<uint64_t, 4096, 4>();
     ok &= run_samplers<uint32_t, 1024, 2>();
     ok &= run_samplers<uint16_t, 128, 1>();
+    ok &= run_poly_p<uint64_t, 4096, 4>();   // tests/poly_p.cpp
+    ok &= run_poly_p<uint32_t, 1024, 2>();
+    ok &= run_poly_p<uint16_t, 128, 1>();
     ok &= other_tu_selftest() == 0;
     std::printf(ok ? "surface: all checks passed\n" : "surface: FAILED\n");
     return ok ? 0 : 1;
