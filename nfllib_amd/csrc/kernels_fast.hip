@@ -403,14 +403,18 @@ enum AsmKind {
   kAsmPolymul = 0, kAsmPolymulNtt, kAsmFwd, kAsmInv, kAsmInvMul,   // 4096-word blocks, 256 threads
   kAsmPolymul16k, kAsmPolymulNtt16k, kAsmFwd16k, kAsmInv16k,        // 16384-word blocks, 1024 threads
   kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
+  kAsmPolymul8k, kAsmPolymulNtt8k, kAsmFwd8k, kAsmInv8k,            // 8192-word blocks, 512 threads
   kAsmCount
 };
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
+static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
 static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "nflhip_polymul_ntt4096_asm",
                                                  "nflhip_ntt_fwd4096_asm",     "nflhip_ntt_inv4096_asm",
                                                  "nflhip_ntt_inv_mul4096_asm", "nflhip_polymul16384_asm",
                                                  "nflhip_polymul_ntt16384_asm", "nflhip_ntt_fwd16384_asm",
-                                                 "nflhip_ntt_inv16384_asm",    "nflhip_polymul_pipe65536_asm"};
+                                                 "nflhip_ntt_inv16384_asm",    "nflhip_polymul_pipe65536_asm",
+                                                 "nflhip_polymul8192_asm",     "nflhip_polymul_ntt8192_asm",
+                                                 "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -451,11 +455,11 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   // one 256-thread workgroup per 4096-word block, or one 1024-thread workgroup per 16384-word block
-  const int blog = is16k(kind) ? kLogN + 2 : kLogN;
+  const int blog = is16k(kind) ? kLogN + 2 : (is8k(kind) ? kLogN + 1 : kLogN);
   if (s.logn < blog) return hipErrorNotSupported;
   const size_t gx = batch << (s.logn - blog);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
-  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, is16k(kind) ? 1024 : kThreads, 1, 1, 0, st,
+  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, is16k(kind) ? 1024 : (is8k(kind) ? 512 : kThreads), 1, 1, 0, st,
                                nullptr, extra);
 }
 
@@ -537,11 +541,14 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
 }
 
 static inline bool row16k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 2 && row16k_level() >= 1; }
+static inline bool row8k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 1 && row16k_level() >= 1; }
 
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                    int b_is_ntt, size_t batch, hipStream_t st) {
   if (row16k_shape(s))  // a 16384-word row fits one CU: the whole product is a single launch
     return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt16k : kAsmPolymul16k, s, t, c, a, b, batch, st);
+  if (row8k_shape(s))   // 8192-word rows: 512 threads, two rows per CU
+    return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt8k : kAsmPolymul8k, s, t, c, a, b, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
@@ -602,6 +609,7 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
 hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
                                    hipStream_t st) {
   if (row16k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmFwd16k, s, t, dst, src, nullptr, batch, st);
+  if (row8k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmFwd8k, s, t, dst, src, nullptr, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   return launch_inner_fwd_fast_u64(s, t, src, dst, batch * s.nm, st);
 }
@@ -609,6 +617,7 @@ hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uin
 hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
                                    hipStream_t st) {
   if (row16k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmInv16k, s, t, dst, src, nullptr, batch, st);
+  if (row8k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmInv8k, s, t, dst, src, nullptr, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   return launch_inner_inv_fast_u64(s, t, src, nullptr, dst, batch * s.nm, st);
 }

@@ -325,7 +325,8 @@ import torch
 from nfllib_amd import Engine
 from nfllib_amd.sharding import digest_words
 out = {}
-for n, m, batch in ((16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (65536, 3, 2), (65536, 2, 5), (65536, 1, 1)):
+for n, m, batch in ((8192, 2, 5), (8192, 1, 1), (16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (65536, 3, 2), (65536, 2, 5),
+                    (65536, 1, 1)):
     e = Engine(64, n, m)
     a = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 0)
     b = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 1)

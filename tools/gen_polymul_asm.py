@@ -796,7 +796,7 @@ S_K0 = {"F0": "s46", "I0": "s47"}
 SLAB_BYTES = (4096 + 256) * 8
 
 
-def configure(mode):
+def configure(mode, groups=4):
     """Select the register map: "pair" = two interleaved butterflies, 15 twiddle records resident,
     168 VGPRs (3 waves/SIMD); "ring" = one butterfly at a time, 9-slot twiddle ring, 128 VGPRs (4 waves/SIMD)."""
     g = globals()
@@ -806,7 +806,8 @@ def configure(mode):
         g.update(V_TWO=g["V_T"][1] + 1, V_TWA=g["V_T"][1] + 4, V_ZERO=g["V_T"][0] + 15)
     else:
         g.update(SINGLE_STREAM=True, V_BIDX=5, V_PHI=6, V_TWO=7, V_TWA=8, V_A=10, V_B=42, V_TW=74, V_T=[110, 110],
-                 NEXT_VGPR=128, NEXT_SGPR=96, RING_SLOTS=9, LDS_BYTES=4 * SLAB_BYTES, WG_SIZE=1024)
+                 NEXT_VGPR=128, NEXT_SGPR=96, RING_SLOTS=9, LDS_BYTES=groups * SLAB_BYTES, WG_SIZE=256 * groups,
+                 ROW_G=groups, ROW_LG=groups.bit_length() - 1)
         g.update(V_ZERO=g["V_T"][0] + 15)
 
 
@@ -840,18 +841,19 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
         em.valu("v_add_u32_e32 v%d, %s, v%d" % (reg, S_SLAB, reg))                  # inside the sub-group's slab
     em.valu("v_mov_b32_e32 v%d, 0" % (V_ZERO,))
     R("s_waitcnt lgkmcnt(0)")
-    # r = logn - 12 (>= 2); wgx = poly * 2^(r-2) + blk16; 16384-word block = ((poly*nm + cm) << (r-2)) + blk16
+    # G = ROW_G sub-groups, LG = log2 G: r = logn - 12 (>= LG); wgx = poly * 2^(r-LG) + blkG;
+    # (4096 G)-word block = ((poly*nm + cm) << (r-LG)) + blkG
     R("s_sub_u32 s88, s88, 12")
-    R("s_sub_u32 s86, s88, 2")                           # r - 2
+    R("s_sub_u32 s86, s88, %d" % ROW_LG)                 # r - LG
     R("s_lshr_b32 s42, s2, s86")                         # poly
     R("s_lshl_b32 s43, s42, s86")
     R("s_sub_u32 s87, s2, s43")                          # blk16
     R("s_mul_i32 s42, s42, s14")
     R("s_add_u32 s42, s42, s3")                          # row
     R("s_lshl_b32 s42, s42, s86")
-    R("s_add_u32 s42, s42, s87")                         # 16384-word block index
-    R("s_lshr_b32 s43, s42, 15")
-    R("s_lshl_b32 s42, s42, 17")                         # * 131072 bytes
+    R("s_add_u32 s42, s42, s87")                         # block index
+    R("s_lshr_b32 s43, s42, %d" % (32 - 15 - ROW_LG,))
+    R("s_lshl_b32 s42, s42, %d" % (15 + ROW_LG,))        # * 4096 G words * 8 bytes
     for base, row in ((6, 16), (8, 18), (4, 20)):
         R("s_add_u32 s%d, s%d, s42" % (row, base))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
@@ -860,13 +862,13 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     R("s_lshl_b32 s42, s3, s43")
     R("s_add_u32 s22, s10, s42")
     R("s_addc_u32 s23, s11, 0")
-    # outer pass constants: K_F0 = 2^(r-2) + blk16, K_I0 = 2^(r-1) - blk16
+    # outer pass constants: K_F0 = 2^(r-LG) + blkG, K_I0 = 2^(r-LG+1) - blkG
     R("s_lshl_b32 %s, 1, s86" % (S_K0["F0"],))
     R("s_add_u32 %s, %s, s87" % (S_K0["F0"], S_K0["F0"]))
     R("s_lshl_b32 %s, 2, s86" % (S_K0["I0"],))
     R("s_sub_u32 %s, %s, s87" % (S_K0["I0"], S_K0["I0"]))
-    # inner pass constants of block blk = 4*blk16 + q
-    R("s_lshl_b32 s89, s87, 2")
+    # inner pass constants of block blk = G*blkG + q
+    R("s_lshl_b32 s89, s87, %d" % ROW_LG)
     R("s_add_u32 s89, s89, %s" % (S_Q,))
     R("s_lshl_b32 s90, 1, s88")
     R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
@@ -889,12 +891,12 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     if stop == -2:
         R("s_waitcnt vmcnt(0) lgkmcnt(0)")
         R("s_endpgm")
-    def row_loads(dst, srow):                             # x[tid + 1024 k]: the layout F0 starts from
+    def row_loads(dst, srow):                             # x[tid + 256 G k]: the layout F0 starts from
         R("s_mov_b64 s[86:87], %s" % (srow,))
         for k in range(16):
             vm.load("global_load_dwordx2 %s, v%d, s[86:87]" % (vp(dst + 2 * k), V_OFF8))
             if k < 15:
-                R("s_add_u32 s86, s86, 0x2000")
+                R("s_add_u32 s86, s86, 0x%x" % (2048 * ROW_G,))
                 R("s_addc_u32 s87, s87, 0")
 
     def block_base(srow):                                 # s[86:87] = first word of this sub-group's 4096-word block
@@ -954,8 +956,9 @@ def build_row16k(kind="polymul", stop=None):
     passes = {"F0": (S_K0["F0"], None, False), "F1": (S_K["F1"], None, False), "F2": (S_K["F2"], V_BIDX, False),
               "F3": (S_K["F3"], V_TID, False), "I1": (S_K["I1"], V_TID, True), "I2": (S_K["I2"], V_BIDX, True),
               "I3": (S_K["I3"], None, True), "I0": (S_K0["I0"], None, True)}
-    order = {"F0": (0, 1), "F1": (0, 1, 2, 3), "F2": (0, 1, 2, 3), "F3": (0, 1, 2, 3), "I1": (3, 2, 1, 0),
-             "I2": (3, 2, 1, 0), "I3": (3, 2, 1, 0), "I0": (1, 0)}
+    order = {"F0": tuple(range(ROW_LG)), "F1": (0, 1, 2, 3), "F2": (0, 1, 2, 3), "F3": (0, 1, 2, 3), "I1": (3, 2, 1, 0),
+             "I2": (3, 2, 1, 0), "I3": (3, 2, 1, 0), "I0": tuple(range(ROW_LG - 1, -1, -1))}
+    per = 16 // ROW_G          # register slots per 4096-word block in the row layout x[tid + 256 G k]
     has_fwd = kind != "inv"
     has_inv = kind != "fwd"
     names = (["F0", "F1", "F2", "F3"] if has_fwd else []) + (["I1", "I2", "I3", "I0"] if has_inv else [])
@@ -1006,8 +1009,9 @@ def build_row16k(kind="polymul", stop=None):
                 R("s_barrier")       # WAR: the slabs are still being read for the previous operand
             em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
             for k in range(16):
-                qq, j = k >> 2, k & 3
-                R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
+                qq, j = k // per, k % per
+                R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k),
+                                                       (qq & 1) * SLAB_BYTES + j * 2048 * ROW_G))
             R("s_waitcnt lgkmcnt(0)")
             R("s_barrier")
             em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
@@ -1091,17 +1095,18 @@ def build_row16k(kind="polymul", stop=None):
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
     em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                              # q*32768 + t*8
     for k in range(16):
-        g_, j = k & 3, k >> 2
-        R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(V_A + 2 * k), j * 8192 + g_ * 2048))
+        g_, j = k % ROW_G, k // ROW_G
+        R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(V_A + 2 * k), j * 2048 * ROW_G + g_ * 2048))
     R("s_waitcnt lgkmcnt(0)")
     R("s_barrier")
-    em.valu("v_add_u32_e32 v%d, 0x10000, v%d" % (AX, V_OFF8))
+    rstep = 2048 * ROW_G                                 # bytes between a reader's consecutive slots
+    em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * rstep, V_OFF8))
     for k in range(16):
-        R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * 8192))
+        R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * rstep))
     R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I0", (1,))
+    inv_pass("I0", order["I0"][:-1])
     ck(9)
-    R("s_cmp_eq_u32 s88, 2")
+    R("s_cmp_eq_u32 s88, %d" % ROW_LG)
     R("s_cbranch_scc1 .Lmerged_last_stage")
     em.comment("r > 2: plain global stage r-2; lazy output for the outer inverse passes")
     tw = ring.get(("I0", 0, 0))
@@ -1116,7 +1121,7 @@ def build_row16k(kind="polymul", stop=None):
     for k in range(16):
         R("global_store_dwordx2 v%d, %s, s[86:87]" % (V_OFF8, vp(V_A + 2 * k)))
         if k < 15:
-            R("s_add_u32 s86, s86, 0x2000")
+            R("s_add_u32 s86, s86, 0x%x" % (2048 * ROW_G,))
             R("s_addc_u32 s87, s87, 0")
     R("s_endpgm")
     return em
@@ -1417,9 +1422,14 @@ def main():
     for kind, (stem, kname) in KERNELS.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind))
     emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
-    configure("ring")
+    configure("ring", 4)
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
+    configure("ring", 2)         # 8192-word rows: two sub-groups, 512 threads, one radix-2 stage around the blocks
+    for kind, (stem, kname) in KERNELS16K.items():
+        emit_file(os.path.join(outdir, stem.replace("16384", "8192") + "_gfx950.s"), kname.replace("16384", "8192"),
+                  build_row16k(kind))
+    configure("ring", 4)
     if os.environ.get("NFL_DEBUG16K"):   # checkpoint variants for bisecting a fault: kernel ends after phase n
         kind = os.environ["NFL_DEBUG16K"]
         for n in range(-3, 10):
