@@ -206,7 +206,7 @@ __device__ __forceinline__ void row1024(u32 *c, const u32 *a, const u32 *b, size
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_row1024_u32(u32 *c, const u32 *a, const u32 *b, const Tw32 *__restrict__ psi,
+__global__ __launch_bounds__(256, 5) void k_row1024_u32(u32 *c, const u32 *a, const u32 *b, const Tw32 *__restrict__ psi,
                                                      const MC32 *__restrict__ mc, int nm, size_t rows) {
   __shared__ u32 slab[4][kSlab32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
