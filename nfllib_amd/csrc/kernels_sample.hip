@@ -178,6 +178,46 @@ __global__ void k_sample_gauss(T *d, const ModConst<T> *__restrict__ mc, int log
   }
 }
 
+// the same map, eight consecutive coefficients per thread: their 8*W stream words are exactly W keystream blocks, so
+// no block is computed twice (the one-coefficient kernel above uses W of the 8 words of each block it derives)
+template <typename T, int W>
+__global__ void k_sample_gauss8(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_coef,
+                                size_t ncoef, const uint64_t *__restrict__ cdt, int entries, long long x_min, uint64_t amp,
+                                ChaChaKey key, uint64_t nonce) {
+  const uint64_t n = ((uint64_t)1) << logn;
+  const size_t ngroups = ncoef >> 3;  // first_coef and ncoef are multiples of 8 (n >= 8)
+  for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t g0 = first_coef + (grp << 3);
+    uint64_t w[8 * W];
+#pragma unroll
+    for (int b = 0; b < W; ++b) chacha20_block(key, (g0 >> 3) * W + b, nonce, w + 8 * b);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int lo = 0, hi = entries - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint64_t *e = cdt + (size_t)mid * W;
+        bool less = false, decided = false;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          const uint64_t r = w[c * W + k];
+          if (!decided && r != e[k]) {
+            less = r < e[k];
+            decided = true;
+          }
+        }
+        if (less) hi = mid; else lo = mid + 1;
+      }
+      const long long x = x_min + lo;
+      const bool neg = x < 0;
+      const uint64_t mag = (uint64_t)(neg ? -x : x);
+      const uint64_t idx = (grp << 3) + c, poly = idx >> logn, i = idx & (n - 1);
+      T *col = d + ((poly * (uint64_t)nm) << logn) + i;
+      for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+    }
+  }
+}
+
 // ---- poly(hwt_dist(h)) (core.hpp:347-391): exactly h coefficients are +-1, uniformly among the C(n,h) supports.
 // The reference draws them by reservoir sampling with rejection-sampled indices; here Floyd's algorithm (the same
 // distribution, h draws instead of n) runs one thread per polynomial over the zero-initialised row 0 as the
@@ -286,8 +326,18 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
   const ChaChaKey key = load_key(key32);
   const size_t ncoef = batch * s.n;
-  const dim3 g(grid_for(ncoef)), b(256);
   const uint64_t fc = (uint64_t)first_poly * s.n;
+  if (s.n >= 8) {  // eight coefficients per thread
+    const dim3 g(grid_for(ncoef / 8)), b(256);
+    switch (words) {
+      case 1: hipLaunchKernelGGL((k_sample_gauss8<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+      case 2: hipLaunchKernelGGL((k_sample_gauss8<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+      case 3: hipLaunchKernelGGL((k_sample_gauss8<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
+  const dim3 g(grid_for(ncoef)), b(256);
   switch (words) {
     case 1: hipLaunchKernelGGL((k_sample_gauss<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
     case 2: hipLaunchKernelGGL((k_sample_gauss<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
