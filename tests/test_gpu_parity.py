@@ -398,3 +398,32 @@ def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_fact
         assert not errors, errors
         for tid in range(4):
             assert np.array_equal(results[tid], want), (lb, n, m, tid)
+
+
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (64, 8192, 2), (64, 16384, 2), (64, 65536, 2), (32, 1024, 2), (64, 1024, 2)])
+def test_adversarial_coefficient_values(lb, n, m, oracle_factory, engine_factory):
+    """The tuned kernels lean on approximate quotients, two-bit folds and lazy ranges whose proofs are about extreme
+    words: feed polynomials built from boundary values (0, 1, p-1, p-2, 2^k, 2^k - 1, runs and alternations of them)
+    instead of uniform noise and require bit-equality with the oracle on every entry point."""
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    rng = np.random.default_rng(lb * n + m)
+    batch = 4
+    a = np.zeros((batch, m, n), dtype=o.dtype)
+    b = np.zeros_like(a)
+    for cm in range(m):
+        p = int(o.P[cm])
+        specials = [0, 1, 2, p - 1, p - 2, p // 2, p // 2 + 1, (1 << (lb - 2)) % p, ((1 << (lb - 2)) - 1) % p,
+                    (1 << (lb // 2)) % p, ((1 << (lb // 2)) - 1) % p, (1 << (lb // 2 - 1)) % p, (p - (1 << (lb // 2))) % p]
+        sp = np.array(specials, dtype=np.uint64).astype(o.dtype)
+        for x in (a, b):
+            x[0, cm, :] = p - 1                                            # all p-1
+            x[1, cm, :] = sp[rng.integers(0, len(sp), n)]                  # random mix of boundary values
+            x[2, cm, :] = np.where(np.arange(n) % 2 == 0, p - 1, 0).astype(o.dtype)
+            x[3, cm, :] = sp[(np.arange(n) // 16 + (x is b)) % len(sp)]    # runs of 16 equal boundary values
+    da, db = e.to_device(a), e.to_device(b)
+    assert np.array_equal(e.to_host(e.polymul(da, db)), o.polymul(a, b))
+    fa = e.ntt_(da.clone())
+    assert np.array_equal(e.to_host(fa), o.ntt(a))
+    assert np.array_equal(e.to_host(e.intt_(da.clone())), o.intt(a))
+    assert np.array_equal(e.to_host(e.intt_(fa.clone())), a)
+    assert np.array_equal(e.to_host(e.polymul(db, fa, b_is_ntt=True)), o.polymul(a, b))
