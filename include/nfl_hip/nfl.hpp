@@ -804,12 +804,35 @@ template <class P> class device_batch {
     for (size_t i = 0; i < count; ++i) { same_size(*operands[i]); ptr[i] = operands[i]->d_; }
     detail::check(P::ctx(), nflhip_eval_dev(P::ctx(), d_, ptr, count, program, len, n_, nullptr), "eval");
   }
+  // the random constructors over the whole resident batch (same tags as poly's; one keystream per call)
+  void set(uniform const &u) {
+    if (u.seeded) detail::check(P::ctx(), nflhip_fill_uniform_dev(P::ctx(), d_, 0, n_, u.seed, 0, nullptr), "set(uniform)");
+    else sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+  }
+  void set(non_uniform const &m) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
+  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO, m.rho, 1, "set(ZO_dist)"); }
+  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT, m.hwt, 1, "set(hwt_dist)"); }
+  template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, value_type, _lu_depth> const &m) {
+    detail::sampler &s = detail::sampler::get();
+    detail::check(P::ctx(), nflhip_sample_gauss_dev(P::ctx(), d_, 0, n_, m.fg_prng->table(P::ctx()), m.amplifier, s.key,
+                                                    s.next++, nullptr), "set(gaussian)");
+  }
+  // replicate one polynomial over the batch (a key shared by every ciphertext, ...)
+  void fill(const P &one) {
+    for (size_t k = 0; k < n_; ++k)
+      detail::check(P::ctx(), nflhip_memcpy_h2d(P::ctx(), static_cast<char *>(d_) + k * sizeof(P), one.cdata(), sizeof(P), nullptr), "fill");
+    sync();
+  }
   bool any_equal(const device_batch &o) const { return cmp(o, true); }    // the reference's `a == b`
   bool any_differs(const device_batch &o) const { return cmp(o, false); } // the reference's `a != b`
 
  private:
   void same_size(const device_batch &o) const {
     if (o.n_ != n_) throw std::runtime_error("nfl(hip): batch size mismatch");
+  }
+  void sample(int dist, uint64_t p0, uint64_t p1, const char *what) {
+    detail::sampler &s = detail::sampler::get();
+    detail::check(P::ctx(), nflhip_sample_dev(P::ctx(), d_, 0, n_, dist, p0, p1, s.key, s.next++, nullptr), what);
   }
   bool cmp(const device_batch &o, bool want_eq) const {
     same_size(o);

@@ -322,6 +322,48 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_poly_p() {
   return true;
 }
 
+// the same LWE round trip on HBM-resident batches (nfl::device_batch): B ciphertexts of 0 under one key
+template <class T, size_t Degree, size_t NbModuli> static bool run_lwe_batch() {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  using batch_t = nfl::device_batch<poly_t>;
+  const size_t B = 16;
+  nfl::FastGaussianNoise<uint8_t, T, 2> fg(3.19, 128, 1 << 10);
+  Heap<poly_t> s{nfl::gaussian<uint8_t, T, 2>(&fg)}, a{nfl::uniform()};
+  s->ntt_pow_phi();
+  batch_t S(B), A(B), U(B), E(B), Ecoef(B), RA(B), DEC(B);
+  S.fill(*s);
+  A.fill(*a);
+  U.set(nfl::gaussian<uint8_t, T, 2>(&fg));
+  E.set(nfl::gaussian<uint8_t, T, 2>(&fg, 2));
+  const unsigned char copy[] = {0};
+  const batch_t *src[] = {&E};
+  Ecoef.assign_program(copy, 1, src, 1);
+  U.ntt_pow_phi();
+  E.ntt_pow_phi();
+  // b = a*s + 2e (public key style, per ciphertext); check b - a*s == 2e after the inverse transform
+  const unsigned char enc[] = {0, 1, NFLHIP_EXPR_MUL, 2, NFLHIP_EXPR_ADD};
+  const batch_t *eo[] = {&A, &S, &E};
+  RA.assign_program(enc, sizeof(enc), eo, 3);
+  const unsigned char dec[] = {0, 1, 2, NFLHIP_EXPR_MUL, NFLHIP_EXPR_SUB};
+  const batch_t *dd[] = {&RA, &A, &S};
+  DEC.assign_program(dec, sizeof(dec), dd, 3);
+  DEC.invntt_pow_invphi();
+  CHECK(!DEC.any_differs(Ecoef));
+  // distinct ciphertexts got distinct noise
+  void *mem = nullptr;
+  if (posix_memalign(&mem, 32, 2 * sizeof(poly_t)) != 0) throw std::bad_alloc();
+  poly_t *host = new (mem) poly_t[2];
+  batch_t two(2);
+  two.set(nfl::non_uniform(1000));
+  two.download(host);
+  const bool distinct = !same(host[0], host[1]);
+  host[0].~poly_t();
+  host[1].~poly_t();
+  free(mem);
+  CHECK(distinct);
+  return true;
+}
+
 int main() {
   try {
     bool ok = true;
@@ -334,6 +376,8 @@ int main() {
     ok &= run_samplers<uint64_t, 4096, 4>();
     ok &= run_samplers<uint32_t, 1024, 2>();
     ok &= run_samplers<uint16_t, 128, 1>();
+    ok &= run_lwe_batch<uint64_t, 4096, 4>();
+    ok &= run_lwe_batch<uint32_t, 1024, 2>();
     ok &= run_poly_p<uint64_t, 4096, 4>();   // tests/poly_p.cpp
     ok &= run_poly_p<uint32_t, 1024, 2>();
     ok &= run_poly_p<uint16_t, 128, 1>();
