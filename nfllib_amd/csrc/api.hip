@@ -573,6 +573,8 @@ int nflhip_ntt_fwd_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
   hipError_t e;
   if (ctx->shape.limb_bits == 64) {
     e = launch_ntt_fwd_fast_u64(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st);
+    if (e == hipErrorNotSupported)
+      e = launch_row1024_u64(ctx->shape, ctx->tabs, 2, (uint64_t *)d, (const uint64_t *)d, nullptr, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(fast)");
   }
@@ -595,6 +597,8 @@ int nflhip_ntt_inv_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
   hipError_t e;
   if (ctx->shape.limb_bits == 64) {
     e = launch_ntt_inv_fast_u64(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st);
+    if (e == hipErrorNotSupported)
+      e = launch_row1024_u64(ctx->shape, ctx->tabs, 3, (uint64_t *)d, (const uint64_t *)d, nullptr, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(fast)");
   }
@@ -651,6 +655,9 @@ static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, i
   if (ctx->shape.limb_bits == 64) {
     hipError_t e = launch_polymul_fast_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b,
                                            b_is_ntt, batch, st);
+    if (e == hipErrorNotSupported)
+      e = launch_row1024_u64(ctx->shape, ctx->tabs, b_is_ntt ? 1 : 0, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b,
+                             batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(fast)");
   }

@@ -130,10 +130,12 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
                                       hipStream_t st);  // NFLHIP_ROW16K: 0 off, 1 rows of 16384 words only (default), 2 also as block kernel of longer rows
 
-// 32-bit limbs, n = 1024: one wave per row (kernels_u32.hip).  mode 0: c = INTT(NTT(a)(.)NTT(b)); 1: b already in
+// n = 1024, 32- and 64-bit limbs: one wave per row (kernels_wave.hip).  mode 0: c = INTT(NTT(a)(.)NTT(b)); 1: b already in
 // NTT form; 2: c = NTT(a); 3: c = INTT(a).  hipErrorNotSupported for other shapes.
 hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                               const uint32_t *b, size_t batch, hipStream_t st);
+hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
+                              const uint64_t *b, size_t batch, hipStream_t st);
 
 // register-resident CRT kernels for 64-bit limbs (kernels_crt.hip); hipErrorNotSupported otherwise
 hipError_t launch_crt_lift_fast_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,

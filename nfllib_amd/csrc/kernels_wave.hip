@@ -1,0 +1,325 @@
+// kernels_wave.hip -- register-tiled kernels for n = 1024, 32-bit limbs (30-bit moduli) and 64-bit limbs (62-bit
+// moduli): ONE WAVE PER RNS ROW.
+//
+// A row is 1024 words = 64 lanes x 16 words, so the whole transform lives in one wavefront's registers and needs no
+// workgroup barrier at all: ten stages = radix-16 (lane holds x[lane + 64k]) -> wave-local LDS exchange -> radix-16 on
+// the 16 independent 64-word blocks -> wave-local exchange -> radix-4 on runs of 16 consecutive words.  The fused
+// product keeps both operands resident (32 VGPRs) and touches HBM once per operand word; the reference's sequence
+// a.ntt_pow_phi(); b.ntt_pow_phi(); c = a*b; c.invntt_pow_invphi() (poly.hpp:167-168,350) is 7 passes over memory.
+// Arithmetic: Harvey lazy butterflies (values < 4p forward, < 2p inverse; 4p < 2^32 because p < 2^30,
+// params.hpp:54-62) with Shoup constants from the same merged psi_br table as every other kernel (kernels.h).
+// 32-bit multiplies are native here, which is why this limb size has the highest coefficient throughput.
+// The structure is a template over an arithmetic policy; the 64-bit policy reuses the fold2 / one-off-quotient
+// butterflies of the 4096-word kernels (modarith64.h), so u64 rows of 1024 words (tests/ntt_perfs.cpp's shape) get a
+// fused product too.
+#include <cstdlib>
+
+#include "kernels.h"
+#include "modarith.h"
+#include "modarith64.h"
+
+namespace nflhip {
+
+typedef Tw<u32> Tw32;
+typedef ModConst<u32> MC32;
+
+static constexpr int kLogN32 = 10;
+static constexpr int kSlab32 = 1088;  // words of LDS per wave (1024 + padding of either exchange layout)
+
+__device__ __forceinline__ u32 lazy2(u32 x, u32 p2) { return min(x, x - p2); }  // [0,4p) -> [0,2p)
+
+__device__ __forceinline__ void ct32(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2) {
+  const u32 X = lazy2(x, p2);
+  const u32 T = mul_shoup_lazy<u32>(y, w.w, w.wp, p);  // any word -> [0,2p)
+  x = X + T;
+  y = X - T + p2;
+}
+__device__ __forceinline__ void gs32(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2) {  // inputs < 2p
+  const u32 s = x + y, d = y - x + p2;
+  x = lazy2(s, p2);
+  y = mul_shoup_lazy<u32>(d, w.w, w.wp, p);
+}
+
+// ---- arithmetic policies ----------------------------------------------------------------------------------------
+struct Pol32 {
+  typedef u32 T;
+  typedef Tw32 TW;
+  typedef MC32 MC;
+  struct K {
+    u32 p, p2, mu;
+  };
+  __device__ __forceinline__ static K make(const MC &c) { return K{c.p, c.p2, c.mu}; }
+  __device__ __forceinline__ static void ct(T &x, T &y, const TW w, const K &k) { ct32(x, y, w, k.p, k.p2); }
+  __device__ __forceinline__ static void gs(T &x, T &y, const TW w, const K &k) { gs32(x, y, w, k.p, k.p2); }
+  __device__ __forceinline__ static T canon(T x, const K &k) { return reduce4<u32>(x, k.p); }  // forward output < 4p
+  __device__ __forceinline__ static T prep(T b, const K &k) { return reduce4<u32>(b, k.p); }   // operand of mul()
+  __device__ __forceinline__ static T mul(T a, T b, const K &k) {  // a lazy, b prepared or canonical -> [0,p)
+    return barrett<u32>::mul(reduce4<u32>(a, k.p), b, k.p, k.mu);
+  }
+  __device__ __forceinline__ static void last(T &u, T &x, const MC &c, const K &k) {  // stage 0 with n^-1, canonical
+    const T s = u + x, d = x - u + k.p2;
+    u = mul_shoup<u32>(s, c.ninv, c.ninv_sh, k.p);
+    x = mul_shoup<u32>(d, c.w1ninv, c.w1ninv_sh, k.p);
+  }
+};
+struct Pol64 {
+  typedef u64 T;
+  typedef Tw64 TW;
+  typedef MC64 MC;
+  struct K {
+    Mod m;
+    u64 mu2;
+  };
+  __device__ __forceinline__ static K make(const MC &c) { return K{make_mod(c), c.mu2}; }
+  __device__ __forceinline__ static void ct(T &x, T &y, const TW w, const K &k) { ct_bfly<3>(x, y, w, k.m); }
+  __device__ __forceinline__ static void gs(T &x, T &y, const TW w, const K &k) { gs_bfly<3>(x, y, w, k.m); }
+  __device__ __forceinline__ static T canon(T x, const K &k) { return nflhip::canon<3>(x, k.m); }
+  __device__ __forceinline__ static T prep(T b, const K &k) { return fold2(b, k.m); }
+  __device__ __forceinline__ static T mul(T a, T b, const K &k) { return mul_lazy(fold2(a, k.m), b, k.mu2, k.m); }  // < 2p
+  __device__ __forceinline__ static void last(T &u, T &x, const MC &c, const K &k) {
+    const T s = u + x, d = x - u + k.m.p2;
+    u = mul_shoup<u64>(s, c.ninv, c.ninv_sh, k.m.p);
+    x = mul_shoup<u64>(d, c.w1ninv, c.w1ninv_sh, k.m.p);
+  }
+};
+
+__device__ __forceinline__ int pad1(int e) { return e + ((e >> 6) << 2); }  // +4 words per 64: exchange 1
+__device__ __forceinline__ int pad2(int e) { return e + (e >> 4); }         // +1 word per 16: exchange 2
+
+// keeps the compiler from hoisting every twiddle load of a transform to its top (188 VGPRs, 2 waves per SIMD
+// without it): loads stay inside the stage that uses them
+__device__ __forceinline__ void stage_fence() { asm volatile("" ::: "memory"); }
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// forward: r[k] = x[lane + 64k] on entry (any words), r[k] = NTT word 16*lane + k on exit (lazy)
+template <class P>
+__device__ __forceinline__ void fwd1024(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw, int lane,
+                                        const typename P::K &k) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int half = 8 >> s;
+    stage_fence();
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      const typename P::TW w = tw[(1 << s) + g];
+#pragma unroll
+      for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+    }
+  }
+  const int B = lane >> 2, l2 = lane & 3;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lds[pad1(lane + 64 * q)] = r[q];
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad1(64 * B + 4 * q + l2)];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int half = 8 >> s;
+    stage_fence();
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      const typename P::TW w = tw[(16 << s) + (B << s) + g];
+#pragma unroll
+      for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+    }
+  }
+  wave_sync();  // (all reads of exchange 1 are done before its words are overwritten)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lds[pad2(64 * B + 4 * q + l2)] = r[q];
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(16 * lane + q)];
+  stage_fence();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const typename P::TW w = tw[256 + 4 * lane + g];
+    P::ct(r[4 * g], r[4 * g + 2], w, k);
+    P::ct(r[4 * g + 1], r[4 * g + 3], w, k);
+  }
+  stage_fence();
+#pragma unroll
+  for (int g = 0; g < 8; ++g) P::ct(r[2 * g], r[2 * g + 1], tw[512 + 8 * lane + g], k);
+}
+
+// inverse: r[k] = NTT word 16*lane + k (< 2p) on entry, r[k] = x[lane + 64k] canonical on exit
+template <class P>
+__device__ __forceinline__ void inv1024(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw,
+                                        const typename P::MC &c, const typename P::K &k, int lane) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) P::gs(r[2 * g], r[2 * g + 1], tw[512 + (511 - (8 * lane + g))], k);
+  stage_fence();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const typename P::TW w = tw[256 + (255 - (4 * lane + g))];
+    P::gs(r[4 * g], r[4 * g + 2], w, k);
+    P::gs(r[4 * g + 1], r[4 * g + 3], w, k);
+  }
+  const int B = lane >> 2, l2 = lane & 3;
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lds[pad2(16 * lane + q)] = r[q];
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(64 * B + 4 * q + l2)];
+#pragma unroll
+  for (int s = 3; s >= 0; --s) {
+    const int half = 8 >> s, m = 16 << s;
+    stage_fence();
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      const typename P::TW w = tw[m + (m - 1 - ((B << s) + g))];
+#pragma unroll
+      for (int h = 0; h < half; ++h) P::gs(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lds[pad1(64 * B + 4 * q + l2)] = r[q];
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad1(lane + 64 * q)];
+#pragma unroll
+  for (int s = 3; s >= 1; --s) {
+    const int half = 8 >> s, m = 1 << s;
+    stage_fence();
+#pragma unroll
+    for (int g = 0; g < (1 << s); ++g) {
+      const typename P::TW w = tw[m + (m - 1 - g)];
+#pragma unroll
+      for (int h = 0; h < half; ++h) P::gs(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 8; ++h) P::last(r[h], r[h + 8], c, k);  // last stage with n^-1 folded in; canonical outputs
+}
+
+// MODE 0: c = INTT(NTT(a) (.) NTT(b));  1: the same with b already in NTT form;  2: dst = NTT(a);  3: dst = INTT(a)
+template <class P, int MODE>
+__device__ __forceinline__ void row1024(typename P::T *c, const typename P::T *a, const typename P::T *b, size_t row,
+                                        typename P::T *lds, const typename P::TW *tw, const typename P::MC &mcr, int lane) {
+  typedef typename P::T T;
+  const typename P::K k = P::make(mcr);
+  const T *ar = a + (row << kLogN32);
+  T ra[16];
+  if (MODE == 3) {  // NTT-form input: lane holds words 16*lane .. 16*lane+15
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ra[q] = ar[16 * lane + q];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ra[j] = ar[lane + 64 * j];
+    fwd1024<P>(ra, lds, tw, lane, k);
+  }
+  if (MODE == 2) {
+    T *o = c + (row << kLogN32) + 16 * lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[q] = P::canon(ra[q], k);
+    return;
+  }
+  if (MODE == 0 || MODE == 1) {
+    const T *br = b + (row << kLogN32);
+    T rb[16];
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rb[j] = br[lane + 64 * j];
+      wave_sync();  // the slab is reused
+      fwd1024<P>(rb, lds, tw, lane, k);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rb[j] = P::prep(rb[j], k);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) rb[q] = br[16 * lane + q];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ra[j] = P::mul(ra[j], rb[j], k);
+  }
+  inv1024<P>(ra, lds, tw, mcr, k, lane);
+  T *cr = c + (row << kLogN32);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) cr[lane + 64 * j] = ra[j];
+}
+
+template <class P, int MODE>
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : 2)) void k_row1024(
+    typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::TW *__restrict__ psi,
+    const typename P::MC *__restrict__ mc, int nm, size_t rows) {
+  __shared__ typename P::T slab[4][kSlab32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;  // whole waves only: no workgroup barrier is used
+  const int cm = (int)(row % (size_t)nm);
+  row1024<P, MODE>(c, a, b, row, slab[wave], psi + ((size_t)cm << kLogN32), mc[cm], lane);
+}
+
+// Persistent variant for few moduli (NMT <= 4 tables): the twiddle tables are copied into LDS once per workgroup and
+// every wave walks over many rows, so the per-lane twiddle reads of the middle stages are LDS reads (~100 cycles)
+// instead of L2 reads (~700).
+template <class P, int MODE, int NMT>
+__global__ __launch_bounds__(256) void k_row1024_lds(typename P::T *c, const typename P::T *a, const typename P::T *b,
+                                                     const typename P::TW *__restrict__ psi,
+                                                     const typename P::MC *__restrict__ mc, int nm, size_t rows) {
+  __shared__ typename P::T slab[4][kSlab32];
+  __shared__ typename P::TW table[NMT][1 << kLogN32];
+  for (int i = threadIdx.x; i < nm << kLogN32; i += 256) table[i >> kLogN32][i & ((1 << kLogN32) - 1)] = psi[i];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t stride = (size_t)gridDim.x * 4;
+  for (size_t row = (size_t)blockIdx.x * 4 + wave; row < rows; row += stride) {
+    const int cm = (int)(row % (size_t)nm);
+    row1024<P, MODE>(c, a, b, row, slab[wave], table[cm], mc[cm], lane);
+    wave_sync();  // the slab is reused by the next row
+  }
+}
+
+template <class P>
+static hipError_t launch_row1024(const Shape &s, const DevTables &t, int mode, typename P::T *c, const typename P::T *a,
+                                 const typename P::T *b, size_t batch, hipStream_t st) {
+  const size_t rows = batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  const size_t blocks = (rows + 3) / 4;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const dim3 bl(256);
+  const typename P::TW *psi = (const typename P::TW *)t.psi;
+  const typename P::MC *mc = (const typename P::MC *)t.mc;
+  static const int use_lds = getenv("NFLHIP_U32_LDS") ? atoi(getenv("NFLHIP_U32_LDS")) : 1;
+  // measured (u32/1024/1, batch 2^19): forward 430 -> 482 M/s, inverse 498 -> 514 M/s with the LDS tables; the fused
+  // products do not gain (they are bound by VALU issue, not by twiddle latency), so they keep the plain kernel
+  if (sizeof(typename P::T) == 4 && use_lds && mode >= 2 && s.nm <= 4 && blocks >= 4096) {
+    const dim3 g(1024);  // 4 resident workgroups per CU (120 VGPRs): every wave walks rows at stride 4096
+#define NFLHIP_W_LDS(M, N) hipLaunchKernelGGL((k_row1024_lds<P, M, N>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows)
+#define NFLHIP_W_LDS_M(M)                    \
+  if (s.nm == 1) NFLHIP_W_LDS(M, 1);         \
+  else if (s.nm == 2) NFLHIP_W_LDS(M, 2);    \
+  else NFLHIP_W_LDS(M, 4)
+    if (mode == 2) { NFLHIP_W_LDS_M(2); } else { NFLHIP_W_LDS_M(3); }
+#undef NFLHIP_W_LDS_M
+#undef NFLHIP_W_LDS
+    return hipGetLastError();
+  }
+  const dim3 g((unsigned)blocks);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((k_row1024<P, 0>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+    case 1: hipLaunchKernelGGL((k_row1024<P, 1>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+    case 2: hipLaunchKernelGGL((k_row1024<P, 2>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+    default: hipLaunchKernelGGL((k_row1024<P, 3>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+  }
+  return hipGetLastError();
+}
+
+// mode as in row1024; hipErrorNotSupported for every other shape
+hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
+                              const uint32_t *b, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 32 || s.logn != kLogN32) return hipErrorNotSupported;
+  return launch_row1024<Pol32>(s, t, mode, c, a, b, batch, st);
+}
+hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
+                              const uint64_t *b, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn != kLogN32 || !s.small_delta) return hipErrorNotSupported;
+  return launch_row1024<Pol64>(s, t, mode, c, a, b, batch, st);
+}
+
+}  // namespace nflhip

@@ -79,4 +79,59 @@ __device__ __forceinline__ Mod make_mod(const MC64 &c) {
   return k;
 }
 
+// ---- one lazy butterfly each way -------------------------------------------------
+// Cooley-Tukey, x' = x + w*y, y' = x - w*y.
+//  ARITH 0: Harvey's ranges, x,y in [0,4p) -> [0,4p).
+//  ARITH 2: x,y ANY 64-bit word -> any 64-bit word: U = fold2(x) < p + 4*delta, m < 2p exactly, so
+//           U + m and U - m + 2p stay below 2^64; the x-path sum is folded into the multiply-add
+//           chain and y' = (2U + 2p) - x'.
+template <int ARITH>
+__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, const Tw64 w, const Mod &k) {
+  if (ARITH == 0) {
+    const u64 u = csub<u64>(x, k.p2);
+    const u64 m = mul_shoup_lazy<u64>(y, w.w, w.wp, k.p);
+    x = u + m;
+    y = u - m + k.p2;
+  } else if (ARITH == 2) {
+    const u64 U = fold2(x, k);
+    const u64 xn = shoup_acc(y, w, U, k);
+    y = ((U << 1) + k.p2) - xn;
+    x = xn;
+  } else {
+    //  ARITH 3: U < p + 4*delta and the product is reduced with the one-off quotient, m < 3p:
+    //           x' = U + m < 4p + 4*delta = 2^64 and y' = U + 3p - m < 2^64 still fit the word.
+    const u64 U = fold2(x, k);
+    const u64 xn = shoup_acc<true>(y, w, U, k);
+    y = ((U << 1) + k.p3) - xn;
+    x = xn;
+  }
+}
+// Gentleman-Sande with the negated mirrored twiddle: u,v in [0,2p) ->
+// u' = u + v, v' = (v - u) * w, both in [0,2p)
+//  ARITH 2: inputs < 2p; the sum is folded to < 2^62 + 3*delta (< 2p) with no compare.
+template <int ARITH>
+__device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, const Tw64 w, const Mod &k) {
+  const u64 s = ARITH >= 2 ? fold2(x + y, k) : csub<u64>(x + y, k.p2);
+  const u64 d = y - x + k.p2;
+  x = s;
+  y = ARITH == 0 ? mul_shoup_lazy<u64>(d, w.w, w.wp, k.p) : shoup_acc(d, w, 0, k);
+}
+// any 64-bit word (ARITH 1) or [0,4p) (ARITH 0) -> [0,p)
+template <int ARITH> __device__ __forceinline__ u64 canon(u64 x, const Mod &k) {
+  if (ARITH >= 2) return csub<u64>(fold2(x, k), k.p);  // < p + 4*delta, one subtract left
+  x = csub<u64>(x, k.p2);
+  return csub<u64>(x, k.p);
+}
+// x*y mod p for lazily reduced x, y (< 2^62 + 3*delta): T < 2^125, q = mulhi(T >> 61, mu2)
+// is within 3 of floor(T/p), r = T - q*p < 4p, folded to < p + 4*delta.
+__device__ __forceinline__ u64 mul_lazy(const u64 x, const u64 y, const u64 mu2, const Mod &k) {
+  const u64 lo = x * y, hi = __umul64hi(x, y);
+  const u64 th = (hi << 3) | (lo >> 61);
+  const u64 q = __umul64hi(th, mu2);
+  const u32 q0 = (u32)q, q1 = (u32)(q >> 32);
+  u64 r = (u64)q0 * k.d + lo;                                   // lo - q*p = lo + q*delta - (q << 62)
+  r += (u64)(q1 * k.d - (q0 << 30)) << 32;
+  return fold2(r, k);
+}
+
 }  // namespace nflhip
