@@ -209,6 +209,13 @@ def main():
         t_su = rate(lambda: eng.sample(c, 0, skey, stream_id=1), 5)
         t_sg = rate(lambda: eng.sample_gauss(c, gs, skey, stream_id=2), 5)
         eng.gauss_destroy(gs)
+        # the host-pointer entry point (nflhip_polymul: pageable host buffers in and out, PCIe included) -- never `value`
+        hb = min(batch, max(1, (256 << 20) // (nm * n * w)))
+        ha, hbb = eng.to_host(a[:hb]), eng.to_host(b[:hb])
+        eng.h_polymul(ha, hbb)
+        t0h = time.perf_counter()
+        eng.h_polymul(ha, hbb)
+        t_host = time.perf_counter() - t0h
         extras = {
             "ntt_fwd_per_s": round(batch / t_f, 1), "ntt_fwd_GBs": round(tr_bytes / t_f / 1e9, 1),
             "ntt_inv_per_s": round(batch / t_i, 1), "ntt_inv_GBs": round(tr_bytes / t_i / 1e9, 1),
@@ -218,6 +225,7 @@ def main():
             "crt_project_per_s": round(sub / t_p, 1), "crt_project_GBs": round(crt_bytes / t_p / 1e9, 1),
             "sample_uniform_per_s": round(batch / t_su, 1), "sample_uniform_GBs": round(batch * nm * n * w / t_su / 1e9, 1),
             "sample_gaussian_per_s": round(batch / t_sg, 1),
+            "host_pointer_polymul_per_s": round(hb / t_host, 1),
             "note": "GB/s are algorithmic bytes (SURVEY.md 8(d)) / event time; polys per second over the same batch",
         }
         del bn, limbs
