@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Determinism soak: repeat the product many times per shape and require every result to equal the first one
+(a missing wait or barrier in an exchange shows up as a rare mismatch).  python tools/soak.py [iterations]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nfllib_amd import Engine
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+bad = 0
+for lb, n, m, batch in ((64, 4096, 4, 2048), (64, 8192, 2, 1024), (64, 16384, 8, 128), (64, 65536, 6, 16), (32, 1024, 2, 8192),
+                        (64, 1024, 2, 4096), (64, 32768, 2, 64)):
+    e = Engine(lb, n, m)
+    a = e.fill_uniform(e.empty(batch), 11, 0)
+    b = e.fill_uniform(e.empty(batch), 11, 1)
+    ref = e.polymul(a, b)
+    fa = e.ntt_(a.clone())
+    torch.cuda.synchronize()
+    mism = 0
+    for it in range(iters):
+        c = e.polymul(a, b)
+        if it % 3 == 0:
+            f2 = e.ntt_(a.clone())
+            mism += int(e.any_neq(f2, fa))
+            mism += int(e.any_neq(e.intt_(f2), a))
+        mism += int(e.any_neq(c, ref))
+    print("u%d/%d/%d batch %d: %d iterations, %d mismatches" % (lb, n, m, batch, iters, mism))
+    bad += mism
+    e.close()
+sys.exit(1 if bad else 0)
