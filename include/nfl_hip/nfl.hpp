@@ -499,6 +499,8 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   /* manual serializers (poly.hpp:180-185): raw little-endian words */
   void serialize_manually(std::ostream &os) { os.write(reinterpret_cast<char *>(_data), N * sizeof(T)); }
   void deserialize_manually(std::istream &is) { is.read(reinterpret_cast<char *>(_data), N * sizeof(T)); }
+  // cereal hook, identical to the reference's (poly.hpp:186-190): works with any archive type that accepts a C array
+  template <class Archive> void serialize(Archive &archive) { archive(_data); }
 
   /* CRT (gmp.hpp:183-219) on little-endian 64-bit limb vectors */
   static size_t crt_limbs() { return nflhip_crt_limbs(ctx()); }
@@ -682,6 +684,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   void invntt_pow_invphi() { poly_obj().invntt_pow_invphi(); }
   void serialize_manually(std::ostream &os) { poly_obj().serialize_manually(os); }
   void deserialize_manually(std::istream &is) { poly_obj().deserialize_manually(is); }
+  template <class Archive> void serialize(Archive &archive) { archive(poly_obj()); }
 
   void set(value_type v, bool reduce_coeffs = true) { poly_obj().set(v, reduce_coeffs); }
   void set(uniform const &m) { poly_obj().set(m); }

@@ -319,6 +319,15 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_poly_p() {
   ret &= (*tmp == a + b * add_p);
   CHECK(same(tmp_p.poly_obj(), *tmp));
   CHECK(ret);
+  // the cereal hook (poly.hpp:186-190) with a stand-in archive that counts the words it is handed
+  struct CountingArchive {
+    size_t words = 0;
+    void operator()(T (&arr)[Degree * NbModuli]) { words += sizeof(arr) / sizeof(T); (void)arr; }
+    void operator()(poly_t &p) { p.serialize(*this); }
+  } ar;
+  tmp->serialize(ar);
+  tmp_p.serialize(ar);
+  CHECK(ar.words == 2 * Degree * NbModuli);
   return true;
 }
 
