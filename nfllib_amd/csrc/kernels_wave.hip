@@ -23,8 +23,7 @@ namespace nflhip {
 typedef Tw<u32> Tw32;
 typedef ModConst<u32> MC32;
 
-static constexpr int kLogN32 = 10;
-static constexpr int kSlab32 = 1088;  // words of LDS per wave (1024 + padding of either exchange layout)
+static constexpr int kSlabWords = 1088;  // LDS words per 1024 row words (padding of either exchange layout included)
 
 __device__ __forceinline__ u32 lazy2(u32 x, u32 p2) { return min(x, x - p2); }  // [0,4p) -> [0,2p)
 
@@ -83,8 +82,10 @@ struct Pol64 {
   }
 };
 
-__device__ __forceinline__ int pad1(int e) { return e + ((e >> 6) << 2); }  // +4 words per 64: exchange 1
-__device__ __forceinline__ int pad2(int e) { return e + (e >> 4); }         // +1 word per 16: exchange 2
+// LB = lanes per 16-block of a row: 4 -> 64 lanes (one wave) own a 1024-word row, 8 -> 128 lanes (two waves) own a
+// 2048-word row.  A row is 16 blocks of BS = 16*LB words; lane t works on block B = t / LB in the middle pass.
+template <int LB> __device__ __forceinline__ int pad1(int e) { return e + (e / (16 * LB)) * LB; }  // +LB words per block
+__device__ __forceinline__ int pad2(int e) { return e + (e >> 4); }                                 // +1 word per 16
 
 // keeps the compiler from hoisting every twiddle load of a transform to its top (188 VGPRs, 2 waves per SIMD
 // without it): loads stay inside the stage that uses them
@@ -95,11 +96,16 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// exchange 1 crosses the whole row: wave-local for one-wave rows, a workgroup barrier when two waves share a row
+template <int LB> __device__ __forceinline__ void row_sync() {
+  if (LB == 4) wave_sync(); else __syncthreads();
+}
 
-// forward: r[k] = x[lane + 64k] on entry (any words), r[k] = NTT word 16*lane + k on exit (lazy)
-template <class P>
-__device__ __forceinline__ void fwd1024(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw, int lane,
+// forward: r[q] = x[t + W q] on entry (any words), r[q] = NTT word 16 t + q on exit (lazy); W = 16 LB lanes per row
+template <class P, int LB>
+__device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw, int t,
                                         const typename P::K &k) {
+  constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : 3;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int half = 8 >> s;
@@ -111,12 +117,12 @@ __device__ __forceinline__ void fwd1024(typename P::T (&r)[16], typename P::T *l
       for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
     }
   }
-  const int B = lane >> 2, l2 = lane & 3;
+  const int B = t / LB, l = t % LB;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad1(lane + 64 * q)] = r[q];
-  wave_sync();
+  for (int q = 0; q < 16; ++q) lds[pad1<LB>(t + W * q)] = r[q];
+  row_sync<LB>();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad1(64 * B + 4 * q + l2)];
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad1<LB>(BS * B + LB * q + l)];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int half = 8 >> s;
@@ -128,44 +134,48 @@ __device__ __forceinline__ void fwd1024(typename P::T (&r)[16], typename P::T *l
       for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
     }
   }
-  wave_sync();  // (all reads of exchange 1 are done before its words are overwritten)
+  row_sync<LB>();  // (all reads of exchange 1 are done before its words are overwritten)
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad2(64 * B + 4 * q + l2)] = r[q];
-  wave_sync();
+  for (int q = 0; q < 16; ++q) lds[pad2(BS * B + LB * q + l)] = r[q];
+  wave_sync();     // exchange 2 stays inside a block = LB consecutive lanes
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(16 * lane + q)];
-  stage_fence();
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(16 * t + q)];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const typename P::TW w = tw[256 + 4 * lane + g];
-    P::ct(r[4 * g], r[4 * g + 2], w, k);
-    P::ct(r[4 * g + 1], r[4 * g + 3], w, k);
+  for (int i = 0; i < NS3; ++i) {  // last NS3 stages on the thread's 16 consecutive words
+    const int d = 1 << (NS3 - 1 - i), G = 8 / d;
+    stage_fence();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const typename P::TW w = tw[(256 << i) + G * t + g];
+#pragma unroll
+      for (int h = 0; h < d; ++h) P::ct(r[2 * d * g + h], r[2 * d * g + h + d], w, k);
+    }
   }
-  stage_fence();
-#pragma unroll
-  for (int g = 0; g < 8; ++g) P::ct(r[2 * g], r[2 * g + 1], tw[512 + 8 * lane + g], k);
 }
 
-// inverse: r[k] = NTT word 16*lane + k (< 2p) on entry, r[k] = x[lane + 64k] canonical on exit
-template <class P>
-__device__ __forceinline__ void inv1024(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw,
-                                        const typename P::MC &c, const typename P::K &k, int lane) {
+// inverse: r[q] = NTT word 16 t + q (< 2p) on entry, r[q] = x[t + W q] canonical on exit
+template <class P, int LB>
+__device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw,
+                                        const typename P::MC &c, const typename P::K &k, int t) {
+  constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : 3;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) P::gs(r[2 * g], r[2 * g + 1], tw[512 + (511 - (8 * lane + g))], k);
-  stage_fence();
+  for (int i = NS3 - 1; i >= 0; --i) {
+    const int d = 1 << (NS3 - 1 - i), G = 8 / d, m = 256 << i;
+    stage_fence();
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const typename P::TW w = tw[256 + (255 - (4 * lane + g))];
-    P::gs(r[4 * g], r[4 * g + 2], w, k);
-    P::gs(r[4 * g + 1], r[4 * g + 3], w, k);
+    for (int g = 0; g < G; ++g) {
+      const typename P::TW w = tw[m + (m - 1 - (G * t + g))];
+#pragma unroll
+      for (int h = 0; h < d; ++h) P::gs(r[2 * d * g + h], r[2 * d * g + h + d], w, k);
+    }
   }
-  const int B = lane >> 2, l2 = lane & 3;
+  const int B = t / LB, l = t % LB;
   wave_sync();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad2(16 * lane + q)] = r[q];
+  for (int q = 0; q < 16; ++q) lds[pad2(16 * t + q)] = r[q];
   wave_sync();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(64 * B + 4 * q + l2)];
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(BS * B + LB * q + l)];
 #pragma unroll
   for (int s = 3; s >= 0; --s) {
     const int half = 8 >> s, m = 16 << s;
@@ -177,12 +187,12 @@ __device__ __forceinline__ void inv1024(typename P::T (&r)[16], typename P::T *l
       for (int h = 0; h < half; ++h) P::gs(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
     }
   }
-  wave_sync();
+  row_sync<LB>();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad1(64 * B + 4 * q + l2)] = r[q];
-  wave_sync();
+  for (int q = 0; q < 16; ++q) lds[pad1<LB>(BS * B + LB * q + l)] = r[q];
+  row_sync<LB>();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad1(lane + 64 * q)];
+  for (int q = 0; q < 16; ++q) r[q] = lds[pad1<LB>(t + W * q)];
 #pragma unroll
   for (int s = 3; s >= 1; --s) {
     const int half = 8 >> s, m = 1 << s;
@@ -199,88 +209,101 @@ __device__ __forceinline__ void inv1024(typename P::T (&r)[16], typename P::T *l
 }
 
 // MODE 0: c = INTT(NTT(a) (.) NTT(b));  1: the same with b already in NTT form;  2: dst = NTT(a);  3: dst = INTT(a)
-template <class P, int MODE>
-__device__ __forceinline__ void row1024(typename P::T *c, const typename P::T *a, const typename P::T *b, size_t row,
-                                        typename P::T *lds, const typename P::TW *tw, const typename P::MC &mcr, int lane) {
+// `store` = false: a surplus row of the last workgroup (it walks through every barrier, writes nothing)
+template <class P, int MODE, int LB>
+__device__ __forceinline__ void row_body(typename P::T *c, const typename P::T *a, const typename P::T *b, size_t row,
+                                         typename P::T *lds, const typename P::TW *tw, const typename P::MC &mcr, int t,
+                                         bool store) {
   typedef typename P::T T;
+  constexpr int W = 16 * LB, LOGN = LB == 4 ? 10 : 11;
   const typename P::K k = P::make(mcr);
-  const T *ar = a + (row << kLogN32);
+  const T *ar = a + (row << LOGN);
   T ra[16];
-  if (MODE == 3) {  // NTT-form input: lane holds words 16*lane .. 16*lane+15
+  if (MODE == 3) {  // NTT-form input: thread holds words 16 t .. 16 t + 15
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ra[q] = ar[16 * lane + q];
+    for (int q = 0; q < 16; ++q) ra[q] = ar[16 * t + q];
   } else {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) ra[j] = ar[lane + 64 * j];
-    fwd1024<P>(ra, lds, tw, lane, k);
+    for (int j = 0; j < 16; ++j) ra[j] = ar[t + W * j];
+    fwd_row<P, LB>(ra, lds, tw, t, k);
   }
   if (MODE == 2) {
-    T *o = c + (row << kLogN32) + 16 * lane;
+    T *o = c + (row << LOGN) + 16 * t;
+    if (store) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) o[q] = P::canon(ra[q], k);
+      for (int q = 0; q < 16; ++q) o[q] = P::canon(ra[q], k);
+    }
     return;
   }
   if (MODE == 0 || MODE == 1) {
-    const T *br = b + (row << kLogN32);
+    const T *br = b + (row << LOGN);
     T rb[16];
     if (MODE == 0) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) rb[j] = br[lane + 64 * j];
-      wave_sync();  // the slab is reused
-      fwd1024<P>(rb, lds, tw, lane, k);
+      for (int j = 0; j < 16; ++j) rb[j] = br[t + W * j];
+      row_sync<LB>();  // the slab is reused
+      fwd_row<P, LB>(rb, lds, tw, t, k);
 #pragma unroll
       for (int j = 0; j < 16; ++j) rb[j] = P::prep(rb[j], k);
     } else {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) rb[q] = br[16 * lane + q];
+      for (int q = 0; q < 16; ++q) rb[q] = br[16 * t + q];
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) ra[j] = P::mul(ra[j], rb[j], k);
   }
-  inv1024<P>(ra, lds, tw, mcr, k, lane);
-  T *cr = c + (row << kLogN32);
+  inv_row<P, LB>(ra, lds, tw, mcr, k, t);
+  T *cr = c + (row << LOGN);
+  if (store) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) cr[lane + 64 * j] = ra[j];
+    for (int j = 0; j < 16; ++j) cr[t + W * j] = ra[j];
+  }
 }
 
-template <class P, int MODE>
-__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : 2)) void k_row1024(
+template <class P, int MODE, int LB>
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : 2)) void k_row(
     typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::TW *__restrict__ psi,
     const typename P::MC *__restrict__ mc, int nm, size_t rows) {
-  __shared__ typename P::T slab[4][kSlab32];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t row = (size_t)blockIdx.x * 4 + wave;
-  if (row >= rows) return;  // whole waves only: no workgroup barrier is used
+  constexpr int W = 16 * LB, RPB = 256 / W, LOGN = LB == 4 ? 10 : 11;  // rows per 256-thread block: 4 or 2
+  __shared__ typename P::T slab[RPB][kSlabWords * (W / 64)];
+  const int sub = threadIdx.x / W, t = threadIdx.x % W;
+  size_t row = (size_t)blockIdx.x * RPB + sub;
+  const bool live = row < rows;
+  if (!live) {
+    if (LB == 4) return;  // one-wave rows use no workgroup barrier: whole waves may leave
+    row = rows - 1;       // two-wave rows: keep walking through the barriers, store nothing
+  }
   const int cm = (int)(row % (size_t)nm);
-  row1024<P, MODE>(c, a, b, row, slab[wave], psi + ((size_t)cm << kLogN32), mc[cm], lane);
+  row_body<P, MODE, LB>(c, a, b, row, slab[sub], psi + ((size_t)cm << LOGN), mc[cm], t, live);
 }
 
-// Persistent variant for few moduli (NMT <= 4 tables): the twiddle tables are copied into LDS once per workgroup and
-// every wave walks over many rows, so the per-lane twiddle reads of the middle stages are LDS reads (~100 cycles)
-// instead of L2 reads (~700).
+// Persistent variant for one-wave rows and few moduli (NMT <= 4 tables): the twiddle tables are copied into LDS once
+// per workgroup and every wave walks over many rows, so the per-lane twiddle reads of the middle stages are LDS reads
+// (~100 cycles) instead of L2 reads (~700).
 template <class P, int MODE, int NMT>
 __global__ __launch_bounds__(256) void k_row1024_lds(typename P::T *c, const typename P::T *a, const typename P::T *b,
                                                      const typename P::TW *__restrict__ psi,
                                                      const typename P::MC *__restrict__ mc, int nm, size_t rows) {
-  __shared__ typename P::T slab[4][kSlab32];
-  __shared__ typename P::TW table[NMT][1 << kLogN32];
-  for (int i = threadIdx.x; i < nm << kLogN32; i += 256) table[i >> kLogN32][i & ((1 << kLogN32) - 1)] = psi[i];
+  __shared__ typename P::T slab[4][kSlabWords];
+  __shared__ typename P::TW table[NMT][1024];
+  for (int i = threadIdx.x; i < nm << 10; i += 256) table[i >> 10][i & 1023] = psi[i];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t stride = (size_t)gridDim.x * 4;
   for (size_t row = (size_t)blockIdx.x * 4 + wave; row < rows; row += stride) {
     const int cm = (int)(row % (size_t)nm);
-    row1024<P, MODE>(c, a, b, row, slab[wave], table[cm], mc[cm], lane);
+    row_body<P, MODE, 4>(c, a, b, row, slab[wave], table[cm], mc[cm], lane, true);
     wave_sync();  // the slab is reused by the next row
   }
 }
 
-template <class P>
-static hipError_t launch_row1024(const Shape &s, const DevTables &t, int mode, typename P::T *c, const typename P::T *a,
-                                 const typename P::T *b, size_t batch, hipStream_t st) {
+template <class P, int LB>
+static hipError_t launch_rows(const Shape &s, const DevTables &t, int mode, typename P::T *c, const typename P::T *a,
+                              const typename P::T *b, size_t batch, hipStream_t st) {
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
-  const size_t blocks = (rows + 3) / 4;
+  constexpr int RPB = 256 / (16 * LB);
+  const size_t blocks = (rows + RPB - 1) / RPB;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 bl(256);
   const typename P::TW *psi = (const typename P::TW *)t.psi;
@@ -288,7 +311,7 @@ static hipError_t launch_row1024(const Shape &s, const DevTables &t, int mode, t
   static const int use_lds = getenv("NFLHIP_U32_LDS") ? atoi(getenv("NFLHIP_U32_LDS")) : 1;
   // measured (u32/1024/1, batch 2^19): forward 430 -> 482 M/s, inverse 498 -> 514 M/s with the LDS tables; the fused
   // products do not gain (they are bound by VALU issue, not by twiddle latency), so they keep the plain kernel
-  if (sizeof(typename P::T) == 4 && use_lds && mode >= 2 && s.nm <= 4 && blocks >= 4096) {
+  if (LB == 4 && sizeof(typename P::T) == 4 && use_lds && mode >= 2 && s.nm <= 4 && blocks >= 4096) {
     const dim3 g(1024);  // 4 resident workgroups per CU (120 VGPRs): every wave walks rows at stride 4096
 #define NFLHIP_W_LDS(M, N) hipLaunchKernelGGL((k_row1024_lds<P, M, N>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows)
 #define NFLHIP_W_LDS_M(M)                    \
@@ -302,24 +325,28 @@ static hipError_t launch_row1024(const Shape &s, const DevTables &t, int mode, t
   }
   const dim3 g((unsigned)blocks);
   switch (mode) {
-    case 0: hipLaunchKernelGGL((k_row1024<P, 0>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
-    case 1: hipLaunchKernelGGL((k_row1024<P, 1>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
-    case 2: hipLaunchKernelGGL((k_row1024<P, 2>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
-    default: hipLaunchKernelGGL((k_row1024<P, 3>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+    case 0: hipLaunchKernelGGL((k_row<P, 0, LB>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+    case 1: hipLaunchKernelGGL((k_row<P, 1, LB>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+    case 2: hipLaunchKernelGGL((k_row<P, 2, LB>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
+    default: hipLaunchKernelGGL((k_row<P, 3, LB>), g, bl, 0, st, c, a, b, psi, mc, (int)s.nm, rows); break;
   }
   return hipGetLastError();
 }
 
-// mode as in row1024; hipErrorNotSupported for every other shape
+// mode as in row_body; n = 1024 (one wave per row) or 2048 (two waves per row); hipErrorNotSupported otherwise
 hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                               const uint32_t *b, size_t batch, hipStream_t st) {
-  if (s.limb_bits != 32 || s.logn != kLogN32) return hipErrorNotSupported;
-  return launch_row1024<Pol32>(s, t, mode, c, a, b, batch, st);
+  if (s.limb_bits != 32) return hipErrorNotSupported;
+  if (s.logn == 10) return launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);
+  if (s.logn == 11) return launch_rows<Pol32, 8>(s, t, mode, c, a, b, batch, st);
+  return hipErrorNotSupported;
 }
 hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
                               const uint64_t *b, size_t batch, hipStream_t st) {
-  if (s.limb_bits != 64 || s.logn != kLogN32 || !s.small_delta) return hipErrorNotSupported;
-  return launch_row1024<Pol64>(s, t, mode, c, a, b, batch, st);
+  if (s.limb_bits != 64 || !s.small_delta) return hipErrorNotSupported;
+  if (s.logn == 10) return launch_rows<Pol64, 4>(s, t, mode, c, a, b, batch, st);
+  if (s.logn == 11) return launch_rows<Pol64, 8>(s, t, mode, c, a, b, batch, st);
+  return hipErrorNotSupported;
 }
 
 }  // namespace nflhip

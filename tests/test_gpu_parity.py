@@ -27,6 +27,8 @@ SHAPES = [
     (64, 64, 3, 4),
     (64, 1024, 2, 3),     # tests/ntt_perfs.cpp shape
     (64, 2048, 1, 2),
+    (64, 2048, 3, 3),     # two-wave rows, odd row count (a surplus row in the last workgroup)
+    (32, 2048, 2, 5),
     (64, 4096, 4, 6),     # BASELINE configs[1] -- the metric shape
     (64, 8192, 2, 2),     # reference CONFIG (8192,124,uint64_t)
     (64, 16384, 8, 2),    # BASELINE configs[2]
@@ -400,7 +402,8 @@ def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_fact
             assert np.array_equal(results[tid], want), (lb, n, m, tid)
 
 
-@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (64, 8192, 2), (64, 16384, 2), (64, 65536, 2), (32, 1024, 2), (64, 1024, 2)])
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (64, 8192, 2), (64, 16384, 2), (64, 65536, 2), (32, 1024, 2), (64, 1024, 2),
+                                    (64, 2048, 1), (32, 2048, 1)])
 def test_adversarial_coefficient_values(lb, n, m, oracle_factory, engine_factory):
     """The tuned kernels lean on approximate quotients, two-bit folds and lazy ranges whose proofs are about extreme
     words: feed polynomials built from boundary values (0, 1, p-1, p-2, 2^k, 2^k - 1, runs and alternations of them)
