@@ -241,7 +241,8 @@ def main():
                    "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm"}.get(args.workload, "composed: k_ntt_fwd_outer x2, nflhip_polymul4096_asm, k_ntt_inv_outer"),
+                     "kernel": {"A": "k_row<Pol32, 0, 4>", "B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm",
+                                "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)"}[args.workload],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
     if extras is not None:
