@@ -430,3 +430,19 @@ def test_adversarial_coefficient_values(lb, n, m, oracle_factory, engine_factory
     assert np.array_equal(e.to_host(e.intt_(da.clone())), o.intt(a))
     assert np.array_equal(e.to_host(e.intt_(fa.clone())), a)
     assert np.array_equal(e.to_host(e.polymul(db, fa, b_is_ntt=True)), o.polymul(a, b))
+
+
+def test_many_moduli_beyond_the_small_delta_range(oracle_factory, engine_factory):
+    """48 of the reference's 62-bit moduli: from the 46th on, 2^62 - p no longer fits 31 bits, so the whole context
+    leaves the delta-form kernels for the Harvey-range ones; results must not change.  (CRT needs <= 32 moduli.)"""
+    lb, n, m, batch = 64, 4096, 48, 2
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    assert (1 << 62) - int(o.P[45]) >= (1 << 31)
+    a, b = _inputs(o, batch)
+    da, db = e.to_device(a), e.to_device(b)
+    assert np.array_equal(e.to_host(e.polymul(da, db)), o.polymul(a, b))
+    fa = e.ntt_(da.clone())
+    assert np.array_equal(e.to_host(fa), o.ntt(a))
+    assert np.array_equal(e.to_host(e.intt_(fa)), a)
+    from nfllib_amd import OP_MUL
+    assert np.array_equal(e.to_host(e.pointwise(OP_MUL, da, db)), o.pointwise(OP_MUL, a, b))
