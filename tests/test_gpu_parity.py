@@ -338,7 +338,10 @@ for n, m, batch in ((8192, 2, 5), (8192, 1, 1), (16384, 8, 5), (16384, 1, 1), (3
          "intt": digest_words(e.to_host(e.intt_(a.clone()))),
          "polymul_ntt": digest_words(e.to_host(e.polymul(a, fb, b_is_ntt=True)))}
     assert not e.any_neq(e.intt_(fb.clone()), b)
-    e.polymul(a, b, out=a)          # in place on an operand
+    b2 = b.clone()
+    e.polymul(a, b2, out=b2)        # in place on the second operand
+    assert not e.any_neq(b2, c)
+    e.polymul(a, b, out=a)          # in place on the first operand
     assert not e.any_neq(a, c)
     out["%d_%d" % (n, m)] = d
 print(json.dumps(out))
