@@ -143,7 +143,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     if (p < 3 || (p >> (wb - 2)) != 0 || (p >> (wb - 3)) == 0)
       return fail(nullptr, NFLHIP_ERR_INVALID, "modulus is not (word-2) bits long");
     c->h_P.push_back(p);
-    if (((((uint64_t)1) << (wb - 2)) - p) >> 31) c->shape.small_delta = 0;
+    if (((((uint64_t)1) << (wb - 2)) - p) >> 32) c->shape.small_delta = 0;
   }
   // CRT constants
   Big Q(1, 1);

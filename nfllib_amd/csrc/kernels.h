@@ -37,7 +37,7 @@ struct Shape {
   size_t n, nm;
   size_t crt_L;      // limbs of a lifted coefficient
   size_t crt_Lacc;   // limbs of the accumulator (L+1)
-  int small_delta;   // every modulus is 2^(W-2) - delta with 2*delta < 2^32 (delta-form butterflies)
+  int small_delta;   // every modulus is 2^(W-2) - delta with delta < 2^32 (delta-form butterflies)
 };
 
 // Device-resident tables of one context.

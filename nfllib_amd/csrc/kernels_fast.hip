@@ -326,8 +326,8 @@ __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, const 
 }
 
 // ---- launchers --------------------------------------------------------------------------
-// The delta-form arithmetic needs 2*delta < 2^32; every prime of the mirrored table
-// qualifies (c <= 587), Shape::small_delta records it per context.
+// The delta-form arithmetic needs delta < 2^32 (c < 2048 in params.hpp:94-97's c*2^21 - 1); every
+// prime of the mirrored table qualifies, Shape::small_delta records it per context.
 static inline bool fast_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN; }
 
 // A/B switch for tools/quick_bench.py and profiling (never needed in production):
@@ -474,7 +474,7 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
   const MC64 *mc = (const MC64 *)t.mc;
   const int nm = (int)s.nm;
   int v = variant();
-  if (!s.small_delta) v = 0;  // delta-form arithmetic needs 2*delta < 2^32
+  if (!s.small_delta) v = 0;  // delta-form arithmetic needs delta < 2^32
 #define NFLHIP_LAUNCH(A, W)                                                                                         \
   hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, A, W>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);     \
   break;

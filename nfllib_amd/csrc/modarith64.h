@@ -12,11 +12,13 @@ typedef Tw<uint64_t> Tw64;
 typedef ModConst<uint64_t> MC64;
 
 // ---- modulus in the form the butterflies want it ------------------------------------
-// The reference's 62-bit primes are p = 2^62 - delta with delta = c*2^21 - 1 < 2^31
-// (params.hpp:94-97), so q*p = (q << 62) - q*delta costs one 32x32 multiply-add.
+// The reference's 62-bit primes are p = 2^62 - delta with delta = c*2^21 - 1 (params.hpp:94-97);
+// delta fits 32 bits for c < 2048 (every prime the reference lists up to index 63 and beyond), so
+// q*p = (q << 62) - q*delta costs one 32x32 multiply-add.  Every range argument below needs only
+// delta < 2^32: fold2 lands below 2^62 + 3*delta = p + 4*delta and 4p + 4*delta = 2^64 exactly.
 struct Mod {
   u64 p, p2, p3;
-  uint32_t d, d2;  // delta, 2*delta
+  uint32_t d;  // delta
 };
 typedef uint32_t u32;
 
@@ -75,7 +77,6 @@ __device__ __forceinline__ Mod make_mod(const MC64 &c) {
   k.p2 = c.p2;
   k.p3 = c.p2 + c.p;
   k.d = (u32)c.delta;
-  k.d2 = 2u * (u32)c.delta;
   return k;
 }
 

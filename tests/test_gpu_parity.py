@@ -435,17 +435,25 @@ def test_adversarial_coefficient_values(lb, n, m, oracle_factory, engine_factory
     assert np.array_equal(e.to_host(e.polymul(db, fa, b_is_ntt=True)), o.polymul(a, b))
 
 
-def test_many_moduli_beyond_the_small_delta_range(oracle_factory, engine_factory):
-    """48 of the reference's 62-bit moduli: from the 46th on, 2^62 - p no longer fits 31 bits, so the whole context
-    leaves the delta-form kernels for the Harvey-range ones; results must not change.  (CRT needs <= 32 moduli.)"""
-    lb, n, m, batch = 64, 4096, 48, 2
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 65536])
+def test_every_mirrored_62_bit_modulus_runs_the_delta_form_kernels(n, oracle_factory, engine_factory):
+    """All 64 mirrored 62-bit moduli in one context.  From the 46th on 2^62 - p needs the full 32 bits (c >= 1024 in
+    params.hpp:94-97's c*2^21 - 1), which is the widest delta the multiply-add butterflies accept: uniform words and
+    the extreme ones (p-1 everywhere: largest products, folds and quotients) must still match the oracle bit for bit
+    on the wave, block, row-resident and pipeline kernels.  (CRT needs <= 32 moduli and is covered elsewhere.)"""
+    lb, m, batch = 64, 64, 3
     o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
-    assert (1 << 62) - int(o.P[45]) >= (1 << 31)
+    assert (1 << 62) - int(o.P[45]) >= (1 << 31) and (1 << 62) - int(o.P[63]) < (1 << 32)
     a, b = _inputs(o, batch)
+    pm1 = (np.array([int(p) for p in o.P], dtype=np.uint64) - 1).astype(o.dtype)[:, None]
+    a[0], b[0] = pm1, pm1
+    b[1] = np.where(np.arange(n) % 2 == 0, pm1, 0)
     da, db = e.to_device(a), e.to_device(b)
     assert np.array_equal(e.to_host(e.polymul(da, db)), o.polymul(a, b))
     fa = e.ntt_(da.clone())
     assert np.array_equal(e.to_host(fa), o.ntt(a))
+    assert np.array_equal(e.to_host(e.intt_(da.clone())), o.intt(a))
+    assert np.array_equal(e.to_host(e.polymul(db, fa, b_is_ntt=True)), o.polymul(a, b))
     assert np.array_equal(e.to_host(e.intt_(fa)), a)
     from nfllib_amd import OP_MUL
     assert np.array_equal(e.to_host(e.pointwise(OP_MUL, da, db)), o.pointwise(OP_MUL, a, b))
