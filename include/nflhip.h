@@ -66,8 +66,9 @@ enum {
 };
 
 int nflhip_abi_version(void);
-/* Text of the last error on this context (or, with ctx == NULL, of the last
- * failed nflhip_ctx_create on the calling thread). Never NULL. */
+/* Text of the last error any nflhip call raised ON THE CALLING THREAD (errno
+ * style, so host threads sharing one context never race on it; ctx may be NULL,
+ * e.g. after a failed nflhip_ctx_create). Never NULL. */
 const char *nflhip_last_error(const nflhip_ctx *ctx);
 int nflhip_device_count(int *count);
 

@@ -20,14 +20,14 @@ using namespace nflhip;
 
 typedef unsigned __int128 u128;
 
-static thread_local std::string g_create_error = "";
+// errno-style: one message per calling thread, so concurrent callers of one context never race on it
+static thread_local std::string g_last_error = "";
 
 struct nflhip_ctx {
   int device = 0;
   Shape shape{};
   DevTables tabs{};
   size_t word = 8;  // bytes per limb
-  mutable std::string err;
   // host-pointer path: staging buffers + private stream, serialised by a mutex
   std::mutex mu;
   hipStream_t hstream = nullptr;
@@ -51,7 +51,8 @@ struct nflhip_ctx {
 };
 
 static int fail(const nflhip_ctx *ctx, int code, const std::string &msg) {
-  if (ctx) ctx->err = msg; else g_create_error = msg;
+  (void)ctx;
+  g_last_error = msg;
   return code;
 }
 static int hipfail(const nflhip_ctx *ctx, hipError_t e, const char *where) {
@@ -405,6 +406,10 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     if (!unsupported) return NFLHIP_OK;
     // (assembly kernel unavailable: fall through to the composed plan, ordered after the helper streams)
   }
+  // an earlier asynchronous plan (issued on any stream) may still be using the scratch
+  if (ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+  if (ctx->ev_prev_valid)
+    for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
   e = launch_ntt_fwd<T>(ctx->shape, ctx->tabs, a, s0, batch, st);
   if (e != hipSuccess) return hipfail(ctx, e, "polymul: ntt(a)");
   if (!b_is_ntt) {
@@ -424,7 +429,10 @@ extern "C" {
 
 int nflhip_abi_version(void) { return NFLHIP_ABI_VERSION; }
 
-const char *nflhip_last_error(const nflhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *nflhip_last_error(const nflhip_ctx *ctx) {
+  (void)ctx;
+  return g_last_error.c_str();
+}
 
 int nflhip_device_count(int *count) {
   if (!count) return fail(nullptr, NFLHIP_ERR_INVALID, "count is NULL");
@@ -1062,8 +1070,12 @@ int nflhip_time_polymul_dev(nflhip_ctx *ctx, void *c, const void *a, const void 
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t e0, e1;
   HIPCHK(ctx, hipEventCreate(&e0));
-  HIPCHK(ctx, hipEventCreate(&e1));
-  HIPCHK(ctx, hipEventRecord(e0, st));
+  hipError_t he = hipEventCreate(&e1);
+  if (he == hipSuccess) he = hipEventRecord(e0, st);
+  if (he != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    return hipfail(ctx, he, "timing events");
+  }
   for (int i = 0; i < iters; ++i) {
     int rc = nflhip_polymul_dev(ctx, c, a, b, batch, stream);
     if (rc) {
@@ -1072,12 +1084,13 @@ int nflhip_time_polymul_dev(nflhip_ctx *ctx, void *c, const void *a, const void 
       return rc;
     }
   }
-  HIPCHK(ctx, hipEventRecord(e1, st));
-  HIPCHK(ctx, hipEventSynchronize(e1));
   float ms = 0.f;
-  HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  he = hipEventRecord(e1, st);
+  if (he == hipSuccess) he = hipEventSynchronize(e1);
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (he != hipSuccess) return hipfail(ctx, he, "timing events");
   *ms_per_pass = ms / (float)iters;
   return NFLHIP_OK;
 }

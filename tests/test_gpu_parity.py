@@ -371,10 +371,12 @@ def test_row_resident_16384_kernel_matches_block_plan():
 
 def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_factory):
     """The threading contract of include/nflhip.h: a context is immutable after creation, so host threads may call
-    the *_dev entry points concurrently on distinct streams (SURVEY.md 8(b) "Threading")."""
+    the *_dev entry points concurrently on distinct streams (SURVEY.md 8(b) "Threading").  The two largest shapes
+    run the multi-launch plans, which share the context's scratch: successive calls from different threads and
+    streams (fused plan, then the b-pre-transformed composed plan) are ordered by the library's own events."""
     import threading
     import torch
-    for lb, n, m, batch in ((64, 4096, 4, 64), (64, 16384, 2, 8), (32, 1024, 2, 64)):
+    for lb, n, m, batch in ((64, 4096, 4, 64), (64, 16384, 2, 8), (32, 1024, 2, 64), (64, 32768, 2, 8), (64, 65536, 1, 8)):
         e = engine_factory(lb, n, m)
         a = e.fill_uniform(e.empty(batch), SEED, 0)
         b = e.fill_uniform(e.empty(batch), SEED, 1)
@@ -387,13 +389,16 @@ def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_fact
                 st = torch.cuda.Stream()
                 with torch.cuda.stream(st):
                     aa, bb = a.clone(), b.clone()
-                    out = None
+                    fb = e.ntt_(b.clone(), stream=st)
+                    out = out2 = None
                     for _ in range(10):
                         out = e.polymul(aa, bb, stream=st)
+                        out2 = e.polymul(aa, fb, b_is_ntt=True, stream=st)
                         f = e.ntt_(aa.clone(), stream=st)
                         aa = e.intt_(f, stream=st)
                     st.synchronize()
                     results[tid] = e.to_host(out)
+                    assert np.array_equal(e.to_host(out2), results[tid])
             except Exception as ex:  # noqa: BLE001
                 errors.append(ex)
 
