@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel secondary rates")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--scatter-gather", action="store_true",
+                    help="N > 1 only: also time one step whose operands start on rank 0 and whose product returns there "
+                         "(grouped RCCL send/recv of contiguous shards, SURVEY.md 8(e)); reported beside `value`, never in it")
     args = ap.parse_args()
 
     import torch
@@ -179,6 +182,28 @@ def main():
         except Exception:
             traffic = None
 
+    scatter = None
+    if world > 1 and args.scatter_gather:
+        # data originating on one device: root -> shards -> polymul -> root.  Outside the timed region of `value`.
+        gdev = torch.device("cuda", dev)
+        fa = fb = fc = None
+        if rank == 0:
+            fa = eng.fill_uniform(eng.empty(batch * world), SEED, 0)
+            fb = eng.fill_uniform(eng.empty(batch * world), SEED, 1)
+            fc = eng.empty(batch * world)
+        torch.cuda.synchronize(); barrier()
+        ts = time.perf_counter()
+        sharding.scatter_batch(fa, a, dist, rank, world)
+        sharding.scatter_batch(fb, b, dist, rank, world)
+        eng.polymul(a, b, out=c)
+        sharding.gather_batch(c, fc, dist, rank, world)
+        torch.cuda.synchronize(); barrier()
+        tsg = sharding.allreduce_max(time.perf_counter() - ts, dist, device=gdev)
+        scatter = {"polymul_per_s_incl_scatter_gather": round(world * batch / tsg, 1), "seconds": round(tsg, 4),
+                   "bytes_moved": 3 * (world - 1) * batch * nm * n * (lb // 8),
+                   "note": "one step; both operands scattered from rank 0, product gathered back (grouped send/recv over xGMI)"}
+        del fa, fb, fc
+
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         # secondary rates of SURVEY.md 8(d): per-kernel transforms, point-wise ops, the
@@ -247,6 +272,8 @@ def main():
     }
     if extras is not None:
         result["extras"] = extras
+    if scatter is not None:
+        result["scatter_gather"] = scatter
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(lb, n, nm, args.cpu_budget)

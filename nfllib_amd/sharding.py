@@ -61,3 +61,61 @@ def allgather_digests(value, dist, world_size, device=None):
     outs = [torch.zeros_like(mine) for _ in range(world_size)]
     dist.all_gather(outs, mine)
     return [int(o[0].item()) | (int(o[1].item()) << 32) for o in outs]
+
+
+# ---- moving a batch that lives on ONE rank (SURVEY.md 8(e) "Collective") ----------------------
+# Steady state needs none of this (operands are generated in place on every device).  When a batch
+# originates on one device, the root sends every peer ITS contiguous shard and later receives the
+# result shards back: grouped point-to-point transfers (torch batch_isend_irecv = grouped
+# ncclSend/ncclRecv on RCCL), one message per peer, so on xGMI every peer's shard travels over that
+# peer's own direct link and nothing is reduced.  Tensors are moved as raw bytes (any limb width).
+def _as_bytes(t):
+    import torch
+    return t.contiguous().view(torch.uint8).reshape(-1)
+
+
+def scatter_batch(full, shard, dist, rank, world, root=0):
+    """Root holds `full` ([global_batch, nm, n]); every rank (root included) ends with its
+    shard_range() slice of it in `shard` ([hi - lo, nm, n], preallocated, contiguous).  Returns `shard`."""
+    if not shard.is_contiguous():
+        raise ValueError("shard buffer must be contiguous")
+    if rank == root:
+        gb = full.shape[0]
+        ops, keep = [], []
+        for r in range(world):
+            lo, hi = shard_range(gb, world, r)
+            if r == root:
+                shard.copy_(full[lo:hi])
+            elif hi > lo:
+                buf = _as_bytes(full[lo:hi])
+                keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, r))
+    else:
+        ops = [dist.P2POp(dist.irecv, _as_bytes(shard), root)] if shard.numel() else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return shard
+
+
+def gather_batch(shard, full, dist, rank, world, root=0):
+    """Inverse of scatter_batch: the root's `full` (contiguous) receives every rank's shard at its slice."""
+    if rank == root:
+        if not full.is_contiguous():
+            raise ValueError("destination batch must be contiguous")
+        gb = full.shape[0]
+        ops = []
+        for r in range(world):
+            lo, hi = shard_range(gb, world, r)
+            if r == root:
+                full[lo:hi].copy_(shard)
+            elif hi > lo:
+                buf = _as_bytes(full[lo:hi])   # a contiguous slice: the view aliases `full`
+                assert buf.data_ptr() == full[lo:hi].data_ptr()
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+    else:
+        ops = [dist.P2POp(dist.isend, _as_bytes(shard), root)] if shard.numel() else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return full if rank == root else None

@@ -72,6 +72,55 @@ def test_two_rank_batch_split_matches_single_process():
     assert all(r[4] == 2.0 for r in res), "timing reduction must be the max over ranks"
 
 
+def _worker_sg(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from nfllib_amd import sharding
+    from nfllib_amd.params import params
+    from oracle import oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lb, n, m = SHAPE
+    o = O.Oracle(lb, n, m, params(lb))
+    lo, hi = sharding.shard_range(GLOBAL_BATCH, world, rank)
+    fa = fb = fc = None
+    if rank == 0:  # the whole batch originates on the root only
+        fa = torch.from_numpy(o.fill_uniform(GLOBAL_BATCH, SEED, 0).view(np.int64))
+        fb = torch.from_numpy(o.fill_uniform(GLOBAL_BATCH, SEED, 1).view(np.int64))
+        fc = torch.zeros_like(fa)
+    sa = sharding.scatter_batch(fa, torch.empty((hi - lo, m, n), dtype=torch.int64), dist, rank, world)
+    sb = sharding.scatter_batch(fb, torch.empty((hi - lo, m, n), dtype=torch.int64), dist, rank, world)
+    c = o.polymul(sa.numpy().view(np.uint64), sb.numpy().view(np.uint64))
+    sharding.gather_batch(torch.from_numpy(c.view(np.int64)), fc, dist, rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, sharding.digest_words(fc.numpy().view(np.uint64)) if rank == 0 else None))
+
+
+def test_scatter_from_root_and_gather_back():
+    """SURVEY.md 8(e) "when data originates on one device": root scatters contiguous shards with grouped
+    point-to-point sends, every rank multiplies its shard, root gathers the products."""
+    sys.path.insert(0, ROOT)
+    from nfllib_amd import sharding
+    from nfllib_amd.params import params
+    from oracle import oracle as O
+    lb, n, m = SHAPE
+    o = O.Oracle(lb, n, m, params(lb))
+    want = sharding.digest_words(o.polymul(o.fill_uniform(GLOBAL_BATCH, SEED, 0), o.fill_uniform(GLOBAL_BATCH, SEED, 1)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sg, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == want
+
+
 def test_shard_range_properties():
     from nfllib_amd.sharding import shard_range
     for B in (0, 1, 7, 8, 1 << 20):
