@@ -79,7 +79,11 @@ int nflhip_device_count(int *count);
  * invkmax point at nmoduli words of that width taken from params<T>
  * (params.hpp:21-36, 55-76, 97-113); kmax_log2 = log2(params<T>::kMaxPolyDegree).
  * The context is immutable after creation: entry points may be called from
- * several host threads with distinct streams.  One context per device. */
+ * several host threads with distinct streams.  One context per device.
+ * The *_dev entry points only enqueue work on the caller's stream (no host
+ * synchronisation, no allocation after the first call of a given size), so a
+ * sequence of them can be captured into a hipGraph and replayed; the exceptions
+ * are nflhip_any_eq_dev / nflhip_any_neq_dev, which return a host value. */
 int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree, size_t nmoduli,
                       const void *P, const void *primitive_roots, const void *invkmax, int kmax_log2);
 int nflhip_ctx_destroy(nflhip_ctx *ctx);

@@ -321,6 +321,19 @@ static int pipe64k_chunks() {
   return v;
 }
 
+// hipGraph capture: the entry points only enqueue work on the caller's stream, so they can be captured.  The
+// multi-launch plans additionally order successive calls on the shared scratch with events recorded OUTSIDE any
+// capture; inside a capture those waits are illegal (and meaningless: a graph orders its own nodes), so they are
+// skipped -- a graph that replays a multi-launch plan must not run concurrently with other work on the same context.
+static bool is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return cs == hipStreamCaptureStatusActive;
+}
+
 // composed path: NTT(a)->c, NTT(b)->scratch, inverse with the product fused into its load
 template <typename T>
 static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b_is_ntt, size_t batch, hipStream_t st) {
@@ -335,6 +348,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
+  const bool cap = is_capturing(st);
   if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 16 && pipe64k_chunks() > 0) {
     // n = 65536: the streaming passes (HBM-bound) and the fused block kernel (VALU-bound) of neighbouring chunks share
     // every CU inside ONE kernel whose workgroups take three roles; consecutive launches on the caller's stream form the
@@ -344,7 +358,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     if (nchunk * 2 > batch) nchunk = batch >= 2 ? batch / 2 : 1;
     auto lo_of = [&](size_t ch) { return batch * ch / nchunk; };
     bool supported = true;
-    if (ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));  // a previous call on another stream
+    if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));  // a previous call on another stream
     for (size_t L = 0; L < nchunk + 2 && supported; ++L) {
       const bool hf = L < nchunk, hv = L >= 1 && L - 1 < nchunk, hi = L >= 2 && L - 2 < nchunk;
       const size_t f0 = hf ? lo_of(L) : 0, v0 = hv ? lo_of(L - 1) : 0, i0 = hi ? lo_of(L - 2) : 0;
@@ -356,10 +370,11 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: pipeline kernel");
     }
     if (supported) {
-      // the scratch is reused by the next call on any stream: order it after this one
-      HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
-      ctx->ev_scratch_valid = true;
-      for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_scratch, 0));
+      if (!cap) {  // the scratch is reused by the next call on any stream: order it after this one
+        HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
+        ctx->ev_scratch_valid = true;
+        for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_scratch, 0));
+      }
       return NFLHIP_OK;
     }
   }
@@ -373,7 +388,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     HIPCHK(ctx, hipEventRecord(ctx->ev_start, st));
     for (int k = 0; k < 2; ++k) {
       HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_start, 0));
-      if (ctx->ev_prev_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_done[1 - k], 0));  // previous call's scratch use
+      if (!cap && ctx->ev_prev_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_done[1 - k], 0));  // previous call's scratch use
     }
     bool unsupported = false;
     int logi = (ctx->shape.logn > 14 && row16k_level() >= 2) ? 14 : 12;  // words (log2) per block of the fused kernel
@@ -402,13 +417,13 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       HIPCHK(ctx, hipEventRecord(ctx->ev_done[k], ctx->aux[k]));
       HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
     }
-    ctx->ev_prev_valid = true;
+    if (!cap) ctx->ev_prev_valid = true;  // (inside a capture the helper streams forked from and joined back into st)
     if (!unsupported) return NFLHIP_OK;
     // (assembly kernel unavailable: fall through to the composed plan, ordered after the helper streams)
   }
   // an earlier asynchronous plan (issued on any stream) may still be using the scratch
-  if (ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
-  if (ctx->ev_prev_valid)
+  if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+  if (!cap && ctx->ev_prev_valid)
     for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
   e = launch_ntt_fwd<T>(ctx->shape, ctx->tabs, a, s0, batch, st);
   if (e != hipSuccess) return hipfail(ctx, e, "polymul: ntt(a)");
@@ -420,8 +435,10 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   e = launch_ntt_inv<T>(ctx->shape, ctx->tabs, s0, bn, c, batch, st);
   if (e != hipSuccess) return hipfail(ctx, e, "polymul: intt");
   // the scratch is reused by the next call on any stream: make that safe
-  e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return hipfail(ctx, e, "polymul: sync");
+  if (!cap) {
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hipfail(ctx, e, "polymul: sync");
+  }
   return NFLHIP_OK;
 }
 
