@@ -462,3 +462,20 @@ def test_every_mirrored_62_bit_modulus_runs_the_delta_form_kernels(n, oracle_fac
     assert np.array_equal(e.to_host(e.intt_(fa)), a)
     from nfllib_amd import OP_MUL
     assert np.array_equal(e.to_host(e.pointwise(OP_MUL, da, db)), o.pointwise(OP_MUL, a, b))
+
+
+def test_host_pointer_calls_of_many_sizes_match_the_resident_path(engine_factory):
+    """The host-pointer entry points stage pageable caller memory through context-owned device buffers that grow on
+    demand: calls from 32 bytes to 50 MiB per operand, growing and shrinking, must equal the resident path."""
+    lb, n, m = 64, 4096, 4   # 128 KiB per polynomial
+    e = engine_factory(lb, n, m)
+    for batch in (1, 32, 33, 400, 131):
+        a = e.fill_uniform(e.empty(batch), SEED + batch, 0)
+        b = e.fill_uniform(e.empty(batch), SEED + batch, 1)
+        ha, hb = e.to_host(a), e.to_host(b)
+        assert np.array_equal(e.h_polymul(ha, hb), e.to_host(e.polymul(a, b))), batch
+        assert np.array_equal(e.h_ntt(ha), e.to_host(e.ntt_(a.clone()))), batch
+        assert e.h_any_neq(ha, hb) and not e.h_any_neq(ha, ha.copy())
+    e2 = engine_factory(16, 16, 1)  # 32-byte polynomials
+    a = e2.fill_uniform(e2.empty(3), SEED, 0)
+    assert np.array_equal(e2.h_intt(e2.h_ntt(e2.to_host(a))), e2.to_host(a))
