@@ -270,6 +270,17 @@ def main():
                                 "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)"}[args.workload],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
+    # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  Instructions per wave are
+    # the SQ_INSTS_VALU / SQ_WAVES of the committed counter passes (= the generator's static count for the assembly kernel);
+    # peak = one wave64 instruction per 4 cycles per SIMD, the rate of v_mad_u64_u32 / carry / multiply opcodes on gfx950.
+    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2593, nm, "profiles/r01_final_pmc_sq_A.txt")}.get(args.workload)
+    if valu:
+        inst_per_poly = valu[0] * valu[1]
+        peak_gi = 256 * 4 * 2.4 / 4.0   # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles, in G wave-instructions/s
+        ach_gi = inst_per_poly * batch / (kernel_ms * 1e-3) / 1e9
+        result["roofline"]["secondary"] = {"bound": "valu-issue", "achieved": round(ach_gi, 1), "peak": round(peak_gi, 1),
+                                           "unit": "G wave64-inst/s", "frac": round(ach_gi / peak_gi, 4),
+                                           "wave_instructions_per_polymul": inst_per_poly, "source": valu[2]}
     if extras is not None:
         result["extras"] = extras
     if scatter is not None:

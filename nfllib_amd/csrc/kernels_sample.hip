@@ -135,41 +135,64 @@ __global__ void k_sample_small(T *d, const ModConst<T> *__restrict__ mc, int log
 }
 
 // ---- poly(gaussian(&fg, amp)) (core.hpp:284-322; FastGaussianNoise.hpp): inversion sampling from a cumulative table
-// of W 64-bit words per entry (most significant first), entry k = floor(2^(64W) * P(X <= x_min + k)); the uniform
-// W-word number r comes from stream words W*(poly*n+i) .. +W-1 (most significant first); x = x_min + #{k : cdt[k] <= r}.
+// of W 64-bit words per entry (most significant first), entry k = floor(2^(64W) * P(X <= x_min + k)):
+// x = x_min + #{k : cdt[k] <= r} for a uniform W-word number r.
+// LAZY PRECISION: the most significant word of r is stream word g (g = global coefficient index poly*n + i); the lower
+// W-1 words only matter when that word EQUALS the top word of a table entry met by the search (probability
+// entries * 2^-64 per sample), and are then read from the secondary stream -- same key and nonce, block counters from
+// 2^63 up: word (W-1)*g + k - 1 of it is word k of r.  The value is exactly the full-precision inversion of
+// r = (word g, secondary words), at one keystream word per sample instead of W.
+// `tie_shift` (0 in production; NFLHIP_GAUSS_TIE_SHIFT for the tests) only widens what counts as a tie -- the first
+// words are compared after dropping their low tie_shift bits -- so that the tie path, whose result is the same
+// full-precision comparison, runs often enough to be tested.
+static constexpr uint64_t kSecondaryCounter = ((uint64_t)1) << 63;
+
+template <int W>
+__device__ __noinline__ bool gauss_tie_less(const uint64_t r0, const uint64_t *e, uint64_t g, const ChaChaKey &key,
+                                            uint64_t nonce) {
+  if (r0 != e[0]) return r0 < e[0];
+  uint64_t blk[8], have = ~(uint64_t)0;
+  for (int k = 1; k < W; ++k) {
+    const uint64_t wi = (uint64_t)(W - 1) * g + (uint64_t)(k - 1);
+    if ((wi >> 3) != have) {
+      have = wi >> 3;
+      chacha20_block(key, kSecondaryCounter | have, nonce, blk);
+    }
+    const uint64_t rk = blk[wi & 7];
+    if (rk != e[k]) return rk < e[k];
+  }
+  return false;  // r == entry: not below it
+}
+
+// smallest k in [0, entries-1] with r < cdt[k] (cdt[entries-1] = all ones)
+template <int W>
+__device__ __forceinline__ int gauss_search(const uint64_t r0, uint64_t g, const uint64_t *__restrict__ cdt, int entries,
+                                            int tie_shift, const ChaChaKey &key, uint64_t nonce) {
+  int lo = 0, hi = entries - 1;
+  const uint64_t rs = r0 >> tie_shift;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const uint64_t *e = cdt + (size_t)mid * W;
+    const uint64_t es = e[0] >> tie_shift;
+    bool less = rs < es;
+    if (W > 1 || tie_shift) {
+      if (rs == es) less = gauss_tie_less<W>(r0, e, g, key, nonce);
+    }
+    if (less) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
 template <typename T, int W>
 __global__ void k_sample_gauss(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_coef,
                                size_t ncoef, const uint64_t *__restrict__ cdt, int entries, long long x_min, uint64_t amp,
-                               ChaChaKey key, uint64_t nonce) {
+                               ChaChaKey key, uint64_t nonce, int tie_shift) {
   const uint64_t n = ((uint64_t)1) << logn;
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t g = first_coef + idx;
-    uint64_t r[W], blk[8];
-    uint64_t have = ~(uint64_t)0;
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-      const uint64_t wi = g * W + k;
-      if ((wi >> 3) != have) {
-        have = wi >> 3;
-        chacha20_block(key, have, nonce, blk);
-      }
-      r[k] = blk[wi & 7];
-    }
-    int lo = 0, hi = entries - 1;  // smallest k in [0, entries-1] with r < cdt[k]  (cdt[entries-1] = all ones)
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      const uint64_t *e = cdt + (size_t)mid * W;
-      bool less = false, decided = false;  // r < e ?
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        if (!decided && r[k] != e[k]) {
-          less = r[k] < e[k];
-          decided = true;
-        }
-      }
-      if (less) hi = mid; else lo = mid + 1;
-    }
-    const long long x = x_min + lo;
+    uint64_t blk[8];
+    chacha20_block(key, g >> 3, nonce, blk);
+    const long long x = x_min + gauss_search<W>(blk[g & 7], g, cdt, entries, tie_shift, key, nonce);
     const bool neg = x < 0;
     const uint64_t mag = (uint64_t)(neg ? -x : x);
     const uint64_t poly = idx >> logn, i = idx & (n - 1);
@@ -178,43 +201,48 @@ __global__ void k_sample_gauss(T *d, const ModConst<T> *__restrict__ mc, int log
   }
 }
 
-// the same map, eight consecutive coefficients per thread: their 8*W stream words are exactly W keystream blocks, so
-// no block is computed twice (the one-coefficient kernel above uses W of the 8 words of each block it derives)
+// the same map for n >= 8, one keystream block (eight consecutive coefficients) per thread; a wave's 512 results go
+// through a wave-local LDS transpose so that every store instruction writes 64 consecutive words of a row
 template <typename T, int W>
-__global__ void k_sample_gauss8(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_coef,
-                                size_t ncoef, const uint64_t *__restrict__ cdt, int entries, long long x_min, uint64_t amp,
-                                ChaChaKey key, uint64_t nonce) {
+__global__ void __launch_bounds__(256) k_sample_gauss8(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm,
+                                                       uint64_t first_coef, size_t ncoef,
+                                                       const uint64_t *__restrict__ cdt, int entries, long long x_min,
+                                                       uint64_t amp, ChaChaKey key, uint64_t nonce, int tie_shift) {
+  constexpr int S = 72;  // row stride of the transpose: 2-way bank conflicts at most in both directions
+  __shared__ int xs[4][8 * S];
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 3;  // first_coef and ncoef are multiples of 8 (n >= 8)
-  for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += (size_t)gridDim.x * blockDim.x) {
-    const uint64_t g0 = first_coef + (grp << 3);
-    uint64_t w[8 * W];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t nwt = (ngroups + 63) >> 6;  // wave tiles of 64 groups = 512 coefficients
+  for (size_t tile = (size_t)blockIdx.x * 4 + wv; tile < nwt; tile += (size_t)gridDim.x * 4) {
+    const size_t grp = (tile << 6) + lane;
+    if (grp < ngroups) {
+      const uint64_t g0 = first_coef + (grp << 3);
+      uint64_t w[8];
+      chacha20_block(key, g0 >> 3, nonce, w);
 #pragma unroll
-    for (int b = 0; b < W; ++b) chacha20_block(key, (g0 >> 3) * W + b, nonce, w + 8 * b);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      int lo = 0, hi = entries - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const uint64_t *e = cdt + (size_t)mid * W;
-        bool less = false, decided = false;
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-          const uint64_t r = w[c * W + k];
-          if (!decided && r != e[k]) {
-            less = r < e[k];
-            decided = true;
-          }
-        }
-        if (less) hi = mid; else lo = mid + 1;
-      }
-      const long long x = x_min + lo;
-      const bool neg = x < 0;
-      const uint64_t mag = (uint64_t)(neg ? -x : x);
-      const uint64_t idx = (grp << 3) + c, poly = idx >> logn, i = idx & (n - 1);
-      T *col = d + ((poly * (uint64_t)nm) << logn) + i;
-      for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+      for (int c = 0; c < 8; ++c)
+        xs[wv][c * S + lane] = gauss_search<W>(w[c], g0 + c, cdt, entries, tie_shift, key, nonce);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int t = k * 64 + lane;               // coefficient of the tile: produced by lane t >> 3 as its result t & 7
+      const size_t idx = (tile << 9) + (size_t)t;
+      if (idx < ncoef) {
+        const long long x = x_min + xs[wv][(t & 7) * S + (t >> 3)];
+        const bool neg = x < 0;
+        const uint64_t mag = (uint64_t)(neg ? -x : x);
+        const uint64_t poly = idx >> logn, i = idx & (n - 1);
+        T *col = d + ((poly * (uint64_t)nm) << logn) + i;
+        for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -327,21 +355,26 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
   const ChaChaKey key = load_key(key32);
   const size_t ncoef = batch * s.n;
   const uint64_t fc = (uint64_t)first_poly * s.n;
+  static const int tie_shift = [] {
+    const char *e = getenv("NFLHIP_GAUSS_TIE_SHIFT");  // test hook, see gauss_search
+    const int v = e ? atoi(e) : 0;
+    return v < 0 ? 0 : (v > 63 ? 63 : v);
+  }();
   if (s.n >= 8) {  // eight coefficients per thread
     const dim3 g(grid_for(ncoef / 8)), b(256);
     switch (words) {
-      case 1: hipLaunchKernelGGL((k_sample_gauss8<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
-      case 2: hipLaunchKernelGGL((k_sample_gauss8<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
-      case 3: hipLaunchKernelGGL((k_sample_gauss8<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+      case 1: hipLaunchKernelGGL((k_sample_gauss8<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+      case 2: hipLaunchKernelGGL((k_sample_gauss8<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+      case 3: hipLaunchKernelGGL((k_sample_gauss8<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
   }
   const dim3 g(grid_for(ncoef)), b(256);
   switch (words) {
-    case 1: hipLaunchKernelGGL((k_sample_gauss<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
-    case 2: hipLaunchKernelGGL((k_sample_gauss<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
-    case 3: hipLaunchKernelGGL((k_sample_gauss<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id); break;
+    case 1: hipLaunchKernelGGL((k_sample_gauss<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+    case 2: hipLaunchKernelGGL((k_sample_gauss<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+    case 3: hipLaunchKernelGGL((k_sample_gauss<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -73,12 +73,16 @@ def centered(data, P):
 
 
 # ---- the device's keystream: ChaCha20 (djb layout: 64-bit counter, 64-bit nonce), kernels_sample.hip -------------
-def chacha20_words(key32, stream_id, first_word, nwords):
-    """64-bit little-endian words [first_word, first_word + nwords) of the keystream (key32, nonce = stream_id)."""
+SECONDARY_COUNTER = 1 << 63   # first block counter of the secondary stream (kernels_sample.hip, lazy-precision Gaussian)
+
+
+def chacha20_words(key32, stream_id, first_word, nwords, counter_base=0):
+    """64-bit little-endian words [first_word, first_word + nwords) of the keystream (key32, nonce = stream_id);
+    counter_base is added to every block counter (the secondary stream starts at block 2^63)."""
     key = np.frombuffer(bytes(key32), dtype="<u4").astype(np.uint32)
     assert key.size == 8
     fb, lb = first_word // 8, (first_word + nwords + 7) // 8
-    ctr = np.arange(fb, lb, dtype=np.uint64)
+    ctr = np.arange(fb, lb, dtype=np.uint64) + np.uint64(counter_base)
     nb = ctr.size
     s = np.empty((16, nb), dtype=np.uint32)
     s[0], s[1], s[2], s[3] = 0x61707865, 0x3320646E, 0x79622D32, 0x6B206574
@@ -115,6 +119,18 @@ def gaussian_pmf(sigma, center, x_min, entries):
     x = np.arange(x_min, x_min + entries, dtype=np.float64)
     rho = np.exp(-((x - center) ** 2) / (2.0 * sigma * sigma))
     return rho / rho.sum()
+
+
+def gaussian_words(key32, stream_id, first_coef, ncoef, W):
+    """The W-word uniform number of every coefficient g in [first_coef, first_coef + ncoef), most significant word first,
+    as the device defines it: word 0 = primary stream word g; word k >= 1 = secondary stream word (W-1)*g + k-1 (the
+    device only ever reads those when word 0 ties with a table entry)."""
+    r = np.empty((ncoef, W), dtype=np.uint64)
+    r[:, 0] = chacha20_words(key32, stream_id, first_coef, ncoef)
+    if W > 1:
+        r[:, 1:] = chacha20_words(key32, stream_id, (W - 1) * first_coef, (W - 1) * ncoef,
+                                  counter_base=SECONDARY_COUNTER).reshape(ncoef, W - 1)
+    return r
 
 
 def gaussian_from_table(r_words, table, x_min):

@@ -133,7 +133,7 @@ def test_gaussian(sigma, engine_factory):
     assert np.array_equal(c[:, 0], c[:, 1]), "one integer per coefficient, replicated over the moduli"
     v = c[:, 0]
     # exact: inversion of the very keystream words through the table
-    r = S.chacha20_words(KEY, 9, 0, 3 * 4 * 1024).reshape(4 * 1024, 3)
+    r = S.gaussian_words(KEY, 9, 0, 4 * 1024, 3)
     assert np.array_equal(S.gaussian_from_table(r, tab, info["x_min"]), v[:4].reshape(-1))
     # statistics: moments, tail, and a two-sample test against the real reference's samples
     flatv = v.reshape(-1)
@@ -157,3 +157,42 @@ def test_gaussian(sigma, engine_factory):
     v2 = S.centered(e.to_host(e.sample_gauss(e.empty(100), g2, KEY, stream_id=4)), P)[:, 0].reshape(-1)
     assert abs(v2.mean() - 2.5) < 5 * sigma / np.sqrt(v2.size) and i2["words"] == 2
     e.gauss_destroy(g2)
+
+
+_TIE_CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from nfllib_amd import Engine
+from oracle import samplers as S
+KEY = bytes(range(32))
+for lb, n, m, batch, sigma, sec, first in ((64, 1024, 2, 3, 3.2, 128, 0), (64, 64, 1, 13, 20.0, 128, 5), (32, 256, 1, 5, 3.2, 64, 2),
+                                          (64, 4, 1, 9, 3.2, 128, 3), (16, 128, 1, 7, 2.0, 20, 0), (64, 4096, 1, 2, 215.0, 100, 1)):
+    e = Engine(lb, n, m)
+    P = [int(e.table(1, cm)[0]) for cm in range(m)]
+    g = e.gauss_create(sigma, security=sec, samples=1024)
+    info = e.gauss_info(g)
+    d = e.to_host(e.sample_gauss(e.empty(batch), g, KEY, stream_id=21, first_poly=first))
+    v = S.centered(d, P)[:, 0].reshape(-1)
+    r = S.gaussian_words(KEY, 21, first * n, batch * n, info["words"])
+    want = S.gaussian_from_table(r, info["table"], info["x_min"])
+    assert np.array_equal(v, want), (lb, n, m, sigma, sec, int((v != want).sum()))
+    e.gauss_destroy(g)
+print("TIE_OK")
+"""
+
+
+@pytest.mark.parametrize("tie_shift", ["0", "56", "63"])
+def test_gaussian_lazy_precision_equals_full_precision_inversion(tie_shift):
+    """One keystream word per sample; the lower words of the W-word uniform number come from the secondary stream only
+    when the first word ties with a table entry (2^-64 per entry in production).  NFLHIP_GAUSS_TIE_SHIFT widens what
+    counts as a tie (56: equal top bytes; 63: equal top bits, i.e. nearly every comparison) without changing the value,
+    so the tie path is exercised: every shape must still equal the oracle's full-precision inversion of the same words
+    (1-, 2- and 3-word tables, the 8-per-thread kernel with ragged wave tiles and the per-coefficient one, shards)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFLHIP_GAUSS_TIE_SHIFT=tie_shift)
+    out = subprocess.run([sys.executable, "-c", _TIE_CHILD % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "TIE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -60,6 +60,12 @@ def test_chacha20_known_answer():
     long = S.chacha20_words(key, 7, 0, 100)
     assert np.array_equal(S.chacha20_words(key, 7, 13, 50), long[13:63])
     assert not np.array_equal(S.chacha20_words(key, 8, 0, 100), long)
+    # the secondary stream (block counters from 2^63) and the W-word numbers of the lazy-precision Gaussian
+    sec = S.chacha20_words(key, 7, 0, 100, counter_base=S.SECONDARY_COUNTER)
+    assert not np.array_equal(sec, long) and np.array_equal(S.chacha20_words(key, 7, 16, 8, counter_base=S.SECONDARY_COUNTER), sec[16:24])
+    r = S.gaussian_words(key, 7, 5, 20, 3)
+    assert np.array_equal(r[:, 0], long[5:25]) and np.array_equal(r[:, 1:].reshape(-1), sec[10:50])
+    assert np.array_equal(S.gaussian_words(key, 7, 5, 20, 1)[:, 0], long[5:25])
 
 
 def test_distribution_fixtures_are_sane():
