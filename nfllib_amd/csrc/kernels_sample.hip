@@ -60,9 +60,38 @@ __global__ void k_random_words(uint64_t *out, uint64_t first_word, size_t nwords
 }
 
 // v * amp mod p for a small signed value (|v| below the modulus in every sensible use; reduced anyway)
+__device__ __noinline__ uint64_t residue_general(uint64_t mag, uint64_t amp, uint64_t p) {
+  return (uint64_t)(((unsigned __int128)(mag % p) * (amp % p)) % p);
+}
 template <typename T> __device__ __forceinline__ T signed_residue(bool neg, uint64_t mag, uint64_t amp, uint64_t p) {
-  const uint64_t m = (uint64_t)(((unsigned __int128)(mag % p) * (amp % p)) % p);
+  const uint64_t prod = mag * amp;  // the sensible case (small noise, small amplifier): one multiply, no division
+  const uint64_t m = (((mag | amp) >> 31) == 0 && prod < p) ? prod : residue_general(mag, amp, p);
   return (T)(neg ? (m ? p - m : 0) : m);
+}
+
+// ---- eight results per lane -> eight coalesced stores per wave -------------------------------------------------
+// Every sampler thread turns one 64-byte keystream block into eight consecutive values; stored directly, each store
+// instruction would scatter 64 words 64 bytes apart.  A wave-local LDS transpose hands lane L the values
+// k*64 + L (k = 0..7) of the wave's 512, so each store instruction writes 64 consecutive words.
+constexpr int kTS = 72;  // row stride: at most 2-way bank conflicts in both directions
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename V>
+__device__ __forceinline__ void wave_transpose8(V *slab, int lane, bool active, const V (&in)[8], V (&out)[8]) {
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) slab[c * kTS + lane] = in[c];
+  }
+  wave_sync_lds();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int t = k * 64 + lane;  // produced by lane t >> 3 as its value t & 7
+    out[k] = slab[(t & 7) * kTS + (t >> 3)];
+  }
+  wave_sync_lds();
 }
 
 // ---- poly(uniform) (core.hpp:152-188): one stream word per residue word, mask to floor(log2 p)+1 bits, one
@@ -83,6 +112,40 @@ __global__ void k_sample_uniform(T *d, const ModConst<T> *__restrict__ mc, int l
         if (v >= c.p) v = (T)(v - c.p);
         d[g - first_word] = v;
       }
+    }
+  }
+}
+
+// n >= 8: a keystream block never straddles a row, so the modulus is looked up once per block
+template <typename T>
+__global__ void __launch_bounds__(256) k_sample_uniform8(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm,
+                                                         uint64_t first_word, size_t total, ChaChaKey key, uint64_t nonce) {
+  __shared__ uint64_t xs[4][8 * kTS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t fb = first_word >> 3;  // first_word and total are multiples of 8
+  const size_t nblk = total >> 3, ntile = (nblk + 63) >> 6;
+  for (size_t tile = (size_t)blockIdx.x * 4 + wv; tile < ntile; tile += (size_t)gridDim.x * 4) {
+    const size_t b = (tile << 6) + lane;
+    const bool active = b < nblk;
+    uint64_t v[8], o[8];
+    if (active) {
+      uint64_t w[8];
+      chacha20_block(key, fb + b, nonce, w);
+      const uint64_t row = (fb + b) >> (logn - 3);
+      const int cm = (row >> 32) == 0 ? (int)((uint32_t)row % (uint32_t)nm) : (int)(row % (uint64_t)nm);
+      const ModConst<T> c = mc[cm];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        T x = (T)((T)w[j] & c.mask);
+        if (x >= c.p) x = (T)(x - c.p);
+        v[j] = x;
+      }
+    }
+    wave_transpose8(xs[wv], lane, active, v, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t idx = (tile << 9) + (size_t)(k * 64 + lane);
+      if (idx < total) d[idx] = (T)o[k];
     }
   }
 }
@@ -134,6 +197,58 @@ __global__ void k_sample_small(T *d, const ModConst<T> *__restrict__ mc, int log
   }
 }
 
+// n >= 8: one block per thread, results as signed 64-bit integers through the transpose
+template <typename T>
+__global__ void __launch_bounds__(256) k_sample_small8(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm,
+                                                       uint64_t first_coef, size_t ncoef, int dist, uint64_t p0, uint64_t p1,
+                                                       ChaChaKey key, uint64_t nonce) {
+  __shared__ long long xs[4][8 * kTS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t n = ((uint64_t)1) << logn, fb = first_coef >> 3;
+  uint64_t mask = 0;
+  if (dist == 1) {
+    const uint64_t t = 2 * p0 - 1;  // >= 1
+    int bits = 0;
+    while (bits < 64 && (t >> bits) != 0) ++bits;  // floor(log2 t) + 1
+    mask = bits >= 64 ? ~(uint64_t)0 : ((((uint64_t)1) << bits) - 1);
+  }
+  const uint64_t amp = dist == 1 ? p1 : 1;
+  const size_t nblk = ncoef >> 3, ntile = (nblk + 63) >> 6;
+  for (size_t tile = (size_t)blockIdx.x * 4 + wv; tile < ntile; tile += (size_t)gridDim.x * 4) {
+    const size_t b = (tile << 6) + lane;
+    const bool active = b < nblk;
+    long long v[8], o[8];
+    if (active) {
+      uint64_t w[8];
+      chacha20_block(key, fb + b, nonce, w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (dist == 1) {  // same statements as k_sample_small
+          uint64_t tmp = w[j] & mask;
+          if (tmp >= 2 * p0 - 1) tmp -= 2 * p0 - 1;
+          v[j] = tmp >= p0 ? -(long long)((2 * p0 - 1) - tmp) : (long long)tmp;
+        } else {
+          const unsigned byte = (unsigned)(w[j] & 0xff);
+          v[j] = byte > (unsigned)p0 ? 0 : ((byte & 2u) == 0 ? -1 : 1);
+        }
+      }
+    }
+    wave_transpose8(xs[wv], lane, active, v, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t idx = (tile << 9) + (size_t)(k * 64 + lane);
+      if (idx < ncoef) {
+        const bool neg = o[k] < 0;
+        const uint64_t mag = (uint64_t)(neg ? -o[k] : o[k]);
+        const uint64_t poly = idx >> logn, i = idx & (n - 1);
+        T *col = d + ((poly * (uint64_t)nm) << logn) + i;
+        for (int cm = 0; cm < nm; ++cm)
+          col[(uint64_t)cm << logn] = mag == 0 ? (T)0 : signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+      }
+    }
+  }
+}
+
 // ---- poly(gaussian(&fg, amp)) (core.hpp:284-322; FastGaussianNoise.hpp): inversion sampling from a cumulative table
 // of W 64-bit words per entry (most significant first), entry k = floor(2^(64W) * P(X <= x_min + k)):
 // x = x_min + #{k : cdt[k] <= r} for a uniform W-word number r.
@@ -158,7 +273,9 @@ __device__ __noinline__ bool gauss_tie_less(const uint64_t r0, const uint64_t *e
       have = wi >> 3;
       chacha20_block(key, kSecondaryCounter | have, nonce, blk);
     }
-    const uint64_t rk = blk[wi & 7];
+    uint64_t rk = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rk = (int)(wi & 7) == j ? blk[j] : rk;  // (no dynamic register indexing)
     if (rk != e[k]) return rk < e[k];
   }
   return false;  // r == entry: not below it
@@ -208,7 +325,7 @@ __global__ void __launch_bounds__(256) k_sample_gauss8(T *d, const ModConst<T> *
                                                        uint64_t first_coef, size_t ncoef,
                                                        const uint64_t *__restrict__ cdt, int entries, long long x_min,
                                                        uint64_t amp, ChaChaKey key, uint64_t nonce, int tie_shift) {
-  constexpr int S = 72;  // row stride of the transpose: 2-way bank conflicts at most in both directions
+  constexpr int S = kTS;
   __shared__ int xs[4][8 * S];
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 3;  // first_coef and ncoef are multiples of 8 (n >= 8)
@@ -324,13 +441,21 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
   const size_t ncoef = batch * s.n, total = ncoef * s.nm;
   switch (dist) {
     case 0:
-      hipLaunchKernelGGL((k_sample_uniform<T>), dim3(grid_for(total / 8 + 2)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
-                         (uint64_t)first_poly * s.nm * s.n, total, key, stream_id);
+      if (s.n >= 8)
+        hipLaunchKernelGGL((k_sample_uniform8<T>), dim3(grid_for(total / 8)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
+                           (uint64_t)first_poly * s.nm * s.n, total, key, stream_id);
+      else
+        hipLaunchKernelGGL((k_sample_uniform<T>), dim3(grid_for(total / 8 + 2)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
+                           (uint64_t)first_poly * s.nm * s.n, total, key, stream_id);
       break;
     case 1:
     case 2:
-      hipLaunchKernelGGL((k_sample_small<T>), dim3(grid_for(ncoef / 8 + 2)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
-                         (uint64_t)first_poly * s.n, ncoef, dist, p0, p1, key, stream_id);
+      if (s.n >= 8)
+        hipLaunchKernelGGL((k_sample_small8<T>), dim3(grid_for(ncoef / 8)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
+                           (uint64_t)first_poly * s.n, ncoef, dist, p0, p1, key, stream_id);
+      else
+        hipLaunchKernelGGL((k_sample_small<T>), dim3(grid_for(ncoef / 8 + 2)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
+                           (uint64_t)first_poly * s.n, ncoef, dist, p0, p1, key, stream_id);
       break;
     case 3: {
       hipError_t e = hipMemsetAsync(d, 0, total * sizeof(T), st);
