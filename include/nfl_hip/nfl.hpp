@@ -22,8 +22,10 @@
 //     never at static-init time (the reference's `static core base`, poly.hpp:247);
 //   * CRT lift/project exchange little-endian 64-bit limb vectors
 //     (poly2limbs / limbs2poly == the mpz_export/mpz_import image of
-//     poly2mpz / mpz2poly, gmp.hpp:183-219); GMP-typed overloads are available
-//     when NFL_HIP_WITH_GMP is defined before inclusion;
+//     poly2mpz / mpz2poly, gmp.hpp:183-219); with NFL_HIP_WITH_GMP defined before
+//     inclusion the reference's GMP-typed surface is there as well (poly.hpp:249-307):
+//     mpz_t / mpz_class constructors, set_mpz, operator=, poly2mpz / mpz2poly on
+//     std::array<mpz_t, Degree>, moduli_product / modulus_shoup / lifting_integers;
 //   * nfl::batch::* operate on contiguous arrays of polys (dense
 //     [batch][NbModuli][Degree], as tests/tools.h:6-17 allocates) in ONE device
 //     pass -- the per-poly members stay for source compatibility;
@@ -59,6 +61,12 @@
 
 #ifdef NFL_HIP_WITH_GMP
 #include <gmp.h>
+#if defined(__has_include)
+#if __has_include(<gmpxx.h>)
+#include <gmpxx.h>
+#define NFL_HIP_HAVE_GMPXX 1
+#endif
+#endif
 #endif
 
 namespace nfl {
@@ -130,6 +138,12 @@ struct ZO_dist {  // P(1) = P(-1) = ((rho + 1) / 256) / 2
 };
 
 namespace detail {
+#ifdef NFL_HIP_WITH_GMP
+inline mpz_srcptr as_mpz(mpz_t const &v) { return v; }
+#ifdef NFL_HIP_HAVE_GMPXX
+inline mpz_srcptr as_mpz(mpz_class const &v) { return v.get_mpz_t(); }
+#endif
+#endif
 
 inline void check(nflhip_ctx *ctx, int rc, const char *what) {
   if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): ") + what + ": " + nflhip_last_error(ctx));
@@ -514,20 +528,121 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
     detail::check(ctx(), nflhip_crt_project(ctx(), _data, limbs, L_in, 1), "mpz2poly");
   }
 #ifdef NFL_HIP_WITH_GMP
+  /* ---- GMP-typed surface (poly.hpp:249-307, gmp.hpp) ---- */
+  // constants of the nested GMP class (gmp.hpp:113-155), imported once from the context (which built them for the
+  // device) -- moduli_product, lifting_integers -- plus modulus_shoup from the reference's formula
+  struct GMP {
+    mpz_t moduli_product, modulus_shoup;
+    size_t bits_in_moduli_product, bits_in_modulus_shoup, shift_modulus_shoup;
+    std::array<mpz_t, NbModuli> lifting_integers;
+    GMP() {
+      const size_t cap = nflhip_crt_limbs(ctx()) + 2;
+      std::vector<uint64_t> buf(cap);
+      size_t nl = 0;
+      detail::check(ctx(), nflhip_get_crt_constant(ctx(), 0, 0, buf.data(), cap, &nl), "GMP: moduli_product");
+      mpz_init(moduli_product);
+      mpz_import(moduli_product, nl, -1, sizeof(uint64_t), 0, 0, buf.data());
+      bits_in_moduli_product = mpz_sizeinbase(moduli_product, 2);
+      size_t lg = 0;
+      while ((size_t(2) << lg) <= NbModuli) ++lg;  // static_log2<nmoduli> (meta.hpp:12-30)
+      shift_modulus_shoup = bits_in_moduli_product + params<T>::kModulusRepresentationBitsize + lg + 1;  // gmp.hpp:124-126
+      mpz_init2(modulus_shoup, shift_modulus_shoup);
+      mpz_ui_pow_ui(modulus_shoup, 2, shift_modulus_shoup);
+      mpz_tdiv_q(modulus_shoup, modulus_shoup, moduli_product);
+      bits_in_modulus_shoup = mpz_sizeinbase(modulus_shoup, 2);
+      for (size_t cm = 0; cm < NbModuli; cm++) {
+        detail::check(ctx(), nflhip_get_crt_constant(ctx(), 1, cm, buf.data(), cap, &nl), "GMP: lifting_integers");
+        mpz_init(lifting_integers[cm]);
+        mpz_import(lifting_integers[cm], nl, -1, sizeof(uint64_t), 0, 0, buf.data());
+      }
+    }
+    ~GMP() {
+      for (size_t cm = 0; cm < NbModuli; cm++) mpz_clear(lifting_integers[cm]);
+      mpz_clears(modulus_shoup, moduli_product, nullptr);
+    }
+    GMP(GMP const &) = delete;
+    GMP &operator=(GMP const &) = delete;
+  };
+  static GMP &gmp() {
+    static GMP g;
+    return g;
+  }
+  static size_t bits_in_moduli_product() { return gmp().bits_in_moduli_product; }
+  static mpz_t &moduli_product() { return gmp().moduli_product; }
+  static mpz_t &modulus_shoup() { return gmp().modulus_shoup; }
+  static std::array<mpz_t, NbModuli> lifting_integers() { return gmp().lifting_integers; }  // shallow, like poly.hpp:307
+
+  poly(mpz_t const &v) { set_mpz(v); }
+  poly(std::array<mpz_t, Degree> const &values) { set_mpz(values); }
+  void set_mpz(mpz_t const &v) { set_mpz(&v, &v + 1); }
+  void set_mpz(std::array<mpz_t, Degree> const &values) { set_mpz(values.begin(), values.end()); }
+  poly &operator=(mpz_t const &v) { set_mpz(v); return *this; }
+  poly &operator=(std::array<mpz_t, Degree> const &values) { set_mpz(values); return *this; }
+#ifdef NFL_HIP_HAVE_GMPXX
+  poly(mpz_class const &v) { set_mpz(v); }
+  poly(std::array<mpz_class, Degree> const &values) { set_mpz(values); }
+  poly(std::initializer_list<mpz_class> const &values) { set_mpz(values); }
+  void set_mpz(mpz_class const &v) { set_mpz(&v, &v + 1); }
+  void set_mpz(std::array<mpz_class, Degree> const &values) { set_mpz(values.begin(), values.end()); }
+  void set_mpz(std::initializer_list<mpz_class> const &values) { set_mpz(values.begin(), values.end()); }
+  poly &operator=(mpz_class const &v) { set_mpz(v); return *this; }
+  poly &operator=(std::array<mpz_class, Degree> const &values) { set_mpz(values); return *this; }
+  poly &operator=(std::initializer_list<mpz_class> const &values) { set_mpz(values); return *this; }
+#endif
+  // gmp.hpp:73-108: fewer than `degree` integers are zero-padded and replicated over the moduli, exactly
+  // degree*nmoduli are taken row by row; every value is reduced with floor semantics (mpz_fdiv_ui: negative
+  // integers give non-negative residues).  A setter, like set(It, It): runs on the host.
+  template <class It> void set_mpz(It first, It last) {
+    const size_t size = size_t(std::distance(first, last));
+    if (size > degree && size != degree * nmoduli)
+      throw std::runtime_error("gmp: CRITICAL, initializer of size above degree but not equal to nmoduli*degree");
+    T *iter = begin();
+    It viter = first;
+    for (size_t cm = 0; cm < nmoduli; cm++) {
+      const value_type p = get_modulus(cm);
+      if (size != degree * nmoduli) viter = first;
+      size_t i = 0;
+      for (; i < degree && viter != last; ++i, ++viter, ++iter) *iter = value_type(mpz_fdiv_ui(detail::as_mpz(*viter), p));
+      for (; i < degree; ++i, ++iter) *iter = 0;
+    }
+  }
+
+  // gmp.hpp:169-209 on the device (nflhip_crt_lift); the returned integers are initialised here and owned by the
+  // caller (mpz_clear), as in the reference
+  std::array<mpz_t, Degree> poly2mpz() const {
+    std::array<mpz_t, Degree> rop;
+    for (size_t i = 0; i < degree; i++) mpz_init2(rop[i], gmp().shift_modulus_shoup - 1);
+    poly2mpz(rop);
+    return rop;
+  }
   void poly2mpz(std::array<mpz_t, Degree> &rop) const {
     std::vector<uint64_t> limbs;
     poly2limbs(limbs);
     const size_t L = crt_limbs();
     for (size_t i = 0; i < degree; i++) mpz_import(rop[i], L, -1, sizeof(uint64_t), 0, 0, limbs.data() + i * L);
   }
+  // gmp.hpp:211-219 on the device (nflhip_crt_project).  mpz_fdiv_ui semantics: a negative integer is first
+  // brought into [0, Q) (same residues), the device only sees magnitudes.
   void mpz2poly(std::array<mpz_t, Degree> const &v) {
     size_t L = 1;
-    for (size_t i = 0; i < degree; i++) L = std::max(L, (mpz_sizeinbase(v[i], 2) + 63) / 64);
-    std::vector<uint64_t> limbs(degree * L, 0);
+    bool any_negative = false;
     for (size_t i = 0; i < degree; i++) {
-      if (mpz_sgn(v[i]) < 0) throw std::runtime_error("gmp: negative coefficient");
-      mpz_export(limbs.data() + i * L, nullptr, -1, sizeof(uint64_t), 0, 0, v[i]);
+      L = std::max(L, (mpz_sizeinbase(v[i], 2) + 63) / 64);
+      any_negative |= mpz_sgn(v[i]) < 0;
     }
+    if (any_negative) L = std::max(L, (bits_in_moduli_product() + 63) / 64);
+    std::vector<uint64_t> limbs(degree * L, 0);
+    mpz_t t;
+    mpz_init(t);
+    for (size_t i = 0; i < degree; i++) {
+      if (mpz_sgn(v[i]) < 0) {
+        mpz_fdiv_r(t, v[i], moduli_product());
+        mpz_export(limbs.data() + i * L, nullptr, -1, sizeof(uint64_t), 0, 0, t);
+      } else {
+        mpz_export(limbs.data() + i * L, nullptr, -1, sizeof(uint64_t), 0, 0, v[i]);
+      }
+    }
+    mpz_clear(t);
     limbs2poly(limbs.data(), L);
   }
 #endif

@@ -6,6 +6,7 @@
 //   CRT round trip (tests/poly_mpz.cpp:19-29), ctor/set semantics (tests/poly_set.cpp),
 //   serialisation round trip (tests/poly_serialize_manually.cpp), stream prefix (tests/nfl_stream.cpp),
 //   the copy-on-write poly_p handle (tests/poly_p.cpp),
+//   the GMP-typed surface: constants, set_mpz, poly2mpz / mpz2poly (tests/poly_mpz.cpp, gmp.hpp),
 //   the random constructors and the LWE round trip (tests/nfllib_demo_main_op.cpp:26-58, 313-332),
 // with memcmp-strength comparisons (the reference's operator== is "any lane equal").
 // Exit code 0 = all good; prints the failing check otherwise.  Needs a GPU.
@@ -373,6 +374,75 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe_batch() {
   return true;
 }
 
+#ifdef NFL_HIP_WITH_GMP
+// tests/poly_mpz.cpp:19-69 + the constants of gmp.hpp:113-155, checked against GMP itself
+template <class T, size_t Degree, size_t NbModuli> static bool run_gmp() {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  // constants
+  mpz_t q, t, u;
+  mpz_inits(q, t, u, nullptr);
+  mpz_set_ui(q, 1);
+  for (size_t cm = 0; cm < NbModuli; cm++) mpz_mul_ui(q, q, poly_t::get_modulus(cm));
+  CHECK(mpz_cmp(q, poly_t::moduli_product()) == 0);
+  CHECK(poly_t::bits_in_moduli_product() == mpz_sizeinbase(q, 2));
+  std::array<mpz_t, NbModuli> lift = poly_t::lifting_integers();
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t k = 0; k < NbModuli; k++) CHECK(mpz_fdiv_ui(lift[cm], poly_t::get_modulus(k)) == (k == cm ? 1u : 0u));
+  size_t lg = 0;
+  while ((size_t(2) << lg) <= NbModuli) ++lg;
+  const size_t shift = mpz_sizeinbase(q, 2) + 8 * sizeof(T) + lg + 1;
+  mpz_ui_pow_ui(t, 2, shift);
+  mpz_tdiv_q(t, t, q);
+  CHECK(mpz_cmp(t, poly_t::modulus_shoup()) == 0);
+  // poly -> integers -> poly round trip; every integer is the CRT lift in [0, Q)
+  Heap<poly_t> a(nfl::uniform(11)), back, c;
+  std::array<mpz_t, Degree> *X = new std::array<mpz_t, Degree>(a->poly2mpz());
+  for (size_t i = 0; i < Degree; i++) {
+    CHECK(mpz_sgn((*X)[i]) >= 0 && mpz_cmp((*X)[i], q) < 0);
+    for (size_t cm = 0; cm < NbModuli; cm++) CHECK(mpz_fdiv_ui((*X)[i], poly_t::get_modulus(cm)) == (*a)(cm, i));
+  }
+  back->mpz2poly(*X);
+  CHECK(same(*back, *a));
+  // floor semantics of mpz2poly for negative and for over-long integers (gmp.hpp:216: mpz_fdiv_ui)
+  for (size_t i = 0; i < Degree; i++) {
+    if (i % 3 == 0) mpz_sub(u, (*X)[i], q), mpz_sub((*X)[i], u, q);        // X - 2Q  (negative)
+    else if (i % 3 == 1) mpz_mul(u, q, q), mpz_add((*X)[i], (*X)[i], u);   // X + Q^2 (twice as long)
+  }
+  c->mpz2poly(*X);
+  CHECK(same(*c, *a));
+  for (size_t i = 0; i < Degree; i++) mpz_clear((*X)[i]);
+  delete X;
+#ifdef NFL_HIP_HAVE_GMPXX
+  // set_mpz: short lists are zero-padded and replicated, negative values wrap (tests/poly_set.cpp's contract on integers)
+  mpz_class big(mpz_class(q) * 5 + 12345), neg(-7);
+  Heap<poly_t> s(std::initializer_list<mpz_class>{big, neg, mpz_class(3)});
+  for (size_t cm = 0; cm < NbModuli; cm++) {
+    const T p = poly_t::get_modulus(cm);
+    CHECK((*s)(cm, 0) == T(12345 % p) && (*s)(cm, 1) == T(p - 7) && (*s)(cm, 2) == T(3 % p));
+    for (size_t j = 3; j < Degree; j++) CHECK((*s)(cm, j) == 0);
+  }
+  *s = mpz_class(42);
+  for (size_t cm = 0; cm < NbModuli; cm++) CHECK((*s)(cm, 0) == T(42 % poly_t::get_modulus(cm)) && (*s)(cm, 1) == 0);
+  std::vector<mpz_class> full(Degree * NbModuli), bad(Degree + 1);
+  for (size_t k = 0; k < full.size(); k++) full[k] = mpz_class((unsigned long)k) - 5;
+  s->set_mpz(full.begin(), full.end());
+  for (size_t cm = 0; cm < NbModuli; cm++)
+    for (size_t j = 0; j < Degree; j++) {
+      const long v = long(cm * Degree + j) - 5;
+      const T p = poly_t::get_modulus(cm);
+      CHECK((*s)(cm, j) == (v < 0 ? T(p + v) : T((unsigned long)v % p)));
+    }
+  bool threw = false;
+  if (NbModuli > 1) {
+    try { s->set_mpz(bad.begin(), bad.end()); } catch (std::runtime_error const &) { threw = true; }
+    CHECK(threw);
+  }
+#endif
+  mpz_clears(q, t, u, nullptr);
+  return true;
+}
+#endif
+
 int main() {
   try {
     bool ok = true;
@@ -390,6 +460,12 @@ int main() {
     ok &= run_poly_p<uint64_t, 4096, 4>();   // tests/poly_p.cpp
     ok &= run_poly_p<uint32_t, 1024, 2>();
     ok &= run_poly_p<uint16_t, 128, 1>();
+#ifdef NFL_HIP_WITH_GMP
+    ok &= run_gmp<uint64_t, 4096, 4>();      // tests/poly_mpz.cpp
+    ok &= run_gmp<uint64_t, 64, 3>();
+    ok &= run_gmp<uint32_t, 1024, 2>();
+    ok &= run_gmp<uint16_t, 128, 1>();
+#endif
     ok &= other_tu_selftest() == 0;
     std::printf(ok ? "surface: all checks passed\n" : "surface: FAILED\n");
     return ok ? 0 : 1;
