@@ -915,6 +915,34 @@ template <class P> class device_batch {
     same_size(a); same_size(b);
     detail::check(P::ctx(), nflhip_polymul_dev(P::ctx(), d_, a.d_, b.d_, n_, nullptr), "polymul");
   }
+  // the same with b already in NTT form (keys of the LWE demo stay transformed, tests/nfllib_demo_main_op.cpp:26-46)
+  void assign_polymul_ntt(const device_batch &a, const device_batch &b_ntt) {
+    same_size(a); same_size(b_ntt);
+    detail::check(P::ctx(), nflhip_polymul_ntt_dev(P::ctx(), d_, a.d_, b_ntt.d_, n_, nullptr), "polymul_ntt");
+  }
+  // CRT lift / project of the whole resident batch (gmp.hpp:183-219): out[(b*degree + i)*L .. +L) = little-endian limbs
+  // of X_{b,i} in [0, Q), L = P::crt_limbs(); limbs2poly takes L_in limbs per coefficient
+  void poly2limbs(std::vector<uint64_t> &out) const {
+    const size_t words = n_ * P::degree * P::crt_limbs();
+    out.assign(words, 0);
+    void *dl = nullptr;
+    detail::check(P::ctx(), nflhip_malloc(P::ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
+    int rc = nflhip_crt_lift_dev(P::ctx(), static_cast<uint64_t *>(dl), d_, n_, nullptr);
+    if (rc == 0) rc = nflhip_memcpy_d2h(P::ctx(), out.data(), dl, words * sizeof(uint64_t), nullptr);
+    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), nullptr);
+    nflhip_free(P::ctx(), dl);
+    detail::check(P::ctx(), rc, "poly2mpz");
+  }
+  void limbs2poly(const uint64_t *limbs, size_t L_in) {
+    const size_t words = n_ * P::degree * L_in;
+    void *dl = nullptr;
+    detail::check(P::ctx(), nflhip_malloc(P::ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
+    int rc = nflhip_memcpy_h2d(P::ctx(), dl, limbs, words * sizeof(uint64_t), nullptr);
+    if (rc == 0) rc = nflhip_crt_project_dev(P::ctx(), d_, static_cast<const uint64_t *>(dl), L_in, n_, nullptr);
+    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), nullptr);
+    nflhip_free(P::ctx(), dl);
+    detail::check(P::ctx(), rc, "mpz2poly");
+  }
   // fused postfix expression over up to NFLHIP_EXPR_MAX_OPERANDS resident batches
   void assign_program(const unsigned char *program, size_t len, const device_batch *const *operands, size_t count) {
     const void *ptr[NFLHIP_EXPR_MAX_OPERANDS];

@@ -374,6 +374,35 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe_batch() {
   return true;
 }
 
+// resident batches: b pre-transformed product and CRT lift / project of the whole batch vs the per-poly members
+template <class T, size_t Degree, size_t NbModuli> static bool run_batch_crt() {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  const size_t count = 3;
+  void *mem = nullptr;
+  if (posix_memalign(&mem, 32, sizeof(poly_t) * count * 3) != 0) throw std::bad_alloc();
+  poly_t *a = static_cast<poly_t *>(mem), *b = a + count, *c = b + count;
+  for (size_t k = 0; k < count; k++) { new (a + k) poly_t(nfl::uniform(100 + k)); new (b + k) poly_t(nfl::uniform(200 + k)); new (c + k) poly_t(); }
+  nfl::device_batch<poly_t> da(a, count), db(b, count), dc(count), dd(count);
+  dc.assign_polymul(da, db);
+  db.ntt_pow_phi();
+  dd.assign_polymul_ntt(da, db);
+  CHECK(!dc.any_differs(dd));
+  std::vector<uint64_t> all, one;
+  da.poly2limbs(all);
+  const size_t L = poly_t::crt_limbs();
+  CHECK(all.size() == count * Degree * L);
+  for (size_t k = 0; k < count; k++) {
+    a[k].poly2limbs(one);
+    CHECK(std::memcmp(one.data(), all.data() + k * Degree * L, one.size() * sizeof(uint64_t)) == 0);
+  }
+  dc.limbs2poly(all.data(), L);
+  dc.download(c);
+  for (size_t k = 0; k < count; k++) CHECK(same(c[k], a[k]));
+  for (size_t k = 0; k < 3 * count; k++) a[k].~poly_t();
+  free(mem);
+  return true;
+}
+
 #ifdef NFL_HIP_WITH_GMP
 // tests/poly_mpz.cpp:19-69 + the constants of gmp.hpp:113-155, checked against GMP itself
 template <class T, size_t Degree, size_t NbModuli> static bool run_gmp() {
@@ -460,6 +489,9 @@ int main() {
     ok &= run_poly_p<uint64_t, 4096, 4>();   // tests/poly_p.cpp
     ok &= run_poly_p<uint32_t, 1024, 2>();
     ok &= run_poly_p<uint16_t, 128, 1>();
+    ok &= run_batch_crt<uint64_t, 4096, 4>();
+    ok &= run_batch_crt<uint32_t, 1024, 2>();
+    ok &= run_batch_crt<uint16_t, 128, 1>();
 #ifdef NFL_HIP_WITH_GMP
     ok &= run_gmp<uint64_t, 4096, 4>();      // tests/poly_mpz.cpp
     ok &= run_gmp<uint64_t, 64, 3>();
