@@ -231,6 +231,15 @@ template <class in_class, class out_class, unsigned _lu_depth> class FastGaussia
     return g;
   }
   double sigma() const { return sigma_; }
+  // FastGaussianNoise.hpp:477-595: rlen raw samples, negative values wrap into out_class exactly like the reference's
+  // `(out_class)output`.  Runs on the device (a small private context only selects it); one keystream per call.
+  void getNoise(out_class *const rand_data2out, uint64_t rlen) {
+    nflhip_ctx *ctx = detail::context<uint64_t, 64, 1>::get();
+    std::vector<int64_t> tmp(rlen);
+    detail::sampler &s = detail::sampler::get();
+    detail::check(ctx, nflhip_gauss_noise(ctx, tmp.data(), rlen, table(ctx), s.key, s.next++), "getNoise");
+    for (uint64_t i = 0; i < rlen; i++) rand_data2out[i] = out_class(tmp[i]);
+  }
 
  private:
   double sigma_;

@@ -229,6 +229,12 @@ int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, si
                             uint64_t amplifier, const unsigned char key[32], uint64_t stream_id, void *stream);
 int nflhip_sample_gauss(nflhip_ctx *ctx, void *h_data, size_t batch, const nflhip_gauss *g, uint64_t amplifier,
                         const unsigned char key[32], uint64_t stream_id);
+/* FastGaussianNoise::getNoise(out, rlen) (FastGaussianNoise.hpp:477-595): `count` raw signed samples; sample j is the
+ * integer that coefficient first_sample + j of a polynomial batch gets from the same (key, stream_id) */
+int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sample, size_t count, const nflhip_gauss *g,
+                           const unsigned char key[32], uint64_t stream_id, void *stream);
+int nflhip_gauss_noise(nflhip_ctx *ctx, int64_t *h_out, size_t count, const nflhip_gauss *g,
+                       const unsigned char key[32], uint64_t stream_id);
 
 /* plain device-memory helpers so a C caller needs no HIP headers */
 int nflhip_malloc(nflhip_ctx *ctx, void **d_ptr, size_t bytes);

@@ -57,6 +57,8 @@ SYMBOLS = [
                                C.POINTER(C.c_double), _vp]),
     ("nflhip_sample_gauss_dev", _i, [_vp, _vp, _sz, _sz, _vp, _u64, _vp, _u64, _vp]),
     ("nflhip_sample_gauss", _i, [_vp, _vp, _sz, _vp, _u64, _vp, _u64]),
+    ("nflhip_gauss_noise_dev", _i, [_vp, _vp, _u64, _sz, _vp, _vp, _u64, _vp]),
+    ("nflhip_gauss_noise", _i, [_vp, _vp, _sz, _vp, _vp, _u64]),
     ("nflhip_malloc", _i, [_vp, C.POINTER(_vp), _sz]),
     ("nflhip_free", _i, [_vp, _vp]),
     ("nflhip_memcpy_h2d", _i, [_vp, _vp, _vp, _sz, _vp]),

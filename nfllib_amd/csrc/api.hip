@@ -872,6 +872,17 @@ int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t 
   return NFLHIP_OK;
 }
 
+int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sample, size_t count, const nflhip_gauss *g,
+                           const unsigned char *key, uint64_t stream_id, void *stream) {
+  CHECK_CTX(ctx);
+  if (!key || !g || (count && !d_out)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (g->device != ctx->device) return fail(ctx, NFLHIP_ERR_INVALID, "gaussian table lives on another device");
+  hipError_t e = launch_gauss_noise((long long *)d_out, first_sample, count, g->d_cdt, g->tab.words, (int)g->tab.entries,
+                                    g->tab.x_min, key, stream_id, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(ctx, e, "gauss_noise");
+  return NFLHIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // memory helpers
 // ---------------------------------------------------------------------------
@@ -1075,6 +1086,20 @@ int nflhip_sample_gauss(nflhip_ctx *ctx, void *d, size_t batch, const nflhip_gau
   rc = nflhip_sample_gauss_dev(ctx, ctx->stage[0], 0, batch, g, amplifier, key, stream_id, ctx->hstream);
   if (rc) return rc;
   return s.out(d, 0, bytes);
+}
+
+int nflhip_gauss_noise(nflhip_ctx *ctx, int64_t *h_out, size_t count, const nflhip_gauss *g, const unsigned char *key,
+                       uint64_t stream_id) {
+  CHECK_CTX(ctx);
+  if (count == 0) return NFLHIP_OK;
+  if (!h_out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  Staged s(ctx);
+  const size_t bytes = count * sizeof(int64_t);
+  int rc = s.in(0, nullptr, bytes);
+  if (rc) return rc;
+  rc = nflhip_gauss_noise_dev(ctx, (int64_t *)ctx->stage[0], 0, count, g, key, stream_id, ctx->hstream);
+  if (rc) return rc;
+  return s.out(h_out, 0, bytes);
 }
 
 // ---------------------------------------------------------------------------

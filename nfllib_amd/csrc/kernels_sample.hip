@@ -363,6 +363,24 @@ __global__ void __launch_bounds__(256) k_sample_gauss8(T *d, const ModConst<T> *
   }
 }
 
+// FastGaussianNoise::getNoise (FastGaussianNoise.hpp:477-595): raw signed samples; sample j of the call is the value
+// coefficient first_sample + j of a polynomial batch would get from the same (key, stream_id)
+template <int W>
+__global__ void k_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *__restrict__ cdt,
+                              int entries, long long x_min, ChaChaKey key, uint64_t nonce, int tie_shift) {
+  const uint64_t fb = first_sample >> 3, nb = ((first_sample + count + 7) >> 3) - fb;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t w[8];
+    chacha20_block(key, fb + b, nonce, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t g = ((fb + b) << 3) + j;
+      if (g >= first_sample && g < first_sample + count)
+        out[g - first_sample] = x_min + gauss_search<W>(w[j], g, cdt, entries, tie_shift, key, nonce);
+    }
+  }
+}
+
 // ---- poly(hwt_dist(h)) (core.hpp:347-391): exactly h coefficients are +-1, uniformly among the C(n,h) supports.
 // The reference draws them by reservoir sampling with rejection-sampled indices; here Floyd's algorithm (the same
 // distribution, h draws instead of n) runs one thread per polynomial over the zero-initialised row 0 as the
@@ -471,6 +489,30 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
   return hipGetLastError();
 }
 
+static int gauss_tie_shift() {
+  static const int v = [] {
+    const char *e = getenv("NFLHIP_GAUSS_TIE_SHIFT");  // test hook, see gauss_search
+    const int t = e ? atoi(e) : 0;
+    return t < 0 ? 0 : (t > 63 ? 63 : t);
+  }();
+  return v;
+}
+
+hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *cdt, int words,
+                              int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
+  if (count == 0) return hipSuccess;
+  const ChaChaKey key = load_key(key32);
+  const dim3 g(grid_for(count / 8 + 2)), b(256);
+  const int ts = gauss_tie_shift();
+  switch (words) {
+    case 1: hipLaunchKernelGGL((k_gauss_noise<1>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
+    case 2: hipLaunchKernelGGL((k_gauss_noise<2>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
+    case 3: hipLaunchKernelGGL((k_gauss_noise<3>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
                                const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
@@ -480,11 +522,7 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
   const ChaChaKey key = load_key(key32);
   const size_t ncoef = batch * s.n;
   const uint64_t fc = (uint64_t)first_poly * s.n;
-  static const int tie_shift = [] {
-    const char *e = getenv("NFLHIP_GAUSS_TIE_SHIFT");  // test hook, see gauss_search
-    const int v = e ? atoi(e) : 0;
-    return v < 0 ? 0 : (v > 63 ? 63 : v);
-  }();
+  const int tie_shift = gauss_tie_shift();
   if (s.n >= 8) {  // eight coefficients per thread
     const dim3 g(grid_for(ncoef / 8)), b(256);
     switch (words) {

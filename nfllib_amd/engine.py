@@ -203,6 +203,19 @@ class Engine:
                                                    self._key(key), stream_id, self._stream(stream)))
         return d
 
+    def gauss_noise(self, g, count, key, stream_id=0, first_sample=0, stream=None):
+        """raw signed samples (FastGaussianNoise::getNoise) as an int64 device tensor"""
+        t = _torch()
+        out = t.empty((count,), dtype=t.int64, device="cuda:%d" % self.device)
+        self._chk(self.lib.nflhip_gauss_noise_dev(self.ctx, _vp(out), first_sample, count, g, self._key(key), stream_id,
+                                                  self._stream(stream)))
+        return out
+
+    def h_gauss_noise(self, g, count, key, stream_id=0):
+        out = np.empty((count,), dtype=np.int64)
+        self._chk(self.lib.nflhip_gauss_noise(self.ctx, out.ctypes.data_as(C.c_void_p), count, g, self._key(key), stream_id))
+        return out
+
     def crt_lift(self, d, stream=None):
         t = _torch()
         batch = self._batch(d)

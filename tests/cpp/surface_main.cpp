@@ -374,6 +374,27 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe_batch() {
   return true;
 }
 
+// FastGaussianNoise::getNoise: raw samples, two's-complement wrap into the output type, sane moments
+static bool run_get_noise() {
+  nfl::FastGaussianNoise<uint8_t, uint32_t, 2> fg(3.19, 128, 1 << 10);
+  std::vector<uint32_t> v(1 << 16);
+  fg.getNoise(v.data(), v.size());
+  double sum = 0, sq = 0;
+  bool neg = false, pos = false;
+  for (uint32_t u : v) {
+    const int32_t x = int32_t(u);
+    CHECK(x > -60 && x < 60);
+    sum += x; sq += double(x) * x;
+    neg |= x < 0; pos |= x > 0;
+  }
+  const double mean = sum / v.size(), var = sq / v.size() - mean * mean;
+  CHECK(neg && pos && mean > -0.1 && mean < 0.1 && var > 0.95 * 3.19 * 3.19 && var < 1.05 * 3.19 * 3.19);
+  std::vector<uint32_t> w(v.size());
+  fg.getNoise(w.data(), w.size());
+  CHECK(v != w);  // every call takes a fresh keystream
+  return true;
+}
+
 // resident batches: b pre-transformed product and CRT lift / project of the whole batch vs the per-poly members
 template <class T, size_t Degree, size_t NbModuli> static bool run_batch_crt() {
   using poly_t = nfl::poly<T, Degree, NbModuli>;
@@ -489,6 +510,7 @@ int main() {
     ok &= run_poly_p<uint64_t, 4096, 4>();   // tests/poly_p.cpp
     ok &= run_poly_p<uint32_t, 1024, 2>();
     ok &= run_poly_p<uint16_t, 128, 1>();
+    ok &= run_get_noise();
     ok &= run_batch_crt<uint64_t, 4096, 4>();
     ok &= run_batch_crt<uint32_t, 1024, 2>();
     ok &= run_batch_crt<uint16_t, 128, 1>();

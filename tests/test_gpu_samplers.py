@@ -145,6 +145,10 @@ def test_gaussian(sigma, engine_factory):
     b = np.zeros(hi - lo + 1, dtype=np.int64)
     b[rlo - lo:rlo - lo + rh.size] = rh
     assert _chi2_two_sample(a, b) < 1.5
+    # FastGaussianNoise::getNoise: the raw integers behind the same keystream positions, device and host entry
+    raw = e.gauss_noise(g, 3 * 1024 + 5, KEY, stream_id=9, first_sample=1024 - 3).cpu().numpy()
+    assert np.array_equal(raw, flatv[1024 - 3:4 * 1024 + 2])
+    assert np.array_equal(e.h_gauss_noise(g, 777, KEY, stream_id=9), flatv[:777])
     # amplifier and sharding
     amp = e.to_host(e.sample_gauss(e.empty(2), g, KEY, stream_id=9, amplifier=5))
     assert np.array_equal(S.centered(amp, P)[:, 0], 5 * v[:2])
