@@ -378,9 +378,10 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       return NFLHIP_OK;
     }
   }
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn > 12 && ctx->aux[0]) {
+  if (sizeof(T) == 8 && ctx->shape.logn > 12 && ctx->aux[0]) {
     // large rows: streaming outer passes, then the fused assembly kernel over the 4096-word blocks,
-    // then the outer inverse passes (9 operand streams of HBM traffic instead of 13).  The batch is cut
+    // then the outer inverse passes (9 operand streams of HBM traffic instead of 13; 7 when b is already transformed:
+    // its 4096-word blocks are exactly what the fused kernel would have computed for it).  The batch is cut
     // into chunks that alternate between two helper streams: one chunk's HBM-bound streaming passes
     // overlap another chunk's VALU-bound fused kernel.  Fully asynchronous w.r.t. the host.
     const size_t nm = ctx->shape.nm, pw = nm * ctx->shape.n;  // words per poly
@@ -399,10 +400,11 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       const uint64_t *ak = (const uint64_t *)a + lo * pw, *bk = (const uint64_t *)b + lo * pw;
       uint64_t *ck = (uint64_t *)c + lo * pw, *s0k = (uint64_t *)s0 + lo * pw, *s1k = (uint64_t *)s1 + lo * pw;
       e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, ak, s0k, cnt * nm, s, logi);
-      if (e == hipSuccess) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, bk, s1k, cnt * nm, s, logi);
+      if (e == hipSuccess && !b_is_ntt) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, bk, s1k, cnt * nm, s, logi);
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer forward");
-      e = logi == 14 ? launch_polymul_blocks16k_asm_u64(ctx->shape, ctx->tabs, ck, s0k, s1k, cnt, s)
-                     : launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, ck, s0k, s1k, cnt, s);
+      const uint64_t *bblk = b_is_ntt ? bk : s1k;
+      e = logi == 14 ? launch_polymul_blocks16k_asm_u64(ctx->shape, ctx->tabs, ck, s0k, bblk, cnt, s, b_is_ntt != 0)
+                     : launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, ck, s0k, bblk, cnt, s, b_is_ntt != 0);
       if (e == hipErrorNotSupported && logi == 14 && ch == 0) {  // no 16384-word kernel: redo this chunk on 4096-word blocks
         logi = 12;
         --ch;

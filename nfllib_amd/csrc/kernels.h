@@ -117,13 +117,14 @@ hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *da
 // fused NTT,NTT,(.),INTT over the 4096-word blocks of rows whose outer forward passes already ran
 // (a_in, b_in) and whose outer inverse passes still have to run on c (logn > 12), or the whole
 // polymul for logn == 12.  hipErrorNotSupported when the assembly code object is unavailable.
+// b_is_ntt: b_in is the fully transformed operand (canonical words), only a_in went through the outer passes.
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
-                                         const uint64_t *b_in, size_t batch, hipStream_t st);
+                                         const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt = false);
 
 // the same over 16384-word blocks (logn >= 14): one 1024-thread workgroup keeps a block on its CU for global stages
 // logn-14 .. logn-1 of both operands, the product and the way back.
 hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
-                                            const uint64_t *b_in, size_t batch, hipStream_t st);
+                                            const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt = false);
 int row16k_level();
 // n = 65536: one launch of the three-role pipeline kernel (block products of chunk j-1, forward streaming pass of
 // chunk j, inverse streaming pass of chunk j-2); hipErrorNotSupported for other shapes

@@ -454,17 +454,17 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
 }
 
 hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
-                                            const uint64_t *b_in, size_t batch, hipStream_t st) {
+                                            const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt) {
   if (s.limb_bits != 64 || s.logn < kLogN + 2 || row16k_level() < (s.logn == kLogN + 2 ? 1 : 2)) return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
-  return launch_asm(kAsmPolymul16k, s, t, c, a_in, b_in, batch, st);
+  return launch_asm(b_is_ntt ? kAsmPolymulNtt16k : kAsmPolymul16k, s, t, c, a_in, b_in, batch, st);
 }
 
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
-                                         const uint64_t *b_in, size_t batch, hipStream_t st) {
+                                         const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt) {
   if (s.limb_bits != 64 || s.logn < kLogN) return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
-  return launch_asm(kAsmPolymul, s, t, c, a_in, b_in, batch, st);
+  return launch_asm(b_is_ntt ? kAsmPolymulNtt : kAsmPolymul, s, t, c, a_in, b_in, batch, st);
 }
 
 template <bool B_IS_NTT>

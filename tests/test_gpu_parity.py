@@ -341,6 +341,11 @@ for n, m, batch in ((8192, 2, 5), (8192, 1, 1), (16384, 8, 5), (16384, 1, 1), (3
     b2 = b.clone()
     e.polymul(a, b2, out=b2)        # in place on the second operand
     assert not e.any_neq(b2, c)
+    fb2, a2 = fb.clone(), a.clone()
+    e.polymul(a, fb2, out=fb2, b_is_ntt=True)   # pre-transformed operand, in place on either side
+    assert not e.any_neq(fb2, c)
+    e.polymul(a2, fb, out=a2, b_is_ntt=True)
+    assert not e.any_neq(a2, c)
     e.polymul(a, b, out=a)          # in place on the first operand
     assert not e.any_neq(a, c)
     out["%d_%d" % (n, m)] = d
