@@ -125,11 +125,18 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    dev = local_rank if world > 1 else 0
+    # test knobs (tests/test_bench_contract.py runs the N = 2 launch line on a 1-GPU box): every rank on device 0 and the
+    # three tiny control collectives (barrier, max, max) over gloo -- RCCL refuses two ranks on one device
+    backend = os.environ.get("NFLHIP_BENCH_BACKEND", "nccl")
+    dev = local_rank if world > 1 and os.environ.get("NFLHIP_BENCH_ONE_DEVICE") != "1" else 0
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = torch.device("cuda", dev) if backend == "nccl" else None
 
     lb, n, nm, dflt = WORKLOADS[args.workload]
     batch = args.batch or dflt
@@ -160,8 +167,8 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
-        dt = sharding.allreduce_max(dt, dist, device=torch.device("cuda", dev))
-        kernel_ms = sharding.allreduce_max(kernel_ms, dist, device=torch.device("cuda", dev))
+        dt = sharding.allreduce_max(dt, dist, device=red_dev)
+        kernel_ms = sharding.allreduce_max(kernel_ms, dist, device=red_dev)
 
     # cheap in-run sanity: one sampled poly against nothing but itself commuting (parity lives in tests/)
     ok = not eng.any_neq(c, eng.polymul(b, a))
@@ -185,7 +192,6 @@ def main():
     scatter = None
     if world > 1 and args.scatter_gather:
         # data originating on one device: root -> shards -> polymul -> root.  Outside the timed region of `value`.
-        gdev = torch.device("cuda", dev)
         fa = fb = fc = None
         if rank == 0:
             fa = eng.fill_uniform(eng.empty(batch * world), SEED, 0)
@@ -198,7 +204,7 @@ def main():
         eng.polymul(a, b, out=c)
         sharding.gather_batch(c, fc, dist, rank, world)
         torch.cuda.synchronize(); barrier()
-        tsg = sharding.allreduce_max(time.perf_counter() - ts, dist, device=gdev)
+        tsg = sharding.allreduce_max(time.perf_counter() - ts, dist, device=red_dev)
         scatter = {"polymul_per_s_incl_scatter_gather": round(world * batch / tsg, 1), "seconds": round(tsg, 4),
                    "bytes_moved": 3 * (world - 1) * batch * nm * n * (lb // 8),
                    "note": "one step; both operands scattered from rank 0, product gathered back (grouped send/recv over xGMI)"}

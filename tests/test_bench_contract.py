@@ -54,3 +54,30 @@ def test_bench_line_contract(workload, batch):
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     if workload == "B":
         assert d["metric"].startswith("poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli")
+
+
+@pytest.mark.gpu
+def test_two_rank_launch_line_of_the_driver():
+    """The driver's N > 1 command line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...) on a 1-GPU box: both ranks share device 0 and the control
+    collectives go over gloo (test knobs of bench.py); rank 0 alone prints the line, value is the whole-job rate, the
+    scatter/gather leg moves the shards and reports beside it."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NFLHIP_BENCH_BACKEND="gloo", NFLHIP_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--batch", "512", "--scatter-gather"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the JSON line"
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 1024
+    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.2
+    assert "cpu_baseline" not in d and "extras" not in d            # rank 0 at N = 1 only
+    sg = d["scatter_gather"]
+    assert sg["polymul_per_s_incl_scatter_gather"] > 0 and sg["bytes_moved"] == 3 * 512 * 4 * 4096 * 8
+    assert d["config"]["self_check"] is True
