@@ -26,6 +26,7 @@ SEED = 0x4E464C6C6962
 WORKLOADS = {
     # name: (limb_bits, degree, nmoduli, default per-GPU batch)
     "B": (64, 4096, 4, 16384),   # BASELINE.json configs[1] -- the metric is quoted on this
+    "D": (64, 4096, 4, 1 << 17), # configs[3]: B at 2^20 polys over 8 GPUs = 2^17 per GPU (3 x 16 GiB resident per GPU)
     "C": (64, 16384, 8, 1024),   # configs[2]
     "E": (64, 65536, 30, 32),    # configs[4]
     "A": (32, 1024, 1, 1 << 19), # configs[0]'s shape (30-bit moduli) on the device -- secondary
@@ -178,11 +179,12 @@ def main():
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     value = world * batch * args.steps / dt
 
+    kwl = "B" if args.workload == "D" else args.workload   # D runs B's kernel on a larger batch
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath)).get("workloads", {}).get(args.workload)
+            tj = json.load(open(tpath)).get("workloads", {}).get(kwl)
             if tj:
                 traffic = tj["hbm_bytes_per_poly"] * batch
                 traffic_src = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes, %s, calibrated)" % tj.get("round", "")
@@ -273,13 +275,13 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": {"A": "k_row<Pol32, 0, 4>", "B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm",
-                                "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)"}[args.workload],
+                                "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
     # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  Instructions per wave are
     # the SQ_INSTS_VALU / SQ_WAVES of the committed counter passes (= the generator's static count for the assembly kernel);
     # peak = one wave64 instruction per 4 cycles per SIMD, the rate of v_mad_u64_u32 / carry / multiply opcodes on gfx950.
-    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2593, nm, "profiles/r01_final_pmc_sq_A.txt")}.get(args.workload)
+    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2593, nm, "profiles/r01_final_pmc_sq_A.txt")}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]
         peak_gi = 256 * 4 * 2.4 / 4.0   # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles, in G wave-instructions/s
