@@ -83,7 +83,7 @@ struct Pol64 {
 };
 
 // LB = lanes per 16-block of a row: 4 -> 64 lanes (one wave) own a 1024-word row, 8 -> 128 lanes (two waves) own a
-// 2048-word row.  A row is 16 blocks of BS = 16*LB words; lane t works on block B = t / LB in the middle pass.
+// 2048-word row, 16 -> a whole 256-thread workgroup owns a 4096-word row (the three passes are then 4 + 4 + 4 stages).  A row is 16 blocks of BS = 16*LB words; lane t works on block B = t / LB in the middle pass.
 template <int LB> __device__ __forceinline__ int pad1(int e) { return e + (e / (16 * LB)) * LB; }  // +LB words per block
 __device__ __forceinline__ int pad2(int e) { return e + (e >> 4); }                                 // +1 word per 16
 
@@ -105,7 +105,7 @@ template <int LB> __device__ __forceinline__ void row_sync() {
 template <class P, int LB>
 __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw, int t,
                                         const typename P::K &k) {
-  constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : 3;
+  constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : (LB == 8 ? 3 : 4);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int half = 8 >> s;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
 template <class P, int LB>
 __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw,
                                         const typename P::MC &c, const typename P::K &k, int t) {
-  constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : 3;
+  constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : (LB == 8 ? 3 : 4);
 #pragma unroll
   for (int i = NS3 - 1; i >= 0; --i) {
     const int d = 1 << (NS3 - 1 - i), G = 8 / d, m = 256 << i;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void row_body(typename P::T *c, const typename P::T *
                                          typename P::T *lds, const typename P::TW *tw, const typename P::MC &mcr, int t,
                                          bool store) {
   typedef typename P::T T;
-  constexpr int W = 16 * LB, LOGN = LB == 4 ? 10 : 11;
+  constexpr int W = 16 * LB, LOGN = LB == 4 ? 10 : (LB == 8 ? 11 : 12);
   const typename P::K k = P::make(mcr);
   const T *ar = a + (row << LOGN);
   T ra[16];
@@ -261,10 +261,10 @@ __device__ __forceinline__ void row_body(typename P::T *c, const typename P::T *
 }
 
 template <class P, int MODE, int LB>
-__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? (LB == 8 && MODE == 0 ? 4 : 5) : 2)) void k_row(
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? (LB >= 8 && MODE == 0 ? 4 : 5) : 2)) void k_row(
     typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::TW *__restrict__ psi,
     const typename P::MC *__restrict__ mc, int nm, size_t rows) {
-  constexpr int W = 16 * LB, RPB = 256 / W, LOGN = LB == 4 ? 10 : 11;  // rows per 256-thread block: 4 or 2
+  constexpr int W = 16 * LB, RPB = 256 / W, LOGN = LB == 4 ? 10 : (LB == 8 ? 11 : 12);  // rows per 256-thread block: 4, 2, 1
   __shared__ typename P::T slab[RPB][kSlabWords * (W / 64)];
   const int sub = threadIdx.x / W, t = threadIdx.x % W;
   size_t row = (size_t)blockIdx.x * RPB + sub;
@@ -333,12 +333,14 @@ static hipError_t launch_rows(const Shape &s, const DevTables &t, int mode, type
   return hipGetLastError();
 }
 
-// mode as in row_body; n = 1024 (one wave per row) or 2048 (two waves per row); hipErrorNotSupported otherwise
+// mode as in row_body; n = 1024 (one wave per row), 2048 (two waves per row) or, for 32-bit limbs, 4096 (a workgroup per
+// row; 64-bit limbs have the assembly kernels there); hipErrorNotSupported otherwise
 hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                               const uint32_t *b, size_t batch, hipStream_t st) {
   if (s.limb_bits != 32) return hipErrorNotSupported;
   if (s.logn == 10) return launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);
   if (s.logn == 11) return launch_rows<Pol32, 8>(s, t, mode, c, a, b, batch, st);
+  if (s.logn == 12) return launch_rows<Pol32, 16>(s, t, mode, c, a, b, batch, st);
   return hipErrorNotSupported;
 }
 hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,

@@ -21,6 +21,7 @@ SHAPES = [
     (32, 8, 2, 9),        # reference CONFIG (8,60,uint32_t)
     (32, 1024, 1, 3),     # BASELINE configs[0]
     (32, 1024, 2, 3),     # reference CONFIG (1024,60,uint32_t)
+    (32, 4096, 3, 3),     # 30-bit moduli, one workgroup per row
     (32, 32768, 1, 1),    # u32 kMaxPolyDegree
     (64, 4, 1, 7),
     (64, 8, 2, 5),
@@ -416,7 +417,7 @@ def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_fact
 
 
 @pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (64, 8192, 2), (64, 16384, 2), (64, 65536, 2), (32, 1024, 2), (64, 1024, 2),
-                                    (64, 2048, 1), (32, 2048, 1)])
+                                    (64, 2048, 1), (32, 2048, 1), (32, 4096, 2)])
 def test_adversarial_coefficient_values(lb, n, m, oracle_factory, engine_factory):
     """The tuned kernels lean on approximate quotients, two-bit folds and lazy ranges whose proofs are about extreme
     words: feed polynomials built from boundary values (0, 1, p-1, p-2, 2^k, 2^k - 1, runs and alternations of them)
