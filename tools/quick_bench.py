@@ -33,7 +33,16 @@ def child(batch, iters, workload):
     fa = e.ntt_(a[:64].clone())
     rt = e.intt_(fa.clone())
     ok = not e.any_neq(rt, a[:64].contiguous())
-    print(json.dumps({"ms": best, "polymul_per_s": batch / best * 1e3, "digest": digest_words(small),
+    def rate(fn, reps=10):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return batch / (e0.elapsed_time(e1) / reps * 1e-3)
+    fwd_rate, inv_rate = rate(lambda: e.ntt_(c)), rate(lambda: e.intt_(c))
+    print(json.dumps({"ms": best, "polymul_per_s": batch / best * 1e3, "ntt_per_s": fwd_rate, "intt_per_s": inv_rate, "digest": digest_words(small),
                       "ntt_digest": digest_words(e.to_host(fa)), "roundtrip_ok": ok}))
 
 
@@ -58,8 +67,9 @@ def main():
             ref = r
         same = r["digest"] == ref["digest"] and r["ntt_digest"] == ref["ntt_digest"]
         alg = {"B": 393216, "C": 3145728, "E": 47185920, "A": 12288, "A2": 24576, "A2K": 24576, "A4K": 196608, "R8": 393216, "H": 768, "S1": 49152, "S2": 49152, "R32": 1572864}[workload]
-        print("variant %4s  %8.3f ms  %10.0f polymul/s  %5.1f%% of 8TB/s  same_as_first=%s roundtrip=%s" % (
-            v, r["ms"], r["polymul_per_s"], r["polymul_per_s"] * alg / 8e12 * 100, same, r["roundtrip_ok"]))
+        print("variant %4s  %8.3f ms  %10.0f polymul/s  %5.1f%% of 8TB/s  fwd %.3g/s (%.2f TB/s)  inv %.3g/s (%.2f TB/s)  same_as_first=%s roundtrip=%s" % (
+            v, r["ms"], r["polymul_per_s"], r["polymul_per_s"] * alg / 8e12 * 100, r["ntt_per_s"], r["ntt_per_s"] * alg / 1.5e12,
+            r["intt_per_s"], r["intt_per_s"] * alg / 1.5e12, same, r["roundtrip_ok"]))
 
 
 if __name__ == "__main__":
