@@ -351,6 +351,7 @@ enum AsmKind {
   kAsmPolymul16k, kAsmPolymulNtt16k, kAsmFwd16k, kAsmInv16k,        // 16384-word blocks, 1024 threads
   kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
   kAsmPolymul8k, kAsmPolymulNtt8k, kAsmFwd8k, kAsmInv8k,            // 8192-word blocks, 512 threads
+  kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
   kAsmCount
 };
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
@@ -361,7 +362,8 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_polymul_ntt16384_asm", "nflhip_ntt_fwd16384_asm",
                                                  "nflhip_ntt_inv16384_asm",    "nflhip_polymul_pipe65536_asm",
                                                  "nflhip_polymul8192_asm",     "nflhip_polymul_ntt8192_asm",
-                                                 "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm"};
+                                                 "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm",
+                                                 "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -408,6 +410,26 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
   return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, is16k(kind) ? 1024 : (is8k(kind) ? 512 : kThreads), 1, 1, 0, st,
                                nullptr, extra);
+}
+
+// n = 4096 stand-alone transforms of a batch: two polynomials (same modulus) per workgroup, like the a / b operands of the
+// fused product -- twice the bytes in flight per workgroup and one set of twiddle loads for both rows.
+// NFLHIP_NTT_X2=0 disables it.
+static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *dst, const uint64_t *src,
+                                size_t batch, hipStream_t st) {
+  static const int enabled = getenv("NFLHIP_NTT_X2") ? atoi(getenv("NFLHIP_NTT_X2")) : 1;
+  if (!enabled || variant() < 50 || !s.small_delta || s.logn != kLogN || s.nm > 65535) return hipErrorNotSupported;
+  if (batch < 2 || batch > 0x7fffffffull) return hipErrorNotSupported;
+  hipFunction_t fn = asm_fn(kind);
+  if (!fn) return hipErrorNotSupported;
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    int nm, logn, count;
+  } args = {dst, src, nullptr, t.psi, t.mc, (int)s.nm, s.logn, (int)batch};
+  size_t size = 52;
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
 
 // rows of >= 16384 words: whole 16384-word blocks stay on one CU (global stages logn-14 .. logn-1 and back).
@@ -517,7 +539,8 @@ hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const u
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   if (rows % s.nm == 0) {  // the generated kernels index rows as (poly, modulus)
-    const hipError_t e = launch_asm(kAsmFwd, s, t, dst, src, nullptr, rows / s.nm, st);
+    hipError_t e = launch_asm_x2(kAsmFwd2, s, t, dst, src, rows / s.nm, st);
+    if (e == hipErrorNotSupported) e = launch_asm(kAsmFwd, s, t, dst, src, nullptr, rows / s.nm, st);
     if (e != hipErrorNotSupported) return e;
   }
   const Tw64 *psi = (const Tw64 *)t.psi;
@@ -537,7 +560,8 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   if (rows % s.nm == 0) {
-    const hipError_t e = launch_asm(mul ? kAsmInvMul : kAsmInv, s, t, dst, src, mul, rows / s.nm, st);
+    hipError_t e = mul ? hipErrorNotSupported : launch_asm_x2(kAsmInv2, s, t, dst, src, rows / s.nm, st);
+    if (e == hipErrorNotSupported) e = launch_asm(mul ? kAsmInvMul : kAsmInv, s, t, dst, src, mul, rows / s.nm, st);
     if (e != hipErrorNotSupported) return e;
   }
   const Tw64 *psi = (const Tw64 *)t.psi;

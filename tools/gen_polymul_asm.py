@@ -459,6 +459,17 @@ def prologue(em, vm, kind="polymul"):
     for s in sorted(set(V_T)):
         em.valu("v_mov_b32_e32 v%d, 0" % (s + 15,))                                 # the persistent zero of ZP
     R("s_waitcnt lgkmcnt(0)")
+    if kind in ("fwd2", "inv2"):
+        # two rows per workgroup (n = 4096 only): polynomials 2 wgx and 2 wgx + 1 of this modulus; the odd one out at
+        # the end of the batch is done twice (same words stored twice)
+        R("s_load_dword s86, s[0:1], 0x30")              # count
+        R("s_lshl_b32 s2, s2, 1")
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_add_u32 s87, s2, 1")
+        R("s_cmp_lt_u32 s87, s86")
+        R("s_cselect_b32 s86, s14, 0")                   # rows to the second polynomial: nm or 0
+        R("s_lshr_b32 s87, s86, 17")
+        R("s_lshl_b32 s86, s86, 15")                     # ... in bytes -> s[86:87] (consumed below)
     # r = logn - 12; wgx = poly * 2^r + blk; block = ((poly*nm + cm) << r) + blk; byte offset = block << 15
     R("s_sub_u32 s88, s88, 12")
     R("s_lshr_b32 s42, s2, s88")                         # poly
@@ -473,6 +484,11 @@ def prologue(em, vm, kind="polymul"):
     for base, row in ((6, 16), (8, 18), (4, 20)):
         R("s_add_u32 s%d, s%d, s42" % (row, base))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    if kind in ("fwd2", "inv2"):
+        R("s_add_u32 s18, s16, s86")                     # second source row
+        R("s_addc_u32 s19, s17, s87")
+        R("s_add_u32 s54, s20, s86")                     # second destination row (s[54:55] is free in the 4096-word map)
+        R("s_addc_u32 s55, s21, s87")
     # tw = psi + (cm << (logn + 4)) ; mc record = mc + cm*112
     R("s_add_u32 s43, s88, 16")
     R("s_lshl_b32 s42, s3, s43")
@@ -531,12 +547,18 @@ def prologue(em, vm, kind="polymul"):
         thread16_loads(V_B, S_BROW)
     elif kind == "fwd":
         row_loads(V_A, S_AROW)
+    elif kind == "fwd2":
+        row_loads(V_A, S_AROW)
+        row_loads(V_B, S_BROW)
     elif kind == "inv":
         lane_loads(V_A, S_AROW)
+    elif kind == "inv2":
+        lane_loads(V_A, S_AROW)
+        lane_loads(V_B, S_BROW)
     elif kind == "inv_mul":
         lane_loads(V_A, S_AROW)
         lane_loads(V_B, S_BROW)
-    first = "I1" if kind in ("inv", "inv_mul") else "F1"
+    first = "I1" if kind in ("inv", "inv_mul", "inv2") else "F1"
     tw_seq = {}
     for s in ((3, 2, 1, 0) if first == "I1" else (0, 1, 2, 3)):
         tw_seq[(first, s)] = PASS_TW[first](em, vm, s)
@@ -610,22 +632,24 @@ def epilogue_inverse(em, vm, last_plain_stage, suffix="", stride=2048):
     R("s_endpgm")
 
 
-def epilogue_forward(em, vm):
+def epilogue_forward(em, vm, end=True, base=None, dst=None):
     """canonical words, then a wave-local LDS transpose so the stores are fully coalesced"""
     R = em.raw
-    run_pairs(em, [canon(V_A + 2 * i) for i in range(16)])
-    lds_write(em, V_L2R, V_A, 8)
+    base = V_A if base is None else base
+    run_pairs(em, [canon(base + 2 * i) for i in range(16)])
+    lds_write(em, V_L2R, base, 8)
     g, l = lane_contig_setup(em)
     for j in range(16):
-        R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * j), l, 544 * j))
+        R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * j), l, 544 * j))
     R("s_waitcnt lgkmcnt(0)")
-    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
+    R("s_mov_b64 s[86:87], %s" % (S_CROW if dst is None else dst,))
     for j in range(16):
-        R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (g, vp(V_A + 2 * j), (j & 7) * 512))
+        R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (g, vp(base + 2 * j), (j & 7) * 512))
         if j == 7:
             R("s_add_u32 s86, s86, 0x1000")
             R("s_addc_u32 s87, s87, 0")
-    R("s_endpgm")
+    if end:
+        R("s_endpgm")
 
 
 def build(kind="polymul"):
@@ -638,10 +662,11 @@ def build(kind="polymul"):
 
 def build_body(em, vm, kind, tw_seq, suffix=""):
     R = em.raw
-    has_fwd = kind in ("polymul", "polymul_ntt", "fwd")
-    has_inv = kind != "fwd"
-    fwd_bases = [V_A, V_B] if kind == "polymul" else [V_A]
+    has_fwd = kind in ("polymul", "polymul_ntt", "fwd", "fwd2")
+    has_inv = kind not in ("fwd", "fwd2")
+    fwd_bases = [V_A, V_B] if kind in ("polymul", "fwd2") else [V_A]
     passes = (["F1", "F2", "F3"] if has_fwd else []) + (["I1", "I2", "I3"] if has_inv else [])
+    inv_bases = [V_A, V_B] if kind == "inv2" else [V_A]
 
     def nxt_of(name):
         i = passes.index(name)
@@ -661,7 +686,8 @@ def build_body(em, vm, kind, tw_seq, suffix=""):
         em.comment("%s; prefetching %s" % (name, nxt))
         for s in stages:
             vm.wait(tw_seq[(name, s)])
-            gs_stage(em, V_A, s)
+            for base in inv_bases:
+                gs_stage(em, base, s)
             if nxt is not None:
                 tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
 
@@ -686,35 +712,51 @@ def build_body(em, vm, kind, tw_seq, suffix=""):
     if kind == "fwd":
         epilogue_forward(em, vm)
         return em
+    if kind == "fwd2":
+        epilogue_forward(em, vm, end=False)
+        epilogue_forward(em, vm, base=V_B, dst="s[54:55]")
+        return em
 
     if kind in ("polymul", "polymul_ntt"):
         em.comment("point-wise product (thread q holds words 16q..16q+15 of both operands)")
         run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i, True, kind == "polymul") for i in range(16)])
     else:
-        R("s_waitcnt vmcnt(%d)" % (vm.issued - (32 if kind == "inv_mul" else 16)))   # the row loads have landed
+        R("s_waitcnt vmcnt(%d)" % (vm.issued - (32 if kind in ("inv_mul", "inv2") else 16)))   # the row loads have landed
         if kind == "inv_mul":
             em.comment("point-wise product of canonical NTT-form operands (any common layout works)")
             run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i, False, False) for i in range(16)])
         em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
         _, l = lane_contig_setup(em)
-        for j in range(16):
-            R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
-        lds_read(em, V_L2R, V_A, 8)
-        R("s_waitcnt lgkmcnt(0)")
+        for base in inv_bases:
+            for j in range(16):
+                R("ds_write_b64 v%d, %s offset:%d" % (l, vp(base + 2 * j), 544 * j))
+            lds_read(em, V_L2R, base, 8)
+            R("s_waitcnt lgkmcnt(0)")
 
     inv_pass("I1")
     em.comment("E2'")
-    lds_write(em, V_L2R, V_A, 8)
-    lds_read(em, V_L1R, V_A, 136)
-    R("s_waitcnt lgkmcnt(0)")
+    for base in inv_bases:
+        lds_write(em, V_L2R, base, 8)
+        lds_read(em, V_L1R, base, 136)
+        R("s_waitcnt lgkmcnt(0)")
     inv_pass("I2")
     em.comment("E1'")
-    lds_write(em, V_L1R, V_A, 136)
-    R("s_waitcnt lgkmcnt(0)")
-    R("s_barrier")
-    lds_read(em, V_L1W, V_A, 2176)
-    R("s_waitcnt lgkmcnt(0)")
+    for i, base in enumerate(inv_bases):
+        if i:
+            R("s_barrier")       # WAR: the slab is still being read for the previous row
+        lds_write(em, V_L1R, base, 136)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        lds_read(em, V_L1W, base, 2176)
+        R("s_waitcnt lgkmcnt(0)")
     inv_pass("I3", stages=(3, 2, 1))
+    if kind == "inv2":
+        em.comment("stage 0 with n^-1 folded in, both rows (n = 4096 only)")
+        for base, dst in ((V_A, S_CROW), (V_B, "s[54:55]")):
+            run_pairs(em, [final_bfly(base + 2 * h, base + 2 * (h + 8)) for h in range(8)])
+            strided_rows(em, None, base, dst, 2048, store=True)
+        R("s_endpgm")
+        return em
 
     def last_plain():
         vm.wait(tw_seq[("I3", 0)])
@@ -1376,6 +1418,8 @@ KERNELS = {   # kind -> (file suffix, kernel symbol)
     "fwd": ("ntt_fwd4096", "nflhip_ntt_fwd4096_asm"),
     "inv": ("ntt_inv4096", "nflhip_ntt_inv4096_asm"),
     "inv_mul": ("ntt_inv_mul4096", "nflhip_ntt_inv_mul4096_asm"),
+    "fwd2": ("ntt_fwd4096x2", "nflhip_ntt_fwd4096x2_asm"),
+    "inv2": ("ntt_inv4096x2", "nflhip_ntt_inv4096x2_asm"),
 }
 
 
@@ -1420,7 +1464,8 @@ def main():
     outdir = os.path.dirname(OUT)
     configure("pair")
     for kind, (stem, kname) in KERNELS.items():
-        emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind))
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind),
+                  args=ARGS_STD + [("i32", 48)] if kind in ("fwd2", "inv2") else None)
     emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
     configure("ring", 4)
     for kind, (stem, kname) in KERNELS16K.items():
