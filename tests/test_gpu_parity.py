@@ -485,3 +485,18 @@ def test_host_pointer_calls_of_many_sizes_match_the_resident_path(engine_factory
     e2 = engine_factory(16, 16, 1)  # 32-byte polynomials
     a = e2.fill_uniform(e2.empty(3), SEED, 0)
     assert np.array_equal(e2.h_intt(e2.h_ntt(e2.to_host(a))), e2.to_host(a))
+
+
+@pytest.mark.parametrize("lb,n,m,batch", [(64, 131072, 2, 2), (64, 262144, 1, 1), (64, 1048576, 1, 1), (32, 16384, 2, 2)])
+def test_degrees_beyond_the_baseline_shapes(lb, n, m, batch, oracle_factory, engine_factory):
+    """Up to params<uint64_t>::kMaxPolyDegree = 2^20 (params.hpp:98-99): two and more streaming passes around the
+    4096-word blocks; product, both transforms and the b-pre-transformed product against the oracle."""
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    a, b = _inputs(o, batch)
+    da, db = e.to_device(a), e.to_device(b)
+    want = o.polymul(a, b)
+    assert np.array_equal(e.to_host(e.polymul(da, db)), want)
+    f = e.ntt_(da.clone())
+    assert np.array_equal(e.to_host(f), o.ntt(a))
+    assert np.array_equal(e.to_host(e.intt_(f)), a)
+    assert np.array_equal(e.to_host(e.polymul(da, e.ntt_(db.clone()), b_is_ntt=True)), want)
