@@ -10,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -493,9 +494,16 @@ int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree
   c->shape.small_delta = 1;
   c->shape.logn = 0;
   while ((((size_t)1) << c->shape.logn) < degree) c->shape.logn++;
-  int rc = limb_bits == 16   ? build_tables<uint16_t>(c, P, primitive_roots, invkmax, kmax_log2)
-           : limb_bits == 32 ? build_tables<uint32_t>(c, P, primitive_roots, invkmax, kmax_log2)
-                             : build_tables<uint64_t>(c, P, primitive_roots, invkmax, kmax_log2);
+  int rc;
+  try {  // (host containers: no exception may cross the C boundary)
+    rc = limb_bits == 16   ? build_tables<uint16_t>(c, P, primitive_roots, invkmax, kmax_log2)
+         : limb_bits == 32 ? build_tables<uint32_t>(c, P, primitive_roots, invkmax, kmax_log2)
+                           : build_tables<uint64_t>(c, P, primitive_roots, invkmax, kmax_log2);
+  } catch (const std::bad_alloc &) {
+    rc = fail(nullptr, NFLHIP_ERR_NOMEM, "out of host memory while building the tables");
+  } catch (const std::exception &ex) {
+    rc = fail(nullptr, NFLHIP_ERR_INVALID, std::string("table construction failed: ") + ex.what());
+  }
   if (rc == NFLHIP_OK) {
     hipError_t se = hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking);
     for (int k = 0; k < 2 && se == hipSuccess; ++k) {
@@ -823,7 +831,11 @@ int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsig
   std::unique_ptr<nflhip_gauss> g(new (std::nothrow) nflhip_gauss());
   if (!g) return fail(ctx, NFLHIP_ERR_NOMEM, "out of host memory");
   std::string err;
-  if (build_gauss_table(sigma, security, samples, center, &g->tab, &err)) return fail(ctx, NFLHIP_ERR_INVALID, err);
+  try {
+    if (build_gauss_table(sigma, security, samples, center, &g->tab, &err)) return fail(ctx, NFLHIP_ERR_INVALID, err);
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, NFLHIP_ERR_NOMEM, "out of host memory while building the gaussian table");
+  }
   g->device = ctx->device;
   const size_t bytes = g->tab.cdt.size() * sizeof(uint64_t);
   HIPCHK(ctx, hipMalloc((void **)&g->d_cdt, bytes));
