@@ -86,6 +86,10 @@ hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords
 template <typename T>
 hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, int dist, uint64_t p0,
                          uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st);
+hipError_t launch_inner_fwd_fast_u32(const Shape &s, const DevTables &t, const uint32_t *src, uint32_t *dst, size_t rows,
+                                     hipStream_t st);
+hipError_t launch_inner_inv_fast_u32(const Shape &s, const DevTables &t, const uint32_t *src, const uint32_t *mul,
+                                     uint32_t *dst, size_t rows, hipStream_t st);
 hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *cdt, int words,
                               int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st);
 template <typename T>

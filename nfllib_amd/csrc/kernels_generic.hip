@@ -289,6 +289,10 @@ hipError_t launch_ntt_fwd(const Shape &s, const DevTables &t, const T *src, T *d
     hipError_t e = launch_inner_fwd_fast_u64(s, t, (const uint64_t *)cur, (uint64_t *)dst, rows, st);
     if (e != hipErrorNotSupported) return e;
   }
+  if (std::is_same<T, uint32_t>::value && logi == kInnerLogMax) {  // register-tiled 4096-word blocks, 30-bit moduli
+    hipError_t e = launch_inner_fwd_fast_u32(s, t, (const uint32_t *)cur, (uint32_t *)dst, rows, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   const unsigned nblk = (unsigned)(rows << (s.logn - logi));
   hipLaunchKernelGGL((k_ntt_fwd_lds<T>), dim3(nblk), dim3(lds_threads(logi)), sizeof(T) << logi, st, cur, dst,
                      (const Tw<T> *)t.psi, (const ModConst<T> *)t.mc, s.logn, logi, (int)s.nm);
@@ -304,6 +308,8 @@ hipError_t launch_ntt_inv(const Shape &s, const DevTables &t, const T *src, cons
   hipError_t e = hipErrorNotSupported;
   if (std::is_same<T, uint64_t>::value && logi == kInnerLogMax)  // register-tiled 4096-word blocks
     e = launch_inner_inv_fast_u64(s, t, (const uint64_t *)src, (const uint64_t *)mul, (uint64_t *)dst, rows, st);
+  if (std::is_same<T, uint32_t>::value && logi == kInnerLogMax)
+    e = launch_inner_inv_fast_u32(s, t, (const uint32_t *)src, (const uint32_t *)mul, (uint32_t *)dst, rows, st);
   if (e == hipErrorNotSupported) {
     const unsigned nblk = (unsigned)(rows << (s.logn - logi));
     hipLaunchKernelGGL((k_ntt_inv_lds<T>), dim3(nblk), dim3(lds_threads(logi)), sizeof(T) << logi, st, src, mul, dst,

@@ -104,7 +104,8 @@ template <int LB> __device__ __forceinline__ void row_sync() {
 // forward: r[q] = x[t + W q] on entry (any words), r[q] = NTT word 16 t + q on exit (lazy); W = 16 LB lanes per row
 template <class P, int LB>
 __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw, int t,
-                                        const typename P::K &k) {
+                                        const typename P::K &k, const unsigned kf = 1u) {
+  // kf = 2^r + blk: the row is block `blk` of a row 2^r times longer whose first r stages already ran (kf = 1: a whole row)
   constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : (LB == 8 ? 3 : 4);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -112,7 +113,7 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
     stage_fence();
 #pragma unroll
     for (int g = 0; g < (1 << s); ++g) {
-      const typename P::TW w = tw[(1 << s) + g];
+      const typename P::TW w = tw[(kf << s) + g];
 #pragma unroll
       for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
     }
@@ -129,7 +130,7 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
     stage_fence();
 #pragma unroll
     for (int g = 0; g < (1 << s); ++g) {
-      const typename P::TW w = tw[(16 << s) + (B << s) + g];
+      const typename P::TW w = tw[((16u * kf + B) << s) + g];
 #pragma unroll
       for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
     }
@@ -146,7 +147,7 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
     stage_fence();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const typename P::TW w = tw[(256 << i) + G * t + g];
+      const typename P::TW w = tw[((256u * kf) << i) + G * t + g];
 #pragma unroll
       for (int h = 0; h < d; ++h) P::ct(r[2 * d * g + h], r[2 * d * g + h + d], w, k);
     }
@@ -156,15 +157,18 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
 // inverse: r[q] = NTT word 16 t + q (< 2p) on entry, r[q] = x[t + W q] canonical on exit
 template <class P, int LB>
 __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *lds, const typename P::TW *tw,
-                                        const typename P::MC &c, const typename P::K &k, int t) {
+                                        const typename P::MC &c, const typename P::K &k, int t, const unsigned ki = 2u,
+                                        const bool plain_last = false) {
+  // ki = 2^(r+1) - blk (mirrored indices of block blk); plain_last: stages r-1 .. 0 follow elsewhere, so the block's last
+  // stage is an ordinary one (twiddle psi[ki - 1]) and the words stay lazy (< 2p)
   constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : (LB == 8 ? 3 : 4);
 #pragma unroll
   for (int i = NS3 - 1; i >= 0; --i) {
-    const int d = 1 << (NS3 - 1 - i), G = 8 / d, m = 256 << i;
+    const int d = 1 << (NS3 - 1 - i), G = 8 / d;
     stage_fence();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const typename P::TW w = tw[m + (m - 1 - (G * t + g))];
+      const typename P::TW w = tw[((256u * ki) << i) - 1u - (unsigned)(G * t + g)];
 #pragma unroll
       for (int h = 0; h < d; ++h) P::gs(r[2 * d * g + h], r[2 * d * g + h + d], w, k);
     }
@@ -178,11 +182,11 @@ __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *l
   for (int q = 0; q < 16; ++q) r[q] = lds[pad2(BS * B + LB * q + l)];
 #pragma unroll
   for (int s = 3; s >= 0; --s) {
-    const int half = 8 >> s, m = 16 << s;
+    const int half = 8 >> s;
     stage_fence();
 #pragma unroll
     for (int g = 0; g < (1 << s); ++g) {
-      const typename P::TW w = tw[m + (m - 1 - ((B << s) + g))];
+      const typename P::TW w = tw[((16u * ki) << s) - 1u - (unsigned)((B << s) + g)];
 #pragma unroll
       for (int h = 0; h < half; ++h) P::gs(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
     }
@@ -195,37 +199,50 @@ __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *l
   for (int q = 0; q < 16; ++q) r[q] = lds[pad1<LB>(t + W * q)];
 #pragma unroll
   for (int s = 3; s >= 1; --s) {
-    const int half = 8 >> s, m = 1 << s;
+    const int half = 8 >> s;
     stage_fence();
 #pragma unroll
     for (int g = 0; g < (1 << s); ++g) {
-      const typename P::TW w = tw[m + (m - 1 - g)];
+      const typename P::TW w = tw[(ki << s) - 1u - (unsigned)g];
 #pragma unroll
       for (int h = 0; h < half; ++h) P::gs(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
     }
   }
+  if (plain_last) {
+    const typename P::TW w = tw[ki - 1u];
 #pragma unroll
-  for (int h = 0; h < 8; ++h) P::last(r[h], r[h + 8], c, k);  // last stage with n^-1 folded in; canonical outputs
+    for (int h = 0; h < 8; ++h) P::gs(r[h], r[h + 8], w, k);
+  } else {
+#pragma unroll
+    for (int h = 0; h < 8; ++h) P::last(r[h], r[h + 8], c, k);  // last stage with n^-1 folded in; canonical outputs
+  }
 }
 
-// MODE 0: c = INTT(NTT(a) (.) NTT(b));  1: the same with b already in NTT form;  2: dst = NTT(a);  3: dst = INTT(a)
+// MODE 0: c = INTT(NTT(a) (.) NTT(b));  1: the same with b already in NTT form;  2: dst = NTT(a);  3: dst = INTT(a);
+//      4: dst = INTT(a (.) b), both in NTT form (the inner inverse of the composed plan of long rows)
 // `store` = false: a surplus row of the last workgroup (it walks through every barrier, writes nothing)
 template <class P, int MODE, int LB>
 __device__ __forceinline__ void row_body(typename P::T *c, const typename P::T *a, const typename P::T *b, size_t row,
                                          typename P::T *lds, const typename P::TW *tw, const typename P::MC &mcr, int t,
-                                         bool store) {
+                                         bool store, const unsigned kf = 1u, const unsigned ki = 2u,
+                                         const bool plain_last = false) {
   typedef typename P::T T;
   constexpr int W = 16 * LB, LOGN = LB == 4 ? 10 : (LB == 8 ? 11 : 12);
   const typename P::K k = P::make(mcr);
   const T *ar = a + (row << LOGN);
   T ra[16];
-  if (MODE == 3) {  // NTT-form input: thread holds words 16 t .. 16 t + 15
+  if (MODE == 3 || MODE == 4) {  // NTT-form input: thread holds words 16 t .. 16 t + 15
 #pragma unroll
     for (int q = 0; q < 16; ++q) ra[q] = ar[16 * t + q];
+    if (MODE == 4) {
+      const T *br = b + (row << LOGN);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ra[q] = P::mul(ra[q], br[16 * t + q], k);
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < 16; ++j) ra[j] = ar[t + W * j];
-    fwd_row<P, LB>(ra, lds, tw, t, k);
+    fwd_row<P, LB>(ra, lds, tw, t, k, kf);
   }
   if (MODE == 2) {
     T *o = c + (row << LOGN) + 16 * t;
@@ -252,7 +269,7 @@ __device__ __forceinline__ void row_body(typename P::T *c, const typename P::T *
 #pragma unroll
     for (int j = 0; j < 16; ++j) ra[j] = P::mul(ra[j], rb[j], k);
   }
-  inv_row<P, LB>(ra, lds, tw, mcr, k, t);
+  inv_row<P, LB>(ra, lds, tw, mcr, k, t, ki, plain_last);
   T *cr = c + (row << LOGN);
   if (store) {
 #pragma unroll
@@ -275,6 +292,21 @@ __global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? ((LB >= 8 && MOD
   }
   const int cm = (int)(row % (size_t)nm);
   row_body<P, MODE, LB>(c, a, b, row, slab[sub], psi + ((size_t)cm << LOGN), mc[cm], t, live);
+}
+
+// 4096-word blocks of longer rows (LB = 16): block = row * 2^r + blk runs global stages r .. r + 11 of its row (forward,
+// MODE 2) or r + 11 .. r (inverse, MODES 3 / 4), the streaming passes of kernels_generic.hip do stages 0 .. r - 1.
+template <class P, int MODE>
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : 2)) void k_row_block(
+    typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::TW *__restrict__ psi,
+    const typename P::MC *__restrict__ mc, int nm, int logn) {
+  __shared__ typename P::T slab[kSlabWords * 4];
+  const int r = logn - 12;
+  const size_t block = blockIdx.x, row = block >> r;
+  const unsigned blk = (unsigned)(block & ((((size_t)1) << r) - 1));
+  const int cm = (int)(row % (size_t)nm);
+  row_body<P, MODE, 16>(c, a, b, block, slab, psi + ((size_t)cm << logn), mc[cm], threadIdx.x, true, (1u << r) + blk,
+                        (2u << r) - blk, r > 0);
 }
 
 // Persistent variant for one-wave rows and few moduli (NMT <= 4 tables): the twiddle tables are copied into LDS once
@@ -343,6 +375,32 @@ hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint
   if (s.logn == 12) return launch_rows<Pol32, 16>(s, t, mode, c, a, b, batch, st);
   return hipErrorNotSupported;
 }
+// 4096-word blocks of rows longer than 4096 words, 32-bit limbs: the inner kernels of launch_ntt_fwd / launch_ntt_inv
+hipError_t launch_inner_fwd_fast_u32(const Shape &s, const DevTables &t, const uint32_t *src, uint32_t *dst, size_t rows,
+                                     hipStream_t st) {
+  if (s.limb_bits != 32 || s.logn <= 12) return hipErrorNotSupported;
+  const size_t blocks = rows << (s.logn - 12);
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_row_block<Pol32, 2>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, (const uint32_t *)nullptr,
+                     (const Tw32 *)t.psi, (const MC32 *)t.mc, (int)s.nm, s.logn);
+  return hipGetLastError();
+}
+hipError_t launch_inner_inv_fast_u32(const Shape &s, const DevTables &t, const uint32_t *src, const uint32_t *mul,
+                                     uint32_t *dst, size_t rows, hipStream_t st) {
+  if (s.limb_bits != 32 || s.logn <= 12) return hipErrorNotSupported;
+  const size_t blocks = rows << (s.logn - 12);
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  if (mul)
+    hipLaunchKernelGGL((k_row_block<Pol32, 4>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, mul, (const Tw32 *)t.psi,
+                       (const MC32 *)t.mc, (int)s.nm, s.logn);
+  else
+    hipLaunchKernelGGL((k_row_block<Pol32, 3>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, (const uint32_t *)nullptr,
+                       (const Tw32 *)t.psi, (const MC32 *)t.mc, (int)s.nm, s.logn);
+  return hipGetLastError();
+}
+
 hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
                               const uint64_t *b, size_t batch, hipStream_t st) {
   if (s.limb_bits != 64 || !s.small_delta) return hipErrorNotSupported;

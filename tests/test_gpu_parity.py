@@ -22,6 +22,7 @@ SHAPES = [
     (32, 1024, 1, 3),     # BASELINE configs[0]
     (32, 1024, 2, 3),     # reference CONFIG (1024,60,uint32_t)
     (32, 4096, 3, 3),     # 30-bit moduli, one workgroup per row
+    (32, 8192, 2, 3),     # 30-bit moduli, streaming pass + 4096-word blocks
     (32, 32768, 1, 1),    # u32 kMaxPolyDegree
     (64, 4, 1, 7),
     (64, 8, 2, 5),
