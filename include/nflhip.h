@@ -221,6 +221,10 @@ typedef struct nflhip_gauss nflhip_gauss;
 int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsigned security, unsigned samples,
                         double center);
 int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g);
+/* the same table without a device (host arithmetic only: what nflhip_gauss_create uploads); h_table may be NULL to
+ * query the sizes first, cap_words = capacity of h_table in 64-bit words */
+int nflhip_gauss_table(double sigma, unsigned security, unsigned samples, double center, long long *x_min, size_t *entries,
+                       int *words, unsigned *bit_precision, double *tail, uint64_t *h_table, size_t cap_words);
 /* introspection: support [x_min, x_min + entries), words per entry, the reference's bit_precision and tail bound;
  * h_table (may be NULL) receives entries*words 64-bit words, most significant word of an entry first */
 int nflhip_gauss_info(const nflhip_gauss *g, long long *x_min, size_t *entries, int *words, unsigned *bit_precision,

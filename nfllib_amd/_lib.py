@@ -53,6 +53,8 @@ SYMBOLS = [
     ("nflhip_random_words_dev", _i, [_vp, _vp, _u64, _sz, _vp, _u64, _vp]),
     ("nflhip_gauss_create", _i, [_vp, C.POINTER(_vp), C.c_double, C.c_uint, C.c_uint, C.c_double]),
     ("nflhip_gauss_destroy", _i, [_vp, _vp]),
+    ("nflhip_gauss_table", _i, [C.c_double, C.c_uint, C.c_uint, C.c_double, C.POINTER(C.c_longlong), C.POINTER(_sz), C.POINTER(_i),
+                               C.POINTER(C.c_uint), C.POINTER(C.c_double), _vp, _sz]),
     ("nflhip_gauss_info", _i, [_vp, C.POINTER(C.c_longlong), C.POINTER(_sz), C.POINTER(_i), C.POINTER(C.c_uint),
                                C.POINTER(C.c_double), _vp]),
     ("nflhip_sample_gauss_dev", _i, [_vp, _vp, _sz, _sz, _vp, _u64, _vp, _u64, _vp]),

@@ -848,6 +848,27 @@ int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsig
   return NFLHIP_OK;
 }
 
+int nflhip_gauss_table(double sigma, unsigned security, unsigned samples, double center, long long *x_min, size_t *entries,
+                       int *words, unsigned *bit_precision, double *tail, uint64_t *h_table, size_t cap_words) {
+  GaussTable tab;
+  std::string err;
+  try {
+    if (build_gauss_table(sigma, security, samples, center, &tab, &err)) return fail(nullptr, NFLHIP_ERR_INVALID, err);
+  } catch (const std::bad_alloc &) {
+    return fail(nullptr, NFLHIP_ERR_NOMEM, "out of host memory while building the gaussian table");
+  }
+  if (x_min) *x_min = tab.x_min;
+  if (entries) *entries = tab.entries;
+  if (words) *words = tab.words;
+  if (bit_precision) *bit_precision = tab.bit_precision;
+  if (tail) *tail = tab.tail;
+  if (h_table) {
+    if (cap_words < tab.cdt.size()) return fail(nullptr, NFLHIP_ERR_INVALID, "output buffer too small");
+    std::memcpy(h_table, tab.cdt.data(), tab.cdt.size() * sizeof(uint64_t));
+  }
+  return NFLHIP_OK;
+}
+
 int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g) {
   if (!g) return NFLHIP_OK;
   if (ctx) (void)hipSetDevice(ctx->device);

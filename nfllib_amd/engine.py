@@ -296,3 +296,20 @@ class Engine:
         n = C.c_size_t(0)
         self._chk(self.lib.nflhip_get_crt_constant(self.ctx, what, cm, _vp(buf), buf.size, C.byref(n)))
         return int.from_bytes(buf[:n.value].tobytes(), "little")
+
+
+def gauss_table(sigma, security=128, samples=1024, center=0.0):
+    """The cumulative table of nflhip_gauss_create, built on the host (no device needed): dict like Engine.gauss_info."""
+    from ._lib import load
+    lib = load()
+    x_min, entries, words, bits, tail = C.c_longlong(), C.c_size_t(), C.c_int(), C.c_uint(), C.c_double()
+    rc = lib.nflhip_gauss_table(sigma, security, samples, center, C.byref(x_min), C.byref(entries), C.byref(words), C.byref(bits),
+                                C.byref(tail), None, 0)
+    if rc:
+        raise NflHipError(rc, lib.nflhip_last_error(None).decode())
+    tab = np.zeros((entries.value, words.value), dtype=np.uint64)
+    rc = lib.nflhip_gauss_table(sigma, security, samples, center, None, None, None, None, None, tab.ctypes.data_as(C.c_void_p), tab.size)
+    if rc:
+        raise NflHipError(rc, lib.nflhip_last_error(None).decode())
+    return {"x_min": x_min.value, "entries": entries.value, "words": words.value, "bit_precision": bits.value,
+            "tail": tail.value, "table": tab}

@@ -196,6 +196,26 @@ def ref_available():
     return os.path.exists(REF_PATH)
 
 
+def ref_gauss_barriers(sigma, security, samples, center=0.0):
+    """The cumulative table the REAL reference builds for FastGaussianNoise<uint8_t, uint64_t, 2>(sigma, security, samples,
+    center) (oracle/ref_gauss_shim.cpp): (bit_precision, rounded_center, [barrier_0, ...] as Python ints of that many
+    bits); None when this build of the reference library lacks the entry point."""
+    L = _load(REF_PATH)
+    if not hasattr(L, "nflref_gauss_barriers"):
+        return None
+    L.nflref_gauss_barriers.restype = C.c_long
+    L.nflref_gauss_barriers.argtypes = [C.c_double, C.c_uint, C.c_uint, C.c_double, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+    bp, wp, nb, rc = C.c_uint(), C.c_uint(), C.c_uint(), C.c_int()
+    need = -L.nflref_gauss_barriers(sigma, security, samples, center, None, 0, C.byref(bp), C.byref(wp), C.byref(nb), C.byref(rc))
+    buf = np.zeros(need, dtype=np.uint8)
+    got = L.nflref_gauss_barriers(sigma, security, samples, center, buf.ctypes.data, buf.size, C.byref(bp), C.byref(wp),
+                                  C.byref(nb), C.byref(rc))
+    assert got == need
+    rows = buf.reshape(nb.value, wp.value)
+    return bp.value, rc.value, [int.from_bytes(bytes(r), "big") for r in rows]
+
+
 class Reference:
     """The REAL reference (one poly at a time), through oracle/ref_shim.cpp."""
 

@@ -90,3 +90,26 @@ def test_rules_match_live_reference():
         assert np.array_equal(S.non_uniform(raw.view(np.uint64), P, 37, 5), out)
         out, raw = ref.sample_replay(2, 0x7F)
         assert np.array_equal(S.zo_dist(raw, P, 0x7F, canonical=False), out)
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="needs oracle/_ref (the real reference)")
+@pytest.mark.parametrize("sigma,security,center", [(3.19, 128, 0.0), (3.19, 64, 0.0), (20.0, 128, 0.0), (215.0, 100, 0.0), (4.0, 80, 2.5)])
+def test_gaussian_table_against_the_real_references_barriers(sigma, security, center):
+    """The engine's cumulative table (host arithmetic of gauss_table.cpp: floor(2^(64 W) * CDF), 192-bit fixed point) vs
+    the table the REAL reference computes with MPFR at its bit precision (round(CDF * (2^bp - 1)), one rounding per
+    accumulated term): same support, same bit precision, and every entry equal to within the reference's own rounding
+    noise -- a few units in the LAST of its bp bits per accumulated term."""
+    from nfllib_amd.engine import gauss_table
+    ref = O.ref_gauss_barriers(sigma, security, 1024, center)
+    if ref is None:
+        pytest.skip("this prebuilt reference library predates nflref_gauss_barriers")
+    bp, rounded_center, bar = ref
+    t = gauss_table(sigma, security, 1024, center)
+    # (the reference rounds its precision up to whole in_class words -- bytes here, FastGaussianNoise.hpp:262-272)
+    assert -(-t["bit_precision"] // 8) * 8 == bp and t["entries"] == len(bar)
+    assert t["x_min"] == rounded_center - (len(bar) - 1) // 2          # FastGaussianNoise.hpp:323
+    W = t["words"]
+    ours = [int.from_bytes(b"".join(int(v).to_bytes(8, "big") for v in row), "big") >> (64 * W - bp) for row in t["table"]]
+    worst = max(abs(a - b) for a, b in zip(ours[:-1], bar[:-1]))       # (the engine's last entry is all ones by definition)
+    assert worst <= len(bar) + 4, worst
+    assert bar[-1] >= (1 << bp) - len(bar) - 4                         # the reference's last barrier is ~ 2^bp - 1
