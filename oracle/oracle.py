@@ -216,6 +216,27 @@ def ref_gauss_barriers(sigma, security, samples, center=0.0):
     return bp.value, rc.value, [int.from_bytes(bytes(r), "big") for r in rows]
 
 
+def ref_gauss_replay(sigma, security, samples, center, rlen):
+    """Fork-replay of the REAL FastGaussianNoise<uint8_t, uint64_t, 2>::getNoise: (samples int64[rlen], raw uint8
+    [3, call_bytes] -- the buffers its fastrandombytes() calls would return, in order --, call_words); None when the
+    prebuilt reference library lacks the entry point."""
+    L = _load(REF_PATH)
+    if not hasattr(L, "nflref_gauss_replay"):
+        return None
+    L.nflref_gauss_replay.restype = C.c_long
+    L.nflref_gauss_replay.argtypes = [C.c_double, C.c_uint, C.c_uint, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    cb, cw = C.c_uint64(), C.c_uint64()
+    out = np.zeros(rlen, dtype=np.int64)
+    need = -L.nflref_gauss_replay(sigma, security, samples, center, rlen, out.ctypes.data, None, 0, C.byref(cb), C.byref(cw))
+    raw = np.zeros(need, dtype=np.uint8)
+    got = L.nflref_gauss_replay(sigma, security, samples, center, rlen, out.ctypes.data, raw.ctypes.data, raw.size,
+                                C.byref(cb), C.byref(cw))
+    if got != need:
+        raise RuntimeError("nflref_gauss_replay failed")
+    return out, raw.reshape(3, cb.value), cw.value
+
+
 class Reference:
     """The REAL reference (one poly at a time), through oracle/ref_shim.cpp."""
 

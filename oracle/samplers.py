@@ -145,3 +145,34 @@ def gaussian_from_table(r_words, table, x_min):
         val = int.from_bytes(b"".join(int(v).to_bytes(8, "big") for v in row), "big")
         out[i] = x_min + bisect.bisect_right(tab, val)
     return out.reshape(np.asarray(r_words).shape[:-1])
+
+
+def gaussian_reference_decode(raw_calls, call_words, barriers, wp, rlen, x0):
+    """What FastGaussianNoise<uint8_t, ., 2>::getNoise (FastGaussianNoise.hpp:477-595) makes of its uniform bytes, stated
+    as inversion: a sample is x0 + #{barriers <= noise}; the reference looks at one byte, at two if some barrier starts
+    with that byte, and at the full wp-byte number only if some barrier starts with those two, and it starts a fresh
+    buffer (the next fastrandombytes call) as soon as fewer than wp bytes + 1 are left of the current one.
+    raw_calls: [ncalls, call_bytes] uint8; barriers: ascending list of wp-byte big-endian bytes objects.
+    Returns (samples, prefixes): the values and the bytes each one consumed."""
+    import bisect
+    first = {b[0] for b in barriers}
+    first2 = {(b[0], b[1]) for b in barriers}
+    out, prefixes = [], []
+    call, pos, used = 0, 0, 0
+    while len(out) < rlen:
+        buf = raw_calls[call]
+        b1 = int(buf[pos])
+        if b1 not in first:
+            k = 1
+        elif (b1, int(buf[pos + 1])) not in first2:
+            k = 2
+        else:
+            k = wp
+        pre = bytes(buf[pos:pos + k])
+        out.append(x0 + bisect.bisect_right(barriers, pre + b"\xff" * (wp - k)))
+        prefixes.append(pre)
+        pos += k
+        used += k
+        if used + wp >= call_words:
+            call, pos, used = call + 1, 0, 0
+    return np.array(out, dtype=np.int64), prefixes

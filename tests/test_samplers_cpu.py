@@ -113,3 +113,31 @@ def test_gaussian_table_against_the_real_references_barriers(sigma, security, ce
     worst = max(abs(a - b) for a, b in zip(ours[:-1], bar[:-1]))       # (the engine's last entry is all ones by definition)
     assert worst <= len(bar) + 4, worst
     assert bar[-1] >= (1 << bp) - len(bar) - 4                         # the reference's last barrier is ~ 2^bp - 1
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="needs oracle/_ref (the real reference)")
+@pytest.mark.parametrize("sigma,security,center", [(3.19, 128, 0.0), (20.0, 64, 0.0), (4.0, 80, 2.5)])
+def test_reference_getnoise_is_the_inversion_the_engine_implements(sigma, security, center):
+    """Fork-replay of the REAL getNoise: (1) its samples are exactly the inversion of its own cumulative table on the
+    bytes it consumed (so the restated rule is the reference's), and (2) the engine's rule -- inversion through the
+    engine's table of a W-word number -- gives the same integer for EVERY completion of those bytes (checked on the
+    all-zeros and all-ones completions), i.e. both samplers compute the same function of the uniform number."""
+    from nfllib_amd.engine import gauss_table
+    rep = O.ref_gauss_replay(sigma, security, 1024, center, 4096)
+    ref = O.ref_gauss_barriers(sigma, security, 1024, center)
+    if rep is None or ref is None:
+        pytest.skip("this prebuilt reference library predates the gaussian entry points")
+    got, raw, call_words = rep
+    bp, rounded_center, bar = ref
+    wp = bp // 8
+    bars = [b.to_bytes(wp, "big") for b in bar]
+    x0 = rounded_center - (len(bar) - 1) // 2
+    want, prefixes = S.gaussian_reference_decode(raw, call_words, bars, wp, got.size, x0)
+    assert np.array_equal(got, want), "the reference's samples are not the inversion of its table on these bytes"
+    assert {len(p) for p in prefixes} >= {1, 2}            # both short paths were taken (the full one is rare)
+    t = gauss_table(sigma, security, 1024, center)
+    W = t["words"]
+    for pad in (b"\x00", b"\xff"):
+        r = np.array([[int.from_bytes((p + pad * (8 * W - len(p)))[8 * k:8 * k + 8], "big") for k in range(W)] for p in prefixes],
+                     dtype=np.uint64)
+        assert np.array_equal(S.gaussian_from_table(r, t["table"], t["x_min"]), got)
