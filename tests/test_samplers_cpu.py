@@ -141,3 +141,27 @@ def test_reference_getnoise_is_the_inversion_the_engine_implements(sigma, securi
         r = np.array([[int.from_bytes((p + pad * (8 * W - len(p)))[8 * k:8 * k + 8], "big") for k in range(W)] for p in prefixes],
                      dtype=np.uint64)
         assert np.array_equal(S.gaussian_from_table(r, t["table"], t["x_min"]), got)
+
+
+def test_gaussian_fixtures_from_the_real_reference():
+    """The same two checks on committed fixtures (tests/golden/gauss_replay.npz, tools/gen_golden_gauss.py), so they run
+    on hosts without the reference: table against the real barriers, rule against a real getNoise replay."""
+    from nfllib_amd.engine import gauss_table
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "gauss_replay.npz"))
+    for k, (sigma, security, center) in enumerate(G["sets"]):
+        bp, rounded_center, call_words = (int(x) for x in G["%d/meta" % k])
+        bars = [bytes(r) for r in G["%d/barriers" % k]]
+        wp, nb = bp // 8, len(bars)
+        got = G["%d/out" % k]
+        x0 = rounded_center - (nb - 1) // 2
+        want, prefixes = S.gaussian_reference_decode(G["%d/raw" % k], call_words, bars, wp, got.size, x0)
+        assert np.array_equal(got, want)
+        t = gauss_table(float(sigma), int(security), 1024, float(center))
+        W = t["words"]
+        assert -(-t["bit_precision"] // 8) * 8 == bp and t["entries"] == nb and t["x_min"] == x0
+        ours = [int.from_bytes(b"".join(int(v).to_bytes(8, "big") for v in row), "big") >> (64 * W - bp) for row in t["table"]]
+        assert max(abs(a - int.from_bytes(b, "big")) for a, b in zip(ours[:-1], bars[:-1])) <= nb + 4
+        for pad in (b"\x00", b"\xff"):
+            r = np.array([[int.from_bytes((p + pad * (8 * W - len(p)))[8 * j:8 * j + 8], "big") for j in range(W)] for p in prefixes],
+                         dtype=np.uint64)
+            assert np.array_equal(S.gaussian_from_table(r, t["table"], t["x_min"]), got)
