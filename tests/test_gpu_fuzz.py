@@ -65,6 +65,40 @@ def test_random_shapes_and_operations(shape, batch, seed, ops, alias, oracle_fac
         assert np.array_equal(e.to_host(e.crt_project(e.crt_lift(da))), a)
 
 
+@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(shape=_shape, batch=st.integers(1, 6), first=st.integers(0, 1000), sid=st.integers(0, 2**64 - 1), ub=st.integers(1, 1 << 13),
+       amp=st.integers(1, 4), rho=st.integers(0, 255), key=st.binary(min_size=32, max_size=32), sigma=st.sampled_from([2.0, 3.19, 20.0]),
+       sec=st.sampled_from([20, 64, 100]))
+def test_random_sampler_calls(shape, batch, first, sid, ub, amp, rho, key, sigma, sec, engine_factory):
+    """The random constructors on random shapes, shards (first_poly), stream ids and keys against the restated rules
+    fed with the very keystream words (oracle/samplers.py, pinned on the real reference)."""
+    from nfllib_amd import DIST_BOUNDED, DIST_UNIFORM, DIST_ZO
+    from oracle import samplers as S
+    lb, logn, m = shape
+    n = 1 << logn
+    e = engine_factory(lb, n, m)
+    P = [int(e.table(1, cm)[0]) for cm in range(m)]
+    dt = e.np_dtype
+    mask = {16: 0xFFFF, 32: 0xFFFFFFFF, 64: 0xFFFFFFFFFFFFFFFF}[lb]
+    words = (S.chacha20_words(key, sid, first * m * n, batch * m * n) & np.uint64(mask)).astype(dt).reshape(batch, m, n)
+    got = e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, key, stream_id=sid, first_poly=first))
+    assert np.array_equal(got, S.uniform(words, P))
+    cw = S.chacha20_words(key, sid, first * n, batch * n).reshape(batch, n)
+    if ub * amp < min(P) // 2:
+        d = e.sample(e.empty(batch), DIST_BOUNDED, key, stream_id=sid, param0=ub, param1=amp, first_poly=first)
+        assert np.array_equal(e.to_host(d), S.non_uniform(cw, P, ub, amp, dtype=dt))
+    d = e.sample(e.empty(batch), DIST_ZO, key, stream_id=sid, param0=rho, first_poly=first)
+    assert np.array_equal(e.to_host(d), S.zo_dist(cw & np.uint64(0xFF), P, rho, canonical=True, dtype=dt))
+    if lb == 16 and sigma > 3.2:
+        return                                           # +-13 sigma does not fit below p/2 of a 14-bit modulus
+    g = e.gauss_create(sigma, security=sec, samples=1024)
+    info = e.gauss_info(g)
+    v = S.centered(e.to_host(e.sample_gauss(e.empty(batch), g, key, stream_id=sid, first_poly=first)), P)[:, 0].reshape(-1)
+    r = S.gaussian_words(key, sid, first * n, batch * n, info["words"])
+    assert np.array_equal(v, S.gaussian_from_table(r, info["table"], info["x_min"]))
+    e.gauss_destroy(g)
+
+
 def test_the_walk_was_wide():
     """(runs after the fuzz above) every limb width and both ends of the degree range were visited"""
     assert len(_RAN) >= 100
