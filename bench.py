@@ -34,8 +34,10 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
-def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0):
-    """Time the CPU path on this host on a bounded sample of the same workload.
+def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0, check=None):
+    """Time the CPU path on this host on a bounded sample of the same workload (median of 5 repetitions,
+    BASELINE.md section 3).  `check` = (a, b, c) host copies of a few polynomials of the timed batch: the checker also
+    recomputes those products and reports whether the GPU's words are identical (`parity_sample_ok`).
     kind "reference": the REAL NFLlib (oracle/_ref/libnflref.so, prebuilt in the
     build container from /root/reference's own sources) when it loads here;
     otherwise kind "port": oracle/nfl_oracle.c, rebuilt -march=native on this host."""
@@ -54,16 +56,24 @@ def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0):
     o = O.Oracle(limb_bits, degree, nmoduli, params(limb_bits), libpath=libpath)
     gen = o.fill_uniform
 
+    REPS = 5
+
     def run(fn, label):
         a, b = gen(8, SEED, 0), gen(8, SEED, 1)
+        fn(a, b)                                                    # warm-up (tables, page faults)
         t0 = time.perf_counter(); fn(a, b); dt = time.perf_counter() - t0
-        chunk = max(8, min(512, int(8 * 1.0 / max(dt, 1e-6))))
+        chunk = max(1, min(512, int(8 * 0.5 / max(dt, 1e-6))))      # ~0.5 s of work per call
         a, b = gen(chunk, SEED, 0), gen(chunk, SEED, 1)
-        done, t_used = 0, 0.0
-        while t_used < budget_s:
-            t0 = time.perf_counter(); fn(a, b); t_used += time.perf_counter() - t0
-            done += chunk
-        return {"value": done / t_used, "sample": "%d polymuls (%s) in %.1f s, 1 thread" % (done, label, t_used)}
+        rates, done, t_all = [], 0, 0.0
+        for _ in range(REPS):
+            d_r, t_r = 0, 0.0
+            while t_r < budget_s / REPS:
+                t0 = time.perf_counter(); fn(a, b); t_r += time.perf_counter() - t0
+                d_r += chunk
+            rates.append(d_r / t_r); done += d_r; t_all += t_r
+        rates.sort()
+        return {"value": rates[REPS // 2], "min": rates[0], "max": rates[-1],
+                "sample": "median of %d repetitions, %d polymuls (%s) in %.1f s, 1 thread" % (REPS, done, label, t_all)}
 
     port = run(o.polymul, "oracle/nfl_oracle.c -O3 -march=native" if libpath else "oracle/nfl_oracle.c -O3 x86-64-v3")
     ref = None
@@ -75,7 +85,13 @@ def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0):
         ref = None
     best = ref or port
     out = {"value": round(best["value"], 2), "unit": "polymul/s", "cores": 1, "kind": "reference" if ref else "port",
-           "sample": best["sample"], "port_value": round(port["value"], 2)}
+           "sample": best["sample"], "spread": [round(best["min"], 2), round(best["max"], 2)],
+           "port_value": round(port["value"], 2)}
+    if check is not None:
+        import numpy as np
+        ha, hb, hc = check
+        out["parity_sample_ok"] = bool(np.array_equal(o.polymul(ha, hb), hc))
+        out["parity_sample"] = "%d polynomials of the timed batch recomputed by the CPU checker, bit-exact compare" % ha.shape[0]
     # socket-level figure for an honest comparison: the same port with the batch split
     # over every host thread (native pthreads inside the oracle library; polys are independent)
     try:
@@ -101,6 +117,46 @@ def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0):
     return out
 
 
+def measure_traffic(workload, batch):
+    """HBM bytes one step moves, measured IN THIS RUN: two short re-runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domains, as MI355X_MICROARCH.md's HBM
+    section prescribes), summed over the product's kernels and corrected for gfx950 (FETCH_SIZE reports half of the
+    streamed bytes, calibration in profiles/pmc_traffic.json).  Returns (bytes_per_step, source) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    steps, warmup = 3, 1
+    products = steps + warmup + 1            # + the commutativity self-check product
+    tot = {}
+    for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        d = tempfile.mkdtemp(prefix="nflhip_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", str(steps),
+                   "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline", "--no-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            per_kernel = pmc_traffic.total(d, counter)
+            if not per_kernel:
+                return None, "no %s rows for the product's kernels" % counter
+            tot[counter] = sum(v[1] for v in per_kernel.values()) * 1024.0 * factor / products
+        except Exception as e:  # the profiler must never take the bench down
+            return None, "in-run counter pass failed: %r" % (e,)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return tot["FETCH_SIZE"] + tot["WRITE_SIZE"], ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over "
+                                                   "%d products, FETCH x2 (gfx950), per step" % products)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +167,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel secondary rates")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.traffic)")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1 only: also time one step whose operands start on rank 0 and whose product returns there "
                          "(grouped RCCL send/recv of contiguous shards, SURVEY.md 8(e)); reported beside `value`, never in it")
@@ -173,6 +230,12 @@ def main():
 
     # cheap in-run sanity: one sampled poly against nothing but itself commuting (parity lives in tests/)
     ok = not eng.any_neq(c, eng.polymul(b, a))
+    # ... and host copies of a few polynomials of the timed product for the CPU checker (cpu_baseline leg below)
+    check = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        idx = sorted({0, batch // 3, batch // 2, batch - 1})
+        check = tuple(np.concatenate([eng.to_host(t[i:i + 1]) for i in idx]) for t in (a, b, c))
 
     alg_bytes_per_poly = 3 * nm * n * (lb // 8)       # read a, read b, write c
     launch_bytes = alg_bytes_per_poly * batch
@@ -181,13 +244,21 @@ def main():
 
     kwl = "B" if args.workload == "D" else args.workload   # D runs B's kernel on a larger batch
     traffic, traffic_src = None, None
+    if rank == 0 and world == 1 and not args.no_traffic:
+        # (bytes per polynomial do not depend on the batch: the counter passes use at most the kernel's default batch)
+        tb = min(batch, WORKLOADS[kwl][3])
+        traffic, traffic_src = measure_traffic(kwl, tb)
+        if traffic is not None:
+            traffic = round(traffic / tb * batch, 1)
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if traffic is None and os.path.exists(tpath):
+        why = traffic_src
         try:
             tj = json.load(open(tpath)).get("workloads", {}).get(kwl)
             if tj:
                 traffic = tj["hbm_bytes_per_poly"] * batch
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes, %s, calibrated)" % tj.get("round", "")
+                traffic_src = "NOT measured in this run (%s): profiles/pmc_traffic.json, rocprofv3 FETCH_SIZE/WRITE_SIZE passes of round %s, kernel %s" % (
+                    why or "skipped", tj.get("round", "?"), ",".join(tj.get("kernels", {})))
         except Exception:
             traffic = None
 
@@ -269,7 +340,7 @@ def main():
         "value": round(value, 1), "unit": "polymul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u%d" % lb, "data": "synthetic",
-        "config": {"workload": "nfl::poly<uint64_t,%d,%d> batched polymul (BASELINE configs %s)" % (n, nm, args.workload),
+        "config": {"workload": "nfl::poly<uint%d_t,%d,%d> batched polymul (BASELINE configs %s)" % (lb, n, nm, args.workload),
                    "degree": n, "nmoduli": nm, "limb_bits": lb, "batch_per_gpu": batch, "global_batch": batch * world,
                    "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -295,13 +366,21 @@ def main():
         result["scatter_gather"] = scatter
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(lb, n, nm, args.cpu_budget)
+            result["cpu_baseline"] = cpu_baseline(lb, n, nm, args.cpu_budget, check=check)
         except Exception as e:  # the checker must never take the bench down
             result["cpu_baseline"] = {"value": None, "unit": "polymul/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    # the headline number carries its own correctness evidence: a product that does not commute, or whose sampled
+    # polynomials differ from the CPU checker's, is not a measurement
+    bad = (not ok) or result.get("cpu_baseline", {}).get("parity_sample_ok") is False
+    if bad:
+        result["invalid_value"] = result["value"]
+        result["value"] = None
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+    if bad:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

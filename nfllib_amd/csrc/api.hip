@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -45,6 +46,11 @@ struct nflhip_ctx {
   bool ev_prev_valid = false;
   hipEvent_t ev_scratch = nullptr;  // end of the last single-stream pipeline that used the scratch
   bool ev_scratch_valid = false;
+  // any_eq / any_neq: every call owns one result slot (device int) for its memset + kernel + readback, so host
+  // threads comparing on distinct streams never share a flag
+  static constexpr int kCmpSlots = 32;
+  std::mutex cmp_mu[kCmpSlots];
+  std::atomic<unsigned> cmp_next{0};
   // host copies for introspection
   std::vector<uint64_t> h_Q;                     // moduli_product limbs
   std::vector<std::vector<uint64_t>> h_lifting;  // lifting_integers[cm]
@@ -276,7 +282,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     for (long w = 0; w < 2 * (long)L - 3; ++w) qt /= 4294967296.0L;
     c->tabs.inv_qtop = (double)(1.0L / qt);
   }
-  HIPCHK(nullptr, hipMalloc((void **)&c->tabs.flag, sizeof(int)));
+  HIPCHK(nullptr, hipMalloc((void **)&c->tabs.flag, nflhip_ctx::kCmpSlots * sizeof(int)));
   return NFLHIP_OK;
 }
 
@@ -360,6 +366,8 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     auto lo_of = [&](size_t ch) { return batch * ch / nchunk; };
     bool supported = true;
     if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));  // a previous call on another stream
+    if (!cap && ctx->ev_prev_valid)  // ... or a helper-stream plan (polymul_ntt_dev at this shape) still reading s0
+      for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
     for (size_t L = 0; L < nchunk + 2 && supported; ++L) {
       const bool hf = L < nchunk, hv = L >= 1 && L - 1 < nchunk, hi = L >= 2 && L - 2 < nchunk;
       const size_t f0 = hf ? lo_of(L) : 0, v0 = hv ? lo_of(L - 1) : 0, i0 = hi ? lo_of(L - 2) : 0;
@@ -729,13 +737,16 @@ static int any_cmp_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t bat
   CHECK_CTX(ctx);
   if (!result || (batch && (!a || !b))) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
+  const unsigned slot = ctx->cmp_next.fetch_add(1, std::memory_order_relaxed) % nflhip_ctx::kCmpSlots;
+  std::lock_guard<std::mutex> lk(ctx->cmp_mu[slot]);  // held until the readback below has completed
+  int *dflag = ctx->tabs.flag + slot;
   hipError_t e = DISPATCH_T(
-      ctx, launch_any_cmp<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)a, (const uint16_t *)b, batch, want_eq, st),
-      launch_any_cmp<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)a, (const uint32_t *)b, batch, want_eq, st),
-      launch_any_cmp<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)a, (const uint64_t *)b, batch, want_eq, st));
+      ctx, launch_any_cmp<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)a, (const uint16_t *)b, batch, want_eq, dflag, st),
+      launch_any_cmp<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)a, (const uint32_t *)b, batch, want_eq, dflag, st),
+      launch_any_cmp<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)a, (const uint64_t *)b, batch, want_eq, dflag, st));
   if (e != hipSuccess) return hipfail(ctx, e, "any_cmp");
   int flag = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->tabs.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
   *result = flag ? 1 : 0;
   return NFLHIP_OK;
@@ -871,7 +882,8 @@ int nflhip_gauss_table(double sigma, unsigned security, unsigned samples, double
 
 int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g) {
   if (!g) return NFLHIP_OK;
-  if (ctx) (void)hipSetDevice(ctx->device);
+  (void)ctx;  // never dereferenced: a FastGaussianNoise with static storage may outlive the context that built its table
+  (void)hipSetDevice(g->device);
   if (g->d_cdt) (void)hipFree(g->d_cdt);
   delete g;
   return NFLHIP_OK;

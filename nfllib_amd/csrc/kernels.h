@@ -50,7 +50,7 @@ struct DevTables {
   uint32_t *bparts; // [proj_K][2][3][nm rounded up to 4] 21-bit parts of 2^(64k+32h) mod p_cm (project), or nullptr
   int proj_K;       // input words the project table covers
   double inv_qtop;  // 2^(32 (2 crt_L - 3)) / Q in double precision (quotient estimate of the lift)
-  int *flag;        // 1 int, result of any_eq / any_neq
+  int *flag;        // kCmpSlots ints: result slots of any_eq / any_neq (one per concurrent call, see api.hip)
 };
 
 // ---- launchers (kernels_generic.hip) ----
@@ -69,7 +69,7 @@ hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const vo
                             const unsigned char *program, int len, size_t batch, hipStream_t st);
 template <typename T>
 hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
-                          hipStream_t st);
+                          int *flag, hipStream_t st);
 template <typename T>
 hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, uint64_t seed,
                                int operand, hipStream_t st);

@@ -481,13 +481,13 @@ __global__ void k_any_cmp(const T *a, const T *b, size_t total, int want_eq, int
 
 template <typename T>
 hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
-                          hipStream_t st) {
-  hipError_t e = hipMemsetAsync(t.flag, 0, sizeof(int), st);
+                          int *flag, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
   if (e != hipSuccess || batch == 0) return e;
   const size_t total = batch * s.nm * s.n;
   size_t blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL((k_any_cmp<T>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, total, want_eq, t.flag);
+  hipLaunchKernelGGL((k_any_cmp<T>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, total, want_eq, flag);
   return hipGetLastError();
 }
 
@@ -639,7 +639,7 @@ hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const ui
                                           const T *, size_t, hipStream_t);                                           \
   template hipError_t launch_eval_expr<T>(const Shape &, const DevTables &, T *, const void *const *, int,           \
                                           const unsigned char *, int, size_t, hipStream_t);                          \
-  template hipError_t launch_any_cmp<T>(const Shape &, const DevTables &, const T *, const T *, size_t, int,         \
+  template hipError_t launch_any_cmp<T>(const Shape &, const DevTables &, const T *, const T *, size_t, int, int *,  \
                                         hipStream_t);                                                                \
   template hipError_t launch_fill_uniform<T>(const Shape &, const DevTables &, T *, size_t, size_t, uint64_t, int,   \
                                              hipStream_t);                                                           \

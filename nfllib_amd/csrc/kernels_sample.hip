@@ -14,7 +14,15 @@ namespace nflhip {
 
 struct ChaChaKey {
   uint32_t k[8];
+  // DOMAIN SEPARATION: every distribution reads its own region of the keystream of (key, stream_id).  Bits 56..62 of
+  // the 64-bit block counter carry the distribution's tag (bit 63 selects the Gaussian sampler's secondary stream), so
+  // uniform / bounded / ZO / hamming-weight / Gaussian calls that share a key AND a stream id never consume the same
+  // keystream word (a public uniform polynomial must not reveal the noise drawn next to it).  The low 56 bits count
+  // blocks: 2^56 x 64 bytes per (key, stream_id, distribution).
+  uint64_t dom;
 };
+// tags: NFLHIP_DIST_* + 1; 0 = the raw words of nflhip_random_words_dev, kDomGauss for both Gaussian entry points
+static constexpr int kDomRaw = 0, kDomGauss = 5;
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
@@ -24,7 +32,7 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) 
 // one 64-byte block as eight little-endian 64-bit words
 __device__ __forceinline__ void chacha20_block(const ChaChaKey &key, uint64_t counter, uint64_t nonce, uint64_t out[8]) {
   uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
-                    key.k[4],    key.k[5],    key.k[6],    key.k[7],    (uint32_t)counter, (uint32_t)(counter >> 32),
+                    key.k[4],    key.k[5],    key.k[6],    key.k[7],    (uint32_t)counter, (uint32_t)((counter | key.dom) >> 32),
                     (uint32_t)nonce, (uint32_t)(nonce >> 32)};
   uint32_t x[16];
 #pragma unroll
@@ -430,8 +438,9 @@ __global__ void k_hwt_spread(T *d, const ModConst<T> *__restrict__ mc, int logn,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static inline ChaChaKey load_key(const unsigned char *key32) {
+static inline ChaChaKey load_key(const unsigned char *key32, int domain) {
   ChaChaKey k;
+  k.dom = ((uint64_t)domain) << 56;
   for (int i = 0; i < 8; ++i)
     k.k[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) |
              ((uint32_t)key32[4 * i + 3] << 24);
@@ -446,7 +455,7 @@ hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords
                                uint64_t stream_id, hipStream_t st) {
   if (nwords == 0) return hipSuccess;
   hipLaunchKernelGGL(k_random_words, dim3(grid_for(nwords / 8 + 2)), dim3(256), 0, st, out, first_word, nwords,
-                     load_key(key32), stream_id);
+                     load_key(key32, kDomRaw), stream_id);
   return hipGetLastError();
 }
 
@@ -455,7 +464,7 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
                          uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
   if (batch == 0) return hipSuccess;
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
-  const ChaChaKey key = load_key(key32);
+  const ChaChaKey key = load_key(key32, dist + 1);
   const size_t ncoef = batch * s.n, total = ncoef * s.nm;
   switch (dist) {
     case 0:
@@ -501,7 +510,7 @@ static int gauss_tie_shift() {
 hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *cdt, int words,
                               int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
   if (count == 0) return hipSuccess;
-  const ChaChaKey key = load_key(key32);
+  const ChaChaKey key = load_key(key32, kDomGauss);
   const dim3 g(grid_for(count / 8 + 2)), b(256);
   const int ts = gauss_tie_shift();
   switch (words) {
@@ -519,7 +528,7 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
                                const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
   if (batch == 0) return hipSuccess;
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
-  const ChaChaKey key = load_key(key32);
+  const ChaChaKey key = load_key(key32, kDomGauss);
   const size_t ncoef = batch * s.n;
   const uint64_t fc = (uint64_t)first_poly * s.n;
   const int tie_shift = gauss_tie_shift();

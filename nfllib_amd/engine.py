@@ -57,6 +57,7 @@ class Engine:
         self.P = [int(v) for v in self._keep[0]]
         self.crt_limbs = self.lib.nflhip_crt_limbs(self.ctx)
         self.words_per_poly = degree * nmoduli
+        self._next_stream = 1 << 32   # ids handed out to sampler calls that do not name one (see _sid)
         self.bytes_per_poly = self.words_per_poly * self.np_dtype.itemsize
 
     def close(self):
@@ -164,11 +165,19 @@ class Engine:
         assert len(key) == 32, "the sampler key is 32 bytes"
         return C.create_string_buffer(key, 32)
 
-    def sample(self, d, dist, key, stream_id=0, param0=0, param1=1, first_poly=0, stream=None):
+    def _sid(self, stream_id):
+        """A (key, stream_id, distribution) triple must never be used twice for values that must be independent (a
+        public polynomial and the noise next to it): without an explicit id every call takes a fresh one."""
+        if stream_id is None:
+            stream_id = self._next_stream
+            self._next_stream += 1
+        return stream_id
+
+    def sample(self, d, dist, key, stream_id=None, param0=0, param1=1, first_poly=0, stream=None):
         """dist: DIST_UNIFORM | DIST_BOUNDED (param0 = upper bound, param1 = amplifier) | DIST_ZO (param0 = rho)
         | DIST_HWT (param0 = hamming weight)"""
         self._chk(self.lib.nflhip_sample_dev(self.ctx, _vp(d), first_poly, self._batch(d), dist, param0, param1,
-                                             self._key(key), stream_id, self._stream(stream)))
+                                             self._key(key), self._sid(stream_id), self._stream(stream)))
         return d
 
     def random_words(self, nwords, key, stream_id=0, first_word=0, stream=None):
@@ -198,22 +207,23 @@ class Engine:
         return {"x_min": x_min.value, "entries": entries.value, "words": words.value, "bit_precision": bits.value,
                 "tail": tail.value, "table": tab}
 
-    def sample_gauss(self, d, g, key, stream_id=0, amplifier=1, first_poly=0, stream=None):
+    def sample_gauss(self, d, g, key, stream_id=None, amplifier=1, first_poly=0, stream=None):
         self._chk(self.lib.nflhip_sample_gauss_dev(self.ctx, _vp(d), first_poly, self._batch(d), g, amplifier,
-                                                   self._key(key), stream_id, self._stream(stream)))
+                                                   self._key(key), self._sid(stream_id), self._stream(stream)))
         return d
 
-    def gauss_noise(self, g, count, key, stream_id=0, first_sample=0, stream=None):
+    def gauss_noise(self, g, count, key, stream_id=None, first_sample=0, stream=None):
         """raw signed samples (FastGaussianNoise::getNoise) as an int64 device tensor"""
         t = _torch()
         out = t.empty((count,), dtype=t.int64, device="cuda:%d" % self.device)
-        self._chk(self.lib.nflhip_gauss_noise_dev(self.ctx, _vp(out), first_sample, count, g, self._key(key), stream_id,
-                                                  self._stream(stream)))
+        self._chk(self.lib.nflhip_gauss_noise_dev(self.ctx, _vp(out), first_sample, count, g, self._key(key),
+                                                  self._sid(stream_id), self._stream(stream)))
         return out
 
-    def h_gauss_noise(self, g, count, key, stream_id=0):
+    def h_gauss_noise(self, g, count, key, stream_id=None):
         out = np.empty((count,), dtype=np.int64)
-        self._chk(self.lib.nflhip_gauss_noise(self.ctx, out.ctypes.data_as(C.c_void_p), count, g, self._key(key), stream_id))
+        self._chk(self.lib.nflhip_gauss_noise(self.ctx, out.ctypes.data_as(C.c_void_p), count, g, self._key(key),
+                                              self._sid(stream_id)))
         return out
 
     def crt_lift(self, d, stream=None):

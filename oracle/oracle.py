@@ -29,9 +29,11 @@ def _load(path):
 def build(native_out=None):
     """(Re)build libnfloracle.so (and _ref when /root/reference exists)."""
     import subprocess
-    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    import sys
+    # (anything make prints goes to stderr: bench.py's stdout is exactly one JSON line)
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"], stdout=sys.stderr)
     if native_out:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "native", "OUT=" + native_out])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native", "OUT=" + native_out], stdout=sys.stderr)
 
 
 class Oracle:

@@ -74,6 +74,13 @@ def centered(data, P):
 
 # ---- the device's keystream: ChaCha20 (djb layout: 64-bit counter, 64-bit nonce), kernels_sample.hip -------------
 SECONDARY_COUNTER = 1 << 63   # first block counter of the secondary stream (kernels_sample.hip, lazy-precision Gaussian)
+# domain separation (kernels_sample.hip, ChaChaKey::dom): bits 56..62 of the block counter carry the distribution's tag,
+# so calls of different distributions that share (key, stream_id) never read the same keystream word
+DOMAIN = {"raw": 0, "uniform": 1, "bounded": 2, "zo": 3, "hwt": 4, "gauss": 5}
+
+
+def domain_base(name):
+    return DOMAIN[name] << 56
 
 
 def chacha20_words(key32, stream_id, first_word, nwords, counter_base=0):
@@ -126,10 +133,10 @@ def gaussian_words(key32, stream_id, first_coef, ncoef, W):
     as the device defines it: word 0 = primary stream word g; word k >= 1 = secondary stream word (W-1)*g + k-1 (the
     device only ever reads those when word 0 ties with a table entry)."""
     r = np.empty((ncoef, W), dtype=np.uint64)
-    r[:, 0] = chacha20_words(key32, stream_id, first_coef, ncoef)
+    r[:, 0] = chacha20_words(key32, stream_id, first_coef, ncoef, counter_base=domain_base("gauss"))
     if W > 1:
         r[:, 1:] = chacha20_words(key32, stream_id, (W - 1) * first_coef, (W - 1) * ncoef,
-                                  counter_base=SECONDARY_COUNTER).reshape(ncoef, W - 1)
+                                  counter_base=SECONDARY_COUNTER | domain_base("gauss")).reshape(ncoef, W - 1)
     return r
 
 

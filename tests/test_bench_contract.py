@@ -39,9 +39,8 @@ def test_bench_line_contract(workload, batch):
                         workload, "--batch", str(batch), "--cpu-budget", "1.0"], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line"
-    d = json.loads(lines[0])
+    assert len(r.stdout.strip().splitlines()) == 1, "stdout is exactly one line: " + r.stdout[:300]
+    d = json.loads(r.stdout)
     assert KEYS <= set(d), KEYS - set(d)
     assert d["unit"] == "polymul/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -50,8 +49,15 @@ def test_bench_line_contract(workload, batch):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # HBM traffic measured in the same run (rocprofv3 counter passes), within a few % of the algorithmic bytes for the
+    # single-launch kernels
+    assert rf["traffic"] is not None and "measured in this run" in rf["traffic_source"], rf["traffic_source"]
+    assert 0.98 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.2
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert "median of 5" in cb["sample"] and cb["spread"][0] <= cb["value"] <= cb["spread"][1]
+    assert cb["parity_sample_ok"] is True
+    assert workload != "A" or "uint32_t" in d["config"]["workload"]
     if workload == "B":
         assert d["metric"].startswith("poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli")
 

@@ -80,15 +80,16 @@ def test_random_sampler_calls(shape, batch, first, sid, ub, amp, rho, key, sigma
     P = [int(e.table(1, cm)[0]) for cm in range(m)]
     dt = e.np_dtype
     mask = {16: 0xFFFF, 32: 0xFFFFFFFF, 64: 0xFFFFFFFFFFFFFFFF}[lb]
-    words = (S.chacha20_words(key, sid, first * m * n, batch * m * n) & np.uint64(mask)).astype(dt).reshape(batch, m, n)
+    words = (S.chacha20_words(key, sid, first * m * n, batch * m * n, counter_base=S.domain_base("uniform")) & np.uint64(mask)).astype(dt).reshape(batch, m, n)
     got = e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, key, stream_id=sid, first_poly=first))
     assert np.array_equal(got, S.uniform(words, P))
-    cw = S.chacha20_words(key, sid, first * n, batch * n).reshape(batch, n)
+    cw = S.chacha20_words(key, sid, first * n, batch * n, counter_base=S.domain_base("bounded")).reshape(batch, n)
+    zw = S.chacha20_words(key, sid, first * n, batch * n, counter_base=S.domain_base("zo")).reshape(batch, n)
     if ub * amp < min(P) // 2:
         d = e.sample(e.empty(batch), DIST_BOUNDED, key, stream_id=sid, param0=ub, param1=amp, first_poly=first)
         assert np.array_equal(e.to_host(d), S.non_uniform(cw, P, ub, amp, dtype=dt))
     d = e.sample(e.empty(batch), DIST_ZO, key, stream_id=sid, param0=rho, first_poly=first)
-    assert np.array_equal(e.to_host(d), S.zo_dist(cw & np.uint64(0xFF), P, rho, canonical=True, dtype=dt))
+    assert np.array_equal(e.to_host(d), S.zo_dist(zw & np.uint64(0xFF), P, rho, canonical=True, dtype=dt))
     if lb == 16 and sigma > 3.2:
         return                                           # +-13 sigma does not fit below p/2 of a 14-bit modulus
     g = e.gauss_create(sigma, security=sec, samples=1024)

@@ -417,6 +417,68 @@ def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_fact
             assert np.array_equal(results[tid], want), (lb, n, m, tid)
 
 
+def test_helper_stream_plan_then_pipeline_on_another_stream(engine_factory):
+    """n = 65536: polymul_ntt_dev (helper-stream plan, reads the context's scratch on aux streams) issued on stream A,
+    immediately followed by polymul_dev (single-stream pipeline, rewrites the same scratch) on stream B: the library
+    must order B's scratch writes after A's helper streams (api.hip pipe64k branch)."""
+    import torch
+    e = engine_factory(64, 65536, 2)
+    batch = 16
+    a = e.fill_uniform(e.empty(batch), SEED, 0)
+    b = e.fill_uniform(e.empty(batch), SEED, 1)
+    fb = e.ntt_(b.clone())
+    want = e.to_host(e.polymul(a, b))
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(8):
+        with torch.cuda.stream(sa):
+            o1 = e.polymul(a, fb, b_is_ntt=True, stream=sa)
+        with torch.cuda.stream(sb):
+            o2 = e.polymul(a, b, stream=sb)
+        with torch.cuda.stream(sa):
+            o3 = e.polymul(a, fb, b_is_ntt=True, stream=sa)
+        sa.synchronize(); sb.synchronize()
+        for o in (o1, o2, o3):
+            assert np.array_equal(e.to_host(o), want)
+
+
+def test_concurrent_comparisons_own_their_result_slot(engine_factory):
+    """nflhip_any_eq_dev / nflhip_any_neq_dev from several host threads on distinct streams (allowed by
+    include/nflhip.h) while the host-pointer compare runs too: every call has its own device result slot, so no
+    call can see another call's memset / atomicOr."""
+    import threading
+    import torch
+    e = engine_factory(64, 4096, 4)
+    batch = 256
+    a = e.fill_uniform(e.empty(batch), SEED, 0)
+    same = a.clone()
+    diff = a.clone()
+    diff[batch - 1, 3, 4095] ^= 1
+    ha, hd = e.to_host(a[:2]), e.to_host(diff[batch - 2:])
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(tid):
+        try:
+            st = torch.cuda.Stream()
+            for k in range(200):
+                if tid == 0:
+                    assert e.h_any_neq(ha, ha) is False and e.h_any_eq(ha, ha) is True
+                    assert e.h_any_neq(e.to_host(a[batch - 2:]), hd) is True
+                elif (tid + k) & 1:
+                    assert e.any_neq(a, same, stream=st) is False, "false positive"
+                    assert e.any_eq(a, same, stream=st) is True
+                else:
+                    assert e.any_neq(a, diff, stream=st) is True, "missed the one differing word"
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (64, 8192, 2), (64, 16384, 2), (64, 65536, 2), (32, 1024, 2), (64, 1024, 2),
                                     (64, 2048, 1), (32, 2048, 1), (32, 4096, 2)])
 def test_adversarial_coefficient_values(lb, n, m, oracle_factory, engine_factory):

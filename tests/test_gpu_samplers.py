@@ -39,7 +39,7 @@ def test_uniform_bounded_zo_are_the_reference_rules(lb, n, m, batch, engine_fact
     e = engine_factory(lb, n, m)
     P, dt = _P(e), e.np_dtype
     d = e.sample(e.empty(batch), DIST_UNIFORM, KEY, stream_id=1)
-    words = (S.chacha20_words(KEY, 1, 0, batch * m * n) & np.uint64(_MASK[lb])).astype(dt).reshape(batch, m, n)
+    words = (S.chacha20_words(KEY, 1, 0, batch * m * n, counter_base=S.domain_base("uniform")) & np.uint64(_MASK[lb])).astype(dt).reshape(batch, m, n)
     got = e.to_host(d)
     assert np.array_equal(got, S.uniform(words, P))
     assert all((got[:, cm] < P[cm]).all() for cm in range(m))
@@ -47,7 +47,10 @@ def test_uniform_bounded_zo_are_the_reference_rules(lb, n, m, batch, engine_fact
     lo = e.sample(e.empty(1), DIST_UNIFORM, KEY, stream_id=1, first_poly=0)
     hi = e.sample(e.empty(batch - 1), DIST_UNIFORM, KEY, stream_id=1, first_poly=1)
     assert np.array_equal(np.concatenate([e.to_host(lo), e.to_host(hi)]), got)
-    cw = S.chacha20_words(KEY, 2, 0, batch * n).reshape(batch, n)
+    # same key and stream id for the bounded and the ZO calls below: the distribution tag in the block counter keeps
+    # their keystream words apart (a public polynomial must not share words with the noise next to it)
+    cw = S.chacha20_words(KEY, 2, 0, batch * n, counter_base=S.domain_base("bounded")).reshape(batch, n)
+    zw = S.chacha20_words(KEY, 2, 0, batch * n, counter_base=S.domain_base("zo")).reshape(batch, n)
     for ub, amp in ((1, 1), (2, 1), (5, 3), (1000, 1), (1 << 12, 1)):
         if ub * amp >= min(P) // 2:
             continue
@@ -55,7 +58,7 @@ def test_uniform_bounded_zo_are_the_reference_rules(lb, n, m, batch, engine_fact
         assert np.array_equal(e.to_host(d), S.non_uniform(cw, P, ub, amp, dtype=dt)), (ub, amp)
     for rho in (0x7F, 0, 255, 10):
         d = e.sample(e.empty(batch), DIST_ZO, KEY, stream_id=2, param0=rho)
-        assert np.array_equal(e.to_host(d), S.zo_dist(cw & np.uint64(0xFF), P, rho, canonical=True, dtype=dt)), rho
+        assert np.array_equal(e.to_host(d), S.zo_dist(zw & np.uint64(0xFF), P, rho, canonical=True, dtype=dt)), rho
     # a different stream id is a different polynomial
     assert not np.array_equal(e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, KEY, stream_id=3)), got)
 

@@ -63,9 +63,16 @@ def test_chacha20_known_answer():
     # the secondary stream (block counters from 2^63) and the W-word numbers of the lazy-precision Gaussian
     sec = S.chacha20_words(key, 7, 0, 100, counter_base=S.SECONDARY_COUNTER)
     assert not np.array_equal(sec, long) and np.array_equal(S.chacha20_words(key, 7, 16, 8, counter_base=S.SECONDARY_COUNTER), sec[16:24])
+    # the Gaussian sampler reads its own domain of (key, stream id): distribution tag in bits 56..62 of the block counter
+    gb = S.domain_base("gauss")
+    glong = S.chacha20_words(key, 7, 0, 100, counter_base=gb)
+    gsec = S.chacha20_words(key, 7, 0, 100, counter_base=S.SECONDARY_COUNTER | gb)
     r = S.gaussian_words(key, 7, 5, 20, 3)
-    assert np.array_equal(r[:, 0], long[5:25]) and np.array_equal(r[:, 1:].reshape(-1), sec[10:50])
-    assert np.array_equal(S.gaussian_words(key, 7, 5, 20, 1)[:, 0], long[5:25])
+    assert np.array_equal(r[:, 0], glong[5:25]) and np.array_equal(r[:, 1:].reshape(-1), gsec[10:50])
+    assert np.array_equal(S.gaussian_words(key, 7, 5, 20, 1)[:, 0], glong[5:25])
+    # no two distributions share a keystream word for the same (key, stream id)
+    runs = [S.chacha20_words(key, 7, 0, 64, counter_base=S.domain_base(d)) for d in S.DOMAIN]
+    assert len({r_.tobytes() for r_ in runs}) == len(S.DOMAIN) and np.array_equal(runs[0], long[:64])
 
 
 def test_distribution_fixtures_are_sane():
