@@ -1,0 +1,6 @@
+// nfl/poly_p.hpp -- forwarding header: the reference splits its surface over include/nfl/*.hpp and callers include
+// the pieces directly (tests/poly_p.cpp:2, tests/nfllib_demo_main.hpp:5); here every piece is the one header.
+#ifndef NFL_HIP_FWD_POLY_P_HPP
+#define NFL_HIP_FWD_POLY_P_HPP
+#include "../nfl.hpp"
+#endif

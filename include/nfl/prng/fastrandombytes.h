@@ -1,0 +1,6 @@
+// nfl/prng/fastrandombytes.h -- forwarding header: nfl::FastGaussianNoise, nfl::fastrandombytes, nfl::randombytes and nfl::rdtsc
+// (FastGaussianNoise.hpp:117-122, 163-204; fastrandombytes.h:12; randombytes.h) are declared by the one header.
+#ifndef NFL_HIP_FWD_PRNG_FASTRANDOMBYTES_H
+#define NFL_HIP_FWD_PRNG_FASTRANDOMBYTES_H
+#include "../../nfl.hpp"
+#endif

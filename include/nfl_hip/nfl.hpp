@@ -1,36 +1,50 @@
 // nfl_hip/nfl.hpp -- header-only host surface of the MI355X NTT polynomial-ring engine.
 //
 // Keeps the template surface of the reference's nfl::poly<T, Degree, NbModuli>
-// (include/nfl/poly.hpp:82-352) and its expression-template operators
-// (include/nfl/ops.hpp:18-97, 249-277) so existing callers compile unchanged,
-// but every whole-polynomial operation is forwarded through the C ABI of
-// include/nflhip.h to hand-written HIP kernels.  There is no CPU arithmetic in
-// this header: without libnflhip.so + a GPU every operation throws
-// std::runtime_error (the reference's error convention: core.hpp:111-115).
+// (include/nfl/poly.hpp:82-352), nfl::poly_p (include/nfl/poly_p.hpp:11-204) and their
+// expression-template operators (include/nfl/ops.hpp:18-97, 249-277) so existing callers compile
+// unchanged -- the reference's own test programs build against this header as they are
+// (tests/reftests/Makefile) -- but every whole-polynomial operation is forwarded through the C ABI of
+// include/nflhip.h to hand-written HIP kernels.  There is no CPU arithmetic on the hot path in this
+// header: without libnflhip.so + a GPU every operation throws std::runtime_error (the reference's error
+// convention: core.hpp:111-115).  Reached as <nfl.hpp>, <nfl/poly.hpp>, <nfl/poly_p.hpp>, ... through the
+// forwarding headers of include/nfl/.
 //
 // What is kept (same names, argument meaning, error behaviour):
-//   storage layout T _data[NbModuli*Degree], 32-byte aligned, modulus-major  poly.hpp:87-88,156-157
-//   ctors / set(): value, initializer_list, iterator range (+reduce_coeffs)   core.hpp:64-137
-//   operator()(cm,i), begin/end, data(), get_modulus, degree/nmoduli/nbits    poly.hpp:142-162
-//   ntt_pow_phi(), invntt_pow_invphi()                                        poly.hpp:167-168
-//   operator+ - * == !=, shoup(a*b,b'), compute_shoup(b), nested expressions  poly.hpp:346-352
-//   explicit operator bool on polys, implicit on == / != expressions         core.hpp:39-43, ops.hpp:81-95
-//   serialize_manually / deserialize_manually                                 poly.hpp:180-185
-//   nfl::add / sub / mul                                                      poly.hpp:314-332
+//   params<T>::P / Pn / primitive_roots / invkMaxPolyDegree / kMax* (all moduli)  params.hpp:11-119
+//   storage layout T _data[NbModuli*Degree], 32-byte aligned, modulus-major      poly.hpp:87-88,156-157
+//   ctors / set(): value, initializer_list, iterator range (+reduce_coeffs)       core.hpp:64-137
+//   the random constructors uniform / non_uniform / ZO_dist / hwt_dist / gaussian core.hpp:146-391
+//   operator()(cm,i), begin/end, data(), get_modulus, degree/nmoduli/nbits        poly.hpp:142-162
+//   ntt_pow_phi(), invntt_pow_invphi()                                            poly.hpp:167-168
+//   operator+ - * == !=, shoup(a*b,b'), compute_shoup(b), nested expressions      poly.hpp:346-352
+//   ops::make_op<ops::NAME<T, tag>>(...), nfl::simd::serial, CC_SIMD             ops.hpp:225-260, arch/common.hpp:11-26
+//   explicit operator bool on polys, implicit on == / != expressions             core.hpp:39-43, ops.hpp:81-95
+//   poly::core (ntt / inv_ntt statics) + `base` tables through the
+//   tests::poly_tests_proxy friend                                                poly.hpp:69-76,85,196-247
+//   serialize_manually / deserialize_manually / serialize(Archive)                poly.hpp:180-191
+//   the GMP-typed surface (mpz_t / mpz_class ctors, set_mpz, poly2mpz, mpz2poly,
+//   moduli_product / modulus_shoup / lifting_integers), on poly and poly_p        poly.hpp:249-307, poly_p.hpp:186-200
+//   nfl::add / sub / mul, poly_from_modulus, poly_p_from_modulus, operator<<      poly.hpp:314-343
+//   FastGaussianNoise (ctor, getNoise), nfl::rdtsc, nfl::fastrandombytes          FastGaussianNoise.hpp, fastrandombytes.h
 // What differs, on purpose:
-//   * tables live in a lazily created per-(T,Degree,NbModuli) device context,
-//     never at static-init time (the reference's `static core base`, poly.hpp:247);
-//   * CRT lift/project exchange little-endian 64-bit limb vectors
-//     (poly2limbs / limbs2poly == the mpz_export/mpz_import image of
-//     poly2mpz / mpz2poly, gmp.hpp:183-219); with NFL_HIP_WITH_GMP defined before
-//     inclusion the reference's GMP-typed surface is there as well (poly.hpp:249-307):
-//     mpz_t / mpz_class constructors, set_mpz, operator=, poly2mpz / mpz2poly on
-//     std::array<mpz_t, Degree>, moduli_product / modulus_shoup / lifting_integers;
-//   * nfl::batch::* operate on contiguous arrays of polys (dense
-//     [batch][NbModuli][Degree], as tests/tools.h:6-17 allocates) in ONE device
-//     pass -- the per-poly members stay for source compatibility;
-//   * nfl::uniform is a seeded counter-based generator with the reference's
-//     mask-then-subtract rule (core.hpp:165-176), not a CSPRNG.
+//   * tables live in a lazily created per-(T,Degree,NbModuli) device context, never at static-init time
+//     (the reference's `static core base`, poly.hpp:247);
+//   * nfl::poly_p is RESIDENT: its shared payload lives in HBM next to an (optional) host image, with a
+//     valid-on-host / valid-on-device pair of bits.  Operator expressions, transforms, comparisons and random
+//     constructors on poly_p handles run the *_dev entry points on the context's stream and never touch the host;
+//     only operator()(cm,i), poly_obj(), serialisation and the GMP surface force a device-to-host copy
+//     (SURVEY.md section 8(f) rank 2).  nfl::poly keeps its words inline on the host (poly.hpp:87-88) and its
+//     member operations therefore cross PCIe per call -- use poly_p or the batch forms for throughput;
+//   * CRT lift/project also exchange little-endian 64-bit limb vectors (poly2limbs / limbs2poly == the
+//     mpz_export/mpz_import image of poly2mpz / mpz2poly, gmp.hpp:183-219);
+//   * nfl::batch::* and nfl::device_batch<P> operate on contiguous arrays of polys (dense
+//     [batch][NbModuli][Degree], as tests/tools.h:6-17 allocates) in ONE device pass;
+//   * nfl::uniform(seed) is an addition: a seeded counter-based operand with the reference's
+//     mask-then-subtract rule (core.hpp:165-176); plain nfl::uniform() draws fresh randomness like the reference.
+// GMP: define NFL_HIP_WITH_GMP before inclusion (the <nfl.hpp> forwarding header does, as the reference always
+// includes <gmpxx.h>: poly.hpp:33); NFL_HIP_REFERENCE_WORDS makes ZO_dist / hwt_dist store +1 as p + 1 like the
+// reference's raw words (core.hpp:341,387) instead of the canonical 1.
 #ifndef NFL_HIP_NFL_HPP
 #define NFL_HIP_NFL_HPP
 
@@ -38,22 +52,31 @@
 #include <array>
 #include <atomic>
 #include <cassert>
+#include <cinttypes>
+#include <climits>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <initializer_list>
 #include <iostream>
 #include <iterator>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <numeric>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <strings.h>
 #include <tuple>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../nflhip.h"
@@ -71,46 +94,101 @@
 
 namespace nfl {
 
+// ---------------------------------------------------------------- simd tags (arch/common.hpp:11-26, arch.hpp:6-17)
+// The reference selects its vector ISA with a tag; here the only host tag is `serial` (the device is selected by
+// linking libnflhip.so, not by a tag) and it is accepted wherever the reference's spelling names one.
+namespace simd {
+struct serial {
+  template <class T> static inline T load(T const *p) { return *p; }
+  template <class T> static inline void store(T *p, T const v) { *p = v; }
+  template <class T> struct elt_count { static constexpr size_t value = 1; };
+  static constexpr int mode = 0;
+};
+}  // namespace simd
+template <class... M> struct common_mode;
+template <class M> struct common_mode<M> { using type = M; };
+template <class M0, class... M> struct common_mode<M0, M...> { using type = typename common_mode<M0, typename common_mode<M...>::type>::type; };
+template <class M> struct common_mode<M, M> { using type = M; };
+#ifndef CC_SIMD
+#define CC_SIMD nfl::simd::serial
+#endif
+
+// ---------------------------------------------------------------- meta.hpp:12-45
+namespace impl {
+template <size_t N> struct _log2 { static constexpr size_t value = 1 + _log2<N / 2>::value; };
+template <> struct _log2<1> { static constexpr size_t value = 0; };
+}  // namespace impl
+template <size_t N> struct static_log2 { static constexpr size_t value = impl::_log2<N>::value; };
+template <> struct static_log2<0> {};
+
 // ---------------------------------------------------------------- params<T> (params.hpp:11-119)
+// Same member names as the reference's.  The tables are class-template statics (defined below, in the header, ODR-safe
+// in C++11) filled from the generated initialisers of include/nflhip_params.h -- every modulus the reference offers.
 template <class T> struct params;
-template <> struct params<uint16_t> {
+namespace detail {
+template <class Dummy> struct params_tables_u16 {
+  static constexpr uint16_t P[NFLHIP_U16_NMODULI] = NFLHIP_U16_P_INIT;
+  static constexpr uint16_t Pn[NFLHIP_U16_NMODULI] = NFLHIP_U16_PN_INIT;
+  static constexpr uint16_t primitive_roots[NFLHIP_U16_NMODULI] = NFLHIP_U16_ROOTS_INIT;
+  static constexpr uint16_t invkMaxPolyDegree[NFLHIP_U16_NMODULI] = NFLHIP_U16_INVKMAX_INIT;
+};
+template <class D> constexpr uint16_t params_tables_u16<D>::P[NFLHIP_U16_NMODULI];
+template <class D> constexpr uint16_t params_tables_u16<D>::Pn[NFLHIP_U16_NMODULI];
+template <class D> constexpr uint16_t params_tables_u16<D>::primitive_roots[NFLHIP_U16_NMODULI];
+template <class D> constexpr uint16_t params_tables_u16<D>::invkMaxPolyDegree[NFLHIP_U16_NMODULI];
+template <class Dummy> struct params_tables_u32 {
+  static constexpr uint32_t P[NFLHIP_U32_NMODULI] = NFLHIP_U32_P_INIT;
+  static constexpr uint32_t Pn[NFLHIP_U32_NMODULI] = NFLHIP_U32_PN_INIT;
+  static constexpr uint32_t primitive_roots[NFLHIP_U32_NMODULI] = NFLHIP_U32_ROOTS_INIT;
+  static constexpr uint32_t invkMaxPolyDegree[NFLHIP_U32_NMODULI] = NFLHIP_U32_INVKMAX_INIT;
+};
+template <class D> constexpr uint32_t params_tables_u32<D>::P[NFLHIP_U32_NMODULI];
+template <class D> constexpr uint32_t params_tables_u32<D>::Pn[NFLHIP_U32_NMODULI];
+template <class D> constexpr uint32_t params_tables_u32<D>::primitive_roots[NFLHIP_U32_NMODULI];
+template <class D> constexpr uint32_t params_tables_u32<D>::invkMaxPolyDegree[NFLHIP_U32_NMODULI];
+template <class Dummy> struct params_tables_u64 {
+  static constexpr uint64_t P[NFLHIP_U64_NMODULI] = NFLHIP_U64_P_INIT;
+  static constexpr uint64_t Pn[NFLHIP_U64_NMODULI] = NFLHIP_U64_PN_INIT;
+  static constexpr uint64_t primitive_roots[NFLHIP_U64_NMODULI] = NFLHIP_U64_ROOTS_INIT;
+  static constexpr uint64_t invkMaxPolyDegree[NFLHIP_U64_NMODULI] = NFLHIP_U64_INVKMAX_INIT;
+};
+template <class D> constexpr uint64_t params_tables_u64<D>::P[NFLHIP_U64_NMODULI];
+template <class D> constexpr uint64_t params_tables_u64<D>::Pn[NFLHIP_U64_NMODULI];
+template <class D> constexpr uint64_t params_tables_u64<D>::primitive_roots[NFLHIP_U64_NMODULI];
+template <class D> constexpr uint64_t params_tables_u64<D>::invkMaxPolyDegree[NFLHIP_U64_NMODULI];
+}  // namespace detail
+template <> struct params<uint16_t> : detail::params_tables_u16<void> {
   typedef uint16_t value_type;
   typedef int16_t signed_value_type;
   typedef uint32_t greater_value_type;
+  typedef value_type *poly_t;
   static constexpr unsigned int kMaxNbModuli = NFLHIP_U16_NMODULI;
   static constexpr unsigned int kModulusBitsize = NFLHIP_U16_MODULUS_BITS;
   static constexpr unsigned int kModulusRepresentationBitsize = 16;
   static constexpr unsigned int kMaxPolyDegree = 1u << NFLHIP_U16_KMAX_LOG2;
   static constexpr int kMaxLog2 = NFLHIP_U16_KMAX_LOG2;
-  static const value_type *P() { return NFLHIP_U16_P; }
-  static const value_type *roots() { return NFLHIP_U16_ROOTS; }
-  static const value_type *invkmax() { return NFLHIP_U16_INVKMAX; }
 };
-template <> struct params<uint32_t> {
+template <> struct params<uint32_t> : detail::params_tables_u32<void> {
   typedef uint32_t value_type;
   typedef int32_t signed_value_type;
   typedef uint64_t greater_value_type;
+  typedef value_type *poly_t;
   static constexpr unsigned int kMaxNbModuli = NFLHIP_U32_NMODULI;
   static constexpr unsigned int kModulusBitsize = NFLHIP_U32_MODULUS_BITS;
   static constexpr unsigned int kModulusRepresentationBitsize = 32;
   static constexpr unsigned int kMaxPolyDegree = 1u << NFLHIP_U32_KMAX_LOG2;
   static constexpr int kMaxLog2 = NFLHIP_U32_KMAX_LOG2;
-  static const value_type *P() { return NFLHIP_U32_P; }
-  static const value_type *roots() { return NFLHIP_U32_ROOTS; }
-  static const value_type *invkmax() { return NFLHIP_U32_INVKMAX; }
 };
-template <> struct params<uint64_t> {
+template <> struct params<uint64_t> : detail::params_tables_u64<void> {
   typedef uint64_t value_type;
   typedef int64_t signed_value_type;
   typedef unsigned __int128 greater_value_type;
+  typedef value_type *poly_t;
   static constexpr unsigned int kMaxNbModuli = NFLHIP_U64_NMODULI;
   static constexpr unsigned int kModulusBitsize = NFLHIP_U64_MODULUS_BITS;
   static constexpr unsigned int kModulusRepresentationBitsize = 64;
   static constexpr unsigned int kMaxPolyDegree = 1u << NFLHIP_U64_KMAX_LOG2;
   static constexpr int kMaxLog2 = NFLHIP_U64_KMAX_LOG2;
-  static const value_type *P() { return NFLHIP_U64_P; }
-  static const value_type *roots() { return NFLHIP_U64_ROOTS; }
-  static const value_type *invkmax() { return NFLHIP_U64_INVKMAX; }
 };
 
 // ---- sampler tags (poly.hpp:42-67).  `uniform()` and the other tags draw fresh randomness on every use, like the
@@ -168,26 +246,72 @@ struct sampler {
   }
 };
 
-// One device context per (T, Degree, NbModuli): the replacement of the
-// reference's static `core base` / `GMP gmp` members (poly.hpp:247, 275), created
-// on first use (function-local static => thread-safe, never before main()).
+// One device context per (T, Degree, NbModuli): the replacement of the reference's static `core base` / `GMP gmp`
+// members (poly.hpp:247, 275), created on first use (function-local static => thread-safe, never before main()).
+// It also owns what the resident poly_p handles share: ONE stream every resident operation is enqueued on (so
+// successive operations are ordered without events) and a free list of polynomial-sized device buffers (hipMalloc /
+// hipFree per temporary would cost more than the kernels).
 template <class T, size_t Degree, size_t NbModuli> struct context {
   nflhip_ctx *ctx;
-  context() : ctx(nullptr) {
-    static_assert(NbModuli <= params<T>::kMaxNbModuli, "not enough moduli of this size (see nflhip_params.h)");
+  void *stream;
+  std::mutex mu;
+  std::vector<void *> pool;
+  static constexpr size_t poly_bytes = Degree * NbModuli * sizeof(T);
+  context() : ctx(nullptr), stream(nullptr) {
+    static_assert(NbModuli <= params<T>::kMaxNbModuli, "not enough moduli of this size (params.hpp)");
     static_assert(Degree <= params<T>::kMaxPolyDegree, "degree is not lower or equal than kMaxPolyDegree");
-    int rc = nflhip_ctx_create(&ctx, 0, int(sizeof(T) * 8), Degree, NbModuli, params<T>::P(), params<T>::roots(),
-                               params<T>::invkmax(), params<T>::kMaxLog2);
+    int rc = nflhip_ctx_create(&ctx, 0, int(sizeof(T) * 8), Degree, NbModuli, params<T>::P, params<T>::primitive_roots,
+                               params<T>::invkMaxPolyDegree, params<T>::kMaxLog2);
     if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): context: ") + nflhip_last_error(nullptr));
+    rc = nflhip_stream_create(ctx, &stream);
+    if (rc != NFLHIP_OK) {
+      nflhip_ctx_destroy(ctx);
+      throw std::runtime_error(std::string("nfl(hip): context stream: ") + nflhip_last_error(nullptr));
+    }
+    alive() = true;
   }
-  ~context() { nflhip_ctx_destroy(ctx); }
+  ~context() {
+    alive() = false;
+    nflhip_stream_sync(ctx, stream);
+    for (void *p : pool) nflhip_free(ctx, p);
+    nflhip_stream_destroy(ctx, stream);
+    nflhip_ctx_destroy(ctx);
+  }
   context(const context &) = delete;
   context &operator=(const context &) = delete;
-  static nflhip_ctx *get() {
+  static bool &alive() {  // false once the static below has been destroyed (objects with static storage may outlive it)
+    static bool a = false;
+    return a;
+  }
+  static context &inst() {
     static context c;
-    return c.ctx;
+    return c;
+  }
+  static nflhip_ctx *get() { return inst().ctx; }
+  static void *queue() { return inst().stream; }
+  static void *acquire() {
+    context &c = inst();
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      if (!c.pool.empty()) {
+        void *p = c.pool.back();
+        c.pool.pop_back();
+        return p;
+      }
+    }
+    void *p = nullptr;
+    check(c.ctx, nflhip_malloc(c.ctx, &p, poly_bytes), "device allocation");
+    return p;
+  }
+  static void release(void *p) {
+    if (!p || !alive()) return;  // (after teardown the runtime reclaims it)
+    context &c = inst();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.pool.push_back(p);  // stream-ordered reuse: every consumer of these buffers runs on `stream`
   }
 };
+
+struct uninitialized_t {};  // poly(uninitialized_t): storage that is about to be overwritten entirely
 
 inline uint64_t splitmix64_at(uint64_t seed, int operand, uint64_t g) {
   uint64_t z = (seed ^ (uint64_t(operand) << 62)) + (g + 1) * 0x9E3779B97F4A7C15ull;
@@ -205,6 +329,28 @@ inline void set_sampler_key(const unsigned char key[32], uint64_t next_stream = 
   s.next.store(next_stream);
 }
 
+/* nfl::rdtsc (FastGaussianNoise.hpp:117-122): the cycle counter callers time getNoise with (tests/prng_demo_main.cpp:17) */
+inline uint64_t rdtsc(void) {
+#if defined(__x86_64__) || defined(__i386__)
+  uint32_t lo, hi;
+  __asm__ volatile("rdtsc" : "=a"(lo), "=d"(hi));
+  return (uint64_t(hi) << 32) | lo;
+#else
+  return 0;
+#endif
+}
+/* nfl::fastrandombytes (nfl/prng/fastrandombytes.h:12; lib/prng/fastrandombytes.cpp:21-37): rlen bytes of the process
+ * stream.  Here: the next keystream of the process-wide sampler state, generated on the device. */
+inline void fastrandombytes(unsigned char *r, unsigned long long rlen) {
+  detail::sampler &s = detail::sampler::get();
+  detail::check(nullptr, nflhip_random_bytes(0, r, size_t(rlen), s.key, s.next++), "fastrandombytes");
+}
+/* nfl::randombytes (nfl/prng/randombytes.h): OS entropy, what the reference keys its stream with */
+inline void randombytes(unsigned char *x, unsigned long long xlen) {
+  std::ifstream f("/dev/urandom", std::ios::binary);
+  if (!f.read(reinterpret_cast<char *>(x), std::streamsize(xlen))) throw std::runtime_error("nfl(hip): /dev/urandom unreadable");
+}
+
 /* FastGaussianNoise<in_class, out_class, _lu_depth>(sigma, security, samples, center) -- same constructor as
  * FastGaussianNoise.hpp:163-204.  The reference builds byte-indexed lookup tables over MPFR barriers; here the object
  * only carries the parameters and owns one cumulative table per device context (built on first use with the
@@ -219,7 +365,9 @@ template <class in_class, class out_class, unsigned _lu_depth> class FastGaussia
   FastGaussianNoise(FastGaussianNoise const &) = delete;
   FastGaussianNoise &operator=(FastGaussianNoise const &) = delete;
   ~FastGaussianNoise() {
-    for (auto &kv : tables_) nflhip_gauss_destroy(kv.first, kv.second);
+    // (the contexts are function-local statics and may already be gone when an object with static storage dies:
+    // nflhip_gauss_destroy never dereferences its context argument)
+    for (auto &kv : tables_) nflhip_gauss_destroy(nullptr, kv.second);
   }
   const nflhip_gauss *table(nflhip_ctx *ctx) {
     std::lock_guard<std::mutex> lk(mu_);
@@ -257,21 +405,120 @@ template <class in_class, class out_class, unsigned _lu_depth> struct gaussian {
 };
 
 template <class T, size_t Degree, size_t NbModuli> class poly;
+template <class T, size_t Degree, size_t NbModuli> class poly_p;
+namespace tests {
+template <class P> class poly_tests_proxy;  // (poly.hpp:69-76) defined by the caller's test code, befriended below
+}
+
+namespace detail {
+#ifdef NFL_HIP_REFERENCE_WORDS
+static constexpr int dist_flags = NFLHIP_DIST_REFERENCE_WORDS;
+#else
+static constexpr int dist_flags = 0;
+#endif
+
+// The shared payload of a poly_p handle (poly_p.hpp:11-204 keeps a std::shared_ptr<poly>): one polynomial that lives
+// in HBM (`dev`), on the host (`host`), or both.  host_valid / dev_valid say which image holds the current value;
+// neither valid = the zero polynomial (what poly_p() is) with nothing allocated yet.  Every device-side operation is
+// enqueued on the context's stream, so the only synchronisation points are the device-to-host copies below.
+template <class P> struct payload {
+  typedef typename P::value_type T;
+  typedef context<T, P::degree, P::nmoduli> ctx_t;
+  static constexpr size_t bytes = sizeof(T) * P::degree * P::nmoduli;
+  P *host;
+  void *dev;
+  bool host_valid, dev_valid;
+
+  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false) {}
+  payload(const payload &o) : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false) {
+    if (o.dev_valid) {  // stays on the device
+      check(ctx(), nflhip_memcpy_d2d(ctx(), dev_wo(), o.dev, bytes, ctx_t::queue()), "poly_p copy");
+    } else if (o.host_valid) {
+      alloc_host();
+      std::memcpy(host->data(), o.host->cdata(), bytes);
+      host_valid = true;
+    }
+  }
+  payload &operator=(const payload &) = delete;
+  ~payload() {
+    if (host) {
+      host->~P();
+      free(host);
+    }
+    ctx_t::release(dev);
+  }
+  static nflhip_ctx *ctx() { return ctx_t::get(); }
+
+  void alloc_host() {
+    if (host) return;
+    void *mem = nullptr;
+    if (posix_memalign(&mem, 32, sizeof(P)) != 0) throw std::bad_alloc();
+    host = new (mem) P(uninitialized_t());
+  }
+  // the host image, current
+  void to_host() {
+    alloc_host();
+    if (host_valid) return;
+    if (dev_valid) {
+      check(ctx(), nflhip_memcpy_d2h(ctx(), host->data(), dev, bytes, ctx_t::queue()), "poly_p download");
+      check(ctx(), nflhip_stream_sync(ctx(), ctx_t::queue()), "poly_p download");
+    } else {
+      std::memset(static_cast<void *>(host->data()), 0, bytes);
+    }
+    host_valid = true;
+  }
+  P &host_rw() {  // the caller may write through the reference: the device image goes stale
+    to_host();
+    dev_valid = false;
+    return *host;
+  }
+  P const &host_ro() {
+    to_host();
+    return *host;
+  }
+  P &host_wo() {  // about to be overwritten entirely on the host
+    alloc_host();
+    host_valid = true;
+    dev_valid = false;
+    return *host;
+  }
+  // the device image, current
+  const void *dev_ro() {
+    if (!dev) dev = ctx_t::acquire();
+    if (!dev_valid) {
+      if (host_valid) check(ctx(), nflhip_memcpy_h2d(ctx(), dev, host->cdata(), bytes, ctx_t::queue()), "poly_p upload");
+      else check(ctx(), nflhip_memset_dev(ctx(), dev, 0, bytes, ctx_t::queue()), "poly_p zero");
+      dev_valid = true;
+    }
+    return dev;
+  }
+  void *dev_rw() {  // in-place device operation
+    dev_ro();
+    host_valid = false;
+    return dev;
+  }
+  void *dev_wo() {  // about to be overwritten entirely on the device
+    if (!dev) dev = ctx_t::acquire();
+    dev_valid = true;
+    host_valid = false;
+    return dev;
+  }
+};
+}  // namespace detail
 
 // ---------------------------------------------------------------- expression templates (ops.hpp:52-97)
-template <class T, size_t Degree, size_t NbModuli> class poly;
-template <class T, size_t Degree, size_t NbModuli> class poly_p;
-
 namespace ops {
 
-struct addmod { static constexpr int code = NFLHIP_OP_ADD; };
-struct submod { static constexpr int code = NFLHIP_OP_SUB; };
-struct mulmod { static constexpr int code = NFLHIP_OP_MUL; };
-struct mulmod_shoup { static constexpr int code = NFLHIP_OP_MUL_SHOUP; };
-struct compute_shoup { static constexpr int code = NFLHIP_OP_COMPUTE_SHOUP; };
-struct eqmod {};
-struct neqmod {};
-struct shoup_marker {};
+// the functors poly::operator=(expr) evaluates (ops.hpp:99-242): on the device they are opcodes; the template
+// parameters keep the reference's spelling (ops::mulmod_shoup<T, nfl::simd::serial>, tests/nfllib_demo_main_op.cpp:79)
+template <class T, class tag> struct addmod { using simd_mode = tag; static constexpr int code = NFLHIP_OP_ADD; };
+template <class T, class tag> struct submod { using simd_mode = tag; static constexpr int code = NFLHIP_OP_SUB; };
+template <class T, class tag> struct mulmod { using simd_mode = tag; static constexpr int code = NFLHIP_OP_MUL; };
+template <class T, class tag> struct mulmod_shoup { using simd_mode = tag; static constexpr int code = NFLHIP_OP_MUL_SHOUP; };
+template <class T, class tag> struct compute_shoup { using simd_mode = tag; static constexpr int code = NFLHIP_OP_COMPUTE_SHOUP; };
+template <class T, class tag> struct eqmod { using simd_mode = tag; static constexpr int code = -1; };
+template <class T, class tag> struct neqmod { using simd_mode = tag; static constexpr int code = -1; };
+template <class T, class tag> struct shoup { using simd_mode = tag; static constexpr int code = -1; };  // marker, ops.hpp:153-163
 
 template <class Op, class... Args> struct expr;
 
@@ -281,21 +528,28 @@ template <class T, size_t D, size_t M> struct is_leaf<poly_p<T, D, M>, poly<T, D
 template <class T, size_t D, size_t M> inline const poly<T, D, M> &leaf(const poly<T, D, M> &p) { return p; }
 template <class T, size_t D, size_t M> inline const poly<T, D, M> &leaf(const poly_p<T, D, M> &p) { return p.poly_obj(); }
 
-// postfix program of one expression tree (include/nflhip.h, NFLHIP_EXPR_*), built when the tree is
-// assigned: distinct leaf polys become operands 0..2, every node appends its opcode.
+// postfix program of one expression tree (include/nflhip.h, NFLHIP_EXPR_*), built when the tree is assigned: distinct
+// leaves become operands 0..7, every node appends its opcode.  A leaf is an inline host poly (`host` = its words) or a
+// resident handle (`pay` = its payload).
 struct program {
   unsigned char code[NFLHIP_EXPR_MAX_LEN];
   size_t len = 0;
-  const void *operand[3] = {nullptr, nullptr, nullptr};
-  size_t noperands = 0;
+  const void *id[NFLHIP_EXPR_MAX_OPERANDS];
+  const void *host[NFLHIP_EXPR_MAX_OPERANDS];
+  void *pay[NFLHIP_EXPR_MAX_OPERANDS];
+  size_t noperands = 0, nhandles = 0;
   int depth = 0;
   bool ok = true;
-  void push_leaf(const void *p) {
+  void push_leaf(const void *ident, const void *h, void *p) {
     size_t k = 0;
-    while (k < noperands && operand[k] != p) ++k;
+    while (k < noperands && id[k] != ident) ++k;
     if (k == noperands) {
-      if (noperands == 3) { ok = false; return; }
-      operand[noperands++] = p;
+      if (noperands == NFLHIP_EXPR_MAX_OPERANDS) { ok = false; return; }
+      id[k] = ident;
+      host[k] = h;
+      pay[k] = p;
+      ++noperands;
+      if (p) ++nhandles;
     }
     emit((unsigned char)k, +1);
   }
@@ -306,30 +560,78 @@ struct program {
     if (depth > 4) ok = false;
   }
 };
+template <class T, size_t D, size_t M> inline void push(program &pr, const poly<T, D, M> &p) { pr.push_leaf(&p, p.cdata(), nullptr); }
+template <class T, size_t D, size_t M> inline void push(program &pr, const poly_p<T, D, M> &p) {
+  pr.push_leaf(p.payload_id(), nullptr, p.payload_id());
+}
+
 template <class Op> struct opcode { static constexpr int value = -1; static constexpr int delta = 0; };
-template <> struct opcode<addmod> { static constexpr int value = NFLHIP_EXPR_ADD; static constexpr int delta = -1; };
-template <> struct opcode<submod> { static constexpr int value = NFLHIP_EXPR_SUB; static constexpr int delta = -1; };
-template <> struct opcode<mulmod> { static constexpr int value = NFLHIP_EXPR_MUL; static constexpr int delta = -1; };
-template <> struct opcode<mulmod_shoup> { static constexpr int value = NFLHIP_EXPR_MUL_SHOUP; static constexpr int delta = -2; };
-template <> struct opcode<compute_shoup> { static constexpr int value = NFLHIP_EXPR_COMPUTE_SHOUP; static constexpr int delta = 0; };
+template <class T, class tag> struct opcode<addmod<T, tag>> { static constexpr int value = NFLHIP_EXPR_ADD; static constexpr int delta = -1; };
+template <class T, class tag> struct opcode<submod<T, tag>> { static constexpr int value = NFLHIP_EXPR_SUB; static constexpr int delta = -1; };
+template <class T, class tag> struct opcode<mulmod<T, tag>> { static constexpr int value = NFLHIP_EXPR_MUL; static constexpr int delta = -1; };
+template <class T, class tag> struct opcode<mulmod_shoup<T, tag>> { static constexpr int value = NFLHIP_EXPR_MUL_SHOUP; static constexpr int delta = -2; };
+template <class T, class tag> struct opcode<compute_shoup<T, tag>> { static constexpr int value = NFLHIP_EXPR_COMPUTE_SHOUP; static constexpr int delta = 0; };
+template <class Op> struct is_eq : std::false_type {};
+template <class T, class tag> struct is_eq<eqmod<T, tag>> : std::true_type {};
+template <class Op> struct is_neq : std::false_type {};
+template <class T, class tag> struct is_neq<neqmod<T, tag>> : std::true_type {};
 
 template <class Op, class... Args> struct expr {
+  using simd_mode = typename Op::simd_mode;
   std::tuple<Args const &...> args;
-  explicit expr(Args const &... a) : args(a...) {}
+  expr(Args const &... a) : args(a...) {}
   typedef typename std::remove_cv<typename std::remove_reference<
       decltype(std::get<0>(std::declval<std::tuple<Args const &...>>()))>::type>::type first_type;
   typedef typename first_type::value_type value_type;
   typedef typename first_type::poly_type poly_type;
+  typedef detail::payload<poly_type> payload_type;
   static constexpr size_t degree = first_type::degree;
   static constexpr size_t nmoduli = first_type::nmoduli;
+  static constexpr size_t nbits = first_type::nbits;
+  static constexpr size_t aggregated_modulus_bit_size = first_type::aggregated_modulus_bit_size;
+  using p = params<value_type>;
 
-  // evaluate this node into `out`: the whole tree in ONE fused device pass when it fits the
-  // postfix program limits (<= 3 distinct polys, stack depth <= 4), else one pass per node
+  // evaluate this node into the host polynomial `out`: the whole tree in ONE fused device pass when it fits the
+  // host-pointer program limits (<= 3 distinct leaves, stack depth <= 4), else one pass per node
   void eval(poly_type &out) const {
     program pr;
     lower(pr);
-    if (pr.ok && opcode<Op>::value >= 0 && out.apply_program(pr)) return;
+    if (pr.ok && opcode<Op>::value >= 0 && pr.noperands <= 3) {
+      const void *h[3] = {nullptr, nullptr, nullptr};
+      for (size_t k = 0; k < pr.noperands; ++k)
+        h[k] = pr.pay[k] ? static_cast<payload_type *>(pr.pay[k])->host_ro().cdata() : pr.host[k];
+      if (out.apply_program(pr, h)) return;
+    }
     eval_impl(out, std::integral_constant<size_t, sizeof...(Args)>());
+  }
+  // evaluate this node into a resident payload: every leaf is read on the device (handles as they are, inline polys
+  // through a pooled staging buffer), the result stays in HBM.  `pr` was lowered by the caller (before it re-seated its
+  // own payload).  false = the program does not fit / the engine declined (tiny rows): the caller goes through the host.
+  static bool run_resident(const program &pr, payload_type &out) {
+    if (!pr.ok || opcode<Op>::value < 0) return false;
+    typedef typename payload_type::ctx_t ctx_t;
+    if (degree * sizeof(value_type) < 16) return false;  // (rows shorter than one 16-byte vector: nflhip_eval declines)
+    nflhip_ctx *ctx = ctx_t::get();
+    const void *d[NFLHIP_EXPR_MAX_OPERANDS];
+    void *staged[NFLHIP_EXPR_MAX_OPERANDS];
+    size_t nstaged = 0;
+    for (size_t k = 0; k < pr.noperands; ++k) {
+      if (pr.pay[k]) {
+        d[k] = static_cast<payload_type *>(pr.pay[k])->dev_ro();
+      } else {
+        void *s = ctx_t::acquire();
+        staged[nstaged++] = s;
+        detail::check(ctx, nflhip_memcpy_h2d(ctx, s, pr.host[k], payload_type::bytes, ctx_t::queue()), "operator=(expr)");
+        d[k] = s;
+      }
+    }
+    bool aliases = false;
+    for (size_t k = 0; k < pr.noperands; ++k) aliases |= pr.pay[k] == static_cast<void *>(&out);
+    void *o = aliases ? out.dev_rw() : out.dev_wo();
+    const int rc = nflhip_eval_dev(ctx, o, d, pr.noperands, pr.code, pr.len, 1, ctx_t::queue());
+    for (size_t k = 0; k < nstaged; ++k) ctx_t::release(staged[k]);
+    detail::check(ctx, rc, "operator=(expr)");
+    return true;
   }
   // append this subtree to a postfix program
   void lower(program &pr) const {
@@ -339,10 +641,10 @@ template <class Op, class... Args> struct expr {
   }
 
   // expr::operator bool (ops.hpp:81-95): true as soon as ONE lane of the value is non-zero
-  operator bool() const { return truth(Op()); }  // (implicit, as in the reference: `ok &= (a == b);` compiles)
+  operator bool() const { return truth(is_eq<Op>(), is_neq<Op>()); }  // (implicit, as in the reference: `ok &= (a == b);` compiles)
 
  private:
-  template <class A> static void lower_one(const A &a, program &pr, std::true_type) { pr.push_leaf(leaf(a).cdata()); }
+  template <class A> static void lower_one(const A &a, program &pr, std::true_type) { push(pr, a); }
   template <class A> static void lower_one(const A &a, program &pr, std::false_type) { a.lower(pr); }
   template <size_t I> void lower_args(program &pr, std::integral_constant<size_t, I>) const {
     typedef typename std::remove_cv<typename std::remove_reference<decltype(std::get<I>(args))>::type>::type A;
@@ -382,14 +684,35 @@ template <class Op, class... Args> struct expr {
     poly_type::drop_temp(t1);
     poly_type::drop_temp(t2);
   }
-  template <class O> bool truth(O) const {  // arithmetic expression: any non-zero word
+  bool truth(std::false_type, std::false_type) const {  // arithmetic expression: any non-zero word
     poly_type *t = poly_type::make_temp();
     eval(*t);
     const bool r = bool(*t);
     poly_type::drop_temp(t);
     return r;
   }
+  // both sides resident handles: compare in HBM; otherwise on host images through the host-pointer entry
+  template <class A, class B> static bool cmp_resident(const A &, const B &, bool, bool &, std::false_type) { return false; }
+  template <class A, class B> static bool cmp_resident(const A &a, const B &b, bool want_eq, bool &result, std::true_type) {
+    typedef typename payload_type::ctx_t ctx_t;
+    payload_type *pa = static_cast<payload_type *>(a.payload_id()), *pb = static_cast<payload_type *>(b.payload_id());
+    if (!(pa->dev_valid || pb->dev_valid)) return false;  // both live on the host: no point uploading
+    int r = 0;
+    nflhip_ctx *ctx = ctx_t::get();
+    const void *da = pa->dev_ro(), *db = pb->dev_ro();
+    detail::check(ctx, want_eq ? nflhip_any_eq_dev(ctx, da, db, 1, &r, ctx_t::queue()) : nflhip_any_neq_dev(ctx, da, db, 1, &r, ctx_t::queue()),
+                  "operator== / !=");
+    result = r != 0;
+    return true;
+  }
   bool cmp(bool want_eq) const {
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(std::get<0>(args))>::type>::type A;
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(std::get<1>(args))>::type>::type B;
+    bool result = false;
+    if (cmp_resident(std::get<0>(args), std::get<1>(args), want_eq, result,
+                     std::integral_constant<bool, std::is_same<A, poly_p<value_type, degree, nmoduli>>::value &&
+                                                      std::is_same<B, poly_p<value_type, degree, nmoduli>>::value>()))
+      return result;
     poly_type *t0 = poly_type::make_temp(), *t1 = poly_type::make_temp();
     const poly_type &a = mat(std::get<0>(args), *t0);
     const poly_type &b = mat(std::get<1>(args), *t1);
@@ -398,14 +721,31 @@ template <class Op, class... Args> struct expr {
     poly_type::drop_temp(t1);
     return r;
   }
-  bool truth(eqmod) const { return cmp(true); }    // "any lane equal"  (the reference's quirk)
-  bool truth(neqmod) const { return cmp(false); }  // "any lane differs"
+  bool truth(std::true_type, std::false_type) const { return cmp(true); }    // "any lane equal"  (the reference's quirk)
+  bool truth(std::false_type, std::true_type) const { return cmp(false); }   // "any lane differs"
 };
+
+// ops::make_op<Op>(args...) (ops.hpp:249-260) incl. the shoup(a*b, b') -> mulmod_shoup(a, b, b') rewrite (ops.hpp:267-277)
+template <class Op, class... Args> struct _make_op {
+  expr<Op, Args...> operator()(Args const &... args) const { return expr<Op, Args...>(args...); }
+};
+template <class... Args> using retag = typename common_mode<typename Args::simd_mode...>::type;
+template <class tag0, class tag1, class type, class Arg0, class Arg1, class Arg2>
+struct _make_op<shoup<type, tag0>, expr<mulmod<type, tag1>, Arg0, Arg1>, Arg2> {
+  expr<mulmod_shoup<type, tag1>, Arg0, Arg1, Arg2> operator()(expr<mulmod<type, tag1>, Arg0, Arg1> const &from0, Arg2 const &from1) const {
+    return expr<mulmod_shoup<type, tag1>, Arg0, Arg1, Arg2>(std::get<0>(from0.args), std::get<1>(from0.args), from1);
+  }
+};
+template <class Op, class... Args> auto make_op(Args const &... args) -> decltype(_make_op<Op, Args...>{}(args...)) {
+  return _make_op<Op, Args...>{}(args...);
+}
 
 }  // namespace ops
 
 // ---------------------------------------------------------------- poly (poly.hpp:82-310)
 template <class T, size_t Degree, size_t NbModuli> class poly {
+  template <class P> friend class tests::poly_tests_proxy;
+
   static constexpr size_t N = Degree * NbModuli;
   T _data[N] __attribute__((aligned(32)));
 
@@ -418,6 +758,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   typedef pointer_type iterator;
   typedef const_pointer_type const_iterator;
   typedef poly poly_type;
+  using simd_mode = CC_SIMD;
   static constexpr size_t degree = Degree;
   static constexpr size_t nmoduli = NbModuli;
   static constexpr size_t nbits = params<T>::kModulusBitsize;
@@ -425,6 +766,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
 
   /* constructors (core.hpp:64-84) */
   poly() { set(value_type(0)); }
+  explicit poly(detail::uninitialized_t) {}  // (engine plumbing: storage about to be overwritten entirely)
   poly(uniform const &u) { set(u); }
   poly(non_uniform const &m) { set(m); }
   poly(hwt_dist const &m) { set(m); }
@@ -478,8 +820,8 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   // bounded / zero-one / hamming-weight / Gaussian noise, one small integer per coefficient replicated over the
   // moduli (core.hpp:195-391); misuse throws std::runtime_error like the reference (core.hpp:205-210)
   void set(non_uniform const &m) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
-  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO, m.rho, 1, "set(ZO_dist)"); }
-  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT, m.hwt, 1, "set(hwt_dist)"); }
+  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)"); }
+  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT | detail::dist_flags, m.hwt, 1, "set(hwt_dist)"); }
   template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, T, _lu_depth> const &m) {
     detail::sampler &s = detail::sampler::get();
     detail::check(ctx(), nflhip_sample_gauss(ctx(), _data, 1, m.fg_prng->table(ctx()), m.amplifier, s.key, s.next++),
@@ -513,7 +855,8 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   value_type &operator()(size_t cm, size_t i) { return _data[cm * degree + i]; }
   pointer_type data() { return _data; }
   const_pointer_type cdata() const { return _data; }
-  static value_type get_modulus(size_t n) { return params<T>::P()[n]; }
+  template <class M> auto load(size_t cm, size_t i) const -> decltype(M::load(&(this->operator()(cm, i)))) { return M::load(&(*this)(cm, i)); }
+  static constexpr value_type get_modulus(size_t n) { return params<T>::P[n]; }
 
   /* ntt stuff - public API (poly.hpp:167-168) */
   void ntt_pow_phi() { detail::check(ctx(), nflhip_ntt_fwd(ctx(), _data, 1), "ntt_pow_phi"); }
@@ -525,6 +868,102 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   // cereal hook, identical to the reference's (poly.hpp:186-190): works with any archive type that accepts a C array
   template <class Archive> void serialize(Archive &archive) { archive(_data); }
 
+  /* poly::core (poly.hpp:196-245) and the static `base` object, reachable through the tests::poly_tests_proxy friend
+   * exactly as tests/ntt_perfs.cpp:121-134 does: core::ntt / core::inv_ntt are the CYCLIC row transforms
+   * (core.hpp:455-557) and run on the device (nflhip_ntt_row); base.omegas[cm] ... are host views of the reference's
+   * own table layouts (nflhip_get_table, NFLHIP_TAB_*), fetched on first access -- nothing happens at static-init
+   * time.  The device engine owns its tables: core::ntt accepts the table pointers base hands out (that is how it
+   * knows the modulus row and the direction) and throws std::runtime_error for foreign tables. */
+ protected:
+  class core {
+    template <class P> friend class tests::poly_tests_proxy;
+    struct tables {
+      std::vector<value_type> phis, shoupphis, invpoly_times_invphis, shoupinvpoly_times_invphis, omegas, invomegas, invpolyDegree;
+      tables() {
+        auto fetch = [](std::vector<value_type> &v, int which, size_t words) {
+          v.assign(NbModuli * words, 0);
+          for (size_t cm = 0; cm < NbModuli; ++cm)
+            detail::check(ctx(), nflhip_get_table(ctx(), which, cm, v.data() + cm * words, words * sizeof(value_type)), "core tables");
+        };
+        fetch(phis, NFLHIP_TAB_PHIS, Degree);
+        fetch(shoupphis, NFLHIP_TAB_SHOUPPHIS, Degree);
+        fetch(invpoly_times_invphis, NFLHIP_TAB_INVPOLY_INVPHIS, Degree);
+        fetch(shoupinvpoly_times_invphis, NFLHIP_TAB_SHOUPINVPOLY_INVPHIS, Degree);
+        fetch(omegas, NFLHIP_TAB_OMEGAS, 2 * Degree);
+        fetch(invomegas, NFLHIP_TAB_INVOMEGAS, 2 * Degree);
+        fetch(invpolyDegree, NFLHIP_TAB_INVDEGREE, 1);
+      }
+    };
+    static tables &tabs() {
+      static tables t;
+      return t;
+    }
+    // member views with the reference's names and index shapes: view[cm][i]
+    template <int Which> struct view {
+      value_type *operator[](size_t cm) const {
+        tables &t = tabs();
+        return Which == 0   ? t.phis.data() + cm * Degree
+               : Which == 1 ? t.shoupphis.data() + cm * Degree
+               : Which == 2 ? t.invpoly_times_invphis.data() + cm * Degree
+               : Which == 3 ? t.shoupinvpoly_times_invphis.data() + cm * Degree
+               : Which == 4 ? t.omegas.data() + cm * 2 * Degree
+               : Which == 5 ? t.omegas.data() + cm * 2 * Degree + Degree
+               : Which == 6 ? t.invomegas.data() + cm * 2 * Degree
+                            : t.invomegas.data() + cm * 2 * Degree + Degree;
+      }
+    };
+    struct scalar_view {
+      value_type &operator[](size_t cm) const { return tabs().invpolyDegree[cm]; }
+    };
+
+   public:
+    core() {}
+    void ntt_pow_phi(poly &op) { op.ntt_pow_phi(); }
+    void invntt_pow_invphi(poly &op) { op.invntt_pow_invphi(); }
+    // core.hpp:455-532: in-place cyclic transform of one row, natural in, bit-reversed out, [0,p)
+    static bool ntt(value_type *x, const value_type *wtab, const value_type *winvtab, value_type const p) {
+      (void)winvtab;
+      return run_row(x, wtab, p, 0);
+    }
+    // core.hpp:539-557: permut, ntt with the inverse tables, permut (invK is unused there too)
+    static bool inv_ntt(value_type *x, const value_type *const inv_wtab, const value_type *const inv_winvtab, value_type invK,
+                        value_type const p) {
+      (void)inv_winvtab;
+      (void)invK;
+      return run_row(x, inv_wtab, p, NFLHIP_ROW_BITREV_IO);
+    }
+
+   private:
+    static bool run_row(value_type *x, const value_type *wtab, value_type p, int mode) {
+      tables &t = tabs();
+      for (size_t cm = 0; cm < NbModuli; ++cm) {
+        if (get_modulus(cm) != p) continue;
+        if (wtab == t.omegas.data() + cm * 2 * Degree) {
+          detail::check(ctx(), nflhip_ntt_row(ctx(), x, cm, mode, 1), "core::ntt");
+          return true;
+        }
+        if (wtab == t.invomegas.data() + cm * 2 * Degree) {
+          detail::check(ctx(), nflhip_ntt_row(ctx(), x, cm, mode | NFLHIP_ROW_INVERSE_TABLES, 1), "core::ntt");
+          return true;
+        }
+      }
+      throw std::runtime_error("nfl(hip): core::ntt runs the engine's own tables (base.omegas / base.invomegas of this modulus)");
+    }
+
+   public:  // (private in the reference, reached through the friend proxy; views are stateless)
+    view<0> phis;
+    view<1> shoupphis;
+    view<2> invpoly_times_invphis;
+    view<3> shoupinvpoly_times_invphis;
+    view<4> omegas;
+    view<5> shoupomegas;
+    view<6> invomegas;
+    view<7> shoupinvomegas;
+    scalar_view invpolyDegree;
+  };
+  static core base;
+
+ public:
   /* CRT (gmp.hpp:183-219) on little-endian 64-bit limb vectors */
   static size_t crt_limbs() { return nflhip_crt_limbs(ctx()); }
   // out[i*L .. i*L+L) = limbs of X_i in [0, Q): the mpz_export image of poly2mpz()
@@ -583,10 +1022,13 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
 
   poly(mpz_t const &v) { set_mpz(v); }
   poly(std::array<mpz_t, Degree> const &values) { set_mpz(values); }
+  poly(std::initializer_list<mpz_t> const &values) { set_mpz(values); }
   void set_mpz(mpz_t const &v) { set_mpz(&v, &v + 1); }
   void set_mpz(std::array<mpz_t, Degree> const &values) { set_mpz(values.begin(), values.end()); }
+  void set_mpz(std::initializer_list<mpz_t> const &values) { set_mpz(values.begin(), values.end()); }
   poly &operator=(mpz_t const &v) { set_mpz(v); return *this; }
   poly &operator=(std::array<mpz_t, Degree> const &values) { set_mpz(values); return *this; }
+  poly &operator=(std::initializer_list<mpz_t> const &values) { set_mpz(values); return *this; }
 #ifdef NFL_HIP_HAVE_GMPXX
   poly(mpz_class const &v) { set_mpz(v); }
   poly(std::array<mpz_class, Degree> const &values) { set_mpz(values); }
@@ -658,6 +1100,9 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
 
   // ---- plumbing used by the expression templates (not part of the reference surface) ----
   static nflhip_ctx *ctx() { return detail::context<T, Degree, NbModuli>::get(); }
+  static void *queue() { return detail::context<T, Degree, NbModuli>::queue(); }  // the stream resident operations run on
+  static void *acquire_device() { return detail::context<T, Degree, NbModuli>::acquire(); }
+  static void release_device(void *p) { detail::context<T, Degree, NbModuli>::release(p); }
   void sample(int dist, uint64_t p0, uint64_t p1, const char *what) {
     detail::sampler &s = detail::sampler::get();
     detail::check(ctx(), nflhip_sample(ctx(), _data, 1, dist, p0, p1, s.key, s.next++), what);
@@ -666,8 +1111,8 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
     detail::check(ctx(), nflhip_pointwise(ctx(), op, _data, a._data, b._data, bp._data, 1), "operator=(expr)");
   }
   // fused tree evaluation; false = the engine declined (tiny rows): the caller goes node by node
-  bool apply_program(const ops::program &pr) {
-    const int rc = nflhip_eval(ctx(), _data, pr.operand, pr.noperands, pr.code, pr.len, 1);
+  bool apply_program(const ops::program &pr, const void *const *host_operands) {
+    const int rc = nflhip_eval(ctx(), _data, host_operands, pr.noperands, pr.code, pr.len, 1);
     if (rc == NFLHIP_ERR_UNSUPPORTED) return false;
     detail::check(ctx(), rc, "operator=(expr)");
     return true;
@@ -681,13 +1126,14 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   static poly *make_temp() {  // polys can be MBs: temporaries of nested expressions live on the heap
     void *mem = nullptr;
     if (posix_memalign(&mem, 32, sizeof(poly)) != 0) throw std::bad_alloc();
-    return new (mem) poly();
+    return new (mem) poly(detail::uninitialized_t());
   }
   static void drop_temp(poly *p) {
     p->~poly();
     free(p);
   }
 } __attribute__((aligned(32)));
+template <class T, size_t Degree, size_t NbModuli> typename poly<T, Degree, NbModuli>::core poly<T, Degree, NbModuli>::base;
 
 // ---------------------------------------------------------------- operators (poly.hpp:346-352, ops.hpp:18-45)
 namespace ops {
@@ -698,70 +1144,147 @@ template <class Op, class... A> struct is_node<expr<Op, A...>> : std::true_type 
 // == and != on a poly_p are its own members (poly_p.hpp:112-140); everything else is generic
 template <class X> struct is_cmp_node : is_node<X> {};
 template <class T, size_t D, size_t M> struct is_cmp_node<poly_p<T, D, M>> : std::false_type {};
+// anything else handed to the shoup marker is a compile-time error, as in the reference (ops.hpp:153-163)
+template <class type, class tag, class A, class B> struct _make_op<shoup<type, tag>, A, B> {
+  static_assert(sizeof(A) == 0, "shoup(expr, b') needs expr = a * b (ops.hpp:160)");
+};
 }  // namespace ops
 
-#define NFL_HIP_BINARY(SYM, NAME)                                                                          \
-  template <class A, class B>                                                                              \
-  typename std::enable_if<ops::is_node<A>::value && ops::is_node<B>::value, ops::expr<ops::NAME, A, B>>::type SYM( \
-      A const &a, B const &b) {                                                                            \
-    static_assert(std::is_same<typename A::poly_type, typename B::poly_type>::value, "correct type combination"); \
-    return ops::expr<ops::NAME, A, B>(a, b);                                                               \
+#define NFL_HIP_BINARY(SYM, NAME)                                                                                       \
+  template <class A, class B>                                                                                           \
+  typename std::enable_if<ops::is_node<A>::value && ops::is_node<B>::value,                                             \
+                          ops::expr<ops::NAME<typename A::value_type, CC_SIMD>, A, B>>::type SYM(A const &a, B const &b) { \
+    static_assert(std::is_same<typename A::poly_type, typename B::poly_type>::value, "correct type combination");       \
+    return ops::make_op<ops::NAME<typename A::value_type, CC_SIMD>>(a, b);                                              \
   }
 NFL_HIP_BINARY(operator-, submod)
 NFL_HIP_BINARY(operator+, addmod)
 NFL_HIP_BINARY(operator*, mulmod)
 #undef NFL_HIP_BINARY
-#define NFL_HIP_COMPARE(SYM, NAME)                                                                               \
-  template <class A, class B>                                                                                    \
-  typename std::enable_if<ops::is_cmp_node<A>::value && ops::is_node<B>::value, ops::expr<ops::NAME, A, B>>::type SYM( \
-      A const &a, B const &b) {                                                                                  \
-    static_assert(std::is_same<typename A::poly_type, typename B::poly_type>::value, "correct type combination"); \
-    return ops::expr<ops::NAME, A, B>(a, b);                                                                     \
+#define NFL_HIP_COMPARE(SYM, NAME)                                                                                      \
+  template <class A, class B>                                                                                           \
+  typename std::enable_if<ops::is_cmp_node<A>::value && ops::is_node<B>::value,                                         \
+                          ops::expr<ops::NAME<typename A::value_type, CC_SIMD>, A, B>>::type SYM(A const &a, B const &b) { \
+    static_assert(std::is_same<typename A::poly_type, typename B::poly_type>::value, "correct type combination");       \
+    return ops::make_op<ops::NAME<typename A::value_type, CC_SIMD>>(a, b);                                              \
   }
 NFL_HIP_COMPARE(operator==, eqmod)
 NFL_HIP_COMPARE(operator!=, neqmod)
 #undef NFL_HIP_COMPARE
 
-template <class A> typename std::enable_if<ops::is_node<A>::value, ops::expr<ops::compute_shoup, A>>::type compute_shoup(A const &a) {
-  return ops::expr<ops::compute_shoup, A>(a);
+template <class A>
+typename std::enable_if<ops::is_node<A>::value, ops::expr<ops::compute_shoup<typename A::value_type, CC_SIMD>, A>>::type compute_shoup(A const &a) {
+  return ops::make_op<ops::compute_shoup<typename A::value_type, CC_SIMD>>(a);
 }
-// shoup(a*b, b') is rewritten into mulmod_shoup(a, b, b') (ops.hpp:267-277); anything else
-// is a compile-time error, as in the reference (ops.hpp:153-163)
-template <class A0, class A1, class B>
-ops::expr<ops::mulmod_shoup, A0, A1, B> shoup(ops::expr<ops::mulmod, A0, A1> const &prod, B const &bprime) {
-  return ops::expr<ops::mulmod_shoup, A0, A1, B>(std::get<0>(prod.args), std::get<1>(prod.args), bprime);
+// shoup(a*b, b') is rewritten into mulmod_shoup(a, b, b') (ops.hpp:267-277)
+template <class A, class B>
+auto shoup(A const &prod, B const &bprime) -> decltype(ops::make_op<ops::shoup<typename A::value_type, CC_SIMD>>(prod, bprime)) {
+  return ops::make_op<ops::shoup<typename A::value_type, CC_SIMD>>(prod, bprime);
 }
 
 // ---------------------------------------------------------------- poly_p (poly_p.hpp:11-204)
-// Copy-on-write handle to a heap-allocated, 32-byte aligned poly: same members as the reference's class.
+// Copy-on-write handle with the reference's members; the shared payload is RESIDENT (detail::payload): operator
+// expressions over handles, transforms, comparisons and the random constructors run on the device and leave the result
+// in HBM; poly_obj(), operator()(cm,i), serialisation and the GMP surface bring it to the host (and a non-const access
+// marks the device image stale).
 template <class T, size_t Degree, size_t NbModuli> class poly_p {
  public:
   typedef poly<T, Degree, NbModuli> poly_type;
   using value_type = typename poly_type::value_type;
   using greater_value_type = typename poly_type::greater_value_type;
+  using simd_mode = typename poly_type::simd_mode;
   static constexpr size_t nmoduli = poly_type::nmoduli;
   static constexpr size_t degree = poly_type::degree;
   static constexpr size_t nbits = poly_type::nbits;
   static constexpr size_t aggregated_modulus_bit_size = poly_type::aggregated_modulus_bit_size;
 
  private:
-  typedef std::shared_ptr<poly_type> ptr_type;
-  template <class... Args> static ptr_type make_pointer(Args &&... args) {
-    void *mem = nullptr;
-    if (posix_memalign(&mem, 32, sizeof(poly_type)) != 0) throw std::bad_alloc();
-    poly_type *p = nullptr;
+  typedef detail::payload<poly_type> payload_type;
+  typedef typename payload_type::ctx_t ctx_t;
+  typedef std::shared_ptr<payload_type> ptr_type;
+  mutable ptr_type _p;
+
+  static ptr_type fresh() { return std::make_shared<payload_type>(); }
+  // constructors: the zero polynomial and the random tags never touch the host; everything else builds the host image
+  // with poly's own constructor (same argument meaning, same exceptions)
+  static ptr_type make_pointer() { return fresh(); }
+  static ptr_type make_pointer(uniform const &m) { ptr_type p = fresh(); sample_into(*p, m); return p; }
+  static ptr_type make_pointer(non_uniform const &m) { ptr_type p = fresh(); sample_into(*p, m); return p; }
+  static ptr_type make_pointer(ZO_dist const &m) { ptr_type p = fresh(); sample_into(*p, m); return p; }
+  static ptr_type make_pointer(hwt_dist const &m) { ptr_type p = fresh(); sample_into(*p, m); return p; }
+  template <class in_class, unsigned _lu_depth> static ptr_type make_pointer(gaussian<in_class, T, _lu_depth> const &m) {
+    ptr_type p = fresh();
+    sample_into(*p, m);
+    return p;
+  }
+  template <class Op, class... A> static ptr_type make_pointer(ops::expr<Op, A...> const &e) {
+    ptr_type p = fresh();
+    assign_expr(p, e);
+    return p;
+  }
+  // (the overloads above must win over this forwarding template for rvalue tags and expressions)
+  template <class X, class Dummy = void> struct device_init : std::false_type {};
+  template <class Dummy> struct device_init<uniform, Dummy> : std::true_type {};
+  template <class Dummy> struct device_init<non_uniform, Dummy> : std::true_type {};
+  template <class Dummy> struct device_init<ZO_dist, Dummy> : std::true_type {};
+  template <class Dummy> struct device_init<hwt_dist, Dummy> : std::true_type {};
+  template <class in_class, unsigned _lu_depth, class Dummy> struct device_init<gaussian<in_class, T, _lu_depth>, Dummy> : std::true_type {};
+  template <class Op, class... A, class Dummy> struct device_init<ops::expr<Op, A...>, Dummy> : std::true_type {};
+  template <class A0, class... Args>
+  static typename std::enable_if<!device_init<typename std::decay<A0>::type>::value || sizeof...(Args) != 0, ptr_type>::type make_pointer(
+      A0 &&a0, Args &&... args) {
+    ptr_type p = fresh();
+    p->alloc_host();
+    p->host->~poly_type();
+    new (p->host) poly_type(std::forward<A0>(a0), std::forward<Args>(args)...);
+    p->host_valid = true;
+    return p;
+  }
+  void detach() const {
+    if (!_p.unique()) _p = std::make_shared<payload_type>(*_p);  // (device-to-device when the value lives in HBM)
+  }
+  void detach_for_overwrite() {
+    if (!_p.unique()) _p = fresh();
+  }
+
+  // ---- device-side samplers (same keystream discipline as poly::sample: a fresh stream id per call)
+  static void sample_dist(payload_type &p, int dist, uint64_t p0, uint64_t p1, const char *what) {
+    detail::sampler &s = detail::sampler::get();
+    detail::check(ctx_t::get(), nflhip_sample_dev(ctx_t::get(), p.dev_wo(), 0, 1, dist, p0, p1, s.key, s.next++, ctx_t::queue()), what);
+  }
+  static void sample_into(payload_type &p, uniform const &u) {
+    if (u.seeded) detail::check(ctx_t::get(), nflhip_fill_uniform_dev(ctx_t::get(), p.dev_wo(), 0, 1, u.seed, 0, ctx_t::queue()), "set(uniform)");
+    else sample_dist(p, NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+  }
+  static void sample_into(payload_type &p, non_uniform const &m) { sample_dist(p, NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
+  static void sample_into(payload_type &p, ZO_dist const &m) { sample_dist(p, NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)"); }
+  static void sample_into(payload_type &p, hwt_dist const &m) { sample_dist(p, NFLHIP_DIST_HWT | detail::dist_flags, m.hwt, 1, "set(hwt_dist)"); }
+  template <class in_class, unsigned _lu_depth> static void sample_into(payload_type &p, gaussian<in_class, T, _lu_depth> const &m) {
+    detail::sampler &s = detail::sampler::get();
+    const nflhip_gauss *tab = m.fg_prng->table(ctx_t::get());
+    detail::check(ctx_t::get(), nflhip_sample_gauss_dev(ctx_t::get(), p.dev_wo(), 0, 1, tab, m.amplifier, s.key, s.next++, ctx_t::queue()),
+                  "set(gaussian)");
+  }
+  // THE evaluation point of an expression tree over handles (core.hpp:24-37): one fused device pass, result resident.
+  // `p` is re-seated first when it is shared (copy-on-write without the copy: the whole value is overwritten); the
+  // program is lowered BEFORE that, so a tree that reads the old value still sees it.
+  template <class Op, class... A> static void assign_expr(ptr_type &p, ops::expr<Op, A...> const &e) {
+    ops::program pr;
+    e.lower(pr);
+    ptr_type keep = p;  // the old payload stays alive while the kernel reads it
+    if (keep.use_count() > 2) p = fresh();  // shared with another handle
+    if (ops::expr<Op, A...>::run_resident(pr, *p)) return;
+    // through the host: node by node, or trees the fused program cannot hold
+    poly_type *tmp = poly_type::make_temp();
     try {
-      p = new (mem) poly_type(std::forward<Args>(args)...);
+      e.eval(*tmp);
     } catch (...) {
-      free(mem);
+      poly_type::drop_temp(tmp);
       throw;
     }
-    return ptr_type(p, [](poly_type *q) { q->~poly_type(); free(q); });
+    std::memcpy(p->host_wo().data(), tmp->cdata(), payload_type::bytes);
+    poly_type::drop_temp(tmp);
   }
-  void detach() {
-    if (!_p.unique()) _p = make_pointer(*_p);
-  }
-  ptr_type _p;
 
  public:
   poly_p(poly_p const &o) : _p(o._p) {}
@@ -771,12 +1294,31 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   poly_p(poly_type const &) = delete;
   poly_p(poly_type &&) = delete;
 
+  // the polynomial as a host object (poly_p.hpp:47-53): forces the value to the host; the non-const form may be
+  // written through, so it also retires the device image
   poly_type &poly_obj() {
     detach();
-    return *_p;
+    return _p->host_rw();
   }
-  poly_type const &poly_obj() const { return *_p; }
+  poly_type const &poly_obj() const { return _p->host_ro(); }
+  void *payload_id() const { return _p.get(); }  // (engine plumbing: identity of the shared payload)
+  bool resident() const { return _p->dev_valid; }  // the current value is in HBM (no upload needed by the next device op)
+  // wait for every enqueued operation of this ring type (results are otherwise only awaited when read on the host)
+  static void synchronize() { detail::check(ctx_t::get(), nflhip_stream_sync(ctx_t::get(), ctx_t::queue()), "synchronize"); }
 
+  template <class Op, class... A> poly_p &operator=(ops::expr<Op, A...> const &e) {
+    assign_expr(_p, e);
+    return *this;
+  }
+  poly_p &operator=(uniform const &m) { detach_for_overwrite(); sample_into(*_p, m); return *this; }
+  poly_p &operator=(non_uniform const &m) { detach_for_overwrite(); sample_into(*_p, m); return *this; }
+  poly_p &operator=(ZO_dist const &m) { detach_for_overwrite(); sample_into(*_p, m); return *this; }
+  poly_p &operator=(hwt_dist const &m) { detach_for_overwrite(); sample_into(*_p, m); return *this; }
+  template <class in_class, unsigned _lu_depth> poly_p &operator=(gaussian<in_class, T, _lu_depth> const &m) {
+    detach_for_overwrite();
+    sample_into(*_p, m);
+    return *this;
+  }
   template <class O> poly_p &operator=(O &&o) {
     poly_obj() = std::forward<O>(o);
     return *this;
@@ -795,29 +1337,62 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     return *this;
   }
 
-  bool operator==(poly_p const &o) const { return _p.get() == o._p.get() ? true : bool(poly_obj() == o.poly_obj()); }
-  bool operator!=(poly_p const &o) const { return _p.get() == o._p.get() ? false : bool(poly_obj() != o.poly_obj()); }
+  bool operator==(poly_p const &o) const { return _p.get() == o._p.get() ? true : bool(ops::make_op<ops::eqmod<T, CC_SIMD>>(*this, o)); }
+  bool operator!=(poly_p const &o) const { return _p.get() == o._p.get() ? false : bool(ops::make_op<ops::neqmod<T, CC_SIMD>>(*this, o)); }
   template <class O> bool operator==(O const &o) const { return bool(poly_obj() == o); }
   template <class O> bool operator!=(O const &o) const { return bool(poly_obj() != o); }
 
   value_type &operator()(size_t cm, size_t i) { return poly_obj()(cm, i); }
   value_type const &operator()(size_t cm, size_t i) const { return poly_obj()(cm, i); }
+  template <class M> auto load(size_t cm, size_t i) const -> decltype(M::load(&(this->operator()(cm, i)))) { return M::load(&(*this)(cm, i)); }
   static constexpr value_type get_modulus(size_t n) { return poly_type::get_modulus(n); }
 
-  void ntt_pow_phi() { poly_obj().ntt_pow_phi(); }
-  void invntt_pow_invphi() { poly_obj().invntt_pow_invphi(); }
+  /* ntt stuff - public API (poly_p.hpp:141-142): in place in HBM */
+  void ntt_pow_phi() {
+    detach();
+    detail::check(ctx_t::get(), nflhip_ntt_fwd_dev(ctx_t::get(), _p->dev_rw(), 1, ctx_t::queue()), "ntt_pow_phi");
+  }
+  void invntt_pow_invphi() {
+    detach();
+    detail::check(ctx_t::get(), nflhip_ntt_inv_dev(ctx_t::get(), _p->dev_rw(), 1, ctx_t::queue()), "invntt_pow_invphi");
+  }
   void serialize_manually(std::ostream &os) { poly_obj().serialize_manually(os); }
   void deserialize_manually(std::istream &is) { poly_obj().deserialize_manually(is); }
   template <class Archive> void serialize(Archive &archive) { archive(poly_obj()); }
 
+  /* set (poly_p.hpp:161-167) */
   void set(value_type v, bool reduce_coeffs = true) { poly_obj().set(v, reduce_coeffs); }
-  void set(uniform const &m) { poly_obj().set(m); }
-  void set(non_uniform const &m) { poly_obj().set(m); }
-  void set(ZO_dist const &m) { poly_obj().set(m); }
-  void set(hwt_dist const &m) { poly_obj().set(m); }
-  template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, T, _lu_depth> const &m) { poly_obj().set(m); }
+  void set(uniform const &m) { *this = m; }
+  void set(non_uniform const &m) { *this = m; }
+  void set(ZO_dist const &m) { *this = m; }
+  void set(hwt_dist const &m) { *this = m; }
+  template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, T, _lu_depth> const &m) { *this = m; }
   void set(std::initializer_list<value_type> values, bool reduce_coeffs = true) { poly_obj().set(values, reduce_coeffs); }
+  void set(std::array<value_type, Degree> values, bool reduce_coeffs = true) { poly_obj().set(values.begin(), values.end(), reduce_coeffs); }
   template <class It> void set(It first, It last, bool reduce_coeffs = true) { poly_obj().set(first, last, reduce_coeffs); }
+
+  /* CRT on limb vectors, as on poly */
+  static size_t crt_limbs() { return poly_type::crt_limbs(); }
+  void poly2limbs(std::vector<uint64_t> &out) const { poly_obj().poly2limbs(out); }
+  void limbs2poly(const uint64_t *limbs, size_t L_in) { poly_obj().limbs2poly(limbs, L_in); }
+#ifdef NFL_HIP_WITH_GMP
+  /* the GMP-typed surface (poly_p.hpp:186-200) */
+  void set_mpz(mpz_t const &v) { poly_obj().set_mpz(v); }
+  void set_mpz(std::array<mpz_t, Degree> const &values) { poly_obj().set_mpz(values); }
+#ifdef NFL_HIP_HAVE_GMPXX
+  void set_mpz(mpz_class const &v) { poly_obj().set_mpz(v); }
+  void set_mpz(std::array<mpz_class, Degree> const &values) { poly_obj().set_mpz(values); }
+  void set_mpz(std::initializer_list<mpz_class> const &values) { poly_obj().set_mpz(values); }
+#endif
+  template <class It> void set_mpz(It first, It last) { poly_obj().set_mpz(first, last); }
+  std::array<mpz_t, Degree> poly2mpz() { return const_cast<poly_p const *>(this)->poly_obj().poly2mpz(); }
+  void poly2mpz(std::array<mpz_t, Degree> &array) { const_cast<poly_p const *>(this)->poly_obj().poly2mpz(array); }
+  void mpz2poly(std::array<mpz_t, Degree> const &array) { poly_obj().mpz2poly(array); }
+  static size_t bits_in_moduli_product() { return poly_type::bits_in_moduli_product(); }
+  static mpz_t &moduli_product() { return poly_type::moduli_product(); }
+  static mpz_t &modulus_shoup() { return poly_type::modulus_shoup(); }
+  static std::array<mpz_t, nmoduli> lifting_integers() { return poly_type::lifting_integers(); }
+#endif
 };
 
 template <class T, size_t Degree, size_t AggregatedModulusBitSize>
@@ -892,42 +1467,42 @@ template <class P> class device_batch {
   const void *data() const { return d_; }
 
   void upload(const P *host) {
-    detail::check(P::ctx(), nflhip_memcpy_h2d(P::ctx(), d_, host->cdata(), bytes(), nullptr), "upload");
+    detail::check(P::ctx(), nflhip_memcpy_h2d(P::ctx(), d_, host->cdata(), bytes(), P::queue()), "upload");
     sync();
   }
   void download(P *host) const {
-    detail::check(P::ctx(), nflhip_memcpy_d2h(P::ctx(), host->data(), d_, bytes(), nullptr), "download");
+    detail::check(P::ctx(), nflhip_memcpy_d2h(P::ctx(), host->data(), d_, bytes(), P::queue()), "download");
     sync();
   }
-  void sync() const { detail::check(P::ctx(), nflhip_stream_sync(P::ctx(), nullptr), "sync"); }
+  void sync() const { detail::check(P::ctx(), nflhip_stream_sync(P::ctx(), P::queue()), "sync"); }
 
   // same names and meaning as the poly members (poly.hpp:167-168), over the whole batch
-  void ntt_pow_phi() { detail::check(P::ctx(), nflhip_ntt_fwd_dev(P::ctx(), d_, n_, nullptr), "ntt_pow_phi"); }
-  void invntt_pow_invphi() { detail::check(P::ctx(), nflhip_ntt_inv_dev(P::ctx(), d_, n_, nullptr), "invntt_pow_invphi"); }
+  void ntt_pow_phi() { detail::check(P::ctx(), nflhip_ntt_fwd_dev(P::ctx(), d_, n_, P::queue()), "ntt_pow_phi"); }
+  void invntt_pow_invphi() { detail::check(P::ctx(), nflhip_ntt_inv_dev(P::ctx(), d_, n_, P::queue()), "invntt_pow_invphi"); }
   // *this = op(a, b[, b'])  (NFLHIP_OP_*); aliasing allowed
   void assign(int op, const device_batch &a, const device_batch &b) {
     same_size(a); same_size(b);
-    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), op, d_, a.d_, b.d_, nullptr, n_, nullptr), "pointwise");
+    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), op, d_, a.d_, b.d_, nullptr, n_, P::queue()), "pointwise");
   }
   void assign_mul_shoup(const device_batch &a, const device_batch &b, const device_batch &bprime) {
     same_size(a); same_size(b); same_size(bprime);
-    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_MUL_SHOUP, d_, a.d_, b.d_, bprime.d_, n_, nullptr),
+    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_MUL_SHOUP, d_, a.d_, b.d_, bprime.d_, n_, P::queue()),
                   "mulmod_shoup");
   }
   void assign_compute_shoup(const device_batch &b) {
     same_size(b);
-    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_COMPUTE_SHOUP, d_, b.d_, nullptr, nullptr, n_, nullptr),
+    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_COMPUTE_SHOUP, d_, b.d_, nullptr, nullptr, n_, P::queue()),
                   "compute_shoup");
   }
   // *this = INTT(NTT(a) (.) NTT(b)), the fused metric path
   void assign_polymul(const device_batch &a, const device_batch &b) {
     same_size(a); same_size(b);
-    detail::check(P::ctx(), nflhip_polymul_dev(P::ctx(), d_, a.d_, b.d_, n_, nullptr), "polymul");
+    detail::check(P::ctx(), nflhip_polymul_dev(P::ctx(), d_, a.d_, b.d_, n_, P::queue()), "polymul");
   }
   // the same with b already in NTT form (keys of the LWE demo stay transformed, tests/nfllib_demo_main_op.cpp:26-46)
   void assign_polymul_ntt(const device_batch &a, const device_batch &b_ntt) {
     same_size(a); same_size(b_ntt);
-    detail::check(P::ctx(), nflhip_polymul_ntt_dev(P::ctx(), d_, a.d_, b_ntt.d_, n_, nullptr), "polymul_ntt");
+    detail::check(P::ctx(), nflhip_polymul_ntt_dev(P::ctx(), d_, a.d_, b_ntt.d_, n_, P::queue()), "polymul_ntt");
   }
   // CRT lift / project of the whole resident batch (gmp.hpp:183-219): out[(b*degree + i)*L .. +L) = little-endian limbs
   // of X_{b,i} in [0, Q), L = P::crt_limbs(); limbs2poly takes L_in limbs per coefficient
@@ -936,9 +1511,9 @@ template <class P> class device_batch {
     out.assign(words, 0);
     void *dl = nullptr;
     detail::check(P::ctx(), nflhip_malloc(P::ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
-    int rc = nflhip_crt_lift_dev(P::ctx(), static_cast<uint64_t *>(dl), d_, n_, nullptr);
-    if (rc == 0) rc = nflhip_memcpy_d2h(P::ctx(), out.data(), dl, words * sizeof(uint64_t), nullptr);
-    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), nullptr);
+    int rc = nflhip_crt_lift_dev(P::ctx(), static_cast<uint64_t *>(dl), d_, n_, P::queue());
+    if (rc == 0) rc = nflhip_memcpy_d2h(P::ctx(), out.data(), dl, words * sizeof(uint64_t), P::queue());
+    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), P::queue());
     nflhip_free(P::ctx(), dl);
     detail::check(P::ctx(), rc, "poly2mpz");
   }
@@ -946,9 +1521,9 @@ template <class P> class device_batch {
     const size_t words = n_ * P::degree * L_in;
     void *dl = nullptr;
     detail::check(P::ctx(), nflhip_malloc(P::ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
-    int rc = nflhip_memcpy_h2d(P::ctx(), dl, limbs, words * sizeof(uint64_t), nullptr);
-    if (rc == 0) rc = nflhip_crt_project_dev(P::ctx(), d_, static_cast<const uint64_t *>(dl), L_in, n_, nullptr);
-    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), nullptr);
+    int rc = nflhip_memcpy_h2d(P::ctx(), dl, limbs, words * sizeof(uint64_t), P::queue());
+    if (rc == 0) rc = nflhip_crt_project_dev(P::ctx(), d_, static_cast<const uint64_t *>(dl), L_in, n_, P::queue());
+    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), P::queue());
     nflhip_free(P::ctx(), dl);
     detail::check(P::ctx(), rc, "mpz2poly");
   }
@@ -957,26 +1532,34 @@ template <class P> class device_batch {
     const void *ptr[NFLHIP_EXPR_MAX_OPERANDS];
     if (count > NFLHIP_EXPR_MAX_OPERANDS) throw std::runtime_error("nfl(hip): too many operands");
     for (size_t i = 0; i < count; ++i) { same_size(*operands[i]); ptr[i] = operands[i]->d_; }
-    detail::check(P::ctx(), nflhip_eval_dev(P::ctx(), d_, ptr, count, program, len, n_, nullptr), "eval");
+    detail::check(P::ctx(), nflhip_eval_dev(P::ctx(), d_, ptr, count, program, len, n_, P::queue()), "eval");
   }
   // the random constructors over the whole resident batch (same tags as poly's; one keystream per call)
   void set(uniform const &u) {
-    if (u.seeded) detail::check(P::ctx(), nflhip_fill_uniform_dev(P::ctx(), d_, 0, n_, u.seed, 0, nullptr), "set(uniform)");
+    if (u.seeded) detail::check(P::ctx(), nflhip_fill_uniform_dev(P::ctx(), d_, 0, n_, u.seed, 0, P::queue()), "set(uniform)");
     else sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
   }
   void set(non_uniform const &m) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
-  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO, m.rho, 1, "set(ZO_dist)"); }
-  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT, m.hwt, 1, "set(hwt_dist)"); }
+  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)"); }
+  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT | detail::dist_flags, m.hwt, 1, "set(hwt_dist)"); }
   template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, value_type, _lu_depth> const &m) {
     detail::sampler &s = detail::sampler::get();
     detail::check(P::ctx(), nflhip_sample_gauss_dev(P::ctx(), d_, 0, n_, m.fg_prng->table(P::ctx()), m.amplifier, s.key,
-                                                    s.next++, nullptr), "set(gaussian)");
+                                                    s.next++, P::queue()), "set(gaussian)");
   }
   // replicate one polynomial over the batch (a key shared by every ciphertext, ...)
-  void fill(const P &one) {
-    for (size_t k = 0; k < n_; ++k)
-      detail::check(P::ctx(), nflhip_memcpy_h2d(P::ctx(), static_cast<char *>(d_) + k * sizeof(P), one.cdata(), sizeof(P), nullptr), "fill");
-    sync();
+  void fill(const P &one) {  // one upload + one broadcast kernel
+    void *tmp = P::acquire_device();
+    int rc = nflhip_memcpy_h2d(P::ctx(), tmp, one.cdata(), sizeof(P), P::queue());
+    if (rc == 0) rc = nflhip_broadcast_dev(P::ctx(), d_, tmp, n_, P::queue());
+    P::release_device(tmp);
+    detail::check(P::ctx(), rc, "fill");
+  }
+  // the same from a resident handle: no host copy at all
+  void fill(const poly_p<value_type, P::degree, P::nmoduli> &one) {
+    typedef detail::payload<P> payload_type;
+    const void *src = static_cast<payload_type *>(one.payload_id())->dev_ro();
+    detail::check(P::ctx(), nflhip_broadcast_dev(P::ctx(), d_, src, n_, P::queue()), "fill");
   }
   bool any_equal(const device_batch &o) const { return cmp(o, true); }    // the reference's `a == b`
   bool any_differs(const device_batch &o) const { return cmp(o, false); } // the reference's `a != b`
@@ -987,13 +1570,13 @@ template <class P> class device_batch {
   }
   void sample(int dist, uint64_t p0, uint64_t p1, const char *what) {
     detail::sampler &s = detail::sampler::get();
-    detail::check(P::ctx(), nflhip_sample_dev(P::ctx(), d_, 0, n_, dist, p0, p1, s.key, s.next++, nullptr), what);
+    detail::check(P::ctx(), nflhip_sample_dev(P::ctx(), d_, 0, n_, dist, p0, p1, s.key, s.next++, P::queue()), what);
   }
   bool cmp(const device_batch &o, bool want_eq) const {
     same_size(o);
     int r = 0;
-    detail::check(P::ctx(), want_eq ? nflhip_any_eq_dev(P::ctx(), d_, o.d_, n_, &r, nullptr)
-                                    : nflhip_any_neq_dev(P::ctx(), d_, o.d_, n_, &r, nullptr), "compare");
+    detail::check(P::ctx(), want_eq ? nflhip_any_eq_dev(P::ctx(), d_, o.d_, n_, &r, P::queue())
+                                    : nflhip_any_neq_dev(P::ctx(), d_, o.d_, n_, &r, P::queue()), "compare");
     return r != 0;
   }
   size_t n_;

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NFLHIP_ABI_VERSION 1
+#define NFLHIP_ABI_VERSION 2
 
 typedef struct nflhip_ctx nflhip_ctx;
 
@@ -62,7 +62,16 @@ enum {
 enum {
   NFLHIP_TAB_PSI = 0,       /* engine layout: n pairs (psi^bitrev(k), Shoup companion), k=0..n-1 */
   NFLHIP_TAB_MODULUS = 1,   /* 1 word: params<T>::P[cm]                       params.hpp:21,55,97 */
-  NFLHIP_TAB_INVDEGREE = 2  /* 1 word: core::invpolyDegree[cm]                core.hpp:664-665 */
+  NFLHIP_TAB_INVDEGREE = 2, /* 1 word: core::invpolyDegree[cm]                core.hpp:664-665 */
+  /* the reference's OWN table layouts (poly.hpp:228-237), rebuilt on the host from the same roots: what a caller that
+   * reads core::base through the tests::poly_tests_proxy friend sees (tests/ntt_perfs.cpp:132-133).  No device needed. */
+  NFLHIP_TAB_PHIS = 3,                 /* degree words: phi^i                          core.hpp:649-656 */
+  NFLHIP_TAB_SHOUPPHIS = 4,            /* degree words: their Shoup companions */
+  NFLHIP_TAB_INVPOLY_INVPHIS = 5,      /* degree words: n^-1 * phi^-i                  core.hpp:664-676 */
+  NFLHIP_TAB_SHOUPINVPOLY_INVPHIS = 6, /* degree words */
+  NFLHIP_TAB_OMEGAS = 7,               /* 2*degree words: stage-concatenated powers of omega = phi^2 (core::prep_wtab,
+                                          core.hpp:564-581), then their Shoup companions at offset degree (shoupomegas) */
+  NFLHIP_TAB_INVOMEGAS = 8             /* 2*degree words: the same for omega^-1 (invomegas / shoupinvomegas) */
 };
 
 int nflhip_abi_version(void);
@@ -109,6 +118,18 @@ int nflhip_ntt_fwd_dev(nflhip_ctx *ctx, void *d_data, size_t batch, void *stream
 int nflhip_ntt_inv_dev(nflhip_ctx *ctx, void *d_data, size_t batch, void *stream);
 int nflhip_ntt_fwd(nflhip_ctx *ctx, void *h_data, size_t batch);
 int nflhip_ntt_inv(nflhip_ctx *ctx, void *h_data, size_t batch);
+
+/* ---- the cyclic transform of single rows ------------------------------------------
+ * core::ntt(x, wtab, winvtab, p)   core.hpp:455-532 (Harvey DIF, algos.hpp:47-73): in-place CYCLIC transform of
+ * `rows` contiguous rows of `degree` words, all of modulus `cm`: natural order in, bit-reversed order out,
+ * out[bitrev(k)] = sum_j x[j] w^(jk), every word in [0,p).  mode bit NFLHIP_ROW_INVERSE_TABLES selects
+ * w = omega^-1 (the reference's invomegas tables) instead of omega = phi^2; bit NFLHIP_ROW_BITREV_IO bit-reverses
+ * the row before and after, i.e. core::inv_ntt (core.hpp:539-557) when combined with the inverse tables.
+ * This is what tests/ntt_perfs.cpp:155-171 times through the poly_tests_proxy friend (BASELINE configs[0]). */
+#define NFLHIP_ROW_INVERSE_TABLES 1
+#define NFLHIP_ROW_BITREV_IO 2
+int nflhip_ntt_row_dev(nflhip_ctx *ctx, void *d_rows, size_t cm, int mode, size_t rows, void *stream);
+int nflhip_ntt_row(nflhip_ctx *ctx, void *h_rows, size_t cm, int mode, size_t rows);
 
 /* ---- element-wise ops: poly::operator=(expr) core.hpp:24-37 ------------------
  * op in NFLHIP_OP_*; b is ignored for COMPUTE_SHOUP, bprime only used by
@@ -200,8 +221,18 @@ enum {
   NFLHIP_DIST_UNIFORM = 0, /* core.hpp:152-188   one word per residue word */
   NFLHIP_DIST_BOUNDED = 1, /* core.hpp:195-277   param0 = upper_bound, param1 = amplifier; one word per coefficient */
   NFLHIP_DIST_ZO = 2,      /* core.hpp:330-340   param0 = rho (0..255) */
-  NFLHIP_DIST_HWT = 3      /* core.hpp:347-391   param0 = hamming weight (1..degree) */
+  NFLHIP_DIST_HWT = 3,     /* core.hpp:347-391   param0 = hamming weight (1..degree) */
+  /* OR into NFLHIP_DIST_ZO / NFLHIP_DIST_HWT: store +1 exactly as the reference does, as the non-canonical word
+   * p + 1 (`pm + (rnd & 2)`, core.hpp:341,387), so that raw _data images diff clean against the CPU library.
+   * Default (flag absent): the canonical 1, which the engine's own operators require (ops.hpp:131,148). */
+  NFLHIP_DIST_REFERENCE_WORDS = 0x100
 };
+/* KEYSTREAM DISCIPLINE.  A (key, stream_id, distribution) triple names one keystream: two calls that share all
+ * three produce the same values.  Different distributions never share keystream words even for the same
+ * (key, stream_id) -- the distribution's tag is part of the ChaCha20 block counter -- so a public uniform polynomial
+ * never reveals the noise drawn next to it; but two draws of the SAME distribution that must be independent (the
+ * secret and the error of an LWE sample) need distinct stream ids.  Callers that want the reference's behaviour draw
+ * the key from the OS once and take a fresh stream id per call (what include/nfl_hip/nfl.hpp does). */
 int nflhip_sample_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, size_t batch, int dist, uint64_t param0,
                       uint64_t param1, const unsigned char key[32], uint64_t stream_id, void *stream);
 int nflhip_sample(nflhip_ctx *ctx, void *h_data, size_t batch, int dist, uint64_t param0, uint64_t param1,
@@ -240,12 +271,23 @@ int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sampl
 int nflhip_gauss_noise(nflhip_ctx *ctx, int64_t *h_out, size_t count, const nflhip_gauss *g,
                        const unsigned char key[32], uint64_t stream_id);
 
+/* nfl::fastrandombytes(r, rlen) (nfl/prng/fastrandombytes.h:12): rlen raw keystream bytes of (key, stream_id) -- the
+ * bytes of nflhip_random_words_dev's words 0.. in little-endian order -- generated on `device`, copied to the host */
+int nflhip_random_bytes(int device, unsigned char *h_out, size_t nbytes, const unsigned char key[32], uint64_t stream_id);
+
 /* plain device-memory helpers so a C caller needs no HIP headers */
 int nflhip_malloc(nflhip_ctx *ctx, void **d_ptr, size_t bytes);
 int nflhip_free(nflhip_ctx *ctx, void *d_ptr);
 int nflhip_memcpy_h2d(nflhip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
 int nflhip_memcpy_d2h(nflhip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int nflhip_memcpy_d2d(nflhip_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
+int nflhip_memset_dev(nflhip_ctx *ctx, void *d_dst, int byte, size_t bytes, void *stream);
 int nflhip_stream_sync(nflhip_ctx *ctx, void *stream);
+/* a non-blocking stream of the context's device (what the header's resident handles enqueue on) */
+int nflhip_stream_create(nflhip_ctx *ctx, void **stream);
+int nflhip_stream_destroy(nflhip_ctx *ctx, void *stream);
+/* d_dst[k] = *d_one for k < count: one polynomial replicated over a resident batch (one kernel, no host copies) */
+int nflhip_broadcast_dev(nflhip_ctx *ctx, void *d_dst, const void *d_one, size_t count, void *stream);
 
 /* ---- in-library timing of the metric kernel (HIP events on `stream`) -----------
  * Runs `iters` back-to-back polymul passes over the batch and returns the mean

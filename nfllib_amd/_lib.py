@@ -13,6 +13,10 @@ LIB_PATH = os.path.join(_HERE, "libnflhip.so")
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = range(6)
 OP_ADD, OP_SUB, OP_MUL, OP_MUL_SHOUP, OP_COMPUTE_SHOUP = range(5)
 TAB_PSI, TAB_MODULUS, TAB_INVDEGREE = range(3)
+TAB_PHIS, TAB_SHOUPPHIS, TAB_INVPOLY_INVPHIS, TAB_SHOUPINVPOLY_INVPHIS, TAB_OMEGAS, TAB_INVOMEGAS = range(3, 9)
+ROW_INVERSE_TABLES, ROW_BITREV_IO = 1, 2
+DIST_REFERENCE_WORDS = 0x100
+ABI_VERSION = 2
 
 # every symbol include/nflhip.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
@@ -32,6 +36,8 @@ SYMBOLS = [
     ("nflhip_ntt_inv_dev", _i, [_vp, _vp, _sz, _vp]),
     ("nflhip_ntt_fwd", _i, [_vp, _vp, _sz]),
     ("nflhip_ntt_inv", _i, [_vp, _vp, _sz]),
+    ("nflhip_ntt_row_dev", _i, [_vp, _vp, _sz, _i, _sz, _vp]),
+    ("nflhip_ntt_row", _i, [_vp, _vp, _sz, _i, _sz]),
     ("nflhip_pointwise_dev", _i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     ("nflhip_pointwise", _i, [_vp, _i, _vp, _vp, _vp, _vp, _sz]),
     ("nflhip_eval_dev", _i, [_vp, _vp, _vp, _sz, _vp, _sz, _sz, _vp]),
@@ -65,7 +71,13 @@ SYMBOLS = [
     ("nflhip_free", _i, [_vp, _vp]),
     ("nflhip_memcpy_h2d", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("nflhip_memcpy_d2h", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_memcpy_d2d", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_memset_dev", _i, [_vp, _vp, _i, _sz, _vp]),
     ("nflhip_stream_sync", _i, [_vp, _vp]),
+    ("nflhip_stream_create", _i, [_vp, C.POINTER(_vp)]),
+    ("nflhip_stream_destroy", _i, [_vp, _vp]),
+    ("nflhip_broadcast_dev", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_random_bytes", _i, [_i, _vp, _sz, _vp, _u64]),
     ("nflhip_time_polymul_dev", _i, [_vp, _vp, _vp, _vp, _sz, _i, _vp, C.POINTER(C.c_float)]),
 ]
 
@@ -97,7 +109,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
-    if lib.nflhip_abi_version() != 1:
+    if lib.nflhip_abi_version() != ABI_VERSION:
         raise ImportError("nfllib_amd: libnflhip.so ABI version mismatch")
     return lib
 

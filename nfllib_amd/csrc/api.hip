@@ -55,6 +55,13 @@ struct nflhip_ctx {
   std::vector<uint64_t> h_Q;                     // moduli_product limbs
   std::vector<std::vector<uint64_t>> h_lifting;  // lifting_integers[cm]
   std::vector<uint64_t> h_P;
+  std::vector<uint64_t> h_roots, h_invk, h_phi;  // params<T>::primitive_roots / invkMaxPolyDegree, phi = 2n-th root per modulus
+  int kmax_log2 = 0;
+  // core::ntt(x, wtab, winvtab, p) (core.hpp:455-532) on the device: one single-modulus child context per
+  // (modulus, table set) whose twiddle table is the CYCLIC one, created on first use -- see nflhip_ntt_row_dev
+  int cyclic = 0;  // 0: negacyclic tables (the normal context); 1 / 2: cyclic over omega / omega^-1 (child contexts)
+  std::mutex row_mu;
+  std::vector<nflhip_ctx *> row_ctx;  // [2 * cm + inverse_tables]
 };
 
 static int fail(const nflhip_ctx *ctx, int code, const std::string &msg) {
@@ -151,8 +158,11 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     if (p < 3 || (p >> (wb - 2)) != 0 || (p >> (wb - 3)) == 0)
       return fail(nullptr, NFLHIP_ERR_INVALID, "modulus is not (word-2) bits long");
     c->h_P.push_back(p);
+    c->h_roots.push_back(roots[cm]);
+    c->h_invk.push_back(invk[cm]);
     if (((((uint64_t)1) << (wb - 2)) - p) >> 32) c->shape.small_delta = 0;
   }
+  c->kmax_log2 = kmax_log2;
   // CRT constants
   Big Q(1, 1);
   for (size_t cm = 0; cm < nm; ++cm) Q = big_mul_u64(Q, P[cm]);
@@ -221,15 +231,26 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     uint64_t phi = roots[cm];
     for (int i = 0; i < kmax_log2 - logn; ++i) phi = mulmod_h(phi, phi, p);
     if (powmod_h(phi, n, p) != p - 1) return fail(nullptr, NFLHIP_ERR_INVALID, "primitive root has the wrong order");
+    c->h_phi.push_back(phi);
+    const uint64_t base = c->cyclic == 2 ? powmod_h(phi, 2 * n - 1, p) : phi;  // phi^-1 for the inverse tables
     std::vector<uint64_t> pw(n);
     uint64_t cur = 1;
     for (size_t i = 0; i < n; ++i) {
       pw[i] = cur;
-      cur = mulmod_h(cur, phi, p);
+      cur = mulmod_h(cur, base, p);
     }
     Tw<T> *tw = psi.data() + cm * n;
     for (size_t k = 0; k < n; ++k) {
-      const uint64_t w = pw[bitrev_h((unsigned)k, logn)];
+      // negacyclic: psi_br[k] = phi^bitrev(k).  With k = m + j (m = the power of two <= k: stage with m blocks, block j)
+      // that exponent is (n/2m)(2 brev_m(j) + 1); the cyclic transform core::ntt computes needs omega^((n/2m) brev_m(j))
+      // = phi^(bitrev(k) - n/2m) in the same slot, so every forward kernel runs it unchanged on this table.
+      size_t e = bitrev_h((unsigned)k, logn);
+      if (c->cyclic && k > 0) {
+        size_t m = 1;
+        while (2 * m <= k) m *= 2;
+        e -= n / (2 * m);
+      }
+      const uint64_t w = pw[e];
       tw[k].w = (T)w;
       tw[k].wp = (T)shoup_h(w, p, wb);
     }
@@ -474,8 +495,8 @@ int nflhip_device_count(int *count) {
   return NFLHIP_OK;
 }
 
-int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree, size_t nmoduli, const void *P,
-                      const void *primitive_roots, const void *invkmax, int kmax_log2) {
+static int ctx_create_mode(nflhip_ctx **out, int device, int limb_bits, size_t degree, size_t nmoduli, const void *P,
+                           const void *primitive_roots, const void *invkmax, int kmax_log2, int cyclic) {
   if (!out) return fail(nullptr, NFLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (limb_bits != 16 && limb_bits != 32 && limb_bits != 64)
@@ -495,6 +516,7 @@ int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree
   nflhip_ctx *c = new (std::nothrow) nflhip_ctx();
   if (!c) return fail(nullptr, NFLHIP_ERR_NOMEM, "out of host memory");
   c->device = device;
+  c->cyclic = cyclic;
   c->word = (size_t)limb_bits / 8;
   c->shape.limb_bits = limb_bits;
   c->shape.n = degree;
@@ -530,8 +552,15 @@ int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree
   return NFLHIP_OK;
 }
 
+int nflhip_ctx_create(nflhip_ctx **out, int device, int limb_bits, size_t degree, size_t nmoduli, const void *P,
+                      const void *primitive_roots, const void *invkmax, int kmax_log2) {
+  return ctx_create_mode(out, device, limb_bits, degree, nmoduli, P, primitive_roots, invkmax, kmax_log2, 0);
+}
+
 int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (!ctx) return NFLHIP_OK;
+  for (nflhip_ctx *child : ctx->row_ctx) nflhip_ctx_destroy(child);
+  ctx->row_ctx.clear();
   (void)hipSetDevice(ctx->device);
   if (ctx->hstream) (void)hipStreamDestroy(ctx->hstream);
   for (int k = 0; k < 2; ++k) {
@@ -562,9 +591,9 @@ size_t nflhip_crt_limbs(const nflhip_ctx *ctx) { return ctx ? ctx->shape.crt_L :
 int nflhip_get_table(const nflhip_ctx *ctx, int which, size_t cm, void *host_out, size_t host_bytes) {
   if (!ctx || !host_out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
   if (cm >= ctx->shape.nm) return fail(ctx, NFLHIP_ERR_INVALID, "modulus index out of range");
-  int rc = set_device(ctx);
-  if (rc) return rc;
   const size_t w = ctx->word;
+  int rc = which >= NFLHIP_TAB_PHIS ? NFLHIP_OK : set_device(ctx);
+  if (rc) return rc;
   const size_t mcsz = sizeof(ModConst<uint64_t>) / 8 * w;  // sizeof(ModConst<T>)
   switch (which) {
     case NFLHIP_TAB_PSI: {
@@ -578,6 +607,52 @@ int nflhip_get_table(const nflhip_ctx *ctx, int which, size_t cm, void *host_out
       if (host_bytes < w) return fail(ctx, NFLHIP_ERR_INVALID, "output buffer too small");
       const size_t off = cm * mcsz + (which == NFLHIP_TAB_MODULUS ? 0 : 3 * w);
       HIPCHK(ctx, hipMemcpy(host_out, (const char *)ctx->tabs.mc + off, w, hipMemcpyDeviceToHost));
+      return NFLHIP_OK;
+    }
+    case NFLHIP_TAB_PHIS:
+    case NFLHIP_TAB_SHOUPPHIS:
+    case NFLHIP_TAB_INVPOLY_INVPHIS:
+    case NFLHIP_TAB_SHOUPINVPOLY_INVPHIS:
+    case NFLHIP_TAB_OMEGAS:
+    case NFLHIP_TAB_INVOMEGAS: {
+      // the reference's own table layouts (poly.hpp:228-237), rebuilt on the host from phi: what a caller holding
+      // core::base sees.  Host arithmetic, once per request; the device never reads these.
+      const size_t n = ctx->shape.n, words = (which == NFLHIP_TAB_OMEGAS || which == NFLHIP_TAB_INVOMEGAS) ? 2 * n : n;
+      if (host_bytes < words * w) return fail(ctx, NFLHIP_ERR_INVALID, "output buffer too small");
+      const uint64_t p = ctx->h_P[cm], phi = ctx->h_phi[cm];
+      const int wb = ctx->shape.limb_bits;
+      std::vector<uint64_t> v(words, 0);
+      const uint64_t invphi = powmod_h(phi, 2 * n - 1, p);
+      if (which == NFLHIP_TAB_PHIS || which == NFLHIP_TAB_SHOUPPHIS) {  // core.hpp:649-656
+        uint64_t t = 1;
+        for (size_t i = 0; i < n; ++i) {
+          v[i] = which == NFLHIP_TAB_PHIS ? t : shoup_h(t, p, wb);
+          t = mulmod_h(t, phi, p);
+        }
+      } else if (which == NFLHIP_TAB_INVPOLY_INVPHIS || which == NFLHIP_TAB_SHOUPINVPOLY_INVPHIS) {  // core.hpp:664-676
+        uint64_t t = mulmod_h(ctx->h_invk[cm], (((uint64_t)1) << ctx->kmax_log2) / n, p);
+        for (size_t i = 0; i < n; ++i) {
+          v[i] = which == NFLHIP_TAB_INVPOLY_INVPHIS ? t : shoup_h(t, p, wb);
+          t = mulmod_h(t, invphi, p);
+        }
+      } else {  // core::prep_wtab, core.hpp:564-581: stage-concatenated powers, Shoup companions at offset n
+        uint64_t wcur = which == NFLHIP_TAB_OMEGAS ? mulmod_h(phi, phi, p) : mulmod_h(invphi, invphi, p);
+        size_t pos = 0;
+        for (size_t K = n; K >= 2; K /= 2) {
+          uint64_t wi = 1;
+          for (size_t i = 0; i < K / 2; ++i, ++pos) {
+            v[pos] = wi;
+            v[n + pos] = shoup_h(wi, p, wb);
+            wi = mulmod_h(wi, wcur, p);
+          }
+          wcur = mulmod_h(wcur, wcur, p);
+        }
+      }
+      for (size_t i = 0; i < words; ++i) {
+        if (w == 8) ((uint64_t *)host_out)[i] = v[i];
+        else if (w == 4) ((uint32_t *)host_out)[i] = (uint32_t)v[i];
+        else ((uint16_t *)host_out)[i] = (uint16_t)v[i];
+      }
       return NFLHIP_OK;
     }
     default: return fail(ctx, NFLHIP_ERR_INVALID, "unknown table id");
@@ -816,6 +891,8 @@ int nflhip_sample_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t batch,
                       const unsigned char *key, uint64_t stream_id, void *stream) {
   CHECK_CTX(ctx);
   if (!key || (batch && !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  const int dist_in = dist;
+  dist &= ~NFLHIP_DIST_REFERENCE_WORDS;
   if (dist < NFLHIP_DIST_UNIFORM || dist > NFLHIP_DIST_HWT) return fail(ctx, NFLHIP_ERR_INVALID, "unknown distribution");
   if (dist == NFLHIP_DIST_BOUNDED) {
     if (p0 == 0 || p0 >= (((uint64_t)1) << 62)) return fail(ctx, NFLHIP_ERR_INVALID, "upper_bound out of range");
@@ -828,9 +905,9 @@ int nflhip_sample_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t batch,
     return fail(ctx, NFLHIP_ERR_INVALID, "hamming weight must be in [1, degree]");
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = DISPATCH_T(
-      ctx, launch_sample<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, dist, p0, p1, key, stream_id, st),
-      launch_sample<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, dist, p0, p1, key, stream_id, st),
-      launch_sample<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, dist, p0, p1, key, stream_id, st));
+      ctx, launch_sample<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, dist_in, p0, p1, key, stream_id, st),
+      launch_sample<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, dist_in, p0, p1, key, stream_id, st),
+      launch_sample<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, dist_in, p0, p1, key, stream_id, st));
   if (e != hipSuccess) return hipfail(ctx, e, "sample");
   return NFLHIP_OK;
 }
@@ -931,8 +1008,112 @@ int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sampl
 }
 
 // ---------------------------------------------------------------------------
+// core::ntt / core::inv_ntt: the cyclic transform of single rows
+// ---------------------------------------------------------------------------
+static int row_child(nflhip_ctx *ctx, size_t cm, int inverse_tables, nflhip_ctx **out) {
+  std::lock_guard<std::mutex> lk(ctx->row_mu);
+  if (ctx->row_ctx.empty()) ctx->row_ctx.assign(2 * ctx->shape.nm, nullptr);
+  nflhip_ctx *&slot = ctx->row_ctx[2 * cm + (inverse_tables ? 1 : 0)];
+  if (!slot) {
+    // one word of each parameter table, in the limb type's own width
+    uint64_t P8 = ctx->h_P[cm], R8 = ctx->h_roots[cm], I8 = ctx->h_invk[cm];
+    uint32_t P4 = (uint32_t)P8, R4 = (uint32_t)R8, I4 = (uint32_t)I8;
+    uint16_t P2 = (uint16_t)P8, R2 = (uint16_t)R8, I2 = (uint16_t)I8;
+    const void *pp = ctx->word == 8 ? (const void *)&P8 : ctx->word == 4 ? (const void *)&P4 : (const void *)&P2;
+    const void *rr = ctx->word == 8 ? (const void *)&R8 : ctx->word == 4 ? (const void *)&R4 : (const void *)&R2;
+    const void *ii = ctx->word == 8 ? (const void *)&I8 : ctx->word == 4 ? (const void *)&I4 : (const void *)&I2;
+    int rc = ctx_create_mode(&slot, ctx->device, ctx->shape.limb_bits, ctx->shape.n, 1, pp, rr, ii, ctx->kmax_log2,
+                             inverse_tables ? 2 : 1);
+    if (rc) return rc;
+  }
+  *out = slot;
+  return NFLHIP_OK;
+}
+
+int nflhip_ntt_row_dev(nflhip_ctx *ctx, void *d_rows, size_t cm, int mode, size_t rows, void *stream) {
+  CHECK_CTX(ctx);
+  if (cm >= ctx->shape.nm) return fail(ctx, NFLHIP_ERR_INVALID, "modulus index out of range");
+  if (mode < 0 || mode > 3) return fail(ctx, NFLHIP_ERR_INVALID, "unknown row-transform mode");
+  if (rows == 0) return NFLHIP_OK;
+  if (!d_rows) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
+  nflhip_ctx *child = nullptr;
+  int rc = row_child(ctx, cm, mode & NFLHIP_ROW_INVERSE_TABLES, &child);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode & NFLHIP_ROW_BITREV_IO) {  // core::inv_ntt: permut, ntt, permut (core.hpp:549-554)
+    hipError_t e = DISPATCH_T(ctx, launch_bitrev_rows<uint16_t>(ctx->shape, (uint16_t *)d_rows, rows, st),
+                              launch_bitrev_rows<uint32_t>(ctx->shape, (uint32_t *)d_rows, rows, st),
+                              launch_bitrev_rows<uint64_t>(ctx->shape, (uint64_t *)d_rows, rows, st));
+    if (e != hipSuccess) return hipfail(ctx, e, "ntt_row: bit reversal");
+  }
+  rc = nflhip_ntt_fwd_dev(child, d_rows, rows, stream);
+  if (rc) return rc;
+  if (mode & NFLHIP_ROW_BITREV_IO) {
+    hipError_t e = DISPATCH_T(ctx, launch_bitrev_rows<uint16_t>(ctx->shape, (uint16_t *)d_rows, rows, st),
+                              launch_bitrev_rows<uint32_t>(ctx->shape, (uint32_t *)d_rows, rows, st),
+                              launch_bitrev_rows<uint64_t>(ctx->shape, (uint64_t *)d_rows, rows, st));
+    if (e != hipSuccess) return hipfail(ctx, e, "ntt_row: bit reversal");
+  }
+  return NFLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // memory helpers
 // ---------------------------------------------------------------------------
+int nflhip_stream_create(nflhip_ctx *ctx, void **stream) {
+  CHECK_CTX(ctx);
+  if (!stream) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipStream_t s = nullptr;
+  HIPCHK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void *)s;
+  return NFLHIP_OK;
+}
+int nflhip_stream_destroy(nflhip_ctx *ctx, void *stream) {
+  CHECK_CTX(ctx);
+  if (stream) HIPCHK(ctx, hipStreamDestroy((hipStream_t)stream));
+  return NFLHIP_OK;
+}
+int nflhip_memcpy_d2d(nflhip_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream) {
+  CHECK_CTX(ctx);
+  HIPCHK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return NFLHIP_OK;
+}
+int nflhip_memset_dev(nflhip_ctx *ctx, void *d_dst, int byte, size_t bytes, void *stream) {
+  CHECK_CTX(ctx);
+  HIPCHK(ctx, hipMemsetAsync(d_dst, byte, bytes, (hipStream_t)stream));
+  return NFLHIP_OK;
+}
+int nflhip_broadcast_dev(nflhip_ctx *ctx, void *d_dst, const void *d_one, size_t count, void *stream) {
+  CHECK_CTX(ctx);
+  if (count && (!d_dst || !d_one)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipError_t e = launch_broadcast(d_dst, d_one, poly_bytes(ctx, 1), count, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(ctx, e, "broadcast");
+  return NFLHIP_OK;
+}
+int nflhip_random_bytes(int device, unsigned char *h_out, size_t nbytes, const unsigned char *key, uint64_t stream_id) {
+  if (nbytes == 0) return NFLHIP_OK;
+  if (!h_out || !key) return fail(nullptr, NFLHIP_ERR_INVALID, "NULL argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, NFLHIP_ERR_NO_DEVICE, "no HIP device available (this engine has no CPU fallback)");
+  HIPCHK(nullptr, hipSetDevice(device));
+  const size_t nwords = (nbytes + 7) / 8;
+  uint64_t *d = nullptr;
+  HIPCHK(nullptr, hipMalloc((void **)&d, nwords * 8));
+  hipError_t e = launch_random_words(d, 0, nwords, key, stream_id, nullptr);
+  std::vector<uint64_t> tmp;
+  if (e == hipSuccess && (nbytes & 7)) {
+    tmp.resize(nwords);
+    e = hipMemcpy(tmp.data(), d, nwords * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) memcpy(h_out, tmp.data(), nbytes);
+  } else if (e == hipSuccess) {
+    e = hipMemcpy(h_out, d, nbytes, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return hipfail(nullptr, e, "random_bytes");
+  return NFLHIP_OK;
+}
+
 int nflhip_malloc(nflhip_ctx *ctx, void **p, size_t bytes) {
   CHECK_CTX(ctx);
   if (!p) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
@@ -1005,6 +1186,18 @@ int nflhip_ntt_inv(nflhip_ctx *ctx, void *h, size_t batch) {
   rc = nflhip_ntt_inv_dev(ctx, ctx->stage[0], batch, ctx->hstream);
   if (rc) return rc;
   return s.out(h, 0, bytes);
+}
+int nflhip_ntt_row(nflhip_ctx *ctx, void *h_rows, size_t cm, int mode, size_t rows) {
+  CHECK_CTX(ctx);
+  if (rows == 0) return NFLHIP_OK;
+  if (!h_rows) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
+  Staged s(ctx);
+  const size_t bytes = rows * ctx->shape.n * ctx->word;
+  int rc = s.in(0, h_rows, bytes);
+  if (rc) return rc;
+  rc = nflhip_ntt_row_dev(ctx, ctx->stage[0], cm, mode, rows, ctx->hstream);
+  if (rc) return rc;
+  return s.out(h_rows, 0, bytes);
 }
 int nflhip_pointwise(nflhip_ctx *ctx, int op, void *o, const void *a, const void *b, const void *bp, size_t batch) {
   CHECK_CTX(ctx);

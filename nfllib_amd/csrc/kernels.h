@@ -73,6 +73,9 @@ hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const 
 template <typename T>
 hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, uint64_t seed,
                                int operand, hipStream_t st);
+// in-place bit reversal of every row (permut.hpp:86-117), and `count` copies of one polynomial
+template <typename T> hipError_t launch_bitrev_rows(const Shape &s, T *d, size_t rows, hipStream_t st);
+hipError_t launch_broadcast(void *dst, const void *one, size_t bytes_per_poly, size_t count, hipStream_t st);
 template <typename T>
 hipError_t launch_crt_lift(const Shape &s, const DevTables &t, uint64_t *limbs, const T *d, size_t batch, hipStream_t st);
 template <typename T>

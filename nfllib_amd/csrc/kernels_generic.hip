@@ -630,6 +630,56 @@ hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const ui
   return hipGetLastError();
 }
 
+// permut<degree>::compute (permut.hpp:86-117) in place: word i of every row trades places with word bitrev(i)
+// (disjoint transpositions, so no temporary row is needed)
+template <typename T>
+__global__ void k_bitrev_rows(T *d, int logn, size_t total) {
+  const size_t mask = (((size_t)1) << logn) - 1;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const unsigned i = (unsigned)(g & mask);
+    const unsigned r = __brev(i) >> (32 - logn);
+    if (i < r) {
+      T *row = d + (g & ~mask);
+      const T x = row[i], y = row[r];
+      row[i] = y;
+      row[r] = x;
+    }
+  }
+}
+template <typename T> hipError_t launch_bitrev_rows(const Shape &s, T *d, size_t rows, hipStream_t st) {
+  if (rows == 0) return hipSuccess;
+  const size_t total = rows * s.n;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL((k_bitrev_rows<T>), dim3((unsigned)blocks), dim3(256), 0, st, d, s.logn, total);
+  return hipGetLastError();
+}
+
+// `count` copies of one polynomial (a key shared by every ciphertext of a resident batch): 16 bytes per lane
+__global__ void k_broadcast(uint4 *dst, const uint4 *__restrict__ one, size_t vec_per_poly, size_t total) {
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x)
+    dst[g] = one[g % vec_per_poly];
+}
+__global__ void k_broadcast_bytes(unsigned char *dst, const unsigned char *__restrict__ one, size_t bytes_per_poly,
+                                  size_t total) {
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x)
+    dst[g] = one[g % bytes_per_poly];
+}
+hipError_t launch_broadcast(void *dst, const void *one, size_t bytes_per_poly, size_t count, hipStream_t st) {
+  if (count == 0 || bytes_per_poly == 0) return hipSuccess;
+  const bool vec = (bytes_per_poly % 16 == 0) && (((uintptr_t)dst | (uintptr_t)one) % 16 == 0);
+  const size_t total = vec ? bytes_per_poly / 16 * count : bytes_per_poly * count;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (vec)
+    hipLaunchKernelGGL(k_broadcast, dim3((unsigned)blocks), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)one,
+                       bytes_per_poly / 16, total);
+  else
+    hipLaunchKernelGGL(k_broadcast_bytes, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char *)dst,
+                       (const unsigned char *)one, bytes_per_poly, total);
+  return hipGetLastError();
+}
+
 // ---- explicit instantiations ----
 #define NFLHIP_INST(T)                                                                                              \
   template hipError_t launch_ntt_fwd<T>(const Shape &, const DevTables &, const T *, T *, size_t, hipStream_t);      \
@@ -643,6 +693,7 @@ hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const ui
                                         hipStream_t);                                                                \
   template hipError_t launch_fill_uniform<T>(const Shape &, const DevTables &, T *, size_t, size_t, uint64_t, int,   \
                                              hipStream_t);                                                           \
+  template hipError_t launch_bitrev_rows<T>(const Shape &, T *, size_t, hipStream_t);                                \
   template hipError_t launch_crt_lift<T>(const Shape &, const DevTables &, uint64_t *, const T *, size_t,            \
                                          hipStream_t);                                                               \
   template hipError_t launch_crt_project<T>(const Shape &, const DevTables &, T *, const uint64_t *, size_t, size_t, \

@@ -169,6 +169,9 @@ __global__ void k_sample_small(T *d, const ModConst<T> *__restrict__ mc, int log
                                size_t ncoef, int dist, uint64_t p0, uint64_t p1, ChaChaKey key, uint64_t nonce) {
   const uint64_t fb = first_coef >> 3, nb = ((first_coef + ncoef + 7) >> 3) - fb;
   const uint64_t n = ((uint64_t)1) << logn;
+  // NFLHIP_DIST_REFERENCE_WORDS: store +1 as the reference does, p + 1 (`pm + (rnd & 2)`, core.hpp:341)
+  const bool refw = (dist & 0x100) != 0;
+  dist &= 0xff;
   uint64_t mask = 0;
   if (dist == 1) {
     const uint64_t t = 2 * p0 - 1;  // >= 1
@@ -200,7 +203,9 @@ __global__ void k_sample_small(T *d, const ModConst<T> *__restrict__ mc, int log
       const uint64_t local = g - first_coef, poly = local >> logn, i = local & (n - 1);
       T *col = d + ((poly * (uint64_t)nm) << logn) + i;
       for (int cm = 0; cm < nm; ++cm)
-        col[(uint64_t)cm << logn] = zero ? (T)0 : signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+        col[(uint64_t)cm << logn] = zero ? (T)0
+                                    : (refw && dist == 2 && !neg) ? (T)(mc[cm].p + 1)
+                                                                  : signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
     }
   }
 }
@@ -213,6 +218,8 @@ __global__ void __launch_bounds__(256) k_sample_small8(T *d, const ModConst<T> *
   __shared__ long long xs[4][8 * kTS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t n = ((uint64_t)1) << logn, fb = first_coef >> 3;
+  const bool refw = (dist & 0x100) != 0;  // see k_sample_small
+  dist &= 0xff;
   uint64_t mask = 0;
   if (dist == 1) {
     const uint64_t t = 2 * p0 - 1;  // >= 1
@@ -251,7 +258,9 @@ __global__ void __launch_bounds__(256) k_sample_small8(T *d, const ModConst<T> *
         const uint64_t poly = idx >> logn, i = idx & (n - 1);
         T *col = d + ((poly * (uint64_t)nm) << logn) + i;
         for (int cm = 0; cm < nm; ++cm)
-          col[(uint64_t)cm << logn] = mag == 0 ? (T)0 : signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+          col[(uint64_t)cm << logn] = mag == 0 ? (T)0
+                                      : (refw && dist == 2 && !neg) ? (T)(mc[cm].p + 1)
+                                                                    : signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
       }
     }
   }
@@ -426,14 +435,15 @@ __global__ void k_hwt_select(T *d, int logn, int nm, uint64_t first_poly, size_t
   }
 }
 template <typename T>
-__global__ void k_hwt_spread(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t ncoef) {
+__global__ void k_hwt_spread(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t ncoef, int refw) {
   const uint64_t n = ((uint64_t)1) << logn;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (size_t)gridDim.x * blockDim.x) {
     const uint64_t poly = idx >> logn, i = idx & (n - 1);
     T *col = d + ((poly * (uint64_t)nm) << logn) + i;
     const T m = col[0];
     if (m == 0) continue;
-    for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = m == 1 ? (T)1 : (T)(mc[cm].p - 1);
+    // (reference words: `pm + (rnd & 2)`, core.hpp:387 -- +1 is stored as p + 1)
+    for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = m == 1 ? (refw ? (T)(mc[cm].p + 1) : (T)1) : (T)(mc[cm].p - 1);
   }
 }
 
@@ -464,6 +474,8 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
                          uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
   if (batch == 0) return hipSuccess;
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+  const int refw = dist & 0x100;   // NFLHIP_DIST_REFERENCE_WORDS
+  dist &= 0xff;
   const ChaChaKey key = load_key(key32, dist + 1);
   const size_t ncoef = batch * s.n, total = ncoef * s.nm;
   switch (dist) {
@@ -479,17 +491,18 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
     case 2:
       if (s.n >= 8)
         hipLaunchKernelGGL((k_sample_small8<T>), dim3(grid_for(ncoef / 8)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
-                           (uint64_t)first_poly * s.n, ncoef, dist, p0, p1, key, stream_id);
+                           (uint64_t)first_poly * s.n, ncoef, dist | refw, p0, p1, key, stream_id);
       else
         hipLaunchKernelGGL((k_sample_small<T>), dim3(grid_for(ncoef / 8 + 2)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
-                           (uint64_t)first_poly * s.n, ncoef, dist, p0, p1, key, stream_id);
+                           (uint64_t)first_poly * s.n, ncoef, dist | refw, p0, p1, key, stream_id);
       break;
     case 3: {
       hipError_t e = hipMemsetAsync(d, 0, total * sizeof(T), st);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL((k_hwt_select<T>), dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, d, s.logn, (int)s.nm,
                          (uint64_t)first_poly, batch, p0, key, stream_id);
-      hipLaunchKernelGGL((k_hwt_spread<T>), dim3(grid_for(ncoef)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm, ncoef);
+      hipLaunchKernelGGL((k_hwt_spread<T>), dim3(grid_for(ncoef)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm, ncoef,
+                         refw);
       break;
     }
     default:

@@ -11,7 +11,9 @@ import numpy as np
 
 from . import _lib
 from ._lib import (NflHipError, OP_ADD, OP_COMPUTE_SHOUP, OP_MUL, OP_MUL_SHOUP, OP_SUB,  # noqa: F401
-                   TAB_INVDEGREE, TAB_MODULUS, TAB_PSI)
+                   DIST_REFERENCE_WORDS, ROW_BITREV_IO, ROW_INVERSE_TABLES, TAB_INVDEGREE, TAB_INVOMEGAS,
+                   TAB_INVPOLY_INVPHIS, TAB_MODULUS, TAB_OMEGAS, TAB_PHIS, TAB_PSI, TAB_SHOUPINVPOLY_INVPHIS,
+                   TAB_SHOUPPHIS)
 from .params import params as limb_params
 
 _NP = {16: np.uint16, 32: np.uint32, 64: np.uint64}
@@ -112,6 +114,21 @@ class Engine:
         self._chk(self.lib.nflhip_ntt_inv_dev(self.ctx, _vp(d), self._batch(d), self._stream(stream)))
         return d
 
+    def ntt_row_(self, rows, cm, inverse_tables=False, bitrev_io=False, stream=None):
+        """core::ntt (core.hpp:455-532) on contiguous rows of modulus cm, in place: cyclic, natural in, bit-reversed
+        out; inverse_tables selects the invomegas tables, bitrev_io wraps it in the two permutations of core::inv_ntt"""
+        assert rows.is_contiguous() and rows.numel() % self.degree == 0
+        mode = (ROW_INVERSE_TABLES if inverse_tables else 0) | (ROW_BITREV_IO if bitrev_io else 0)
+        self._chk(self.lib.nflhip_ntt_row_dev(self.ctx, _vp(rows), cm, mode, rows.numel() // self.degree,
+                                              self._stream(stream)))
+        return rows
+
+    def h_ntt_row(self, rows, cm, inverse_tables=False, bitrev_io=False):
+        out = np.ascontiguousarray(rows, dtype=self.np_dtype).copy()
+        mode = (ROW_INVERSE_TABLES if inverse_tables else 0) | (ROW_BITREV_IO if bitrev_io else 0)
+        self._chk(self.lib.nflhip_ntt_row(self.ctx, _vp(out), cm, mode, out.size // self.degree))
+        return out
+
     def pointwise(self, op, a, b=None, bprime=None, out=None, stream=None):
         out = out if out is not None else _torch().empty_like(a)
         self._chk(self.lib.nflhip_pointwise_dev(self.ctx, op, _vp(out), _vp(a), _vp(b), _vp(bprime), self._batch(a),
@@ -152,6 +169,12 @@ class Engine:
         r = C.c_int(0)
         self._chk(self.lib.nflhip_any_neq_dev(self.ctx, _vp(a), _vp(b), self._batch(a), C.byref(r), self._stream(stream)))
         return bool(r.value)
+
+    def broadcast(self, one, count, stream=None):
+        """`count` copies of one polynomial (nflhip_broadcast_dev)"""
+        out = self.empty(count)
+        self._chk(self.lib.nflhip_broadcast_dev(self.ctx, _vp(out), _vp(one), count, self._stream(stream)))
+        return out
 
     def fill_uniform(self, d, seed, operand=0, first_poly=0, stream=None):
         self._chk(self.lib.nflhip_fill_uniform_dev(self.ctx, _vp(d), first_poly, self._batch(d), seed, operand,
@@ -296,7 +319,8 @@ class Engine:
         return out
 
     def table(self, which, cm):
-        n = 2 * self.degree if which == TAB_PSI else 1
+        n = {TAB_PSI: 2 * self.degree, TAB_OMEGAS: 2 * self.degree, TAB_INVOMEGAS: 2 * self.degree, TAB_MODULUS: 1,
+             TAB_INVDEGREE: 1}.get(which, self.degree)
         out = np.zeros(n, dtype=self.np_dtype)
         self._chk(self.lib.nflhip_get_table(self.ctx, which, cm, _vp(out), out.nbytes))
         return out

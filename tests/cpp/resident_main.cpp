@@ -1,0 +1,217 @@
+// tests/cpp/resident_main.cpp -- nfl::poly_p as a RESIDENT handle: the shared payload of
+// the reference's copy-on-write handle (poly_p.hpp:11-204) lives in HBM; operator expressions, transforms, comparisons
+// and the random constructors on handles run on the device and only poly_obj() / operator()(cm,i) / serialisation
+// bring the value to the host.  Checks, with memcmp strength against the inline-storage poly path:
+//   residency bits across every kind of access, copy-on-write (incl. device-to-device detach and the re-seat on a
+//   whole-value overwrite), aliasing (a = a + b), mixed poly / poly_p trees, trees beyond the fused program,
+//   comparisons in HBM, the zero handle -- and the reference's LWE demo (tests/nfllib_demo_main_op.cpp:26-58, 260-332)
+//   written with plain poly_p operators, timed next to the same work on a resident batch (nfl::device_batch).
+// Exit code 0 = all good.  Prints one JSON line with the rates.  Needs a GPU.
+#include <nfl.hpp>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#define CHECK(cond)                                                      \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);        \
+      return false;                                                      \
+    }                                                                    \
+  } while (0)
+
+template <class P> struct Heap {
+  P *p;
+  template <class... A> explicit Heap(A &&... a) {
+    void *mem = nullptr;
+    if (posix_memalign(&mem, 32, sizeof(P)) != 0) throw std::bad_alloc();
+    p = new (mem) P(std::forward<A>(a)...);
+  }
+  ~Heap() { p->~P(); free(p); }
+  P &operator*() { return *p; }
+  P *operator->() { return p; }
+};
+template <class P> static bool same(const P &a, const P &b) {
+  return std::memcmp(a.cdata(), b.cdata(), sizeof(typename P::value_type) * P::degree * P::nmoduli) == 0;
+}
+
+template <class T, size_t Degree, size_t NbModuli> static bool run_residency() {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  using poly_p = nfl::poly_p<T, Degree, NbModuli>;
+  const poly_p a{nfl::uniform(11)}, b{nfl::uniform(12)}, d{nfl::uniform(13)};
+  CHECK(a.resident() && b.resident());                 // the seeded constructor fills in HBM
+  Heap<poly_t> A(nfl::uniform(11)), B(nfl::uniform(12)), D(nfl::uniform(13)), R;
+  poly_p c = a * b + d;                                // one fused device pass, stays resident
+  CHECK(c.resident());
+  *R = *A * *B + *D;
+  CHECK(same(c.poly_obj(), *R));                       // const access: value on the host AND still in HBM
+  CHECK(const_cast<const poly_p &>(c).resident());
+  // copy-on-write: the copy shares the payload until one side is written; transforms detach device-to-device
+  poly_p e = c;
+  CHECK(e.payload_id() == c.payload_id());
+  e.ntt_pow_phi();
+  CHECK(e.payload_id() != c.payload_id() && e.resident());
+  CHECK(same(const_cast<const poly_p &>(c).poly_obj(), *R));
+  R->ntt_pow_phi();
+  CHECK(same(const_cast<const poly_p &>(e).poly_obj(), *R));
+  e.invntt_pow_invphi();
+  CHECK(bool(e == c) && !bool(e != c));                // compared in HBM (the reference's "any lane" semantics)
+  // a whole-value overwrite of a shared handle re-seats it without copying; the other owner keeps the old value
+  poly_p f = c, g = c;
+  f = a - b;
+  *R = *A - *B;
+  CHECK(same(const_cast<const poly_p &>(f).poly_obj(), *R) && g.payload_id() == c.payload_id());
+  // ... also when the tree reads the handle being overwritten
+  poly_p h = c, keep = h;
+  h = h + h * a;
+  *R = *A * *B + *D;
+  Heap<poly_t> R2(*R + *R * *A);
+  CHECK(same(const_cast<const poly_p &>(h).poly_obj(), *R2) && same(const_cast<const poly_p &>(keep).poly_obj(), *R));
+  // aliasing on a unique handle: in place
+  poly_p acc{nfl::uniform(11)};
+  const void *id = acc.payload_id();
+  acc = acc + b;
+  *R = *A + *B;
+  CHECK(acc.payload_id() == id && same(const_cast<const poly_p &>(acc).poly_obj(), *R));
+  // host write access retires the device image; the next device op uploads the new words
+  poly_p w{nfl::uniform(11)};
+  w(0, 0) = 0;
+  CHECK(!w.resident());
+  (*A)(0, 0) = 0;
+  poly_p w2 = w * b;
+  *R = *A * *B;
+  CHECK(w.resident() && same(const_cast<const poly_p &>(w2).poly_obj(), *R));
+  (*A)(0, 0) = const_cast<const poly_p &>(a)(0, 0);
+  // mixed trees: inline polys are staged, handles are read where they are
+  poly_p m = a * *B + d;
+  *R = *A * *B + *D;
+  CHECK(m.resident() && same(const_cast<const poly_p &>(m).poly_obj(), *R));
+  *R = a * b + *D;                                     // host target, handle leaves
+  Heap<poly_t> R3(*A * *B + *D);
+  CHECK(same(*R, *R3));
+  // a tree with more than three distinct leaves still is ONE device pass for handles (8 operands)
+  const poly_p x{nfl::uniform(14)}, y{nfl::uniform(15)};
+  Heap<poly_t> X(nfl::uniform(14)), Y(nfl::uniform(15));
+  poly_p big = (a + b) * (d - x) + y * a;
+  *R = *A + *B;
+  Heap<poly_t> T1(*D - *X), T2(*R * *T1), T3(*Y * *A);
+  *R = *T2 + *T3;
+  CHECK(big.resident() && same(const_cast<const poly_p &>(big).poly_obj(), *R));
+  // shoup forms on handles
+  poly_p bs = nfl::compute_shoup(b), prod = nfl::shoup(a * b, bs);
+  *R = *A * *B;
+  CHECK(prod.resident() && same(const_cast<const poly_p &>(prod).poly_obj(), *R));
+  // the zero handle costs nothing until used, and is the zero polynomial on either side
+  poly_p z;
+  CHECK(!z.resident());
+  poly_p zz = z + a;
+  CHECK(same(const_cast<const poly_p &>(zz).poly_obj(), *A));
+  CHECK(!bool(const_cast<const poly_p &>(z).poly_obj()));
+  // random tags: fresh values per call, in HBM
+  poly_p r1{nfl::uniform()}, r2{nfl::uniform()};
+  CHECK(r1.resident() && bool(r1 != r2));
+  r1 = nfl::non_uniform(5);
+  for (auto v : const_cast<const poly_p &>(r1).poly_obj()) CHECK(v < 5 || v > poly_t::get_modulus(0) - 5 || NbModuli > 1);
+  return true;
+}
+
+// the reference's LWE demo with plain poly_p operators (tests/nfllib_demo_main_op.cpp:26-58, 260-332)
+template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *enc_per_s, double *dec_per_s, double *batch_enc_per_s,
+                                                                       double *batch_dec_per_s) {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  using poly_p = nfl::poly_p<T, Degree, NbModuli>;
+  using G = nfl::gaussian<uint8_t, T, 2>;
+  nfl::FastGaussianNoise<uint8_t, T, 2> g_prng(4, 128, 1 << 10);
+  const size_t REPS = 2048;
+  poly_p s{G(&g_prng)};
+  s.ntt_pow_phi();
+  poly_p sprime = nfl::compute_shoup(s);
+  poly_p pka{nfl::uniform()}, pkb{G(&g_prng, 2)};
+  pkb.ntt_pow_phi();
+  pkb = pkb + nfl::shoup(pka * s, sprime);
+  std::vector<poly_p> resa(REPS), resb(REPS);
+  auto encrypt = [&](poly_p &ra, poly_p &rb) {
+    poly_p u{G(&g_prng)}, e1{G(&g_prng, 2)}, e2{G(&g_prng, 2)};
+    u.ntt_pow_phi();
+    e1.ntt_pow_phi();
+    e2.ntt_pow_phi();
+    ra = u * pka + e1;
+    rb = u * pkb + e2;
+  };
+  auto decrypt = [&](poly_p &out, poly_p const &ra, poly_p const &rb) {
+    out = rb - ra * s;
+    out.invntt_pow_invphi();
+  };
+  for (size_t i = 0; i < 8; i++) encrypt(resa[i], resb[i]);   // warm-up: tables, buffer pool
+  poly_p::synchronize();
+  auto t0 = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < REPS; i++) encrypt(resa[i], resb[i]);
+  poly_p::synchronize();
+  auto t1 = std::chrono::steady_clock::now();
+  std::vector<poly_p> dec(REPS);
+  for (size_t i = 0; i < REPS; i++) decrypt(dec[i], resa[i], resb[i]);
+  poly_p::synchronize();
+  auto t2 = std::chrono::steady_clock::now();
+  *enc_per_s = REPS / std::chrono::duration<double>(t1 - t0).count();
+  *dec_per_s = REPS / std::chrono::duration<double>(t2 - t1).count();
+  // the demo's own check: ciphertexts of 0 decrypt to even noise, so the parities sum to 0
+  const T modulus = poly_t::get_modulus(0);
+  for (size_t i = 0; i < REPS; i += 97) {
+    const poly_t &t = const_cast<const poly_p &>(dec[i]).poly_obj();
+    for (size_t j = 0; j < Degree; j++) {
+      const T v = t(0, j);
+      CHECK(((v < modulus / 2) ? v % 2 : 1 - v % 2) == 0);
+    }
+  }
+  // the same work on a resident batch (what tools/lwe_demo.py times)
+  using batch_t = nfl::device_batch<poly_t>;
+  const size_t B = 4096;
+  batch_t S(B), PKA(B), PKB(B), U(B), E1(B), E2(B), RA(B), RB(B), DEC(B);
+  S.fill(s);
+  PKA.fill(pka);
+  PKB.fill(pkb);
+  const unsigned char fma[] = {0, 1, NFLHIP_EXPR_MUL, 2, NFLHIP_EXPR_ADD}, dcd[] = {0, 1, 2, NFLHIP_EXPR_MUL, NFLHIP_EXPR_SUB};
+  auto batch_enc = [&]() {
+    U.set(G(&g_prng)); E1.set(G(&g_prng, 2)); E2.set(G(&g_prng, 2));
+    U.ntt_pow_phi(); E1.ntt_pow_phi(); E2.ntt_pow_phi();
+    const batch_t *o1[] = {&U, &PKA, &E1}, *o2[] = {&U, &PKB, &E2};
+    RA.assign_program(fma, sizeof(fma), o1, 3);
+    RB.assign_program(fma, sizeof(fma), o2, 3);
+  };
+  auto batch_dec = [&]() {
+    const batch_t *o[] = {&RB, &RA, &S};
+    DEC.assign_program(dcd, sizeof(dcd), o, 3);
+    DEC.invntt_pow_invphi();
+  };
+  batch_enc(); batch_dec(); S.sync();
+  t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < 4; k++) batch_enc();
+  S.sync();
+  t1 = std::chrono::steady_clock::now();
+  for (int k = 0; k < 4; k++) batch_dec();
+  S.sync();
+  t2 = std::chrono::steady_clock::now();
+  *batch_enc_per_s = 4 * B / std::chrono::duration<double>(t1 - t0).count();
+  *batch_dec_per_s = 4 * B / std::chrono::duration<double>(t2 - t1).count();
+  return true;
+}
+
+int main() {
+  try {
+    if (!run_residency<uint64_t, 4096, 4>()) return 1;
+    if (!run_residency<uint32_t, 1024, 2>()) return 1;
+    if (!run_residency<uint16_t, 128, 1>()) return 1;
+    if (!run_residency<uint32_t, 8, 2>()) return 1;      // rows shorter than a 16-byte vector: the host route
+    if (!run_residency<uint64_t, 32768, 2>()) return 1;
+    double e = 0, d = 0, be = 0, bd = 0;
+    if (!run_lwe<uint64_t, 4096, 4>(&e, &d, &be, &bd)) return 1;
+    std::printf("{\"lwe_u64_4096_4\": {\"poly_p_encryptions_per_s\": %.1f, \"poly_p_decryptions_per_s\": %.1f, "
+                "\"device_batch_encryptions_per_s\": %.1f, \"device_batch_decryptions_per_s\": %.1f}}\n", e, d, be, bd);
+    std::printf("all checks passed\n");
+    return 0;
+  } catch (const std::exception &ex) {
+    std::printf("exception: %s\n", ex.what());
+    return 2;
+  }
+}

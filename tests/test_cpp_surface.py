@@ -13,9 +13,12 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 BIN = os.path.join(CPP, "surface_test")
 
 
+RES = os.path.join(CPP, "resident_test")
+
+
 def _build():
-    subprocess.check_call(["make", "-s", "-C", CPP])
-    assert os.path.exists(BIN)
+    subprocess.check_call(["make", "-s", "-C", CPP, "surface_test", "resident_test"])
+    assert os.path.exists(BIN) and os.path.exists(RES)
 
 
 def _gpu():
@@ -40,3 +43,17 @@ def test_surface_reference_style_checks_on_gpu():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_resident_poly_p_handles_and_the_lwe_demo_on_plain_operators():
+    """nfl::poly_p with its payload in HBM (SURVEY.md 8(f) rank 2): residency bits, copy-on-write, aliasing, mixed and
+    oversized trees, comparisons in HBM -- and the reference's LWE demo written with plain poly_p operators."""
+    import json
+    _build()
+    r = subprocess.run([RES], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout
+    rates = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["lwe_u64_4096_4"]
+    assert rates["poly_p_encryptions_per_s"] > 0 and rates["device_batch_encryptions_per_s"] > 0
+    print(rates)
