@@ -255,8 +255,10 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   nflhip_ctx *ctx;
   void *stream;
   std::mutex mu;
-  std::vector<void *> pool;
+  std::vector<void *> pool, slabs;
   static constexpr size_t poly_bytes = Degree * NbModuli * sizeof(T);
+  static constexpr size_t chunk_bytes = (poly_bytes + 255) / 256 * 256;          // device buffers are 256-byte aligned
+  static constexpr size_t slab_chunks = chunk_bytes >= (size_t(64) << 20) ? 1 : (size_t(64) << 20) / chunk_bytes > 1024 ? 1024 : (size_t(64) << 20) / chunk_bytes;
   context() : ctx(nullptr), stream(nullptr) {
     static_assert(NbModuli <= params<T>::kMaxNbModuli, "not enough moduli of this size (params.hpp)");
     static_assert(Degree <= params<T>::kMaxPolyDegree, "degree is not lower or equal than kMaxPolyDegree");
@@ -273,7 +275,7 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   ~context() {
     alive() = false;
     nflhip_stream_sync(ctx, stream);
-    for (void *p : pool) nflhip_free(ctx, p);
+    for (void *p : slabs) nflhip_free(ctx, p);
     nflhip_stream_destroy(ctx, stream);
     nflhip_ctx_destroy(ctx);
   }
@@ -291,16 +293,17 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   static void *queue() { return inst().stream; }
   static void *acquire() {
     context &c = inst();
-    {
-      std::lock_guard<std::mutex> lk(c.mu);
-      if (!c.pool.empty()) {
-        void *p = c.pool.back();
-        c.pool.pop_back();
-        return p;
-      }
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.pool.empty()) {
+      // a slab of up to 64 MiB, carved into polynomial-sized buffers: a hipMalloc per handle (~100 us) would dwarf the
+      // kernels a handle is used by.  Slabs live as long as the context.
+      void *slab = nullptr;
+      check(c.ctx, nflhip_malloc(c.ctx, &slab, chunk_bytes * slab_chunks), "device allocation");
+      c.slabs.push_back(slab);
+      for (size_t k = slab_chunks; k-- > 0;) c.pool.push_back(static_cast<char *>(slab) + k * chunk_bytes);
     }
-    void *p = nullptr;
-    check(c.ctx, nflhip_malloc(c.ctx, &p, poly_bytes), "device allocation");
+    void *p = c.pool.back();
+    c.pool.pop_back();
     return p;
   }
   static void release(void *p) {

@@ -189,6 +189,24 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     Big sh = big_shl(Q, k, Lacc);
     for (size_t i = 0; i < Lacc; ++i) qsh[k * kStride + i] = sh[i];
   }
+  // beyond the register-resident lift kernels (nm > 32 or more limbs than their tables hold): limb-serial tables
+  std::vector<uint64_t> qhat_w, qsh_w;
+  int Lw = 0, nsh = 0;
+  if (!crt_ok || nm > 32) {
+    Lw = (int)c->shape.crt_L + 2;
+    while ((((size_t)1) << nsh) <= nm) ++nsh;  // 2^nsh > nm >= S / Q
+    qhat_w.assign(nm * (size_t)Lw, 0);
+    qsh_w.assign((size_t)nsh * Lw, 0);
+    for (size_t cm = 0; cm < nm; ++cm) {
+      Big quot;
+      big_divrem_u64(Q, P[cm], &quot);
+      for (size_t k = 0; k < quot.size(); ++k) qhat_w[cm * Lw + k] = quot[k];
+    }
+    for (int k = 0; k < nsh; ++k) {
+      Big sh = big_shl(Q, k, (size_t)Lw);
+      for (int i = 0; i < Lw; ++i) qsh_w[(size_t)k * Lw + i] = sh[i];
+    }
+  }
   // carry-free multiply-accumulate tables for 64-bit limbs (kernels_crt.hip)
   std::vector<uint32_t> qparts, bparts;
   int proj_K = 0;
@@ -302,6 +320,16 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     for (size_t k = L; k-- > 0;) qt = qt * 18446744073709551616.0L + (long double)Q[k];
     for (long w = 0; w < 2 * (long)L - 3; ++w) qt /= 4294967296.0L;
     c->tabs.inv_qtop = (double)(1.0L / qt);
+  }
+  c->tabs.qhat_w = nullptr;
+  c->tabs.qsh_w = nullptr;
+  c->tabs.crt_Lw = Lw;
+  c->tabs.crt_nsh = nsh;
+  if (!qhat_w.empty()) {
+    HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qhat_w, qhat_w.size() * sizeof(uint64_t)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.qhat_w, qhat_w.data(), qhat_w.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qsh_w, qsh_w.size() * sizeof(uint64_t)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.qsh_w, qsh_w.data(), qsh_w.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
   HIPCHK(nullptr, hipMalloc((void **)&c->tabs.flag, nflhip_ctx::kCmpSlots * sizeof(int)));
   return NFLHIP_OK;
@@ -579,6 +607,8 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->tabs.qparts) (void)hipFree(ctx->tabs.qparts);
   if (ctx->tabs.bparts) (void)hipFree(ctx->tabs.bparts);
   if (ctx->tabs.flag) (void)hipFree(ctx->tabs.flag);
+  if (ctx->tabs.qhat_w) (void)hipFree(ctx->tabs.qhat_w);
+  if (ctx->tabs.qsh_w) (void)hipFree(ctx->tabs.qsh_w);
   delete ctx;
   return NFLHIP_OK;
 }
@@ -837,6 +867,18 @@ int nflhip_crt_lift_dev(nflhip_ctx *ctx, uint64_t *limbs, const void *d, size_t 
   CHECK_CTX(ctx);
   if (batch && (!limbs || !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
+  if (ctx->tabs.qhat_w && batch) {
+    // any number of moduli: the limb-serial kernel over a stream-ordered scratch (the unreduced sums)
+    uint64_t *scr = nullptr;
+    const size_t words = batch * ctx->shape.n * (size_t)ctx->tabs.crt_Lw;
+    HIPCHK(ctx, hipMallocAsync((void **)&scr, words * sizeof(uint64_t), st));
+    hipError_t we = DISPATCH_T(ctx, launch_crt_lift_wide<uint16_t>(ctx->shape, ctx->tabs, limbs, (const uint16_t *)d, batch, scr, st),
+                               launch_crt_lift_wide<uint32_t>(ctx->shape, ctx->tabs, limbs, (const uint32_t *)d, batch, scr, st),
+                               launch_crt_lift_wide<uint64_t>(ctx->shape, ctx->tabs, limbs, (const uint64_t *)d, batch, scr, st));
+    (void)hipFreeAsync(scr, st);
+    if (we != hipSuccess) return hipfail(ctx, we, "crt_lift (wide)");
+    return NFLHIP_OK;
+  }
   hipError_t e = DISPATCH_T(ctx, launch_crt_lift<uint16_t>(ctx->shape, ctx->tabs, limbs, (const uint16_t *)d, batch, st),
                             launch_crt_lift<uint32_t>(ctx->shape, ctx->tabs, limbs, (const uint32_t *)d, batch, st),
                             launch_crt_lift<uint64_t>(ctx->shape, ctx->tabs, limbs, (const uint64_t *)d, batch, st));

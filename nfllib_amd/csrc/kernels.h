@@ -51,6 +51,10 @@ struct DevTables {
   int proj_K;       // input words the project table covers
   double inv_qtop;  // 2^(32 (2 crt_L - 3)) / Q in double precision (quotient estimate of the lift)
   int *flag;        // kCmpSlots ints: result slots of any_eq / any_neq (one per concurrent call, see api.hip)
+  // CRT lift beyond the register-resident kernels (more than 32 moduli / 36 limbs): limb-serial kernel, any size
+  uint64_t *qhat_w; // [nm][crt_Lw]   Q/p_cm, little-endian limbs, or nullptr when the fast tables cover the shape
+  uint64_t *qsh_w;  // [crt_nsh][crt_Lw]  Q << k
+  int crt_Lw, crt_nsh;
 };
 
 // ---- launchers (kernels_generic.hip) ----
@@ -81,6 +85,10 @@ hipError_t launch_crt_lift(const Shape &s, const DevTables &t, uint64_t *limbs, 
 template <typename T>
 hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const uint64_t *limbs, size_t L_in, size_t batch,
                               hipStream_t st);
+// any number of moduli: `scratch` = batch * n * t.crt_Lw words (the unreduced sums, limb-major)
+template <typename T>
+hipError_t launch_crt_lift_wide(const Shape &s, const DevTables &t, uint64_t *limbs, const T *d, size_t batch,
+                                uint64_t *scratch, hipStream_t st);
 
 // ---- samplers (kernels_sample.hip): ChaCha20 counter streams keyed by (key32, stream_id) ----
 hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords, const unsigned char *key32,

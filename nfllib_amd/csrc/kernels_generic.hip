@@ -585,6 +585,66 @@ hipError_t launch_crt_lift(const Shape &s, const DevTables &t, uint64_t *limbs, 
   return hipGetLastError();
 }
 
+// The same lift for ANY number of moduli (the reference's GMP::poly2mpz has no cap, gmp.hpp:183-209): limb-serial, one
+// thread per coefficient.  Limb k of the unreduced sum S = sum_cm (Q/p_cm) * y_cm is
+//   sum_cm [ lo64(qhat[cm][k] * y_cm) + hi64(qhat[cm][k-1] * y_cm) ] + carry   (a 128-bit accumulator per limb),
+// so nothing but the running carry survives from one limb to the next and no per-thread array is needed; y_cm is
+// recomputed per limb.  S (< nm * Q, Lw = L + 2 limbs) goes to a limb-major scratch, then Q << k is subtracted
+// conditionally for k = nsh-1 .. 0 (2^nsh > nm).  Throughput is not the point here: no caller of the reference goes
+// beyond a few dozen moduli; this removes the cap.
+template <typename T>
+__global__ void k_crt_lift_wide(uint64_t *out, uint64_t *scr, const T *d, const ModConst<T> *__restrict__ mc,
+                                const uint64_t *__restrict__ qhat, const uint64_t *__restrict__ qsh, int nsh, int logn,
+                                int nm, int L, int Lw, size_t ncoef) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncoef) return;
+  const size_t b = gid >> logn, i = gid & ((((size_t)1) << logn) - 1);
+  const T *col = d + ((b * nm) << logn) + i;
+  unsigned __int128 carry = 0;
+  for (int k = 0; k < Lw; ++k) {
+    unsigned __int128 acc = carry;
+    for (int cm = 0; cm < nm; ++cm) {
+      const ModConst<T> c = mc[cm];
+      const uint64_t y = (uint64_t)mul_shoup<T>(col[(size_t)cm << logn], c.yinv, c.yinv_sh, c.p);
+      const uint64_t *qh = qhat + (size_t)cm * Lw;
+      acc += (unsigned __int128)(qh[k] * y);
+      if (k > 0) acc += (unsigned __int128)__umul64hi(qh[k - 1], y);
+    }
+    scr[(size_t)k * ncoef + gid] = (uint64_t)acc;
+    carry = acc >> 64;
+  }
+  for (int sft = nsh - 1; sft >= 0; --sft) {
+    const uint64_t *qs = qsh + (size_t)sft * Lw;
+    bool ge = true;
+    for (int k = Lw - 1; k >= 0; --k) {
+      const uint64_t a = scr[(size_t)k * ncoef + gid];
+      if (a != qs[k]) { ge = a > qs[k]; break; }
+    }
+    if (ge) {
+      uint64_t borrow = 0;
+      for (int k = 0; k < Lw; ++k) {
+        const uint64_t a = scr[(size_t)k * ncoef + gid], q = qs[k];
+        scr[(size_t)k * ncoef + gid] = a - q - borrow;
+        borrow = (a < q || (a == q && borrow)) ? 1 : 0;
+      }
+    }
+  }
+  uint64_t *o = out + gid * (size_t)L;
+  for (int k = 0; k < L; ++k) o[k] = scr[(size_t)k * ncoef + gid];
+}
+
+template <typename T>
+hipError_t launch_crt_lift_wide(const Shape &s, const DevTables &t, uint64_t *limbs, const T *d, size_t batch,
+                                uint64_t *scratch, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  if (!t.qhat_w) return hipErrorNotSupported;
+  const size_t ncoef = batch * s.n;
+  hipLaunchKernelGGL((k_crt_lift_wide<T>), dim3((unsigned)((ncoef + 63) / 64)), dim3(64), 0, st, limbs, scratch, d,
+                     (const ModConst<T> *)t.mc, t.qhat_w, t.qsh_w, t.crt_nsh, s.logn, (int)s.nm, (int)s.crt_L, t.crt_Lw,
+                     ncoef);
+  return hipGetLastError();
+}
+
 // CRT project (GMP::mpz2poly gmp.hpp:211-219): x(cm,i) = X_i mod p_cm by Horner
 // over the 64-bit limbs with beta = 2^64 mod p.
 template <typename T>
@@ -697,7 +757,9 @@ hipError_t launch_broadcast(void *dst, const void *one, size_t bytes_per_poly, s
   template hipError_t launch_crt_lift<T>(const Shape &, const DevTables &, uint64_t *, const T *, size_t,            \
                                          hipStream_t);                                                               \
   template hipError_t launch_crt_project<T>(const Shape &, const DevTables &, T *, const uint64_t *, size_t, size_t, \
-                                            hipStream_t);
+                                            hipStream_t);                                                            \
+  template hipError_t launch_crt_lift_wide<T>(const Shape &, const DevTables &, uint64_t *, const T *, size_t,       \
+                                              uint64_t *, hipStream_t);
 NFLHIP_INST(uint16_t)
 NFLHIP_INST(uint32_t)
 NFLHIP_INST(uint64_t)

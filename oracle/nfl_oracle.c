@@ -64,7 +64,7 @@ static inline uint64_t oracle_splitmix64(uint64_t seed, int operand, uint64_t g)
 
 /* ---- little-endian multi-limb helpers for the CRT constants (stand in for libgmp,
  * which the reference uses: gmp.hpp:113-219) ---- */
-#define BIG_MAX 160
+#define BIG_MAX 2048
 typedef struct {
   size_t n; /* significant limbs (no leading zero limb unless value is 0 -> n==0) */
   uint64_t v[BIG_MAX];

@@ -158,7 +158,7 @@ class Oracle:
         return self.lib.nfl_oracle_crt_shift(self.ctx)
 
     def _big(self, fn, *pre):
-        buf = np.zeros(160, dtype=np.uint64)
+        buf = np.zeros(2048, dtype=np.uint64)
         n = fn(self.ctx, *pre, _vp(buf), buf.size)
         return int.from_bytes(buf[:n].tobytes(), "little")
 
@@ -338,7 +338,7 @@ class Reference:
         return self.lib.nflref_crt_shift(self.id)
 
     def _big(self, fn, *pre):
-        buf = np.zeros(160, dtype=np.uint64)
+        buf = np.zeros(2048, dtype=np.uint64)
         n = fn(self.id, *pre, _vp(buf), buf.size)
         return int.from_bytes(buf[:n].tobytes(), "little")
 

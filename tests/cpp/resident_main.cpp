@@ -45,7 +45,7 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_residency() {
   poly_p c = a * b + d;                                // one fused device pass, stays resident
   CHECK(c.resident());
   *R = *A * *B + *D;
-  CHECK(same(c.poly_obj(), *R));                       // const access: value on the host AND still in HBM
+  CHECK(same(const_cast<const poly_p &>(c).poly_obj(), *R));   // const access: value on the host AND still in HBM
   CHECK(const_cast<const poly_p &>(c).resident());
   // copy-on-write: the copy shares the payload until one side is written; transforms detach device-to-device
   poly_p e = c;

@@ -563,3 +563,23 @@ def test_degrees_beyond_the_baseline_shapes(lb, n, m, batch, oracle_factory, eng
     assert np.array_equal(e.to_host(f), o.ntt(a))
     assert np.array_equal(e.to_host(e.intt_(f)), a)
     assert np.array_equal(e.to_host(e.polymul(da, e.ntt_(db.clone()), b_is_ntt=True)), want)
+
+
+@pytest.mark.parametrize("lb,n,m,batch", [(64, 64, 33, 2), (64, 256, 40, 1), (64, 16, 100, 2), (32, 64, 64, 2), (32, 32, 291, 1),
+                                          (64, 8, 1000, 1)])
+def test_crt_beyond_32_moduli(lb, n, m, batch, oracle_factory, engine_factory):
+    """GMP::poly2mpz / mpz2poly have no modulus-count cap in the reference (gmp.hpp:113-219, any NbModuli up to
+    params<T>::kMaxNbModuli = 1000 / 291): the limb-serial lift and the generic projection cover every count."""
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    assert e.crt_limbs == o.crt_limbs and e.crt_constant(0) == o.crt_modulus()
+    a = o.fill_uniform(batch, SEED, 0)
+    a[0, :, 0] = [p - 1 for p in o.P]          # X = Q - 1
+    a[0, :, 1] = 0
+    a[0, :, 2] = 1
+    limbs = e.crt_lift(e.to_device(a))
+    assert np.array_equal(e.to_host(limbs).view(np.uint64), o.crt_lift(a)), "poly2mpz differs"
+    Q = o.crt_modulus()
+    x0 = int.from_bytes(e.to_host(limbs)[0, 0].view(np.uint64).tobytes(), "little")
+    assert x0 == Q - 1
+    assert np.array_equal(e.to_host(e.crt_project(limbs)), a)
+    assert np.array_equal(e.h_crt_project(e.h_crt_lift(a)), a)

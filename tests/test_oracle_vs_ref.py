@@ -8,7 +8,8 @@ from oracle import oracle as O
 pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (no /root/reference here)")
 
 SHAPES = [(16, 128, 1), (32, 8, 2), (32, 1024, 1), (32, 1024, 2), (64, 8, 2), (64, 64, 3), (64, 1024, 2), (64, 4096, 4),
-          (64, 8192, 2), (64, 16384, 8), (64, 32768, 2)]
+          (64, 8192, 2), (64, 16384, 8), (64, 32768, 2),
+          (64, 16, 40), (32, 32, 64)]   # more than 32 moduli: pins the CRT of the limb-serial device lift
 
 
 @pytest.mark.parametrize("lb,n,m", SHAPES)
