@@ -30,6 +30,8 @@ WORKLOADS = {
     "C": (64, 16384, 8, 1024),   # configs[2]
     "E": (64, 65536, 30, 32),    # configs[4]
     "A": (32, 1024, 1, 1 << 19), # configs[0]'s shape (30-bit moduli) on the device -- secondary
+    "F": (64, 32768, 2, 512),    # the reference's own largest test config (32768, 124, uint64_t): tests/CMakeLists.txt:19-48
+    "G": (64, 8192, 2, 8192),    # ... and (8192, 124, uint64_t)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
@@ -320,6 +322,21 @@ def main():
         t0h = time.perf_counter()
         eng.h_polymul(ha, hbb)
         t_host = time.perf_counter() - t0h
+        # core::ntt (core.hpp:455-532), the cyclic row transform tests/ntt_perfs.cpp:155-171 times on
+        # poly<uint64_t,1024,2> rows (BASELINE configs[0]'s path): nflhip_ntt_row_dev over resident rows of one modulus
+        row_extra = {}
+        try:
+            er = Engine(64, 1024, 2, device=dev)
+            nrows = 1 << 17
+            rows = er.fill_uniform(er.empty(nrows // 2), SEED, 0).view(-1, 1024)
+            t_row = rate(lambda: er.ntt_row_(rows, 0))
+            row_extra = {"core_ntt_rows_per_s_u64_1024": round(nrows / t_row, 1),
+                         "core_ntt_GBs_u64_1024": round(nrows * 1024 * 8 * 2 / t_row / 1e9, 1),
+                         "core_ntt_reference_us_per_row": "6.86 us on one core (tests/ntt_perfs.cpp, SURVEY.md section 6)"}
+            del rows
+            er.close()
+        except Exception as ex:  # secondary figure: never takes the bench down
+            row_extra = {"core_ntt_rows_per_s_u64_1024": None, "core_ntt_error": repr(ex)}
         extras = {
             "ntt_fwd_per_s": round(batch / t_f, 1), "ntt_fwd_GBs": round(tr_bytes / t_f / 1e9, 1),
             "ntt_inv_per_s": round(batch / t_i, 1), "ntt_inv_GBs": round(tr_bytes / t_i / 1e9, 1),
@@ -330,6 +347,7 @@ def main():
             "sample_uniform_per_s": round(batch / t_su, 1), "sample_uniform_GBs": round(batch * nm * n * w / t_su / 1e9, 1),
             "sample_gaussian_per_s": round(batch / t_sg, 1),
             "host_pointer_polymul_per_s": round(hb / t_host, 1),
+            **row_extra,
             "note": "GB/s are algorithmic bytes (SURVEY.md 8(d)) / event time; polys per second over the same batch",
         }
         del bn, limbs
@@ -346,7 +364,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": {"A": "k_row<Pol32, 0, 4>", "B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm",
-                                "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)"}[kwl],
+                                "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)",
+                                "F": "k_ntt_fwd_outer x2 + nflhip_polymul4096_asm (blocks) + k_ntt_inv_outer (three-kernel plan, chunked on two streams)",
+                                "G": "nflhip_polymul8192_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
     # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  Instructions per wave are
