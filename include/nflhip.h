@@ -159,6 +159,14 @@ int nflhip_eval_dev(nflhip_ctx *ctx, void *d_out, const void *const *d_operands,
                     const unsigned char *program, size_t proglen, size_t batch, void *stream);
 int nflhip_eval(nflhip_ctx *ctx, void *h_out, const void *const *h_operands, size_t noperands,
                 const unsigned char *program, size_t proglen, size_t batch);
+/* The same over operands that advance by their own stride (in polynomials) from one batch element to the next:
+ * 1 = a dense array of polynomials, 0 = ONE polynomial shared by the whole batch (a key), k = every k-th polynomial of
+ * an interleaved array.  Element i reads operand j at d_operands[j] + i*strides[j] polynomials and writes
+ * d_out + i*out_stride polynomials (out_stride >= 1).  What the header's deferred per-polynomial operations are
+ * coalesced into (one launch for a loop of `r[i] = u[i] * key + e[i]`). */
+int nflhip_eval_strided_dev(nflhip_ctx *ctx, void *d_out, size_t out_stride, const void *const *d_operands,
+                            const size_t *strides, size_t noperands, const unsigned char *program, size_t proglen,
+                            size_t batch, void *stream);
 
 /* ---- the metric path ---------------------------------------------------------
  * c = INTT( NTT(a) (.) NTT(b) ): the reference sequence
@@ -237,6 +245,12 @@ int nflhip_sample_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, size_t b
                       uint64_t param1, const unsigned char key[32], uint64_t stream_id, void *stream);
 int nflhip_sample(nflhip_ctx *ctx, void *h_data, size_t batch, int dist, uint64_t param0, uint64_t param1,
                   const unsigned char key[32], uint64_t stream_id);
+/* SEQUENCE forms: polynomial b of the dense batch at d is exactly what the one-polynomial call
+ * nflhip_sample_dev(ctx, d_b, 0, 1, dist, param0, param1, key, first_stream_id + b*stream_id_stride, stream) produces
+ * (one keystream per polynomial instead of one keystream per batch) -- so a loop of per-polynomial constructor calls
+ * and ONE batched launch give the same polynomials.  Needs degree >= 8 (NFLHIP_ERR_UNSUPPORTED otherwise). */
+int nflhip_sample_seq_dev(nflhip_ctx *ctx, void *d_data, size_t batch, int dist, uint64_t param0, uint64_t param1,
+                          const unsigned char key[32], uint64_t first_stream_id, uint64_t stream_id_stride, void *stream);
 /* raw keystream words [first_word, first_word + nwords) of (key, stream_id) -- what the samplers consume */
 int nflhip_random_words_dev(nflhip_ctx *ctx, uint64_t *d_out, uint64_t first_word, size_t nwords,
                             const unsigned char key[32], uint64_t stream_id, void *stream);
@@ -264,6 +278,10 @@ int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d_data, size_t first_poly, si
                             uint64_t amplifier, const unsigned char key[32], uint64_t stream_id, void *stream);
 int nflhip_sample_gauss(nflhip_ctx *ctx, void *h_data, size_t batch, const nflhip_gauss *g, uint64_t amplifier,
                         const unsigned char key[32], uint64_t stream_id);
+/* sequence form, see nflhip_sample_seq_dev */
+int nflhip_sample_gauss_seq_dev(nflhip_ctx *ctx, void *d_data, size_t batch, const nflhip_gauss *g, uint64_t amplifier,
+                                const unsigned char key[32], uint64_t first_stream_id, uint64_t stream_id_stride,
+                                void *stream);
 /* FastGaussianNoise::getNoise(out, rlen) (FastGaussianNoise.hpp:477-595): `count` raw signed samples; sample j is the
  * integer that coefficient first_sample + j of a polynomial batch gets from the same (key, stream_id) */
 int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sample, size_t count, const nflhip_gauss *g,

@@ -42,6 +42,7 @@ SYMBOLS = [
     ("nflhip_pointwise", _i, [_vp, _i, _vp, _vp, _vp, _vp, _sz]),
     ("nflhip_eval_dev", _i, [_vp, _vp, _vp, _sz, _vp, _sz, _sz, _vp]),
     ("nflhip_eval", _i, [_vp, _vp, _vp, _sz, _vp, _sz, _sz]),
+    ("nflhip_eval_strided_dev", _i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _sz, _vp]),
     ("nflhip_polymul_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     ("nflhip_polymul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("nflhip_polymul_ntt_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
@@ -56,6 +57,8 @@ SYMBOLS = [
     ("nflhip_fill_uniform_dev", _i, [_vp, _vp, _sz, _sz, _u64, _i, _vp]),
     ("nflhip_sample_dev", _i, [_vp, _vp, _sz, _sz, _i, _u64, _u64, _vp, _u64, _vp]),
     ("nflhip_sample", _i, [_vp, _vp, _sz, _i, _u64, _u64, _vp, _u64]),
+    ("nflhip_sample_seq_dev", _i, [_vp, _vp, _sz, _i, _u64, _u64, _vp, _u64, _u64, _vp]),
+    ("nflhip_sample_gauss_seq_dev", _i, [_vp, _vp, _sz, _vp, _u64, _vp, _u64, _u64, _vp]),
     ("nflhip_random_words_dev", _i, [_vp, _vp, _u64, _sz, _vp, _u64, _vp]),
     ("nflhip_gauss_create", _i, [_vp, C.POINTER(_vp), C.c_double, C.c_uint, C.c_uint, C.c_double]),
     ("nflhip_gauss_destroy", _i, [_vp, _vp]),

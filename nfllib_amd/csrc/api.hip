@@ -783,12 +783,12 @@ int nflhip_pointwise_dev(nflhip_ctx *ctx, int op, void *o, const void *a, const 
 }
 
 static int eval_dev(nflhip_ctx *ctx, void *out, const void *const *ops, size_t nops, const unsigned char *prog, size_t len,
-                    size_t batch, void *stream) {
+                    size_t batch, void *stream, const unsigned *strides = nullptr, unsigned out_stride = 1) {
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = DISPATCH_T(
-      ctx, launch_eval_expr<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)out, ops, (int)nops, prog, (int)len, batch, st),
-      launch_eval_expr<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)out, ops, (int)nops, prog, (int)len, batch, st),
-      launch_eval_expr<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)out, ops, (int)nops, prog, (int)len, batch, st));
+      ctx, launch_eval_expr<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)out, ops, (int)nops, prog, (int)len, batch, st, strides, out_stride),
+      launch_eval_expr<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)out, ops, (int)nops, prog, (int)len, batch, st, strides, out_stride),
+      launch_eval_expr<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)out, ops, (int)nops, prog, (int)len, batch, st, strides, out_stride));
   if (e == hipErrorInvalidValue) return fail(ctx, NFLHIP_ERR_INVALID, "malformed expression program");
   if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "row shorter than one 16-byte vector");
   if (e != hipSuccess) return hipfail(ctx, e, "eval");
@@ -829,6 +829,23 @@ int nflhip_eval_dev(nflhip_ctx *ctx, void *d_out, const void *const *d_operands,
   for (size_t i = 0; i < noperands; ++i)
     if (batch && !d_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
   return eval_dev(ctx, d_out, d_operands, noperands, program, proglen, batch, stream);
+}
+
+int nflhip_eval_strided_dev(nflhip_ctx *ctx, void *d_out, size_t out_stride, const void *const *d_operands,
+                            const size_t *strides, size_t noperands, const unsigned char *program, size_t proglen,
+                            size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (!program || !d_operands || !strides || (batch && !d_out)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (noperands == 0 || noperands > NFLHIP_EXPR_MAX_OPERANDS || proglen == 0 || proglen > NFLHIP_EXPR_MAX_LEN)
+    return fail(ctx, NFLHIP_ERR_INVALID, "expression program too large");
+  unsigned sd[NFLHIP_EXPR_MAX_OPERANDS];
+  for (size_t i = 0; i < noperands; ++i) {
+    if (batch && !d_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+    if (strides[i] > 0xffffffffu) return fail(ctx, NFLHIP_ERR_INVALID, "operand stride out of range");
+    sd[i] = (unsigned)strides[i];
+  }
+  if (out_stride == 0 || out_stride > 0xffffffffu) return fail(ctx, NFLHIP_ERR_INVALID, "the result stride must be positive");
+  return eval_dev(ctx, d_out, d_operands, noperands, program, proglen, batch, stream, sd, (unsigned)out_stride);
 }
 
 int nflhip_polymul_dev(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_t batch, void *stream) {
@@ -951,6 +968,41 @@ int nflhip_sample_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t batch,
       launch_sample<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, dist_in, p0, p1, key, stream_id, st),
       launch_sample<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, dist_in, p0, p1, key, stream_id, st));
   if (e != hipSuccess) return hipfail(ctx, e, "sample");
+  return NFLHIP_OK;
+}
+
+int nflhip_sample_seq_dev(nflhip_ctx *ctx, void *d, size_t batch, int dist, uint64_t p0, uint64_t p1, const unsigned char *key,
+                          uint64_t first_stream_id, uint64_t stream_id_stride, void *stream) {
+  // argument checks are those of nflhip_sample_dev (same messages): validate through it with an empty batch
+  int rc = nflhip_sample_dev(ctx, d, 0, 0, dist, p0, p1, key, first_stream_id, stream);
+  if (rc) return rc;
+  if (batch && !d) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = DISPATCH_T(
+      ctx, launch_sample<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, 0, batch, dist, p0, p1, key, first_stream_id, st, 1, stream_id_stride),
+      launch_sample<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, 0, batch, dist, p0, p1, key, first_stream_id, st, 1, stream_id_stride),
+      launch_sample<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, 0, batch, dist, p0, p1, key, first_stream_id, st, 1, stream_id_stride));
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8");
+  if (e != hipSuccess) return hipfail(ctx, e, "sample_seq");
+  return NFLHIP_OK;
+}
+
+int nflhip_sample_gauss_seq_dev(nflhip_ctx *ctx, void *d, size_t batch, const nflhip_gauss *g, uint64_t amplifier,
+                                const unsigned char *key, uint64_t first_stream_id, uint64_t stream_id_stride, void *stream) {
+  CHECK_CTX(ctx);
+  if (!key || !g || (batch && !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (g->device != ctx->device) return fail(ctx, NFLHIP_ERR_INVALID, "gaussian table lives on another device");
+  if (amplifier == 0) return fail(ctx, NFLHIP_ERR_INVALID, "amplifier must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const int w = g->tab.words, en = (int)g->tab.entries;
+  const long long x0 = g->tab.x_min;
+  hipError_t e = DISPATCH_T(
+      ctx,
+      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride),
+      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride),
+      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride));
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8");
+  if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss_seq");
   return NFLHIP_OK;
 }
 

@@ -70,7 +70,8 @@ hipError_t launch_pointwise(const Shape &s, const DevTables &t, int op, T *out, 
 // postfix expression program (include/nflhip.h NFLHIP_EXPR_*) over up to 8 operands, one fused pass
 template <typename T>
 hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const void *const *operands, int noperands,
-                            const unsigned char *program, int len, size_t batch, hipStream_t st);
+                            const unsigned char *program, int len, size_t batch, hipStream_t st,
+                            const unsigned *strides = nullptr, unsigned out_stride = 1);  // strides in polynomials (0 = shared)
 template <typename T>
 hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
                           int *flag, hipStream_t st);
@@ -96,7 +97,8 @@ hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords
 // dist: 0 uniform | 1 bounded (p0 = upper bound, p1 = amplifier) | 2 zero/one (p0 = rho) | 3 hamming weight (p0 = h)
 template <typename T>
 hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, int dist, uint64_t p0,
-                         uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st);
+                         uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on = 0,
+                         uint64_t seq_stride = 0);  // seq_on: polynomial b = a one-polynomial call with stream id + b * seq_stride
 hipError_t launch_inner_fwd_fast_u32(const Shape &s, const DevTables &t, const uint32_t *src, uint32_t *dst, size_t rows,
                                      hipStream_t st);
 hipError_t launch_inner_inv_fast_u32(const Shape &s, const DevTables &t, const uint32_t *src, const uint32_t *mul,
@@ -106,7 +108,8 @@ hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t coun
 template <typename T>
 hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
                                const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
-                               const unsigned char *key32, uint64_t stream_id, hipStream_t st);
+                               const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on = 0,
+                               uint64_t seq_stride = 0);
 
 // ---- fast paths (kernels_fast.hip); return hipErrorNotSupported when the shape has none ----
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,

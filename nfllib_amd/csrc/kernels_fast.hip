@@ -352,6 +352,7 @@ enum AsmKind {
   kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
   kAsmPolymul8k, kAsmPolymulNtt8k, kAsmFwd8k, kAsmInv8k,            // 8192-word blocks, 512 threads
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
+  kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmCount
 };
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
@@ -363,7 +364,8 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_ntt_inv16384_asm",    "nflhip_polymul_pipe65536_asm",
                                                  "nflhip_polymul8192_asm",     "nflhip_polymul_ntt8192_asm",
                                                  "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm",
-                                                 "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm"};
+                                                 "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm",
+                                                 "nflhip_polymul_pipe65536nt_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -453,7 +455,9 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
                                       hipStream_t st) {
   if (s.limb_bits != 64 || s.logn != 16 || variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
-  hipFunction_t fn = asm_fn(kAsmPipe64k);
+  // NFLHIP_PIPE_NT=1: coefficient loads / stores bypass L2 retention (`nt`), so the twiddle tables stay resident there
+  static const int use_nt = getenv("NFLHIP_PIPE_NT") ? atoi(getenv("NFLHIP_PIPE_NT")) : 1;  // measured +3 % (E, batch 32 and 128)
+  hipFunction_t fn = asm_fn(use_nt ? kAsmPipe64kNt : kAsmPipe64k);
   if (!fn) return hipErrorNotSupported;
   const int mx = cnt_v > cnt_f ? (cnt_v > cnt_i ? cnt_v : cnt_i) : (cnt_f > cnt_i ? cnt_f : cnt_i);
   if (mx <= 0) return hipSuccess;

@@ -437,9 +437,60 @@ __global__ void k_eval_expr(T *out, ExprProgram prog, const ModConst<T> *__restr
   }
 }
 
+// The same program over a batch whose operands (and result) advance by their own stride from one polynomial to the
+// next: stride 1 = a dense array of polynomials, 0 = ONE polynomial shared by the whole batch (a key), k = every k-th
+// polynomial of an interleaved array.  blockIdx.y = polynomial, so no division is needed to find it.
+struct ExprStrides {
+  unsigned op[8];
+  unsigned out;
+};
+template <typename T>
+__global__ void k_eval_expr_strided(T *out, ExprProgram prog, ExprStrides sd, const ModConst<T> *__restrict__ mc, int logn,
+                                    int nm) {
+  constexpr int V = 16 / sizeof(T);
+  struct alignas(16) Vec { T e[V]; };
+  const size_t vpp = (((size_t)nm) << logn) / V;  // vectors per polynomial
+  const size_t poly = blockIdx.y;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < vpp; w += (size_t)gridDim.x * blockDim.x) {
+    const int cm = (int)((w * V) >> logn);
+    const T p = mc[cm].p, mu = mc[cm].mu;
+    ExprStack<T> st[V];
+    for (int pc = 0; pc < prog.len; ++pc) {
+      const unsigned c = prog.code[pc];
+      if (c < 8) {
+        const Vec x = reinterpret_cast<const Vec *>(prog.operand[c])[poly * sd.op[c] * vpp + w];
+#pragma unroll
+        for (int k = 0; k < V; ++k) st[k].push(x.e[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          ExprStack<T> &s = st[k];
+          switch (c) {
+            case 0x10: { const T r = csub<T>((T)(s.s1 + s.s0), p); s.drop(); s.s0 = r; } break;
+            case 0x11: { const T r = csub<T>((T)(s.s1 + (T)(p - s.s0)), p); s.drop(); s.s0 = r; } break;
+            case 0x12: { const T r = barrett<T>::mul(s.s1, s.s0, p, mu); s.drop(); s.s0 = r; } break;
+            case 0x13: { const T r = mul_shoup<T>(s.s2, s.s1, s.s0, p); s.drop(); s.drop(); s.s0 = r; } break;
+            default: {
+              T x = s.s0;
+              x = csub<T>(x, (T)(4 * p)); x = csub<T>(x, (T)(2 * p)); x = csub<T>(x, p);
+              if (sizeof(T) < 8) { while (x >= p) x -= p; }
+              s.s0 = shoup_of<T>::get(x, p, mu);
+            } break;
+          }
+        }
+      }
+    }
+    Vec o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o.e[k] = st[k].s0;
+    reinterpret_cast<Vec *>(out)[poly * sd.out * vpp + w] = o;
+  }
+}
+
 template <typename T>
 hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const void *const *operands, int noperands,
-                            const unsigned char *program, int len, size_t batch, hipStream_t st) {
+                            const unsigned char *program, int len, size_t batch, hipStream_t st,
+                            const unsigned *strides, unsigned out_stride) {
   if (batch == 0) return hipSuccess;
   if (len <= 0 || len > 24 || noperands < 1 || noperands > 8) return hipErrorInvalidValue;
   const size_t total = batch * s.nm * s.n;
@@ -460,6 +511,24 @@ hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const vo
   if (depth != 1) return hipErrorInvalidValue;
   prog.len = len;
   for (int i = 0; i < 8; ++i) prog.operand[i] = i < noperands ? operands[i] : nullptr;
+  if (strides) {
+    if (batch > 65535 * 1024u) return hipErrorInvalidValue;
+    ExprStrides sd;
+    for (int i = 0; i < 8; ++i) sd.op[i] = i < noperands ? strides[i] : 0;
+    sd.out = out_stride;
+    const size_t vpp = s.nm * s.n / V;
+    size_t bx = (vpp + 255) / 256;
+    if (bx > 64) bx = 64;
+    // grid.y is limited to 65535: longer batches go in slices (the strides advance the base pointers)
+    for (size_t lo = 0; lo < batch; lo += 65535) {
+      const size_t cnt = batch - lo < 65535 ? batch - lo : 65535;
+      ExprProgram pp = prog;
+      for (int i = 0; i < noperands; ++i) pp.operand[i] = (const T *)prog.operand[i] + lo * sd.op[i] * s.nm * s.n;
+      hipLaunchKernelGGL((k_eval_expr_strided<T>), dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, st,
+                         out + lo * sd.out * s.nm * s.n, pp, sd, (const ModConst<T> *)t.mc, s.logn, (int)s.nm);
+    }
+    return hipGetLastError();
+  }
   const size_t nvec = total / V;
   size_t blocks = (nvec + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -748,7 +817,8 @@ hipError_t launch_broadcast(void *dst, const void *one, size_t bytes_per_poly, s
   template hipError_t launch_pointwise<T>(const Shape &, const DevTables &, int, T *, const T *, const T *,          \
                                           const T *, size_t, hipStream_t);                                           \
   template hipError_t launch_eval_expr<T>(const Shape &, const DevTables &, T *, const void *const *, int,           \
-                                          const unsigned char *, int, size_t, hipStream_t);                          \
+                                          const unsigned char *, int, size_t, hipStream_t, const unsigned *,         \
+                                          unsigned);                                                                 \
   template hipError_t launch_any_cmp<T>(const Shape &, const DevTables &, const T *, const T *, size_t, int, int *,  \
                                         hipStream_t);                                                                \
   template hipError_t launch_fill_uniform<T>(const Shape &, const DevTables &, T *, size_t, size_t, uint64_t, int,   \

@@ -20,6 +20,11 @@ struct ChaChaKey {
   // keystream word (a public uniform polynomial must not reveal the noise drawn next to it).  The low 56 bits count
   // blocks: 2^56 x 64 bytes per (key, stream_id, distribution).
   uint64_t dom;
+  // SEQUENCE MODE (nflhip_sample_seq_dev): polynomial b of the batch is what a one-polynomial call with stream id
+  // nonce + b * seq_stride would produce (word positions restart at 0 in every polynomial).  seq_on = 0: the batch is
+  // one keystream read by global position (first_poly offsets it).
+  uint32_t seq_on;
+  uint64_t seq_stride;
 };
 // tags: NFLHIP_DIST_* + 1; 0 = the raw words of nflhip_random_words_dev, kDomGauss for both Gaussian entry points
 static constexpr int kDomRaw = 0, kDomGauss = 5;
@@ -138,9 +143,14 @@ __global__ void __launch_bounds__(256) k_sample_uniform8(T *d, const ModConst<T>
     uint64_t v[8], o[8];
     if (active) {
       uint64_t w[8];
-      chacha20_block(key, fb + b, nonce, w);
       const uint64_t row = (fb + b) >> (logn - 3);
       const int cm = (row >> 32) == 0 ? (int)((uint32_t)row % (uint32_t)nm) : (int)(row % (uint64_t)nm);
+      if (key.seq_on) {  // per-polynomial keystreams: block index inside the polynomial, stream id of the polynomial
+        const uint64_t poly = row / (uint64_t)nm;
+        chacha20_block(key, (fb + b) - ((poly * (uint64_t)nm) << (logn - 3)), nonce + poly * key.seq_stride, w);
+      } else {
+        chacha20_block(key, fb + b, nonce, w);
+      }
       const ModConst<T> c = mc[cm];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -235,7 +245,8 @@ __global__ void __launch_bounds__(256) k_sample_small8(T *d, const ModConst<T> *
     long long v[8], o[8];
     if (active) {
       uint64_t w[8];
-      chacha20_block(key, fb + b, nonce, w);
+      if (key.seq_on) chacha20_block(key, (fb + b) & ((n >> 3) - 1), nonce + ((fb + b) >> (logn - 3)) * key.seq_stride, w);
+      else chacha20_block(key, fb + b, nonce, w);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (dist == 1) {  // same statements as k_sample_small
@@ -351,12 +362,16 @@ __global__ void __launch_bounds__(256) k_sample_gauss8(T *d, const ModConst<T> *
   for (size_t tile = (size_t)blockIdx.x * 4 + wv; tile < nwt; tile += (size_t)gridDim.x * 4) {
     const size_t grp = (tile << 6) + lane;
     if (grp < ngroups) {
-      const uint64_t g0 = first_coef + (grp << 3);
+      uint64_t g0 = first_coef + (grp << 3), nc = nonce;
+      if (key.seq_on) {  // coefficient index inside the polynomial, stream id of the polynomial
+        nc += (g0 >> logn) * key.seq_stride;
+        g0 &= n - 1;
+      }
       uint64_t w[8];
-      chacha20_block(key, g0 >> 3, nonce, w);
+      chacha20_block(key, g0 >> 3, nc, w);
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        xs[wv][c * S + lane] = gauss_search<W>(w[c], g0 + c, cdt, entries, tie_shift, key, nonce);
+        xs[wv][c * S + lane] = gauss_search<W>(w[c], g0 + c, cdt, entries, tie_shift, key, nc);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -409,7 +424,8 @@ __global__ void k_hwt_select(T *d, int logn, int nm, uint64_t first_poly, size_t
                              uint64_t nonce) {
   const size_t P = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (P >= batch) return;
-  const uint64_t n = ((uint64_t)1) << logn, base = (first_poly + P) * 4 * n;
+  const uint64_t n = ((uint64_t)1) << logn, base = key.seq_on ? 0 : (first_poly + P) * 4 * n;
+  if (key.seq_on) nonce += P * key.seq_stride;
   T *row0 = d + ((P * (uint64_t)nm) << logn);
   uint64_t blk[8], have = ~(uint64_t)0, ctr = 0;
   auto word = [&](uint64_t wi) {
@@ -448,9 +464,11 @@ __global__ void k_hwt_spread(T *d, const ModConst<T> *__restrict__ mc, int logn,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static inline ChaChaKey load_key(const unsigned char *key32, int domain) {
+static inline ChaChaKey load_key(const unsigned char *key32, int domain, int seq_on = 0, uint64_t seq_stride = 0) {
   ChaChaKey k;
   k.dom = ((uint64_t)domain) << 56;
+  k.seq_on = (uint32_t)seq_on;
+  k.seq_stride = seq_stride;
   for (int i = 0; i < 8; ++i)
     k.k[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) |
              ((uint32_t)key32[4 * i + 3] << 24);
@@ -471,12 +489,14 @@ hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords
 
 template <typename T>
 hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, int dist, uint64_t p0,
-                         uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
+                         uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on,
+                         uint64_t seq_stride) {
   if (batch == 0) return hipSuccess;
+  if (seq_on && (s.n < 8 || first_poly != 0)) return hipErrorNotSupported;  // (keystream blocks must not straddle polynomials)
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
   const int refw = dist & 0x100;   // NFLHIP_DIST_REFERENCE_WORDS
   dist &= 0xff;
-  const ChaChaKey key = load_key(key32, dist + 1);
+  const ChaChaKey key = load_key(key32, dist + 1, seq_on, seq_stride);
   const size_t ncoef = batch * s.n, total = ncoef * s.nm;
   switch (dist) {
     case 0:
@@ -538,10 +558,12 @@ hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t coun
 template <typename T>
 hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
                                const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
-                               const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
+                               const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on,
+                               uint64_t seq_stride) {
   if (batch == 0) return hipSuccess;
+  if (seq_on && (s.n < 8 || first_poly != 0)) return hipErrorNotSupported;
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
-  const ChaChaKey key = load_key(key32, kDomGauss);
+  const ChaChaKey key = load_key(key32, kDomGauss, seq_on, seq_stride);
   const size_t ncoef = batch * s.n;
   const uint64_t fc = (uint64_t)first_poly * s.n;
   const int tie_shift = gauss_tie_shift();
@@ -567,9 +589,10 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
 
 #define NFLHIP_INST(T)                                                                                                   \
   template hipError_t launch_sample<T>(const Shape &, const DevTables &, T *, size_t, size_t, int, uint64_t, uint64_t,   \
-                                       const unsigned char *, uint64_t, hipStream_t);                                    \
+                                       const unsigned char *, uint64_t, hipStream_t, int, uint64_t);                     \
   template hipError_t launch_sample_gauss<T>(const Shape &, const DevTables &, T *, size_t, size_t, const uint64_t *, int, \
-                                             int, long long, uint64_t, const unsigned char *, uint64_t, hipStream_t);
+                                             int, long long, uint64_t, const unsigned char *, uint64_t, hipStream_t, int,  \
+                                             uint64_t);
 NFLHIP_INST(uint16_t)
 NFLHIP_INST(uint32_t)
 NFLHIP_INST(uint64_t)

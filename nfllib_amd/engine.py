@@ -146,6 +146,17 @@ class Engine:
                                            self._stream(stream)))
         return out
 
+    def eval_strided(self, program, operands, strides, out, out_stride=1, batch=None, stream=None):
+        """nflhip_eval_strided_dev: element i reads operand j at operands[j] + i*strides[j] polynomials (0 = one shared
+        polynomial) and writes out + i*out_stride polynomials"""
+        ptrs = (C.c_void_p * len(operands))(*[o.data_ptr() for o in operands])
+        sd = (C.c_size_t * len(operands))(*strides)
+        prog = (C.c_ubyte * len(program))(*program)
+        self._chk(self.lib.nflhip_eval_strided_dev(self.ctx, _vp(out), out_stride, C.cast(ptrs, C.c_void_p),
+                                                   C.cast(sd, C.c_void_p), len(operands), C.cast(prog, C.c_void_p),
+                                                   len(program), batch, self._stream(stream)))
+        return out
+
     def h_eval(self, program, operands):
         out = np.empty_like(operands[0])
         ptrs = (C.c_void_p * len(operands))(*[o.ctypes.data for o in operands])
@@ -201,6 +212,17 @@ class Engine:
         | DIST_HWT (param0 = hamming weight)"""
         self._chk(self.lib.nflhip_sample_dev(self.ctx, _vp(d), first_poly, self._batch(d), dist, param0, param1,
                                              self._key(key), self._sid(stream_id), self._stream(stream)))
+        return d
+
+    def sample_seq(self, d, dist, key, first_stream_id, stream_id_stride=1, param0=0, param1=1, stream=None):
+        """polynomial b = sample(one polynomial, stream id first_stream_id + b*stride) (nflhip_sample_seq_dev)"""
+        self._chk(self.lib.nflhip_sample_seq_dev(self.ctx, _vp(d), self._batch(d), dist, param0, param1, self._key(key),
+                                                 first_stream_id, stream_id_stride, self._stream(stream)))
+        return d
+
+    def sample_gauss_seq(self, d, g, key, first_stream_id, stream_id_stride=1, amplifier=1, stream=None):
+        self._chk(self.lib.nflhip_sample_gauss_seq_dev(self.ctx, _vp(d), self._batch(d), g, amplifier, self._key(key),
+                                                       first_stream_id, stream_id_stride, self._stream(stream)))
         return d
 
     def random_words(self, nwords, key, stream_id=0, first_word=0, stream=None):

@@ -110,3 +110,51 @@ def test_reference_words_mode_of_zo_and_hwt(lb, n, m, engine_factory):
         c, r = can[:, cm].astype(object), ref[:, cm].astype(object)
         assert np.array_equal(np.where(r == p + 1, 1, r), c) and set(np.unique(r).tolist()) <= {0, p - 1, p + 1}
         assert (r == p + 1).sum() == (c == 1).sum() and ((c == 1).sum() > 0 or n < 128)
+
+
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (32, 1024, 2), (16, 128, 1), (64, 8, 3), (64, 2048, 5)])
+def test_sequence_samplers_equal_a_loop_of_single_calls(lb, n, m, engine_factory):
+    """nflhip_sample_seq_dev / nflhip_sample_gauss_seq_dev: one launch over a dense batch == per-polynomial calls with
+    stream ids first + b*stride (what the header's deferred random constructors are coalesced into)."""
+    from nfllib_amd import DIST_BOUNDED, DIST_HWT, DIST_UNIFORM, DIST_ZO
+    e = engine_factory(lb, n, m)
+    key, batch = bytes(range(32)), 7
+    for dist, p0, p1 in ((DIST_UNIFORM, 0, 1), (DIST_BOUNDED, 9, 2), (DIST_ZO, 0x7F, 1), (DIST_HWT, max(1, n // 8), 1)):
+        for first, stride in ((100, 1), (5, 3)):
+            got = e.to_host(e.sample_seq(e.empty(batch), dist, key, first, stride, param0=p0, param1=p1))
+            for b in range(batch):
+                one = e.to_host(e.sample(e.empty(1), dist, key, stream_id=first + b * stride, param0=p0, param1=p1))
+                assert np.array_equal(got[b:b + 1], one), (dist, first, stride, b)
+    if lb == 16:
+        return
+    for sigma, sec in ((3.19, 128), (20.0, 64)):
+        g = e.gauss_create(sigma, security=sec, samples=n)
+        got = e.to_host(e.sample_gauss_seq(e.empty(batch), g, key, 40, 2, amplifier=2))
+        for b in range(batch):
+            one = e.to_host(e.sample_gauss(e.empty(1), g, key, stream_id=40 + 2 * b, amplifier=2))
+            assert np.array_equal(got[b:b + 1], one), (sigma, b)
+        e.gauss_destroy(g)
+
+
+@pytest.mark.parametrize("lb,n,m", [(64, 4096, 4), (32, 1024, 2), (16, 128, 1), (64, 8, 3)])
+def test_strided_expression_batches(lb, n, m, oracle_factory, engine_factory):
+    """nflhip_eval_strided_dev: dense, shared (stride 0) and interleaved (stride 2) operands in one launch, against the
+    dense evaluation of the gathered operands."""
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    k = 6
+    u = e.to_device(o.fill_uniform(k, SEED, 0))
+    key = e.to_device(o.fill_uniform(1, SEED + 1, 0))
+    inter = e.to_device(o.fill_uniform(2 * k, SEED + 2, 1))          # e1_0, e2_0, e1_1, e2_1, ...
+    out = e.empty(2 * k)
+    out.zero_()
+    prog = [0, 1, 0x12, 2, 0x10]                                       # u * key + e
+    e.eval_strided(prog, [u, key, inter], [1, 0, 2], out, out_stride=2, batch=k)
+    e.eval_strided(prog, [u, key, inter[1:]], [1, 0, 2], out[1:], out_stride=2, batch=k)
+    dense_key = key.expand(k, -1, -1).contiguous()
+    want1 = e.to_host(e.eval(prog, [u, dense_key, inter[0::2].contiguous()]))
+    want2 = e.to_host(e.eval(prog, [u, dense_key, inter[1::2].contiguous()]))
+    got = e.to_host(out)
+    assert np.array_equal(got[0::2], want1) and np.array_equal(got[1::2], want2)
+    # aliasing: in place on the interleaved operand
+    e.eval_strided(prog, [u, key, inter], [1, 0, 2], inter, out_stride=2, batch=k)
+    assert np.array_equal(e.to_host(inter)[0::2], want1)
