@@ -76,6 +76,7 @@
 #include <strings.h>
 #include <tuple>
 #include <type_traits>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -255,11 +256,20 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   nflhip_ctx *ctx;
   void *stream;
   std::mutex mu;
-  std::vector<void *> pool, slabs;
   static constexpr size_t poly_bytes = Degree * NbModuli * sizeof(T);
   static constexpr size_t chunk_bytes = (poly_bytes + 255) / 256 * 256;          // device buffers are 256-byte aligned
-  static constexpr size_t slab_chunks = chunk_bytes >= (size_t(64) << 20) ? 1 : (size_t(64) << 20) / chunk_bytes > 1024 ? 1024 : (size_t(64) << 20) / chunk_bytes;
-  context() : ctx(nullptr), stream(nullptr) {
+  // Device buffers of the resident handles: slabs (256 MiB first, doubling up to 2 GiB -- the device has 288 GB) carved
+  // into polynomial-sized chunks.  A slab hands out fresh chunks in address order (consecutive acquisitions are
+  // CONTIGUOUS, which is what lets deferred per-polynomial operations run as dense batches), keeps the chunks it gets
+  // back on a free list for single acquisitions, and starts over once every chunk is back.
+  struct slab {
+    char *base;
+    size_t chunks, bump, live;
+    std::vector<void *> free;
+  };
+  std::map<char *, slab> slabs;
+  size_t next_slab_bytes;
+  context() : ctx(nullptr), stream(nullptr), next_slab_bytes(size_t(256) << 20) {
     static_assert(NbModuli <= params<T>::kMaxNbModuli, "not enough moduli of this size (params.hpp)");
     static_assert(Degree <= params<T>::kMaxPolyDegree, "degree is not lower or equal than kMaxPolyDegree");
     int rc = nflhip_ctx_create(&ctx, 0, int(sizeof(T) * 8), Degree, NbModuli, params<T>::P, params<T>::primitive_roots,
@@ -275,7 +285,7 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   ~context() {
     alive() = false;
     nflhip_stream_sync(ctx, stream);
-    for (void *p : slabs) nflhip_free(ctx, p);
+    for (auto &kv : slabs) nflhip_free(ctx, kv.first);
     nflhip_stream_destroy(ctx, stream);
     nflhip_ctx_destroy(ctx);
   }
@@ -291,26 +301,78 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   }
   static nflhip_ctx *get() { return inst().ctx; }
   static void *queue() { return inst().stream; }
+
+  slab &grow(size_t min_chunks) {
+    size_t bytes = next_slab_bytes;
+    while (bytes / chunk_bytes < min_chunks) bytes *= 2;
+    if (next_slab_bytes < (size_t(2) << 30)) next_slab_bytes *= 2;
+    const size_t n = bytes / chunk_bytes ? bytes / chunk_bytes : 1;
+    void *mem = nullptr;
+    check(ctx, nflhip_malloc(ctx, &mem, n * chunk_bytes), "device allocation");
+    slab &sl = slabs[static_cast<char *>(mem)];
+    sl.base = static_cast<char *>(mem);
+    sl.chunks = n;
+    sl.bump = sl.live = 0;
+    return sl;
+  }
+  // `cnt` buffers, as contiguous as the slabs allow (fresh space first; recycled chunks only when no slab has room)
+  void acquire_many_locked(size_t cnt, void **out) {
+    size_t got = 0;
+    while (got < cnt) {
+      slab *best = nullptr;
+      for (auto &kv : slabs)
+        if (kv.second.bump < kv.second.chunks && (!best || kv.second.chunks - kv.second.bump > best->chunks - best->bump)) best = &kv.second;
+      if (!best) {
+        for (auto &kv : slabs) {  // recycle before growing without bound
+          slab &sl = kv.second;
+          while (got < cnt && !sl.free.empty()) {
+            out[got++] = sl.free.back();
+            sl.free.pop_back();
+            ++sl.live;
+          }
+        }
+        if (got == cnt) return;
+        best = &grow(cnt - got);
+      }
+      while (got < cnt && best->bump < best->chunks) {
+        out[got++] = best->base + best->bump++ * chunk_bytes;
+        ++best->live;
+      }
+    }
+  }
+  static void acquire_many(size_t cnt, void **out) {
+    context &c = inst();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.acquire_many_locked(cnt, out);
+  }
   static void *acquire() {
     context &c = inst();
     std::lock_guard<std::mutex> lk(c.mu);
-    if (c.pool.empty()) {
-      // a slab of up to 64 MiB, carved into polynomial-sized buffers: a hipMalloc per handle (~100 us) would dwarf the
-      // kernels a handle is used by.  Slabs live as long as the context.
-      void *slab = nullptr;
-      check(c.ctx, nflhip_malloc(c.ctx, &slab, chunk_bytes * slab_chunks), "device allocation");
-      c.slabs.push_back(slab);
-      for (size_t k = slab_chunks; k-- > 0;) c.pool.push_back(static_cast<char *>(slab) + k * chunk_bytes);
-    }
-    void *p = c.pool.back();
-    c.pool.pop_back();
+    for (auto &kv : c.slabs)
+      if (!kv.second.free.empty()) {
+        void *p = kv.second.free.back();
+        kv.second.free.pop_back();
+        ++kv.second.live;
+        return p;
+      }
+    void *p = nullptr;
+    c.acquire_many_locked(1, &p);
     return p;
   }
   static void release(void *p) {
     if (!p || !alive()) return;  // (after teardown the runtime reclaims it)
     context &c = inst();
     std::lock_guard<std::mutex> lk(c.mu);
-    c.pool.push_back(p);  // stream-ordered reuse: every consumer of these buffers runs on `stream`
+    auto it = c.slabs.upper_bound(static_cast<char *>(p));
+    if (it == c.slabs.begin()) return;
+    slab &sl = (--it)->second;
+    // stream-ordered reuse: every consumer of these buffers runs on `stream`
+    if (--sl.live == 0) {
+      sl.bump = 0;
+      sl.free.clear();
+    } else {
+      sl.free.push_back(p);
+    }
   }
 };
 
@@ -324,6 +386,10 @@ inline uint64_t splitmix64_at(uint64_t seed, int operand, uint64_t g) {
 }
 
 }  // namespace detail
+
+/* deferred execution of operations on resident poly_p handles (see detail::lazy): on by default; switching it off makes
+ * every operation launch when it is called (flush the ring types in use first: poly_p<...>::flush()) */
+inline void set_deferred(bool on);
 
 /* pin the sampler state: `key` (32 bytes) and the id of the next keystream -- reproducible runs */
 inline void set_sampler_key(const unsigned char key[32], uint64_t next_stream = 0) {
@@ -409,6 +475,10 @@ template <class in_class, class out_class, unsigned _lu_depth> struct gaussian {
 
 template <class T, size_t Degree, size_t NbModuli> class poly;
 template <class T, size_t Degree, size_t NbModuli> class poly_p;
+namespace detail {
+inline std::atomic<bool> &deferred_flag();
+}
+inline void set_deferred(bool on) { detail::deferred_flag().store(on); }
 namespace tests {
 template <class P> class poly_tests_proxy;  // (poly.hpp:69-76) defined by the caller's test code, befriended below
 }
@@ -420,20 +490,27 @@ static constexpr int dist_flags = NFLHIP_DIST_REFERENCE_WORDS;
 static constexpr int dist_flags = 0;
 #endif
 
+template <class P> struct lazy;
+
 // The shared payload of a poly_p handle (poly_p.hpp:11-204 keeps a std::shared_ptr<poly>): one polynomial that lives
 // in HBM (`dev`), on the host (`host`), or both.  host_valid / dev_valid say which image holds the current value;
 // neither valid = the zero polynomial (what poly_p() is) with nothing allocated yet.  Every device-side operation is
 // enqueued on the context's stream, so the only synchronisation points are the device-to-host copies below.
-template <class P> struct payload {
+// `queued`: the value is the result of operations that are still in the deferred queue (lazy<P> below); every access
+// other than enqueueing more work runs the queue first (pending()).
+template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   typedef typename P::value_type T;
   typedef context<T, P::degree, P::nmoduli> ctx_t;
   static constexpr size_t bytes = sizeof(T) * P::degree * P::nmoduli;
   P *host;
   void *dev;
-  bool host_valid, dev_valid;
+  bool host_valid, dev_valid, queued;
+  long qrefs;  // references held by deferred operations (not handles): copy-on-write decisions look past them
 
-  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false) {}
-  payload(const payload &o) : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false) {
+  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), qrefs(0) {}
+  payload(const payload &o) : std::enable_shared_from_this<payload<P>>(), host(nullptr), dev(nullptr), host_valid(false),
+                              dev_valid(false), queued(false), qrefs(0) {
+    pending();
     if (o.dev_valid) {  // stays on the device
       check(ctx(), nflhip_memcpy_d2d(ctx(), dev_wo(), o.dev, bytes, ctx_t::queue()), "poly_p copy");
     } else if (o.host_valid) {
@@ -451,6 +528,7 @@ template <class P> struct payload {
     ctx_t::release(dev);
   }
   static nflhip_ctx *ctx() { return ctx_t::get(); }
+  static void pending() { lazy<P>::inst().flush(); }  // run whatever is still deferred
 
   void alloc_host() {
     if (host) return;
@@ -460,6 +538,7 @@ template <class P> struct payload {
   }
   // the host image, current
   void to_host() {
+    pending();
     alloc_host();
     if (host_valid) return;
     if (dev_valid) {
@@ -480,6 +559,7 @@ template <class P> struct payload {
     return *host;
   }
   P &host_wo() {  // about to be overwritten entirely on the host
+    pending();
     alloc_host();
     host_valid = true;
     dev_valid = false;
@@ -487,6 +567,11 @@ template <class P> struct payload {
   }
   // the device image, current
   const void *dev_ro() {
+    pending();
+    return dev_ro_nf();
+  }
+  const void *dev_ro_nf() {  // (the queue's own form: never runs the queue)
+    if (queued) return dev;  // produced by a deferred operation; its buffer is assigned when the queue runs
     if (!dev) dev = ctx_t::acquire();
     if (!dev_valid) {
       if (host_valid) check(ctx(), nflhip_memcpy_h2d(ctx(), dev, host->cdata(), bytes, ctx_t::queue()), "poly_p upload");
@@ -501,10 +586,304 @@ template <class P> struct payload {
     return dev;
   }
   void *dev_wo() {  // about to be overwritten entirely on the device
+    pending();
     if (!dev) dev = ctx_t::acquire();
     dev_valid = true;
     host_valid = false;
     return dev;
+  }
+};
+
+// ---------------------------------------------------------------- deferred execution of per-polynomial operations
+// One polynomial is 4 workgroups of work: a kernel launched for it runs for ~15 us on an otherwise empty GPU, and code
+// written against the reference issues exactly such operations in loops (tests/nfllib_demo_main_op.cpp:26-58: three
+// Gaussian polynomials, three transforms and two fused multiply-adds per encryption, one polynomial at a time).  So
+// operations on resident handles are not launched when they are called: they are appended to a per-ring queue, and
+// when a value is needed on the host (or the queue is long) the queue runs as a few BATCHED launches:
+//   * operations are levelled by their data dependencies (read-after-write, write-after-read, write-after-write on
+//     the shared payloads), so everything inside a level is independent;
+//   * inside a level, operations with the same signature (same expression program, same distribution and parameters,
+//     same transform) form a group; operands that are the same polynomial throughout (a key) split groups;
+//   * results that have no buffer yet get CONSECUTIVE buffers (context::acquire_many), so a loop's temporaries form
+//     dense arrays; a group is cut into runs whose operands advance by constant strides and every run is ONE launch of
+//     the batch entry points (nflhip_eval_strided_dev, nflhip_sample[_gauss]_seq_dev, nflhip_ntt_fwd/inv_dev).
+// Results are bit-identical to immediate execution (the random constructors keep the stream id they took when they
+// were called).  nfl::set_deferred(false) (or -DNFL_HIP_EAGER) launches every operation at once instead.
+inline std::atomic<bool> &deferred_flag() {
+#ifdef NFL_HIP_EAGER
+  static std::atomic<bool> f(false);
+#else
+  static std::atomic<bool> f(true);
+#endif
+  return f;
+}
+
+template <class P> struct lazy {
+  typedef payload<P> pay_t;
+  typedef typename pay_t::ctx_t ctx_t;
+  typedef typename P::value_type T;
+  typedef std::shared_ptr<pay_t> ptr_t;
+  enum kind_t { K_EVAL = 0, K_NTT_FWD, K_NTT_INV, K_SAMPLE, K_GAUSS, K_FILL };
+  struct op {
+    int kind;
+    ptr_t out;
+    ptr_t in[NFLHIP_EXPR_MAX_OPERANDS];
+    int nin;
+    unsigned char code[NFLHIP_EXPR_MAX_LEN];
+    int len;
+    int dist;
+    uint64_t p0, p1, sid;
+    const nflhip_gauss *tab;
+    op() : kind(0), nin(0), len(0), dist(0), p0(0), p1(0), sid(0), tab(nullptr) {}
+  };
+  std::recursive_mutex mu;
+  std::vector<op> q;
+  size_t launches, coalesced;  // statistics: launches issued / operations they carried
+  static constexpr size_t kMaxQueue = 16384;
+
+  lazy() : launches(0), coalesced(0) { ctx_t::inst(); }  // (the context is constructed first, so it is destroyed last)
+  static lazy &inst() {
+    static lazy l;
+    return l;
+  }
+  // whether this ring's operations can be deferred at all: dense chunks, vectors of 16 bytes, sequence samplers
+  static bool usable() {
+    return deferred_flag().load(std::memory_order_relaxed) && ctx_t::chunk_bytes == ctx_t::poly_bytes && P::degree >= 8 &&
+           P::degree * sizeof(T) >= 16;
+  }
+  // inputs must hold a device value (or be produced by the queue) before the operation is recorded
+  void push(op &&o) {
+    std::lock_guard<std::recursive_mutex> lk(mu);
+    for (int j = 0; j < o.nin; ++j) o.in[j]->dev_ro_nf();
+    const bool in_place = o.kind == K_NTT_FWD || o.kind == K_NTT_INV;
+    if (in_place) o.out->dev_ro_nf();
+    bool reads_out = in_place;
+    for (int j = 0; j < o.nin; ++j) reads_out |= o.in[j].get() == o.out.get();
+    (void)reads_out;
+    ++o.out->qrefs;
+    for (int j = 0; j < o.nin; ++j) ++o.in[j]->qrefs;
+    o.out->queued = true;
+    o.out->dev_valid = true;
+    o.out->host_valid = false;
+    q.push_back(std::move(o));
+    if (q.size() >= kMaxQueue) flush();
+  }
+  void flush() {
+    std::lock_guard<std::recursive_mutex> lk(mu);
+    if (q.empty()) return;
+    std::vector<op> ops;
+    ops.swap(q);
+    struct done_guard {  // whatever happens, the payloads stop claiming a queued value
+      std::vector<op> &o;
+      ~done_guard() {
+        for (auto &x : o) {
+          x.out->queued = false;
+          --x.out->qrefs;
+          for (int j = 0; j < x.nin; ++j) --x.in[j]->qrefs;
+        }
+      }
+    } guard{ops};
+    // ---- 1. levels
+    std::unordered_map<const pay_t *, int> wl, rl;
+    wl.reserve(ops.size() * 2);
+    rl.reserve(ops.size() * 4);
+    std::vector<int> lvl(ops.size(), 0);
+    int nlev = 0;
+    for (size_t i = 0; i < ops.size(); ++i) {
+      op &o = ops[i];
+      int L = 0;
+      for (int j = 0; j < o.nin; ++j) {
+        auto it = wl.find(o.in[j].get());
+        if (it != wl.end()) L = std::max(L, it->second + 1);
+      }
+      auto w = wl.find(o.out.get());
+      if (w != wl.end()) L = std::max(L, w->second + 1);
+      auto r = rl.find(o.out.get());
+      if (r != rl.end()) L = std::max(L, r->second + 1);
+      lvl[i] = L;
+      wl[o.out.get()] = L;
+      for (int j = 0; j < o.nin; ++j) {
+        int &x = rl.insert(std::make_pair(o.in[j].get(), -1)).first->second;
+        x = std::max(x, L);
+      }
+      if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) {
+        int &x = rl.insert(std::make_pair(o.out.get(), -1)).first->second;
+        x = std::max(x, L);
+      }
+      nlev = std::max(nlev, L + 1);
+    }
+    // ---- 2. groups: (level, signature) -> operations in program order
+    std::unordered_map<std::string, std::vector<size_t>> by_sig;
+    std::string sig;
+    for (size_t i = 0; i < ops.size(); ++i) {
+      const op &o = ops[i];
+      sig.assign(reinterpret_cast<const char *>(&lvl[i]), sizeof(int));
+      sig.push_back(char('A' + o.kind));
+      if (o.kind == K_EVAL) {
+        sig.append(reinterpret_cast<const char *>(o.code), size_t(o.len));
+        sig.push_back(char(o.nin));
+      } else if (o.kind == K_SAMPLE || o.kind == K_GAUSS || o.kind == K_FILL) {
+        sig.append(reinterpret_cast<const char *>(&o.dist), sizeof(o.dist));
+        sig.append(reinterpret_cast<const char *>(&o.p0), sizeof(o.p0));
+        sig.append(reinterpret_cast<const char *>(&o.p1), sizeof(o.p1));
+        sig.append(reinterpret_cast<const char *>(&o.tab), sizeof(o.tab));
+        if (o.kind == K_FILL) sig.append(reinterpret_cast<const char *>(&o.sid), sizeof(o.sid));
+      }
+      by_sig[sig].push_back(i);
+    }
+    std::map<std::pair<int, std::string>, std::vector<size_t>> groups;  // few entries: ordered by level
+    for (auto &kv : by_sig) groups[std::make_pair(lvl[kv.second[0]], kv.first)].swap(kv.second);
+    nflhip_ctx *ctx = ctx_t::get();
+    void *st = ctx_t::queue();
+    detail::sampler &smp = detail::sampler::get();
+    static const bool trace = getenv("NFL_HIP_TRACE_DEFERRED") != nullptr;
+    for (auto &kv : groups) {
+      std::vector<size_t> &idx = kv.second;
+      const int kind = ops[idx[0]].kind;
+      const size_t launches_before = launches;
+      struct tracer {
+        bool on; int level, kind; size_t n; const size_t &now; size_t before;
+        ~tracer() { if (on) std::fprintf(stderr, "nfl(hip) deferred: level %d kind %d: %zu operations -> %zu launches\n", level, kind, n, now - before); }
+      } tr{trace, kv.first.first, kind, idx.size(), launches, launches_before};
+      if ((kind == K_SAMPLE || kind == K_GAUSS) && idx.size() >= 4) {
+        // A loop body that draws several polynomials of one distribution (e1, e2 of an encryption) interleaves their
+        // stream ids: k+1, k+2, k+4, k+5, ...  Find the period of the id differences and regroup the operations into
+        // that many arithmetic progressions, each of which then gets its own dense array of buffers and is one launch.
+        for (size_t period = 2; period <= 8 && period * 2 <= idx.size(); ++period) {
+          bool periodic = true, constant = true;
+          for (size_t i = 0; i + 1 < idx.size() && periodic; ++i) {
+            const uint64_t d = ops[idx[i + 1]].sid - ops[idx[i]].sid;
+            if (i + 1 + period < idx.size()) periodic = d == ops[idx[i + 1 + period]].sid - ops[idx[i + period]].sid;
+            constant &= d == ops[idx[1]].sid - ops[idx[0]].sid;
+          }
+          if (constant) break;
+          if (periodic) {
+            std::vector<size_t> re;
+            for (size_t r = 0; r < period; ++r)
+              for (size_t i = r; i < idx.size(); i += period) re.push_back(idx[i]);
+            idx.swap(re);
+            break;
+          }
+        }
+      }
+      // ---- 3. buffers for results that have none yet: consecutive, in program order
+      std::vector<size_t> need;
+      for (size_t i : idx)
+        if (!ops[i].out->dev) need.push_back(i);
+      if (!need.empty()) {
+        std::vector<void *> bufs(need.size());
+        ctx_t::acquire_many(need.size(), bufs.data());
+        for (size_t k = 0; k < need.size(); ++k) ops[need[k]].out->dev = bufs[k];
+      }
+      if (kind == K_NTT_FWD || kind == K_NTT_INV) {
+        // in place, mutually independent: any order -- by address, so that neighbours become one dense batch
+        std::vector<char *> ptr;
+        for (size_t i : idx) ptr.push_back(static_cast<char *>(ops[i].out->dev));
+        std::sort(ptr.begin(), ptr.end());
+        for (size_t a = 0; a < ptr.size();) {
+          size_t b = a + 1;
+          while (b < ptr.size() && ptr[b] == ptr[b - 1] + ctx_t::chunk_bytes) ++b;
+          check(ctx, kind == K_NTT_FWD ? nflhip_ntt_fwd_dev(ctx, ptr[a], b - a, st) : nflhip_ntt_inv_dev(ctx, ptr[a], b - a, st),
+                "deferred transform");
+          ++launches;
+          coalesced += b - a;
+          a = b;
+        }
+        continue;
+      }
+      if (kind == K_FILL) {
+        for (size_t i : idx) {
+          check(ctx, nflhip_fill_uniform_dev(ctx, ops[i].out->dev, 0, 1, ops[i].sid, 0, st), "deferred set(uniform)");
+          ++launches;
+          ++coalesced;
+        }
+        continue;
+      }
+      if (kind == K_SAMPLE || kind == K_GAUSS) {
+        // program order; a run = consecutive buffers + stream ids in arithmetic progression
+        for (size_t a = 0; a < idx.size();) {
+          const op &o0 = ops[idx[a]];
+          size_t b = a + 1;
+          uint64_t stride = 0;
+          while (b < idx.size()) {
+            const op &prev = ops[idx[b - 1]], &cur = ops[idx[b]];
+            if (static_cast<char *>(cur.out->dev) != static_cast<char *>(prev.out->dev) + ctx_t::chunk_bytes) break;
+            const uint64_t d = cur.sid - prev.sid;
+            if (b == a + 1) stride = d;
+            else if (d != stride) break;
+            ++b;
+          }
+          const size_t cnt = b - a;
+          if (kind == K_SAMPLE)
+            check(ctx, cnt == 1 ? nflhip_sample_dev(ctx, o0.out->dev, 0, 1, o0.dist, o0.p0, o0.p1, smp.key, o0.sid, st)
+                                : nflhip_sample_seq_dev(ctx, o0.out->dev, cnt, o0.dist, o0.p0, o0.p1, smp.key, o0.sid, stride, st),
+                  "deferred random constructor");
+          else
+            check(ctx, cnt == 1 ? nflhip_sample_gauss_dev(ctx, o0.out->dev, 0, 1, o0.tab, o0.p1, smp.key, o0.sid, st)
+                                : nflhip_sample_gauss_seq_dev(ctx, o0.out->dev, cnt, o0.tab, o0.p1, smp.key, o0.sid, stride, st),
+                  "deferred set(gaussian)");
+          ++launches;
+          coalesced += cnt;
+          a = b;
+        }
+        continue;
+      }
+      // ---- K_EVAL: operands that are one polynomial for (almost) the whole group split it; then stride runs
+      const int nin = ops[idx[0]].nin;
+      std::map<std::vector<const pay_t *>, std::vector<size_t>> sub;
+      {
+        std::vector<bool> keyslot(size_t(nin), false);
+        for (int j = 0; j < nin; ++j) {
+          std::map<const pay_t *, size_t> seen;
+          for (size_t i : idx)
+            if (seen.size() <= idx.size() / 8 + 1) ++seen[ops[i].in[j].get()];
+          keyslot[size_t(j)] = idx.size() >= 2 && seen.size() <= idx.size() / 8 + 1 && seen.size() < idx.size();
+        }
+        for (size_t i : idx) {
+          std::vector<const pay_t *> k;
+          for (int j = 0; j < nin; ++j)
+            if (keyslot[size_t(j)]) k.push_back(ops[i].in[j].get());
+          sub[k].push_back(i);
+        }
+      }
+      for (auto &sv : sub) {
+        std::vector<size_t> &sidx = sv.second;
+        std::stable_sort(sidx.begin(), sidx.end(), [&](size_t x, size_t y) { return ops[x].out->dev < ops[y].out->dev; });
+        for (size_t a = 0; a < sidx.size();) {
+          const op &o0 = ops[sidx[a]];
+          size_t stride[NFLHIP_EXPR_MAX_OPERANDS], ostride = 1;
+          size_t b = a + 1;
+          while (b < sidx.size()) {
+            const op &prev = ops[sidx[b - 1]], &cur = ops[sidx[b]];
+            bool ok = true;
+            const ptrdiff_t od = static_cast<char *>(cur.out->dev) - static_cast<char *>(prev.out->dev);
+            if (od <= 0 || od % ptrdiff_t(ctx_t::chunk_bytes)) break;
+            if (b == a + 1) ostride = size_t(od) / ctx_t::chunk_bytes;
+            else if (size_t(od) != ostride * ctx_t::chunk_bytes) break;
+            for (int j = 0; j < nin && ok; ++j) {
+              const ptrdiff_t d = static_cast<char *>(cur.in[j]->dev) - static_cast<char *>(prev.in[j]->dev);
+              if (d < 0 || d % ptrdiff_t(ctx_t::chunk_bytes)) ok = false;
+              else if (b == a + 1) stride[j] = size_t(d) / ctx_t::chunk_bytes;
+              else if (size_t(d) != stride[j] * ctx_t::chunk_bytes) ok = false;
+            }
+            if (!ok) break;
+            ++b;
+          }
+          const size_t cnt = b - a;
+          const void *d[NFLHIP_EXPR_MAX_OPERANDS];
+          for (int j = 0; j < nin; ++j) d[j] = o0.in[j]->dev;
+          if (cnt == 1) {
+            check(ctx, nflhip_eval_dev(ctx, o0.out->dev, d, size_t(nin), o0.code, size_t(o0.len), 1, st), "deferred operator=(expr)");
+          } else {
+            check(ctx, nflhip_eval_strided_dev(ctx, o0.out->dev, ostride, d, stride, size_t(nin), o0.code, size_t(o0.len), cnt, st),
+                  "deferred operator=(expr)");
+          }
+          ++launches;
+          coalesced += cnt;
+          a = b;
+        }
+      }
+    }
   }
 };
 }  // namespace detail
@@ -614,6 +993,18 @@ template <class Op, class... Args> struct expr {
     if (!pr.ok || opcode<Op>::value < 0) return false;
     typedef typename payload_type::ctx_t ctx_t;
     if (degree * sizeof(value_type) < 16) return false;  // (rows shorter than one 16-byte vector: nflhip_eval declines)
+    typedef detail::lazy<poly_type> lazy_t;
+    if (lazy_t::usable() && pr.nhandles == pr.noperands) {  // every leaf is a handle: record, do not launch
+      typename lazy_t::op o;
+      o.kind = lazy_t::K_EVAL;
+      o.out = out.shared_from_this();
+      o.nin = int(pr.noperands);
+      for (size_t k = 0; k < pr.noperands; ++k) o.in[k] = static_cast<payload_type *>(pr.pay[k])->shared_from_this();
+      o.len = int(pr.len);
+      std::memcpy(o.code, pr.code, pr.len);
+      lazy_t::inst().push(std::move(o));
+      return true;
+    }
     nflhip_ctx *ctx = ctx_t::get();
     const void *d[NFLHIP_EXPR_MAX_OPERANDS];
     void *staged[NFLHIP_EXPR_MAX_OPERANDS];
@@ -1243,21 +1634,58 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     p->host_valid = true;
     return p;
   }
+  // shared with another HANDLE (references held by deferred operations do not count)
+  static bool shared(const ptr_type &p, long extra = 0) { return p.use_count() - p->qrefs - extra > 1; }
   void detach() const {
-    if (!_p.unique()) _p = std::make_shared<payload_type>(*_p);  // (device-to-device when the value lives in HBM)
+    if (shared(_p)) _p = std::make_shared<payload_type>(*_p);  // (device-to-device when the value lives in HBM)
   }
   void detach_for_overwrite() {
-    if (!_p.unique()) _p = fresh();
+    if (shared(_p)) _p = fresh();
   }
 
   // ---- device-side samplers (same keystream discipline as poly::sample: a fresh stream id per call)
+  typedef detail::lazy<poly_type> lazy_t;
+  static void check_sample_args(int dist, uint64_t p0, uint64_t p1, const nflhip_gauss *tab) {
+    // a deferred constructor must still throw where it is written (core.hpp:205-210): validate with an empty batch
+    const unsigned char zero[32] = {0};
+    if (tab) detail::check(ctx_t::get(), nflhip_sample_gauss_dev(ctx_t::get(), nullptr, 0, 0, tab, p1, zero, 0, ctx_t::queue()), "set(gaussian)");
+    else detail::check(ctx_t::get(), nflhip_sample_dev(ctx_t::get(), nullptr, 0, 0, dist, p0, p1, zero, 0, ctx_t::queue()), "random constructor");
+  }
+  static bool defer_sample(payload_type &p, int kind, int dist, uint64_t p0, uint64_t p1, uint64_t sid, const nflhip_gauss *tab) {
+    if (!lazy_t::usable()) return false;
+    if (kind != lazy_t::K_FILL) {
+      // (validated once per distinct argument tuple in a row: loops repeat the same constructor)
+      struct last_t { int dist; uint64_t p0, p1; const nflhip_gauss *tab; bool any; };
+      static thread_local last_t last = {0, 0, 0, nullptr, false};
+      if (!last.any || last.dist != dist || last.p0 != p0 || last.p1 != p1 || last.tab != tab) {
+        check_sample_args(dist, p0, p1, tab);
+        last = last_t{dist, p0, p1, tab, true};
+      }
+    }
+    typename lazy_t::op o;
+    o.kind = kind;
+    o.out = p.shared_from_this();
+    o.dist = dist;
+    o.p0 = p0;
+    o.p1 = p1;
+    o.sid = sid;
+    o.tab = tab;
+    lazy_t::inst().push(std::move(o));
+    return true;
+  }
   static void sample_dist(payload_type &p, int dist, uint64_t p0, uint64_t p1, const char *what) {
     detail::sampler &s = detail::sampler::get();
-    detail::check(ctx_t::get(), nflhip_sample_dev(ctx_t::get(), p.dev_wo(), 0, 1, dist, p0, p1, s.key, s.next++, ctx_t::queue()), what);
+    const uint64_t sid = s.next++;
+    if (defer_sample(p, lazy_t::K_SAMPLE, dist, p0, p1, sid, nullptr)) return;
+    detail::check(ctx_t::get(), nflhip_sample_dev(ctx_t::get(), p.dev_wo(), 0, 1, dist, p0, p1, s.key, sid, ctx_t::queue()), what);
   }
   static void sample_into(payload_type &p, uniform const &u) {
-    if (u.seeded) detail::check(ctx_t::get(), nflhip_fill_uniform_dev(ctx_t::get(), p.dev_wo(), 0, 1, u.seed, 0, ctx_t::queue()), "set(uniform)");
-    else sample_dist(p, NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+    if (u.seeded) {
+      if (defer_sample(p, lazy_t::K_FILL, 0, 0, 0, u.seed, nullptr)) return;
+      detail::check(ctx_t::get(), nflhip_fill_uniform_dev(ctx_t::get(), p.dev_wo(), 0, 1, u.seed, 0, ctx_t::queue()), "set(uniform)");
+    } else {
+      sample_dist(p, NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+    }
   }
   static void sample_into(payload_type &p, non_uniform const &m) { sample_dist(p, NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
   static void sample_into(payload_type &p, ZO_dist const &m) { sample_dist(p, NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)"); }
@@ -1265,7 +1693,9 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   template <class in_class, unsigned _lu_depth> static void sample_into(payload_type &p, gaussian<in_class, T, _lu_depth> const &m) {
     detail::sampler &s = detail::sampler::get();
     const nflhip_gauss *tab = m.fg_prng->table(ctx_t::get());
-    detail::check(ctx_t::get(), nflhip_sample_gauss_dev(ctx_t::get(), p.dev_wo(), 0, 1, tab, m.amplifier, s.key, s.next++, ctx_t::queue()),
+    const uint64_t sid = s.next++;
+    if (defer_sample(p, lazy_t::K_GAUSS, 0, 0, m.amplifier, sid, tab)) return;
+    detail::check(ctx_t::get(), nflhip_sample_gauss_dev(ctx_t::get(), p.dev_wo(), 0, 1, tab, m.amplifier, s.key, sid, ctx_t::queue()),
                   "set(gaussian)");
   }
   // THE evaluation point of an expression tree over handles (core.hpp:24-37): one fused device pass, result resident.
@@ -1275,7 +1705,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     ops::program pr;
     e.lower(pr);
     ptr_type keep = p;  // the old payload stays alive while the kernel reads it
-    if (keep.use_count() > 2) p = fresh();  // shared with another handle
+    if (shared(p, 1)) p = fresh();  // shared with another handle (`keep` is the extra reference)
     if (ops::expr<Op, A...>::run_resident(pr, *p)) return;
     // through the host: node by node, or trees the fused program cannot hold
     poly_type *tmp = poly_type::make_temp();
@@ -1307,7 +1737,14 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   void *payload_id() const { return _p.get(); }  // (engine plumbing: identity of the shared payload)
   bool resident() const { return _p->dev_valid; }  // the current value is in HBM (no upload needed by the next device op)
   // wait for every enqueued operation of this ring type (results are otherwise only awaited when read on the host)
-  static void synchronize() { detail::check(ctx_t::get(), nflhip_stream_sync(ctx_t::get(), ctx_t::queue()), "synchronize"); }
+  static void synchronize() {
+    lazy_t::inst().flush();
+    detail::check(ctx_t::get(), nflhip_stream_sync(ctx_t::get(), ctx_t::queue()), "synchronize");
+  }
+  // run the deferred operations of this ring type now (without waiting for the device); statistics of the queue so far
+  static void flush() { lazy_t::inst().flush(); }
+  static size_t deferred_launches() { return lazy_t::inst().launches; }
+  static size_t deferred_operations() { return lazy_t::inst().coalesced; }
 
   template <class Op, class... A> poly_p &operator=(ops::expr<Op, A...> const &e) {
     assign_expr(_p, e);
@@ -1322,7 +1759,12 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     sample_into(*_p, m);
     return *this;
   }
-  template <class O> poly_p &operator=(O &&o) {
+  // (everything else goes through the host polynomial, as in the reference; the overloads above must win for rvalue
+  // expressions and tags, which a plain forwarding template would otherwise capture)
+  template <class O>
+  typename std::enable_if<!device_init<typename std::decay<O>::type>::value && !std::is_same<typename std::decay<O>::type, poly_p>::value,
+                          poly_p &>::type
+  operator=(O &&o) {
     poly_obj() = std::forward<O>(o);
     return *this;
   }
@@ -1351,14 +1793,25 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   static constexpr value_type get_modulus(size_t n) { return poly_type::get_modulus(n); }
 
   /* ntt stuff - public API (poly_p.hpp:141-142): in place in HBM */
-  void ntt_pow_phi() {
+  void ntt_pow_phi() { transform(lazy_t::K_NTT_FWD); }
+  void invntt_pow_invphi() { transform(lazy_t::K_NTT_INV); }
+
+ private:
+  void transform(int kind) {
     detach();
-    detail::check(ctx_t::get(), nflhip_ntt_fwd_dev(ctx_t::get(), _p->dev_rw(), 1, ctx_t::queue()), "ntt_pow_phi");
+    if (lazy_t::usable()) {
+      typename lazy_t::op o;
+      o.kind = kind;
+      o.out = _p;
+      lazy_t::inst().push(std::move(o));
+      return;
+    }
+    detail::check(ctx_t::get(), kind == lazy_t::K_NTT_FWD ? nflhip_ntt_fwd_dev(ctx_t::get(), _p->dev_rw(), 1, ctx_t::queue())
+                                                          : nflhip_ntt_inv_dev(ctx_t::get(), _p->dev_rw(), 1, ctx_t::queue()),
+                  kind == lazy_t::K_NTT_FWD ? "ntt_pow_phi" : "invntt_pow_invphi");
   }
-  void invntt_pow_invphi() {
-    detach();
-    detail::check(ctx_t::get(), nflhip_ntt_inv_dev(ctx_t::get(), _p->dev_rw(), 1, ctx_t::queue()), "invntt_pow_invphi");
-  }
+
+ public:
   void serialize_manually(std::ostream &os) { poly_obj().serialize_manually(os); }
   void deserialize_manually(std::istream &is) { poly_obj().deserialize_manually(is); }
   template <class Archive> void serialize(Archive &archive) { archive(poly_obj()); }

@@ -118,7 +118,7 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_residency() {
 
 // the reference's LWE demo with plain poly_p operators (tests/nfllib_demo_main_op.cpp:26-58, 260-332)
 template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *enc_per_s, double *dec_per_s, double *batch_enc_per_s,
-                                                                       double *batch_dec_per_s) {
+                                                                       double *batch_dec_per_s, size_t *launches, size_t *operations) {
   using poly_t = nfl::poly<T, Degree, NbModuli>;
   using poly_p = nfl::poly_p<T, Degree, NbModuli>;
   using G = nfl::gaussian<uint8_t, T, 2>;
@@ -145,6 +145,7 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *e
   };
   for (size_t i = 0; i < 8; i++) encrypt(resa[i], resb[i]);   // warm-up: tables, buffer pool
   poly_p::synchronize();
+  const size_t l0 = poly_p::deferred_launches(), o0 = poly_p::deferred_operations();
   auto t0 = std::chrono::steady_clock::now();
   for (size_t i = 0; i < REPS; i++) encrypt(resa[i], resb[i]);
   poly_p::synchronize();
@@ -153,6 +154,8 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *e
   for (size_t i = 0; i < REPS; i++) decrypt(dec[i], resa[i], resb[i]);
   poly_p::synchronize();
   auto t2 = std::chrono::steady_clock::now();
+  *launches = poly_p::deferred_launches() - l0;
+  *operations = poly_p::deferred_operations() - o0;
   *enc_per_s = REPS / std::chrono::duration<double>(t1 - t0).count();
   *dec_per_s = REPS / std::chrono::duration<double>(t2 - t1).count();
   // the demo's own check: ciphertexts of 0 decrypt to even noise, so the parities sum to 0
@@ -205,9 +208,19 @@ int main() {
     if (!run_residency<uint32_t, 8, 2>()) return 1;      // rows shorter than a 16-byte vector: the host route
     if (!run_residency<uint64_t, 32768, 2>()) return 1;
     double e = 0, d = 0, be = 0, bd = 0;
-    if (!run_lwe<uint64_t, 4096, 4>(&e, &d, &be, &bd)) return 1;
+    size_t nl = 0, no = 0;
+    if (!run_lwe<uint64_t, 4096, 4>(&e, &d, &be, &bd, &nl, &no)) return 1;
+    // the same loops with every operation launched when it is called (no deferral): what a per-polynomial API costs
+    nfl::poly_p<uint64_t, 4096, 4>::synchronize();
+    nfl::set_deferred(false);
+    double ee = 0, ed = 0, x0 = 0, x1 = 0;
+    size_t y0 = 0, y1 = 0;
+    if (!run_lwe<uint64_t, 4096, 4>(&ee, &ed, &x0, &x1, &y0, &y1)) return 1;
+    nfl::set_deferred(true);
     std::printf("{\"lwe_u64_4096_4\": {\"poly_p_encryptions_per_s\": %.1f, \"poly_p_decryptions_per_s\": %.1f, "
-                "\"device_batch_encryptions_per_s\": %.1f, \"device_batch_decryptions_per_s\": %.1f}}\n", e, d, be, bd);
+                "\"device_batch_encryptions_per_s\": %.1f, \"device_batch_decryptions_per_s\": %.1f, "
+                "\"poly_p_eager_encryptions_per_s\": %.1f, \"poly_p_eager_decryptions_per_s\": %.1f, "
+                "\"deferred_operations\": %zu, \"launches_they_became\": %zu}}\n", e, d, be, bd, ee, ed, no, nl);
     std::printf("all checks passed\n");
     return 0;
   } catch (const std::exception &ex) {

@@ -56,4 +56,8 @@ def test_resident_poly_p_handles_and_the_lwe_demo_on_plain_operators():
     assert "all checks passed" in r.stdout
     rates = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["lwe_u64_4096_4"]
     assert rates["poly_p_encryptions_per_s"] > 0 and rates["device_batch_encryptions_per_s"] > 0
+    # deferred execution coalesces the loop's per-polynomial operations into a few dozen batched launches ...
+    assert rates["launches_they_became"] * 50 < rates["deferred_operations"]
+    # ... which is what makes the per-polynomial surface usable: an order of magnitude over launching every operation
+    assert rates["poly_p_encryptions_per_s"] > 8 * rates["poly_p_eager_encryptions_per_s"]
     print(rates)
