@@ -317,6 +317,10 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   }
   // `cnt` buffers, as contiguous as the slabs allow (fresh space first; recycled chunks only when no slab has room)
   void acquire_many_locked(size_t cnt, void **out) {
+    struct sorter {  // recycled chunks come back in release order: hand them out by address, neighbours together
+      void **o; size_t n;
+      ~sorter() { std::sort(o, o + n); }
+    } srt{out, cnt};
     size_t got = 0;
     while (got < cnt) {
       slab *best = nullptr;

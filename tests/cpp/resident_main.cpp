@@ -143,20 +143,26 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *e
     out = rb - ra * s;
     out.invntt_pow_invphi();
   };
-  for (size_t i = 0; i < 8; i++) encrypt(resa[i], resb[i]);   // warm-up: tables, buffer pool
+  // warm-up: tables, and one full round so that the buffer pool has its slabs -- the timed round is the steady state
+  // (results overwrite the previous round's, temporaries recycle the pool)
+  for (size_t i = 0; i < REPS; i++) encrypt(resa[i], resb[i]);
   poly_p::synchronize();
   const size_t l0 = poly_p::deferred_launches(), o0 = poly_p::deferred_operations();
   auto t0 = std::chrono::steady_clock::now();
   for (size_t i = 0; i < REPS; i++) encrypt(resa[i], resb[i]);
   poly_p::synchronize();
   auto t1 = std::chrono::steady_clock::now();
+  const double enc_s = std::chrono::duration<double>(t1 - t0).count();
+  *launches = poly_p::deferred_launches() - l0;
+  *operations = poly_p::deferred_operations() - o0;
   std::vector<poly_p> dec(REPS);
   for (size_t i = 0; i < REPS; i++) decrypt(dec[i], resa[i], resb[i]);
   poly_p::synchronize();
+  t1 = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < REPS; i++) decrypt(dec[i], resa[i], resb[i]);
+  poly_p::synchronize();
   auto t2 = std::chrono::steady_clock::now();
-  *launches = poly_p::deferred_launches() - l0;
-  *operations = poly_p::deferred_operations() - o0;
-  *enc_per_s = REPS / std::chrono::duration<double>(t1 - t0).count();
+  *enc_per_s = REPS / enc_s;
   *dec_per_s = REPS / std::chrono::duration<double>(t2 - t1).count();
   // the demo's own check: ciphertexts of 0 decrypt to even noise, so the parities sum to 0
   const T modulus = poly_t::get_modulus(0);
