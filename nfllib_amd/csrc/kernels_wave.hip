@@ -27,29 +27,71 @@ static constexpr int kSlabWords = 1088;  // LDS words per 1024 row words (paddin
 
 __device__ __forceinline__ u32 lazy2(u32 x, u32 p2) { return min(x, x - p2); }  // [0,4p) -> [0,2p)
 
-__device__ __forceinline__ void ct32(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2) {
+// 32-bit limbs: v_mad_u64_u32's low result dword is a*b + lo(c) whatever the high dwords hold, so
+//   x' = X + (y w - q p) = lo( y*w + ( q*(-p) + (X, *) ) )        two multiply-adds, seeded with X
+// and a Cooley-Tukey butterfly is 7 instructions (sub, min, mul_hi, mad, mad, lshl_add, sub) instead of 9, a
+// Gentleman-Sande one 8 (the product is seeded with a pair whose low dword is 0).  Same words as before.
+// The expressions are plain 64-bit C (the compiler schedules them like any instruction); what keeps it from narrowing
+// them back to 32-bit multiplies is that every result's HIGH dword is "used": it is threaded, at no instruction,
+// through a chain of empty asm statements (`tok`) that ends in one volatile consumer per pass.
+// NFLHIP_U32_MAD=0 compiles the multiply / subtract butterflies instead.
+#ifndef NFLHIP_U32_MAD
+#define NFLHIP_U32_MAD 1
+#endif
+__device__ __forceinline__ u32 mad_low(u64 acc, u32 &tok) {
+  asm("" : "=v"(tok) : "0"(tok), "v"((u32)(acc >> 32)));  // tok "depends" on the high dword; no instruction
+  return (u32)acc;
+}
+__device__ __forceinline__ void tok_end(u32 tok) { asm volatile("" ::"v"(tok)); }
+
+// Cooley-Tukey, Harvey ranges (x < 4p, y any word -> both < 4p): x' = X + (y w - q p), y' = 2X + 2p - x'
+__device__ __forceinline__ void ct32(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2, u32 &tok) {
+  const u32 X = lazy2(x, p2);
+  const u32 q = __umulhi(y, w.wp);
+  x = mad_low((u64)y * w.w + ((u64)q * (0u - p) + junk_above(X)), tok);
+  y = (X << 1) + p2 - x;
+}
+__device__ __forceinline__ void gs32(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2, u32 &tok) {  // inputs < 2p
+  const u32 s = x + y, d = y - x + p2;
+  x = lazy2(s, p2);
+  const u32 q = __umulhi(d, w.wp);
+  y = mad_low((u64)d * w.w + ((u64)q * (0u - p) + junk_above(0u)), tok);
+}
+__device__ __forceinline__ void ct32_plain(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2) {
   const u32 X = lazy2(x, p2);
   const u32 T = mul_shoup_lazy<u32>(y, w.w, w.wp, p);  // any word -> [0,2p)
   x = X + T;
   y = X - T + p2;
 }
-__device__ __forceinline__ void gs32(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2) {  // inputs < 2p
+__device__ __forceinline__ void gs32_plain(u32 &x, u32 &y, const Tw32 w, u32 p, u32 p2) {  // inputs < 2p
   const u32 s = x + y, d = y - x + p2;
   x = lazy2(s, p2);
   y = mul_shoup_lazy<u32>(d, w.w, w.wp, p);
 }
 
 // ---- arithmetic policies ----------------------------------------------------------------------------------------
-struct Pol32 {
+// MAD: the multiply-add butterflies (ct32 / gs32).  Measured (MI355X, round 2): rows of 4096 words (one 256-thread
+// workgroup per row) 9.9 -> 11.4 M products/s at u32/4096/4 (+15 %); wave-per-row kernels (n = 1024 / 2048) 201 -> 194 and
+// 90 -> 85 M/s (-4 %: there the schedule, not the instruction count, is what binds) -- so only the 4096-word kernels use them.
+template <bool MAD> struct Pol32T {
   typedef u32 T;
+  typedef u32 WT;
   typedef Tw32 TW;
   typedef MC32 MC;
   struct K {
     u32 p, p2, mu;
+    mutable u32 tok;  // the chain that keeps the high dwords of the multiply-adds "used" (ct32); ended by pass_end()
   };
-  __device__ __forceinline__ static K make(const MC &c) { return K{c.p, c.p2, c.mu}; }
-  __device__ __forceinline__ static void ct(T &x, T &y, const TW w, const K &k) { ct32(x, y, w, k.p, k.p2); }
-  __device__ __forceinline__ static void gs(T &x, T &y, const TW w, const K &k) { gs32(x, y, w, k.p, k.p2); }
+  __device__ __forceinline__ static K make(const MC &c) { return K{c.p, c.p2, c.mu, 0u}; }
+  __device__ __forceinline__ static WT wrap(T x) { return x; }
+  __device__ __forceinline__ static T unwrap(WT x) { return x; }
+  __device__ __forceinline__ static void pass_end(const K &k) { if (MAD) tok_end(k.tok); }
+  __device__ __forceinline__ static void ct(WT &x, WT &y, const TW w, const K &k) {
+    if (MAD) ct32(x, y, w, k.p, k.p2, k.tok); else ct32_plain(x, y, w, k.p, k.p2);
+  }
+  __device__ __forceinline__ static void gs(WT &x, WT &y, const TW w, const K &k) {
+    if (MAD) gs32(x, y, w, k.p, k.p2, k.tok); else gs32_plain(x, y, w, k.p, k.p2);
+  }
   __device__ __forceinline__ static T canon(T x, const K &k) { return reduce4<u32>(x, k.p); }  // forward output < 4p
   __device__ __forceinline__ static T prep(T b, const K &k) { return reduce4<u32>(b, k.p); }   // operand of mul()
   __device__ __forceinline__ static T mul(T a, T b, const K &k) {  // a lazy, b prepared or canonical -> [0,p)
@@ -61,15 +103,21 @@ struct Pol32 {
     x = mul_shoup<u32>(d, c.w1ninv, c.w1ninv_sh, k.p);
   }
 };
+typedef Pol32T<false> Pol32;
+typedef Pol32T<NFLHIP_U32_MAD != 0> Pol32M;
 struct Pol64 {
   typedef u64 T;
+  typedef u64 WT;
   typedef Tw64 TW;
   typedef MC64 MC;
+  __device__ __forceinline__ static WT wrap(T x) { return x; }
+  __device__ __forceinline__ static T unwrap(WT x) { return x; }
   struct K {
     Mod m;
     u64 mu2;
   };
   __device__ __forceinline__ static K make(const MC &c) { return K{make_mod(c), c.mu2}; }
+  __device__ __forceinline__ static void pass_end(const K &) {}
   __device__ __forceinline__ static void ct(T &x, T &y, const TW w, const K &k) { ct_bfly<3>(x, y, w, k.m); }
   __device__ __forceinline__ static void gs(T &x, T &y, const TW w, const K &k) { gs_bfly<3>(x, y, w, k.m); }
   __device__ __forceinline__ static T canon(T x, const K &k) { return nflhip::canon<3>(x, k.m); }
@@ -107,6 +155,9 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
                                         const typename P::K &k, const unsigned kf = 1u) {
   // kf = 2^r + blk: the row is block `blk` of a row 2^r times longer whose first r stages already ran (kf = 1: a whole row)
   constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : (LB == 8 ? 3 : 4);
+  typename P::WT R[16];  // working form of the words (32-bit limbs: low dword of a pair, see ct32)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) R[q] = P::wrap(r[q]);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int half = 8 >> s;
@@ -115,15 +166,15 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
     for (int g = 0; g < (1 << s); ++g) {
       const typename P::TW w = tw[(kf << s) + g];
 #pragma unroll
-      for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+      for (int h = 0; h < half; ++h) P::ct(R[g * 2 * half + h], R[g * 2 * half + h + half], w, k);
     }
   }
   const int B = t / LB, l = t % LB;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad1<LB>(t + W * q)] = r[q];
+  for (int q = 0; q < 16; ++q) lds[pad1<LB>(t + W * q)] = P::unwrap(R[q]);
   row_sync<LB>();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad1<LB>(BS * B + LB * q + l)];
+  for (int q = 0; q < 16; ++q) R[q] = P::wrap(lds[pad1<LB>(BS * B + LB * q + l)]);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int half = 8 >> s;
@@ -132,15 +183,15 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
     for (int g = 0; g < (1 << s); ++g) {
       const typename P::TW w = tw[((16u * kf + B) << s) + g];
 #pragma unroll
-      for (int h = 0; h < half; ++h) P::ct(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+      for (int h = 0; h < half; ++h) P::ct(R[g * 2 * half + h], R[g * 2 * half + h + half], w, k);
     }
   }
   row_sync<LB>();  // (all reads of exchange 1 are done before its words are overwritten)
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad2(BS * B + LB * q + l)] = r[q];
+  for (int q = 0; q < 16; ++q) lds[pad2(BS * B + LB * q + l)] = P::unwrap(R[q]);
   wave_sync();     // exchange 2 stays inside a block = LB consecutive lanes
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(16 * t + q)];
+  for (int q = 0; q < 16; ++q) R[q] = P::wrap(lds[pad2(16 * t + q)]);
 #pragma unroll
   for (int i = 0; i < NS3; ++i) {  // last NS3 stages on the thread's 16 consecutive words
     const int d = 1 << (NS3 - 1 - i), G = 8 / d;
@@ -149,9 +200,12 @@ __device__ __forceinline__ void fwd_row(typename P::T (&r)[16], typename P::T *l
     for (int g = 0; g < G; ++g) {
       const typename P::TW w = tw[((256u * kf) << i) + G * t + g];
 #pragma unroll
-      for (int h = 0; h < d; ++h) P::ct(r[2 * d * g + h], r[2 * d * g + h + d], w, k);
+      for (int h = 0; h < d; ++h) P::ct(R[2 * d * g + h], R[2 * d * g + h + d], w, k);
     }
   }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = P::unwrap(R[q]);
+  P::pass_end(k);
 }
 
 // inverse: r[q] = NTT word 16 t + q (< 2p) on entry, r[q] = x[t + W q] canonical on exit
@@ -162,6 +216,9 @@ __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *l
   // ki = 2^(r+1) - blk (mirrored indices of block blk); plain_last: stages r-1 .. 0 follow elsewhere, so the block's last
   // stage is an ordinary one (twiddle psi[ki - 1]) and the words stay lazy (< 2p)
   constexpr int W = 16 * LB, BS = 16 * LB, NS3 = LB == 4 ? 2 : (LB == 8 ? 3 : 4);
+  typename P::WT R[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) R[q] = P::wrap(r[q]);
 #pragma unroll
   for (int i = NS3 - 1; i >= 0; --i) {
     const int d = 1 << (NS3 - 1 - i), G = 8 / d;
@@ -170,16 +227,16 @@ __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *l
     for (int g = 0; g < G; ++g) {
       const typename P::TW w = tw[((256u * ki) << i) - 1u - (unsigned)(G * t + g)];
 #pragma unroll
-      for (int h = 0; h < d; ++h) P::gs(r[2 * d * g + h], r[2 * d * g + h + d], w, k);
+      for (int h = 0; h < d; ++h) P::gs(R[2 * d * g + h], R[2 * d * g + h + d], w, k);
     }
   }
   const int B = t / LB, l = t % LB;
   wave_sync();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad2(16 * t + q)] = r[q];
+  for (int q = 0; q < 16; ++q) lds[pad2(16 * t + q)] = P::unwrap(R[q]);
   wave_sync();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad2(BS * B + LB * q + l)];
+  for (int q = 0; q < 16; ++q) R[q] = P::wrap(lds[pad2(BS * B + LB * q + l)]);
 #pragma unroll
   for (int s = 3; s >= 0; --s) {
     const int half = 8 >> s;
@@ -188,15 +245,15 @@ __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *l
     for (int g = 0; g < (1 << s); ++g) {
       const typename P::TW w = tw[((16u * ki) << s) - 1u - (unsigned)((B << s) + g)];
 #pragma unroll
-      for (int h = 0; h < half; ++h) P::gs(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+      for (int h = 0; h < half; ++h) P::gs(R[g * 2 * half + h], R[g * 2 * half + h + half], w, k);
     }
   }
   row_sync<LB>();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) lds[pad1<LB>(BS * B + LB * q + l)] = r[q];
+  for (int q = 0; q < 16; ++q) lds[pad1<LB>(BS * B + LB * q + l)] = P::unwrap(R[q]);
   row_sync<LB>();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) r[q] = lds[pad1<LB>(t + W * q)];
+  for (int q = 0; q < 16; ++q) R[q] = P::wrap(lds[pad1<LB>(t + W * q)]);
 #pragma unroll
   for (int s = 3; s >= 1; --s) {
     const int half = 8 >> s;
@@ -205,14 +262,18 @@ __device__ __forceinline__ void inv_row(typename P::T (&r)[16], typename P::T *l
     for (int g = 0; g < (1 << s); ++g) {
       const typename P::TW w = tw[(ki << s) - 1u - (unsigned)g];
 #pragma unroll
-      for (int h = 0; h < half; ++h) P::gs(r[g * 2 * half + h], r[g * 2 * half + h + half], w, k);
+      for (int h = 0; h < half; ++h) P::gs(R[g * 2 * half + h], R[g * 2 * half + h + half], w, k);
     }
   }
   if (plain_last) {
     const typename P::TW w = tw[ki - 1u];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) P::gs(r[h], r[h + 8], w, k);
-  } else {
+    for (int h = 0; h < 8; ++h) P::gs(R[h], R[h + 8], w, k);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = P::unwrap(R[q]);
+  P::pass_end(k);
+  if (!plain_last) {
 #pragma unroll
     for (int h = 0; h < 8; ++h) P::last(r[h], r[h + 8], c, k);  // last stage with n^-1 folded in; canonical outputs
   }
@@ -370,9 +431,12 @@ static hipError_t launch_rows(const Shape &s, const DevTables &t, int mode, type
 hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                               const uint32_t *b, size_t batch, hipStream_t st) {
   if (s.limb_bits != 32) return hipErrorNotSupported;
-  if (s.logn == 10) return launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);
-  if (s.logn == 11) return launch_rows<Pol32, 8>(s, t, mode, c, a, b, batch, st);
-  if (s.logn == 12) return launch_rows<Pol32, 16>(s, t, mode, c, a, b, batch, st);
+  // NFLHIP_U32_MADS (A/B switch, bit-identical results): 0 = multiply / subtract butterflies everywhere, 1 = multiply-add
+  // butterflies everywhere, unset = per kernel as measured (see Pol32T)
+  static const int mads = getenv("NFLHIP_U32_MADS") ? atoi(getenv("NFLHIP_U32_MADS")) : -1;
+  if (s.logn == 10) return mads == 1 ? launch_rows<Pol32M, 4>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);
+  if (s.logn == 11) return mads == 1 ? launch_rows<Pol32M, 8>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32, 8>(s, t, mode, c, a, b, batch, st);
+  if (s.logn == 12) return mads == 0 ? launch_rows<Pol32, 16>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32M, 16>(s, t, mode, c, a, b, batch, st);
   return hipErrorNotSupported;
 }
 // 4096-word blocks of rows longer than 4096 words, 32-bit limbs: the inner kernels of launch_ntt_fwd / launch_ntt_inv
@@ -382,7 +446,7 @@ hipError_t launch_inner_fwd_fast_u32(const Shape &s, const DevTables &t, const u
   const size_t blocks = rows << (s.logn - 12);
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((k_row_block<Pol32, 2>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, (const uint32_t *)nullptr,
+  hipLaunchKernelGGL((k_row_block<Pol32M, 2>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, (const uint32_t *)nullptr,
                      (const Tw32 *)t.psi, (const MC32 *)t.mc, (int)s.nm, s.logn);
   return hipGetLastError();
 }
@@ -393,10 +457,10 @@ hipError_t launch_inner_inv_fast_u32(const Shape &s, const DevTables &t, const u
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   if (mul)
-    hipLaunchKernelGGL((k_row_block<Pol32, 4>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, mul, (const Tw32 *)t.psi,
+    hipLaunchKernelGGL((k_row_block<Pol32M, 4>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, mul, (const Tw32 *)t.psi,
                        (const MC32 *)t.mc, (int)s.nm, s.logn);
   else
-    hipLaunchKernelGGL((k_row_block<Pol32, 3>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, (const uint32_t *)nullptr,
+    hipLaunchKernelGGL((k_row_block<Pol32M, 3>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, (const uint32_t *)nullptr,
                        (const Tw32 *)t.psi, (const MC32 *)t.mc, (int)s.nm, s.logn);
   return hipGetLastError();
 }

@@ -42,6 +42,21 @@ template <typename T> __device__ __forceinline__ T mul_shoup_lazy(T x, T w, T wp
   const T q = limb<T>::mulhi(x, wp);
   return (T)(mullo<T>(x, w) - mullo<T>(q, p));
 }
+// 32-bit limbs: gfx950 has no full-word v_mad_u32, but the LOW dword of v_mad_u64_u32 (32 x 32 + 64) is a*b + lo(c)
+// whatever the addend's high dword holds -- x w - q p is two such multiply-adds instead of two multiplies and a
+// subtract.  The register-tiled 32-bit kernels (kernels_wave.hip) use it by carrying every word in the low half of a
+// 64-bit pair whose high half is never looked at; these two helpers keep the compiler from narrowing such expressions
+// back to 32-bit multiplies: an arbitrary register as high half (no instruction), and a consumer of a high half (no
+// instruction either).
+__device__ __forceinline__ uint64_t junk_above(uint32_t lo) {
+  uint32_t junk = 0;
+  junk = __builtin_nondeterministic_value(junk);  // an arbitrary (frozen) value: no instruction, any register
+  return ((uint64_t)junk << 32) | lo;
+}
+__device__ __forceinline__ uint32_t low_of_pair(uint64_t acc) {
+  asm volatile("" ::"v"((uint32_t)(acc >> 32)));
+  return (uint32_t)acc;
+}
 template <typename T> __device__ __forceinline__ T mul_shoup(T x, T w, T wp, T p) {
   return csub<T>(mul_shoup_lazy<T>(x, w, wp, p), p);
 }
