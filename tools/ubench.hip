@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <vector>
 
+#include "../nfllib_amd/csrc/modarith64.h"   // the product kernels' own butterflies (ct_bfly<ARITH>)
+
 #define CK(x)                                                                          \
   do {                                                                                 \
     hipError_t e_ = (x);                                                               \
@@ -114,6 +116,51 @@ __global__ void k_bfly64(uint64_t *out, uint64_t w, uint64_t wp, uint64_t p) {
       const uint64_t m = y * w - q * p;
       r[k] = x + m;
       r[k + 1] = x - m + p2;
+    }
+  }
+  uint64_t s = 0;
+  for (int k = 0; k < ACC; ++k) s ^= r[k];
+  if (s == 0x12345678u) out[0] = s;
+}
+// ---- the alternatives for one lazy Cooley-Tukey butterfly on 62-bit primes p = 2^62 - delta, as hipcc compiles them
+// (the generated assembly kernel is the ARITH 3 formulation hand-scheduled: 18 instructions, profiles/ r01_v6_asm_pmc.txt).
+//   ARITH 0: Harvey ranges + Shoup with q*p as a full 64-bit multiply        (what the reference's algorithm maps to)
+//   ARITH 2: two-bit fold + Shoup, q*p = (q<<62) - q*delta, exact quotient
+//   ARITH 3: the same with the one-off quotient                              (the shipped formulation)
+//   SOLINAS: no Shoup companion at all: 128-bit product y*w, then 2^62 = delta (mod p) folded three times
+template <int ARITH> __global__ void k_bfly_arith(uint64_t *out, uint64_t w, uint64_t wp, uint64_t p) {
+  using namespace nflhip;
+  uint64_t r[ACC];
+  for (int k = 0; k < ACC; ++k) r[k] = (threadIdx.x * 0x9E3779B97F4A7C15ull + k) >> 2;
+  Mod m;
+  m.p = p; m.p2 = 2 * p; m.p3 = 3 * p; m.d = (uint32_t)((1ull << 62) - p);
+  Tw64 tw;
+  tw.w = w; tw.wp = wp;
+  for (int it = 0; it < ITER / 4; ++it) {
+#pragma unroll
+    for (int k = 0; k < ACC; k += 2) ct_bfly<ARITH>(r[k], r[k + 1], tw, m);
+  }
+  uint64_t s = 0;
+  for (int k = 0; k < ACC; ++k) s ^= r[k];
+  if (s == 0x12345678u) out[0] = s;
+}
+__global__ void k_bfly_solinas(uint64_t *out, uint64_t w, uint64_t wp, uint64_t p) {
+  typedef unsigned __int128 u128;
+  uint64_t r[ACC];
+  for (int k = 0; k < ACC; ++k) r[k] = (threadIdx.x * 0x9E3779B97F4A7C15ull + k) >> 2;
+  const uint64_t M62 = (1ull << 62) - 1, delta = (1ull << 62) - p, p3 = 3 * p;
+  (void)wp;
+  for (int it = 0; it < ITER / 4; ++it) {
+#pragma unroll
+    for (int k = 0; k < ACC; k += 2) {
+      const uint64_t x = r[k], y = r[k + 1];
+      const uint64_t U = (x & M62) + (x >> 62) * delta;                   // fold2(x) < p + 4 delta
+      const u128 P = (u128)y * w;                                          // < 2^126
+      const u128 t = (u128)(uint64_t)(P >> 62) * delta + ((uint64_t)P & M62);   // < 2^96 + 2^62
+      const u128 t2 = (u128)(uint64_t)(t >> 62) * delta + ((uint64_t)t & M62);  // < 2^67 + 2^62
+      const uint64_t mm = ((uint64_t)t2 & M62) + (uint64_t)(t2 >> 62) * delta;  // < 2^62 + 2^38: lazily reduced y*w
+      r[k] = U + mm;
+      r[k + 1] = U + p3 - mm;
     }
   }
   uint64_t s = 0;
@@ -247,6 +294,17 @@ int main() {
     double ops = waves * (ITER / 4) * (ACC / 2);
     printf("%-18s %8.3f ms  %7.2f Gwavebfly/s %6.2f cyc/bfly/SIMD@2.4GHz (%.2f T bfly/s)\n", "k_bfly64", ms,
            ops / ms / 1e6, ms * 1e-3 * clk * simds / ops, ops * 64 / ms / 1e9);
+  }
+  {
+    auto line = [&](const char *name, double ms) {
+      double ops = waves * (ITER / 4) * (ACC / 2);
+      printf("%-18s %8.3f ms  %7.2f Gwavebfly/s %6.2f cyc/bfly/SIMD@2.4GHz (%.2f T bfly/s)\n", name, ms, ops / ms / 1e6,
+             ms * 1e-3 * clk * simds / ops, ops * 64 / ms / 1e9);
+    };
+    line("ct_harvey_shoup", time_ms([&] { hipLaunchKernelGGL(k_bfly_arith<0>, dim3(blocks), dim3(threads), 0, 0, d64, w, wp, p); }, 5));
+    line("ct_fold2_exactq", time_ms([&] { hipLaunchKernelGGL(k_bfly_arith<2>, dim3(blocks), dim3(threads), 0, 0, d64, w, wp, p); }, 5));
+    line("ct_fold2_oneoffq", time_ms([&] { hipLaunchKernelGGL(k_bfly_arith<3>, dim3(blocks), dim3(threads), 0, 0, d64, w, wp, p); }, 5));
+    line("ct_solinas_3fold", time_ms([&] { hipLaunchKernelGGL(k_bfly_solinas, dim3(blocks), dim3(threads), 0, 0, d64, w, wp, p); }, 5));
   }
   // clock
   long long *dclk;
