@@ -377,6 +377,12 @@ static int pipe64k_chunks() {
   return v;
 }
 
+// NFLHIP_PIPE32K=0: rows of 32768 words use the three-kernel plan instead of the pipeline kernel (A/B switch)
+static int pipe32k_on() {
+  static const int v = getenv("NFLHIP_PIPE32K") ? atoi(getenv("NFLHIP_PIPE32K")) : 1;
+  return v;
+}
+
 // hipGraph capture: the entry points only enqueue work on the caller's stream, so they can be captured.  The
 // multi-launch plans additionally order successive calls on the shared scratch with events recorded OUTSIDE any
 // capture; inside a capture those waits are illegal (and meaningless: a graph orders its own nodes), so they are
@@ -405,7 +411,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
   const bool cap = is_capturing(st);
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 16 && pipe64k_chunks() > 0) {
+  if (sizeof(T) == 8 && !b_is_ntt && (ctx->shape.logn == 16 || (ctx->shape.logn == 15 && pipe32k_on())) && pipe64k_chunks() > 0) {
     // n = 65536: the streaming passes (HBM-bound) and the fused block kernel (VALU-bound) of neighbouring chunks share
     // every CU inside ONE kernel whose workgroups take three roles; consecutive launches on the caller's stream form the
     // pipeline: launch L = forward pass of chunk L, block products of chunk L-1, inverse pass of chunk L-2.

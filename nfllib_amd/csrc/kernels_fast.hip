@@ -353,6 +353,7 @@ enum AsmKind {
   kAsmPolymul8k, kAsmPolymulNtt8k, kAsmFwd8k, kAsmInv8k,            // 8192-word blocks, 512 threads
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
+  kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
   kAsmCount
 };
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
@@ -365,7 +366,7 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_polymul8192_asm",     "nflhip_polymul_ntt8192_asm",
                                                  "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm",
                                                  "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm",
-                                                 "nflhip_polymul_pipe65536nt_asm"};
+                                                 "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -454,10 +455,10 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
                                       hipStream_t st) {
-  if (s.limb_bits != 64 || s.logn != 16 || variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+  if (s.limb_bits != 64 || (s.logn != 16 && s.logn != 15) || variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
   // NFLHIP_PIPE_NT=1: coefficient loads / stores bypass L2 retention (`nt`), so the twiddle tables stay resident there
   static const int use_nt = getenv("NFLHIP_PIPE_NT") ? atoi(getenv("NFLHIP_PIPE_NT")) : 1;  // measured +3 % (E, batch 32 and 128)
-  hipFunction_t fn = asm_fn(use_nt ? kAsmPipe64kNt : kAsmPipe64k);
+  hipFunction_t fn = asm_fn(s.logn == 15 ? kAsmPipe32k : (use_nt ? kAsmPipe64kNt : kAsmPipe64k));
   if (!fn) return hipErrorNotSupported;
   const int mx = cnt_v > cnt_f ? (cnt_v > cnt_i ? cnt_v : cnt_i) : (cnt_f > cnt_i ? cnt_f : cnt_i);
   if (mx <= 0) return hipSuccess;
@@ -474,7 +475,8 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_pipe65536_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  const size_t gx = (size_t)mx * 28;  // per polynomial row: 16 block products + 3 x 4 streaming workgroups
+  // per polynomial row: 16 block products + 3 x 4 streaming workgroups (n = 65536), 8 + 3 x 2 (n = 32768)
+  const size_t gx = (size_t)mx * (s.logn == 16 ? 28 : 14);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
   return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }

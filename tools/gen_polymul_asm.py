@@ -581,7 +581,7 @@ def prologue(em, vm, kind="polymul"):
     return tw_seq
 
 
-def strided_rows(em, vm, base, srow, stride, store=False, offset=0):
+def strided_rows(em, vm, base, srow, stride, store=False, offset=0, nwords=16):
     """16 words x[t + k*stride/8] of the row at srow (+ offset bytes) <-> register pairs base+2k; returns the number
     of the last memory instruction issued (stores are counted too when a VmCounter is given)"""
     R = em.raw
@@ -590,7 +590,7 @@ def strided_rows(em, vm, base, srow, stride, store=False, offset=0):
     if offset:
         R("s_add_u32 s86, s86, 0x%x" % offset)
         R("s_addc_u32 s87, s87, 0")
-    for k in range(16):
+    for k in range(nwords):
         if stride == 2048:
             off = (k & 1) * 2048
         else:
@@ -607,7 +607,7 @@ def strided_rows(em, vm, base, srow, stride, store=False, offset=0):
             if k & 1:
                 R("s_add_u32 s86, s86, 0x1000")
                 R("s_addc_u32 s87, s87, 0")
-        elif k < 15:
+        elif k < nwords - 1:
             R("s_add_u32 s86, s86, 0x%x" % stride)
             R("s_addc_u32 s87, s87, 0")
     return seq
@@ -1210,11 +1210,22 @@ def emit_consts(em):
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
 
 
-def build_pipe():
+def build_pipe(logn=None):
+    """n = 65536 (logn 16): radix-16 streaming roles, 16 + 3 x 4 = 28 workgroups per row.
+    n = 32768 (logn 15): radix-8 streaming roles (a thread's 16 registers hold two columns of 8 words), 8 + 3 x 2 = 14."""
+    global PIPE_LOGN
+    if logn is not None:
+        PIPE_LOGN = logn
     em = Emitter()
     R = em.raw
     n_words = 1 << PIPE_LOGN
-    stride = n_words // 16 * 8                            # bytes between x[o + k n/16]
+    RL = PIPE_LOGN - 12                                   # global stages done by the streaming roles: 4 (radix 16) or 3 (radix 8)
+    RADIX = 1 << RL
+    NV = n_words // 4096                                  # block products per row
+    NSW = 4 if RL == 4 else 2                             # streaming workgroups per row and operand
+    PER_ROW = NV + 3 * NSW
+    CG_LOG = 11 if RL == 4 else 12                        # bytes (log2) of one column group: 256 columns x (16 / RADIX) x 8 B
+    stride = n_words // RADIX * 8                         # bytes between x[o + k n/RADIX]
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c_v, a_v, b_v, psi
     R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
     R("s_load_dword s14, s[0:1], 0x28")                  # nm
@@ -1236,16 +1247,16 @@ def build_pipe():
     # 28 workgroups per polynomial row -- w = wgx mod 28: 0..15 block products, 16..19 / 20..23 forward streaming of
     # a / b (four column groups each), 24..27 inverse streaming.  28 = 4 mod 8, so the XCD of a role rotates with the
     # polynomial index and every role is spread over all XCDs.
-    R("s_mul_hi_u32 s86, s2, 0x%x" % ((1 << 32) // 28 + 1,))   # poly = wgx / 28 (exact below 1.7e8)
-    R("s_mul_i32 s43, s86, 28")
+    R("s_mul_hi_u32 s86, s2, 0x%x" % ((1 << 32) // PER_ROW + 1,))   # poly = wgx / PER_ROW (exact below 1.7e8)
+    R("s_mul_i32 s43, s86, %d" % PER_ROW)
     R("s_sub_u32 s89, s2, s43")                          # w
     R("s_mov_b32 s42, 0")                                # role 0: block product, blk = w
-    R("s_cmp_lt_u32 s89, 16")
+    R("s_cmp_lt_u32 s89, %d" % NV)
     R("s_cbranch_scc1 .Lrole_known")
-    R("s_sub_u32 s89, s89, 16")
-    R("s_lshr_b32 s42, s89, 2")
+    R("s_sub_u32 s89, s89, %d" % NV)
+    R("s_lshr_b32 s42, s89, %d" % (NSW.bit_length() - 1))
     R("s_add_u32 s42, s42, 1")                           # role 1, 2, 3
-    R("s_and_b32 s89, s89, 3")                           # q: column groups q, q+4, q+8, q+12
+    R("s_and_b32 s89, s89, %d" % (NSW - 1))              # q: column groups q, q+NSW, q+2 NSW, q+3 NSW
     em.lines.append(".Lrole_known:")
     R("s_mul_i32 s87, s86, s14")
     R("s_add_u32 s87, s87, s3")                          # row = poly*nm + cm
@@ -1261,29 +1272,71 @@ def build_pipe():
     # A streaming workgroup owns the four column groups sub, sub+4, sub+8, sub+12 of its row (sub < 4; the others
     # exit at once) and double-buffers them through the a / b register files: the loads of group g+1 are in flight
     # while group g is transformed, and the 15 twiddle records of the pass are loaded once.
-    GROUPS, GSTEP = 4, 4 * 2048
+    GROUPS, GSTEP = 4, NSW << CG_LOG
+
+    def group_io(buf, srow, offset, store=False):
+        """one column group <-> 16 register pairs: radix 16: x[t + k n/16], k < 16; radix 8: x[t + k n/8] in pairs 0..7 and
+        x[t + 256 + k n/8] in pairs 8..15"""
+        if RL == 4:
+            return strided_rows(em, vm_cur[0], buf, srow, stride, store=store, offset=offset)
+        seq = 0
+        for half in range(2):
+            seq = strided_rows(em, vm_cur[0], buf + 16 * half, srow, stride, store=store, offset=offset + 2048 * half, nwords=8)
+        return seq
+
+    def radix_stage_fwd(buf, st):
+        if RL == 4:
+            return ct_stage(em, [buf], st)
+        half = 4 >> st
+        jobs = []
+        for g in range(1 << st):
+            tw = twreg(tw_slot(st, g))
+            for h in range(half):
+                for grp in (0, 8):
+                    i0 = grp + g * 2 * half + h
+                    jobs.append(ct_bfly(buf + 2 * i0, buf + 2 * (i0 + half), tw))
+        run_pairs(em, jobs)
+
+    def radix_stage_inv(buf, st):
+        if RL == 4:
+            return gs_stage(em, buf, st)
+        half = 4 >> st
+        jobs = []
+        for g in range(1 << st):
+            tw = twreg(tw_slot(st, g))
+            for h in range(half):
+                for grp in (0, 8):
+                    i0 = grp + g * 2 * half + h
+                    jobs.append(gs_bfly(buf + 2 * i0, buf + 2 * (i0 + half), tw))
+        run_pairs(em, jobs)
+
+    vm_cur = [None]
 
     def stream_role(kind):
         vm = VmCounter(em)
+        vm_cur[0] = vm
         bufs = [V_A, V_B]
-        seq_of = {0: strided_rows(em, vm, bufs[0], S_AROW, stride)}
+        seq_of = {0: group_io(bufs[0], S_AROW, 0)}
         tw_last = 0
-        for st in ((0, 1, 2, 3) if kind == "F" else (3, 2, 1, 0)):
+        for st in (tuple(range(RL)) if kind == "F" else tuple(range(RL - 1, -1, -1))):
             tw_last = PASS_TW["F1" if kind == "F" else "I3"](em, vm, st)
         emit_consts(em)
         for gi in range(GROUPS):
             buf = bufs[gi & 1]
             if gi + 1 < GROUPS:
-                seq_of[gi + 1] = strided_rows(em, vm, bufs[(gi + 1) & 1], S_AROW, stride, offset=(gi + 1) * GSTEP)
+                seq_of[gi + 1] = group_io(bufs[(gi + 1) & 1], S_AROW, (gi + 1) * GSTEP)
             vm.wait(max(seq_of[gi], tw_last))
             if kind == "F":
-                for st in range(4):
-                    ct_stage(em, [buf], st)
+                for st in range(RL):
+                    radix_stage_fwd(buf, st)
             else:
-                for st in (3, 2, 1):
-                    gs_stage(em, buf, st)
-                run_pairs(em, [final_bfly(buf + 2 * h, buf + 2 * (h + 8)) for h in range(8)])
-            strided_rows(em, vm, buf, S_CROW, stride, store=True, offset=gi * GSTEP)
+                for st in range(RL - 1, 0, -1):
+                    radix_stage_inv(buf, st)
+                if RL == 4:
+                    run_pairs(em, [final_bfly(buf + 2 * h, buf + 2 * (h + 8)) for h in range(8)])
+                else:
+                    run_pairs(em, [final_bfly(buf + 2 * (grp + h), buf + 2 * (grp + h + 4)) for h in range(4) for grp in (0, 8)])
+            group_io(buf, S_CROW, gi * GSTEP, store=True)
         R("s_endpgm")
 
     em.comment("role F: x[o + k n/16] -> radix-16 over global stages 0..3 -> lazy words (the block kernel takes any word)")
@@ -1294,8 +1347,8 @@ def build_pipe():
     R("s_cselect_b64 s[20:21], s[62:63], s[66:67]")      # dst
     R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
     R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))      # row * n * 8
-    R("s_lshl_b32 s86, s89, 11")
-    R("s_add_u32 s42, s42, s86")                         # + 256 columns * 8 B * group (no carry: low 19 bits were zero)
+    R("s_lshl_b32 s86, s89, %d" % CG_LOG)
+    R("s_add_u32 s42, s42, s86")                         # + the bytes of q column groups (no carry: the low bits were zero)
     for row in (16, 20):
         R("s_add_u32 s%d, s%d, s42" % (row, row))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, row + 1))
@@ -1309,7 +1362,7 @@ def build_pipe():
     R("s_cbranch_scc1 .Lidle")
     R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
     R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))
-    R("s_lshl_b32 s86, s89, 11")
+    R("s_lshl_b32 s86, s89, %d" % CG_LOG)
     R("s_add_u32 s42, s42, s86")
     R("s_add_u32 s16, s68, s42")
     R("s_addc_u32 s17, s69, s43")
@@ -1323,8 +1376,8 @@ def build_pipe():
     em.comment("role V: one 4096-word block, exactly the stand-alone block kernel (r = 4, blk = s89)")
     R("s_cmp_ge_u32 s86, s56")
     R("s_cbranch_scc1 .Lidle")
-    R("s_lshl_b32 s42, s87, 4")
-    R("s_add_u32 s42, s42, s89")                         # block index = row * 16 + blk
+    R("s_lshl_b32 s42, s87, %d" % RL)
+    R("s_add_u32 s42, s42, s89")                         # block index = row * (n / 4096) + blk
     R("s_lshr_b32 s43, s42, 17")
     R("s_lshl_b32 s42, s42, 15")
     for base, row in ((6, 16), (8, 18), (4, 20)):
@@ -1472,6 +1525,11 @@ def main():
     em_nt = build_pipe()
     em_nt.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em_nt.lines]
     emit_file(os.path.join(outdir, "polymul_pipe65536nt_gfx950.s"), "nflhip_polymul_pipe65536nt_asm", em_nt, args=ARGS_PIPE)
+    # n = 32768: the same three-role kernel with radix-8 streaming roles
+    em15 = build_pipe(15)
+    em15.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em15.lines]
+    emit_file(os.path.join(outdir, "polymul_pipe32768_gfx950.s"), "nflhip_polymul_pipe32768_asm", em15, args=ARGS_PIPE)
+    build_pipe(16)   # (leave the module-level PIPE_LOGN as it was)
     configure("ring", 4)
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
