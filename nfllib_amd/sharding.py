@@ -74,37 +74,55 @@ def _as_bytes(t):
     return t.contiguous().view(torch.uint8).reshape(-1)
 
 
-def scatter_batch(full, shard, dist, rank, world, root=0):
+# One message per peer and group, at most this many bytes each: a config-D shard is 16 GiB, and 32-bit element counts
+# inside a transport must never see it whole.  Pieces of one shard are posted in the same order on both sides, group
+# after group (piece k of every peer travels in group k, so all links stay busy).
+MAX_MESSAGE_BYTES = 1 << 30
+
+
+def _pieces(buf, limit):
+    n = buf.numel()
+    return [buf[o:min(o + limit, n)] for o in range(0, n, limit)] if n else []
+
+
+def _run_groups(dist, per_peer):
+    """per_peer: list of (op, peer, [pieces]); issues group k = piece k of every peer that still has one."""
+    depth = max((len(p) for _, _, p in per_peer), default=0)
+    for k in range(depth):
+        ops = [dist.P2POp(op, pieces[k], peer) for op, peer, pieces in per_peer if k < len(pieces)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def scatter_batch(full, shard, dist, rank, world, root=0, max_message_bytes=None):
     """Root holds `full` ([global_batch, nm, n]); every rank (root included) ends with its
     shard_range() slice of it in `shard` ([hi - lo, nm, n], preallocated, contiguous).  Returns `shard`."""
     if not shard.is_contiguous():
         raise ValueError("shard buffer must be contiguous")
+    limit = max_message_bytes or MAX_MESSAGE_BYTES
+    per_peer = []
     if rank == root:
         gb = full.shape[0]
-        ops, keep = [], []
         for r in range(world):
             lo, hi = shard_range(gb, world, r)
             if r == root:
                 shard.copy_(full[lo:hi])
             elif hi > lo:
-                buf = _as_bytes(full[lo:hi])
-                keep.append(buf)
-                ops.append(dist.P2POp(dist.isend, buf, r))
-    else:
-        ops = [dist.P2POp(dist.irecv, _as_bytes(shard), root)] if shard.numel() else []
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+                per_peer.append((dist.isend, r, _pieces(_as_bytes(full[lo:hi]), limit)))
+    elif shard.numel():
+        per_peer.append((dist.irecv, root, _pieces(_as_bytes(shard), limit)))
+    _run_groups(dist, per_peer)
     return shard
 
 
-def gather_batch(shard, full, dist, rank, world, root=0):
+def gather_batch(shard, full, dist, rank, world, root=0, max_message_bytes=None):
     """Inverse of scatter_batch: the root's `full` (contiguous) receives every rank's shard at its slice."""
+    limit = max_message_bytes or MAX_MESSAGE_BYTES
+    per_peer = []
     if rank == root:
         if not full.is_contiguous():
             raise ValueError("destination batch must be contiguous")
         gb = full.shape[0]
-        ops = []
         for r in range(world):
             lo, hi = shard_range(gb, world, r)
             if r == root:
@@ -112,10 +130,8 @@ def gather_batch(shard, full, dist, rank, world, root=0):
             elif hi > lo:
                 buf = _as_bytes(full[lo:hi])   # a contiguous slice: the view aliases `full`
                 assert buf.data_ptr() == full[lo:hi].data_ptr()
-                ops.append(dist.P2POp(dist.irecv, buf, r))
-    else:
-        ops = [dist.P2POp(dist.isend, _as_bytes(shard), root)] if shard.numel() else []
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+                per_peer.append((dist.irecv, r, _pieces(buf, limit)))
+    elif shard.numel():
+        per_peer.append((dist.isend, root, _pieces(_as_bytes(shard), limit)))
+    _run_groups(dist, per_peer)
     return full if rank == root else None

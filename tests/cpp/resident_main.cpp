@@ -116,6 +116,71 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_residency() {
   return true;
 }
 
+// deferred execution is an execution strategy, not a semantics: with the sampler state pinned, the same program gives the
+// same polynomials whether operations are queued and coalesced or launched one by one; errors surface where they are
+// written; resident batches and handles share one stream and stay ordered.
+template <class T, size_t Degree, size_t NbModuli> static bool run_deferred_semantics() {
+  using poly_t = nfl::poly<T, Degree, NbModuli>;
+  using poly_p = nfl::poly_p<T, Degree, NbModuli>;
+  using G = nfl::gaussian<uint8_t, T, 2>;
+  nfl::FastGaussianNoise<uint8_t, T, 2> fg(3.19, 128, 1 << 10);
+  unsigned char key[32];
+  for (int i = 0; i < 32; i++) key[i] = (unsigned char)(41 * i + 7);
+  const size_t K = 24;
+  auto program = [&](std::vector<poly_t> &out) {
+    nfl::set_sampler_key(key, 500);
+    std::vector<poly_p> r(K);
+    poly_p s{G(&fg)}, a{nfl::uniform()};
+    s.ntt_pow_phi();
+    a.ntt_pow_phi();
+    for (size_t i = 0; i < K; i++) {
+      poly_p e{G(&fg, 2)}, z{nfl::ZO_dist()}, h{nfl::hwt_dist(Degree / 8)}, n{nfl::non_uniform(17, 3)};
+      e.ntt_pow_phi();
+      z.ntt_pow_phi();
+      r[i] = a * s + e + z * h - n;        // (h, n stay in coefficient form: any words do for the comparison)
+      if (i % 5 == 4) r[i].invntt_pow_invphi();
+      if (i % 7 == 6) r[i] = r[i] + r[i - 1];   // a dependency across iterations
+    }
+    out.resize(K);
+    for (size_t i = 0; i < K; i++) std::memcpy(out[i].data(), const_cast<const poly_p &>(r[i]).poly_obj().cdata(), sizeof(poly_t));
+  };
+  std::vector<poly_t> lazy_out, eager_out;
+  nfl::set_deferred(true);
+  program(lazy_out);
+  poly_p::synchronize();
+  nfl::set_deferred(false);
+  program(eager_out);
+  nfl::set_deferred(true);
+  for (size_t i = 0; i < K; i++) CHECK(same(lazy_out[i], eager_out[i]));
+  // a constructor that must throw throws where it is written, deferred or not (core.hpp:205-210)
+  for (int mode = 0; mode < 2; mode++) {
+    nfl::set_deferred(mode == 0);
+    bool threw = false;
+    try {
+      poly_p bad{nfl::non_uniform(uint64_t(poly_t::get_modulus(0)) + 1)};
+    } catch (const std::runtime_error &) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+  nfl::set_deferred(true);
+  // handles and resident batches share the ring's stream: a key built by deferred operations, replicated into a batch
+  poly_p k1{nfl::uniform(5)}, k2{nfl::uniform(6)};
+  poly_p ks = k1 * k2 + k1;
+  nfl::device_batch<poly_t> B(3);
+  B.fill(ks);                                   // reads the handle: runs the queue first
+  Heap<poly_t> K1(nfl::uniform(5)), K2(nfl::uniform(6)), KS(*K1 * *K2 + *K1);
+  void *mem = nullptr;
+  if (posix_memalign(&mem, 32, 3 * sizeof(poly_t)) != 0) throw std::bad_alloc();
+  poly_t *host = new (mem) poly_t[3];
+  B.download(host);
+  bool ok = same(host[0], *KS) && same(host[1], *KS) && same(host[2], *KS);
+  for (int i = 0; i < 3; i++) host[i].~poly_t();
+  free(mem);
+  CHECK(ok);
+  return true;
+}
+
 // the reference's LWE demo with plain poly_p operators (tests/nfllib_demo_main_op.cpp:26-58, 260-332)
 template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *enc_per_s, double *dec_per_s, double *batch_enc_per_s,
                                                                        double *batch_dec_per_s, size_t *launches, size_t *operations) {
@@ -213,6 +278,9 @@ int main() {
     if (!run_residency<uint16_t, 128, 1>()) return 1;
     if (!run_residency<uint32_t, 8, 2>()) return 1;      // rows shorter than a 16-byte vector: the host route
     if (!run_residency<uint64_t, 32768, 2>()) return 1;
+    if (!run_deferred_semantics<uint64_t, 4096, 4>()) return 1;
+    if (!run_deferred_semantics<uint32_t, 1024, 2>()) return 1;
+    if (!run_deferred_semantics<uint64_t, 1024, 1>()) return 1;
     double e = 0, d = 0, be = 0, bd = 0;
     size_t nl = 0, no = 0;
     if (!run_lwe<uint64_t, 4096, 4>(&e, &d, &be, &bd, &nl, &no)) return 1;

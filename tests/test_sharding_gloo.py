@@ -89,10 +89,13 @@ def _worker_sg(rank, world, port, q):
         fa = torch.from_numpy(o.fill_uniform(GLOBAL_BATCH, SEED, 0).view(np.int64))
         fb = torch.from_numpy(o.fill_uniform(GLOBAL_BATCH, SEED, 1).view(np.int64))
         fc = torch.zeros_like(fa)
+    # one operand in one message per peer, the other cut into many pieces (the cap that keeps a 16 GiB config-D shard
+    # away from 32-bit counts, here lowered so that a few polynomials already need several groups; 5000 is not a
+    # multiple of anything in sight)
     sa = sharding.scatter_batch(fa, torch.empty((hi - lo, m, n), dtype=torch.int64), dist, rank, world)
-    sb = sharding.scatter_batch(fb, torch.empty((hi - lo, m, n), dtype=torch.int64), dist, rank, world)
+    sb = sharding.scatter_batch(fb, torch.empty((hi - lo, m, n), dtype=torch.int64), dist, rank, world, max_message_bytes=5000)
     c = o.polymul(sa.numpy().view(np.uint64), sb.numpy().view(np.uint64))
-    sharding.gather_batch(torch.from_numpy(c.view(np.int64)), fc, dist, rank, world)
+    sharding.gather_batch(torch.from_numpy(c.view(np.int64)), fc, dist, rank, world, max_message_bytes=7777)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, sharding.digest_words(fc.numpy().view(np.uint64)) if rank == 0 else None))
