@@ -510,10 +510,13 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   void *dev;
   bool host_valid, dev_valid, queued;
   long qrefs;  // references held by deferred operations (not handles): copy-on-write decisions look past them
+  // levelling scratch of lazy<P>::flush (valid when `epoch` is the current flush): last level that writes / reads this value
+  unsigned epoch;
+  int wlev, rlev;
 
-  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), qrefs(0) {}
+  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {}
   payload(const payload &o) : std::enable_shared_from_this<payload<P>>(), host(nullptr), dev(nullptr), host_valid(false),
-                              dev_valid(false), queued(false), qrefs(0) {
+                              dev_valid(false), queued(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {
     pending();
     if (o.dev_valid) {  // stays on the device
       check(ctx(), nflhip_memcpy_d2d(ctx(), dev_wo(), o.dev, bytes, ctx_t::queue()), "poly_p copy");
@@ -643,7 +646,12 @@ template <class P> struct lazy {
   std::recursive_mutex mu;
   std::vector<op> q;
   size_t launches, coalesced;  // statistics: launches issued / operations they carried
-  static constexpr size_t kMaxQueue = 16384;
+  // records after which the queue runs by itself: long enough for wide launches, short enough that the device works on
+  // one part of a long loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments)
+  static size_t max_queue() {
+    static const size_t v = getenv("NFL_HIP_QUEUE_LIMIT") ? size_t(atol(getenv("NFL_HIP_QUEUE_LIMIT"))) : 16384;
+    return v ? v : 1;
+  }
 
   lazy() : launches(0), coalesced(0) { ctx_t::inst(); }  // (the context is constructed first, so it is destroyed last)
   static lazy &inst() {
@@ -670,7 +678,7 @@ template <class P> struct lazy {
     o.out->dev_valid = true;
     o.out->host_valid = false;
     q.push_back(std::move(o));
-    if (q.size() >= kMaxQueue) flush();
+    if (q.size() >= max_queue()) flush();
   }
   void flush() {
     std::lock_guard<std::recursive_mutex> lk(mu);
@@ -687,56 +695,64 @@ template <class P> struct lazy {
         }
       }
     } guard{ops};
-    // ---- 1. levels
-    std::unordered_map<const pay_t *, int> wl, rl;
-    wl.reserve(ops.size() * 2);
-    rl.reserve(ops.size() * 4);
+    // ---- 1. levels (the last writing / reading level of a value is kept in its payload, tagged with this flush's epoch)
+    static unsigned epoch_counter = 0;
+    const unsigned ep = ++epoch_counter;
+    auto touch = [ep](pay_t *p) {
+      if (p->epoch != ep) {
+        p->epoch = ep;
+        p->wlev = p->rlev = -1;
+      }
+    };
     std::vector<int> lvl(ops.size(), 0);
-    int nlev = 0;
     for (size_t i = 0; i < ops.size(); ++i) {
       op &o = ops[i];
       int L = 0;
       for (int j = 0; j < o.nin; ++j) {
-        auto it = wl.find(o.in[j].get());
-        if (it != wl.end()) L = std::max(L, it->second + 1);
+        touch(o.in[j].get());
+        L = std::max(L, o.in[j]->wlev + 1);
       }
-      auto w = wl.find(o.out.get());
-      if (w != wl.end()) L = std::max(L, w->second + 1);
-      auto r = rl.find(o.out.get());
-      if (r != rl.end()) L = std::max(L, r->second + 1);
+      touch(o.out.get());
+      L = std::max(L, std::max(o.out->wlev, o.out->rlev) + 1);
       lvl[i] = L;
-      wl[o.out.get()] = L;
-      for (int j = 0; j < o.nin; ++j) {
-        int &x = rl.insert(std::make_pair(o.in[j].get(), -1)).first->second;
-        x = std::max(x, L);
-      }
-      if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) {
-        int &x = rl.insert(std::make_pair(o.out.get(), -1)).first->second;
-        x = std::max(x, L);
-      }
-      nlev = std::max(nlev, L + 1);
+      o.out->wlev = L;
+      for (int j = 0; j < o.nin; ++j) o.in[j]->rlev = std::max(o.in[j]->rlev, L);
+      if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) o.out->rlev = std::max(o.out->rlev, L);
     }
-    // ---- 2. groups: (level, signature) -> operations in program order
-    std::unordered_map<std::string, std::vector<size_t>> by_sig;
-    std::string sig;
+    // ---- 2. groups: (level, signature) -> operations in program order.  A loop produces a handful of distinct
+    // signatures, so a linear table of the ones seen (64-bit FNV-1a of the fields, plus the level) beats a map.
+    struct gkey { int level; uint64_t hash; };
+    std::vector<gkey> keys;
+    std::vector<std::vector<size_t>> members;
+    auto fnv = [](uint64_t h, const void *data, size_t n) {
+      const unsigned char *b = static_cast<const unsigned char *>(data);
+      for (size_t k = 0; k < n; ++k) h = (h ^ b[k]) * 0x100000001b3ull;
+      return h;
+    };
     for (size_t i = 0; i < ops.size(); ++i) {
       const op &o = ops[i];
-      sig.assign(reinterpret_cast<const char *>(&lvl[i]), sizeof(int));
-      sig.push_back(char('A' + o.kind));
+      uint64_t h = fnv(0xcbf29ce484222325ull, &o.kind, sizeof(o.kind));
       if (o.kind == K_EVAL) {
-        sig.append(reinterpret_cast<const char *>(o.code), size_t(o.len));
-        sig.push_back(char(o.nin));
+        h = fnv(h, o.code, size_t(o.len));
+        h = fnv(h, &o.nin, sizeof(o.nin));
       } else if (o.kind == K_SAMPLE || o.kind == K_GAUSS || o.kind == K_FILL) {
-        sig.append(reinterpret_cast<const char *>(&o.dist), sizeof(o.dist));
-        sig.append(reinterpret_cast<const char *>(&o.p0), sizeof(o.p0));
-        sig.append(reinterpret_cast<const char *>(&o.p1), sizeof(o.p1));
-        sig.append(reinterpret_cast<const char *>(&o.tab), sizeof(o.tab));
-        if (o.kind == K_FILL) sig.append(reinterpret_cast<const char *>(&o.sid), sizeof(o.sid));
+        h = fnv(h, &o.dist, sizeof(o.dist));
+        h = fnv(h, &o.p0, sizeof(o.p0));
+        h = fnv(h, &o.p1, sizeof(o.p1));
+        h = fnv(h, &o.tab, sizeof(o.tab));
+        if (o.kind == K_FILL) h = fnv(h, &o.sid, sizeof(o.sid));
       }
-      by_sig[sig].push_back(i);
+      size_t g = keys.size();
+      for (size_t k = keys.size(); k-- > 0;)   // (recent groups first: neighbouring operations repeat)
+        if (keys[k].level == lvl[i] && keys[k].hash == h) { g = k; break; }
+      if (g == keys.size()) {
+        keys.push_back(gkey{lvl[i], h});
+        members.emplace_back();
+      }
+      members[g].push_back(i);
     }
-    std::map<std::pair<int, std::string>, std::vector<size_t>> groups;  // few entries: ordered by level
-    for (auto &kv : by_sig) groups[std::make_pair(lvl[kv.second[0]], kv.first)].swap(kv.second);
+    std::map<std::pair<int, uint64_t>, std::vector<size_t>> groups;  // few entries: ordered by level
+    for (size_t g = 0; g < keys.size(); ++g) groups[std::make_pair(keys[g].level, keys[g].hash)].swap(members[g]);
     nflhip_ctx *ctx = ctx_t::get();
     void *st = ctx_t::queue();
     detail::sampler &smp = detail::sampler::get();
