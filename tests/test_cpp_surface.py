@@ -14,11 +14,12 @@ BIN = os.path.join(CPP, "surface_test")
 
 
 RES = os.path.join(CPP, "resident_test")
+FUZZ = os.path.join(CPP, "deferred_fuzz")
 
 
 def _build():
-    subprocess.check_call(["make", "-s", "-C", CPP, "surface_test", "resident_test"])
-    assert os.path.exists(BIN) and os.path.exists(RES)
+    subprocess.check_call(["make", "-s", "-C", CPP, "surface_test", "resident_test", "deferred_fuzz"])
+    assert os.path.exists(BIN) and os.path.exists(RES) and os.path.exists(FUZZ)
 
 
 def _gpu():
@@ -61,3 +62,13 @@ def test_resident_poly_p_handles_and_the_lwe_demo_on_plain_operators():
     # ... which is what makes the per-polynomial surface usable: an order of magnitude over launching every operation
     assert rates["poly_p_encryptions_per_s"] > 4 * rates["poly_p_eager_encryptions_per_s"]
     print(rates)
+
+
+@pytest.mark.gpu
+def test_deferred_execution_equals_immediate_execution_on_random_programs():
+    """Random programs over a pool of resident handles (dependencies of every kind, copy-on-write, aliasing, random
+    constructors, host accesses inside a queue, dying temporaries): deferred + coalesced == launched one by one."""
+    _build()
+    r = subprocess.run([FUZZ, "150", "2024"], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout
