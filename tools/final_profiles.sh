@@ -1,20 +1,33 @@
 #!/bin/bash
-# Round-end evidence (GPU box): the bench line of every workload and the rocprofv3 kernel summary of the metric run.
-# Usage: bash tools/final_profiles.sh <tag>   -> gpurun_out/<tag>_bench_{A,B,C,E}.json, gpurun_out/<tag>_kernel_stats_B.csv
+# Round-end evidence (GPU box): the bench line of every workload (each carries roofline incl. the HBM traffic measured
+# in the same run, and cpu_baseline) and the rocprofv3 kernel summaries of the same commands.
+# Usage: bash tools/final_profiles.sh <tag>   -> gpurun_out/<tag>_bench_<W>.json, gpurun_out/<tag>_kernel_stats_<W>.csv, ...
 set -u
-tag=${1:-r01_final}
+tag=${1:-r02_final}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-for wl in B A C E; do
-  python bench.py --workload $wl 2>/dev/null | grep '^{' | tail -1 > $out/${tag}_bench_${wl}.json
+for wl in B A C E F G D; do
+  python bench.py --workload $wl 2>/dev/null | tail -1 > $out/${tag}_bench_${wl}.json
 done
-rm -rf $out/prof_B
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_B -- python bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > $out/${tag}_bench_B_under_rocprof.json 2>/dev/null
-f=$(find $out/prof_B -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats_B.csv
-rm -rf $out/prof_B
+here=$(pwd)
+for wl in B A C E F; do
+  rm -rf /tmp/prof_$wl
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python $here/bench.py --workload $wl --steps 20 --warmup 3 --no-extras --no-cpu-baseline --no-traffic > $here/$out/${tag}_bench_${wl}_under_rocprof.json 2>/dev/null)
+  f=$(find /tmp/prof_$wl -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats_${wl}.csv
+  rm -rf /tmp/prof_$wl
+done
+# stand-alone transforms of the metric shape
+for mode in fwd inv; do
+  rm -rf /tmp/prof_t
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -- python $here/tools/ntt_only.py $mode > /dev/null 2>&1)
+  f=$(find /tmp/prof_t -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats_transform_${mode}.csv
+done
+rm -rf /tmp/prof_t
+tests/cpp/resident_test | head -1 > $out/${tag}_lwe_poly_p.json
 python tools/lwe_demo.py 2>/dev/null > $out/${tag}_lwe.jsonl
 python tools/lwe_demo.py --degree 16384 --nmoduli 8 --batch 512 2>/dev/null >> $out/${tag}_lwe.jsonl
 python tools/lwe_demo.py --degree 1024 --nmoduli 2 --batch 65536 2>/dev/null >> $out/${tag}_lwe.jsonl
-ls -la $out | tail -12
+ls -la $out | tail -25
