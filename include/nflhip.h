@@ -257,7 +257,7 @@ int nflhip_random_words_dev(nflhip_ctx *ctx, uint64_t *d_out, uint64_t first_wor
 
 /* Discrete Gaussian (FastGaussianNoise<in,out,lu>(sigma, security, samples, center),
  * FastGaussianNoise.hpp:163-290): cumulative table with the reference's tail bound and bit precision
- * (<= 192 bits), sampled by inversion.  The table lives on the context's device.
+ * (<= 384 bits: security parameters up to ~ 360), sampled by inversion.  The table lives on the context's device.
  * Keystream use: the top 64 bits of coefficient g's uniform number are word g of stream (key, stream_id)
  * (g = (first_poly + poly) * degree + i); its lower words -- words (W-1)*g .. of the same stream counted from
  * block 2^63 -- are only generated when the top word ties with a table entry; the sample is exactly the

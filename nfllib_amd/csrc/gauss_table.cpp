@@ -3,8 +3,9 @@
 //
 // The reference computes the barriers with MPFR at bit_precision = ceil(k + log2(2*tail*sigma)) bits, where
 // k = security + 1 + ceil(log2(samples)) and tail solves tail^2 - 2 ln(tail) - 1 - 2 k ln 2 = 0 (lines 239-262).
-// No multiprecision library is assumed here: probabilities are evaluated in 64.192-bit unsigned fixed point
-// (exp by range reduction + Taylor series) and exported with 64*W bits, W = ceil(bit_precision/64) <= 3.
+// No multiprecision library is assumed here: probabilities are evaluated in 64.448-bit unsigned fixed point
+// (exp by range reduction + Taylor series) and exported with 64*W bits, W = ceil(bit_precision/64) <= 6 (security
+// parameters up to ~ 360 bits; the reference takes its precision from MPFR and has no such cap).
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -17,16 +18,33 @@ namespace {
 
 typedef unsigned __int128 u128;
 
-// unsigned fixed point, value = sum l[i] * 2^(64 i - 192); l[3] is the integer part
+// unsigned fixed point, value = sum l[i] * 2^(64 i - FB); l[FL] is the integer part
+constexpr int FL = 7;            // fraction limbs (one guard limb beyond the widest export)
+constexpr int NL = FL + 1;       // limbs
+constexpr int FB = 64 * FL;      // fraction bits
+constexpr int kMaxWords = 6;     // widest exported entry
 struct Fix {
-  uint64_t l[4];
+  uint64_t l[NL];
 };
-static Fix fix_zero() { return Fix{{0, 0, 0, 0}}; }
-static Fix fix_int(uint64_t v) { return Fix{{0, 0, 0, v}}; }
+static Fix fix_zero() {
+  Fix r;
+  for (int i = 0; i < NL; ++i) r.l[i] = 0;
+  return r;
+}
+static Fix fix_int(uint64_t v) {
+  Fix r = fix_zero();
+  r.l[FL] = v;
+  return r;
+}
+static bool fix_is_zero(const Fix &a) {
+  uint64_t o = 0;
+  for (int i = 0; i < NL; ++i) o |= a.l[i];
+  return o == 0;
+}
 static Fix fix_add(const Fix &a, const Fix &b) {
   Fix r;
   u128 c = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NL; ++i) {
     c += (u128)a.l[i] + b.l[i];
     r.l[i] = (uint64_t)c;
     c >>= 64;
@@ -36,7 +54,7 @@ static Fix fix_add(const Fix &a, const Fix &b) {
 static Fix fix_sub(const Fix &a, const Fix &b) {  // a >= b
   Fix r;
   unsigned borrow = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NL; ++i) {
     const u128 t = (u128)a.l[i] - b.l[i] - borrow;
     r.l[i] = (uint64_t)t;
     borrow = (unsigned)((t >> 64) & 1);
@@ -44,47 +62,52 @@ static Fix fix_sub(const Fix &a, const Fix &b) {  // a >= b
   return r;
 }
 static int fix_cmp(const Fix &a, const Fix &b) {
-  for (int i = 3; i >= 0; --i)
+  for (int i = NL - 1; i >= 0; --i)
     if (a.l[i] != b.l[i]) return a.l[i] < b.l[i] ? -1 : 1;
   return 0;
 }
 static Fix fix_mul(const Fix &a, const Fix &b) {  // truncated product (the result must fit)
-  uint64_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; ++i) {
+  uint64_t p[2 * NL];
+  for (int i = 0; i < 2 * NL; ++i) p[i] = 0;
+  for (int i = 0; i < NL; ++i) {
     u128 c = 0;
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NL; ++j) {
       c += (u128)a.l[i] * b.l[j] + p[i + j];
       p[i + j] = (uint64_t)c;
       c >>= 64;
     }
-    p[i + 4] = (uint64_t)c;
+    p[i + NL] = (uint64_t)c;
   }
-  return Fix{{p[3], p[4], p[5], p[6]}};  // >> 192
+  Fix r;
+  for (int i = 0; i < NL; ++i) r.l[i] = p[i + FL];  // >> FB
+  return r;
 }
 static Fix fix_div_small(const Fix &a, uint64_t d) {
   Fix r;
   u128 rem = 0;
-  for (int i = 3; i >= 0; --i) {
+  for (int i = NL - 1; i >= 0; --i) {
     const u128 cur = (rem << 64) | a.l[i];
     r.l[i] = (uint64_t)(cur / d);
     rem = cur % d;
   }
   return r;
 }
-// a / b as fixed point (restoring division, 256 result bits)
+// a / b as fixed point (restoring division, 64*NL result bits)
 static Fix fix_div(const Fix &a, const Fix &b) {
-  // numerator a * 2^192 as 8 limbs, shifted in bit by bit
-  uint64_t num[8] = {0, 0, 0, a.l[0], a.l[1], a.l[2], a.l[3], 0};
+  // numerator a * 2^FB as 2*NL limbs, shifted in bit by bit
+  uint64_t num[2 * NL];
+  for (int i = 0; i < 2 * NL; ++i) num[i] = 0;
+  for (int i = 0; i < NL; ++i) num[i + FL] = a.l[i];
   Fix rem = fix_zero(), q = fix_zero();
-  uint64_t rem_hi = 0;  // bit 256 of the running remainder
-  for (int bit = 447; bit >= 0; --bit) {
+  uint64_t rem_hi = 0;  // the bit above the running remainder
+  for (int bit = 64 * (NL + FL) - 1; bit >= 0; --bit) {
     // rem = (rem << 1) | num[bit]
-    rem_hi = rem.l[3] >> 63;
-    for (int i = 3; i > 0; --i) rem.l[i] = (rem.l[i] << 1) | (rem.l[i - 1] >> 63);
+    rem_hi = rem.l[NL - 1] >> 63;
+    for (int i = NL - 1; i > 0; --i) rem.l[i] = (rem.l[i] << 1) | (rem.l[i - 1] >> 63);
     rem.l[0] = (rem.l[0] << 1) | ((num[bit >> 6] >> (bit & 63)) & 1);
     if (rem_hi || fix_cmp(rem, b) >= 0) {
       rem = fix_sub(rem, b);  // (wraps correctly when rem_hi is set)
-      if (bit < 256) q.l[bit >> 6] |= ((uint64_t)1) << (bit & 63);
+      if (bit < 64 * NL) q.l[bit >> 6] |= ((uint64_t)1) << (bit & 63);
     }
   }
   return q;
@@ -95,33 +118,33 @@ static Fix fix_from_double(double v) {  // v >= 0, exact (a double has 53 signif
   int e;
   const double m = std::frexp(v, &e);             // v = m * 2^e, m in [0.5, 1)
   const uint64_t mant = (uint64_t)std::ldexp(m, 53);  // 53-bit integer
-  const int sh = e - 53 + 192;                     // value = mant * 2^(sh - 192)
+  const int sh = e - 53 + FB;                      // value = mant * 2^(sh - FB)
   for (int i = 0; i < 53; ++i)
     if ((mant >> i) & 1) {
       const int pos = sh + i;
-      if (pos >= 0 && pos < 256) r.l[pos >> 6] |= ((uint64_t)1) << (pos & 63);
+      if (pos >= 0 && pos < 64 * NL) r.l[pos >> 6] |= ((uint64_t)1) << (pos & 63);
     }
   return r;
 }
 // exp(-t), t >= 0
 static Fix fix_exp_neg(const Fix &t) {
-  const uint64_t m = t.l[3];
+  const uint64_t m = t.l[FL];
   Fix f = t;
-  f.l[3] = 0;  // fractional part in [0,1)
+  f.l[FL] = 0;  // fractional part in [0,1)
   // e^-f = sum (-f)^k / k!  (alternating, terms decrease): accumulate positive and negative parts separately
   Fix pos = fix_int(1), neg = fix_zero(), term = fix_int(1);
-  for (uint64_t k = 1; k < 80; ++k) {
+  for (uint64_t k = 1; k < 200; ++k) {
     term = fix_div_small(fix_mul(term, f), k);
-    if (!(term.l[0] | term.l[1] | term.l[2] | term.l[3])) break;
+    if (fix_is_zero(term)) break;
     if (k & 1) neg = fix_add(neg, term); else pos = fix_add(pos, term);
   }
   Fix r = fix_sub(pos, neg);
   if (m) {
     // e^-1 by the same series at f = 1
     Fix p1 = fix_int(1), n1 = fix_zero(), t1 = fix_int(1);
-    for (uint64_t k = 1; k < 80; ++k) {
+    for (uint64_t k = 1; k < 200; ++k) {
       t1 = fix_div_small(t1, k);
-      if (!(t1.l[0] | t1.l[1] | t1.l[2] | t1.l[3])) break;
+      if (fix_is_zero(t1)) break;
       if (k & 1) n1 = fix_add(n1, t1); else p1 = fix_add(p1, t1);
     }
     Fix base = fix_sub(p1, n1);
@@ -157,8 +180,8 @@ int build_gauss_table(double sigma, unsigned security, unsigned samples, double 
   const unsigned bit_precision = (unsigned)std::ceil(epsi);
   int words = (int)((bit_precision + 63) / 64);
   if (words < 1) words = 1;
-  if (words > 3) {
-    *err = "gaussian: the requested security needs more than 192 bits of table precision";
+  if (words > kMaxWords) {
+    *err = "gaussian: the requested security needs more than 384 bits of table precision";
     return 1;
   }
   const long long half = (long long)std::ceil(tail * sigma);
@@ -171,7 +194,7 @@ int build_gauss_table(double sigma, unsigned security, unsigned samples, double 
   // 1 / (2 sigma^2)
   const Fix sig = fix_from_double(sigma);
   const Fix two_sig2 = fix_mul(fix_mul(sig, sig), fix_int(2));
-  if (!(two_sig2.l[0] | two_sig2.l[1] | two_sig2.l[2] | two_sig2.l[3])) {
+  if (fix_is_zero(two_sig2)) {
     *err = "gaussian: sigma too small";
     return 1;
   }
@@ -198,8 +221,8 @@ int build_gauss_table(double sigma, unsigned security, unsigned samples, double 
       for (int w = 0; w < words; ++w) e[w] = ~(uint64_t)0;  // P(X <= max) = 1
       break;
     }
-    const Fix q = fix_div(cum[i], sum);  // in [0,1): fractional limbs l[2] (most significant), l[1], l[0]
-    for (int w = 0; w < words; ++w) e[w] = q.l[2 - w];
+    const Fix q = fix_div(cum[i], sum);  // in [0,1): fractional limbs l[FL-1] (most significant) ... l[0]
+    for (int w = 0; w < words; ++w) e[w] = q.l[FL - 1 - w];
   }
   return 0;
 }

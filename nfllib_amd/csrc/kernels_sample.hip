@@ -550,6 +550,9 @@ hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t coun
     case 1: hipLaunchKernelGGL((k_gauss_noise<1>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
     case 2: hipLaunchKernelGGL((k_gauss_noise<2>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
     case 3: hipLaunchKernelGGL((k_gauss_noise<3>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
+    case 4: hipLaunchKernelGGL((k_gauss_noise<4>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
+    case 5: hipLaunchKernelGGL((k_gauss_noise<5>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
+    case 6: hipLaunchKernelGGL((k_gauss_noise<6>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -573,6 +576,9 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
       case 1: hipLaunchKernelGGL((k_sample_gauss8<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
       case 2: hipLaunchKernelGGL((k_sample_gauss8<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
       case 3: hipLaunchKernelGGL((k_sample_gauss8<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+      case 4: hipLaunchKernelGGL((k_sample_gauss8<T, 4>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+      case 5: hipLaunchKernelGGL((k_sample_gauss8<T, 5>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+      case 6: hipLaunchKernelGGL((k_sample_gauss8<T, 6>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -582,6 +588,9 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
     case 1: hipLaunchKernelGGL((k_sample_gauss<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
     case 2: hipLaunchKernelGGL((k_sample_gauss<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
     case 3: hipLaunchKernelGGL((k_sample_gauss<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+    case 4: hipLaunchKernelGGL((k_sample_gauss<T, 4>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+    case 5: hipLaunchKernelGGL((k_sample_gauss<T, 5>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+    case 6: hipLaunchKernelGGL((k_sample_gauss<T, 6>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

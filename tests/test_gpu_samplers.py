@@ -203,3 +203,26 @@ def test_gaussian_lazy_precision_equals_full_precision_inversion(tie_shift):
     env = dict(os.environ, NFLHIP_GAUSS_TIE_SHIFT=tie_shift)
     out = subprocess.run([sys.executable, "-c", _TIE_CHILD % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "TIE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("sigma,security,words", [(3.19, 256, 5), (20.0, 300, 6), (3.19, 200, 4)])
+def test_gaussian_beyond_192_bits(sigma, security, words, engine_factory):
+    """Tables of 4, 5 and 6 words per entry (the reference takes its precision from MPFR and has no cap,
+    FastGaussianNoise.hpp:239-272): the device sampler is the exact inversion of the very keystream words, incl. with
+    NFLHIP_GAUSS_TIE_SHIFT-style ties resolved by the lower words (here: plain run, the tie path has its own test)."""
+    e = engine_factory(64, 1024, 2)
+    P = _P(e)
+    g = e.gauss_create(sigma, security=security, samples=1024)
+    info = e.gauss_info(g)
+    assert info["words"] == words and info["bit_precision"] > 192
+    tab = info["table"]
+    flat = [int.from_bytes(b"".join(int(v).to_bytes(8, "big") for v in row), "big") for row in tab]
+    assert all(x <= y for x, y in zip(flat, flat[1:])) and (tab[-1] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    v = S.centered(e.to_host(e.sample_gauss(e.empty(64), g, KEY, stream_id=31)), P)[:, 0]
+    r = S.gaussian_words(KEY, 31, 0, 8 * 1024, words)
+    assert np.array_equal(S.gaussian_from_table(r, tab, info["x_min"]), v[:8].reshape(-1))
+    flatv = v.reshape(-1)
+    assert abs(flatv.mean()) < 5 * sigma / np.sqrt(flatv.size) and abs(flatv.var() / sigma ** 2 - 1) < 0.05
+    raw = e.gauss_noise(g, 2048, KEY, stream_id=31).cpu().numpy()
+    assert np.array_equal(raw, flatv[:2048])
+    e.gauss_destroy(g)

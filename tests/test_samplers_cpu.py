@@ -100,9 +100,10 @@ def test_rules_match_live_reference():
 
 
 @pytest.mark.skipif(not O.ref_available(), reason="needs oracle/_ref (the real reference)")
-@pytest.mark.parametrize("sigma,security,center", [(3.19, 128, 0.0), (3.19, 64, 0.0), (20.0, 128, 0.0), (215.0, 100, 0.0), (4.0, 80, 2.5)])
+@pytest.mark.parametrize("sigma,security,center", [(3.19, 128, 0.0), (3.19, 64, 0.0), (20.0, 128, 0.0), (215.0, 100, 0.0), (4.0, 80, 2.5),
+                                                   (3.19, 256, 0.0), (20.0, 300, 1.5)])   # 274 / 321 bits: 5 / 6 words per entry
 def test_gaussian_table_against_the_real_references_barriers(sigma, security, center):
-    """The engine's cumulative table (host arithmetic of gauss_table.cpp: floor(2^(64 W) * CDF), 192-bit fixed point) vs
+    """The engine's cumulative table (host arithmetic of gauss_table.cpp: floor(2^(64 W) * CDF), 448-bit fixed point) vs
     the table the REAL reference computes with MPFR at its bit precision (round(CDF * (2^bp - 1)), one rounding per
     accumulated term): same support, same bit precision, and every entry equal to within the reference's own rounding
     noise -- a few units in the LAST of its bp bits per accumulated term."""
