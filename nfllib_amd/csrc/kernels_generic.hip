@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "modarith.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace nflhip {
@@ -355,6 +356,20 @@ __global__ void k_pointwise(T *out, const T *a, const T *b, const T *bp, const M
   }
 }
 
+// Grid of the grid-stride streaming kernels: the chip's copy rate peaks with two to four 256-thread workgroups per CU
+// (measured on the point-wise kernels, u64/4096/4, batch 16 384: add 5.43 / 5.23 / 5.13 / 4.74 TB/s and mul 5.25 / 5.14 /
+// 5.50 / 5.00 TB/s at 512 / 768 / 1024 / 4096 workgroups; copy kernel: 5.8 TB/s at 1024 against 4.7 at 4096,
+// profiles/r02_ubench_gfx950.txt) -- more resident waves only add DRAM page conflicts.  NFLHIP_STREAM_BLOCKS overrides.
+// The interpreter loop of the expression kernel is the opposite case (it needs the waves to hide its own latency:
+// a*b+d 3.1 TB/s at 768 workgroups, 4.9 at 4096), comparisons and fills are indifferent: they keep their wide grids.
+static inline size_t stream_blocks(size_t items_per_thread_total, size_t dflt = 768) {
+  static const size_t env = getenv("NFLHIP_STREAM_BLOCKS") ? (size_t)atol(getenv("NFLHIP_STREAM_BLOCKS")) : 0;
+  const size_t cap = env ? env : dflt;
+  size_t blocks = (items_per_thread_total + 255) / 256;
+  if (blocks > cap) blocks = cap;
+  return blocks ? blocks : 1;
+}
+
 template <typename T>
 hipError_t launch_pointwise(const Shape &s, const DevTables &t, int op, T *out, const T *a, const T *b, const T *bp,
                             size_t batch, hipStream_t st) {
@@ -363,8 +378,7 @@ hipError_t launch_pointwise(const Shape &s, const DevTables &t, int op, T *out, 
   constexpr size_t V = 16 / sizeof(T);
   if (total % V) return hipErrorInvalidValue;
   const size_t nvec = total / V;
-  size_t blocks = (nvec + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const size_t blocks = stream_blocks(nvec);
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
   const dim3 g((unsigned)blocks), bl(256);
   switch (op) {
@@ -519,6 +533,8 @@ hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const vo
     const size_t vpp = s.nm * s.n / V;
     size_t bx = (vpp + 255) / 256;
     if (bx > 64) bx = 64;
+    // (every polynomial is a grid row: all of them are launched, the column count is what can be trimmed)
+    while (bx > 1 && bx * (batch < 65535 ? batch : 65535) > 4096) bx /= 2;
     // grid.y is limited to 65535: longer batches go in slices (the strides advance the base pointers)
     for (size_t lo = 0; lo < batch; lo += 65535) {
       const size_t cnt = batch - lo < 65535 ? batch - lo : 65535;
@@ -530,8 +546,7 @@ hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const vo
     return hipGetLastError();
   }
   const size_t nvec = total / V;
-  size_t blocks = (nvec + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const size_t blocks = stream_blocks(nvec, 256 * 16);
   hipLaunchKernelGGL((k_eval_expr<T>), dim3((unsigned)blocks), dim3(256), 0, st, out, prog, (const ModConst<T> *)t.mc, s.logn,
                      (int)s.nm, total);
   return hipGetLastError();
@@ -554,8 +569,7 @@ hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const 
   hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
   if (e != hipSuccess || batch == 0) return e;
   const size_t total = batch * s.nm * s.n;
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  const size_t blocks = stream_blocks(total, 2048);
   hipLaunchKernelGGL((k_any_cmp<T>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, total, want_eq, flag);
   return hipGetLastError();
 }
@@ -579,8 +593,7 @@ hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t 
                                int operand, hipStream_t st) {
   if (batch == 0) return hipSuccess;
   const size_t total = batch * s.nm * s.n;
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  const size_t blocks = stream_blocks(total, 256 * 32);
   hipLaunchKernelGGL((k_fill_uniform<T>), dim3((unsigned)blocks), dim3(256), 0, st, d, (const ModConst<T> *)t.mc, s.logn,
                      (int)s.nm, first_poly * s.nm * s.n, total, seed, operand);
   return hipGetLastError();
@@ -778,8 +791,7 @@ __global__ void k_bitrev_rows(T *d, int logn, size_t total) {
 template <typename T> hipError_t launch_bitrev_rows(const Shape &s, T *d, size_t rows, hipStream_t st) {
   if (rows == 0) return hipSuccess;
   const size_t total = rows * s.n;
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  const size_t blocks = stream_blocks(total);
   hipLaunchKernelGGL((k_bitrev_rows<T>), dim3((unsigned)blocks), dim3(256), 0, st, d, s.logn, total);
   return hipGetLastError();
 }
@@ -798,8 +810,7 @@ hipError_t launch_broadcast(void *dst, const void *one, size_t bytes_per_poly, s
   if (count == 0 || bytes_per_poly == 0) return hipSuccess;
   const bool vec = (bytes_per_poly % 16 == 0) && (((uintptr_t)dst | (uintptr_t)one) % 16 == 0);
   const size_t total = vec ? bytes_per_poly / 16 * count : bytes_per_poly * count;
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  const size_t blocks = stream_blocks(total);
   if (vec)
     hipLaunchKernelGGL(k_broadcast, dim3((unsigned)blocks), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)one,
                        bytes_per_poly / 16, total);
