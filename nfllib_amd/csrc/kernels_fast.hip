@@ -354,6 +354,7 @@ enum AsmKind {
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
+  kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
   kAsmCount
 };
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
@@ -366,7 +367,9 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_polymul8192_asm",     "nflhip_polymul_ntt8192_asm",
                                                  "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm",
                                                  "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm",
-                                                 "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm"};
+                                                 "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm",
+                                                 "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
+                                                 "nflhip_ntt_inv4096x2nt_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -394,9 +397,14 @@ static hipFunction_t asm_fn(AsmKind kind) {
 }
 
 // every generated kernel takes (dst, src_a, src_b, psi, mc, nm, logn) and one workgroup per 4096-word block
+static int nt4096() {
+  static const int v = getenv("NFLHIP_NT4096") ? atoi(getenv("NFLHIP_NT4096")) : 1;  // measured +1 % on B (profiles/README)
+  return v;
+}
 static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a,
                              const uint64_t *b, size_t batch, hipStream_t st) {
   if (variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+  if (kind == kAsmPolymul && nt4096() && s.logn == kLogN) kind = kAsmPolymulNt;
   hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
   struct {
@@ -407,7 +415,7 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   // one 256-thread workgroup per 4096-word block, or one 1024-thread workgroup per 16384-word block
-  const int blog = is16k(kind) ? kLogN + 2 : (is8k(kind) ? kLogN + 1 : kLogN);
+  const int blog = is16k(kind) ? kLogN + 2 : (is8k(kind) ? kLogN + 1 : kLogN);  // (kAsmPolymulNt: 4096-word blocks)
   if (s.logn < blog) return hipErrorNotSupported;
   const size_t gx = batch << (s.logn - blog);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
@@ -423,6 +431,7 @@ static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t
   static const int enabled = getenv("NFLHIP_NTT_X2") ? atoi(getenv("NFLHIP_NTT_X2")) : 1;
   if (!enabled || variant() < 50 || !s.small_delta || s.logn != kLogN || s.nm > 65535) return hipErrorNotSupported;
   if (batch < 2 || batch > 0x7fffffffull) return hipErrorNotSupported;
+  if (nt4096()) kind = kind == kAsmFwd2 ? kAsmFwd2Nt : (kind == kAsmInv2 ? kAsmInv2Nt : kind);
   hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
   struct {

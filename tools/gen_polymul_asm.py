@@ -1519,6 +1519,13 @@ def main():
     for kind, (stem, kname) in KERNELS.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind),
                   args=ARGS_STD + [("i32", 48)] if kind in ("fwd2", "inv2") else None)
+    # the n = 4096 product and the two-row transforms with non-temporal coefficient streams (the default; NFLHIP_NT4096=0 = plain)
+    for kind in ("polymul", "fwd2", "inv2"):
+        stem, kname = KERNELS[kind]
+        em_nt = build(kind)
+        em_nt.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em_nt.lines]
+        emit_file(os.path.join(outdir, stem + "nt_gfx950.s"), kname.replace("_asm", "nt_asm"), em_nt,
+                  args=ARGS_STD + [("i32", 48)] if kind in ("fwd2", "inv2") else None)
     emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
     # the same kernel with the coefficient streams marked non-temporal (`nt`): 3 x 15.7 MB of data per product pass
     # through each XCD's 4 MiB L2 exactly once, the 31 MB of twiddle tables are what is worth keeping there
