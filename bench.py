@@ -156,7 +156,8 @@ def measure_traffic(workload, batch):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return tot["FETCH_SIZE"] + tot["WRITE_SIZE"], ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over "
-                                                   "%d products, FETCH x2 (gfx950), per step" % products)
+                                                   "%d products, FETCH x2 (gfx950), per step; read %.4g B + written %.4g B"
+                                                   % (products, tot["FETCH_SIZE"], tot["WRITE_SIZE"]))
 
 
 def main():

@@ -383,6 +383,20 @@ static int pipe32k_on() {
   return v;
 }
 
+// Rows of 65536 / 32768 words in ONE launch of persistent workgroups (kernels_fast.hip launch_polymul_xcd_u64) instead
+// of the chunked pipeline.  NFLHIP_XCD: 0 never, 1 always, unset = when the batch has at most NFLHIP_XCD_MAX_ROWS rows
+// (the pipeline's fill and drain launches dominate small batches; measured crossover in DESIGN.md).  Read on every
+// call, so a test can switch it.
+static bool xcd_on(const nflhip_ctx *ctx, size_t batch) {
+  const char *e = getenv("NFLHIP_XCD");
+  if (e) return atoi(e) != 0;
+  const char *m = getenv("NFLHIP_XCD_MAX_ROWS");
+  // measured (MI355X): n = 32768 / 2 moduli +23 % at batch 64, +18 % at 128, +6 % at 256, +2 % at 512, -2 % at 2048;
+  // n = 65536 / 30 moduli +5 % at batch 4, +11 % at 8, +-0 at 16, -2 % at 64
+  const size_t max_rows = m ? (size_t)atoll(m) : (ctx->shape.logn == 15 ? 1024 : 256);
+  return batch * ctx->shape.nm <= max_rows;
+}
+
 // hipGraph capture: the entry points only enqueue work on the caller's stream, so they can be captured.  The
 // multi-launch plans additionally order successive calls on the shared scratch with events recorded OUTSIDE any
 // capture; inside a capture those waits are illegal (and meaningless: a graph orders its own nodes), so they are
@@ -406,11 +420,34 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   // c may alias a or b: transform a into c first only when that does not clobber b
   const size_t bytes = poly_bytes(ctx, batch);
   lk.lock();
+  const bool cap = is_capturing(st);
+  if (sizeof(T) == 8 && !b_is_ntt && xcd_on(ctx, batch)) {
+    // rows of 65536 / 32768 words: ONE launch of persistent workgroups, every row's three roles on one XCD and the
+    // intermediates through that XCD's L2 (kernels_fast.hip launch_polymul_xcd_u64); needs only a ring of row slots
+    const size_t need = xcd_plan_bytes(ctx->shape, batch);
+    if (need) {
+      int rcx = ensure_scratch(ctx, need);
+      if (rcx) return rcx;
+      if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+      if (!cap && ctx->ev_prev_valid)
+        for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
+      e = launch_polymul_xcd_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b, batch,
+                                 ctx->scratch, st);
+      if (e == hipSuccess) {
+        if (!cap) {
+          HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
+          ctx->ev_scratch_valid = true;
+          for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_scratch, 0));
+        }
+        return NFLHIP_OK;
+      }
+      if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul: one-launch kernel");
+    }
+  }
   int rc = ensure_scratch(ctx, 2 * bytes);
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
-  const bool cap = is_capturing(st);
   if (sizeof(T) == 8 && !b_is_ntt && (ctx->shape.logn == 16 || (ctx->shape.logn == 15 && pipe32k_on())) && pipe64k_chunks() > 0) {
     // n = 65536: the streaming passes (HBM-bound) and the fused block kernel (VALU-bound) of neighbouring chunks share
     // every CU inside ONE kernel whose workgroups take three roles; consecutive launches on the caller's stream form the

@@ -146,6 +146,11 @@ hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, 
 int row16k_level();
 // n = 65536: one launch of the three-role pipeline kernel (block products of chunk j-1, forward streaming pass of
 // chunk j, inverse streaming pass of chunk j-2); hipErrorNotSupported for other shapes
+// one launch for the whole batch, rows pinned to an XCD (n = 65536 / 32768); xcd_plan_bytes() = 0 when the shape / batch
+// is not covered.  `work`: device memory of that many bytes, initialised by the call on `st`.
+size_t xcd_plan_bytes(const Shape &s, size_t batch);
+hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
+                                  size_t batch, void *work, hipStream_t st);
 hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,

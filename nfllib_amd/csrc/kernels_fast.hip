@@ -27,6 +27,7 @@
 
 #include "kernels.h"
 #include "modarith64.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace nflhip {
@@ -354,6 +355,7 @@ enum AsmKind {
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
+  kAsmXcd64k, kAsmXcd32k,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
   kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
   kAsmCount
 };
@@ -368,6 +370,7 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm",
                                                  "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm",
                                                  "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm",
+                                                 "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
                                                  "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
                                                  "nflhip_ntt_inv4096x2nt_asm"};
 struct AsmKernel {
@@ -488,6 +491,83 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
   const size_t gx = (size_t)mx * (s.logn == 16 ? 28 : 14);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
   return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+}
+
+// n = 65536 / 32768, whole batch in ONE launch of persistent workgroups (tools/gen_polymul_asm.py fused_header): the three
+// roles of a row run on one XCD and hand the intermediates over through that XCD's L2.  `work` is device memory of at
+// least xcd_plan_bytes(); it is (re)initialised here, on `st`.
+// development aid: a device buffer of 8 x 65536 16-byte records {ticket | role << 28, t0, t1, t2} (s_memtime low words: draw,
+// dependencies met, done) filled by the next launches; see tools/xcd_trace.py
+static void *g_xcd_trace = nullptr;
+extern "C" void nflhip_debug_xcd_trace(void *device_buffer) { g_xcd_trace = device_buffer; }
+static std::atomic<unsigned long long> g_xcd_launches{0};
+extern "C" unsigned long long nflhip_debug_xcd_launches(void) { return g_xcd_launches.load(); }  // tests: which plan ran
+__global__ void k_xcd_reset(uint4 *ctl) {   // block 0: the header; block d + 1: record d at byte 4096 + 69632 d
+  uint4 *p = blockIdx.x == 0 ? ctl : ctl + (4096 + (size_t)(blockIdx.x - 1) * 0x11000) / 16;
+  p[threadIdx.x] = make_uint4(0, 0, 0, 0);
+}
+struct XcdPlan {
+  int rlog, wgs, dlog;
+  unsigned magic;
+  size_t ctl_bytes, slot_bytes, total;
+};
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static bool xcd_plan(const Shape &s, size_t batch, XcdPlan *p) {
+  if (s.limb_bits != 64 || (s.logn != 16 && s.logn != 15) || variant() < 50 || !s.small_delta || s.nm > 65535) return false;
+  // the kernel derives a row's XCD from the hardware XCC id: it needs the whole 8-XCD device (no compute partition)
+  static int cus[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (cus[dev] != 256) return false;
+  const unsigned long long rows = (unsigned long long)batch * s.nm;
+  if (batch < 2 || rows < 8 || rows > 0x0fffffffull) return false;  // every XCD serves rows xcd, xcd + 8, ...
+  const bool pow2 = (batch & (batch - 1)) == 0;
+  if (!pow2 && rows * batch >= (1ull << 32)) return false;  // the kernel divides row numbers by the batch with one multiply
+  p->magic = (unsigned)(pow2 ? (1ull << 32) / batch : (1ull << 32) / batch + 1);
+  p->rlog = env_int("NFLHIP_XCD_RLOG", 3);  // 2^rlog rows in flight per scheduling domain
+  p->dlog = env_int("NFLHIP_XCD_DLOG", 2);  // 2^dlog scheduling domains per XCD (measured: 1 domain 13.8 k, 2: 23.7 k, 4: 26.1 k products/s)
+  p->wgs = env_int("NFLHIP_XCD_WGS", 768);
+  if (p->rlog < 1 || p->rlog > 5 || p->dlog < 0 || p->dlog > 3 || p->wgs < 256 || rows < (8ull << p->dlog)) return false;
+  p->ctl_bytes = 4096 + ((size_t)8 << p->dlog) * 0x11000;  // word 0: next row; one 256 B scheduler record per XCD, 68 KiB apart, from byte 4096
+  p->slot_bytes = (size_t)rows * (s.n * 8);  // per operand: the scratch mirrors the batch (every row its own scratch rows)
+  p->total = p->ctl_bytes + 2 * p->slot_bytes;
+  return true;
+}
+size_t xcd_plan_bytes(const Shape &s, size_t batch) {
+  XcdPlan p;
+  return xcd_plan(s, batch, &p) ? p.total : 0;
+}
+hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
+                                  size_t batch, void *work, hipStream_t st) {
+  XcdPlan p;
+  if (!xcd_plan(s, batch, &p)) return hipErrorNotSupported;
+  hipFunction_t fn = asm_fn(s.logn == 16 ? kAsmXcd64k : kAsmXcd32k);
+  if (!fn) return hipErrorNotSupported;
+  // fresh counters: word block 0 (workgroups that joined, per XCD) and the first KiB of every domain's record
+  hipLaunchKernelGGL(k_xcd_reset, dim3((8u << p.dlog) + 1), dim3(64), 0, st, (uint4 *)work);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  char *w = (char *)work;
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    int nm, logn;
+    int rows, batch;
+    unsigned magic;
+    int d, rlog, jmax, spin, inv;
+    void *scr_a, *scr_b, *ctl, *trace;
+  } args = {c, a, b, t.psi, t.mc, (int)s.nm, s.logn, (int)(batch * s.nm), (int)batch, p.magic, p.dlog, p.rlog, 0,
+            env_int("NFLHIP_XCD_SPIN", 1 << 22), 0, w + p.ctl_bytes, w + p.ctl_bytes + p.slot_bytes, w,
+            g_xcd_trace};
+  static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_xcd*_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  g_xcd_launches.fetch_add(1);
+  return hipModuleLaunchKernel(fn, (unsigned)p.wgs, 1, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
 
 hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,

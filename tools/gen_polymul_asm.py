@@ -1210,39 +1210,8 @@ def emit_consts(em):
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
 
 
-def build_pipe(logn=None):
-    """n = 65536 (logn 16): radix-16 streaming roles, 16 + 3 x 4 = 28 workgroups per row.
-    n = 32768 (logn 15): radix-8 streaming roles (a thread's 16 registers hold two columns of 8 words), 8 + 3 x 2 = 14."""
-    global PIPE_LOGN
-    if logn is not None:
-        PIPE_LOGN = logn
-    em = Emitter()
+def legacy_role_map(em, PER_ROW, NV, NSW):
     R = em.raw
-    n_words = 1 << PIPE_LOGN
-    RL = PIPE_LOGN - 12                                   # global stages done by the streaming roles: 4 (radix 16) or 3 (radix 8)
-    RADIX = 1 << RL
-    NV = n_words // 4096                                  # block products per row
-    NSW = 4 if RL == 4 else 2                             # streaming workgroups per row and operand
-    PER_ROW = NV + 3 * NSW
-    CG_LOG = 11 if RL == 4 else 12                        # bytes (log2) of one column group: 256 columns x (16 / RADIX) x 8 B
-    stride = n_words // RADIX * 8                         # bytes between x[o + k n/RADIX]
-    R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c_v, a_v, b_v, psi
-    R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
-    R("s_load_dword s14, s[0:1], 0x28")                  # nm
-    R("s_load_dwordx16 s[56:71], s[0:1], 0x30")          # cntV cntF cntI pad | fa_src fa_dst fb_src fb_dst inv pad
-    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
-    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                     # B = t >> 4
-    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
-    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
-    em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
-    em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
-    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_BIDX, V_L2R, V_L1R))     # 272*B + r
-    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
-    em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
-    em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
-    for t0 in sorted(set(V_T)):
-        em.valu("v_mov_b32_e32 v%d, 0" % (t0 + 15,))                                # the persistent zero of ZP
-    R("s_waitcnt lgkmcnt(0)")
     # Dense role map, no idle workgroups (a workgroup launch costs ~35 ns of dispatcher time chip-wide, measured):
     # 28 workgroups per polynomial row -- w = wgx mod 28: 0..15 block products, 16..19 / 20..23 forward streaming of
     # a / b (four column groups each), 24..27 inverse streaming.  28 = 4 mod 8, so the XCD of a role rotates with the
@@ -1268,6 +1237,451 @@ def build_pipe(logn=None):
     R("s_cmp_eq_u32 s42, 3")
     R("s_cbranch_scc1 .Lrole_i")
 
+
+# ------------------------------------------------------------------ one launch, rows pinned to an XCD
+# The two-pass plan for rows that do not fit one CU moves every word 3 times (operand -> scratch -> scratch -> result):
+# 9 word transfers per 3 algorithmic ones when the scratch lives in HBM.  Here the scratch of a row lives in the L2 of
+# ONE XCD for the few microseconds between its producer and its consumer:
+#   * row g of the batch (modulus-major: g = cm * batch + poly, so all XCDs work on the same modulus at the same time and
+#     its twiddles stay in every L2) is job g / 8 of XCD g mod 8.  The grid is a fixed number of PERSISTENT workgroups;
+#     each reads its XCC_ID once and then serves that XCD's jobs, whatever the placement of the workgroups.
+#   * a job is 2 NSW forward streaming roles, then NV block products, then NSW inverse streaming roles.  Per XCD and kind
+#     there is a CREDIT counter (roles that may start) and a TICKET counter (roles handed out, in job order).  A free
+#     workgroup (its wave 0) reads the credits with one load, takes one with an atomic subtract (undone if it lost a race)
+#     in the order inverse > product > forward -- inverse-first drains rows as fast as they mature -- and then draws the
+#     next ticket of that kind.  Nothing spins on a shared word while work is available, and no atomic ever has to be
+#     retried: hand-out is two fetch-and-adds.
+#   * credits are posted by the role that completes a stage of a job (it sees the per-slot completion counter reach the
+#     stage's size): forward -> NV product credits, product -> NSW inverse credits, inverse -> 2 NSW forward credits for
+#     the job that reuses the scratch slot (R slots per XCD, job j uses slot j mod R).  Stages may complete out of job
+#     order while tickets are in job order, so a role re-checks its own job's inputs before touching them; if k stages
+#     have completed, the tickets of the first k jobs' roles of that stage have all been handed out (tickets are in
+#     order), hence such a wait is only ever for roles that are already running: no deadlock.
+#   * a role publishes "done" with one atomic add after all its stores were acknowledged by the L2 (s_waitcnt vmcnt(0) +
+#     s_barrier); producer and consumer share the L2, nothing is written back in between.  The consumer's L1 is the one
+#     cache that is not coherent with it, and it is kept out of the way by construction instead of by invalidation: every
+#     row has its OWN scratch rows (the scratch mirrors the batch), so within a launch a scratch word is loaded by exactly
+#     one workgroup after its last write, on a CU that either never touched the line or wrote it itself (block product:
+#     reads a'[k], writes c'[k] over it -- write-through keeps its own L1 current); L1s start a launch invalidated.
+#     What was measured on the way (tools/probes/l2_flag_probe.hip, profiles/README): workgroup-scope (sc0) loads hit
+#     in the L1 and never see another CU's update; device-scope (sc1) loads and atomics are served memory-side (0.15 -
+#     0.5 us) -- scratch read with sc1 loads was correct but moved MORE HBM bytes than the chunked pipeline (3.8x vs 3.3x
+#     the algorithmic bytes); `buffer_inv sc0` does not reliably drop stale lines (wrong words in 4 of 9 runs).
+#     The ring only bounds the rows in flight (R per domain): its slots index the completion counters.
+# Kernel arguments after the standard seven: rows, batch, ceil(2^32 / batch), log2 D | Rlog, -, spin limit, - | scrA, scrB,
+# ctl, trace buffer (or null).  D = scheduling domains per XCD (each with its own record, jobs and ring; they only share the
+# L2).  ctl: +64 + 4 xcd: workgroups that joined; the record of domain d = xcd + 8 sub at byte 4096 + 69632 d (zeroed by the host):
+#   +0 credits {forward (biased by the initial min(R, jobs) * 2 NSW), product, inverse}, +12 exit flag, +16 trace count
+#   +128 tickets {forward, product, inverse}      +256 + 16 slot: completed {forward, product, inverse} roles (all epochs)
+FUSED_NT = int(os.environ.get("NFL_FUSED_NT", "1"))
+FUSED_LOADS = ""                         # modifier of the scratch loads: " sc1" = device scope (L1 bypass), "" = plain after a buffer_inv sc0
+LDS_TICKET = (4096 + 256) * 8           # 64 B behind the exchange slab: wave 0's decision and the running role's completion record
+
+
+def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
+    R = em.raw
+    L = em.lines.append
+    NB = PIPE_LOGN + 3                                    # log2 bytes of a row
+    LI, LV, LF = NSW.bit_length() - 1, NV.bit_length() - 1, NSW.bit_length()   # log2 roles per job: inverse, product, forward
+    Z = V_ZERO
+    T = LDS_TICKET      # +0 kind, +4 ticket | +16 counter offset (0: none), +20 target, +24 credit offset, +28 amount | +32 id, +36 t0, +40 t1
+
+    def lane0():
+        R("s_mov_b64 exec, 1")
+
+    def all_lanes():
+        R("s_mov_b64 exec, -1")
+
+    def poll(name, off_sgpr, want_sgpr):
+        """wait until the dword at record + off_sgpr equals want_sgpr (normally true at once); bounded"""
+        R("s_add_u32 s84, s72, %s" % off_sgpr)
+        R("s_addc_u32 s85, s73, 0")
+        R("s_mov_b32 s92, 0")
+        L(".Lpoll_%s:" % name)
+        R("global_load_dword v7, v%d, s[84:85] sc1" % Z)
+        R("s_waitcnt vmcnt(0)")
+        R("v_readfirstlane_b32 s91, v7")
+        R("s_cmp_eq_u32 s91, %s" % want_sgpr)
+        R("s_cbranch_scc1 .Lpoll_%s_done" % name)
+        R("s_sleep 4")
+        R("s_add_u32 s92, s92, 1")
+        R("s_cmp_lt_u32 s92, s62")
+        R("s_cbranch_scc1 .Lpoll_%s" % name)
+        R("s_trap 2")                                    # an input that never completes: fail loudly, do not hang
+        L(".Lpoll_%s_done:" % name)
+
+    def take(kind, cdw, bias, nxt):
+        """wave 0, lane 0 active: take one credit of counter cdw (effective value = stored + bias SGPR or 0), then a ticket"""
+        R("v_mov_b32_e32 v12, 1")
+        R("global_atomic_sub v12, v%d, v12, s[72:73] offset:%d sc0" % (Z, 4 * cdw))
+        R("s_waitcnt vmcnt(0)")
+        R("v_readfirstlane_b32 s84, v12")
+        if bias:
+            R("s_add_u32 s84, s84, %s" % bias)
+        R("s_cmp_gt_i32 s84, 0")
+        R("s_cbranch_scc1 .Ltook_%d" % kind)
+        R("v_mov_b32_e32 v12, 1")
+        R("global_atomic_add v%d, v12, s[72:73] offset:%d" % (Z, 4 * cdw))   # lost the race for the last credit: give it back
+        R("s_branch %s" % nxt)
+        L(".Ltook_%d:" % kind)
+        R("v_mov_b32_e32 v12, 1")
+        R("global_atomic_add v12, v%d, v12, s[72:73] offset:%d sc0" % (Z, 128 + 4 * cdw))
+        R("s_waitcnt vmcnt(0)")
+        R("v_readfirstlane_b32 s83, v12")
+        R("s_mov_b32 s82, %d" % kind)
+        R("s_branch .Ldecided")
+
+    def stamp_t1(name):
+        """trace: the role's inputs are ready (wave 0 keeps the stamp in LDS)"""
+        R("v_readfirstlane_b32 s84, v%d" % V_TID)
+        R("s_cmp_lg_u32 s84, 0")
+        R("s_cbranch_scc1 .Lt1_%s" % name)
+        R("s_memtime s[84:85]")
+        lane0()
+        R("s_waitcnt lgkmcnt(0)")
+        R("v_mov_b32_e32 v8, s84")
+        R("ds_write_b32 v%d, v8 offset:%d" % (Z, T + 40))
+        all_lanes()
+        L(".Lt1_%s:" % name)
+
+    # scheduling domain of this workgroup: 2^s59 independent domains per XCD (own record, own jobs, own ring) keep the
+    # atomic traffic per record line low; workgroups of an XCD join them round-robin.  s98 = domain = xcd + 8 * sub
+    R("s_getreg_b32 s98, hwreg(HW_REG_XCC_ID, 0, 4)")
+    R("s_and_b32 s98, s98, 7")
+    R("s_load_dwordx16 s[56:71], s[0:1], 0x30")
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_lshl_b32 s42, s98, 2")
+    R("s_add_u32 s42, s42, 64")
+    R("s_add_u32 s72, s68, s42")
+    R("s_addc_u32 s73, s69, 0")                          # ctl + 64 + 4 xcd: workgroups of this XCD seen so far
+    R("v_readfirstlane_b32 s74, v%d" % V_TID)
+    R("s_cmp_lg_u32 s74, 0")
+    R("s_cbranch_scc1 .Ldom_wait")
+    lane0()
+    R("v_mov_b32_e32 v7, 1")
+    R("global_atomic_add v7, v%d, v7, s[72:73] sc0" % Z)
+    R("v_mov_b32_e32 v8, 0")
+    R("s_waitcnt vmcnt(0)")
+    R("ds_write_b32 v%d, v7 offset:%d" % (Z, T))
+    R("ds_write_b32 v%d, v8 offset:%d" % (Z, T + 16))    # no completion to publish yet
+    R("s_waitcnt lgkmcnt(0)")
+    all_lanes()
+    L(".Ldom_wait:")
+    R("s_barrier")
+    R("ds_read_b32 v7, v%d offset:%d" % (Z, T))
+    R("s_waitcnt lgkmcnt(0)")
+    R("v_readfirstlane_b32 s74, v7")
+    R("s_lshl_b32 s75, 1, s59")
+    R("s_sub_u32 s75, s75, 1")
+    R("s_and_b32 s74, s74, s75")                         # sub
+    R("s_lshl_b32 s74, s74, 3")
+    R("s_add_u32 s98, s98, s74")
+    R("s_barrier")                                       # (wave 0 reuses the LDS word)
+    R("s_branch .Lticket")
+    L(".Lnext:")
+    R("s_waitcnt vmcnt(0) lgkmcnt(0)")                   # this wave's stores are in the L2
+    R("s_barrier")
+    L(".Lticket:")
+    R("s_load_dwordx16 s[56:71], s[0:1], 0x30")
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mul_i32 s42, s98, 0x11000")
+    R("s_add_u32 s42, s42, 4096")                        # records 68 KiB apart (different memory channels)
+    R("s_add_u32 s72, s68, s42")
+    R("s_addc_u32 s73, s69, 0")                          # s[72:73]: this XCD's record
+    R("s_add_u32 s93, s59, 3")                           # log2 of the number of domains
+    R("s_lshl_b32 s42, 1, s93")
+    R("s_sub_u32 s42, s42, 1")
+    R("s_sub_u32 s99, s56, s98")
+    R("s_add_u32 s99, s99, s42")
+    R("s_lshr_b32 s99, s99, s93")                        # jobs of this domain: rows dom, dom + 8 D, ...  (rows >= 8 D checked by the host)
+    R("v_readfirstlane_b32 s74, v%d" % V_TID)
+    R("s_cmp_lg_u32 s74, 0")
+    R("s_cbranch_scc1 .Lsched_done")                     # waves 1..3 wait at the barrier for wave 0's decision
+    # ---- wave 0: publish the finished role (and the credits it releases), then find the next one
+    R("s_memtime s[86:87]")
+    lane0()
+    R("ds_read_b128 v[8:11], v%d offset:%d" % (Z, T + 16))  # counter offset, target, credit offset, amount
+    R("ds_read_b128 v[14:17], v%d offset:%d" % (Z, T + 32)) # id, t0, t1, -
+    R("s_waitcnt lgkmcnt(0)")
+    R("v_readfirstlane_b32 s74, v8")
+    R("s_cmp_eq_u32 s74, 0")
+    R("s_cbranch_scc1 .Lt_noflag")
+    R("v_readfirstlane_b32 s75, v9")
+    R("v_readfirstlane_b32 s76, v10")
+    R("v_readfirstlane_b32 s77, v11")
+    R("s_add_u32 s84, s72, s74")
+    R("s_addc_u32 s85, s73, 0")
+    R("v_mov_b32_e32 v12, 1")
+    R("global_atomic_add v12, v%d, v12, s[84:85] sc0" % Z)  # the role just finished: one more "done"
+    R("s_waitcnt vmcnt(0)")
+    R("v_readfirstlane_b32 s78, v12")
+    R("s_add_u32 s78, s78, 1")
+    R("s_cmp_eq_u32 s78, s75")
+    R("s_cbranch_scc0 .Lt_posted")                       # not the last role of its stage
+    R("s_cmp_eq_u32 s77, 0")
+    R("s_cbranch_scc1 .Lt_posted")
+    R("s_add_u32 s84, s72, s76")
+    R("s_addc_u32 s85, s73, 0")
+    R("v_mov_b32_e32 v12, s77")
+    R("global_atomic_add v%d, v12, s[84:85]" % Z)        # the next stage of that job (or the slot's next job) may start
+    L(".Lt_posted:")
+    # optional trace record {ticket | kind << 28, t0, t1, t2} (low words of s_memtime), 16 B per role, 2^16 per XCD
+    R("s_cmp_eq_u64 s[70:71], 0")
+    R("s_cbranch_scc1 .Lt_noflag")
+    R("v_mov_b32_e32 v12, 1")
+    R("global_atomic_add v12, v%d, v12, s[72:73] offset:16 sc0" % Z)
+    R("s_waitcnt vmcnt(0)")
+    R("v_readfirstlane_b32 s74, v12")
+    R("s_and_b32 s74, s74, 0xffff")
+    R("s_lshl_b32 s75, s98, 16")
+    R("s_or_b32 s74, s74, s75")
+    R("s_lshl_b32 s74, s74, 4")
+    R("s_add_u32 s74, s70, s74")
+    R("s_addc_u32 s75, s71, 0")
+    R("v_mov_b32_e32 v17, s86")
+    R("global_store_dwordx4 v%d, v[14:17], s[74:75]" % Z)
+    L(".Lt_noflag:")
+    R("v_mov_b32_e32 v8, 0")
+    R("v_mov_b32_e32 v9, s86")
+    R("ds_write_b32 v%d, v8 offset:%d" % (Z, T + 16))    # nothing to publish until a role is set up
+    R("ds_write_b32 v%d, v9 offset:%d" % (Z, T + 36))    # t0: this workgroup is free
+    R("s_mov_b32 s88, 0")                                # polls so far
+    R("s_lshl_b32 s79, 1, s60")                          # R
+    R("s_min_u32 s79, s79, s99")
+    R("s_lshl_b32 s79, s79, %d" % LF)                    # forward credits the host's zero stands for: min(R, jobs) * 2 NSW
+    L(".Lsched:")
+    R("global_load_dwordx4 v[8:11], v%d, s[72:73] sc1" % Z)   # sc1: device scope; plain and sc0 loads hit in the L1
+    R("s_waitcnt vmcnt(0)")
+    R("v_readfirstlane_b32 s77, v10")                    # inverse credits
+    R("s_cmp_gt_i32 s77, 0")
+    R("s_cbranch_scc0 .Lsee_v")
+    take(3, 2, None, ".Lsee_v")
+    L(".Lsee_v:")
+    R("v_readfirstlane_b32 s76, v9")                     # product credits
+    R("s_cmp_gt_i32 s76, 0")
+    R("s_cbranch_scc0 .Lsee_f")
+    take(0, 1, None, ".Lsee_f")
+    L(".Lsee_f:")
+    R("v_readfirstlane_b32 s75, v8")                     # forward credits (biased)
+    R("s_add_u32 s75, s75, s79")
+    R("s_cmp_gt_i32 s75, 0")
+    R("s_cbranch_scc0 .Lsee_exit")
+    take(1, 0, "s79", ".Lsee_exit")
+    L(".Lsee_exit:")
+    R("v_readfirstlane_b32 s78, v11")
+    R("s_cmp_eq_u32 s78, 0")
+    R("s_cbranch_scc1 .Lnothing")
+    R("s_mov_b32 s82, 4")                                # every inverse role has been handed out: done
+    R("s_mov_b32 s83, 0")
+    R("s_branch .Ldecided")
+    L(".Lnothing:")
+    R("s_sleep 8")
+    R("s_cmp_lt_u32 s88, 8")
+    R("s_cbranch_scc1 .Lnothing_short")
+    R("s_sleep 60")                                      # nothing for a while: poll every ~2 us
+    L(".Lnothing_short:")
+    R("s_add_u32 s88, s88, 1")
+    R("s_cmp_lt_u32 s88, s62")
+    R("s_cbranch_scc1 .Lsched")
+    R("s_trap 2")                                        # nothing became ready for seconds: fail loudly, do not hang
+    L(".Ldecided:")
+    R("v_mov_b32_e32 v10, s82")
+    R("v_mov_b32_e32 v11, s83")
+    R("ds_write_b64 v%d, v[10:11] offset:%d" % (Z, T))
+    R("s_waitcnt lgkmcnt(0)")
+    all_lanes()
+    L(".Lsched_done:")
+    R("s_barrier")
+    R("ds_read_b64 v[10:11], v%d offset:%d" % (Z, T))
+    R("s_waitcnt lgkmcnt(0)")
+    R("v_readfirstlane_b32 s42, v10")                    # kind: 0 product, 1 forward, 3 inverse, 4 exit
+    R("v_readfirstlane_b32 s2, v11")                     # role number within its kind
+    R("s_cmp_eq_u32 s42, 4")
+    R("s_cbranch_scc0 .Lwork")
+    R("S_EXIT")
+    L(".Lwork:")
+    # ---- job, slot and sub-index of the role; its completion record
+    #      s74 job, s77 slot, s78 epoch, s89 sub-index; s75 byte offset of the counter to bump, s76 its value when the stage
+    #      is complete, s80 the credit word that stage completion feeds, s81 how many credits
+    R("s_cmp_eq_u32 s42, 3")
+    R("s_cbranch_scc0 .Ldec_not_i")
+    R("s_lshr_b32 s74, s2, %d" % LI)
+    R("s_and_b32 s89, s2, %d" % (NSW - 1))
+    R("s_mov_b32 s75, 8")
+    R("s_mov_b32 s76, %d" % NSW)
+    R("s_mov_b32 s80, 0")                                # -> forward credits of the job that reuses the slot ...
+    R("s_lshl_b32 s81, 1, s60")
+    R("s_add_u32 s81, s81, s74")
+    R("s_cmp_lt_u32 s81, s99")                           # ... if there is one
+    R("s_cselect_b32 s81, %d, 0" % (2 * NSW))
+    R("s_add_u32 s43, s2, 1")
+    R("s_lshl_b32 s83, s99, %d" % LI)
+    R("s_cmp_eq_u32 s43, s83")                           # the XCD's last inverse role: tell the idle workgroups to leave
+    R("s_cbranch_scc0 .Ldec_done")
+    R("v_readfirstlane_b32 s43, v%d" % V_TID)
+    R("s_cmp_lg_u32 s43, 0")
+    R("s_cbranch_scc1 .Ldec_done")
+    lane0()
+    R("v_mov_b32_e32 v7, 1")
+    R("global_atomic_add v%d, v7, s[72:73] offset:12" % Z)
+    all_lanes()
+    R("s_branch .Ldec_done")
+    L(".Ldec_not_i:")
+    R("s_cmp_eq_u32 s42, 0")
+    R("s_cbranch_scc0 .Ldec_f")
+    R("s_lshr_b32 s74, s2, %d" % LV)
+    R("s_and_b32 s89, s2, %d" % (NV - 1))
+    R("s_mov_b32 s75, 4")
+    R("s_mov_b32 s76, %d" % NV)
+    R("s_mov_b32 s80, 8")                                # -> inverse credits
+    R("s_mov_b32 s81, %d" % NSW)
+    R("s_branch .Ldec_done")
+    L(".Ldec_f:")
+    R("s_lshr_b32 s74, s2, %d" % LF)
+    R("s_and_b32 s89, s2, %d" % (2 * NSW - 1))
+    R("s_mov_b32 s75, 0")
+    R("s_mov_b32 s76, %d" % (2 * NSW))
+    R("s_mov_b32 s80, 4")                                # -> product credits
+    R("s_mov_b32 s81, %d" % NV)
+    L(".Ldec_done:")
+    R("s_lshl_b32 s43, 1, s60")
+    R("s_sub_u32 s43, s43, 1")
+    R("s_and_b32 s77, s74, s43")                         # slot
+    R("s_lshr_b32 s78, s74, s60")                        # epoch
+    R("s_lshl_b32 s43, s77, 4")
+    R("s_add_u32 s43, s43, 256")                         # the slot's counters
+    R("s_add_u32 s75, s75, s43")
+    R("s_add_u32 s83, s78, 1")
+    R("s_mul_i32 s76, s76, s83")                         # the counter's value when this job's stage is complete
+    R("v_readfirstlane_b32 s84, v%d" % V_TID)
+    R("s_cmp_lg_u32 s84, 0")
+    R("s_cbranch_scc1 .Lrec_done")
+    lane0()
+    R("v_mov_b32_e32 v8, s75")
+    R("v_mov_b32_e32 v9, s76")
+    R("v_mov_b32_e32 v10, s80")
+    R("v_mov_b32_e32 v11, s81")
+    R("ds_write_b128 v%d, v[8:11] offset:%d" % (Z, T + 16))
+    R("s_lshl_b32 s84, s42, 28")
+    R("s_and_b32 s85, s2, 0xfffffff")
+    R("s_or_b32 s84, s84, s85")
+    R("v_mov_b32_e32 v8, s84")
+    R("ds_write_b32 v%d, v8 offset:%d" % (Z, T + 32))
+    all_lanes()
+    L(".Lrec_done:")
+    # ---- the job's row: g = 8 D job + domain (modulus-major)
+    R("s_add_u32 s84, s59, 3")
+    R("s_lshl_b32 s84, s74, s84")
+    R("s_add_u32 s84, s84, s98")
+    R("s_mul_hi_u32 s3, s84, s58")                       # cm = g / batch
+    R("s_mul_i32 s43, s3, s57")
+    R("s_sub_u32 s86, s84, s43")                         # poly
+    R("s_mul_i32 s87, s86, s14")
+    R("s_add_u32 s87, s87, s3")                          # row = poly*nm + cm
+    R("s_lshl_b32 s43, s3, %d" % (PIPE_LOGN + 4,))
+    R("s_add_u32 s22, s10, s43")
+    R("s_addc_u32 s23, s11, 0")                          # twiddles of the modulus
+    R("s_lshr_b32 s83, s87, %d" % (32 - NB))
+    R("s_lshl_b32 s82, s87, %d" % NB)                    # s[82:83]: byte offset of the row in the batch ...
+    R("s_mov_b64 s[80:81], s[82:83]")                    # ... and in the scratch, which mirrors the batch (see above)
+    R("s_lshl_b32 s43, s77, 4")
+    R("s_add_u32 s79, s43, 256")                         # byte offset of the slot's counters in the record
+    R("s_cmp_eq_u32 s42, 0")
+    R("s_cbranch_scc1 .Lprep_v")
+    R("s_cmp_eq_u32 s42, 3")
+    R("s_cbranch_scc1 .Lprep_i")
+    # ---- forward streaming role: operand s89 >> log NSW, column groups q = s89 mod NSW; the slot must be drained
+    R("s_lshl_b32 s76, s78, %d" % LI)                    # inverse roles completed on the slot by earlier epochs
+    R("s_add_u32 s75, s79, 8")
+    poll("slot", "s75", "s76")
+    R("s_lshr_b32 s42, s89, %d" % LI)
+    R("s_and_b32 s89, s89, %d" % (NSW - 1))
+    R("s_lshl_b32 s43, s89, %d" % CG_LOG)                # the bytes of q column groups
+    R("s_add_u32 s80, s80, s43")
+    R("s_add_u32 s82, s82, s43")                         # (no carries: the low bits were zero)
+    R("s_cmp_eq_u32 s42, 0")
+    R("s_cselect_b64 s[16:17], s[6:7], s[8:9]")
+    R("s_cselect_b64 s[20:21], s[64:65], s[66:67]")
+    R("s_add_u32 s16, s16, s82")
+    R("s_addc_u32 s17, s17, s83")
+    R("s_add_u32 s20, s20, s80")
+    R("s_addc_u32 s21, s21, s81")
+    R("s_mov_b32 s90, 1")
+    stamp_t1("f")
+    R("s_branch .Lbody_f")
+    L(".Lprep_i:")
+    R("s_add_u32 s76, s78, 1")
+    R("s_lshl_b32 s76, s76, %d" % LV)                    # every block product of the job
+    R("s_add_u32 s75, s79, 4")
+    poll("vdone", "s75", "s76")
+    R("s_lshl_b32 s43, s89, %d" % CG_LOG)
+    R("s_add_u32 s80, s80, s43")
+    R("s_add_u32 s82, s82, s43")
+    R("s_add_u32 s16, s64, s80")
+    R("s_addc_u32 s17, s65, s81")
+    R("s_add_u32 s20, s4, s82")
+    R("s_addc_u32 s21, s5, s83")
+    R("s_mov_b32 s95, 2")
+    stamp_t1("i")
+    R("s_branch .Lbody_i")
+    L(".Lprep_v:")
+    R("s_add_u32 s76, s78, 1")
+    R("s_lshl_b32 s76, s76, %d" % LF)                    # every forward role of the job
+    R("s_mov_b32 s75, s79")
+    poll("fdone", "s75", "s76")
+    R("s_lshl_b32 s43, s89, 15")
+    R("s_add_u32 s80, s80, s43")
+    R("s_add_u32 s16, s64, s80")
+    R("s_addc_u32 s17, s65, s81")
+    R("s_add_u32 s18, s66, s80")
+    R("s_addc_u32 s19, s67, s81")
+    R("s_mov_b64 s[20:21], s[16:17]")                    # the block product overwrites its a' block
+    stamp_t1("v")
+    R("s_branch .Lbody_v")
+
+
+def build_pipe(logn=None, fused=False):
+    """n = 65536 (logn 16): radix-16 streaming roles, 16 + 3 x 4 = 28 workgroups per row.
+    n = 32768 (logn 15): radix-8 streaming roles (a thread's 16 registers hold two columns of 8 words), 8 + 3 x 2 = 14.
+    fused: ONE launch of persistent workgroups for the whole batch; the three roles of a row run on ONE XCD, ordered by
+    a per-XCD ticket queue and per-row completion counters, so the intermediates travel through that XCD's L2
+    (see fused_header below)."""
+    global PIPE_LOGN
+    if logn is not None:
+        PIPE_LOGN = logn
+    em = Emitter()
+    R = em.raw
+    n_words = 1 << PIPE_LOGN
+    RL = PIPE_LOGN - 12                                   # global stages done by the streaming roles: 4 (radix 16) or 3 (radix 8)
+    RADIX = 1 << RL
+    NV = n_words // 4096                                  # block products per row
+    NSW = 4 if RL == 4 else 2                             # streaming workgroups per row and operand
+    PER_ROW = NV + 3 * NSW
+    CG_LOG = 11 if RL == 4 else 12                        # bytes (log2) of one column group: 256 columns x (16 / RADIX) x 8 B
+    stride = n_words // RADIX * 8                         # bytes between x[o + k n/RADIX]
+    R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c_v, a_v, b_v, psi
+    R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
+    R("s_load_dword s14, s[0:1], 0x28")                  # nm
+    if not fused:
+        R("s_load_dwordx16 s[56:71], s[0:1], 0x30")      # cntV cntF cntI pad | fa_src fa_dst fb_src fb_dst inv pad
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                     # B = t >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
+    em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
+    em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_BIDX, V_L2R, V_L1R))     # 272*B + r
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
+    em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
+    em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
+    for t0 in sorted(set(V_T)):
+        em.valu("v_mov_b32_e32 v%d, 0" % (t0 + 15,))                                # the persistent zero of ZP
+    R("s_waitcnt lgkmcnt(0)")
+    if fused:
+        fused_header(em, PER_ROW, NV, NSW, CG_LOG)
+    else:
+        legacy_role_map(em, PER_ROW, NV, NSW)
+    stream_setup = {}
     # ---------------------------------------------------------------- streaming roles
     # A streaming workgroup owns the four column groups sub, sub+4, sub+8, sub+12 of its row (sub < 4; the others
     # exit at once) and double-buffers them through the a / b register files: the loads of group g+1 are in flight
@@ -1340,49 +1754,66 @@ def build_pipe(logn=None):
         R("s_endpgm")
 
     em.comment("role F: x[o + k n/16] -> radix-16 over global stages 0..3 -> lazy words (the block kernel takes any word)")
-    R("s_cmp_ge_u32 s86, s57")
-    R("s_cbranch_scc1 .Lidle")
-    R("s_cmp_eq_u32 s42, 1")
-    R("s_cselect_b64 s[16:17], s[60:61], s[64:65]")      # src
-    R("s_cselect_b64 s[20:21], s[62:63], s[66:67]")      # dst
-    R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
-    R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))      # row * n * 8
-    R("s_lshl_b32 s86, s89, %d" % CG_LOG)
-    R("s_add_u32 s42, s42, s86")                         # + the bytes of q column groups (no carry: the low bits were zero)
-    for row in (16, 20):
-        R("s_add_u32 s%d, s%d, s42" % (row, row))
-        R("s_addc_u32 s%d, s%d, s43" % (row + 1, row + 1))
-    R("s_mov_b32 s90, 1")                                # K_F1 of the row's first four stages
+    if fused:
+        em.lines.append(".Lbody_f:")
+    else:
+        R("s_cmp_ge_u32 s86, s57")
+        R("s_cbranch_scc1 .Lidle")
+        R("s_cmp_eq_u32 s42, 1")
+        R("s_cselect_b64 s[16:17], s[60:61], s[64:65]")      # src
+        R("s_cselect_b64 s[20:21], s[62:63], s[66:67]")      # dst
+        R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
+        R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))      # row * n * 8
+        R("s_lshl_b32 s86, s89, %d" % CG_LOG)
+        R("s_add_u32 s42, s42, s86")                         # + the bytes of q column groups (no carry: the low bits were zero)
+        for row in (16, 20):
+            R("s_add_u32 s%d, s%d, s42" % (row, row))
+            R("s_addc_u32 s%d, s%d, s43" % (row + 1, row + 1))
+        R("s_mov_b32 s90, 1")                                # K_F1 of the row's first four stages
     emit_mc_load(em)
+    mark = len(em.lines)
     stream_role("F")
+    if fused and FUSED_NT:   # the operands are read once; the scratch they are written to is what the L2 should keep
+        em.lines[mark:] = [l + " nt" if "global_load_dwordx2" in l else l for l in em.lines[mark:]]
 
     em.lines.append(".Lrole_i:")
     em.comment("role I: lazy words of the block kernel -> global stages 3..0 with n^-1 -> canonical x[o + k n/16]")
-    R("s_cmp_ge_u32 s86, s58")
-    R("s_cbranch_scc1 .Lidle")
-    R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
-    R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))
-    R("s_lshl_b32 s86, s89, %d" % CG_LOG)
-    R("s_add_u32 s42, s42, s86")
-    R("s_add_u32 s16, s68, s42")
-    R("s_addc_u32 s17, s69, s43")
-    R("s_mov_b64 s[20:21], s[16:17]")
-    R("s_mov_b32 s95, 2")                                # K_I3 of the row's last four stages
+    if fused:
+        em.lines.append(".Lbody_i:")
+    else:
+        R("s_cmp_ge_u32 s86, s58")
+        R("s_cbranch_scc1 .Lidle")
+        R("s_lshr_b32 s43, s87, %d" % (32 - (PIPE_LOGN + 3),))
+        R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))
+        R("s_lshl_b32 s86, s89, %d" % CG_LOG)
+        R("s_add_u32 s42, s42, s86")
+        R("s_add_u32 s16, s68, s42")
+        R("s_addc_u32 s17, s69, s43")
+        R("s_mov_b64 s[20:21], s[16:17]")
+        R("s_mov_b32 s95, 2")                                # K_I3 of the row's last four stages
     emit_mc_load(em)
+    mark = len(em.lines)
     stream_role("I")
+    if fused:   # the scratch comes from another CU of the XCD: read it from the L2, not from this CU's L1
+        em.lines[mark:] = [l + FUSED_LOADS if "global_load_dwordx2" in l else l for l in em.lines[mark:]]
+    if fused and FUSED_NT:   # ... and the result is written once
+        em.lines[mark:] = [l + " nt" if "global_store_dwordx2" in l else l for l in em.lines[mark:]]
 
     # ---------------------------------------------------------------- role 0: the fused block product
     em.lines.append(".Lrole_v:")
     em.comment("role V: one 4096-word block, exactly the stand-alone block kernel (r = 4, blk = s89)")
-    R("s_cmp_ge_u32 s86, s56")
-    R("s_cbranch_scc1 .Lidle")
-    R("s_lshl_b32 s42, s87, %d" % RL)
-    R("s_add_u32 s42, s42, s89")                         # block index = row * (n / 4096) + blk
-    R("s_lshr_b32 s43, s42, 17")
-    R("s_lshl_b32 s42, s42, 15")
-    for base, row in ((6, 16), (8, 18), (4, 20)):
-        R("s_add_u32 s%d, s%d, s42" % (row, base))
-        R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    if fused:
+        em.lines.append(".Lbody_v:")
+    else:
+        R("s_cmp_ge_u32 s86, s56")
+        R("s_cbranch_scc1 .Lidle")
+        R("s_lshl_b32 s42, s87, %d" % RL)
+        R("s_add_u32 s42, s42, s89")                         # block index = row * (n / 4096) + blk
+        R("s_lshr_b32 s43, s42, 17")
+        R("s_lshl_b32 s42, s42, 15")
+        for base, row in ((6, 16), (8, 18), (4, 20)):
+            R("s_add_u32 s%d, s%d, s42" % (row, base))
+            R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
     R("s_mov_b32 s88, %d" % (PIPE_LOGN - 12,))
     R("s_lshl_b32 s90, 1, s88")
     R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
@@ -1398,15 +1829,22 @@ def build_pipe(logn=None):
     R("s_sub_u32 s95, s95, s89")                         # (2<<r) - blk
     emit_mc_load(em)
     vm = VmCounter(em)
+    mark_v = len(em.lines)
     strided_rows(em, vm, V_A, S_AROW, 2048)
     strided_rows(em, vm, V_B, S_BROW, 2048)
     tw_seq = {}
     for st in range(4):
         tw_seq[("F1", st)] = PASS_TW["F1"](em, vm, st)
     emit_consts(em)
+    mark = len(em.lines)
     build_body(em, vm, "polymul", tw_seq, "_v")
+    if fused:
+        em.lines[mark_v:mark] = [l + FUSED_LOADS if "global_load_dwordx2" in l else l for l in em.lines[mark_v:mark]]
     em.lines.append(".Lidle:")
     R("s_endpgm")
+    if fused:   # every role ends by drawing the next ticket; the only exit is the VOID inverse role of the header
+        em.lines = ["\ts_branch .Lnext" if l.strip() == "s_endpgm" else l for l in em.lines]
+        em.lines = ["\ts_endpgm" if l.strip() == "S_EXIT" else l for l in em.lines]
     return em
 
 
@@ -1491,11 +1929,11 @@ def args_yaml(spec):
     return "\n".join(out) + "\n"
 
 
-def emit_file(path, kname, em, args=None):
+def emit_file(path, kname, em, args=None, lds=None):
     accum = (NEXT_VGPR + 3) // 4 * 4
     args = ARGS_STD if args is None else args
     karg = args[-1][1] + (8 if args[-1][0] == "ptr" else 4)
-    params = dict(k=kname, lds=LDS_BYTES, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=WG_SIZE,
+    params = dict(k=kname, lds=LDS_BYTES if lds is None else lds, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=WG_SIZE,
                   karg=karg, args=args_yaml(args))
     with open(path, "w") as f:
         f.write("; GENERATED by tools/gen_polymul_asm.py -- do not edit.\n")
@@ -1536,6 +1974,13 @@ def main():
     em15 = build_pipe(15)
     em15.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em15.lines]
     emit_file(os.path.join(outdir, "polymul_pipe32768_gfx950.s"), "nflhip_polymul_pipe32768_asm", em15, args=ARGS_PIPE)
+    # one-launch variants: rows pinned to an XCD, intermediates through its L2 (fused_header)
+    global FUSED_LOADS
+    for lg, mod, sfx in ((16, "", ""), (15, "", "")):
+        FUSED_LOADS = mod
+        emf = build_pipe(lg, fused=True)
+        emit_file(os.path.join(outdir, "polymul_xcd%d%s_gfx950.s" % (1 << lg, sfx)), "nflhip_polymul_xcd%d%s_asm" % (1 << lg, sfx), emf,
+                  args=ARGS_PIPE, lds=LDS_BYTES + 64)
     build_pipe(16)   # (leave the module-level PIPE_LOGN as it was)
     configure("ring", 4)
     for kind, (stem, kname) in KERNELS16K.items():
