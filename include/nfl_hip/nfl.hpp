@@ -644,7 +644,7 @@ template <class P> struct lazy {
     op() : kind(0), nin(0), len(0), dist(0), p0(0), p1(0), sid(0), tab(nullptr) {}
   };
   std::recursive_mutex mu;
-  std::vector<op> q;
+  std::vector<op> q, running;  // recorded operations; the ones a queue run is working on (two buffers that swap: no regrowth)
   size_t launches, coalesced;  // statistics: launches issued / operations they carried
   // records after which the queue runs by itself: long enough for wide launches, short enough that the device works on
   // one part of a long loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments)
@@ -663,28 +663,33 @@ template <class P> struct lazy {
     return deferred_flag().load(std::memory_order_relaxed) && ctx_t::chunk_bytes == ctx_t::poly_bytes && P::degree >= 8 &&
            P::degree * sizeof(T) >= 16;
   }
-  // inputs must hold a device value (or be produced by the queue) before the operation is recorded
-  void push(op &&o) {
+  // `fill(op &)` writes the record in place, in the queue (a record is ~250 bytes: built once, never moved)
+  template <class F> void record(F fill) {
     std::lock_guard<std::recursive_mutex> lk(mu);
-    for (int j = 0; j < o.nin; ++j) o.in[j]->dev_ro_nf();
-    const bool in_place = o.kind == K_NTT_FWD || o.kind == K_NTT_INV;
-    if (in_place) o.out->dev_ro_nf();
-    bool reads_out = in_place;
-    for (int j = 0; j < o.nin; ++j) reads_out |= o.in[j].get() == o.out.get();
-    (void)reads_out;
+    q.emplace_back();
+    op &o = q.back();
+    try {  // inputs must hold a device value (or be produced by the queue) before the operation counts as recorded
+      fill(o);
+      for (int j = 0; j < o.nin; ++j) o.in[j]->dev_ro_nf();
+      if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) o.out->dev_ro_nf();
+    } catch (...) {
+      q.pop_back();
+      throw;
+    }
     ++o.out->qrefs;
     for (int j = 0; j < o.nin; ++j) ++o.in[j]->qrefs;
     o.out->queued = true;
     o.out->dev_valid = true;
     o.out->host_valid = false;
-    q.push_back(std::move(o));
     if (q.size() >= max_queue()) flush();
   }
   void flush() {
     std::lock_guard<std::recursive_mutex> lk(mu);
     if (q.empty()) return;
-    std::vector<op> ops;
+    std::vector<op> local;  // (a queue run started from inside another one: cannot happen today, costs nothing to allow)
+    std::vector<op> &ops = running.empty() ? running : local;
     ops.swap(q);
+    if (q.capacity() < ops.capacity()) q.reserve(ops.capacity());
     struct done_guard {  // whatever happens, the payloads stop claiming a queued value
       std::vector<op> &o;
       ~done_guard() {
@@ -693,6 +698,7 @@ template <class P> struct lazy {
           --x.out->qrefs;
           for (int j = 0; j < x.nin; ++j) --x.in[j]->qrefs;
         }
+        o.clear();
       }
     } guard{ops};
     // ---- 1. levels (the last writing / reading level of a value is kept in its payload, tagged with this flush's epoch)
@@ -724,23 +730,21 @@ template <class P> struct lazy {
     struct gkey { int level; uint64_t hash; };
     std::vector<gkey> keys;
     std::vector<std::vector<size_t>> members;
-    auto fnv = [](uint64_t h, const void *data, size_t n) {
-      const unsigned char *b = static_cast<const unsigned char *>(data);
-      for (size_t k = 0; k < n; ++k) h = (h ^ b[k]) * 0x100000001b3ull;
-      return h;
+    auto mix = [](uint64_t h, uint64_t v) {  // (one multiply-xorshift round per 64-bit field: the signatures are a few words)
+      h = (h ^ v) * 0x9E3779B97F4A7C15ull;
+      return h ^ (h >> 29);
     };
+    static_assert(NFLHIP_EXPR_MAX_LEN <= 24, "the program is hashed as three words");
     for (size_t i = 0; i < ops.size(); ++i) {
       const op &o = ops[i];
-      uint64_t h = fnv(0xcbf29ce484222325ull, &o.kind, sizeof(o.kind));
+      uint64_t h = mix(0xcbf29ce484222325ull, uint64_t(o.kind));
       if (o.kind == K_EVAL) {
-        h = fnv(h, o.code, size_t(o.len));
-        h = fnv(h, &o.nin, sizeof(o.nin));
+        uint64_t w[3] = {0, 0, 0};
+        std::memcpy(w, o.code, size_t(o.len));
+        h = mix(mix(mix(mix(h, w[0]), w[1]), w[2]), (uint64_t(o.len) << 8) | uint64_t(o.nin));
       } else if (o.kind == K_SAMPLE || o.kind == K_GAUSS || o.kind == K_FILL) {
-        h = fnv(h, &o.dist, sizeof(o.dist));
-        h = fnv(h, &o.p0, sizeof(o.p0));
-        h = fnv(h, &o.p1, sizeof(o.p1));
-        h = fnv(h, &o.tab, sizeof(o.tab));
-        if (o.kind == K_FILL) h = fnv(h, &o.sid, sizeof(o.sid));
+        h = mix(mix(mix(mix(h, uint64_t(o.dist)), o.p0), o.p1), uint64_t(reinterpret_cast<uintptr_t>(o.tab)));
+        if (o.kind == K_FILL) h = mix(h, o.sid);
       }
       size_t g = keys.size();
       for (size_t k = keys.size(); k-- > 0;)   // (recent groups first: neighbouring operations repeat)
@@ -748,23 +752,26 @@ template <class P> struct lazy {
       if (g == keys.size()) {
         keys.push_back(gkey{lvl[i], h});
         members.emplace_back();
+        members.back().reserve(ops.size() / 4 + 1);
       }
       members[g].push_back(i);
     }
-    std::map<std::pair<int, uint64_t>, std::vector<size_t>> groups;  // few entries: ordered by level
-    for (size_t g = 0; g < keys.size(); ++g) groups[std::make_pair(keys[g].level, keys[g].hash)].swap(members[g]);
+    // groups run level by level (inside a level the order is irrelevant: they are independent)
+    std::vector<size_t> order(keys.size());
+    for (size_t g = 0; g < order.size(); ++g) order[g] = g;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return keys[x].level < keys[y].level; });
     nflhip_ctx *ctx = ctx_t::get();
     void *st = ctx_t::queue();
     detail::sampler &smp = detail::sampler::get();
     static const bool trace = getenv("NFL_HIP_TRACE_DEFERRED") != nullptr;
-    for (auto &kv : groups) {
-      std::vector<size_t> &idx = kv.second;
+    for (size_t gi : order) {
+      std::vector<size_t> &idx = members[gi];
       const int kind = ops[idx[0]].kind;
       const size_t launches_before = launches;
       struct tracer {
         bool on; int level, kind; size_t n; const size_t &now; size_t before;
         ~tracer() { if (on) std::fprintf(stderr, "nfl(hip) deferred: level %d kind %d: %zu operations -> %zu launches\n", level, kind, n, now - before); }
-      } tr{trace, kv.first.first, kind, idx.size(), launches, launches_before};
+      } tr{trace, keys[gi].level, kind, idx.size(), launches, launches_before};
       if ((kind == K_SAMPLE || kind == K_GAUSS) && idx.size() >= 4) {
         // A loop body that draws several polynomials of one distribution (e1, e2 of an encryption) interleaves their
         // stream ids: k+1, k+2, k+4, k+5, ...  Find the period of the id differences and regroup the operations into
@@ -798,8 +805,9 @@ template <class P> struct lazy {
       if (kind == K_NTT_FWD || kind == K_NTT_INV) {
         // in place, mutually independent: any order -- by address, so that neighbours become one dense batch
         std::vector<char *> ptr;
+        ptr.reserve(idx.size());
         for (size_t i : idx) ptr.push_back(static_cast<char *>(ops[i].out->dev));
-        std::sort(ptr.begin(), ptr.end());
+        if (!std::is_sorted(ptr.begin(), ptr.end())) std::sort(ptr.begin(), ptr.end());  // (a loop's temporaries already are)
         for (size_t a = 0; a < ptr.size();) {
           size_t b = a + 1;
           while (b < ptr.size() && ptr[b] == ptr[b - 1] + ctx_t::chunk_bytes) ++b;
@@ -850,25 +858,49 @@ template <class P> struct lazy {
       }
       // ---- K_EVAL: operands that are one polynomial for (almost) the whole group split it; then stride runs
       const int nin = ops[idx[0]].nin;
-      std::map<std::vector<const pay_t *>, std::vector<size_t>> sub;
+      // a "key" slot holds one of a few polynomials throughout the group (at most 8, and at most every eighth operation a
+      // new one); each combination of keys becomes its own sub-group, whose other operands then advance by strides
+      struct subgroup { const pay_t *key[NFLHIP_EXPR_MAX_OPERANDS]; std::vector<size_t> idx; };
+      std::vector<subgroup> sub;
       {
-        std::vector<bool> keyslot(size_t(nin), false);
+        bool keyslot[NFLHIP_EXPR_MAX_OPERANDS];
+        const size_t cap = std::min<size_t>(idx.size() / 8 + 1, 8);
         for (int j = 0; j < nin; ++j) {
-          std::map<const pay_t *, size_t> seen;
-          for (size_t i : idx)
-            if (seen.size() <= idx.size() / 8 + 1) ++seen[ops[i].in[j].get()];
-          keyslot[size_t(j)] = idx.size() >= 2 && seen.size() <= idx.size() / 8 + 1 && seen.size() < idx.size();
+          const pay_t *seen[8];
+          size_t ns = 0;
+          bool few = idx.size() >= 2;
+          for (size_t i : idx) {
+            if (!few) break;
+            const pay_t *p = ops[i].in[j].get();
+            size_t k = ns;
+            while (k-- > 0 && seen[k] != p) {}
+            if (k == size_t(-1)) {
+              if (ns == cap) few = false;
+              else seen[ns++] = p;
+            }
+          }
+          keyslot[j] = few && ns < idx.size();
         }
         for (size_t i : idx) {
-          std::vector<const pay_t *> k;
-          for (int j = 0; j < nin; ++j)
-            if (keyslot[size_t(j)]) k.push_back(ops[i].in[j].get());
-          sub[k].push_back(i);
+          const pay_t *key[NFLHIP_EXPR_MAX_OPERANDS];
+          for (int j = 0; j < nin; ++j) key[j] = keyslot[j] ? ops[i].in[j].get() : nullptr;
+          size_t g = sub.size();
+          for (size_t k = sub.size(); k-- > 0;)
+            if (std::equal(key, key + nin, sub[k].key)) { g = k; break; }
+          if (g == sub.size()) {
+            sub.emplace_back();
+            std::copy(key, key + nin, sub.back().key);
+          }
+          sub[g].idx.push_back(i);
         }
       }
       for (auto &sv : sub) {
-        std::vector<size_t> &sidx = sv.second;
-        std::stable_sort(sidx.begin(), sidx.end(), [&](size_t x, size_t y) { return ops[x].out->dev < ops[y].out->dev; });
+        std::vector<size_t> &sidx = sv.idx;
+        {  // by destination address (program order among equals); a loop's results already are in that order
+          bool sorted = true;
+          for (size_t k = 1; k < sidx.size() && sorted; ++k) sorted = !(ops[sidx[k]].out->dev < ops[sidx[k - 1]].out->dev);
+          if (!sorted) std::stable_sort(sidx.begin(), sidx.end(), [&](size_t x, size_t y) { return ops[x].out->dev < ops[y].out->dev; });
+        }
         for (size_t a = 0; a < sidx.size();) {
           const op &o0 = ops[sidx[a]];
           size_t stride[NFLHIP_EXPR_MAX_OPERANDS], ostride = 1;
@@ -1015,14 +1047,14 @@ template <class Op, class... Args> struct expr {
     if (degree * sizeof(value_type) < 16) return false;  // (rows shorter than one 16-byte vector: nflhip_eval declines)
     typedef detail::lazy<poly_type> lazy_t;
     if (lazy_t::usable() && pr.nhandles == pr.noperands) {  // every leaf is a handle: record, do not launch
-      typename lazy_t::op o;
-      o.kind = lazy_t::K_EVAL;
-      o.out = out.shared_from_this();
-      o.nin = int(pr.noperands);
-      for (size_t k = 0; k < pr.noperands; ++k) o.in[k] = static_cast<payload_type *>(pr.pay[k])->shared_from_this();
-      o.len = int(pr.len);
-      std::memcpy(o.code, pr.code, pr.len);
-      lazy_t::inst().push(std::move(o));
+      lazy_t::inst().record([&](typename lazy_t::op &o) {
+        o.kind = lazy_t::K_EVAL;
+        o.out = out.shared_from_this();
+        o.nin = int(pr.noperands);
+        for (size_t k = 0; k < pr.noperands; ++k) o.in[k] = static_cast<payload_type *>(pr.pay[k])->shared_from_this();
+        o.len = int(pr.len);
+        std::memcpy(o.code, pr.code, pr.len);
+      });
       return true;
     }
     nflhip_ctx *ctx = ctx_t::get();
@@ -1682,15 +1714,15 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
         last = last_t{dist, p0, p1, tab, true};
       }
     }
-    typename lazy_t::op o;
-    o.kind = kind;
-    o.out = p.shared_from_this();
-    o.dist = dist;
-    o.p0 = p0;
-    o.p1 = p1;
-    o.sid = sid;
-    o.tab = tab;
-    lazy_t::inst().push(std::move(o));
+    lazy_t::inst().record([&](typename lazy_t::op &o) {
+      o.kind = kind;
+      o.out = p.shared_from_this();
+      o.dist = dist;
+      o.p0 = p0;
+      o.p1 = p1;
+      o.sid = sid;
+      o.tab = tab;
+    });
     return true;
   }
   static void sample_dist(payload_type &p, int dist, uint64_t p0, uint64_t p1, const char *what) {
@@ -1820,10 +1852,10 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   void transform(int kind) {
     detach();
     if (lazy_t::usable()) {
-      typename lazy_t::op o;
-      o.kind = kind;
-      o.out = _p;
-      lazy_t::inst().push(std::move(o));
+      lazy_t::inst().record([&](typename lazy_t::op &o) {
+        o.kind = kind;
+        o.out = _p;
+      });
       return;
     }
     detail::check(ctx_t::get(), kind == lazy_t::K_NTT_FWD ? nflhip_ntt_fwd_dev(ctx_t::get(), _p->dev_rw(), 1, ctx_t::queue())

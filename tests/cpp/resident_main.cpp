@@ -188,7 +188,7 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *e
   using poly_p = nfl::poly_p<T, Degree, NbModuli>;
   using G = nfl::gaussian<uint8_t, T, 2>;
   nfl::FastGaussianNoise<uint8_t, T, 2> g_prng(4, 128, 1 << 10);
-  const size_t REPS = 2048;
+  const size_t REPS = getenv("NFL_LWE_REPS") ? size_t(atol(getenv("NFL_LWE_REPS"))) : 2048;
   poly_p s{G(&g_prng)};
   s.ntt_pow_phi();
   poly_p sprime = nfl::compute_shoup(s);
@@ -215,9 +215,13 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *e
   const size_t l0 = poly_p::deferred_launches(), o0 = poly_p::deferred_operations();
   auto t0 = std::chrono::steady_clock::now();
   for (size_t i = 0; i < REPS; i++) encrypt(resa[i], resb[i]);
+  auto t_rec = std::chrono::steady_clock::now();
   poly_p::synchronize();
   auto t1 = std::chrono::steady_clock::now();
   const double enc_s = std::chrono::duration<double>(t1 - t0).count();
+  if (getenv("NFL_LWE_VERBOSE"))
+    std::fprintf(stderr, "lwe: %zu encryptions: recorded in %.3f ms (incl. queue runs), finished after %.3f ms\n", REPS,
+                 std::chrono::duration<double>(t_rec - t0).count() * 1e3, enc_s * 1e3);
   *launches = poly_p::deferred_launches() - l0;
   *operations = poly_p::deferred_operations() - o0;
   std::vector<poly_p> dec(REPS);
