@@ -339,7 +339,9 @@ __device__ __forceinline__ void row_body(typename P::T *c, const typename P::T *
 }
 
 template <class P, int MODE, int LB>
-__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? ((LB >= 8 && MODE == 0) || (LB == 16 && MODE == 1) ? 4 : 5) : 2)) void k_row(
+// 32-bit limbs: 4 waves per SIMD for the fused products (measured round 2, u32/1024/1: 3, 4, 5 waves 198, 201, 193 M
+// products/s, 6 and 8 (spills) 169 and 152 -- the kernel is bound by VALU issue, not by latency), 5 for the transforms
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? (MODE == 0 || (LB == 16 && MODE == 1) ? 4 : 5) : 2)) void k_row(
     typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::TW *__restrict__ psi,
     const typename P::MC *__restrict__ mc, int nm, size_t rows) {
   constexpr int W = 16 * LB, RPB = 256 / W, LOGN = LB == 4 ? 10 : (LB == 8 ? 11 : 12);  // rows per 256-thread block: 4, 2, 1
