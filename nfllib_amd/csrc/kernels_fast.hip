@@ -355,7 +355,7 @@ enum AsmKind {
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
-  kAsmXcd64k, kAsmXcd32k,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
+  kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
   kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
   kAsmCount
 };
@@ -371,6 +371,7 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm",
                                                  "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm",
                                                  "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
+                                                 "nflhip_polymul_xcd65536l_asm", "nflhip_polymul_xcd32768l_asm",
                                                  "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
                                                  "nflhip_ntt_inv4096x2nt_asm"};
 struct AsmKernel {
@@ -502,12 +503,14 @@ static void *g_xcd_trace = nullptr;
 extern "C" void nflhip_debug_xcd_trace(void *device_buffer) { g_xcd_trace = device_buffer; }
 static std::atomic<unsigned long long> g_xcd_launches{0};
 extern "C" unsigned long long nflhip_debug_xcd_launches(void) { return g_xcd_launches.load(); }  // tests: which plan ran
-__global__ void k_xcd_reset(uint4 *ctl) {   // block 0: the header; block d + 1: record d at byte 4096 + 69632 d
+__global__ void k_xcd_reset(uint4 *ctl) {   // block 0: the header; block d + 1: record d at byte 4096 + 69632 d (2 KiB each)
   uint4 *p = blockIdx.x == 0 ? ctl : ctl + (4096 + (size_t)(blockIdx.x - 1) * 0x11000) / 16;
   p[threadIdx.x] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && (threadIdx.x == 8 || threadIdx.x == 9)) p[threadIdx.x] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  // (bytes 128 .. 159: one free mask of 32 scratch slots per XCD -- the pooled plan)
 }
 struct XcdPlan {
-  int rlog, wgs, dlog;
+  int rlog, wgs, dlog, pooled;
   unsigned magic;
   size_t ctl_bytes, slot_bytes, total;
 };
@@ -533,8 +536,17 @@ static bool xcd_plan(const Shape &s, size_t batch, XcdPlan *p) {
   p->wgs = env_int("NFLHIP_XCD_WGS", 768);
   if (p->rlog < 1 || p->rlog > 5 || p->dlog < 0 || p->dlog > 3 || p->wgs < 256 || rows < (8ull << p->dlog)) return false;
   p->ctl_bytes = 4096 + ((size_t)8 << p->dlog) * 0x11000;  // word 0: next row; one 256 B scheduler record per XCD, 68 KiB apart, from byte 4096
-  p->slot_bytes = (size_t)rows * (s.n * 8);  // per operand: the scratch mirrors the batch (every row its own scratch rows)
-  p->total = p->ctl_bytes + 2 * p->slot_bytes;
+  p->pooled = env_int("NFLHIP_XCD_POOL", 0);  // 1: scratch rows from a per-XCD pool of 32 slots, lowest free first (see the generator)
+  if (p->pooled) {
+    // a row in flight holds up to 3 slots: at most 8 rows in flight per XCD, so the pool can never run dry
+    if (!getenv("NFLHIP_XCD_RLOG")) p->rlog = 1;
+    if (p->rlog + p->dlog > 3) return false;
+    p->slot_bytes = (size_t)8 * 32 * (s.n * 8);
+    p->total = p->ctl_bytes + p->slot_bytes;
+  } else {
+    p->slot_bytes = (size_t)rows * (s.n * 8);  // per operand: the scratch mirrors the batch (every row its own scratch rows)
+    p->total = p->ctl_bytes + 2 * p->slot_bytes;
+  }
   return true;
 }
 size_t xcd_plan_bytes(const Shape &s, size_t batch) {
@@ -545,10 +557,10 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
                                   size_t batch, void *work, hipStream_t st) {
   XcdPlan p;
   if (!xcd_plan(s, batch, &p)) return hipErrorNotSupported;
-  hipFunction_t fn = asm_fn(s.logn == 16 ? kAsmXcd64k : kAsmXcd32k);
+  hipFunction_t fn = asm_fn(s.logn == 16 ? (p.pooled ? kAsmXcd64kL : kAsmXcd64k) : (p.pooled ? kAsmXcd32kL : kAsmXcd32k));
   if (!fn) return hipErrorNotSupported;
   // fresh counters: word block 0 (workgroups that joined, per XCD) and the first KiB of every domain's record
-  hipLaunchKernelGGL(k_xcd_reset, dim3((8u << p.dlog) + 1), dim3(64), 0, st, (uint4 *)work);
+  hipLaunchKernelGGL(k_xcd_reset, dim3((8u << p.dlog) + 1), dim3(128), 0, st, (uint4 *)work);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   char *w = (char *)work;

@@ -13,7 +13,7 @@ from conftest import SEED
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("NFLHIP_XCD", "NFLHIP_XCD_RLOG", "NFLHIP_XCD_DLOG", "NFLHIP_XCD_WGS", "NFLHIP_XCD_MAX_ROWS")
+KNOBS = ("NFLHIP_XCD", "NFLHIP_XCD_RLOG", "NFLHIP_XCD_DLOG", "NFLHIP_XCD_WGS", "NFLHIP_XCD_MAX_ROWS", "NFLHIP_XCD_POOL")
 
 
 @pytest.fixture(autouse=True)
@@ -34,7 +34,7 @@ def _launches(e):
 
 def _product(e, a, b, xcd, **knobs):
     os.environ["NFLHIP_XCD"] = "1" if xcd else "0"
-    for k in ("NFLHIP_XCD_RLOG", "NFLHIP_XCD_DLOG", "NFLHIP_XCD_WGS"):
+    for k in ("NFLHIP_XCD_RLOG", "NFLHIP_XCD_DLOG", "NFLHIP_XCD_WGS", "NFLHIP_XCD_POOL"):
         os.environ.pop(k, None)
     for k, v in knobs.items():
         os.environ["NFLHIP_XCD_" + k.upper()] = str(v)
@@ -76,6 +76,19 @@ def test_every_ring_and_domain_setting(rlog, dlog, wgs, engine_factory):
         b = e.fill_uniform(e.empty(batch), SEED + 1, 1)
         want = e.to_host(_product(e, a, b, xcd=False))
         assert np.array_equal(e.to_host(_product(e, a, b, xcd=True, rlog=rlog, dlog=dlog, wgs=wgs)), want)
+
+
+@pytest.mark.parametrize("rlog,dlog", [(1, 2), (2, 1), (1, 0), (3, 0)])
+def test_pooled_scratch_variant(rlog, dlog, engine_factory):
+    """NFLHIP_XCD_POOL=1 (experiment kept for its measurements): scratch rows come from a per-XCD pool of 32
+    slots that are reused within the launch, consumers read them with `nt` loads -- same words"""
+    for n, m, batch in ((32768, 2, 45), (65536, 3, 19), (65536, 30, 4)):
+        e = engine_factory(64, n, m)
+        a = e.fill_uniform(e.empty(batch), SEED + 2, 0)
+        b = e.fill_uniform(e.empty(batch), SEED + 2, 1)
+        want = e.to_host(_product(e, a, b, xcd=False))
+        for rep in range(3):   # (slot reuse across launches too)
+            assert np.array_equal(e.to_host(_product(e, a, b, xcd=True, pool=1, rlog=rlog, dlog=dlog)), want)
 
 
 def test_small_batches_fall_back(engine_factory):

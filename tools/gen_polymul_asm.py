@@ -1274,8 +1274,142 @@ def legacy_role_map(em, PER_ROW, NV, NSW):
 #   +0 credits {forward (biased by the initial min(R, jobs) * 2 NSW), product, inverse}, +12 exit flag, +16 trace count
 #   +128 tickets {forward, product, inverse}      +256 + 16 slot: completed {forward, product, inverse} roles (all epochs)
 FUSED_NT = int(os.environ.get("NFL_FUSED_NT", "1"))
+FUSED_LIFO = False                       # scratch rows come from a per-XCD pool, lowest free slot first (lifo_* below)
 FUSED_LOADS = ""                         # modifier of the scratch loads: " sc1" = device scope (L1 bypass), "" = plain after a buffer_inv sc0
 LDS_TICKET = (4096 + 256) * 8           # 64 B behind the exchange slab: wave 0's decision and the running role's completion record
+
+
+
+# ---- per-XCD scratch pool (FUSED_LIFO): 32 row slots per XCD, a free mask at ctl + 128 + 4 xcd.  A row's a' and b' live
+# in two slots from its first forward role until every block product has LOADED them (signalled a few microseconds into
+# the product, after its first barrier), c' in a third from the first product's store to the last inverse role's end.
+# "Lowest free slot first" keeps the set of slots in use as small as the concurrency allows, so a slot is rewritten
+# while its previous (dead, dirty) contents still sit in the L2 -- the lines are overwritten there instead of being
+# written back.  Consumers read the scratch with `nt` loads: measured (tools/probes) to miss the L1 and see other CUs'
+# stores, which a slot that is reused within a launch needs.
+# Aux record of a job at record + 1024 + 16 slot: {1 + job, (a slot + 1) | (b slot + 1) << 8, c word, products that loaded};
+# c word: 0 none, bit 31 = a product is allocating it, low byte = c slot + 1.
+def lifo_mask_addr(em, dst_pair, ctl_pair, tmp):
+    """dst = ctl + 128 + 4 * xcd"""
+    R = em.raw
+    lo = int(dst_pair[2:].split(":")[0])
+    clo = int(ctl_pair[2:].split(":")[0])
+    R("s_and_b32 %s, s98, 7" % tmp)
+    R("s_lshl_b32 %s, %s, 2" % (tmp, tmp))
+    R("s_add_u32 %s, %s, 128" % (tmp, tmp))
+    R("s_add_u32 s%d, s%d, %s" % (lo, clo, tmp))
+    R("s_addc_u32 s%d, s%d, 0" % (lo + 1, clo + 1))
+
+
+def lifo_pop(em, name, vt, mask_pair, out, t0, t1, spin):
+    """out = index of a free slot, now taken (one lane active); bounded"""
+    R = em.raw
+    L = em.lines.append
+    R("s_mov_b32 %s, 0" % spin)
+    L(".Lpop_%s:" % name)
+    R("global_load_dword v%d, v%d, %s sc1" % (vt, V_ZERO, mask_pair))
+    R("s_waitcnt vmcnt(0)")
+    R("v_readfirstlane_b32 %s, v%d" % (t0, vt))
+    R("s_cmp_lg_u32 %s, 0" % t0)
+    R("s_cbranch_scc1 .Lpop_%s_try" % name)
+    R("s_sleep 8")
+    R("s_add_u32 %s, %s, 1" % (spin, spin))
+    R("s_cmp_lt_u32 %s, 0x200000" % spin)
+    R("s_cbranch_scc1 .Lpop_%s" % name)
+    R("s_trap 2")                                        # the pool never refills: fail loudly
+    L(".Lpop_%s_try:" % name)
+    R("s_ff1_i32_b32 %s, %s" % (out, t0))
+    R("s_lshl_b32 %s, 1, %s" % (t1, out))
+    R("s_not_b32 %s, %s" % (t0, t1))
+    R("v_mov_b32_e32 v%d, %s" % (vt, t0))
+    R("global_atomic_and v%d, v%d, v%d, %s sc0" % (vt, V_ZERO, vt, mask_pair))
+    R("s_waitcnt vmcnt(0)")
+    R("v_readfirstlane_b32 %s, v%d" % (t0, vt))
+    R("s_and_b32 %s, %s, %s" % (t0, t0, t1))
+    R("s_cmp_lg_u32 %s, 0" % t0)
+    R("s_cbranch_scc0 .Lpop_%s" % name)                  # somebody else took that slot first
+
+
+def lifo_slot_addr(em, dst_lo, slot_sgpr, scr_pair, tmp, NB):
+    """s[dst_lo:dst_lo+1] = scr + ((xcd * 32 + slot) << NB)"""
+    R = em.raw
+    slo = int(scr_pair[2:].split(":")[0])
+    R("s_and_b32 %s, s98, 7" % tmp)
+    R("s_lshl_b32 %s, %s, 5" % (tmp, tmp))
+    R("s_add_u32 %s, %s, %s" % (tmp, tmp, slot_sgpr))
+    R("s_lshr_b32 s%d, %s, %d" % (dst_lo + 1, tmp, 32 - NB))
+    R("s_lshl_b32 s%d, %s, %d" % (dst_lo, tmp, NB))
+    R("s_add_u32 s%d, s%d, s%d" % (dst_lo, dst_lo, slo))
+    R("s_addc_u32 s%d, s%d, s%d" % (dst_lo + 1, dst_lo + 1, slo + 1))
+
+
+def lifo_product_loaded(em, NV):
+    """injected after the block product's first barrier: its a' / b' blocks are in registers.  The last product of the
+    job to get here returns both slots to the pool.  s[96:97] = the job's aux record, s100 = the two slots' bits."""
+    R = em.raw
+    L = em.lines.append
+    R("v_readfirstlane_b32 s42, v%d" % V_TID)
+    R("s_cmp_lg_u32 s42, 0")
+    R("s_cbranch_scc1 .Lvl_done")
+    R("s_mov_b64 exec, 1")
+    R("v_mov_b32_e32 v7, 1")
+    R("global_atomic_add v7, v%d, v7, s[96:97] offset:12 sc0" % V_ZERO)
+    R("s_load_dwordx2 s[46:47], s[0:1], 0x60")           # ctl
+    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    R("v_readfirstlane_b32 s42, v7")
+    R("s_cmp_eq_u32 s42, %d" % (NV - 1))
+    R("s_cbranch_scc0 .Lvl_restore")
+    lifo_mask_addr(em, "s[46:47]", "s[46:47]", "s42")
+    R("v_mov_b32_e32 v7, s100")
+    R("global_atomic_or v%d, v7, s[46:47]" % V_ZERO)
+    L(".Lvl_restore:")
+    R("s_mov_b64 exec, -1")
+    L(".Lvl_done:")
+
+
+def lifo_product_store(em, NB):
+    """injected in front of the block product's stores: learn (or allocate) the job's c' slot, point S_CROW at this
+    product's block of it.  Every wave runs it (no workgroup exchange needed): v[40:41] are free by now (b is consumed)."""
+    R = em.raw
+    L = em.lines.append
+    R("s_load_dwordx2 s[46:47], s[0:1], 0x60")           # ctl
+    R("s_load_dwordx2 s[52:53], s[0:1], 0x50")           # scratch pool
+    R("s_mov_b64 exec, 1")
+    R("v_bfrev_b32_e32 v40, 1")                          # 0x80000000
+    R("global_atomic_or v40, v%d, v40, s[96:97] offset:8 sc0" % V_ZERO)
+    R("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    R("v_readfirstlane_b32 s42, v40")
+    R("s_cmp_eq_u32 s42, 0")
+    R("s_cbranch_scc0 .Lcs_wait")
+    # first product of the job to finish: take a slot, publish it
+    lifo_mask_addr(em, "s[46:47]", "s[46:47]", "s43")
+    lifo_pop(em, "c", 40, "s[46:47]", "s44", "s42", "s43", "s45")
+    R("s_add_u32 s42, s44, 1")
+    R("v_mov_b32_e32 v40, s42")
+    R("global_atomic_or v%d, v40, s[96:97] offset:8" % V_ZERO)
+    R("s_branch .Lcs_known")
+    L(".Lcs_wait:")
+    R("s_mov_b32 s45, 0")
+    L(".Lcs_poll:")
+    R("s_and_b32 s44, s42, 0xff")
+    R("s_cmp_lg_u32 s44, 0")
+    R("s_cbranch_scc1 .Lcs_have")
+    R("s_sleep 2")
+    R("global_load_dword v40, v%d, s[96:97] offset:8 sc1" % V_ZERO)
+    R("s_waitcnt vmcnt(0)")
+    R("v_readfirstlane_b32 s42, v40")
+    R("s_add_u32 s45, s45, 1")
+    R("s_cmp_lt_u32 s45, 0x200000")
+    R("s_cbranch_scc1 .Lcs_poll")
+    R("s_trap 2")
+    L(".Lcs_have:")
+    R("s_sub_u32 s44, s44, 1")
+    L(".Lcs_known:")
+    R("s_mov_b64 exec, -1")
+    lifo_slot_addr(em, 20, "s44", "s[52:53]", "s42", NB)
+    R("s_lshl_b32 s42, s89, 15")
+    R("s_add_u32 s20, s20, s42")
+    R("s_addc_u32 s21, s21, 0")                          # S_CROW: block s89 of the c' slot
 
 
 def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
@@ -1418,6 +1552,14 @@ def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
     R("s_add_u32 s78, s78, 1")
     R("s_cmp_eq_u32 s78, s75")
     R("s_cbranch_scc0 .Lt_posted")                       # not the last role of its stage
+    if FUSED_LIFO:
+        R("v_readfirstlane_b32 s79, v17")                # (v[14:17] = id, t0, t1, slots to free)
+        R("s_cmp_eq_u32 s79, 0")
+        R("s_cbranch_scc1 .Lt_nofree")
+        lifo_mask_addr(em, "s[84:85]", "s[68:69]", "s80")
+        R("v_mov_b32_e32 v12, s79")
+        R("global_atomic_or v%d, v12, s[84:85]" % Z)     # the inverse stage is complete: its c' slot returns to the pool
+        L(".Lt_nofree:")
     R("s_cmp_eq_u32 s77, 0")
     R("s_cbranch_scc1 .Lt_posted")
     R("s_add_u32 s84, s72, s76")
@@ -1567,6 +1709,9 @@ def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
     R("s_or_b32 s84, s84, s85")
     R("v_mov_b32_e32 v8, s84")
     R("ds_write_b32 v%d, v8 offset:%d" % (Z, T + 32))
+    if FUSED_LIFO:
+        R("v_mov_b32_e32 v8, 0")
+        R("ds_write_b32 v%d, v8 offset:%d" % (Z, T + 44))  # pool slots to free when this role completes its stage (set by the inverse role)
     all_lanes()
     L(".Lrec_done:")
     # ---- the job's row: g = 8 D job + domain (modulus-major)
@@ -1594,18 +1739,78 @@ def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
     R("s_lshl_b32 s76, s78, %d" % LI)                    # inverse roles completed on the slot by earlier epochs
     R("s_add_u32 s75, s79, 8")
     poll("slot", "s75", "s76")
-    R("s_lshr_b32 s42, s89, %d" % LI)
-    R("s_and_b32 s89, s89, %d" % (NSW - 1))
-    R("s_lshl_b32 s43, s89, %d" % CG_LOG)                # the bytes of q column groups
-    R("s_add_u32 s80, s80, s43")
-    R("s_add_u32 s82, s82, s43")                         # (no carries: the low bits were zero)
-    R("s_cmp_eq_u32 s42, 0")
-    R("s_cselect_b64 s[16:17], s[6:7], s[8:9]")
-    R("s_cselect_b64 s[20:21], s[64:65], s[66:67]")
-    R("s_add_u32 s16, s16, s82")
-    R("s_addc_u32 s17, s17, s83")
-    R("s_add_u32 s20, s20, s80")
-    R("s_addc_u32 s21, s21, s81")
+    if FUSED_LIFO:
+        # the job's first forward role takes two slots from the XCD's pool and publishes them; everybody reads them
+        R("s_lshl_b32 s43, s77, 4")
+        R("s_add_u32 s43, s43, 1024")
+        R("s_add_u32 s96, s72, s43")
+        R("s_addc_u32 s97, s73, 0")                      # s[96:97]: the job's aux record
+        R("s_add_u32 s76, s74, 1")                       # tag = job + 1
+        R("s_cmp_lg_u32 s89, 0")
+        R("s_cbranch_scc1 .Lf_slots")
+        R("v_readfirstlane_b32 s43, v%d" % V_TID)
+        R("s_cmp_lg_u32 s43, 0")
+        R("s_cbranch_scc1 .Lf_slots")
+        lane0()
+        lifo_mask_addr(em, "s[84:85]", "s[68:69]", "s43")
+        lifo_pop(em, "a", 7, "s[84:85]", "s80", "s42", "s43", "s81")
+        lifo_pop(em, "b", 7, "s[84:85]", "s91", "s42", "s43", "s81")
+        R("s_add_u32 s80, s80, 1")
+        R("s_add_u32 s91, s91, 1")
+        R("s_lshl_b32 s91, s91, 8")
+        R("s_or_b32 s80, s80, s91")
+        R("v_mov_b32_e32 v8, 0")
+        R("v_mov_b32_e32 v9, 0")
+        R("global_atomic_swap_x2 v%d, v[8:9], s[96:97] offset:8" % Z)   # c word, products that loaded
+        R("v_mov_b32_e32 v7, s80")
+        R("global_atomic_swap v%d, v7, s[96:97] offset:4" % Z)
+        R("s_waitcnt vmcnt(0)")
+        R("v_mov_b32_e32 v7, s76")
+        R("global_atomic_swap v%d, v7, s[96:97]" % Z)    # the tag last: the record is valid for this job
+        all_lanes()
+        L(".Lf_slots:")
+        R("s_mov_b32 s92, 0")
+        L(".Lf_slots_poll:")
+        R("global_load_dwordx2 v[10:11], v%d, s[96:97] sc1" % Z)
+        R("s_waitcnt vmcnt(0)")
+        R("v_readfirstlane_b32 s91, v10")
+        R("v_readfirstlane_b32 s80, v11")
+        R("s_cmp_eq_u32 s91, s76")
+        R("s_cbranch_scc1 .Lf_slots_known")
+        R("s_sleep 2")
+        R("s_add_u32 s92, s92, 1")
+        R("s_cmp_lt_u32 s92, s62")
+        R("s_cbranch_scc1 .Lf_slots_poll")
+        R("s_trap 2")
+        L(".Lf_slots_known:")
+        R("s_lshr_b32 s42, s89, %d" % LI)                # operand: 0 = a, 1 = b
+        R("s_and_b32 s89, s89, %d" % (NSW - 1))
+        R("s_lshl_b32 s43, s42, 3")
+        R("s_lshr_b32 s80, s80, s43")
+        R("s_and_b32 s80, s80, 0xff")
+        R("s_sub_u32 s80, s80, 1")                       # the operand's slot
+        lifo_slot_addr(em, 20, "s80", "s[64:65]", "s43", NB)
+        R("s_lshl_b32 s43, s89, %d" % CG_LOG)            # the bytes of q column groups
+        R("s_add_u32 s20, s20, s43")
+        R("s_addc_u32 s21, s21, 0")
+        R("s_add_u32 s82, s82, s43")                     # (no carry: the low bits were zero)
+        R("s_cmp_eq_u32 s42, 0")
+        R("s_cselect_b64 s[16:17], s[6:7], s[8:9]")
+        R("s_add_u32 s16, s16, s82")
+        R("s_addc_u32 s17, s17, s83")
+    else:
+        R("s_lshr_b32 s42, s89, %d" % LI)
+        R("s_and_b32 s89, s89, %d" % (NSW - 1))
+        R("s_lshl_b32 s43, s89, %d" % CG_LOG)                # the bytes of q column groups
+        R("s_add_u32 s80, s80, s43")
+        R("s_add_u32 s82, s82, s43")                         # (no carries: the low bits were zero)
+        R("s_cmp_eq_u32 s42, 0")
+        R("s_cselect_b64 s[16:17], s[6:7], s[8:9]")
+        R("s_cselect_b64 s[20:21], s[64:65], s[66:67]")
+        R("s_add_u32 s16, s16, s82")
+        R("s_addc_u32 s17, s17, s83")
+        R("s_add_u32 s20, s20, s80")
+        R("s_addc_u32 s21, s21, s81")
     R("s_mov_b32 s90, 1")
     stamp_t1("f")
     R("s_branch .Lbody_f")
@@ -1614,11 +1819,36 @@ def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
     R("s_lshl_b32 s76, s76, %d" % LV)                    # every block product of the job
     R("s_add_u32 s75, s79, 4")
     poll("vdone", "s75", "s76")
-    R("s_lshl_b32 s43, s89, %d" % CG_LOG)
-    R("s_add_u32 s80, s80, s43")
-    R("s_add_u32 s82, s82, s43")
-    R("s_add_u32 s16, s64, s80")
-    R("s_addc_u32 s17, s65, s81")
+    if FUSED_LIFO:
+        R("s_lshl_b32 s43, s77, 4")
+        R("s_add_u32 s43, s43, 1024")
+        R("s_add_u32 s96, s72, s43")
+        R("s_addc_u32 s97, s73, 0")
+        R("global_load_dword v7, v%d, s[96:97] offset:8 sc1" % Z)       # the c word (published before any product completed)
+        R("s_waitcnt vmcnt(0)")
+        R("v_readfirstlane_b32 s80, v7")
+        R("s_and_b32 s80, s80, 0xff")
+        R("s_sub_u32 s80, s80, 1")
+        R("v_readfirstlane_b32 s43, v%d" % V_TID)
+        R("s_cmp_lg_u32 s43, 0")
+        R("s_cbranch_scc1 .Li_free_noted")
+        lane0()
+        R("s_lshl_b32 s43, 1, s80")
+        R("v_mov_b32_e32 v8, s43")
+        R("ds_write_b32 v%d, v8 offset:%d" % (Z, T + 44))   # returned to the pool by whoever completes the inverse stage
+        all_lanes()
+        L(".Li_free_noted:")
+        lifo_slot_addr(em, 16, "s80", "s[64:65]", "s43", NB)
+        R("s_lshl_b32 s43, s89, %d" % CG_LOG)
+        R("s_add_u32 s16, s16, s43")
+        R("s_addc_u32 s17, s17, 0")
+        R("s_add_u32 s82, s82, s43")
+    else:
+        R("s_lshl_b32 s43, s89, %d" % CG_LOG)
+        R("s_add_u32 s80, s80, s43")
+        R("s_add_u32 s82, s82, s43")
+        R("s_add_u32 s16, s64, s80")
+        R("s_addc_u32 s17, s65, s81")
     R("s_add_u32 s20, s4, s82")
     R("s_addc_u32 s21, s5, s83")
     R("s_mov_b32 s95, 2")
@@ -1629,13 +1859,38 @@ def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
     R("s_lshl_b32 s76, s76, %d" % LF)                    # every forward role of the job
     R("s_mov_b32 s75, s79")
     poll("fdone", "s75", "s76")
-    R("s_lshl_b32 s43, s89, 15")
-    R("s_add_u32 s80, s80, s43")
-    R("s_add_u32 s16, s64, s80")
-    R("s_addc_u32 s17, s65, s81")
-    R("s_add_u32 s18, s66, s80")
-    R("s_addc_u32 s19, s67, s81")
-    R("s_mov_b64 s[20:21], s[16:17]")                    # the block product overwrites its a' block
+    if FUSED_LIFO:
+        R("s_lshl_b32 s43, s77, 4")
+        R("s_add_u32 s43, s43, 1024")
+        R("s_add_u32 s96, s72, s43")
+        R("s_addc_u32 s97, s73, 0")                      # s[96:97]: the job's aux record (kept through the role)
+        R("global_load_dword v7, v%d, s[96:97] offset:4 sc1" % Z)
+        R("s_waitcnt vmcnt(0)")
+        R("v_readfirstlane_b32 s80, v7")
+        R("s_and_b32 s81, s80, 0xff")
+        R("s_sub_u32 s81, s81, 1")                       # a' slot
+        R("s_lshr_b32 s80, s80, 8")
+        R("s_and_b32 s80, s80, 0xff")
+        R("s_sub_u32 s80, s80, 1")                       # b' slot
+        R("s_lshl_b32 s100, 1, s81")
+        R("s_lshl_b32 s43, 1, s80")
+        R("s_or_b32 s100, s100, s43")                    # both bits: returned to the pool once every product has loaded
+        lifo_slot_addr(em, 16, "s81", "s[64:65]", "s43", NB)
+        lifo_slot_addr(em, 18, "s80", "s[64:65]", "s43", NB)
+        R("s_lshl_b32 s43, s89, 15")
+        R("s_add_u32 s16, s16, s43")
+        R("s_addc_u32 s17, s17, 0")
+        R("s_add_u32 s18, s18, s43")
+        R("s_addc_u32 s19, s19, 0")
+        R("s_mov_b64 s[20:21], 0")                       # (the c' block is known when the stores start)
+    else:
+        R("s_lshl_b32 s43, s89, 15")
+        R("s_add_u32 s80, s80, s43")
+        R("s_add_u32 s16, s64, s80")
+        R("s_addc_u32 s17, s65, s81")
+        R("s_add_u32 s18, s66, s80")
+        R("s_addc_u32 s19, s67, s81")
+        R("s_mov_b64 s[20:21], s[16:17]")                    # the block product overwrites its a' block
     stamp_t1("v")
     R("s_branch .Lbody_v")
 
@@ -1795,7 +2050,7 @@ def build_pipe(logn=None, fused=False):
     mark = len(em.lines)
     stream_role("I")
     if fused:   # the scratch comes from another CU of the XCD: read it from the L2, not from this CU's L1
-        em.lines[mark:] = [l + FUSED_LOADS if "global_load_dwordx2" in l else l for l in em.lines[mark:]]
+        em.lines[mark:] = [l + (" nt" if FUSED_LIFO else FUSED_LOADS) if "global_load_dwordx2" in l else l for l in em.lines[mark:]]
     if fused and FUSED_NT:   # ... and the result is written once
         em.lines[mark:] = [l + " nt" if "global_store_dwordx2" in l else l for l in em.lines[mark:]]
 
@@ -1839,7 +2094,19 @@ def build_pipe(logn=None, fused=False):
     mark = len(em.lines)
     build_body(em, vm, "polymul", tw_seq, "_v")
     if fused:
-        em.lines[mark_v:mark] = [l + FUSED_LOADS if "global_load_dwordx2" in l else l for l in em.lines[mark_v:mark]]
+        mod = " nt" if FUSED_LIFO else FUSED_LOADS
+        em.lines[mark_v:mark] = [l + mod if "global_load_dwordx2" in l else l for l in em.lines[mark_v:mark]]
+    if fused and FUSED_LIFO:
+        # splice the pool protocol into the product: "loaded" after its first barrier, the c' slot in front of its stores
+        body = em.lines[mark:]
+        e1, e2 = Emitter(), Emitter()
+        lifo_product_loaded(e1, NV)
+        lifo_product_store(e2, PIPE_LOGN + 3)
+        b = next(i for i, l in enumerate(body) if l.strip() == "s_barrier")
+        body[b + 1:b + 1] = e1.lines
+        st = next(i for i, l in enumerate(body) if l.strip() == ".Lstore:")
+        body[st + 1:st + 1] = e2.lines
+        em.lines[mark:] = body
     em.lines.append(".Lidle:")
     R("s_endpgm")
     if fused:   # every role ends by drawing the next ticket; the only exit is the VOID inverse role of the header
@@ -1975,12 +2242,14 @@ def main():
     em15.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em15.lines]
     emit_file(os.path.join(outdir, "polymul_pipe32768_gfx950.s"), "nflhip_polymul_pipe32768_asm", em15, args=ARGS_PIPE)
     # one-launch variants: rows pinned to an XCD, intermediates through its L2 (fused_header)
-    global FUSED_LOADS
-    for lg, mod, sfx in ((16, "", ""), (15, "", "")):
+    global FUSED_LOADS, FUSED_LIFO
+    for lg, mod, sfx in ((16, "", ""), (15, "", ""), (16, "", "l"), (15, "", "l")):
         FUSED_LOADS = mod
+        FUSED_LIFO = sfx == "l"
         emf = build_pipe(lg, fused=True)
         emit_file(os.path.join(outdir, "polymul_xcd%d%s_gfx950.s" % (1 << lg, sfx)), "nflhip_polymul_xcd%d%s_asm" % (1 << lg, sfx), emf,
                   args=ARGS_PIPE, lds=LDS_BYTES + 64)
+    FUSED_LIFO = False
     build_pipe(16)   # (leave the module-level PIPE_LOGN as it was)
     configure("ring", 4)
     for kind, (stem, kname) in KERNELS16K.items():

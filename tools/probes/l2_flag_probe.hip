@@ -6,7 +6,7 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-enum { kVecPlain, kVecSc0, kVecSc1, kScalarPlain, kScalarGlc, kAtomicRet, kKinds };
+enum { kVecPlain, kVecSc0, kVecSc1, kScalarPlain, kScalarGlc, kAtomicRet, kVecNt, kVecSc0Nt, kVecInvSc0, kVecInvSc1, kKinds };
 __device__ __forceinline__ unsigned probe(const unsigned *p, int kind) {
   unsigned v;
   switch (kind) {
@@ -15,6 +15,10 @@ __device__ __forceinline__ unsigned probe(const unsigned *p, int kind) {
     case kVecSc1: asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); break;
     case kScalarPlain: asm volatile("s_load_dword %0, %1, 0x0\n s_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory"); break;
     case kScalarGlc: asm volatile("s_load_dword %0, %1, 0x0 glc\n s_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory"); break;
+    case kVecNt: asm volatile("global_load_dword %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); break;
+    case kVecSc0Nt: asm volatile("global_load_dword %0, %1, off sc0 nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); break;
+    case kVecInvSc0: asm volatile("buffer_inv sc0\n global_load_dword %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); break;
+    case kVecInvSc1: asm volatile("buffer_inv sc1\n global_load_dword %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); break;
     default: v = __hip_atomic_fetch_add(const_cast<unsigned *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
   }
   return v;
@@ -65,7 +69,7 @@ int main() {
   CHECK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
   CHECK(hipMemcpy(hx.data(), xcc, wgs * 4, hipMemcpyDeviceToHost));
   printf("kernel %.3f ms (producer: %d bumps)\n", ms, bumps);
-  const char *names[kKinds] = {"vector plain", "vector sc0", "vector sc1", "scalar plain", "scalar glc", "atomic +0 ret"};
+  const char *names[kKinds] = {"vector plain", "vector sc0", "vector sc1", "scalar plain", "scalar glc", "atomic +0 ret", "vector nt", "vector sc0 nt", "inv sc0 + plain", "inv sc1 + plain"};
   for (int wg : {8, 1, 9}) {
     printf("consumer wg %d on XCC %u (producer wg 0 on XCC %u)\n", wg, hx[wg], hx[0]);
     for (int kind = 0; kind < kKinds; ++kind) {
