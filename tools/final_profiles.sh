@@ -27,6 +27,7 @@ for mode in fwd inv; do
 done
 rm -rf /tmp/prof_t
 tests/cpp/resident_test | head -1 > $out/${tag}_lwe_poly_p.json
+NFL_LWE_REPS=16384 tests/cpp/resident_test | head -1 >> $out/${tag}_lwe_poly_p.json   # long loop: queue runs overlap recording
 python tools/lwe_demo.py 2>/dev/null > $out/${tag}_lwe.jsonl
 python tools/lwe_demo.py --degree 16384 --nmoduli 8 --batch 512 2>/dev/null >> $out/${tag}_lwe.jsonl
 python tools/lwe_demo.py --degree 1024 --nmoduli 2 --batch 65536 2>/dev/null >> $out/${tag}_lwe.jsonl
