@@ -436,6 +436,12 @@ hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint
   // NFLHIP_U32_MADS (A/B switch, bit-identical results): 0 = multiply / subtract butterflies everywhere, 1 = multiply-add
   // butterflies everywhere, unset = per kernel as measured (see Pol32T)
   static const int mads = getenv("NFLHIP_U32_MADS") ? atoi(getenv("NFLHIP_U32_MADS")) : -1;
+  // NFLHIP_U32_ASM (A/B switch, bit-identical): the hand-scheduled fused product for n = 1024 (0 = the compiled kernel)
+  static const int use_asm = getenv("NFLHIP_U32_ASM") ? atoi(getenv("NFLHIP_U32_ASM")) : 1;
+  if (use_asm && s.logn == 10 && mode == 0) {
+    const hipError_t e = launch_row1024_u32_asm(s, t, c, a, b, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (s.logn == 10) return mads == 1 ? launch_rows<Pol32M, 4>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);
   if (s.logn == 11) return mads == 1 ? launch_rows<Pol32M, 8>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32, 8>(s, t, mode, c, a, b, batch, st);
   if (s.logn == 12) return mads == 0 ? launch_rows<Pol32, 16>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32M, 16>(s, t, mode, c, a, b, batch, st);

@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate nfllib_amd/csrc/row1024_u32_gfx950.s -- the hand-scheduled gfx950 assembly version of the fused product
+for 32-bit limbs, n = 1024 (BASELINE configs[0]'s shape): c = INTT(NTT(a) (.) NTT(b)), ONE WAVE PER RNS ROW.
+
+Same algorithm, lane mapping, LDS layouts and device tables as k_row<Pol32, 0, 4> in kernels_wave.hip (read fwd_row /
+inv_row there first); what the generator adds over hipcc:
+
+  * every coefficient lives in the LOW half of an even-aligned VGPR pair whose high half is scratch, so the
+    multiply-add butterflies need no moves at all: a Cooley-Tukey butterfly is 7 instructions
+        t = x - 2p ; X = min(x, t) ; q = mulhi(y, w') ; u = 2X + 2p ; (X,*) += q*(-p) ; (X,*) += y*w ; y = u - X'
+    (9 in the compiled kernel) and a Gentleman-Sande one 8 (9);
+  * a's and b's forward transforms run together and share every twiddle register and twiddle load;
+  * the 15 twiddles of the first forward / last inverse pass are wave-uniform: they sit in SGPRs for the whole kernel;
+  * the point-wise product leaves its result in [0, 2p) (the inverse butterflies take that), 14 instead of 16.
+
+Run by nfllib_amd/csrc/Makefile (after tools/gen_polymul_asm.py, whose emitter and file templates it reuses).
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_polymul_asm as G   # noqa: E402  (Emitter, interleave, HEADER / FOOTER, args_yaml)
+
+KNAME = "nflhip_row1024_u32_asm"
+OUT = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row1024_u32_gfx950.s")
+
+# ---- registers
+S_P, S_2P, S_NEGP, S_MU, S_NINV, S_NINVSH, S_W1N, S_W1NSH = 30, 31, 32, 33, 34, 35, 36, 37
+S_TW = 40            # s[40:69]: tw[1..15] = {w, w'} pairs: record k at s[40 + 2(k-1)]
+S_DUMMY = "s[72:73]"
+V_TID, V_LANE, V_GOFF, V_A1, V_A2, V_A3, V_TWO, V_TMP = 0, 1, 2, 3, 4, 5, 6, 7
+V_A, V_B = 8, 40     # 16 even-aligned pairs each: coefficient q of a in v[8 + 2q] (low half), scratch in v[9 + 2q]
+V_TWA, V_TWB = 72, 88   # two buffers of 8 per-lane twiddle records {w, w'}
+V_S = [104, 108]     # per-stream temporaries: T0, Q, T2, S
+V_PW = 112           # point-wise temp pair
+NEXT_VGPR = 116
+NEXT_SGPR = 80
+SLAB = 1088 * 4      # bytes of LDS per wave (1024 words + the padding of either exchange layout)
+
+
+def sreg(k):
+    """twiddle record k (1..15) of the uniform passes as operand strings (w, w')"""
+    return "s%d" % (S_TW + 2 * (k - 1)), "s%d" % (S_TW + 2 * (k - 1) + 1)
+
+
+def vrec(buf, i):
+    return "v%d" % (buf + 2 * i), "v%d" % (buf + 2 * i + 1)
+
+
+def pair(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def ct(x, y, tw):
+    """x' = X + (y w - q p), y' = 2X + 2p - x' (Harvey ranges: x < 4p in, both < 4p out)"""
+    w, wp = tw
+
+    def gen(s):
+        T0, Q, T2 = V_S[s], V_S[s] + 1, V_S[s] + 2
+        yield "v_subrev_u32_e32 v%d, s%d, v%d" % (T0, S_2P, x), None, None
+        yield "v_min_u32_e32 v%d, v%d, v%d" % (x, x, T0), None, None
+        yield "v_mul_hi_u32 v%d, v%d, %s" % (Q, y, wp), None, None
+        yield "v_lshl_add_u32 v%d, v%d, 1, s%d" % (T2, x, S_2P), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, s%d, %s" % (pair(x), S_DUMMY, Q, S_NEGP, pair(x)), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (pair(x), S_DUMMY, y, w, pair(x)), None, None
+        yield "v_sub_u32_e32 v%d, v%d, v%d" % (y, T2, x), None, None
+    return gen
+
+
+def gs(x, y, tw):
+    """x' = lazy(x + y), y' = (y - x + 2p) w - q p (inputs < 2p, outputs < 2p)"""
+    w, wp = tw
+
+    def gen(s):
+        T0, Q, D, S = V_S[s], V_S[s] + 1, V_S[s] + 2, V_S[s] + 3
+        yield "v_add_u32_e32 v%d, v%d, v%d" % (S, x, y), None, None
+        yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, y, x), None, None
+        yield "v_add_u32_e32 v%d, s%d, v%d" % (D, S_2P, D), None, None
+        yield "v_subrev_u32_e32 v%d, s%d, v%d" % (T0, S_2P, S), None, None
+        yield "v_min_u32_e32 v%d, v%d, v%d" % (x, S, T0), None, None
+        yield "v_mul_hi_u32 v%d, v%d, %s" % (Q, D, wp), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, s%d, 0" % (pair(y), S_DUMMY, Q, S_NEGP), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (pair(y), S_DUMMY, D, w, pair(y)), None, None
+    return gen
+
+
+def csub(reg, dst, bound_sgpr, s):
+    T0 = V_S[s]
+    yield "v_subrev_u32_e32 v%d, s%d, v%d" % (T0, bound_sgpr, reg), None, None
+    yield "v_min_u32_e32 v%d, v%d, v%d" % (dst, reg, T0), None, None
+
+
+def pointwise(a, b):
+    """a = a*b mod p in [0, 2p): exact Barrett on canonical operands (barrett<uint32_t>::mul without its last subtract)"""
+    def gen(s):
+        Q, TH = V_S[s] + 1, V_S[s] + 2
+        P0 = V_PW + 2 * s
+        for r in (a, b):
+            yield from csub(r, r, S_2P, s)
+            yield from csub(r, r, S_P, s)
+        yield "v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (pair(P0), S_DUMMY, a, b), None, None
+        yield "v_alignbit_b32 v%d, v%d, v%d, 28" % (TH, P0 + 1, P0), None, None
+        yield "v_mul_hi_u32 v%d, v%d, s%d" % (Q, TH, S_MU), None, None
+        yield "v_mad_u64_u32 %s, %s, v%d, s%d, %s" % (pair(P0), S_DUMMY, Q, S_NEGP, pair(P0)), None, None
+        yield from csub(P0, a, S_2P, s)
+    return gen
+
+
+def mul_shoup_exact(y, dst, w_s, wp_s, s):
+    """dst = y * w mod p, canonical (dst is the low half of its pair)"""
+    Q = V_S[s] + 1
+    yield "v_mul_hi_u32 v%d, v%d, s%d" % (Q, y, wp_s), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, s%d, 0" % (pair(dst), S_DUMMY, Q, S_NEGP), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, s%d, %s" % (pair(dst), S_DUMMY, y, w_s, pair(dst)), None, None
+    yield from csub(dst, dst, S_P, s)
+
+
+def last(u, x):
+    """stage 0 of the inverse with n^-1 folded in: canonical outputs (Pol32T::last)"""
+    def gen(s):
+        D, S = V_S[s] + 2, V_S[s] + 3
+        yield "v_add_u32_e32 v%d, v%d, v%d" % (S, u, x), None, None
+        yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, x, u), None, None
+        yield "v_add_u32_e32 v%d, s%d, v%d" % (D, S_2P, D), None, None
+        yield from mul_shoup_exact(S, u, S_NINV, S_NINVSH, s)
+        yield from mul_shoup_exact(D, x, S_W1N, S_W1NSH, s)
+    return gen
+
+
+def run(em, jobs):
+    for i in range(0, len(jobs), 2):
+        gens = [jobs[i](0)]
+        if i + 1 < len(jobs):
+            gens.append(jobs[i + 1](1))
+        G.interleave(em, gens)
+
+
+def build():
+    em = G.Emitter()
+    R = em.raw
+    L = em.lines.append
+    V = em.valu
+    R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
+    R("s_load_dwordx4 s[12:15], s[0:1], 0x20")           # mc, nm, magic = ceil(2^32 / nm) (0 when nm = 1)
+    R("s_load_dwordx2 s[16:17], s[0:1], 0x30")           # rows
+    V("v_and_b32_e32 v%d, 63, v%d" % (V_LANE, V_TID))
+    V("v_lshlrev_b32_e32 v%d, 2, v%d" % (V_GOFF, V_LANE))
+    V("v_readfirstlane_b32 s18, v%d" % V_TID)
+    R("s_lshr_b32 s18, s18, 6")                          # wave of the workgroup
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_lshl_b32 s19, s2, 2")
+    R("s_add_u32 s19, s19, s18")                         # row
+    R("s_cmp_lt_u32 s19, s16")
+    R("s_cbranch_scc1 .Llive")
+    R("s_endpgm")                                        # a surplus wave of the last workgroup (no workgroup barrier anywhere)
+    L(".Llive:")
+    R("s_mul_hi_u32 s20, s19, s15")
+    R("s_mul_i32 s20, s20, s14")
+    R("s_sub_u32 s20, s19, s20")                         # cm = row mod nm
+    R("s_cmp_eq_u32 s14, 1")
+    R("s_cselect_b32 s20, 0, s20")
+    R("s_lshl_b32 s74, s20, 13")                         # twiddles of the modulus: psi + cm * 1024 * 8
+    R("s_add_u32 s22, s10, s74")
+    R("s_addc_u32 s23, s11, 0")
+    R("s_mul_i32 s74, s20, 56")                          # its ModConst<u32> record
+    R("s_add_u32 s74, s12, s74")
+    R("s_addc_u32 s75, s13, 0")
+    R("s_load_dwordx8 s[56:63], s[74:75], 0x0")          # p 2p mu ninv ninv_sh w1ninv w1ninv_sh beta
+    R("s_lshr_b32 s75, s19, 20")
+    R("s_lshl_b32 s74, s19, 12")                         # row * 4096 bytes
+    for base, dst in ((6, 24), (8, 26), (4, 28)):
+        R("s_add_u32 s%d, s%d, s74" % (dst, base))
+        R("s_addc_u32 s%d, s%d, s75" % (dst + 1, base + 1))
+    # operands: lane t holds x[t + 64 q] in pair q
+    for q in range(16):
+        R("global_load_dword v%d, v%d, s[24:25] offset:%d" % (V_A + 2 * q, V_GOFF, 256 * q))
+    for q in range(16):
+        R("global_load_dword v%d, v%d, s[26:27] offset:%d" % (V_B + 2 * q, V_GOFF, 256 * q))
+    # LDS addresses of the wave's slab: A1 = 4 t (+ 272 q), A2 = 4 (68 B + l) (+ 16 q [+ 4 (q >> 2)]), A3 = 68 t (+ 4 q)
+    R("s_mul_i32 s76, s18, %d" % SLAB)
+    V("v_add_u32_e32 v%d, s76, v%d" % (V_A1, V_GOFF))
+    V("v_lshrrev_b32_e32 v%d, 2, v%d" % (V_TMP, V_LANE))                  # B
+    V("v_and_b32_e32 v%d, 3, v%d" % (V_A2, V_LANE))                       # l
+    V("v_mov_b32_e32 v%d, 68" % V_A3)
+    V("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_A2, V_TMP, V_A3, V_A2))     # 68 B + l
+    V("v_lshlrev_b32_e32 v%d, 2, v%d" % (V_A2, V_A2))
+    V("v_add_u32_e32 v%d, s76, v%d" % (V_A2, V_A2))
+    V("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_A3, V_LANE, V_A3))           # 68 t
+    V("v_add_u32_e32 v%d, s76, v%d" % (V_A3, V_A3))
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b32 s%d, s56" % S_P)
+    R("s_mov_b32 s%d, s57" % S_2P)
+    R("s_sub_u32 s%d, 0, s56" % S_NEGP)
+    R("s_mov_b32 s%d, s58" % S_MU)
+    R("s_mov_b32 s%d, s59" % S_NINV)
+    R("s_mov_b32 s%d, s60" % S_NINVSH)
+    R("s_mov_b32 s%d, s61" % S_W1N)
+    R("s_mov_b32 s%d, s62" % S_W1NSH)
+    R("s_load_dwordx16 s[40:55], s[22:23], 0x8")         # tw[1..8]
+    R("s_load_dwordx16 s[56:71], s[22:23], 0x48")        # tw[9..16) (+ one record that is not used)
+
+    def lane_tw(buf, first_index_expr, nrec, descending=False):
+        """per-lane records tw[first .. first + nrec) -> buf (ascending addresses; a descending pass indexes them from the
+        top).  first_index_expr(emit) leaves the record index of the lane in V_TWO."""
+        first_index_expr()
+        V("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_TWO, V_TWO))
+        if nrec == 1:
+            R("global_load_dwordx2 v[%d:%d], v%d, s[22:23]" % (buf, buf + 1, V_TWO))
+        else:
+            for i in range(nrec // 2):
+                R("global_load_dwordx4 v[%d:%d], v%d, s[22:23] offset:%d" % (buf + 4 * i, buf + 4 * i + 3, V_TWO, 16 * i))
+
+    def idx_pass2(s):   # tw[((16 + B) << s) + g]
+        def f():
+            V("v_lshrrev_b32_e32 v%d, 2, v%d" % (V_TWO, V_LANE))
+            V("v_add_u32_e32 v%d, 16, v%d" % (V_TWO, V_TWO))
+            if s:
+                V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s, V_TWO))
+        return f
+
+    def idx_pass3(i):   # tw[(256 << i) + G t + g], G = 4 << i
+        def f():
+            V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, 2 + i, V_LANE))
+            V("v_add_u32_e32 v%d, %d, v%d" % (V_TWO, 256 << i, V_TWO)) if (256 << i) <= 64 else V(
+                "v_add_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 256 << i, V_TWO))
+        return f
+
+    def idx_inv1(i):    # tw[(512 << i) - 1 - (G t + g)], g < G = 4 << i: the block [(512 << i) - G (t + 1), +G)
+        def f():
+            V("v_add_u32_e32 v%d, 1, v%d" % (V_TWO, V_LANE))
+            V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, 2 + i, V_TWO))
+            V("v_sub_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 512 << i, V_TWO))
+        return f
+
+    def idx_inv2(s):    # tw[(32 << s) - 1 - ((B << s) + g)], g < 2^s: the block [(32 - B - 1) << s, +2^s)
+        def f():
+            V("v_lshrrev_b32_e32 v%d, 2, v%d" % (V_TWO, V_LANE))
+            V("v_sub_u32_e32 v%d, 31, v%d" % (V_TWO, V_TWO))
+            if s:
+                V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s, V_TWO))
+        return f
+
+    def stage16(bases, s, twf, op):
+        """radix-2 stage s of a 16-point block: groups g < 2^s, butterflies (g 2 half + h, + half)"""
+        half = 8 >> s
+        jobs = []
+        for g in range(1 << s):
+            for h in range(half):
+                for b in bases:
+                    i0 = g * 2 * half + h
+                    jobs.append(op(b + 2 * i0, b + 2 * (i0 + half), twf(g)))
+        run(em, jobs)
+
+    def exchange(bases, waddr, woff, raddr, roff):
+        for b in bases:
+            for q in range(16):
+                R("ds_write_b32 v%d, v%d offset:%d" % (waddr, b + 2 * q, woff(q)))
+            for q in range(16):
+                R("ds_read_b32 v%d, v%d offset:%d" % (b + 2 * q, raddr, roff(q)))
+            R("s_waitcnt lgkmcnt(0)")                    # (also orders this operand's reads before the next one's writes)
+
+    both = [V_A, V_B]
+    # ---------------------------------------------------------------- forward, both operands
+    lane_tw(V_TWA, idx_pass2(0), 1)
+    R("s_waitcnt vmcnt(1) lgkmcnt(0)")                   # operands landed (the twiddle prefetch may still fly)
+    for s in range(4):
+        stage16(both, s, lambda g, s=s: sreg((1 << s) + g), ct)
+    exchange(both, V_A1, lambda q: 272 * q, V_A2, lambda q: 16 * q)
+    bufs = [V_TWA, V_TWB]
+    for s in range(4):
+        cur = bufs[s & 1]
+        if s < 3:
+            lane_tw(bufs[(s + 1) & 1], idx_pass2(s + 1), 2 << s)
+            R("s_waitcnt vmcnt(%d)" % (1 if s == 0 else (1 << s)))      # this stage's records (issued one stage earlier)
+        else:
+            lane_tw(bufs[(s + 1) & 1], idx_pass3(0), 4)
+            R("s_waitcnt vmcnt(2)")
+        stage16(both, s, lambda g, cur=cur: vrec(cur, g), ct)
+    exchange(both, V_A2, lambda q: 16 * q + 4 * (q >> 2), V_A3, lambda q: 4 * q)
+    # last two stages on the lane's 16 consecutive words: i = 0: d = 2, G = 4; i = 1: d = 1, G = 8
+    lane_tw(V_TWB, idx_pass3(1), 8)
+    R("s_waitcnt vmcnt(4)")
+    jobs = []
+    for g in range(4):
+        for h in range(2):
+            for b in both:
+                jobs.append(ct(b + 2 * (4 * g + h), b + 2 * (4 * g + h + 2), vrec(V_TWA, g)))
+    run(em, jobs)
+    lane_tw(V_TWA, idx_inv1(1), 8)                       # (first inverse stage, descending)
+    R("s_waitcnt vmcnt(4)")
+    jobs = []
+    for g in range(8):
+        for b in both:
+            jobs.append(ct(b + 2 * (2 * g), b + 2 * (2 * g + 1), vrec(V_TWB, g)))
+    run(em, jobs)
+    # ---------------------------------------------------------------- point-wise product -> a, in [0, 2p)
+    run(em, [pointwise(V_A + 2 * q, V_B + 2 * q) for q in range(16)])
+    # ---------------------------------------------------------------- inverse (one operand)
+    one = [V_A]
+    lane_tw(V_TWB, idx_inv1(0), 4)
+    R("s_waitcnt vmcnt(2)")
+    jobs = [gs(V_A + 2 * (2 * g), V_A + 2 * (2 * g + 1), vrec(V_TWA, 7 - g)) for g in range(8)]     # i = 1: d = 1
+    run(em, jobs)
+    lane_tw(V_TWA, idx_inv2(3), 8)
+    R("s_waitcnt vmcnt(4)")
+    jobs = []
+    for g in range(4):                                                                               # i = 0: d = 2
+        for h in range(2):
+            jobs.append(gs(V_A + 2 * (4 * g + h), V_A + 2 * (4 * g + h + 2), vrec(V_TWB, 3 - g)))
+    run(em, jobs)
+    exchange(one, V_A3, lambda q: 4 * q, V_A2, lambda q: 16 * q + 4 * (q >> 2))
+    bufs = [V_TWA, V_TWB]
+    for k, s in enumerate((3, 2, 1, 0)):
+        cur = bufs[k & 1]
+        n = 1 << s
+        if s > 0:
+            lane_tw(bufs[(k + 1) & 1], idx_inv2(s - 1), max(n // 2, 1))
+            R("s_waitcnt vmcnt(%d)" % max(n // 4, 1))
+        else:
+            R("s_waitcnt vmcnt(0)")
+        stage16(one, s, lambda g, cur=cur, n=n: vrec(cur, n - 1 - g), gs)
+    exchange(one, V_A2, lambda q: 16 * q, V_A1, lambda q: 272 * q)
+    for s in (3, 2, 1):                                                                              # uniform: tw[(2 << s) - 1 - g]
+        stage16(one, s, lambda g, s=s: sreg((2 << s) - 1 - g), gs)
+    run(em, [last(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
+    for q in range(16):
+        R("global_store_dword v%d, v%d, s[28:29] offset:%d" % (V_GOFF, V_A + 2 * q, 256 * q))
+    R("s_endpgm")
+    return em
+
+
+ARGS = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 40), ("i32", 44), ("ptr", 48)]
+
+
+def main():
+    em = build()
+    karg = 56
+    accum = (NEXT_VGPR + 3) // 4 * 4
+    params = dict(k=KNAME, lds=4 * SLAB, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
+                  karg=karg, args=G.args_yaml(ARGS).replace("{.address_space: global, .offset: 48, .size: 8, .value_kind: global_buffer}",
+                                                              "{.offset: 48, .size: 8, .value_kind: by_value}"))
+    with open(OUT, "w") as f:
+        f.write("; GENERATED by tools/gen_row1024_u32_asm.py -- do not edit.\n")
+        f.write(G.HEADER % params)
+        f.write("\n".join(em.lines) + "\n")
+        f.write(G.FOOTER % params)
+    print("wrote %s: %d VALU instructions (static), %d lines" % (OUT, em.n_valu, len(em.lines)))
+
+
+if __name__ == "__main__":
+    main()
