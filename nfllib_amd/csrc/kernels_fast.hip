@@ -355,7 +355,7 @@ enum AsmKind {
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
-  kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
+  kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
   kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
   kAsmCount
 };
@@ -371,7 +371,7 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm",
                                                  "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm",
                                                  "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
-                                                 "nflhip_polymul_xcd65536l_asm", "nflhip_polymul_xcd32768l_asm", "nflhip_row1024_u32_asm",
+                                                 "nflhip_polymul_xcd65536l_asm", "nflhip_polymul_xcd32768l_asm", "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm",
                                                  "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
                                                  "nflhip_ntt_inv4096x2nt_asm"};
 struct AsmKernel {
@@ -582,14 +582,15 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
   return hipModuleLaunchKernel(fn, (unsigned)p.wgs, 1, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
 
-// 32-bit limbs, n = 1024: the fused product with one wave per row (tools/gen_row1024_u32_asm.py)
+// 32-bit limbs, n = 1024 / 2048 / 4096: the fused product with one / two / four waves per row (tools/gen_row1024_u32_asm.py)
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, uint32_t *c, const uint32_t *a, const uint32_t *b,
                                   size_t batch, hipStream_t st) {
-  if (s.limb_bits != 32 || s.logn != 10 || variant() < 50) return hipErrorNotSupported;
+  if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || variant() < 50) return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;  // (row mod nm is one multiply in the kernel)
-  hipFunction_t fn = asm_fn(kAsmRow1024U32);
+  hipFunction_t fn = asm_fn(s.logn == 10 ? kAsmRow1024U32 : (s.logn == 11 ? kAsmRow2048U32 : kAsmRow4096U32));
+  const unsigned rpb = 4u >> (s.logn - 10);  // rows per 256-thread workgroup
   if (!fn) return hipErrorNotSupported;
   struct {
     void *c;
@@ -600,7 +601,7 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, uint32_t *
   static_assert(sizeof(args) == 56, "kernarg layout of nflhip_row1024_u32_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(fn, (unsigned)((rows + 3) / 4), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
+  return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
 }
 
 hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,

@@ -436,9 +436,11 @@ hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint
   // NFLHIP_U32_MADS (A/B switch, bit-identical results): 0 = multiply / subtract butterflies everywhere, 1 = multiply-add
   // butterflies everywhere, unset = per kernel as measured (see Pol32T)
   static const int mads = getenv("NFLHIP_U32_MADS") ? atoi(getenv("NFLHIP_U32_MADS")) : -1;
-  // NFLHIP_U32_ASM (A/B switch, bit-identical): the hand-scheduled fused product for n = 1024 (0 = the compiled kernel)
-  static const int use_asm = getenv("NFLHIP_U32_ASM") ? atoi(getenv("NFLHIP_U32_ASM")) : 1;
-  if (use_asm && s.logn == 10 && mode == 0) {
+  // NFLHIP_U32_ASM (A/B switch, bit-identical; read on every call so that a test can flip it): the generated assembly
+  // kernels of the fused product, n = 1024 / 2048 / 4096 (0 = the compiled kernels below).  Measured (MI355X, round 2):
+  // 201 -> 243 M products/s at u32/1024/1, 78.9 -> 96.7 M at u32/2048/1, 11.2 -> 13.3 M at u32/4096/4
+  const char *ua = getenv("NFLHIP_U32_ASM");
+  if ((!ua || atoi(ua) != 0) && s.logn >= 10 && s.logn <= 12 && mode == 0) {
     const hipError_t e = launch_row1024_u32_asm(s, t, c, a, b, batch, st);
     if (e != hipErrorNotSupported) return e;
   }

@@ -1,0 +1,62 @@
+"""The generated gfx950 assembly kernels of the 32-bit fused product (tools/gen_row1024_u32_asm.py: n = 1024 / 2048 /
+4096, one / two / four waves per row) against the compiled kernels they replace (NFLHIP_U32_ASM=0) and against the
+oracle: row counts that leave surplus waves / rows in the last workgroup, several moduli per polynomial, boundary
+words."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SEED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_env():
+    saved = os.environ.get("NFLHIP_U32_ASM")
+    yield
+    if saved is None:
+        os.environ.pop("NFLHIP_U32_ASM", None)
+    else:
+        os.environ["NFLHIP_U32_ASM"] = saved
+
+
+@pytest.mark.parametrize("n,m,batch", [(1024, 1, 7), (1024, 3, 5), (1024, 2, 1), (2048, 2, 5), (2048, 3, 3), (2048, 1, 1),
+                                        (4096, 3, 3), (4096, 1, 2), (1024, 4, 257), (2048, 1, 129), (4096, 2, 65)])
+def test_assembly_product_matches_compiled_kernel_and_oracle(n, m, batch, oracle_factory, engine_factory):
+    o, e = oracle_factory(32, n, m), engine_factory(32, n, m)
+    a = e.fill_uniform(e.empty(batch), SEED, 0)
+    b = e.fill_uniform(e.empty(batch), SEED, 1)
+    ha, hb = e.to_host(a), e.to_host(b)
+    # boundary words: 0, 1, p - 1 in the first polynomial
+    P = np.asarray(o.P[:m], dtype=ha.dtype)
+    ha[0, :, 0], ha[0, :, 1], ha[0, :, 2] = 0, 1, P - 1
+    hb[0, :, 0], hb[0, :, 1], hb[0, :, 2] = P - 1, P - 1, P - 1
+    ha[0, :, n - 1], hb[0, :, n - 1] = P - 1, P - 1
+    a, b = e.to_device(ha), e.to_device(hb)
+    os.environ["NFLHIP_U32_ASM"] = "0"
+    want = e.to_host(e.polymul(a, b))
+    os.environ["NFLHIP_U32_ASM"] = "1"
+    got = e.to_host(e.polymul(a, b))
+    assert np.array_equal(got, want)
+    k = min(batch, 3)
+    assert np.array_equal(got[:k], o.polymul(ha[:k], hb[:k]))
+    # in place on either operand, and commuted
+    a2, b2 = a.clone(), b.clone()
+    e.polymul(a2, b, out=a2)
+    e.polymul(a, b2, out=b2)
+    assert np.array_equal(e.to_host(a2), want) and np.array_equal(e.to_host(b2), want)
+    assert np.array_equal(e.to_host(e.polymul(b, a)), want)
+
+
+def test_assembly_product_every_modulus_of_the_table(oracle_factory, engine_factory):
+    """all 32-bit moduli the context can hold at once, one row each"""
+    from nfllib_amd.params import params
+    m = min(64, params(32).max_moduli)
+    o, e = oracle_factory(32, 1024, m), engine_factory(32, 1024, m)
+    a = e.fill_uniform(e.empty(2), SEED + 3, 0)
+    b = e.fill_uniform(e.empty(2), SEED + 3, 1)
+    os.environ["NFLHIP_U32_ASM"] = "1"
+    got = e.to_host(e.polymul(a, b))
+    assert np.array_equal(got, o.polymul(e.to_host(a), e.to_host(b)))

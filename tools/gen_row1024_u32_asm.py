@@ -21,8 +21,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gen_polymul_asm as G   # noqa: E402  (Emitter, interleave, HEADER / FOOTER, args_yaml)
 
-KNAME = "nflhip_row1024_u32_asm"
-OUT = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row1024_u32_gfx950.s")
+# LB = lanes per 16-block of a row: 4 -> one wave per 1024-word row, 8 -> two waves per 2048-word row, 16 -> a whole
+# 256-thread workgroup per 4096-word row (kernels_wave.hip's LB); the last pass then has 2, 3, 4 stages
+SHAPES = {4: 1024, 8: 2048, 16: 4096}
 
 # ---- registers
 S_P, S_2P, S_NEGP, S_MU, S_NINV, S_NINVSH, S_W1N, S_W1NSH = 30, 31, 32, 33, 34, 35, 36, 37
@@ -35,7 +36,7 @@ V_S = [104, 108]     # per-stream temporaries: T0, Q, T2, S
 V_PW = 112           # point-wise temp pair
 NEXT_VGPR = 116
 NEXT_SGPR = 80
-SLAB = 1088 * 4      # bytes of LDS per wave (1024 words + the padding of either exchange layout)
+SLAB = 1088 * 4      # bytes of LDS per 1024 row words (the padding of either exchange layout included)
 
 
 def sreg(k):
@@ -135,7 +136,12 @@ def run(em, jobs):
         G.interleave(em, gens)
 
 
-def build():
+def build(LB=4):
+    W = 16 * LB                       # lanes per row
+    LG = LB.bit_length() - 1          # log2 LB
+    LOGN = 8 + LG
+    NS3 = LG                          # stages of the last pass: 2, 3, 4
+    WAVES = W // 64                   # waves per row
     em = G.Emitter()
     R = em.raw
     L = em.lines.append
@@ -143,50 +149,69 @@ def build():
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c, a, b, psi
     R("s_load_dwordx4 s[12:15], s[0:1], 0x20")           # mc, nm, magic = ceil(2^32 / nm) (0 when nm = 1)
     R("s_load_dwordx2 s[16:17], s[0:1], 0x30")           # rows
-    V("v_and_b32_e32 v%d, 63, v%d" % (V_LANE, V_TID))
+    V("v_and_b32_e32 v%d, %d, v%d" % (V_LANE, W - 1, V_TID))             # t: lane of the row
     V("v_lshlrev_b32_e32 v%d, 2, v%d" % (V_GOFF, V_LANE))
     V("v_readfirstlane_b32 s18, v%d" % V_TID)
-    R("s_lshr_b32 s18, s18, 6")                          # wave of the workgroup
+    R("s_lshr_b32 s18, s18, %d" % (6 + (WAVES.bit_length() - 1)))        # row of the workgroup
     R("s_waitcnt lgkmcnt(0)")
-    R("s_lshl_b32 s19, s2, 2")
+    R("s_lshl_b32 s19, s2, %d" % (2 - (WAVES.bit_length() - 1)))
     R("s_add_u32 s19, s19, s18")                         # row
+    R("s_mov_b32 s21, 1")                                # store the result
     R("s_cmp_lt_u32 s19, s16")
     R("s_cbranch_scc1 .Llive")
-    R("s_endpgm")                                        # a surplus wave of the last workgroup (no workgroup barrier anywhere)
+    if LB == 4:
+        R("s_endpgm")                                    # a surplus wave of the last workgroup (no workgroup barrier anywhere)
+    else:
+        R("s_sub_u32 s19, s16, 1")                       # a surplus row: walk through every barrier on the last row, store nothing
+        R("s_mov_b32 s21, 0")
     L(".Llive:")
     R("s_mul_hi_u32 s20, s19, s15")
     R("s_mul_i32 s20, s20, s14")
     R("s_sub_u32 s20, s19, s20")                         # cm = row mod nm
     R("s_cmp_eq_u32 s14, 1")
     R("s_cselect_b32 s20, 0, s20")
-    R("s_lshl_b32 s74, s20, 13")                         # twiddles of the modulus: psi + cm * 1024 * 8
+    R("s_lshl_b32 s74, s20, %d" % (LOGN + 3))            # twiddles of the modulus: psi + cm * n * 8
     R("s_add_u32 s22, s10, s74")
     R("s_addc_u32 s23, s11, 0")
     R("s_mul_i32 s74, s20, 56")                          # its ModConst<u32> record
     R("s_add_u32 s74, s12, s74")
     R("s_addc_u32 s75, s13, 0")
     R("s_load_dwordx8 s[56:63], s[74:75], 0x0")          # p 2p mu ninv ninv_sh w1ninv w1ninv_sh beta
-    R("s_lshr_b32 s75, s19, 20")
-    R("s_lshl_b32 s74, s19, 12")                         # row * 4096 bytes
+    R("s_lshr_b32 s75, s19, %d" % (32 - (LOGN + 2)))
+    R("s_lshl_b32 s74, s19, %d" % (LOGN + 2))            # row * n * 4 bytes
     for base, dst in ((6, 24), (8, 26), (4, 28)):
         R("s_add_u32 s%d, s%d, s74" % (dst, base))
         R("s_addc_u32 s%d, s%d, s75" % (dst + 1, base + 1))
-    # operands: lane t holds x[t + 64 q] in pair q
-    for q in range(16):
-        R("global_load_dword v%d, v%d, s[24:25] offset:%d" % (V_A + 2 * q, V_GOFF, 256 * q))
-    for q in range(16):
-        R("global_load_dword v%d, v%d, s[26:27] offset:%d" % (V_B + 2 * q, V_GOFF, 256 * q))
-    # LDS addresses of the wave's slab: A1 = 4 t (+ 272 q), A2 = 4 (68 B + l) (+ 16 q [+ 4 (q >> 2)]), A3 = 68 t (+ 4 q)
-    R("s_mul_i32 s76, s18, %d" % SLAB)
-    V("v_add_u32_e32 v%d, s76, v%d" % (V_A1, V_GOFF))
-    V("v_lshrrev_b32_e32 v%d, 2, v%d" % (V_TMP, V_LANE))                  # B
-    V("v_and_b32_e32 v%d, 3, v%d" % (V_A2, V_LANE))                       # l
-    V("v_mov_b32_e32 v%d, 68" % V_A3)
-    V("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_A2, V_TMP, V_A3, V_A2))     # 68 B + l
+
+    def row_io(base, ptr, store=False):
+        """lane t <-> x[t + W q] in pair q (the immediate offset reaches 4095 bytes: the pointer steps every 4096)"""
+        per = 4096 // (4 * W)
+        R("s_mov_b64 s[76:77], s[%d:%d]" % (ptr, ptr + 1))
+        for q in range(16):
+            if q and q % per == 0:
+                R("s_add_u32 s76, s76, 0x1000")
+                R("s_addc_u32 s77, s77, 0")
+            off = 4 * W * (q % per)
+            if store:
+                R("global_store_dword v%d, v%d, s[76:77] offset:%d" % (V_GOFF, base + 2 * q, off))
+            else:
+                R("global_load_dword v%d, v%d, s[76:77] offset:%d" % (base + 2 * q, V_GOFF, off))
+
+    row_io(V_A, 24)
+    row_io(V_B, 26)
+    # LDS addresses of the row's slab: A1 = 4 t (+ 4 (W + LB) q), A2 = 4 ((W + LB) B + l) (+ 4 LB q [+ 4 (q >> (4 - lg LB))]),
+    # A3 = 68 t (+ 4 q)
+    R("s_mul_i32 s78, s18, %d" % (SLAB * WAVES))
+    V("v_add_u32_e32 v%d, s78, v%d" % (V_A1, V_GOFF))
+    V("v_lshrrev_b32_e32 v%d, %d, v%d" % (V_TMP, LG, V_LANE))             # B
+    V("v_and_b32_e32 v%d, %d, v%d" % (V_A2, LB - 1, V_LANE))              # l
+    V("v_mov_b32_e32 v%d, %d" % (V_A3, W + LB))
+    V("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_A2, V_TMP, V_A3, V_A2))     # (W + LB) B + l
     V("v_lshlrev_b32_e32 v%d, 2, v%d" % (V_A2, V_A2))
-    V("v_add_u32_e32 v%d, s76, v%d" % (V_A2, V_A2))
+    V("v_add_u32_e32 v%d, s78, v%d" % (V_A2, V_A2))
+    V("v_mov_b32_e32 v%d, 68" % V_A3)
     V("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_A3, V_LANE, V_A3))           # 68 t
-    V("v_add_u32_e32 v%d, s76, v%d" % (V_A3, V_A3))
+    V("v_add_u32_e32 v%d, s78, v%d" % (V_A3, V_A3))
     R("s_waitcnt lgkmcnt(0)")
     R("s_mov_b32 s%d, s56" % S_P)
     R("s_mov_b32 s%d, s57" % S_2P)
@@ -199,42 +224,58 @@ def build():
     R("s_load_dwordx16 s[40:55], s[22:23], 0x8")         # tw[1..8]
     R("s_load_dwordx16 s[56:71], s[22:23], 0x48")        # tw[9..16) (+ one record that is not used)
 
-    def lane_tw(buf, first_index_expr, nrec, descending=False):
+    class VM:
+        """counts vector-memory operations so that waits can name the one they need (in-order return)"""
+        issued = 0
+    vm = VM()
+
+    def lane_tw(buf, index_expr, nrec):
         """per-lane records tw[first .. first + nrec) -> buf (ascending addresses; a descending pass indexes them from the
-        top).  first_index_expr(emit) leaves the record index of the lane in V_TWO."""
-        first_index_expr()
+        top).  index_expr() leaves the lane's first record index in V_TWO.  Returns the number of the last load."""
+        index_expr()
         V("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_TWO, V_TWO))
         if nrec == 1:
             R("global_load_dwordx2 v[%d:%d], v%d, s[22:23]" % (buf, buf + 1, V_TWO))
+            vm.issued += 1
         else:
             for i in range(nrec // 2):
                 R("global_load_dwordx4 v[%d:%d], v%d, s[22:23] offset:%d" % (buf + 4 * i, buf + 4 * i + 3, V_TWO, 16 * i))
+                vm.issued += 1
+        return vm.issued
+
+    def wait(seq):
+        R("s_waitcnt vmcnt(%d)" % (vm.issued - seq))
 
     def idx_pass2(s):   # tw[((16 + B) << s) + g]
         def f():
-            V("v_lshrrev_b32_e32 v%d, 2, v%d" % (V_TWO, V_LANE))
+            V("v_lshrrev_b32_e32 v%d, %d, v%d" % (V_TWO, LG, V_LANE))
             V("v_add_u32_e32 v%d, 16, v%d" % (V_TWO, V_TWO))
             if s:
                 V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s, V_TWO))
         return f
 
-    def idx_pass3(i):   # tw[(256 << i) + G t + g], G = 4 << i
+    def idx_pass3(i):   # tw[(256 << i) + G t + g], G = 8 >> (NS3 - 1 - i)
+        lgG = 3 - (NS3 - 1 - i)
         def f():
-            V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, 2 + i, V_LANE))
-            V("v_add_u32_e32 v%d, %d, v%d" % (V_TWO, 256 << i, V_TWO)) if (256 << i) <= 64 else V(
-                "v_add_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 256 << i, V_TWO))
+            if lgG:
+                V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, lgG, V_LANE))
+                V("v_add_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 256 << i, V_TWO))
+            else:
+                V("v_add_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 256 << i, V_LANE))
         return f
 
-    def idx_inv1(i):    # tw[(512 << i) - 1 - (G t + g)], g < G = 4 << i: the block [(512 << i) - G (t + 1), +G)
+    def idx_inv1(i):    # tw[(512 << i) - 1 - (G t + g)], g < G: the block [(512 << i) - G (t + 1), +G)
+        lgG = 3 - (NS3 - 1 - i)
         def f():
             V("v_add_u32_e32 v%d, 1, v%d" % (V_TWO, V_LANE))
-            V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, 2 + i, V_TWO))
+            if lgG:
+                V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, lgG, V_TWO))
             V("v_sub_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 512 << i, V_TWO))
         return f
 
     def idx_inv2(s):    # tw[(32 << s) - 1 - ((B << s) + g)], g < 2^s: the block [(32 - B - 1) << s, +2^s)
         def f():
-            V("v_lshrrev_b32_e32 v%d, 2, v%d" % (V_TWO, V_LANE))
+            V("v_lshrrev_b32_e32 v%d, %d, v%d" % (V_TWO, LG, V_LANE))
             V("v_sub_u32_e32 v%d, 31, v%d" % (V_TWO, V_TWO))
             if s:
                 V("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s, V_TWO))
@@ -251,100 +292,122 @@ def build():
                     jobs.append(op(b + 2 * i0, b + 2 * (i0 + half), twf(g)))
         run(em, jobs)
 
-    def exchange(bases, waddr, woff, raddr, roff):
-        for b in bases:
+    def row_sync():
+        if LB > 4:
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+
+    def exchange(bases, waddr, woff, raddr, roff, sync_between=False, sync_before=False):
+        """LDS exchange of the listed operands, one after the other.  sync_between: writers and readers are different
+        waves of the row (workgroup barrier when the row has more than one wave); sync_before: the slab's previous readers
+        were other waves too"""
+        for n, b in enumerate(bases):
+            if sync_before or (n and sync_between):
+                row_sync()
             for q in range(16):
                 R("ds_write_b32 v%d, v%d offset:%d" % (waddr, b + 2 * q, woff(q)))
+            if sync_between:
+                row_sync()
             for q in range(16):
                 R("ds_read_b32 v%d, v%d offset:%d" % (b + 2 * q, raddr, roff(q)))
-            R("s_waitcnt lgkmcnt(0)")                    # (also orders this operand's reads before the next one's writes)
+            R("s_waitcnt lgkmcnt(0)")
 
+    e1_row = lambda q: 4 * (W + LB) * q                  # x[t + W q]
+    e1_blk = lambda q: 4 * LB * q                        # word LB q + l of block B
+    e2_blk = lambda q: 4 * LB * q + 4 * (q >> (4 - LG))
+    e2_thr = lambda q: 4 * q                             # word 16 t + q
     both = [V_A, V_B]
     # ---------------------------------------------------------------- forward, both operands
-    lane_tw(V_TWA, idx_pass2(0), 1)
+    seq = lane_tw(V_TWA, idx_pass2(0), 1)
     R("s_waitcnt vmcnt(1) lgkmcnt(0)")                   # operands landed (the twiddle prefetch may still fly)
     for s in range(4):
         stage16(both, s, lambda g, s=s: sreg((1 << s) + g), ct)
-    exchange(both, V_A1, lambda q: 272 * q, V_A2, lambda q: 16 * q)
+    exchange(both, V_A1, e1_row, V_A2, e1_blk, sync_between=True)
     bufs = [V_TWA, V_TWB]
     for s in range(4):
-        cur = bufs[s & 1]
+        cur, cur_seq = bufs[s & 1], seq
         if s < 3:
-            lane_tw(bufs[(s + 1) & 1], idx_pass2(s + 1), 2 << s)
-            R("s_waitcnt vmcnt(%d)" % (1 if s == 0 else (1 << s)))      # this stage's records (issued one stage earlier)
+            seq = lane_tw(bufs[(s + 1) & 1], idx_pass2(s + 1), 2 << s)
         else:
-            lane_tw(bufs[(s + 1) & 1], idx_pass3(0), 4)
-            R("s_waitcnt vmcnt(2)")
+            seq = lane_tw(bufs[(s + 1) & 1], idx_pass3(0), 8 >> (NS3 - 1))
+        wait(cur_seq)
         stage16(both, s, lambda g, cur=cur: vrec(cur, g), ct)
-    exchange(both, V_A2, lambda q: 16 * q + 4 * (q >> 2), V_A3, lambda q: 4 * q)
-    # last two stages on the lane's 16 consecutive words: i = 0: d = 2, G = 4; i = 1: d = 1, G = 8
-    lane_tw(V_TWB, idx_pass3(1), 8)
-    R("s_waitcnt vmcnt(4)")
-    jobs = []
-    for g in range(4):
-        for h in range(2):
-            for b in both:
-                jobs.append(ct(b + 2 * (4 * g + h), b + 2 * (4 * g + h + 2), vrec(V_TWA, g)))
-    run(em, jobs)
-    lane_tw(V_TWA, idx_inv1(1), 8)                       # (first inverse stage, descending)
-    R("s_waitcnt vmcnt(4)")
-    jobs = []
-    for g in range(8):
-        for b in both:
-            jobs.append(ct(b + 2 * (2 * g), b + 2 * (2 * g + 1), vrec(V_TWB, g)))
-    run(em, jobs)
+    exchange(both, V_A2, e2_blk, V_A3, e2_thr, sync_before=True)
+    # the last NS3 stages on the lane's 16 consecutive words: stage i has d = 1 << (NS3 - 1 - i), G = 8 / d groups
+    for i in range(NS3):
+        d = 1 << (NS3 - 1 - i)
+        Gn = 8 // d
+        cur, cur_seq = bufs[i & 1], seq
+        if i + 1 < NS3:
+            seq = lane_tw(bufs[(i + 1) & 1], idx_pass3(i + 1), 8 // (d // 2))
+        else:
+            seq = lane_tw(bufs[(i + 1) & 1], idx_inv1(NS3 - 1), 8)   # (first inverse stage, descending)
+        wait(cur_seq)
+        jobs = []
+        for g in range(Gn):
+            for h in range(d):
+                for b in both:
+                    jobs.append(ct(b + 2 * (2 * d * g + h), b + 2 * (2 * d * g + h + d), vrec(cur, g)))
+        run(em, jobs)
     # ---------------------------------------------------------------- point-wise product -> a, in [0, 2p)
     run(em, [pointwise(V_A + 2 * q, V_B + 2 * q) for q in range(16)])
     # ---------------------------------------------------------------- inverse (one operand)
     one = [V_A]
-    lane_tw(V_TWB, idx_inv1(0), 4)
-    R("s_waitcnt vmcnt(2)")
-    jobs = [gs(V_A + 2 * (2 * g), V_A + 2 * (2 * g + 1), vrec(V_TWA, 7 - g)) for g in range(8)]     # i = 1: d = 1
-    run(em, jobs)
-    lane_tw(V_TWA, idx_inv2(3), 8)
-    R("s_waitcnt vmcnt(4)")
-    jobs = []
-    for g in range(4):                                                                               # i = 0: d = 2
-        for h in range(2):
-            jobs.append(gs(V_A + 2 * (4 * g + h), V_A + 2 * (4 * g + h + 2), vrec(V_TWB, 3 - g)))
-    run(em, jobs)
-    exchange(one, V_A3, lambda q: 4 * q, V_A2, lambda q: 16 * q + 4 * (q >> 2))
-    bufs = [V_TWA, V_TWB]
+    for k, i in enumerate(range(NS3 - 1, -1, -1)):
+        d = 1 << (NS3 - 1 - i)
+        Gn = 8 // d
+        cur, cur_seq = bufs[(NS3 + k) & 1], seq
+        if i > 0:
+            seq = lane_tw(bufs[(NS3 + k + 1) & 1], idx_inv1(i - 1), Gn // 2)
+        else:
+            seq = lane_tw(bufs[(NS3 + k + 1) & 1], idx_inv2(3), 8)
+        wait(cur_seq)
+        jobs = []
+        for g in range(Gn):
+            for h in range(d):
+                jobs.append(gs(V_A + 2 * (2 * d * g + h), V_A + 2 * (2 * d * g + h + d), vrec(cur, Gn - 1 - g)))
+        run(em, jobs)
+    exchange(one, V_A3, e2_thr, V_A2, e2_blk)
+    base_k = 2 * NS3
     for k, s in enumerate((3, 2, 1, 0)):
-        cur = bufs[k & 1]
+        cur, cur_seq = bufs[(base_k + k) & 1], seq
         n = 1 << s
         if s > 0:
-            lane_tw(bufs[(k + 1) & 1], idx_inv2(s - 1), max(n // 2, 1))
-            R("s_waitcnt vmcnt(%d)" % max(n // 4, 1))
-        else:
-            R("s_waitcnt vmcnt(0)")
+            seq = lane_tw(bufs[(base_k + k + 1) & 1], idx_inv2(s - 1), n // 2)
+        wait(cur_seq)
         stage16(one, s, lambda g, cur=cur, n=n: vrec(cur, n - 1 - g), gs)
-    exchange(one, V_A2, lambda q: 16 * q, V_A1, lambda q: 272 * q)
+    exchange(one, V_A2, e1_blk, V_A1, e1_row, sync_between=True, sync_before=True)
     for s in (3, 2, 1):                                                                              # uniform: tw[(2 << s) - 1 - g]
         stage16(one, s, lambda g, s=s: sreg((2 << s) - 1 - g), gs)
     run(em, [last(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
-    for q in range(16):
-        R("global_store_dword v%d, v%d, s[28:29] offset:%d" % (V_GOFF, V_A + 2 * q, 256 * q))
+    if LB > 4:
+        R("s_cmp_eq_u32 s21, 0")
+        R("s_cbranch_scc1 .Ldone")
+    row_io(V_A, 28, store=True)
+    L(".Ldone:")
     R("s_endpgm")
-    return em
+    return em, 4 * SLAB
 
 
 ARGS = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 40), ("i32", 44), ("ptr", 48)]
 
 
 def main():
-    em = build()
-    karg = 56
-    accum = (NEXT_VGPR + 3) // 4 * 4
-    params = dict(k=KNAME, lds=4 * SLAB, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
-                  karg=karg, args=G.args_yaml(ARGS).replace("{.address_space: global, .offset: 48, .size: 8, .value_kind: global_buffer}",
-                                                              "{.offset: 48, .size: 8, .value_kind: by_value}"))
-    with open(OUT, "w") as f:
-        f.write("; GENERATED by tools/gen_row1024_u32_asm.py -- do not edit.\n")
-        f.write(G.HEADER % params)
-        f.write("\n".join(em.lines) + "\n")
-        f.write(G.FOOTER % params)
-    print("wrote %s: %d VALU instructions (static), %d lines" % (OUT, em.n_valu, len(em.lines)))
+    for LB, n in sorted(SHAPES.items()):
+        em, lds = build(LB)
+        kname = "nflhip_row%d_u32_asm" % n
+        out = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row%d_u32_gfx950.s" % n)
+        karg = 56
+        accum = (NEXT_VGPR + 3) // 4 * 4
+        params = dict(k=kname, lds=lds, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
+                      karg=karg, args=G.args_yaml(ARGS).replace("{.address_space: global, .offset: 48, .size: 8, .value_kind: global_buffer}",
+                                                                  "{.offset: 48, .size: 8, .value_kind: by_value}"))
+        with open(out, "w") as f:
+            f.write("; GENERATED by tools/gen_row1024_u32_asm.py -- do not edit.\n")
+            f.write(G.HEADER % params)
+            f.write("\n".join(em.lines) + "\n")
+            f.write(G.FOOTER % params)
+        print("wrote %s: %d VALU instructions (static), %d lines" % (out, em.n_valu, len(em.lines)))
 
 
 if __name__ == "__main__":
