@@ -148,8 +148,8 @@ int row16k_level();
 // chunk j, inverse streaming pass of chunk j-2); hipErrorNotSupported for other shapes
 // one launch for the whole batch, rows pinned to an XCD (n = 65536 / 32768); xcd_plan_bytes() = 0 when the shape / batch
 // 32-bit limbs, n = 1024, fused product: the generated gfx950 assembly kernel (hipErrorNotSupported: use k_row)
-hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, uint32_t *c, const uint32_t *a, const uint32_t *b,
-                                  size_t batch, hipStream_t st);
+hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
+                                  const uint32_t *b, size_t batch, hipStream_t st);
 // is not covered.  `work`: device memory of that many bytes, initialised by the call on `st`.
 size_t xcd_plan_bytes(const Shape &s, size_t batch);
 hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,

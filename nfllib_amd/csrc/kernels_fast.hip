@@ -355,7 +355,8 @@ enum AsmKind {
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
-  kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
+  kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
+  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
   kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
   kAsmCount
 };
@@ -372,6 +373,8 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm",
                                                  "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
                                                  "nflhip_polymul_xcd65536l_asm", "nflhip_polymul_xcd32768l_asm", "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm",
+                                                 "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
+                                                 "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm",
                                                  "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
                                                  "nflhip_ntt_inv4096x2nt_asm"};
 struct AsmKernel {
@@ -583,13 +586,15 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
 }
 
 // 32-bit limbs, n = 1024 / 2048 / 4096: the fused product with one / two / four waves per row (tools/gen_row1024_u32_asm.py)
-hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, uint32_t *c, const uint32_t *a, const uint32_t *b,
-                                  size_t batch, hipStream_t st) {
-  if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || variant() < 50) return hipErrorNotSupported;
+hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
+                                  const uint32_t *b, size_t batch, hipStream_t st) {
+  // mode (as launch_row1024_u32): 0 fused product, 2 forward (canonical NTT-form words out), 3 inverse
+  if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || variant() < 50 || (mode != 0 && mode != 2 && mode != 3)) return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;  // (row mod nm is one multiply in the kernel)
-  hipFunction_t fn = asm_fn(s.logn == 10 ? kAsmRow1024U32 : (s.logn == 11 ? kAsmRow2048U32 : kAsmRow4096U32));
+  const int first = mode == 0 ? kAsmRow1024U32 : (mode == 2 ? kAsmRowFwd1024U32 : kAsmRowInv1024U32);
+  hipFunction_t fn = asm_fn((AsmKind)(first + (s.logn - 10)));
   const unsigned rpb = 4u >> (s.logn - 10);  // rows per 256-thread workgroup
   if (!fn) return hipErrorNotSupported;
   struct {

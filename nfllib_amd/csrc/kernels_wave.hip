@@ -438,10 +438,12 @@ hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint
   static const int mads = getenv("NFLHIP_U32_MADS") ? atoi(getenv("NFLHIP_U32_MADS")) : -1;
   // NFLHIP_U32_ASM (A/B switch, bit-identical; read on every call so that a test can flip it): the generated assembly
   // kernels of the fused product, n = 1024 / 2048 / 4096 (0 = the compiled kernels below).  Measured (MI355X, round 2):
-  // 201 -> 243 M products/s at u32/1024/1, 78.9 -> 96.7 M at u32/2048/1, 11.2 -> 13.3 M at u32/4096/4
+  // 201 -> 243 M products/s at u32/1024/1, 78.9 -> 96.7 M at u32/2048/1, 11.2 -> 13.3 M at u32/4096/4; transforms (batch 2^17)
+  // forward / inverse 439 / 408 -> 463 / 444 M at n = 1024, 189 / 207 -> 212 / 234 M at 2048, 25.7 / 23.5 -> 28.9 / 30.6 M at 4096/4
   const char *ua = getenv("NFLHIP_U32_ASM");
-  if ((!ua || atoi(ua) != 0) && s.logn >= 10 && s.logn <= 12 && mode == 0) {
-    const hipError_t e = launch_row1024_u32_asm(s, t, c, a, b, batch, st);
+  const int ual = ua ? atoi(ua) : 2;   // 1: only the fused products, 2 (default): the stand-alone transforms too
+  if (ual != 0 && s.logn >= 10 && s.logn <= 12 && (mode == 0 || (ual >= 2 && (mode == 2 || mode == 3)))) {
+    const hipError_t e = launch_row1024_u32_asm(s, t, mode, c, a, b, batch, st);
     if (e != hipErrorNotSupported) return e;
   }
   if (s.logn == 10) return mads == 1 ? launch_rows<Pol32M, 4>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);

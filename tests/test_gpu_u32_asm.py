@@ -37,9 +37,17 @@ def test_assembly_product_matches_compiled_kernel_and_oracle(n, m, batch, oracle
     a, b = e.to_device(ha), e.to_device(hb)
     os.environ["NFLHIP_U32_ASM"] = "0"
     want = e.to_host(e.polymul(a, b))
-    os.environ["NFLHIP_U32_ASM"] = "1"
+    want_f = e.to_host(e.ntt_(a.clone()))
+    want_i = e.to_host(e.intt_(e.ntt_(b.clone())))
+    os.environ["NFLHIP_U32_ASM"] = "2"
     got = e.to_host(e.polymul(a, b))
     assert np.array_equal(got, want)
+    # the stand-alone transforms (in place): forward = the compiled kernel's and the oracle's words, inverse undoes it
+    fa = e.ntt_(a.clone())
+    assert np.array_equal(e.to_host(fa), want_f)
+    assert np.array_equal(want_f[:1], o.ntt(ha[:1]))
+    assert np.array_equal(e.to_host(e.intt_(fa)), ha)
+    assert np.array_equal(e.to_host(e.intt_(e.ntt_(b.clone()))), want_i) and np.array_equal(want_i, hb)
     k = min(batch, 3)
     assert np.array_equal(got[:k], o.polymul(ha[:k], hb[:k]))
     # in place on either operand, and commuted

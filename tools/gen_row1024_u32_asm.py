@@ -68,14 +68,16 @@ def ct(x, y, tw):
     return gen
 
 
-def gs(x, y, tw):
-    """x' = lazy(x + y), y' = (y - x + 2p) w - q p (inputs < 2p, outputs < 2p)"""
+def gs(x, y, tw, xsrc=None, ysrc=None):
+    """x' = lazy(x + y), y' = (y - x + 2p) w - q p (inputs < 2p, outputs < 2p); xsrc / ysrc: read the inputs from other
+    registers (the inverse-only kernel's first stage takes them from its load block)"""
     w, wp = tw
+    xs, ys = (x if xsrc is None else xsrc), (y if ysrc is None else ysrc)
 
     def gen(s):
         T0, Q, D, S = V_S[s], V_S[s] + 1, V_S[s] + 2, V_S[s] + 3
-        yield "v_add_u32_e32 v%d, v%d, v%d" % (S, x, y), None, None
-        yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, y, x), None, None
+        yield "v_add_u32_e32 v%d, v%d, v%d" % (S, xs, ys), None, None
+        yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, ys, xs), None, None
         yield "v_add_u32_e32 v%d, s%d, v%d" % (D, S_2P, D), None, None
         yield "v_subrev_u32_e32 v%d, s%d, v%d" % (T0, S_2P, S), None, None
         yield "v_min_u32_e32 v%d, v%d, v%d" % (x, S, T0), None, None
@@ -136,7 +138,8 @@ def run(em, jobs):
         G.interleave(em, gens)
 
 
-def build(LB=4):
+def build(LB=4, mode="polymul"):
+    """mode: polymul (c = INTT(NTT(a) (.) NTT(b))) | fwd (c = NTT(a), canonical) | inv (c = INTT(a))"""
     W = 16 * LB                       # lanes per row
     LG = LB.bit_length() - 1          # log2 LB
     LOGN = 8 + LG
@@ -197,8 +200,14 @@ def build(LB=4):
             else:
                 R("global_load_dword v%d, v%d, s[76:77] offset:%d" % (base + 2 * q, V_GOFF, off))
 
-    row_io(V_A, 24)
-    row_io(V_B, 26)
+    if mode == "inv":     # NTT-form input: lane t holds words 16 t .. 16 t + 15 (the b register block serves as load block)
+        V("v_lshlrev_b32_e32 v%d, 6, v%d" % (V_TMP, V_LANE))
+        for i in range(4):
+            R("global_load_dwordx4 v[%d:%d], v%d, s[24:25] offset:%d" % (V_B + 4 * i, V_B + 4 * i + 3, V_TMP, 16 * i))
+    else:
+        row_io(V_A, 24)
+        if mode == "polymul":
+            row_io(V_B, 26)
     # LDS addresses of the row's slab: A1 = 4 t (+ 4 (W + LB) q), A2 = 4 ((W + LB) B + l) (+ 4 LB q [+ 4 (q >> (4 - lg LB))]),
     # A3 = 68 t (+ 4 q)
     R("s_mul_i32 s78, s18, %d" % (SLAB * WAVES))
@@ -316,59 +325,87 @@ def build(LB=4):
     e1_blk = lambda q: 4 * LB * q                        # word LB q + l of block B
     e2_blk = lambda q: 4 * LB * q + 4 * (q >> (4 - LG))
     e2_thr = lambda q: 4 * q                             # word 16 t + q
-    both = [V_A, V_B]
-    # ---------------------------------------------------------------- forward, both operands
-    seq = lane_tw(V_TWA, idx_pass2(0), 1)
-    R("s_waitcnt vmcnt(1) lgkmcnt(0)")                   # operands landed (the twiddle prefetch may still fly)
-    for s in range(4):
-        stage16(both, s, lambda g, s=s: sreg((1 << s) + g), ct)
-    exchange(both, V_A1, e1_row, V_A2, e1_blk, sync_between=True)
+    both = [V_A, V_B] if mode == "polymul" else [V_A]
     bufs = [V_TWA, V_TWB]
-    for s in range(4):
-        cur, cur_seq = bufs[s & 1], seq
-        if s < 3:
-            seq = lane_tw(bufs[(s + 1) & 1], idx_pass2(s + 1), 2 << s)
-        else:
-            seq = lane_tw(bufs[(s + 1) & 1], idx_pass3(0), 8 >> (NS3 - 1))
-        wait(cur_seq)
-        stage16(both, s, lambda g, cur=cur: vrec(cur, g), ct)
-    exchange(both, V_A2, e2_blk, V_A3, e2_thr, sync_before=True)
-    # the last NS3 stages on the lane's 16 consecutive words: stage i has d = 1 << (NS3 - 1 - i), G = 8 / d groups
-    for i in range(NS3):
-        d = 1 << (NS3 - 1 - i)
-        Gn = 8 // d
-        cur, cur_seq = bufs[i & 1], seq
-        if i + 1 < NS3:
-            seq = lane_tw(bufs[(i + 1) & 1], idx_pass3(i + 1), 8 // (d // 2))
-        else:
-            seq = lane_tw(bufs[(i + 1) & 1], idx_inv1(NS3 - 1), 8)   # (first inverse stage, descending)
-        wait(cur_seq)
-        jobs = []
-        for g in range(Gn):
-            for h in range(d):
-                for b in both:
-                    jobs.append(ct(b + 2 * (2 * d * g + h), b + 2 * (2 * d * g + h + d), vrec(cur, g)))
-        run(em, jobs)
-    # ---------------------------------------------------------------- point-wise product -> a, in [0, 2p)
-    run(em, [pointwise(V_A + 2 * q, V_B + 2 * q) for q in range(16)])
-    # ---------------------------------------------------------------- inverse (one operand)
     one = [V_A]
+    if mode != "inv":
+        # ---------------------------------------------------------------- forward (both operands of a product together)
+        seq = lane_tw(V_TWA, idx_pass2(0), 1)
+        R("s_waitcnt vmcnt(1) lgkmcnt(0)")               # operands landed (the twiddle prefetch may still fly)
+        for s in range(4):
+            stage16(both, s, lambda g, s=s: sreg((1 << s) + g), ct)
+        exchange(both, V_A1, e1_row, V_A2, e1_blk, sync_between=True)
+        for s in range(4):
+            cur, cur_seq = bufs[s & 1], seq
+            if s < 3:
+                seq = lane_tw(bufs[(s + 1) & 1], idx_pass2(s + 1), 2 << s)
+            else:
+                seq = lane_tw(bufs[(s + 1) & 1], idx_pass3(0), 8 >> (NS3 - 1))
+            wait(cur_seq)
+            stage16(both, s, lambda g, cur=cur: vrec(cur, g), ct)
+        exchange(both, V_A2, e2_blk, V_A3, e2_thr, sync_before=True)
+        # the last NS3 stages on the lane's 16 consecutive words: stage i has d = 1 << (NS3 - 1 - i), G = 8 / d groups
+        for i in range(NS3):
+            d = 1 << (NS3 - 1 - i)
+            Gn = 8 // d
+            cur, cur_seq = bufs[i & 1], seq
+            if i + 1 < NS3:
+                seq = lane_tw(bufs[(i + 1) & 1], idx_pass3(i + 1), 8 // (d // 2))
+            elif mode == "polymul":
+                seq = lane_tw(bufs[(i + 1) & 1], idx_inv1(NS3 - 1), 8)   # (first inverse stage, descending)
+            wait(cur_seq)
+            jobs = []
+            for g in range(Gn):
+                for h in range(d):
+                    for b in both:
+                        jobs.append(ct(b + 2 * (2 * d * g + h), b + 2 * (2 * d * g + h + d), vrec(cur, g)))
+            run(em, jobs)
+    if mode == "fwd":
+        # canonical words 16 t .. 16 t + 15 into a block of consecutive registers, four 16-byte stores per lane
+        def canon(q):
+            def gen(s):
+                yield from csub(V_A + 2 * q, V_A + 2 * q, S_2P, s)
+                yield from csub(V_A + 2 * q, V_B + q, S_P, s)
+            return gen
+        run(em, [canon(q) for q in range(16)])
+        V("v_lshlrev_b32_e32 v%d, 6, v%d" % (V_TMP, V_LANE))
+        if LB > 4:
+            R("s_cmp_eq_u32 s21, 0")
+            R("s_cbranch_scc1 .Ldone")
+        for i in range(4):
+            R("global_store_dwordx4 v%d, v[%d:%d], s[28:29] offset:%d" % (V_TMP, V_B + 4 * i, V_B + 4 * i + 3, 16 * i))
+        L(".Ldone:")
+        R("s_endpgm")
+        return em, 4 * SLAB
+    if mode == "polymul":
+        # ------------------------------------------------------------ point-wise product -> a, in [0, 2p)
+        run(em, [pointwise(V_A + 2 * q, V_B + 2 * q) for q in range(16)])
+        k0 = NS3
+    else:
+        seq = lane_tw(bufs[0], idx_inv1(NS3 - 1), 8)
+        R("s_waitcnt lgkmcnt(0)")
+        k0 = 0
+    # ---------------------------------------------------------------- inverse (one operand)
     for k, i in enumerate(range(NS3 - 1, -1, -1)):
         d = 1 << (NS3 - 1 - i)
         Gn = 8 // d
-        cur, cur_seq = bufs[(NS3 + k) & 1], seq
+        cur, cur_seq = bufs[(k0 + k) & 1], seq
         if i > 0:
-            seq = lane_tw(bufs[(NS3 + k + 1) & 1], idx_inv1(i - 1), Gn // 2)
+            seq = lane_tw(bufs[(k0 + k + 1) & 1], idx_inv1(i - 1), Gn // 2)
         else:
-            seq = lane_tw(bufs[(NS3 + k + 1) & 1], idx_inv2(3), 8)
+            seq = lane_tw(bufs[(k0 + k + 1) & 1], idx_inv2(3), 8)
         wait(cur_seq)
         jobs = []
         for g in range(Gn):
             for h in range(d):
-                jobs.append(gs(V_A + 2 * (2 * d * g + h), V_A + 2 * (2 * d * g + h + d), vrec(cur, Gn - 1 - g)))
+                x, y = 2 * d * g + h, 2 * d * g + h + d
+                if mode == "inv" and k == 0:   # the loaded words sit in the consecutive block
+                    jobs.append(gs(V_A + 2 * x, V_A + 2 * y, vrec(cur, Gn - 1 - g), xsrc=V_B + x, ysrc=V_B + y))
+                else:
+                    jobs.append(gs(V_A + 2 * x, V_A + 2 * y, vrec(cur, Gn - 1 - g)))
         run(em, jobs)
     exchange(one, V_A3, e2_thr, V_A2, e2_blk)
-    base_k = 2 * NS3
+    base_k = k0 + NS3
     for k, s in enumerate((3, 2, 1, 0)):
         cur, cur_seq = bufs[(base_k + k) & 1], seq
         n = 1 << s
@@ -393,10 +430,11 @@ ARGS = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 4
 
 
 def main():
-    for LB, n in sorted(SHAPES.items()):
-        em, lds = build(LB)
-        kname = "nflhip_row%d_u32_asm" % n
-        out = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row%d_u32_gfx950.s" % n)
+    for LB, n, mode in [(LB, n, mode) for LB, n in sorted(SHAPES.items()) for mode in ("polymul", "fwd", "inv")]:
+        em, lds = build(LB, mode)
+        sfx = "" if mode == "polymul" else "_" + mode
+        kname = "nflhip_row%d%s_u32_asm" % (n, sfx)
+        out = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row%d%s_u32_gfx950.s" % (n, sfx))
         karg = 56
         accum = (NEXT_VGPR + 3) // 4 * 4
         params = dict(k=kname, lds=lds, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
