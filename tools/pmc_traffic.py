@@ -19,7 +19,7 @@ import json
 import os
 import sys
 
-KERNELS = ("nflhip_polymul", "k_ntt_fwd_outer", "k_ntt_inv_outer", "k_row1024_u32", "k_row<", "k_row_block", "k_polymul4096")
+KERNELS = ("nflhip_polymul", "nflhip_row", "nflhip_ntt", "k_ntt_fwd_outer", "k_ntt_inv_outer", "k_row1024_u32", "k_row<", "k_row_block", "k_polymul4096")
 
 
 def total(d, counter):
