@@ -509,7 +509,7 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   P *host;
   void *dev;
   bool host_valid, dev_valid, queued;
-  long qrefs;  // references held by deferred operations (not handles): copy-on-write decisions look past them
+  long qrefs;  // 1 while the deferred queue holds its (single) reference to this value, else 0: copy-on-write decisions look past it
   // levelling scratch of lazy<P>::flush (valid when `epoch` is the current flush): last level that writes / reads this value
   unsigned epoch;
   int wlev, rlev;
@@ -631,20 +631,27 @@ template <class P> struct lazy {
   typedef typename P::value_type T;
   typedef std::shared_ptr<pay_t> ptr_t;
   enum kind_t { K_EVAL = 0, K_NTT_FWD, K_NTT_INV, K_SAMPLE, K_GAUSS, K_FILL };
+  // One recorded operation: 72 bytes, trivially destructible.  The payloads it names are kept alive by ONE reference per
+  // payload and queue run (`pins`), not one per mention -- a loop's temporaries are mentioned three times each.
+  static constexpr int max_in = 4;  // expressions with more distinct handle operands are launched at once, not recorded
   struct op {
-    int kind;
-    ptr_t out;
-    ptr_t in[NFLHIP_EXPR_MAX_OPERANDS];
-    int nin;
-    unsigned char code[NFLHIP_EXPR_MAX_LEN];
-    int len;
-    int dist;
-    uint64_t p0, p1, sid;
-    const nflhip_gauss *tab;
-    op() : kind(0), nin(0), len(0), dist(0), p0(0), p1(0), sid(0), tab(nullptr) {}
+    pay_t *out;
+    union {
+      struct {
+        pay_t *in[max_in];
+        unsigned char code[NFLHIP_EXPR_MAX_LEN];
+      } e;          // K_EVAL (the transforms use out only)
+      struct {
+        uint64_t p0, p1, sid;
+        const nflhip_gauss *tab;
+        int dist;
+      } s;          // K_SAMPLE, K_GAUSS, K_FILL
+    };
+    unsigned char kind, nin, len;
   };
   std::recursive_mutex mu;
   std::vector<op> q, running;  // recorded operations; the ones a queue run is working on (two buffers that swap: no regrowth)
+  std::vector<ptr_t> pins, pins_running;  // the payloads they name, one reference each
   size_t launches, coalesced;  // statistics: launches issued / operations they carried
   // records after which the queue runs by itself: long enough for wide launches, short enough that the device works on
   // one part of a long loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments)
@@ -663,21 +670,30 @@ template <class P> struct lazy {
     return deferred_flag().load(std::memory_order_relaxed) && ctx_t::chunk_bytes == ctx_t::poly_bytes && P::degree >= 8 &&
            P::degree * sizeof(T) >= 16;
   }
-  // `fill(op &)` writes the record in place, in the queue (a record is ~250 bytes: built once, never moved)
+  // the queue's reference to a payload (taken the first time a queue run's operations mention it)
+  void pin(pay_t *p) {
+    if (!p->qrefs) {
+      pins.push_back(p->shared_from_this());
+      p->qrefs = 1;
+    }
+  }
+  // `fill(op &)` writes the record in place, in the queue; the payloads it names are pinned here
   template <class F> void record(F fill) {
     std::lock_guard<std::recursive_mutex> lk(mu);
     q.emplace_back();
     op &o = q.back();
+    o.nin = 0;
+    o.len = 0;
     try {  // inputs must hold a device value (or be produced by the queue) before the operation counts as recorded
       fill(o);
-      for (int j = 0; j < o.nin; ++j) o.in[j]->dev_ro_nf();
+      for (int j = 0; j < o.nin; ++j) o.e.in[j]->dev_ro_nf();
       if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) o.out->dev_ro_nf();
+      pin(o.out);
+      for (int j = 0; j < o.nin; ++j) pin(o.e.in[j]);
     } catch (...) {
       q.pop_back();
       throw;
     }
-    ++o.out->qrefs;
-    for (int j = 0; j < o.nin; ++j) ++o.in[j]->qrefs;
     o.out->queued = true;
     o.out->dev_valid = true;
     o.out->host_valid = false;
@@ -687,20 +703,23 @@ template <class P> struct lazy {
     std::lock_guard<std::recursive_mutex> lk(mu);
     if (q.empty()) return;
     std::vector<op> local;  // (a queue run started from inside another one: cannot happen today, costs nothing to allow)
-    std::vector<op> &ops = running.empty() ? running : local;
+    std::vector<ptr_t> local_pins;
+    const bool outer = running.empty() && pins_running.empty();
+    std::vector<op> &ops = outer ? running : local;
+    std::vector<ptr_t> &held = outer ? pins_running : local_pins;
     ops.swap(q);
+    held.swap(pins);
     if (q.capacity() < ops.capacity()) q.reserve(ops.capacity());
-    struct done_guard {  // whatever happens, the payloads stop claiming a queued value
+    for (auto &p : held) p->qrefs = 0;  // (operations recorded from now on belong to the next run and pin again)
+    struct done_guard {  // whatever happens, the payloads stop claiming a queued value, and the run's references go
       std::vector<op> &o;
+      std::vector<ptr_t> &h;
       ~done_guard() {
-        for (auto &x : o) {
-          x.out->queued = false;
-          --x.out->qrefs;
-          for (int j = 0; j < x.nin; ++j) --x.in[j]->qrefs;
-        }
+        for (auto &x : o) x.out->queued = false;
         o.clear();
+        h.clear();
       }
-    } guard{ops};
+    } guard{ops, held};
     // ---- 1. levels (the last writing / reading level of a value is kept in its payload, tagged with this flush's epoch)
     static unsigned epoch_counter = 0;
     const unsigned ep = ++epoch_counter;
@@ -715,14 +734,14 @@ template <class P> struct lazy {
       op &o = ops[i];
       int L = 0;
       for (int j = 0; j < o.nin; ++j) {
-        touch(o.in[j].get());
-        L = std::max(L, o.in[j]->wlev + 1);
+        touch(o.e.in[j]);
+        L = std::max(L, o.e.in[j]->wlev + 1);
       }
-      touch(o.out.get());
+      touch(o.out);
       L = std::max(L, std::max(o.out->wlev, o.out->rlev) + 1);
       lvl[i] = L;
       o.out->wlev = L;
-      for (int j = 0; j < o.nin; ++j) o.in[j]->rlev = std::max(o.in[j]->rlev, L);
+      for (int j = 0; j < o.nin; ++j) o.e.in[j]->rlev = std::max(o.e.in[j]->rlev, L);
       if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) o.out->rlev = std::max(o.out->rlev, L);
     }
     // ---- 2. groups: (level, signature) -> operations in program order.  A loop produces a handful of distinct
@@ -740,11 +759,11 @@ template <class P> struct lazy {
       uint64_t h = mix(0xcbf29ce484222325ull, uint64_t(o.kind));
       if (o.kind == K_EVAL) {
         uint64_t w[3] = {0, 0, 0};
-        std::memcpy(w, o.code, size_t(o.len));
+        std::memcpy(w, o.e.code, size_t(o.len));
         h = mix(mix(mix(mix(h, w[0]), w[1]), w[2]), (uint64_t(o.len) << 8) | uint64_t(o.nin));
       } else if (o.kind == K_SAMPLE || o.kind == K_GAUSS || o.kind == K_FILL) {
-        h = mix(mix(mix(mix(h, uint64_t(o.dist)), o.p0), o.p1), uint64_t(reinterpret_cast<uintptr_t>(o.tab)));
-        if (o.kind == K_FILL) h = mix(h, o.sid);
+        h = mix(mix(mix(mix(h, uint64_t(o.s.dist)), o.s.p0), o.s.p1), uint64_t(reinterpret_cast<uintptr_t>(o.s.tab)));
+        if (o.kind == K_FILL) h = mix(h, o.s.sid);
       }
       size_t g = keys.size();
       for (size_t k = keys.size(); k-- > 0;)   // (recent groups first: neighbouring operations repeat)
@@ -779,9 +798,9 @@ template <class P> struct lazy {
         for (size_t period = 2; period <= 8 && period * 2 <= idx.size(); ++period) {
           bool periodic = true, constant = true;
           for (size_t i = 0; i + 1 < idx.size() && periodic; ++i) {
-            const uint64_t d = ops[idx[i + 1]].sid - ops[idx[i]].sid;
-            if (i + 1 + period < idx.size()) periodic = d == ops[idx[i + 1 + period]].sid - ops[idx[i + period]].sid;
-            constant &= d == ops[idx[1]].sid - ops[idx[0]].sid;
+            const uint64_t d = ops[idx[i + 1]].s.sid - ops[idx[i]].s.sid;
+            if (i + 1 + period < idx.size()) periodic = d == ops[idx[i + 1 + period]].s.sid - ops[idx[i + period]].s.sid;
+            constant &= d == ops[idx[1]].s.sid - ops[idx[0]].s.sid;
           }
           if (constant) break;
           if (periodic) {
@@ -821,7 +840,7 @@ template <class P> struct lazy {
       }
       if (kind == K_FILL) {
         for (size_t i : idx) {
-          check(ctx, nflhip_fill_uniform_dev(ctx, ops[i].out->dev, 0, 1, ops[i].sid, 0, st), "deferred set(uniform)");
+          check(ctx, nflhip_fill_uniform_dev(ctx, ops[i].out->dev, 0, 1, ops[i].s.sid, 0, st), "deferred set(uniform)");
           ++launches;
           ++coalesced;
         }
@@ -836,19 +855,19 @@ template <class P> struct lazy {
           while (b < idx.size()) {
             const op &prev = ops[idx[b - 1]], &cur = ops[idx[b]];
             if (static_cast<char *>(cur.out->dev) != static_cast<char *>(prev.out->dev) + ctx_t::chunk_bytes) break;
-            const uint64_t d = cur.sid - prev.sid;
+            const uint64_t d = cur.s.sid - prev.s.sid;
             if (b == a + 1) stride = d;
             else if (d != stride) break;
             ++b;
           }
           const size_t cnt = b - a;
           if (kind == K_SAMPLE)
-            check(ctx, cnt == 1 ? nflhip_sample_dev(ctx, o0.out->dev, 0, 1, o0.dist, o0.p0, o0.p1, smp.key, o0.sid, st)
-                                : nflhip_sample_seq_dev(ctx, o0.out->dev, cnt, o0.dist, o0.p0, o0.p1, smp.key, o0.sid, stride, st),
+            check(ctx, cnt == 1 ? nflhip_sample_dev(ctx, o0.out->dev, 0, 1, o0.s.dist, o0.s.p0, o0.s.p1, smp.key, o0.s.sid, st)
+                                : nflhip_sample_seq_dev(ctx, o0.out->dev, cnt, o0.s.dist, o0.s.p0, o0.s.p1, smp.key, o0.s.sid, stride, st),
                   "deferred random constructor");
           else
-            check(ctx, cnt == 1 ? nflhip_sample_gauss_dev(ctx, o0.out->dev, 0, 1, o0.tab, o0.p1, smp.key, o0.sid, st)
-                                : nflhip_sample_gauss_seq_dev(ctx, o0.out->dev, cnt, o0.tab, o0.p1, smp.key, o0.sid, stride, st),
+            check(ctx, cnt == 1 ? nflhip_sample_gauss_dev(ctx, o0.out->dev, 0, 1, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, st)
+                                : nflhip_sample_gauss_seq_dev(ctx, o0.out->dev, cnt, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, stride, st),
                   "deferred set(gaussian)");
           ++launches;
           coalesced += cnt;
@@ -871,7 +890,7 @@ template <class P> struct lazy {
           bool few = idx.size() >= 2;
           for (size_t i : idx) {
             if (!few) break;
-            const pay_t *p = ops[i].in[j].get();
+            const pay_t *p = ops[i].e.in[j];
             size_t k = ns;
             while (k-- > 0 && seen[k] != p) {}
             if (k == size_t(-1)) {
@@ -883,7 +902,7 @@ template <class P> struct lazy {
         }
         for (size_t i : idx) {
           const pay_t *key[NFLHIP_EXPR_MAX_OPERANDS];
-          for (int j = 0; j < nin; ++j) key[j] = keyslot[j] ? ops[i].in[j].get() : nullptr;
+          for (int j = 0; j < nin; ++j) key[j] = keyslot[j] ? ops[i].e.in[j] : nullptr;
           size_t g = sub.size();
           for (size_t k = sub.size(); k-- > 0;)
             if (std::equal(key, key + nin, sub[k].key)) { g = k; break; }
@@ -913,7 +932,7 @@ template <class P> struct lazy {
             if (b == a + 1) ostride = size_t(od) / ctx_t::chunk_bytes;
             else if (size_t(od) != ostride * ctx_t::chunk_bytes) break;
             for (int j = 0; j < nin && ok; ++j) {
-              const ptrdiff_t d = static_cast<char *>(cur.in[j]->dev) - static_cast<char *>(prev.in[j]->dev);
+              const ptrdiff_t d = static_cast<char *>(cur.e.in[j]->dev) - static_cast<char *>(prev.e.in[j]->dev);
               if (d < 0 || d % ptrdiff_t(ctx_t::chunk_bytes)) ok = false;
               else if (b == a + 1) stride[j] = size_t(d) / ctx_t::chunk_bytes;
               else if (size_t(d) != stride[j] * ctx_t::chunk_bytes) ok = false;
@@ -923,11 +942,11 @@ template <class P> struct lazy {
           }
           const size_t cnt = b - a;
           const void *d[NFLHIP_EXPR_MAX_OPERANDS];
-          for (int j = 0; j < nin; ++j) d[j] = o0.in[j]->dev;
+          for (int j = 0; j < nin; ++j) d[j] = o0.e.in[j]->dev;
           if (cnt == 1) {
-            check(ctx, nflhip_eval_dev(ctx, o0.out->dev, d, size_t(nin), o0.code, size_t(o0.len), 1, st), "deferred operator=(expr)");
+            check(ctx, nflhip_eval_dev(ctx, o0.out->dev, d, size_t(nin), o0.e.code, size_t(o0.len), 1, st), "deferred operator=(expr)");
           } else {
-            check(ctx, nflhip_eval_strided_dev(ctx, o0.out->dev, ostride, d, stride, size_t(nin), o0.code, size_t(o0.len), cnt, st),
+            check(ctx, nflhip_eval_strided_dev(ctx, o0.out->dev, ostride, d, stride, size_t(nin), o0.e.code, size_t(o0.len), cnt, st),
                   "deferred operator=(expr)");
           }
           ++launches;
@@ -1046,14 +1065,14 @@ template <class Op, class... Args> struct expr {
     typedef typename payload_type::ctx_t ctx_t;
     if (degree * sizeof(value_type) < 16) return false;  // (rows shorter than one 16-byte vector: nflhip_eval declines)
     typedef detail::lazy<poly_type> lazy_t;
-    if (lazy_t::usable() && pr.nhandles == pr.noperands) {  // every leaf is a handle: record, do not launch
+    if (lazy_t::usable() && pr.nhandles == pr.noperands && pr.noperands <= size_t(lazy_t::max_in)) {  // every leaf is a handle: record, do not launch
       lazy_t::inst().record([&](typename lazy_t::op &o) {
         o.kind = lazy_t::K_EVAL;
-        o.out = out.shared_from_this();
-        o.nin = int(pr.noperands);
-        for (size_t k = 0; k < pr.noperands; ++k) o.in[k] = static_cast<payload_type *>(pr.pay[k])->shared_from_this();
-        o.len = int(pr.len);
-        std::memcpy(o.code, pr.code, pr.len);
+        o.out = &out;
+        o.nin = static_cast<unsigned char>(pr.noperands);
+        for (size_t k = 0; k < pr.noperands; ++k) o.e.in[k] = static_cast<payload_type *>(pr.pay[k]);
+        o.len = static_cast<unsigned char>(pr.len);
+        std::memcpy(o.e.code, pr.code, pr.len);
       });
       return true;
     }
@@ -1715,13 +1734,13 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
       }
     }
     lazy_t::inst().record([&](typename lazy_t::op &o) {
-      o.kind = kind;
-      o.out = p.shared_from_this();
-      o.dist = dist;
-      o.p0 = p0;
-      o.p1 = p1;
-      o.sid = sid;
-      o.tab = tab;
+      o.kind = static_cast<unsigned char>(kind);
+      o.out = &p;
+      o.s.dist = dist;
+      o.s.p0 = p0;
+      o.s.p1 = p1;
+      o.s.sid = sid;
+      o.s.tab = tab;
     });
     return true;
   }
@@ -1853,8 +1872,8 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     detach();
     if (lazy_t::usable()) {
       lazy_t::inst().record([&](typename lazy_t::op &o) {
-        o.kind = kind;
-        o.out = _p;
+        o.kind = static_cast<unsigned char>(kind);
+        o.out = _p.get();
       });
       return;
     }
