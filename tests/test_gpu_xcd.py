@@ -169,3 +169,27 @@ def test_graph_capture_of_one_launch_plan(engine_factory):
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(e.to_host(c), want)
+
+
+def test_two_persistent_kernels_at_once(engine_factory):
+    """two contexts launch their one-launch plans on two streams: 2 x 768 persistent workgroups cannot all be resident;
+    nothing may depend on workgroups that are not (each kernel's roles are served by whichever of ITS workgroups run)"""
+    import torch
+    e1, e2 = engine_factory(64, 65536, 3), engine_factory(64, 32768, 2)
+    a1, b1 = e1.fill_uniform(e1.empty(24), SEED, 0), e1.fill_uniform(e1.empty(24), SEED, 1)
+    a2, b2 = e2.fill_uniform(e2.empty(96), SEED, 2), e2.fill_uniform(e2.empty(96), SEED, 3)
+    os.environ["NFLHIP_XCD"] = "0"
+    w1, w2 = e1.to_host(e1.polymul(a1, b1)), e2.to_host(e2.polymul(a2, b2))
+    os.environ["NFLHIP_XCD"] = "1"
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(6):
+        with torch.cuda.stream(s1):
+            c1 = e1.polymul(a1, b1, stream=s1)
+        with torch.cuda.stream(s2):
+            c2 = e2.polymul(a2, b2, stream=s2)
+        outs.append((c1, c2))
+    torch.cuda.synchronize()
+    for c1, c2 in outs:
+        assert np.array_equal(e1.to_host(c1), w1) and np.array_equal(e2.to_host(c2), w2)
