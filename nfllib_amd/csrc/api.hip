@@ -858,6 +858,15 @@ static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, i
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u32)");
   }
+  if (ctx->shape.limb_bits == 16 && !b_is_ntt) {
+    // NFLHIP_U16_ASM=0: the composed plan on the generic kernels instead of the generated assembly product (A/B switch)
+    const char *ua = getenv("NFLHIP_U16_ASM");
+    if (!ua || atoi(ua) != 0) {
+      hipError_t e = launch_row128_u16_asm(ctx->shape, ctx->tabs, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, batch, st);
+      if (e == hipSuccess) return NFLHIP_OK;
+      if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u16)");
+    }
+  }
   return DISPATCH_T(ctx, polymul_composed<uint16_t>(ctx, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, b_is_ntt, batch, st),
                     polymul_composed<uint32_t>(ctx, (uint32_t *)c, (const uint32_t *)a, (const uint32_t *)b, b_is_ntt, batch, st),
                     polymul_composed<uint64_t>(ctx, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b, b_is_ntt, batch, st));
