@@ -383,6 +383,13 @@ static int pipe32k_on() {
   return v;
 }
 
+// NFLHIP_U16_ASM=0: the generic kernels instead of the generated assembly kernels of 16-bit limbs, n = 128 (A/B switch,
+// bit-identical; read on every call so that a test can flip it)
+static bool u16_asm_on() {
+  const char *ua = getenv("NFLHIP_U16_ASM");
+  return !ua || atoi(ua) != 0;
+}
+
 // Rows of 65536 / 32768 words in ONE launch of persistent workgroups (kernels_fast.hip launch_polymul_xcd_u64) instead
 // of the chunked pipeline.  NFLHIP_XCD: 0 never, 1 always, unset = when the batch has at most NFLHIP_XCD_MAX_ROWS rows
 // (the pipeline's fill and drain launches dominate small batches; measured crossover in DESIGN.md).  Read on every
@@ -774,6 +781,11 @@ int nflhip_ntt_fwd_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(u32)");
   }
+  if (ctx->shape.limb_bits == 16 && u16_asm_on()) {
+    e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 2, (uint16_t *)d, (const uint16_t *)d, nullptr, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(u16)");
+  }
   e = DISPATCH_T(ctx, launch_ntt_fwd<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d, (uint16_t *)d, batch, st),
                  launch_ntt_fwd<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)d, (uint32_t *)d, batch, st),
                  launch_ntt_fwd<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)d, (uint64_t *)d, batch, st));
@@ -797,6 +809,11 @@ int nflhip_ntt_inv_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
     e = launch_row1024_u32(ctx->shape, ctx->tabs, 3, (uint32_t *)d, (const uint32_t *)d, nullptr, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(u32)");
+  }
+  if (ctx->shape.limb_bits == 16 && u16_asm_on()) {
+    e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 3, (uint16_t *)d, (const uint16_t *)d, nullptr, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(u16)");
   }
   e = DISPATCH_T(ctx,
                  launch_ntt_inv<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d, nullptr, (uint16_t *)d, batch, st),
@@ -860,9 +877,8 @@ static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, i
   }
   if (ctx->shape.limb_bits == 16 && !b_is_ntt) {
     // NFLHIP_U16_ASM=0: the composed plan on the generic kernels instead of the generated assembly product (A/B switch)
-    const char *ua = getenv("NFLHIP_U16_ASM");
-    if (!ua || atoi(ua) != 0) {
-      hipError_t e = launch_row128_u16_asm(ctx->shape, ctx->tabs, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, batch, st);
+    if (u16_asm_on()) {
+      hipError_t e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 0, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, batch, st);
       if (e == hipSuccess) return NFLHIP_OK;
       if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u16)");
     }

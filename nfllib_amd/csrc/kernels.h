@@ -148,8 +148,8 @@ int row16k_level();
 // chunk j, inverse streaming pass of chunk j-2); hipErrorNotSupported for other shapes
 // one launch for the whole batch, rows pinned to an XCD (n = 65536 / 32768); xcd_plan_bytes() = 0 when the shape / batch
 // 16-bit limbs, n = 128, fused product: the generated gfx950 assembly kernel (hipErrorNotSupported: composed plan)
-hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, uint16_t *c, const uint16_t *a, const uint16_t *b,
-                                 size_t batch, hipStream_t st);
+hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, uint16_t *c, const uint16_t *a,
+                                 const uint16_t *b, size_t batch, hipStream_t st);
 // 32-bit limbs, n = 1024, fused product: the generated gfx950 assembly kernel (hipErrorNotSupported: use k_row)
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                                   const uint32_t *b, size_t batch, hipStream_t st);

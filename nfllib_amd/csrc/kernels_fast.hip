@@ -356,7 +356,7 @@ enum AsmKind {
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
   kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
-  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow128U16,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
+  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow128U16, kAsmRowFwd128U16, kAsmRowInv128U16,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
   kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
   kAsmCount
 };
@@ -374,7 +374,7 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
                                                  "nflhip_polymul_xcd65536l_asm", "nflhip_polymul_xcd32768l_asm", "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm",
                                                  "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
-                                                 "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row128_u16_asm",
+                                                 "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row128_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm",
                                                  "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
                                                  "nflhip_ntt_inv4096x2nt_asm"};
 struct AsmKernel {
@@ -611,13 +611,15 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
 
 // 16-bit limbs, n = 128 (the reference's (128, 14, uint16_t) config): the fused product, eight rows per wave
 // (tools/gen_row128_u16_asm.py)
-hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, uint16_t *c, const uint16_t *a, const uint16_t *b,
-                                 size_t batch, hipStream_t st) {
-  if (s.limb_bits != 16 || s.logn != 7 || variant() < 50 || (s.nm & (s.nm - 1)) != 0) return hipErrorNotSupported;
+hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, uint16_t *c, const uint16_t *a,
+                                 const uint16_t *b, size_t batch, hipStream_t st) {
+  // mode: 0 fused product, 2 forward (canonical NTT-form words out), 3 inverse
+  if (s.limb_bits != 16 || s.logn != 7 || variant() < 50 || (s.nm & (s.nm - 1)) != 0 || (mode != 0 && mode != 2 && mode != 3))
+    return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorNotSupported;
-  hipFunction_t fn = asm_fn(kAsmRow128U16);
+  hipFunction_t fn = asm_fn(mode == 0 ? kAsmRow128U16 : (mode == 2 ? kAsmRowFwd128U16 : kAsmRowInv128U16));
   if (!fn) return hipErrorNotSupported;
   struct {
     void *c;

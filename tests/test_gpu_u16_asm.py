@@ -34,9 +34,16 @@ def test_assembly_product_matches_generic_kernels_and_oracle(m, batch, oracle_fa
     a, b = e.to_device(ha), e.to_device(hb)
     os.environ["NFLHIP_U16_ASM"] = "0"
     want = e.to_host(e.polymul(a, b))
+    want_f = e.to_host(e.ntt_(a.clone()))
     os.environ["NFLHIP_U16_ASM"] = "1"
     got = e.to_host(e.polymul(a, b))
     assert np.array_equal(got, want)
+    # the stand-alone transforms (in place)
+    fa = e.ntt_(a.clone())
+    assert np.array_equal(e.to_host(fa), want_f)
+    assert np.array_equal(want_f[:1], o.ntt(ha[:1]))
+    assert np.array_equal(e.to_host(e.intt_(fa)), ha)
+    assert np.array_equal(e.to_host(e.intt_(e.ntt_(b.clone()))), hb)
     k = min(batch, 9)
     assert np.array_equal(got[:k], o.polymul(ha[:k], hb[:k]))
     a2, b2 = a.clone(), b.clone()

@@ -20,8 +20,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gen_polymul_asm as G   # noqa: E402
 
-KNAME = "nflhip_row128_u16_asm"
-OUT = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row128_u16_gfx950.s")
 
 V_TID, V_LANE, V_L, V_R, V_GOFF, V_LW, V_LR, V_TWOFF = 0, 1, 2, 3, 4, 5, 6, 7
 V_P, V_2P, V_MU, V_NINV, V_NINVSH, V_W1N, V_W1NSH, V_ROW = 8, 9, 10, 11, 12, 13, 14, 15
@@ -30,6 +28,7 @@ V_W1, V_WP1 = 48, 64          # records 1 .. 15 of the row-uniform passes (index
 V_W2, V_WP2 = 80, 94          # 14 per-lane records of the other pass
 V_S = [108, 114]              # per-stream temporaries (6 each)
 V_X = 120                     # address temporaries (2)
+V_OFF2 = 122                  # byte offset of the lane's 16 consecutive words (NTT-form I/O of the stand-alone transforms)
 NEXT_VGPR = 124
 NEXT_SGPR = 40
 ROW_WORDS = 136               # LDS words per row: 128 + one pad word per 16
@@ -115,7 +114,8 @@ def run(em, jobs):
         G.interleave(em, gens)
 
 
-def build():
+def build(mode="polymul"):
+    """mode: polymul | fwd (c = NTT(a), canonical) | inv (c = INTT(a))"""
     em = G.Emitter()
     R = em.raw
     L = em.lines.append
@@ -153,10 +153,17 @@ def build():
     V("v_subrev_u32_e32 v%d, s19, v%d" % (V_GOFF, V_X))
     V("v_lshlrev_b32_e32 v%d, 8, v%d" % (V_GOFF, V_GOFF))
     V("v_lshl_add_u32 v%d, v%d, 1, v%d" % (V_GOFF, V_L, V_GOFF))   # (row - first row) * 256 + 2 l
-    for q in range(16):
-        R("global_load_ushort v%d, v%d, s[24:25] offset:%d" % (V_A + q, V_GOFF, 16 * q))
-    for q in range(16):
-        R("global_load_ushort v%d, v%d, s[26:27] offset:%d" % (V_B + q, V_GOFF, 16 * q))
+    V("v_mov_b32_e32 v%d, 30" % V_OFF2)
+    V("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_OFF2, V_L, V_OFF2, V_GOFF))   # NTT-form words 16 l + j: (row - first row) * 256 + 32 l
+    if mode == "inv":
+        for j in range(16):
+            R("global_load_ushort v%d, v%d, s[24:25] offset:%d" % (V_A + j, V_OFF2, 2 * j))
+    else:
+        for q in range(16):
+            R("global_load_ushort v%d, v%d, s[24:25] offset:%d" % (V_A + q, V_GOFF, 16 * q))
+        if mode == "polymul":
+            for q in range(16):
+                R("global_load_ushort v%d, v%d, s[26:27] offset:%d" % (V_B + q, V_GOFF, 16 * q))
     for k in range(1, 16):                               # the row-uniform records, raw {w | w' << 16} into the w' registers
         R("global_load_dword v%d, v%d, s[10:11] offset:%d" % (V_WP1 + k, V_TWOFF, 4 * k))
     # LDS: word e of row r at 4 (136 r + e + (e >> 4)); write base (e = l + 8 q), read base (e = 16 l + j)
@@ -212,39 +219,54 @@ def build():
                     R("ds_read_b32 v%d, v%d offset:%d" % (b + q, V_LW, 4 * (8 * q + (q >> 1))))
             R("s_waitcnt lgkmcnt(0)")
 
-    both = [V_A, V_B]
-    # ---------------------------------------------------------------- forward, both operands
+    both = [V_A, V_B] if mode == "polymul" else [V_A]
     R("s_waitcnt vmcnt(0)")
     unpack(V_W1, V_WP1, range(1, 16))
-    for s in range(4):
-        half = 8 >> s
-        jobs = []
-        for g in range(1 << s):
-            k = (1 << s) + g
-            for h in range(half):
-                for b in both:
-                    i0 = g * 2 * half + h
-                    jobs.append(ct(b + i0, b + i0 + half, V_W1 + k, V_WP1 + k))
-        run(em, jobs)
-    for i in range(3):                                   # (all three stages' records: 14 registers)
-        lane_records(i, False)
-    exchange(both, True)
-    R("s_waitcnt vmcnt(0)")
-    unpack(V_W2, V_WP2, range(14))
-    for i in range(3):
-        d = 4 >> i
-        Gn = 2 << i
-        off = Gn - 2
-        jobs = []
-        for g in range(Gn):
-            for h in range(d):
-                for b in both:
-                    jobs.append(ct(b + 2 * d * g + h, b + 2 * d * g + h + d, V_W2 + off + g, V_WP2 + off + g))
-        run(em, jobs)
+    if mode != "inv":
+        # ------------------------------------------------------------ forward (both operands of a product together)
+        for s in range(4):
+            half = 8 >> s
+            jobs = []
+            for g in range(1 << s):
+                k = (1 << s) + g
+                for h in range(half):
+                    for b in both:
+                        i0 = g * 2 * half + h
+                        jobs.append(ct(b + i0, b + i0 + half, V_W1 + k, V_WP1 + k))
+            run(em, jobs)
+        for i in range(3):                               # (all three stages' records: 14 registers)
+            lane_records(i, False)
+        exchange(both, True)
+        R("s_waitcnt vmcnt(0)")
+        unpack(V_W2, V_WP2, range(14))
+        for i in range(3):
+            d = 4 >> i
+            Gn = 2 << i
+            off = Gn - 2
+            jobs = []
+            for g in range(Gn):
+                for h in range(d):
+                    for b in both:
+                        jobs.append(ct(b + 2 * d * g + h, b + 2 * d * g + h + d, V_W2 + off + g, V_WP2 + off + g))
+            run(em, jobs)
+    V("v_cmp_gt_u32_e32 vcc, s16, v%d" % V_ROW)          # rows > row: a real row (surplus lanes store nothing)
+    if mode == "fwd":
+        def canon(q):
+            def gen(s):
+                yield from csub(V_A + q, V_A + q, V_2P, s)
+                yield from csub(V_A + q, V_A + q, V_P, s)
+            return gen
+        run(em, [canon(q) for q in range(16)])
+        R("s_and_saveexec_b64 s[32:33], vcc")
+        for j in range(16):
+            R("global_store_short v%d, v%d, s[28:29] offset:%d" % (V_OFF2, V_A + j, 2 * j))
+        R("s_endpgm")
+        return em
     for i in range(3):
         lane_records(i, True)
-    # ---------------------------------------------------------------- point-wise product -> a, in [0, 2p)
-    run(em, [pointwise(V_A + q, V_B + q) for q in range(16)])
+    if mode == "polymul":
+        # ------------------------------------------------------------ point-wise product -> a, in [0, 2p)
+        run(em, [pointwise(V_A + q, V_B + q) for q in range(16)])
     # ---------------------------------------------------------------- inverse
     R("s_waitcnt vmcnt(0)")
     unpack(V_W2, V_WP2, range(14))
@@ -268,7 +290,7 @@ def build():
                 jobs.append(gs(V_A + i0, V_A + i0 + half, V_W1 + k, V_WP1 + k))
         run(em, jobs)
     run(em, [last(V_A + h, V_A + h + 8) for h in range(8)])
-    V("v_cmp_gt_u32_e32 vcc, s16, v%d" % V_ROW)          # rows > row: a real row
+    V("v_cmp_gt_u32_e32 vcc, s16, v%d" % V_ROW)
     R("s_and_saveexec_b64 s[32:33], vcc")
     for q in range(16):
         R("global_store_short v%d, v%d, s[28:29] offset:%d" % (V_GOFF, V_A + q, 16 * q))
@@ -280,17 +302,21 @@ ARGS = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 4
 
 
 def main():
-    em = build()
-    accum = (NEXT_VGPR + 3) // 4 * 4
-    params = dict(k=KNAME, lds=4 * SLAB, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
-                  karg=56, args=G.args_yaml(ARGS).replace("{.address_space: global, .offset: 48, .size: 8, .value_kind: global_buffer}",
-                                                            "{.offset: 48, .size: 8, .value_kind: by_value}"))
-    with open(OUT, "w") as f:
-        f.write("; GENERATED by tools/gen_row128_u16_asm.py -- do not edit.\n")
-        f.write(G.HEADER % params)
-        f.write("\n".join(em.lines) + "\n")
-        f.write(G.FOOTER % params)
-    print("wrote %s: %d VALU instructions (static), %d lines" % (OUT, em.n_valu, len(em.lines)))
+    for mode in ("polymul", "fwd", "inv"):
+        em = build(mode)
+        sfx = "" if mode == "polymul" else "_" + mode
+        kname = "nflhip_row128%s_u16_asm" % sfx
+        out = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row128%s_u16_gfx950.s" % sfx)
+        accum = (NEXT_VGPR + 3) // 4 * 4
+        params = dict(k=kname, lds=4 * SLAB, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
+                      karg=56, args=G.args_yaml(ARGS).replace("{.address_space: global, .offset: 48, .size: 8, .value_kind: global_buffer}",
+                                                                "{.offset: 48, .size: 8, .value_kind: by_value}"))
+        with open(out, "w") as f:
+            f.write("; GENERATED by tools/gen_row128_u16_asm.py -- do not edit.\n")
+            f.write(G.HEADER % params)
+            f.write("\n".join(em.lines) + "\n")
+            f.write(G.FOOTER % params)
+        print("wrote %s: %d VALU instructions (static), %d lines" % (out, em.n_valu, len(em.lines)))
 
 
 if __name__ == "__main__":
