@@ -356,7 +356,7 @@ enum AsmKind {
   kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
   kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
   kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
-  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow128U16, kAsmRowFwd128U16, kAsmRowInv128U16,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
+  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow128U16, kAsmRowFwd128U16, kAsmRowInv128U16, kAsmRow8U32,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
   kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
   kAsmCount
 };
@@ -374,7 +374,7 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
                                                  "nflhip_polymul_xcd65536l_asm", "nflhip_polymul_xcd32768l_asm", "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm",
                                                  "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
-                                                 "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row128_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm",
+                                                 "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row128_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm", "nflhip_row8_u32_asm",
                                                  "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
                                                  "nflhip_ntt_inv4096x2nt_asm"};
 struct AsmKernel {
@@ -589,6 +589,23 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                                   const uint32_t *b, size_t batch, hipStream_t st) {
   // mode (as launch_row1024_u32): 0 fused product, 2 forward (canonical NTT-form words out), 3 inverse
+  if (s.limb_bits == 32 && s.logn == 3 && mode == 0 && variant() >= 50) {
+    // n = 8 (the reference's (8, 60, uint32_t) config): one LANE per row, 256 rows per workgroup (tools/gen_row8_u32_asm.py)
+    const unsigned long long rows8 = (unsigned long long)batch * s.nm;
+    if (rows8 == 0) return hipSuccess;
+    if (rows8 * s.nm >= (1ull << 32)) return hipErrorNotSupported;
+    hipFunction_t f8 = asm_fn(kAsmRow8U32);
+    if (!f8) return hipErrorNotSupported;
+    struct {
+      void *c;
+      const void *a, *b, *psi, *mc;
+      unsigned nm, magic;
+      unsigned long long rows;
+    } a8 = {c, a, b, t.psi, t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows8};
+    size_t sz8 = sizeof(a8);
+    void *ex8[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz8, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(f8, (unsigned)((rows8 + 255) / 256), 1, 1, 256, 1, 1, 0, st, nullptr, ex8);
+  }
   if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || variant() < 50 || (mode != 0 && mode != 2 && mode != 3)) return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;

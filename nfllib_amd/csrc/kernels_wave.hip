@@ -442,7 +442,7 @@ hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint
   // forward / inverse 439 / 408 -> 463 / 444 M at n = 1024, 189 / 207 -> 212 / 234 M at 2048, 25.7 / 23.5 -> 28.9 / 30.6 M at 4096/4
   const char *ua = getenv("NFLHIP_U32_ASM");
   const int ual = ua ? atoi(ua) : 2;   // 1: only the fused products, 2 (default): the stand-alone transforms too
-  if (ual != 0 && s.logn >= 10 && s.logn <= 12 && (mode == 0 || (ual >= 2 && (mode == 2 || mode == 3)))) {
+  if (ual != 0 && ((s.logn >= 10 && s.logn <= 12 && (mode == 0 || (ual >= 2 && (mode == 2 || mode == 3)))) || (s.logn == 3 && mode == 0))) {
     const hipError_t e = launch_row1024_u32_asm(s, t, mode, c, a, b, batch, st);
     if (e != hipErrorNotSupported) return e;
   }

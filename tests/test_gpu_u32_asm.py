@@ -68,3 +68,26 @@ def test_assembly_product_every_modulus_of_the_table(oracle_factory, engine_fact
     os.environ["NFLHIP_U32_ASM"] = "1"
     got = e.to_host(e.polymul(a, b))
     assert np.array_equal(got, o.polymul(e.to_host(a), e.to_host(b)))
+
+
+@pytest.mark.parametrize("m,batch", [(1, 1), (2, 1), (2, 127), (1, 257), (2, 300), (3, 85), (2, 70001)])
+def test_lane_per_row_product_n8(m, batch, oracle_factory, engine_factory):
+    """n = 8 (the reference's (8, 60, uint32_t) config): one lane per row (tools/gen_row8_u32_asm.py)"""
+    o, e = oracle_factory(32, 8, m), engine_factory(32, 8, m)
+    a = e.fill_uniform(e.empty(batch), SEED, 0)
+    b = e.fill_uniform(e.empty(batch), SEED, 1)
+    ha, hb = e.to_host(a), e.to_host(b)
+    P = np.asarray(o.P[:m], dtype=ha.dtype)
+    ha[0, :, 0], ha[0, :, 1], ha[0, :, 2] = 0, 1, P - 1
+    hb[0, :, 0], hb[0, :, 1], hb[0, :, 7] = P - 1, P - 1, P - 1
+    a, b = e.to_device(ha), e.to_device(hb)
+    os.environ["NFLHIP_U32_ASM"] = "0"
+    want = e.to_host(e.polymul(a, b))
+    os.environ["NFLHIP_U32_ASM"] = "2"
+    got = e.to_host(e.polymul(a, b))
+    assert np.array_equal(got, want)
+    k = min(batch, 300)
+    assert np.array_equal(got[:k], o.polymul(ha[:k], hb[:k]))
+    a2 = a.clone()
+    e.polymul(a2, b, out=a2)
+    assert np.array_equal(e.to_host(a2), want)

@@ -20,7 +20,7 @@ def child(batch, iters, workload):
     from nfllib_amd import Engine
     from nfllib_amd.sharding import digest_words
     lb, n, nm = {"B": (64, 4096, 4), "C": (64, 16384, 8), "E": (64, 65536, 30), "A": (32, 1024, 1), "A2": (32, 1024, 2), "A2K": (32, 2048, 1), "A4K": (32, 4096, 4), "A16K": (32, 16384, 4), "R8": (64, 8192, 2), "S1": (64, 1024, 2), "S2": (64, 2048, 1), "R32": (64, 32768, 2),
-                  "H": (16, 128, 1)}[workload]
+                  "H": (16, 128, 1), "T8": (32, 8, 2)}[workload]
     e = Engine(lb, n, nm)
     a = e.fill_uniform(e.empty(batch), 0x4E464C6C6962, 0)
     b = e.fill_uniform(e.empty(batch), 0x4E464C6C6962, 1)
@@ -66,7 +66,7 @@ def main():
         if ref is None:
             ref = r
         same = r["digest"] == ref["digest"] and r["ntt_digest"] == ref["ntt_digest"]
-        alg = {"B": 393216, "C": 3145728, "E": 47185920, "A": 12288, "A2": 24576, "A2K": 24576, "A4K": 196608, "A16K": 786432, "R8": 393216, "H": 768, "S1": 49152, "S2": 49152, "R32": 1572864}[workload]
+        alg = {"B": 393216, "C": 3145728, "E": 47185920, "A": 12288, "A2": 24576, "A2K": 24576, "A4K": 196608, "A16K": 786432, "R8": 393216, "H": 768, "T8": 192, "S1": 49152, "S2": 49152, "R32": 1572864}[workload]
         print("variant %4s  %8.3f ms  %10.0f polymul/s  %5.1f%% of 8TB/s  fwd %.3g/s (%.2f TB/s)  inv %.3g/s (%.2f TB/s)  same_as_first=%s roundtrip=%s" % (
             v, r["ms"], r["polymul_per_s"], r["polymul_per_s"] * alg / 8e12 * 100, r["ntt_per_s"], r["ntt_per_s"] * alg / 1.5e12,
             r["intt_per_s"], r["intt_per_s"] * alg / 1.5e12, same, r["roundtrip_ok"]))
