@@ -32,6 +32,8 @@ WORKLOADS = {
     "A": (32, 1024, 1, 1 << 19), # configs[0]'s shape (30-bit moduli) on the device -- secondary
     "F": (64, 32768, 2, 512),    # the reference's own largest test config (32768, 124, uint64_t): tests/CMakeLists.txt:19-48
     "G": (64, 8192, 2, 8192),    # ... and (8192, 124, uint64_t)
+    "H": (16, 128, 1, 1 << 22),  # ... (128, 14, uint16_t)
+    "T": (32, 8, 2, 1 << 23),    # ... (8, 60, uint32_t)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
@@ -364,16 +366,17 @@ def main():
                    "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"A": "k_row<Pol32, 0, 4>", "B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm",
+                     "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm",
                                 "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)",
-                                "F": "k_ntt_fwd_outer x2 + nflhip_polymul4096_asm (blocks) + k_ntt_inv_outer (three-kernel plan, chunked on two streams)",
-                                "G": "nflhip_polymul8192_asm"}[kwl],
+                                "F": "nflhip_polymul_xcd32768_asm (one launch of persistent workgroups: forward streaming, block products, "
+                                     "inverse streaming of every row on one XCD)",
+                                "G": "nflhip_polymul8192_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
     # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  Instructions per wave are
     # the SQ_INSTS_VALU / SQ_WAVES of the committed counter passes (= the generator's static count for the assembly kernel);
     # peak = one wave64 instruction per 4 cycles per SIMD, the rate of v_mad_u64_u32 / carry / multiply opcodes on gfx950.
-    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2593, nm, "profiles/r01_final_pmc_sq_A.txt")}.get(kwl)
+    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2081, nm, "profiles/r02_pmc_sq_A.txt")}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]
         peak_gi = 256 * 4 * 2.4 / 4.0   # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles, in G wave-instructions/s

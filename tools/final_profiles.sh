@@ -7,7 +7,7 @@ tag=${1:-r02_final}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-for wl in B A C E F G D; do
+for wl in B A C E F G D H T; do
   python bench.py --workload $wl 2>/dev/null | tail -1 > $out/${tag}_bench_${wl}.json
 done
 here=$(pwd)
