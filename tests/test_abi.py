@@ -88,3 +88,31 @@ def test_product_path_never_touches_the_oracle():
                     if re.search(r"nfl_oracle|from oracle|import oracle|oracle/", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_every_generated_kernel_the_launchers_name_is_in_the_code_object():
+    """kernels_fast.hip looks the generated assembly kernels up BY NAME in the embedded code object and treats a miss as
+    "not supported" (the compiled kernels then serve the call): a typo would silently cost the tuned path.  Every name in
+    kAsmNames must be a kernel symbol of the code object the Makefile links, and every kernel in it must be named."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "nfllib_amd", "csrc")
+    src = open(os.path.join(csrc, "kernels_fast.hip")).read()
+    block = src[src.index("kAsmNames[kAsmCount] = {"):]
+    block = block[:block.index("};")]
+    names = re.findall(r'"(nflhip_[a-z0-9_]+_asm)"', block)
+    assert len(names) >= 30 and len(set(names)) == len(names)
+    enum = src[src.index("enum AsmKind {"):]
+    enum = enum[:enum.index("kAsmCount")]
+    kinds = re.findall(r"\bkAsm[A-Za-z0-9]+\b", re.sub(r"//[^\n]*", "", enum))
+    assert len(kinds) == len(names), "enum AsmKind and kAsmNames must list the same kernels in the same order"
+    hsaco = os.path.join(csrc, "polymul4096_gfx950.hsaco")
+    if not os.path.exists(hsaco):
+        pytest.skip("code object not built here")
+    tool = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(tool):
+        pytest.skip("llvm-readelf not here")
+    syms = subprocess.run([tool, "--symbols", "--wide", hsaco], capture_output=True, text=True, check=True).stdout
+    defined = set(re.findall(r"\bFUNC\s+GLOBAL\s+\S+\s+\d+\s+(nflhip_[a-z0-9_]+_asm)\b", syms))
+    assert set(names) <= defined, sorted(set(names) - defined)
+    assert defined <= set(names), sorted(defined - set(names))
