@@ -1,0 +1,117 @@
+"""CPU-side parity of the GENERATED assembly row kernels: the text tools/gen_row*_asm.py emit is executed by the small
+gfx950 interpreter in tests/asm_emu.py and compared with the oracle, so the `-m "not gpu"` gate covers the arithmetic of
+the assembly kernels too (register allocation, butterfly order, twiddle indexing, exchange addressing, tail handling).
+The GPU tests (tests/test_gpu_u32_asm.py, tests/test_gpu_u16_asm.py) remain the parity tests proper.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import asm_emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nfllib_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def generated():
+    """the generated sources (made by the library's Makefile; regenerated here when absent)"""
+    def get(stem):
+        path = os.path.join(CSRC, stem + "_gfx950.s")
+        if not os.path.exists(path):
+            for g in ("gen_row1024_u32_asm.py", "gen_row128_u16_asm.py", "gen_row8_u32_asm.py"):
+                subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", g)])
+        return path
+    return get
+
+
+def operands(o, limb_bits, n, nm, batch, seed):
+    from nfllib_amd.params import params
+    prm = params(limb_bits)
+    rng = np.random.default_rng(seed)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    a = (rng.integers(0, 1 << 62, size=(batch, nm, n), dtype=np.uint64) % P[None, :, None]).astype(prm.dtype)
+    b = (rng.integers(0, 1 << 62, size=(batch, nm, n), dtype=np.uint64) % P[None, :, None]).astype(prm.dtype)
+    Pw = P.astype(prm.dtype)
+    a[0, :, 0], a[0, :, 1], a[0, :, 2], a[0, :, n - 1] = 0, 1, Pw - 1, Pw - 1
+    b[0, :, 0], b[0, :, 1], b[0, :, 2], b[0, :, n - 1] = Pw - 1, Pw - 1, Pw - 1, Pw - 1
+    return prm, a, b
+
+
+@pytest.mark.parametrize("nm,batch", [(1, 3), (2, 5), (3, 90)])
+def test_emulated_lane_per_row_product_n8(nm, batch, generated, oracle_factory):
+    o = oracle_factory(32, 8, nm)
+    prm, a, b = operands(o, 32, 8, nm, batch, 11)
+    got = asm_emu.run_row_kernel(generated("row8_u32"), 32, 8, nm, prm, a, b, 256, True)
+    assert np.array_equal(got, o.polymul(a, b))
+
+
+@pytest.mark.parametrize("n,nm,batch", [(1024, 1, 1), (1024, 3, 3), (2048, 2, 1), (4096, 1, 1), (4096, 3, 1)])
+def test_emulated_u32_product(n, nm, batch, generated, oracle_factory):
+    o = oracle_factory(32, n, nm)
+    prm, a, b = operands(o, 32, n, nm, batch, 12)
+    got = asm_emu.run_row_kernel(generated("row%d_u32" % n), 32, n, nm, prm, a, b, 4096 // n, True)
+    assert np.array_equal(got, o.polymul(a, b))
+
+
+@pytest.mark.parametrize("n,nm,batch", [(1024, 2, 3), (2048, 1, 1), (4096, 2, 1)])
+def test_emulated_u32_transforms(n, nm, batch, generated, oracle_factory):
+    o = oracle_factory(32, n, nm)
+    prm, a, _ = operands(o, 32, n, nm, batch, 13)
+    f = asm_emu.run_row_kernel(generated("row%d_fwd_u32" % n), 32, n, nm, prm, a, a, 4096 // n, True)
+    assert np.array_equal(f, o.ntt(a))
+    back = asm_emu.run_row_kernel(generated("row%d_inv_u32" % n), 32, n, nm, prm, f, f, 4096 // n, True)
+    assert np.array_equal(back, a)
+
+
+@pytest.mark.parametrize("nm,batch", [(1, 1), (1, 9), (2, 21)])
+def test_emulated_u16_product_and_transforms(nm, batch, generated, oracle_factory):
+    o = oracle_factory(16, 128, nm)
+    prm, a, b = operands(o, 16, 128, nm, batch, 14)
+    got = asm_emu.run_row_kernel(generated("row128_u16"), 16, 128, nm, prm, a, b, 32, False)
+    assert np.array_equal(got, o.polymul(a, b))
+    f = asm_emu.run_row_kernel(generated("row128_fwd_u16"), 16, 128, nm, prm, a, a, 32, False)
+    assert np.array_equal(f, o.ntt(a))
+    back = asm_emu.run_row_kernel(generated("row128_inv_u16"), 16, 128, nm, prm, f, f, 32, False)
+    assert np.array_equal(back, a)
+
+
+@pytest.mark.parametrize("stem,n,block_log,nm,batch", [("polymul4096", 4096, 12, 2, 2), ("polymul4096nt", 4096, 12, 1, 1),
+                                                        ("polymul8192", 8192, 13, 1, 1), ("polymul16384", 16384, 14, 1, 1)])
+def test_emulated_u64_block_product(stem, n, block_log, nm, batch, generated, oracle_factory):
+    """the metric kernel (workloads B / D) and its 8192- and 16384-word siblings: one row per workgroup"""
+    o = oracle_factory(64, n, nm)
+    prm, a, b = operands(o, 64, n, nm, batch, 15)
+    got = asm_emu.run_block_kernel(generated(stem), n, nm, prm, a, b, block_log)
+    assert np.array_equal(got, o.polymul(a, b))
+
+
+@pytest.mark.parametrize("suffix,n,block_log", [("4096", 4096, 12), ("8192", 8192, 13), ("16384", 16384, 14)])
+def test_emulated_u64_block_transforms(suffix, n, block_log, generated, oracle_factory):
+    """stand-alone forward / inverse, the product with b already in NTT form, and (4096) the inverse with a fused
+    pointwise multiply"""
+    nm = 2 if n == 4096 else 1
+    o = oracle_factory(64, n, nm)
+    prm, a, b = operands(o, 64, n, nm, 1, 16)
+    fa, fb = o.ntt(a), o.ntt(b)
+    want = o.polymul(a, b)
+    assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_fwd" + suffix), n, nm, prm, a, a, block_log), fa)
+    assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_inv" + suffix), n, nm, prm, fa, fa, block_log), a)
+    assert np.array_equal(asm_emu.run_block_kernel(generated("polymul_ntt" + suffix), n, nm, prm, a, fb, block_log), want)
+    if n == 4096:
+        assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_inv_mul4096"), n, nm, prm, fa, fb, block_log), want)
+
+
+@pytest.mark.parametrize("nt", ["", "nt"])
+@pytest.mark.parametrize("nm,batch", [(1, 3), (2, 2)])
+def test_emulated_u64_two_rows_per_workgroup_transforms(nt, nm, batch, generated, oracle_factory):
+    """n = 4096 stand-alone transforms, two polynomials per workgroup (an odd count leaves half a workgroup)"""
+    n = 4096
+    o = oracle_factory(64, n, nm)
+    prm, a, _ = operands(o, 64, n, nm, batch, 17)
+    fa = o.ntt(a)
+    assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_fwd4096x2" + nt), n, nm, prm, a, a, 12, count=batch), fa)
+    assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_inv4096x2" + nt), n, nm, prm, fa, fa, 12, count=batch), a)
