@@ -1,11 +1,14 @@
-"""TEST INFRASTRUCTURE: a small interpreter for the subset of gfx950 assembly that the row-kernel generators
-(tools/gen_row1024_u32_asm.py, gen_row128_u16_asm.py, gen_row8_u32_asm.py) emit, so that the GENERATED kernels can be
-checked against the oracle on a machine without a GPU (tests/test_asm_emulated.py, `-m "not gpu"`).
+"""TEST INFRASTRUCTURE: a small interpreter for the subset of gfx950 assembly that the kernel generators
+(tools/gen_polymul_asm.py, gen_row1024_u32_asm.py, gen_row128_u16_asm.py, gen_row8_u32_asm.py) emit, so that the
+GENERATED kernels can be checked against the oracle on a machine without a GPU (tests/test_asm_emulated.py,
+`-m "not gpu"`).
 
 It executes the text the generators produce: one numpy vector of 64 lanes per VGPR, scalar registers, VCC / EXEC / SCC,
-a flat "device memory" made of registered buffers, one LDS array per workgroup, waves of a workgroup interleaved at
-s_barrier.  Timing, hazards and wait counts are ignored (every memory operation completes at once); an instruction the
-interpreter does not know raises, so a generator change that needs more of the ISA fails loudly here.
+a flat "device memory" made of registered buffers (one coherent copy: no caches), one LDS array per workgroup, waves of
+a workgroup interleaved at s_barrier, workgroups of a launch either one after the other or -- for the persistent
+one-launch plan -- interleaved at their s_sleep polls in an order the test chooses.  Timing, hazards and wait counts are
+ignored (every memory operation completes at once); an instruction the interpreter does not know raises, so a generator
+change that needs more of the ISA fails loudly here.
 """
 import re
 
@@ -13,6 +16,8 @@ import numpy as np
 
 M32 = 0xFFFFFFFF
 M64 = (1 << 64) - 1
+U = np.uint64
+U32 = U(M32)
 
 
 class Memory:
@@ -21,13 +26,13 @@ class Memory:
     def __init__(self):
         self.bufs = []
         self.next = 0x100000000
+        self.version = 0          # bumped by every store / atomic (deadlock detection of the concurrent scheduler)
 
     def add(self, arr):
         a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
         base = self.next
         self.bufs.append((base, a))
-        self.next += (a.size + 0xFFFF) & ~0xFFFF
-        self.next += 0x10000
+        self.next += ((a.size + 0xFFFF) & ~0xFFFF) + 0x10000
         return base
 
     def find(self, addr, n):
@@ -43,11 +48,58 @@ class Memory:
     def write(self, addr, data):
         a, o = self.find(addr, len(data))
         a[o:o + len(data)] = np.frombuffer(data, dtype=np.uint8)
+        self.version += 1
+
+    def gather(self, addrs, n):
+        """addrs: int64 vector -> (len, n) uint8"""
+        a, o = self.find(int(addrs.min()), int(addrs.max() - addrs.min()) + n)
+        idx = (addrs - addrs.min() + o)[:, None] + np.arange(n)
+        return a[idx]
+
+    def scatter(self, addrs, data):
+        n = data.shape[1]
+        a, o = self.find(int(addrs.min()), int(addrs.max() - addrs.min()) + n)
+        idx = (addrs - addrs.min() + o)[:, None] + np.arange(n)
+        a[idx] = data
+        self.version += 1
+
+
+# operand kinds
+K_V, K_S, K_IMM, K_V2, K_S2, K_VCC, K_EXEC, K_VCCLO, K_OFF, K_VN, K_SN = range(11)
+_DEC = {}
+
+
+def dec(op):
+    d = _DEC.get(op)
+    if d is None:
+        m = re.fullmatch(r"([vs])(\d+)", op)
+        m2 = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", op)
+        if m:
+            d = (K_V if m.group(1) == "v" else K_S, int(m.group(2)))
+        elif m2:
+            lo, hi = int(m2.group(2)), int(m2.group(3))
+            if hi == lo + 1:
+                d = (K_V2 if m2.group(1) == "v" else K_S2, lo)
+            else:
+                d = (K_VN if m2.group(1) == "v" else K_SN, lo)
+        elif op == "vcc":
+            d = (K_VCC, 0)
+        elif op == "exec":
+            d = (K_EXEC, 0)
+        elif op == "vcc_lo":
+            d = (K_VCCLO, 0)
+        elif op == "off":
+            d = (K_OFF, 0)
+        else:
+            d = (K_IMM, int(op, 0))
+        _DEC[op] = d
+    return d
 
 
 def parse_program(text):
-    """-> (instructions, labels): instructions = list of (mnemonic, operands, modifiers); reads up to .Lfunc_end"""
+    """-> (instructions, labels): instructions = list of (mnemonic, decoded operands, modifiers); reads up to .Lfunc_end"""
     ins, labels = [], {}
+    pat = r"\b(offset|dst_sel|dst_unused|src0_sel|src1_sel):(\S+)"
     for raw in text.split("\n"):
         line = raw.split(";")[0].strip()
         if not line:
@@ -62,335 +114,613 @@ def parse_program(text):
         m = re.match(r"([a-z_0-9]+)\s*(.*)", line)
         mn, rest = m.group(1), m.group(2)
         mods = {}
-        pat = r"\b(offset|dst_sel|dst_unused|src0_sel|src1_sel):(\S+)"
         for key, val in re.findall(pat, rest):
-            mods[key] = val
+            mods[key] = int(val, 0) if key == "offset" else val
         rest = re.sub(pat, "", rest)
         for flag in ("sc0", "sc1", "nt", "glc"):
             if re.search(r"\b%s\b" % flag, rest):
                 mods[flag] = True
                 rest = re.sub(r"\b%s\b" % flag, "", rest)
-        if mn == "s_waitcnt":
+        if mn in ("s_waitcnt", "s_nop", "s_sleep", "s_trap"):
             ops = []
+        elif mn == "s_getreg_b32":
+            dst, reg = rest.split(",", 1)
+            ops = [dec(dst.strip()), reg.strip()]
+        elif mn.startswith("s_cbranch") or mn == "s_branch":
+            ops = [rest.strip()]
         else:
-            ops = [o.strip() for o in rest.split(",") if o.strip()]
+            ops = [dec(o.strip()) for o in rest.split(",") if o.strip()]
         ins.append((mn, ops, mods))
     return ins, labels
 
 
+_ALL = np.ones(64, dtype=bool)
+
+
+def mask_of(bits):
+    return np.unpackbits(np.array([bits], dtype="<u8").view(np.uint8), bitorder="little").astype(bool)
+
+
+def bits_of(flags):
+    return int(np.packbits(np.broadcast_to(flags, (64,)), bitorder="little").view("<u8")[0])
+
+
 class Wave:
-    def __init__(self, prog, labels, mem, lds, kernarg_addr, wg_id, wave_in_wg, wg_y=0):
+    ticks = 0      # s_memtime: instructions executed by the whole launch
+
+    def __init__(self, prog, labels, mem, lds, kernarg_addr, wg_id, wave_in_wg, wg_y=0, xcc_id=0):
         self.prog, self.labels, self.mem, self.lds = prog, labels, mem, lds
         self.v = np.zeros((256, 64), dtype=np.uint64)     # (kept as uint64, masked to 32 bits)
         self.s = [0] * 108
         self.vcc = 0
-        self.exec = M64
         self.scc = 0
         self.pc = 0
+        self.set_exec(M64)
         self.s[0], self.s[1] = kernarg_addr & M32, kernarg_addr >> 32
         self.s[2] = wg_id
         self.s[3] = wg_y
         self.v[0] = np.arange(64, dtype=np.uint64) + 64 * wave_in_wg
-        self.done = False
+        self.xcc_id = xcc_id
+
+    def set_exec(self, bits):
+        self.exec = bits & M64
+        self.full = self.exec == M64
+        self.act = _ALL if self.full else mask_of(self.exec)
 
     # ---- operands
-    def lanes(self):
-        return self.mask_of(self.exec)
+    def rd32(self, d):
+        k, x = d
+        if k == K_V:
+            return self.v[x]
+        if k == K_S:
+            return U(self.s[x])
+        if k == K_IMM:
+            return U(x & M32)
+        if k == K_VCCLO:
+            return U(self.vcc & M32)
+        raise RuntimeError("32-bit operand %r" % (d,))
 
-    @staticmethod
-    def mask_of(bits):
-        return np.unpackbits(np.array([bits], dtype="<u8").view(np.uint8), bitorder="little").astype(bool)
+    def rd64(self, d):
+        k, x = d
+        if k == K_V2:
+            return self.v[x] | (self.v[x + 1] << U(32))
+        if k == K_S2:
+            return U(self.s[x] | (self.s[x + 1] << 32))
+        if k == K_IMM:
+            return U(x & M64)
+        if k == K_VCC:
+            return U(self.vcc)
+        raise RuntimeError("64-bit operand %r" % (d,))
 
-    @staticmethod
-    def bits_of(flags):
-        return int(np.packbits(flags, bitorder="little").view("<u8")[0])
+    def srd(self, d):
+        k, x = d
+        if k == K_S:
+            return self.s[x]
+        if k == K_IMM:
+            return x & M32
+        if k == K_VCCLO:
+            return self.vcc & M32
+        raise RuntimeError("scalar operand %r" % (d,))
 
-    def rd32(self, op):
-        """32-bit source operand -> numpy uint64 vector (or scalar broadcast)"""
-        if re.fullmatch(r"v\d+", op):
-            return self.v[int(op[1:])].copy()
-        if re.fullmatch(r"s\d+", op):
-            return np.full(64, self.s[int(op[1:])], dtype=np.uint64)
-        if op == "vcc_lo":
-            return np.full(64, self.vcc & M32, dtype=np.uint64)
-        return np.full(64, int(op, 0) & M32, dtype=np.uint64)
-
-    def rd64(self, op):
-        m = re.fullmatch(r"v\[(\d+):(\d+)\]", op)
-        if m:
-            lo = int(m.group(1))
-            return self.v[lo] | (self.v[lo + 1] << np.uint64(32))
-        m = re.fullmatch(r"s\[(\d+):(\d+)\]", op)
-        if m:
-            lo = int(m.group(1))
-            return np.full(64, self.s[lo] | (self.s[lo + 1] << 32), dtype=np.uint64)
-        return np.full(64, int(op, 0) & M64, dtype=np.uint64)
-
-    def srd(self, op):
-        if re.fullmatch(r"s\d+", op):
-            return self.s[int(op[1:])]
-        return int(op, 0) & M32
-
-    def srd64(self, op):
-        m = re.fullmatch(r"s\[(\d+):(\d+)\]", op)
-        if m:
-            lo = int(m.group(1))
-            return self.s[lo] | (self.s[lo + 1] << 32)
-        if op == "vcc":
+    def srd64(self, d):
+        k, x = d
+        if k == K_S2:
+            return self.s[x] | (self.s[x + 1] << 32)
+        if k == K_VCC:
             return self.vcc
-        if op == "exec":
+        if k == K_EXEC:
             return self.exec
-        return int(op, 0) & M64
+        if k == K_IMM:
+            return x & M64
+        raise RuntimeError("scalar 64-bit operand %r" % (d,))
 
-    def swr(self, op, val):
-        self.s[int(op[1:])] = val & M32
+    def swr(self, d, val):
+        assert d[0] == K_S
+        self.s[d[1]] = val & M32
 
-    def swr64(self, op, val):
-        if op == "vcc":
+    def swr64(self, d, val):
+        k, x = d
+        if k == K_VCC:
             self.vcc = val & M64
-        elif op == "exec":
-            self.exec = val & M64
+        elif k == K_EXEC:
+            self.set_exec(val)
         else:
-            lo = int(re.fullmatch(r"s\[(\d+):(\d+)\]", op).group(1))
-            self.s[lo], self.s[lo + 1] = val & M32, (val >> 32) & M32
+            assert k == K_S2
+            self.s[x], self.s[x + 1] = val & M32, (val >> 32) & M32
 
-    def wr32(self, op, val):
-        r = int(op[1:])
-        act = self.lanes()
-        self.v[r][act] = (val & np.uint64(M32))[act]
+    def wr32(self, d, val):
+        assert d[0] == K_V
+        if self.full:
+            self.v[d[1]] = val & U32
+        else:
+            np.copyto(self.v[d[1]], val & U32, where=self.act)
 
-    def wr64(self, op, val):
-        lo = int(re.fullmatch(r"v\[(\d+):(\d+)\]", op).group(1))
-        act = self.lanes()
-        self.v[lo][act] = (val & np.uint64(M32))[act]
-        self.v[lo + 1][act] = (val >> np.uint64(32))[act]
+    def wr64(self, d, val):
+        assert d[0] == K_V2
+        if self.full:
+            self.v[d[1]] = val & U32
+            self.v[d[1] + 1] = val >> U(32)
+        else:
+            np.copyto(self.v[d[1]], val & U32, where=self.act)
+            np.copyto(self.v[d[1] + 1], val >> U(32), where=self.act)
 
     @staticmethod
     def sel(vec, how):
         if how in (None, "DWORD"):
             return vec
         if how == "WORD_0":
-            return vec & np.uint64(0xFFFF)
+            return vec & U(0xFFFF)
         if how == "WORD_1":
-            return (vec >> np.uint64(16)) & np.uint64(0xFFFF)
+            return (vec >> U(16)) & U(0xFFFF)
         raise RuntimeError("SDWA select %s" % how)
 
     def gaddr(self, vaddr, saddr, mods):
-        """global_* addressing: (scalar base + immediate, per-lane offsets); `off` = a 64-bit address in a VGPR pair"""
-        imm = int(mods.get("offset", "0"), 0)
-        if saddr == "off":
-            return imm, self.rd64(vaddr)
-        return self.srd64(saddr) + imm, self.v[int(vaddr[1:])]
+        """global_* addressing -> int64 byte addresses of the active lanes; `off` = a 64-bit address in a VGPR pair"""
+        imm = mods.get("offset", 0)
+        if saddr[0] == K_OFF:
+            a = self.rd64(vaddr).astype(np.int64) + imm
+        else:
+            a = self.v[vaddr[1]].astype(np.int64) + (self.srd64(saddr) + imm)
+        return a if self.full else a[self.act]
 
     # ---- execution
     def run(self):
-        """generator: yields at every s_barrier, returns at s_endpgm"""
-        prog = self.prog
-        u = np.uint64
+        """generator: yields "barrier" at every s_barrier and "sleep" at every s_sleep, returns at s_endpgm"""
+        prog, table = self.prog, HANDLERS
         while True:
             mn, ops, mods = prog[self.pc]
             self.pc += 1
-            if mn in ("s_waitcnt", "s_nop", "s_sleep"):
-                continue
-            if mn == "s_endpgm":
-                self.done = True
+            Wave.ticks += 1
+            h = table.get(mn)
+            if h is not None:
+                h(self, ops, mods)
+            elif mn == "s_barrier":
+                yield "barrier"
+            elif mn == "s_sleep":
+                yield "sleep"
+            elif mn == "s_endpgm":
                 return
-            if mn == "s_barrier":
-                yield
-                continue
-            if mn.startswith("s_load_dword"):
-                n = 1 if mn == "s_load_dword" else int(mn.split("x")[1])
-                addr = self.srd64(ops[1]) + int(ops[2], 0)
-                data = np.frombuffer(self.mem.read(addr, 4 * n), dtype=np.uint32)
-                lo = int(re.match(r"s\[?(\d+)", ops[0]).group(1))
-                for k in range(n):
-                    self.s[lo + k] = int(data[k])
-                continue
-            if mn in ("s_mov_b32",):
-                self.swr(ops[0], self.srd(ops[1])); continue
-            if mn == "s_mov_b64":
-                self.swr64(ops[0], self.srd64(ops[1])); continue
-            if mn in ("s_add_u32", "s_sub_u32", "s_addc_u32", "s_subb_u32"):
-                a, b = self.srd(ops[1]), self.srd(ops[2])
-                if mn == "s_add_u32":
-                    r = a + b; self.scc = r >> 32
-                elif mn == "s_addc_u32":
-                    r = a + b + self.scc; self.scc = r >> 32
-                elif mn == "s_sub_u32":
-                    r = a - b; self.scc = 1 if b > a else 0
-                else:
-                    r = a - b - self.scc; self.scc = 1 if b + self.scc > a else 0
-                self.swr(ops[0], r); continue
-            if mn in ("s_lshl_b32", "s_lshr_b32", "s_mul_i32", "s_mul_hi_u32", "s_and_b32", "s_or_b32", "s_min_u32"):
-                a, b = self.srd(ops[1]), self.srd(ops[2])
-                r = {"s_lshl_b32": lambda: a << (b & 31), "s_lshr_b32": lambda: a >> (b & 31), "s_mul_i32": lambda: a * b,
-                     "s_mul_hi_u32": lambda: (a * b) >> 32, "s_and_b32": lambda: a & b, "s_or_b32": lambda: a | b,
-                     "s_min_u32": lambda: min(a, b)}[mn]()
-                if mn in ("s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32"):
-                    self.scc = 1 if (r & M32) else 0
-                self.swr(ops[0], r); continue
-            if mn.startswith("s_cmp_"):
-                a, b = self.srd(ops[0]), self.srd(ops[1])
-                self.scc = int({"s_cmp_lt_u32": a < b, "s_cmp_eq_u32": a == b, "s_cmp_lg_u32": a != b, "s_cmp_ge_u32": a >= b,
-                                "s_cmp_gt_u32": a > b, "s_cmp_le_u32": a <= b}[mn]); continue
-            if mn in ("s_cbranch_scc1", "s_cbranch_scc0", "s_branch", "s_cbranch_execz"):
-                take = {"s_cbranch_scc1": self.scc == 1, "s_cbranch_scc0": self.scc == 0, "s_branch": True,
-                        "s_cbranch_execz": self.exec == 0}[mn]
-                if take:
-                    self.pc = self.labels[ops[0]]
-                continue
-            if mn == "s_cselect_b32":
-                self.swr(ops[0], self.srd(ops[1]) if self.scc else self.srd(ops[2])); continue
-            if mn == "s_cselect_b64":
-                self.swr64(ops[0], self.srd64(ops[1]) if self.scc else self.srd64(ops[2])); continue
-            if mn == "s_and_saveexec_b64":
-                old = self.exec
-                self.exec &= self.srd64(ops[1])
-                self.swr64(ops[0], old)
-                self.scc = 1 if self.exec else 0
-                continue
-            # ---- vector ALU
-            if mn == "v_readfirstlane_b32":
-                first = next(i for i in range(64) if (self.exec >> i) & 1) if self.exec else 0
-                self.swr(ops[0], int(self.v[int(ops[1][1:])][first])); continue
-            if mn in ("v_mov_b32_e32",):
-                self.wr32(ops[0], self.rd32(ops[1])); continue
-            if mn == "v_mad_u64_u32":
-                prod = self.rd32(ops[2]) * self.rd32(ops[3])
-                r = prod + self.rd64(ops[4])           # (wraps at 64 bits)
-                act = self.lanes()
-                self.swr64(ops[1], self.bits_of(act & (r < prod)))
-                self.wr64(ops[0], r); continue
-            if mn in ("v_mul_u32_u24_sdwa", "v_mul_u32_u24_e32"):
-                a = self.sel(self.rd32(ops[1]), mods.get("src0_sel")) & u(0xFFFFFF)
-                b = self.sel(self.rd32(ops[2]), mods.get("src1_sel")) & u(0xFFFFFF)
-                self.wr32(ops[0], a * b); continue
-            if mn == "v_mad_u32_u24":
-                self.wr32(ops[0], (self.rd32(ops[1]) & u(0xFFFFFF)) * (self.rd32(ops[2]) & u(0xFFFFFF)) + self.rd32(ops[3])); continue
-            if mn == "v_lshl_add_u32":
-                self.wr32(ops[0], (self.rd32(ops[1]) << (self.rd32(ops[2]) & u(31))) + self.rd32(ops[3])); continue
-            if mn == "v_alignbit_b32":
-                w = (self.rd32(ops[1]) << u(32)) | self.rd32(ops[2])
-                self.wr32(ops[0], w >> (self.rd32(ops[3]) & u(31))); continue
-            if mn == "v_mul_hi_u32":
-                self.wr32(ops[0], (self.rd32(ops[1]) * self.rd32(ops[2])) >> u(32)); continue
-            if mn == "v_mul_lo_u32":
-                self.wr32(ops[0], self.rd32(ops[1]) * self.rd32(ops[2])); continue
-            if mn.startswith("v_cmp_") and mn.endswith("_u32_e32"):
-                a, b = self.rd32(ops[1]), self.rd32(ops[2])
-                r = {"gt": a > b, "lt": a < b, "ge": a >= b, "le": a <= b, "eq": a == b, "ne": a != b}[mn.split("_")[2]]
-                act = self.lanes()
-                self.vcc = self.bits_of(act & r); continue
-            if mn in ("v_cndmask_b32_e64", "v_cndmask_b32_e32"):
-                m = self.mask_of(self.srd64(ops[3]) if len(ops) > 3 else self.vcc)
-                self.wr32(ops[0], np.where(m, self.rd32(ops[2]), self.rd32(ops[1]))); continue
-            if mn in ("v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_min_u32_e32", "v_and_b32_e32", "v_or_b32_e32",
-                      "v_lshlrev_b32_e32", "v_lshrrev_b32_e32", "v_max_u32_e32", "v_xor_b32_e32"):
-                a, b = self.rd32(ops[1]), self.rd32(ops[2])
-                r = {"v_add_u32_e32": lambda: a + b, "v_sub_u32_e32": lambda: a - b, "v_subrev_u32_e32": lambda: b - a,
-                     "v_min_u32_e32": lambda: np.minimum(a, b), "v_max_u32_e32": lambda: np.maximum(a, b),
-                     "v_and_b32_e32": lambda: a & b, "v_or_b32_e32": lambda: a | b, "v_xor_b32_e32": lambda: a ^ b,
-                     "v_lshlrev_b32_e32": lambda: b << (a & u(31)), "v_lshrrev_b32_e32": lambda: b >> (a & u(31))}[mn]()
-                self.wr32(ops[0], r & u(M32)); continue
-            if mn == "v_lshl_add_u64":
-                self.wr64(ops[0], ((self.rd64(ops[1]) << (self.rd32(ops[2]) & u(63))) + self.rd64(ops[3])) & u(M64)); continue
-            if mn in ("v_add_co_u32_e64", "v_add_co_u32_e32", "v_addc_co_u32_e64", "v_addc_co_u32_e32", "v_sub_co_u32_e64",
-                      "v_sub_co_u32_e32", "v_subb_co_u32_e64", "v_subb_co_u32_e32", "v_subrev_co_u32_e32", "v_subbrev_co_u32_e32"):
-                a, b = self.rd32(ops[2]), self.rd32(ops[3])
-                cin = self.mask_of(self.srd64(ops[4])).astype(np.uint64) if len(ops) > 4 else u(0)
-                if "rev" in mn:
-                    a, b = b, a
-                if mn.startswith("v_add"):
-                    r = a + b + cin
-                    cout = r > u(M32)
-                else:
-                    r = a - b - cin            # (wraps in 64 bits; the low word is what counts)
-                    cout = (b + cin) > a
-                act = self.lanes()
-                self.swr64(ops[1], self.bits_of(act & cout))
-                self.wr32(ops[0], r & u(M32)); continue
-            # ---- memory
-            if mn.startswith("global_load_"):
-                n = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16, "ushort": 2, "ubyte": 1}[mn[len("global_load_"):]]
-                base, off = self.gaddr(ops[1], ops[2], mods)
-                lo = int(re.match(r"v\[?(\d+)", ops[0]).group(1))
-                act = self.lanes()
-                for lane in range(64):
-                    if not act[lane]:
-                        continue
-                    raw = self.mem.read(base + int(off[lane]), n)
-                    if n >= 4:
-                        for k, w in enumerate(np.frombuffer(raw, dtype=np.uint32)):
-                            self.v[lo + k][lane] = int(w)
-                    else:
-                        self.v[lo][lane] = int.from_bytes(raw, "little")
-                continue
-            if mn.startswith("global_store_"):
-                n = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16, "short": 2, "byte": 1}[mn[len("global_store_"):]]
-                base, off = self.gaddr(ops[0], ops[2], mods)
-                lo = int(re.match(r"v\[?(\d+)", ops[1]).group(1))
-                act = self.lanes()
-                for lane in range(64):
-                    if not act[lane]:
-                        continue
-                    if n >= 4:
-                        data = b"".join(int(self.v[lo + k][lane]).to_bytes(4, "little") for k in range(n // 4))
-                    else:
-                        data = (int(self.v[lo][lane]) & ((1 << (8 * n)) - 1)).to_bytes(n, "little")
-                    self.mem.write(base + int(off[lane]), data)
-                continue
-            if mn in ("ds_write_b32", "ds_read_b32"):
-                imm = int(mods.get("offset", "0"), 0)
-                act = self.lanes()
-                if mn == "ds_write_b32":
-                    addr, data = self.v[int(ops[0][1:])], self.v[int(ops[1][1:])]
-                    for lane in range(64):
-                        if act[lane]:
-                            self.lds[(int(addr[lane]) + imm) // 4] = int(data[lane])
-                else:
-                    addr = self.v[int(ops[1][1:])]
-                    r = int(ops[0][1:])
-                    for lane in range(64):
-                        if act[lane]:
-                            self.v[r][lane] = self.lds[(int(addr[lane]) + imm) // 4]
-                continue
-            if mn in ("ds_write_b64", "ds_read_b64"):
-                imm = int(mods.get("offset", "0"), 0)
-                act = self.lanes()
-                if mn == "ds_write_b64":
-                    addr = self.v[int(ops[0][1:])]
-                    lo = int(re.match(r"v\[(\d+)", ops[1]).group(1))
-                    for lane in range(64):
-                        if act[lane]:
-                            w = (int(addr[lane]) + imm) // 4
-                            self.lds[w], self.lds[w + 1] = int(self.v[lo][lane]), int(self.v[lo + 1][lane])
-                else:
-                    addr = self.v[int(ops[1][1:])]
-                    lo = int(re.match(r"v\[(\d+)", ops[0]).group(1))
-                    for lane in range(64):
-                        if act[lane]:
-                            w = (int(addr[lane]) + imm) // 4
-                            self.v[lo][lane], self.v[lo + 1][lane] = self.lds[w], self.lds[w + 1]
-                continue
-            raise RuntimeError("emulator: unknown instruction %s %s" % (mn, ops))
+            elif mn == "s_trap":
+                raise RuntimeError("s_trap reached (a bounded wait of the kernel ran out)")
+            else:
+                raise RuntimeError("emulator: unknown instruction %s" % mn)
 
 
-def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4):
-    """execute the workgroups of the kernel in asm_text one after the other; grid = gx or (gx, gy); kernarg = bytes"""
+HANDLERS = {}
+
+
+def op(*names):
+    def reg(fn):
+        for n in names:
+            HANDLERS[n] = fn
+        return fn
+    return reg
+
+
+@op("s_waitcnt", "s_nop")
+def _nop(w, ops, mods):
+    pass
+
+
+def _sload(n):
+    def h(w, ops, mods):
+        addr = w.srd64(ops[1]) + ops[2][1]
+        data = np.frombuffer(w.mem.read(addr, 4 * n), dtype=np.uint32)
+        lo = ops[0][1]
+        for k in range(n):
+            w.s[lo + k] = int(data[k])
+    return h
+
+
+for _n, _name in ((1, "s_load_dword"), (2, "s_load_dwordx2"), (4, "s_load_dwordx4"), (8, "s_load_dwordx8"), (16, "s_load_dwordx16")):
+    HANDLERS[_name] = _sload(_n)
+
+
+@op("s_mov_b32")
+def _(w, ops, mods):
+    w.swr(ops[0], w.srd(ops[1]))
+
+
+@op("s_mov_b64")
+def _(w, ops, mods):
+    w.swr64(ops[0], w.srd64(ops[1]))
+
+
+def _sarith(kind):
+    def h(w, ops, mods):
+        a, b = w.srd(ops[1]), w.srd(ops[2])
+        if kind == "add":
+            r = a + b
+            w.scc = r >> 32
+        elif kind == "addc":
+            r = a + b + w.scc
+            w.scc = r >> 32
+        elif kind == "sub":
+            r = a - b
+            w.scc = 1 if b > a else 0
+        else:
+            r = a - b - w.scc
+            w.scc = 1 if b + w.scc > a else 0
+        w.swr(ops[0], r)
+    return h
+
+
+HANDLERS.update({"s_add_u32": _sarith("add"), "s_addc_u32": _sarith("addc"), "s_sub_u32": _sarith("sub"), "s_subb_u32": _sarith("subb")})
+
+
+def _s2(fn, sets_scc):
+    def h(w, ops, mods):
+        r = fn(w.srd(ops[1]), w.srd(ops[2])) & M32
+        if sets_scc:
+            w.scc = 1 if r else 0
+        w.swr(ops[0], r)
+    return h
+
+
+HANDLERS.update({
+    "s_lshl_b32": _s2(lambda a, b: a << (b & 31), True), "s_lshr_b32": _s2(lambda a, b: a >> (b & 31), True),
+    "s_and_b32": _s2(lambda a, b: a & b, True), "s_or_b32": _s2(lambda a, b: a | b, True),
+    "s_xor_b32": _s2(lambda a, b: a ^ b, True), "s_andn2_b32": _s2(lambda a, b: a & ~b, True),
+    "s_mul_i32": _s2(lambda a, b: a * b, False), "s_mul_hi_u32": _s2(lambda a, b: (a * b) >> 32, False),
+    "s_min_u32": _s2(min, False), "s_max_u32": _s2(max, False),
+})
+
+
+def _signed(x):
+    return x - (1 << 32) if x & 0x80000000 else x
+
+
+def _scmp(fn, signed=False):
+    def h(w, ops, mods):
+        a, b = w.srd(ops[0]), w.srd(ops[1])
+        if signed:
+            a, b = _signed(a), _signed(b)
+        w.scc = int(fn(a, b))
+    return h
+
+
+HANDLERS.update({
+    "s_cmp_lt_u32": _scmp(lambda a, b: a < b), "s_cmp_eq_u32": _scmp(lambda a, b: a == b), "s_cmp_lg_u32": _scmp(lambda a, b: a != b),
+    "s_cmp_ge_u32": _scmp(lambda a, b: a >= b), "s_cmp_gt_u32": _scmp(lambda a, b: a > b), "s_cmp_le_u32": _scmp(lambda a, b: a <= b),
+    "s_cmp_gt_i32": _scmp(lambda a, b: a > b, True), "s_cmp_lt_i32": _scmp(lambda a, b: a < b, True),
+    "s_cmp_ge_i32": _scmp(lambda a, b: a >= b, True), "s_cmp_le_i32": _scmp(lambda a, b: a <= b, True),
+    "s_cmp_eq_i32": _scmp(lambda a, b: a == b), "s_cmp_lg_i32": _scmp(lambda a, b: a != b),
+})
+
+
+@op("s_cmp_eq_u64")
+def _(w, ops, mods):
+    w.scc = int(w.srd64(ops[0]) == w.srd64(ops[1]))
+
+
+@op("s_cmp_lg_u64")
+def _(w, ops, mods):
+    w.scc = int(w.srd64(ops[0]) != w.srd64(ops[1]))
+
+
+def _branch(cond):
+    def h(w, ops, mods):
+        if cond(w):
+            w.pc = w.labels[ops[0]]
+    return h
+
+
+HANDLERS.update({
+    "s_branch": _branch(lambda w: True), "s_cbranch_scc1": _branch(lambda w: w.scc == 1), "s_cbranch_scc0": _branch(lambda w: w.scc == 0),
+    "s_cbranch_execz": _branch(lambda w: w.exec == 0), "s_cbranch_execnz": _branch(lambda w: w.exec != 0),
+    "s_cbranch_vccz": _branch(lambda w: w.vcc == 0), "s_cbranch_vccnz": _branch(lambda w: w.vcc != 0),
+})
+
+
+@op("s_cselect_b32")
+def _(w, ops, mods):
+    w.swr(ops[0], w.srd(ops[1]) if w.scc else w.srd(ops[2]))
+
+
+@op("s_cselect_b64")
+def _(w, ops, mods):
+    w.swr64(ops[0], w.srd64(ops[1]) if w.scc else w.srd64(ops[2]))
+
+
+@op("s_and_saveexec_b64")
+def _(w, ops, mods):
+    old = w.exec
+    w.set_exec(old & w.srd64(ops[1]))
+    w.swr64(ops[0], old)
+    w.scc = 1 if w.exec else 0
+
+
+@op("s_ff1_i32_b32")
+def _(w, ops, mods):
+    x = w.srd(ops[1])
+    w.swr(ops[0], (x & -x).bit_length() - 1 if x else M32)
+
+
+@op("s_not_b32")
+def _(w, ops, mods):
+    r = ~w.srd(ops[1]) & M32
+    w.scc = 1 if r else 0
+    w.swr(ops[0], r)
+
+
+@op("v_bfrev_b32_e32")
+def _(w, ops, mods):
+    x = w.rd32(ops[1]) & U32
+    r = np.zeros(64, dtype=np.uint64)
+    for i in range(32):
+        r |= ((x >> U(i)) & U(1)) << U(31 - i)
+    w.wr32(ops[0], r)
+
+
+@op("s_getreg_b32")
+def _(w, ops, mods):
+    if "HW_REG_XCC_ID" not in ops[1]:
+        raise RuntimeError("s_getreg_b32 %s" % ops[1])
+    w.swr(ops[0], w.xcc_id)
+
+
+@op("s_memtime")
+def _(w, ops, mods):
+    w.swr64(ops[0], Wave.ticks)
+
+
+# ---- vector ALU
+@op("v_readfirstlane_b32")
+def _(w, ops, mods):
+    first = (w.exec & -w.exec).bit_length() - 1 if w.exec else 0
+    w.swr(ops[0], int(w.v[ops[1][1]][first]))
+
+
+@op("v_mov_b32_e32")
+def _(w, ops, mods):
+    w.wr32(ops[0], w.rd32(ops[1]))
+
+
+@op("v_mad_u64_u32")
+def _(w, ops, mods):
+    prod = w.rd32(ops[2]) * w.rd32(ops[3])
+    r = prod + w.rd64(ops[4])           # (wraps at 64 bits)
+    w.swr64(ops[1], bits_of(w.act & (r < prod)))
+    w.wr64(ops[0], r)
+
+
+@op("v_mul_u32_u24_sdwa", "v_mul_u32_u24_e32")
+def _(w, ops, mods):
+    a = w.sel(w.rd32(ops[1]), mods.get("src0_sel")) & U(0xFFFFFF)
+    b = w.sel(w.rd32(ops[2]), mods.get("src1_sel")) & U(0xFFFFFF)
+    w.wr32(ops[0], a * b)
+
+
+@op("v_mad_u32_u24")
+def _(w, ops, mods):
+    w.wr32(ops[0], (w.rd32(ops[1]) & U(0xFFFFFF)) * (w.rd32(ops[2]) & U(0xFFFFFF)) + w.rd32(ops[3]))
+
+
+@op("v_lshl_add_u32")
+def _(w, ops, mods):
+    w.wr32(ops[0], (w.rd32(ops[1]) << (w.rd32(ops[2]) & U(31))) + w.rd32(ops[3]))
+
+
+@op("v_lshl_add_u64")
+def _(w, ops, mods):
+    w.wr64(ops[0], (w.rd64(ops[1]) << (w.rd32(ops[2]) & U(63))) + w.rd64(ops[3]))
+
+
+@op("v_alignbit_b32")
+def _(w, ops, mods):
+    w.wr32(ops[0], ((w.rd32(ops[1]) << U(32)) | w.rd32(ops[2])) >> (w.rd32(ops[3]) & U(31)))
+
+
+@op("v_mul_hi_u32")
+def _(w, ops, mods):
+    w.wr32(ops[0], (w.rd32(ops[1]) * w.rd32(ops[2])) >> U(32))
+
+
+@op("v_mul_lo_u32")
+def _(w, ops, mods):
+    w.wr32(ops[0], w.rd32(ops[1]) * w.rd32(ops[2]))
+
+
+def _vcmp(fn):
+    def h(w, ops, mods):
+        w.swr64(ops[0], bits_of(w.act & fn(w.rd32(ops[1]), w.rd32(ops[2]))))
+    return h
+
+
+for _c, _f in (("gt", lambda a, b: a > b), ("lt", lambda a, b: a < b), ("ge", lambda a, b: a >= b), ("le", lambda a, b: a <= b),
+               ("eq", lambda a, b: a == b), ("ne", lambda a, b: a != b)):
+    HANDLERS["v_cmp_%s_u32_e32" % _c] = HANDLERS["v_cmp_%s_u32_e64" % _c] = _vcmp(_f)
+
+
+@op("v_cndmask_b32_e64", "v_cndmask_b32_e32")
+def _(w, ops, mods):
+    m = mask_of(w.srd64(ops[3]) if len(ops) > 3 else w.vcc)
+    w.wr32(ops[0], np.where(m, w.rd32(ops[2]), w.rd32(ops[1])))
+
+
+def _v2(fn):
+    def h(w, ops, mods):
+        w.wr32(ops[0], fn(w.rd32(ops[1]), w.rd32(ops[2])))
+    return h
+
+
+HANDLERS.update({
+    "v_add_u32_e32": _v2(lambda a, b: a + b), "v_sub_u32_e32": _v2(lambda a, b: a - b), "v_subrev_u32_e32": _v2(lambda a, b: b - a),
+    "v_min_u32_e32": _v2(np.minimum), "v_max_u32_e32": _v2(np.maximum), "v_and_b32_e32": _v2(lambda a, b: a & b),
+    "v_or_b32_e32": _v2(lambda a, b: a | b), "v_xor_b32_e32": _v2(lambda a, b: a ^ b),
+    "v_lshlrev_b32_e32": _v2(lambda a, b: b << (a & U(31))), "v_lshrrev_b32_e32": _v2(lambda a, b: b >> (a & U(31))),
+})
+
+
+def _vcarry(kind, rev):
+    def h(w, ops, mods):
+        a, b = w.rd32(ops[2]), w.rd32(ops[3])
+        cin = mask_of(w.srd64(ops[4])).astype(np.uint64) if len(ops) > 4 else U(0)
+        if rev:
+            a, b = b, a
+        if kind == "add":
+            r = a + b + cin
+            cout = r > U32
+        else:
+            r = a - b - cin            # (wraps in 64 bits; the low word is what counts)
+            cout = (b + cin) > a
+        w.swr64(ops[1], bits_of(w.act & cout))
+        w.wr32(ops[0], r)
+    return h
+
+
+for _sfx in ("e32", "e64"):
+    HANDLERS["v_add_co_u32_" + _sfx] = HANDLERS["v_addc_co_u32_" + _sfx] = _vcarry("add", False)
+    HANDLERS["v_sub_co_u32_" + _sfx] = HANDLERS["v_subb_co_u32_" + _sfx] = _vcarry("sub", False)
+    HANDLERS["v_subrev_co_u32_" + _sfx] = HANDLERS["v_subbrev_co_u32_" + _sfx] = _vcarry("sub", True)
+
+
+# ---- memory
+def _gload(nbytes):
+    def h(w, ops, mods):
+        if not w.exec:
+            return
+        raw = w.mem.gather(w.gaddr(ops[1], ops[2], mods), nbytes)
+        lo = ops[0][1]
+        if nbytes >= 4:
+            words = np.ascontiguousarray(raw).view("<u4")
+            for k in range(nbytes // 4):
+                _put(w, lo + k, words[:, k].astype(np.uint64))
+        else:
+            _put(w, lo, np.ascontiguousarray(raw).view("<u2" if nbytes == 2 else np.uint8)[:, 0].astype(np.uint64))
+    return h
+
+
+def _put(w, r, vals):
+    if w.full:
+        w.v[r] = vals
+    else:
+        w.v[r][w.act] = vals
+
+
+def _get(w, r):
+    return w.v[r] if w.full else w.v[r][w.act]
+
+
+def _gstore(nbytes):
+    def h(w, ops, mods):
+        if not w.exec:
+            return
+        lo = ops[1][1]
+        if nbytes >= 4:
+            words = np.stack([_get(w, lo + k) for k in range(nbytes // 4)], axis=1).astype("<u4")
+            data = words.view(np.uint8)
+        else:
+            data = np.ascontiguousarray(_get(w, lo).astype("<u2" if nbytes == 2 else np.uint8)[:, None]).view(np.uint8)
+        w.mem.scatter(w.gaddr(ops[0], ops[2], mods), data)
+    return h
+
+
+for _name, _nb in (("dword", 4), ("dwordx2", 8), ("dwordx3", 12), ("dwordx4", 16), ("ushort", 2), ("ubyte", 1)):
+    HANDLERS["global_load_" + _name] = _gload(_nb)
+for _name, _nb in (("dword", 4), ("dwordx2", 8), ("dwordx3", 12), ("dwordx4", 16), ("short", 2), ("byte", 1)):
+    HANDLERS["global_store_" + _name] = _gstore(_nb)
+
+
+def _atomic(fn, width=4):
+    """lanes in order (the generated code issues its atomics from lane 0 alone); with a destination (sc0): the old value"""
+    def h(w, ops, mods):
+        ret = len(ops) == 4
+        vaddr, vdata, saddr = (ops[1], ops[2], ops[3]) if ret else (ops[0], ops[1], ops[2])
+        lanes = np.nonzero(w.act)[0]
+        addrs = w.gaddr(vaddr, saddr, mods)
+        mask = (1 << (8 * width)) - 1
+        for i, lane in enumerate(lanes):
+            d = int(w.v[vdata[1]][lane])
+            if width == 8:
+                d |= int(w.v[vdata[1] + 1][lane]) << 32
+            old = int.from_bytes(w.mem.read(int(addrs[i]), width), "little")
+            w.mem.write(int(addrs[i]), (fn(old, d) & mask).to_bytes(width, "little"))
+            if ret:
+                w.v[ops[0][1]][lane] = old & M32
+                if width == 8:
+                    w.v[ops[0][1] + 1][lane] = old >> 32
+    return h
+
+
+for _name, _f in (("add", lambda o, d: o + d), ("sub", lambda o, d: o - d), ("or", lambda o, d: o | d), ("and", lambda o, d: o & d),
+                  ("xor", lambda o, d: o ^ d), ("swap", lambda o, d: d), ("umax", max), ("umin", min)):
+    HANDLERS["global_atomic_" + _name] = _atomic(_f)
+    HANDLERS["global_atomic_%s_x2" % _name] = _atomic(_f, 8)
+
+
+def _ds(words, write):
+    def h(w, ops, mods):
+        if not w.exec:
+            return
+        imm = mods.get("offset", 0)
+        if write:
+            idx = ((_get(w, ops[0][1]).astype(np.int64) + imm) >> 2)
+            for k in range(words):
+                w.lds[idx + k] = _get(w, ops[1][1] + k)
+        else:
+            idx = ((_get(w, ops[1][1]).astype(np.int64) + imm) >> 2)
+            vals = [w.lds[idx + k].astype(np.uint64) for k in range(words)]   # (all read before any destination is written)
+            for k in range(words):
+                _put(w, ops[0][1] + k, vals[k])
+    return h
+
+
+for _name, _nw in (("b32", 1), ("b64", 2), ("b128", 4)):
+    HANDLERS["ds_write_" + _name] = _ds(_nw, True)
+    HANDLERS["ds_read_" + _name] = _ds(_nw, False)
+
+
+def _workgroup(waves):
+    """generator over one workgroup: its waves advance from barrier to barrier in turn; yields at every s_sleep"""
+    gens = [w.run() for w in waves]
+    live = list(range(len(waves)))
+    while live:
+        for i in list(live):
+            while True:
+                try:
+                    ev = next(gens[i])
+                except StopIteration:
+                    live.remove(i)
+                    break
+                if ev == "barrier":
+                    break
+                yield          # s_sleep: a poll did not succeed -- let other workgroups run
+
+
+def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4, concurrent=None):
+    """execute the workgroups of the kernel in asm_text; grid = gx or (gx, gy); kernarg = bytes.
+    concurrent = None: one workgroup after the other (kernels whose workgroups are independent).
+    concurrent = (xcc_of, pick): all workgroups resident (persistent kernels that wait for each other): workgroup i runs on
+    XCD xcc_of(i); whenever the running workgroup sleeps in a poll, pick(list of live workgroup numbers) names the next."""
     prog, labels = parse_program(asm_text)
     karg = mem.add(np.frombuffer(kernarg + b"\0" * 64, dtype=np.uint8).copy())
     gx, gy = grid if isinstance(grid, tuple) else (grid, 1)
-    for wg in range(gx * gy):
+
+    def make(wg):
         lds = np.zeros(lds_bytes // 4 + 16, dtype=np.uint32)
-        waves = [Wave(prog, labels, mem, lds, karg, wg % gx, w, wg // gx) for w in range(waves_per_wg)]
-        gens = [w.run() for w in waves]
-        live = list(range(waves_per_wg))
-        while live:
-            for i in list(live):
-                try:
-                    next(gens[i])        # runs to the next barrier
-                except StopIteration:
-                    live.remove(i)
+        xcc = concurrent[0](wg) if concurrent else 0
+        return _workgroup([Wave(prog, labels, mem, lds, karg, wg % gx, w, wg // gx, xcc) for w in range(waves_per_wg)])
+
+    if concurrent is None:
+        for wg in range(gx * gy):
+            for _ in make(wg):
+                pass               # (a lone workgroup that sleeps just polls again)
+        return
+    gens = {wg: make(wg) for wg in range(gx * gy)}
+    idle, seen = 0, mem.version
+    while gens:
+        wg = concurrent[1](sorted(gens))
+        try:
+            next(gens[wg])
+        except StopIteration:
+            del gens[wg]
+        if mem.version != seen:
+            idle, seen = 0, mem.version
+        else:
+            idle += 1
+            if idle > 64 * (len(gens) + 1):
+                raise RuntimeError("emulated launch is stuck: %d workgroups poll and nothing changes" % len(gens))
 
 
 def device_tables(limb_bits, n, nm, prm):
@@ -456,5 +786,66 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None):
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
     gx = (batch + 1) // 2 if count is not None else batch << (logn - block_log)
     run_kernel(text, mem, kernarg, (gx, nm), lds, waves_per_wg=(1 << block_log) // 16 // 64)
+    out, _ = mem.find(pc, c.nbytes)
+    return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
+
+
+def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False):
+    """n = 32768 / 65536: the three-role kernel of tools/gen_polymul_asm.py build_pipe (kernarg as
+    launch_polymul_pipe64k_u64 packs it) driven the way the composed product does: forward streaming pass of both
+    operands, fused block products, inverse streaming pass in place -- three launches of the same kernel"""
+    import struct
+    mem = Memory()
+    psi, mc = device_tables(64, n, nm, prm)
+    logn = n.bit_length() - 1
+    batch = a.shape[0]
+    c, sa, sb = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)
+    pa, pb, pc, psa, psb = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(sa), mem.add(sb)
+    ppsi, pmc = mem.add(psi), mem.add(mc)
+    with open(asm_path) as f:
+        text = f.read()
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
+    per_row = 28 if logn == 16 else 14
+
+    def launch(cnt_v, cnt_f, cnt_i):
+        kernarg = struct.pack("<5Q6i6Q", pc, psa, psb, ppsi, pmc, nm, logn, cnt_v, cnt_f, cnt_i, 0, pa, psa, pb, psb, pc, 0)
+        run_kernel(text, mem, kernarg, (max(cnt_v, cnt_f, cnt_i) * per_row, nm), lds)
+
+    launch(0, batch, 0)
+    launch(batch, 0, 0)
+    launch(0, 0, batch)
+    out, _ = mem.find(pc, c.nbytes)
+    return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
+
+
+def run_xcd_product(asm_path, n, nm, prm, a, b, dlog, rlog, pooled, wgs, pick, spin=20000, free_mask=0xFF):
+    """n = 32768 / 65536, the whole batch in ONE launch of persistent workgroups (tools/gen_polymul_asm.py fused_header;
+    kernarg and work area as launch_polymul_xcd_u64 / k_xcd_reset lay them out).  Workgroup i runs on XCD i mod 8 (the
+    hardware's round-robin); `pick` chooses which workgroup continues whenever one sleeps in a poll."""
+    import struct
+    mem = Memory()
+    psi, mc = device_tables(64, n, nm, prm)
+    logn = n.bit_length() - 1
+    batch = a.shape[0]
+    rows = batch * nm
+    assert batch >= 2 and rows >= (8 << dlog)
+    pow2 = (batch & (batch - 1)) == 0
+    magic = ((1 << 32) // batch) if pow2 else ((1 << 32) // batch + 1)
+    ctl_bytes = 4096 + (8 << dlog) * 0x11000
+    slot_bytes = 8 * 32 * n * 8 if pooled else rows * n * 8
+    ctl = np.zeros(ctl_bytes, dtype=np.uint8)
+    ctl[128:160] = free_mask                              # free masks of the pooled plan (32 slots per XCD)
+    scr_a = np.zeros(slot_bytes, dtype=np.uint8)
+    scr_b = np.zeros(slot_bytes if not pooled else 16, dtype=np.uint8)
+    c = np.zeros_like(a)
+    pa, pb, pc, ppsi, pmc = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(psi), mem.add(mc)
+    pctl, psa, psb = mem.add(ctl), mem.add(scr_a), mem.add(scr_b)
+    kernarg = struct.pack("<5Q4iI5i4Q", pc, pa, pb, ppsi, pmc, nm, logn, rows, batch, magic, dlog, rlog, 0, spin, 0,
+                          psa, psb, pctl, 0)
+    assert len(kernarg) == 112
+    with open(asm_path) as f:
+        text = f.read()
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
+    run_kernel(text, mem, kernarg, wgs, lds, concurrent=(lambda wg: wg % 8, pick))
     out, _ = mem.find(pc, c.nbytes)
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
