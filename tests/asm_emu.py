@@ -18,6 +18,20 @@ M32 = 0xFFFFFFFF
 M64 = (1 << 64) - 1
 U = np.uint64
 U32 = U(M32)
+VCC_LO = 106          # SGPR numbers of VCC (strict-mode bookkeeping only)
+STRICT = True
+
+
+class StrictError(RuntimeError):
+    """Strict mode: besides computing results the interpreter keeps, per wave, what real hardware would still have in
+    flight, and raises when the executed instruction stream relies on something the ISA does not guarantee:
+      * a register read (or overwritten) while a load into it has not been waited for -- counted `s_waitcnt vmcnt(N)` /
+        `lgkmcnt(N)` retire the oldest operations first (vector memory and LDS return in order, scalar loads do not);
+      * the gfx90a / gfx950 software-visible data hazards the assembler does not pad: VALU writes an SGPR / VCC -> VALU
+        reads it (2 wait states), -> a vector-memory instruction reads it (5); VALU writes a VGPR -> v_readfirstlane
+        reads it (1); a store of more than 64 bits -> VALU overwrites its data registers (2);
+      * LDS words written by one wave and read (or overwritten) by another wave of the workgroup with no s_barrier
+        between the two, or an s_barrier reached with LDS writes still outstanding."""
 
 
 class Memory:
@@ -97,7 +111,8 @@ def dec(op):
 
 
 def parse_program(text):
-    """-> (instructions, labels): instructions = list of (mnemonic, decoded operands, modifiers); reads up to .Lfunc_end"""
+    """-> (instructions, labels): instructions = list of (mnemonic, decoded operands, modifiers, class); reads up to
+    .Lfunc_end"""
     ins, labels = [], {}
     pat = r"\b(offset|dst_sel|dst_unused|src0_sel|src1_sel):(\S+)"
     for raw in text.split("\n"):
@@ -121,8 +136,11 @@ def parse_program(text):
             if re.search(r"\b%s\b" % flag, rest):
                 mods[flag] = True
                 rest = re.sub(r"\b%s\b" % flag, "", rest)
-        if mn in ("s_waitcnt", "s_nop", "s_sleep", "s_trap"):
-            ops = []
+        if mn == "s_waitcnt":
+            vm, lg = re.search(r"vmcnt\((\d+)\)", rest), re.search(r"lgkmcnt\((\d+)\)", rest)
+            ops = [int(vm.group(1)) if vm else None, int(lg.group(1)) if lg else None]
+        elif mn in ("s_nop", "s_sleep", "s_trap"):
+            ops = [int(rest.strip() or "0", 0)]
         elif mn == "s_getreg_b32":
             dst, reg = rest.split(",", 1)
             ops = [dec(dst.strip()), reg.strip()]
@@ -130,7 +148,9 @@ def parse_program(text):
             ops = [rest.strip()]
         else:
             ops = [dec(o.strip()) for o in rest.split(",") if o.strip()]
-        ins.append((mn, ops, mods))
+        cls = ("valu" if mn.startswith("v_") else "vmem" if mn.startswith("global_") else "lds" if mn.startswith("ds_") else
+               "smem" if mn.startswith("s_load") or mn == "s_memtime" else "salu")
+        ins.append((mn, ops, mods, cls))
     return ins, labels
 
 
@@ -142,7 +162,9 @@ def mask_of(bits):
 
 
 def bits_of(flags):
-    return int(np.packbits(np.broadcast_to(flags, (64,)), bitorder="little").view("<u8")[0])
+    if np.ndim(flags) == 0:
+        return M64 if flags else 0
+    return int.from_bytes(np.packbits(flags, bitorder="little").tobytes(), "little")
 
 
 class Wave:
@@ -161,52 +183,168 @@ class Wave:
         self.s[3] = wg_y
         self.v[0] = np.arange(64, dtype=np.uint64) + 64 * wave_in_wg
         self.xcc_id = xcc_id
+        # strict mode (see StrictError): what the hardware would still have in flight, and who wrote what when
+        self.strict = STRICT
+        self.cls = "salu"
+        self.slot = 0                 # wait states issued so far
+        self.vm_q, self.lgkm_q = [], []           # outstanding operations, oldest first: tuples of destination registers
+        self.pend_v, self.pend_s = {}, {}         # register -> number of outstanding operations that will write it
+        self.valu_swrite, self.valu_vwrite, self.wide_store = {}, {}, {}   # register -> slot of the producing instruction
+        self.wave_in_wg = wave_in_wg
+        self.epoch = 0                # barriers passed (LDS race detection)
+        self.lds_track = None
 
     def set_exec(self, bits):
         self.exec = bits & M64
         self.full = self.exec == M64
         self.act = _ALL if self.full else mask_of(self.exec)
 
+    # ---- strict mode
+    def fail(self, what):
+        mn, ops, mods, cls = self.prog[self.pc - 1]
+        raise StrictError("%s (instruction %d: %s, wave %d)" % (what, self.pc - 1, mn, self.wave_in_wg))
+
+    def use_v(self, r, n=1):
+        """a VGPR is read by the current instruction"""
+        if not self.strict:
+            return
+        for k in range(r, r + n):
+            if self.pend_v and k in self.pend_v:
+                self.fail("v%d is read while a load into it is still outstanding (missing s_waitcnt)" % k)
+            if self.cls == "valu_lane" and self.slot - self.valu_vwrite.get(k, -99) - 1 < 1:
+                self.fail("v%d: VALU write -> v_readfirstlane needs 1 wait state" % k)
+
+    def def_v(self, r, n=1):
+        """a VGPR is written by the current instruction"""
+        if not self.strict:
+            return
+        for k in range(r, r + n):
+            if self.pend_v and k in self.pend_v:
+                self.fail("v%d is written while a load into it is still outstanding" % k)
+            if self.cls in ("valu", "valu_lane"):
+                if self.slot - self.wide_store.get(k, -99) - 1 < 2:
+                    self.fail("v%d: store of more than 64 bits -> VALU write of its data needs 2 wait states" % k)
+                self.valu_vwrite[k] = self.slot
+
+    def use_s(self, r, n=1):
+        if not self.strict:
+            return
+        for k in range(r, r + n):
+            if self.pend_s and k in self.pend_s:
+                self.fail("s%d is read while a scalar load into it is still outstanding" % k)
+            gap = self.slot - self.valu_swrite.get(k, -99) - 1
+            if self.cls in ("valu", "valu_lane") and gap < 2:
+                self.fail("s%d: VALU write -> VALU read needs 2 wait states, has %d" % (k, gap))
+            if self.cls == "vmem" and gap < 5:
+                self.fail("s%d: VALU write -> VMEM read needs 5 wait states, has %d" % (k, gap))
+
+    def def_s(self, r, n=1):
+        if not self.strict:
+            return
+        for k in range(r, r + n):
+            if self.pend_s and k in self.pend_s:
+                self.fail("s%d is written while a scalar load into it is still outstanding" % k)
+            if self.cls in ("valu", "valu_lane"):
+                self.valu_swrite[k] = self.slot
+            else:
+                self.valu_swrite.pop(k, None)
+
+    def issue(self, queue, dests, kind="v"):
+        """a memory operation was issued; dests = registers it will write when it returns"""
+        if not self.strict:
+            return
+        pend = self.pend_s if kind == "s" else self.pend_v
+        for k in dests:
+            pend[k] = pend.get(k, 0) + 1
+        queue.append((kind, tuple(dests)))
+
+    def retire(self, queue, keep):
+        while len(queue) > keep:
+            kind, dests = queue.pop(0)
+            pend = self.pend_s if kind == "s" else self.pend_v
+            for k in dests:
+                if pend[k] == 1:
+                    del pend[k]
+                else:
+                    pend[k] -= 1
+
+    def waitcnt(self, vm, lgkm):
+        if vm is not None:
+            self.retire(self.vm_q, vm)            # vector memory operations return in the order issued
+        if lgkm is not None:
+            # LDS operations return in order; scalar loads may not: with one outstanding only lgkmcnt(0) is a guarantee
+            if lgkm == 0 or all(kind != "s" for kind, _ in self.lgkm_q):
+                self.retire(self.lgkm_q, lgkm)
+
+    def lds_touch(self, idx, write):
+        """LDS race detection: words touched by two waves of the workgroup between the same pair of barriers"""
+        if not self.strict:
+            return
+        t = self.lds_track
+        me, ep = self.wave_in_wg, self.epoch
+        clash = (t["w_ep"][idx] == ep) & (t["w_wave"][idx] != me)
+        if write:
+            clash |= (t["r_ep"][idx] == ep) & (t["r_wave"][idx] != me)
+        if clash.any():
+            self.fail("LDS word %d is %s here and was %s by another wave with no barrier in between"
+                      % (int(np.asarray(idx)[clash][0]), "written" if write else "read", "touched" if write else "written"))
+        if write:
+            t["w_ep"][idx], t["w_wave"][idx] = ep, me
+        else:
+            same = t["r_ep"][idx] == ep
+            t["r_wave"][idx] = np.where(same & (t["r_wave"][idx] != me), -2, me)
+            t["r_ep"][idx] = ep
+
     # ---- operands
     def rd32(self, d):
         k, x = d
         if k == K_V:
+            self.use_v(x)
             return self.v[x]
         if k == K_S:
+            self.use_s(x)
             return U(self.s[x])
         if k == K_IMM:
             return U(x & M32)
         if k == K_VCCLO:
+            self.use_s(VCC_LO)
             return U(self.vcc & M32)
         raise RuntimeError("32-bit operand %r" % (d,))
 
     def rd64(self, d):
         k, x = d
         if k == K_V2:
+            self.use_v(x, 2)
             return self.v[x] | (self.v[x + 1] << U(32))
         if k == K_S2:
+            self.use_s(x, 2)
             return U(self.s[x] | (self.s[x + 1] << 32))
         if k == K_IMM:
             return U(x & M64)
         if k == K_VCC:
+            self.use_s(VCC_LO, 2)
             return U(self.vcc)
         raise RuntimeError("64-bit operand %r" % (d,))
 
     def srd(self, d):
         k, x = d
         if k == K_S:
+            self.use_s(x)
             return self.s[x]
         if k == K_IMM:
             return x & M32
         if k == K_VCCLO:
+            self.use_s(VCC_LO)
             return self.vcc & M32
         raise RuntimeError("scalar operand %r" % (d,))
 
     def srd64(self, d):
         k, x = d
         if k == K_S2:
+            self.use_s(x, 2)
             return self.s[x] | (self.s[x + 1] << 32)
         if k == K_VCC:
+            self.use_s(VCC_LO, 2)
             return self.vcc
         if k == K_EXEC:
             return self.exec
@@ -216,20 +354,24 @@ class Wave:
 
     def swr(self, d, val):
         assert d[0] == K_S
+        self.def_s(d[1])
         self.s[d[1]] = val & M32
 
     def swr64(self, d, val):
         k, x = d
         if k == K_VCC:
+            self.def_s(VCC_LO, 2)
             self.vcc = val & M64
         elif k == K_EXEC:
             self.set_exec(val)
         else:
             assert k == K_S2
+            self.def_s(x, 2)
             self.s[x], self.s[x + 1] = val & M32, (val >> 32) & M32
 
     def wr32(self, d, val):
         assert d[0] == K_V
+        self.def_v(d[1])
         if self.full:
             self.v[d[1]] = val & U32
         else:
@@ -237,6 +379,7 @@ class Wave:
 
     def wr64(self, d, val):
         assert d[0] == K_V2
+        self.def_v(d[1], 2)
         if self.full:
             self.v[d[1]] = val & U32
             self.v[d[1] + 1] = val >> U(32)
@@ -260,6 +403,7 @@ class Wave:
         if saddr[0] == K_OFF:
             a = self.rd64(vaddr).astype(np.int64) + imm
         else:
+            self.use_v(vaddr[1])
             a = self.v[vaddr[1]].astype(np.int64) + (self.srd64(saddr) + imm)
         return a if self.full else a[self.act]
 
@@ -268,15 +412,21 @@ class Wave:
         """generator: yields "barrier" at every s_barrier and "sleep" at every s_sleep, returns at s_endpgm"""
         prog, table = self.prog, HANDLERS
         while True:
-            mn, ops, mods = prog[self.pc]
+            mn, ops, mods, self.cls = prog[self.pc]
             self.pc += 1
             Wave.ticks += 1
             h = table.get(mn)
             if h is not None:
                 h(self, ops, mods)
+                self.slot += 1
             elif mn == "s_barrier":
+                if self.strict and any(kind == "w" for kind, _ in self.lgkm_q):
+                    self.fail("s_barrier with LDS writes of this wave not waited for (the other waves may not see them yet)")
+                self.slot += 1
+                self.epoch += 1
                 yield "barrier"
             elif mn == "s_sleep":
+                self.slot += 1
                 yield "sleep"
             elif mn == "s_endpgm":
                 return
@@ -297,9 +447,15 @@ def op(*names):
     return reg
 
 
-@op("s_waitcnt", "s_nop")
-def _nop(w, ops, mods):
-    pass
+@op("s_waitcnt")
+def _(w, ops, mods):
+    if w.strict:
+        w.waitcnt(ops[0], ops[1])
+
+
+@op("s_nop")
+def _(w, ops, mods):
+    w.slot += ops[0]          # s_nop N = N + 1 wait states (the run loop adds the one)
 
 
 def _sload(n):
@@ -307,8 +463,10 @@ def _sload(n):
         addr = w.srd64(ops[1]) + ops[2][1]
         data = np.frombuffer(w.mem.read(addr, 4 * n), dtype=np.uint32)
         lo = ops[0][1]
+        w.def_s(lo, n)
         for k in range(n):
             w.s[lo + k] = int(data[k])
+        w.issue(w.lgkm_q, range(lo, lo + n), "s")
     return h
 
 
@@ -462,12 +620,15 @@ def _(w, ops, mods):
 @op("s_memtime")
 def _(w, ops, mods):
     w.swr64(ops[0], Wave.ticks)
+    w.issue(w.lgkm_q, (ops[0][1], ops[0][1] + 1), "s")
 
 
 # ---- vector ALU
 @op("v_readfirstlane_b32")
 def _(w, ops, mods):
     first = (w.exec & -w.exec).bit_length() - 1 if w.exec else 0
+    w.cls = "valu_lane"
+    w.use_v(ops[1][1])
     w.swr(ops[0], int(w.v[ops[1][1]][first]))
 
 
@@ -480,7 +641,8 @@ def _(w, ops, mods):
 def _(w, ops, mods):
     prod = w.rd32(ops[2]) * w.rd32(ops[3])
     r = prod + w.rd64(ops[4])           # (wraps at 64 bits)
-    w.swr64(ops[1], bits_of(w.act & (r < prod)))
+    carry = r < prod
+    w.swr64(ops[1], bits_of(carry if w.full else (w.act & carry)))
     w.wr64(ops[0], r)
 
 
@@ -578,10 +740,13 @@ for _sfx in ("e32", "e64"):
 # ---- memory
 def _gload(nbytes):
     def h(w, ops, mods):
+        lo, nreg = ops[0][1], max(1, nbytes // 4)
+        w.def_v(lo, nreg)
         if not w.exec:
+            w.issue(w.vm_q, range(lo, lo + nreg))
             return
         raw = w.mem.gather(w.gaddr(ops[1], ops[2], mods), nbytes)
-        lo = ops[0][1]
+        w.issue(w.vm_q, range(lo, lo + nreg))
         if nbytes >= 4:
             words = np.ascontiguousarray(raw).view("<u4")
             for k in range(nbytes // 4):
@@ -604,9 +769,14 @@ def _get(w, r):
 
 def _gstore(nbytes):
     def h(w, ops, mods):
+        lo = ops[1][1]
+        w.use_v(lo, max(1, nbytes // 4))
+        w.issue(w.vm_q, ())
+        if w.strict and nbytes > 8:
+            for k in range(lo, lo + nbytes // 4):
+                w.wide_store[k] = w.slot
         if not w.exec:
             return
-        lo = ops[1][1]
         if nbytes >= 4:
             words = np.stack([_get(w, lo + k) for k in range(nbytes // 4)], axis=1).astype("<u4")
             data = words.view(np.uint8)
@@ -627,6 +797,10 @@ def _atomic(fn, width=4):
     def h(w, ops, mods):
         ret = len(ops) == 4
         vaddr, vdata, saddr = (ops[1], ops[2], ops[3]) if ret else (ops[0], ops[1], ops[2])
+        w.use_v(vdata[1], width // 4)
+        if ret:
+            w.def_v(ops[0][1], width // 4)
+        w.issue(w.vm_q, range(ops[0][1], ops[0][1] + width // 4) if ret else ())
         lanes = np.nonzero(w.act)[0]
         addrs = w.gaddr(vaddr, saddr, mods)
         mask = (1 << (8 * width)) - 1
@@ -651,18 +825,27 @@ for _name, _f in (("add", lambda o, d: o + d), ("sub", lambda o, d: o - d), ("or
 
 def _ds(words, write):
     def h(w, ops, mods):
-        if not w.exec:
-            return
         imm = mods.get("offset", 0)
         if write:
+            w.use_v(ops[0][1])
+            w.use_v(ops[1][1], words)
+            w.issue(w.lgkm_q, (), "w")
+            if not w.exec:
+                return
             idx = ((_get(w, ops[0][1]).astype(np.int64) + imm) >> 2)
             for k in range(words):
+                w.lds_touch(idx + k, True)
                 w.lds[idx + k] = _get(w, ops[1][1] + k)
         else:
-            idx = ((_get(w, ops[1][1]).astype(np.int64) + imm) >> 2)
-            vals = [w.lds[idx + k].astype(np.uint64) for k in range(words)]   # (all read before any destination is written)
-            for k in range(words):
-                _put(w, ops[0][1] + k, vals[k])
+            w.use_v(ops[1][1])
+            w.def_v(ops[0][1], words)
+            if w.exec:
+                idx = ((_get(w, ops[1][1]).astype(np.int64) + imm) >> 2)
+                vals = [w.lds[idx + k].astype(np.uint64) for k in range(words)]   # (all read before any destination is written)
+                for k in range(words):
+                    w.lds_touch(idx + k, False)
+                    _put(w, ops[0][1] + k, vals[k])
+            w.issue(w.lgkm_q, range(ops[0][1], ops[0][1] + words))
     return h
 
 
@@ -673,6 +856,11 @@ for _name, _nw in (("b32", 1), ("b64", 2), ("b128", 4)):
 
 def _workgroup(waves):
     """generator over one workgroup: its waves advance from barrier to barrier in turn; yields at every s_sleep"""
+    nw = len(waves[0].lds)
+    track = {"w_ep": np.full(nw, -1, dtype=np.int32), "w_wave": np.full(nw, -1, dtype=np.int16),
+             "r_ep": np.full(nw, -1, dtype=np.int32), "r_wave": np.full(nw, -1, dtype=np.int16)}
+    for w in waves:
+        w.lds_track = track
     gens = [w.run() for w in waves]
     live = list(range(len(waves)))
     while live:
@@ -688,12 +876,18 @@ def _workgroup(waves):
                 yield          # s_sleep: a poll did not succeed -- let other workgroups run
 
 
+_PARSED = {}
+
+
 def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4, concurrent=None):
     """execute the workgroups of the kernel in asm_text; grid = gx or (gx, gy); kernarg = bytes.
     concurrent = None: one workgroup after the other (kernels whose workgroups are independent).
     concurrent = (xcc_of, pick): all workgroups resident (persistent kernels that wait for each other): workgroup i runs on
     XCD xcc_of(i); whenever the running workgroup sleeps in a poll, pick(list of live workgroup numbers) names the next."""
-    prog, labels = parse_program(asm_text)
+    key = hash(asm_text)
+    if key not in _PARSED:
+        _PARSED[key] = parse_program(asm_text)
+    prog, labels = _PARSED[key]
     karg = mem.add(np.frombuffer(kernarg + b"\0" * 64, dtype=np.uint8).copy())
     gx, gy = grid if isinstance(grid, tuple) else (grid, 1)
 

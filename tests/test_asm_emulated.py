@@ -149,9 +149,8 @@ def _picker(kind):
 
 
 @pytest.mark.parametrize("stem,n,nm,batch,dlog,rlog,pooled,wgs,order", [
-    ("polymul_xcd32768", 32768, 1, 8, 0, 1, 0, 16, "random"),
-    ("polymul_xcd32768l", 32768, 1, 9, 0, 2, 1, 8, "highest"),      # pooled scratch slots, batch not a power of two, one workgroup per XCD
-    ("polymul_xcd32768", 32768, 2, 4, 0, 3, 0, 40, "round-robin"),  # two moduli, five workgroups per XCD
+    ("polymul_xcd32768", 32768, 1, 8, 0, 3, 0, 40, "round-robin"),  # five workgroups per XCD
+    ("polymul_xcd32768l", 32768, 2, 5, 0, 2, 1, 8, "highest"),      # pooled scratch slots, two moduli, batch not a power of two, one workgroup per XCD
     ("polymul_xcd32768l", 32768, 1, 16, 1, 1, 1, 24, "random"),     # two scheduling domains per XCD
     ("polymul_xcd65536", 65536, 1, 8, 0, 1, 0, 16, "random"),
 ])
@@ -172,3 +171,42 @@ def test_emulated_one_launch_plan_fails_loudly_when_it_cannot_progress(generated
     with pytest.raises(RuntimeError, match="s_trap|stuck"):
         asm_emu.run_xcd_product(generated("polymul_xcd32768l"), 32768, 1, prm, a, b, 0, 1, 1, 8, _picker("random"), spin=50,
                                 free_mask=0)
+
+
+def _mutant(path, tmp_path, pick, edit):
+    """a copy of a generated source with ONE line changed: pick(lines) -> index, edit(line) -> replacement (None = drop)"""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    i = pick(lines)
+    new = edit(lines[i])
+    lines[i:i + 1] = [] if new is None else [new]
+    out = tmp_path / os.path.basename(path)
+    out.write_text("\n".join(lines))
+    return str(out)
+
+
+def test_strict_mode_catches_what_the_gpu_might_forgive(generated, oracle_factory, tmp_path):
+    """the interpreter is not only an arithmetic model: a relaxed wait count, a dropped hazard nop and a dropped barrier --
+    each of which would usually still pass on hardware -- are errors"""
+    import re
+    o = oracle_factory(32, 2048, 1)
+    prm, a, b = operands(o, 32, 2048, 1, 1, 21)
+    src = generated("row2048_u32")
+
+    def nth(pattern, k):
+        return lambda lines: [i for i, l in enumerate(lines) if re.search(pattern, l)][k]
+
+    assert np.array_equal(asm_emu.run_row_kernel(src, 32, 2048, 1, prm, a, b, 2, True), o.polymul(a, b))
+    relaxed = _mutant(src, tmp_path, nth(r"s_waitcnt vmcnt\(\d+\)", 3),
+                      lambda l: re.sub(r"vmcnt\((\d+)\)", lambda m: "vmcnt(%d)" % (int(m.group(1)) + 1), l))
+    with pytest.raises(asm_emu.StrictError, match="still outstanding"):
+        asm_emu.run_row_kernel(relaxed, 32, 2048, 1, prm, a, b, 2, True)
+    no_barrier = _mutant(src, tmp_path, nth(r"s_barrier", 2), lambda l: None)
+    with pytest.raises(asm_emu.StrictError, match="no barrier in between"):
+        asm_emu.run_row_kernel(no_barrier, 32, 2048, 1, prm, a, b, 2, True)
+    # the 64-bit metric kernel: a carry written by one VALU instruction and consumed two slots later
+    o64 = oracle_factory(64, 4096, 1)
+    prm64, a64, b64 = operands(o64, 64, 4096, 1, 1, 22)
+    no_nop = _mutant(generated("polymul4096"), tmp_path, nth(r"s_nop", 5), lambda l: None)
+    with pytest.raises(asm_emu.StrictError, match="wait state"):
+        asm_emu.run_block_kernel(no_nop, 4096, 1, prm64, a64, b64, 12)
