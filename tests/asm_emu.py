@@ -31,7 +31,11 @@ class StrictError(RuntimeError):
         reads it (2 wait states), -> a vector-memory instruction reads it (5); VALU writes a VGPR -> v_readfirstlane
         reads it (1); a store of more than 64 bits -> VALU overwrites its data registers (2);
       * LDS words written by one wave and read (or overwritten) by another wave of the workgroup with no s_barrier
-        between the two, or an s_barrier reached with LDS writes still outstanding."""
+        between the two, or an s_barrier reached with LDS writes still outstanding;
+      * visibility between workgroups as measured on the MI355X (profiles/r02_l2_flag_probe.txt): plain and sc0 vector
+        loads and scalar loads without glc may be served by a cache of the XCD that holds the line from BEFORE another
+        workgroup's store; sc1 / nt loads and atomics see memory.  The model is pessimistic: caches never evict (until the
+        launch ends) and any two workgroups of an XCD may share a CU."""
 
 
 class Memory:
@@ -41,6 +45,41 @@ class Memory:
         self.bufs = []
         self.next = 0x100000000
         self.version = 0          # bumped by every store / atomic (deadlock detection of the concurrent scheduler)
+        # strict mode, visibility between workgroups: who may hold a 128-byte line in a cache that is not coherent with
+        # other CUs' stores -- line -> {(xcd, workgroup that loaded it): None, or the workgroup whose later store made that
+        # copy stale}; one table for the vector L1s, one for the scalar caches; both forgotten at a launch boundary
+        self.cur = (0, 0)         # (workgroup, XCD) now running
+        self.l1, self.k1 = {}, {}
+        self.stale_lines = set()  # lines with at least one stale copy (the only ones a load has to look at closely)
+
+    def new_launch(self):
+        self.l1, self.k1 = {}, {}
+        self.stale_lines = set()
+
+    def wrote(self, lines):
+        me = self.cur[0]
+        for line in lines:
+            for table, own_ok in ((self.l1, True), (self.k1, False)):
+                holders = table.get(line)
+                if holders:
+                    for key, stale in holders.items():
+                        if stale is None and not (own_ok and key[1] == me):   # (a CU's own store updates its own L1)
+                            holders[key] = me
+                            self.stale_lines.add(line)
+
+    def cached_read(self, table, lines, vector=True):
+        """a load that a cache may serve (plain / sc0 vector loads: the CU's L1; scalar loads without glc: the scalar
+        cache).  Workgroups of one XCD may or may not share a CU, so a copy that ANY workgroup of this XCD loaded and
+        that a store from elsewhere has since made stale is an error -- unless that store was the reader's own (then
+        either it updated the copy, same CU, or the reader's CU holds no copy)."""
+        me, xcd = self.cur
+        for line in lines:
+            holders = table.setdefault(line, {})
+            for (x, holder), stale in (holders.items() if line in self.stale_lines else ()):
+                if x == xcd and stale is not None and not (vector and stale == me):
+                    raise StrictError("load of line 0x%x may hit a stale cache line: workgroup %d cached it, workgroup %d stored "
+                                      "to it afterwards (needs an sc1 / nt load or an invalidate)" % (line << 7, holder, stale))
+            holders[(xcd, me)] = None
 
     def add(self, arr):
         a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
@@ -63,9 +102,12 @@ class Memory:
         a, o = self.find(addr, len(data))
         a[o:o + len(data)] = np.frombuffer(data, dtype=np.uint8)
         self.version += 1
+        self.wrote(range(addr >> 7, ((addr + len(data) - 1) >> 7) + 1))
 
-    def gather(self, addrs, n):
+    def gather(self, addrs, n, cached=False):
         """addrs: int64 vector -> (len, n) uint8"""
+        if cached and STRICT:
+            self.cached_read(self.l1, np.unique(np.concatenate((addrs >> 7, (addrs + (n - 1)) >> 7))).tolist())
         a, o = self.find(int(addrs.min()), int(addrs.max() - addrs.min()) + n)
         idx = (addrs - addrs.min() + o)[:, None] + np.arange(n)
         return a[idx]
@@ -76,6 +118,7 @@ class Memory:
         idx = (addrs - addrs.min() + o)[:, None] + np.arange(n)
         a[idx] = data
         self.version += 1
+        self.wrote(np.unique(np.concatenate((addrs >> 7, (addrs + (n - 1)) >> 7))).tolist())
 
 
 # operand kinds
@@ -461,6 +504,8 @@ def _(w, ops, mods):
 def _sload(n):
     def h(w, ops, mods):
         addr = w.srd64(ops[1]) + ops[2][1]
+        if w.strict and not mods.get("glc"):
+            w.mem.cached_read(w.mem.k1, range(addr >> 7, ((addr + 4 * n - 1) >> 7) + 1), vector=False)
         data = np.frombuffer(w.mem.read(addr, 4 * n), dtype=np.uint32)
         lo = ops[0][1]
         w.def_s(lo, n)
@@ -745,7 +790,7 @@ def _gload(nbytes):
         if not w.exec:
             w.issue(w.vm_q, range(lo, lo + nreg))
             return
-        raw = w.mem.gather(w.gaddr(ops[1], ops[2], mods), nbytes)
+        raw = w.mem.gather(w.gaddr(ops[1], ops[2], mods), nbytes, cached=not (mods.get("sc1") or mods.get("nt")))
         w.issue(w.vm_q, range(lo, lo + nreg))
         if nbytes >= 4:
             words = np.ascontiguousarray(raw).view("<u4")
@@ -873,7 +918,8 @@ def _workgroup(waves):
                     break
                 if ev == "barrier":
                     break
-                yield          # s_sleep: a poll did not succeed -- let other workgroups run
+                yield "sleep"      # a poll did not succeed -- let other workgroups run
+        yield "barrier"            # every wave is at the barrier (or done): a point where other workgroups may run too
 
 
 _PARSED = {}
@@ -883,13 +929,15 @@ def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4, concurre
     """execute the workgroups of the kernel in asm_text; grid = gx or (gx, gy); kernarg = bytes.
     concurrent = None: one workgroup after the other (kernels whose workgroups are independent).
     concurrent = (xcc_of, pick): all workgroups resident (persistent kernels that wait for each other): workgroup i runs on
-    XCD xcc_of(i); whenever the running workgroup sleeps in a poll, pick(list of live workgroup numbers) names the next."""
+    XCD xcc_of(i); whenever the running workgroup sleeps in a poll or passes a barrier, pick(list of live workgroup numbers)
+    names the next."""
     key = hash(asm_text)
     if key not in _PARSED:
         _PARSED[key] = parse_program(asm_text)
     prog, labels = _PARSED[key]
     karg = mem.add(np.frombuffer(kernarg + b"\0" * 64, dtype=np.uint8).copy())
     gx, gy = grid if isinstance(grid, tuple) else (grid, 1)
+    mem.new_launch()
 
     def make(wg):
         lds = np.zeros(lds_bytes // 4 + 16, dtype=np.uint32)
@@ -898,6 +946,7 @@ def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4, concurre
 
     if concurrent is None:
         for wg in range(gx * gy):
+            mem.cur = (wg, 0)
             for _ in make(wg):
                 pass               # (a lone workgroup that sleeps just polls again)
         return
@@ -905,13 +954,15 @@ def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4, concurre
     idle, seen = 0, mem.version
     while gens:
         wg = concurrent[1](sorted(gens))
+        mem.cur = (wg, concurrent[0](wg))
         try:
-            next(gens[wg])
+            ev = next(gens[wg])
         except StopIteration:
+            ev = None
             del gens[wg]
         if mem.version != seen:
             idle, seen = 0, mem.version
-        else:
+        elif ev == "sleep":
             idle += 1
             if idle > 64 * (len(gens) + 1):
                 raise RuntimeError("emulated launch is stuck: %d workgroups poll and nothing changes" % len(gens))

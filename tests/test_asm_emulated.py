@@ -210,3 +210,17 @@ def test_strict_mode_catches_what_the_gpu_might_forgive(generated, oracle_factor
     no_nop = _mutant(generated("polymul4096"), tmp_path, nth(r"s_nop", 5), lambda l: None)
     with pytest.raises(asm_emu.StrictError, match="wait state"):
         asm_emu.run_block_kernel(no_nop, 4096, 1, prm64, a64, b64, 12)
+
+
+def test_strict_mode_models_the_measured_visibility_rules(generated, oracle_factory, tmp_path):
+    """polls of the one-launch plan read with plain loads instead of sc1: the second poll of a counter may be served by the
+    CU's L1 (profiles/r02_l2_flag_probe.txt) -- reported, although the interpreter's own memory is coherent"""
+    import re
+    o = oracle_factory(64, 32768, 1)
+    prm, a, b = operands(o, 64, 32768, 1, 8, 23)
+    with open(generated("polymul_xcd32768")) as f:
+        text = f.read()
+    mutant = tmp_path / "plain_polls.s"
+    mutant.write_text(re.sub(r"(global_load_dword .*) sc1\n", r"\1\n", text))
+    with pytest.raises(asm_emu.StrictError, match="stale cache line"):
+        asm_emu.run_xcd_product(str(mutant), 32768, 1, prm, a, b, 0, 1, 0, 16, _picker("random"))
