@@ -1,0 +1,80 @@
+"""Host logic of the header-only layer WITHOUT a GPU: the resident poly_p handles and the deferred queue of
+include/nfl_hip/nfl.hpp (levelling by data dependencies, grouping by signature, key operands, stride runs, consecutive
+buffers, the queue that runs by itself) executed against tests/cpp/mock -- the C ABI over host memory with toy arithmetic
+that keeps the contracts between entry points (batch = loop of singles, strides, sequence stream ids) and in which no
+two operations commute.  The programs compare deferred with immediate execution word for word; on the GPU the same
+programs run against the real library (tests/test_cpp_surface.py)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "cpp", "_mock")
+
+
+def build_program(src, out, include=os.path.join(ROOT, "include")):
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-I" + include, "-DNFL_HIP_NO_GMP", "-o", out,
+                           os.path.join(ROOT, "tests", "cpp", src), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+
+
+@pytest.fixture(scope="module")
+def mock():
+    os.makedirs(MOCK, exist_ok=True)
+    c = os.path.join(MOCK, "mock_backend.c")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "cpp", "mock", "make_mock_backend.py"), c],
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o",
+                           os.path.join(MOCK, "libnflhip.so"), c])
+    for name in ("deferred_fuzz", "deferred_loops"):
+        build_program(name + ".cpp", os.path.join(MOCK, name))
+    return MOCK
+
+
+def run(exe, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_random_programs_deferred_equals_immediate(mock):
+    r = run(os.path.join(mock, "deferred_fuzz"), 60, 2024)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("limit", [None, 97, 1])
+def test_loop_shapes_deferred_equals_immediate(mock, limit):
+    """the LWE loop, strided / reversed / chained loops, handles dying queued; with the default queue length, with a queue
+    that runs by itself every 97 records (in the middle of groups) and with one that holds a single record"""
+    r = run(os.path.join(mock, "deferred_loops"), 300 if limit != 1 else 40,
+            env=None if limit is None else {"NFL_HIP_QUEUE_LIMIT": str(limit)})
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_loops_are_coalesced(mock):
+    """what deferral is for: the LWE loop's 300 x 8 operations leave as a handful of launches"""
+    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1"})
+    assert r.returncode == 0
+    lines = [l for l in r.stderr.splitlines() if l.startswith("nfl(hip) deferred:")]
+    first_ring = lines[:7]      # level 0: gaussians (3 groups), level 1: transforms, 2: products, 3: decryption, 4: inverse
+    ops = sum(int(l.split(":")[2].split()[0]) for l in first_ring)
+    launches = sum(int(l.split("->")[1].split()[0]) for l in first_ring)
+    assert ops >= 300 * 10 and launches <= 12, first_ring
+
+
+def test_the_harness_notices_a_broken_queue(mock, tmp_path):
+    """a header whose levelling forgets write-after-read hazards must fail the comparison (the toy operations do not
+    commute): proof that the mock keeps what the queue's correctness depends on"""
+    inc = tmp_path / "include"
+    shutil.copytree(os.path.join(ROOT, "include"), inc)
+    hdr = inc / "nfl_hip" / "nfl.hpp"
+    text = hdr.read_text()
+    good = "L = std::max(L, std::max(o.out->wlev, o.out->rlev) + 1);"
+    assert good in text
+    hdr.write_text(text.replace(good, "L = std::max(L, o.out->wlev + 1);"))
+    exe = str(tmp_path / "fuzz_mutant")
+    build_program("deferred_fuzz.cpp", exe, include=str(inc))
+    r = run(exe, 40, 1)
+    assert r.returncode != 0 and "all checks passed" not in r.stdout

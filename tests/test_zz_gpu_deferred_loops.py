@@ -1,0 +1,21 @@
+"""The loop shapes of tests/cpp/deferred_loops.cpp (LWE loop, strided / reversed / chained loops, handles dying queued)
+against the REAL library: deferred == immediate, word for word.  The same program runs on the CPU against the toy
+arithmetic of tests/cpp/mock (tests/test_host_logic.py).  (Sorted last on purpose: it is the newest GPU test.)"""
+import os
+import subprocess
+
+import pytest
+
+CPP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit", [None, 97])
+def test_loop_shapes_deferred_equals_immediate_on_the_gpu(limit):
+    subprocess.check_call(["make", "-s", "-C", CPP, "deferred_loops"])
+    env = dict(os.environ)
+    if limit is not None:
+        env["NFL_HIP_QUEUE_LIMIT"] = str(limit)
+    r = subprocess.run([os.path.join(CPP, "deferred_loops"), "200"], capture_output=True, text=True, timeout=1800, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout
