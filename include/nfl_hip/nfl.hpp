@@ -49,6 +49,7 @@
 #define NFL_HIP_NFL_HPP
 
 #include <algorithm>
+#include <functional>
 #include <array>
 #include <atomic>
 #include <cassert>
@@ -268,8 +269,9 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
     std::vector<void *> free;
   };
   std::map<char *, slab> slabs;
+  slab *last_released;
   size_t next_slab_bytes;
-  context() : ctx(nullptr), stream(nullptr), next_slab_bytes(size_t(256) << 20) {
+  context() : ctx(nullptr), stream(nullptr), last_released(nullptr), next_slab_bytes(size_t(256) << 20) {
     static_assert(NbModuli <= params<T>::kMaxNbModuli, "not enough moduli of this size (params.hpp)");
     static_assert(Degree <= params<T>::kMaxPolyDegree, "degree is not lower or equal than kMaxPolyDegree");
     int rc = nflhip_ctx_create(&ctx, 0, int(sizeof(T) * 8), Degree, NbModuli, params<T>::P, params<T>::primitive_roots,
@@ -319,7 +321,11 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   void acquire_many_locked(size_t cnt, void **out) {
     struct sorter {  // recycled chunks come back in release order: hand them out by address, neighbours together
       void **o; size_t n;
-      ~sorter() { std::sort(o, o + n); }
+      ~sorter() {  // (fresh space already is in order; a loop's temporaries, released in order, come back reversed)
+        if (std::is_sorted(o, o + n)) return;
+        if (std::is_sorted(o, o + n, std::greater<void *>())) std::reverse(o, o + n);
+        else std::sort(o, o + n);
+      }
     } srt{out, cnt};
     size_t got = 0;
     while (got < cnt) {
@@ -367,9 +373,13 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
     if (!p || !alive()) return;  // (after teardown the runtime reclaims it)
     context &c = inst();
     std::lock_guard<std::mutex> lk(c.mu);
-    auto it = c.slabs.upper_bound(static_cast<char *>(p));
-    if (it == c.slabs.begin()) return;
-    slab &sl = (--it)->second;
+    slab *hit = c.last_released;  // (neighbouring handles die together: the slab of the previous release, usually)
+    if (!hit || static_cast<char *>(p) < hit->base || static_cast<char *>(p) >= hit->base + hit->chunks * chunk_bytes) {
+      auto it = c.slabs.upper_bound(static_cast<char *>(p));
+      if (it == c.slabs.begin()) return;
+      hit = c.last_released = &(--it)->second;  // (map nodes do not move; slabs are only removed by the destructor)
+    }
+    slab &sl = *hit;
     // stream-ordered reuse: every consumer of these buffers runs on `stream`
     if (--sl.live == 0) {
       sl.bump = 0;
@@ -670,6 +680,26 @@ template <class P> struct lazy {
     return deferred_flag().load(std::memory_order_relaxed) && ctx_t::chunk_bytes == ctx_t::poly_bytes && P::degree >= 8 &&
            P::degree * sizeof(T) >= 16;
   }
+  // ascending order for addresses that usually are `period` interleaved ascending sequences already (a loop body that
+  // transforms u, e1, e2 -- each kind a dense array of its own -- yields u0 e1_0 e2_0 u1 e1_1 e2_1 ...): merged in O(n)
+  static void sort_interleaved(std::vector<char *> &v) {
+    if (std::is_sorted(v.begin(), v.end())) return;
+    for (size_t period = 2; period <= 8 && period * 2 <= v.size(); ++period) {
+      bool ok = true;
+      for (size_t i = period; i < v.size() && ok; ++i) ok = !(v[i] < v[i - period]);
+      if (!ok) continue;
+      std::vector<char *> out;
+      out.reserve(v.size());
+      for (size_t r = 0; r < period; ++r) {
+        const size_t mid = out.size();
+        for (size_t i = r; i < v.size(); i += period) out.push_back(v[i]);
+        std::inplace_merge(out.begin(), out.begin() + ptrdiff_t(mid), out.end());
+      }
+      v.swap(out);
+      return;
+    }
+    std::sort(v.begin(), v.end());
+  }
   // the queue's reference to a payload (taken the first time a queue run's operations mention it)
   void pin(pay_t *p) {
     if (!p->qrefs) {
@@ -826,7 +856,7 @@ template <class P> struct lazy {
         std::vector<char *> ptr;
         ptr.reserve(idx.size());
         for (size_t i : idx) ptr.push_back(static_cast<char *>(ops[i].out->dev));
-        if (!std::is_sorted(ptr.begin(), ptr.end())) std::sort(ptr.begin(), ptr.end());  // (a loop's temporaries already are)
+        sort_interleaved(ptr);
         for (size_t a = 0; a < ptr.size();) {
           size_t b = a + 1;
           while (b < ptr.size() && ptr[b] == ptr[b - 1] + ctx_t::chunk_bytes) ++b;

@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#ifdef HOSTPROF_PCSAMPLE
+#include "pcsample.h"
+#endif
 
 int main(int argc, char **argv) {
   using T = uint64_t;
@@ -33,6 +36,9 @@ int main(int argc, char **argv) {
     out.invntt_pow_invphi();
   };
   double best_e = 1e9, best_d = 1e9;
+#ifdef HOSTPROF_PCSAMPLE
+  pcsample_start();
+#endif
   for (int round = 0; round < 6; ++round) {
     auto t0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < REPS; i++) encrypt(resa[i], resb[i]);
@@ -48,6 +54,9 @@ int main(int argc, char **argv) {
     const double e = std::chrono::duration<double>(t1 - t0).count(), d = std::chrono::duration<double>(t2 - t1).count();
     if (round) best_e = e < best_e ? e : best_e, best_d = d < best_d ? d : best_d;
   }
+#ifdef HOSTPROF_PCSAMPLE
+  pcsample_dump("/tmp/hostprof_pcs.txt");
+#endif
   std::printf("host cost per encryption %.0f ns (8 deferred operations), per decryption %.0f ns (2); %zu reps, launches %zu for %zu operations\n",
               best_e / REPS * 1e9, best_d / REPS * 1e9, REPS, poly_p::deferred_launches(), poly_p::deferred_operations());
   return 0;
