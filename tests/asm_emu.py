@@ -1074,6 +1074,7 @@ def run_xcd_product(asm_path, n, nm, prm, a, b, dlog, rlog, pooled, wgs, pick, s
     batch = a.shape[0]
     rows = batch * nm
     assert batch >= 2 and rows >= (8 << dlog)
+    assert wgs >= (8 << dlog), "every scheduling domain needs a workgroup (the launcher starts >= 256: 32 per XCD, at most 8 domains)"
     pow2 = (batch & (batch - 1)) == 0
     magic = ((1 << 32) // batch) if pow2 else ((1 << 32) // batch + 1)
     ctl_bytes = 4096 + (8 << dlog) * 0x11000
