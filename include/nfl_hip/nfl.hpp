@@ -1736,7 +1736,13 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     return p;
   }
   // shared with another HANDLE (references held by deferred operations do not count)
-  static bool shared(const ptr_type &p, long extra = 0) { return p.use_count() - p->qrefs - extra > 1; }
+  static bool shared(const ptr_type &p, long extra = 0) {
+    if (p.use_count() - extra <= 1) return false;  // nobody else at all
+    // The queue's reference and the flag that discounts it change together under the queue's lock -- also when a queue
+    // run started by ANOTHER thread retires this handle's operations -- so they are read under it.
+    std::lock_guard<std::recursive_mutex> lk(lazy_t::inst().mu);
+    return p.use_count() - p->qrefs - extra > 1;
+  }
   void detach() const {
     if (shared(_p)) _p = std::make_shared<payload_type>(*_p);  // (device-to-device when the value lives in HBM)
   }

@@ -78,3 +78,29 @@ def test_the_harness_notices_a_broken_queue(mock, tmp_path):
     build_program("deferred_fuzz.cpp", exe, include=str(inc))
     r = run(exe, 40, 1)
     assert r.returncode != 0 and "all checks passed" not in r.stdout
+
+
+def test_random_programs_under_address_and_undefined_behaviour_sanitizers(mock, tmp_path):
+    """the same random programs with ASan + UBSan + leak detection: handles dying while queued, the queue's raw payload
+    pointers and its one-reference-per-run pins, the buffer pool's free lists"""
+    exe = str(tmp_path / "fuzz_asan")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "deferred_fuzz.cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+    r = run(exe, 12, 99, env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "NFL_HIP_QUEUE_LIMIT": "61"})
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_threads_with_their_own_handles_share_the_queue_safely(mock, tmp_path):
+    """several host threads, each on its own handles: the queue, the stream and the buffer pool are shared, and a queue
+    run started by one thread retires the others' operations.  Under ThreadSanitizer, with a queue that runs by itself
+    every 37 records: no data race (the copy-on-write test reads the queue's reference and its flag under the queue's
+    lock) and every thread's results equal those of the same program run alone."""
+    exe = str(tmp_path / "threads_tsan")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           "-DNFL_HIP_NO_GMP", "-o", exe, os.path.join(ROOT, "tests", "cpp", "deferred_threads.cpp"),
+                           "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+    for _ in range(3):
+        r = run(exe, 6, 400, env={"NFL_HIP_QUEUE_LIMIT": "37", "TSAN_OPTIONS": "halt_on_error=0"})
+        assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[:4000]

@@ -19,3 +19,15 @@ def test_loop_shapes_deferred_equals_immediate_on_the_gpu(limit):
     r = subprocess.run([os.path.join(CPP, "deferred_loops"), "200"], capture_output=True, text=True, timeout=1800, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_threads_with_their_own_handles_on_the_gpu():
+    """tests/cpp/deferred_threads.cpp against the real library: four host threads on their own poly_p handles (shared
+    queue, stream and buffer pool); every thread's results equal the same program run alone"""
+    subprocess.check_call(["make", "-s", "-C", CPP, "deferred_threads"])
+    env = dict(os.environ)
+    env["NFL_HIP_QUEUE_LIMIT"] = "61"
+    r = subprocess.run([os.path.join(CPP, "deferred_threads"), "4", "200"], capture_output=True, text=True, timeout=1800, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout
