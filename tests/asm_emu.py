@@ -212,6 +212,7 @@ def bits_of(flags):
 
 class Wave:
     ticks = 0      # s_memtime: instructions executed by the whole launch
+    counts = {}    # instruction class -> instructions executed by all waves since the table was last cleared (tools/asm_cost.py)
 
     def __init__(self, prog, labels, mem, lds, kernarg_addr, wg_id, wave_in_wg, wg_y=0, xcc_id=0):
         self.prog, self.labels, self.mem, self.lds = prog, labels, mem, lds
@@ -458,6 +459,7 @@ class Wave:
             mn, ops, mods, self.cls = prog[self.pc]
             self.pc += 1
             Wave.ticks += 1
+            Wave.counts[self.cls] = Wave.counts.get(self.cls, 0) + 1
             h = table.get(mn)
             if h is not None:
                 h(self, ops, mods)

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""ANALYSIS AID (CPU only): dynamic instruction counts of the generated assembly kernels, taken by executing them on the
+gfx950 interpreter of tests/asm_emu.py, turned into the VALU-issue bound of each product kernel: a SIMD issues one VALU
+instruction of a wave64 per ~4 cycles (profiles/r02_pmc_sq_A.txt), the chip has 1024 SIMDs at
+~2.03 GHz under load.  Prints, per kernel: VALU / SALU / vector-memory / LDS instructions per product and the bound in
+products per second; the measured rates are quoted next to it from profiles/r02_final_bench_*.json.
+usage: tools/asm_cost.py > profiles/r02_valu_issue_model.txt"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import asm_emu                                 # noqa: E402
+from nfllib_amd.params import params           # noqa: E402
+
+SIMDS, CLOCK, CYCLES = 1024, 2.03e9, 4.0
+CSRC = os.path.join(ROOT, "nfllib_amd", "csrc")
+asm_emu.STRICT = False
+
+
+def operands(bits, n, nm, batch):
+    prm = params(bits)
+    rng = np.random.default_rng(5)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    a = (rng.integers(0, 1 << 62, size=(batch, nm, n), dtype=np.uint64) % P[None, :, None]).astype(prm.dtype)
+    return prm, a
+
+
+def measured(workload):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_final_bench_%s.json" % workload)) as f:
+            return json.loads(f.read().strip().splitlines()[-1])["value"]
+    except Exception:
+        return None
+
+
+rows = []
+
+
+def case(name, workload, nm_workload, run, products):
+    asm_emu.Wave.counts = {}
+    run()
+    c = asm_emu.Wave.counts
+    per = {k: v / products for k, v in c.items()}           # per product of ONE modulus
+    valu = per.get("valu", 0) * nm_workload
+    bound = SIMDS * CLOCK / CYCLES / valu
+    m = measured(workload)
+    rows.append((name, workload, valu, per.get("salu", 0) * nm_workload, per.get("vmem", 0) * nm_workload,
+                 per.get("lds", 0) * nm_workload, bound, m))
+
+
+def block(stem, n, block_log, workload, nm_w):
+    prm, a = operands(64, n, 1, 1)
+    case(stem, workload, nm_w, lambda: asm_emu.run_block_kernel(os.path.join(CSRC, stem + "_gfx950.s"), n, 1, prm, a, a, block_log), 1)
+
+
+def row(stem, bits, n, rows_per_wg, magic, workload, nm_w, batch):
+    prm, a = operands(bits, n, 1, batch)
+    case(stem, workload, nm_w, lambda: asm_emu.run_row_kernel(os.path.join(CSRC, stem + "_gfx950.s"), bits, n, 1, prm, a, a, rows_per_wg, magic), batch)
+
+
+def pipe(stem, n, workload, nm_w):
+    prm, a = operands(64, n, 1, 1)
+    case(stem, workload, nm_w, lambda: asm_emu.run_pipe_product(os.path.join(CSRC, stem + "_gfx950.s"), n, 1, prm, a, a), 1)
+
+
+block("polymul4096nt", 4096, 12, "B", 4)
+block("polymul8192", 8192, 13, "G", 2)
+block("polymul16384", 16384, 14, "C", 8)
+pipe("polymul_pipe32768", 32768, "F", 2)
+pipe("polymul_pipe65536nt", 65536, "E", 30)
+row("row1024_u32", 32, 1024, 4, True, "A", 1, 4)
+row("row128_u16", 16, 128, 32, False, "H", 1, 32)
+row("row8_u32", 32, 8, 256, True, "T", 2, 256)
+
+print("VALU-issue bound of the generated product kernels (dynamic counts from the interpreter; one VALU instruction per SIMD per %.0f"
+      " cycles, %d SIMDs, %.2f GHz)" % (CYCLES, SIMDS, CLOCK / 1e9))
+print("%-22s %-3s %12s %9s %9s %9s %14s %14s %7s" % ("kernel", "wl", "VALU/product", "SALU", "VMEM", "LDS", "bound [1/s]", "measured [1/s]", "ratio"))
+for name, wl, valu, salu, vmem, lds, bound, m in rows:
+    print("%-22s %-3s %12.0f %9.0f %9.0f %9.0f %14.4g %14s %7s" % (name, wl, valu, salu, vmem, lds, bound, "%.4g" % m if m else "-",
+                                                                  "%.2f" % (m / bound) if m else "-"))
+print("(wave-instructions per product of the workload's shape, all moduli; measured = profiles/r02_final_bench_<wl>.json)")
