@@ -664,9 +664,11 @@ template <class P> struct lazy {
   std::vector<ptr_t> pins, pins_running;  // the payloads they name, one reference each
   size_t launches, coalesced;  // statistics: launches issued / operations they carried
   // records after which the queue runs by itself: long enough for wide launches, short enough that the device works on
-  // one part of a long loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments)
+  // one part of a loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments).  Measured on the
+  // LWE demo loop (profiles/r02_late_queue_limit.txt): 2 048 iterations 614 k / 738 k / 1.04 M / 861 k encryptions/s with
+  // 2 048 / 4 096 / 8 192 / 16 384 records, 16 384 iterations 1.09 M / 1.21 M / 1.16 M / 1.16 M with 4 096 ... 32 768.
   static size_t max_queue() {
-    static const size_t v = getenv("NFL_HIP_QUEUE_LIMIT") ? size_t(atol(getenv("NFL_HIP_QUEUE_LIMIT"))) : 16384;
+    static const size_t v = getenv("NFL_HIP_QUEUE_LIMIT") ? size_t(atol(getenv("NFL_HIP_QUEUE_LIMIT"))) : 8192;
     return v ? v : 1;
   }
 
