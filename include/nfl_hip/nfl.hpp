@@ -672,6 +672,12 @@ template <class P> struct lazy {
     return v ? v : 1;
   }
 
+  // NFL_HIP_EARLY_RUN=1 (experimental, off by default until measured): from 1 024 records on, every 512 records the queue
+  // asks whether the stream is idle (nflhip_stream_idle: one hipStreamQuery) and runs at once if it is
+  static bool early_run() {
+    static const bool v = getenv("NFL_HIP_EARLY_RUN") && atoi(getenv("NFL_HIP_EARLY_RUN")) != 0;
+    return v;
+  }
   lazy() : launches(0), coalesced(0) { ctx_t::inst(); }  // (the context is constructed first, so it is destroyed last)
   static lazy &inst() {
     static lazy l;
@@ -730,6 +736,11 @@ template <class P> struct lazy {
     o.out->dev_valid = true;
     o.out->host_valid = false;
     if (q.size() >= max_queue()) flush();
+    else if (early_run() && q.size() >= 1024 && q.size() % 512 == 0) {
+      // a loop shorter than the queue: do not let the device sit idle until the loop's end
+      int idle = 0;
+      if (nflhip_stream_idle(ctx_t::get(), ctx_t::queue(), &idle) == NFLHIP_OK && idle) flush();
+    }
   }
   void flush() {
     std::lock_guard<std::recursive_mutex> lk(mu);

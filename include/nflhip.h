@@ -301,6 +301,10 @@ int nflhip_memcpy_d2h(nflhip_ctx *ctx, void *h_dst, const void *d_src, size_t by
 int nflhip_memcpy_d2d(nflhip_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
 int nflhip_memset_dev(nflhip_ctx *ctx, void *d_dst, int byte, size_t bytes, void *stream);
 int nflhip_stream_sync(nflhip_ctx *ctx, void *stream);
+/* never blocks: *idle = 1 when everything enqueued on `stream` so far has completed, else 0 (hipStreamQuery).  What the
+ * header's deferred queue asks before it starts a run early (a short loop's records would otherwise wait for the loop's
+ * end with the device idle). */
+int nflhip_stream_idle(nflhip_ctx *ctx, void *stream, int *idle);
 /* a non-blocking stream of the context's device (what the header's resident handles enqueue on) */
 int nflhip_stream_create(nflhip_ctx *ctx, void **stream);
 int nflhip_stream_destroy(nflhip_ctx *ctx, void *stream);

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("nflhip_memcpy_d2d", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("nflhip_memset_dev", _i, [_vp, _vp, _i, _sz, _vp]),
     ("nflhip_stream_sync", _i, [_vp, _vp]),
+    ("nflhip_stream_idle", _i, [_vp, _vp, C.POINTER(_i)]),
     ("nflhip_stream_create", _i, [_vp, C.POINTER(_vp)]),
     ("nflhip_stream_destroy", _i, [_vp, _vp]),
     ("nflhip_broadcast_dev", _i, [_vp, _vp, _vp, _sz, _vp]),

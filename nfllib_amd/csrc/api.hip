@@ -1304,6 +1304,15 @@ int nflhip_stream_sync(nflhip_ctx *ctx, void *stream) {
   HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
   return NFLHIP_OK;
 }
+int nflhip_stream_idle(nflhip_ctx *ctx, void *stream, int *idle) {
+  CHECK_CTX(ctx);
+  if (!idle) return fail(ctx, NFLHIP_ERR_INVALID, "idle is NULL");
+  const hipError_t e = hipStreamQuery((hipStream_t)stream);
+  if (e == hipErrorNotReady) (void)hipGetLastError();  // "not ready" is an answer, not an error: do not leave it for the next launch's check
+  else if (e != hipSuccess) HIPCHK(ctx, e);
+  *idle = e == hipSuccess ? 1 : 0;
+  return NFLHIP_OK;
+}
 
 // ---------------------------------------------------------------------------
 // host-pointer entry points: stage through context-owned device buffers

@@ -53,6 +53,14 @@ def test_loop_shapes_deferred_equals_immediate(mock, limit):
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
 
 
+def test_early_queue_runs_do_not_change_results(mock):
+    """NFL_HIP_EARLY_RUN=1: from 1 024 records on the queue runs whenever the stream is idle (always, on the toy device):
+    runs start in the middle of loop iterations and of groups"""
+    for exe, args in (("deferred_loops", (700,)), ("deferred_fuzz", (30, 77))):
+        r = run(os.path.join(mock, exe), *args, env={"NFL_HIP_EARLY_RUN": "1"})
+        assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
 def test_the_loops_are_coalesced(mock):
     """what deferral is for: the LWE loop's 300 x 8 operations leave as a handful of launches"""
     r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1"})
