@@ -20,6 +20,7 @@ U = np.uint64
 U32 = U(M32)
 VCC_LO = 106          # SGPR numbers of VCC (strict-mode bookkeeping only)
 STRICT = True
+COUNT = False        # tools/asm_cost.py: count executed instructions by class (Wave.counts)
 
 
 class StrictError(RuntimeError):
@@ -459,7 +460,8 @@ class Wave:
             mn, ops, mods, self.cls = prog[self.pc]
             self.pc += 1
             Wave.ticks += 1
-            Wave.counts[self.cls] = Wave.counts.get(self.cls, 0) + 1
+            if COUNT:
+                Wave.counts[self.cls] = Wave.counts.get(self.cls, 0) + 1
             h = table.get(mn)
             if h is not None:
                 h(self, ops, mods)

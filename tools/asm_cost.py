@@ -20,6 +20,7 @@ from nfllib_amd.params import params           # noqa: E402
 SIMDS, CLOCK, CYCLES = 1024, 2.03e9, 4.0
 CSRC = os.path.join(ROOT, "nfllib_amd", "csrc")
 asm_emu.STRICT = False
+asm_emu.COUNT = True
 
 
 def operands(bits, n, nm, batch):
