@@ -376,7 +376,12 @@ def main():
     # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  Instructions per wave are
     # the SQ_INSTS_VALU / SQ_WAVES of the committed counter passes (= the generator's static count for the assembly kernel);
     # peak = one wave64 instruction per 4 cycles per SIMD, the rate of v_mad_u64_u32 / carry / multiply opcodes on gfx950.
-    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2081, nm, "profiles/r02_pmc_sq_A.txt")}.get(kwl)
+    # The other workloads: DYNAMIC counts per product (all moduli) from executing the generated kernels on the interpreter of
+    # tests/asm_emu.py (tools/asm_cost.py -> profiles/r02_valu_issue_model.txt; B and A agree with their counter passes).
+    model = "profiles/r02_valu_issue_model.txt"
+    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2081, nm, "profiles/r02_pmc_sq_A.txt"),
+            "G": (103856, 1, model), "C": (888192, 1, model), "F": (475184, 1, model), "E": (15115680, 1, model),
+            "H": (227, 1, model), "T": (13, 1, model)}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]
         peak_gi = 256 * 4 * 2.4 / 4.0   # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles, in G wave-instructions/s
