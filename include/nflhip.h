@@ -303,7 +303,7 @@ int nflhip_memset_dev(nflhip_ctx *ctx, void *d_dst, int byte, size_t bytes, void
 int nflhip_stream_sync(nflhip_ctx *ctx, void *stream);
 /* never blocks: *idle = 1 when everything enqueued on `stream` so far has completed, else 0 (hipStreamQuery).  What the
  * header's deferred queue asks before it starts a run early (a short loop's records would otherwise wait for the loop's
- * end with the device idle). */
+ * end with the device idle).  Not for a stream that is being captured into a hipGraph (a query ends the capture). */
 int nflhip_stream_idle(nflhip_ctx *ctx, void *stream, int *idle);
 /* a non-blocking stream of the context's device (what the header's resident handles enqueue on) */
 int nflhip_stream_create(nflhip_ctx *ctx, void **stream);
