@@ -90,6 +90,24 @@ def test_product_path_never_touches_the_oracle():
     assert not bad, bad
 
 
+def test_product_path_never_touches_the_test_doubles():
+    """tests/cpp/mock (the C ABI over host memory with toy arithmetic) and tools/hostprof (the do-nothing stand-in) exist for
+    CPU tests / host profiling of the header layer only: nothing the product, the bench or smoke() loads may name them, and
+    the library path the Python layer opens is the in-tree HIP build"""
+    from nfllib_amd import _lib
+    assert os.path.realpath(_lib.LIB_PATH) == os.path.realpath(os.path.join(ROOT, "nfllib_amd", "libnflhip.so"))
+    bad = []
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for base in ("nfllib_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", "Makefile"))]
+    for f in files:
+        txt = open(f, errors="ignore").read()
+        if re.search(r"_mock|mock_backend|null_backend|hostprof/_build", txt):
+            bad.append(f)
+    assert not bad, bad
+
+
 def test_every_generated_kernel_the_launchers_name_is_in_the_code_object():
     """kernels_fast.hip looks the generated assembly kernels up BY NAME in the embedded code object and treats a miss as
     "not supported" (the compiled kernels then serve the call): a typo would silently cost the tuned path.  Every name in
