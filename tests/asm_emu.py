@@ -1128,3 +1128,31 @@ def run_xcd_product(asm_path, n, nm, prm, a, b, dlog, rlog, pooled, wgs, pick, s
     run_kernel(text, mem, kernarg, wgs, lds, concurrent=(lambda wg: wg % 8, pick))
     out, _ = mem.find(pc, c.nbytes)
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
+
+
+def run_pipe_product_pipelined(asm_path, n, nm, prm, a, b):
+    """the same three-role kernel driven as the chunked plan drives it: launch t runs the forward pass of polynomial t, the
+    block products of polynomial t - 1 and the inverse pass of polynomial t - 2 TOGETHER (all three roles in one launch,
+    on different rows), batch + 2 launches in all"""
+    import struct
+    mem = Memory()
+    psi, mc = device_tables(64, n, nm, prm)
+    logn = n.bit_length() - 1
+    batch = a.shape[0]
+    c, sa, sb = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)
+    pa, pb, pc, psa, psb = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(sa), mem.add(sb)
+    ppsi, pmc = mem.add(psi), mem.add(mc)
+    with open(asm_path) as f:
+        text = f.read()
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
+    per_row = 28 if logn == 16 else 14
+    poly_bytes = nm * n * 8
+    for t in range(batch + 2):
+        f, v, i = t, t - 1, t - 2
+        cnt_f, cnt_v, cnt_i = int(0 <= f < batch), int(0 <= v < batch), int(0 <= i < batch)
+        off = lambda base, k: base + max(k, 0) * poly_bytes      # noqa: E731
+        kernarg = struct.pack("<5Q6i6Q", off(pc, v), off(psa, v), off(psb, v), ppsi, pmc, nm, logn, cnt_v, cnt_f, cnt_i, 0,
+                              off(pa, f), off(psa, f), off(pb, f), off(psb, f), off(pc, i), 0)
+        run_kernel(text, mem, kernarg, (max(cnt_v, cnt_f, cnt_i) * per_row, nm), lds)
+    out, _ = mem.find(pc, c.nbytes)
+    return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()

@@ -227,3 +227,11 @@ def test_strict_mode_models_the_measured_visibility_rules(generated, oracle_fact
     mutant.write_text(re.sub(r"(global_load_dword .*) sc1\n", r"\1\n", text))
     with pytest.raises(asm_emu.StrictError, match="stale cache line"):
         asm_emu.run_xcd_product(str(mutant), 32768, 1, prm, a, b, 0, 1, 0, 16, _picker("random"))
+
+
+def test_emulated_u64_three_roles_in_one_launch(generated, oracle_factory):
+    """the chunked plan's software pipeline at n = 32768: the middle launch carries a forward pass, block products and an
+    inverse pass of three different polynomials"""
+    o = oracle_factory(64, 32768, 1)
+    prm, a, b = operands(o, 64, 32768, 1, 3, 24)
+    assert np.array_equal(asm_emu.run_pipe_product_pipelined(generated("polymul_pipe32768"), 32768, 1, prm, a, b), o.polymul(a, b))
