@@ -142,7 +142,7 @@ def measure_traffic(workload, batch):
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", str(steps),
-                   "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline", "--no-traffic"]
+                   "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline", "--no-traffic", "--no-rccl"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel secondary rates")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.traffic)")
+    ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: skip the world-size-1 RCCL initialisation")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1 only: also time one step whose operands start on rank 0 and whose product returns there "
                          "(grouped RCCL send/recv of contiguous shards, SURVEY.md 8(e)); reported beside `value`, never in it")
@@ -193,12 +194,27 @@ def main():
     backend = os.environ.get("NFLHIP_BENCH_BACKEND", "nccl")
     dev = local_rank if world > 1 and os.environ.get("NFLHIP_BENCH_ONE_DEVICE") != "1" else 0
     torch.cuda.set_device(dev)
-    if world > 1:
+    # RCCL is initialised at EVERY world size, 1 included (a 1-GPU box then exercises the same init / barrier / all-reduce
+    # calls the N-GPU launch line makes; --no-rccl keeps the profiler's inner re-runs of this script light)
+    rccl = {"initialised": False}
+    use_dist = world > 1 or not args.no_rccl
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend=backend)
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        except Exception as e:
+            if world > 1:
+                raise
+            use_dist = False
+            rccl["error"] = "torch.distributed init failed: %r" % (e,)
     red_dev = torch.device("cuda", dev) if backend == "nccl" else None
 
     lb, n, nm, dflt = WORKLOADS[args.workload]
@@ -211,8 +227,28 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
+
+    # the engine's own communicator (include/nflhip.h nflhip_comm_*: ncclCommInitRank through the C ABI; the id travels
+    # over torch.distributed) -- what a C++ caller with one process per GPU uses; here it carries the digests
+    comm = None
+    if use_dist and backend == "nccl":
+        try:
+            from nfllib_amd import Comm
+            box = [Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = Comm(eng, world, rank, box[0])
+            comm.barrier()
+            probe = torch.ones(1, dtype=torch.int64, device=red_dev)
+            dist.all_reduce(probe)
+            rccl = {"initialised": True, "world_size": world, "all_reduce_of_ones": int(probe.item()),
+                    "calls": "torch.distributed nccl init + barrier + all_reduce; nflhip_comm_create (ncclCommInitRank) + "
+                             "nflhip_comm_barrier + nflhip_comm_allgather_u64"}
+        except Exception as e:
+            if world > 1:
+                raise
+            rccl = {"initialised": False, "error": repr(e)}
 
     for _ in range(args.warmup):
         eng.polymul(a, b, out=c)
@@ -229,7 +265,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
+    if use_dist:
         dt = sharding.allreduce_max(dt, dist, device=red_dev)
         kernel_ms = sharding.allreduce_max(kernel_ms, dist, device=red_dev)
 
@@ -241,6 +277,29 @@ def main():
         import numpy as np
         idx = sorted({0, batch // 3, batch // 2, batch - 1})
         check = tuple(np.concatenate([eng.to_host(t[i:i + 1]) for i in idx]) for t in (a, b, c))
+
+    # checksum of checksums: every rank digests ITS shard of the product (positions counted in the
+    # logical global batch, so the digests add up to the digest of the whole batch) and then recomputes its NEIGHBOUR's
+    # shard from the shared counter stream on its own GPU; the two sets of digests -- shard r computed on GPU r, and on
+    # GPU r - 1 -- must be identical, rank by rank and in the sum.
+    def gather_u64(v):
+        if comm is not None:
+            return comm.allgather_u64(v)
+        if use_dist:
+            return sharding.allgather_digests(v, dist, world, device=red_dev)
+        return [v]
+    own = gather_u64(eng.digest(c, first_poly=first_poly))
+    nxt = (rank + 1) % world
+    eng.fill_uniform(a, SEED, 0, first_poly=nxt * batch)
+    eng.fill_uniform(b, SEED, 1, first_poly=nxt * batch)
+    eng.polymul(a, b, out=c)
+    cross = gather_u64(eng.digest(c, first_poly=nxt * batch))      # entry r = shard (r + 1) mod world
+    cross = [cross[(r - 1) % world] for r in range(world)]          # ... reordered: entry r = shard r
+    sums_ok = own == cross
+    checksum = {"ok": bool(sums_ok), "sum_of_shard_digests": "%016x" % sharding.combine_digests(own),
+                "recomputed_on_the_neighbouring_gpu": "%016x" % sharding.combine_digests(cross), "shards": world,
+                "via": "nflhip_comm_allgather_u64 (RCCL)" if comm is not None else ("torch.distributed" if use_dist else "local")}
+    ok = ok and sums_ok
 
     alg_bytes_per_poly = 3 * nm * n * (lb // 8)       # read a, read b, write c
     launch_bytes = alg_bytes_per_poly * batch
@@ -268,7 +327,27 @@ def main():
             traffic = None
 
     scatter = None
-    if world > 1 and args.scatter_gather:
+    if world > 1 and args.scatter_gather and comm is not None:
+        # data originating on one device: root -> shards -> polymul -> root, through the C ABI's RCCL scatter / gather
+        # (grouped ncclSend / ncclRecv of contiguous shards).  Outside the timed region of `value`.
+        fa = fb = fc = None
+        if rank == 0:
+            fa = eng.fill_uniform(eng.empty(batch * world), SEED, 0)
+            fb = eng.fill_uniform(eng.empty(batch * world), SEED, 1)
+            fc = eng.empty(batch * world)
+        torch.cuda.synchronize(); barrier()
+        ts = time.perf_counter()
+        comm.scatter(a, fa, batch * world)
+        comm.scatter(b, fb, batch * world)
+        eng.polymul(a, b, out=c)
+        comm.gather(fc, c, batch * world)
+        torch.cuda.synchronize(); barrier()
+        tsg = sharding.allreduce_max(time.perf_counter() - ts, dist, device=red_dev)
+        scatter = {"polymul_per_s_incl_scatter_gather": round(world * batch / tsg, 1), "seconds": round(tsg, 4),
+                   "bytes_moved": 3 * (world - 1) * batch * nm * n * (lb // 8), "via": "nflhip_scatter_dev / nflhip_gather_dev (RCCL)",
+                   "note": "one step; both operands scattered from rank 0, product gathered back (grouped send/recv over xGMI)"}
+        del fa, fb, fc
+    elif world > 1 and args.scatter_gather:
         # data originating on one device: root -> shards -> polymul -> root.  Outside the timed region of `value`.
         fa = fb = fc = None
         if rank == 0:
@@ -363,7 +442,8 @@ def main():
         "vs_baseline": None, "dtype": "u%d" % lb, "data": "synthetic",
         "config": {"workload": "nfl::poly<uint%d_t,%d,%d> batched polymul (BASELINE configs %s)" % (lb, n, nm, args.workload),
                    "degree": n, "nmoduli": nm, "limb_bits": lb, "batch_per_gpu": batch, "global_batch": batch * world,
-                   "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok)},
+                   "parallelism": "batch-split x%d, no data-path collective" % world, "self_check": bool(ok),
+                   "checksum_of_checksums": checksum, "rccl": rccl},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm",
@@ -406,7 +486,9 @@ def main():
         result["value"] = None
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if comm is not None:
+        comm.close()
+    if use_dist:
         dist.destroy_process_group()
     if bad:
         raise SystemExit(1)

@@ -229,12 +229,43 @@ inline void check(nflhip_ctx *ctx, int rc, const char *what) {
   if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): ") + what + ": " + nflhip_last_error(ctx));
 }
 
+// Every ring type whose per-polynomial operations can be deferred (detail::lazy<P> below) registers the function that
+// runs its queue.  Whoever is about to invalidate something recorded operations refer to -- a FastGaussianNoise that
+// dies (its device tables), nfl::set_sampler_key (the key recorded draws will be made with) -- runs all queues first.
+// Leaked on purpose: objects with static storage may call it while the program's other statics are being destroyed.
+struct queue_registry {
+  std::mutex mu;
+  std::vector<void (*)()> runners;
+  static queue_registry &get() {
+    static queue_registry *r = new queue_registry;
+    return *r;
+  }
+  void add(void (*f)()) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto g : runners) if (g == f) return;
+    runners.push_back(f);
+  }
+  void run_all() {
+    std::vector<void (*)()> fs;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      fs = runners;
+    }
+    for (auto f : fs) f();
+  }
+};
+
 // The process-wide sampler state: the counterpart of fastrandombytes' static key and nonce
 // (lib/prng/fastrandombytes.cpp:17-37).  The key is drawn from the OS once; every sampling call takes the next
 // 64-bit stream id.  nfl::set_sampler_key() pins both for reproducible runs.
 struct sampler {
   unsigned char key[32];
+  std::mutex key_mu;  // set_sampler_key against a queue run's copy of the key (another thread)
   std::atomic<uint64_t> next;
+  void copy_key(unsigned char out[32]) {
+    std::lock_guard<std::mutex> lk(key_mu);
+    std::memcpy(out, key, 32);
+  }
   sampler() : next(0) {
     std::random_device rd;
     for (int i = 0; i < 32; i += 4) {
@@ -253,9 +284,18 @@ struct sampler {
 // It also owns what the resident poly_p handles share: ONE stream every resident operation is enqueued on (so
 // successive operations are ordered without events) and a free list of polynomial-sized device buffers (hipMalloc /
 // hipFree per temporary would cost more than the kernels).
+// The device the per-polynomial surface (poly, poly_p, the static contexts) lives on: NFL_HIP_DEVICE in the environment,
+// or nfl::set_device() before the first polynomial of a ring type is used; 0 otherwise.  Batches name their device
+// themselves (device_batch(count, device), sharded_batch).
+inline std::atomic<int> &default_device() {
+  static std::atomic<int> d(getenv("NFL_HIP_DEVICE") ? atoi(getenv("NFL_HIP_DEVICE")) : 0);
+  return d;
+}
+
 template <class T, size_t Degree, size_t NbModuli> struct context {
   nflhip_ctx *ctx;
   void *stream;
+  int device;
   std::mutex mu;
   static constexpr size_t poly_bytes = Degree * NbModuli * sizeof(T);
   static constexpr size_t chunk_bytes = (poly_bytes + 255) / 256 * 256;          // device buffers are 256-byte aligned
@@ -269,12 +309,14 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
     std::vector<void *> free;
   };
   std::map<char *, slab> slabs;
+  const bool is_static;  // the function-local static of inst(): the one the resident poly_p handles allocate from
   slab *last_released;
   size_t next_slab_bytes;
-  context() : ctx(nullptr), stream(nullptr), last_released(nullptr), next_slab_bytes(size_t(256) << 20) {
+  explicit context(int dev, bool is_static_ = false)
+      : ctx(nullptr), stream(nullptr), device(dev), is_static(is_static_), last_released(nullptr), next_slab_bytes(size_t(256) << 20) {
     static_assert(NbModuli <= params<T>::kMaxNbModuli, "not enough moduli of this size (params.hpp)");
     static_assert(Degree <= params<T>::kMaxPolyDegree, "degree is not lower or equal than kMaxPolyDegree");
-    int rc = nflhip_ctx_create(&ctx, 0, int(sizeof(T) * 8), Degree, NbModuli, params<T>::P, params<T>::primitive_roots,
+    int rc = nflhip_ctx_create(&ctx, dev, int(sizeof(T) * 8), Degree, NbModuli, params<T>::P, params<T>::primitive_roots,
                                params<T>::invkMaxPolyDegree, params<T>::kMaxLog2);
     if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): context: ") + nflhip_last_error(nullptr));
     rc = nflhip_stream_create(ctx, &stream);
@@ -282,10 +324,10 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
       nflhip_ctx_destroy(ctx);
       throw std::runtime_error(std::string("nfl(hip): context stream: ") + nflhip_last_error(nullptr));
     }
-    alive() = true;
+    if (is_static) alive() = true;
   }
   ~context() {
-    alive() = false;
+    if (is_static) alive() = false;
     nflhip_stream_sync(ctx, stream);
     for (auto &kv : slabs) nflhip_free(ctx, kv.first);
     nflhip_stream_destroy(ctx, stream);
@@ -298,8 +340,21 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
     return a;
   }
   static context &inst() {
-    static context c;
+    static context c(default_device().load(), true);
     return c;
+  }
+  // The context of this ring type on `device`: the static one for the default device, otherwise one per device created on
+  // first use (what device_batch(count, device) and sharded_batch run on).  Same tables everywhere: they are a
+  // deterministic function of params<T> (core.hpp:625-686), so nothing is broadcast.
+  static context &on(int dev) {
+    context &def = inst();
+    if (dev == def.device) return def;
+    static std::mutex m;
+    static std::map<int, std::unique_ptr<context>> others;
+    std::lock_guard<std::mutex> lk(m);
+    std::unique_ptr<context> &slot = others[dev];
+    if (!slot) slot.reset(new context(dev));
+    return *slot;
   }
   static nflhip_ctx *get() { return inst().ctx; }
   static void *queue() { return inst().stream; }
@@ -405,9 +460,20 @@ inline uint64_t splitmix64_at(uint64_t seed, int operand, uint64_t g) {
  * every operation launch when it is called (flush the ring types in use first: poly_p<...>::flush()) */
 inline void set_deferred(bool on);
 
+/* the GPU the per-polynomial surface runs on (default: NFL_HIP_DEVICE or 0); call before the first polynomial of a ring
+ * type is used -- the static context of that type is created once */
+inline void set_device(int device) { detail::default_device().store(device); }
+inline int device_count() {
+  int n = 0;
+  detail::check(nullptr, nflhip_device_count(&n), "device_count");
+  return n;
+}
+
 /* pin the sampler state: `key` (32 bytes) and the id of the next keystream -- reproducible runs */
 inline void set_sampler_key(const unsigned char key[32], uint64_t next_stream = 0) {
   detail::sampler &s = detail::sampler::get();
+  detail::queue_registry::get().run_all();  // draws recorded so far are made with the key they were recorded under
+  std::lock_guard<std::mutex> lk(s.key_mu);
   std::memcpy(s.key, key, 32);
   s.next.store(next_stream);
 }
@@ -426,7 +492,7 @@ inline uint64_t rdtsc(void) {
  * stream.  Here: the next keystream of the process-wide sampler state, generated on the device. */
 inline void fastrandombytes(unsigned char *r, unsigned long long rlen) {
   detail::sampler &s = detail::sampler::get();
-  detail::check(nullptr, nflhip_random_bytes(0, r, size_t(rlen), s.key, s.next++), "fastrandombytes");
+  detail::check(nullptr, nflhip_random_bytes(detail::default_device().load(), r, size_t(rlen), s.key, s.next++), "fastrandombytes");
 }
 /* nfl::randombytes (nfl/prng/randombytes.h): OS entropy, what the reference keys its stream with */
 inline void randombytes(unsigned char *x, unsigned long long xlen) {
@@ -448,6 +514,9 @@ template <class in_class, class out_class, unsigned _lu_depth> class FastGaussia
   FastGaussianNoise(FastGaussianNoise const &) = delete;
   FastGaussianNoise &operator=(FastGaussianNoise const &) = delete;
   ~FastGaussianNoise() {
+    // deferred draws refer to these tables (the reference samples inside the constructor, so a generator may well die
+    // before the polynomials built from it are used): run every queue before the tables go
+    try { detail::queue_registry::get().run_all(); } catch (...) {}
     // (the contexts are function-local statics and may already be gone when an object with static storage dies:
     // nflhip_gauss_destroy never dereferences its context argument)
     for (auto &kv : tables_) nflhip_gauss_destroy(nullptr, kv.second);
@@ -519,15 +588,17 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   P *host;
   void *dev;
   bool host_valid, dev_valid, queued;
+  bool poisoned;  // the deferred operation that was to produce this value never ran (an earlier launch of its queue run failed)
   long qrefs;  // 1 while the deferred queue holds its (single) reference to this value, else 0: copy-on-write decisions look past it
   // levelling scratch of lazy<P>::flush (valid when `epoch` is the current flush): last level that writes / reads this value
   unsigned epoch;
   int wlev, rlev;
 
-  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {}
+  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {}
   payload(const payload &o) : std::enable_shared_from_this<payload<P>>(), host(nullptr), dev(nullptr), host_valid(false),
-                              dev_valid(false), queued(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {
+                              dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {
     pending();
+    o.usable();
     if (o.dev_valid) {  // stays on the device
       check(ctx(), nflhip_memcpy_d2d(ctx(), dev_wo(), o.dev, bytes, ctx_t::queue()), "poly_p copy");
     } else if (o.host_valid) {
@@ -546,6 +617,9 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   }
   static nflhip_ctx *ctx() { return ctx_t::get(); }
   static void pending() { lazy<P>::inst().flush(); }  // run whatever is still deferred
+  void usable() const {  // reading a value whose producing operation never ran is an error, not stale HBM
+    if (poisoned) throw std::runtime_error("nfl(hip): this polynomial's deferred operation did not run (an earlier operation of its queue failed)");
+  }
 
   void alloc_host() {
     if (host) return;
@@ -556,6 +630,7 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   // the host image, current
   void to_host() {
     pending();
+    usable();
     alloc_host();
     if (host_valid) return;
     if (dev_valid) {
@@ -580,6 +655,7 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
     alloc_host();
     host_valid = true;
     dev_valid = false;
+    poisoned = false;
     return *host;
   }
   // the device image, current
@@ -589,6 +665,7 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   }
   const void *dev_ro_nf() {  // (the queue's own form: never runs the queue)
     if (queued) return dev;  // produced by a deferred operation; its buffer is assigned when the queue runs
+    usable();
     if (!dev) dev = ctx_t::acquire();
     if (!dev_valid) {
       if (host_valid) check(ctx(), nflhip_memcpy_h2d(ctx(), dev, host->cdata(), bytes, ctx_t::queue()), "poly_p upload");
@@ -607,6 +684,7 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
     if (!dev) dev = ctx_t::acquire();
     dev_valid = true;
     host_valid = false;
+    poisoned = false;
     return dev;
   }
 };
@@ -679,10 +757,30 @@ template <class P> struct lazy {
     static const bool v = getenv("NFL_HIP_EARLY_RUN") && atoi(getenv("NFL_HIP_EARLY_RUN")) != 0;
     return v;
   }
-  lazy() : launches(0), coalesced(0) { ctx_t::inst(); }  // (the context is constructed first, so it is destroyed last)
+  lazy() : launches(0), coalesced(0) {
+    ctx_t::inst();  // (the context is constructed first, so it is destroyed last)
+    alive() = true;
+    queue_registry::get().add(&lazy::run_if_alive);
+  }
+  ~lazy() { alive() = false; }
+  static bool &alive() {
+    static bool a = false;
+    return a;
+  }
+  static void run_if_alive() {  // what queue_registry calls (possibly while the program's statics are being destroyed)
+    if (alive() && ctx_t::alive()) inst().flush();
+  }
   static lazy &inst() {
     static lazy l;
     return l;
+  }
+  // whether two recorded operations may share a launch: everything a launch takes from its first member
+  static bool same_signature(const op &a, const op &b) {
+    if (a.kind != b.kind) return false;
+    if (a.kind == K_EVAL) return a.len == b.len && a.nin == b.nin && std::memcmp(a.e.code, b.e.code, a.len) == 0;
+    if (a.kind == K_SAMPLE || a.kind == K_GAUSS) return a.s.dist == b.s.dist && a.s.p0 == b.s.p0 && a.s.p1 == b.s.p1 && a.s.tab == b.s.tab;
+    if (a.kind == K_FILL) return a.s.sid == b.s.sid;
+    return true;
   }
   // whether this ring's operations can be deferred at all: dense chunks, vectors of 16 bytes, sequence samplers
   static bool usable() {
@@ -736,6 +834,7 @@ template <class P> struct lazy {
     o.out->queued = true;
     o.out->dev_valid = true;
     o.out->host_valid = false;
+    if (o.kind != K_NTT_FWD && o.kind != K_NTT_INV) o.out->poisoned = false;  // overwritten entirely
     if (q.size() >= max_queue()) flush();
     else if (early_run() && q.size() >= 1024 && q.size() % 512 == 0) {
       // a loop shorter than the queue: do not let the device sit idle until the loop's end
@@ -755,15 +854,24 @@ template <class P> struct lazy {
     held.swap(pins);
     if (q.capacity() < ops.capacity()) q.reserve(ops.capacity());
     for (auto &p : held) p->qrefs = 0;  // (operations recorded from now on belong to the next run and pin again)
+    std::vector<unsigned char> launched(ops.size(), 0);
     struct done_guard {  // whatever happens, the payloads stop claiming a queued value, and the run's references go
       std::vector<op> &o;
       std::vector<ptr_t> &h;
+      std::vector<unsigned char> &launched;
+      bool complete;
       ~done_guard() {
         for (auto &x : o) x.out->queued = false;
+        if (!complete)  // a launch failed: what was never launched holds no value -- later accesses throw (payload::usable)
+          for (size_t i = 0; i < o.size(); ++i)
+            if (!launched[i]) {
+              o[i].out->dev_valid = false;
+              o[i].out->poisoned = true;
+            }
         o.clear();
         h.clear();
       }
-    } guard{ops, held};
+    } guard{ops, held, launched, false};
     // ---- 1. levels (the last writing / reading level of a value is kept in its payload, tagged with this flush's epoch)
     static unsigned epoch_counter = 0;
     const unsigned ep = ++epoch_counter;
@@ -811,7 +919,7 @@ template <class P> struct lazy {
       }
       size_t g = keys.size();
       for (size_t k = keys.size(); k-- > 0;)   // (recent groups first: neighbouring operations repeat)
-        if (keys[k].level == lvl[i] && keys[k].hash == h) { g = k; break; }
+        if (keys[k].level == lvl[i] && keys[k].hash == h && same_signature(ops[members[k][0]], o)) { g = k; break; }
       if (g == keys.size()) {
         keys.push_back(gkey{lvl[i], h});
         members.emplace_back();
@@ -825,7 +933,8 @@ template <class P> struct lazy {
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return keys[x].level < keys[y].level; });
     nflhip_ctx *ctx = ctx_t::get();
     void *st = ctx_t::queue();
-    detail::sampler &smp = detail::sampler::get();
+    struct { unsigned char key[32]; } smp;  // the key as it is NOW: set_sampler_key runs the queues before it changes it
+    detail::sampler::get().copy_key(smp.key);
     static const bool trace = getenv("NFL_HIP_TRACE_DEFERRED") != nullptr;
     for (size_t gi : order) {
       std::vector<size_t> &idx = members[gi];
@@ -880,11 +989,13 @@ template <class P> struct lazy {
           coalesced += b - a;
           a = b;
         }
+        for (size_t i : idx) launched[i] = 1;
         continue;
       }
       if (kind == K_FILL) {
         for (size_t i : idx) {
           check(ctx, nflhip_fill_uniform_dev(ctx, ops[i].out->dev, 0, 1, ops[i].s.sid, 0, st), "deferred set(uniform)");
+          launched[i] = 1;
           ++launches;
           ++coalesced;
         }
@@ -913,6 +1024,7 @@ template <class P> struct lazy {
             check(ctx, cnt == 1 ? nflhip_sample_gauss_dev(ctx, o0.out->dev, 0, 1, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, st)
                                 : nflhip_sample_gauss_seq_dev(ctx, o0.out->dev, cnt, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, stride, st),
                   "deferred set(gaussian)");
+          for (size_t k = a; k < b; ++k) launched[idx[k]] = 1;
           ++launches;
           coalesced += cnt;
           a = b;
@@ -993,12 +1105,14 @@ template <class P> struct lazy {
             check(ctx, nflhip_eval_strided_dev(ctx, o0.out->dev, ostride, d, stride, size_t(nin), o0.e.code, size_t(o0.len), cnt, st),
                   "deferred operator=(expr)");
           }
+          for (size_t k = a; k < b; ++k) launched[sidx[k]] = 1;
           ++launches;
           coalesced += cnt;
           a = b;
         }
       }
     }
+    guard.complete = true;
   }
 };
 }  // namespace detail
@@ -2025,61 +2139,67 @@ template <class P> void pointwise(int op, P *out, P const *a, P const *b, P cons
 // above crosses PCIe twice.  device_batch<P> keeps a dense [count][NbModuli][Degree] tensor resident
 // in HBM (the role poly_p's shared payload plays on the host, poly_p.hpp:11-204) and runs the same
 // operations through the *_dev entry points on one stream: upload once, compute, download once.
+// device_batch(count, device) puts it on a GPU of its choice (default: the per-polynomial surface's device).
 template <class P> class device_batch {
  public:
   typedef typename P::value_type value_type;
-  explicit device_batch(size_t count) : n_(count), d_(nullptr) {
+  typedef detail::context<value_type, P::degree, P::nmoduli> context_type;
+  explicit device_batch(size_t count) : device_batch(count, detail::default_device().load()) {}
+  device_batch(size_t count, int device) : n_(count), d_(nullptr), c_(&context_type::on(device)) {
     static_assert(sizeof(P) == P::degree * P::nmoduli * sizeof(value_type), "dense poly array");
-    detail::check(P::ctx(), nflhip_malloc(P::ctx(), &d_, bytes()), "device_batch");
+    detail::check(ctx(), nflhip_malloc(ctx(), &d_, bytes()), "device_batch");
   }
   device_batch(const P *host, size_t count) : device_batch(count) { upload(host); }
-  ~device_batch() { if (d_) nflhip_free(P::ctx(), d_); }
+  ~device_batch() { if (d_) nflhip_free(ctx(), d_); }
   device_batch(const device_batch &) = delete;
   device_batch &operator=(const device_batch &) = delete;
-  device_batch(device_batch &&o) noexcept : n_(o.n_), d_(o.d_) { o.d_ = nullptr; }
+  device_batch(device_batch &&o) noexcept : n_(o.n_), d_(o.d_), c_(o.c_) { o.d_ = nullptr; }
 
   size_t size() const { return n_; }
   size_t bytes() const { return n_ * sizeof(P); }
   void *data() { return d_; }
   const void *data() const { return d_; }
+  int device() const { return c_->device; }
+  nflhip_ctx *ctx() const { return c_->ctx; }     // the context of this batch's device ...
+  void *queue() const { return c_->stream; }      // ... and the stream its operations are enqueued on
 
   void upload(const P *host) {
-    detail::check(P::ctx(), nflhip_memcpy_h2d(P::ctx(), d_, host->cdata(), bytes(), P::queue()), "upload");
+    detail::check(ctx(), nflhip_memcpy_h2d(ctx(), d_, host->cdata(), bytes(), queue()), "upload");
     sync();
   }
   void download(P *host) const {
-    detail::check(P::ctx(), nflhip_memcpy_d2h(P::ctx(), host->data(), d_, bytes(), P::queue()), "download");
+    detail::check(ctx(), nflhip_memcpy_d2h(ctx(), host->data(), d_, bytes(), queue()), "download");
     sync();
   }
-  void sync() const { detail::check(P::ctx(), nflhip_stream_sync(P::ctx(), P::queue()), "sync"); }
+  void sync() const { detail::check(ctx(), nflhip_stream_sync(ctx(), queue()), "sync"); }
 
   // same names and meaning as the poly members (poly.hpp:167-168), over the whole batch
-  void ntt_pow_phi() { detail::check(P::ctx(), nflhip_ntt_fwd_dev(P::ctx(), d_, n_, P::queue()), "ntt_pow_phi"); }
-  void invntt_pow_invphi() { detail::check(P::ctx(), nflhip_ntt_inv_dev(P::ctx(), d_, n_, P::queue()), "invntt_pow_invphi"); }
+  void ntt_pow_phi() { detail::check(ctx(), nflhip_ntt_fwd_dev(ctx(), d_, n_, queue()), "ntt_pow_phi"); }
+  void invntt_pow_invphi() { detail::check(ctx(), nflhip_ntt_inv_dev(ctx(), d_, n_, queue()), "invntt_pow_invphi"); }
   // *this = op(a, b[, b'])  (NFLHIP_OP_*); aliasing allowed
   void assign(int op, const device_batch &a, const device_batch &b) {
     same_size(a); same_size(b);
-    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), op, d_, a.d_, b.d_, nullptr, n_, P::queue()), "pointwise");
+    detail::check(ctx(), nflhip_pointwise_dev(ctx(), op, d_, a.d_, b.d_, nullptr, n_, queue()), "pointwise");
   }
   void assign_mul_shoup(const device_batch &a, const device_batch &b, const device_batch &bprime) {
     same_size(a); same_size(b); same_size(bprime);
-    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_MUL_SHOUP, d_, a.d_, b.d_, bprime.d_, n_, P::queue()),
+    detail::check(ctx(), nflhip_pointwise_dev(ctx(), NFLHIP_OP_MUL_SHOUP, d_, a.d_, b.d_, bprime.d_, n_, queue()),
                   "mulmod_shoup");
   }
   void assign_compute_shoup(const device_batch &b) {
     same_size(b);
-    detail::check(P::ctx(), nflhip_pointwise_dev(P::ctx(), NFLHIP_OP_COMPUTE_SHOUP, d_, b.d_, nullptr, nullptr, n_, P::queue()),
+    detail::check(ctx(), nflhip_pointwise_dev(ctx(), NFLHIP_OP_COMPUTE_SHOUP, d_, b.d_, nullptr, nullptr, n_, queue()),
                   "compute_shoup");
   }
   // *this = INTT(NTT(a) (.) NTT(b)), the fused metric path
   void assign_polymul(const device_batch &a, const device_batch &b) {
     same_size(a); same_size(b);
-    detail::check(P::ctx(), nflhip_polymul_dev(P::ctx(), d_, a.d_, b.d_, n_, P::queue()), "polymul");
+    detail::check(ctx(), nflhip_polymul_dev(ctx(), d_, a.d_, b.d_, n_, queue()), "polymul");
   }
   // the same with b already in NTT form (keys of the LWE demo stay transformed, tests/nfllib_demo_main_op.cpp:26-46)
   void assign_polymul_ntt(const device_batch &a, const device_batch &b_ntt) {
     same_size(a); same_size(b_ntt);
-    detail::check(P::ctx(), nflhip_polymul_ntt_dev(P::ctx(), d_, a.d_, b_ntt.d_, n_, P::queue()), "polymul_ntt");
+    detail::check(ctx(), nflhip_polymul_ntt_dev(ctx(), d_, a.d_, b_ntt.d_, n_, queue()), "polymul_ntt");
   }
   // CRT lift / project of the whole resident batch (gmp.hpp:183-219): out[(b*degree + i)*L .. +L) = little-endian limbs
   // of X_{b,i} in [0, Q), L = P::crt_limbs(); limbs2poly takes L_in limbs per coefficient
@@ -2087,77 +2207,270 @@ template <class P> class device_batch {
     const size_t words = n_ * P::degree * P::crt_limbs();
     out.assign(words, 0);
     void *dl = nullptr;
-    detail::check(P::ctx(), nflhip_malloc(P::ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
-    int rc = nflhip_crt_lift_dev(P::ctx(), static_cast<uint64_t *>(dl), d_, n_, P::queue());
-    if (rc == 0) rc = nflhip_memcpy_d2h(P::ctx(), out.data(), dl, words * sizeof(uint64_t), P::queue());
-    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), P::queue());
-    nflhip_free(P::ctx(), dl);
-    detail::check(P::ctx(), rc, "poly2mpz");
+    detail::check(ctx(), nflhip_malloc(ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
+    int rc = nflhip_crt_lift_dev(ctx(), static_cast<uint64_t *>(dl), d_, n_, queue());
+    if (rc == 0) rc = nflhip_memcpy_d2h(ctx(), out.data(), dl, words * sizeof(uint64_t), queue());
+    if (rc == 0) rc = nflhip_stream_sync(ctx(), queue());
+    nflhip_free(ctx(), dl);
+    detail::check(ctx(), rc, "poly2mpz");
   }
   void limbs2poly(const uint64_t *limbs, size_t L_in) {
     const size_t words = n_ * P::degree * L_in;
     void *dl = nullptr;
-    detail::check(P::ctx(), nflhip_malloc(P::ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
-    int rc = nflhip_memcpy_h2d(P::ctx(), dl, limbs, words * sizeof(uint64_t), P::queue());
-    if (rc == 0) rc = nflhip_crt_project_dev(P::ctx(), d_, static_cast<const uint64_t *>(dl), L_in, n_, P::queue());
-    if (rc == 0) rc = nflhip_stream_sync(P::ctx(), P::queue());
-    nflhip_free(P::ctx(), dl);
-    detail::check(P::ctx(), rc, "mpz2poly");
+    detail::check(ctx(), nflhip_malloc(ctx(), &dl, words * sizeof(uint64_t)), "device allocation");
+    int rc = nflhip_memcpy_h2d(ctx(), dl, limbs, words * sizeof(uint64_t), queue());
+    if (rc == 0) rc = nflhip_crt_project_dev(ctx(), d_, static_cast<const uint64_t *>(dl), L_in, n_, queue());
+    if (rc == 0) rc = nflhip_stream_sync(ctx(), queue());
+    nflhip_free(ctx(), dl);
+    detail::check(ctx(), rc, "mpz2poly");
   }
   // fused postfix expression over up to NFLHIP_EXPR_MAX_OPERANDS resident batches
   void assign_program(const unsigned char *program, size_t len, const device_batch *const *operands, size_t count) {
     const void *ptr[NFLHIP_EXPR_MAX_OPERANDS];
     if (count > NFLHIP_EXPR_MAX_OPERANDS) throw std::runtime_error("nfl(hip): too many operands");
     for (size_t i = 0; i < count; ++i) { same_size(*operands[i]); ptr[i] = operands[i]->d_; }
-    detail::check(P::ctx(), nflhip_eval_dev(P::ctx(), d_, ptr, count, program, len, n_, P::queue()), "eval");
+    detail::check(ctx(), nflhip_eval_dev(ctx(), d_, ptr, count, program, len, n_, queue()), "eval");
   }
-  // the random constructors over the whole resident batch (same tags as poly's; one keystream per call)
-  void set(uniform const &u) {
-    if (u.seeded) detail::check(P::ctx(), nflhip_fill_uniform_dev(P::ctx(), d_, 0, n_, u.seed, 0, P::queue()), "set(uniform)");
-    else sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+  // the random constructors over the whole resident batch (same tags as poly's; one keystream per call).
+  // `first_poly` / `stream_id` are for shards of one logical batch (sharded_batch): polynomial k of this batch is
+  // polynomial first_poly + k of the keystream, so that the shards of a batch equal the batch drawn on one device.
+  void set(uniform const &u, size_t first_poly = 0) {
+    if (u.seeded) detail::check(ctx(), nflhip_fill_uniform_dev(ctx(), d_, first_poly, n_, u.seed, 0, queue()), "set(uniform)");
+    else sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)", first_poly, detail::sampler::get().next++);
   }
-  void set(non_uniform const &m) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
-  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)"); }
-  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT | detail::dist_flags, m.hwt, 1, "set(hwt_dist)"); }
+  void set(non_uniform const &m) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)", 0, detail::sampler::get().next++); }
+  void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)", 0, detail::sampler::get().next++); }
+  void set(hwt_dist const &m) { sample(NFLHIP_DIST_HWT | detail::dist_flags, m.hwt, 1, "set(hwt_dist)", 0, detail::sampler::get().next++); }
   template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, value_type, _lu_depth> const &m) {
+    set_at(m, 0, detail::sampler::get().next++);
+  }
+  void set_at(uniform const &, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)", first_poly, stream_id); }
+  void set_at(non_uniform const &m, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)", first_poly, stream_id); }
+  void set_at(ZO_dist const &m, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)", first_poly, stream_id); }
+  void set_at(hwt_dist const &m, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_HWT | detail::dist_flags, m.hwt, 1, "set(hwt_dist)", first_poly, stream_id); }
+  template <class in_class, unsigned _lu_depth>
+  void set_at(gaussian<in_class, value_type, _lu_depth> const &m, size_t first_poly, uint64_t stream_id) {
     detail::sampler &s = detail::sampler::get();
-    detail::check(P::ctx(), nflhip_sample_gauss_dev(P::ctx(), d_, 0, n_, m.fg_prng->table(P::ctx()), m.amplifier, s.key,
-                                                    s.next++, P::queue()), "set(gaussian)");
+    detail::check(ctx(), nflhip_sample_gauss_dev(ctx(), d_, first_poly, n_, m.fg_prng->table(ctx()), m.amplifier, s.key,
+                                                 stream_id, queue()), "set(gaussian)");
   }
   // replicate one polynomial over the batch (a key shared by every ciphertext, ...)
   void fill(const P &one) {  // one upload + one broadcast kernel
-    void *tmp = P::acquire_device();
-    int rc = nflhip_memcpy_h2d(P::ctx(), tmp, one.cdata(), sizeof(P), P::queue());
-    if (rc == 0) rc = nflhip_broadcast_dev(P::ctx(), d_, tmp, n_, P::queue());
-    P::release_device(tmp);
-    detail::check(P::ctx(), rc, "fill");
+    void *tmp = nullptr;
+    detail::check(ctx(), nflhip_malloc(ctx(), &tmp, sizeof(P)), "device allocation");
+    int rc = nflhip_memcpy_h2d(ctx(), tmp, one.cdata(), sizeof(P), queue());
+    if (rc == 0) rc = nflhip_broadcast_dev(ctx(), d_, tmp, n_, queue());
+    if (rc == 0) rc = nflhip_stream_sync(ctx(), queue());
+    nflhip_free(ctx(), tmp);
+    detail::check(ctx(), rc, "fill");
   }
-  // the same from a resident handle: no host copy at all
+  // the same from a resident handle: no host copy at all (a peer-to-peer copy when the batch lives on another device)
   void fill(const poly_p<value_type, P::degree, P::nmoduli> &one) {
     typedef detail::payload<P> payload_type;
     const void *src = static_cast<payload_type *>(one.payload_id())->dev_ro();
-    detail::check(P::ctx(), nflhip_broadcast_dev(P::ctx(), d_, src, n_, P::queue()), "fill");
+    if (ctx() == P::ctx()) {
+      detail::check(ctx(), nflhip_broadcast_dev(ctx(), d_, src, n_, queue()), "fill");
+      return;
+    }
+    detail::check(P::ctx(), nflhip_stream_sync(P::ctx(), P::queue()), "fill");  // the handle's pending writes
+    void *tmp = nullptr;
+    detail::check(ctx(), nflhip_malloc(ctx(), &tmp, sizeof(P)), "device allocation");
+    int rc = nflhip_memcpy_peer_dev(ctx(), tmp, P::ctx(), src, sizeof(P), queue());
+    if (rc == 0) rc = nflhip_broadcast_dev(ctx(), d_, tmp, n_, queue());
+    if (rc == 0) rc = nflhip_stream_sync(ctx(), queue());
+    nflhip_free(ctx(), tmp);
+    detail::check(ctx(), rc, "fill");
   }
   bool any_equal(const device_batch &o) const { return cmp(o, true); }    // the reference's `a == b`
   bool any_differs(const device_batch &o) const { return cmp(o, false); } // the reference's `a != b`
+  // 64-bit digest that composes over shards (nflhip_digest_dev): the digests of the shards of a batch add up to the
+  // digest of the batch
+  uint64_t digest(size_t first_poly = 0) const {
+    uint64_t h = 0;
+    detail::check(ctx(), nflhip_digest_dev(ctx(), d_, first_poly, n_, &h, queue()), "digest");
+    return h;
+  }
 
  private:
   void same_size(const device_batch &o) const {
     if (o.n_ != n_) throw std::runtime_error("nfl(hip): batch size mismatch");
+    if (o.c_ != c_) throw std::runtime_error("nfl(hip): the batches of one operation must live on one device");
   }
-  void sample(int dist, uint64_t p0, uint64_t p1, const char *what) {
+  void sample(int dist, uint64_t p0, uint64_t p1, const char *what, size_t first_poly, uint64_t stream_id) {
     detail::sampler &s = detail::sampler::get();
-    detail::check(P::ctx(), nflhip_sample_dev(P::ctx(), d_, 0, n_, dist, p0, p1, s.key, s.next++, P::queue()), what);
+    detail::check(ctx(), nflhip_sample_dev(ctx(), d_, first_poly, n_, dist, p0, p1, s.key, stream_id, queue()), what);
   }
   bool cmp(const device_batch &o, bool want_eq) const {
     same_size(o);
     int r = 0;
-    detail::check(P::ctx(), want_eq ? nflhip_any_eq_dev(P::ctx(), d_, o.d_, n_, &r, P::queue())
-                                    : nflhip_any_neq_dev(P::ctx(), d_, o.d_, n_, &r, P::queue()), "compare");
+    detail::check(ctx(), want_eq ? nflhip_any_eq_dev(ctx(), d_, o.d_, n_, &r, queue())
+                                 : nflhip_any_neq_dev(ctx(), d_, o.d_, n_, &r, queue()), "compare");
     return r != 0;
   }
   size_t n_;
   void *d_;
+  context_type *c_;
+};
+
+// ---------------------------------------------------------------- batches split over the GPUs of one node
+// The reference's callers hold dense arrays of independent polynomials (tests/tools.h:6-17) and loop over them; nothing
+// in a loop iteration depends on another (core.hpp:597-599, 610-612, 31-35).  sharded_batch<P> cuts such an array into
+// CONTIGUOUS shards, one per GPU (device r of n owns polynomials [first(r), first(r) + count(r)), nflhip_shard_range),
+// from ONE process: one context and one stream per device, every operation fans out as one asynchronous call per shard
+// (the host thread only enqueues), and there is no data-path collective -- operands are generated in place (the random
+// constructors offset their keystream by the shard's first polynomial, so the shards of a batch equal the batch drawn
+// on one device), uploaded shard by shard, or scattered once from a batch that lives on one device (peer-to-peer copies,
+// one per link).  digest() is the checksum of checksums: the shard digests add up to the digest of the whole batch.
+template <class P> class sharded_batch {
+ public:
+  typedef typename P::value_type value_type;
+  typedef device_batch<P> shard_type;
+  // all GPUs of the node
+  explicit sharded_batch(size_t count) : sharded_batch(count, all_devices()) {}
+  sharded_batch(size_t count, std::vector<int> const &devices) : n_(count) {
+    if (devices.empty()) throw std::runtime_error("nfl(hip): sharded_batch needs at least one device");
+    const int nd = int(devices.size());
+    for (int r = 0; r < nd; ++r) {
+      size_t f = 0, c = 0;
+      detail::check(nullptr, nflhip_shard_range(count, nd, r, &f, &c), "shard_range");
+      first_.push_back(f);
+      shards_.emplace_back(c, devices[size_t(r)]);
+    }
+  }
+  static std::vector<int> all_devices() {
+    std::vector<int> d;
+    for (int i = 0, n = device_count(); i < n; ++i) d.push_back(i);
+    return d;
+  }
+  size_t size() const { return n_; }
+  size_t shards() const { return shards_.size(); }
+  shard_type &shard(size_t r) { return shards_[r]; }
+  const shard_type &shard(size_t r) const { return shards_[r]; }
+  size_t first(size_t r) const { return first_[r]; }
+  size_t count(size_t r) const { return shards_[r].size(); }
+
+  // host array <-> shards: every device moves its own slice (n independent PCIe streams), then one wait for all
+  void upload(const P *host) {
+    for (size_t r = 0; r < shards(); ++r)
+      if (count(r)) detail::check(shards_[r].ctx(), nflhip_memcpy_h2d(shards_[r].ctx(), shards_[r].data(), host[first_[r]].cdata(),
+                                                                       shards_[r].bytes(), shards_[r].queue()), "upload");
+    sync();
+  }
+  void download(P *host) const {
+    for (size_t r = 0; r < shards(); ++r)
+      if (count(r)) detail::check(shards_[r].ctx(), nflhip_memcpy_d2h(shards_[r].ctx(), host[first_[r]].data(), shards_[r].data(),
+                                                                       shards_[r].bytes(), shards_[r].queue()), "download");
+    sync();
+  }
+  // a batch resident on ONE device <-> shards: peer-to-peer copies, each on the receiving / sending peer's stream
+  void scatter(const shard_type &full) { move(const_cast<shard_type &>(full), true); }
+  void gather(shard_type &full) const { const_cast<sharded_batch *>(this)->move(full, false); }
+
+  void sync() const { for (auto &s : shards_) s.sync(); }
+
+  // the batch operations of device_batch, one asynchronous call per shard
+  void ntt_pow_phi() { for (auto &s : shards_) if (s.size()) s.ntt_pow_phi(); }
+  void invntt_pow_invphi() { for (auto &s : shards_) if (s.size()) s.invntt_pow_invphi(); }
+  void assign(int op, const sharded_batch &a, const sharded_batch &b) {
+    same_split(a); same_split(b);
+    for (size_t r = 0; r < shards(); ++r) if (count(r)) shards_[r].assign(op, a.shards_[r], b.shards_[r]);
+  }
+  void assign_mul_shoup(const sharded_batch &a, const sharded_batch &b, const sharded_batch &bprime) {
+    same_split(a); same_split(b); same_split(bprime);
+    for (size_t r = 0; r < shards(); ++r) if (count(r)) shards_[r].assign_mul_shoup(a.shards_[r], b.shards_[r], bprime.shards_[r]);
+  }
+  void assign_compute_shoup(const sharded_batch &b) {
+    same_split(b);
+    for (size_t r = 0; r < shards(); ++r) if (count(r)) shards_[r].assign_compute_shoup(b.shards_[r]);
+  }
+  void assign_polymul(const sharded_batch &a, const sharded_batch &b) {
+    same_split(a); same_split(b);
+    for (size_t r = 0; r < shards(); ++r) if (count(r)) shards_[r].assign_polymul(a.shards_[r], b.shards_[r]);
+  }
+  void assign_polymul_ntt(const sharded_batch &a, const sharded_batch &b_ntt) {
+    same_split(a); same_split(b_ntt);
+    for (size_t r = 0; r < shards(); ++r) if (count(r)) shards_[r].assign_polymul_ntt(a.shards_[r], b_ntt.shards_[r]);
+  }
+  void assign_program(const unsigned char *program, size_t len, const sharded_batch *const *operands, size_t nops) {
+    if (nops > NFLHIP_EXPR_MAX_OPERANDS) throw std::runtime_error("nfl(hip): too many operands");
+    for (size_t i = 0; i < nops; ++i) same_split(*operands[i]);
+    for (size_t r = 0; r < shards(); ++r) {
+      if (!count(r)) continue;
+      const shard_type *ops[NFLHIP_EXPR_MAX_OPERANDS];
+      for (size_t i = 0; i < nops; ++i) ops[i] = &operands[i]->shards_[r];
+      shards_[r].assign_program(program, len, ops, nops);
+    }
+  }
+  // in-place generation: ONE keystream for the logical batch, every shard reads its own positions of it
+  void set(uniform const &u) {
+    const uint64_t sid = u.seeded ? 0 : detail::sampler::get().next++;
+    for (size_t r = 0; r < shards(); ++r) {
+      if (!count(r)) continue;
+      if (u.seeded) shards_[r].set(u, first_[r]);
+      else shards_[r].set_at(u, first_[r], sid);
+    }
+  }
+  void set(non_uniform const &m) { set_shards(m); }
+  void set(ZO_dist const &m) { set_shards(m); }
+  void set(hwt_dist const &m) { set_shards(m); }
+  template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, value_type, _lu_depth> const &m) { set_shards(m); }
+  // one polynomial replicated over every shard
+  void fill(const P &one) { for (auto &s : shards_) if (s.size()) s.fill(one); }
+
+  // the reference's `==` / `!=` over the whole array ("any lane", ops.hpp:81-117): any shard
+  bool any_equal(const sharded_batch &o) const {
+    same_split(o);
+    bool r = false;
+    for (size_t k = 0; k < shards(); ++k) if (count(k)) r = shards_[k].any_equal(o.shards_[k]) || r;
+    return r;
+  }
+  bool any_differs(const sharded_batch &o) const {
+    same_split(o);
+    bool r = false;
+    for (size_t k = 0; k < shards(); ++k) if (count(k)) r = shards_[k].any_differs(o.shards_[k]) || r;
+    return r;
+  }
+  // per-shard digests (positions counted in the WHOLE batch) and their sum = the digest of the batch on one device
+  std::vector<uint64_t> digests() const {
+    std::vector<uint64_t> d(shards());
+    for (size_t r = 0; r < shards(); ++r) d[r] = count(r) ? shards_[r].digest(first_[r]) : 0;
+    return d;
+  }
+  uint64_t digest() const {
+    uint64_t s = 0;
+    for (uint64_t d : digests()) s += d;
+    return s;
+  }
+
+ private:
+  template <class D> void set_shards(D const &m) {
+    const uint64_t sid = detail::sampler::get().next++;
+    for (size_t r = 0; r < shards(); ++r) if (count(r)) shards_[r].set_at(m, first_[r], sid);
+  }
+  void same_split(const sharded_batch &o) const {
+    if (o.n_ != n_ || o.shards() != shards()) throw std::runtime_error("nfl(hip): batch size mismatch");
+    for (size_t r = 0; r < shards(); ++r)
+      if (o.shards_[r].ctx() != shards_[r].ctx()) throw std::runtime_error("nfl(hip): the batches of one operation must be split over the same devices");
+  }
+  void move(shard_type &full, bool to_shards) {
+    if (full.size() != n_) throw std::runtime_error("nfl(hip): batch size mismatch");
+    std::vector<nflhip_ctx *> ctxs;
+    std::vector<void *> ptrs, streams;
+    int root = -1;
+    for (size_t r = 0; r < shards(); ++r) {
+      ctxs.push_back(shards_[r].ctx());
+      ptrs.push_back(shards_[r].data());
+      streams.push_back(shards_[r].queue());
+      if (shards_[r].ctx() == full.ctx()) root = int(r);
+    }
+    if (root < 0) throw std::runtime_error("nfl(hip): the whole batch must live on one of the shards' devices");
+    const int rc = to_shards ? nflhip_scatter_local_dev(ctxs.data(), int(ctxs.size()), ptrs.data(), root, full.data(), n_, streams.data())
+                             : nflhip_gather_local_dev(ctxs.data(), int(ctxs.size()), full.data(), root, ptrs.data(), n_, streams.data());
+    detail::check(full.ctx(), rc, to_shards ? "scatter" : "gather");
+  }
+  size_t n_;
+  std::vector<size_t> first_;
+  std::vector<shard_type> shards_;
 };
 
 }  // namespace nfl

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NFLHIP_ABI_VERSION 2
+#define NFLHIP_ABI_VERSION 3
 
 typedef struct nflhip_ctx nflhip_ctx;
 
@@ -310,6 +310,59 @@ int nflhip_stream_create(nflhip_ctx *ctx, void **stream);
 int nflhip_stream_destroy(nflhip_ctx *ctx, void *stream);
 /* d_dst[k] = *d_one for k < count: one polynomial replicated over a resident batch (one kernel, no host copies) */
 int nflhip_broadcast_dev(nflhip_ctx *ctx, void *d_dst, const void *d_one, size_t count, void *stream);
+
+/* ---- multi-GPU: the batch split --------------------------------------------------------
+ * The reference has no distributed layer; its callers hold dense arrays of independent polynomials
+ * (tests/tools.h:6-17: alloc_aligned<poly_t, 32>(N)) and loop over them (tests/nfl_mul_main.cpp, nfllib_demo_main_op.cpp).
+ * Across the GPUs of one node that array is cut into contiguous shards: device r of n owns polynomials
+ * [first, first + count) of `total` as nflhip_shard_range says, every device builds identical tables locally (one
+ * context per device: nflhip_ctx_create's `device` argument) and there is NO data-path collective: operands are generated
+ * in place (the `first_poly` argument of nflhip_fill_uniform_dev / nflhip_sample*_dev) or scattered once.  Two ways to
+ * drive it:
+ *   ONE PROCESS, n devices  -- n contexts, one stream each; nflhip_scatter_local_dev / nflhip_gather_local_dev move
+ *                              shards with peer-to-peer copies (hipMemcpyPeerAsync), one per peer, each on that peer's
+ *                              stream so that every xGMI link is busy at once;
+ *   ONE PROCESS PER DEVICE  -- an nflhip_comm on RCCL: nflhip_scatter_dev / nflhip_gather_dev are grouped
+ *                              ncclSend / ncclRecv of contiguous shards (one message per peer and group, <= 1 GiB each).
+ * RCCL is bound at run time (librccl.so.1 is opened by the first nflhip_comm_* call), so single-GPU callers do not
+ * depend on it. */
+int nflhip_ctx_device(const nflhip_ctx *ctx);
+/* contiguous, balanced split: the first (total mod nranks) ranks own one polynomial more */
+int nflhip_shard_range(size_t total, int nranks, int rank, size_t *first, size_t *count);
+/* 64-bit digest of `batch` resident polynomials that COMPOSES over shards: sum over words of
+ * (g + 1) * mix(word) mod 2^64, g = the word's index in the whole logical batch (first_poly offsets it), so the sum of
+ * the shards' digests equals the digest of the whole batch ("checksum of checksums").  Synchronises `stream`. */
+int nflhip_digest_dev(nflhip_ctx *ctx, const void *d_data, size_t first_poly, size_t batch, uint64_t *h_digest,
+                      void *stream);
+/* copy between the devices of two contexts of this process, asynchronous on `stream` (a stream of dst_ctx's device) */
+int nflhip_memcpy_peer_dev(nflhip_ctx *dst_ctx, void *d_dst, nflhip_ctx *src_ctx, const void *d_src, size_t bytes,
+                           void *stream);
+/* ONE PROCESS: ctxs[r] / d_shards[r] / streams[r] belong to device r of n (same shape everywhere); d_full holds `total`
+ * polynomials on ctxs[root]'s device.  scatter: shard r <- full[first_r, first_r + count_r); gather: the inverse.
+ * Each peer's copy runs on that peer's stream after everything enqueued so far on the root's stream (scatter) / on the
+ * peer's stream (gather), and the root's stream waits for all of them: no host synchronisation. */
+int nflhip_scatter_local_dev(nflhip_ctx *const *ctxs, int n, void *const *d_shards, int root, const void *d_full,
+                             size_t total, void *const *streams);
+int nflhip_gather_local_dev(nflhip_ctx *const *ctxs, int n, void *d_full, int root, const void *const *d_shards,
+                            size_t total, void *const *streams);
+/* ONE PROCESS PER DEVICE: a communicator over RCCL (ncclCommInitRank).  Rank 0 draws the id (ncclGetUniqueId) and hands
+ * it to the other ranks out of band (a file, MPI, torch.distributed's store ...).  nranks = 1 is legal (and what a
+ * single-GPU box can run). */
+typedef struct nflhip_comm nflhip_comm;
+#define NFLHIP_COMM_ID_BYTES 128
+int nflhip_comm_unique_id(unsigned char id[NFLHIP_COMM_ID_BYTES]);
+int nflhip_comm_create(nflhip_comm **out, nflhip_ctx *ctx, int nranks, int rank, const unsigned char id[NFLHIP_COMM_ID_BYTES]);
+int nflhip_comm_destroy(nflhip_comm *comm);
+int nflhip_comm_rank(const nflhip_comm *comm);
+int nflhip_comm_size(const nflhip_comm *comm);
+/* scatter: rank `root` holds d_full (`total` polynomials, ignored elsewhere); every rank receives its shard_range slice
+ * in d_shard.  gather: the inverse.  Asynchronous on `stream`; every rank must call with the same total and root. */
+int nflhip_scatter_dev(nflhip_comm *comm, void *d_shard, const void *d_full, size_t total, int root, void *stream);
+int nflhip_gather_dev(nflhip_comm *comm, void *d_full, const void *d_shard, size_t total, int root, void *stream);
+/* control plane: a barrier (one-word all-reduce) and an all-gather of one 64-bit word per rank (shard digests, clocks).
+ * Both synchronise `stream`. */
+int nflhip_comm_barrier(nflhip_comm *comm, void *stream);
+int nflhip_comm_allgather_u64(nflhip_comm *comm, uint64_t mine, uint64_t *h_all, void *stream);
 
 /* ---- in-library timing of the metric kernel (HIP events on `stream`) -----------
  * Runs `iters` back-to-back polymul passes over the batch and returns the mean

@@ -16,7 +16,7 @@ TAB_PSI, TAB_MODULUS, TAB_INVDEGREE = range(3)
 TAB_PHIS, TAB_SHOUPPHIS, TAB_INVPOLY_INVPHIS, TAB_SHOUPINVPOLY_INVPHIS, TAB_OMEGAS, TAB_INVOMEGAS = range(3, 9)
 ROW_INVERSE_TABLES, ROW_BITREV_IO = 1, 2
 DIST_REFERENCE_WORDS = 0x100
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/nflhip.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
@@ -83,7 +83,24 @@ SYMBOLS = [
     ("nflhip_broadcast_dev", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("nflhip_random_bytes", _i, [_i, _vp, _sz, _vp, _u64]),
     ("nflhip_time_polymul_dev", _i, [_vp, _vp, _vp, _vp, _sz, _i, _vp, C.POINTER(C.c_float)]),
+    # multi-GPU: the batch split
+    ("nflhip_ctx_device", _i, [_vp]),
+    ("nflhip_shard_range", _i, [_sz, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("nflhip_digest_dev", _i, [_vp, _vp, _sz, _sz, C.POINTER(_u64), _vp]),
+    ("nflhip_memcpy_peer_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_scatter_local_dev", _i, [_vp, _i, _vp, _i, _vp, _sz, _vp]),
+    ("nflhip_gather_local_dev", _i, [_vp, _i, _vp, _i, _vp, _sz, _vp]),
+    ("nflhip_comm_unique_id", _i, [_vp]),
+    ("nflhip_comm_create", _i, [C.POINTER(_vp), _vp, _i, _i, _vp]),
+    ("nflhip_comm_destroy", _i, [_vp]),
+    ("nflhip_comm_rank", _i, [_vp]),
+    ("nflhip_comm_size", _i, [_vp]),
+    ("nflhip_scatter_dev", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    ("nflhip_gather_dev", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    ("nflhip_comm_barrier", _i, [_vp, _vp]),
+    ("nflhip_comm_allgather_u64", _i, [_vp, _u64, C.POINTER(_u64), _vp]),
 ]
+COMM_ID_BYTES = 128
 
 
 class NflHipError(RuntimeError):

@@ -64,6 +64,13 @@ struct nflhip_ctx {
   std::vector<nflhip_ctx *> row_ctx;  // [2 * cm + inverse_tables]
 };
 
+namespace nflhip {
+int set_error(int code, const std::string &msg) {  // for the library's other translation units (comm.hip)
+  g_last_error = msg;
+  return code;
+}
+}  // namespace nflhip
+
 static int fail(const nflhip_ctx *ctx, int code, const std::string &msg) {
   (void)ctx;
   g_last_error = msg;
@@ -663,6 +670,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   return NFLHIP_OK;
 }
 
+int nflhip_ctx_device(const nflhip_ctx *ctx) { return ctx ? ctx->device : -1; }
 size_t nflhip_degree(const nflhip_ctx *ctx) { return ctx ? ctx->shape.n : 0; }
 size_t nflhip_nmoduli(const nflhip_ctx *ctx) { return ctx ? ctx->shape.nm : 0; }
 int nflhip_limb_bits(const nflhip_ctx *ctx) { return ctx ? ctx->shape.limb_bits : 0; }

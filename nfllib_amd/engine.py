@@ -149,6 +149,12 @@ class Engine:
     def eval_strided(self, program, operands, strides, out, out_stride=1, batch=None, stream=None):
         """nflhip_eval_strided_dev: element i reads operand j at operands[j] + i*strides[j] polynomials (0 = one shared
         polynomial) and writes out + i*out_stride polynomials"""
+        if len(strides) != len(operands):
+            raise ValueError("one stride per operand")
+        if not out.is_contiguous() or not all(o.is_contiguous() for o in operands):
+            raise ValueError("operands and result must be contiguous tensors")
+        if batch is None:   # the elements the result buffer holds at this stride
+            batch = (self._batch(out) + out_stride - 1) // out_stride
         ptrs = (C.c_void_p * len(operands))(*[o.data_ptr() for o in operands])
         sd = (C.c_size_t * len(operands))(*strides)
         prog = (C.c_ubyte * len(program))(*program)
@@ -285,6 +291,13 @@ class Engine:
         self._chk(self.lib.nflhip_crt_project_dev(self.ctx, _vp(out), _vp(limbs), L, batch, self._stream(stream)))
         return out
 
+    # ---- the batch split (include/nflhip.h "multi-GPU") ----
+    def digest(self, d, first_poly=0, stream=None):
+        """shard-composable 64-bit digest of a resident batch (sharding.digest_words is its numpy statement)"""
+        out = C.c_uint64(0)
+        self._chk(self.lib.nflhip_digest_dev(self.ctx, _vp(d), first_poly, self._batch(d), C.byref(out), self._stream(stream)))
+        return int(out.value)
+
     def time_polymul(self, c, a, b, iters, stream=None):
         ms = C.c_float(0)
         self._chk(self.lib.nflhip_time_polymul_dev(self.ctx, _vp(c), _vp(a), _vp(b), self._batch(a), iters,
@@ -352,6 +365,62 @@ class Engine:
         n = C.c_size_t(0)
         self._chk(self.lib.nflhip_get_crt_constant(self.ctx, what, cm, _vp(buf), buf.size, C.byref(n)))
         return int.from_bytes(buf[:n.value].tobytes(), "little")
+
+
+def shard_range(total, nranks, rank):
+    """(first, count) of rank's contiguous shard: nflhip_shard_range (no device needed)"""
+    f, c = C.c_size_t(0), C.c_size_t(0)
+    rc = _lib.lib.nflhip_shard_range(total, nranks, rank, C.byref(f), C.byref(c))
+    if rc != 0:
+        raise NflHipError(rc, _lib.lib.nflhip_last_error(None).decode())
+    return int(f.value), int(c.value)
+
+
+class Comm:
+    """One process per GPU: the RCCL communicator of include/nflhip.h (nflhip_comm_*).  Rank 0 draws `Comm.unique_id()`
+    and hands the 128 bytes to the other ranks out of band (bench.py: torch.distributed's broadcast)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        rc = _lib.lib.nflhip_comm_unique_id(buf)
+        if rc != 0:
+            raise NflHipError(rc, _lib.lib.nflhip_last_error(None).decode())
+        return bytes(buf)
+
+    def __init__(self, engine, nranks, rank, unique_id):
+        self.eng, self.lib = engine, _lib.lib
+        h = C.c_void_p()
+        idb = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        rc = self.lib.nflhip_comm_create(C.byref(h), engine.ctx, nranks, rank, idb)
+        if rc != 0:
+            raise NflHipError(rc, self.lib.nflhip_last_error(None).decode())
+        self.h, self.nranks, self.rank = h, nranks, rank
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nflhip_comm_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NflHipError(rc, self.lib.nflhip_last_error(None).decode())
+
+    def scatter(self, shard, full, total, root=0, stream=None):
+        self._chk(self.lib.nflhip_scatter_dev(self.h, _vp(shard), _vp(full), total, root, self.eng._stream(stream)))
+        return shard
+
+    def gather(self, full, shard, total, root=0, stream=None):
+        self._chk(self.lib.nflhip_gather_dev(self.h, _vp(full), _vp(shard), total, root, self.eng._stream(stream)))
+        return full
+
+    def barrier(self, stream=None):
+        self._chk(self.lib.nflhip_comm_barrier(self.h, self.eng._stream(stream)))
+
+    def allgather_u64(self, value, stream=None):
+        out = (C.c_uint64 * self.nranks)()
+        self._chk(self.lib.nflhip_comm_allgather_u64(self.h, value & ((1 << 64) - 1), out, self.eng._stream(stream)))
+        return [int(v) for v in out]
 
 
 def gauss_table(sigma, security=128, samples=1024, center=0.0):

@@ -27,7 +27,7 @@ def mock():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "cpp", "mock", "make_mock_backend.py"), c],
                           stdout=subprocess.DEVNULL)
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o",
-                           os.path.join(MOCK, "libnflhip.so"), c])
+                           os.path.join(MOCK, "libnflhip.so"), c, "-lpthread"])
     for name in ("deferred_fuzz", "deferred_loops"):
         build_program(name + ".cpp", os.path.join(MOCK, name))
     return MOCK
@@ -112,3 +112,17 @@ def test_threads_with_their_own_handles_share_the_queue_safely(mock, tmp_path):
         r = run(exe, 6, 400, env={"NFL_HIP_QUEUE_LIMIT": "37", "TSAN_OPTIONS": "halt_on_error=0"})
         assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
         assert "ThreadSanitizer" not in r.stderr, r.stderr[:4000]
+
+
+def test_generators_that_die_early_key_changes_and_failing_launches(mock, tmp_path):
+    """tests/cpp/deferred_edges.cpp under ASan + UBSan: a FastGaussianNoise destroyed before the polynomials built from it
+    are used (its device table must outlive the recorded draws), nfl::set_sampler_key between a random constructor and the
+    queue run (deferred == immediate), and a launch that fails in the middle of a queue run (injected by the CPU stand-in):
+    what ran keeps its value, what never ran throws on access, an overwritten handle is usable again"""
+    exe = str(tmp_path / "edges_asan")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "deferred_edges.cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+    for limit in (None, "64"):
+        r = run(exe, env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", **({"NFL_HIP_QUEUE_LIMIT": limit} if limit else {})})
+        assert r.returncode == 0 and "with failure injection" in r.stdout and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

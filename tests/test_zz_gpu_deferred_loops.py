@@ -31,3 +31,12 @@ def test_threads_with_their_own_handles_on_the_gpu():
     r = subprocess.run([os.path.join(CPP, "deferred_threads"), "4", "200"], capture_output=True, text=True, timeout=1800, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_generators_that_die_early_and_key_changes_on_the_gpu():
+    """tests/cpp/deferred_edges.cpp against the real library: a FastGaussianNoise that dies before its polynomials are
+    used, set_sampler_key between a constructor and the queue run -- deferred == immediate"""
+    subprocess.check_call(["make", "-s", "-C", CPP, "deferred_edges"])
+    r = subprocess.run([os.path.join(CPP, "deferred_edges")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
