@@ -346,7 +346,7 @@ int nflhip_scatter_local_dev(nflhip_ctx *const *ctxs, int n, void *const *d_shar
 int nflhip_gather_local_dev(nflhip_ctx *const *ctxs, int n, void *d_full, int root, const void *const *d_shards,
                             size_t total, void *const *streams);
 /* ONE PROCESS PER DEVICE: a communicator over RCCL (ncclCommInitRank).  Rank 0 draws the id (ncclGetUniqueId) and hands
- * it to the other ranks out of band (a file, MPI, torch.distributed's store ...).  nranks = 1 is legal (and what a
+ * it to the other ranks out of band (a file, MPI, a key-value store ...).  nranks = 1 is legal (and what a
  * single-GPU box can run). */
 typedef struct nflhip_comm nflhip_comm;
 #define NFLHIP_COMM_ID_BYTES 128
