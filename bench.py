@@ -135,7 +135,7 @@ def measure_traffic(workload, batch):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
     steps, warmup = 3, 1
-    products = steps + warmup + 1            # + the commutativity self-check product
+    products = steps + warmup + 2            # + the commutativity self-check product + the neighbour's shard (checksum of checksums)
     tot = {}
     for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         d = tempfile.mkdtemp(prefix="nflhip_pmc_", dir="/tmp")
@@ -178,6 +178,12 @@ def main():
                     help="N > 1 only: also time one step whose operands start on rank 0 and whose product returns there "
                          "(grouped RCCL send/recv of contiguous shards, SURVEY.md 8(e)); reported beside `value`, never in it")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the result: libraries that print banners there (RCCL announces its version on
+    # communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -485,7 +491,8 @@ def main():
         result["invalid_value"] = result["value"]
         result["value"] = None
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if comm is not None:
         comm.close()
     if use_dist:

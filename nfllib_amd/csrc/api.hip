@@ -435,6 +435,27 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   const size_t bytes = poly_bytes(ctx, batch);
   lk.lock();
   const bool cap = is_capturing(st);
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 15 && row32k_on()) {
+    // rows of 32768 words: b' = NTT(b) into the scratch (one read, one write), then c = INTT(NTT(a) (.) b') with the row
+    // of a register-resident and b' streamed through the point-wise step (two reads, one write): 5 operand passes
+    int rcs = ensure_scratch(ctx, bytes);
+    if (rcs) return rcs;
+    if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+    if (!cap && ctx->ev_prev_valid)
+      for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
+    e = launch_row32k_u64(ctx->shape, ctx->tabs, 2, (uint64_t *)ctx->scratch, (const uint64_t *)b, nullptr, batch, st);
+    if (e == hipSuccess)
+      e = launch_row32k_u64(ctx->shape, ctx->tabs, 1, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)ctx->scratch, batch, st);
+    if (e == hipSuccess) {
+      if (!cap) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
+        ctx->ev_scratch_valid = true;
+        for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_scratch, 0));
+      }
+      return NFLHIP_OK;
+    }
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul: 32768-word row kernels");
+  }
   if (sizeof(T) == 8 && !b_is_ntt && xcd_on(ctx, batch)) {
     // rows of 65536 / 32768 words: ONE launch of persistent workgroups, every row's three roles on one XCD and the
     // intermediates through that XCD's L2 (kernels_fast.hip launch_polymul_xcd_u64); needs only a ring of row slots

@@ -144,6 +144,11 @@ hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uin
 hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                             const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt = false);
 int row16k_level();
+// 32768-word rows, ONE operand register-resident per 1024-thread workgroup: mode 1: c = INTT(NTT(a) (.) b) with b already
+// transformed (streamed through the point-wise step), 2: c = NTT(a), 3: c = INTT(a); hipErrorNotSupported for other shapes
+int row32k_on();
+hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a, const uint64_t *b,
+                             size_t batch, hipStream_t st);
 // n = 65536: one launch of the three-role pipeline kernel (block products of chunk j-1, forward streaming pass of
 // chunk j, inverse streaming pass of chunk j-2); hipErrorNotSupported for other shapes
 // one launch for the whole batch, rows pinned to an XCD (n = 65536 / 32768); xcd_plan_bytes() = 0 when the shape / batch

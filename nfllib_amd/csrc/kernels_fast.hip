@@ -358,9 +358,11 @@ enum AsmKind {
   kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
   kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow128U16, kAsmRowFwd128U16, kAsmRowInv128U16, kAsmRow8U32,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
   kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
+  kAsmFwd32k, kAsmInv32k, kAsmPolymulNtt32k,                         // 32768-word rows: ONE operand register-resident, 1024 threads
   kAsmCount
 };
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
+static inline bool is32k(AsmKind k) { return k >= kAsmFwd32k && k <= kAsmPolymulNtt32k; }
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
 static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "nflhip_polymul_ntt4096_asm",
                                                  "nflhip_ntt_fwd4096_asm",     "nflhip_ntt_inv4096_asm",
@@ -376,7 +378,8 @@ static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "
                                                  "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
                                                  "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row128_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm", "nflhip_row8_u32_asm",
                                                  "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
-                                                 "nflhip_ntt_inv4096x2nt_asm"};
+                                                 "nflhip_ntt_inv4096x2nt_asm", "nflhip_ntt_fwd32768_asm",
+                                                 "nflhip_ntt_inv32768_asm",    "nflhip_polymul_ntt32768_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -422,11 +425,11 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   // one 256-thread workgroup per 4096-word block, or one 1024-thread workgroup per 16384-word block
-  const int blog = is16k(kind) ? kLogN + 2 : (is8k(kind) ? kLogN + 1 : kLogN);  // (kAsmPolymulNt: 4096-word blocks)
+  const int blog = is32k(kind) ? kLogN + 3 : is16k(kind) ? kLogN + 2 : (is8k(kind) ? kLogN + 1 : kLogN);  // (kAsmPolymulNt: 4096-word blocks)
   if (s.logn < blog) return hipErrorNotSupported;
   const size_t gx = batch << (s.logn - blog);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
-  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, is16k(kind) ? 1024 : (is8k(kind) ? 512 : kThreads), 1, 1, 0, st,
+  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, is16k(kind) || is32k(kind) ? 1024 : (is8k(kind) ? 512 : kThreads), 1, 1, 0, st,
                                nullptr, extra);
 }
 
@@ -686,6 +689,19 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
 
 static inline bool row16k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 2 && row16k_level() >= 1; }
 static inline bool row8k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 1 && row16k_level() >= 1; }
+// 32768-word rows: one operand register-resident in a 1024-thread workgroup (tools/gen_polymul_asm.py build_row32k).
+// NFLHIP_ROW32K=0: the three-role / one-launch plans of round 2 instead (A/B switch)
+int row32k_on() {
+  static const int v = getenv("NFLHIP_ROW32K") ? atoi(getenv("NFLHIP_ROW32K")) : 1;
+  return v;
+}
+static inline bool row32k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 3 && row32k_on(); }
+hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a, const uint64_t *b,
+                             size_t batch, hipStream_t st) {
+  if (!row32k_shape(s)) return hipErrorNotSupported;
+  if (batch == 0) return hipSuccess;
+  return launch_asm(mode == 1 ? kAsmPolymulNtt32k : (mode == 2 ? kAsmFwd32k : kAsmInv32k), s, t, c, a, b, batch, st);
+}
 
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                    int b_is_ntt, size_t batch, hipStream_t st) {
@@ -693,6 +709,7 @@ hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t 
     return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt16k : kAsmPolymul16k, s, t, c, a, b, batch, st);
   if (row8k_shape(s))   // 8192-word rows: 512 threads, two rows per CU
     return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt8k : kAsmPolymul8k, s, t, c, a, b, batch, st);
+  if (row32k_shape(s) && b_is_ntt) return launch_row32k_u64(s, t, 1, c, a, b, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
@@ -756,6 +773,7 @@ hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uin
                                    hipStream_t st) {
   if (row16k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmFwd16k, s, t, dst, src, nullptr, batch, st);
   if (row8k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmFwd8k, s, t, dst, src, nullptr, batch, st);
+  if (row32k_shape(s)) return launch_row32k_u64(s, t, 2, dst, src, nullptr, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   return launch_inner_fwd_fast_u64(s, t, src, dst, batch * s.nm, st);
 }
@@ -764,6 +782,7 @@ hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uin
                                    hipStream_t st) {
   if (row16k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmInv16k, s, t, dst, src, nullptr, batch, st);
   if (row8k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmInv8k, s, t, dst, src, nullptr, batch, st);
+  if (row32k_shape(s)) return launch_row32k_u64(s, t, 3, dst, src, nullptr, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   return launch_inner_inv_fast_u64(s, t, src, nullptr, dst, batch * s.nm, st);
 }

@@ -1047,7 +1047,7 @@ def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magi
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None):
+def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16):
     """the 64-bit block kernels of tools/gen_polymul_asm.py (kernarg: dst, a, b, psi, mc, nm, logn[, count]; grid =
     (blocks of the batch, nm); 2^block_log words per workgroup, 16 per thread).  count (the two-rows-per-workgroup
     transforms) = number of polynomials"""
@@ -1063,7 +1063,7 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None):
         text = f.read()
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
     gx = (batch + 1) // 2 if count is not None else batch << (logn - block_log)
-    run_kernel(text, mem, kernarg, (gx, nm), lds, waves_per_wg=(1 << block_log) // 16 // 64)
+    run_kernel(text, mem, kernarg, (gx, nm), lds, waves_per_wg=(1 << block_log) // words_per_thread // 64)
     out, _ = mem.find(pc, c.nbytes)
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 

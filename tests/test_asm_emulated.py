@@ -113,6 +113,20 @@ def test_emulated_u64_block_transforms(suffix, n, block_log, generated, oracle_f
         assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_inv_mul4096"), n, nm, prm, fa, fb, block_log), want)
 
 
+@pytest.mark.parametrize("nm,batch", [(1, 1), (2, 2)])
+def test_emulated_u64_register_resident_32768_word_rows(nm, batch, generated, oracle_factory):
+    """n = 32768 (workload F, the reference's largest test config): ONE operand register-resident in a 1024-thread
+    workgroup, 32 words per thread -- forward, inverse, and the product with b' streamed through the point-wise step"""
+    n = 32768
+    o = oracle_factory(64, n, nm)
+    prm, a, b = operands(o, 64, n, nm, batch, 21)
+    fa, fb = o.ntt(a), o.ntt(b)
+    run = lambda stem, x, y: asm_emu.run_block_kernel(generated(stem), n, nm, prm, x, y, 15, words_per_thread=32)
+    assert np.array_equal(run("ntt_fwd32768", a, a), fa)
+    assert np.array_equal(run("ntt_inv32768", fa, fa), a)
+    assert np.array_equal(run("polymul_ntt32768", a, fb), o.polymul(a, b))
+
+
 @pytest.mark.parametrize("nt", ["", "nt"])
 @pytest.mark.parametrize("nm,batch", [(1, 3), (2, 2)])
 def test_emulated_u64_two_rows_per_workgroup_transforms(nt, nm, batch, generated, oracle_factory):

@@ -188,11 +188,18 @@ def lowchain(s, y, tw, acc, seed, after_low=None):
     yield "v_add_u32_e32 v%d, v%d, v%d" % (acc + 1, acc + 1, H), None, None
 
 
+def v_mask():
+    """VGPR holding 0x3fffffff: the one temporary slot (T + 1 of stream 0) no butterfly uses"""
+    return V_T[0] + 1
+
+
 def fold2(s, dst, src):
     """dst = (src & (2^62-1)) + (src >> 62)*delta  (< 2^62 + 3*delta); clobbers src's high dword."""
     t = T(s, 0)
     yield "v_lshrrev_b32_e32 v%d, 30, v%d" % (t, src + 1), None, None
-    yield "v_and_b32_e32 v%d, %s, v%d" % (src + 1, S_MASK, src + 1), None, None
+    # (the mask comes from a VGPR: plain VOP2 add / sub / and / mov / lshr issue in ~2.5 cycles per wave64 when every
+    # operand is a VGPR and in ~4.4 with an SGPR operand -- profiles/r03_ubench_issue.txt)
+    yield "v_and_b32_e32 v%d, v%d, v%d" % (src + 1, v_mask(), src + 1), None, None
     yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(dst), S_DUMMY, t, S_DELTA, vp(src)), None, None
 
 
@@ -356,8 +363,11 @@ def gs_stage(em, base, s):
     run_pairs(em, jobs)
 
 
-def tw_base(em, kreg, s, descending):
-    """s[84:85] = tw + 16 * ((K << s) [- 1])"""
+def tw_base(em, kreg, s, descending, koff=0):
+    """s[84:85] = tw + 16 * (((K + koff) << s) [- 1])"""
+    if koff:
+        em.raw("s_%s_u32 s86, %s, 0x%x" % ("add" if koff > 0 else "sub", kreg, abs(koff)))
+        kreg = "s86"
     em.raw("s_lshl_b32 s86, %s, %d" % (kreg, s))
     if descending:
         em.raw("s_sub_u32 s86, s86, 1")
@@ -425,7 +435,7 @@ def lane_contig_setup(em):
     """T(1,0) = byte offset of element 1024*w + l inside a 4096-word block (w = t>>6, l = t&63);
     T(1,1) = padded LDS byte address of the same element.  Per j the element 1024w + 64j + l sits at
     +512*j bytes in global memory and +544*j bytes in the padded slab."""
-    g, l = T(1, 0), T(1, 1)
+    g, l = T(1, 0), T(1, 6)       # (T + 1 of stream 0 holds the fold mask: in single-stream mode both streams share the temporaries)
     em.valu("v_lshrrev_b32_e32 v%d, 6, v%d" % (g, V_TID))                 # w
     em.valu("v_and_b32_e32 v%d, 63, v%d" % (l, V_TID))                    # l
     em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (T(1, 2), l))               # l >> 4
@@ -577,6 +587,7 @@ def prologue(em, vm, kind="polymul"):
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+    em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
     return tw_seq
 
@@ -797,10 +808,16 @@ class Ring:
         slot = self.free.pop(0)
         self.slot_of[use] = slot
         name, s, g = use
-        kreg, vidx, desc = self.passes[name]
         em, r = self.em, V_TW + 4 * slot
+        if callable(self.passes[name]):   # not a twiddle record: the pass supplies the load (row32k streams b' this way)
+            text = self.passes[name](em, r, s, g, self.cur != (name, s))
+            self.cur = (name, s)
+            self.seq_of[use] = self.vm.load(text)
+            return
+        kreg, vidx, desc = self.passes[name][:3]
+        koff = self.passes[name][3] if len(self.passes[name]) > 3 else 0
         if self.cur != (name, s):
-            tw_base(em, kreg, s, desc)
+            tw_base(em, kreg, s, desc, koff)
             if vidx is not None:
                 em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
                 if desc:
@@ -969,6 +986,8 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
         thread16_loads(V_B, S_BROW)
     elif kind == "fwd":
         row_loads(V_A, S_AROW)
+    elif kind == "none":      # (build_row32k issues its own loads)
+        pass
     else:
         lane_loads(V_A, S_AROW)
     if stop == -1:
@@ -988,6 +1007,7 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+    em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
 
 def build_row16k(kind="polymul", stop=None):
@@ -1169,6 +1189,256 @@ def build_row16k(kind="polymul", stop=None):
     return em
 
 
+# ------------------------------------------------------------------ 32768-word rows: ONE operand register-resident
+# A 32768-word row (256 KiB) is exactly the register footprint the 16384-word kernel manages for TWO operands: one
+# 1024-thread workgroup, 32 words per thread in the two coefficient files v[V_A..] / v[V_B..] (64 VGPRs), one butterfly at
+# a time, the twiddle records streaming through the 9-slot ring: 128 VGPRs, 4 waves per SIMD.  The row is HBM traffic
+# exactly once per direction:
+#   F0  radix-8 pass over all 32 slots (global stages r-3 .. r-1): thread tid holds x[tid + 1024 k], k = c + 4 m, i.e.
+#       four columns c of the eight 4096-word blocks m; file A = blocks 0..3, file B = blocks 4..7
+#   X0  through LDS in TWO rounds (a 32768-word row does not fit the 160 KiB): file A -> the four sub-groups' slabs ->
+#       file A of sub-group q = block q; then file B -> block q + 4.  Same addresses as the 16384-word kernel's X0.
+#   F1 F2 F3 / I1 I2 I3: the 4096-word passes of the block kernel, once per file (the files are different blocks of ONE
+#       row here, so they do not share twiddles: file B's records are the block q + 4 ones, K offset by a constant)
+#   X0' in two rounds, I0 radix-8 with the mirrored table, n^-1 folded into the last stage when the row is the whole row.
+# kinds: fwd (canonical NTT-form words out), inv, polymul_ntt: c = INTT(NTT(a) (.) b') with b' (already transformed,
+# canonical) STREAMED through the twiddle ring during the point-wise step -- the large-row product is then
+# b' = fwd(b) (read + write) followed by polymul_ntt(a, b') (two reads + one write): 5 operand passes instead of 9.
+def build_row32k(kind="fwd"):
+    assert SINGLE_STREAM and ROW_G == 4 and ROW_LG == 3
+    em = Emitter()
+    vm = VmCounter(em)
+    R = em.raw
+    FILES = ((V_A, 0), (V_B, 4))                      # (register base, block offset inside the row)
+    DK = {"F1": 1, "F2": 16, "F3": 256, "I1": -256, "I2": -16, "I3": -1}   # dK / d(block) of the pass constants
+    inner = {"F1": (S_K["F1"], None, False), "F2": (S_K["F2"], V_BIDX, False), "F3": (S_K["F3"], V_TID, False),
+             "I1": (S_K["I1"], V_TID, True), "I2": (S_K["I2"], V_BIDX, True), "I3": (S_K["I3"], None, True)}
+    passes = {"F0": (S_K0["F0"], None, False), "I0": (S_K0["I0"], None, True)}
+    for f, (_, boff) in enumerate(FILES):
+        for name, (kreg, vidx, desc) in inner.items():
+            passes[name + "ab"[f]] = (kreg, vidx, desc, DK[name] * boff)
+
+    def bprime_loader(boff):
+        def load(em_, r, s_, i, first):               # words 16t + 2i, 16t + 2i + 1 of block q + boff of b' -> one ring slot
+            if first:
+                em_.raw("s_lshl_b32 s42, %s, 15" % (S_Q,))
+                if boff:
+                    em_.raw("s_add_u32 s42, s42, 0x%x" % (boff << 15,))
+                em_.raw("s_add_u32 s96, s18, s42")
+                em_.raw("s_addc_u32 s97, s19, 0")
+                em_.valu("v_lshlrev_b32_e32 v%d, 7, v%d" % (V_TWO, V_TID))
+            return "global_load_dwordx4 v[%d:%d], v%d, s[96:97] offset:%d" % (r, r + 3, V_TWO, 16 * i)
+        return load
+    passes["Ba"], passes["Bb"] = bprime_loader(0), bprime_loader(4)
+
+    has_fwd, has_inv = kind != "inv", kind != "fwd"
+    uses = []
+    if has_fwd:
+        uses += [("F0", s_, g) for s_ in range(3) for g in range(1 << s_)]
+        for name in ("F1", "F2", "F3"):
+            for f in range(2):
+                uses += [(name + "ab"[f], s_, g) for s_ in range(4) for g in range(1 << s_)]
+    if kind == "polymul_ntt":
+        for f in range(2):
+            uses += [("B" + "ab"[f], 0, i) for i in range(8)]
+    if has_inv:
+        for name in ("I1", "I2", "I3"):
+            for f in range(2):
+                uses += [(name + "ab"[f], s_, g) for s_ in (3, 2, 1, 0) for g in range(1 << s_)]
+        uses += [("I0", s_, g) for s_ in (2, 1, 0) for g in range(1 << s_)]
+    ring = Ring(em, vm, RING_SLOTS, uses, passes)
+    prologue16k(em, vm, None, "none")
+    AX = T(0, 0)   # exchange address scratch (the butterfly temporaries are idle during exchanges)
+
+    def block_base(srow, boff):                           # s[86:87] = first word of block q + boff of the row at srow
+        lo, hi = srow[2:-1].split(":")
+        R("s_lshl_b32 s42, %s, 15" % (S_Q,))
+        if boff:
+            R("s_add_u32 s42, s42, 0x%x" % (boff << 15,))
+        R("s_add_u32 s86, s%s, s42" % lo)
+        R("s_addc_u32 s87, s%s, 0" % hi)
+
+    n_row_loads = 0
+    if has_fwd:
+        em.comment("the row: x[tid + 1024 k] -> slot k (8 KiB contiguous per workgroup load)")
+        R("s_mov_b64 s[86:87], %s" % (S_AROW,))
+        for k in range(32):
+            vm.load("global_load_dwordx2 %s, v%d, s[86:87] nt" % (vp(V_A + 2 * k), V_OFF8))
+            if k < 31:
+                R("s_add_u32 s86, s86, 0x2000")
+                R("s_addc_u32 s87, s87, 0")
+    else:
+        em.comment("NTT-form words: block element 1024w + 64j + l -> pair j of the block's file (512 B per wave load)")
+        g_, _ = lane_contig_setup(em)
+        for base, boff in FILES:
+            block_base(S_AROW, boff)
+            for j in range(16):
+                vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d nt" % (vp(base + 2 * j), g_, (j & 7) * 512))
+                if j == 7:
+                    R("s_add_u32 s86, s86, 0x1000")
+                    R("s_addc_u32 s87, s87, 0")
+    n_row_loads = vm.issued
+    ring.prime()
+
+    def fwd_pass(name):
+        for f, (base, _) in enumerate(FILES):
+            nm_ = name + "ab"[f]
+            em.comment("%s, file %s" % (name, "AB"[f]))
+            for s_ in range(4):
+                half = 8 >> s_
+                for g in range(1 << s_):
+                    tw = ring.get((nm_, s_, g))
+                    run_pairs(em, [ct_bfly(base + 2 * (g * 2 * half + h), base + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                    ring.done((nm_, s_, g))
+
+    def inv_pass(name):
+        for f, (base, _) in enumerate(FILES):
+            nm_ = name + "ab"[f]
+            em.comment("%s, file %s" % (name, "AB"[f]))
+            for s_ in (3, 2, 1, 0):
+                half = 8 >> s_
+                for g in range(1 << s_):
+                    tw = ring.get((nm_, s_, g))
+                    run_pairs(em, [gs_bfly(base + 2 * (g * 2 * half + h), base + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                    ring.done((nm_, s_, g))
+
+    if has_fwd:
+        em.comment("F0: radix-8 over the 32 slots (stage 0 couples the files)")
+        for s_ in range(3):
+            half = 16 >> s_
+            for g in range(1 << s_):
+                tw = ring.get(("F0", s_, g))
+                run_pairs(em, [ct_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                ring.done(("F0", s_, g))
+        for i, (base, _) in enumerate(FILES):
+            em.comment("X0 round %d: thread (q, t) slot 4*m + c of this file -> sub-group m, thread t, slot q + 4*c" % i)
+            if i:
+                R("s_barrier")       # WAR: the slabs are still being read for the previous file
+            em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+            for k in range(16):
+                qq, j = k // 4, k % 4
+                R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+            em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+            for k in range(16):
+                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+            R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F1")
+        for base, _ in FILES:
+            em.comment("E1")
+            R("s_barrier")           # WAR against the previous exchange through this slab
+            lds_write(em, V_L1W, base, 2176)
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            lds_read(em, V_L1R, base, 136)
+            R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F2")
+        em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+        for base, _ in FILES:
+            lds_write(em, V_L1R, base, 136)
+            lds_read(em, V_L2R, base, 8)
+            R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F3")
+    if kind == "fwd":
+        em.comment("canonical words, then a wave-local LDS transpose per file so the stores are fully coalesced")
+        run_pairs(em, [canon(V_A + 2 * i) for i in range(32)])
+        for base, boff in FILES:
+            lds_write(em, V_L2R, base, 8)
+            g_, l_ = lane_contig_setup(em)
+            em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
+            for j in range(16):
+                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * j), l_, 544 * j))
+            R("s_waitcnt lgkmcnt(0)")
+            block_base(S_CROW, boff)
+            for j in range(16):
+                R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d nt" % (g_, vp(base + 2 * j), (j & 7) * 512))
+                if j == 7:
+                    R("s_add_u32 s86, s86, 0x1000")
+                    R("s_addc_u32 s87, s87, 0")
+        R("s_endpgm")
+        return em
+
+    if kind == "polymul_ntt":
+        em.comment("point-wise product with b' streamed through the ring: slot i of a file = words 16t + 2i, 16t + 2i + 1 of its block")
+        for f, (base, _) in enumerate(FILES):
+            for i in range(8):
+                use = ("B" + "ab"[f], 0, i)
+                ring.get(use)
+                r = V_TW + 4 * ring.slot_of[use]
+                run_pairs(em, [pointwise(base + 4 * i, r, True, False), pointwise(base + 4 * i + 2, r + 2, True, False)])
+                ring.done(use)
+    else:
+        R("s_waitcnt vmcnt(%d)" % (vm.issued - n_row_loads))          # the block loads have landed
+        em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region, file by file")
+        _, l_ = lane_contig_setup(em)
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
+        for base, _ in FILES:
+            for j in range(16):
+                R("ds_write_b64 v%d, %s offset:%d" % (l_, vp(base + 2 * j), 544 * j))
+            lds_read(em, V_L2R, base, 8)
+            R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I1")
+    em.comment("E2'")
+    for base, _ in FILES:
+        lds_write(em, V_L2R, base, 8)
+        lds_read(em, V_L1R, base, 136)
+        R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I2")
+    for i, (base, _) in enumerate(FILES):
+        em.comment("E1'")
+        if i:
+            R("s_barrier")           # WAR: the slab is still being read for the previous file
+        lds_write(em, V_L1R, base, 136)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        lds_read(em, V_L1W, base, 2176)
+        R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I3")
+    for i, (base, _) in enumerate(FILES):
+        em.comment("X0' round %d: thread (q, t) slot g + 4*j of this file -> thread (g, t) slot 4*q + j, layout [slot][tid]" % i)
+        R("s_barrier")               # every wave is done reading the previous exchange
+        R("s_lshl_b32 s86, %s, 15" % (S_Q,))
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                          # q*32768 + t*8
+        for k in range(16):
+            g_, j = k % 4, k // 4
+            R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(base + 2 * k), j * 8192 + g_ * 2048))
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * 8192, V_OFF8))
+        for k in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * 8192))
+        R("s_waitcnt lgkmcnt(0)")
+    em.comment("I0: radix-8 over the 32 slots, mirrored table")
+    for s_ in (2, 1):
+        half = 16 >> s_
+        for g in range(1 << s_):
+            tw = ring.get(("I0", s_, g))
+            run_pairs(em, [gs_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+            ring.done(("I0", s_, g))
+    R("s_cmp_eq_u32 s88, %d" % ROW_LG)
+    R("s_cbranch_scc1 .Lmerged_last_stage")
+    em.comment("r > 3: plain global stage r-3; lazy output for the outer inverse passes")
+    tw = ring.get(("I0", 0, 0))
+    run_pairs(em, [gs_bfly(V_A + 2 * h, V_A + 2 * (h + 16), tw) for h in range(16)])
+    R("s_branch .Lstore")
+    em.lines.append(".Lmerged_last_stage:")
+    em.comment("n == 32768: stage 0 with n^-1 folded in")
+    R("s_waitcnt vmcnt(0)")
+    run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 16)) for h in range(16)])
+    em.lines.append(".Lstore:")
+    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
+    for k in range(32):
+        R("global_store_dwordx2 v%d, %s, s[86:87] nt" % (V_OFF8, vp(V_A + 2 * k)))
+        if k < 31:
+            R("s_add_u32 s86, s86, 0x2000")
+            R("s_addc_u32 s87, s87, 0")
+    R("s_endpgm")
+    return em
+
+
 # ------------------------------------------------------------------ n = 65536: the three-role pipeline kernel
 # Long rows need streaming radix-16 passes around the fused 4096-word block kernel, and the two kinds of work bound
 # different resources (HBM vs integer VALU).  Kernels from different streams do not interleave on a CU in practice
@@ -1208,6 +1478,7 @@ def emit_consts(em):
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+    em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
 
 def legacy_role_map(em, PER_ROW, NV, NSW):
@@ -2258,6 +2529,12 @@ def main():
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem.replace("16384", "8192") + "_gfx950.s"), kname.replace("16384", "8192"),
                   build_row16k(kind))
+    configure("ring", 4)
+    # 32768-word rows: one operand register-resident in a 1024-thread workgroup (4 sub-groups x 2 blocks)
+    g = globals()
+    g.update(ROW_LG=3, NEXT_SGPR=98)
+    for kind, stem in (("fwd", "ntt_fwd32768"), ("inv", "ntt_inv32768"), ("polymul_ntt", "polymul_ntt32768")):
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind))
     configure("ring", 4)
     if os.environ.get("NFL_DEBUG16K"):   # checkpoint variants for bisecting a fault: kernel ends after phase n
         kind = os.environ["NFL_DEBUG16K"]

@@ -34,7 +34,9 @@ V_A, V_B = 8, 40     # 16 even-aligned pairs each: coefficient q of a in v[8 + 2
 V_TWA, V_TWB = 72, 88   # two buffers of 8 per-lane twiddle records {w, w'}
 V_S = [104, 108]     # per-stream temporaries: T0, Q, T2, S
 V_PW = 112           # point-wise temp pair
-NEXT_VGPR = 116
+V_P, V_2P = 116, 117  # p and 2p once more, in VGPRs: a plain VOP2 add / sub issues in ~2.5 cycles per wave64 with VGPR operands
+                      # only and in ~4.4 with an SGPR operand (profiles/r03_ubench_issue.txt)
+NEXT_VGPR = 118
 NEXT_SGPR = 80
 SLAB = 1088 * 4      # bytes of LDS per 1024 row words (the padding of either exchange layout included)
 
@@ -58,7 +60,7 @@ def ct(x, y, tw):
 
     def gen(s):
         T0, Q, T2 = V_S[s], V_S[s] + 1, V_S[s] + 2
-        yield "v_subrev_u32_e32 v%d, s%d, v%d" % (T0, S_2P, x), None, None
+        yield "v_sub_u32_e32 v%d, v%d, v%d" % (T0, x, V_2P), None, None
         yield "v_min_u32_e32 v%d, v%d, v%d" % (x, x, T0), None, None
         yield "v_mul_hi_u32 v%d, v%d, %s" % (Q, y, wp), None, None
         yield "v_lshl_add_u32 v%d, v%d, 1, s%d" % (T2, x, S_2P), None, None
@@ -78,8 +80,8 @@ def gs(x, y, tw, xsrc=None, ysrc=None):
         T0, Q, D, S = V_S[s], V_S[s] + 1, V_S[s] + 2, V_S[s] + 3
         yield "v_add_u32_e32 v%d, v%d, v%d" % (S, xs, ys), None, None
         yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, ys, xs), None, None
-        yield "v_add_u32_e32 v%d, s%d, v%d" % (D, S_2P, D), None, None
-        yield "v_subrev_u32_e32 v%d, s%d, v%d" % (T0, S_2P, S), None, None
+        yield "v_add_u32_e32 v%d, v%d, v%d" % (D, V_2P, D), None, None
+        yield "v_sub_u32_e32 v%d, v%d, v%d" % (T0, S, V_2P), None, None
         yield "v_min_u32_e32 v%d, v%d, v%d" % (x, S, T0), None, None
         yield "v_mul_hi_u32 v%d, v%d, %s" % (Q, D, wp), None, None
         yield "v_mad_u64_u32 %s, %s, v%d, s%d, 0" % (pair(y), S_DUMMY, Q, S_NEGP), None, None
@@ -89,7 +91,7 @@ def gs(x, y, tw, xsrc=None, ysrc=None):
 
 def csub(reg, dst, bound_sgpr, s):
     T0 = V_S[s]
-    yield "v_subrev_u32_e32 v%d, s%d, v%d" % (T0, bound_sgpr, reg), None, None
+    yield "v_sub_u32_e32 v%d, v%d, v%d" % (T0, reg, {S_P: V_P, S_2P: V_2P}[bound_sgpr]), None, None
     yield "v_min_u32_e32 v%d, v%d, v%d" % (dst, reg, T0), None, None
 
 
@@ -124,7 +126,7 @@ def last(u, x):
         D, S = V_S[s] + 2, V_S[s] + 3
         yield "v_add_u32_e32 v%d, v%d, v%d" % (S, u, x), None, None
         yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, x, u), None, None
-        yield "v_add_u32_e32 v%d, s%d, v%d" % (D, S_2P, D), None, None
+        yield "v_add_u32_e32 v%d, v%d, v%d" % (D, V_2P, D), None, None
         yield from mul_shoup_exact(S, u, S_NINV, S_NINVSH, s)
         yield from mul_shoup_exact(D, x, S_W1N, S_W1NSH, s)
     return gen
@@ -224,6 +226,8 @@ def build(LB=4, mode="polymul"):
     R("s_waitcnt lgkmcnt(0)")
     R("s_mov_b32 s%d, s56" % S_P)
     R("s_mov_b32 s%d, s57" % S_2P)
+    V("v_mov_b32_e32 v%d, s56" % V_P)
+    V("v_mov_b32_e32 v%d, s57" % V_2P)
     R("s_sub_u32 s%d, 0, s56" % S_NEGP)
     R("s_mov_b32 s%d, s58" % S_MU)
     R("s_mov_b32 s%d, s59" % S_NINV)

@@ -1,93 +1,27 @@
 // tools/ubench_issue.hip -- the VALU issue model of gfx950 that the product kernels are priced against, measured as a
-// GRID instead of one point (round-2 verdict, "light opcodes issue at 2.3-2.6 cycles isolated, ~4.2 in situ"):
-//   opcode x encoding  x  waves per SIMD (1..8)  x  dependency distance (1..8 independent accumulators)
-//   + light:heavy interleave ratios, + the 7-instruction 30-bit butterfly and the 18-instruction 62-bit butterfly of
-//     the generated kernels as straight-line assembly, + the EFFECTIVE SHADER CLOCK of every run:
-// every kernel brackets its loop with s_memtime (shader clock) and s_memrealtime (100 MHz), so "cycles per instruction"
-// is in cycles that actually elapsed, not at an assumed 2.4 GHz.
+// GRID instead of one point (round-2 verdict: "light opcodes issue at 2.3-2.6 cycles isolated, ~4.2 in situ"):
+//   stream (tools/gen_ubench_issue.py: single opcodes at two dependency distances, light:heavy mixes, the 30- and 62-bit
+//   butterflies of the generated kernels, the same butterflies as long straight-line code)  x  waves per SIMD 1..8.
+// Every stream is ONE inline-assembly block on fixed registers (hipcc pads separate asm statements with s_nop, which
+// made round 2's isolated figures a two-instruction measurement).  Waves per SIMD are FORCED: every 256-thread block
+// (one wave per SIMD) asks for 160 KiB / W of LDS, so exactly W blocks fit a CU and all 256 W blocks are resident at once.
+// Two clocks bracket every loop: s_memtime (shader clock) and s_memrealtime (100 MHz), so cycles are cycles that elapsed.
+//   per-SIMD cycles per unit = mean over waves of (elapsed s_memtime cycles) / (units per wave * W)
+//   the same from the wall clock of the whole launch (HIP events) at the measured MHz -- they must agree
 //
-//   hipcc --offload-arch=gfx950 -O3 -o ubench_issue tools/ubench_issue.hip && ./ubench_issue > profiles/r03_ubench_issue.txt
+//   python tools/gen_ubench_issue.py && hipcc --offload-arch=gfx950 -O3 -o build/ubench_issue tools/ubench_issue.hip
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
-
-constexpr int ITER = 2048;
 
 struct Clk { long long cyc, ref; };
 
-// ACC independent accumulators: instruction k of an iteration depends on instruction k of the previous iteration, i.e.
-// the dependency distance is ACC instructions.  NPER = instructions per accumulator and iteration in ASM.
-#define DEF_GRID(NAME, DECL, ASM, OUTC, INC)                                                        \
-  template <int ACC> __global__ void NAME(uint32_t *out, uint32_t a, uint32_t b, Clk *clk) {       \
-    DECL r[ACC];                                                                                    \
-    for (int k = 0; k < ACC; ++k) r[k] = threadIdx.x + k;                                           \
-    uint32_t x = a + threadIdx.x, y = b;                                                            \
-    uint64_t z = ((uint64_t)a << 32) | b;                                                           \
-    (void)z;                                                                                        \
-    const long long c0 = clock64(), w0 = wall_clock64();                                            \
-    for (int it = 0; it < ITER; ++it) {                                                             \
-      _Pragma("unroll") for (int k = 0; k < ACC; ++k) asm volatile(ASM : OUTC(r[k]) : INC : "vcc"); \
-    }                                                                                               \
-    const long long c1 = clock64(), w1 = wall_clock64();                                            \
-    DECL s = 0;                                                                                     \
-    for (int k = 0; k < ACC; ++k) s ^= r[k];                                                        \
-    if (s == 0x12345678u) out[0] = (uint32_t)s;                                                     \
-    if (threadIdx.x == 0) clk[blockIdx.x] = Clk{c1 - c0, w1 - w0};                                  \
-  }
-#define IN32 "v"(x), "v"(y), "s"(b)
-#define IN64 "v"(x), "v"(y), "v"(z), "s"(b)
-#define RW "+v"
+#include "ubench_issue_gen.inc"
 
-// light candidates (VOP2, no carry)
-DEF_GRID(g_add_e32, uint32_t, "v_add_u32_e32 %0, %1, %0", RW, IN32)
-DEF_GRID(g_add_e64, uint32_t, "v_add_u32_e64 %0, %1, %0", RW, IN32)
-DEF_GRID(g_add_sgpr, uint32_t, "v_add_u32_e32 %0, %3, %0", RW, IN32)
-DEF_GRID(g_sub_e32, uint32_t, "v_sub_u32_e32 %0, %1, %0", RW, IN32)
-DEF_GRID(g_and_e32, uint32_t, "v_and_b32_e32 %0, %1, %0", RW, IN32)
-DEF_GRID(g_mov_e32, uint32_t, "v_mov_b32_e32 %0, %1", RW, IN32)
-DEF_GRID(g_lshl_e32, uint32_t, "v_lshlrev_b32_e32 %0, 3, %0", RW, IN32)
-DEF_GRID(g_lshr_e32, uint32_t, "v_lshrrev_b32_e32 %0, 3, %0", RW, IN32)
-DEF_GRID(g_ashr_e32, uint32_t, "v_ashrrev_i32_e32 %0, 3, %0", RW, IN32)
-DEF_GRID(g_or_e32, uint32_t, "v_or_b32_e32 %0, %1, %0", RW, IN32)
-DEF_GRID(g_max_e32, uint32_t, "v_max_u32_e32 %0, %1, %0", RW, IN32)
-// heavy
-DEF_GRID(g_min_e32, uint32_t, "v_min_u32_e32 %0, %1, %0", RW, IN32)
-DEF_GRID(g_mulhi, uint32_t, "v_mul_hi_u32 %0, %1, %0", RW, IN32)
-DEF_GRID(g_lshl_add, uint32_t, "v_lshl_add_u32 %0, %0, 1, %1", RW, IN32)
-DEF_GRID(g_addco, uint32_t, "v_add_co_u32_e32 %0, vcc, %1, %0", RW, IN32)
-DEF_GRID(g_mad64, uint64_t, "v_mad_u64_u32 %0, vcc, %1, %2, %0", RW, IN64)
-DEF_GRID(g_mad64_sgpr, uint64_t, "v_mad_u64_u32 %0, vcc, %1, %4, %0", RW, IN64)
-DEF_GRID(g_lshl_add64, uint64_t, "v_lshl_add_u64 %0, %3, 0, %0", RW, IN64)
-// interleaves: H = v_mad_u64_u32 on a 64-bit accumulator, L = v_add_u32 / v_and / v_sub on a 32-bit accumulator of its own
-// (two chains per slot; AMDGPU inline assembly cannot name the halves of a compiler-allocated pair)
-#define DEF_GRID2(NAME, ASM)                                                                        \
-  template <int ACC> __global__ void NAME(uint32_t *out, uint32_t a, uint32_t b, Clk *clk) {       \
-    uint64_t r[ACC];                                                                                \
-    uint32_t l[ACC];                                                                                \
-    for (int k = 0; k < ACC; ++k) { r[k] = threadIdx.x + k; l[k] = 7 * threadIdx.x + k; }           \
-    uint32_t x = a + threadIdx.x, y = b;                                                            \
-    const long long c0 = clock64(), w0 = wall_clock64();                                            \
-    for (int it = 0; it < ITER; ++it) {                                                             \
-      _Pragma("unroll") for (int k = 0; k < ACC; ++k) asm volatile(ASM : "+v"(r[k]), "+v"(l[k]) : "v"(x), "v"(y) : "vcc"); \
-    }                                                                                               \
-    const long long c1 = clock64(), w1 = wall_clock64();                                            \
-    uint64_t s = 0;                                                                                 \
-    for (int k = 0; k < ACC; ++k) s ^= r[k] ^ l[k];                                                 \
-    if (s == 0x12345678u) out[0] = (uint32_t)s;                                                     \
-    if (threadIdx.x == 0) clk[blockIdx.x] = Clk{c1 - c0, w1 - w0};                                  \
-  }
-DEF_GRID2(g_mix_h1l1, "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_add_u32_e32 %1, %2, %1")
-DEF_GRID2(g_mix_h1l2, "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_add_u32_e32 %1, %2, %1\n v_and_b32_e32 %1, %3, %1")
-DEF_GRID2(g_mix_h2l1, "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %0, vcc, %3, %2, %0\n v_add_u32_e32 %1, %2, %1")
-DEF_GRID2(g_mix_h1l3, "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_add_u32_e32 %1, %2, %1\n v_and_b32_e32 %1, %3, %1\n v_sub_u32_e32 %1, %3, %1")
-
-// the butterflies of the generated kernels as straight-line assembly on fixed registers (tools/gen_ubench_issue.py)
-#include "ubench_issue_bfly.inc"
-
-// an IDLE probe of the two clocks (one lane): what s_memtime counts against the 100 MHz reference with nothing else running
 __global__ void k_clock(Clk *out) {
   const long long t0 = wall_clock64(), c0 = clock64();
   while (wall_clock64() - t0 < 10000000) {}
@@ -98,122 +32,84 @@ static int g_cus = 256;
 static uint32_t *g_d32;
 static Clk *g_clk;
 
-struct Result { double ms, cyc_per_inst_ref24, cyc_per_inst_true, mhz; };
+struct Result { double ms, per_wave, per_time, mhz; };
 
-template <typename K, typename... Args> static Result run(K kernel, int waves_per_simd, double inst_per_wave, Args... args) {
-  const int blocks = g_cus * waves_per_simd;  // 256 threads = one wave on each of the CU's four SIMDs
+static Result run(const KernelRow &k, int W, int iters) {
+  const int blocks = g_cus * W;
+  size_t lds = (size_t)(163840 / W) & ~(size_t)127;
+  if (W == 8) lds = 20480;
+  (void)hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint32_t p32 = 1073479681u, w32 = 123456789u, wp32 = (uint32_t)(((uint64_t)w32 << 32) / p32);
+  const uint64_t p = 4611686018326724609ull, w = 2262382610096409597ull;
+  const uint64_t wsh = (uint64_t)((((unsigned __int128)w) << 64) / p);
+  const uint32_t delta = (uint32_t)((1ull << 62) - p);
+  auto launch = [&] {
+    if (!strcmp(k.kind, "b64"))
+      hipLaunchKernelGGL((void (*)(uint32_t *, int, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, uint32_t, Clk *))k.fn,
+                         dim3(blocks), dim3(256), lds, 0, g_d32, iters, delta, 0x3fffffffu, (uint32_t)w, (uint32_t)(w >> 32), (uint32_t)wsh,
+                         (uint32_t)(wsh >> 32), 3 * p, 0xC0000000u, g_clk);
+    else if (!strcmp(k.kind, "b32"))
+      hipLaunchKernelGGL((void (*)(uint32_t *, int, uint32_t, uint32_t, uint32_t, uint32_t, Clk *))k.fn, dim3(blocks), dim3(256), lds, 0, g_d32,
+                         iters, 2 * p32, 0u - p32, w32, wp32, g_clk);
+    else
+      hipLaunchKernelGGL((void (*)(uint32_t *, int, uint32_t, Clk *))k.fn, dim3(blocks), dim3(256), lds, 0, g_d32, iters, 5u, g_clk);
+  };
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, g_d32, args..., g_clk);
-  hipDeviceSynchronize();
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  launch();
+  (void)hipDeviceSynchronize();
   const int reps = 3;
-  hipEventRecord(e0, 0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, g_d32, args..., g_clk);
-  hipEventRecord(e1, 0);
-  hipEventSynchronize(e1);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
   float ms = 0;
-  hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  std::vector<Clk> h(blocks);
-  hipMemcpy(h.data(), g_clk, sizeof(Clk) * blocks, hipMemcpyDeviceToHost);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  std::vector<Clk> h((size_t)blocks * 4);
+  (void)hipMemcpy(h.data(), g_clk, sizeof(Clk) * h.size(), hipMemcpyDeviceToHost);
   double cyc = 0, ref = 0;
   for (auto &c : h) { cyc += (double)c.cyc; ref += (double)c.ref; }
   Result r;
   r.ms = ms;
-  r.mhz = 100.0 * cyc / ref;  // s_memrealtime counts at 100 MHz
-  // per SIMD: waves_per_simd waves issue inst_per_wave instructions each during the loop's (mean) s_memtime span
-  r.cyc_per_inst_true = (cyc / blocks) / (inst_per_wave * waves_per_simd);
-  r.cyc_per_inst_ref24 = (ref / blocks) * 24.0 / (inst_per_wave * waves_per_simd);
+  r.mhz = 100.0 * cyc / ref;
+  const double units_per_wave = (double)iters * k.units;
+  r.per_wave = (cyc / h.size()) / (units_per_wave * W);
+  r.per_time = ms * 1e-3 * (r.mhz * 1e6) * (g_cus * 4.0) / (units_per_wave * blocks * 4.0);
   return r;
 }
 
-#define GRID_ROW(NAME, NPER)                                                                                  \
-  {                                                                                                           \
-    printf("%-14s", #NAME + 2);                                                                               \
-    for (int w : {1, 2, 4, 8}) {                                                                              \
-      Result r1 = run(NAME<1>, w, (double)ITER * 1 * (NPER), 3u, 5u);                                         \
-      Result r2 = run(NAME<2>, w, (double)ITER * 2 * (NPER), 3u, 5u);                                         \
-      Result r4 = run(NAME<4>, w, (double)ITER * 4 * (NPER), 3u, 5u);                                         \
-      Result r8 = run(NAME<8>, w, (double)ITER * 8 * (NPER), 3u, 5u);                                         \
-      printf(" | %5.2f %5.2f %5.2f %5.2f (%4.0f)", r1.cyc_per_inst_true, r2.cyc_per_inst_true, r4.cyc_per_inst_true, \
-             r8.cyc_per_inst_true, r8.mhz);                                                                   \
-    }                                                                                                         \
-    printf("\n");                                                                                             \
-    fflush(stdout);                                                                                           \
-  }
-
-int main() {
+int main(int argc, char **argv) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { printf("no device\n"); return 1; }
   g_cus = prop.multiProcessorCount;
-  hipMalloc(&g_d32, 1024);
-  hipMalloc(&g_clk, sizeof(Clk) * g_cus * 8);
+  (void)hipMalloc(&g_d32, 1024);
+  (void)hipMalloc(&g_clk, sizeof(Clk) * g_cus * 8 * 4);
   printf("device: %s  CUs=%d  clockRate=%d kHz\n", prop.name, g_cus, prop.clockRate);
   hipLaunchKernelGGL(k_clock, dim3(1), dim3(1), 0, 0, g_clk);
   Clk idle;
-  hipMemcpy(&idle, g_clk, sizeof(Clk), hipMemcpyDeviceToHost);
-  printf("idle probe: s_memtime / s_memrealtime = %.4f  (s_memrealtime = 100 MHz => s_memtime counts at %.1f MHz)\n",
-         (double)idle.cyc / idle.ref, 100.0 * idle.cyc / idle.ref);
-  printf("\ncycles per wave64 instruction per SIMD, in s_memtime cycles that elapsed inside the kernel (NOT at an assumed clock).\n"
-         "columns: waves per SIMD 1 | 2 | 4 | 8; inside a column: dependency distance 1 2 4 8 instructions; (MHz) = s_memtime rate\n"
-         "against the 100 MHz reference during the 8-accumulator run\n");
-  printf("%-14s | %-30s | %-30s | %-30s | %-30s\n", "opcode", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD", "8 waves/SIMD");
-  GRID_ROW(g_add_e32, 1)
-  GRID_ROW(g_add_e64, 1)
-  GRID_ROW(g_add_sgpr, 1)
-  GRID_ROW(g_sub_e32, 1)
-  GRID_ROW(g_and_e32, 1)
-  GRID_ROW(g_or_e32, 1)
-  GRID_ROW(g_mov_e32, 1)
-  GRID_ROW(g_lshl_e32, 1)
-  GRID_ROW(g_lshr_e32, 1)
-  GRID_ROW(g_ashr_e32, 1)
-  GRID_ROW(g_max_e32, 1)
-  GRID_ROW(g_min_e32, 1)
-  GRID_ROW(g_mulhi, 1)
-  GRID_ROW(g_lshl_add, 1)
-  GRID_ROW(g_addco, 1)
-  GRID_ROW(g_mad64, 1)
-  GRID_ROW(g_mad64_sgpr, 1)
-  GRID_ROW(g_lshl_add64, 1)
-  printf("\ninterleaves (H = v_mad_u64_u32, L = add / and / sub on a half of the same pair): cycles per INSTRUCTION\n");
-  GRID_ROW(g_mix_h1l1, 2)
-  GRID_ROW(g_mix_h1l2, 3)
-  GRID_ROW(g_mix_h2l1, 3)
-  GRID_ROW(g_mix_h1l3, 4)
-  printf("\nthe generated kernels' butterflies as straight-line assembly on fixed registers: cycles per BUTTERFLY\n"
-         "(bfly32 = the 7-instruction 30-bit Cooley-Tukey butterfly of gen_row1024_u32_asm.py, ideal 5 x 4 + 2 x 2 = 24 cycles if the two\n"
-         " plain subtractions issue at 2 cycles; bfly64 = the 18-instruction 62-bit one of gen_polymul_asm.py; 'i' = two butterflies\n"
-         " interleaved instruction by instruction as the kernels do; columns: waves per SIMD 1 | 2 | 3 | 4 | 8; (MHz) of the last entry)\n");
-  {
-    const uint32_t p32 = 1073479681u, w32 = 123456789u, wp32 = (uint32_t)(((uint64_t)w32 << 32) / p32);
-    const uint64_t p = 4611686018326724609ull, w = 2262382610096409597ull;
-    const uint64_t wsh = (uint64_t)((((unsigned __int128)w) << 64) / p);
-    const uint32_t delta = (uint32_t)((1ull << 62) - p);
-#define BROW32(K, ACC)                                                                                           \
-    {                                                                                                            \
-      printf("%-14s", #K + 2);                                                                                   \
-      for (int wv : {1, 2, 3, 4, 8}) {                                                                           \
-        Result r = run(K, wv, (double)(ITER / 4) * (ACC), 2 * p32, 0u - p32, w32, wp32);                         \
-        printf(" | %6.1f (%4.0f)", r.cyc_per_inst_true, r.mhz);                                                  \
-      }                                                                                                          \
-      printf("\n");                                                                                              \
+  (void)hipMemcpy(&idle, g_clk, sizeof(Clk), hipMemcpyDeviceToHost);
+  printf("idle probe: s_memtime counts at %.1f MHz against the 100 MHz s_memrealtime\n", 100.0 * idle.cyc / idle.ref);
+  printf("\nper-SIMD cycles per unit (unit = one instruction for op_* / mix_*, one BUTTERFLY for bfly*); every cell:\n"
+         "  from the waves' own s_memtime spans / from the launch's wall clock at the measured MHz (MHz)\n");
+  const int Ws[] = {1, 2, 3, 4, 6, 8};
+  printf("%-22s %5s", "stream", "instr");
+  for (int W : Ws) printf(" | %d wave%s/SIMD        ", W, W > 1 ? "s" : " ");
+  printf("\n");
+  const std::string only = argc > 1 ? argv[1] : "";
+  for (const KernelRow &k : kRows) {
+    if (!only.empty() && std::string(k.name).find(only) == std::string::npos) continue;
+    printf("%-22s %5d", k.name, k.ninstr);
+    const int iters = std::max(4, 400000 / k.ninstr);
+    for (int W : Ws) {
+      Result r = run(k, W, iters);
+      printf(" | %6.2f %6.2f (%4.0f)", r.per_wave, r.per_time, r.mhz);
     }
-#define BROW64(K, ACC)                                                                                           \
-    {                                                                                                            \
-      printf("%-14s", #K + 2);                                                                                   \
-      for (int wv : {1, 2, 3, 4, 8}) {                                                                           \
-        Result r = run(K, wv, (double)(ITER / 4) * (ACC), delta, 0x3fffffffu, (uint32_t)w, (uint32_t)(w >> 32), \
-                       (uint32_t)wsh, (uint32_t)(wsh >> 32), 3 * p, 0xC0000000u);                                \
-        printf(" | %6.1f (%4.0f)", r.cyc_per_inst_true, r.mhz);                                                  \
-      }                                                                                                          \
-      printf("\n");                                                                                              \
-    }
-    BROW32(g_bfly32_1, 1) BROW32(g_bfly32_2, 2) BROW32(g_bfly32i_2, 2) BROW32(g_bfly32_4, 4) BROW32(g_bfly32i_4, 4) BROW32(g_bfly32_8, 8) BROW32(g_bfly32i_8, 8)
-    BROW64(g_bfly64_1, 1) BROW64(g_bfly64_2, 2) BROW64(g_bfly64i_2, 2) BROW64(g_bfly64_4, 4) BROW64(g_bfly64i_4, 4)
+    printf("\n");
+    fflush(stdout);
   }
   return 0;
 }
