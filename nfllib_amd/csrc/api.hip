@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -13,6 +14,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gauss_table.h"
@@ -35,6 +37,8 @@ struct nflhip_ctx {
   hipStream_t hstream = nullptr;
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
+  // large host-pointer calls: a three-slot pipeline of pinned staging chunks (HostPipe below), created on first use
+  struct HostPipe *pipe = nullptr;
   // scratch for the composed (non-fused) polymul path, per stream use is serialised by the caller
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -70,6 +74,8 @@ int set_error(int code, const std::string &msg) {  // for the library's other tr
   return code;
 }
 }  // namespace nflhip
+
+static void pipe_destroy(nflhip_ctx *ctx);  // (HostPipe is defined with the host-pointer entry points)
 
 static int fail(const nflhip_ctx *ctx, int code, const std::string &msg) {
   (void)ctx;
@@ -435,7 +441,9 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   const size_t bytes = poly_bytes(ctx, batch);
   lk.lock();
   const bool cap = is_capturing(st);
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 15 && row32k_on()) {
+  // (from 256 rows on; below that the one-launch plan further down spreads a row over more CUs -- measured, same box:
+  // batch 8 / 32 / 128 / 512 of two moduli 58 / 223 / 716 / 785 k products/s here against 68 / 302 / 622 / 779 k)
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 15 && row32k_on() && batch * ctx->shape.nm >= 256) {
     // rows of 32768 words: b' = NTT(b) into the scratch (one read, one write), then c = INTT(NTT(a) (.) b') with the row
     // of a register-resident and b' streamed through the point-wise step (two reads, one write): 5 operand passes
     int rcs = ensure_scratch(ctx, bytes);
@@ -675,6 +683,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   }
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_scratch) (void)hipEventDestroy(ctx->ev_scratch);
+  pipe_destroy(ctx);
   for (int i = 0; i < 4; ++i)
     if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -1346,6 +1355,186 @@ int nflhip_stream_idle(nflhip_ctx *ctx, void *stream, int *idle) {
 // ---------------------------------------------------------------------------
 // host-pointer entry points: stage through context-owned device buffers
 // ---------------------------------------------------------------------------
+}  // extern "C"
+
+// Large batches through the host-pointer entry points (what an unchanged caller holding arrays of inline-storage
+// nfl::poly gets: poly.hpp:87-88, tests/tools.h:6-17).  hipMemcpy from pageable memory tops out at ~12 GB/s on this
+// platform (the runtime's single staging thread), 5x below PCIe.  Here the batch is cut into chunks that flow through
+// three slots of PINNED staging buffers: several host threads copy chunk k + 1 into its slot while chunk k crosses PCIe
+// (H2D stream), chunk k - 1 is computed (compute stream) and chunk k - 2 returns (D2H stream) and is copied out.
+// Results are what one call over the whole batch gives (every operation here is per-polynomial).
+namespace {
+class CopyPool {  // a few host threads that memcpy slices; process-wide, started on first use
+ public:
+  static CopyPool &get() {
+    static CopyPool *p = new CopyPool();  // (leaked on purpose: worker threads must not be joined from a static destructor)
+    return *p;
+  }
+  void copy(void *dst, const void *src, size_t bytes) {
+    const size_t slice = 1 << 20;
+    const size_t parts = (bytes + slice - 1) / slice;
+    if (parts <= 1 || workers_.empty()) {
+      std::memcpy(dst, src, bytes);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    dst_ = (char *)dst;
+    src_ = (const char *)src;
+    bytes_ = bytes;
+    slice_ = slice;
+    next_ = 0;
+    parts_ = parts;
+    done_ = 0;
+    ++generation_;
+    cv_.notify_all();
+    lk.unlock();
+    work();  // the calling thread copies too
+    lk.lock();
+    cv_done_.wait(lk, [&] { return done_ == parts_; });
+  }
+
+ private:
+  CopyPool() {
+    unsigned n = std::thread::hardware_concurrency();
+    n = n > 16 ? 7 : (n > 2 ? n / 2 - 1 : 0);  // + the caller: 8 copying threads on a server host
+    for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); }), workers_.back().detach();
+  }
+  void work() {
+    for (;;) {
+      size_t k;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (next_ >= parts_) return;
+        k = next_++;
+      }
+      const size_t off = k * slice_, len = bytes_ - off < slice_ ? bytes_ - off : slice_;
+      std::memcpy(dst_ + off, src_ + off, len);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (++done_ == parts_) cv_done_.notify_all();
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      work();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, cv_done_;
+  std::vector<std::thread> workers_;
+  char *dst_ = nullptr;
+  const char *src_ = nullptr;
+  size_t bytes_ = 0, slice_ = 0, next_ = 0, parts_ = 0, done_ = 0;
+  unsigned long long generation_ = 0;
+};
+}  // namespace
+
+struct HostPipe {
+  static constexpr int kSlots = 3, kBufs = 4;            // per slot: up to 3 inputs + 1 output
+  static constexpr size_t kChunkBytes = size_t(8) << 20;  // per operand and slot
+  void *pinned[kSlots][kBufs] = {};
+  void *dev[kSlots][kBufs] = {};
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  hipEvent_t ev_h2d[kSlots] = {}, ev_k[kSlots] = {}, ev_d2h[kSlots] = {};
+  ~HostPipe() {
+    for (int s = 0; s < kSlots; ++s) {
+      for (int b = 0; b < kBufs; ++b) {
+        if (pinned[s][b]) (void)hipHostFree(pinned[s][b]);
+        if (dev[s][b]) (void)hipFree(dev[s][b]);
+      }
+      if (ev_h2d[s]) (void)hipEventDestroy(ev_h2d[s]);
+      if (ev_k[s]) (void)hipEventDestroy(ev_k[s]);
+      if (ev_d2h[s]) (void)hipEventDestroy(ev_d2h[s]);
+    }
+    if (s_h2d) (void)hipStreamDestroy(s_h2d);
+    if (s_d2h) (void)hipStreamDestroy(s_d2h);
+  }
+};
+
+static void pipe_destroy(nflhip_ctx *ctx) {
+  delete ctx->pipe;
+  ctx->pipe = nullptr;
+}
+
+static int pipe_get(nflhip_ctx *ctx, HostPipe **out) {
+  if (!ctx->pipe) {
+    std::unique_ptr<HostPipe> p(new (std::nothrow) HostPipe());
+    if (!p) return fail(ctx, NFLHIP_ERR_NOMEM, "out of host memory");
+    HIPCHK(ctx, hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking));
+    for (int s = 0; s < HostPipe::kSlots; ++s) {
+      for (int b = 0; b < HostPipe::kBufs; ++b) {
+        HIPCHK(ctx, hipHostMalloc(&p->pinned[s][b], HostPipe::kChunkBytes, hipHostMallocDefault));
+        HIPCHK(ctx, hipMalloc(&p->dev[s][b], HostPipe::kChunkBytes));
+      }
+      HIPCHK(ctx, hipEventCreateWithFlags(&p->ev_h2d[s], hipEventDisableTiming));
+      HIPCHK(ctx, hipEventCreateWithFlags(&p->ev_k[s], hipEventDisableTiming));
+      HIPCHK(ctx, hipEventCreateWithFlags(&p->ev_d2h[s], hipEventDisableTiming));
+    }
+    ctx->pipe = p.release();
+  }
+  *out = ctx->pipe;
+  return NFLHIP_OK;
+}
+
+// in[j] (nin <= 3 host arrays of `batch` polynomials) -> out (host array); launch(d_in[], d_out, count, stream) enqueues
+// the per-polynomial operation on a chunk.  Caller holds ctx->mu.  Returns NFLHIP_ERR_UNSUPPORTED when the batch is too
+// small to pipeline (the simple staged path then serves it).
+template <typename F>
+static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, int nin, void *out, F launch) {
+  const size_t pb = poly_bytes(ctx, 1);
+  const size_t per = HostPipe::kChunkBytes / pb;  // polynomials per chunk
+  if (per == 0 || batch < 2 * per) return NFLHIP_ERR_UNSUPPORTED;
+  HostPipe *p = nullptr;
+  int rc = pipe_get(ctx, &p);
+  if (rc) return rc;
+  CopyPool &pool = CopyPool::get();
+  const size_t nchunks = (batch + per - 1) / per;
+  auto count_of = [&](size_t k) { return k + 1 < nchunks ? per : batch - k * per; };
+  auto drain = [&](size_t k) -> int {  // chunk k is back in its pinned slot: hand it to the caller
+    const int s = int(k % HostPipe::kSlots);
+    HIPCHK(ctx, hipEventSynchronize(p->ev_d2h[s]));
+    pool.copy((char *)out + k * per * pb, p->pinned[s][3], count_of(k) * pb);
+    return NFLHIP_OK;
+  };
+  for (size_t k = 0; k < nchunks; ++k) {
+    const int s = int(k % HostPipe::kSlots);
+    if (k >= size_t(HostPipe::kSlots) && (rc = drain(k - HostPipe::kSlots))) return rc;  // the slot's previous tenant
+    const size_t cnt = count_of(k), bytes = cnt * pb;
+    const void *d_in[3] = {nullptr, nullptr, nullptr};
+    for (int j = 0; j < nin; ++j) {
+      // (aliased operands -- polymul(a, a) -- are staged once)
+      int same = -1;
+      for (int i = 0; i < j; ++i)
+        if (in[i] == in[j]) same = i;
+      if (same >= 0) { d_in[j] = d_in[same]; continue; }
+      pool.copy(p->pinned[s][j], (const char *)in[j] + k * per * pb, bytes);
+      HIPCHK(ctx, hipMemcpyAsync(p->dev[s][j], p->pinned[s][j], bytes, hipMemcpyHostToDevice, p->s_h2d));
+      d_in[j] = p->dev[s][j];
+    }
+    HIPCHK(ctx, hipEventRecord(p->ev_h2d[s], p->s_h2d));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->hstream, p->ev_h2d[s], 0));
+    rc = launch(d_in, p->dev[s][3], cnt, (void *)ctx->hstream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(p->ev_k[s], ctx->hstream));
+    HIPCHK(ctx, hipStreamWaitEvent(p->s_d2h, p->ev_k[s], 0));
+    HIPCHK(ctx, hipMemcpyAsync(p->pinned[s][3], p->dev[s][3], bytes, hipMemcpyDeviceToHost, p->s_d2h));
+    HIPCHK(ctx, hipEventRecord(p->ev_d2h[s], p->s_d2h));
+    // the next H2D into this slot's device inputs must not overtake this chunk's kernel
+    HIPCHK(ctx, hipStreamWaitEvent(p->s_h2d, p->ev_k[s], 0));
+  }
+  for (size_t k = nchunks > size_t(HostPipe::kSlots) ? nchunks - HostPipe::kSlots : 0; k < nchunks; ++k)
+    if ((rc = drain(k))) return rc;
+  return NFLHIP_OK;
+}
+
+extern "C" {
+
 struct Staged {
   nflhip_ctx *ctx;
   std::unique_lock<std::mutex> lk;
@@ -1369,7 +1558,13 @@ int nflhip_ntt_fwd(nflhip_ctx *ctx, void *h, size_t batch) {
   if (!h) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
   Staged s(ctx);
   const size_t bytes = poly_bytes(ctx, batch);
-  int rc = s.in(0, h, bytes);
+  const void *ins[1] = {h};
+  int rc = run_pipelined(ctx, batch, ins, 1, h, [&](const void *const *d, void *o, size_t cnt, void *st) {
+    HIPCHK(ctx, hipMemcpyAsync(o, d[0], poly_bytes(ctx, cnt), hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return nflhip_ntt_fwd_dev(ctx, o, cnt, st);
+  });
+  if (rc != NFLHIP_ERR_UNSUPPORTED) return rc;
+  rc = s.in(0, h, bytes);
   if (rc) return rc;
   rc = nflhip_ntt_fwd_dev(ctx, ctx->stage[0], batch, ctx->hstream);
   if (rc) return rc;
@@ -1381,7 +1576,13 @@ int nflhip_ntt_inv(nflhip_ctx *ctx, void *h, size_t batch) {
   if (!h) return fail(ctx, NFLHIP_ERR_INVALID, "NULL data pointer");
   Staged s(ctx);
   const size_t bytes = poly_bytes(ctx, batch);
-  int rc = s.in(0, h, bytes);
+  const void *ins[1] = {h};
+  int rc = run_pipelined(ctx, batch, ins, 1, h, [&](const void *const *d, void *o, size_t cnt, void *st) {
+    HIPCHK(ctx, hipMemcpyAsync(o, d[0], poly_bytes(ctx, cnt), hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return nflhip_ntt_inv_dev(ctx, o, cnt, st);
+  });
+  if (rc != NFLHIP_ERR_UNSUPPORTED) return rc;
+  rc = s.in(0, h, bytes);
   if (rc) return rc;
   rc = nflhip_ntt_inv_dev(ctx, ctx->stage[0], batch, ctx->hstream);
   if (rc) return rc;
@@ -1407,7 +1608,12 @@ int nflhip_pointwise(nflhip_ctx *ctx, int op, void *o, const void *a, const void
     return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
   Staged s(ctx);
   const size_t bytes = poly_bytes(ctx, batch);
-  int rc = s.in(0, a, bytes);
+  const void *ins[3] = {a, op != NFLHIP_OP_COMPUTE_SHOUP ? b : a, op == NFLHIP_OP_MUL_SHOUP ? bp : a};
+  int rc = run_pipelined(ctx, batch, ins, 3, o, [&](const void *const *d, void *out, size_t cnt, void *st) {
+    return nflhip_pointwise_dev(ctx, op, out, d[0], d[1], d[2], cnt, st);
+  });
+  if (rc != NFLHIP_ERR_UNSUPPORTED) return rc;
+  rc = s.in(0, a, bytes);
   if (rc) return rc;
   if (op != NFLHIP_OP_COMPUTE_SHOUP && (rc = s.in(1, b, bytes))) return rc;
   if (op == NFLHIP_OP_MUL_SHOUP && (rc = s.in(2, bp, bytes))) return rc;
@@ -1425,6 +1631,14 @@ int nflhip_eval(nflhip_ctx *ctx, void *h_out, const void *const *h_operands, siz
   if (!h_out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL output");
   Staged s(ctx);
   const size_t bytes = poly_bytes(ctx, batch);
+  for (size_t i = 0; i < noperands; ++i)
+    if (!h_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  {
+    int prc = run_pipelined(ctx, batch, h_operands, (int)noperands, h_out, [&](const void *const *d, void *out, size_t cnt, void *st) {
+      return eval_dev(ctx, out, d, noperands, program, proglen, cnt, st);
+    });
+    if (prc != NFLHIP_ERR_UNSUPPORTED) return prc;
+  }
   const void *dops[3] = {nullptr, nullptr, nullptr};
   for (size_t i = 0; i < noperands; ++i) {
     if (!h_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
@@ -1445,7 +1659,12 @@ int nflhip_polymul(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_
   if (!c || !a || !b) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
   Staged s(ctx);
   const size_t bytes = poly_bytes(ctx, batch);
-  int rc = s.in(0, a, bytes);
+  const void *ins[2] = {a, b};
+  int rc = run_pipelined(ctx, batch, ins, 2, c, [&](const void *const *d, void *out, size_t cnt, void *st) {
+    return nflhip_polymul_dev(ctx, out, d[0], d[1], cnt, st);
+  });
+  if (rc != NFLHIP_ERR_UNSUPPORTED) return rc;
+  rc = s.in(0, a, bytes);
   if (rc) return rc;
   if ((rc = s.in(1, b, bytes))) return rc;
   rc = nflhip_polymul_dev(ctx, ctx->stage[0], ctx->stage[0], ctx->stage[1], batch, ctx->hstream);

@@ -550,6 +550,35 @@ def test_host_pointer_calls_of_many_sizes_match_the_resident_path(engine_factory
     assert np.array_equal(e2.h_intt(e2.h_ntt(e2.to_host(a))), e2.to_host(a))
 
 
+@pytest.mark.parametrize("lb,n,m,batches", [(64, 4096, 4, (128, 129, 200, 453)), (32, 1024, 2, (2048, 5000)), (16, 128, 1, (65536, 70001)),
+                                            (64, 32768, 2, (32, 37))])
+def test_large_host_pointer_calls_through_the_pinned_pipeline(lb, n, m, batches, oracle_factory, engine_factory):
+    """Host arrays of two or more 8 MiB chunks per operand take the pipelined path (pinned staging slots, host threads
+    copying chunk k + 1 while chunk k crosses PCIe, chunk k - 1 is computed and chunk k - 2 returns): every entry point
+    that uses it against the resident path over the same words (chunk boundaries, the short last chunk, in-place
+    transforms, operands that alias each other) -- and a sample against the oracle."""
+    from nfllib_amd import OP_ADD, OP_MUL, OP_MUL_SHOUP, OP_COMPUTE_SHOUP
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    for batch in batches:
+        a = e.fill_uniform(e.empty(batch), SEED + batch, 0)
+        b = e.fill_uniform(e.empty(batch), SEED + batch, 1)
+        ha, hb = e.to_host(a), e.to_host(b)
+        hc = e.h_polymul(ha, hb)
+        assert np.array_equal(hc, e.to_host(e.polymul(a, b))), batch
+        for k in (0, batch // 2, batch - 1):   # first, a middle and the last (short) chunk against the CPU checker
+            assert np.array_equal(hc[k:k + 1], o.polymul(ha[k:k + 1], hb[k:k + 1])), (batch, k)
+        assert np.array_equal(e.h_polymul(ha, ha), e.to_host(e.polymul(a, a))), batch          # aliased operands
+        f = e.h_ntt(ha)
+        assert np.array_equal(f, e.to_host(e.ntt_(a.clone()))), batch
+        assert np.array_equal(e.h_intt(f), ha), batch
+        assert np.array_equal(e.h_pointwise(OP_ADD, ha, hb), e.to_host(e.pointwise(OP_ADD, a, b))), batch
+        assert np.array_equal(e.h_pointwise(OP_MUL, ha, hb), e.to_host(e.pointwise(OP_MUL, a, b))), batch
+        hbp = e.h_pointwise(OP_COMPUTE_SHOUP, hb)
+        assert np.array_equal(e.h_pointwise(OP_MUL_SHOUP, ha, hb, hbp), e.to_host(e.pointwise(OP_MUL, a, b))), batch
+        prog = [0, 1, 0x12, 2, 0x10]                                                              # a * b + c
+        assert np.array_equal(e.h_eval(prog, [ha, hb, hc]), e.to_host(e.eval(prog, [a, b, e.to_device(hc)]))), batch
+
+
 @pytest.mark.parametrize("lb,n,m,batch", [(64, 131072, 2, 2), (64, 262144, 1, 1), (64, 1048576, 1, 1), (32, 16384, 2, 2)])
 def test_degrees_beyond_the_baseline_shapes(lb, n, m, batch, oracle_factory, engine_factory):
     """Up to params<uint64_t>::kMaxPolyDegree = 2^20 (params.hpp:98-99): two and more streaming passes around the

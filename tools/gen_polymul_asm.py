@@ -123,6 +123,7 @@ def interleave(em, gens):
 
 
 SINGLE_STREAM = False   # ring mode: one butterfly at a time (18 temporaries instead of 36)
+RING_RECOMPUTE_TWA = False
 
 
 def run_pairs(em, jobs):
@@ -199,7 +200,13 @@ def fold2(s, dst, src):
     yield "v_lshrrev_b32_e32 v%d, 30, v%d" % (t, src + 1), None, None
     # (the mask comes from a VGPR: plain VOP2 add / sub / and / mov / lshr issue in ~2.5 cycles per wave64 when every
     # operand is a VGPR and in ~4.4 with an SGPR operand -- profiles/r03_ubench_issue.txt)
-    yield "v_and_b32_e32 v%d, v%d, v%d" % (src + 1, v_mask(), src + 1), None, None
+    # (the mask stays in an SGPR.  The isolated streams of tools/ubench_issue.hip price a plain VOP2 op with an SGPR operand
+    # at 4.4 cycles and an all-VGPR one at 2.5, but IN the metric kernel the VGPR form costs 5.3 % MORE cycles per launch
+    # (GRBM_GUI_ACTIVE 6.04 M vs 5.73 M per XCD, same box, profiles/r03_operand_ab.txt); NFL_GEN_VGPR_OPERANDS=1 rebuilds it)
+    if os.environ.get("NFL_GEN_VGPR_OPERANDS"):
+        yield "v_and_b32_e32 v%d, v%d, v%d" % (src + 1, v_mask(), src + 1), None, None
+        return
+    yield "v_and_b32_e32 v%d, %s, v%d" % (src + 1, S_MASK, src + 1), None, None
     yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(dst), S_DUMMY, t, S_DELTA, vp(src)), None, None
 
 
@@ -587,7 +594,8 @@ def prologue(em, vm, kind="polymul"):
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
-    em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
+    if os.environ.get("NFL_GEN_VGPR_OPERANDS"):
+        em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
     return tw_seq
 
@@ -816,16 +824,17 @@ class Ring:
             return
         kreg, vidx, desc = self.passes[name][:3]
         koff = self.passes[name][3] if len(self.passes[name]) > 3 else 0
-        if self.cur != (name, s):
+        fresh = self.cur != (name, s)
+        if fresh:
             tw_base(em, kreg, s, desc, koff)
             if vidx is not None:
                 em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
-                if desc:
-                    em.valu("v_mov_b32_e32 v%d, s84" % (V_TWA,))
-                    em.valu("v_mov_b32_e32 v%d, s85" % (V_TWA + 1,))
-                    em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (V_TWA, V_TWA, V_TWO), "vcc", None)
-                    em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (V_TWA + 1, V_TWA + 1), "vcc", "vcc")
             self.cur = (name, s)
+        if vidx is not None and desc and (fresh or RING_RECOMPUTE_TWA):   # (the address pair is butterfly scratch in ringpair mode)
+            em.valu("v_mov_b32_e32 v%d, s84" % (V_TWA,))
+            em.valu("v_mov_b32_e32 v%d, s85" % (V_TWA + 1,))
+            em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (V_TWA, V_TWA, V_TWO), "vcc", None)
+            em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (V_TWA + 1, V_TWA + 1), "vcc", "vcc")
         off = -g * 16 if desc else g * 16
         if vidx is None:
             text = "global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_ZERO, S_BASE2, off)
@@ -863,10 +872,20 @@ def configure(mode, groups=4):
         g.update(SINGLE_STREAM=False, V_BIDX=5, V_PHI=6, V_A=8, V_B=40, V_TW=72, V_T=[132, 150], NEXT_VGPR=168,
                  NEXT_SGPR=96, LDS_BYTES=SLAB_BYTES, WG_SIZE=256)
         g.update(V_TWO=g["V_T"][1] + 1, V_TWA=g["V_T"][1] + 4, V_ZERO=g["V_T"][0] + 15)
+    elif mode == "ringpair":
+        # experiment (NFL_GEN_RINGPAIR=1): the 128-VGPR row kernels with TWO interleaved butterflies and a 5-slot ring instead
+        # of one butterfly at a time and 9 slots; the twiddle address scratch lives in stream 1's temporaries
+        g.update(SINGLE_STREAM=False, V_BIDX=5, V_PHI=6, V_A=8, V_B=40, V_TW=72, V_T=[92, 110], NEXT_VGPR=128, NEXT_SGPR=96,
+                 RING_SLOTS=5, LDS_BYTES=groups * SLAB_BYTES, WG_SIZE=256 * groups, ROW_G=groups,
+                 ROW_LG=groups.bit_length() - 1, RING_RECOMPUTE_TWA=True)
+        g.update(V_TWO=g["V_T"][1] + 1, V_TWA=g["V_T"][1] + 4, V_ZERO=g["V_T"][0] + 15)
+        g["S_K0"].update(F0="s98", I0="s99")   # (s46 / s47 are stream 1's carry pair here)
+        g["NEXT_SGPR"] = 100
     else:
+        g["S_K0"].update(F0="s46", I0="s47")
         g.update(SINGLE_STREAM=True, V_BIDX=5, V_PHI=6, V_TWO=7, V_TWA=8, V_A=10, V_B=42, V_TW=74, V_T=[110, 110],
                  NEXT_VGPR=128, NEXT_SGPR=96, RING_SLOTS=9, LDS_BYTES=groups * SLAB_BYTES, WG_SIZE=256 * groups,
-                 ROW_G=groups, ROW_LG=groups.bit_length() - 1)
+                 ROW_G=groups, ROW_LG=groups.bit_length() - 1, RING_RECOMPUTE_TWA=False)
         g.update(V_ZERO=g["V_T"][0] + 15)
 
 
@@ -898,7 +917,8 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
     for reg in (V_L1W, V_L1R, V_L2R):
         em.valu("v_add_u32_e32 v%d, %s, v%d" % (reg, S_SLAB, reg))                  # inside the sub-group's slab
-    em.valu("v_mov_b32_e32 v%d, 0" % (V_ZERO,))
+    for t_ in sorted(set(V_T)):
+        em.valu("v_mov_b32_e32 v%d, 0" % (t_ + 15,))                                # the persistent zero of each stream's ZP pair
     R("s_waitcnt lgkmcnt(0)")
     # G = ROW_G sub-groups, LG = log2 G: r = logn - 12 (>= LG); wgx = poly * 2^(r-LG) + blkG;
     # (4096 G)-word block = ((poly*nm + cm) << (r-LG)) + blkG
@@ -1007,7 +1027,8 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
-    em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
+    if os.environ.get("NFL_GEN_VGPR_OPERANDS"):
+        em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
 
 def build_row16k(kind="polymul", stop=None):
@@ -1205,7 +1226,7 @@ def build_row16k(kind="polymul", stop=None):
 # canonical) STREAMED through the twiddle ring during the point-wise step -- the large-row product is then
 # b' = fwd(b) (read + write) followed by polymul_ntt(a, b') (two reads + one write): 5 operand passes instead of 9.
 def build_row32k(kind="fwd"):
-    assert SINGLE_STREAM and ROW_G == 4 and ROW_LG == 3
+    assert ROW_G == 4 and ROW_LG == 3 and NEXT_VGPR == 128
     em = Emitter()
     vm = VmCounter(em)
     R = em.raw
@@ -1478,7 +1499,8 @@ def emit_consts(em):
     R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
     R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
     em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
-    em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
+    if os.environ.get("NFL_GEN_VGPR_OPERANDS"):
+        em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
 
 def legacy_role_map(em, PER_ROW, NV, NSW):
@@ -2522,17 +2544,18 @@ def main():
                   args=ARGS_PIPE, lds=LDS_BYTES + 64)
     FUSED_LIFO = False
     build_pipe(16)   # (leave the module-level PIPE_LOGN as it was)
-    configure("ring", 4)
+    ring = "ringpair" if os.environ.get("NFL_GEN_RINGPAIR") else "ring"
+    configure(ring, 4)
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
-    configure("ring", 2)         # 8192-word rows: two sub-groups, 512 threads, one radix-2 stage around the blocks
+    configure(ring, 2)         # 8192-word rows: two sub-groups, 512 threads, one radix-2 stage around the blocks
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem.replace("16384", "8192") + "_gfx950.s"), kname.replace("16384", "8192"),
                   build_row16k(kind))
-    configure("ring", 4)
+    configure(ring, 4)
     # 32768-word rows: one operand register-resident in a 1024-thread workgroup (4 sub-groups x 2 blocks)
     g = globals()
-    g.update(ROW_LG=3, NEXT_SGPR=98)
+    g.update(ROW_LG=3, NEXT_SGPR=max(NEXT_SGPR, 98))
     for kind, stem in (("fwd", "ntt_fwd32768"), ("inv", "ntt_inv32768"), ("polymul_ntt", "polymul_ntt32768")):
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind))
     configure("ring", 4)

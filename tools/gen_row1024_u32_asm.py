@@ -37,6 +37,23 @@ V_PW = 112           # point-wise temp pair
 V_P, V_2P = 116, 117  # p and 2p once more, in VGPRs: a plain VOP2 add / sub issues in ~2.5 cycles per wave64 with VGPR operands
                       # only and in ~4.4 with an SGPR operand (profiles/r03_ubench_issue.txt)
 NEXT_VGPR = 118
+# p / 2p of the plain subtractions and additions stay SGPR operands: the all-VGPR form (which isolated streams price at
+# 2.5 instead of 4.4 cycles, tools/ubench_issue.hip) changes nothing in the kernel -- 4.454 M vs 4.443 M cycles per launch and
+# XCD, 236.6 vs 237.4 M products/s on the same box (profiles/r03_operand_ab.txt).  NFL_GEN_VGPR_OPERANDS=1 rebuilds it.
+SGPR_OPERANDS = not os.environ.get("NFL_GEN_VGPR_OPERANDS")
+
+
+def sub_const(dst, src, which):
+    """dst = src - {p, 2p}"""
+    if SGPR_OPERANDS:
+        return "v_subrev_u32_e32 v%d, s%d, v%d" % (dst, which, src)
+    return "v_sub_u32_e32 v%d, v%d, v%d" % (dst, src, {S_P: V_P, S_2P: V_2P}[which])
+
+
+def add_2p(reg):
+    if SGPR_OPERANDS:
+        return "v_add_u32_e32 v%d, s%d, v%d" % (reg, S_2P, reg)
+    return "v_add_u32_e32 v%d, v%d, v%d" % (reg, V_2P, reg)
 NEXT_SGPR = 80
 SLAB = 1088 * 4      # bytes of LDS per 1024 row words (the padding of either exchange layout included)
 
@@ -60,7 +77,7 @@ def ct(x, y, tw):
 
     def gen(s):
         T0, Q, T2 = V_S[s], V_S[s] + 1, V_S[s] + 2
-        yield "v_sub_u32_e32 v%d, v%d, v%d" % (T0, x, V_2P), None, None
+        yield sub_const(T0, x, S_2P), None, None
         yield "v_min_u32_e32 v%d, v%d, v%d" % (x, x, T0), None, None
         yield "v_mul_hi_u32 v%d, v%d, %s" % (Q, y, wp), None, None
         yield "v_lshl_add_u32 v%d, v%d, 1, s%d" % (T2, x, S_2P), None, None
@@ -80,8 +97,8 @@ def gs(x, y, tw, xsrc=None, ysrc=None):
         T0, Q, D, S = V_S[s], V_S[s] + 1, V_S[s] + 2, V_S[s] + 3
         yield "v_add_u32_e32 v%d, v%d, v%d" % (S, xs, ys), None, None
         yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, ys, xs), None, None
-        yield "v_add_u32_e32 v%d, v%d, v%d" % (D, V_2P, D), None, None
-        yield "v_sub_u32_e32 v%d, v%d, v%d" % (T0, S, V_2P), None, None
+        yield add_2p(D), None, None
+        yield sub_const(T0, S, S_2P), None, None
         yield "v_min_u32_e32 v%d, v%d, v%d" % (x, S, T0), None, None
         yield "v_mul_hi_u32 v%d, v%d, %s" % (Q, D, wp), None, None
         yield "v_mad_u64_u32 %s, %s, v%d, s%d, 0" % (pair(y), S_DUMMY, Q, S_NEGP), None, None
@@ -91,7 +108,7 @@ def gs(x, y, tw, xsrc=None, ysrc=None):
 
 def csub(reg, dst, bound_sgpr, s):
     T0 = V_S[s]
-    yield "v_sub_u32_e32 v%d, v%d, v%d" % (T0, reg, {S_P: V_P, S_2P: V_2P}[bound_sgpr]), None, None
+    yield sub_const(T0, reg, bound_sgpr), None, None
     yield "v_min_u32_e32 v%d, v%d, v%d" % (dst, reg, T0), None, None
 
 
@@ -126,7 +143,7 @@ def last(u, x):
         D, S = V_S[s] + 2, V_S[s] + 3
         yield "v_add_u32_e32 v%d, v%d, v%d" % (S, u, x), None, None
         yield "v_sub_u32_e32 v%d, v%d, v%d" % (D, x, u), None, None
-        yield "v_add_u32_e32 v%d, v%d, v%d" % (D, V_2P, D), None, None
+        yield add_2p(D), None, None
         yield from mul_shoup_exact(S, u, S_NINV, S_NINVSH, s)
         yield from mul_shoup_exact(D, x, S_W1N, S_W1NSH, s)
     return gen
@@ -226,8 +243,9 @@ def build(LB=4, mode="polymul"):
     R("s_waitcnt lgkmcnt(0)")
     R("s_mov_b32 s%d, s56" % S_P)
     R("s_mov_b32 s%d, s57" % S_2P)
-    V("v_mov_b32_e32 v%d, s56" % V_P)
-    V("v_mov_b32_e32 v%d, s57" % V_2P)
+    if not SGPR_OPERANDS:
+        V("v_mov_b32_e32 v%d, s56" % V_P)
+        V("v_mov_b32_e32 v%d, s57" % V_2P)
     R("s_sub_u32 s%d, 0, s56" % S_NEGP)
     R("s_mov_b32 s%d, s58" % S_MU)
     R("s_mov_b32 s%d, s59" % S_NINV)
