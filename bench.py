@@ -406,9 +406,9 @@ def main():
         # the host-pointer entry point (nflhip_polymul: pageable host buffers in and out, PCIe included) -- never `value`
         hb = min(batch, max(1, (256 << 20) // (nm * n * w)))
         ha, hbb = eng.to_host(a[:hb]), eng.to_host(b[:hb])
-        eng.h_polymul(ha, hbb)
+        hcc = eng.h_polymul(ha, hbb)          # (also touches the result array's pages: the caller's arrays exist before the call)
         t0h = time.perf_counter()
-        eng.h_polymul(ha, hbb)
+        eng.h_polymul(ha, hbb, out=hcc)
         t_host = time.perf_counter() - t0h
         # core::ntt (core.hpp:455-532), the cyclic row transform tests/ntt_perfs.cpp:155-171 times on
         # poly<uint64_t,1024,2> rows (BASELINE configs[0]'s path): nflhip_ntt_row_dev over resident rows of one modulus

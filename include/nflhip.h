@@ -16,6 +16,14 @@
  * is NO CPU fallback: without a usable GPU every compute call fails with
  * NFLHIP_ERR_NO_DEVICE.
  *
+ * Environment (all of it; every variable is read ONCE, when a context / communicator is created)
+ *   NFLHIP_VARIANT=hipcc   the context serves every call with the compiled (hipcc) kernels instead of the generated
+ *                          gfx950 assembly kernels: the independent cross-check the tests use (bit-identical results)
+ *   NFLHIP_XCD=0|1         rows of 32768 / 65536 words: never / always the one-launch plan of persistent workgroups
+ *                          (default: by batch size)
+ *   NFLHIP_COMM_PIECE_BYTES  upper bound of one RCCL message of nflhip_scatter_dev / nflhip_gather_dev (default 1 GiB)
+ * Test hooks are entry points of their own (include/nflhip_debug.h), not environment variables.
+ *
  * Pointer conventions
  *   *_dev entry points take DEVICE pointers and a hipStream_t (passed as
  *   void*; NULL = the null stream) and are asynchronous on that stream.

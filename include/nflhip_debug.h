@@ -1,0 +1,29 @@
+/* nflhip_debug.h -- test hooks of libnflhip.so.  NOT part of the product boundary (include/nflhip.h): nothing in
+ * include/nfl_hip/nfl.hpp, nfllib_amd/ or bench.py calls these; tests do (tests/test_gpu_xcd.py, tests/test_gpu_samplers.py).
+ * They exist so that the library reads no test knobs from the environment. */
+#ifndef NFLHIP_DEBUG_H
+#define NFLHIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of launches of the one-launch plan (persistent workgroups, rows of 32768 / 65536 words) issued by this process:
+ * lets a test assert WHICH plan served a call */
+unsigned long long nflhip_debug_xcd_launches(void);
+
+/* the Gaussian samplers compare the top 64 bits of a uniform number with the top word of a table entry and fetch the
+ * number's lower words only on a tie (2^-64 per entry).  shift > 0 makes the comparison treat words that agree in their
+ * top (64 - shift) bits as ties, so that the tie path runs on nearly every sample -- the VALUE drawn does not change.
+ * 0 restores production behaviour. */
+void nflhip_debug_gauss_tie_shift(int shift);
+
+/* where the pipelined host-pointer path of this context spent its time so far (seconds): out[0] host threads copying
+ * caller memory into the pinned slots, out[1] copying results out, out[2] waiting for the device, out[3] inside the calls */
+struct nflhip_ctx;
+void nflhip_debug_host_pipe_seconds(const struct nflhip_ctx *ctx, double out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFLHIP_DEBUG_H */

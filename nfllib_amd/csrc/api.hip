@@ -2,10 +2,12 @@
 // and the host/device entry points.  No CPU compute path exists here: every
 // operation is a launch of a gfx950 kernel (kernels_generic.hip / kernels_fast.hip).
 #include "../../include/nflhip.h"
+#include "../../include/nflhip_debug.h"
 
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -379,42 +381,18 @@ static int ensure_scratch(nflhip_ctx *ctx, size_t bytes) {
   return NFLHIP_OK;
 }
 
-// NFLHIP_PIPE_CHUNKS: chunks of a batch in the n = 65536 pipeline (0 = use the three-kernel plan instead)
-static int pipe64k_chunks() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("NFLHIP_PIPE_CHUNKS");
-    v = e ? atoi(e) : 4;
-    if (v < 0) v = 0;
-  }
-  return v;
-}
-
-// NFLHIP_PIPE32K=0: rows of 32768 words use the three-kernel plan instead of the pipeline kernel (A/B switch)
-static int pipe32k_on() {
-  static const int v = getenv("NFLHIP_PIPE32K") ? atoi(getenv("NFLHIP_PIPE32K")) : 1;
-  return v;
-}
-
-// NFLHIP_U16_ASM=0: the generic kernels instead of the generated assembly kernels of 16-bit limbs, n = 128 (A/B switch,
-// bit-identical; read on every call so that a test can flip it)
-static bool u16_asm_on() {
-  const char *ua = getenv("NFLHIP_U16_ASM");
-  return !ua || atoi(ua) != 0;
-}
+// chunks of a batch in the n = 65536 pipeline (fill + drain cost ~0.7 chunk; small grids lose efficiency: 4 measured best)
+static constexpr int kPipeChunks = 4;
 
 // Rows of 65536 / 32768 words in ONE launch of persistent workgroups (kernels_fast.hip launch_polymul_xcd_u64) instead
-// of the chunked pipeline.  NFLHIP_XCD: 0 never, 1 always, unset = when the batch has at most NFLHIP_XCD_MAX_ROWS rows
-// (the pipeline's fill and drain launches dominate small batches; measured crossover in DESIGN.md).  Read on every
-// call, so a test can switch it.
+// of the chunked pipeline / the register-resident row kernels: by default for SMALL batches, where the other plans'
+// fill and drain launches (n = 65536) or the one-workgroup-per-row grid (n = 32768) leave CUs idle.  Measured (MI355X):
+// n = 65536 / 30 moduli +5 % at batch 4, +11 % at 8, +-0 at 16, -2 % at 64; n = 32768 / 2 moduli against the row
+// kernels 68 vs 58 k products/s at batch 8, 302 vs 223 k at 32, 622 vs 716 k at 128.  Shape::plan (NFLHIP_XCD at context
+// creation) forces either.
 static bool xcd_on(const nflhip_ctx *ctx, size_t batch) {
-  const char *e = getenv("NFLHIP_XCD");
-  if (e) return atoi(e) != 0;
-  const char *m = getenv("NFLHIP_XCD_MAX_ROWS");
-  // measured (MI355X): n = 32768 / 2 moduli +23 % at batch 64, +18 % at 128, +6 % at 256, +2 % at 512, -2 % at 2048;
-  // n = 65536 / 30 moduli +5 % at batch 4, +11 % at 8, +-0 at 16, -2 % at 64
-  const size_t max_rows = m ? (size_t)atoll(m) : (ctx->shape.logn == 15 ? 1024 : 256);
-  return batch * ctx->shape.nm <= max_rows;
+  if (ctx->shape.plan >= 0) return ctx->shape.plan != 0;
+  return batch * ctx->shape.nm <= (ctx->shape.logn == 15 ? 255u : 256u);
 }
 
 // hipGraph capture: the entry points only enqueue work on the caller's stream, so they can be captured.  The
@@ -443,7 +421,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   const bool cap = is_capturing(st);
   // (from 256 rows on; below that the one-launch plan further down spreads a row over more CUs -- measured, same box:
   // batch 8 / 32 / 128 / 512 of two moduli 58 / 223 / 716 / 785 k products/s here against 68 / 302 / 622 / 779 k)
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 15 && row32k_on() && batch * ctx->shape.nm >= 256) {
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 15 && !xcd_on(ctx, batch)) {
     // rows of 32768 words: b' = NTT(b) into the scratch (one read, one write), then c = INTT(NTT(a) (.) b') with the row
     // of a register-resident and b' streamed through the point-wise step (two reads, one write): 5 operand passes
     int rcs = ensure_scratch(ctx, bytes);
@@ -491,12 +469,12 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
-  if (sizeof(T) == 8 && !b_is_ntt && (ctx->shape.logn == 16 || (ctx->shape.logn == 15 && pipe32k_on())) && pipe64k_chunks() > 0) {
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 16) {
     // n = 65536: the streaming passes (HBM-bound) and the fused block kernel (VALU-bound) of neighbouring chunks share
     // every CU inside ONE kernel whose workgroups take three roles; consecutive launches on the caller's stream form the
     // pipeline: launch L = forward pass of chunk L, block products of chunk L-1, inverse pass of chunk L-2.
     const size_t pw = ctx->shape.nm * ctx->shape.n;
-    size_t nchunk = (size_t)pipe64k_chunks();  // fill + drain cost ~0.7 chunk; small grids lose efficiency: 4 measured best
+    size_t nchunk = (size_t)kPipeChunks;
     if (nchunk * 2 > batch) nchunk = batch >= 2 ? batch / 2 : 1;
     auto lo_of = [&](size_t ch) { return batch * ch / nchunk; };
     bool supported = true;
@@ -536,7 +514,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       if (!cap && ctx->ev_prev_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->ev_done[1 - k], 0));  // previous call's scratch use
     }
     bool unsupported = false;
-    int logi = (ctx->shape.logn > 14 && row16k_level() >= 2) ? 14 : 12;  // words (log2) per block of the fused kernel
+    const int logi = 12;  // words (log2) per block of the fused kernel
     for (size_t ch = 0; ch < nchunk && !unsupported; ++ch) {
       const size_t lo = batch * ch / nchunk, hi = batch * (ch + 1) / nchunk, cnt = hi - lo;
       if (cnt == 0) continue;
@@ -547,13 +525,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       if (e == hipSuccess && !b_is_ntt) e = launch_outer_fwd_u64(ctx->shape, ctx->tabs, bk, s1k, cnt * nm, s, logi);
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: outer forward");
       const uint64_t *bblk = b_is_ntt ? bk : s1k;
-      e = logi == 14 ? launch_polymul_blocks16k_asm_u64(ctx->shape, ctx->tabs, ck, s0k, bblk, cnt, s, b_is_ntt != 0)
-                     : launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, ck, s0k, bblk, cnt, s, b_is_ntt != 0);
-      if (e == hipErrorNotSupported && logi == 14 && ch == 0) {  // no 16384-word kernel: redo this chunk on 4096-word blocks
-        logi = 12;
-        --ch;
-        continue;
-      }
+      e = launch_polymul_blocks_asm_u64(ctx->shape, ctx->tabs, ck, s0k, bblk, cnt, s, b_is_ntt != 0);
       if (e == hipErrorNotSupported) { unsupported = true; break; }
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: fused blocks");
       e = launch_outer_inv_u64(ctx->shape, ctx->tabs, ck, cnt * nm, s, logi);
@@ -591,6 +563,11 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
 extern "C" {
 
 int nflhip_abi_version(void) { return NFLHIP_ABI_VERSION; }
+
+// include/nflhip_debug.h: test hooks, not part of the product boundary
+void nflhip_debug_gauss_tie_shift(int shift) { set_gauss_tie_shift(shift); }
+static void pipe_stats(const nflhip_ctx *ctx, double out[4]);
+void nflhip_debug_host_pipe_seconds(const nflhip_ctx *ctx, double out[4]) { pipe_stats(ctx, out); }
 
 const char *nflhip_last_error(const nflhip_ctx *ctx) {
   (void)ctx;
@@ -636,6 +613,13 @@ static int ctx_create_mode(nflhip_ctx **out, int device, int limb_bits, size_t d
   c->shape.n = degree;
   c->shape.nm = nmoduli;
   c->shape.small_delta = 1;
+  // the environment is read HERE, once per context (include/nflhip.h "environment")
+  {
+    const char *v = getenv("NFLHIP_VARIANT");
+    c->shape.compiled_only = v && (!strcmp(v, "hipcc") || !strcmp(v, "compiled")) ? 1 : 0;
+    const char *x = getenv("NFLHIP_XCD");
+    c->shape.plan = x && *x ? (atoi(x) != 0 ? 1 : 0) : -1;
+  }
   c->shape.logn = 0;
   while ((((size_t)1) << c->shape.logn) < degree) c->shape.logn++;
   int rc;
@@ -819,7 +803,7 @@ int nflhip_ntt_fwd_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(u32)");
   }
-  if (ctx->shape.limb_bits == 16 && u16_asm_on()) {
+  if (ctx->shape.limb_bits == 16) {
     e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 2, (uint16_t *)d, (const uint16_t *)d, nullptr, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_fwd(u16)");
@@ -848,7 +832,7 @@ int nflhip_ntt_inv_dev(nflhip_ctx *ctx, void *d, size_t batch, void *stream) {
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(u32)");
   }
-  if (ctx->shape.limb_bits == 16 && u16_asm_on()) {
+  if (ctx->shape.limb_bits == 16) {
     e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 3, (uint16_t *)d, (const uint16_t *)d, nullptr, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "ntt_inv(u16)");
@@ -914,12 +898,9 @@ static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, i
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u32)");
   }
   if (ctx->shape.limb_bits == 16 && !b_is_ntt) {
-    // NFLHIP_U16_ASM=0: the composed plan on the generic kernels instead of the generated assembly product (A/B switch)
-    if (u16_asm_on()) {
-      hipError_t e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 0, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, batch, st);
-      if (e == hipSuccess) return NFLHIP_OK;
-      if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u16)");
-    }
+    hipError_t e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 0, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u16)");
   }
   return DISPATCH_T(ctx, polymul_composed<uint16_t>(ctx, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, b_is_ntt, batch, st),
                     polymul_composed<uint32_t>(ctx, (uint32_t *)c, (const uint32_t *)a, (const uint32_t *)b, b_is_ntt, batch, st),
@@ -1371,7 +1352,7 @@ class CopyPool {  // a few host threads that memcpy slices; process-wide, starte
     return *p;
   }
   void copy(void *dst, const void *src, size_t bytes) {
-    const size_t slice = 1 << 20;
+    const size_t slice = 512 << 10;
     const size_t parts = (bytes + slice - 1) / slice;
     if (parts <= 1 || workers_.empty()) {
       std::memcpy(dst, src, bytes);
@@ -1396,7 +1377,7 @@ class CopyPool {  // a few host threads that memcpy slices; process-wide, starte
  private:
   CopyPool() {
     unsigned n = std::thread::hardware_concurrency();
-    n = n > 16 ? 7 : (n > 2 ? n / 2 - 1 : 0);  // + the caller: 8 copying threads on a server host
+    n = n >= 64 ? 15 : (n > 16 ? 7 : (n > 2 ? n / 2 - 1 : 0));  // + the caller: 16 copying threads on a server host
     for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); }), workers_.back().detach();
   }
   void work() {
@@ -1441,6 +1422,7 @@ struct HostPipe {
   void *dev[kSlots][kBufs] = {};
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;
   hipEvent_t ev_h2d[kSlots] = {}, ev_k[kSlots] = {}, ev_d2h[kSlots] = {};
+  double t_in = 0, t_out = 0, t_wait = 0, t_total = 0;   // seconds spent copying in / out, waiting for the device, in calls
   ~HostPipe() {
     for (int s = 0; s < kSlots; ++s) {
       for (int b = 0; b < kBufs; ++b) {
@@ -1456,6 +1438,13 @@ struct HostPipe {
   }
 };
 
+static void pipe_stats(const nflhip_ctx *ctx, double out[4]) {
+  const HostPipe *p = ctx ? ctx->pipe : nullptr;
+  out[0] = p ? p->t_in : 0;
+  out[1] = p ? p->t_out : 0;
+  out[2] = p ? p->t_wait : 0;
+  out[3] = p ? p->t_total : 0;
+}
 static void pipe_destroy(nflhip_ctx *ctx) {
   delete ctx->pipe;
   ctx->pipe = nullptr;
@@ -1496,10 +1485,17 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
   CopyPool &pool = CopyPool::get();
   const size_t nchunks = (batch + per - 1) / per;
   auto count_of = [&](size_t k) { return k + 1 < nchunks ? per : batch - k * per; };
+  typedef std::chrono::steady_clock clk;
+  auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const clk::time_point t_begin = clk::now();
   auto drain = [&](size_t k) -> int {  // chunk k is back in its pinned slot: hand it to the caller
     const int s = int(k % HostPipe::kSlots);
+    const clk::time_point t0 = clk::now();
     HIPCHK(ctx, hipEventSynchronize(p->ev_d2h[s]));
+    const clk::time_point t1 = clk::now();
     pool.copy((char *)out + k * per * pb, p->pinned[s][3], count_of(k) * pb);
+    p->t_wait += secs(t0, t1);
+    p->t_out += secs(t1, clk::now());
     return NFLHIP_OK;
   };
   for (size_t k = 0; k < nchunks; ++k) {
@@ -1513,7 +1509,9 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
       for (int i = 0; i < j; ++i)
         if (in[i] == in[j]) same = i;
       if (same >= 0) { d_in[j] = d_in[same]; continue; }
+      const clk::time_point t0 = clk::now();
       pool.copy(p->pinned[s][j], (const char *)in[j] + k * per * pb, bytes);
+      p->t_in += secs(t0, clk::now());
       HIPCHK(ctx, hipMemcpyAsync(p->dev[s][j], p->pinned[s][j], bytes, hipMemcpyHostToDevice, p->s_h2d));
       d_in[j] = p->dev[s][j];
     }
@@ -1530,6 +1528,7 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
   }
   for (size_t k = nchunks > size_t(HostPipe::kSlots) ? nchunks - HostPipe::kSlots : 0; k < nchunks; ++k)
     if ((rc = drain(k))) return rc;
+  p->t_total += secs(t_begin, clk::now());
   return NFLHIP_OK;
 }
 

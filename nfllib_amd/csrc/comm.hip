@@ -183,8 +183,14 @@ int nflhip_digest_dev(nflhip_ctx *ctx, const void *d_data, size_t first_poly, si
   if (batch == 0) return NFLHIP_OK;
   hipStream_t st = (hipStream_t)stream;
   const unsigned long long per = (unsigned long long)nflhip_degree(ctx) * nflhip_nmoduli(ctx);
-  unsigned long long *d_out = nullptr;
-  HIPCHK(hipMallocAsync((void **)&d_out, sizeof(unsigned long long), st));
+  // one result word per device, owned by the library; calls on a device take turns (a digest is a control-plane call)
+  static std::mutex mu[16];
+  static unsigned long long *slot[16] = {};
+  const int dev = nflhip_ctx_device(ctx);
+  if (dev < 0 || dev >= 16) return set_error(NFLHIP_ERR_INVALID, "device index out of range");
+  std::lock_guard<std::mutex> lk(mu[dev]);
+  if (!slot[dev]) HIPCHK(hipMalloc((void **)&slot[dev], sizeof(unsigned long long)));
+  unsigned long long *d_out = slot[dev];
   hipError_t e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long), st);
   if (e == hipSuccess) {
     const int lb = nflhip_limb_bits(ctx);
@@ -194,7 +200,6 @@ int nflhip_digest_dev(nflhip_ctx *ctx, const void *d_data, size_t first_poly, si
   }
   unsigned long long h = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, st);
-  (void)hipFreeAsync(d_out, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return hip_error(e, "digest");
   *h_digest = h;

@@ -38,6 +38,11 @@ struct Shape {
   size_t crt_L;      // limbs of a lifted coefficient
   size_t crt_Lacc;   // limbs of the accumulator (L+1)
   int small_delta;   // every modulus is 2^(W-2) - delta with delta < 2^32 (delta-form butterflies)
+  // configuration, read ONCE when the context is created (include/nflhip.h "environment"):
+  int compiled_only; // NFLHIP_VARIANT=hipcc: the compiled (hipcc) kernels serve every call -- the independent cross-check
+                     // of the generated assembly kernels (bit-identical results, tests/test_gpu_variants.py)
+  int plan;          // NFLHIP_XCD: rows of 32768 / 65536 words -- -1 by batch size (default), 0 never / 1 always the
+                     // one-launch plan of persistent workgroups
 };
 
 // Device-resident tables of one context.
@@ -92,6 +97,7 @@ hipError_t launch_crt_lift_wide(const Shape &s, const DevTables &t, uint64_t *li
                                 uint64_t *scratch, hipStream_t st);
 
 // ---- samplers (kernels_sample.hip): ChaCha20 counter streams keyed by (key32, stream_id) ----
+void set_gauss_tie_shift(int shift);  // debug entry point nflhip_debug_gauss_tie_shift (include/nflhip_debug.h)
 hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords, const unsigned char *key32,
                                uint64_t stream_id, hipStream_t st);
 // dist: 0 uniform | 1 bounded (p0 = upper bound, p1 = amplifier) | 2 zero/one (p0 = rho) | 3 hamming weight (p0 = h)
@@ -139,14 +145,8 @@ hipError_t launch_outer_inv_u64(const Shape &s, const DevTables &t, uint64_t *da
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                          const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt = false);
 
-// the same over 16384-word blocks (logn >= 14): one 1024-thread workgroup keeps a block on its CU for global stages
-// logn-14 .. logn-1 of both operands, the product and the way back.
-hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
-                                            const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt = false);
-int row16k_level();
 // 32768-word rows, ONE operand register-resident per 1024-thread workgroup: mode 1: c = INTT(NTT(a) (.) b) with b already
 // transformed (streamed through the point-wise step), 2: c = NTT(a), 3: c = INTT(a); hipErrorNotSupported for other shapes
-int row32k_on();
 hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a, const uint64_t *b,
                              size_t batch, hipStream_t st);
 // n = 65536: one launch of the three-role pipeline kernel (block products of chunk j-1, forward streaming pass of
@@ -165,7 +165,7 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
 hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
-                                      hipStream_t st);  // NFLHIP_ROW16K: 0 off, 1 rows of 16384 words only (default), 2 also as block kernel of longer rows
+                                      hipStream_t st);
 
 // n = 1024, 32- and 64-bit limbs: one wave per row (kernels_wave.hip).  mode 0: c = INTT(NTT(a)(.)NTT(b)); 1: b already in
 // NTT form; 2: c = NTT(a); 3: c = INTT(a).  hipErrorNotSupported for other shapes.

@@ -331,55 +331,37 @@ __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, const 
 // prime of the mirrored table qualifies, Shape::small_delta records it per context.
 static inline bool fast_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN; }
 
-// A/B switch for tools/quick_bench.py and profiling (never needed in production):
-//   NFLHIP_VARIANT = 0x hipcc kernel with Harvey ranges | 2x two-bit fold | 3x + one-off quotient |
-//                    5x (default) the generated assembly kernel, hipcc 3x for everything it does not cover.
-static int variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("NFLHIP_VARIANT");
-    v = e ? atoi(e) : 52;
-  }
-  return v;
-}
-
 // ---- hand-scheduled assembly version (tools/gen_polymul_asm.py) ----------------------------
 static const unsigned char kPolymulHsaco[] = {
 #include "polymul4096_hsaco.inc"
 };
 enum AsmKind {
-  kAsmPolymul = 0, kAsmPolymulNtt, kAsmFwd, kAsmInv, kAsmInvMul,   // 4096-word blocks, 256 threads
-  kAsmPolymul16k, kAsmPolymulNtt16k, kAsmFwd16k, kAsmInv16k,        // 16384-word blocks, 1024 threads
-  kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
-  kAsmPolymul8k, kAsmPolymulNtt8k, kAsmFwd8k, kAsmInv8k,            // 8192-word blocks, 512 threads
+  kAsmPolymul = 0, kAsmPolymulNtt, kAsmFwd, kAsmInv, kAsmInvMul,   // 4096-word blocks, 256 threads (coefficient streams non-temporal)
   kAsmFwd2, kAsmInv2,                                                // n = 4096 stand-alone transforms, two rows per workgroup
-  kAsmPipe64kNt,                                                     // the pipeline kernel with non-temporal coefficient streams
-  kAsmPipe32k,                                                       // n = 32768: the same with radix-8 streaming roles
-  kAsmXcd64k, kAsmXcd32k, kAsmXcd64kL, kAsmXcd32kL, kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
-  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow128U16, kAsmRowFwd128U16, kAsmRowInv128U16, kAsmRow8U32,                                            // one launch, rows pinned to an XCD (intermediates through its L2)
-  kAsmPolymulNt, kAsmFwd2Nt, kAsmInv2Nt,                             // non-temporal coefficient streams at n = 4096 (default; NFLHIP_NT4096=0 selects the plain ones)
+  kAsmPolymul8k, kAsmPolymulNtt8k, kAsmFwd8k, kAsmInv8k,            // 8192-word rows, 512 threads
+  kAsmPolymul16k, kAsmPolymulNtt16k, kAsmFwd16k, kAsmInv16k,        // 16384-word rows, 1024 threads
   kAsmFwd32k, kAsmInv32k, kAsmPolymulNtt32k,                         // 32768-word rows: ONE operand register-resident, 1024 threads
+  kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
+  kAsmXcd64k, kAsmXcd32k,                                            // one launch of persistent workgroups, rows pinned to an XCD
+  kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
+  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow8U32,                                  // 32-bit limbs
+  kAsmRow128U16, kAsmRowFwd128U16, kAsmRowInv128U16,                 // 16-bit limbs
   kAsmCount
 };
+static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
 static inline bool is32k(AsmKind k) { return k >= kAsmFwd32k && k <= kAsmPolymulNtt32k; }
-static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
-static const char *const kAsmNames[kAsmCount] = {"nflhip_polymul4096_asm",     "nflhip_polymul_ntt4096_asm",
-                                                 "nflhip_ntt_fwd4096_asm",     "nflhip_ntt_inv4096_asm",
-                                                 "nflhip_ntt_inv_mul4096_asm", "nflhip_polymul16384_asm",
-                                                 "nflhip_polymul_ntt16384_asm", "nflhip_ntt_fwd16384_asm",
-                                                 "nflhip_ntt_inv16384_asm",    "nflhip_polymul_pipe65536_asm",
-                                                 "nflhip_polymul8192_asm",     "nflhip_polymul_ntt8192_asm",
-                                                 "nflhip_ntt_fwd8192_asm",     "nflhip_ntt_inv8192_asm",
-                                                 "nflhip_ntt_fwd4096x2_asm",   "nflhip_ntt_inv4096x2_asm",
-                                                 "nflhip_polymul_pipe65536nt_asm", "nflhip_polymul_pipe32768_asm",
-                                                 "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
-                                                 "nflhip_polymul_xcd65536l_asm", "nflhip_polymul_xcd32768l_asm", "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm",
-                                                 "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
-                                                 "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row128_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm", "nflhip_row8_u32_asm",
-                                                 "nflhip_polymul4096nt_asm",   "nflhip_ntt_fwd4096x2nt_asm",
-                                                 "nflhip_ntt_inv4096x2nt_asm", "nflhip_ntt_fwd32768_asm",
-                                                 "nflhip_ntt_inv32768_asm",    "nflhip_polymul_ntt32768_asm"};
+static const char *const kAsmNames[kAsmCount] = {
+    "nflhip_polymul4096nt_asm", "nflhip_polymul_ntt4096_asm", "nflhip_ntt_fwd4096_asm", "nflhip_ntt_inv4096_asm", "nflhip_ntt_inv_mul4096_asm",
+    "nflhip_ntt_fwd4096x2nt_asm", "nflhip_ntt_inv4096x2nt_asm",
+    "nflhip_polymul8192_asm", "nflhip_polymul_ntt8192_asm", "nflhip_ntt_fwd8192_asm", "nflhip_ntt_inv8192_asm",
+    "nflhip_polymul16384_asm", "nflhip_polymul_ntt16384_asm", "nflhip_ntt_fwd16384_asm", "nflhip_ntt_inv16384_asm",
+    "nflhip_ntt_fwd32768_asm", "nflhip_ntt_inv32768_asm", "nflhip_polymul_ntt32768_asm",
+    "nflhip_polymul_pipe65536nt_asm",
+    "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
+    "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm", "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
+    "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row8_u32_asm",
+    "nflhip_row128_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -406,15 +388,10 @@ static hipFunction_t asm_fn(AsmKind kind) {
   return k.fn[kind];
 }
 
-// every generated kernel takes (dst, src_a, src_b, psi, mc, nm, logn) and one workgroup per 4096-word block
-static int nt4096() {
-  static const int v = getenv("NFLHIP_NT4096") ? atoi(getenv("NFLHIP_NT4096")) : 1;  // measured +1 % on B (profiles/README)
-  return v;
-}
+// every generated kernel takes (dst, src_a, src_b, psi, mc, nm, logn) and one workgroup per block of its size
 static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a,
                              const uint64_t *b, size_t batch, hipStream_t st) {
-  if (variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
-  if (kind == kAsmPolymul && nt4096() && s.logn == kLogN) kind = kAsmPolymulNt;
+  if (s.compiled_only || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
   hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
   struct {
@@ -435,13 +412,10 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
 
 // n = 4096 stand-alone transforms of a batch: two polynomials (same modulus) per workgroup, like the a / b operands of the
 // fused product -- twice the bytes in flight per workgroup and one set of twiddle loads for both rows.
-// NFLHIP_NTT_X2=0 disables it.
 static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *dst, const uint64_t *src,
                                 size_t batch, hipStream_t st) {
-  static const int enabled = getenv("NFLHIP_NTT_X2") ? atoi(getenv("NFLHIP_NTT_X2")) : 1;
-  if (!enabled || variant() < 50 || !s.small_delta || s.logn != kLogN || s.nm > 65535) return hipErrorNotSupported;
+  if (s.compiled_only || !s.small_delta || s.logn != kLogN || s.nm > 65535) return hipErrorNotSupported;
   if (batch < 2 || batch > 0x7fffffffull) return hipErrorNotSupported;
-  if (nt4096()) kind = kind == kAsmFwd2 ? kAsmFwd2Nt : (kind == kAsmInv2 ? kAsmInv2Nt : kind);
   hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
   struct {
@@ -454,18 +428,6 @@ static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t
   return hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
 
-// rows of >= 16384 words: whole 16384-word blocks stay on one CU (global stages logn-14 .. logn-1 and back).
-// NFLHIP_ROW16K = 0 never | 1 (default) rows of exactly 16384 words, where it removes both streaming passes
-// (measured +29 %) | 2 also as the block kernel of longer rows (measured 9 % slower than 4096-word blocks at
-// n = 65536: same HBM traffic, and the single-stream 128-VGPR schedule issues less densely).
-int row16k_level() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("NFLHIP_ROW16K");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
 // n = 65536: one launch of the three-role kernel (tools/gen_polymul_asm.py build_pipe): fused block products of `cnt_v`
 // polynomials whose operands already went through the forward streaming pass (a_v, b_v -> c_v), the forward streaming
 // pass of `cnt_f` polynomials (fa_src -> fa_dst, fb_src -> fb_dst) and the inverse streaming pass of `cnt_i`
@@ -474,10 +436,9 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
                                       hipStream_t st) {
-  if (s.limb_bits != 64 || (s.logn != 16 && s.logn != 15) || variant() < 50 || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
-  // NFLHIP_PIPE_NT=1: coefficient loads / stores bypass L2 retention (`nt`), so the twiddle tables stay resident there
-  static const int use_nt = getenv("NFLHIP_PIPE_NT") ? atoi(getenv("NFLHIP_PIPE_NT")) : 1;  // measured +3 % (E, batch 32 and 128)
-  hipFunction_t fn = asm_fn(s.logn == 15 ? kAsmPipe32k : (use_nt ? kAsmPipe64kNt : kAsmPipe64k));
+  if (s.limb_bits != 64 || s.logn != 16 || s.compiled_only || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+  // (coefficient loads / stores carry `nt`: they pass through the L2 once, the twiddle tables stay resident: measured +3 %)
+  hipFunction_t fn = asm_fn(kAsmPipe64k);
   if (!fn) return hipErrorNotSupported;
   const int mx = cnt_v > cnt_f ? (cnt_v > cnt_i ? cnt_v : cnt_i) : (cnt_f > cnt_i ? cnt_f : cnt_i);
   if (mx <= 0) return hipSuccess;
@@ -494,8 +455,8 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_pipe65536_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  // per polynomial row: 16 block products + 3 x 4 streaming workgroups (n = 65536), 8 + 3 x 2 (n = 32768)
-  const size_t gx = (size_t)mx * (s.logn == 16 ? 28 : 14);
+  // per polynomial row: 16 block products + 3 x 4 streaming workgroups
+  const size_t gx = (size_t)mx * 28;
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
   return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
@@ -503,12 +464,8 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
 // n = 65536 / 32768, whole batch in ONE launch of persistent workgroups (tools/gen_polymul_asm.py fused_header): the three
 // roles of a row run on one XCD and hand the intermediates over through that XCD's L2.  `work` is device memory of at
 // least xcd_plan_bytes(); it is (re)initialised here, on `st`.
-// development aid: a device buffer of 8 x 65536 16-byte records {ticket | role << 28, t0, t1, t2} (s_memtime low words: draw,
-// dependencies met, done) filled by the next launches; see tools/xcd_trace.py
-static void *g_xcd_trace = nullptr;
-extern "C" void nflhip_debug_xcd_trace(void *device_buffer) { g_xcd_trace = device_buffer; }
 static std::atomic<unsigned long long> g_xcd_launches{0};
-extern "C" unsigned long long nflhip_debug_xcd_launches(void) { return g_xcd_launches.load(); }  // tests: which plan ran
+extern "C" unsigned long long nflhip_debug_xcd_launches(void) { return g_xcd_launches.load(); }  // include/nflhip_debug.h
 __global__ void k_xcd_reset(uint4 *ctl) {   // block 0: the header; block d + 1: record d at byte 4096 + 69632 d (2 KiB each)
   uint4 *p = blockIdx.x == 0 ? ctl : ctl + (4096 + (size_t)(blockIdx.x - 1) * 0x11000) / 16;
   p[threadIdx.x] = make_uint4(0, 0, 0, 0);
@@ -516,16 +473,12 @@ __global__ void k_xcd_reset(uint4 *ctl) {   // block 0: the header; block d + 1:
   // (bytes 128 .. 159: one free mask of 32 scratch slots per XCD -- the pooled plan)
 }
 struct XcdPlan {
-  int rlog, wgs, dlog, pooled;
+  int rlog, wgs, dlog;
   unsigned magic;
   size_t ctl_bytes, slot_bytes, total;
 };
-static int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 static bool xcd_plan(const Shape &s, size_t batch, XcdPlan *p) {
-  if (s.limb_bits != 64 || (s.logn != 16 && s.logn != 15) || variant() < 50 || !s.small_delta || s.nm > 65535) return false;
+  if (s.limb_bits != 64 || (s.logn != 16 && s.logn != 15) || s.compiled_only || !s.small_delta || s.nm > 65535) return false;
   // the kernel derives a row's XCD from the hardware XCC id: it needs the whole 8-XCD device (no compute partition)
   static int cus[16] = {};
   int dev = 0;
@@ -537,22 +490,13 @@ static bool xcd_plan(const Shape &s, size_t batch, XcdPlan *p) {
   const bool pow2 = (batch & (batch - 1)) == 0;
   if (!pow2 && rows * batch >= (1ull << 32)) return false;  // the kernel divides row numbers by the batch with one multiply
   p->magic = (unsigned)(pow2 ? (1ull << 32) / batch : (1ull << 32) / batch + 1);
-  p->rlog = env_int("NFLHIP_XCD_RLOG", 3);  // 2^rlog rows in flight per scheduling domain
-  p->dlog = env_int("NFLHIP_XCD_DLOG", 2);  // 2^dlog scheduling domains per XCD (measured: 1 domain 13.8 k, 2: 23.7 k, 4: 26.1 k products/s)
-  p->wgs = env_int("NFLHIP_XCD_WGS", 768);
-  if (p->rlog < 1 || p->rlog > 5 || p->dlog < 0 || p->dlog > 3 || p->wgs < 256 || rows < (8ull << p->dlog)) return false;
-  p->ctl_bytes = 4096 + ((size_t)8 << p->dlog) * 0x11000;  // word 0: next row; one 256 B scheduler record per XCD, 68 KiB apart, from byte 4096
-  p->pooled = env_int("NFLHIP_XCD_POOL", 0);  // 1: scratch rows from a per-XCD pool of 32 slots, lowest free first (see the generator)
-  if (p->pooled) {
-    // a row in flight holds up to 3 slots: at most 8 rows in flight per XCD, so the pool can never run dry
-    if (!getenv("NFLHIP_XCD_RLOG")) p->rlog = 1;
-    if (p->rlog + p->dlog > 3) return false;
-    p->slot_bytes = (size_t)8 * 32 * (s.n * 8);
-    p->total = p->ctl_bytes + p->slot_bytes;
-  } else {
-    p->slot_bytes = (size_t)rows * (s.n * 8);  // per operand: the scratch mirrors the batch (every row its own scratch rows)
-    p->total = p->ctl_bytes + 2 * p->slot_bytes;
-  }
+  p->rlog = 3;   // 2^rlog rows in flight per scheduling domain
+  p->dlog = 2;   // 2^dlog scheduling domains per XCD (measured: 1 domain 13.8 k, 2: 23.7 k, 4: 26.1 k products/s at n = 65536)
+  p->wgs = 768;  // persistent workgroups: three per CU
+  if (rows < (8ull << p->dlog)) return false;
+  p->ctl_bytes = 4096 + ((size_t)8 << p->dlog) * 0x11000;  // word 0: next row; one 256 B scheduler record per domain, 68 KiB apart, from byte 4096
+  p->slot_bytes = (size_t)rows * (s.n * 8);                 // per operand: the scratch mirrors the batch (every row its own scratch rows)
+  p->total = p->ctl_bytes + 2 * p->slot_bytes;
   return true;
 }
 size_t xcd_plan_bytes(const Shape &s, size_t batch) {
@@ -563,7 +507,7 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
                                   size_t batch, void *work, hipStream_t st) {
   XcdPlan p;
   if (!xcd_plan(s, batch, &p)) return hipErrorNotSupported;
-  hipFunction_t fn = asm_fn(s.logn == 16 ? (p.pooled ? kAsmXcd64kL : kAsmXcd64k) : (p.pooled ? kAsmXcd32kL : kAsmXcd32k));
+  hipFunction_t fn = asm_fn(s.logn == 16 ? kAsmXcd64k : kAsmXcd32k);
   if (!fn) return hipErrorNotSupported;
   // fresh counters: word block 0 (workgroups that joined, per XCD) and the first KiB of every domain's record
   hipLaunchKernelGGL(k_xcd_reset, dim3((8u << p.dlog) + 1), dim3(128), 0, st, (uint4 *)work);
@@ -579,8 +523,7 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
     int d, rlog, jmax, spin, inv;
     void *scr_a, *scr_b, *ctl, *trace;
   } args = {c, a, b, t.psi, t.mc, (int)s.nm, s.logn, (int)(batch * s.nm), (int)batch, p.magic, p.dlog, p.rlog, 0,
-            env_int("NFLHIP_XCD_SPIN", 1 << 22), 0, w + p.ctl_bytes, w + p.ctl_bytes + p.slot_bytes, w,
-            g_xcd_trace};
+            1 << 22, 0, w + p.ctl_bytes, w + p.ctl_bytes + p.slot_bytes, w, nullptr};
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_xcd*_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -592,7 +535,7 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                                   const uint32_t *b, size_t batch, hipStream_t st) {
   // mode (as launch_row1024_u32): 0 fused product, 2 forward (canonical NTT-form words out), 3 inverse
-  if (s.limb_bits == 32 && s.logn == 3 && mode == 0 && variant() >= 50) {
+  if (s.limb_bits == 32 && s.logn == 3 && mode == 0 && !s.compiled_only) {
     // n = 8 (the reference's (8, 60, uint32_t) config): one LANE per row, 256 rows per workgroup (tools/gen_row8_u32_asm.py)
     const unsigned long long rows8 = (unsigned long long)batch * s.nm;
     if (rows8 == 0) return hipSuccess;
@@ -609,7 +552,7 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
     void *ex8[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a8, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz8, HIP_LAUNCH_PARAM_END};
     return hipModuleLaunchKernel(f8, (unsigned)((rows8 + 255) / 256), 1, 1, 256, 1, 1, 0, st, nullptr, ex8);
   }
-  if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || variant() < 50 || (mode != 0 && mode != 2 && mode != 3)) return hipErrorNotSupported;
+  if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || s.compiled_only || (mode != 0 && mode != 2 && mode != 3)) return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;  // (row mod nm is one multiply in the kernel)
@@ -634,7 +577,7 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
 hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, uint16_t *c, const uint16_t *a,
                                  const uint16_t *b, size_t batch, hipStream_t st) {
   // mode: 0 fused product, 2 forward (canonical NTT-form words out), 3 inverse
-  if (s.limb_bits != 16 || s.logn != 7 || variant() < 50 || (s.nm & (s.nm - 1)) != 0 || (mode != 0 && mode != 2 && mode != 3))
+  if (s.limb_bits != 16 || s.logn != 7 || s.compiled_only || (s.nm & (s.nm - 1)) != 0 || (mode != 0 && mode != 2 && mode != 3))
     return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
@@ -653,13 +596,6 @@ hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, u
   return hipModuleLaunchKernel(fn, (unsigned)((rows + 31) / 32), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
 }
 
-hipError_t launch_polymul_blocks16k_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
-                                            const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt) {
-  if (s.limb_bits != 64 || s.logn < kLogN + 2 || row16k_level() < (s.logn == kLogN + 2 ? 1 : 2)) return hipErrorNotSupported;
-  if (batch == 0) return hipSuccess;
-  return launch_asm(b_is_ntt ? kAsmPolymulNtt16k : kAsmPolymul16k, s, t, c, a_in, b_in, batch, st);
-}
-
 hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a_in,
                                          const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt) {
   if (s.limb_bits != 64 || s.logn < kLogN) return hipErrorNotSupported;
@@ -673,29 +609,17 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const int nm = (int)s.nm;
-  int v = variant();
-  if (!s.small_delta) v = 0;  // delta-form arithmetic needs delta < 2^32
-#define NFLHIP_LAUNCH(A, W)                                                                                         \
-  hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, A, W>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);     \
-  break;
-  switch (v / 10) {
-    case 0: NFLHIP_LAUNCH(0, 2)   // Harvey ranges, generic Shoup (any modulus)
-    case 2: NFLHIP_LAUNCH(2, 2)   // two-bit fold, exact quotient
-    default: NFLHIP_LAUNCH(3, 2)  // + one-off quotient in the forward butterflies
-  }
-#undef NFLHIP_LAUNCH
+  // delta-form arithmetic (two-bit fold, one-off quotient: the assembly kernel's formulation) needs delta < 2^32; any other
+  // modulus takes the Harvey ranges with the generic Shoup product
+  if (s.small_delta) hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, 3, 2>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);
+  else hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, 0, 2>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);
   return hipGetLastError();
 }
 
-static inline bool row16k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 2 && row16k_level() >= 1; }
-static inline bool row8k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 1 && row16k_level() >= 1; }
+static inline bool row16k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 2; }
+static inline bool row8k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 1; }
 // 32768-word rows: one operand register-resident in a 1024-thread workgroup (tools/gen_polymul_asm.py build_row32k).
-// NFLHIP_ROW32K=0: the three-role / one-launch plans of round 2 instead (A/B switch)
-int row32k_on() {
-  static const int v = getenv("NFLHIP_ROW32K") ? atoi(getenv("NFLHIP_ROW32K")) : 1;
-  return v;
-}
-static inline bool row32k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 3 && row32k_on(); }
+static inline bool row32k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 3 && !s.compiled_only; }
 hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a, const uint64_t *b,
                              size_t batch, hipStream_t st) {
   if (!row32k_shape(s)) return hipErrorNotSupported;
@@ -738,9 +662,7 @@ hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const u
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const dim3 g((unsigned)blocks), b(kThreads);
-  const int v = s.small_delta ? variant() : 0;
-  if (v >= 30) hipLaunchKernelGGL(k_ntt_fwd4096<3>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
-  else if (v >= 20) hipLaunchKernelGGL(k_ntt_fwd4096<2>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
+  if (s.small_delta) hipLaunchKernelGGL(k_ntt_fwd4096<3>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
   else hipLaunchKernelGGL(k_ntt_fwd4096<0>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
   return hipGetLastError();
 }
@@ -759,11 +681,10 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const dim3 g((unsigned)blocks), b(kThreads);
-  const int v = s.small_delta ? variant() : 0;
 #define NFLHIP_INV(A)                                                                                                  \
   if (mul) hipLaunchKernelGGL((k_ntt_inv4096<A, true>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);      \
   else hipLaunchKernelGGL((k_ntt_inv4096<A, false>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);
-  if (v >= 20) { NFLHIP_INV(2) }
+  if (s.small_delta) { NFLHIP_INV(2) }
   else { NFLHIP_INV(0) }
 #undef NFLHIP_INV
   return hipGetLastError();

@@ -359,12 +359,11 @@ __global__ void k_pointwise(T *out, const T *a, const T *b, const T *bp, const M
 // Grid of the grid-stride streaming kernels: the chip's copy rate peaks with two to four 256-thread workgroups per CU
 // (measured on the point-wise kernels, u64/4096/4, batch 16 384: add 5.43 / 5.23 / 5.13 / 4.74 TB/s and mul 5.25 / 5.14 /
 // 5.50 / 5.00 TB/s at 512 / 768 / 1024 / 4096 workgroups; copy kernel: 5.8 TB/s at 1024 against 4.7 at 4096,
-// profiles/r02_ubench_gfx950.txt) -- more resident waves only add DRAM page conflicts.  NFLHIP_STREAM_BLOCKS overrides.
+// profiles/r02_ubench_gfx950.txt) -- more resident waves only add DRAM page conflicts.
 // The interpreter loop of the expression kernel is the opposite case (it needs the waves to hide its own latency:
 // a*b+d 3.1 TB/s at 768 workgroups, 4.9 at 4096), comparisons and fills are indifferent: they keep their wide grids.
 static inline size_t stream_blocks(size_t items_per_thread_total, size_t dflt = 768) {
-  static const size_t env = getenv("NFLHIP_STREAM_BLOCKS") ? (size_t)atol(getenv("NFLHIP_STREAM_BLOCKS")) : 0;
-  const size_t cap = env ? env : dflt;
+  const size_t cap = dflt;
   size_t blocks = (items_per_thread_total + 255) / 256;
   if (blocks > cap) blocks = cap;
   return blocks ? blocks : 1;

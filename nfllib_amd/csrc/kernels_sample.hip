@@ -7,6 +7,8 @@
 // a fixed word of its stream, so the output does not depend on the launch geometry or on how a batch is sharded.
 // The map from random words to values is the reference's, statement for statement (cited per kernel); the tests feed
 // the same words through a numpy restatement that is pinned against the real reference.
+#include <atomic>
+
 #include "kernels.h"
 #include "modarith.h"
 
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(256) k_sample_small8(T *d, const ModConst<T> *
 // entries * 2^-64 per sample), and are then read from the secondary stream -- same key and nonce, block counters from
 // 2^63 up: word (W-1)*g + k - 1 of it is word k of r.  The value is exactly the full-precision inversion of
 // r = (word g, secondary words), at one keystream word per sample instead of W.
-// `tie_shift` (0 in production; NFLHIP_GAUSS_TIE_SHIFT for the tests) only widens what counts as a tie -- the first
+// `tie_shift` (0 in production; nflhip_debug_gauss_tie_shift for the tests) only widens what counts as a tie -- the first
 // words are compared after dropping their low tie_shift bits -- so that the tie path, whose result is the same
 // full-precision comparison, runs often enough to be tested.
 static constexpr uint64_t kSecondaryCounter = ((uint64_t)1) << 63;
@@ -531,14 +533,10 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
   return hipGetLastError();
 }
 
-static int gauss_tie_shift() {
-  static const int v = [] {
-    const char *e = getenv("NFLHIP_GAUSS_TIE_SHIFT");  // test hook, see gauss_search
-    const int t = e ? atoi(e) : 0;
-    return t < 0 ? 0 : (t > 63 ? 63 : t);
-  }();
-  return v;
-}
+// test hook of gauss_search (include/nflhip_debug.h nflhip_debug_gauss_tie_shift): never set in production
+static std::atomic<int> g_gauss_tie_shift{0};
+void set_gauss_tie_shift(int shift) { g_gauss_tie_shift.store(shift < 0 ? 0 : (shift > 63 ? 63 : shift)); }
+static int gauss_tie_shift() { return g_gauss_tie_shift.load(std::memory_order_relaxed); }
 
 hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *cdt, int words,
                               int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {

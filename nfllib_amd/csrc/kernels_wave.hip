@@ -403,7 +403,7 @@ static hipError_t launch_rows(const Shape &s, const DevTables &t, int mode, type
   const dim3 bl(256);
   const typename P::TW *psi = (const typename P::TW *)t.psi;
   const typename P::MC *mc = (const typename P::MC *)t.mc;
-  static const int use_lds = getenv("NFLHIP_U32_LDS") ? atoi(getenv("NFLHIP_U32_LDS")) : 1;
+  const int use_lds = 1;
   // measured (u32/1024/1, batch 2^19): forward 430 -> 482 M/s, inverse 498 -> 514 M/s with the LDS tables; the fused
   // products do not gain (they are bound by VALU issue, not by twiddle latency), so they keep the plain kernel
   if (LB == 4 && sizeof(typename P::T) == 4 && use_lds && mode >= 2 && s.nm <= 4 && blocks >= 4096) {
@@ -433,22 +433,18 @@ static hipError_t launch_rows(const Shape &s, const DevTables &t, int mode, type
 hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                               const uint32_t *b, size_t batch, hipStream_t st) {
   if (s.limb_bits != 32) return hipErrorNotSupported;
-  // NFLHIP_U32_MADS (A/B switch, bit-identical results): 0 = multiply / subtract butterflies everywhere, 1 = multiply-add
-  // butterflies everywhere, unset = per kernel as measured (see Pol32T)
-  static const int mads = getenv("NFLHIP_U32_MADS") ? atoi(getenv("NFLHIP_U32_MADS")) : -1;
-  // NFLHIP_U32_ASM (A/B switch, bit-identical; read on every call so that a test can flip it): the generated assembly
-  // kernels of the fused product, n = 1024 / 2048 / 4096 (0 = the compiled kernels below).  Measured (MI355X, round 2):
-  // 201 -> 243 M products/s at u32/1024/1, 78.9 -> 96.7 M at u32/2048/1, 11.2 -> 13.3 M at u32/4096/4; transforms (batch 2^17)
-  // forward / inverse 439 / 408 -> 463 / 444 M at n = 1024, 189 / 207 -> 212 / 234 M at 2048, 25.7 / 23.5 -> 28.9 / 30.6 M at 4096/4
-  const char *ua = getenv("NFLHIP_U32_ASM");
-  const int ual = ua ? atoi(ua) : 2;   // 1: only the fused products, 2 (default): the stand-alone transforms too
-  if (ual != 0 && ((s.logn >= 10 && s.logn <= 12 && (mode == 0 || (ual >= 2 && (mode == 2 || mode == 3)))) || (s.logn == 3 && mode == 0))) {
+  // the generated assembly kernels of the fused product and the stand-alone transforms, n = 1024 / 2048 / 4096 and n = 8
+  // (Shape::compiled_only = the compiled kernels below instead).  Measured (MI355X, round 2): 201 -> 243 M products/s at
+  // u32/1024/1, 78.9 -> 96.7 M at u32/2048/1, 11.2 -> 13.3 M at u32/4096/4; transforms (batch 2^17) forward / inverse
+  // 439 / 408 -> 463 / 444 M at n = 1024, 189 / 207 -> 212 / 234 M at 2048, 25.7 / 23.5 -> 28.9 / 30.6 M at 4096/4
+  if (!s.compiled_only && ((s.logn >= 10 && s.logn <= 12 && (mode == 0 || mode == 2 || mode == 3)) || (s.logn == 3 && mode == 0))) {
     const hipError_t e = launch_row1024_u32_asm(s, t, mode, c, a, b, batch, st);
     if (e != hipErrorNotSupported) return e;
   }
-  if (s.logn == 10) return mads == 1 ? launch_rows<Pol32M, 4>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);
-  if (s.logn == 11) return mads == 1 ? launch_rows<Pol32M, 8>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32, 8>(s, t, mode, c, a, b, batch, st);
-  if (s.logn == 12) return mads == 0 ? launch_rows<Pol32, 16>(s, t, mode, c, a, b, batch, st) : launch_rows<Pol32M, 16>(s, t, mode, c, a, b, batch, st);
+  // multiply-add butterflies (Pol32M) where they measured faster: the 4096-word rows
+  if (s.logn == 10) return launch_rows<Pol32, 4>(s, t, mode, c, a, b, batch, st);
+  if (s.logn == 11) return launch_rows<Pol32, 8>(s, t, mode, c, a, b, batch, st);
+  if (s.logn == 12) return launch_rows<Pol32M, 16>(s, t, mode, c, a, b, batch, st);
   return hipErrorNotSupported;
 }
 // 4096-word blocks of rows longer than 4096 words, 32-bit limbs: the inner kernels of launch_ntt_fwd / launch_ntt_inv

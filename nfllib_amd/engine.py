@@ -325,8 +325,8 @@ class Engine:
         self._chk(self.lib.nflhip_pointwise(self.ctx, op, _vp(out), _vp(a), _vp(b), _vp(bprime), self._hb(a)))
         return out
 
-    def h_polymul(self, a, b):
-        out = np.empty_like(a)
+    def h_polymul(self, a, b, out=None):
+        out = np.empty_like(a) if out is None else out
         self._chk(self.lib.nflhip_polymul(self.ctx, _vp(out), _vp(a), _vp(b), self._hb(a)))
         return out
 

@@ -61,3 +61,29 @@ def engine_factory():
     yield get
     for e in cache.values():
         e.close()
+
+
+@pytest.fixture(scope="session")
+def compiled_engine_factory():
+    """contexts that were created under NFLHIP_VARIANT=hipcc: every call is served by the compiled (hipcc) kernels -- the
+    independent cross-check of the generated assembly kernels (the variable is read once, at context creation)"""
+    from nfllib_amd import Engine
+    cache = {}
+
+    def get(limb_bits, degree, nmoduli):
+        key = (limb_bits, degree, nmoduli)
+        if key not in cache:
+            saved = os.environ.get("NFLHIP_VARIANT")
+            os.environ["NFLHIP_VARIANT"] = "hipcc"
+            try:
+                cache[key] = Engine(limb_bits, degree, nmoduli, device=0)
+            finally:
+                if saved is None:
+                    os.environ.pop("NFLHIP_VARIANT", None)
+                else:
+                    os.environ["NFLHIP_VARIANT"] = saved
+        return cache[key]
+
+    yield get
+    for e in cache.values():
+        e.close()

@@ -28,6 +28,34 @@ def test_header_symbols_all_exported_and_bound():
     assert lib.nflhip_abi_version() == _lib.ABI_VERSION == 3
 
 
+def test_the_library_exports_exactly_what_its_two_headers_declare():
+    """every exported C symbol is declared in include/nflhip.h (the boundary) or include/nflhip_debug.h (test hooks), and
+    nothing else leaks out of the shared object"""
+    import subprocess
+    from nfllib_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "nflhip_debug.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    debug = set(re.findall(r"\b(nflhip_[a-z0-9_]+)\s*\(", txt))
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and not l.split()[-1].startswith("_Z")}
+    exported = {e for e in exported if e not in ("_init", "_fini")}
+    assert exported == set(_declared()) | debug, sorted(exported ^ (set(_declared()) | debug))
+    assert len(debug) <= 4
+
+
+def test_the_library_reads_three_environment_variables():
+    import subprocess
+    from nfllib_amd import _lib
+    strings = subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    knobs = sorted(set(re.findall(r"\bNFLHIP_[A-Z0-9_]+\b", strings)))
+    assert knobs == ["NFLHIP_COMM_PIECE_BYTES", "NFLHIP_VARIANT", "NFLHIP_XCD"], knobs
+    srcs = ""
+    for f in os.listdir(os.path.join(ROOT, "nfllib_amd", "csrc")):
+        if f.endswith((".hip", ".cpp", ".h")):
+            srcs += open(os.path.join(ROOT, "nfllib_amd", "csrc", f)).read()
+    assert srcs.count("getenv(") == 3
+
+
 def test_no_torch_types_in_the_boundary():
     txt = open(os.path.join(ROOT, "include", "nflhip.h")).read()
     assert "torch" not in txt.lower() and "at::" not in txt and "#include <hip" not in txt

@@ -303,34 +303,34 @@ print(json.dumps(out))
 
 
 def test_assembly_and_compiled_kernels_agree():
-    """Two independently produced device programs for the 4096-word blocks -- the generated assembly
-    (tools/gen_polymul_asm.py, default) and the hipcc-compiled templates (NFLHIP_VARIANT=32) -- must give the
-    same words for every entry point they serve, over whole batches.  The variant is latched per process."""
+    """Two independently produced device programs -- the generated assembly (tools/gen_*_asm.py, default) and the
+    hipcc-compiled templates (NFLHIP_VARIANT=hipcc when the context is created) -- must give the same words for every
+    entry point they serve, over whole batches; for the long rows that compares the plans too (register-resident rows
+    / three-role pipeline / one launch of persistent workgroups against streaming passes around compiled blocks)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for v in ("52", "32", "2"):
-        # 52: also without the 16384-word row kernel, so both plans for n = 16384 are compared
-        env = dict(os.environ, NFLHIP_VARIANT=v, NFLHIP_ROW16K="1" if v == "52" else "0")
+    for v in ("asm", "hipcc"):
+        env = dict(os.environ, NFLHIP_VARIANT=v)
         r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD, root, str(SEED)], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         got[v] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert got["52"] == got["32"] == got["2"]
+    assert got["asm"] == got["hipcc"]
 
 
-_ROW16K_CHILD = r"""
+_ROWS_CHILD = r"""
 import json, sys
 sys.path.insert(0, sys.argv[1])
 import torch
 from nfllib_amd import Engine
 from nfllib_amd.sharding import digest_words
 out = {}
-for n, m, batch in ((8192, 2, 5), (8192, 1, 1), (16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (65536, 3, 2), (65536, 2, 5),
-                    (65536, 1, 1)):
+for n, m, batch in ((8192, 2, 5), (8192, 1, 1), (16384, 8, 5), (16384, 1, 1), (32768, 2, 3), (32768, 2, 130), (65536, 3, 2),
+                    (65536, 2, 5), (65536, 1, 1)):
     e = Engine(64, n, m)
     a = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 0)
     b = e.fill_uniform(e.empty(batch), int(sys.argv[2]), 1)
@@ -350,30 +350,33 @@ for n, m, batch in ((8192, 2, 5), (8192, 1, 1), (16384, 8, 5), (16384, 1, 1), (3
     assert not e.any_neq(a2, c)
     e.polymul(a, b, out=a)          # in place on the first operand
     assert not e.any_neq(a, c)
-    out["%d_%d" % (n, m)] = d
+    out["%d_%d" % (n, m) + ("_%d" % batch if batch > 100 else "")] = d
 print(json.dumps(out))
 """
 
 
-def test_row_resident_16384_kernel_matches_block_plan():
-    """The 1024-thread kernel that keeps 16384-word blocks on one CU (NFLHIP_ROW16K: 1 = rows of exactly 16384
-    words, 2 = also as the block kernel of longer rows, exercising its plain-last-stage tail) against the
-    4096-word-block plan (0); test_polymul compares the default against the oracle."""
+def test_every_plan_of_the_long_rows_gives_the_same_words():
+    """Rows of 8192 ... 65536 words: the default plan of every shape (row-resident kernels at 8192 / 16384; at 32768 the
+    one-launch plan for the small batch and the register-resident rows for the large one; the pipeline at 65536),
+    NFLHIP_XCD=0 / 1 (never / always the one-launch plan at 32768 and 65536) and the compiled kernels
+    (NFLHIP_VARIANT=hipcc): identical digests, in-place variants included; test_polymul compares the default against
+    the oracle."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    # NFLHIP_PIPE_CHUNKS: the n = 65536 three-role pipeline kernel (default 4 chunks; 0 = the three-kernel plan;
-    # 3 with the child's batch of 2 or 5 exercises uneven and single-polynomial chunks)
-    for v, pipe in (("0", "0"), ("1", "4"), ("2", "0"), ("1", "3")):
-        env = dict(os.environ, NFLHIP_ROW16K=v, NFLHIP_PIPE_CHUNKS=pipe)
-        r = subprocess.run([sys.executable, "-c", _ROW16K_CHILD, root, str(SEED)], env=env, capture_output=True,
-                           text=True, timeout=600)
+    for name, extra in (("default", {}), ("xcd0", {"NFLHIP_XCD": "0"}), ("xcd1", {"NFLHIP_XCD": "1"}), ("hipcc", {"NFLHIP_VARIANT": "hipcc"})):
+        env = dict(os.environ)
+        env.pop("NFLHIP_XCD", None)
+        env.pop("NFLHIP_VARIANT", None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", _ROWS_CHILD, root, str(SEED)], env=env, capture_output=True,
+                           text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
-        got[v + pipe] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert got["00"] == got["14"] == got["20"] == got["13"]
+        got[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["default"] == got["xcd0"] == got["xcd1"] == got["hipcc"]
 
 
 def test_concurrent_host_threads_on_distinct_streams(oracle_factory, engine_factory):

@@ -172,6 +172,11 @@ sys.path.insert(0, %(root)r)
 import numpy as np
 from nfllib_amd import Engine
 from oracle import samplers as S
+import ctypes
+from nfllib_amd import _lib
+_lib.lib.nflhip_debug_gauss_tie_shift.argtypes = [ctypes.c_int]
+_lib.lib.nflhip_debug_gauss_tie_shift.restype = None
+_lib.lib.nflhip_debug_gauss_tie_shift(int(sys.argv[1]))
 KEY = bytes(range(32))
 for lb, n, m, batch, sigma, sec, first in ((64, 1024, 2, 3, 3.2, 128, 0), (64, 64, 1, 13, 20.0, 128, 5), (32, 256, 1, 5, 3.2, 64, 2),
                                           (64, 4, 1, 9, 3.2, 128, 3), (16, 128, 1, 7, 2.0, 20, 0), (64, 4096, 1, 2, 215.0, 100, 1)):
@@ -192,7 +197,8 @@ print("TIE_OK")
 @pytest.mark.parametrize("tie_shift", ["0", "56", "63"])
 def test_gaussian_lazy_precision_equals_full_precision_inversion(tie_shift):
     """One keystream word per sample; the lower words of the W-word uniform number come from the secondary stream only
-    when the first word ties with a table entry (2^-64 per entry in production).  NFLHIP_GAUSS_TIE_SHIFT widens what
+    when the first word ties with a table entry (2^-64 per entry in production).  The debug entry point
+    nflhip_debug_gauss_tie_shift (include/nflhip_debug.h; never called in production) widens what
     counts as a tie (56: equal top bytes; 63: equal top bits, i.e. nearly every comparison) without changing the value,
     so the tie path is exercised: every shape must still equal the oracle's full-precision inversion of the same words
     (1-, 2- and 3-word tables, the 8-per-thread kernel with ragged wave tiles and the per-coefficient one, shards)."""
@@ -200,8 +206,7 @@ def test_gaussian_lazy_precision_equals_full_precision_inversion(tie_shift):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NFLHIP_GAUSS_TIE_SHIFT=tie_shift)
-    out = subprocess.run([sys.executable, "-c", _TIE_CHILD % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", _TIE_CHILD % {"root": root}, tie_shift], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "TIE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -209,7 +214,7 @@ def test_gaussian_lazy_precision_equals_full_precision_inversion(tie_shift):
 def test_gaussian_beyond_192_bits(sigma, security, words, engine_factory):
     """Tables of 4, 5 and 6 words per entry (the reference takes its precision from MPFR and has no cap,
     FastGaussianNoise.hpp:239-272): the device sampler is the exact inversion of the very keystream words, incl. with
-    NFLHIP_GAUSS_TIE_SHIFT-style ties resolved by the lower words (here: plain run, the tie path has its own test)."""
+    widened ties resolved by the lower words (here: plain run, the tie path has its own test)."""
     e = engine_factory(64, 1024, 2)
     P = _P(e)
     g = e.gauss_create(sigma, security=security, samples=1024)

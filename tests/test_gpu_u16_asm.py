@@ -1,8 +1,7 @@
 """The generated assembly product for 16-bit limbs, n = 128 (tools/gen_row128_u16_asm.py: the reference's
-(128, 14, uint16_t) config, eight rows per wave) against the composed plan on the generic kernels (NFLHIP_U16_ASM=0)
+(128, 14, uint16_t) config, eight rows per wave) against the composed plan on the generic kernels (a context created under
+NFLHIP_VARIANT=hipcc)
 and against the oracle: one and two moduli, row counts that leave surplus lanes, boundary words."""
-import os
-
 import numpy as np
 import pytest
 
@@ -11,19 +10,9 @@ from conftest import SEED
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _restore_env():
-    saved = os.environ.get("NFLHIP_U16_ASM")
-    yield
-    if saved is None:
-        os.environ.pop("NFLHIP_U16_ASM", None)
-    else:
-        os.environ["NFLHIP_U16_ASM"] = saved
-
-
 @pytest.mark.parametrize("m,batch", [(1, 1), (1, 7), (1, 8), (1, 33), (2, 1), (2, 5), (2, 16), (2, 129), (1, 4099)])
-def test_assembly_product_matches_generic_kernels_and_oracle(m, batch, oracle_factory, engine_factory):
-    o, e = oracle_factory(16, 128, m), engine_factory(16, 128, m)
+def test_assembly_product_matches_generic_kernels_and_oracle(m, batch, oracle_factory, engine_factory, compiled_engine_factory):
+    o, e, ec = oracle_factory(16, 128, m), engine_factory(16, 128, m), compiled_engine_factory(16, 128, m)
     a = e.fill_uniform(e.empty(batch), SEED, 0)
     b = e.fill_uniform(e.empty(batch), SEED, 1)
     ha, hb = e.to_host(a), e.to_host(b)
@@ -32,10 +21,8 @@ def test_assembly_product_matches_generic_kernels_and_oracle(m, batch, oracle_fa
     hb[0, :, 0], hb[0, :, 1], hb[0, :, 2] = P - 1, P - 1, P - 1
     ha[0, :, 127], hb[0, :, 127] = P - 1, P - 1
     a, b = e.to_device(ha), e.to_device(hb)
-    os.environ["NFLHIP_U16_ASM"] = "0"
-    want = e.to_host(e.polymul(a, b))
-    want_f = e.to_host(e.ntt_(a.clone()))
-    os.environ["NFLHIP_U16_ASM"] = "1"
+    want = ec.to_host(ec.polymul(a, b))
+    want_f = ec.to_host(ec.ntt_(a.clone()))
     got = e.to_host(e.polymul(a, b))
     assert np.array_equal(got, want)
     # the stand-alone transforms (in place)

@@ -1,9 +1,8 @@
 """The generated gfx950 assembly kernels of the 32-bit fused product (tools/gen_row1024_u32_asm.py: n = 1024 / 2048 /
-4096, one / two / four waves per row) against the compiled kernels they replace (NFLHIP_U32_ASM=0) and against the
+4096, one / two / four waves per row) against the compiled kernels they replace (a context created under
+NFLHIP_VARIANT=hipcc) and against the
 oracle: row counts that leave surplus waves / rows in the last workgroup, several moduli per polynomial, boundary
 words."""
-import os
-
 import numpy as np
 import pytest
 
@@ -12,20 +11,10 @@ from conftest import SEED
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _restore_env():
-    saved = os.environ.get("NFLHIP_U32_ASM")
-    yield
-    if saved is None:
-        os.environ.pop("NFLHIP_U32_ASM", None)
-    else:
-        os.environ["NFLHIP_U32_ASM"] = saved
-
-
 @pytest.mark.parametrize("n,m,batch", [(1024, 1, 7), (1024, 3, 5), (1024, 2, 1), (2048, 2, 5), (2048, 3, 3), (2048, 1, 1),
                                         (4096, 3, 3), (4096, 1, 2), (1024, 4, 257), (2048, 1, 129), (4096, 2, 65)])
-def test_assembly_product_matches_compiled_kernel_and_oracle(n, m, batch, oracle_factory, engine_factory):
-    o, e = oracle_factory(32, n, m), engine_factory(32, n, m)
+def test_assembly_product_matches_compiled_kernel_and_oracle(n, m, batch, oracle_factory, engine_factory, compiled_engine_factory):
+    o, e, ec = oracle_factory(32, n, m), engine_factory(32, n, m), compiled_engine_factory(32, n, m)
     a = e.fill_uniform(e.empty(batch), SEED, 0)
     b = e.fill_uniform(e.empty(batch), SEED, 1)
     ha, hb = e.to_host(a), e.to_host(b)
@@ -35,11 +24,9 @@ def test_assembly_product_matches_compiled_kernel_and_oracle(n, m, batch, oracle
     hb[0, :, 0], hb[0, :, 1], hb[0, :, 2] = P - 1, P - 1, P - 1
     ha[0, :, n - 1], hb[0, :, n - 1] = P - 1, P - 1
     a, b = e.to_device(ha), e.to_device(hb)
-    os.environ["NFLHIP_U32_ASM"] = "0"
-    want = e.to_host(e.polymul(a, b))
-    want_f = e.to_host(e.ntt_(a.clone()))
-    want_i = e.to_host(e.intt_(e.ntt_(b.clone())))
-    os.environ["NFLHIP_U32_ASM"] = "2"
+    want = ec.to_host(ec.polymul(a, b))
+    want_f = ec.to_host(ec.ntt_(a.clone()))
+    want_i = ec.to_host(ec.intt_(ec.ntt_(b.clone())))
     got = e.to_host(e.polymul(a, b))
     assert np.array_equal(got, want)
     # the stand-alone transforms (in place): forward = the compiled kernel's and the oracle's words, inverse undoes it
@@ -65,15 +52,14 @@ def test_assembly_product_every_modulus_of_the_table(oracle_factory, engine_fact
     o, e = oracle_factory(32, 1024, m), engine_factory(32, 1024, m)
     a = e.fill_uniform(e.empty(2), SEED + 3, 0)
     b = e.fill_uniform(e.empty(2), SEED + 3, 1)
-    os.environ["NFLHIP_U32_ASM"] = "1"
     got = e.to_host(e.polymul(a, b))
     assert np.array_equal(got, o.polymul(e.to_host(a), e.to_host(b)))
 
 
 @pytest.mark.parametrize("m,batch", [(1, 1), (2, 1), (2, 127), (1, 257), (2, 300), (3, 85), (2, 70001)])
-def test_lane_per_row_product_n8(m, batch, oracle_factory, engine_factory):
+def test_lane_per_row_product_n8(m, batch, oracle_factory, engine_factory, compiled_engine_factory):
     """n = 8 (the reference's (8, 60, uint32_t) config): one lane per row (tools/gen_row8_u32_asm.py)"""
-    o, e = oracle_factory(32, 8, m), engine_factory(32, 8, m)
+    o, e, ec = oracle_factory(32, 8, m), engine_factory(32, 8, m), compiled_engine_factory(32, 8, m)
     a = e.fill_uniform(e.empty(batch), SEED, 0)
     b = e.fill_uniform(e.empty(batch), SEED, 1)
     ha, hb = e.to_host(a), e.to_host(b)
@@ -81,9 +67,7 @@ def test_lane_per_row_product_n8(m, batch, oracle_factory, engine_factory):
     ha[0, :, 0], ha[0, :, 1], ha[0, :, 2] = 0, 1, P - 1
     hb[0, :, 0], hb[0, :, 1], hb[0, :, 7] = P - 1, P - 1, P - 1
     a, b = e.to_device(ha), e.to_device(hb)
-    os.environ["NFLHIP_U32_ASM"] = "0"
-    want = e.to_host(e.polymul(a, b))
-    os.environ["NFLHIP_U32_ASM"] = "2"
+    want = ec.to_host(ec.polymul(a, b))
     got = e.to_host(e.polymul(a, b))
     assert np.array_equal(got, want)
     k = min(batch, 300)

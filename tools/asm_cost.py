@@ -78,7 +78,13 @@ def pipe(stem, n, workload, nm_w):
 block("polymul4096nt", 4096, 12, "B", 4)
 block("polymul8192", 8192, 13, "G", 2)
 block("polymul16384", 16384, 14, "C", 8)
-pipe("polymul_pipe32768", 32768, "F", 2)
+def rows32k(workload, nm_w):   # b' = NTT(b), then c = INTT(NTT(a) (.) b'): the two register-resident row kernels of n = 32768
+    prm, a = operands(64, 32768, 1, 1)
+    k = lambda stem: asm_emu.run_block_kernel(os.path.join(CSRC, stem + "_gfx950.s"), 32768, 1, prm, a, a, 15, words_per_thread=32)
+    case("ntt_fwd32768 + polymul_ntt32768", workload, nm_w, lambda: (k("ntt_fwd32768"), k("polymul_ntt32768")), 1)
+
+
+rows32k("F", 2)
 pipe("polymul_pipe65536nt", 65536, "E", 30)
 row("row1024_u32", 32, 1024, 4, True, "A", 1, 4)
 row("row128_u16", 16, 128, 32, False, "H", 1, 32)

@@ -2513,30 +2513,33 @@ KERNELS16K = {
 
 def main():
     outdir = os.path.dirname(OUT)
+    experiments = bool(os.environ.get("NFL_GEN_EXPERIMENTS"))   # also emit the variants that were measured and not kept
+    nt = lambda em_: [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em_.lines]
     configure("pair")
     for kind, (stem, kname) in KERNELS.items():
-        emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind),
-                  args=ARGS_STD + [("i32", 48)] if kind in ("fwd2", "inv2") else None)
-    # the n = 4096 product and the two-row transforms with non-temporal coefficient streams (the default; NFLHIP_NT4096=0 = plain)
-    for kind in ("polymul", "fwd2", "inv2"):
-        stem, kname = KERNELS[kind]
-        em_nt = build(kind)
-        em_nt.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em_nt.lines]
-        emit_file(os.path.join(outdir, stem + "nt_gfx950.s"), kname.replace("_asm", "nt_asm"), em_nt,
-                  args=ARGS_STD + [("i32", 48)] if kind in ("fwd2", "inv2") else None)
-    emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
-    # the same kernel with the coefficient streams marked non-temporal (`nt`): 3 x 15.7 MB of data per product pass
-    # through each XCD's 4 MiB L2 exactly once, the 31 MB of twiddle tables are what is worth keeping there
+        args = ARGS_STD + [("i32", 48)] if kind in ("fwd2", "inv2") else None
+        if kind in ("polymul", "fwd2", "inv2"):
+            # the n = 4096 product and the two-row transforms stream their coefficients with `nt` (+1 % on workload B)
+            em_nt = build(kind)
+            em_nt.lines = nt(em_nt)
+            emit_file(os.path.join(outdir, stem + "nt_gfx950.s"), kname.replace("_asm", "nt_asm"), em_nt, args=args)
+            if not experiments:
+                continue
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind), args=args)
+    # n = 65536: the three-role pipeline kernel; coefficient streams `nt`: 3 x 15.7 MB of data per product pass through each
+    # XCD's 4 MiB L2 exactly once, the 31 MB of twiddle tables are what is worth keeping there (+3 % on workload E)
     em_nt = build_pipe()
-    em_nt.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em_nt.lines]
+    em_nt.lines = nt(em_nt)
     emit_file(os.path.join(outdir, "polymul_pipe65536nt_gfx950.s"), "nflhip_polymul_pipe65536nt_asm", em_nt, args=ARGS_PIPE)
-    # n = 32768: the same three-role kernel with radix-8 streaming roles
-    em15 = build_pipe(15)
-    em15.lines = [l + " nt" if ("global_load_dwordx2" in l or "global_store_dwordx2" in l) else l for l in em15.lines]
-    emit_file(os.path.join(outdir, "polymul_pipe32768_gfx950.s"), "nflhip_polymul_pipe32768_asm", em15, args=ARGS_PIPE)
-    # one-launch variants: rows pinned to an XCD, intermediates through its L2 (fused_header)
+    if experiments:
+        emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
+        em15 = build_pipe(15)     # n = 32768 on the same kernel with radix-8 streaming roles (superseded by build_row32k)
+        em15.lines = nt(em15)
+        emit_file(os.path.join(outdir, "polymul_pipe32768_gfx950.s"), "nflhip_polymul_pipe32768_asm", em15, args=ARGS_PIPE)
+    # one-launch variants: rows pinned to an XCD, intermediates through its L2 (fused_header); "l" = the pooled-scratch
+    # experiment (measured, not kept)
     global FUSED_LOADS, FUSED_LIFO
-    for lg, mod, sfx in ((16, "", ""), (15, "", ""), (16, "", "l"), (15, "", "l")):
+    for lg, mod, sfx in ((16, "", ""), (15, "", "")) + (((16, "", "l"), (15, "", "l")) if experiments else ()):
         FUSED_LOADS = mod
         FUSED_LIFO = sfx == "l"
         emf = build_pipe(lg, fused=True)

@@ -13,7 +13,7 @@ def rate(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 by = 3 * batch * 4 * 4096 * 8
-print(os.environ.get("NFLHIP_STREAM_BLOCKS"), "add %.2f TB/s  mul %.2f TB/s" % (by / rate(lambda: e.pointwise(OP_ADD, a, b, out=c)) / 1e12, by / rate(lambda: e.pointwise(OP_MUL, a, b, out=c)) / 1e12))
+print("add %.2f TB/s  mul %.2f TB/s" % (by / rate(lambda: e.pointwise(OP_ADD, a, b, out=c)) / 1e12, by / rate(lambda: e.pointwise(OP_MUL, a, b, out=c)) / 1e12))
 d = e.fill_uniform(e.empty(batch), 2, 0)
 print("eval a*b+d %.2f TB/s" % (4 * batch * 4 * 4096 * 8 / rate(lambda: e.eval([0, 1, 0x12, 2, 0x10], [a, b, d], out=c)) / 1e12),
       "fill %.2f TB/s" % (batch * 4 * 4096 * 8 / rate(lambda: e.fill_uniform(c, 3, 0)) / 1e12),

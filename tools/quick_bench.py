@@ -2,9 +2,9 @@
 """Experiment driver (GPU box): time kernel variants of the metric kernel and
 check that every variant produces the same words as variant 2 (the plain
 Harvey-range arithmetic).  One subprocess per variant because the variant is
-latched from the NFLHIP_VARIANT environment variable at first launch.
+read from the NFLHIP_VARIANT environment variable when a context is created.
 
-  python tools/quick_bench.py 2 22 32 52 [--batch 16384] [--iters 10]
+  python tools/quick_bench.py asm hipcc [--batch 16384] [--iters 10]
 """
 import json
 import os
