@@ -187,6 +187,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   const size_t Lacc = c->shape.crt_Lacc;
   c->h_Q = Q;
   c->h_Q.resize(c->shape.crt_L, 0);
+  c->shape.crt_Q0 = Q.empty() ? 0 : Q[0];
   const size_t kStride = 36;  // fixed, zero-padded row stride of the device CRT tables
   const bool crt_ok = Lacc <= kStride;  // beyond that crt_lift reports NFLHIP_ERR_UNSUPPORTED, the transforms still work
   std::vector<uint64_t> qhat(nm * kStride, 0), qsh(6 * kStride, 0);
@@ -897,8 +898,8 @@ static int polymul_any(nflhip_ctx *ctx, void *c, const void *a, const void *b, i
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u32)");
   }
-  if (ctx->shape.limb_bits == 16 && !b_is_ntt) {
-    hipError_t e = launch_row128_u16_asm(ctx->shape, ctx->tabs, 0, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, batch, st);
+  if (ctx->shape.limb_bits == 16) {
+    hipError_t e = launch_row128_u16_asm(ctx->shape, ctx->tabs, b_is_ntt ? 1 : 0, (uint16_t *)c, (const uint16_t *)a, (const uint16_t *)b, batch, st);
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "polymul(u16)");
   }

@@ -37,6 +37,7 @@ struct Shape {
   size_t n, nm;
   size_t crt_L;      // limbs of a lifted coefficient
   size_t crt_Lacc;   // limbs of the accumulator (L+1)
+  uint64_t crt_Q0;   // the moduli product when it is below 2^64 (crt_L == 1), else its low word
   int small_delta;   // every modulus is 2^(W-2) - delta with delta < 2^32 (delta-form butterflies)
   // configuration, read ONCE when the context is created (include/nflhip.h "environment"):
   int compiled_only; // NFLHIP_VARIANT=hipcc: the compiled (hipcc) kernels serve every call -- the independent cross-check

@@ -344,8 +344,9 @@ enum AsmKind {
   kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
   kAsmXcd64k, kAsmXcd32k,                                            // one launch of persistent workgroups, rows pinned to an XCD
   kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
-  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32, kAsmRow8U32,                                  // 32-bit limbs
-  kAsmRow128U16, kAsmRowFwd128U16, kAsmRowInv128U16,                 // 16-bit limbs
+  kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32,                                               // 32-bit limbs
+  kAsmRow8U32, kAsmRowNtt8U32, kAsmRowFwd8U32, kAsmRowInv8U32,       // 32-bit limbs, n = 8: one lane per row
+  kAsmRow128U16, kAsmRowNtt128U16, kAsmRowFwd128U16, kAsmRowInv128U16,   // 16-bit limbs
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -360,8 +361,9 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul_pipe65536nt_asm",
     "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
     "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm", "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
-    "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm", "nflhip_row8_u32_asm",
-    "nflhip_row128_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm"};
+    "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm",
+    "nflhip_row8_u32_asm", "nflhip_row8_ntt_u32_asm", "nflhip_row8_fwd_u32_asm", "nflhip_row8_inv_u32_asm",
+    "nflhip_row128_u16_asm", "nflhip_row128_ntt_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -534,13 +536,14 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
 // 32-bit limbs, n = 1024 / 2048 / 4096: the fused product with one / two / four waves per row (tools/gen_row1024_u32_asm.py)
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                                   const uint32_t *b, size_t batch, hipStream_t st) {
-  // mode (as launch_row1024_u32): 0 fused product, 2 forward (canonical NTT-form words out), 3 inverse
-  if (s.limb_bits == 32 && s.logn == 3 && mode == 0 && !s.compiled_only) {
+  // mode (as launch_row1024_u32): 0 fused product, 1 product with b already transformed (n = 8 only), 2 forward
+  // (canonical NTT-form words out), 3 inverse
+  if (s.limb_bits == 32 && s.logn == 3 && mode >= 0 && mode <= 3 && !s.compiled_only) {
     // n = 8 (the reference's (8, 60, uint32_t) config): one LANE per row, 256 rows per workgroup (tools/gen_row8_u32_asm.py)
     const unsigned long long rows8 = (unsigned long long)batch * s.nm;
     if (rows8 == 0) return hipSuccess;
     if (rows8 * s.nm >= (1ull << 32)) return hipErrorNotSupported;
-    hipFunction_t f8 = asm_fn(kAsmRow8U32);
+    hipFunction_t f8 = asm_fn((AsmKind)(kAsmRow8U32 + mode));
     if (!f8) return hipErrorNotSupported;
     struct {
       void *c;
@@ -576,13 +579,13 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
 // (tools/gen_row128_u16_asm.py)
 hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, uint16_t *c, const uint16_t *a,
                                  const uint16_t *b, size_t batch, hipStream_t st) {
-  // mode: 0 fused product, 2 forward (canonical NTT-form words out), 3 inverse
-  if (s.limb_bits != 16 || s.logn != 7 || s.compiled_only || (s.nm & (s.nm - 1)) != 0 || (mode != 0 && mode != 2 && mode != 3))
+  // mode: 0 fused product, 1 product with b already transformed, 2 forward (canonical NTT-form words out), 3 inverse
+  if (s.limb_bits != 16 || s.logn != 7 || s.compiled_only || (s.nm & (s.nm - 1)) != 0 || mode < 0 || mode > 3)
     return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorNotSupported;
-  hipFunction_t fn = asm_fn(mode == 0 ? kAsmRow128U16 : (mode == 2 ? kAsmRowFwd128U16 : kAsmRowInv128U16));
+  hipFunction_t fn = asm_fn((AsmKind)(kAsmRow128U16 + mode));
   if (!fn) return hipErrorNotSupported;
   struct {
     void *c;

@@ -652,9 +652,135 @@ __global__ void k_crt_lift(uint64_t *out, const T *d, const ModConst<T> *__restr
   for (int k = 0; k < L; ++k) o[k] = acc[k];
 }
 
+// 16- and 32-bit limbs with a moduli product below 2^64 (one lifted limb: every configuration the reference's tests use for
+// these widths, e.g. (1024, 60-bit, uint32_t) and (128, 14-bit, uint16_t), tests/CMakeLists.txt:19-48): HBM-bound streaming
+// kernels.  A thread owns FOUR consecutive coefficients: one vector load per modulus row, two 16-byte stores of lifted
+// words; algorithmic bytes = nm n w + 8 n per polynomial.
+template <typename T, int NM> struct alignas(4 * sizeof(T)) Quad { T v[4]; };
+
+template <typename T, int NM>
+__global__ void __launch_bounds__(256) k_crt_lift_small(uint64_t *__restrict__ out, const T *__restrict__ d,
+                                                        const ModConst<T> *__restrict__ mc, const uint64_t *__restrict__ qhat,
+                                                        uint64_t Q, int logn, size_t nquads) {
+  typedef Quad<T, NM> Q4;
+  uint64_t qh[NM];
+  T yinv[NM], yinv_sh[NM], p[NM];
+#pragma unroll
+  for (int cm = 0; cm < NM; ++cm) {
+    qh[cm] = qhat[(size_t)cm * kCrtMaxLimbs];
+    yinv[cm] = mc[cm].yinv;
+    yinv_sh[cm] = mc[cm].yinv_sh;
+    p[cm] = mc[cm].p;
+  }
+  const size_t qlog = (size_t)logn - 2;  // quads per row
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < nquads; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g >> qlog, i4 = g & ((((size_t)1) << qlog) - 1);
+    unsigned __int128 acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int cm = 0; cm < NM; ++cm) {
+      const Q4 x = reinterpret_cast<const Q4 *>(d + ((b * NM + cm) << logn))[i4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += (unsigned __int128)qh[cm] * (uint64_t)mul_shoup<T>(x.v[k], yinv[cm], yinv_sh[cm], p[cm]);
+    }
+    ulonglong2 o[2];
+    uint64_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned __int128 a = acc[k];          // < NM * Q: at most NM - 1 subtractions
+#pragma unroll
+      for (int t = 1; t < NM; ++t) a = a >= (unsigned __int128)Q ? a - Q : a;
+      r[k] = (uint64_t)a;
+    }
+    o[0] = make_ulonglong2(r[0], r[1]);
+    o[1] = make_ulonglong2(r[2], r[3]);
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(out + g * 4);
+    dst[0] = o[0];
+    dst[1] = o[1];
+  }
+}
+
+// x mod p for p < 2^30 and any 64-bit x: Barrett with mu = floor(2^64 / p) (the quotient estimate is at most 2 short)
+__device__ __forceinline__ uint32_t mod_small(uint64_t x, uint32_t p, uint64_t mu) {
+  uint64_t r = x - __umul64hi(x, mu) * p;
+  r = r >= p ? r - p : r;
+  r = r >= p ? r - p : r;
+  return (uint32_t)r;
+}
+
+template <typename T, int NM>
+__global__ void __launch_bounds__(256) k_crt_project_small(T *__restrict__ d, const uint64_t *__restrict__ limbs,
+                                                           const ModConst<T> *__restrict__ mc, int logn, int Lin, size_t nquads) {
+  typedef Quad<T, NM> Q4;
+  uint32_t p[NM], beta[NM];
+  uint64_t mu[NM];
+#pragma unroll
+  for (int cm = 0; cm < NM; ++cm) {
+    p[cm] = mc[cm].p;
+    beta[cm] = mc[cm].beta;            // 2^64 mod p
+    mu[cm] = ~0ull / p[cm];            // floor((2^64 - 1) / p) = floor(2^64 / p) for odd p
+  }
+  const size_t qlog = (size_t)logn - 2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < nquads; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g >> qlog, i4 = g & ((((size_t)1) << qlog) - 1);
+    const uint64_t *x = limbs + g * 4 * (size_t)Lin;
+    uint32_t r[NM][4];
+#pragma unroll
+    for (int cm = 0; cm < NM; ++cm)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[cm][k] = 0;
+    for (int l = Lin - 1; l >= 0; --l) {   // Horner over the limbs, most significant first
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint64_t w = x[(size_t)k * Lin + l];
+#pragma unroll
+        for (int cm = 0; cm < NM; ++cm)
+          r[cm][k] = mod_small((uint64_t)r[cm][k] * beta[cm] + mod_small(w, p[cm], mu[cm]), p[cm], mu[cm]);
+      }
+    }
+#pragma unroll
+    for (int cm = 0; cm < NM; ++cm) {
+      Q4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.v[k] = (T)r[cm][k];
+      reinterpret_cast<Q4 *>(d + ((b * NM + cm) << logn))[i4] = o;
+    }
+  }
+}
+
+template <typename T>
+static hipError_t launch_crt_small(const Shape &s, const DevTables &t, uint64_t *limbs_out, const T *d_in, T *d_out,
+                                   const uint64_t *limbs_in, size_t L_in, size_t batch, hipStream_t st) {
+  const size_t nquads = batch * (s.n >> 2);
+  size_t blocks = (nquads + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+#define NFLHIP_CRT_SMALL(NM)                                                                                              \
+  if (limbs_out) hipLaunchKernelGGL((k_crt_lift_small<T, NM>), dim3((unsigned)blocks), dim3(256), 0, st, limbs_out, d_in, mc, \
+                                    t.qhat, s.crt_Q0, s.logn, nquads);                                                    \
+  else hipLaunchKernelGGL((k_crt_project_small<T, NM>), dim3((unsigned)blocks), dim3(256), 0, st, d_out, limbs_in, mc,     \
+                          s.logn, (int)L_in, nquads);
+  switch (s.nm) {
+    case 1: NFLHIP_CRT_SMALL(1) break;
+    case 2: NFLHIP_CRT_SMALL(2) break;
+    case 3: NFLHIP_CRT_SMALL(3) break;
+    case 4: NFLHIP_CRT_SMALL(4) break;
+    default: return hipErrorNotSupported;
+  }
+#undef NFLHIP_CRT_SMALL
+  return hipGetLastError();
+}
+template <> hipError_t launch_crt_small<uint64_t>(const Shape &, const DevTables &, uint64_t *, const uint64_t *, uint64_t *,
+                                                  const uint64_t *, size_t, size_t, hipStream_t) {
+  return hipErrorNotSupported;
+}
+
 template <typename T>
 hipError_t launch_crt_lift(const Shape &s, const DevTables &t, uint64_t *limbs, const T *d, size_t batch, hipStream_t st) {
   if (batch == 0) return hipSuccess;
+  if (sizeof(T) < 8 && s.crt_L == 1 && s.nm <= 4 && s.logn >= 2 && (((uintptr_t)d | (uintptr_t)limbs) & 15) == 0) {
+    hipError_t e = launch_crt_small<T>(s, t, limbs, d, nullptr, nullptr, 0, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (std::is_same<T, uint64_t>::value) {
     hipError_t e = launch_crt_lift_fast_u64(s, t, limbs, (const uint64_t *)d, batch, st);
     if (e != hipErrorNotSupported) return e;
@@ -763,6 +889,10 @@ hipError_t launch_crt_project(const Shape &s, const DevTables &t, T *d, const ui
   if (batch == 0) return hipSuccess;
   if (std::is_same<T, uint64_t>::value) {
     hipError_t e = launch_crt_project_fast_u64(s, t, (uint64_t *)d, limbs, L_in, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
+  if (sizeof(T) < 8 && s.nm <= 4 && s.logn >= 2 && L_in <= 64 && (((uintptr_t)d | (uintptr_t)limbs) & 15) == 0) {
+    hipError_t e = launch_crt_small<T>(s, t, nullptr, nullptr, d, limbs, L_in, batch, st);
     if (e != hipErrorNotSupported) return e;
   }
   const size_t total = batch * s.nm * s.n;

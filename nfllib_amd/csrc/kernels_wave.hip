@@ -437,7 +437,7 @@ hipError_t launch_row1024_u32(const Shape &s, const DevTables &t, int mode, uint
   // (Shape::compiled_only = the compiled kernels below instead).  Measured (MI355X, round 2): 201 -> 243 M products/s at
   // u32/1024/1, 78.9 -> 96.7 M at u32/2048/1, 11.2 -> 13.3 M at u32/4096/4; transforms (batch 2^17) forward / inverse
   // 439 / 408 -> 463 / 444 M at n = 1024, 189 / 207 -> 212 / 234 M at 2048, 25.7 / 23.5 -> 28.9 / 30.6 M at 4096/4
-  if (!s.compiled_only && ((s.logn >= 10 && s.logn <= 12 && (mode == 0 || mode == 2 || mode == 3)) || (s.logn == 3 && mode == 0))) {
+  if (!s.compiled_only && ((s.logn >= 10 && s.logn <= 12 && (mode == 0 || mode == 2 || mode == 3)) || s.logn == 3)) {
     const hipError_t e = launch_row1024_u32_asm(s, t, mode, c, a, b, batch, st);
     if (e != hipErrorNotSupported) return e;
   }

@@ -55,6 +55,11 @@ def test_emulated_lane_per_row_product_n8(nm, batch, generated, oracle_factory):
     prm, a, b = operands(o, 32, 8, nm, batch, 11)
     got = asm_emu.run_row_kernel(generated("row8_u32"), 32, 8, nm, prm, a, b, 256, True)
     assert np.array_equal(got, o.polymul(a, b))
+    # the stand-alone transforms and the product with b already transformed
+    fa, fb = o.ntt(a), o.ntt(b)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row8_fwd_u32"), 32, 8, nm, prm, a, a, 256, True), fa)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row8_inv_u32"), 32, 8, nm, prm, fa, fa, 256, True), a)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row8_ntt_u32"), 32, 8, nm, prm, a, fb, 256, True), o.polymul(a, b))
 
 
 @pytest.mark.parametrize("n,nm,batch", [(1024, 1, 1), (1024, 3, 3), (2048, 2, 1), (4096, 1, 1), (4096, 3, 1)])
@@ -85,6 +90,7 @@ def test_emulated_u16_product_and_transforms(nm, batch, generated, oracle_factor
     assert np.array_equal(f, o.ntt(a))
     back = asm_emu.run_row_kernel(generated("row128_inv_u16"), 16, 128, nm, prm, f, f, 32, False)
     assert np.array_equal(back, a)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row128_ntt_u16"), 16, 128, nm, prm, a, o.ntt(b), 32, False), o.polymul(a, b))
 
 
 @pytest.mark.parametrize("stem,n,block_log,nm,batch", [("polymul4096nt", 4096, 12, 2, 2), ("polymul4096nt", 4096, 12, 1, 1),

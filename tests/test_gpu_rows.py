@@ -122,6 +122,18 @@ def test_sequence_samplers_equal_a_loop_of_single_calls(lb, n, m, engine_factory
     for dist, p0, p1 in ((DIST_UNIFORM, 0, 1), (DIST_BOUNDED, 9, 2), (DIST_ZO, 0x7F, 1), (DIST_HWT, max(1, n // 8), 1)):
         for first, stride in ((100, 1), (5, 3)):
             got = e.to_host(e.sample_seq(e.empty(batch), dist, key, first, stride, param0=p0, param1=p1))
+            if dist in (DIST_UNIFORM, DIST_BOUNDED):   # ... and against the CPU statement of the rule on the same keystream
+                from oracle import samplers as S
+                for b in (0, batch - 1):
+                    sid = first + b * stride
+                    if dist == DIST_UNIFORM:
+                        w = S.chacha20_words(key, sid, 0, m * n, counter_base=S.domain_base("uniform"))
+                        w = (w & np.uint64((1 << lb) - 1)).astype(e.np_dtype).reshape(1, m, n)
+                        want = S.uniform(w, [int(x) for x in e.P])
+                    else:
+                        w = S.chacha20_words(key, sid, 0, n, counter_base=S.domain_base("bounded")).reshape(1, n)
+                        want = S.non_uniform(w, [int(x) for x in e.P], p0, p1, dtype=e.np_dtype)
+                    assert np.array_equal(got[b:b + 1], want), (dist, first, stride, b)
             for b in range(batch):
                 one = e.to_host(e.sample(e.empty(1), dist, key, stream_id=first + b * stride, param0=p0, param1=p1))
                 assert np.array_equal(got[b:b + 1], one), (dist, first, stride, b)
@@ -155,6 +167,11 @@ def test_strided_expression_batches(lb, n, m, oracle_factory, engine_factory):
     want2 = e.to_host(e.eval(prog, [u, dense_key, inter[1::2].contiguous()]))
     got = e.to_host(out)
     assert np.array_equal(got[0::2], want1) and np.array_equal(got[1::2], want2)
+    # ... and against the CPU checker directly: u * key + e with the reference's mulmod / addmod (ops.hpp:124-135, 183-219)
+    from nfllib_amd import OP_ADD, OP_MUL
+    hu, hkey, hinter = e.to_host(u), e.to_host(dense_key), e.to_host(inter)
+    for half, col in ((0, got[0::2]), (1, got[1::2])):
+        assert np.array_equal(col, o.pointwise(OP_ADD, o.pointwise(OP_MUL, hu, hkey), np.ascontiguousarray(hinter[half::2])))
     # aliasing: in place on the interleaved operand
     e.eval_strided(prog, [u, key, inter], [1, 0, 2], inter, out_stride=2, batch=k)
     assert np.array_equal(e.to_host(inter)[0::2], want1)

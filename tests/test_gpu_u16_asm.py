@@ -31,6 +31,10 @@ def test_assembly_product_matches_generic_kernels_and_oracle(m, batch, oracle_fa
     assert np.array_equal(want_f[:1], o.ntt(ha[:1]))
     assert np.array_equal(e.to_host(e.intt_(fa)), ha)
     assert np.array_equal(e.to_host(e.intt_(e.ntt_(b.clone()))), hb)
+    # the product with b already transformed (keys kept in NTT form: tests/nfllib_demo_main_op.cpp:26-46)
+    fb = e.ntt_(b.clone())
+    assert np.array_equal(e.to_host(e.polymul(a, fb, b_is_ntt=True)), want)
+    assert np.array_equal(ec.to_host(ec.polymul(a, fb, b_is_ntt=True)), want)
     k = min(batch, 9)
     assert np.array_equal(got[:k], o.polymul(ha[:k], hb[:k]))
     a2, b2 = a.clone(), b.clone()

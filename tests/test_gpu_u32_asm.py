@@ -72,6 +72,12 @@ def test_lane_per_row_product_n8(m, batch, oracle_factory, engine_factory, compi
     assert np.array_equal(got, want)
     k = min(batch, 300)
     assert np.array_equal(got[:k], o.polymul(ha[:k], hb[:k]))
+    # stand-alone transforms and the product with b already transformed: generated kernels of their own too
+    fa, fb = e.ntt_(a.clone()), e.ntt_(b.clone())
+    assert np.array_equal(e.to_host(fa), ec.to_host(ec.ntt_(a.clone())))
+    assert np.array_equal(e.to_host(fa)[:k], o.ntt(ha[:k]))
+    assert np.array_equal(e.to_host(e.intt_(fa.clone())), ha)
+    assert np.array_equal(e.to_host(e.polymul(a, fb, b_is_ntt=True)), want)
     a2 = a.clone()
     e.polymul(a2, b, out=a2)
     assert np.array_equal(e.to_host(a2), want)

@@ -40,3 +40,27 @@ def test_generators_that_die_early_and_key_changes_on_the_gpu():
     subprocess.check_call(["make", "-s", "-C", CPP, "deferred_edges"])
     r = subprocess.run([os.path.join(CPP, "deferred_edges")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_deferred_poly_p_products_against_the_cpu_checker(tmp_path, oracle_factory):
+    """the reference's product sequence on resident handles in a loop (queued, levelled, coalesced into batched launches)
+    against the ORACLE, not against another HIP path: operand i is nfl::uniform(seed + i), which the checker regenerates"""
+    import numpy as np
+    from conftest import SEED
+    subprocess.check_call(["make", "-s", "-C", CPP, "deferred_product"])
+    K, out = 40, str(tmp_path / "products.bin")
+    r = subprocess.run([os.path.join(CPP, "deferred_product"), out, str(K), str(SEED)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw = open(out, "rb").read()
+    off = 0
+    for lb, n, m in ((64, 4096, 4), (32, 1024, 2)):
+        o = oracle_factory(lb, n, m)
+        dt = {64: np.uint64, 32: np.uint32}[lb]
+        words = K * n * m
+        got = np.frombuffer(raw, dtype=dt, count=words, offset=off).reshape(K, m, n)
+        off += words * (lb // 8)
+        a = np.concatenate([o.fill_uniform(1, SEED + 2 * i, 0) for i in range(K)])
+        b = np.concatenate([o.fill_uniform(1, SEED + 2 * i + 1, 0) for i in range(K)])
+        assert np.array_equal(got, o.polymul(a, b)), (lb, n, m)
+    assert off == len(raw)

@@ -115,7 +115,7 @@ def run(em, jobs):
 
 
 def build(mode="polymul"):
-    """mode: polymul | fwd (c = NTT(a), canonical) | inv (c = INTT(a))"""
+    """mode: polymul | polymul_ntt (b already in NTT form) | fwd (c = NTT(a), canonical) | inv (c = INTT(a))"""
     em = G.Emitter()
     R = em.raw
     L = em.lines.append
@@ -164,6 +164,9 @@ def build(mode="polymul"):
         if mode == "polymul":
             for q in range(16):
                 R("global_load_ushort v%d, v%d, s[26:27] offset:%d" % (V_B + q, V_GOFF, 16 * q))
+        elif mode == "polymul_ntt":   # NTT-form words 16 l + j: the layout the point-wise step works in
+            for j in range(16):
+                R("global_load_ushort v%d, v%d, s[26:27] offset:%d" % (V_B + j, V_OFF2, 2 * j))
     for k in range(1, 16):                               # the row-uniform records, raw {w | w' << 16} into the w' registers
         R("global_load_dword v%d, v%d, s[10:11] offset:%d" % (V_WP1 + k, V_TWOFF, 4 * k))
     # LDS: word e of row r at 4 (136 r + e + (e >> 4)); write base (e = l + 8 q), read base (e = 16 l + j)
@@ -264,7 +267,7 @@ def build(mode="polymul"):
         return em
     for i in range(3):
         lane_records(i, True)
-    if mode == "polymul":
+    if mode in ("polymul", "polymul_ntt"):
         # ------------------------------------------------------------ point-wise product -> a, in [0, 2p)
         run(em, [pointwise(V_A + q, V_B + q) for q in range(16)])
     # ---------------------------------------------------------------- inverse
@@ -302,9 +305,9 @@ ARGS = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 4
 
 
 def main():
-    for mode in ("polymul", "fwd", "inv"):
+    for mode in ("polymul", "polymul_ntt", "fwd", "inv"):
         em = build(mode)
-        sfx = "" if mode == "polymul" else "_" + mode
+        sfx = {"polymul": "", "polymul_ntt": "_ntt"}.get(mode, "_" + mode)
         kname = "nflhip_row128%s_u16_asm" % sfx
         out = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row128%s_u16_gfx950.s" % sfx)
         accum = (NEXT_VGPR + 3) // 4 * 4

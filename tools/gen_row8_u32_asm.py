@@ -111,7 +111,8 @@ def last(u, x, du, dx):
     return gen
 
 
-def build():
+def build(mode="polymul"):
+    """mode: polymul | polymul_ntt (b already in NTT form) | fwd (c = NTT(a), canonical) | inv (c = INTT(a))"""
     em = G.Emitter()
     R = em.raw
     V = em.valu
@@ -132,9 +133,11 @@ def build():
     V("v_mul_u32_u24_e32 v%d, 56, v%d" % (V_MCOFF, V_TWOFF))       # its ModConst<u32> record
     V("v_lshlrev_b32_e32 v%d, 6, v%d" % (V_TWOFF, V_TWOFF))        # its twiddle table: 8 records of 8 bytes
     V("v_lshlrev_b32_e32 v%d, 5, v%d" % (V_OFF, V_OFF))            # the row: 32 bytes
+    has_b = mode in ("polymul", "polymul_ntt")
     for i in range(2):
         R("global_load_dwordx4 v[%d:%d], v%d, s[6:7] offset:%d" % (V_CA + 4 * i, V_CA + 4 * i + 3, V_OFF, 16 * i))
-        R("global_load_dwordx4 v[%d:%d], v%d, s[8:9] offset:%d" % (V_CB + 4 * i, V_CB + 4 * i + 3, V_OFF, 16 * i))
+        if has_b:
+            R("global_load_dwordx4 v[%d:%d], v%d, s[8:9] offset:%d" % (V_CB + 4 * i, V_CB + 4 * i + 3, V_OFF, 16 * i))
     # p 2p mu ninv | ninv_sh w1ninv w1ninv_sh (beta): 28 bytes used
     R("global_load_dwordx4 v[%d:%d], v%d, s[12:13]" % (V_S[0], V_S[0] + 3, V_MCOFF))
     R("global_load_dwordx3 v[%d:%d], v%d, s[12:13] offset:16" % (V_S[1], V_S[1] + 2, V_MCOFF))
@@ -150,30 +153,46 @@ def build():
     V("v_mov_b32_e32 v%d, v%d" % (V_W1NSH, V_S[1] + 2))
     V("v_sub_u32_e32 v%d, 0, v%d" % (V_NEGP, V_P))
     R("s_waitcnt vmcnt(0)")
-    # ---------------------------------------------------------------- forward, both operands: tw[(1 << s) + g]
+    # ---------------------------------------------------------------- forward (both operands of a full product): tw[(1 << s) + g]
+    fwd_ops = {"polymul": ((V_CA, V_A), (V_CB, V_B)), "polymul_ntt": ((V_CA, V_A),), "fwd": ((V_CA, V_A),), "inv": ()}[mode]
     for s in range(3):
         half = 4 >> s
         jobs = []
         for g in range(1 << s):
             for h in range(half):
-                for src, dst in ((V_CA, V_A), (V_CB, V_B)):
+                for src, dst in fwd_ops:
                     i0 = g * 2 * half + h
                     if s == 0:   # the loaded words sit in consecutive registers
                         jobs.append(ct(dst + 2 * i0, dst + 2 * (i0 + half), (1 << s) + g, xsrc=src + i0, ysrc=src + i0 + half))
                     else:
                         jobs.append(ct(dst + 2 * i0, dst + 2 * (i0 + half), (1 << s) + g))
-        U.run(em, jobs)
-    U.run(em, [pointwise(V_A + 2 * q, V_B + 2 * q) for q in range(8)])
-    # ---------------------------------------------------------------- inverse: tw[(2 << s) - 1 - g], then n^-1
-    for s in (2, 1):
-        half = 4 >> s
-        jobs = []
-        for g in range(1 << s):
-            for h in range(half):
-                i0 = g * 2 * half + h
-                jobs.append(gs(V_A + 2 * i0, V_A + 2 * (i0 + half), (2 << s) - 1 - g))
-        U.run(em, jobs)
-    U.run(em, [last(V_A + 2 * h, V_A + 2 * (h + 4), V_CA + h, V_CA + h + 4) for h in range(4)])
+        if jobs:
+            U.run(em, jobs)
+    if mode == "fwd":            # canonical words into the consecutive registers, then out
+        def canon(q):
+            def gen(s_):
+                yield from csub(V_A + 2 * q, V_A + 2 * q, V_2P, s_)
+                yield from csub(V_A + 2 * q, V_CA + q, V_P, s_)
+            return gen
+        U.run(em, [canon(q) for q in range(8)])
+    elif mode == "inv":          # NTT-form words (canonical) into the coefficient pairs
+        for q in range(8):
+            V("v_mov_b32_e32 v%d, v%d" % (V_A + 2 * q, V_CA + q))
+    elif mode == "polymul_ntt":  # b arrives transformed: its words are the loaded registers themselves
+        U.run(em, [pointwise(V_A + 2 * q, V_CB + q) for q in range(8)])
+    else:
+        U.run(em, [pointwise(V_A + 2 * q, V_B + 2 * q) for q in range(8)])
+    if mode != "fwd":
+        # ------------------------------------------------------------ inverse: tw[(2 << s) - 1 - g], then n^-1
+        for s in (2, 1):
+            half = 4 >> s
+            jobs = []
+            for g in range(1 << s):
+                for h in range(half):
+                    i0 = g * 2 * half + h
+                    jobs.append(gs(V_A + 2 * i0, V_A + 2 * (i0 + half), (2 << s) - 1 - g))
+            U.run(em, jobs)
+        U.run(em, [last(V_A + 2 * h, V_A + 2 * (h + 4), V_CA + h, V_CA + h + 4) for h in range(4)])
     V("v_cmp_gt_u32_e32 vcc, s16, v%d" % V_ROW)
     R("s_and_saveexec_b64 s[32:33], vcc")
     for i in range(2):
@@ -186,17 +205,20 @@ ARGS = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 4
 
 
 def main():
-    em = build()
-    accum = (NEXT_VGPR + 3) // 4 * 4
-    params = dict(k=KNAME, lds=0, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
-                  karg=56, args=G.args_yaml(ARGS).replace("{.address_space: global, .offset: 48, .size: 8, .value_kind: global_buffer}",
-                                                            "{.offset: 48, .size: 8, .value_kind: by_value}"))
-    with open(OUT, "w") as f:
-        f.write("; GENERATED by tools/gen_row8_u32_asm.py -- do not edit.\n")
-        f.write(G.HEADER % params)
-        f.write("\n".join(em.lines) + "\n")
-        f.write(G.FOOTER % params)
-    print("wrote %s: %d VALU instructions (static), %d lines" % (OUT, em.n_valu, len(em.lines)))
+    for mode, sfx in (("polymul", ""), ("polymul_ntt", "_ntt"), ("fwd", "_fwd"), ("inv", "_inv")):
+        em = build(mode)
+        kname = "nflhip_row8%s_u32_asm" % sfx
+        out = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row8%s_u32_gfx950.s" % sfx)
+        accum = (NEXT_VGPR + 3) // 4 * 4
+        params = dict(k=kname, lds=0, vgpr=NEXT_VGPR, sgpr=NEXT_SGPR, accum=accum, sgprc=NEXT_SGPR + 6, wg=256,
+                      karg=56, args=G.args_yaml(ARGS).replace("{.address_space: global, .offset: 48, .size: 8, .value_kind: global_buffer}",
+                                                                "{.offset: 48, .size: 8, .value_kind: by_value}"))
+        with open(out, "w") as f:
+            f.write("; GENERATED by tools/gen_row8_u32_asm.py -- do not edit.\n")
+            f.write(G.HEADER % params)
+            f.write("\n".join(em.lines) + "\n")
+            f.write(G.FOOTER % params)
+        print("wrote %s: %d VALU instructions (static), %d lines" % (out, em.n_valu, len(em.lines)))
 
 
 if __name__ == "__main__":
