@@ -393,7 +393,7 @@ def main():
         t_f = rate(lambda: eng.ntt_(c)); t_i = rate(lambda: eng.intt_(c))
         t_add = rate(lambda: eng.pointwise(OP_ADD, a, b, out=c)); t_mul = rate(lambda: eng.pointwise(OP_MUL, a, b, out=c))
         t_pn = rate(lambda: eng.polymul(a, bn, out=c, b_is_ntt=True))
-        sub = min(batch, 2048)
+        sub = min(batch, max(2048, (256 << 20) // (nm * n * w)))   # (enough bytes for the launch not to dominate)
         limbs = eng.crt_lift(a[:sub])
         t_l = rate(lambda: eng.crt_lift(a[:sub]), 5); t_p = rate(lambda: eng.crt_project(limbs), 5)
         crt_bytes = sub * (nm * n * w + n * eng.crt_limbs * 8)
@@ -452,29 +452,36 @@ def main():
                    "checksum_of_checksums": checksum, "rccl": rccl},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096_asm", "C": "nflhip_polymul16384_asm",
-                                "E": "nflhip_polymul_pipe65536_asm (block products + streaming passes, 6 launches per step)",
-                                "F": "nflhip_polymul_xcd32768_asm (one launch of persistent workgroups: forward streaming, block products, "
-                                     "inverse streaming of every row on one XCD)",
+                     "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096nt_asm", "C": "nflhip_polymul16384_asm",
+                                "E": "nflhip_polymul_pipe65536nt_asm (block products + streaming passes, 6 launches per step)",
+                                "F": "nflhip_ntt_fwd32768_asm (b) + nflhip_polymul_ntt32768_asm (a, b' streamed): register-resident "
+                                     "32768-word rows, 2 launches per step" if batch * nm >= 256 else
+                                     "nflhip_polymul_xcd32768_asm (one launch of persistent workgroups; fewer than 256 rows)",
                                 "G": "nflhip_polymul8192_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
-    # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  Instructions per wave are
-    # the SQ_INSTS_VALU / SQ_WAVES of the committed counter passes (= the generator's static count for the assembly kernel);
-    # peak = one wave64 instruction per 4 cycles per SIMD, the rate of v_mad_u64_u32 / carry / multiply opcodes on gfx950.
-    # The other workloads: DYNAMIC counts per product (all moduli) from executing the generated kernels on the interpreter of
-    # tests/asm_emu.py (tools/asm_cost.py -> profiles/r02_valu_issue_model.txt; B and A agree with their counter passes).
-    model = "profiles/r02_valu_issue_model.txt"
-    valu = {"B": (6029, 4 * nm, "profiles/r01_v6_asm_pmc.txt"), "A": (2081, nm, "profiles/r02_pmc_sq_A.txt"),
-            "G": (103856, 1, model), "C": (888192, 1, model), "F": (475184, 1, model), "E": (15115680, 1, model),
-            "H": (227, 1, model), "T": (13, 1, model)}.get(kwl)
+    # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue AT THE CLOCK THE KERNEL GETS.
+    # Instructions per product: dynamic counts of the generated kernels on the interpreter of tests/asm_emu.py
+    # (tools/asm_cost.py -> profiles/r03_valu_issue_model.txt; B and A agree with their SQ counter passes).  Issue cost of
+    # the mix: isolated streams price multiply / carry / VOP3 opcodes at 4.2 and plain VOP2 ones at 2.5 cycles per wave64
+    # (profiles/r03_ubench_issue.txt: the 18-instruction 62-bit butterfly 69.5 cycles = 3.86 per instruction); the metric
+    # kernel needs 3.92 cycles per instruction in situ (GRBM_GUI_ACTIVE per launch, profiles/r03_operand_ab.txt).  Clock:
+    # these kernels run at the 1 400 W package limit, sclk ~ 2.0 GHz sustained against 2.4 nominal
+    # (profiles/r03_power_clock.txt) -- the peak below is priced at 2.0 GHz.
+    model = "profiles/r03_valu_issue_model.txt"
+    valu = {"B": (96464, 1), "A": (2081, nm), "G": (103856, 1), "C": (888192, 1), "F": (2 * 16 * (4605 + 10655), 1),
+            "E": (15115680, 1), "H": (227, 1), "T": (13, 1)}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]
-        peak_gi = 256 * 4 * 2.4 / 4.0   # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles, in G wave-instructions/s
+        clock_ghz, cyc_per_inst = 2.0, 3.86
+        peak_gi = 256 * 4 * clock_ghz / cyc_per_inst   # G wave-instructions/s
         ach_gi = inst_per_poly * batch / (kernel_ms * 1e-3) / 1e9
-        result["roofline"]["secondary"] = {"bound": "valu-issue", "achieved": round(ach_gi, 1), "peak": round(peak_gi, 1),
-                                           "unit": "G wave64-inst/s", "frac": round(ach_gi / peak_gi, 4),
-                                           "wave_instructions_per_polymul": inst_per_poly, "source": valu[2]}
+        result["roofline"]["secondary"] = {"bound": "valu-issue at the 1400 W package limit", "achieved": round(ach_gi, 1),
+                                           "peak": round(peak_gi, 1), "unit": "G wave64-inst/s", "frac": round(ach_gi / peak_gi, 4),
+                                           "wave_instructions_per_polymul": inst_per_poly, "clock_GHz": clock_ghz,
+                                           "cycles_per_instruction": cyc_per_inst,
+                                           "source": model + ", profiles/r03_ubench_issue.txt, profiles/r03_power_clock.txt, "
+                                                     "profiles/r03_operand_ab.txt"}
     if extras is not None:
         result["extras"] = extras
     if scatter is not None:

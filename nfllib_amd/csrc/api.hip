@@ -1368,6 +1368,7 @@ class CopyPool {  // a few host threads that memcpy slices; process-wide, starte
     parts_ = parts;
     done_ = 0;
     ++generation_;
+    gen_hint_.store(generation_, std::memory_order_release);
     cv_.notify_all();
     lk.unlock();
     work();  // the calling thread copies too
@@ -1398,14 +1399,22 @@ class CopyPool {  // a few host threads that memcpy slices; process-wide, starte
   void loop() {
     unsigned long long seen = 0;
     for (;;) {
+      // a chunk is ~0.3 ms of copying for one thread: a sleeping worker wakes too late to help, so workers spin for a
+      // while after every job (the next chunk follows within microseconds while a call is in flight) and only then sleep
+      bool got = false;
+      for (int spin = 0; spin < 20000 && !got; ++spin) {
+        if (gen_hint_.load(std::memory_order_acquire) != seen) got = true;
+        else __builtin_ia32_pause();
+      }
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return generation_ != seen; });
+        if (!got) cv_.wait(lk, [&] { return generation_ != seen; });
         seen = generation_;
       }
       work();
     }
   }
+  std::atomic<unsigned long long> gen_hint_{0};
   std::mutex mu_;
   std::condition_variable cv_, cv_done_;
   std::vector<std::thread> workers_;
@@ -1489,19 +1498,48 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
   typedef std::chrono::steady_clock clk;
   auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   const clk::time_point t_begin = clk::now();
-  auto drain = [&](size_t k) -> int {  // chunk k is back in its pinned slot: hand it to the caller
+  // chunk k is back in its pinned slot: hand it to the caller.  Done by a SECOND host thread, so that results leave while
+  // the calling thread (and the pool) copies the next chunks in: the two directions overlap on the host as they do on PCIe
+  std::atomic<size_t> issued{0}, drained{0};
+  std::atomic<int> drain_rc{NFLHIP_OK};
+  std::atomic<bool> stop{false};
+  std::string drain_err;
+  auto drain_one = [&](size_t k) -> int {
     const int s = int(k % HostPipe::kSlots);
     const clk::time_point t0 = clk::now();
-    HIPCHK(ctx, hipEventSynchronize(p->ev_d2h[s]));
+    hipError_t he = hipEventSynchronize(p->ev_d2h[s]);
+    if (he != hipSuccess) {
+      drain_err = std::string("hipEventSynchronize: ") + hipGetErrorString(he);
+      return NFLHIP_ERR_HIP;
+    }
     const clk::time_point t1 = clk::now();
-    pool.copy((char *)out + k * per * pb, p->pinned[s][3], count_of(k) * pb);
+    std::memcpy((char *)out + k * per * pb, p->pinned[s][3], count_of(k) * pb);
     p->t_wait += secs(t0, t1);
     p->t_out += secs(t1, clk::now());
     return NFLHIP_OK;
   };
+  std::thread drainer([&] {
+    (void)hipSetDevice(ctx->device);
+    for (size_t k = 0; k < nchunks; ++k) {
+      while (issued.load(std::memory_order_acquire) <= k) {
+        if (stop.load(std::memory_order_acquire)) return;
+        __builtin_ia32_pause();
+      }
+      const int r = drain_one(k);
+      if (r) { drain_rc.store(r); return; }
+      drained.store(k + 1, std::memory_order_release);
+    }
+  });
+  struct joiner {
+    std::thread &t; std::atomic<bool> &stop;
+    ~joiner() { stop.store(true); if (t.joinable()) t.join(); }
+  } join_guard{drainer, stop};
   for (size_t k = 0; k < nchunks; ++k) {
     const int s = int(k % HostPipe::kSlots);
-    if (k >= size_t(HostPipe::kSlots) && (rc = drain(k - HostPipe::kSlots))) return rc;  // the slot's previous tenant
+    while (k >= size_t(HostPipe::kSlots) && drained.load(std::memory_order_acquire) + HostPipe::kSlots <= k) {  // the slot's previous tenant
+      if (drain_rc.load()) return fail(ctx, drain_rc.load(), drain_err);
+      __builtin_ia32_pause();
+    }
     const size_t cnt = count_of(k), bytes = cnt * pb;
     const void *d_in[3] = {nullptr, nullptr, nullptr};
     for (int j = 0; j < nin; ++j) {
@@ -1526,9 +1564,12 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
     HIPCHK(ctx, hipEventRecord(p->ev_d2h[s], p->s_d2h));
     // the next H2D into this slot's device inputs must not overtake this chunk's kernel
     HIPCHK(ctx, hipStreamWaitEvent(p->s_h2d, p->ev_k[s], 0));
+    issued.store(k + 1, std::memory_order_release);
   }
-  for (size_t k = nchunks > size_t(HostPipe::kSlots) ? nchunks - HostPipe::kSlots : 0; k < nchunks; ++k)
-    if ((rc = drain(k))) return rc;
+  while (drained.load(std::memory_order_acquire) < nchunks) {
+    if (drain_rc.load()) return fail(ctx, drain_rc.load(), drain_err);
+    __builtin_ia32_pause();
+  }
   p->t_total += secs(t_begin, clk::now());
   return NFLHIP_OK;
 }
