@@ -180,7 +180,11 @@ int nflhip_eval_strided_dev(nflhip_ctx *ctx, void *d_out, size_t out_stride, con
  * c = INTT( NTT(a) (.) NTT(b) ): the reference sequence
  *   a.ntt_pow_phi(); b.ntt_pow_phi(); c = a*b; c.invntt_pow_invphi();
  * (poly.hpp:167-168, 350) as one fused device pass.  a, b, c in coefficient
- * form; a and b are not modified; c may alias a or b. */
+ * form; a and b are not modified; c may alias a or b.
+ * Rows of up to 16384 words are ONE launch that touches nothing but its operands: calls on distinct streams run
+ * concurrently.  Longer rows (32768 words: b' = NTT(b) into a scratch, then the product kernel; 65536 and beyond: streaming
+ * passes around block products) go through ONE context-owned scratch area: calls on different streams of one context are
+ * ordered one after the other by events (no host synchronisation); use one context per stream to overlap them. */
 int nflhip_polymul_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const void *d_b, size_t batch,
                        void *stream);
 int nflhip_polymul(nflhip_ctx *ctx, void *h_c, const void *h_a, const void *h_b, size_t batch);

@@ -3,7 +3,7 @@
 # in the same run, and cpu_baseline) and the rocprofv3 kernel summaries of the same commands.
 # Usage: bash tools/final_profiles.sh <tag>   -> gpurun_out/<tag>_bench_<W>.json, gpurun_out/<tag>_kernel_stats_<W>.csv, ...
 set -u
-tag=${1:-r02_final}
+tag=${1:-r03_final}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
@@ -31,4 +31,18 @@ NFL_LWE_REPS=16384 tests/cpp/resident_test | head -1 >> $out/${tag}_lwe_poly_p.j
 python tools/lwe_demo.py 2>/dev/null > $out/${tag}_lwe.jsonl
 python tools/lwe_demo.py --degree 16384 --nmoduli 8 --batch 512 2>/dev/null >> $out/${tag}_lwe.jsonl
 python tools/lwe_demo.py --degree 1024 --nmoduli 2 --batch 65536 2>/dev/null >> $out/${tag}_lwe.jsonl
+# effective clock and power under the product kernels: GRBM_GUI_ACTIVE per launch (cycles, summed over the 8 XCDs) and
+# rocm-smi sampled during a long run
+for wl in B A C F; do
+  rm -rf /tmp/pmc_clk_$wl
+  (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_clk_$wl -- python $here/bench.py --workload $wl --steps 8 --warmup 2 --no-extras --no-cpu-baseline --no-traffic --no-rccl > /dev/null 2>&1)
+  f=$(find /tmp/pmc_clk_$wl -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp "$f" $out/${tag}_pmc_GRBM_GUI_ACTIVE_$wl.csv
+  rm -rf /tmp/pmc_clk_$wl
+done
+smi() { for i in $(seq 1 $2); do rocm-smi -P -c --json 2>/dev/null | tr -d '\n'; echo; sleep 0.25; done > $out/${tag}_smi_$1.jsonl; }
+for wl in C F E; do
+  steps=$([ $wl = E ] && echo 150 || echo 3000)
+  (smi $wl 36 &) ; timeout 120 python bench.py --workload $wl --steps $steps --warmup 10 --no-cpu-baseline --no-traffic --no-extras > $out/${tag}_bench_${wl}_long.json 2>/dev/null; sleep 1.5
+done
 ls -la $out | tail -25
