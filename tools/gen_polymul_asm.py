@@ -126,6 +126,15 @@ SINGLE_STREAM = False   # ring mode: one butterfly at a time (18 temporaries ins
 RING_RECOMPUTE_TWA = False
 
 
+# Power / time ablations of the product kernels (tools/sessions/gpu_round3_g.sh; the results are WRONG by construction, the
+# instruction stream is otherwise the shipped one): NFL_GEN_ABLATE = comma list of
+#   tw0    every lane fetches the twiddle record of lane 0 (one cache line per wave instead of up to 64)
+#   nolds  the exchanges through LDS are dropped (barriers stay)
+#   row0   every workgroup works on one of the first 16 rows (operands and result stay in the L2)
+#   nobfly the butterflies of the register passes are dropped (memory, LDS and the point-wise step remain)
+ABLATE = set(filter(None, os.environ.get("NFL_GEN_ABLATE", "").split(",")))
+
+
 def run_pairs(em, jobs):
     """jobs: list of callables(stream) -> generator; executed two at a time, interleaved."""
     if SINGLE_STREAM:
@@ -348,6 +357,8 @@ class VmCounter:
 
 
 def ct_stage(em, bases, s):
+    if "nobfly" in ABLATE:
+        return
     half = 8 >> s
     jobs = []
     for g in range(1 << s):
@@ -360,6 +371,8 @@ def ct_stage(em, bases, s):
 
 
 def gs_stage(em, base, s):
+    if "nobfly" in ABLATE:
+        return
     half = 8 >> s
     jobs = []
     for g in range(1 << s):
@@ -399,6 +412,8 @@ def tw_lane_stage(em, vm, s, vidx, kreg, descending):
     Descending (inverse, mirrored): index = (K << s) - 1 - (vidx << s) - g.  vidx: VGPR with B or t."""
     tw_base(em, kreg, s, descending)
     em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
+    if "tw0" in ABLATE:
+        em.valu("v_mov_b32_e32 v%d, 0" % (V_TWO,))
     seq = 0
     if not descending:
         for g in range(1 << s):
@@ -416,11 +431,15 @@ def tw_lane_stage(em, vm, s, vidx, kreg, descending):
 
 
 def lds_write(em, addr, base, stride):
+    if "nolds" in ABLATE:
+        return
     for k in range(16):
         em.raw("ds_write_b64 v%d, %s offset:%d" % (addr, vp(base + 2 * k), stride * k))
 
 
 def lds_read(em, addr, base, stride):
+    if "nolds" in ABLATE:
+        return
     for k in range(16):
         em.raw("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), addr, stride * k))
 
@@ -496,6 +515,8 @@ def prologue(em, vm, kind="polymul"):
     R("s_add_u32 s42, s42, s3")                          # row
     R("s_lshl_b32 s42, s42, s88")
     R("s_add_u32 s42, s42, s89")                         # block index
+    if "row0" in ABLATE:
+        R("s_and_b32 s42, s42, 15")
     R("s_lshr_b32 s43, s42, 17")
     R("s_lshl_b32 s42, s42, 15")
     for base, row in ((6, 16), (8, 18), (4, 20)):
@@ -829,6 +850,8 @@ class Ring:
             tw_base(em, kreg, s, desc, koff)
             if vidx is not None:
                 em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
+                if "tw0" in ABLATE:
+                    em.valu("v_mov_b32_e32 v%d, 0" % (V_TWO,))
             self.cur = (name, s)
         if vidx is not None and desc and (fresh or RING_RECOMPUTE_TWA):   # (the address pair is butterfly scratch in ringpair mode)
             em.valu("v_mov_b32_e32 v%d, s84" % (V_TWA,))

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -99,6 +100,30 @@ int main(int argc, char **argv) {
   printf("%-22s %5s", "stream", "instr");
   for (int W : Ws) printf(" | %d wave%s/SIMD        ", W, W > 1 ? "s" : " ");
   printf("\n");
+  // --sustain STREAM W SECONDS: the same launch back to back for SECONDS, the in-kernel clock printed every half second
+  // (sample rocm-smi -P -c beside it): does the stream hold its clock once the power controller has had time to react?
+  if (argc > 4 && !strcmp(argv[1], "--sustain")) {
+    const int W = atoi(argv[3]);
+    const double seconds = atof(argv[4]);
+    for (const KernelRow &k : kRows) {
+      if (strcmp(k.name, argv[2])) continue;
+      const int iters = std::max(4, 400000 / k.ninstr);
+      double elapsed = 0, next = 0.5;
+      while (elapsed < seconds) {
+        Result r = run(k, W, iters);
+        elapsed += 4 * r.ms * 1e-3;
+        if (elapsed >= next) {
+          printf("sustain %s W=%d t=%.1f s: %.2f cycles per unit per SIMD (wall clock), %.0f MHz, %.3f ms per launch\n", k.name, W, elapsed,
+                 r.per_time, r.mhz, r.ms);
+          fflush(stdout);
+          next += 0.5;
+        }
+      }
+      return 0;
+    }
+    printf("no stream named %s\n", argv[2]);
+    return 1;
+  }
   const std::string only = argc > 1 ? argv[1] : "";
   for (const KernelRow &k : kRows) {
     if (!only.empty() && std::string(k.name).find(only) == std::string::npos) continue;
