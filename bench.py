@@ -407,9 +407,12 @@ def main():
         hb = min(batch, max(1, (256 << 20) // (nm * n * w)))
         ha, hbb = eng.to_host(a[:hb]), eng.to_host(b[:hb])
         hcc = eng.h_polymul(ha, hbb)          # (also touches the result array's pages: the caller's arrays exist before the call)
-        t0h = time.perf_counter()
-        eng.h_polymul(ha, hbb, out=hcc)
-        t_host = time.perf_counter() - t0h
+        t_hosts = []
+        for _ in range(5):                    # host threads copy: the median of five calls (single calls vary 2-3x with page placement)
+            t0h = time.perf_counter()
+            eng.h_polymul(ha, hbb, out=hcc)
+            t_hosts.append(time.perf_counter() - t0h)
+        t_host = sorted(t_hosts)[2]
         # core::ntt (core.hpp:455-532), the cyclic row transform tests/ntt_perfs.cpp:155-171 times on
         # poly<uint64_t,1024,2> rows (BASELINE configs[0]'s path): nflhip_ntt_row_dev over resident rows of one modulus
         row_extra = {}
@@ -465,11 +468,11 @@ def main():
     # (tools/asm_cost.py -> profiles/r03_valu_issue_model.txt; B and A agree with their SQ counter passes).  Issue cost of
     # the mix: isolated streams price multiply / carry / VOP3 opcodes at 4.2 and plain VOP2 ones at 2.5 cycles per wave64
     # (profiles/r03_ubench_issue.txt: the 18-instruction 62-bit butterfly 69.5 cycles = 3.86 per instruction); the metric
-    # kernel needs 3.92 cycles per instruction in situ (GRBM_GUI_ACTIVE per launch, profiles/r03_operand_ab.txt).  Clock:
+    # kernel needs 3.7 - 3.9 cycles per instruction in situ (GRBM_GUI_ACTIVE per launch, profiles/r03_operand_ab.txt).  Clock:
     # these kernels run at the 1 400 W package limit, sclk ~ 2.0 GHz sustained against 2.4 nominal
     # (profiles/r03_power_clock.txt) -- the peak below is priced at 2.0 GHz.
     model = "profiles/r03_valu_issue_model.txt"
-    valu = {"B": (96464, 1), "A": (2081, nm), "G": (103856, 1), "C": (888192, 1), "F": (2 * 16 * (4605 + 10655), 1),
+    valu = {"B": (96464, 1), "A": (2081, nm), "G": (103856, 1), "C": (888192, 1), "F": (478144, 1),
             "E": (15115680, 1), "H": (227, 1), "T": (13, 1)}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]

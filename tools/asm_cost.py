@@ -90,7 +90,7 @@ row("row1024_u32", 32, 1024, 4, True, "A", 1, 4)
 row("row128_u16", 16, 128, 32, False, "H", 1, 32)
 row("row8_u32", 32, 8, 256, True, "T", 2, 256)
 
-print("VALU-issue bound of the generated product kernels (dynamic counts from the interpreter; one VALU instruction per SIMD per %.0f"
+print("VALU-issue bound of the generated product kernels (dynamic counts from the interpreter; one VALU instruction per SIMD per %.2f"
       " cycles, %d SIMDs, %.2f GHz)" % (CYCLES, SIMDS, CLOCK / 1e9))
 print("%-22s %-3s %12s %9s %9s %9s %14s %14s %7s" % ("kernel", "wl", "VALU/product", "SALU", "VMEM", "LDS", "bound [1/s]", "measured [1/s]", "ratio"))
 for name, wl, valu, salu, vmem, lds, bound, m in rows:

@@ -77,6 +77,16 @@ def sp(pair):
     return "s[%d:%d]" % pair
 
 
+# Power / time ablations of the product kernels (tools/sessions/gpu_round3_g.sh; the results are WRONG by construction, the
+# instruction stream is otherwise the shipped one): NFL_GEN_ABLATE = comma list of
+#   tw0    every lane fetches the twiddle record of lane 0 (one cache line per wave instead of up to 64)
+#   nolds  the exchanges through LDS are dropped (barriers stay)
+#   row0   every workgroup works on one of the first 16 rows (operands and result stay in the L2)
+#   nobar  the workgroup barriers are dropped as well
+#   nobfly the butterflies of the register passes are dropped (memory, LDS and the point-wise step remain)
+ABLATE = set(filter(None, os.environ.get("NFL_GEN_ABLATE", "").split(",")))
+
+
 class Emitter:
     """Collects instructions, counts VALU work and pads the gfx950
     'VALU writes SGPR -> VALU reads that SGPR: 2 wait states' hazard."""
@@ -89,6 +99,8 @@ class Emitter:
         self.n_nop = 0
 
     def raw(self, text):
+        if ("nolds" in ABLATE and text.startswith("ds_")) or ("nobar" in ABLATE and text.startswith("s_barrier")):
+            return
         self.lines.append("\t" + text)
         self.pos += 1
 
@@ -124,15 +136,6 @@ def interleave(em, gens):
 
 SINGLE_STREAM = False   # ring mode: one butterfly at a time (18 temporaries instead of 36)
 RING_RECOMPUTE_TWA = False
-
-
-# Power / time ablations of the product kernels (tools/sessions/gpu_round3_g.sh; the results are WRONG by construction, the
-# instruction stream is otherwise the shipped one): NFL_GEN_ABLATE = comma list of
-#   tw0    every lane fetches the twiddle record of lane 0 (one cache line per wave instead of up to 64)
-#   nolds  the exchanges through LDS are dropped (barriers stay)
-#   row0   every workgroup works on one of the first 16 rows (operands and result stay in the L2)
-#   nobfly the butterflies of the register passes are dropped (memory, LDS and the point-wise step remain)
-ABLATE = set(filter(None, os.environ.get("NFL_GEN_ABLATE", "").split(",")))
 
 
 def run_pairs(em, jobs):
@@ -222,6 +225,8 @@ def fold2(s, dst, src):
 def ct_bfly(x, y, tw):
     """Cooley-Tukey: x' = x + w*y, y' = x - w*y (any 64-bit words in, any 64-bit words out)."""
     def gen(s):
+        if "nobfly" in ABLATE:
+            return
         U, Y2 = T(s, 4), T(s, 12)
         yield from fold2(s, U, x)
         yield from quotient(s, y, tw, exact=False)
@@ -237,6 +242,8 @@ def ct_bfly(x, y, tw):
 def gs_bfly(x, y, tw):
     """Gentleman-Sande with the negated mirrored twiddle: x' = fold(x + y), y' = (y - x)*w; inputs < 2p."""
     def gen(s):
+        if "nobfly" in ABLATE:
+            return
         E, D, SUM = T(s, 12), T(s, 4), T(s, 16)
         yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(y), S_P2), None, None
         yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (D, S_BORROW[s], E, x), S_BORROW[s], None
@@ -954,6 +961,8 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     R("s_add_u32 s42, s42, s3")                          # row
     R("s_lshl_b32 s42, s42, s86")
     R("s_add_u32 s42, s42, s87")                         # block index
+    if "row0" in ABLATE:
+        R("s_and_b32 s42, s42, 3")
     R("s_lshr_b32 s43, s42, %d" % (32 - 15 - ROW_LG,))
     R("s_lshl_b32 s42, s42, %d" % (15 + ROW_LG,))        # * 4096 G words * 8 bytes
     for base, row in ((6, 16), (8, 18), (4, 20)):

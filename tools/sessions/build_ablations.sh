@@ -2,7 +2,7 @@
 # Builds the ablated libraries of tools/sessions/gpu_round3_g.sh into build/abl_<name>/nfllib_amd/libnflhip.so (run from the
 # repository root, on the CPU container; the objects of the current build are reused, only the code object is regenerated).
 set -eu
-for v in tw0 nolds row0 nobfly tw0,nolds,row0; do
+for v in ${ABLATIONS:-tw0 nolds row0 nobfly tw0,nolds,row0}; do
   d=build/abl_$(echo $v | tr , _)
   rm -rf $d
   mkdir -p $d/nfllib_amd $d/tools
