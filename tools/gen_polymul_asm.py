@@ -210,15 +210,13 @@ def fold2(s, dst, src):
     """dst = (src & (2^62-1)) + (src >> 62)*delta  (< 2^62 + 3*delta); clobbers src's high dword."""
     t = T(s, 0)
     yield "v_lshrrev_b32_e32 v%d, 30, v%d" % (t, src + 1), None, None
-    # (the mask comes from a VGPR: plain VOP2 add / sub / and / mov / lshr issue in ~2.5 cycles per wave64 when every
-    # operand is a VGPR and in ~4.4 with an SGPR operand -- profiles/r03_ubench_issue.txt)
     # (the mask stays in an SGPR.  The isolated streams of tools/ubench_issue.hip price a plain VOP2 op with an SGPR operand
-    # at 4.4 cycles and an all-VGPR one at 2.5, but IN the metric kernel the VGPR form costs 5.3 % MORE cycles per launch
-    # (GRBM_GUI_ACTIVE 6.04 M vs 5.73 M per XCD, same box, profiles/r03_operand_ab.txt); NFL_GEN_VGPR_OPERANDS=1 rebuilds it)
+    # at 4.4 cycles and an all-VGPR one at 2.5, but IN the metric kernel the two forms are the same to 0.2 % (3.10 ms per
+    # launch either way, same box, same checksums: profiles/r03_operand_ab.txt); NFL_GEN_VGPR_OPERANDS=1 rebuilds the other)
     if os.environ.get("NFL_GEN_VGPR_OPERANDS"):
         yield "v_and_b32_e32 v%d, v%d, v%d" % (src + 1, v_mask(), src + 1), None, None
-        return
-    yield "v_and_b32_e32 v%d, %s, v%d" % (src + 1, S_MASK, src + 1), None, None
+    else:
+        yield "v_and_b32_e32 v%d, %s, v%d" % (src + 1, S_MASK, src + 1), None, None
     yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(dst), S_DUMMY, t, S_DELTA, vp(src)), None, None
 
 
@@ -827,8 +825,9 @@ class Ring:
     whole kernel consumes its records is static, so each slot is refilled with the record
     that is NSLOTS uses ahead as soon as its last butterfly has been issued."""
 
-    def __init__(self, em, vm, nslots, uses, passes):
+    def __init__(self, em, vm, nslots, uses, passes, side=None):
         self.em, self.vm, self.uses, self.passes = em, vm, uses, passes
+        self.side = side or {}    # issue index -> callables: other loads woven into the twiddle stream (row prefetches)
         self.free = list(range(nslots))
         self.slot_of, self.seq_of = {}, {}
         self.next = 0
@@ -839,6 +838,11 @@ class Ring:
         return ("v%d" % b, "v%d" % (b + 1), "v%d" % (b + 2), "v%d" % (b + 3))
 
     def _issue(self):
+        self._issue_record()
+        for f in self.side.get(self.next - 1, ()):
+            f()
+
+    def _issue_record(self):
         use = self.uses[self.next]
         self.next += 1
         slot = self.free.pop(0)
@@ -1238,6 +1242,191 @@ def build_row16k(kind="polymul", stop=None):
         if k < 15:
             R("s_add_u32 s86, s86, 0x%x" % (2048 * ROW_G,))
             R("s_addc_u32 s87, s87, 0")
+    R("s_endpgm")
+    return em
+
+
+# ------------------------------------------------------------------ n = 16384, persistent with row prefetch
+# One 1024-thread workgroup per CU means a row's loads, its arithmetic and its stores run one after the other (the
+# skeleton without butterflies needs 58 % of the kernel's time, profiles/r03_longrow_ablation.txt).  This variant keeps
+# the workgroup on the CU and moves the memory phases UNDER the arithmetic:
+#   workgroup (x, cm) of a (G, nm) grid walks polynomials x, x + G, ...
+#   b is transformed first and alone (file B) while a's row loads are in flight (file A);
+#   after the point-wise step file B is free: b of the NEXT polynomial is loaded during the inverse transform;
+#   the result is stored pair by pair out of the last stage, and drains under the next polynomial's first passes.
+# vmcnt retires in order, so a block of row loads in front of a twiddle wait would make that wait absorb the HBM
+# latency (what defeated round 2's persistent 4096-word kernel): the row loads are woven INTO the twiddle stream, one
+# per ring issue, so each is waited for nine ring uses after it was issued.  Cost: the forward twiddles are fetched
+# once per operand instead of once per pair (+48 records per wave and row).
+# MEASURED (profiles/r03_persistent_rows.txt): bit-exact, and SLOWER -- n = 16384 x 8 moduli 459 k against 491 k products/s,
+# n = 8192 x 2 moduli 4.06 M against 4.55 M.  The bound was there to read beforehand: with the rows served from the L2
+# (no HBM phase at all, and its power back) the shipped kernels gain 18 % / 15 %, most of it clock; what an overlap of the
+# memory phases alone can return is a few per cent, less than the second set of twiddle fetches costs.  Emitted only with
+# NFL_GEN_EXPERIMENTS=1; tests/asm_emu.py run_block_kernel(grid_x=...) executes it.
+# kernarg: c a b psi mc | nm logn | count G        grid (G, nm)
+def build_row16k_loop():   # (also the 8192-word rows: ROW_G = 2, 512 threads, two workgroups per CU)
+    assert ROW_G in (2, 4) and SINGLE_STREAM
+    em = Emitter()
+    vm = VmCounter(em)
+    R = em.raw
+    base = {"F0": (S_K0["F0"], None, False), "F1": (S_K["F1"], None, False), "F2": (S_K["F2"], V_BIDX, False),
+            "F3": (S_K["F3"], V_TID, False), "I1": (S_K["I1"], V_TID, True), "I2": (S_K["I2"], V_BIDX, True),
+            "I3": (S_K["I3"], None, True), "I0": (S_K0["I0"], None, True)}
+    order = {"F0": tuple(range(ROW_LG)), "F1": (0, 1, 2, 3), "F2": (0, 1, 2, 3), "F3": (0, 1, 2, 3), "I1": (3, 2, 1, 0),
+             "I2": (3, 2, 1, 0), "I3": (3, 2, 1, 0), "I0": tuple(range(ROW_LG - 1, 0, -1))}
+    per = 16 // ROW_G          # register slots per 4096-word block in the row layout x[tid + 256 G k]
+    passes, uses = {}, []
+    for tag in "ba":
+        for name in ("F0", "F1", "F2", "F3"):
+            passes[name + tag] = base[name]
+            uses += [(name + tag, s_, g) for s_ in order[name] for g in range(1 << s_)]
+    n_fwd = len(uses)
+    for name in ("I1", "I2", "I3", "I0"):
+        passes[name] = base[name]
+        uses += [(name, s_, g) for s_ in order[name] for g in range(1 << s_)]
+    S_I, S_G, S_COUNT, S_STRIDE, S_RUN = "s2", "s3", "s96", ("s98", "s99"), ("s100", "s101")
+
+    def side_load(dst_pair):
+        def f():
+            vm.load("global_load_dwordx2 %s, v%d, s[100:101]" % (vp(dst_pair), V_OFF8))
+            R("s_add_u32 s100, s100, 0x%x" % (2048 * ROW_G,))
+            R("s_addc_u32 s101, s101, 0")
+        return f
+    side = {}
+    for k in range(16):
+        side[RING_SLOTS + k] = [side_load(V_A + 2 * k)]                    # a: under b's forward transform
+        side[n_fwd + RING_SLOTS + k] = [side_load(V_B + 2 * k)]            # next b: under the inverse transform
+    ring = Ring(em, vm, RING_SLOTS, uses, passes, side)
+    R("s_load_dwordx2 s[96:97], s[0:1], 0x30")                             # count, G
+    prologue16k(em, vm, None, "none")
+    AX = T(0, 0)
+    R("s_cmp_ge_u32 %s, %s" % (S_I, S_COUNT))
+    R("s_cbranch_scc0 .Lhas_work")
+    R("s_endpgm")
+    em.lines.append(".Lhas_work:")
+    R("s_mov_b32 %s, s97" % S_G)                                            # (cm is not needed any more)
+    R("s_mul_i32 s42, %s, s14" % S_G)                                       # G * nm rows of 2^17 bytes between polynomials
+    R("s_lshr_b32 %s, s42, %d" % (S_STRIDE[1], 32 - 15 - ROW_LG))
+    R("s_lshl_b32 %s, s42, %d" % (S_STRIDE[0], 15 + ROW_LG))
+    em.comment("b of the first polynomial (x[tid + 1024 k] -> slot k)")
+    R("s_mov_b64 s[86:87], %s" % (S_BROW,))
+    for k in range(16):
+        vm.load("global_load_dwordx2 %s, v%d, s[86:87]" % (vp(V_B + 2 * k), V_OFF8))
+        if k < 15:
+            R("s_add_u32 s86, s86, 0x%x" % (2048 * ROW_G,))
+            R("s_addc_u32 s87, s87, 0")
+    em.lines.append(".Lnext_polynomial:")
+    em.comment("b row of the polynomial after this one (this one again if it is the last: a harmless reload)")
+    R("s_add_u32 s52, %s, %s" % (S_I, S_G))
+    R("s_cmp_lt_u32 s52, %s" % S_COUNT)
+    R("s_cselect_b32 s52, %s, 0" % S_STRIDE[0])
+    R("s_cselect_b32 s53, %s, 0" % S_STRIDE[1])
+    R("s_add_u32 s18, s18, s52")
+    R("s_addc_u32 s19, s19, s53")
+    R("s_mov_b64 s[100:101], %s" % (S_AROW,))
+    ring.prime()
+
+    def X0(b_):
+        em.comment("X0: thread (q, t) slot 4*qq + j  ->  sub-group qq, thread t, slot q + 4*j")
+        R("s_barrier")               # WAR: every wave is done reading the previous exchange
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+        for k in range(16):
+            qq, j = k // per, k % per
+            R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(b_ + 2 * k), (qq & 1) * SLAB_BYTES + j * 2048 * ROW_G))
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+        for k in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(b_ + 2 * k), AX, 2048 * k))
+        R("s_waitcnt lgkmcnt(0)")
+
+    def E1(b_):
+        em.comment("E1")
+        R("s_barrier")               # WAR against the previous exchange through this slab
+        lds_write(em, V_L1W, b_, 2176)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        lds_read(em, V_L1R, b_, 136)
+        R("s_waitcnt lgkmcnt(0)")
+
+    def E2(b_):
+        em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+        lds_write(em, V_L1R, b_, 136)
+        lds_read(em, V_L2R, b_, 8)
+        R("s_waitcnt lgkmcnt(0)")
+
+    def fwd_one(b_, tag):
+        for name, after in (("F0", X0), ("F1", E1), ("F2", E2), ("F3", None)):
+            em.comment("%s, operand %s" % (name, tag))
+            for s_ in order[name]:
+                half = 8 >> s_
+                for g in range(1 << s_):
+                    use = (name + tag, s_, g)
+                    tw = ring.get(use)
+                    run_pairs(em, [ct_bfly(b_ + 2 * (g * 2 * half + h), b_ + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                    ring.done(use)
+            if after:
+                after(b_)
+
+    def inv_pass(name):
+        em.comment(name)
+        for s_ in order[name]:
+            half = 8 >> s_
+            for g in range(1 << s_):
+                tw = ring.get((name, s_, g))
+                run_pairs(em, [gs_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                ring.done((name, s_, g))
+
+    fwd_one(V_B, "b")
+    fwd_one(V_A, "a")
+    em.comment("point-wise product (thread t of sub-group q holds words 16t..16t+15 of block q of both operands)")
+    run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i, True, True) for i in range(16)])
+    R("s_mov_b64 s[100:101], %s" % (S_BROW,))          # file B is free: the ring's side loads now fetch the next b
+    inv_pass("I1")
+    em.comment("E2'")
+    lds_write(em, V_L2R, V_A, 8)
+    lds_read(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I2")
+    em.comment("E1'")
+    lds_write(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    lds_read(em, V_L1W, V_A, 2176)
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I3")
+    em.comment("X0': thread (q, t) slot g + 4*j  ->  thread (g, t) slot 4*q + j, reader-major layout [slot][tid]")
+    R("s_barrier")               # every wave is done reading E1'
+    R("s_lshl_b32 s86, %s, 15" % (S_Q,))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+    em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                              # q*32768 + t*8
+    for k in range(16):
+        g_, j = k % ROW_G, k // ROW_G
+        R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(V_A + 2 * k), j * 2048 * ROW_G + g_ * 2048))
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    rstep = 2048 * ROW_G
+    em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * rstep, V_OFF8))
+    for k in range(16):
+        R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * rstep))
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I0")
+    assert ring.next == len(uses) and len(ring.free) == RING_SLOTS
+    em.comment("stage 0 with n^-1 folded in; every finished pair is stored at once (the next b has landed long ago)")
+    R("s_waitcnt vmcnt(0)")
+    for h in range(8):
+        run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8))])
+        for k in (h, h + 8):
+            R("s_add_u32 s86, s20, 0x%x" % (k * 2048 * ROW_G,))
+            R("s_addc_u32 s87, s21, 0")
+            R("global_store_dwordx2 v%d, %s, s[86:87]" % (V_OFF8, vp(V_A + 2 * k)))
+    for lo in (16, 20):
+        R("s_add_u32 s%d, s%d, %s" % (lo, lo, S_STRIDE[0]))
+        R("s_addc_u32 s%d, s%d, %s" % (lo + 1, lo + 1, S_STRIDE[1]))
+    R("s_add_u32 %s, %s, %s" % (S_I, S_I, S_G))
+    R("s_cmp_lt_u32 %s, %s" % (S_I, S_COUNT))
+    R("s_cbranch_scc1 .Lnext_polynomial")
     R("s_endpgm")
     return em
 
@@ -2583,10 +2772,19 @@ def main():
     configure(ring, 4)
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
+    g = globals()
+    if experiments:            # persistent workgroups with row prefetch: measured -6.5 % (n = 16384) / -11 % (n = 8192), not kept
+        g.update(NEXT_SGPR=102)
+        emit_file(os.path.join(outdir, "polymul16384p_gfx950.s"), "nflhip_polymul16384p_asm", build_row16k_loop(),
+                  args=ARGS_STD + [("i32", 48), ("i32", 52)])
     configure(ring, 2)         # 8192-word rows: two sub-groups, 512 threads, one radix-2 stage around the blocks
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem.replace("16384", "8192") + "_gfx950.s"), kname.replace("16384", "8192"),
                   build_row16k(kind))
+    if experiments:
+        g.update(NEXT_SGPR=102)
+        emit_file(os.path.join(outdir, "polymul8192p_gfx950.s"), "nflhip_polymul8192p_asm", build_row16k_loop(),
+                  args=ARGS_STD + [("i32", 48), ("i32", 52)])
     configure(ring, 4)
     # 32768-word rows: one operand register-resident in a 1024-thread workgroup (4 sub-groups x 2 blocks)
     g = globals()
