@@ -315,6 +315,23 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
 
   HIPCHK(nullptr, hipMalloc(&c->tabs.psi, psi.size() * sizeof(Tw<T>)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.psi, psi.data(), psi.size() * sizeof(Tw<T>), hipMemcpyHostToDevice));
+  c->tabs.psi_lm = nullptr;
+  if (sizeof(T) == 8 && n >= 4096) {
+    // the generated 64-bit kernels read the last four stages (indices n/16 .. n-1) LANE-MAJOR: stage logn-4+s transposed
+    // from [(u << s) + g] to [g (n/16) + u], so that the 64 lanes of a wave fetch consecutive records
+    // (tools/gen_polymul_asm.py tw_base_lm); indices below n/16 are shared with the natural table
+    std::vector<Tw<T>> lm(psi);
+    const size_t m = n >> 4;
+    for (size_t cm = 0; cm < nm; ++cm)
+      for (int s = 0; s < 4; ++s) {
+        const Tw<T> *src = psi.data() + cm * n + (m << s);
+        Tw<T> *dst = lm.data() + cm * n + (m << s);
+        for (size_t u = 0; u < m; ++u)
+          for (size_t g = 0; g < ((size_t)1 << s); ++g) dst[g * m + u] = src[(u << s) + g];
+      }
+    HIPCHK(nullptr, hipMalloc(&c->tabs.psi_lm, lm.size() * sizeof(Tw<T>)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.psi_lm, lm.data(), lm.size() * sizeof(Tw<T>), hipMemcpyHostToDevice));
+  }
   HIPCHK(nullptr, hipMalloc(&c->tabs.mc, mc.size() * sizeof(ModConst<T>)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.mc, mc.data(), mc.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
   HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qhat, qhat.size() * sizeof(uint64_t)));
@@ -673,6 +690,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
     if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->tabs.psi) (void)hipFree(ctx->tabs.psi);
+  if (ctx->tabs.psi_lm) (void)hipFree(ctx->tabs.psi_lm);
   if (ctx->tabs.mc) (void)hipFree(ctx->tabs.mc);
   if (ctx->tabs.qhat) (void)hipFree(ctx->tabs.qhat);
   if (ctx->tabs.qsh) (void)hipFree(ctx->tabs.qsh);

@@ -49,6 +49,7 @@ struct Shape {
 // Device-resident tables of one context.
 struct DevTables {
   void *psi;        // [nm][n] Tw<T>
+  void *psi_lm;     // 64-bit limbs, n >= 4096: the same with the last four stages lane-major (what the generated kernels read)
   void *mc;         // [nm] ModConst<T>
   uint64_t *qhat;   // [nm][crt_Lacc]  Q/p_cm, little-endian limbs
   uint64_t *qsh;    // [6][crt_Lacc]   Q << k, k = 0..5

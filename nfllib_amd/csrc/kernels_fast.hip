@@ -390,6 +390,16 @@ static hipFunction_t asm_fn(AsmKind kind) {
   return k.fn[kind];
 }
 
+// The ring-mode kernels (rows of 8192 / 16384 / 32768 words) read the twiddle table with its last four stages lane-major
+// (DevTables::psi_lm, tools/gen_polymul_asm.py tw_base_lm); the 4096-word kernels read the natural table.
+// -DNFLHIP_NATURAL_TWIDDLES + NFL_GEN_NATURAL_TWIDDLES=1 rebuild the natural-order variant of the former for same-box
+// comparisons (tools/sessions/gpu_round3_l.sh).
+#ifdef NFLHIP_NATURAL_TWIDDLES
+#define PSI_LM(t) ((t).psi)
+#else
+#define PSI_LM(t) ((t).psi_lm)
+#endif
+
 // every generated kernel takes (dst, src_a, src_b, psi, mc, nm, logn) and one workgroup per block of its size
 static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a,
                              const uint64_t *b, size_t batch, hipStream_t st) {
@@ -400,7 +410,7 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
     void *c;
     const void *a, *b, *psi, *mc;
     int nm, logn;
-  } args = {c, a, b, t.psi, t.mc, (int)s.nm, s.logn};
+  } args = {c, a, b, is8k(kind) || is16k(kind) || is32k(kind) ? PSI_LM(t) : t.psi, t.mc, (int)s.nm, s.logn};
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   // one 256-thread workgroup per 4096-word block, or one 1024-thread workgroup per 16384-word block

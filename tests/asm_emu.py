@@ -1001,9 +1001,11 @@ def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4, concurre
                 raise RuntimeError("emulated launch is stuck: %d workgroups poll and nothing changes" % len(gens))
 
 
-def device_tables(limb_bits, n, nm, prm):
+def device_tables(limb_bits, n, nm, prm, lane_major=False):
     """the twiddle table (Tw<T>: {psi^bitrev(k), Shoup companion}) and the ModConst<T> records exactly as
-    nfllib_amd/csrc/api.hip build_tables lays them out on the device (negacyclic case), from params<T>"""
+    nfllib_amd/csrc/api.hip build_tables lays them out on the device (negacyclic case), from params<T>.
+    lane_major: DevTables::psi_lm, what the ring-mode 64-bit kernels (rows of 8192 words and up) are handed -- the last four stages (indices n/16 .. n-1)
+    with stage logn-4+s transposed from [(u << s) + g] to [g * (n/16) + u]"""
     wb, logn = limb_bits, n.bit_length() - 1
     dt = prm.dtype
     psi = np.zeros((nm, n, 2), dtype=dt)
@@ -1026,6 +1028,13 @@ def device_tables(limb_bits, n, nm, prm):
         rec = [p, 2 * p, (1 << (2 * wb - 4)) // p, ninv, (ninv << wb) // p, w1n, (w1n << wb) // p, beta, (beta << wb) // p,
                0, 0, (1 << bits) - 1, (1 << (wb - 2)) - p, (1 << (2 * wb - 3)) // p]   # (yinv: CRT only, unused by the row kernels)
         mc[cm] = [r & ((1 << wb) - 1) for r in rec]
+    if lane_major:
+        assert logn >= 12
+        m = n >> 4
+        for s_ in range(4):
+            lo, cnt = m << s_, m << s_
+            blk = psi[:, lo:lo + cnt].reshape(nm, m, 1 << s_, 2)          # [u][g]
+            psi[:, lo:lo + cnt] = blk.transpose(0, 2, 1, 3).reshape(nm, cnt, 2)   # [g][u]
     return psi, mc
 
 
@@ -1053,7 +1062,7 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     transforms) = number of polynomials"""
     import struct
     mem = Memory()
-    psi, mc = device_tables(64, n, nm, prm)
+    psi, mc = device_tables(64, n, nm, prm, lane_major=block_log >= 13)   # (the ring-mode kernels: tw_base_lm)
     c = np.zeros_like(a)
     pa, pb, pc, ppsi, pmc = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(psi), mem.add(mc)
     logn = n.bit_length() - 1

@@ -401,6 +401,45 @@ def tw_base(em, kreg, s, descending, koff=0):
     em.raw("s_addc_u32 s85, s23, 0")
 
 
+# In the ring-mode kernels (rows of 8192 / 16384 / 32768 words: one butterfly at a time, twiddle records streamed through
+# the ring) the passes whose twiddle index depends on the THREAD (F3 / I1: global stages logn-4 .. logn-1, 15/16 of the
+# table) read a lane-major copy of those stages: stage S = logn-4+s holds M 2^s records (M = n/16 = 256 << r), natural position
+# (u << s) + g for thread-index u = 256 blk + t and group g, lane-major position g M + u.  A wave's 64 lanes then fetch 64
+# CONSECUTIVE records per load (8 cache lines, all bytes used) instead of 64 records 16 << s bytes apart (up to 64 lines,
+# 16 bytes used of each: 5.7 x the L2 -> L1 traffic over a pass).  The host lays the copy out (api.hip build_tables,
+# DevTables::psi_lm); every other pass reads indices below n/16, which both layouts share.
+#   ascending  (F3): index = K + ((256 c) << r) + t,          c  = 2^s - 1 + g            (K = 256 (2^r + blk))
+#   descending (I1): index = K + ((256 c') << r) - 1 - t,     c' = 2^(s+1) - 2 - g        (K = (512 << r) - 256 blk)
+# The lane part is the same for every stage: V_TWO = 16 t (ascending) or 16 (255 - t) (descending, base lowered by 256).
+# Same-box A/B against the natural order (profiles/r03_lane_major_twiddles.txt): products +1 % (16384) / +3 % (8192) / +5 %
+# (32768), inverse transforms +6 ... +16 %, forward +2 ... +8 %.  The 4096-word kernels (three workgroups per CU, all 15
+# records of a pass resident) gain nothing from it (product +-0, pre-transformed product -2 %) and keep the natural table.
+LANE_MAJOR = not os.environ.get("NFL_GEN_NATURAL_TWIDDLES")
+
+
+def tw_base_lm(em, kreg, s, g, descending, koff=0):
+    c = (2 << s) - 2 - g if descending else (1 << s) - 1 + g
+    if c:
+        em.raw("s_lshl_b32 s86, 0x%x, %s" % (256 * c, S_R))
+        em.raw("s_add_u32 s86, s86, %s" % kreg)
+    else:
+        em.raw("s_mov_b32 s86, %s" % kreg)
+    k = koff - (256 if descending else 0)
+    if k:
+        em.raw("s_%s_u32 s86, s86, 0x%x" % ("add" if k > 0 else "sub", abs(k)))
+    em.raw("s_lshl_b32 s86, s86, 4")
+    em.raw("s_add_u32 s84, s22, s86")
+    em.raw("s_addc_u32 s85, s23, 0")
+
+
+def tw_lane_offset_lm(em, descending):
+    em.valu("v_lshlrev_b32_e32 v%d, 4, v%d" % (V_TWO, V_TID))
+    if descending:
+        em.valu("v_sub_u32_e32 v%d, 0xff0, v%d" % (V_TWO, V_TWO))
+    if "tw0" in ABLATE:
+        em.valu("v_mov_b32_e32 v%d, 0" % (V_TWO,))
+
+
 def tw_uniform_stage(em, vm, s, kreg, descending):
     """Twiddle records of sub-stage s at wave-uniform indices (K << s) + g  /  (K << s) - 1 - g."""
     tw_base(em, kreg, s, descending)
@@ -415,11 +454,11 @@ def tw_uniform_stage(em, vm, s, kreg, descending):
 def tw_lane_stage(em, vm, s, vidx, kreg, descending):
     """Per-lane twiddle records of sub-stage s.  Ascending (forward): index = (K << s) + (vidx << s) + g.
     Descending (inverse, mirrored): index = (K << s) - 1 - (vidx << s) - g.  vidx: VGPR with B or t."""
+    seq = 0
     tw_base(em, kreg, s, descending)
     em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
     if "tw0" in ABLATE:
         em.valu("v_mov_b32_e32 v%d, 0" % (V_TWO,))
-    seq = 0
     if not descending:
         for g in range(1 << s):
             r = V_TW + 4 * tw_slot(s, g)
@@ -857,6 +896,13 @@ class Ring:
         kreg, vidx, desc = self.passes[name][:3]
         koff = self.passes[name][3] if len(self.passes[name]) > 3 else 0
         fresh = self.cur != (name, s)
+        if LANE_MAJOR and vidx is not None and vidx == V_TID:
+            if self.cur is None or self.cur[0] != name:
+                tw_lane_offset_lm(em, desc)
+            self.cur = (name, s)
+            tw_base_lm(em, kreg, s, g, desc, koff)
+            self.seq_of[use] = self.vm.load("global_load_dwordx4 v[%d:%d], v%d, %s" % (r, r + 3, V_TWO, S_BASE2))
+            return
         if fresh:
             tw_base(em, kreg, s, desc, koff)
             if vidx is not None:
