@@ -415,6 +415,7 @@ def tw_base(em, kreg, s, descending, koff=0):
 # (32768), inverse transforms +6 ... +16 %, forward +2 ... +8 %.  The 4096-word kernels (three workgroups per CU, all 15
 # records of a pass resident) gain nothing from it (product +-0, pre-transformed product -2 %) and keep the natural table.
 LANE_MAJOR = not os.environ.get("NFL_GEN_NATURAL_TWIDDLES")
+SPLIT32K = not os.environ.get("NFL_GEN_SERIAL_EXCHANGE")   # build_row32k: exchanges of one file under the arithmetic of the other
 
 
 def tw_base_lm(em, kreg, s, g, descending, koff=0):
@@ -1590,115 +1591,262 @@ def build_row32k(kind="fwd"):
                     run_pairs(em, [gs_bfly(base + 2 * (g * 2 * half + h), base + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
                     ring.done((nm_, s_, g))
 
-    if has_fwd:
-        em.comment("F0: radix-8 over the 32 slots (stage 0 couples the files)")
-        for s_ in range(3):
-            half = 16 >> s_
-            for g in range(1 << s_):
-                tw = ring.get(("F0", s_, g))
-                run_pairs(em, [ct_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
-                ring.done(("F0", s_, g))
-        for i, (base, _) in enumerate(FILES):
-            em.comment("X0 round %d: thread (q, t) slot 4*m + c of this file -> sub-group m, thread t, slot q + 4*c" % i)
-            if i:
-                R("s_barrier")       # WAR: the slabs are still being read for the previous file
-            em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
-            for k in range(16):
-                qq, j = k // 4, k % 4
-                R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
-            R("s_waitcnt lgkmcnt(0)")
-            R("s_barrier")
-            em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
-            em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
-            for k in range(16):
-                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
-            R("s_waitcnt lgkmcnt(0)")
-        fwd_pass("F1")
-        for base, _ in FILES:
-            em.comment("E1")
-            R("s_barrier")           # WAR against the previous exchange through this slab
-            lds_write(em, V_L1W, base, 2176)
-            R("s_waitcnt lgkmcnt(0)")
-            R("s_barrier")
-            lds_read(em, V_L1R, base, 136)
-            R("s_waitcnt lgkmcnt(0)")
-        fwd_pass("F2")
-        em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
-        for base, _ in FILES:
-            lds_write(em, V_L1R, base, 136)
-            lds_read(em, V_L2R, base, 8)
-            R("s_waitcnt lgkmcnt(0)")
-        fwd_pass("F3")
-    if kind == "fwd":
-        em.comment("canonical words, then a wave-local LDS transpose per file so the stores are fully coalesced")
-        run_pairs(em, [canon(V_A + 2 * i) for i in range(32)])
-        for base, boff in FILES:
-            lds_write(em, V_L2R, base, 8)
-            g_, l_ = lane_contig_setup(em)
-            em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
-            for j in range(16):
-                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * j), l_, 544 * j))
-            R("s_waitcnt lgkmcnt(0)")
-            block_base(S_CROW, boff)
-            for j in range(16):
-                R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d nt" % (g_, vp(base + 2 * j), (j & 7) * 512))
-                if j == 7:
-                    R("s_add_u32 s86, s86, 0x1000")
-                    R("s_addc_u32 s87, s87, 0")
-        R("s_endpgm")
-        return em
+    # ---- split-phase exchanges: the two files are independent between F0 and I0, so every LDS batch of one file (the
+    # writes of an exchange, or its reads) is issued in FRONT of a half pass of arithmetic on the OTHER file and waited for
+    # behind it; the arithmetic order -- and with it the order in which the ring consumes its records -- is unchanged.
+    # Only the first forward round (file A after F0) and the last inverse round (file B before I0) stay exposed.
+    W0 = "s_waitcnt lgkmcnt(0)"
 
-    if kind == "polymul_ntt":
-        em.comment("point-wise product with b' streamed through the ring: slot i of a file = words 16t + 2i, 16t + 2i + 1 of its block")
-        for f, (base, _) in enumerate(FILES):
-            for i in range(8):
-                use = ("B" + "ab"[f], 0, i)
-                ring.get(use)
-                r = V_TW + 4 * ring.slot_of[use]
-                run_pairs(em, [pointwise(base + 4 * i, r, True, False), pointwise(base + 4 * i + 2, r + 2, True, False)])
-                ring.done(use)
-    else:
-        R("s_waitcnt vmcnt(%d)" % (vm.issued - n_row_loads))          # the block loads have landed
-        em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region, file by file")
-        _, l_ = lane_contig_setup(em)
-        em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
-        for base, _ in FILES:
-            for j in range(16):
-                R("ds_write_b64 v%d, %s offset:%d" % (l_, vp(base + 2 * j), 544 * j))
-            lds_read(em, V_L2R, base, 8)
-            R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I1")
-    em.comment("E2'")
-    for base, _ in FILES:
-        lds_write(em, V_L2R, base, 8)
-        lds_read(em, V_L1R, base, 136)
-        R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I2")
-    for i, (base, _) in enumerate(FILES):
-        em.comment("E1'")
-        if i:
-            R("s_barrier")           # WAR: the slab is still being read for the previous file
-        lds_write(em, V_L1R, base, 136)
-        R("s_waitcnt lgkmcnt(0)")
-        R("s_barrier")
-        lds_read(em, V_L1W, base, 2176)
-        R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I3")
-    for i, (base, _) in enumerate(FILES):
-        em.comment("X0' round %d: thread (q, t) slot g + 4*j of this file -> thread (g, t) slot 4*q + j, layout [slot][tid]" % i)
-        R("s_barrier")               # every wave is done reading the previous exchange
+    def fwd_stages(f, name, stages):
+        base, nm_ = FILES[f][0], name + "ab"[f]
+        em.comment("%s, file %s, stages %s" % (name, "AB"[f], stages))
+        for s_ in stages:
+            half = 8 >> s_
+            for g in range(1 << s_):
+                tw = ring.get((nm_, s_, g))
+                run_pairs(em, [ct_bfly(base + 2 * (g * 2 * half + h), base + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                ring.done((nm_, s_, g))
+
+    def inv_stages(f, name, stages):
+        base, nm_ = FILES[f][0], name + "ab"[f]
+        em.comment("%s, file %s, stages %s" % (name, "AB"[f], stages))
+        for s_ in stages:
+            half = 8 >> s_
+            for g in range(1 << s_):
+                tw = ring.get((nm_, s_, g))
+                run_pairs(em, [gs_bfly(base + 2 * (g * 2 * half + h), base + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                ring.done((nm_, s_, g))
+
+    def X0w(f):
+        base = FILES[f][0]
+        em.comment("X0 writes, file %s: thread (q, t) slot 4*m + c -> sub-group m, thread t, slot q + 4*c" % "AB"[f])
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+        for k in range(16):
+            qq, j = k // 4, k % 4
+            R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
+
+    def X0r(f):
+        base = FILES[f][0]
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+        for k in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+
+    def X0iw(f):
+        base = FILES[f][0]
+        em.comment("X0' writes, file %s: thread (q, t) slot g + 4*j -> thread (g, t) slot 4*q + j, layout [slot][tid]" % "AB"[f])
         R("s_lshl_b32 s86, %s, 15" % (S_Q,))
         em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
         em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                          # q*32768 + t*8
         for k in range(16):
             g_, j = k % 4, k // 4
             R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(base + 2 * k), j * 8192 + g_ * 2048))
-        R("s_waitcnt lgkmcnt(0)")
-        R("s_barrier")
+
+    def X0ir(f):
+        base = FILES[f][0]
         em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * 8192, V_OFF8))
         for k in range(16):
             R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * 8192))
-        R("s_waitcnt lgkmcnt(0)")
+
+    def seq(*items):          # strings are emitted as they are, callables are called
+        for it in items:
+            if isinstance(it, str):
+                R(it)
+            else:
+                it()
+
+    def split_phase_schedule():
+        A_, B_ = FILES[0][0], FILES[1][0]
+        BAR = "s_barrier"
+        if has_fwd:
+            em.comment("F0: radix-8 over the 32 slots (stage 0 couples the files)")
+            for s_ in range(3):
+                half = 16 >> s_
+                for g in range(1 << s_):
+                    tw = ring.get(("F0", s_, g))
+                    run_pairs(em, [ct_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                    ring.done(("F0", s_, g))
+            seq(lambda: X0w(0), W0, BAR, lambda: X0r(0), W0, BAR,
+                lambda: X0w(1), lambda: fwd_stages(0, "F1", (0, 1)), W0, BAR, lambda: X0r(1), lambda: fwd_stages(0, "F1", (2, 3)), W0, BAR,
+                lambda: lds_write(em, V_L1W, A_, 2176), lambda: fwd_stages(1, "F1", (0, 1)), W0, BAR,
+                lambda: lds_read(em, V_L1R, A_, 136), lambda: fwd_stages(1, "F1", (2, 3)), W0, BAR,
+                lambda: lds_write(em, V_L1W, B_, 2176), lambda: fwd_stages(0, "F2", (0, 1)), W0, BAR,
+                lambda: lds_read(em, V_L1R, B_, 136), lambda: fwd_stages(0, "F2", (2, 3)), W0,
+                # E2 is wave-local (LDS is in order per wave): file A's transposes run under F2 of file B, B's under F3 of A
+                lambda: lds_write(em, V_L1R, A_, 136), lambda: lds_read(em, V_L2R, A_, 8), lambda: fwd_stages(1, "F2", (0, 1, 2, 3)), W0,
+                lambda: lds_write(em, V_L1R, B_, 136), lambda: lds_read(em, V_L2R, B_, 8), lambda: fwd_stages(0, "F3", (0, 1, 2, 3)), W0,
+                lambda: fwd_stages(1, "F3", (0, 1, 2, 3)))
+        if kind == "fwd":
+            em.comment("canonical words, then a wave-local LDS transpose per file so the stores are fully coalesced; file B's"
+                       " reduction runs under file A's transposes")
+            def stores(base, boff):
+                g_, _ = lane_contig_setup(em)
+                block_base(S_CROW, boff)
+                for j in range(16):
+                    R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d nt" % (g_, vp(base + 2 * j), (j & 7) * 512))
+                    if j == 7:
+                        R("s_add_u32 s86, s86, 0x1000")
+                        R("s_addc_u32 s87, s87, 0")
+            def transposes(base):
+                lds_write(em, V_L2R, base, 8)
+                _, l_ = lane_contig_setup(em)
+                em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
+                for j in range(16):
+                    R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * j), l_, 544 * j))
+            run_pairs(em, [canon(A_ + 2 * i) for i in range(16)])
+            transposes(A_)
+            run_pairs(em, [canon(B_ + 2 * i) for i in range(16)])
+            R(W0)
+            stores(A_, FILES[0][1])
+            transposes(B_)
+            R(W0)
+            stores(B_, FILES[1][1])
+            R("s_endpgm")
+            return True
+        if kind == "polymul_ntt":
+            em.comment("point-wise product with b' streamed through the ring: slot i of a file = words 16t + 2i, 16t + 2i + 1 of its block")
+            for f, (base, _) in enumerate(FILES):
+                for i in range(8):
+                    use = ("B" + "ab"[f], 0, i)
+                    ring.get(use)
+                    r = V_TW + 4 * ring.slot_of[use]
+                    run_pairs(em, [pointwise(base + 4 * i, r, True, False), pointwise(base + 4 * i + 2, r + 2, True, False)])
+                    ring.done(use)
+            seq(lambda: inv_stages(0, "I1", (3, 2, 1, 0)))
+        else:
+            R("s_waitcnt vmcnt(%d)" % (vm.issued - n_row_loads))          # the block loads have landed
+            em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region; file B's under I1 of file A")
+            def to_threads(base):
+                _, l_ = lane_contig_setup(em)
+                em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
+                for j in range(16):
+                    R("ds_write_b64 v%d, %s offset:%d" % (l_, vp(base + 2 * j), 544 * j))
+                lds_read(em, V_L2R, base, 8)
+            seq(lambda: to_threads(A_), W0, lambda: to_threads(B_), lambda: inv_stages(0, "I1", (3, 2, 1, 0)), W0)
+        seq(# E2' is wave-local: file A's under I1 of file B, file B's under I2 of file A
+            lambda: lds_write(em, V_L2R, A_, 8), lambda: lds_read(em, V_L1R, A_, 136), lambda: inv_stages(1, "I1", (3, 2, 1, 0)), W0,
+            lambda: lds_write(em, V_L2R, B_, 8), lambda: lds_read(em, V_L1R, B_, 136), lambda: inv_stages(0, "I2", (3, 2, 1, 0)), W0,
+            lambda: lds_write(em, V_L1R, A_, 136), lambda: inv_stages(1, "I2", (3, 2)), W0, BAR,
+            lambda: lds_read(em, V_L1W, A_, 2176), lambda: inv_stages(1, "I2", (1, 0)), W0, BAR,
+            lambda: lds_write(em, V_L1R, B_, 136), lambda: inv_stages(0, "I3", (3, 2)), W0, BAR,
+            lambda: lds_read(em, V_L1W, B_, 2176), lambda: inv_stages(0, "I3", (1, 0)), W0, BAR,
+            lambda: X0iw(0), lambda: inv_stages(1, "I3", (3, 2)), W0, BAR, lambda: X0ir(0), lambda: inv_stages(1, "I3", (1, 0)), W0, BAR,
+            lambda: X0iw(1), W0, BAR, lambda: X0ir(1), W0)
+        return False
+
+    if SPLIT32K:
+        if split_phase_schedule():
+            return em
+    else:
+        if has_fwd:
+            em.comment("F0: radix-8 over the 32 slots (stage 0 couples the files)")
+            for s_ in range(3):
+                half = 16 >> s_
+                for g in range(1 << s_):
+                    tw = ring.get(("F0", s_, g))
+                    run_pairs(em, [ct_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                    ring.done(("F0", s_, g))
+            for i, (base, _) in enumerate(FILES):
+                em.comment("X0 round %d: thread (q, t) slot 4*m + c of this file -> sub-group m, thread t, slot q + 4*c" % i)
+                if i:
+                    R("s_barrier")       # WAR: the slabs are still being read for the previous file
+                em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+                for k in range(16):
+                    qq, j = k // 4, k % 4
+                    R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 8192))
+                R("s_waitcnt lgkmcnt(0)")
+                R("s_barrier")
+                em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+                em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+                for k in range(16):
+                    R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+                R("s_waitcnt lgkmcnt(0)")
+            fwd_pass("F1")
+            for base, _ in FILES:
+                em.comment("E1")
+                R("s_barrier")           # WAR against the previous exchange through this slab
+                lds_write(em, V_L1W, base, 2176)
+                R("s_waitcnt lgkmcnt(0)")
+                R("s_barrier")
+                lds_read(em, V_L1R, base, 136)
+                R("s_waitcnt lgkmcnt(0)")
+            fwd_pass("F2")
+            em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+            for base, _ in FILES:
+                lds_write(em, V_L1R, base, 136)
+                lds_read(em, V_L2R, base, 8)
+                R("s_waitcnt lgkmcnt(0)")
+            fwd_pass("F3")
+        if kind == "fwd":
+            em.comment("canonical words, then a wave-local LDS transpose per file so the stores are fully coalesced")
+            run_pairs(em, [canon(V_A + 2 * i) for i in range(32)])
+            for base, boff in FILES:
+                lds_write(em, V_L2R, base, 8)
+                g_, l_ = lane_contig_setup(em)
+                em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
+                for j in range(16):
+                    R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * j), l_, 544 * j))
+                R("s_waitcnt lgkmcnt(0)")
+                block_base(S_CROW, boff)
+                for j in range(16):
+                    R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d nt" % (g_, vp(base + 2 * j), (j & 7) * 512))
+                    if j == 7:
+                        R("s_add_u32 s86, s86, 0x1000")
+                        R("s_addc_u32 s87, s87, 0")
+            R("s_endpgm")
+            return em
+
+        if kind == "polymul_ntt":
+            em.comment("point-wise product with b' streamed through the ring: slot i of a file = words 16t + 2i, 16t + 2i + 1 of its block")
+            for f, (base, _) in enumerate(FILES):
+                for i in range(8):
+                    use = ("B" + "ab"[f], 0, i)
+                    ring.get(use)
+                    r = V_TW + 4 * ring.slot_of[use]
+                    run_pairs(em, [pointwise(base + 4 * i, r, True, False), pointwise(base + 4 * i + 2, r + 2, True, False)])
+                    ring.done(use)
+        else:
+            R("s_waitcnt vmcnt(%d)" % (vm.issued - n_row_loads))          # the block loads have landed
+            em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region, file by file")
+            _, l_ = lane_contig_setup(em)
+            em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
+            for base, _ in FILES:
+                for j in range(16):
+                    R("ds_write_b64 v%d, %s offset:%d" % (l_, vp(base + 2 * j), 544 * j))
+                lds_read(em, V_L2R, base, 8)
+                R("s_waitcnt lgkmcnt(0)")
+        inv_pass("I1")
+        em.comment("E2'")
+        for base, _ in FILES:
+            lds_write(em, V_L2R, base, 8)
+            lds_read(em, V_L1R, base, 136)
+            R("s_waitcnt lgkmcnt(0)")
+        inv_pass("I2")
+        for i, (base, _) in enumerate(FILES):
+            em.comment("E1'")
+            if i:
+                R("s_barrier")           # WAR: the slab is still being read for the previous file
+            lds_write(em, V_L1R, base, 136)
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            lds_read(em, V_L1W, base, 2176)
+            R("s_waitcnt lgkmcnt(0)")
+        inv_pass("I3")
+        for i, (base, _) in enumerate(FILES):
+            em.comment("X0' round %d: thread (q, t) slot g + 4*j of this file -> thread (g, t) slot 4*q + j, layout [slot][tid]" % i)
+            R("s_barrier")               # every wave is done reading the previous exchange
+            R("s_lshl_b32 s86, %s, 15" % (S_Q,))
+            em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+            em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                          # q*32768 + t*8
+            for k in range(16):
+                g_, j = k % 4, k // 4
+                R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(base + 2 * k), j * 8192 + g_ * 2048))
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * 8192, V_OFF8))
+            for k in range(16):
+                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * 8192))
+            R("s_waitcnt lgkmcnt(0)")
     em.comment("I0: radix-8 over the 32 slots, mirrored table")
     for s_ in (2, 1):
         half = 16 >> s_
