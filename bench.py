@@ -373,6 +373,37 @@ def main():
         del fa, fb, fc
 
     extras = None
+    power = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # package power and shader clock UNDER the product kernel (the product kernels run at the package
+        # power limit, so their clock -- not their schedule -- is what separates them from the issue bound): ~2.5 s of
+        # products queued on the stream, rocm-smi sampled beside them.  Outside the timed region.
+        try:
+            import subprocess
+            t_step = dt / args.steps
+            for _ in range(max(8, min(20000, int(2.5 / max(t_step, 1e-6))))):
+                eng.polymul(a, b, out=c)
+            samples = []
+            t_end = time.perf_counter() + 2.2
+            while time.perf_counter() < t_end and len(samples) < 8:
+                txt = subprocess.run(["rocm-smi", "-P", "-c", "-M", "--json"], capture_output=True, text=True, timeout=10).stdout
+                js = json.loads([ln for ln in txt.splitlines() if ln.startswith("{")][-1])
+                card = js.get("card%d" % dev) or next(iter(js.values()))
+                watts = next((float(v) for k, v in card.items() if "Power (W)" in k and "Max" not in k), None)
+                cap = next((float(v) for k, v in card.items() if "Max" in k and "Power" in k), None)
+                sclk = next((v for k, v in card.items() if k.startswith("sclk clock speed")), "")
+                mhz = int("".join(ch for ch in sclk if ch.isdigit()) or 0)
+                if watts is not None:
+                    samples.append((watts, mhz, cap))
+            torch.cuda.synchronize()
+            busy = [x for x in samples[1:] if x[0] > 0.5 * max(y[0] for y in samples)] or samples
+            if busy:
+                power = {"package_W": round(sum(x[0] for x in busy) / len(busy), 1), "sclk_MHz": round(sum(x[1] for x in busy) / len(busy)),
+                         "package_limit_W": busy[0][2], "samples": len(busy),
+                         "how": "rocm-smi -P -c -M sampled while ~2.5 s of products run, outside the timed region"}
+        except Exception as ex:  # reported, never fatal
+            torch.cuda.synchronize()
+            power = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_extras:
         # secondary rates of SURVEY.md 8(d): per-kernel transforms, point-wise ops, the
         # "one operand pre-transformed" product and CRT lift/project (same batch, same stream)
@@ -476,12 +507,14 @@ def main():
     if valu:
         inst_per_poly = valu[0] * valu[1]
         clock_ghz, cyc_per_inst = 2.0, 3.86
+        if power and power.get("sclk_MHz"):
+            clock_ghz = round(power["sclk_MHz"] / 1000.0, 3)    # the clock THIS run's kernel got (sampled above)
         peak_gi = 256 * 4 * clock_ghz / cyc_per_inst   # G wave-instructions/s
         ach_gi = inst_per_poly * batch / (kernel_ms * 1e-3) / 1e9
         result["roofline"]["secondary"] = {"bound": "valu-issue at the 1400 W package limit", "achieved": round(ach_gi, 1),
                                            "peak": round(peak_gi, 1), "unit": "G wave64-inst/s", "frac": round(ach_gi / peak_gi, 4),
                                            "wave_instructions_per_polymul": inst_per_poly, "clock_GHz": clock_ghz,
-                                           "cycles_per_instruction": cyc_per_inst,
+                                           "cycles_per_instruction": cyc_per_inst, "power": power,
                                            "source": model + ", profiles/r03_ubench_issue.txt, profiles/r03_power_clock.txt, "
                                                      "profiles/r03_operand_ab.txt"}
     if extras is not None:
