@@ -108,6 +108,22 @@ class Emitter:
         self.lines.append("\t; " + text)
 
     def valu(self, text, wr=None, rd=None):
+        if SWAP_MULHI and text.startswith("v_mul_hi_u32 "):   # experiment: the same question for v_mul_hi_u32
+            ops = [o.strip() for o in text[len("v_mul_hi_u32 "):].split(",")]
+            if len(ops) == 3:
+                text = "v_mul_hi_u32 %s, %s, %s" % (ops[0], ops[2], ops[1])
+        if SWAP_MAD != "0" and text.startswith("v_mad_u64_u32 "):
+            # The butterfly code is written "data x constant" (v_mad_u64_u32 D, carry, data, twiddle-or-constant, addend); what is
+            # EMITTED is "constant x data": same result, same issue cost, and 1.1 - 2.3 % more products/s on the metric kernel --
+            # the kernels run at the package power limit and the multiplier draws less with the sparse constants (delta < 2^27,
+            # the 2^62 term) in its first operand (same-box A/B, equal checksums: profiles/r03_mad_operand_order.txt; exchanging
+            # only the SGPR-constant ones +1.8 %, only the twiddle ones +0.4 %, all +2.3 %).  NFL_GEN_SWAP_MAD=0 / sgpr / vgpr.
+            ops = [o.strip() for o in text[len("v_mad_u64_u32 "):].split(",")]
+            # operands: vdst ("v[a:b]"), sdst ("s[a:b]"), src0, src1, src2
+            sgpr = ops[3].startswith("s") if len(ops) == 5 else False
+            if len(ops) == 5 and (SWAP_MAD in ("", "1") or (SWAP_MAD == "sgpr" and sgpr) or (SWAP_MAD == "vgpr" and not sgpr)):
+                ops[2], ops[3] = ops[3], ops[2]
+                text = "v_mad_u64_u32 " + ", ".join(ops)
         if rd is not None and rd in self.last_swrite:
             gap = self.pos - self.last_swrite[rd]
             if gap < 3:
@@ -415,6 +431,8 @@ def tw_base(em, kreg, s, descending, koff=0):
 # (32768), inverse transforms +6 ... +16 %, forward +2 ... +8 %.  The 4096-word kernels (three workgroups per CU, all 15
 # records of a pass resident) gain nothing from it (product +-0, pre-transformed product -2 %) and keep the natural table.
 LANE_MAJOR = not os.environ.get("NFL_GEN_NATURAL_TWIDDLES")
+SWAP_MAD = os.environ.get("NFL_GEN_SWAP_MAD", "")   # "" / "1" all (shipped), "0" none, "sgpr" / "vgpr": only the multiply-adds whose second factor is an SGPR / a VGPR
+SWAP_MULHI = bool(os.environ.get("NFL_GEN_SWAP_MULHI"))
 SPLIT32K = not os.environ.get("NFL_GEN_SERIAL_EXCHANGE")   # build_row32k: exchanges of one file under the arithmetic of the other
 
 
