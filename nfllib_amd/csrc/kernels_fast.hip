@@ -458,18 +458,29 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
     void *c;
     const void *a, *b, *psi, *mc;
     int nm, logn;
-    int cnt_v, cnt_f, cnt_i, pad;
+    int cnt_v, cnt_f, cnt_i, remap_gx;
     const void *fa_src;
     void *fa_dst;
     const void *fb_src;
-    void *fb_dst, *inv, *pad2;
-  } args = {c_v, a_v, b_v, t.psi, t.mc, (int)s.nm, s.logn, cnt_v, cnt_f, cnt_i, 0, fa_src, fa_dst, fb_src, fb_dst, inv, nullptr};
+    void *fb_dst, *inv;
+    unsigned remap_per, remap_magic;
+  } args = {c_v, a_v, b_v, t.psi, t.mc, (int)s.nm, s.logn, cnt_v, cnt_f, cnt_i, 0, fa_src, fa_dst, fb_src, fb_dst, inv, 0u, 0u};
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_pipe65536_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   // per polynomial row: 16 block products + 3 x 4 streaming workgroups
   const size_t gx = (size_t)mx * 28;
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
+#ifndef NFLHIP_NO_PIPE_REMAP
+  // modulus-major units in contiguous ranges per XCD slot (see build_pipe): every twiddle table is then fetched by ~1.3 of
+  // the 8 private L2s instead of all 8.  Needs units divisible by 8 and the kernel's one-multiply division by gx exact.
+  const unsigned long long units = (unsigned long long)gx * s.nm;
+  if (units % 8 == 0 && units * gx < (1ull << 32)) {
+    args.remap_gx = (int)gx;
+    args.remap_per = (unsigned)(units / 8);
+    args.remap_magic = (unsigned)((1ull << 32) / gx + 1);
+  }
+#endif
   return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
 

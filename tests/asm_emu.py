@@ -1081,7 +1081,7 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False):
+def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=False):
     """n = 32768 / 65536: the three-role kernel of tools/gen_polymul_asm.py build_pipe (kernarg as
     launch_polymul_pipe64k_u64 packs it) driven the way the composed product does: forward streaming pass of both
     operands, fused block products, inverse streaming pass in place -- three launches of the same kernel"""
@@ -1099,8 +1099,11 @@ def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False):
     per_row = 28 if logn == 16 else 14
 
     def launch(cnt_v, cnt_f, cnt_i):
-        kernarg = struct.pack("<5Q6i6Q", pc, psa, psb, ppsi, pmc, nm, logn, cnt_v, cnt_f, cnt_i, 0, pa, psa, pb, psb, pc, 0)
-        run_kernel(text, mem, kernarg, (max(cnt_v, cnt_f, cnt_i) * per_row, nm), lds)
+        gx = max(cnt_v, cnt_f, cnt_i) * per_row
+        rm = (gx, gx * nm // 8, (1 << 32) // gx + 1) if remap else (0, 0, 0)    # (launch_polymul_pipe64k_u64's XCD remap)
+        assert not remap or (gx * nm) % 8 == 0
+        kernarg = struct.pack("<5Q5ii5Q2I", pc, psa, psb, ppsi, pmc, nm, logn, cnt_v, cnt_f, cnt_i, rm[0], pa, psa, pb, psb, pc, rm[1], rm[2])
+        run_kernel(text, mem, kernarg, (gx, nm), lds)
 
     launch(0, batch, 0)
     launch(batch, 0, 0)

@@ -151,6 +151,11 @@ def test_emulated_u64_three_role_kernel(stem, n, generated, oracle_factory):
     o = oracle_factory(64, n, 1)
     prm, a, b = operands(o, 64, n, 1, 1, 18)
     assert np.array_equal(asm_emu.run_pipe_product(generated(stem), n, 1, prm, a, b), o.polymul(a, b))
+    # two moduli with the launcher's XCD remap: the workgroup with linear index L takes unit (L mod 8) U/8 + L div 8 of the
+    # modulus-major order, so that one XCD walks through a contiguous range of moduli (their twiddle tables stay in ITS L2)
+    o2 = oracle_factory(64, n, 2)
+    prm, a, b = operands(o2, 64, n, 2, 1, 19)
+    assert np.array_equal(asm_emu.run_pipe_product(generated(stem), n, 2, prm, a, b, remap=True), o2.polymul(a, b))
 
 
 def _picker(kind):

@@ -2661,6 +2661,23 @@ def build_pipe(logn=None, fused=False):
     if fused:
         fused_header(em, PER_ROW, NV, NSW, CG_LOG)
     else:
+        # Workgroups are dealt to the 8 XCDs round-robin by their linear index, so with the plain (wgx, cm) grid every XCD works
+        # on every modulus and every private L2 fetches every twiddle table once per pass: at n = 65536 x 30 moduli that is
+        # 8 x 31 MB per pass, a third of the operand bytes again (3.34 x the algorithmic traffic where the plan moves 3.0).
+        # Remap: unit u = cm gx + wgx (modulus-major); XCD slot k = L mod 8 takes the CONTIGUOUS units [k U/8, (k+1) U/8):
+        # an XCD then walks through ~nm/8 moduli, one after the other.  kernarg: gx (0 = off), U/8, ceil(2^32 / gx).
+        R("s_cmp_eq_u32 s59, 0")
+        R("s_cbranch_scc1 .Lno_remap")
+        R("s_mul_i32 s42, s3, s59")
+        R("s_add_u32 s42, s42, s2")                          # L
+        R("s_and_b32 s43, s42, 7")
+        R("s_lshr_b32 s42, s42, 3")
+        R("s_mul_i32 s43, s43, s70")
+        R("s_add_u32 s42, s42, s43")                         # u
+        R("s_mul_hi_u32 s3, s42, s71")                       # cm = u / gx
+        R("s_mul_i32 s43, s3, s59")
+        R("s_sub_u32 s2, s42, s43")                          # wgx = u mod gx
+        em.lines.append(".Lno_remap:")
         legacy_role_map(em, PER_ROW, NV, NSW)
     stream_setup = {}
     # ---------------------------------------------------------------- streaming roles
@@ -2909,7 +2926,7 @@ KERNELS = {   # kind -> (file suffix, kernel symbol)
 
 ARGS_STD = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 40), ("i32", 44)]
 ARGS_PIPE = ARGS_STD + [("i32", 48), ("i32", 52), ("i32", 56), ("i32", 60), ("ptr", 64), ("ptr", 72), ("ptr", 80), ("ptr", 88),
-                        ("ptr", 96), ("ptr", 104)]
+                        ("ptr", 96), ("i32", 104), ("i32", 108)]
 
 
 def args_yaml(spec):
