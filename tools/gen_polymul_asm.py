@@ -1184,45 +1184,136 @@ def build_row16k(kind="polymul", stop=None):
                 ring.done((name, s, g))
 
     AX = T(0, 0)   # exchange address scratch (the butterfly temporaries are idle during exchanges)
-    if has_fwd:
-        fwd_pass("F0")
-        ck(1)
-        for i, base in enumerate(fwd_bases):
-            em.comment("X0: thread (q, t) slot 4*qq + j  ->  sub-group qq, thread t, slot q + 4*j")
-            if i:
-                R("s_barrier")       # WAR: the slabs are still being read for the previous operand
-            em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
-            for k in range(16):
-                qq, j = k // per, k % per
-                R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k),
-                                                       (qq & 1) * SLAB_BYTES + j * 2048 * ROW_G))
+    # ---- two operands on shared twiddle records, exchanges under the arithmetic (kind "polymul"): in the last stage of a
+    # pass and in the first two of the next one the butterflies of a run first, the records stay in the ring, then b's:
+    #   last stage: a | W_a | b | barrier | R_a | barrier | W_b     next pass, stage 0: a | barrier | R_b     stage 1: a | b, b
+    # so that a's writes, b's writes and b's reads are in flight under butterflies; only a's reads are waited for in the open.
+    # (Ring: the 8 records of a last stage are all live at once -- 9 slots; nothing is fetched twice.)
+    def bflys(base, s_, g, tw):
+        half = 8 >> s_
+        return [ct_bfly(base + 2 * (g * 2 * half + h), base + 2 * (g * 2 * half + h + half), tw) for h in range(half)]
+
+    def hold_a(name, s_):
+        for g in range(1 << s_):
+            run_pairs(em, bflys(V_A, s_, g, ring.get((name, s_, g))))
+
+    def then_b(name, s_):
+        for g in range(1 << s_):
+            run_pairs(em, bflys(V_B, s_, g, ring.regs((name, s_, g))))
+            ring.done((name, s_, g))
+
+    def both(name, s_):
+        for g in range(1 << s_):
+            tw = ring.get((name, s_, g))
+            jobs = []
+            for ja, jb in zip(bflys(V_A, s_, g, tw), bflys(V_B, s_, g, tw)):
+                jobs += [ja, jb]
+            run_pairs(em, jobs)
+            ring.done((name, s_, g))
+
+    def x0_w(base):
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+        for k in range(16):
+            qq, j = k // per, k % per
+            R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 2048 * ROW_G))
+
+    def x0_r(base):
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+        for k in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+
+    def fwd_split():
+        W0, BAR = "s_waitcnt lgkmcnt(0)", "s_barrier"
+        exch = {"F0": (x0_w, x0_r, True),
+                "F1": (lambda b_: lds_write(em, V_L1W, b_, 2176), lambda b_: lds_read(em, V_L1R, b_, 136), True),
+                "F2": (lambda b_: lds_write(em, V_L1R, b_, 136), lambda b_: lds_read(em, V_L2R, b_, 8), False)}   # E2: wave-local
+        names = ["F0", "F1", "F2", "F3"]
+        pending = None          # exchange of operand b still to be finished inside the next pass
+        for name in names:
+            stages = list(order[name])
+            em.comment("%s (operands share the twiddle records; exchanges under the arithmetic)" % name)
+            k = 0
+            if pending is not None:
+                w_, r_, cross = pending
+                # stage 0: a alone while b's writes fly; then b's reads under stage 1 of a
+                hold_a(name, stages[0])
+                if cross:
+                    R(W0)
+                    R(BAR)
+                    r_(V_B)
+                hold_a(name, stages[1])
+                R(W0)
+                if cross:
+                    R(BAR)           # every wave is done reading: the next exchange may write
+                then_b(name, stages[0])
+                then_b(name, stages[1])
+                k = 2
+                pending = None
+            last = stages[-1] if name in exch else None
+            for s_ in stages[k:]:
+                if s_ != last:
+                    both(name, s_)
+            if last is not None:
+                w_, r_, cross = exch[name]
+                hold_a(name, last)
+                w_(V_A)
+                if not cross:        # wave-local transposes (LDS is in order per wave): a's reads follow its writes at once
+                    r_(V_A)
+                then_b(name, last)
+                R(W0)
+                if cross:
+                    R(BAR)
+                    r_(V_A)
+                    R(W0)
+                    R(BAR)
+                w_(V_B)
+                if not cross:
+                    r_(V_B)
+                pending = exch[name]
+        assert pending is None
+
+    if has_fwd and kind == "polymul" and SPLIT32K:
+        fwd_split()
+    elif has_fwd:
+            fwd_pass("F0")
+            ck(1)
+            for i, base in enumerate(fwd_bases):
+                em.comment("X0: thread (q, t) slot 4*qq + j  ->  sub-group qq, thread t, slot q + 4*j")
+                if i:
+                    R("s_barrier")       # WAR: the slabs are still being read for the previous operand
+                em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+                for k in range(16):
+                    qq, j = k // per, k % per
+                    R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k),
+                                                           (qq & 1) * SLAB_BYTES + j * 2048 * ROW_G))
+                R("s_waitcnt lgkmcnt(0)")
+                R("s_barrier")
+                em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+                em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+                for k in range(16):
+                    R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+                R("s_waitcnt lgkmcnt(0)")
+            ck(2)
+            fwd_pass("F1")
+            ck(3)
+            for base in fwd_bases:
+                em.comment("E1")
+                R("s_barrier")           # WAR against the previous exchange through this slab
+                lds_write(em, V_L1W, base, 2176)
+                R("s_waitcnt lgkmcnt(0)")
+                R("s_barrier")
+                lds_read(em, V_L1R, base, 136)
+                R("s_waitcnt lgkmcnt(0)")
+            fwd_pass("F2")
+            ck(4)
+            em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+            for base in fwd_bases:
+                lds_write(em, V_L1R, base, 136)
+                lds_read(em, V_L2R, base, 8)
             R("s_waitcnt lgkmcnt(0)")
-            R("s_barrier")
-            em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
-            em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
-            for k in range(16):
-                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
-            R("s_waitcnt lgkmcnt(0)")
-        ck(2)
-        fwd_pass("F1")
-        ck(3)
-        for base in fwd_bases:
-            em.comment("E1")
-            R("s_barrier")           # WAR against the previous exchange through this slab
-            lds_write(em, V_L1W, base, 2176)
-            R("s_waitcnt lgkmcnt(0)")
-            R("s_barrier")
-            lds_read(em, V_L1R, base, 136)
-            R("s_waitcnt lgkmcnt(0)")
-        fwd_pass("F2")
-        ck(4)
-        em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
-        for base in fwd_bases:
-            lds_write(em, V_L1R, base, 136)
-            lds_read(em, V_L2R, base, 8)
-        R("s_waitcnt lgkmcnt(0)")
-        fwd_pass("F3")
-        ck(5)
+            fwd_pass("F3")
+            ck(5)
     if kind == "fwd":
         em.comment("canonical words, then a wave-local LDS transpose so the stores are fully coalesced")
         run_pairs(em, [canon(V_A + 2 * i) for i in range(16)])
