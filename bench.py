@@ -327,7 +327,7 @@ def main():
             if tj:
                 traffic = tj["hbm_bytes_per_poly"] * batch
                 traffic_src = "NOT measured in this run (%s): profiles/pmc_traffic.json, rocprofv3 FETCH_SIZE/WRITE_SIZE passes of round %s, kernel %s" % (
-                    why or "skipped", tj.get("round", "?"), ",".join(tj.get("kernels", {})))
+                    why or "skipped", tj.get("round", "?"), tj.get("kernel") or ",".join(tj.get("kernels", {})))
         except Exception:
             traffic = None
 
