@@ -1187,7 +1187,8 @@ def build_row16k(kind="polymul", stop=None):
     # ---- two operands on shared twiddle records, exchanges under the arithmetic (kind "polymul"): in the last stage of a
     # pass and in the first two of the next one the butterflies of a run first, the records stay in the ring, then b's:
     #   last stage: a | W_a | b | barrier | R_a | barrier | W_b     next pass, stage 0: a | barrier | R_b     stage 1: a | b, b
-    # so that a's writes, b's writes and b's reads are in flight under butterflies; only a's reads are waited for in the open.
+    # so that a's writes, b's writes and b's reads are in flight under butterflies; only a's reads are waited for in the open
+    # (consuming them word by word under a's stage 0 as well was measured: nothing, tools/sessions/gpu_round3_x.sh).
     # (Ring: the 8 records of a last stage are all live at once -- 9 slots; nothing is fetched twice.)
     def bflys(base, s_, g, tw):
         half = 8 >> s_
@@ -1273,8 +1274,69 @@ def build_row16k(kind="polymul", stop=None):
                 pending = exch[name]
         assert pending is None
 
+    def fwd_progressive():
+        """one operand: every exchange written word by word out of a pass's last stage and read in the order the next
+        pass's first stage consumes (see the inverse half below)"""
+        def fwd_stage(name, s_, pre=None, post=None):
+            half, i_ = 8 >> s_, 0
+            for g in range(1 << s_):
+                tw = ring.get((name, s_, g))
+                for h in range(half):
+                    x, y = g * 2 * half + h, g * 2 * half + h + half
+                    if pre:
+                        pre(i_)
+                    run_pairs(em, [ct_bfly(V_A + 2 * x, V_A + 2 * y, tw)])
+                    if post:
+                        post(x)
+                        post(y)
+                    i_ += 1
+                ring.done((name, s_, g))
+
+        first = [k for h in range(8) for k in (h, h + 8)]        # visiting order of a pass's stage 0
+        arrive = lambda i_: R("s_waitcnt lgkmcnt(%d)" % (14 - 2 * i_))
+        AXP = V_TWA                                               # (idle in the forward passes)
+        em.comment("F0; X0 written out of its last stage: thread (q, t) slot 4*qq + j  ->  sub-group qq, thread t, slot q + 4*j")
+        for s_ in order["F0"][:-1]:
+            fwd_stage("F0", s_)
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AXP, 2 * SLAB_BYTES, V_OFF8))
+        fwd_stage("F0", order["F0"][-1], post=lambda k: R("ds_write_b64 v%d, %s offset:%d" % (
+            V_OFF8 if k // per < 2 else AXP, vp(V_A + 2 * k), ((k // per) & 1) * SLAB_BYTES + (k % per) * 2048 * ROW_G)))
+        ck(1)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+        for k in first:
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), AX, 2048 * k))
+        ck(2)
+        fwd_stage("F1", 0, pre=arrive)
+        for s_ in (1, 2):
+            fwd_stage("F1", s_)
+        em.comment("E1 written out of F1's last stage")
+        R("s_barrier")               # WAR: every wave is done reading X0
+        fwd_stage("F1", 3, post=lambda k: R("ds_write_b64 v%d, %s offset:%d" % (V_L1W, vp(V_A + 2 * k), 2176 * k)))
+        ck(3)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        for k in first:
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_L1R, 136 * k))
+        fwd_stage("F2", 0, pre=arrive)
+        for s_ in (1, 2):
+            fwd_stage("F2", s_)
+        em.comment("E2 (wave-local 16-lane transposes) written out of F2's last stage")
+        fwd_stage("F2", 3, post=lambda k: R("ds_write_b64 v%d, %s offset:%d" % (V_L1R, vp(V_A + 2 * k), 136 * k)))
+        ck(4)
+        for k in first:
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_L2R, 8 * k))
+        fwd_stage("F3", 0, pre=arrive)
+        for s_ in (1, 2, 3):
+            fwd_stage("F3", s_)
+        ck(5)
+
     if has_fwd and kind == "polymul" and SPLIT32K:
         fwd_split()
+    elif has_fwd and SPLIT32K:
+        fwd_progressive()
     elif has_fwd:
             fwd_pass("F0")
             ck(1)
@@ -1348,39 +1410,108 @@ def build_row16k(kind="polymul", stop=None):
             R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
         lds_read(em, V_L2R, V_A, 8)
         R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I1", (3, 2, 1, 0))
-    ck(6)
-    em.comment("E2'")
-    lds_write(em, V_L2R, V_A, 8)
-    lds_read(em, V_L1R, V_A, 136)
-    R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I2", (3, 2, 1, 0))
-    ck(7)
-    em.comment("E1'")
-    lds_write(em, V_L1R, V_A, 136)
-    R("s_waitcnt lgkmcnt(0)")
-    R("s_barrier")
-    lds_read(em, V_L1W, V_A, 2176)
-    R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I3", (3, 2, 1, 0))
-    ck(8)
-    em.comment("X0': thread (q, t) slot g + 4*j  ->  thread (g, t) slot 4*q + j, reader-major layout [slot][tid]")
-    R("s_barrier")               # every wave is done reading E1'
-    R("s_lshl_b32 s86, %s, 15" % (S_Q,))
-    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
-    em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                              # q*32768 + t*8
-    for k in range(16):
-        g_, j = k % ROW_G, k // ROW_G
-        R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(V_A + 2 * k), j * 2048 * ROW_G + g_ * 2048))
-    R("s_waitcnt lgkmcnt(0)")
-    R("s_barrier")
-    rstep = 2048 * ROW_G                                 # bytes between a reader's consecutive slots
-    em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * rstep, V_OFF8))
-    for k in range(16):
-        R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * rstep))
-    R("s_waitcnt lgkmcnt(0)")
-    inv_pass("I0", order["I0"][:-1])
-    ck(9)
+    if SPLIT32K:
+        # ---- progressive exchanges of the inverse half (one operand, nothing else to run under an exchange): every word is
+        # written to the LDS as soon as the pass's last stage has finished it, and the reads are issued in the order the next
+        # pass's first stage consumes them, each butterfly waiting only for its own two (LDS returns in order).
+        def inv_stage(name, s_, pre=None, post=None):
+            half, i_ = 8 >> s_, 0
+            for g in range(1 << s_):
+                tw = ring.get((name, s_, g))
+                for h in range(half):
+                    x, y = g * 2 * half + h, g * 2 * half + h + half
+                    if pre:
+                        pre(i_)
+                    run_pairs(em, [gs_bfly(V_A + 2 * x, V_A + 2 * y, tw)])
+                    if post:
+                        post(x)
+                        post(y)
+                    i_ += 1
+                ring.done((name, s_, g))
+
+        def visit(s_):
+            half = 8 >> s_
+            return [k for g in range(1 << s_) for h in range(half) for k in (g * 2 * half + h, g * 2 * half + h + half)]
+
+        def arrive(i_):
+            R("s_waitcnt lgkmcnt(%d)" % (14 - 2 * i_))
+
+        AXP = V_TWA                                          # (idle in the uniform pass I3 and in I0)
+        rstep = 2048 * ROW_G                                 # bytes between a reader's consecutive slots
+        for s_ in (3, 2, 1):
+            inv_stage("I1", s_)
+        em.comment("E2' (wave-local): written word by word out of I1's last stage, read in I2's order")
+        inv_stage("I1", 0, post=lambda k: R("ds_write_b64 v%d, %s offset:%d" % (V_L2R, vp(V_A + 2 * k), 8 * k)))
+        ck(6)
+        for k in visit(3):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_L1R, 136 * k))
+        inv_stage("I2", 3, pre=arrive)
+        for s_ in (2, 1):
+            inv_stage("I2", s_)
+        em.comment("E1': written out of I2's last stage (into positions only this wave has read), read in I3's order")
+        inv_stage("I2", 0, post=lambda k: R("ds_write_b64 v%d, %s offset:%d" % (V_L1R, vp(V_A + 2 * k), 136 * k)))
+        ck(7)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        for k in visit(3):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_L1W, 2176 * k))
+        inv_stage("I3", 3, pre=arrive)
+        for s_ in (2, 1):
+            inv_stage("I3", s_)
+        em.comment("X0': thread (q, t) slot g + 4*j  ->  thread (g, t) slot 4*q + j, reader-major layout [slot][tid]; written out of I3's last stage")
+        R("s_barrier")               # every wave is done reading E1'
+        R("s_lshl_b32 s86, %s, 15" % (S_Q,))
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AXP, V_TID))
+        em.valu("v_add_u32_e32 v%d, s86, v%d" % (AXP, AXP))                            # q*32768 + t*8
+        inv_stage("I3", 0, post=lambda k: R("ds_write_b64 v%d, %s offset:%d" % (AXP, vp(V_A + 2 * k), (k // ROW_G) * 2048 * ROW_G + (k % ROW_G) * 2048)))
+        ck(8)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * rstep, V_OFF8))
+        first = order["I0"][:-1]
+        for k in (visit(first[0]) if first else range(16)):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * rstep))
+        if first:
+            inv_stage("I0", first[0], pre=arrive)
+            for s_ in first[1:]:
+                inv_stage("I0", s_)
+        else:
+            R("s_waitcnt lgkmcnt(0)")
+        ck(9)
+    else:
+        inv_pass("I1", (3, 2, 1, 0))
+        ck(6)
+        em.comment("E2'")
+        lds_write(em, V_L2R, V_A, 8)
+        lds_read(em, V_L1R, V_A, 136)
+        R("s_waitcnt lgkmcnt(0)")
+        inv_pass("I2", (3, 2, 1, 0))
+        ck(7)
+        em.comment("E1'")
+        lds_write(em, V_L1R, V_A, 136)
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        lds_read(em, V_L1W, V_A, 2176)
+        R("s_waitcnt lgkmcnt(0)")
+        inv_pass("I3", (3, 2, 1, 0))
+        ck(8)
+        em.comment("X0': thread (q, t) slot g + 4*j  ->  thread (g, t) slot 4*q + j, reader-major layout [slot][tid]")
+        R("s_barrier")               # every wave is done reading E1'
+        R("s_lshl_b32 s86, %s, 15" % (S_Q,))
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                              # q*32768 + t*8
+        for k in range(16):
+            g_, j = k % ROW_G, k // ROW_G
+            R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(V_A + 2 * k), j * 2048 * ROW_G + g_ * 2048))
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        rstep = 2048 * ROW_G                                 # bytes between a reader's consecutive slots
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * rstep, V_OFF8))
+        for k in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * rstep))
+        R("s_waitcnt lgkmcnt(0)")
+        inv_pass("I0", order["I0"][:-1])
+        ck(9)
     R("s_cmp_eq_u32 s88, %d" % ROW_LG)
     R("s_cbranch_scc1 .Lmerged_last_stage")
     em.comment("r > 2: plain global stage r-2; lazy output for the outer inverse passes")
