@@ -9,7 +9,8 @@ from nfllib_amd import Engine
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 bad = 0
 for lb, n, m, batch in ((64, 4096, 4, 2048), (64, 8192, 2, 1024), (64, 16384, 8, 128), (64, 65536, 6, 16), (32, 1024, 2, 8192),
-                        (64, 1024, 2, 4096), (64, 32768, 2, 64), (64, 2048, 1, 4097), (32, 2048, 1, 8191), (32, 4096, 2, 2049)):
+                        (64, 1024, 2, 4096), (64, 32768, 2, 64), (64, 32768, 2, 300), (64, 16384, 6, 257), (64, 8192, 3, 513), (64, 2048, 1, 4097),
+                        (32, 2048, 1, 8191), (32, 4096, 2, 2049)):   # (32768 x 2 x 64: the one-launch plan; x 300: the register-resident rows)
     e = Engine(lb, n, m)
     a = e.fill_uniform(e.empty(batch), 11, 0)
     b = e.fill_uniform(e.empty(batch), 11, 1)
