@@ -148,7 +148,9 @@ hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uin
                                          const uint64_t *b_in, size_t batch, hipStream_t st, bool b_is_ntt = false);
 
 // 32768-word rows, ONE operand register-resident per 1024-thread workgroup: mode 1: c = INTT(NTT(a) (.) b) with b already
-// transformed (streamed through the point-wise step), 2: c = NTT(a), 3: c = INTT(a); hipErrorNotSupported for other shapes
+// transformed (streamed through the point-wise step), 2: c = NTT(a), 3: c = INTT(a); 4 / 5: modes 2 / 1 with the transformed
+// operand in the layout [block][pair][thread] that only these two kernels share (the composed product's scratch: coalesced on
+// both sides, no transposes); hipErrorNotSupported for other shapes
 hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a, const uint64_t *b,
                              size_t batch, hipStream_t st);
 // n = 65536: one launch of the three-role pipeline kernel (block products of chunk j-1, forward streaming pass of

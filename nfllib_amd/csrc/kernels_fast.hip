@@ -341,6 +341,7 @@ enum AsmKind {
   kAsmPolymul8k, kAsmPolymulNtt8k, kAsmFwd8k, kAsmInv8k,            // 8192-word rows, 512 threads
   kAsmPolymul16k, kAsmPolymulNtt16k, kAsmFwd16k, kAsmInv16k,        // 16384-word rows, 1024 threads
   kAsmFwd32k, kAsmInv32k, kAsmPolymulNtt32k,                         // 32768-word rows: ONE operand register-resident, 1024 threads
+  kAsmFwd32kS, kAsmPolymulNtt32kS,                                   // ... the pair of the composed product: b' in the scratch layout [block][pair][thread]
   kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
   kAsmXcd64k, kAsmXcd32k,                                            // one launch of persistent workgroups, rows pinned to an XCD
   kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
@@ -351,13 +352,14 @@ enum AsmKind {
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
 static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
-static inline bool is32k(AsmKind k) { return k >= kAsmFwd32k && k <= kAsmPolymulNtt32k; }
+static inline bool is32k(AsmKind k) { return k >= kAsmFwd32k && k <= kAsmPolymulNtt32kS; }
 static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul4096nt_asm", "nflhip_polymul_ntt4096_asm", "nflhip_ntt_fwd4096_asm", "nflhip_ntt_inv4096_asm", "nflhip_ntt_inv_mul4096_asm",
     "nflhip_ntt_fwd4096x2nt_asm", "nflhip_ntt_inv4096x2nt_asm",
     "nflhip_polymul8192_asm", "nflhip_polymul_ntt8192_asm", "nflhip_ntt_fwd8192_asm", "nflhip_ntt_inv8192_asm",
     "nflhip_polymul16384_asm", "nflhip_polymul_ntt16384_asm", "nflhip_ntt_fwd16384_asm", "nflhip_ntt_inv16384_asm",
     "nflhip_ntt_fwd32768_asm", "nflhip_ntt_inv32768_asm", "nflhip_polymul_ntt32768_asm",
+    "nflhip_ntt_fwd32768s_asm", "nflhip_polymul_ntt32768s_asm",
     "nflhip_polymul_pipe65536nt_asm",
     "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
     "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm", "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
@@ -648,7 +650,9 @@ hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint6
                              size_t batch, hipStream_t st) {
   if (!row32k_shape(s)) return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
-  return launch_asm(mode == 1 ? kAsmPolymulNtt32k : (mode == 2 ? kAsmFwd32k : kAsmInv32k), s, t, c, a, b, batch, st);
+  // modes 4 / 5: the two halves of the composed product -- b' goes through the context's scratch in a layout only these two share
+  const AsmKind k = mode == 1 ? kAsmPolymulNtt32k : mode == 2 ? kAsmFwd32k : mode == 3 ? kAsmInv32k : mode == 4 ? kAsmFwd32kS : kAsmPolymulNtt32kS;
+  return launch_asm(k, s, t, c, a, b, batch, st);
 }
 
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,

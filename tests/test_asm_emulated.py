@@ -131,6 +131,11 @@ def test_emulated_u64_register_resident_32768_word_rows(nm, batch, generated, or
     assert np.array_equal(run("ntt_fwd32768", a, a), fa)
     assert np.array_equal(run("ntt_inv32768", fa, fa), a)
     assert np.array_equal(run("polymul_ntt32768", a, fb), o.polymul(a, b))
+    # the pair of the composed product: b' travels through the scratch as [block][slot pair i][thread] x 16 bytes (coalesced
+    # on both sides), not in the reference's order
+    scratch = run("ntt_fwd32768s", b, b)
+    assert np.array_equal(scratch.reshape(batch, nm, 8, 8, 256, 2), fb.reshape(batch, nm, 8, 256, 8, 2).transpose(0, 1, 2, 4, 3, 5))
+    assert np.array_equal(run("polymul_ntt32768s", a, scratch), o.polymul(a, b))
 
 
 @pytest.mark.parametrize("nt", ["nt"])

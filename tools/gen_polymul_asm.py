@@ -1747,6 +1747,16 @@ def build_row32k(kind="fwd"):
         for name, (kreg, vidx, desc) in inner.items():
             passes[name + "ab"[f]] = (kreg, vidx, desc, DK[name] * boff)
 
+    # b' of the composed product lives in the context's scratch in a layout of OUR choice ("_s" kinds): block-major, then the
+    # slot pair i, then the thread -- [block q + boff][i][t] x 16 bytes -- so that the 64 lanes of a wave store / fetch 64
+    # consecutive 16-byte pairs (8 cache lines).  In the reference's order (the user-visible one: kinds without "_s") thread t
+    # owns words 16t .. 16t + 15, i.e. a lane's pair sits alone in its 128-byte line: 64 lines per load, 16 bytes used of each,
+    # half of the product kernel's L1 fills -- and the forward kernel pays two LDS transposes to produce it with coalesced stores.
+    scratch_layout = kind.endswith("_s")
+    kind = kind[:-2] if scratch_layout else kind
+    if scratch_layout:
+        kind = {"polymul": "polymul_ntt"}.get(kind, kind)
+
     def bprime_loader(boff):
         def load(em_, r, s_, i, first):               # words 16t + 2i, 16t + 2i + 1 of block q + boff of b' -> one ring slot
             if first:
@@ -1755,7 +1765,11 @@ def build_row32k(kind="fwd"):
                     em_.raw("s_add_u32 s42, s42, 0x%x" % (boff << 15,))
                 em_.raw("s_add_u32 s96, s18, s42")
                 em_.raw("s_addc_u32 s97, s19, 0")
-                em_.valu("v_lshlrev_b32_e32 v%d, 7, v%d" % (V_TWO, V_TID))
+                em_.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, 4 if scratch_layout else 7, V_TID))
+            if scratch_layout:
+                em_.raw("s_add_u32 s86, s96, 0x%x" % (4096 * i,))
+                em_.raw("s_addc_u32 s87, s97, 0")
+                return "global_load_dwordx4 v[%d:%d], v%d, s[86:87] nt" % (r, r + 3, V_TWO)
             return "global_load_dwordx4 v[%d:%d], v%d, s[96:97] offset:%d" % (r, r + 3, V_TWO, 16 * i)
         return load
     passes["Ba"], passes["Bb"] = bprime_loader(0), bprime_loader(4)
@@ -1916,6 +1930,19 @@ def build_row32k(kind="fwd"):
                 lambda: lds_write(em, V_L1R, A_, 136), lambda: lds_read(em, V_L2R, A_, 8), lambda: fwd_stages(1, "F2", (0, 1, 2, 3)), W0,
                 lambda: lds_write(em, V_L1R, B_, 136), lambda: lds_read(em, V_L2R, B_, 8), lambda: fwd_stages(0, "F3", (0, 1, 2, 3)), W0,
                 lambda: fwd_stages(1, "F3", (0, 1, 2, 3)))
+        if kind == "fwd" and scratch_layout:
+            em.comment("canonical words straight into the product's scratch layout [block][pair i][thread]: no transposes")
+            em.valu("v_lshlrev_b32_e32 v%d, 4, v%d" % (V_TWO, V_TID))
+            for base, boff in FILES:
+                run_pairs(em, [canon(base + 2 * i) for i in range(16)])
+                block_base(S_CROW, boff)
+                for i in range(8):
+                    R("global_store_dwordx4 v%d, v[%d:%d], s[86:87] nt" % (V_TWO, base + 4 * i, base + 4 * i + 3))
+                    if i < 7:
+                        R("s_add_u32 s86, s86, 0x1000")
+                        R("s_addc_u32 s87, s87, 0")
+            R("s_endpgm")
+            return True
         if kind == "fwd":
             em.comment("canonical words, then a wave-local LDS transpose per file so the stores are fully coalesced; file B's"
                        " reduction runs under file A's transposes")
@@ -3240,7 +3267,8 @@ def main():
     # 32768-word rows: one operand register-resident in a 1024-thread workgroup (4 sub-groups x 2 blocks)
     g = globals()
     g.update(ROW_LG=3, NEXT_SGPR=max(NEXT_SGPR, 98))
-    for kind, stem in (("fwd", "ntt_fwd32768"), ("inv", "ntt_inv32768"), ("polymul_ntt", "polymul_ntt32768")):
+    for kind, stem in (("fwd", "ntt_fwd32768"), ("inv", "ntt_inv32768"), ("polymul_ntt", "polymul_ntt32768"),
+                       ("fwd_s", "ntt_fwd32768s"), ("polymul_s", "polymul_ntt32768s")):
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind))
     configure("ring", 4)
     if os.environ.get("NFL_DEBUG16K"):   # checkpoint variants for bisecting a fault: kernel ends after phase n
