@@ -487,8 +487,8 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096nt_asm", "C": "nflhip_polymul16384_asm",
                                 "E": "nflhip_polymul_pipe65536nt_asm (block products + streaming passes, 6 launches per step)",
-                                "F": "nflhip_ntt_fwd32768_asm (b) + nflhip_polymul_ntt32768_asm (a, b' streamed): register-resident "
-                                     "32768-word rows, 2 launches per step" if batch * nm >= 256 else
+                                "F": "nflhip_ntt_fwd32768s_asm (b -> scratch, layout [block][pair][thread]) + nflhip_polymul_ntt32768s_asm (a, b' streamed): "
+                                     "register-resident 32768-word rows, 2 launches per step" if batch * nm >= 256 else
                                      "nflhip_polymul_xcd32768_asm (one launch of persistent workgroups; fewer than 256 rows)",
                                 "G": "nflhip_polymul8192_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
