@@ -126,3 +126,37 @@ def test_generators_that_die_early_key_changes_and_failing_launches(mock, tmp_pa
     for limit in (None, "64"):
         r = run(exe, env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", **({"NFL_HIP_QUEUE_LIMIT": limit} if limit else {})})
         assert r.returncode == 0 and "with failure injection" in r.stdout and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_pipeline_xcd_remap_is_a_bijection_and_its_one_multiply_division_is_exact():
+    """n = 65536 pipeline kernel (tools/gen_polymul_asm.py build_pipe, kernels_fast.hip launch_polymul_pipe64k_u64): the workgroup
+    with linear index L = wgx + gx * cm takes unit u = (L mod 8) * U/8 + L div 8 of the modulus-major order and recovers
+    (cm, wgx) = (u div gx, u mod gx) with ONE 32-bit multiply-high by ceil(2^32 / gx).  The launcher switches the remap on
+    only if U = gx * nm is a multiple of 8 and U * gx < 2^32: under exactly that condition the division must be exact and the
+    map a bijection onto the (wgx, cm) grid, and XCD slot k must get a contiguous range of units."""
+    import random
+    rnd = random.Random(5)
+    cases = [(28 * c, nm) for c in (1, 2, 8, 32, 256, 1024) for nm in (1, 2, 3, 6, 8, 30, 64)]
+    cases += [(28 * rnd.randrange(1, 600), rnd.randrange(1, 64)) for _ in range(300)]
+    checked = 0
+    for gx, nm in cases:
+        units = gx * nm
+        if units % 8 or units * gx >= 1 << 32:
+            continue                      # (the launcher leaves the plain grid in place)
+        per, magic = units // 8, (1 << 32) // gx + 1
+        sample = range(units) if units <= 20000 else sorted({rnd.randrange(units) for _ in range(4000)} | {0, units - 1, per - 1, per})
+        seen = set()
+        for L in sample:
+            u = (L & 7) * per + (L >> 3)
+            cm = (u * magic) >> 32
+            wgx = u - cm * gx
+            assert cm == u // gx and 0 <= wgx < gx and cm < nm, (gx, nm, L)
+            seen.add((wgx, cm))
+        assert len(seen) == len(sample)
+        if units <= 20000:
+            assert seen == {(x, c) for x in range(gx) for c in range(nm)}
+            for k in range(8):            # XCD slot k walks through a contiguous, modulus-major range
+                us = sorted((L & 7) * per + (L >> 3) for L in range(k, units, 8))
+                assert us == list(range(k * per, (k + 1) * per))
+        checked += 1
+    assert checked > 60
