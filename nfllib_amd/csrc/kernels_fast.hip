@@ -342,6 +342,7 @@ enum AsmKind {
   kAsmPolymul16k, kAsmPolymulNtt16k, kAsmFwd16k, kAsmInv16k,        // 16384-word rows, 1024 threads
   kAsmFwd32k, kAsmInv32k, kAsmPolymulNtt32k,                         // 32768-word rows: ONE operand register-resident, 1024 threads
   kAsmFwd32kS, kAsmPolymulNtt32kS,                                   // ... the pair of the composed product: b' in the scratch layout [block][pair][thread]
+  kAsmFwd16kX2, kAsmFwd8kX2,                                         // stand-alone forward transform, two rows of one modulus per workgroup
   kAsmPipe64k,                                                       // n = 65536: three-role pipeline kernel
   kAsmXcd64k, kAsmXcd32k,                                            // one launch of persistent workgroups, rows pinned to an XCD
   kAsmRow1024U32, kAsmRow2048U32, kAsmRow4096U32, kAsmRowFwd1024U32, kAsmRowFwd2048U32, kAsmRowFwd4096U32,
@@ -360,6 +361,7 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul16384_asm", "nflhip_polymul_ntt16384_asm", "nflhip_ntt_fwd16384_asm", "nflhip_ntt_inv16384_asm",
     "nflhip_ntt_fwd32768_asm", "nflhip_ntt_inv32768_asm", "nflhip_polymul_ntt32768_asm",
     "nflhip_ntt_fwd32768s_asm", "nflhip_polymul_ntt32768s_asm",
+    "nflhip_ntt_fwd16384x2_asm", "nflhip_ntt_fwd8192x2_asm",
     "nflhip_polymul_pipe65536nt_asm",
     "nflhip_polymul_xcd65536_asm", "nflhip_polymul_xcd32768_asm",
     "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm", "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
@@ -428,7 +430,9 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
 // fused product -- twice the bytes in flight per workgroup and one set of twiddle loads for both rows.
 static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *dst, const uint64_t *src,
                                 size_t batch, hipStream_t st) {
-  if (s.compiled_only || !s.small_delta || s.logn != kLogN || s.nm > 65535) return hipErrorNotSupported;
+  // (the same for rows of 16384 / 8192 words: the forward half of their fused products without the product)
+  const bool k16 = kind == kAsmFwd16kX2, k8 = kind == kAsmFwd8kX2;
+  if (s.compiled_only || !s.small_delta || s.logn != (k16 ? kLogN + 2 : k8 ? kLogN + 1 : kLogN) || s.nm > 65535) return hipErrorNotSupported;
   if (batch < 2 || batch > 0x7fffffffull) return hipErrorNotSupported;
   hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
@@ -436,10 +440,10 @@ static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t
     void *c;
     const void *a, *b, *psi, *mc;
     int nm, logn, count;
-  } args = {dst, src, nullptr, t.psi, t.mc, (int)s.nm, s.logn, (int)batch};
+  } args = {dst, src, nullptr, k16 || k8 ? PSI_LM(t) : t.psi, t.mc, (int)s.nm, s.logn, (int)batch};
   size_t size = 52;
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+  return hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), (unsigned)s.nm, 1, k16 ? 1024 : k8 ? 512 : kThreads, 1, 1, 0, st, nullptr, extra);
 }
 
 // n = 65536: one launch of the three-role kernel (tools/gen_polymul_asm.py build_pipe): fused block products of `cnt_v`
@@ -720,8 +724,12 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
 
 hipError_t launch_ntt_fwd_fast_u64(const Shape &s, const DevTables &t, const uint64_t *src, uint64_t *dst, size_t batch,
                                    hipStream_t st) {
-  if (row16k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmFwd16k, s, t, dst, src, nullptr, batch, st);
-  if (row8k_shape(s)) return batch == 0 ? hipSuccess : launch_asm(kAsmFwd8k, s, t, dst, src, nullptr, batch, st);
+  if (row16k_shape(s) || row8k_shape(s)) {
+    if (batch == 0) return hipSuccess;
+    const hipError_t e = launch_asm_x2(row16k_shape(s) ? kAsmFwd16kX2 : kAsmFwd8kX2, s, t, dst, src, batch, st);   // (batch >= 2)
+    if (e != hipErrorNotSupported) return e;
+    return launch_asm(row16k_shape(s) ? kAsmFwd16k : kAsmFwd8k, s, t, dst, src, nullptr, batch, st);
+  }
   if (row32k_shape(s)) return launch_row32k_u64(s, t, 2, dst, src, nullptr, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   return launch_inner_fwd_fast_u64(s, t, src, dst, batch * s.nm, st);

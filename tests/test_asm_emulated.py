@@ -119,6 +119,16 @@ def test_emulated_u64_block_transforms(suffix, n, block_log, generated, oracle_f
         assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_inv_mul4096"), n, nm, prm, fa, fb, block_log), want)
 
 
+@pytest.mark.parametrize("n,nm,batch", [(16384, 2, 3), (8192, 3, 4), (8192, 1, 1)])
+def test_emulated_u64_two_rows_per_workgroup_forward_transform_of_long_rows(n, nm, batch, generated, oracle_factory):
+    """stand-alone forward transform at n = 16384 / 8192: two polynomials of one modulus per workgroup on shared twiddle
+    records (the forward half of the fused product without the product); the odd one out is transformed twice"""
+    o = oracle_factory(64, n, nm)
+    prm, a, _ = operands(o, 64, n, nm, batch, 27)
+    got = asm_emu.run_block_kernel(generated("ntt_fwd%dx2" % n), n, nm, prm, a, a, n.bit_length() - 1, count=batch)
+    assert np.array_equal(got, o.ntt(a))
+
+
 @pytest.mark.parametrize("nm,batch", [(1, 1), (2, 2)])
 def test_emulated_u64_register_resident_32768_word_rows(nm, batch, generated, oracle_factory):
     """n = 32768 (workload F, the reference's largest test config): ONE operand register-resident in a 1024-thread

@@ -998,6 +998,8 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     R("s_load_dwordx2 s[12:13], s[0:1], 0x20")           # mc
     R("s_load_dword s14, s[0:1], 0x28")                  # nm
     R("s_load_dword s88, s[0:1], 0x2c")                  # logn
+    if kind == "fwd2":
+        R("s_load_dword s96, s[0:1], 0x30")              # count: the workgroup transforms polynomials 2 wgx and 2 wgx + 1
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))                      # tid*8
     em.valu("v_lshrrev_b32_e32 v%d, 8, v%d" % (V_BIDX, V_TID))                      # q (wave-uniform)
     R("s_nop 1")                 # gfx950: a VALU VGPR write needs a wait state before v_readfirstlane reads it
@@ -1019,6 +1021,8 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     for t_ in sorted(set(V_T)):
         em.valu("v_mov_b32_e32 v%d, 0" % (t_ + 15,))                                # the persistent zero of each stream's ZP pair
     R("s_waitcnt lgkmcnt(0)")
+    if kind == "fwd2":
+        R("s_lshl_b32 s2, s2, 1")
     # G = ROW_G sub-groups, LG = log2 G: r = logn - 12 (>= LG); wgx = poly * 2^(r-LG) + blkG;
     # (4096 G)-word block = ((poly*nm + cm) << (r-LG)) + blkG
     R("s_sub_u32 s88, s88, 12")
@@ -1037,6 +1041,18 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     for base, row in ((6, 16), (8, 18), (4, 20)):
         R("s_add_u32 s%d, s%d, s42" % (row, base))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    if kind == "fwd2":
+        # the second polynomial (same modulus: nm rows further), or the first one again for the odd one out at the end of
+        # the batch (transformed twice, stored twice to the same place): source s[18:19], destination s[96:97]
+        R("s_add_u32 s42, s2, 1")
+        R("s_cmp_lt_u32 s42, s96")
+        R("s_cselect_b32 s42, s14, 0")                   # rows to the second polynomial: nm or 0
+        R("s_lshr_b32 s43, s42, %d" % (32 - 15 - ROW_LG,))
+        R("s_lshl_b32 s42, s42, %d" % (15 + ROW_LG,))
+        R("s_add_u32 s18, s16, s42")
+        R("s_addc_u32 s19, s17, s43")
+        R("s_add_u32 s96, s20, s42")
+        R("s_addc_u32 s97, s21, s43")
     # tw = psi + (cm << (logn + 4))
     R("s_add_u32 s43, s88, 16")
     R("s_lshl_b32 s42, s3, s43")
@@ -1099,7 +1115,7 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
                 R("s_add_u32 s86, s86, 0x1000")
                 R("s_addc_u32 s87, s87, 0")
 
-    if kind == "polymul":
+    if kind in ("polymul", "fwd2"):
         row_loads(V_A, S_AROW)
         row_loads(V_B, S_BROW)
     elif kind == "polymul_ntt":
@@ -1144,11 +1160,11 @@ def build_row16k(kind="polymul", stop=None):
              "I2": (3, 2, 1, 0), "I3": (3, 2, 1, 0), "I0": tuple(range(ROW_LG - 1, -1, -1))}
     per = 16 // ROW_G          # register slots per 4096-word block in the row layout x[tid + 256 G k]
     has_fwd = kind != "inv"
-    has_inv = kind != "fwd"
+    has_inv = kind not in ("fwd", "fwd2")
     names = (["F0", "F1", "F2", "F3"] if has_fwd else []) + (["I1", "I2", "I3", "I0"] if has_inv else [])
     uses = [(name, s, g) for name in names for s in order[name] for g in range(1 << s)]
     ring = Ring(em, vm, RING_SLOTS, uses, passes)
-    fwd_bases = (V_A, V_B) if kind == "polymul" else (V_A,)
+    fwd_bases = (V_A, V_B) if kind in ("polymul", "fwd2") else (V_A,)
     prologue16k(em, vm, stop, kind)
     n_before_ring = vm.issued
     ring.prime()
@@ -1333,7 +1349,7 @@ def build_row16k(kind="polymul", stop=None):
             fwd_stage("F3", s_)
         ck(5)
 
-    if has_fwd and kind == "polymul" and SPLIT32K:
+    if has_fwd and kind in ("polymul", "fwd2") and SPLIT32K:
         fwd_split()
     elif has_fwd and SPLIT32K:
         fwd_progressive()
@@ -1376,6 +1392,36 @@ def build_row16k(kind="polymul", stop=None):
             R("s_waitcnt lgkmcnt(0)")
             fwd_pass("F3")
             ck(5)
+    if kind == "fwd2":
+        em.comment("two rows: canonical words, a wave-local LDS transpose per row so the stores are fully coalesced; the second"
+                   " row's reduction runs under the first one's transposes")
+        def transposes(base):
+            lds_write(em, V_L2R, base, 8)
+            _, l = lane_contig_setup(em)
+            em.valu("v_add_u32_e32 v%d, %s, v%d" % (l, S_SLAB, l))
+            for j in range(16):
+                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * j), l, 544 * j))
+
+        def stores(base, lo, hi):
+            g, _ = lane_contig_setup(em)
+            R("s_lshl_b32 s42, %s, 15" % (S_Q,))
+            R("s_add_u32 s86, s%d, s42" % lo)
+            R("s_addc_u32 s87, s%d, 0" % hi)
+            for j in range(16):
+                R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d" % (g, vp(base + 2 * j), (j & 7) * 512))
+                if j == 7:
+                    R("s_add_u32 s86, s86, 0x1000")
+                    R("s_addc_u32 s87, s87, 0")
+        run_pairs(em, [canon(V_A + 2 * i) for i in range(16)])
+        transposes(V_A)
+        run_pairs(em, [canon(V_B + 2 * i) for i in range(16)])
+        R("s_waitcnt lgkmcnt(0)")
+        stores(V_A, 20, 21)
+        transposes(V_B)
+        R("s_waitcnt lgkmcnt(0)")
+        stores(V_B, 96, 97)
+        R("s_endpgm")
+        return em
     if kind == "fwd":
         em.comment("canonical words, then a wave-local LDS transpose so the stores are fully coalesced")
         run_pairs(em, [canon(V_A + 2 * i) for i in range(16)])
@@ -3251,6 +3297,9 @@ def main():
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
     g = globals()
+    g.update(NEXT_SGPR=98)     # two rows of one modulus per workgroup on shared twiddle records (stand-alone forward transform)
+    emit_file(os.path.join(outdir, "ntt_fwd16384x2_gfx950.s"), "nflhip_ntt_fwd16384x2_asm", build_row16k("fwd2"), args=ARGS_STD + [("i32", 48)])
+    g.update(NEXT_SGPR=96)
     if experiments:            # persistent workgroups with row prefetch: measured -6.5 % (n = 16384) / -11 % (n = 8192), not kept
         g.update(NEXT_SGPR=102)
         emit_file(os.path.join(outdir, "polymul16384p_gfx950.s"), "nflhip_polymul16384p_asm", build_row16k_loop(),
@@ -3259,6 +3308,9 @@ def main():
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem.replace("16384", "8192") + "_gfx950.s"), kname.replace("16384", "8192"),
                   build_row16k(kind))
+    g.update(NEXT_SGPR=98)
+    emit_file(os.path.join(outdir, "ntt_fwd8192x2_gfx950.s"), "nflhip_ntt_fwd8192x2_asm", build_row16k("fwd2"), args=ARGS_STD + [("i32", 48)])
+    g.update(NEXT_SGPR=96)
     if experiments:
         g.update(NEXT_SGPR=102)
         emit_file(os.path.join(outdir, "polymul8192p_gfx950.s"), "nflhip_polymul8192p_asm", build_row16k_loop(),
