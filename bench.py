@@ -162,6 +162,82 @@ def measure_traffic(workload, batch):
                                                    % (products, tot["FETCH_SIZE"], tot["WRITE_SIZE"]))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: re-run this command line as N ranks of one node
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...),
+    one device each, RCCL backend; rank 0's JSON line passes through on stdout.  Exits non-zero when the node has fewer
+    than N devices (NFLHIP_BENCH_ONE_DEVICE=1, the 1-GPU test knob, puts every rank on device 0 instead)."""
+    import socket
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("NFLHIP_BENCH_ONE_DEVICE") != "1":
+        raise SystemExit("--gpus %d: this node has %d GPU(s); refusing to report an n_gpus the run did not have" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # the host driver only supports dmabuf IPC (RCCL across processes)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False):
+    """One more BASELINE config timed inside the driver's run (extras.configs): `steps` products over a resident batch,
+    HIP events on the launch stream, in-run counter traffic -- the same quantities as the headline, for the shapes the
+    driver does not time itself."""
+    lb, n, nm, _ = WORKLOADS[workload]
+    eng = Engine(lb, n, nm, device=dev)
+    try:
+        a = eng.fill_uniform(eng.empty(batch), SEED, 0)
+        b = eng.fill_uniform(eng.empty(batch), SEED, 1)
+        c = eng.empty(batch)
+        for _ in range(2):
+            eng.polymul(a, b, out=c)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            eng.polymul(a, b, out=c)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        ok = not eng.any_neq(c, eng.polymul(b, a))
+        alg = 3 * nm * n * (lb // 8)
+        out = {"workload": "nfl::poly<uint%d_t,%d,%d> batched polymul (BASELINE configs %s)" % (lb, n, nm, workload), "batch": batch,
+               "steps": steps, "value": round(batch / (ms * 1e-3), 1), "unit": "polymul/s", "ms_per_step": round(ms, 4),
+               "achieved_GBs": round(alg * batch / (ms * 1e-3) / 1e9, 1), "frac": round(alg * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "algorithmic_bytes_per_polymul": alg, "self_check": bool(ok)}
+        if with_crt:
+            # BASELINE configs[4] is "CRT lift + poly-mul": GMP::poly2mpz (gmp.hpp:183-209) of the product, all coefficients
+            L = eng.crt_limbs
+            limbs = eng.crt_lift(c)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                eng.crt_lift(c)
+            e1.record()
+            torch.cuda.synchronize()
+            msl = e0.elapsed_time(e1) / steps
+            crt_bytes = nm * n * (lb // 8) + n * L * 8      # residues read + limbs written (SURVEY.md 8(d))
+            out["crt_lift"] = {"value": round(batch / (msl * 1e-3), 1), "unit": "polys/s", "ms_per_step": round(msl, 4),
+                               "achieved_GBs": round(crt_bytes * batch / (msl * 1e-3) / 1e9, 1),
+                               "frac": round(crt_bytes * batch / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_bytes_per_poly": crt_bytes, "limbs_per_coefficient": L}
+            del limbs
+        del a, b, c
+    finally:
+        eng.close()
+    tr, src = measure_traffic(workload, batch)
+    out["traffic_bytes_per_polymul"] = None if tr is None else round(tr / batch, 1)
+    out["traffic_ratio"] = None if tr is None else round(tr / batch / alg, 4)
+    out["traffic_source"] = src
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,10 +250,18 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.traffic)")
     ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: skip the world-size-1 RCCL initialisation")
+    ap.add_argument("--no-side-configs", action="store_true", help="workload B only: skip extras.configs (configs C and E timed in the same run)")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1 only: also time one step whose operands start on rank 0 and whose product returns there "
                          "(grouped RCCL send/recv of contiguous shards, SURVEY.md 8(e)); reported beside `value`, never in it")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): become the driver's launch line -- N ranks, one per GPU, under
+        # torch.distributed.run on 127.0.0.1 -- instead of quietly running one rank.  Refuses when the node has fewer devices.
+        sys.exit(self_launch(args.gpus))
 
     # stdout carries exactly ONE line, the result: libraries that print banners there (RCCL announces its version on
     # communicator creation) are sent to stderr for the whole run
@@ -374,6 +458,7 @@ def main():
 
     extras = None
     power = None
+    sustained = None
     if rank == 0 and world == 1 and not args.no_extras:
         # package power and shader clock UNDER the product kernel (the product kernels run at the package
         # power limit, so their clock -- not their schedule -- is what separates them from the issue bound): ~2.5 s of
@@ -381,8 +466,12 @@ def main():
         try:
             import subprocess
             t_step = dt / args.steps
-            for _ in range(max(8, min(20000, int(2.5 / max(t_step, 1e-6))))):
+            n_sus = max(8, min(20000, int(2.5 / max(t_step, 1e-6))))
+            sus0, sus1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sus0.record()
+            for _ in range(n_sus):
                 eng.polymul(a, b, out=c)
+            sus1.record()
             samples = []
             t_end = time.perf_counter() + 2.2
             while time.perf_counter() < t_end and len(samples) < 8:
@@ -396,6 +485,11 @@ def main():
                 if watts is not None:
                     samples.append((watts, mhz, cap))
             torch.cuda.synchronize()
+            sus_s = sus0.elapsed_time(sus1) * 1e-3
+            sustained = {"value": round(n_sus * batch / sus_s, 1), "unit": "polymul/s", "steps": n_sus, "seconds": round(sus_s, 3),
+                         "frac": round(n_sus * batch * 3 * nm * n * (lb // 8) / sus_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "how": "the same launch held for ~2.5 s (HIP events on the launch stream): the package settles at its power "
+                                "limit after the first ~0.1 s, which the K-step headline does not reach"}
             busy = [x for x in samples[1:] if x[0] > 0.5 * max(y[0] for y in samples)] or samples
             if busy:
                 power = {"package_W": round(sum(x[0] for x in busy) / len(busy), 1), "sclk_MHz": round(sum(x[1] for x in busy) / len(busy)),
@@ -472,6 +566,18 @@ def main():
             "note": "GB/s are algorithmic bytes (SURVEY.md 8(d)) / event time; polys per second over the same batch",
         }
         del bn, limbs
+        # the other single-GPU BASELINE configs, timed inside this same run (driver-visible, not builder-only): configs[2]
+        # (C) and configs[4] (E: "CRT lift + poly-mul"); the headline's own tensors are released first
+        if args.workload == "B" and not args.no_side_configs:
+            del a, b, c
+            torch.cuda.empty_cache()
+            side = {}
+            for wl, sb, st_, crt in (("C", 1024, 10, False), ("E", 32, 10, True)):
+                try:
+                    side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt)
+                except Exception as ex:   # reported, never fatal
+                    side[wl] = {"error": repr(ex)}
+            extras["configs"] = side
 
     result = {
         "metric": "poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli" if args.workload == "B"
@@ -493,30 +599,43 @@ def main():
                                 "G": "nflhip_polymul8192_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
-    # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue AT THE CLOCK THE KERNEL GETS.
+    # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  `peak` / `frac` are the
+    # HARDWARE ceiling and do not depend on this kernel or this run: one wave64 VALU instruction per SIMD every 2 cycles
+    # (MI355X_MICROARCH.md) at the nominal 2.4 GHz, 256 CUs x 4 SIMDs = 1 228.8 G wave-instructions/s.  Two tighter, still
+    # kernel-independent prices ride along: `opcode_grid` = the isolated issue costs of tools/ubench_issue.hip (multiply /
+    # carry / VOP3 opcodes 4.2 cycles, plain VOP2 2.5: the 62-bit butterfly's 10 + 8 mix = 62 cycles per 18 instructions) at
+    # 2.4 GHz; and `model` = the FITTED figure of earlier rounds (3.86 cycles per instruction, the butterfly stream's own
+    # measured cost, at the clock this run got under the 1 400 W package limit) -- by construction close to 1, kept only as
+    # a consistency check of the instruction counts.
     # Instructions per product: dynamic counts of the generated kernels on the interpreter of tests/asm_emu.py
-    # (tools/asm_cost.py -> profiles/r03_valu_issue_model.txt; B and A agree with their SQ counter passes).  Issue cost of
-    # the mix: isolated streams price multiply / carry / VOP3 opcodes at 4.2 and plain VOP2 ones at 2.5 cycles per wave64
-    # (profiles/r03_ubench_issue.txt: the 18-instruction 62-bit butterfly 69.5 cycles = 3.86 per instruction); the metric
-    # kernel needs 3.7 - 3.9 cycles per instruction in situ (GRBM_GUI_ACTIVE per launch, profiles/r03_operand_ab.txt).  Clock:
-    # these kernels run at the 1 400 W package limit, sclk ~ 2.0 GHz sustained against 2.4 nominal
-    # (profiles/r03_power_clock.txt) -- the peak below is priced at 2.0 GHz.
+    # (tools/asm_cost.py -> profiles/r03_valu_issue_model.txt; B and A agree with their SQ counter passes).
     model = "profiles/r03_valu_issue_model.txt"
     valu = {"B": (96464, 1), "A": (2081, nm), "G": (103856, 1), "C": (888192, 1), "F": (478144, 1),
             "E": (15115680, 1), "H": (227, 1), "T": (13, 1)}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]
+        nominal_ghz = 2.4
+        peak_hw = 256 * 4 * nominal_ghz / 2.0            # G wave64-instructions/s
+        ach_gi = inst_per_poly * batch / (kernel_ms * 1e-3) / 1e9
+        sec = {"bound": "valu-issue", "achieved": round(ach_gi, 1), "peak": round(peak_hw, 1), "unit": "G wave64-inst/s",
+               "frac": round(ach_gi / peak_hw, 4), "peak_is": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+               "wave_instructions_per_polymul": inst_per_poly}
+        if lb == 64:
+            grid_cpi = (10 * 4.2 + 8 * 2.5) / 18.0
+            peak_grid = 256 * 4 * nominal_ghz / grid_cpi
+            sec["opcode_grid"] = {"peak": round(peak_grid, 1), "frac": round(ach_gi / peak_grid, 4), "cycles_per_instruction": round(grid_cpi, 3),
+                                  "clock_GHz": nominal_ghz, "source": "profiles/r03_ubench_issue.txt (isolated streams, all-VGPR operands)"}
         clock_ghz, cyc_per_inst = 2.0, 3.86
         if power and power.get("sclk_MHz"):
             clock_ghz = round(power["sclk_MHz"] / 1000.0, 3)    # the clock THIS run's kernel got (sampled above)
-        peak_gi = 256 * 4 * clock_ghz / cyc_per_inst   # G wave-instructions/s
-        ach_gi = inst_per_poly * batch / (kernel_ms * 1e-3) / 1e9
-        result["roofline"]["secondary"] = {"bound": "valu-issue at the 1400 W package limit", "achieved": round(ach_gi, 1),
-                                           "peak": round(peak_gi, 1), "unit": "G wave64-inst/s", "frac": round(ach_gi / peak_gi, 4),
-                                           "wave_instructions_per_polymul": inst_per_poly, "clock_GHz": clock_ghz,
-                                           "cycles_per_instruction": cyc_per_inst, "power": power,
-                                           "source": model + ", profiles/r03_ubench_issue.txt, profiles/r03_power_clock.txt, "
-                                                     "profiles/r03_operand_ab.txt"}
+        peak_fit = 256 * 4 * clock_ghz / cyc_per_inst
+        sec["model"] = {"kind": "fitted", "peak_at_measured_clock": round(peak_fit, 1), "frac": round(ach_gi / peak_fit, 4),
+                        "clock_GHz": clock_ghz, "cycles_per_instruction": cyc_per_inst,
+                        "source": model + ", profiles/r03_ubench_issue.txt, profiles/r03_power_clock.txt, profiles/r03_operand_ab.txt"}
+        sec["power"] = power
+        result["roofline"]["secondary"] = sec
+    if sustained is not None:
+        result["sustained"] = sustained
     if extras is not None:
         result["extras"] = extras
     if scatter is not None:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NFLHIP_ABI_VERSION 3
+#define NFLHIP_ABI_VERSION 4
 
 typedef struct nflhip_ctx nflhip_ctx;
 
@@ -193,6 +193,45 @@ int nflhip_polymul(nflhip_ctx *ctx, void *h_c, const void *h_a, const void *h_b,
 int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const void *d_bntt, size_t batch,
                            void *stream);
 
+/* ---- transform-fused pipelines ------------------------------------------------------
+ * What the reference's callers run AROUND the transforms, as one device pass per batch.  The reference's only
+ * end-to-end ring code is the LWE demo (tests/nfllib_demo_main_op.cpp:26-58):
+ *   encrypt():  u.ntt_pow_phi(); e1.ntt_pow_phi(); e2.ntt_pow_phi(); resa = u * pka + e1; resb = u * pkb + e2;
+ *   decrypt():  tmp = resb - resa * s; tmp.invntt_pow_invphi();
+ * (poly.hpp:167-168 + the evaluation loop core.hpp:24-37).  Run operator by operator that is 8 + 2 launches and ~17 + 5
+ * polynomial passes over HBM; here the transformed operands never leave the registers of the workgroup that owns the row:
+ *   nflhip_fwd_fma_dev    out  = NTT(x) * k + NTT(e)
+ *   nflhip_fwd_fma2_dev   out0 = NTT(x) * k0 + NTT(e0),  out1 = NTT(x) * k1 + NTT(e1)       (x is transformed once)
+ *   nflhip_fma_inv_dev    out  = INTT(b + a * k)   or   INTT(b - a * k)  (subtract != 0)
+ * Results are bit-identical to the operator-by-operator sequence.  Every operand names its own stride (in polynomials
+ * from one batch element to the next: 1 = dense array, 0 = ONE polynomial for the whole batch -- a key) and, for the
+ * inputs of the forward entries, its format: NFLHIP_FMT_WORDS = residue words [nmoduli][degree] in coefficient form, or
+ * one SIGNED integer per coefficient shared by all moduli (int8 / int16 / int32; v < 0 stands for p + v; |v| must be
+ * below every modulus) -- what the samplers produce before they spread a value over the moduli (core.hpp:230-277); see
+ * nflhip_sample_gauss_small_dev.  k operands and the operands of nflhip_fma_inv_dev are words in NTT form (canonical,
+ * ops.hpp:131,211).  Results are dense; a result may alias a dense input of the same call.  u64 limbs at degree 4096
+ * run one generated gfx950 kernel per call; every other shape composes the same result from the plain kernels through
+ * the context's scratch (calls on different streams of one context are then ordered by events, as for nflhip_polymul_dev). */
+#define NFLHIP_FMT_WORDS 0
+#define NFLHIP_FMT_I8 1
+#define NFLHIP_FMT_I16 2
+#define NFLHIP_FMT_I32 3
+typedef struct nflhip_operand {
+  const void *ptr; /* device pointer */
+  size_t stride;   /* polynomials (of the operand's own format) between consecutive batch elements */
+  int format;      /* NFLHIP_FMT_* */
+} nflhip_operand;
+int nflhip_fwd_fma_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *x, const nflhip_operand *k,
+                       const nflhip_operand *e, size_t batch, void *stream);
+int nflhip_fwd_fma2_dev(nflhip_ctx *ctx, void *d_out0, void *d_out1, const nflhip_operand *x, const nflhip_operand *k0,
+                        const nflhip_operand *e0, const nflhip_operand *k1, const nflhip_operand *e1, size_t batch,
+                        void *stream);
+int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, const nflhip_operand *k,
+                       const nflhip_operand *b, int subtract, size_t batch, void *stream);
+/* compact polynomial(s) -> residue words: d_data[b][cm][i] = v < 0 ? p_cm + v : v, v = element i of src's polynomial
+ * b * stride (format NFLHIP_FMT_WORDS: a strided gather of word rows) */
+int nflhip_expand_small_dev(nflhip_ctx *ctx, void *d_data, const nflhip_operand *src, size_t batch, void *stream);
+
 /* ---- comparisons: expr::operator bool over eqmod / neqmod (ops.hpp:81-117) ----
  * *result = 1 iff ANY word of a equals (any_eq) / differs from (any_neq) the
  * matching word of b -- the reference's semantics for `a == b` / `a != b`.
@@ -294,6 +333,17 @@ int nflhip_sample_gauss(nflhip_ctx *ctx, void *h_data, size_t batch, const nflhi
 int nflhip_sample_gauss_seq_dev(nflhip_ctx *ctx, void *d_data, size_t batch, const nflhip_gauss *g, uint64_t amplifier,
                                 const unsigned char key[32], uint64_t first_stream_id, uint64_t stream_id_stride,
                                 void *stream);
+/* COMPACT forms (format NFLHIP_FMT_I8 / I16 / I32): d_out[b][i] = x * amplifier as ONE signed integer per coefficient,
+ * x exactly the sample nflhip_sample_gauss_dev / nflhip_sample_gauss_seq_dev would spread over the moduli for the same
+ * arguments -- so nflhip_expand_small_dev (or the forward entries above, which expand in their prologue) reproduce those
+ * calls' words bit for bit at 1/32 (int8, 4 moduli of 64 bits) of the bytes.  NFLHIP_ERR_INVALID when a possible sample
+ * does not fit the format or is not below every modulus. */
+int nflhip_sample_gauss_small_dev(nflhip_ctx *ctx, void *d_out, int format, size_t first_poly, size_t batch,
+                                  const nflhip_gauss *g, uint64_t amplifier, const unsigned char key[32], uint64_t stream_id,
+                                  void *stream);
+int nflhip_sample_gauss_small_seq_dev(nflhip_ctx *ctx, void *d_out, int format, size_t batch, const nflhip_gauss *g,
+                                      uint64_t amplifier, const unsigned char key[32], uint64_t first_stream_id,
+                                      uint64_t stream_id_stride, void *stream);
 /* FastGaussianNoise::getNoise(out, rlen) (FastGaussianNoise.hpp:477-595): `count` raw signed samples; sample j is the
  * integer that coefficient first_sample + j of a polynomial batch gets from the same (key, stream_id) */
 int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sample, size_t count, const nflhip_gauss *g,

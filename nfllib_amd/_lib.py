@@ -16,7 +16,8 @@ TAB_PSI, TAB_MODULUS, TAB_INVDEGREE = range(3)
 TAB_PHIS, TAB_SHOUPPHIS, TAB_INVPOLY_INVPHIS, TAB_SHOUPINVPOLY_INVPHIS, TAB_OMEGAS, TAB_INVOMEGAS = range(3, 9)
 ROW_INVERSE_TABLES, ROW_BITREV_IO = 1, 2
 DIST_REFERENCE_WORDS = 0x100
-ABI_VERSION = 3
+ABI_VERSION = 4
+FMT_WORDS, FMT_I8, FMT_I16, FMT_I32 = range(4)
 
 # every symbol include/nflhip.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
@@ -46,6 +47,10 @@ SYMBOLS = [
     ("nflhip_polymul_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     ("nflhip_polymul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("nflhip_polymul_ntt_dev", _i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_fwd_fma_dev", _i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_fwd_fma2_dev", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_fma_inv_dev", _i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
+    ("nflhip_expand_small_dev", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("nflhip_any_eq_dev", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i), _vp]),
     ("nflhip_any_neq_dev", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i), _vp]),
     ("nflhip_any_eq", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i)]),
@@ -68,6 +73,8 @@ SYMBOLS = [
                                C.POINTER(C.c_double), _vp]),
     ("nflhip_sample_gauss_dev", _i, [_vp, _vp, _sz, _sz, _vp, _u64, _vp, _u64, _vp]),
     ("nflhip_sample_gauss", _i, [_vp, _vp, _sz, _vp, _u64, _vp, _u64]),
+    ("nflhip_sample_gauss_small_dev", _i, [_vp, _vp, _i, _sz, _sz, _vp, _u64, _vp, _u64, _vp]),
+    ("nflhip_sample_gauss_small_seq_dev", _i, [_vp, _vp, _i, _sz, _vp, _u64, _vp, _u64, _u64, _vp]),
     ("nflhip_gauss_noise_dev", _i, [_vp, _vp, _u64, _sz, _vp, _vp, _u64, _vp]),
     ("nflhip_gauss_noise", _i, [_vp, _vp, _sz, _vp, _vp, _u64]),
     ("nflhip_malloc", _i, [_vp, C.POINTER(_vp), _sz]),
@@ -101,6 +108,11 @@ SYMBOLS = [
     ("nflhip_comm_allgather_u64", _i, [_vp, _u64, C.POINTER(_u64), _vp]),
 ]
 COMM_ID_BYTES = 128
+
+
+class Operand(C.Structure):
+    """nflhip_operand: device pointer, stride in polynomials (0 = one polynomial for the whole batch), NFLHIP_FMT_*"""
+    _fields_ = [("ptr", C.c_void_p), ("stride", C.c_size_t), ("format", C.c_int)]
 
 
 class NflHipError(RuntimeError):

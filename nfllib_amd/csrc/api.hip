@@ -961,6 +961,141 @@ int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *c, const void *a, const void *
   return polymul_any(ctx, c, a, bntt, 1, batch, stream);
 }
 
+// ---------------------------------------------------------------------------
+// transform-fused pipelines
+// ---------------------------------------------------------------------------
+static int check_operand(const nflhip_ctx *ctx, const nflhip_operand *o, size_t batch, bool words_only, const char *what) {
+  if (!o || (batch && !o->ptr)) return fail(ctx, NFLHIP_ERR_INVALID, std::string("NULL operand: ") + what);
+  if (o->format < NFLHIP_FMT_WORDS || o->format > NFLHIP_FMT_I32 || (words_only && o->format != NFLHIP_FMT_WORDS))
+    return fail(ctx, NFLHIP_ERR_INVALID, std::string("operand format: ") + what);
+  if (o->stride > 0xffffffffu || (batch > 1 && (uint64_t)o->stride * (batch - 1) > 0xffffffffull))
+    return fail(ctx, NFLHIP_ERR_INVALID, std::string("operand stride out of range: ") + what);
+  return NFLHIP_OK;
+}
+
+static hipError_t expand_any(nflhip_ctx *ctx, void *dst, const nflhip_operand *src, size_t batch, hipStream_t st) {
+  return DISPATCH_T(ctx, launch_expand_small<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)dst, src->ptr, src->format, (unsigned)src->stride, batch, st),
+                    launch_expand_small<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)dst, src->ptr, src->format, (unsigned)src->stride, batch, st),
+                    launch_expand_small<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)dst, src->ptr, src->format, (unsigned)src->stride, batch, st));
+}
+
+static int fused_fwd_composed(nflhip_ctx *ctx, void *out0, void *out1, const nflhip_operand *x, const nflhip_operand *k0,
+                              const nflhip_operand *e0, const nflhip_operand *k1, const nflhip_operand *e1, size_t batch,
+                              hipStream_t st) {
+  // the same result from the plain kernels: expand / gather into the context's scratch, transform there, one fused
+  // multiply-add pass per result (what serves every shape without a generated kernel, and NFLHIP_VARIANT=hipcc)
+  const size_t bytes = poly_bytes(ctx, batch);
+  std::unique_lock<std::mutex> lk(ctx->scratch_mu);
+  const bool cap = is_capturing(st);
+  int rc = ensure_scratch(ctx, 2 * bytes);
+  if (rc) return rc;
+  if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+  if (!cap && ctx->ev_prev_valid)
+    for (int j = 0; j < 2; ++j) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[j], 0));
+  void *s0 = ctx->scratch, *s1 = (char *)ctx->scratch + bytes;
+  static const unsigned char prog[5] = {0, 1, NFLHIP_EXPR_MUL, 2, NFLHIP_EXPR_ADD};
+  hipError_t e = expand_any(ctx, s0, x, batch, st);
+  if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
+  rc = nflhip_ntt_fwd_dev(ctx, s0, batch, st);
+  if (rc) return rc;
+  for (int h = 0; h < (out1 ? 2 : 1); ++h) {
+    const nflhip_operand *kk = h ? k1 : k0, *ee = h ? e1 : e0;
+    e = expand_any(ctx, s1, ee, batch, st);
+    if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
+    rc = nflhip_ntt_fwd_dev(ctx, s1, batch, st);
+    if (rc) return rc;
+    const void *ops[3] = {s0, kk->ptr, s1};
+    const unsigned sd[3] = {1, (unsigned)kk->stride, 1};
+    rc = eval_dev(ctx, h ? out1 : out0, ops, 3, prog, sizeof(prog), batch, st, sd, 1);
+    if (rc) return rc;
+  }
+  if (!cap) {  // the scratch is reused by the next call on any stream: order it after this one
+    HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
+    ctx->ev_scratch_valid = true;
+    for (int j = 0; j < 2; ++j)
+      if (ctx->aux[j]) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[j], ctx->ev_scratch, 0));
+  }
+  return NFLHIP_OK;
+}
+
+static int fused_fwd_any(nflhip_ctx *ctx, void *out0, void *out1, const nflhip_operand *x, const nflhip_operand *k0,
+                         const nflhip_operand *e0, const nflhip_operand *k1, const nflhip_operand *e1, size_t batch,
+                         void *stream) {
+  CHECK_CTX(ctx);
+  const bool two = k1 != nullptr;
+  if (batch && (!out0 || (two && !out1))) return fail(ctx, NFLHIP_ERR_INVALID, "NULL result pointer");
+  int rc = check_operand(ctx, x, batch, false, "x");
+  if (!rc) rc = check_operand(ctx, k0, batch, true, "k0");
+  if (!rc) rc = check_operand(ctx, e0, batch, false, "e0");
+  if (!rc && two) rc = check_operand(ctx, k1, batch, true, "k1");
+  if (!rc && two) rc = check_operand(ctx, e1, batch, false, "e1");
+  if (rc) return rc;
+  if (batch == 0) return NFLHIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (ctx->shape.limb_bits == 64) {
+    const void *xs[3] = {x->ptr, e0->ptr, two ? e1->ptr : nullptr};
+    const unsigned xstr[3] = {(unsigned)x->stride, (unsigned)e0->stride, two ? (unsigned)e1->stride : 0u};
+    const int xf[3] = {x->format, e0->format, two ? e1->format : 0};
+    const void *ks[2] = {k0->ptr, two ? k1->ptr : nullptr};
+    const unsigned kstr[2] = {(unsigned)k0->stride, two ? (unsigned)k1->stride : 0u};
+    hipError_t e = launch_fused_asm_u64(ctx->shape, ctx->tabs, two ? 0 : 1, (uint64_t *)out0, (uint64_t *)out1, xs, xstr, xf, ks, kstr,
+                                        batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "fwd_fma(fused)");
+  }
+  return fused_fwd_composed(ctx, out0, out1, x, k0, e0, k1, e1, batch, st);
+}
+
+int nflhip_fwd_fma_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *x, const nflhip_operand *k, const nflhip_operand *e,
+                       size_t batch, void *stream) {
+  return fused_fwd_any(ctx, d_out, nullptr, x, k, e, nullptr, nullptr, batch, stream);
+}
+
+int nflhip_fwd_fma2_dev(nflhip_ctx *ctx, void *d_out0, void *d_out1, const nflhip_operand *x, const nflhip_operand *k0,
+                        const nflhip_operand *e0, const nflhip_operand *k1, const nflhip_operand *e1, size_t batch, void *stream) {
+  if (!k1 || !e1) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
+  return fused_fwd_any(ctx, d_out0, d_out1, x, k0, e0, k1, e1, batch, stream);
+}
+
+int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, const nflhip_operand *k, const nflhip_operand *b,
+                       int subtract, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (batch && !d_out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL result pointer");
+  int rc = check_operand(ctx, a, batch, true, "a");
+  if (!rc) rc = check_operand(ctx, k, batch, true, "k");
+  if (!rc) rc = check_operand(ctx, b, batch, true, "b");
+  if (rc) return rc;
+  if (batch == 0) return NFLHIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (ctx->shape.limb_bits == 64) {
+    const void *xs[3] = {a->ptr, b->ptr, nullptr};
+    const unsigned xstr[3] = {(unsigned)a->stride, (unsigned)b->stride, 0u};
+    const int xf[3] = {0, 0, 0};
+    const void *ks[2] = {k->ptr, nullptr};
+    const unsigned kstr[2] = {(unsigned)k->stride, 0u};
+    hipError_t e = launch_fused_asm_u64(ctx->shape, ctx->tabs, subtract ? 2 : 3, (uint64_t *)d_out, nullptr, xs, xstr, xf, ks, kstr, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "fma_inv(fused)");
+  }
+  // composed: one fused multiply-add / -subtract pass into the result, inverse transform in place
+  const unsigned char prog[5] = {0, 1, 2, NFLHIP_EXPR_MUL, (unsigned char)(subtract ? NFLHIP_EXPR_SUB : NFLHIP_EXPR_ADD)};
+  const void *ops[3] = {b->ptr, a->ptr, k->ptr};
+  const unsigned sd[3] = {(unsigned)b->stride, (unsigned)a->stride, (unsigned)k->stride};
+  rc = eval_dev(ctx, d_out, ops, 3, prog, sizeof(prog), batch, stream, sd, 1);
+  if (rc) return rc;
+  return nflhip_ntt_inv_dev(ctx, d_out, batch, stream);
+}
+
+int nflhip_expand_small_dev(nflhip_ctx *ctx, void *d_data, const nflhip_operand *src, size_t batch, void *stream) {
+  CHECK_CTX(ctx);
+  if (batch && !d_data) return fail(ctx, NFLHIP_ERR_INVALID, "NULL result pointer");
+  int rc = check_operand(ctx, src, batch, false, "src");
+  if (rc) return rc;
+  hipError_t e = expand_any(ctx, d_data, src, batch, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(ctx, e, "expand_small");
+  return NFLHIP_OK;
+}
+
 static int any_cmp_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int want_eq, int *result, void *stream) {
   CHECK_CTX(ctx);
   if (!result || (batch && (!a || !b))) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
@@ -1194,6 +1329,40 @@ int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t 
       launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st));
   if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss");
   return NFLHIP_OK;
+}
+
+static int gauss_small_any(nflhip_ctx *ctx, void *d_out, int format, size_t first_poly, size_t batch, const nflhip_gauss *g,
+                           uint64_t amplifier, const unsigned char *key, uint64_t stream_id, void *stream, int seq_on,
+                           uint64_t seq_stride) {
+  CHECK_CTX(ctx);
+  if (!key || !g || (batch && !d_out)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (g->device != ctx->device) return fail(ctx, NFLHIP_ERR_INVALID, "gaussian table lives on another device");
+  if (amplifier == 0) return fail(ctx, NFLHIP_ERR_INVALID, "amplifier must be positive");
+  if (format < NFLHIP_FMT_I8 || format > NFLHIP_FMT_I32) return fail(ctx, NFLHIP_ERR_INVALID, "the compact format is int8, int16 or int32");
+  // every sample x * amplifier must fit the format and stay below every modulus (so that p + v is its residue)
+  const long long lo = g->tab.x_min, hi = g->tab.x_min + (long long)g->tab.entries - 1;
+  const uint64_t mag = (uint64_t)std::max(lo < 0 ? -lo : lo, hi < 0 ? -hi : hi);
+  const uint64_t cap = format == NFLHIP_FMT_I8 ? 127u : format == NFLHIP_FMT_I16 ? 32767u : 2147483647u;
+  if (amplifier > cap || mag > cap / amplifier) return fail(ctx, NFLHIP_ERR_INVALID, "the samples do not fit the compact format");
+  for (uint64_t p : ctx->h_P)
+    if (mag * amplifier >= p) return fail(ctx, NFLHIP_ERR_INVALID, "the samples are not below the modulus");
+  hipError_t e = launch_gauss_small(ctx->shape, d_out, format, first_poly, batch, g->d_cdt, g->tab.words, (int)g->tab.entries,
+                                    g->tab.x_min, amplifier, key, stream_id, (hipStream_t)stream, seq_on, seq_stride);
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8");
+  if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss_small");
+  return NFLHIP_OK;
+}
+
+int nflhip_sample_gauss_small_dev(nflhip_ctx *ctx, void *d_out, int format, size_t first_poly, size_t batch,
+                                  const nflhip_gauss *g, uint64_t amplifier, const unsigned char *key, uint64_t stream_id,
+                                  void *stream) {
+  return gauss_small_any(ctx, d_out, format, first_poly, batch, g, amplifier, key, stream_id, stream, 0, 0);
+}
+
+int nflhip_sample_gauss_small_seq_dev(nflhip_ctx *ctx, void *d_out, int format, size_t batch, const nflhip_gauss *g,
+                                      uint64_t amplifier, const unsigned char *key, uint64_t first_stream_id,
+                                      uint64_t stream_id_stride, void *stream) {
+  return gauss_small_any(ctx, d_out, format, 0, batch, g, amplifier, key, first_stream_id, stream, 1, stream_id_stride);
 }
 
 int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sample, size_t count, const nflhip_gauss *g,

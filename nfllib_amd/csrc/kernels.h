@@ -119,6 +119,22 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
                                const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on = 0,
                                uint64_t seq_stride = 0);
 
+// compact Gaussian polynomials (one signed integer x * amp per coefficient; format 1 int8 | 2 int16 | 3 int32) and their
+// expansion into residue words (format 0 = word rows: a strided gather); stride in polynomials, 0 = shared
+hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_poly, size_t batch, const uint64_t *cdt,
+                              int words, int entries, long long x_min, uint64_t amp, const unsigned char *key32,
+                              uint64_t stream_id, hipStream_t st, int seq_on = 0, uint64_t seq_stride = 0);
+template <typename T>
+hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const void *src, int format, unsigned stride,
+                               size_t batch, hipStream_t st);
+
+// transform-fused pipelines at n = 4096, 64-bit limbs (tools/gen_polymul_asm.py build_fused): kind 0 enc2 | 1 fma_fwd |
+// 2 fms_inv | 3 fma_inv; x: up to three operands with their formats (forward kinds) and strides, k: key rows with strides.
+// hipErrorNotSupported for other shapes / the compiled-only variant (api.hip composes the same result from the plain kernels)
+hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, uint64_t *out0, uint64_t *out1,
+                                const void *const *x, const unsigned *xstride, const int *xfmt, const void *const *k,
+                                const unsigned *kstride, size_t batch, hipStream_t st);
+
 // ---- fast paths (kernels_fast.hip); return hipErrorNotSupported when the shape has none ----
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                    int b_is_ntt, size_t batch, hipStream_t st);

@@ -349,6 +349,7 @@ enum AsmKind {
   kAsmRowInv1024U32, kAsmRowInv2048U32, kAsmRowInv4096U32,                                               // 32-bit limbs
   kAsmRow8U32, kAsmRowNtt8U32, kAsmRowFwd8U32, kAsmRowInv8U32,       // 32-bit limbs, n = 8: one lane per row
   kAsmRow128U16, kAsmRowNtt128U16, kAsmRowFwd128U16, kAsmRowInv128U16,   // 16-bit limbs
+  kAsmFusedEnc2, kAsmFusedFmaFwd, kAsmFusedFmsInv, kAsmFusedFmaInv,      // transform-fused pipelines, n = 4096 (build_fused)
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -367,7 +368,8 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_row1024_u32_asm", "nflhip_row2048_u32_asm", "nflhip_row4096_u32_asm", "nflhip_row1024_fwd_u32_asm", "nflhip_row2048_fwd_u32_asm", "nflhip_row4096_fwd_u32_asm",
     "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm",
     "nflhip_row8_u32_asm", "nflhip_row8_ntt_u32_asm", "nflhip_row8_fwd_u32_asm", "nflhip_row8_inv_u32_asm",
-    "nflhip_row128_u16_asm", "nflhip_row128_ntt_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm"};
+    "nflhip_row128_u16_asm", "nflhip_row128_ntt_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm",
+    "nflhip_fused_enc2_4096_asm", "nflhip_fused_fma_fwd4096_asm", "nflhip_fused_fms_inv4096_asm", "nflhip_fused_fma_inv4096_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -444,6 +446,50 @@ static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t
   size_t size = 52;
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   return hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), (unsigned)s.nm, 1, k16 ? 1024 : k8 ? 512 : kThreads, 1, 1, 0, st, nullptr, extra);
+}
+
+// transform-fused pipelines (tools/gen_polymul_asm.py build_fused, kernarg ARGS_FUSED): one 256-thread workgroup per
+// (batch element, modulus); the intermediate polynomials of `x.ntt_pow_phi(); r = x * k + e` / `(b - a * s).invntt_pow_invphi()`
+// (tests/nfllib_demo_main_op.cpp:26-58) never reach HBM
+hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, uint64_t *out0, uint64_t *out1,
+                                const void *const *x, const unsigned *xstride, const int *xfmt, const void *const *k,
+                                const unsigned *kstride, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn != kLogN || s.compiled_only || !s.small_delta || s.nm > 65535 || kind < 0 || kind > 3)
+    return hipErrorNotSupported;
+  if (batch == 0) return hipSuccess;
+  if (batch > 0x7fffffffull) return hipErrorInvalidValue;
+  hipFunction_t fn = asm_fn((AsmKind)(kAsmFusedEnc2 + kind));
+  if (!fn) return hipErrorNotSupported;
+  const int nx = kind == 0 ? 3 : 2, nk = kind == 0 ? 2 : 1;
+  struct {
+    void *out0, *out1;
+    const void *x[3], *k[2], *psi, *mc;
+    int nm, logn, fmt;
+    unsigned sx[3], sk[2], so[2];
+  } args = {};
+  static_assert(sizeof(args) == 112, "kernarg layout of nflhip_fused_*_asm (ARGS_FUSED)");
+  args.out0 = out0;
+  args.out1 = out1;
+  for (int i = 0; i < nx; ++i) {
+    // (the stride multiplies the batch index in 32 bits inside the kernel)
+    if ((uint64_t)xstride[i] * (batch - 1) > 0xffffffffull || xfmt[i] < 0 || xfmt[i] > 3 || (kind >= 2 && xfmt[i])) return hipErrorInvalidValue;
+    args.x[i] = x[i];
+    args.sx[i] = xstride[i];
+    args.fmt |= xfmt[i] << (4 * i);
+  }
+  for (int i = 0; i < nk; ++i) {
+    if ((uint64_t)kstride[i] * (batch - 1) > 0xffffffffull) return hipErrorInvalidValue;
+    args.k[i] = k[i];
+    args.sk[i] = kstride[i];
+  }
+  args.psi = t.psi;
+  args.mc = t.mc;
+  args.nm = (int)s.nm;
+  args.logn = s.logn;
+  args.so[0] = args.so[1] = 1;
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
 
 // n = 65536: one launch of the three-role kernel (tools/gen_polymul_asm.py build_pipe): fused block products of `cnt_v`

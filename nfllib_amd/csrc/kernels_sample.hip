@@ -10,6 +10,7 @@
 #include <atomic>
 
 #include "kernels.h"
+#include <type_traits>
 #include "modarith.h"
 
 namespace nflhip {
@@ -330,6 +331,44 @@ __device__ __forceinline__ int gauss_search(const uint64_t r0, uint64_t g, const
   return lo;
 }
 
+// Eight searches side by side over the table's FIRST words held in LDS (`top`, one word per entry; the launchers stage
+// it when the table has at most kGaussLdsEntries entries): a fixed number of branch-free steps (iters = ceil(log2
+// entries)), so the eight dependent chains interleave and no step waits for global memory.  A step whose first words tie
+// (probability entries * 2^-64 per sample; under the tie_shift test hook: often) marks the sample, which is then redone by
+// the exact search above -- the result is the full-precision inversion either way.
+constexpr int kGaussLdsEntries = 4096;
+template <int W>
+__device__ __forceinline__ void gauss_search8(const uint64_t (&w)[8], uint64_t g0, const uint64_t *top,
+                                              const uint64_t *__restrict__ cdt, int entries, int iters, int tie_shift,
+                                              const ChaChaKey &key, uint64_t nc, int (&out)[8]) {
+  int lo[8], hi[8];
+  unsigned tied = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) lo[c] = 0, hi[c] = entries - 1;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int mid = (lo[c] + hi[c]) >> 1;
+      const uint64_t es = top[mid] >> tie_shift, rs = w[c] >> tie_shift;
+      const bool open = lo[c] < hi[c], less = rs < es;
+      tied |= (open && rs == es && (W > 1 || tie_shift)) ? (1u << c) : 0u;
+      hi[c] = (open && less) ? mid : hi[c];
+      lo[c] = (open && !less) ? mid + 1 : lo[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) out[c] = lo[c];
+  if (tied) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (tied & (1u << c)) out[c] = gauss_search<W>(w[c], g0 + c, cdt, entries, tie_shift, key, nc);
+  }
+}
+__device__ __forceinline__ void stage_gauss_top(uint64_t *top, const uint64_t *__restrict__ cdt, int entries, int W) {
+  for (int k = threadIdx.x; k < entries; k += blockDim.x) top[k] = cdt[(size_t)k * W];
+  __syncthreads();
+}
+
 template <typename T, int W>
 __global__ void k_sample_gauss(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_coef,
                                size_t ncoef, const uint64_t *__restrict__ cdt, int entries, long long x_min, uint64_t amp,
@@ -354,9 +393,11 @@ template <typename T, int W>
 __global__ void __launch_bounds__(256) k_sample_gauss8(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm,
                                                        uint64_t first_coef, size_t ncoef,
                                                        const uint64_t *__restrict__ cdt, int entries, long long x_min,
-                                                       uint64_t amp, ChaChaKey key, uint64_t nonce, int tie_shift) {
+                                                       uint64_t amp, ChaChaKey key, uint64_t nonce, int tie_shift, int iters) {
   constexpr int S = kTS;
   __shared__ int xs[4][8 * S];
+  extern __shared__ uint64_t gtop[];   // the table's first words (iters > 0)
+  if (iters) stage_gauss_top(gtop, cdt, entries, W);
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 3;  // first_coef and ncoef are multiples of 8 (n >= 8)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -371,9 +412,16 @@ __global__ void __launch_bounds__(256) k_sample_gauss8(T *d, const ModConst<T> *
       }
       uint64_t w[8];
       chacha20_block(key, g0 >> 3, nc, w);
+      if (iters) {
+        int r[8];
+        gauss_search8<W>(w, g0, gtop, cdt, entries, iters, tie_shift, key, nc, r);
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        xs[wv][c * S + lane] = gauss_search<W>(w[c], g0 + c, cdt, entries, tie_shift, key, nc);
+        for (int c = 0; c < 8; ++c) xs[wv][c * S + lane] = r[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          xs[wv][c * S + lane] = gauss_search<W>(w[c], g0 + c, cdt, entries, tie_shift, key, nc);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -394,6 +442,93 @@ __global__ void __launch_bounds__(256) k_sample_gauss8(T *d, const ModConst<T> *
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---- compact Gaussian polynomials: ONE signed integer per coefficient (x * amplifier) instead of nm residue words.
+// Coefficient g gets exactly the integer k_sample_gauss / k_sample_gauss8 spread over the moduli from the same
+// (key, stream id), so expanding the compact form (v < 0 ? p + v : v, k_expand_small below or the transform-fused
+// kernels' own prologue) reproduces nflhip_sample_gauss_dev's words bit for bit.  S = int8_t / int16_t / int32_t; the
+// launcher checks that every possible sample fits.
+template <typename S, int W>
+__global__ void __launch_bounds__(256) k_gauss_small8(S *d, int logn, uint64_t first_coef, size_t ncoef,
+                                                      const uint64_t *__restrict__ cdt, int entries, long long x_min,
+                                                      long long amp, ChaChaKey key, uint64_t nonce, int tie_shift, int iters) {
+  // a thread's keystream block = eight CONSECUTIVE coefficients = 8 / 16 / 32 contiguous bytes of the compact row: packed
+  // and stored by the thread itself (a wave store covers 512 consecutive coefficients; no transpose)
+  extern __shared__ uint64_t gtop[];
+  if (iters) stage_gauss_top(gtop, cdt, entries, W);
+  const uint64_t n = ((uint64_t)1) << logn;
+  const size_t ngroups = ncoef >> 3;  // first_coef and ncoef are multiples of 8 (n >= 8)
+  for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += (size_t)gridDim.x * blockDim.x) {
+    uint64_t g0 = first_coef + (grp << 3), nc = nonce;
+    if (key.seq_on) {
+      nc += (g0 >> logn) * key.seq_stride;
+      g0 &= n - 1;
+    }
+    uint64_t w[8];
+    chacha20_block(key, g0 >> 3, nc, w);
+    int r[8];
+    if (iters) {
+      gauss_search8<W>(w, g0, gtop, cdt, entries, iters, tie_shift, key, nc, r);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) r[c] = gauss_search<W>(w[c], g0 + c, cdt, entries, tie_shift, key, nc);
+    }
+    S v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (S)((x_min + r[c]) * amp);
+    S *dst = d + (grp << 3);
+    if (sizeof(S) == 1) {
+      uint64_t pk = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pk |= (uint64_t)(uint8_t)v[c] << (8 * c);
+      *reinterpret_cast<uint64_t *>(dst) = pk;
+    } else if (sizeof(S) == 2) {
+      uint4 pk;
+      pk.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
+      pk.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+      pk.z = (uint32_t)(uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16);
+      pk.w = (uint32_t)(uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
+      *reinterpret_cast<uint4 *>(dst) = pk;
+    } else {
+      uint4 p0, p1;
+      p0.x = (uint32_t)v[0]; p0.y = (uint32_t)v[1]; p0.z = (uint32_t)v[2]; p0.w = (uint32_t)v[3];
+      p1.x = (uint32_t)v[4]; p1.y = (uint32_t)v[5]; p1.z = (uint32_t)v[6]; p1.w = (uint32_t)v[7];
+      reinterpret_cast<uint4 *>(dst)[0] = p0;
+      reinterpret_cast<uint4 *>(dst)[1] = p1;
+    }
+  }
+}
+
+template <typename S, int W>
+__global__ void k_gauss_small(S *d, uint64_t first_coef, size_t ncoef, const uint64_t *__restrict__ cdt, int entries,
+                              long long x_min, long long amp, ChaChaKey key, uint64_t nonce, int tie_shift) {
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t g = first_coef + idx;
+    uint64_t blk[8];
+    chacha20_block(key, g >> 3, nonce, blk);
+    d[idx] = (S)((x_min + gauss_search<W>(blk[g & 7], g, cdt, entries, tie_shift, key, nonce)) * amp);
+  }
+}
+
+// compact -> residue words: dst[b][cm][i] = v < 0 ? p_cm + v : v with v = src[b * stride][i] (|v| < every modulus:
+// checked by the producer); stride 0 = one compact polynomial for the whole batch.  S = T selects plain word rows
+// (dst[b] = src[b * stride], a strided gather).
+template <typename T, typename S>
+__global__ void k_expand_small(T *dst, const S *src, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t ncoef,
+                               unsigned stride) {
+  const uint64_t n = ((uint64_t)1) << logn;
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t poly = idx >> logn, i = idx & (n - 1);
+    T *col = dst + ((poly * (uint64_t)nm) << logn) + i;
+    if (sizeof(S) == sizeof(T) && !std::is_signed<S>::value) {
+      const S *scol = src + ((poly * stride * (uint64_t)nm) << logn) + i;
+      for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = (T)scol[(uint64_t)cm << logn];
+    } else {
+      const long long v = (long long)src[((poly * stride) << logn) + i];
+      for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = (T)(v < 0 ? (long long)mc[cm].p + v : v);
+    }
   }
 }
 
@@ -537,6 +672,13 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
 static std::atomic<int> g_gauss_tie_shift{0};
 void set_gauss_tie_shift(int shift) { g_gauss_tie_shift.store(shift < 0 ? 0 : (shift > 63 ? 63 : shift)); }
 static int gauss_tie_shift() { return g_gauss_tie_shift.load(std::memory_order_relaxed); }
+// steps of the LDS-resident search (gauss_search8), 0 = the table is too long for LDS: the per-sample search over global memory
+static int gauss_lds_iters(int entries) {
+  if (entries < 2 || entries > kGaussLdsEntries) return 0;
+  int it = 0;
+  while ((1 << it) < entries) ++it;
+  return it;
+}
 
 hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *cdt, int words,
                               int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
@@ -570,13 +712,15 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
   const int tie_shift = gauss_tie_shift();
   if (s.n >= 8) {  // eight coefficients per thread
     const dim3 g(grid_for(ncoef / 8)), b(256);
+    const int iters = gauss_lds_iters(entries);
+    const size_t lds = iters ? (size_t)entries * 8 : 0;
     switch (words) {
-      case 1: hipLaunchKernelGGL((k_sample_gauss8<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-      case 2: hipLaunchKernelGGL((k_sample_gauss8<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-      case 3: hipLaunchKernelGGL((k_sample_gauss8<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-      case 4: hipLaunchKernelGGL((k_sample_gauss8<T, 4>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-      case 5: hipLaunchKernelGGL((k_sample_gauss8<T, 5>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-      case 6: hipLaunchKernelGGL((k_sample_gauss8<T, 6>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+      case 1: hipLaunchKernelGGL((k_sample_gauss8<T, 1>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 2: hipLaunchKernelGGL((k_sample_gauss8<T, 2>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 3: hipLaunchKernelGGL((k_sample_gauss8<T, 3>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 4: hipLaunchKernelGGL((k_sample_gauss8<T, 4>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 5: hipLaunchKernelGGL((k_sample_gauss8<T, 5>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 6: hipLaunchKernelGGL((k_sample_gauss8<T, 6>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -594,12 +738,68 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
   return hipGetLastError();
 }
 
+// format: 1 int8 | 2 int16 | 3 int32 (NFLHIP_FMT_*)
+hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_poly, size_t batch, const uint64_t *cdt,
+                              int words, int entries, long long x_min, uint64_t amp, const unsigned char *key32,
+                              uint64_t stream_id, hipStream_t st, int seq_on, uint64_t seq_stride) {
+  if (batch == 0) return hipSuccess;
+  if (seq_on && (s.n < 8 || first_poly != 0)) return hipErrorNotSupported;
+  if (words < 1 || words > 6 || format < 1 || format > 3) return hipErrorInvalidValue;
+  const ChaChaKey key = load_key(key32, kDomGauss, seq_on, seq_stride);
+  const size_t ncoef = batch * s.n;
+  const uint64_t fc = (uint64_t)first_poly * s.n;
+  const int tie_shift = gauss_tie_shift();
+  const long long a = (long long)amp;
+  const int iters = gauss_lds_iters(entries);
+  const size_t lds = iters ? (size_t)entries * 8 : 0;
+#define NFLHIP_GS(S, W)                                                                                                              \
+  do {                                                                                                                               \
+    if (s.n >= 8)                                                                                                                    \
+      hipLaunchKernelGGL((k_gauss_small8<S, W>), dim3(grid_for(ncoef / 8)), dim3(256), lds, st, (S *)d, s.logn, fc, ncoef, cdt,    \
+                         entries, x_min, a, key, stream_id, tie_shift, iters);                                                       \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((k_gauss_small<S, W>), dim3(grid_for(ncoef)), dim3(256), 0, st, (S *)d, fc, ncoef, cdt, entries, x_min, a, \
+                         key, stream_id, tie_shift);                                                                                 \
+  } while (0)
+#define NFLHIP_GSW(S)                    \
+  switch (words) {                       \
+    case 1: NFLHIP_GS(S, 1); break;      \
+    case 2: NFLHIP_GS(S, 2); break;      \
+    case 3: NFLHIP_GS(S, 3); break;      \
+    case 4: NFLHIP_GS(S, 4); break;      \
+    case 5: NFLHIP_GS(S, 5); break;      \
+    default: NFLHIP_GS(S, 6); break;     \
+  }
+  if (format == 1) { NFLHIP_GSW(int8_t) } else if (format == 2) { NFLHIP_GSW(int16_t) } else { NFLHIP_GSW(int32_t) }
+#undef NFLHIP_GSW
+#undef NFLHIP_GS
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const void *src, int format, unsigned stride,
+                               size_t batch, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  const ModConst<T> *mc = (const ModConst<T> *)t.mc;
+  const size_t ncoef = batch * s.n;
+  const dim3 g(grid_for(ncoef)), b(256);
+  switch (format) {
+    case 0: hipLaunchKernelGGL((k_expand_small<T, T>), g, b, 0, st, dst, (const T *)src, mc, s.logn, (int)s.nm, ncoef, stride); break;
+    case 1: hipLaunchKernelGGL((k_expand_small<T, int8_t>), g, b, 0, st, dst, (const int8_t *)src, mc, s.logn, (int)s.nm, ncoef, stride); break;
+    case 2: hipLaunchKernelGGL((k_expand_small<T, int16_t>), g, b, 0, st, dst, (const int16_t *)src, mc, s.logn, (int)s.nm, ncoef, stride); break;
+    case 3: hipLaunchKernelGGL((k_expand_small<T, int32_t>), g, b, 0, st, dst, (const int32_t *)src, mc, s.logn, (int)s.nm, ncoef, stride); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 #define NFLHIP_INST(T)                                                                                                   \
   template hipError_t launch_sample<T>(const Shape &, const DevTables &, T *, size_t, size_t, int, uint64_t, uint64_t,   \
                                        const unsigned char *, uint64_t, hipStream_t, int, uint64_t);                     \
   template hipError_t launch_sample_gauss<T>(const Shape &, const DevTables &, T *, size_t, size_t, const uint64_t *, int, \
                                              int, long long, uint64_t, const unsigned char *, uint64_t, hipStream_t, int,  \
-                                             uint64_t);
+                                             uint64_t);                                                                    \
+  template hipError_t launch_expand_small<T>(const Shape &, const DevTables &, T *, const void *, int, unsigned, size_t, hipStream_t);
 NFLHIP_INST(uint16_t)
 NFLHIP_INST(uint32_t)
 NFLHIP_INST(uint64_t)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (NflHipError, OP_ADD, OP_COMPUTE_SHOUP, OP_MUL, OP_MUL_SHOUP, OP_SUB,  # noqa: F401
+from ._lib import (FMT_I8, FMT_I16, FMT_I32, FMT_WORDS, NflHipError, OP_ADD, OP_COMPUTE_SHOUP, OP_MUL, OP_MUL_SHOUP, OP_SUB,  # noqa: F401
                    DIST_REFERENCE_WORDS, ROW_BITREV_IO, ROW_INVERSE_TABLES, TAB_INVDEGREE, TAB_INVOMEGAS,
                    TAB_INVPOLY_INVPHIS, TAB_MODULUS, TAB_OMEGAS, TAB_PHIS, TAB_PSI, TAB_SHOUPINVPOLY_INVPHIS,
                    TAB_SHOUPPHIS)
@@ -176,6 +176,75 @@ class Engine:
         fn = self.lib.nflhip_polymul_ntt_dev if b_is_ntt else self.lib.nflhip_polymul_dev
         self._chk(fn(self.ctx, _vp(out), _vp(a), _vp(b), self._batch(a), self._stream(stream)))
         return out
+
+    # ---- transform-fused pipelines (include/nflhip.h "transform-fused pipelines") ----
+    def _operand(self, ten, words_only=False):
+        """nflhip_operand of a tensor: [count][nmoduli][degree] limb words, or -- forward inputs -- [count][degree] int8 /
+        int16 / int32 (one signed integer per coefficient); count 1 = one polynomial for the whole batch (stride 0)"""
+        t = _torch()
+        if not ten.is_contiguous():
+            raise ValueError("operands must be contiguous tensors")
+        fmt = {t.int8: FMT_I8, t.int16: FMT_I16, t.int32: FMT_I32}.get(ten.dtype, FMT_WORDS)
+        if ten.dtype == self.torch_dtype and ten.dim() == 3:
+            fmt = FMT_WORDS
+        per = self.degree if fmt != FMT_WORDS else self.words_per_poly
+        if (fmt == FMT_WORDS and ten.dtype != self.torch_dtype) or ten.numel() % per or (words_only and fmt != FMT_WORDS):
+            raise ValueError("operand shape / dtype")
+        count = ten.numel() // per
+        return _lib.Operand(ten.data_ptr(), 0 if count == 1 else 1, fmt), count
+
+    def fwd_fma(self, x, k, e, out=None, batch=None, stream=None):
+        """out = NTT(x) * k + NTT(e) in one pass (nflhip_fwd_fma_dev)"""
+        (ox, nx), (ok, nk), (oe, ne) = self._operand(x), self._operand(k, True), self._operand(e)
+        batch = batch if batch is not None else max(nx, nk, ne)
+        out = out if out is not None else self.empty(batch)
+        self._chk(self.lib.nflhip_fwd_fma_dev(self.ctx, _vp(out), C.byref(ox), C.byref(ok), C.byref(oe), batch, self._stream(stream)))
+        return out
+
+    def fwd_fma2(self, x, k0, e0, k1, e1, out0=None, out1=None, batch=None, stream=None):
+        """out0 = NTT(x) * k0 + NTT(e0), out1 = NTT(x) * k1 + NTT(e1) in one pass: the LWE demo's encrypt()
+        (tests/nfllib_demo_main_op.cpp:26-46) for the whole batch (nflhip_fwd_fma2_dev)"""
+        ops = [self._operand(x), self._operand(k0, True), self._operand(e0), self._operand(k1, True), self._operand(e1)]
+        batch = batch if batch is not None else max(n for _, n in ops)
+        out0 = out0 if out0 is not None else self.empty(batch)
+        out1 = out1 if out1 is not None else self.empty(batch)
+        self._chk(self.lib.nflhip_fwd_fma2_dev(self.ctx, _vp(out0), _vp(out1), *[C.byref(o) for o, _ in ops], batch, self._stream(stream)))
+        return out0, out1
+
+    def fma_inv(self, a, k, b, subtract=False, out=None, batch=None, stream=None):
+        """out = INTT(b + a * k) or INTT(b - a * k): the demo's decrypt() (tests/nfllib_demo_main_op.cpp:49-51)"""
+        (oa, na), (ok, nk), (ob, nb) = self._operand(a, True), self._operand(k, True), self._operand(b, True)
+        batch = batch if batch is not None else max(na, nk, nb)
+        out = out if out is not None else self.empty(batch)
+        self._chk(self.lib.nflhip_fma_inv_dev(self.ctx, _vp(out), C.byref(oa), C.byref(ok), C.byref(ob), int(bool(subtract)), batch,
+                                              self._stream(stream)))
+        return out
+
+    def expand_small(self, src, batch=None, out=None, stream=None):
+        """compact polynomials (one signed integer per coefficient) -> residue words (nflhip_expand_small_dev)"""
+        o, n = self._operand(src)
+        batch = batch if batch is not None else n
+        out = out if out is not None else self.empty(batch)
+        self._chk(self.lib.nflhip_expand_small_dev(self.ctx, _vp(out), C.byref(o), batch, self._stream(stream)))
+        return out
+
+    def empty_small(self, batch, fmt=FMT_I8):
+        t = _torch()
+        return t.empty((batch, self.degree), dtype={FMT_I8: t.int8, FMT_I16: t.int16, FMT_I32: t.int32}[fmt], device="cuda:%d" % self.device)
+
+    def sample_gauss_small(self, d, g, key, stream_id=None, amplifier=1, first_poly=0, stream=None):
+        """compact Gaussian polynomials: d[b][i] = sample * amplifier as int8 / int16 / int32 (the tensor's dtype), the same
+        samples sample_gauss spreads over the moduli"""
+        o, n = self._operand(d)
+        self._chk(self.lib.nflhip_sample_gauss_small_dev(self.ctx, _vp(d), o.format, first_poly, n, g, amplifier, self._key(key),
+                                                         self._sid(stream_id), self._stream(stream)))
+        return d
+
+    def sample_gauss_small_seq(self, d, g, key, first_stream_id, stream_id_stride=1, amplifier=1, stream=None):
+        o, n = self._operand(d)
+        self._chk(self.lib.nflhip_sample_gauss_small_seq_dev(self.ctx, _vp(d), o.format, n, g, amplifier, self._key(key),
+                                                             first_stream_id, stream_id_stride, self._stream(stream)))
+        return d
 
     def any_eq(self, a, b, stream=None):
         r = C.c_int(0)

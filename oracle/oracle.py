@@ -126,6 +126,8 @@ class Oracle:
 
     def pointwise(self, op, a, b=None, bprime=None):
         out = np.empty_like(a)
+        for other in (b, bprime):
+            assert other is None or (other.flags.c_contiguous and other.shape == a.shape and other.dtype == a.dtype)
         self.lib.nfl_oracle_pointwise(self.ctx, op, _vp(out), _vp(a), _vp(b), _vp(bprime), self._chk(a))
         return out
 

@@ -619,6 +619,21 @@ HANDLERS.update({
 })
 
 
+@op("s_bfe_u32")
+def _(w, ops, mods):
+    x, c = w.srd(ops[1]), w.srd(ops[2])
+    r = (x >> (c & 31)) & ((1 << ((c >> 16) & 0x7F)) - 1)
+    w.scc = 1 if r else 0
+    w.swr(ops[0], r)
+
+
+@op("s_lshl_b64")
+def _(w, ops, mods):
+    r = (w.srd64(ops[1]) << (w.srd(ops[2]) & 63)) & M64
+    w.scc = 1 if r else 0
+    w.swr64(ops[0], r)
+
+
 @op("s_cselect_b32")
 def _(w, ops, mods):
     w.swr(ops[0], w.srd(ops[1]) if w.scc else w.srd(ops[2]))
@@ -763,6 +778,14 @@ HANDLERS.update({
 })
 
 
+@op("v_ashrrev_i32_e32")
+def _(w, ops, mods):
+    sh = np.asarray(w.rd32(ops[1]), dtype=np.uint64).astype(np.int64) & 31
+    x = np.asarray(w.rd32(ops[2]), dtype=np.uint64).astype(np.int64)
+    x = np.where(x & 0x80000000, x - (1 << 32), x)
+    w.wr32(ops[0], ((x >> sh) & M32).astype(np.uint64) + np.zeros(64, dtype=np.uint64))
+
+
 def _vcarry(kind, rev):
     def h(w, ops, mods):
         a, b = w.rd32(ops[2]), w.rd32(ops[3])
@@ -787,7 +810,7 @@ for _sfx in ("e32", "e64"):
 
 
 # ---- memory
-def _gload(nbytes):
+def _gload(nbytes, signed=False):
     def h(w, ops, mods):
         lo, nreg = ops[0][1], max(1, nbytes // 4)
         w.def_v(lo, nreg)
@@ -800,6 +823,8 @@ def _gload(nbytes):
             words = np.ascontiguousarray(raw).view("<u4")
             for k in range(nbytes // 4):
                 _put(w, lo + k, words[:, k].astype(np.uint64))
+        elif signed:   # sign-extended to the 32-bit register
+            _put(w, lo, np.ascontiguousarray(raw).view("<i2" if nbytes == 2 else np.int8)[:, 0].astype(np.int64).astype(np.uint64) & U32)
         else:
             _put(w, lo, np.ascontiguousarray(raw).view("<u2" if nbytes == 2 else np.uint8)[:, 0].astype(np.uint64))
     return h
@@ -837,6 +862,8 @@ def _gstore(nbytes):
 
 for _name, _nb in (("dword", 4), ("dwordx2", 8), ("dwordx3", 12), ("dwordx4", 16), ("ushort", 2), ("ubyte", 1)):
     HANDLERS["global_load_" + _name] = _gload(_nb)
+HANDLERS["global_load_sbyte"] = _gload(1, True)
+HANDLERS["global_load_sshort"] = _gload(2, True)
 for _name, _nb in (("dword", 4), ("dwordx2", 8), ("dwordx3", 12), ("dwordx4", 16), ("short", 2), ("byte", 1)):
     HANDLERS["global_store_" + _name] = _gstore(_nb)
 
@@ -1079,6 +1106,41 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     run_kernel(text, mem, kernarg, (gx, nm), lds, waves_per_wg=(1 << block_log) // words_per_thread // 64)
     out, _ = mem.find(pc, c.nbytes)
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
+
+
+def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts):
+    """the transform-fused kernels of tools/gen_polymul_asm.py build_fused (kernarg ARGS_FUSED: out0 out1 x0 x1 x2 k0 k1 psi
+    mc | nm logn fmt | strides x0 x1 x2 k0 k1 out0 out1; grid (batch, nm)).  xs: up to three forward inputs / inverse
+    operands -- uint64 arrays (count, nm, n) are word rows (format 0), int8 / int16 / int32 arrays (count, n) the compact
+    formats 1 / 2 / 3; ks: key rows (count, nm, n).  An operand with count 1 is shared by the whole batch (stride 0).
+    -> list of `nouts` result arrays (batch, nm, n)"""
+    import struct
+    mem = Memory()
+    psi, mc = device_tables(64, n, nm, prm)
+    outs = [np.zeros((batch, nm, n), dtype=np.uint64) for _ in range(nouts)]
+    fmt_of = {np.dtype(np.uint64): 0, np.dtype(np.int8): 1, np.dtype(np.int16): 2, np.dtype(np.int32): 3}
+    px, sx, fmt = [0, 0, 0], [0, 0, 0], 0
+    for i, x in enumerate(xs):
+        px[i] = mem.add(np.ascontiguousarray(x).copy())
+        sx[i] = 0 if x.shape[0] == 1 else 1
+        fmt |= fmt_of[x.dtype] << (4 * i)
+    pk, sk = [0, 0], [0, 0]
+    for i, k in enumerate(ks):
+        pk[i] = mem.add(np.ascontiguousarray(k).copy())
+        sk[i] = 0 if k.shape[0] == 1 else 1
+    po = [mem.add(o) for o in outs] + [0, 0]
+    ppsi, pmc = mem.add(psi), mem.add(mc)
+    kernarg = struct.pack("<9Q10i", po[0], po[1], px[0], px[1], px[2], pk[0], pk[1], ppsi, pmc, nm, n.bit_length() - 1, fmt,
+                          sx[0], sx[1], sx[2], sk[0], sk[1], 1, 1)
+    with open(asm_path) as f:
+        text = f.read()
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
+    run_kernel(text, mem, kernarg, (batch, nm), lds, waves_per_wg=4)
+    res = []
+    for i in range(nouts):
+        out, _ = mem.find(po[i], outs[i].nbytes)
+        res.append(out[:outs[i].nbytes].view(np.uint64).reshape(outs[i].shape).copy())
+    return res
 
 
 def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=False):

@@ -119,6 +119,57 @@ def test_emulated_u64_block_transforms(suffix, n, block_log, generated, oracle_f
         assert np.array_equal(asm_emu.run_block_kernel(generated("ntt_inv_mul4096"), n, nm, prm, fa, fb, block_log), want)
 
 
+def _signed_rows(x, P):
+    """(count, n) signed integers -> (count, nm, n) canonical residue words (what the samplers store: core.hpp:230-277)"""
+    v = x.astype(np.int64)[:, None, :]
+    return np.where(v < 0, (P[None, :, None].astype(np.int64) + v), v).astype(np.uint64)
+
+
+@pytest.mark.parametrize("fmt,nm,batch", [(np.int8, 2, 2), (np.int16, 1, 1), (np.int32, 1, 1), (np.uint64, 2, 1)])
+def test_emulated_u64_transform_fused_forward_multiply_add(fmt, nm, batch, generated, oracle_factory):
+    """out0 = NTT(x0) * k0 + NTT(x1), out1 = NTT(x0) * k1 + NTT(x2) in ONE launch (the LWE demo's encrypt(),
+    tests/nfllib_demo_main_op.cpp:26-46), inputs as residue words or as one signed integer per coefficient; the keys are one
+    polynomial for the whole batch"""
+    n = 4096
+    o = oracle_factory(64, n, nm)
+    prm, ka, kb = operands(o, 64, n, nm, 1, 31)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    rng = np.random.default_rng(32)
+    if fmt is np.uint64:
+        _, x0, x1 = operands(o, 64, n, nm, batch, 33)
+        _, x2, _ = operands(o, 64, n, nm, batch, 34)
+        w = [x0, x1, x2]
+        xs = w
+    else:
+        info = np.iinfo(fmt)
+        xs = [rng.integers(info.min, info.max, size=(batch, n), endpoint=True).astype(fmt) for _ in range(3)]
+        xs[0][0, :4] = (info.min, info.max, 0, -1)
+        w = [_signed_rows(x, P) for x in xs]
+    f = [o.ntt(x) for x in w]
+    KA, KB = (np.ascontiguousarray(np.broadcast_to(k_, f[0].shape)) for k_ in (ka, kb))
+    want0 = o.pointwise(0, o.pointwise(2, f[0], KA), f[1])
+    want1 = o.pointwise(0, o.pointwise(2, f[0], KB), f[2])
+    got = asm_emu.run_fused_kernel(generated("fused_enc2_4096"), n, nm, prm, xs, [ka, kb], batch, 2)
+    assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1)
+    got = asm_emu.run_fused_kernel(generated("fused_fma_fwd4096"), n, nm, prm, xs[:2], [ka], batch, 1)
+    assert np.array_equal(got[0], want0)
+
+
+@pytest.mark.parametrize("nm,batch", [(2, 2), (1, 1)])
+def test_emulated_u64_transform_fused_multiply_subtract_inverse(nm, batch, generated, oracle_factory):
+    """out = INTT(x1 - x0 * k) (the demo's decrypt(), tests/nfllib_demo_main_op.cpp:49-58) and INTT(x1 + x0 * k)"""
+    n = 4096
+    o = oracle_factory(64, n, nm)
+    prm, x0, x1 = operands(o, 64, n, nm, batch, 35)
+    _, k, _ = operands(o, 64, n, nm, 1, 36)
+    K = np.ascontiguousarray(np.broadcast_to(k, x0.shape))
+    prod = o.pointwise(2, x0, K)
+    got = asm_emu.run_fused_kernel(generated("fused_fms_inv4096"), n, nm, prm, [x0, x1], [k], batch, 1)
+    assert np.array_equal(got[0], o.intt(o.pointwise(1, x1, prod)))
+    got = asm_emu.run_fused_kernel(generated("fused_fma_inv4096"), n, nm, prm, [x0, x1], [k], batch, 1)
+    assert np.array_equal(got[0], o.intt(o.pointwise(0, x1, prod)))
+
+
 @pytest.mark.parametrize("n,nm,batch", [(16384, 2, 3), (8192, 3, 4), (8192, 1, 1)])
 def test_emulated_u64_two_rows_per_workgroup_forward_transform_of_long_rows(n, nm, batch, generated, oracle_factory):
     """stand-alone forward transform at n = 16384 / 8192: two polynomials of one modulus per workgroup on shared twiddle

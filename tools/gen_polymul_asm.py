@@ -3153,6 +3153,388 @@ def build_pipe(logn=None, fused=False):
     return em
 
 
+# ------------------------------------------------------------------ transform-fused pipelines (n = 4096, one row per workgroup)
+# What callers of the reference run around the transforms (tests/nfllib_demo_main_op.cpp:26-58: three Gaussian polynomials,
+# three forward transforms and two multiply-adds per encryption; one multiply-subtract and one inverse transform per
+# decryption) as ONE launch per batch: [expand | load] -> forward passes in registers -> point-wise step against key rows ->
+# store, or load -> point-wise step -> inverse passes -> store.  The intermediate polynomials never reach HBM.
+#   fma_fwd   out0 = NTT(x0) * k0 + NTT(x1)
+#   enc2      out0 = NTT(x0) * k0 + NTT(x1),  out1 = NTT(x0) * k1 + NTT(x2)      (x0' stays in registers for the second half)
+#   fms_inv   out0 = INTT(x1 - x0 * k0)        fma_inv   out0 = INTT(x1 + x0 * k0)
+# Every operand advances by its own stride (in polynomials) from one batch element to the next: 0 = one polynomial for the
+# whole batch (a key), 1 = dense.  A forward input x is either full residue words (format 0: [nm][n] words in coefficient
+# form) or ONE signed integer per coefficient shared by all moduli (formats 1 / 2 / 3: int8 / int16 / int32 -- what the
+# samplers produce before they are spread over the moduli, core.hpp:230-277; x < 0 is expanded to p + x).
+# kernarg: out0 out1 x0 x1 x2 k0 k1 psi mc | nm logn fmt (4 bits per x) | strides x0 x1 x2 k0 k1 out0 out1
+ARGS_FUSED = [("ptr", 8 * i) for i in range(9)] + [("i32", 72 + 4 * i) for i in range(10)]
+S_FMT, S_F = "s4", "s5"
+S_X2ROW, S_K0ROW, S_K1ROW, S_O1ROW = "s[54:55]", "s[96:97]", "s[98:99]", "s[100:101]"
+
+
+def prologue_fused(em, vm, kind):
+    """256 threads, workgroup (x, y) = (batch element, modulus).  Leaves the row pointers, the pass constants (r = 0), the
+    ModConst record requested, the first pass's twiddle loads issued and -- forward kinds -- x0 / x1 on their way into V_A /
+    V_B; returns (tw_seq, sequence number of the last operand load)"""
+    R = em.raw
+    fwd = kind in ("enc2", "fma_fwd")
+    R("s_load_dwordx16 s[56:71], s[0:1], 0x0")           # out0 out1 x0 x1 x2 k0 k1 psi
+    R("s_load_dwordx2 s[12:13], s[0:1], 0x40")           # mc
+    R("s_load_dwordx2 s[72:73], s[0:1], 0x48")           # nm, logn
+    R("s_load_dwordx8 s[76:83], s[0:1], 0x50")           # fmt, strides x0 x1 x2 k0 k1 out0 out1
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                     # B = t >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
+    em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
+    em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_BIDX, V_L2R, V_L1R))     # 272*B + r
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
+    em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
+    em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
+    for s in sorted(set(V_T)):
+        em.valu("v_mov_b32_e32 v%d, 0" % (s + 15,))                                 # the persistent zero of ZP
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b32 s14, s72")                              # nm
+    R("s_sub_u32 s88, s73, 12")                          # r = 0: rows of exactly 4096 words
+    R("s_mov_b32 s89, 0")                                # blk
+    R("s_mov_b32 %s, s76" % S_FMT)
+    R("s_mov_b64 s[10:11], s[70:71]")                    # psi
+
+    def word_row(dst, base, stride):
+        """s[dst:dst+1] = base + (((x * stride) * nm + y) << 15)"""
+        R("s_mul_i32 s42, s2, s%d" % stride)
+        R("s_mul_hi_u32 s43, s42, s14")
+        R("s_mul_i32 s42, s42, s14")
+        R("s_add_u32 s42, s42, s3")
+        R("s_addc_u32 s43, s43, 0")
+        R("s_lshl_b64 s[42:43], s[42:43], 15")
+        R("s_add_u32 s%d, s%d, s42" % (dst, base))
+        R("s_addc_u32 s%d, s%d, s43" % (dst + 1, base + 1))
+
+    def x_row(dst, base, stride, k):
+        """the same for a forward input: its format decides between word rows and the compact (x * stride) << (11 + f)"""
+        if not fwd:
+            return word_row(dst, base, stride)
+        R("s_bfe_u32 %s, %s, 0x%x" % (S_F, S_FMT, (4 << 16) | (4 * k)))
+        R("s_mul_i32 s42, s2, s%d" % stride)
+        R("s_mul_hi_u32 s45, s42, s14")
+        R("s_mul_i32 s44, s42, s14")
+        R("s_add_u32 s44, s44, s3")
+        R("s_addc_u32 s45, s45, 0")
+        R("s_lshl_b64 s[44:45], s[44:45], 15")
+        R("s_add_u32 s87, %s, 11" % S_F)
+        R("s_mov_b32 s43, 0")
+        R("s_lshl_b64 s[42:43], s[42:43], s87")
+        R("s_cmp_eq_u32 %s, 0" % S_F)
+        R("s_cselect_b64 s[42:43], s[44:45], s[42:43]")
+        R("s_add_u32 s%d, s%d, s42" % (dst, base))
+        R("s_addc_u32 s%d, s%d, s43" % (dst + 1, base + 1))
+
+    x_row(16, 60, 77, 0)                                 # x0 -> S_AROW
+    x_row(18, 62, 78, 1)                                 # x1 -> S_BROW
+    word_row(20, 56, 82)                                 # out0 -> S_CROW
+    word_row(96, 66, 80)                                 # k0
+    if kind == "enc2":
+        x_row(54, 64, 79, 2)                             # x2
+        word_row(98, 68, 81)                             # k1
+        word_row(100, 58, 83)                            # out1
+    # tw = psi + (cm << (logn + 4)); pass constants K (prologue())
+    R("s_add_u32 s43, s88, 16")
+    R("s_lshl_b32 s42, s3, s43")
+    R("s_add_u32 s22, s10, s42")
+    R("s_addc_u32 s23, s11, 0")
+    R("s_lshl_b32 s90, 1, s88")
+    R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
+    R("s_lshl_b32 s91, s90, 4")
+    R("s_lshl_b32 s92, s90, 8")
+    R("s_lshl_b32 s93, 0x200, s88")
+    R("s_lshl_b32 s42, s89, 8")
+    R("s_sub_u32 s93, s93, s42")                         # (512<<r) - 256*blk
+    R("s_lshl_b32 s94, 32, s88")
+    R("s_lshl_b32 s42, s89, 4")
+    R("s_sub_u32 s94, s94, s42")                         # (32<<r) - 16*blk
+    R("s_lshl_b32 s95, 2, s88")
+    R("s_sub_u32 s95, s95, s89")                         # (2<<r) - blk
+    R("s_mul_i32 s42, s3, 0x70")
+    R("s_add_u32 s42, s12, s42")
+    R("s_addc_u32 s43, s13, 0")
+    R("s_load_dwordx16 s[56:71], s[42:43], 0x0")          # p p2 mu ninv ninv_sh w1ninv w1ninv_sh beta   (the kernarg copies are spent)
+    R("s_load_dwordx8 s[72:79], s[42:43], 0x40")          # beta_sh yinv yinv_sh mask
+    R("s_load_dwordx4 s[80:83], s[42:43], 0x60")          # delta mu2
+    seq = 0
+    if fwd:
+        seq = fused_x_loads(em, vm, V_A, S_AROW, 0, "x0")
+        seq = fused_x_loads(em, vm, V_B, S_BROW, 1, "x1")
+        first = "F1"
+    else:
+        seq = fused_lane_loads(em, vm, V_A, S_AROW)
+        seq = fused_lane_loads(em, vm, V_TW, S_K0ROW, stream=False)
+        seq = fused_lane_loads(em, vm, V_B, S_BROW)
+        first = None
+    tw_seq = {}
+    if first:
+        for s in (0, 1, 2, 3):
+            tw_seq[(first, s)] = PASS_TW[first](em, vm, s)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b64 s[24:25], s[56:57]")                    # p
+    R("s_mov_b64 s[26:27], s[58:59]")                    # 2p
+    R("s_add_u32 s28, s58, s56")                         # 3p
+    R("s_addc_u32 s29, s59, s57")
+    R("s_mov_b32 s30, s80")                              # delta
+    R("s_mov_b32 s31, 0x3fffffff")
+    R("s_mov_b32 s15, 0xc0000000")
+    R("s_mov_b64 s[32:33], s[82:83]")                    # mu2
+    R("s_mov_b64 s[34:35], s[62:63]")                    # ninv
+    R("s_mov_b64 s[36:37], s[64:65]")                    # ninv_sh
+    R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
+    R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
+    em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+    return tw_seq, seq
+
+
+def fused_x_loads(em, vm, dst, srow, k, tag):
+    """x[t + 256 j] -> register pair j (the layout F1 starts from), whatever the operand's format: 16 vector loads on every
+    path, so the static load count of the VmCounter holds"""
+    R = em.raw
+    A = T(1, 0)
+    R("s_bfe_u32 %s, %s, 0x%x" % (S_F, S_FMT, (4 << 16) | (4 * k)))
+    R("s_mov_b64 s[86:87], %s" % (srow,))
+    R("s_cmp_eq_u32 %s, 0" % S_F)
+    R("s_cbranch_scc0 .L%s_compact" % tag)
+    seq = 0
+    for j in range(16):
+        seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d nt" % (vp(dst + 2 * j), V_OFF8, (j & 1) * 2048))
+        if j & 1:
+            R("s_add_u32 s86, s86, 0x1000")
+            R("s_addc_u32 s87, s87, 0")
+    R("s_branch .L%s_issued" % tag)
+    em.lines.append(".L%s_compact:" % tag)
+    R("s_cmp_eq_u32 %s, 1" % S_F)
+    R("s_cbranch_scc0 .L%s_i16" % tag)
+    for j in range(16):
+        R("global_load_sbyte v%d, v%d, s[86:87] offset:%d" % (dst + 2 * j, V_TID, 256 * j))
+    R("s_branch .L%s_issued" % tag)
+    em.lines.append(".L%s_i16:" % tag)
+    R("s_cmp_eq_u32 %s, 2" % S_F)
+    R("s_cbranch_scc0 .L%s_i32" % tag)
+    em.valu("v_lshlrev_b32_e32 v%d, 1, v%d" % (A, V_TID))
+    for j in range(16):
+        R("global_load_sshort v%d, v%d, s[86:87] offset:%d" % (dst + 2 * j, A, 512 * (j & 7)))
+        if j == 7:
+            R("s_add_u32 s86, s86, 0x1000")
+            R("s_addc_u32 s87, s87, 0")
+    R("s_branch .L%s_issued" % tag)
+    em.lines.append(".L%s_i32:" % tag)
+    em.valu("v_lshlrev_b32_e32 v%d, 2, v%d" % (A, V_TID))
+    for j in range(16):
+        R("global_load_dword v%d, v%d, s[86:87] offset:%d" % (dst + 2 * j, A, 1024 * (j & 3)))
+        if j & 3 == 3:
+            R("s_add_u32 s86, s86, 0x1000")
+            R("s_addc_u32 s87, s87, 0")
+    em.lines.append(".L%s_issued:" % tag)
+    return seq
+
+
+def fused_x_expand(em, dst, k, tag):
+    """compact formats: the sign-extended integer x becomes x (x >= 0) or p + x (x < 0) -- any 64-bit word congruent to the
+    coefficient is a legal input of the first butterfly"""
+    R = em.raw
+    R("s_bfe_u32 %s, %s, 0x%x" % (S_F, S_FMT, (4 << 16) | (4 * k)))
+    R("s_cmp_eq_u32 %s, 0" % S_F)
+    R("s_cbranch_scc1 .L%s_words" % tag)
+    t = T(0, 4)
+    for j in range(16):
+        x = dst + 2 * j
+        em.valu("v_ashrrev_i32_e32 v%d, 31, v%d" % (x + 1, x))
+        em.valu("v_and_b32_e32 v%d, s24, v%d" % (t, x + 1))
+        em.valu("v_and_b32_e32 v%d, s25, v%d" % (t + 1, x + 1))
+        em.valu("v_lshl_add_u64 %s, %s, 0, %s" % (vp(x), vp(x), vp(t)))
+    em.lines.append(".L%s_words:" % tag)
+
+
+def fused_lane_loads(em, vm, dst, srow, stream=True):
+    """element 1024w + 64j + l of the row -> register pair j (512 B per wave instruction): any layout serves a point-wise
+    step as long as all operands share it.  stream: a row nobody reads again (`nt`); the key row stays in the caches"""
+    g, _ = lane_contig_setup(em)
+    em.raw("s_mov_b64 s[86:87], %s" % (srow,))
+    seq = 0
+    for j in range(16):
+        seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d%s" % (vp(dst + 2 * j), g, (j & 7) * 512, " nt" if stream else ""))
+        if j == 7:
+            em.raw("s_add_u32 s86, s86, 0x1000")
+            em.raw("s_addc_u32 s87, s87, 0")
+    return seq
+
+
+def fma_job(k, a, b, fold_a):
+    """k = canonical(k * a + b): k a canonical key word, a / b lazily reduced words (a is folded in place the first time)"""
+    def gen(s):
+        yield from pointwise(k, a, False, fold_a)(s)
+        yield from fold2(s, b, b)
+        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(k), vp(k), vp(b)), None, None
+        yield from fold2(s, k, k)
+        yield from csub_p(s, k)
+    return gen
+
+
+def fms_job(a, k, b, subtract):
+    """a = fold(b -+ a * k) < p + 4 delta, all inputs canonical (the contract of the reference's operators, ops.hpp:131,211)"""
+    def gen(s):
+        yield from pointwise(a, k, False, False)(s)
+        if subtract:
+            E = T(s, 12)
+            yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(b), S_P2), None, None
+            yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (a, S_BORROW[s], E, a), S_BORROW[s], None
+            yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (a + 1, S_DUMMY, E + 1, a + 1, S_BORROW[s]), None, S_BORROW[s]
+        else:
+            yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(a), vp(a), vp(b)), None, None
+        yield from fold2(s, a, a)
+    return gen
+
+
+def build_fused(kind):
+    """kind: enc2 | fma_fwd | fms_inv | fma_inv"""
+    em = Emitter()
+    vm = VmCounter(em)
+    R = em.raw
+    tw_seq, seq_x = prologue_fused(em, vm, kind)
+    V_K = V_TW                      # key words: twiddle slots 0..7
+
+    def forward(bases, k_row, first_pass_ready):
+        """F1 E1 F2 E2 F3 over `bases` (shared twiddle records); the key row's loads are woven into F3: seven of its eight
+        16-byte loads as soon as F3's sub-stage 2 is done with slots 0..6, the last one behind sub-stage 3.  Returns the
+        sequence numbers of the key loads"""
+        for name, nxt in (("F1", "F2"), ("F2", "F3"), ("F3", None)):
+            em.comment("%s%s" % (name, "; prefetching " + nxt if nxt else "; then the key row"))
+            kseq = []
+            for s in range(4):
+                vm.wait(tw_seq[(name, s)])
+                ct_stage(em, bases, s)
+                if nxt is not None:
+                    tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
+                elif s >= 2:
+                    em.valu("v_lshlrev_b32_e32 v%d, 7, v%d" % (T(1, 0), V_TID))     # (butterfly scratch: recomputed per batch of loads)
+                    for i in (range(7) if s == 2 else (7,)):
+                        kseq.append(vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d"
+                                            % (V_K + 4 * i, V_K + 4 * i + 3, T(1, 0), k_row, 16 * i)))
+            if name == "F1":
+                for i, base in enumerate(bases):
+                    em.comment("E1")
+                    if i or not first_pass_ready:
+                        R("s_barrier")       # WAR: the slab is still being read (previous operand / the first half's store transposes)
+                    lds_write(em, V_L1W, base, 2176)
+                    R("s_waitcnt lgkmcnt(0)")
+                    R("s_barrier")
+                    lds_read(em, V_L1R, base, 136)
+                    R("s_waitcnt lgkmcnt(0)")
+            elif name == "F2":
+                em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+                for base in bases:
+                    lds_write(em, V_L1R, base, 136)
+                    lds_read(em, V_L2R, base, 8)
+                R("s_waitcnt lgkmcnt(0)")
+        return kseq
+
+    def fma_store(xb, fold_a, kseq, dst_row, early=None):
+        """V_K = canonical(V_K * V_A + xb) -> dst_row (NTT form: thread q holds words 16q..16q+15; a wave-local LDS transpose
+        makes the stores 512 B per wave instruction)"""
+        em.comment("point-wise multiply-add against the key row")
+        for i in range(8):
+            vm.wait(kseq[i])
+            run_pairs(em, [fma_job(V_K + 4 * i, V_A + 4 * i, xb + 4 * i, fold_a), fma_job(V_K + 4 * i + 2, V_A + 4 * i + 2, xb + 4 * i + 2, fold_a)])
+        if early is not None:
+            early()
+        lds_write(em, V_L2R, V_K, 8)
+        g, l = lane_contig_setup(em)
+        for j in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_K + 2 * j), l, 544 * j))
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_mov_b64 s[86:87], %s" % (dst_row,))
+        for j in range(16):
+            vm.load("global_store_dwordx2 v%d, %s, s[86:87] offset:%d nt" % (g, vp(V_K + 2 * j), (j & 7) * 512))
+            if j == 7:
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+
+    if kind in ("enc2", "fma_fwd"):
+        vm.wait(seq_x)
+        fused_x_expand(em, V_A, 0, "e0")
+        fused_x_expand(em, V_B, 1, "e1")
+        kseq = forward([V_A, V_B], S_K0ROW, True)
+        if kind == "fma_fwd":
+            fma_store(V_B, True, kseq, S_CROW)
+            R("s_endpgm")
+            return em
+        state = {}
+
+        def early():   # x2 is requested as soon as V_B is free: its latency hides behind the store of out0
+            state["x2"] = fused_x_loads(em, vm, V_B, S_X2ROW, 2, "x2")
+        fma_store(V_B, True, kseq, S_CROW, early)
+        em.comment("second half: x2 alone, x0' stays in V_A")
+        for s in (0, 1, 2, 3):
+            tw_seq[("F1", s)] = PASS_TW["F1"](em, vm, s)
+        vm.wait(state["x2"])
+        fused_x_expand(em, V_B, 2, "e2")
+        kseq = forward([V_B], S_K1ROW, False)
+        fma_store(V_B, False, kseq, S_O1ROW)
+        R("s_endpgm")
+        return em
+
+    # ---- fms_inv / fma_inv: point-wise step in the loaded (lane-contiguous) layout, then the inverse passes of build_body
+    vm.wait(seq_x)
+    em.comment("x1 -+ x0 * k0")
+    run_pairs(em, [fms_job(V_A + 2 * i, V_K + 2 * i, V_B + 2 * i, kind == "fms_inv") for i in range(16)])
+    for s in (3, 2, 1, 0):
+        tw_seq[("I1", s)] = PASS_TW["I1"](em, vm, s)
+    em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
+    _, l = lane_contig_setup(em)
+    for j in range(16):
+        R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
+    lds_read(em, V_L2R, V_A, 8)
+    R("s_waitcnt lgkmcnt(0)")
+    inverse_half(em, vm, tw_seq)
+    return em
+
+
+def inverse_half(em, vm, tw_seq):
+    """I1 E2' I2 E1' I3 and the merged last stage over V_A (thread-contiguous words in), store to S_CROW"""
+    R = em.raw
+    order = ["I1", "I2", "I3"]
+    for name in order:
+        nxt = order[order.index(name) + 1] if name != "I3" else None
+        em.comment("%s%s" % (name, "; prefetching " + nxt if nxt else ""))
+        for s in ((3, 2, 1, 0) if name != "I3" else (3, 2, 1)):
+            vm.wait(tw_seq[(name, s)])
+            gs_stage(em, V_A, s)
+            if nxt is not None:
+                tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
+        if name == "I1":
+            em.comment("E2'")
+            lds_write(em, V_L2R, V_A, 8)
+            lds_read(em, V_L1R, V_A, 136)
+            R("s_waitcnt lgkmcnt(0)")
+        elif name == "I2":
+            em.comment("E1'")
+            lds_write(em, V_L1R, V_A, 136)
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            lds_read(em, V_L1W, V_A, 2176)
+            R("s_waitcnt lgkmcnt(0)")
+
+    def last_plain():
+        vm.wait(tw_seq[("I3", 0)])
+        gs_stage(em, V_A, 0)
+    epilogue_inverse(em, vm, last_plain)
+
+
+KERNELS_FUSED = {
+    "enc2": ("fused_enc2_4096", "nflhip_fused_enc2_4096_asm"),
+    "fma_fwd": ("fused_fma_fwd4096", "nflhip_fused_fma_fwd4096_asm"),
+    "fms_inv": ("fused_fms_inv4096", "nflhip_fused_fms_inv4096_asm"),
+    "fma_inv": ("fused_fma_inv4096", "nflhip_fused_fma_inv4096_asm"),
+}
+
+
 HEADER = """\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
 \t.amdhsa_code_object_version 6
 \t.text
@@ -3271,6 +3653,14 @@ def main():
             if not experiments:
                 continue
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind), args=args)
+    # transform-fused pipelines (n = 4096): word-row streams `nt`, key rows and compact inputs through the caches
+    g = globals()
+    g.update(NEXT_SGPR=102)
+    for kind, (stem, kname) in KERNELS_FUSED.items():
+        emf = build_fused(kind)
+        emf.lines = [l + " nt" if "global_store_dwordx2" in l and not l.endswith(" nt") else l for l in emf.lines]   # (the inverse kinds' result rows)
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, emf, args=ARGS_FUSED)
+    g.update(NEXT_SGPR=96)
     # n = 65536: the three-role pipeline kernel; coefficient streams `nt`: 3 x 15.7 MB of data per product pass through each
     # XCD's 4 MiB L2 exactly once, the 31 MB of twiddle tables are what is worth keeping there (+3 % on workload E)
     em_nt = build_pipe()
