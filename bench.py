@@ -195,7 +195,7 @@ def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False):
         a = eng.fill_uniform(eng.empty(batch), SEED, 0)
         b = eng.fill_uniform(eng.empty(batch), SEED, 1)
         c = eng.empty(batch)
-        for _ in range(2):
+        for _ in range(4):
             eng.polymul(a, b, out=c)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -286,7 +286,7 @@ def main():
     torch.cuda.set_device(dev)
     # RCCL is initialised at EVERY world size, 1 included (a 1-GPU box then exercises the same init / barrier / all-reduce
     # calls the N-GPU launch line makes; --no-rccl keeps the profiler's inner re-runs of this script light)
-    rccl = {"initialised": False}
+    rccl = {"initialised": False, "world_size": world, "backend": backend}
     use_dist = world > 1 or not args.no_rccl
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -332,12 +332,12 @@ def main():
             comm.barrier()
             probe = torch.ones(1, dtype=torch.int64, device=red_dev)
             dist.all_reduce(probe)
-            rccl = {"initialised": True, "world_size": world, "all_reduce_of_ones": int(probe.item()),
+            rccl = {"initialised": True, "world_size": world, "backend": backend, "all_reduce_of_ones": int(probe.item()),
                     "calls": "torch.distributed nccl init + barrier + all_reduce; nflhip_comm_create (ncclCommInitRank) + "
                              "nflhip_comm_barrier + nflhip_comm_allgather_u64"}
         except Exception as e:   # the digests then travel over torch.distributed (same RCCL); the line says so
             comm = None
-            rccl = {"initialised": world > 1, "world_size": world, "error": "nflhip_comm: " + repr(e)}
+            rccl = {"initialised": world > 1, "world_size": world, "backend": backend, "error": "nflhip_comm: " + repr(e)}
 
     for _ in range(args.warmup):
         eng.polymul(a, b, out=c)
@@ -572,7 +572,7 @@ def main():
             del a, b, c
             torch.cuda.empty_cache()
             side = {}
-            for wl, sb, st_, crt in (("C", 1024, 10, False), ("E", 32, 10, True)):
+            for wl, sb, st_, crt in (("C", 1024, 20, False), ("E", 32, 20, True)):
                 try:
                     side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt)
                 except Exception as ex:   # reported, never fatal

@@ -439,7 +439,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   const bool cap = is_capturing(st);
   // (from 256 rows on; below that the one-launch plan further down spreads a row over more CUs -- measured, same box:
   // batch 8 / 32 / 128 / 512 of two moduli 58 / 223 / 716 / 785 k products/s here against 68 / 302 / 622 / 779 k)
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 15 && !xcd_on(ctx, batch)) {
+  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 15 && !(xcd_on(ctx, batch) && xcd_plan_bytes(ctx->shape, batch) != 0)) {
     // rows of 32768 words: b' = NTT(b) into the scratch (one read, one write), then c = INTT(NTT(a) (.) b') with the row
     // of a register-resident and b' streamed through the point-wise step (two reads, one write): 5 operand passes
     int rcs = ensure_scratch(ctx, bytes);
@@ -1546,6 +1546,9 @@ class CopyPool {  // a few host threads that memcpy slices; process-wide, starte
       std::memcpy(dst, src, bytes);
       return;
     }
+    // ONE job at a time: the pool is process-wide and keeps a single job's state, while callers on different contexts
+    // (one host thread per GPU, two ring types) hold only their own context's lock
+    std::lock_guard<std::mutex> call(call_mu_);
     std::unique_lock<std::mutex> lk(mu_);
     dst_ = (char *)dst;
     src_ = (const char *)src;
@@ -1602,7 +1605,7 @@ class CopyPool {  // a few host threads that memcpy slices; process-wide, starte
     }
   }
   std::atomic<unsigned long long> gen_hint_{0};
-  std::mutex mu_;
+  std::mutex mu_, call_mu_;
   std::condition_variable cv_, cv_done_;
   std::vector<std::thread> workers_;
   char *dst_ = nullptr;
@@ -1705,22 +1708,40 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
     p->t_out += secs(t1, clk::now());
     return NFLHIP_OK;
   };
-  std::thread drainer([&] {
-    (void)hipSetDevice(ctx->device);
-    for (size_t k = 0; k < nchunks; ++k) {
-      while (issued.load(std::memory_order_acquire) <= k) {
-        if (stop.load(std::memory_order_acquire)) return;
-        __builtin_ia32_pause();
+  std::thread drainer;
+  try {
+    drainer = std::thread([&] {
+      (void)hipSetDevice(ctx->device);
+      for (size_t k = 0; k < nchunks; ++k) {
+        while (issued.load(std::memory_order_acquire) <= k) {
+          if (stop.load(std::memory_order_acquire)) return;
+          __builtin_ia32_pause();
+        }
+        const int r = drain_one(k);
+        if (r) { drain_rc.store(r); return; }
+        drained.store(k + 1, std::memory_order_release);
       }
-      const int r = drain_one(k);
-      if (r) { drain_rc.store(r); return; }
-      drained.store(k + 1, std::memory_order_release);
-    }
-  });
+    });
+  } catch (...) {  // (no exception crosses the C boundary)
+    return fail(ctx, NFLHIP_ERR_NOMEM, "cannot start the host thread that copies results out");
+  }
+  // Whatever way this function is left: the drainer is joined, and -- on an error path, where copies and kernels may still
+  // be in flight on the three streams against the pinned and device slots -- the streams are drained before the slots
+  // can be reused by the next call on this context
+  bool completed = false;
   struct joiner {
-    std::thread &t; std::atomic<bool> &stop;
-    ~joiner() { stop.store(true); if (t.joinable()) t.join(); }
-  } join_guard{drainer, stop};
+    std::thread &t; std::atomic<bool> &stop; bool &completed; HostPipe *p; nflhip_ctx *ctx;
+    ~joiner() {
+      stop.store(true);
+      if (t.joinable()) t.join();
+      if (!completed) {
+        (void)hipStreamSynchronize(p->s_h2d);
+        (void)hipStreamSynchronize(ctx->hstream);
+        (void)hipStreamSynchronize(p->s_d2h);
+        (void)hipGetLastError();
+      }
+    }
+  } join_guard{drainer, stop, completed, p, ctx};
   for (size_t k = 0; k < nchunks; ++k) {
     const int s = int(k % HostPipe::kSlots);
     while (k >= size_t(HostPipe::kSlots) && drained.load(std::memory_order_acquire) + HostPipe::kSlots <= k) {  // the slot's previous tenant
@@ -1749,8 +1770,9 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
     HIPCHK(ctx, hipStreamWaitEvent(p->s_d2h, p->ev_k[s], 0));
     HIPCHK(ctx, hipMemcpyAsync(p->pinned[s][3], p->dev[s][3], bytes, hipMemcpyDeviceToHost, p->s_d2h));
     HIPCHK(ctx, hipEventRecord(p->ev_d2h[s], p->s_d2h));
-    // the next H2D into this slot's device inputs must not overtake this chunk's kernel
-    HIPCHK(ctx, hipStreamWaitEvent(p->s_h2d, p->ev_k[s], 0));
+    // (the next H2D into this slot's device inputs cannot overtake this chunk's kernel: the host reuses a slot only after
+    // its result has been drained.  No wait on the in-order H2D stream here -- it would hold chunk k + 1's copy, which
+    // goes to ANOTHER slot, behind kernel k, and copies would never overlap compute)
     issued.store(k + 1, std::memory_order_release);
   }
   while (drained.load(std::memory_order_acquire) < nchunks) {
@@ -1758,6 +1780,7 @@ static int run_pipelined(nflhip_ctx *ctx, size_t batch, const void *const *in, i
     __builtin_ia32_pause();
   }
   p->t_total += secs(t_begin, clk::now());
+  completed = true;
   return NFLHIP_OK;
 }
 

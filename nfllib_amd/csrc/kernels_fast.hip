@@ -465,7 +465,7 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
     void *out0, *out1;
     const void *x[3], *k[2], *psi, *mc;
     int nm, logn, fmt;
-    unsigned sx[3], sk[2], so[2];
+    unsigned sx[3], sk[2], count, magic;
   } args = {};
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_fused_*_asm (ARGS_FUSED)");
   args.out0 = out0;
@@ -486,9 +486,15 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
   args.mc = t.mc;
   args.nm = (int)s.nm;
   args.logn = s.logn;
-  args.so[0] = args.so[1] = 1;
+  args.count = (unsigned)batch;
+  // forward kinds with more than one modulus: the nm rows of a batch element back to back on one XCD (1-D grid, the kernel
+  // deals the workgroups itself), so that compact inputs -- one copy for all moduli -- come from HBM once
+  const size_t groups = (batch + 7) / 8, wgs = groups * 8 * s.nm;
+  const bool remap = kind < 2 && s.nm > 1 && (args.fmt != 0) && wgs <= 0x7fffffffull && groups * s.nm < (0xffffffffull / s.nm);
+  args.magic = remap ? (unsigned)(0x100000000ull / s.nm + 1) : 0u;
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  if (remap) return hipModuleLaunchKernel(fn, (unsigned)wgs, 1, 1, kThreads, 1, 1, 0, st, nullptr, extra);
   return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
 }
 

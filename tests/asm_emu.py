@@ -1108,9 +1108,10 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts):
+def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts, remap=False):
     """the transform-fused kernels of tools/gen_polymul_asm.py build_fused (kernarg ARGS_FUSED: out0 out1 x0 x1 x2 k0 k1 psi
-    mc | nm logn fmt | strides x0 x1 x2 k0 k1 out0 out1; grid (batch, nm)).  xs: up to three forward inputs / inverse
+    mc | nm logn fmt | strides x0 x1 x2 k0 k1 | count magic; grid (batch, nm), or -- remap -- the 1-D grid whose workgroups
+    the kernel deals to (batch element, modulus) itself, the nm rows of an element back to back on one XCD).  xs: up to three forward inputs / inverse
     operands -- uint64 arrays (count, nm, n) are word rows (format 0), int8 / int16 / int32 arrays (count, n) the compact
     formats 1 / 2 / 3; ks: key rows (count, nm, n).  An operand with count 1 is shared by the whole batch (stride 0).
     -> list of `nouts` result arrays (batch, nm, n)"""
@@ -1130,12 +1131,12 @@ def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts):
         sk[i] = 0 if k.shape[0] == 1 else 1
     po = [mem.add(o) for o in outs] + [0, 0]
     ppsi, pmc = mem.add(psi), mem.add(mc)
-    kernarg = struct.pack("<9Q10i", po[0], po[1], px[0], px[1], px[2], pk[0], pk[1], ppsi, pmc, nm, n.bit_length() - 1, fmt,
-                          sx[0], sx[1], sx[2], sk[0], sk[1], 1, 1)
+    kernarg = struct.pack("<9Q8i2I", po[0], po[1], px[0], px[1], px[2], pk[0], pk[1], ppsi, pmc, nm, n.bit_length() - 1, fmt,
+                          sx[0], sx[1], sx[2], sk[0], sk[1], batch, ((1 << 32) // nm + 1) if remap else 0)
     with open(asm_path) as f:
         text = f.read()
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
-    run_kernel(text, mem, kernarg, (batch, nm), lds, waves_per_wg=4)
+    run_kernel(text, mem, kernarg, (nm * 8 * ((batch + 7) // 8), 1) if remap else (batch, nm), lds, waves_per_wg=4)
     res = []
     for i in range(nouts):
         out, _ = mem.find(po[i], outs[i].nbytes)

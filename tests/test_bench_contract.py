@@ -88,3 +88,50 @@ def test_two_rank_launch_line_of_the_driver():
     sg = d["scatter_gather"]
     assert sg["polymul_per_s_incl_scatter_gather"] > 0 and sg["bytes_moved"] == 3 * 512 * 4 * 4096 * 8
     assert d["config"]["self_check"] is True
+
+
+@pytest.mark.gpu
+def test_plain_gpus_n_launches_n_ranks_itself_or_refuses():
+    """`python bench.py --gpus 2` with NO launcher around it spawns the two ranks itself (torch.distributed.run on
+    127.0.0.1) and reports n_gpus 2 -- here on one device through the test knobs; without the knob, on a box with fewer
+    than N devices, it exits non-zero instead of printing an n_gpus the run did not have"""
+    import torch
+    env = dict(os.environ, NFLHIP_BENCH_BACKEND="gloo", NFLHIP_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl"]["world_size"] == 2 and d["config"]["global_batch"] == 1024
+    assert d["config"]["checksum_of_checksums"]["ok"] is True and d["config"]["checksum_of_checksums"]["shards"] == 2
+    if torch.cuda.device_count() < 2:
+        env.pop("NFLHIP_BENCH_ONE_DEVICE")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_headline_line_carries_sustained_independent_secondary_and_side_configs():
+    """workload B's line (what the driver records): `sustained` (the same launch held for seconds), `roofline.secondary`
+    priced at the hardware issue rate with the fitted figure labelled as such, and extras.configs with configs C and E
+    (polymul and CRT lift) timed and counter-measured inside the same run"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-budget", "1.0"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    sus = d["sustained"]
+    assert sus["unit"] == "polymul/s" and sus["seconds"] > 1.5 and 0 < sus["frac"] < 1 and sus["value"] > 0
+    sec = d["roofline"]["secondary"]
+    assert sec["peak"] == 1228.8 and abs(sec["frac"] - sec["achieved"] / sec["peak"]) < 1e-3
+    assert sec["model"]["kind"] == "fitted" and "peak_at_measured_clock" in sec["model"] and sec["opcode_grid"]["clock_GHz"] == 2.4
+    cfg = d["extras"]["configs"]
+    for wl in ("C", "E"):
+        c = cfg[wl]
+        assert "error" not in c, c
+        assert c["self_check"] is True and c["value"] > 0 and 0 < c["frac"] < 1 and c["traffic_ratio"] is not None and c["traffic_ratio"] > 0.98
+    assert cfg["E"]["crt_lift"]["value"] > 0 and cfg["E"]["crt_lift"]["limbs_per_coefficient"] == 30

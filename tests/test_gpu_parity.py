@@ -582,6 +582,34 @@ def test_large_host_pointer_calls_through_the_pinned_pipeline(lb, n, m, batches,
         assert np.array_equal(e.h_eval(prog, [ha, hb, hc]), e.to_host(e.eval(prog, [a, b, e.to_device(hc)]))), batch
 
 
+def test_concurrent_host_pointer_calls_on_two_contexts(engine_factory):
+    """Two host threads, each with its own context, inside the pinned pipeline at once (one thread per GPU of the batch
+    split; two ring types of one program): the process-wide pool of copying threads serves one job at a time, so neither
+    call sees the other's slices.  Every product against the resident path over the same words, several rounds."""
+    import threading
+    e1, e2 = engine_factory(64, 4096, 4), engine_factory(64, 4096, 2)
+    jobs = []
+    for e, batch in ((e1, 200), (e2, 330)):       # 3.1 and 2.6 chunks of 8 MiB per operand
+        a = e.fill_uniform(e.empty(batch), SEED + batch, 0)
+        b = e.fill_uniform(e.empty(batch), SEED + batch, 1)
+        jobs.append((e, e.to_host(a), e.to_host(b), e.to_host(e.polymul(a, b))))
+    errors = []
+
+    def worker(e, ha, hb, want):
+        try:
+            for _ in range(6):
+                if not np.array_equal(e.h_polymul(ha, hb), want):
+                    errors.append("a concurrent host-pointer product differs from the resident one")
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+
+
 @pytest.mark.parametrize("lb,n,m,batch", [(64, 131072, 2, 2), (64, 262144, 1, 1), (64, 1048576, 1, 1), (32, 16384, 2, 2)])
 def test_degrees_beyond_the_baseline_shapes(lb, n, m, batch, oracle_factory, engine_factory):
     """Up to params<uint64_t>::kMaxPolyDegree = 2^20 (params.hpp:98-99): two and more streaming passes around the

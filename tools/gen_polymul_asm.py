@@ -470,16 +470,18 @@ def tw_uniform_stage(em, vm, s, kreg, descending):
     return seq
 
 
-def tw_lane_stage(em, vm, s, vidx, kreg, descending):
+def tw_lane_stage(em, vm, s, vidx, kreg, descending, groups=None):
     """Per-lane twiddle records of sub-stage s.  Ascending (forward): index = (K << s) + (vidx << s) + g.
-    Descending (inverse, mirrored): index = (K << s) - 1 - (vidx << s) - g.  vidx: VGPR with B or t."""
+    Descending (inverse, mirrored): index = (K << s) - 1 - (vidx << s) - g.  vidx: VGPR with B or t.
+    groups: only these g (default: all 2^s)"""
     seq = 0
+    groups = range(1 << s) if groups is None else groups
     tw_base(em, kreg, s, descending)
     em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (V_TWO, s + 4, vidx))
     if "tw0" in ABLATE:
         em.valu("v_mov_b32_e32 v%d, 0" % (V_TWO,))
     if not descending:
-        for g in range(1 << s):
+        for g in groups:
             r = V_TW + 4 * tw_slot(s, g)
             seq = vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, V_TWO, S_BASE2, g * 16))
     else:
@@ -487,7 +489,7 @@ def tw_lane_stage(em, vm, s, vidx, kreg, descending):
         em.valu("v_mov_b32_e32 v%d, s85" % (V_TWA + 1,))
         em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (V_TWA, V_TWA, V_TWO), "vcc", None)
         em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (V_TWA + 1, V_TWA + 1), "vcc", "vcc")
-        for g in range(1 << s):
+        for g in groups:
             r = V_TW + 4 * tw_slot(s, g)
             seq = vm.load("global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (r, r + 3, vp(V_TWA), -g * 16))
     return seq
@@ -3165,7 +3167,7 @@ def build_pipe(logn=None, fused=False):
 # whole batch (a key), 1 = dense.  A forward input x is either full residue words (format 0: [nm][n] words in coefficient
 # form) or ONE signed integer per coefficient shared by all moduli (formats 1 / 2 / 3: int8 / int16 / int32 -- what the
 # samplers produce before they are spread over the moduli, core.hpp:230-277; x < 0 is expanded to p + x).
-# kernarg: out0 out1 x0 x1 x2 k0 k1 psi mc | nm logn fmt (4 bits per x) | strides x0 x1 x2 k0 k1 out0 out1
+# kernarg: out0 out1 x0 x1 x2 k0 k1 psi mc | nm logn fmt (4 bits per x) | strides x0 x1 x2 k0 k1 | count magic (prologue_fused)
 ARGS_FUSED = [("ptr", 8 * i) for i in range(9)] + [("i32", 72 + 4 * i) for i in range(10)]
 S_FMT, S_F = "s4", "s5"
 S_X2ROW, S_K0ROW, S_K1ROW, S_O1ROW = "s[54:55]", "s[96:97]", "s[98:99]", "s[100:101]"
@@ -3180,7 +3182,7 @@ def prologue_fused(em, vm, kind):
     R("s_load_dwordx16 s[56:71], s[0:1], 0x0")           # out0 out1 x0 x1 x2 k0 k1 psi
     R("s_load_dwordx2 s[12:13], s[0:1], 0x40")           # mc
     R("s_load_dwordx2 s[72:73], s[0:1], 0x48")           # nm, logn
-    R("s_load_dwordx8 s[76:83], s[0:1], 0x50")           # fmt, strides x0 x1 x2 k0 k1 out0 out1
+    R("s_load_dwordx8 s[76:83], s[0:1], 0x50")           # fmt, strides x0 x1 x2 k0 k1, count, magic
     em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))
     em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                     # B = t >> 4
     em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
@@ -3195,14 +3197,31 @@ def prologue_fused(em, vm, kind):
         em.valu("v_mov_b32_e32 v%d, 0" % (s + 15,))                                 # the persistent zero of ZP
     R("s_waitcnt lgkmcnt(0)")
     R("s_mov_b32 s14, s72")                              # nm
+    # workgroup -> (batch element, modulus).  magic = 0: the grid is (batch, nm).  Otherwise a 1-D grid of nm * 8 * ceil(count / 8)
+    # workgroups dealt so that the nm rows of one batch element run BACK TO BACK ON ONE XCD (workgroups go to the XCDs round-robin
+    # by linear index): L = 8 q + xcd, q = nm j + cm, element = 8 j + xcd -- the compact inputs the nm rows share are then
+    # fetched from HBM once, by that XCD's L2 (j = q / nm by one multiply: magic = 2^32 / nm + 1, exact below 2^32 / nm)
+    R("s_cmp_eq_u32 s83, 0")
+    R("s_cbranch_scc1 .Lplain_grid")
+    R("s_and_b32 s42, s2, 7")                            # xcd
+    R("s_lshr_b32 s43, s2, 3")                           # q
+    R("s_mul_hi_u32 s44, s43, s83")                      # j
+    R("s_mul_i32 s45, s44, s14")
+    R("s_sub_u32 s3, s43, s45")                          # cm
+    R("s_lshl_b32 s44, s44, 3")
+    R("s_add_u32 s2, s44, s42")                          # element
+    R("s_cmp_lt_u32 s2, s82")
+    R("s_cbranch_scc1 .Lplain_grid")
+    R("s_endpgm")                                        # padding of the last group of eight
+    em.lines.append(".Lplain_grid:")
     R("s_sub_u32 s88, s73, 12")                          # r = 0: rows of exactly 4096 words
     R("s_mov_b32 s89, 0")                                # blk
     R("s_mov_b32 %s, s76" % S_FMT)
     R("s_mov_b64 s[10:11], s[70:71]")                    # psi
 
     def word_row(dst, base, stride):
-        """s[dst:dst+1] = base + (((x * stride) * nm + y) << 15)"""
-        R("s_mul_i32 s42, s2, s%d" % stride)
+        """s[dst:dst+1] = base + (((x * stride) * nm + y) << 15); stride None = dense"""
+        R("s_mul_i32 s42, s2, s%d" % stride if stride is not None else "s_mov_b32 s42, s2")
         R("s_mul_hi_u32 s43, s42, s14")
         R("s_mul_i32 s42, s42, s14")
         R("s_add_u32 s42, s42, s3")
@@ -3232,12 +3251,12 @@ def prologue_fused(em, vm, kind):
 
     x_row(16, 60, 77, 0)                                 # x0 -> S_AROW
     x_row(18, 62, 78, 1)                                 # x1 -> S_BROW
-    word_row(20, 56, 82)                                 # out0 -> S_CROW
+    word_row(20, 56, None)                               # out0 -> S_CROW (results are dense)
     word_row(96, 66, 80)                                 # k0
     if kind == "enc2":
         x_row(54, 64, 79, 2)                             # x2
         word_row(98, 68, 81)                             # k1
-        word_row(100, 58, 83)                            # out1
+        word_row(100, 58, None)                          # out1
     # tw = psi + (cm << (logn + 4)); pass constants K (prologue())
     R("s_add_u32 s43, s88, 16")
     R("s_lshl_b32 s42, s3, s43")
@@ -3267,14 +3286,17 @@ def prologue_fused(em, vm, kind):
         seq = fused_x_loads(em, vm, V_B, S_BROW, 1, "x1")
         first = "F1"
     else:
-        seq = fused_lane_loads(em, vm, V_A, S_AROW)
-        seq = fused_lane_loads(em, vm, V_TW, S_K0ROW, stream=False)
-        seq = fused_lane_loads(em, vm, V_B, S_BROW)
+        # x0 and the key row first (the product needs them), x1 behind them; then the part of I1's first sub-stage that
+        # fits beside the key row (records g = 1..7 in slots 8..14; the key row occupies slots 0..7 until it is consumed)
+        fused_lane_loads(em, vm, V_A, S_AROW)
+        seq = (fused_lane_loads(em, vm, V_TW, S_K0ROW, stream=False)[-1], fused_lane_loads(em, vm, V_B, S_BROW))
         first = None
     tw_seq = {}
     if first:
         for s in (0, 1, 2, 3):
             tw_seq[(first, s)] = PASS_TW[first](em, vm, s)
+    else:
+        tw_seq[("I1", 3, "late")] = tw_lane_stage(em, vm, 3, V_TID, S_K["I1"], True, groups=range(1, 8))
     R("s_waitcnt lgkmcnt(0)")
     R("s_mov_b64 s[24:25], s[56:57]")                    # p
     R("s_mov_b64 s[26:27], s[58:59]")                    # 2p
@@ -3357,13 +3379,13 @@ def fused_lane_loads(em, vm, dst, srow, stream=True):
     step as long as all operands share it.  stream: a row nobody reads again (`nt`); the key row stays in the caches"""
     g, _ = lane_contig_setup(em)
     em.raw("s_mov_b64 s[86:87], %s" % (srow,))
-    seq = 0
+    seqs = []
     for j in range(16):
-        seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d%s" % (vp(dst + 2 * j), g, (j & 7) * 512, " nt" if stream else ""))
+        seqs.append(vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d%s" % (vp(dst + 2 * j), g, (j & 7) * 512, " nt" if stream else "")))
         if j == 7:
             em.raw("s_add_u32 s86, s86, 0x1000")
             em.raw("s_addc_u32 s87, s87, 0")
-    return seq
+    return seqs
 
 
 def fma_job(k, a, b, fold_a):
@@ -3481,10 +3503,14 @@ def build_fused(kind):
         return em
 
     # ---- fms_inv / fma_inv: point-wise step in the loaded (lane-contiguous) layout, then the inverse passes of build_body
-    vm.wait(seq_x)
-    em.comment("x1 -+ x0 * k0")
-    run_pairs(em, [fms_job(V_A + 2 * i, V_K + 2 * i, V_B + 2 * i, kind == "fms_inv") for i in range(16)])
-    for s in (3, 2, 1, 0):
+    seq_k, seq_b = seq_x
+    vm.wait(seq_k)
+    em.comment("x1 -+ x0 * k0 (x1 is consumed word by word as it lands)")
+    for i in range(0, 16, 2):
+        vm.wait(seq_b[i + 1])
+        run_pairs(em, [fms_job(V_A + 2 * j, V_K + 2 * j, V_B + 2 * j, kind == "fms_inv") for j in (i, i + 1)])
+    tw_seq[("I1", 3)] = tw_lane_stage(em, vm, 3, V_TID, S_K["I1"], True, groups=(0,))   # the record the key row was in the way of
+    for s in (2, 1, 0):
         tw_seq[("I1", s)] = PASS_TW["I1"](em, vm, s)
     em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
     _, l = lane_contig_setup(em)
@@ -3492,11 +3518,19 @@ def build_fused(kind):
         R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
     lds_read(em, V_L2R, V_A, 8)
     R("s_waitcnt lgkmcnt(0)")
-    inverse_half(em, vm, tw_seq)
+
+    def first_stage():
+        """I1's sub-stage 3 with the late record's butterfly last: groups 1..7 run on the records fetched beside the key row"""
+        jobs = [gs_bfly(V_A + 4 * g, V_A + 4 * g + 2, twreg(tw_slot(3, g))) for g in (1, 2, 3, 4, 5, 6, 7, 0)]
+        vm.wait(tw_seq[("I1", 3, "late")])
+        run_pairs(em, jobs[:6])
+        vm.wait(tw_seq[("I1", 3)])
+        run_pairs(em, jobs[6:])
+    inverse_half(em, vm, tw_seq, first_stage)
     return em
 
 
-def inverse_half(em, vm, tw_seq):
+def inverse_half(em, vm, tw_seq, first_stage=None):
     """I1 E2' I2 E1' I3 and the merged last stage over V_A (thread-contiguous words in), store to S_CROW"""
     R = em.raw
     order = ["I1", "I2", "I3"]
@@ -3504,8 +3538,11 @@ def inverse_half(em, vm, tw_seq):
         nxt = order[order.index(name) + 1] if name != "I3" else None
         em.comment("%s%s" % (name, "; prefetching " + nxt if nxt else ""))
         for s in ((3, 2, 1, 0) if name != "I3" else (3, 2, 1)):
-            vm.wait(tw_seq[(name, s)])
-            gs_stage(em, V_A, s)
+            if name == "I1" and s == 3 and first_stage is not None:
+                first_stage()
+            else:
+                vm.wait(tw_seq[(name, s)])
+                gs_stage(em, V_A, s)
             if nxt is not None:
                 tw_seq[(nxt, s)] = PASS_TW[nxt](em, vm, s)
         if name == "I1":
