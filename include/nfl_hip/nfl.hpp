@@ -229,6 +229,59 @@ inline void check(nflhip_ctx *ctx, int rc, const char *what) {
   if (rc != NFLHIP_OK) throw std::runtime_error(std::string("nfl(hip): ") + what + ": " + nflhip_last_error(ctx));
 }
 
+// CHECK_STRICTMOD (debug.hpp:21-37): the reference's ASSERT_STRICTMOD is assert(), i.e. active when the macro is defined and
+// NDEBUG is not -- how its own tests are built (tests/CMakeLists.txt:10).  It asserts x < p on what goes INTO the
+// transforms (core.hpp:457-462) and into addmod / submod / mulmod / mulmod_shoup (ops.hpp:131,148,190,211,235).  Here the
+// same operands are checked where an operation is issued -- host words on the host, resident values by one streaming
+// compare on the device (nflhip_check_range[_dev]) -- and a violation throws std::runtime_error, this header's error
+// convention, instead of aborting.  The Shoup companion b' of mulmod_shoup is a quotient, not a residue: exempt.
+#if defined(CHECK_STRICTMOD) && !defined(NDEBUG)
+static constexpr bool strictmod = true;
+#else
+static constexpr bool strictmod = false;
+#endif
+inline void strict_fail(const char *what) {
+  throw std::runtime_error(std::string("nfl(hip): CHECK_STRICTMOD: ") + what + ": an operand word is not below its modulus");
+}
+inline void strict_host(nflhip_ctx *ctx, const void *words, size_t polys, const char *what) {
+  int bad = 0;
+  check(ctx, nflhip_check_range(ctx, words, polys, &bad), what);
+  if (bad) strict_fail(what);
+}
+inline void strict_dev(nflhip_ctx *ctx, const void *d, size_t polys, void *stream, const char *what) {
+  int bad = 0;
+  check(ctx, nflhip_check_range_dev(ctx, d, polys, &bad, stream), what);
+  if (bad) strict_fail(what);
+}
+// operands of a postfix program that are only ever consumed as the Shoup companion of a mulmod_shoup (bit k = operand k)
+inline unsigned strict_exempt(const unsigned char *code, size_t len) {
+  int leaf[NFLHIP_EXPR_MAX_LEN + 1];
+  int sp = 0;
+  unsigned as_companion = 0, as_value = 0;
+  for (size_t q = 0; q < len; ++q) {
+    const unsigned char b = code[q];
+    if (b < NFLHIP_EXPR_MAX_OPERANDS) {
+      leaf[sp++] = int(b);
+    } else if (b == NFLHIP_EXPR_MUL_SHOUP && sp >= 3) {
+      if (leaf[sp - 1] >= 0) as_companion |= 1u << leaf[sp - 1];
+      for (int k = 2; k <= 3; ++k)
+        if (leaf[sp - k] >= 0) as_value |= 1u << leaf[sp - k];
+      sp -= 2;
+      leaf[sp - 1] = -1;
+    } else if (b == NFLHIP_EXPR_COMPUTE_SHOUP && sp >= 1) {
+      if (leaf[sp - 1] >= 0) as_value |= 1u << leaf[sp - 1];
+      leaf[sp - 1] = -1;
+    } else if (sp >= 2) {
+      for (int k = 1; k <= 2; ++k)
+        if (leaf[sp - k] >= 0) as_value |= 1u << leaf[sp - k];
+      --sp;
+      leaf[sp - 1] = -1;
+    }
+  }
+  if (sp == 1 && leaf[0] >= 0) as_value |= 1u << leaf[0];   // (a bare copy)
+  return as_companion & ~as_value;
+}
+
 // Every ring type whose per-polynomial operations can be deferred (detail::lazy<P> below) registers the function that
 // runs its queue.  Whoever is about to invalidate something recorded operations refer to -- a FastGaussianNoise that
 // dies (its device tables), nfl::set_sampler_key (the key recorded draws will be made with) -- runs all queues first.
@@ -593,10 +646,12 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   // levelling scratch of lazy<P>::flush (valid when `epoch` is the current flush): last level that writes / reads this value
   unsigned epoch;
   int wlev, rlev;
+  int fw;  // scratch of lazy<P>::fuse (valid when `epoch` is the current flush): the recorded operation that last wrote this value
+  unsigned pin_at;  // where the queue's reference to this payload sits in its pin list (valid while qrefs is set / during that run)
 
-  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {}
+  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0) {}
   payload(const payload &o) : std::enable_shared_from_this<payload<P>>(), host(nullptr), dev(nullptr), host_valid(false),
-                              dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1) {
+                              dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0) {
     pending();
     o.usable();
     if (o.dev_valid) {  // stays on the device
@@ -718,7 +773,8 @@ template <class P> struct lazy {
   typedef typename pay_t::ctx_t ctx_t;
   typedef typename P::value_type T;
   typedef std::shared_ptr<pay_t> ptr_t;
-  enum kind_t { K_EVAL = 0, K_NTT_FWD, K_NTT_INV, K_SAMPLE, K_GAUSS, K_FILL };
+  // K_FWD_FMA / K_FMA_INV / K_NOP are never recorded: a queue run rewrites recorded sequences into them (fuse())
+  enum kind_t { K_EVAL = 0, K_NTT_FWD, K_NTT_INV, K_SAMPLE, K_GAUSS, K_FILL, K_FWD_FMA, K_FMA_INV, K_NOP };
   // One recorded operation: 72 bytes, trivially destructible.  The payloads it names are kept alive by ONE reference per
   // payload and queue run (`pins`), not one per mention -- a loop's temporaries are mentioned three times each.
   static constexpr int max_in = 4;  // expressions with more distinct handle operands are launched at once, not recorded
@@ -734,6 +790,13 @@ template <class P> struct lazy {
         const nflhip_gauss *tab;
         int dist;
       } s;          // K_SAMPLE, K_GAUSS, K_FILL
+      struct {
+        pay_t *in[max_in];     // the key operands k0 [, k1] (same place as e.in: the levelling reads them through it)
+        pay_t *out2;           // second result (out1 = NTT(x) * k1 + NTT(e1)), or nullptr
+        uint64_t sid[3];       // stream ids of the Gaussian polynomials x, e0, e1
+        uint32_t amp[3];       // their amplifiers
+        const nflhip_gauss *tab;
+      } f;          // K_FWD_FMA
     };
     unsigned char kind, nin, len;
   };
@@ -757,12 +820,15 @@ template <class P> struct lazy {
     static const bool v = getenv("NFL_HIP_EARLY_RUN") && atoi(getenv("NFL_HIP_EARLY_RUN")) != 0;
     return v;
   }
-  lazy() : launches(0), coalesced(0) {
+  lazy() : launches(0), coalesced(0), small_(nullptr), small_cap_(0), fused_fwd(0), fused_inv(0) {
     ctx_t::inst();  // (the context is constructed first, so it is destroyed last)
     alive() = true;
     queue_registry::get().add(&lazy::run_if_alive);
   }
-  ~lazy() { alive() = false; }
+  ~lazy() {
+    alive() = false;
+    if (small_ && ctx_t::alive()) nflhip_free(ctx_t::get(), small_);
+  }
   static bool &alive() {
     static bool a = false;
     return a;
@@ -780,7 +846,210 @@ template <class P> struct lazy {
     if (a.kind == K_EVAL) return a.len == b.len && a.nin == b.nin && std::memcmp(a.e.code, b.e.code, a.len) == 0;
     if (a.kind == K_SAMPLE || a.kind == K_GAUSS) return a.s.dist == b.s.dist && a.s.p0 == b.s.p0 && a.s.p1 == b.s.p1 && a.s.tab == b.s.tab;
     if (a.kind == K_FILL) return a.s.sid == b.s.sid;
+    if (a.kind == K_FWD_FMA)
+      return a.nin == b.nin && a.f.tab == b.f.tab && a.f.amp[0] == b.f.amp[0] && a.f.amp[1] == b.f.amp[1] && a.f.amp[2] == b.f.amp[2];
+    if (a.kind == K_FMA_INV) return a.e.code[0] == b.e.code[0];
     return true;
+  }
+  // ---- transform fusion.  Code written against the reference transforms, combines, transforms back:
+  //        u.ntt_pow_phi(); e.ntt_pow_phi(); r = u * key + e;          out = rb - ra * s; out.invntt_pow_invphi();
+  // (tests/nfllib_demo_main_op.cpp:26-58).  When this context runs such a sequence as ONE kernel (nflhip_has_fused_kernels),
+  // a queue run rewrites what it recorded before it levels it:
+  //   * K_GAUSS x, K_NTT_FWD x, K_GAUSS e, K_NTT_FWD e, K_EVAL r = x * k + e (either operand order; a second K_EVAL on the
+  //     same x with its own k, e joins) -> K_FWD_FMA, provided nothing else reads the sampled or transformed x / e and
+  //     their handles are gone (the queue holds the last reference): those polynomials then never exist in HBM -- the
+  //     samplers write one byte per coefficient (nflhip_sample_gauss_small_seq_dev) and the kernel transforms in registers;
+  //   * K_EVAL t = c +- a * b, K_NTT_INV t with nothing reading t in between -> K_FMA_INV.
+  // Results are bit-identical to the operator-by-operator run.  NFL_HIP_NO_FUSION=1 switches the rewriting off.
+  static bool fusion_on() {
+    static const bool v = !getenv("NFL_HIP_NO_FUSION") && nflhip_has_fused_kernels(ctx_t::get()) != 0;
+    return v;
+  }
+  // c +- a * b as a 5-byte postfix program over three distinct operands: {a, b, c, subtract}, or false
+  static bool parse_fma(const op &o, int &a, int &b, int &c, bool &sub) {
+    if (o.kind != K_EVAL || o.len != 5 || o.nin != 3) return false;
+    const unsigned char *q = o.e.code;
+    if (q[0] < 3 && q[1] < 3 && q[2] == NFLHIP_EXPR_MUL && q[3] < 3 && q[4] == NFLHIP_EXPR_ADD) {            // a b * c +
+      a = q[0]; b = q[1]; c = q[3]; sub = false;
+    } else if (q[0] < 3 && q[1] < 3 && q[2] < 3 && q[3] == NFLHIP_EXPR_MUL && (q[4] == NFLHIP_EXPR_ADD || q[4] == NFLHIP_EXPR_SUB)) {  // c a b * +-
+      c = q[0]; a = q[1]; b = q[2]; sub = q[4] == NFLHIP_EXPR_SUB;
+    } else {
+      return false;
+    }
+    return a != b && a != c && b != c;
+  }
+  static bool mentions(const op &o, const pay_t *p) {
+    if (o.kind == K_NOP) return false;
+    if (o.out == p || (o.kind == K_FWD_FMA && o.f.out2 == p)) return true;
+    if (o.kind == K_EVAL || o.kind == K_FWD_FMA || o.kind == K_FMA_INV)
+      for (int j = 0; j < o.nin; ++j)
+        if (o.e.in[j] == p) return true;
+    return false;
+  }
+  // compact Gaussian polynomials of a fused run live in ONE grow-only device buffer (every consumer is on the queue's stream)
+  void *small_;
+  size_t small_cap_;
+  void *small_buffer(size_t bytes) {
+    if (bytes > small_cap_) {
+      nflhip_ctx *c = ctx_t::get();
+      if (small_) {
+        check(c, nflhip_stream_sync(c, ctx_t::queue()), "compact sampler buffer");   // (its last readers)
+        nflhip_free(c, small_);
+        small_ = nullptr;
+        small_cap_ = 0;
+      }
+      size_t cap = size_t(1) << 20;
+      while (cap < bytes) cap *= 2;
+      check(c, nflhip_malloc(c, &small_, cap), "compact sampler buffer");
+      small_cap_ = cap;
+    }
+    return small_;
+  }
+  // the narrowest compact format that holds every sample of `tab` times `amp` (NFLHIP_FMT_I8 / I16 / I32; 99 = none)
+  static int small_format(const nflhip_gauss *tab, uint32_t amp) {
+    struct last_t { const nflhip_gauss *tab; uint64_t mag; };
+    static thread_local last_t last = {nullptr, 0};
+    if (last.tab != tab) {
+      long long x_min = 0;
+      size_t entries = 0;
+      check(ctx_t::get(), nflhip_gauss_info(tab, &x_min, &entries, nullptr, nullptr, nullptr, nullptr), "gaussian table");
+      const long long hi = x_min + (long long)entries - 1;
+      last.tab = tab;
+      last.mag = uint64_t(std::max(x_min < 0 ? -x_min : x_min, hi < 0 ? -hi : hi));
+    }
+    const uint64_t v = last.mag * uint64_t(amp);
+    return v <= 127 ? NFLHIP_FMT_I8 : v <= 32767 ? NFLHIP_FMT_I16 : v <= 2147483647ull ? NFLHIP_FMT_I32 : 99;
+  }
+  size_t fused_fwd, fused_inv;  // statistics: sequences rewritten so far
+  void fuse(std::vector<op> &ops, const std::vector<ptr_t> &held, unsigned ep) {
+    const int n = int(ops.size());
+    if (n < 2 || !fusion_on()) return;
+    // definitions: prev[i] = the operation that wrote ops[i].out before i (what an in-place transform reads), def[i][j] =
+    // the one that wrote input j of an expression; uses[d] = reads of the value operation d wrote; -1 = from before this run
+    std::vector<int> prev(size_t(n), -1), uses(size_t(n), 0), def(size_t(n) * 3, -1);
+    auto touch = [ep](pay_t *p) {
+      if (p->epoch != ep) {
+        p->epoch = ep;
+        p->wlev = p->rlev = -1;
+        p->fw = -1;
+      }
+    };
+    bool any_fwd = false, any_inv = false;
+    for (int i = 0; i < n; ++i) {
+      op &o = ops[size_t(i)];
+      if (o.kind == K_EVAL)
+        for (int j = 0; j < o.nin; ++j) {
+          touch(o.e.in[j]);
+          const int d = o.e.in[j]->fw;
+          if (j < 3) def[size_t(i) * 3 + size_t(j)] = d;
+          if (d >= 0) ++uses[size_t(d)];
+        }
+      touch(o.out);
+      prev[size_t(i)] = o.out->fw;
+      if ((o.kind == K_NTT_FWD || o.kind == K_NTT_INV) && o.out->fw >= 0) ++uses[size_t(o.out->fw)];
+      o.out->fw = i;
+      any_fwd |= o.kind == K_NTT_FWD;
+      any_inv |= o.kind == K_NTT_INV;
+    }
+    // the value an operation wrote is still its payload's at the end of the run: only fusable away when no handle is left
+    auto dead_after = [&](int d) {
+      pay_t *p = ops[size_t(d)].out;
+      return p->fw != d || held[p->pin_at].use_count() == 1;   // (the queue's pin is the last reference)
+    };
+    // a sampled-and-transformed polynomial nobody else sees: -> index of its K_GAUSS record, or -1
+    auto gauss_chain = [&](int dn, int want_uses) {
+      if (dn < 0 || ops[size_t(dn)].kind != K_NTT_FWD || uses[size_t(dn)] != want_uses || !dead_after(dn)) return -1;
+      const int g = prev[size_t(dn)];
+      if (g < 0 || ops[size_t(g)].kind != K_GAUSS || uses[size_t(g)] != 1 || (ops[size_t(g)].s.p1 >> 32) != 0) return -1;
+      if (small_format(ops[size_t(g)].s.tab, uint32_t(ops[size_t(g)].s.p1)) > NFLHIP_FMT_I32) return -1;
+      return g;
+    };
+    if (any_inv)
+      for (int i = 0; i < n; ++i) {
+        op &t = ops[size_t(i)];
+        if (t.kind != K_NTT_INV) continue;
+        const int d = prev[size_t(i)];
+        int a, b, c;
+        bool sub;
+        if (d < 0 || i - d > 4 || uses[size_t(d)] != 1 || !parse_fma(ops[size_t(d)], a, b, c, sub)) continue;
+        op &e = ops[size_t(d)];
+        bool clean = true;   // nothing between the two rewrites an operand (the fused operation reads them at i, not at d)
+        for (int k = d + 1; k < i && clean; ++k)
+          clean = ops[size_t(k)].kind == K_NOP || (ops[size_t(k)].out != e.e.in[0] && ops[size_t(k)].out != e.e.in[1] && ops[size_t(k)].out != e.e.in[2]);
+        if (!clean) continue;
+        pay_t *pc = e.e.in[c], *pa = e.e.in[a], *pb = e.e.in[b];
+        t.kind = K_FMA_INV;
+        t.nin = 3;
+        t.len = 1;
+        t.e.in[0] = pc;
+        t.e.in[1] = pa;
+        t.e.in[2] = pb;
+        t.e.code[0] = sub ? 1 : 0;
+        e.kind = K_NOP;
+        ++fused_inv;
+      }
+    if (!any_fwd) return;
+    // forward: candidates per transformed x (an expression names it once; a second expression on the same x joins)
+    struct cand { int i, xs, ks, es, gx, ge; };
+    std::vector<cand> cands;
+    for (int i = 0; i < n; ++i) {
+      int a, b, c;
+      bool sub;
+      if (!parse_fma(ops[size_t(i)], a, b, c, sub) || sub) continue;
+      for (int turn = 0; turn < 2; ++turn) {
+        const int xs = turn ? b : a, ks = turn ? a : b;
+        const int dx = def[size_t(i) * 3 + size_t(xs)], de = def[size_t(i) * 3 + size_t(c)];
+        if (dx < 0 || de < 0 || dx == de) continue;
+        const int ux = uses[size_t(dx)];
+        if (ux != 1 && ux != 2) continue;
+        const int gx = gauss_chain(dx, ux), ge = gauss_chain(de, 1);
+        if (gx < 0 || ge < 0 || ops[size_t(gx)].s.tab != ops[size_t(ge)].s.tab) continue;
+        cands.push_back(cand{i, xs, ks, c, gx, ge});
+        break;
+      }
+    }
+    for (size_t q = 0; q < cands.size(); ++q) {
+      const cand &c0 = cands[q];
+      if (c0.i < 0) continue;
+      const int dx = def[size_t(c0.i) * 3 + size_t(c0.xs)];
+      const cand *c1 = nullptr;
+      if (uses[size_t(dx)] == 2) {   // the other reader of NTT(x) must be a candidate too, close by, and independent of this one
+        for (size_t r = q + 1; r < cands.size() && !c1; ++r)
+          if (cands[r].i >= 0 && def[size_t(cands[r].i) * 3 + size_t(cands[r].xs)] == dx) c1 = &cands[r];
+        if (!c1 || c1->i - c0.i > 4) continue;
+        const op &e0 = ops[size_t(c0.i)], &e1 = ops[size_t(c1->i)];
+        bool clean = e1.e.in[c1->ks] != e0.out && e1.out != e0.out;   // (the fused operation writes both results at e1's place)
+        for (int k = c0.i + 1; k < c1->i && clean; ++k)
+          clean = !mentions(ops[size_t(k)], e0.out) && (ops[size_t(k)].kind == K_NOP || ops[size_t(k)].out != e0.e.in[c0.ks]);
+        if (!clean) continue;
+      }
+      const op e0 = ops[size_t(c0.i)];
+      op &t = ops[size_t(c1 ? c1->i : c0.i)];
+      const op e1 = t;
+      const op &gx = ops[size_t(c0.gx)], &g0 = ops[size_t(c0.ge)];
+      t.kind = K_FWD_FMA;
+      t.out = e0.out;
+      t.nin = c1 ? 2 : 1;
+      t.len = 0;
+      t.f.in[0] = e0.e.in[c0.ks];
+      t.f.in[1] = c1 ? e1.e.in[c1->ks] : nullptr;
+      t.f.in[2] = t.f.in[3] = nullptr;
+      t.f.out2 = c1 ? e1.out : nullptr;
+      t.f.tab = gx.s.tab;
+      t.f.sid[0] = gx.s.sid;
+      t.f.amp[0] = uint32_t(gx.s.p1);
+      t.f.sid[1] = g0.s.sid;
+      t.f.amp[1] = uint32_t(g0.s.p1);
+      t.f.sid[2] = c1 ? ops[size_t(c1->ge)].s.sid : 0;
+      t.f.amp[2] = c1 ? uint32_t(ops[size_t(c1->ge)].s.p1) : 0;
+      // the records the fused operation stands for
+      const int gone[] = {c0.gx, dx, c0.ge, def[size_t(c0.i) * 3 + size_t(c0.es)], c1 ? c0.i : -1, c1 ? c1->ge : -1,
+                          c1 ? def[size_t(c1->i) * 3 + size_t(c1->es)] : -1};
+      for (int g : gone)
+        if (g >= 0) ops[size_t(g)].kind = K_NOP;
+      if (c1) const_cast<cand *>(c1)->i = -1;
+      ++fused_fwd;
+    }
   }
   // whether this ring's operations can be deferred at all: dense chunks, vectors of 16 bytes, sequence samplers
   static bool usable() {
@@ -810,6 +1079,7 @@ template <class P> struct lazy {
   // the queue's reference to a payload (taken the first time a queue run's operations mention it)
   void pin(pay_t *p) {
     if (!p->qrefs) {
+      p->pin_at = unsigned(pins.size());
       pins.push_back(p->shared_from_this());
       p->qrefs = 1;
     }
@@ -881,9 +1151,15 @@ template <class P> struct lazy {
         p->wlev = p->rlev = -1;
       }
     };
+    fuse(ops, held, ep);   // (tags the payloads it sees with this flush's epoch: wlev / rlev start at -1 either way)
     std::vector<int> lvl(ops.size(), 0);
     for (size_t i = 0; i < ops.size(); ++i) {
       op &o = ops[i];
+      if (o.kind == K_NOP) {   // its work moved into a fused operation
+        lvl[i] = -1;
+        launched[i] = 1;
+        continue;
+      }
       int L = 0;
       for (int j = 0; j < o.nin; ++j) {
         touch(o.e.in[j]);
@@ -891,8 +1167,14 @@ template <class P> struct lazy {
       }
       touch(o.out);
       L = std::max(L, std::max(o.out->wlev, o.out->rlev) + 1);
+      pay_t *out2 = o.kind == K_FWD_FMA ? o.f.out2 : nullptr;
+      if (out2) {
+        touch(out2);
+        L = std::max(L, std::max(out2->wlev, out2->rlev) + 1);
+      }
       lvl[i] = L;
       o.out->wlev = L;
+      if (out2) out2->wlev = L;
       for (int j = 0; j < o.nin; ++j) o.e.in[j]->rlev = std::max(o.e.in[j]->rlev, L);
       if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) o.out->rlev = std::max(o.out->rlev, L);
     }
@@ -908,8 +1190,13 @@ template <class P> struct lazy {
     static_assert(NFLHIP_EXPR_MAX_LEN <= 24, "the program is hashed as three words");
     for (size_t i = 0; i < ops.size(); ++i) {
       const op &o = ops[i];
+      if (o.kind == K_NOP) continue;
       uint64_t h = mix(0xcbf29ce484222325ull, uint64_t(o.kind));
-      if (o.kind == K_EVAL) {
+      if (o.kind == K_FWD_FMA) {
+        h = mix(mix(mix(h, uint64_t(reinterpret_cast<uintptr_t>(o.f.tab))), (uint64_t(o.f.amp[0]) << 32) | o.f.amp[1]), (uint64_t(o.f.amp[2]) << 8) | o.nin);
+      } else if (o.kind == K_FMA_INV) {
+        h = mix(h, o.e.code[0]);
+      } else if (o.kind == K_EVAL) {
         uint64_t w[3] = {0, 0, 0};
         std::memcpy(w, o.e.code, size_t(o.len));
         h = mix(mix(mix(mix(h, w[0]), w[1]), w[2]), (uint64_t(o.len) << 8) | uint64_t(o.nin));
@@ -974,6 +1261,16 @@ template <class P> struct lazy {
         ctx_t::acquire_many(need.size(), bufs.data());
         for (size_t k = 0; k < need.size(); ++k) ops[need[k]].out->dev = bufs[k];
       }
+      if (kind == K_FWD_FMA) {   // the second results: a dense array of their own
+        need.clear();
+        for (size_t i : idx)
+          if (ops[i].f.out2 && !ops[i].f.out2->dev) need.push_back(i);
+        if (!need.empty()) {
+          std::vector<void *> bufs(need.size());
+          ctx_t::acquire_many(need.size(), bufs.data());
+          for (size_t k = 0; k < need.size(); ++k) ops[need[k]].f.out2->dev = bufs[k];
+        }
+      }
       if (kind == K_NTT_FWD || kind == K_NTT_INV) {
         // in place, mutually independent: any order -- by address, so that neighbours become one dense batch
         std::vector<char *> ptr;
@@ -1031,7 +1328,8 @@ template <class P> struct lazy {
         }
         continue;
       }
-      // ---- K_EVAL: operands that are one polynomial for (almost) the whole group split it; then stride runs
+      // ---- K_EVAL (and the fused kinds, whose operands sit in the same slots): operands that are one polynomial for
+      // (almost) the whole group split it; then stride runs
       const int nin = ops[idx[0]].nin;
       // a "key" slot holds one of a few polynomials throughout the group (at most 8, and at most every eighth operation a
       // new one); each combination of keys becomes its own sub-group, whose other operands then advance by strides
@@ -1071,6 +1369,63 @@ template <class P> struct lazy {
       }
       for (auto &sv : sub) {
         std::vector<size_t> &sidx = sv.idx;
+        if (kind == K_FWD_FMA) {
+          // program order; a run = consecutive result buffers (both results), keys at constant strides, stream ids of
+          // every Gaussian operand in arithmetic progression: the samplers' compact outputs and ONE fused launch
+          const bool two = nin == 2;
+          const int nx = two ? 3 : 2;
+          for (size_t a = 0; a < sidx.size();) {
+            const op &o0 = ops[sidx[a]];
+            size_t kstride[2] = {0, 0};
+            uint64_t sstride[3] = {0, 0, 0};
+            size_t b = a + 1;
+            while (b < sidx.size()) {
+              const op &prev = ops[sidx[b - 1]], &cur = ops[sidx[b]];
+              bool ok = static_cast<char *>(cur.out->dev) == static_cast<char *>(prev.out->dev) + ctx_t::chunk_bytes &&
+                        (!two || static_cast<char *>(cur.f.out2->dev) == static_cast<char *>(prev.f.out2->dev) + ctx_t::chunk_bytes);
+              for (int j = 0; j < nin && ok; ++j) {
+                const ptrdiff_t d = static_cast<char *>(cur.f.in[j]->dev) - static_cast<char *>(prev.f.in[j]->dev);
+                if (d < 0 || d % ptrdiff_t(ctx_t::chunk_bytes)) ok = false;
+                else if (b == a + 1) kstride[j] = size_t(d) / ctx_t::chunk_bytes;
+                else if (size_t(d) != kstride[j] * ctx_t::chunk_bytes) ok = false;
+              }
+              for (int j = 0; j < nx && ok; ++j) {
+                const uint64_t d = cur.f.sid[j] - prev.f.sid[j];
+                if (b == a + 1) sstride[j] = d;
+                else if (d != sstride[j]) ok = false;
+              }
+              if (!ok) break;
+              ++b;
+            }
+            const size_t cnt = b - a;
+            int fmt = NFLHIP_FMT_I8;
+            for (int j = 0; j < nx; ++j) fmt = std::max(fmt, small_format(o0.f.tab, o0.f.amp[j]));
+            const size_t es = fmt == NFLHIP_FMT_I8 ? 1 : fmt == NFLHIP_FMT_I16 ? 2 : 4, each = (cnt * P::degree * es + 255) / 256 * 256;
+            char *buf = static_cast<char *>(small_buffer(each * size_t(nx)));
+            nflhip_operand x[3], k[2];
+            for (int j = 0; j < nx; ++j) {
+              check(ctx, nflhip_sample_gauss_small_seq_dev(ctx, buf + each * size_t(j), fmt, cnt, o0.f.tab, o0.f.amp[j], smp.key, o0.f.sid[j],
+                                                           sstride[j], st), "deferred set(gaussian), compact");
+              x[j].ptr = buf + each * size_t(j);
+              x[j].stride = 1;
+              x[j].format = fmt;
+              ++launches;
+            }
+            for (int j = 0; j < nin; ++j) {
+              k[j].ptr = o0.f.in[j]->dev;
+              k[j].stride = cnt > 1 ? kstride[j] : 0;
+              k[j].format = NFLHIP_FMT_WORDS;
+            }
+            check(ctx, two ? nflhip_fwd_fma2_dev(ctx, o0.out->dev, o0.f.out2->dev, &x[0], &k[0], &x[1], &k[1], &x[2], cnt, st)
+                           : nflhip_fwd_fma_dev(ctx, o0.out->dev, &x[0], &k[0], &x[1], cnt, st),
+                  "deferred transform + multiply-add");
+            for (size_t q = a; q < b; ++q) launched[sidx[q]] = 1;
+            ++launches;
+            coalesced += cnt * (two ? 8 : 5);   // (the operations the run's members were recorded as)
+            a = b;
+          }
+          continue;
+        }
         {  // by destination address (program order among equals); a loop's results already are in that order
           bool sorted = true;
           for (size_t k = 1; k < sidx.size() && sorted; ++k) sorted = !(ops[sidx[k]].out->dev < ops[sidx[k - 1]].out->dev);
@@ -1085,6 +1440,7 @@ template <class P> struct lazy {
             bool ok = true;
             const ptrdiff_t od = static_cast<char *>(cur.out->dev) - static_cast<char *>(prev.out->dev);
             if (od <= 0 || od % ptrdiff_t(ctx_t::chunk_bytes)) break;
+            if (kind == K_FMA_INV && size_t(od) != ctx_t::chunk_bytes) break;   // (the fused entry writes dense results)
             if (b == a + 1) ostride = size_t(od) / ctx_t::chunk_bytes;
             else if (size_t(od) != ostride * ctx_t::chunk_bytes) break;
             for (int j = 0; j < nin && ok; ++j) {
@@ -1099,7 +1455,16 @@ template <class P> struct lazy {
           const size_t cnt = b - a;
           const void *d[NFLHIP_EXPR_MAX_OPERANDS];
           for (int j = 0; j < nin; ++j) d[j] = o0.e.in[j]->dev;
-          if (cnt == 1) {
+          if (kind == K_FMA_INV) {   // in[0] +- in[1] * in[2], then the inverse transform: one launch
+            nflhip_operand w[3];
+            for (int j = 0; j < 3; ++j) {
+              w[j].ptr = d[j];
+              w[j].stride = cnt > 1 ? stride[j] : 0;
+              w[j].format = NFLHIP_FMT_WORDS;
+            }
+            check(ctx, nflhip_fma_inv_dev(ctx, o0.out->dev, &w[1], &w[2], &w[0], o0.e.code[0], cnt, st), "deferred multiply-add + inverse transform");
+            coalesced += cnt;   // (two recorded operations per member)
+          } else if (cnt == 1) {
             check(ctx, nflhip_eval_dev(ctx, o0.out->dev, d, size_t(nin), o0.e.code, size_t(o0.len), 1, st), "deferred operator=(expr)");
           } else {
             check(ctx, nflhip_eval_strided_dev(ctx, o0.out->dev, ostride, d, stride, size_t(nin), o0.e.code, size_t(o0.len), cnt, st),
@@ -1222,6 +1587,14 @@ template <class Op, class... Args> struct expr {
     if (!pr.ok || opcode<Op>::value < 0) return false;
     typedef typename payload_type::ctx_t ctx_t;
     if (degree * sizeof(value_type) < 16) return false;  // (rows shorter than one 16-byte vector: nflhip_eval declines)
+    if (detail::strictmod) {   // (runs the queue: a debugging build trades the batching for the assertion)
+      const unsigned skip = detail::strict_exempt(pr.code, pr.len);
+      for (size_t k = 0; k < pr.noperands; ++k) {
+        if (skip >> k & 1) continue;
+        if (pr.pay[k]) detail::strict_dev(ctx_t::get(), static_cast<payload_type *>(pr.pay[k])->dev_ro(), 1, ctx_t::queue(), "operator=(expr)");
+        else detail::strict_host(ctx_t::get(), pr.host[k], 1, "operator=(expr)");
+      }
+    }
     typedef detail::lazy<poly_type> lazy_t;
     if (lazy_t::usable() && pr.nhandles == pr.noperands && pr.noperands <= size_t(lazy_t::max_in)) {  // every leaf is a handle: record, do not launch
       lazy_t::inst().record([&](typename lazy_t::op &o) {
@@ -1405,22 +1778,29 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
     else set({v}, reduce_coeffs);
   }
   void set(std::initializer_list<value_type> values, bool reduce_coeffs = true) { set(values.begin(), values.end(), reduce_coeffs); }
-  // same contract as core.hpp:101-137: fewer than `degree` values are zero-padded and
-  // replicated across moduli; otherwise exactly degree*nmoduli values are required
+  // contract of core.hpp:101-137: up to `degree` values are ONE row image, zero-padded to the degree and written to every
+  // modulus row (reduced per row unless reduce_coeffs is off); otherwise exactly degree * nmoduli values, row by row
   template <class It> void set(It first, It last, bool reduce_coeffs = true) {
-    const size_t size = size_t(std::distance(first, last));
-    if (size > degree && size != degree * nmoduli)
-      throw std::runtime_error("core: CRITICAL, initializer of size above degree but not equal to nmoduli*degree");
-    T *iter = begin();
-    It viter = first;
-    for (size_t cm = 0; cm < nmoduli; cm++) {
+    rows_from(first, size_t(std::distance(first, last)), "core",
+              [reduce_coeffs](decltype(*first) v, value_type p) { return reduce_coeffs ? value_type(v % p) : value_type(v); });
+  }
+ private:
+  // the row filler behind set(It, It) and set_mpz(It, It): residue(value, modulus) gives the word to store
+  template <class It, class F> void rows_from(It first, size_t count, const char *who, F residue) {
+    const bool row_by_row = count == degree * nmoduli;
+    if (count > degree && !row_by_row)
+      throw std::runtime_error(std::string(who) + ": an initializer longer than the degree must hold degree * nmoduli values");
+    const size_t given = row_by_row ? degree : count;
+    It src = first;
+    for (size_t cm = 0; cm < nmoduli; ++cm) {
+      if (!row_by_row) src = first;             // (the same row image for every modulus)
       const value_type p = get_modulus(cm);
-      if (size != degree * nmoduli) viter = first;
-      size_t i = 0;
-      for (; i < degree && viter != last; ++i, ++viter, ++iter) *iter = reduce_coeffs ? value_type((*viter) % p) : value_type(*viter);
-      for (; i < degree; ++i, ++iter) *iter = 0;
+      T *row = _data + cm * degree;
+      for (size_t i = 0; i < given; ++i, ++src) row[i] = residue(*src, p);
+      std::fill(row + given, row + degree, value_type(0));
     }
   }
+ public:
   // mask-then-subtract rule of core.hpp:165-176: on the device's keystream (fresh per call), or on a seeded
   // counter stream for `uniform(seed)`
   void set(uniform const &u) {
@@ -1482,8 +1862,14 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   static constexpr value_type get_modulus(size_t n) { return params<T>::P[n]; }
 
   /* ntt stuff - public API (poly.hpp:167-168) */
-  void ntt_pow_phi() { detail::check(ctx(), nflhip_ntt_fwd(ctx(), _data, 1), "ntt_pow_phi"); }
-  void invntt_pow_invphi() { detail::check(ctx(), nflhip_ntt_inv(ctx(), _data, 1), "invntt_pow_invphi"); }
+  void ntt_pow_phi() {
+    if (detail::strictmod) detail::strict_host(ctx(), _data, 1, "ntt_pow_phi");
+    detail::check(ctx(), nflhip_ntt_fwd(ctx(), _data, 1), "ntt_pow_phi");
+  }
+  void invntt_pow_invphi() {
+    if (detail::strictmod) detail::strict_host(ctx(), _data, 1, "invntt_pow_invphi");
+    detail::check(ctx(), nflhip_ntt_inv(ctx(), _data, 1), "invntt_pow_invphi");
+  }
 
   /* manual serializers (poly.hpp:180-185): raw little-endian words */
   void serialize_manually(std::ostream &os) { os.write(reinterpret_cast<char *>(_data), N * sizeof(T)); }
@@ -1667,18 +2053,8 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   // degree*nmoduli are taken row by row; every value is reduced with floor semantics (mpz_fdiv_ui: negative
   // integers give non-negative residues).  A setter, like set(It, It): runs on the host.
   template <class It> void set_mpz(It first, It last) {
-    const size_t size = size_t(std::distance(first, last));
-    if (size > degree && size != degree * nmoduli)
-      throw std::runtime_error("gmp: CRITICAL, initializer of size above degree but not equal to nmoduli*degree");
-    T *iter = begin();
-    It viter = first;
-    for (size_t cm = 0; cm < nmoduli; cm++) {
-      const value_type p = get_modulus(cm);
-      if (size != degree * nmoduli) viter = first;
-      size_t i = 0;
-      for (; i < degree && viter != last; ++i, ++viter, ++iter) *iter = value_type(mpz_fdiv_ui(detail::as_mpz(*viter), p));
-      for (; i < degree; ++i, ++iter) *iter = 0;
-    }
+    rows_from(first, size_t(std::distance(first, last)), "gmp",
+              [](decltype(*first) v, value_type p) { return value_type(mpz_fdiv_ui(detail::as_mpz(v), p)); });
   }
 
   // gmp.hpp:169-209 on the device (nflhip_crt_lift); the returned integers are initialised here and owned by the
@@ -1731,10 +2107,19 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
     detail::check(ctx(), nflhip_sample(ctx(), _data, 1, dist, p0, p1, s.key, s.next++), what);
   }
   void apply(int op, const poly &a, const poly &b, const poly &bp) {
+    if (detail::strictmod) {
+      if (op != NFLHIP_OP_COMPUTE_SHOUP) detail::strict_host(ctx(), a._data, 1, "operator=(expr)");
+      detail::strict_host(ctx(), op == NFLHIP_OP_COMPUTE_SHOUP ? a._data : b._data, 1, "operator=(expr)");
+    }
     detail::check(ctx(), nflhip_pointwise(ctx(), op, _data, a._data, b._data, bp._data, 1), "operator=(expr)");
   }
   // fused tree evaluation; false = the engine declined (tiny rows): the caller goes node by node
   bool apply_program(const ops::program &pr, const void *const *host_operands) {
+    if (detail::strictmod) {
+      const unsigned skip = detail::strict_exempt(pr.code, pr.len);
+      for (size_t k = 0; k < pr.noperands; ++k)
+        if (!(skip >> k & 1)) detail::strict_host(ctx(), host_operands[k], 1, "operator=(expr)");
+    }
     const int rc = nflhip_eval(ctx(), _data, host_operands, pr.noperands, pr.code, pr.len, 1);
     if (rc == NFLHIP_ERR_UNSUPPORTED) return false;
     detail::check(ctx(), rc, "operator=(expr)");
@@ -2034,6 +2419,8 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
  private:
   void transform(int kind) {
     detach();
+    if (detail::strictmod)
+      detail::strict_dev(ctx_t::get(), _p->dev_ro(), 1, ctx_t::queue(), kind == lazy_t::K_NTT_FWD ? "ntt_pow_phi" : "invntt_pow_invphi");
     if (lazy_t::usable()) {
       lazy_t::inst().record([&](typename lazy_t::op &o) {
         o.kind = static_cast<unsigned char>(kind);
@@ -2174,15 +2561,26 @@ template <class P> class device_batch {
   void sync() const { detail::check(ctx(), nflhip_stream_sync(ctx(), queue()), "sync"); }
 
   // same names and meaning as the poly members (poly.hpp:167-168), over the whole batch
-  void ntt_pow_phi() { detail::check(ctx(), nflhip_ntt_fwd_dev(ctx(), d_, n_, queue()), "ntt_pow_phi"); }
-  void invntt_pow_invphi() { detail::check(ctx(), nflhip_ntt_inv_dev(ctx(), d_, n_, queue()), "invntt_pow_invphi"); }
+  void strict(const char *what) const {   // CHECK_STRICTMOD's assertion over the whole resident batch
+    if (detail::strictmod) detail::strict_dev(ctx(), d_, n_, queue(), what);
+  }
+  void ntt_pow_phi() {
+    strict("ntt_pow_phi");
+    detail::check(ctx(), nflhip_ntt_fwd_dev(ctx(), d_, n_, queue()), "ntt_pow_phi");
+  }
+  void invntt_pow_invphi() {
+    strict("invntt_pow_invphi");
+    detail::check(ctx(), nflhip_ntt_inv_dev(ctx(), d_, n_, queue()), "invntt_pow_invphi");
+  }
   // *this = op(a, b[, b'])  (NFLHIP_OP_*); aliasing allowed
   void assign(int op, const device_batch &a, const device_batch &b) {
     same_size(a); same_size(b);
+    a.strict("pointwise"); b.strict("pointwise");
     detail::check(ctx(), nflhip_pointwise_dev(ctx(), op, d_, a.d_, b.d_, nullptr, n_, queue()), "pointwise");
   }
   void assign_mul_shoup(const device_batch &a, const device_batch &b, const device_batch &bprime) {
     same_size(a); same_size(b); same_size(bprime);
+    a.strict("mulmod_shoup"); b.strict("mulmod_shoup");
     detail::check(ctx(), nflhip_pointwise_dev(ctx(), NFLHIP_OP_MUL_SHOUP, d_, a.d_, b.d_, bprime.d_, n_, queue()),
                   "mulmod_shoup");
   }
@@ -2229,6 +2627,11 @@ template <class P> class device_batch {
     const void *ptr[NFLHIP_EXPR_MAX_OPERANDS];
     if (count > NFLHIP_EXPR_MAX_OPERANDS) throw std::runtime_error("nfl(hip): too many operands");
     for (size_t i = 0; i < count; ++i) { same_size(*operands[i]); ptr[i] = operands[i]->d_; }
+    if (detail::strictmod) {
+      const unsigned skip = detail::strict_exempt(program, len);
+      for (size_t i = 0; i < count; ++i)
+        if (!(skip >> i & 1)) operands[i]->strict("eval");
+    }
     detail::check(ctx(), nflhip_eval_dev(ctx(), d_, ptr, count, program, len, n_, queue()), "eval");
   }
   // the random constructors over the whole resident batch (same tags as poly's; one keystream per call).

@@ -228,6 +228,10 @@ int nflhip_fwd_fma2_dev(nflhip_ctx *ctx, void *d_out0, void *d_out1, const nflhi
                         void *stream);
 int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, const nflhip_operand *k,
                        const nflhip_operand *b, int subtract, size_t batch, void *stream);
+/* 1 when the three entries above run as ONE generated kernel each on this context (u64 limbs, degree 4096, the default
+ * kernel variant), 0 when they compose the result from the plain kernels: what a caller that can choose between its own
+ * operator sequence and these entries asks (the header's deferred queue only rewrites sequences when it gains a pass) */
+int nflhip_has_fused_kernels(const nflhip_ctx *ctx);
 /* compact polynomial(s) -> residue words: d_data[b][cm][i] = v < 0 ? p_cm + v : v, v = element i of src's polynomial
  * b * stride (format NFLHIP_FMT_WORDS: a strided gather of word rows) */
 int nflhip_expand_small_dev(nflhip_ctx *ctx, void *d_data, const nflhip_operand *src, size_t batch, void *stream);
@@ -242,6 +246,17 @@ int nflhip_any_neq_dev(nflhip_ctx *ctx, const void *d_a, const void *d_b, size_t
                        void *stream);
 int nflhip_any_eq(nflhip_ctx *ctx, const void *h_a, const void *h_b, size_t batch, int *result);
 int nflhip_any_neq(nflhip_ctx *ctx, const void *h_a, const void *h_b, size_t batch, int *result);
+
+/* ---- range assertion: CHECK_STRICTMOD ---------------------------------------------
+ * The reference's tests are compiled with CHECK_STRICTMOD (tests/CMakeLists.txt:10): ASSERT_STRICTMOD (debug.hpp:33-37)
+ * then asserts that every operand word is the canonical representative, x < p -- at the entry of the transforms
+ * (core.hpp:457-462), in addmod / submod / mulmod / mulmod_shoup (ops.hpp:131,148,190,211,235) and after the samplers
+ * (core.hpp:179-185, 275-281, 319-325).  *bad = 1 iff some word of the batch is >= its row's modulus.  The _dev form is one
+ * streaming compare on the device and synchronises the stream; the host form reads host words against the context's
+ * copy of the moduli (no device needed).  include/nfl_hip/nfl.hpp calls them under -DCHECK_STRICTMOD (without NDEBUG) on
+ * the operands of transforms and expressions and throws std::runtime_error where the reference's assert would fire. */
+int nflhip_check_range_dev(nflhip_ctx *ctx, const void *d_data, size_t batch, int *bad, void *stream);
+int nflhip_check_range(const nflhip_ctx *ctx, const void *h_data, size_t batch, int *bad);
 
 /* ---- CRT ---------------------------------------------------------------------
  * lift:    GMP::poly2mpz gmp.hpp:183-209 -- limbs[b][i][0..L) = little-endian

@@ -51,10 +51,13 @@ SYMBOLS = [
     ("nflhip_fwd_fma2_dev", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     ("nflhip_fma_inv_dev", _i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     ("nflhip_expand_small_dev", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("nflhip_has_fused_kernels", _i, [_vp]),
     ("nflhip_any_eq_dev", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i), _vp]),
     ("nflhip_any_neq_dev", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i), _vp]),
     ("nflhip_any_eq", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i)]),
     ("nflhip_any_neq", _i, [_vp, _vp, _vp, _sz, C.POINTER(_i)]),
+    ("nflhip_check_range_dev", _i, [_vp, _vp, _sz, C.POINTER(_i), _vp]),
+    ("nflhip_check_range", _i, [_vp, _vp, _sz, C.POINTER(_i)]),
     ("nflhip_crt_lift_dev", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("nflhip_crt_project_dev", _i, [_vp, _vp, _vp, _sz, _sz, _vp]),
     ("nflhip_crt_lift", _i, [_vp, _vp, _vp, _sz]),

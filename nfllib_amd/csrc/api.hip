@@ -1086,6 +1086,11 @@ int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, co
   return nflhip_ntt_inv_dev(ctx, d_out, batch, stream);
 }
 
+int nflhip_has_fused_kernels(const nflhip_ctx *ctx) {
+  return ctx && ctx->shape.limb_bits == 64 && ctx->shape.logn == 12 && !ctx->shape.compiled_only && ctx->shape.small_delta &&
+         ctx->shape.nm <= 65535 && !ctx->cyclic;
+}
+
 int nflhip_expand_small_dev(nflhip_ctx *ctx, void *d_data, const nflhip_operand *src, size_t batch, void *stream) {
   CHECK_CTX(ctx);
   if (batch && !d_data) return fail(ctx, NFLHIP_ERR_INVALID, "NULL result pointer");
@@ -1114,6 +1119,40 @@ static int any_cmp_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t bat
   *result = flag ? 1 : 0;
   return NFLHIP_OK;
 }
+int nflhip_check_range_dev(nflhip_ctx *ctx, const void *d_data, size_t batch, int *bad, void *stream) {
+  CHECK_CTX(ctx);
+  if (!bad || (batch && !d_data)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned slot = ctx->cmp_next.fetch_add(1, std::memory_order_relaxed) % nflhip_ctx::kCmpSlots;
+  std::lock_guard<std::mutex> lk(ctx->cmp_mu[slot]);  // held until the readback below has completed
+  int *dflag = ctx->tabs.flag + slot;
+  hipError_t e = DISPATCH_T(ctx, launch_check_range<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d_data, batch, dflag, st),
+                            launch_check_range<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)d_data, batch, dflag, st),
+                            launch_check_range<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)d_data, batch, dflag, st));
+  if (e != hipSuccess) return hipfail(ctx, e, "check_range");
+  int flag = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  *bad = flag ? 1 : 0;
+  return NFLHIP_OK;
+}
+
+int nflhip_check_range(const nflhip_ctx *ctx, const void *h_data, size_t batch, int *bad) {
+  // host words against the host copy of the moduli: an assertion about the CALLER's data, nothing is computed
+  if (!ctx) return fail(nullptr, NFLHIP_ERR_INVALID, "ctx is NULL");
+  if (!bad || (batch && !h_data)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  const size_t n = ctx->shape.n, nm = ctx->shape.nm;
+  int hit = 0;
+  for (size_t r = 0; r < batch * nm && !hit; ++r) {
+    const uint64_t p = ctx->h_P[r % nm];
+    if (ctx->word == 8) { const uint64_t *w = (const uint64_t *)h_data + r * n; for (size_t i = 0; i < n; ++i) hit |= w[i] >= p; }
+    else if (ctx->word == 4) { const uint32_t *w = (const uint32_t *)h_data + r * n; for (size_t i = 0; i < n; ++i) hit |= w[i] >= p; }
+    else { const uint16_t *w = (const uint16_t *)h_data + r * n; for (size_t i = 0; i < n; ++i) hit |= w[i] >= p; }
+  }
+  *bad = hit ? 1 : 0;
+  return NFLHIP_OK;
+}
+
 int nflhip_any_eq_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int *result, void *stream) {
   return any_cmp_dev(ctx, a, b, batch, 1, result, stream);
 }

@@ -83,6 +83,8 @@ template <typename T>
 hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
                           int *flag, hipStream_t st);
 template <typename T>
+hipError_t launch_check_range(const Shape &s, const DevTables &t, const T *d, size_t batch, int *flag, hipStream_t st);
+template <typename T>
 hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, uint64_t seed,
                                int operand, hipStream_t st);
 // in-place bit reversal of every row (permut.hpp:86-117), and `count` copies of one polynomial

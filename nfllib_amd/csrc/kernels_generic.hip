@@ -573,6 +573,28 @@ hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const 
   return hipGetLastError();
 }
 
+// CHECK_STRICTMOD (debug.hpp:33-37; the asserts of ops.hpp:131,148,211,235 and core.hpp:457-462): any word that is not the
+// canonical representative of its row's modulus
+template <typename T>
+__global__ void k_check_range(const T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t total, int *flag) {
+  int hit = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    hit |= d[i] >= mc[(int)((i >> logn) % (size_t)nm)].p ? 1 : 0;
+  if (__any(hit)) {
+    if ((threadIdx.x & 63) == 0) atomicOr(flag, 1);
+  }
+}
+
+template <typename T>
+hipError_t launch_check_range(const Shape &s, const DevTables &t, const T *d, size_t batch, int *flag, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+  if (e != hipSuccess || batch == 0) return e;
+  const size_t total = batch * s.nm * s.n;
+  hipLaunchKernelGGL((k_check_range<T>), dim3((unsigned)stream_blocks(total, 2048)), dim3(256), 0, st, d, (const ModConst<T> *)t.mc,
+                     s.logn, (int)s.nm, total, flag);
+  return hipGetLastError();
+}
+
 // seeded synthetic operands: mask-then-subtract rule of nfl::uniform (core.hpp:165-176)
 template <typename T>
 __global__ void k_fill_uniform(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t first_word,
@@ -959,6 +981,7 @@ hipError_t launch_broadcast(void *dst, const void *one, size_t bytes_per_poly, s
   template hipError_t launch_eval_expr<T>(const Shape &, const DevTables &, T *, const void *const *, int,           \
                                           const unsigned char *, int, size_t, hipStream_t, const unsigned *,         \
                                           unsigned);                                                                 \
+  template hipError_t launch_check_range<T>(const Shape &, const DevTables &, const T *, size_t, int *, hipStream_t); \
   template hipError_t launch_any_cmp<T>(const Shape &, const DevTables &, const T *, const T *, size_t, int, int *,  \
                                         hipStream_t);                                                                \
   template hipError_t launch_fill_uniform<T>(const Shape &, const DevTables &, T *, size_t, size_t, uint64_t, int,   \

@@ -246,6 +246,17 @@ class Engine:
                                                              first_stream_id, stream_id_stride, self._stream(stream)))
         return d
 
+    def check_range(self, d, stream=None):
+        """CHECK_STRICTMOD's assertion over a resident batch: True iff some word is >= its row's modulus"""
+        r = C.c_int(0)
+        self._chk(self.lib.nflhip_check_range_dev(self.ctx, _vp(d), self._batch(d), C.byref(r), self._stream(stream)))
+        return bool(r.value)
+
+    def h_check_range(self, a):
+        r = C.c_int(0)
+        self._chk(self.lib.nflhip_check_range(self.ctx, _vp(a), self._hb(a), C.byref(r)))
+        return bool(r.value)
+
     def any_eq(self, a, b, stream=None):
         r = C.c_int(0)
         self._chk(self.lib.nflhip_any_eq_dev(self.ctx, _vp(a), _vp(b), self._batch(a), C.byref(r), self._stream(stream)))

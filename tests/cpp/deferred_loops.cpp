@@ -7,7 +7,11 @@
 //      key operand each; then the decryption loop over the results;
 //   2. results written into every second / in reverse order of a pre-allocated array (strides other than 1, unsorted
 //      destinations), operands shared between neighbours (stride 0 for a few elements, then a new key);
-//   3. a queue that runs by itself in the middle of the loop (NFL_HIP_QUEUE_LIMIT small) and handles that die queued.
+//   3. a queue that runs by itself in the middle of the loop (NFL_HIP_QUEUE_LIMIT small) and handles that die queued;
+//   4. the sequences the transform fusion rewrites (sample, transform, multiply-add; multiply-add, inverse transform) in
+//      every operand order, next to look-alikes it must leave alone: a third reader of a transformed temporary, a
+//      temporary whose handle survives, a key rewritten between two results, a result feeding the next, a sum that is
+//      read before it is transformed back.
 // Usage: deferred_loops [reps].  Exit code 0 = identical.  Runs against the real library (GPU) and against the toy
 // arithmetic of tests/cpp/mock (CPU: tests/test_host_logic.py).
 #include <nfl.hpp>
@@ -78,6 +82,41 @@ template <class T, size_t Degree, size_t NbModuli> static bool run(size_t reps) 
       }
       save(acc);
       for (auto &k : keep) save(k);
+    }
+    {  // 4. shapes around the transform fusion (detail::lazy::fuse): sequences it may rewrite and sequences it must leave alone
+      poly_p s{G(&fg)}, k1{nfl::uniform()}, k2{nfl::uniform()};
+      s.ntt_pow_phi();
+      const size_t m = reps / 4 + 3;
+      std::vector<poly_p> r0(m), r1(m), r2(m), alive;
+      for (size_t i = 0; i < m; ++i) {
+        poly_p u{G(&fg)}, e1{G(&fg, 2)}, e2{G(&fg, 3)};
+        u.ntt_pow_phi();
+        e1.ntt_pow_phi();
+        e2.ntt_pow_phi();
+        switch (i % 6) {
+          case 0: r0[i] = e1 + k1 * u; r1[i] = k2 * u + e2; break;                       // operand orders
+          case 1: r0[i] = u * k1 + e1; r1[i] = u * k2 + e2; r2[i] = u + e1; break;        // a third reader of NTT(u) and NTT(e1)
+          case 2: r0[i] = u * k1 + e1; alive.push_back(u); r1[i] = u * k2 + e2; break;    // the temporary outlives the run
+          case 3: r0[i] = u * k1 + e1; k1 = k1 + k2; r1[i] = u * k1 + e2; break;          // the key changes between the two results
+          case 4: r0[i] = u * k1 + e1; r1[i] = u * r0[i] + e2; break;                     // the second result reads the first
+          default: u = u * k1 + e1; r0[i] = u; r1[i] = e2 * k2 + e2; break;               // in place; e2 twice in one expression
+        }
+      }
+      for (size_t i = 0; i < m; ++i) {
+        poly_p d, t;
+        switch (i % 4) {
+          case 0: r1[i] = r1[i] - r0[i] * s; r1[i].invntt_pow_invphi(); break;            // in place
+          case 1: d = r0[i] * s + r1[i]; t = d; d.invntt_pow_invphi(); r1[i] = d + t; break;   // the sum is read before its transform
+          case 2: d = r1[i] - r0[i] * s; r0[i] = r0[i] + s; d.invntt_pow_invphi(); r1[i] = d; break;  // an operand changes in between
+          default: d = r1[i] + s * r0[i]; d.invntt_pow_invphi(); r1[i] = d; break;
+        }
+      }
+      for (size_t i = 0; i < m; ++i) {
+        save(r0[i]);
+        save(r1[i]);
+        if (i % 6 == 1) save(r2[i]);
+      }
+      for (auto &a : alive) save(a);
     }
     poly_p::synchronize();
   }

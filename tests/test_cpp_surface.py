@@ -18,7 +18,7 @@ FUZZ = os.path.join(CPP, "deferred_fuzz")
 
 
 def _build():
-    subprocess.check_call(["make", "-s", "-C", CPP, "surface_test", "resident_test", "deferred_fuzz"])
+    subprocess.check_call(["make", "-s", "-C", CPP, "surface_test", "resident_test", "deferred_fuzz", "serialize_archive", "strictmod_test"])
     assert os.path.exists(BIN) and os.path.exists(RES) and os.path.exists(FUZZ)
 
 
@@ -72,3 +72,23 @@ def test_deferred_execution_equals_immediate_execution_on_random_programs():
     r = subprocess.run([FUZZ, "150", "2024"], capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_archive_hook_round_trips_poly_and_poly_p():
+    """poly::serialize(Archive &) / poly_p::serialize(Archive &) (reference poly.hpp:189-191, tests/poly_serialize_cereal.cpp)
+    through a binary archive of cereal's calling convention: byte-identical to serialize_manually, exact round trips, and
+    the handle read back transforms on the device"""
+    _build()
+    r = subprocess.run([os.path.join(CPP, "serialize_archive")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_check_strictmod_builds_assert_operand_ranges():
+    """-DCHECK_STRICTMOD (how the reference builds its tests: tests/CMakeLists.txt:10, debug.hpp:33-37): a word >= p in an
+    operand of a transform or an operator throws -- inline polys on the host, resident handles and batches through
+    nflhip_check_range_dev -- canonical operands and Shoup companions pass"""
+    _build()
+    r = subprocess.run([os.path.join(CPP, "strictmod_test")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -28,7 +28,7 @@ def mock():
                           stdout=subprocess.DEVNULL)
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o",
                            os.path.join(MOCK, "libnflhip.so"), c, "-lpthread"])
-    for name in ("deferred_fuzz", "deferred_loops"):
+    for name in ("deferred_fuzz", "deferred_loops", "serialize_archive"):
         build_program(name + ".cpp", os.path.join(MOCK, name))
     return MOCK
 
@@ -41,6 +41,14 @@ def run(exe, *args, env=None):
 
 def test_random_programs_deferred_equals_immediate(mock):
     r = run(os.path.join(mock, "deferred_fuzz"), 60, 2024)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_archive_hook_writes_the_manual_image(mock):
+    """poly::serialize(Archive &) / poly_p::serialize(Archive &) (poly.hpp:189-191; the reference's
+    tests/poly_serialize_cereal.cpp) instantiated with a binary archive of cereal's calling convention: the bytes are
+    serialize_manually's, and they read back (host logic only: the toy device serves the handles)"""
+    r = run(os.path.join(mock, "serialize_archive"), "toy")
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
 
 
@@ -62,14 +70,25 @@ def test_early_queue_runs_do_not_change_results(mock):
 
 
 def test_the_loops_are_coalesced(mock):
-    """what deferral is for: the LWE loop's 300 x 8 operations leave as a handful of launches"""
-    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1"})
+    """what deferral is for: the LWE loop's 300 x 10 operations leave as a handful of launches -- with the transform fusion
+    (the default where the context has the fused kernels: the toy device says it does) as 300 forward multiply-adds in
+    four launches (three compact sampler launches + the fused one) and 300 multiply-subtract-inverse operations in one;
+    without it (NFL_HIP_NO_FUSION=1) operator by operator, as recorded"""
+    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1", "NFL_HIP_NO_FUSION": "1"})
     assert r.returncode == 0
     lines = [l for l in r.stderr.splitlines() if l.startswith("nfl(hip) deferred:")]
     first_ring = lines[:7]      # level 0: gaussians (3 groups), level 1: transforms, 2: products, 3: decryption, 4: inverse
     ops = sum(int(l.split(":")[2].split()[0]) for l in first_ring)
     launches = sum(int(l.split("->")[1].split()[0]) for l in first_ring)
     assert ops >= 300 * 10 and launches <= 12, first_ring
+    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1"})
+    assert r.returncode == 0 and "all checks passed" in r.stdout
+    lines = [l for l in r.stderr.splitlines() if l.startswith("nfl(hip) deferred:")]
+    fused = [l for l in lines[:6] if " kind 6:" in l or " kind 7:" in l]       # K_FWD_FMA, K_FMA_INV
+    assert len(fused) == 2, lines[:8]
+    assert all(int(l.split(":")[2].split()[0]) == 300 for l in fused), fused
+    assert sum(int(l.split("->")[1].split()[0]) for l in fused) <= 5, fused
+    assert sum(int(l.split("->")[1].split()[0]) for l in lines[:6]) <= 11, lines[:6]
 
 
 def test_the_harness_notices_a_broken_queue(mock, tmp_path):
@@ -86,6 +105,24 @@ def test_the_harness_notices_a_broken_queue(mock, tmp_path):
     build_program("deferred_fuzz.cpp", exe, include=str(inc))
     r = run(exe, 40, 1)
     assert r.returncode != 0 and "all checks passed" not in r.stdout
+
+
+def test_the_harness_notices_a_broken_fusion(mock, tmp_path):
+    """a header whose transform fusion forgets that a sampled-and-transformed temporary may still have a handle (or another
+    reader) must fail the loop comparison: proof that the look-alike shapes of deferred_loops.cpp bite"""
+    good = {"      return p->fw != d || held[p->pin_at].use_count() == 1;": "      return true;",
+            "uses[size_t(dn)] != want_uses || ": ""}
+    for k, (old, new) in enumerate(good.items()):
+        inc = tmp_path / ("include%d" % k)
+        shutil.copytree(os.path.join(ROOT, "include"), inc)
+        hdr = inc / "nfl_hip" / "nfl.hpp"
+        text = hdr.read_text()
+        assert old in text
+        hdr.write_text(text.replace(old, new).replace("if (ux != 1 && ux != 2) continue;", "if (ux < 1) continue;") if k else text.replace(old, new))
+        exe = str(tmp_path / ("loops_mutant%d" % k))
+        build_program("deferred_loops.cpp", exe, include=str(inc))
+        r = run(exe, 60)
+        assert r.returncode != 0 and "all checks passed" not in r.stdout
 
 
 def test_random_programs_under_address_and_undefined_behaviour_sanitizers(mock, tmp_path):
