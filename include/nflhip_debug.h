@@ -23,6 +23,11 @@ void nflhip_debug_gauss_tie_shift(int shift);
 struct nflhip_ctx;
 void nflhip_debug_host_pipe_seconds(const struct nflhip_ctx *ctx, double out[4]);
 
+/* grid of the transform-fused kernels (u64, degree 4096): 0 = the library's policy (forward entries with compact inputs and
+ * more than one modulus deal the nm rows of a batch element to one XCD; everything else one workgroup per (element, modulus)
+ * in a 2-D grid), 1 = always the 2-D grid, 2 = always the XCD-dealt 1-D grid.  Same results either way. */
+void nflhip_debug_fused_grid(int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -487,7 +487,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
   if (rc) return rc;
   T *s0 = (T *)ctx->scratch, *s1 = (T *)((char *)ctx->scratch + bytes);
   (void)acopy;
-  if (sizeof(T) == 8 && !b_is_ntt && ctx->shape.logn == 16) {
+  if (sizeof(T) == 8 && ctx->shape.logn == 16) {
     // n = 65536: the streaming passes (HBM-bound) and the fused block kernel (VALU-bound) of neighbouring chunks share
     // every CU inside ONE kernel whose workgroups take three roles; consecutive launches on the caller's stream form the
     // pipeline: launch L = forward pass of chunk L, block products of chunk L-1, inverse pass of chunk L-2.
@@ -503,9 +503,11 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       const bool hf = L < nchunk, hv = L >= 1 && L - 1 < nchunk, hi = L >= 2 && L - 2 < nchunk;
       const size_t f0 = hf ? lo_of(L) : 0, v0 = hv ? lo_of(L - 1) : 0, i0 = hi ? lo_of(L - 2) : 0;
       const int cf = hf ? (int)(lo_of(L + 1) - f0) : 0, cv = hv ? (int)(lo_of(L) - v0) : 0, ci = hi ? (int)(lo_of(L - 1) - i0) : 0;
+      // (b already transformed: its blocks are read from the caller's array by the block products, no forward pass, no scratch)
       e = launch_polymul_pipe64k_u64(ctx->shape, ctx->tabs, (uint64_t *)c + v0 * pw, (const uint64_t *)s0 + v0 * pw,
-                                     (const uint64_t *)s1 + v0 * pw, cv, (const uint64_t *)a + f0 * pw, (uint64_t *)s0 + f0 * pw,
-                                     (const uint64_t *)b + f0 * pw, (uint64_t *)s1 + f0 * pw, cf, (uint64_t *)c + i0 * pw, ci, st);
+                                     (b_is_ntt ? (const uint64_t *)b : (const uint64_t *)s1) + v0 * pw, cv, (const uint64_t *)a + f0 * pw,
+                                     (uint64_t *)s0 + f0 * pw, b_is_ntt ? nullptr : (const uint64_t *)b + f0 * pw,
+                                     b_is_ntt ? nullptr : (uint64_t *)s1 + f0 * pw, cf, (uint64_t *)c + i0 * pw, ci, st, b_is_ntt != 0);
       if (e == hipErrorNotSupported && L == 0) { supported = false; break; }
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: pipeline kernel");
     }

@@ -187,7 +187,7 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
 hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
-                                      hipStream_t st);
+                                      hipStream_t st, bool b_is_ntt = false);
 
 // n = 1024, 32- and 64-bit limbs: one wave per row (kernels_wave.hip).  mode 0: c = INTT(NTT(a)(.)NTT(b)); 1: b already in
 // NTT form; 2: c = NTT(a); 3: c = INTT(a).  hipErrorNotSupported for other shapes.

@@ -350,6 +350,7 @@ enum AsmKind {
   kAsmRow8U32, kAsmRowNtt8U32, kAsmRowFwd8U32, kAsmRowInv8U32,       // 32-bit limbs, n = 8: one lane per row
   kAsmRow128U16, kAsmRowNtt128U16, kAsmRowFwd128U16, kAsmRowInv128U16,   // 16-bit limbs
   kAsmFusedEnc2, kAsmFusedFmaFwd, kAsmFusedFmsInv, kAsmFusedFmaInv,      // transform-fused pipelines, n = 4096 (build_fused)
+  kAsmPipe64kB,                                                      // n = 65536, operand b already transformed (build_pipe b_ntt)
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -369,7 +370,8 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_row1024_inv_u32_asm", "nflhip_row2048_inv_u32_asm", "nflhip_row4096_inv_u32_asm",
     "nflhip_row8_u32_asm", "nflhip_row8_ntt_u32_asm", "nflhip_row8_fwd_u32_asm", "nflhip_row8_inv_u32_asm",
     "nflhip_row128_u16_asm", "nflhip_row128_ntt_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm",
-    "nflhip_fused_enc2_4096_asm", "nflhip_fused_fma_fwd4096_asm", "nflhip_fused_fms_inv4096_asm", "nflhip_fused_fma_inv4096_asm"};
+    "nflhip_fused_enc2_4096_asm", "nflhip_fused_fma_fwd4096_asm", "nflhip_fused_fms_inv4096_asm", "nflhip_fused_fma_inv4096_asm",
+    "nflhip_polymul_pipe65536ntb_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -451,6 +453,8 @@ static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t
 // transform-fused pipelines (tools/gen_polymul_asm.py build_fused, kernarg ARGS_FUSED): one 256-thread workgroup per
 // (batch element, modulus); the intermediate polynomials of `x.ntt_pow_phi(); r = x * k + e` / `(b - a * s).invntt_pow_invphi()`
 // (tests/nfllib_demo_main_op.cpp:26-58) never reach HBM
+static std::atomic<int> g_fused_grid{0};
+extern "C" void nflhip_debug_fused_grid(int mode) { g_fused_grid.store(mode); }  // include/nflhip_debug.h
 hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, uint64_t *out0, uint64_t *out1,
                                 const void *const *x, const unsigned *xstride, const int *xfmt, const void *const *k,
                                 const unsigned *kstride, size_t batch, hipStream_t st) {
@@ -490,7 +494,9 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
   // forward kinds with more than one modulus: the nm rows of a batch element back to back on one XCD (1-D grid, the kernel
   // deals the workgroups itself), so that compact inputs -- one copy for all moduli -- come from HBM once
   const size_t groups = (batch + 7) / 8, wgs = groups * 8 * s.nm;
-  const bool remap = kind < 2 && s.nm > 1 && (args.fmt != 0) && wgs <= 0x7fffffffull && groups * s.nm < (0xffffffffull / s.nm);
+  const int forced = g_fused_grid.load(std::memory_order_relaxed);
+  const bool fits = wgs <= 0x7fffffffull && groups * s.nm < (0xffffffffull / s.nm);
+  const bool remap = fits && forced != 1 && (forced == 2 || (kind < 2 && s.nm > 1 && args.fmt != 0));
   args.magic = remap ? (unsigned)(0x100000000ull / s.nm + 1) : 0u;
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -505,10 +511,11 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
 hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
-                                      hipStream_t st) {
+                                      hipStream_t st, bool b_is_ntt) {
   if (s.limb_bits != 64 || s.logn != 16 || s.compiled_only || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
   // (coefficient loads / stores carry `nt`: they pass through the L2 once, the twiddle tables stay resident: measured +3 %)
-  hipFunction_t fn = asm_fn(kAsmPipe64k);
+  // b_is_ntt: b_v is the caller's transformed operand (canonical words), read block-wise as it lies; no forward role for it
+  hipFunction_t fn = asm_fn(b_is_ntt ? kAsmPipe64kB : kAsmPipe64k);
   if (!fn) return hipErrorNotSupported;
   const int mx = cnt_v > cnt_f ? (cnt_v > cnt_i ? cnt_v : cnt_i) : (cnt_f > cnt_i ? cnt_f : cnt_i);
   if (mx <= 0) return hipSuccess;
@@ -526,8 +533,8 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_pipe65536_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  // per polynomial row: 16 block products + 3 x 4 streaming workgroups
-  const size_t gx = (size_t)mx * 28;
+  // per polynomial row: 16 block products + 3 x 4 streaming workgroups (2 x 4 when b needs no forward pass)
+  const size_t gx = (size_t)mx * (b_is_ntt ? 24 : 28);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
 #ifndef NFLHIP_NO_PIPE_REMAP
   // modulus-major units in contiguous ranges per XCD slot (see build_pipe): every twiddle table is then fetched by ~1.3 of

@@ -1144,7 +1144,7 @@ def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts, remap=False):
     return res
 
 
-def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=False):
+def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=False, b_ntt=False):
     """n = 32768 / 65536: the three-role kernel of tools/gen_polymul_asm.py build_pipe (kernarg as
     launch_polymul_pipe64k_u64 packs it) driven the way the composed product does: forward streaming pass of both
     operands, fused block products, inverse streaming pass in place -- three launches of the same kernel"""
@@ -1159,13 +1159,14 @@ def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=F
     with open(asm_path) as f:
         text = f.read()
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
-    per_row = 28 if logn == 16 else 14
+    per_row = (28 if logn == 16 else 14) if not b_ntt else 24     # b_ntt (n = 65536 only): b is the transformed operand, read in place
 
     def launch(cnt_v, cnt_f, cnt_i):
         gx = max(cnt_v, cnt_f, cnt_i) * per_row
         rm = (gx, gx * nm // 8, (1 << 32) // gx + 1) if remap else (0, 0, 0)    # (launch_polymul_pipe64k_u64's XCD remap)
         assert not remap or (gx * nm) % 8 == 0
-        kernarg = struct.pack("<5Q5ii5Q2I", pc, psa, psb, ppsi, pmc, nm, logn, cnt_v, cnt_f, cnt_i, rm[0], pa, psa, pb, psb, pc, rm[1], rm[2])
+        kernarg = struct.pack("<5Q5ii5Q2I", pc, psa, pb if b_ntt else psb, ppsi, pmc, nm, logn, cnt_v, cnt_f, cnt_i, rm[0], pa, psa,
+                              0 if b_ntt else pb, 0 if b_ntt else psb, pc, rm[1], rm[2])
         run_kernel(text, mem, kernarg, (gx, nm), lds)
 
     launch(0, batch, 0)

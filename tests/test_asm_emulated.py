@@ -225,6 +225,9 @@ def test_emulated_u64_three_role_kernel(stem, n, generated, oracle_factory):
     o2 = oracle_factory(64, n, 2)
     prm, a, b = operands(o2, 64, n, 2, 1, 19)
     assert np.array_equal(asm_emu.run_pipe_product(generated(stem), n, 2, prm, a, b, remap=True), o2.polymul(a, b))
+    # operand b already transformed: the variant without a forward role for it (24 workgroups per row), b' read block-wise
+    fb = o2.ntt(b)
+    assert np.array_equal(asm_emu.run_pipe_product(generated(stem + "b"), n, 2, prm, a, fb, remap=True, b_ntt=True), o2.polymul(a, b))
 
 
 def _picker(kind):

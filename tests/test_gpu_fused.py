@@ -180,3 +180,28 @@ def test_fused_entries_reject_bad_arguments(engine_factory):
         e.fma_inv(torch.zeros((2, 4096), dtype=torch.int8, device="cuda:0"), x, x)   # compact operands only feed the forward entries
     with pytest.raises(NflHipError):
         e._chk(e.lib.nflhip_fwd_fma_dev(e.ctx, None, None, None, None, 2, None))
+
+
+def test_both_grids_of_the_fused_kernels_give_the_same_words(engine_factory):
+    """the 2-D (element, modulus) grid and the 1-D grid that deals the nm rows of an element to one XCD (include/nflhip_debug.h
+    nflhip_debug_fused_grid), every fused entry, ragged batches (the 1-D grid pads to groups of eight elements)"""
+    import torch
+    from nfllib_amd import _lib
+    from nfllib_amd._lib import FMT_I16
+    e = engine_factory(64, 4096, 4)
+    g = e.gauss_create(3.19, 128, 1 << 10)
+    try:
+        for batch in (1, 7, 8, 9, 100):
+            x = e.sample_gauss_small(e.empty_small(batch, FMT_I16), g, KEY, 40, amplifier=3)
+            w = e.fill_uniform(e.empty(batch), 5, 0)
+            k0, k1 = e.fill_uniform(e.empty(1), 6, 0), e.fill_uniform(e.empty(batch), 6, 1)
+            got = []
+            for mode in (1, 2, 0):
+                _lib.lib.nflhip_debug_fused_grid(mode)
+                a0, a1 = e.fwd_fma2(x, k0, w, k1, x)
+                got.append((a0, a1, e.fwd_fma(w, k1, x), e.fma_inv(a0, k0, a1, subtract=True), e.fma_inv(a0, k1, a1)))
+            for other in got[1:]:
+                assert all(torch.equal(p, q) for p, q in zip(got[0], other)), batch
+    finally:
+        _lib.lib.nflhip_debug_fused_grid(0)
+        e.gauss_destroy(g)

@@ -2233,7 +2233,7 @@ def emit_consts(em):
         em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
 
-def legacy_role_map(em, PER_ROW, NV, NSW):
+def legacy_role_map(em, PER_ROW, NV, NSW, b_ntt=False):
     R = em.raw
     # Dense role map, no idle workgroups (a workgroup launch costs ~35 ns of dispatcher time chip-wide, measured):
     # 28 workgroups per polynomial row -- w = wgx mod 28: 0..15 block products, 16..19 / 20..23 forward streaming of
@@ -2248,6 +2248,9 @@ def legacy_role_map(em, PER_ROW, NV, NSW):
     R("s_sub_u32 s89, s89, %d" % NV)
     R("s_lshr_b32 s42, s89, %d" % (NSW.bit_length() - 1))
     R("s_add_u32 s42, s42, 1")                           # role 1, 2, 3
+    if b_ntt:                                            # (no forward role for b: the second streaming role is the inverse one)
+        R("s_cmp_eq_u32 s42, 2")
+        R("s_cselect_b32 s42, 3, s42")
     R("s_and_b32 s89, s89, %d" % (NSW - 1))              # q: column groups q, q+NSW, q+2 NSW, q+3 NSW
     em.lines.append(".Lrole_known:")
     R("s_mul_i32 s87, s86, s14")
@@ -2918,12 +2921,15 @@ def fused_header(em, PER_ROW, NV, NSW, CG_LOG):
     R("s_branch .Lbody_v")
 
 
-def build_pipe(logn=None, fused=False):
+def build_pipe(logn=None, fused=False, b_ntt=False):
     """n = 65536 (logn 16): radix-16 streaming roles, 16 + 3 x 4 = 28 workgroups per row.
     n = 32768 (logn 15): radix-8 streaming roles (a thread's 16 registers hold two columns of 8 words), 8 + 3 x 2 = 14.
     fused: ONE launch of persistent workgroups for the whole batch; the three roles of a row run on ONE XCD, ordered by
     a per-XCD ticket queue and per-row completion counters, so the intermediates travel through that XCD's L2
-    (see fused_header below)."""
+    (see fused_header below).
+    b_ntt: operand b is ALREADY transformed (canonical words in the reference's order): there is no forward streaming role
+    for it -- NV + 2 NSW workgroups per row -- and the block products read its block as it lies (16 consecutive words per
+    thread: what the inner forward passes would have left in the registers), like the stand-alone polymul_ntt kernel."""
     global PIPE_LOGN
     if logn is not None:
         PIPE_LOGN = logn
@@ -2934,7 +2940,8 @@ def build_pipe(logn=None, fused=False):
     RADIX = 1 << RL
     NV = n_words // 4096                                  # block products per row
     NSW = 4 if RL == 4 else 2                             # streaming workgroups per row and operand
-    PER_ROW = NV + 3 * NSW
+    PER_ROW = NV + (2 if b_ntt else 3) * NSW
+    assert not (fused and b_ntt)
     CG_LOG = 11 if RL == 4 else 12                        # bytes (log2) of one column group: 256 columns x (16 / RADIX) x 8 B
     stride = n_words // RADIX * 8                         # bytes between x[o + k n/RADIX]
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c_v, a_v, b_v, psi
@@ -2975,7 +2982,7 @@ def build_pipe(logn=None, fused=False):
         R("s_mul_i32 s43, s3, s59")
         R("s_sub_u32 s2, s42, s43")                          # wgx = u mod gx
         em.lines.append(".Lno_remap:")
-        legacy_role_map(em, PER_ROW, NV, NSW)
+        legacy_role_map(em, PER_ROW, NV, NSW, b_ntt)
     stream_setup = {}
     # ---------------------------------------------------------------- streaming roles
     # A streaming workgroup owns the four column groups sub, sub+4, sub+8, sub+12 of its row (sub < 4; the others
@@ -3126,13 +3133,18 @@ def build_pipe(logn=None, fused=False):
     vm = VmCounter(em)
     mark_v = len(em.lines)
     strided_rows(em, vm, V_A, S_AROW, 2048)
-    strided_rows(em, vm, V_B, S_BROW, 2048)
+    if b_ntt:
+        em.valu("v_lshlrev_b32_e32 v%d, 7, v%d" % (T(1, 0), V_TID))
+        for i in range(8):
+            vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (V_B + 4 * i, V_B + 4 * i + 3, T(1, 0), S_BROW, 16 * i))
+    else:
+        strided_rows(em, vm, V_B, S_BROW, 2048)
     tw_seq = {}
     for st in range(4):
         tw_seq[("F1", st)] = PASS_TW["F1"](em, vm, st)
     emit_consts(em)
     mark = len(em.lines)
-    build_body(em, vm, "polymul", tw_seq, "_v")
+    build_body(em, vm, "polymul_ntt" if b_ntt else "polymul", tw_seq, "_v")
     if fused:
         mod = " nt" if FUSED_LIFO else FUSED_LOADS
         em.lines[mark_v:mark] = [l + mod if "global_load_dwordx2" in l else l for l in em.lines[mark_v:mark]]
@@ -3703,6 +3715,9 @@ def main():
     em_nt = build_pipe()
     em_nt.lines = nt(em_nt)
     emit_file(os.path.join(outdir, "polymul_pipe65536nt_gfx950.s"), "nflhip_polymul_pipe65536nt_asm", em_nt, args=ARGS_PIPE)
+    em_b = build_pipe(b_ntt=True)     # operand b already transformed: two streaming roles per row, b' read block-wise as it lies
+    em_b.lines = nt(em_b)
+    emit_file(os.path.join(outdir, "polymul_pipe65536ntb_gfx950.s"), "nflhip_polymul_pipe65536ntb_asm", em_b, args=ARGS_PIPE)
     if experiments:
         emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
         em15 = build_pipe(15)     # n = 32768 on the same kernel with radix-8 streaming roles (superseded by build_row32k)

@@ -40,6 +40,9 @@ def run(args):
     EXPR_ADD, EXPR_SUB, EXPR_MUL = 0x10, 0x11, 0x12                 # NFLHIP_EXPR_* (include/nflhip.h)
 
     e = Engine(64, args.degree, args.nmoduli)
+    if args.grid:
+        from nfllib_amd import _lib
+        _lib.lib.nflhip_debug_fused_grid(args.grid)
     key = bytes(range(1, 33)) if args.fixed_key else os.urandom(32)
     B = args.batch
     g = e.gauss_create(args.sigma, 128, 1 << 10)                    # FastGaussianNoise(SIGMA, 128, 1<<10), line 271
@@ -101,7 +104,7 @@ def run(args):
     bits = np.where(v < P[0] // 2, v % 2, 1 - v % 2)
     ok = bool((bits == 0).all())
     noise = np.where(v < P[0] // 2, v, v - P[0]).astype(np.float64)
-    out = {"demo": "LWE-like symmetric encryption of 0 (tests/nfllib_demo_main_op.cpp)", "plan": args.plan, "degree": args.degree,
+    out = {"demo": "LWE-like symmetric encryption of 0 (tests/nfllib_demo_main_op.cpp)", "plan": args.plan, "grid": args.grid, "degree": args.degree,
            "nmoduli": args.nmoduli, "batch": B, "encrypt_us_per_ciphertext": round(t_enc / B * 1e6, 4),
            "decrypt_us_per_ciphertext": round(t_dec / B * 1e6, 4), "encryptions_per_s": round(B / t_enc, 1),
            "decryptions_per_s": round(B / t_dec, 1), "decrypts_to_zero": ok,
@@ -149,6 +152,7 @@ def main():
     ap.add_argument("--plan", choices=("fused", "unfused"), default="fused")
     ap.add_argument("--traffic", action="store_true")
     ap.add_argument("--fixed-key", action="store_true", help="a fixed sampler key (reproducible digests)")
+    ap.add_argument("--grid", type=int, default=0, help="experiment: 1 / 2 force the 2-D / the XCD-dealt 1-D grid of the fused kernels (nflhip_debug_fused_grid)")
     args = ap.parse_args()
     out, ok = run(args)
     if args.traffic:
