@@ -28,7 +28,7 @@ WORKLOADS = {
     "B": (64, 4096, 4, 16384),   # BASELINE.json configs[1] -- the metric is quoted on this
     "D": (64, 4096, 4, 1 << 17), # configs[3]: B at 2^20 polys over 8 GPUs = 2^17 per GPU (3 x 16 GiB resident per GPU)
     "C": (64, 16384, 8, 1024),   # configs[2]
-    "E": (64, 65536, 30, 32),    # configs[4]
+    "E": (64, 65536, 30, 128),   # configs[4] (3 x 2 GiB resident + 4 GiB of scratch; 32 polynomials leave the pipeline's fill and drain visible: 0.140 / 0.153 / 0.162 at 32 / 64 / 128, profiles/r04_E_chunks.txt)
     "A": (32, 1024, 1, 1 << 19), # configs[0]'s shape (30-bit moduli) on the device -- secondary
     "F": (64, 32768, 2, 512),    # the reference's own largest test config (32768, 124, uint64_t): tests/CMakeLists.txt:19-48
     "G": (64, 8192, 2, 8192),    # ... and (8192, 124, uint64_t)
@@ -572,7 +572,7 @@ def main():
             del a, b, c
             torch.cuda.empty_cache()
             side = {}
-            for wl, sb, st_, crt in (("C", 1024, 20, False), ("E", 32, 20, True)):
+            for wl, sb, st_, crt in (("C", 1024, 20, False), ("E", 64, 20, True)):
                 try:
                     side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt)
                 except Exception as ex:   # reported, never fatal

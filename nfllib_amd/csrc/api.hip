@@ -400,7 +400,10 @@ static int ensure_scratch(nflhip_ctx *ctx, size_t bytes) {
 }
 
 // chunks of a batch in the n = 65536 pipeline (fill + drain cost ~0.7 chunk; small grids lose efficiency: 4 measured best)
-static constexpr int kPipeChunks = 4;
+#ifndef NFLHIP_PIPE_CHUNKS
+#define NFLHIP_PIPE_CHUNKS 4
+#endif
+static constexpr int kPipeChunks = NFLHIP_PIPE_CHUNKS;
 
 // Rows of 65536 / 32768 words in ONE launch of persistent workgroups (kernels_fast.hip launch_polymul_xcd_u64) instead
 // of the chunked pipeline / the register-resident row kernels: by default for SMALL batches, where the other plans'
