@@ -1092,7 +1092,7 @@ int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, co
 }
 
 int nflhip_has_fused_kernels(const nflhip_ctx *ctx) {
-  return ctx && ctx->shape.limb_bits == 64 && ctx->shape.logn == 12 && !ctx->shape.compiled_only && ctx->shape.small_delta &&
+  return ctx && ctx->shape.limb_bits == 64 && ctx->shape.logn >= 12 && ctx->shape.logn <= 14 && !ctx->shape.compiled_only && ctx->shape.small_delta &&
          ctx->shape.nm <= 65535 && !ctx->cyclic;
 }
 

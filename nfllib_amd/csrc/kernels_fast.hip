@@ -351,6 +351,8 @@ enum AsmKind {
   kAsmRow128U16, kAsmRowNtt128U16, kAsmRowFwd128U16, kAsmRowInv128U16,   // 16-bit limbs
   kAsmFusedEnc2, kAsmFusedFmaFwd, kAsmFusedFmsInv, kAsmFusedFmaInv,      // transform-fused pipelines, n = 4096 (build_fused)
   kAsmPipe64kB,                                                      // n = 65536, operand b already transformed (build_pipe b_ntt)
+  kAsmFused8kEnc2, kAsmFused8kFmaFwd, kAsmFused8kFmsInv, kAsmFused8kFmaInv,      // transform-fused pipelines, rows of 8192 words (build_fused_rows)
+  kAsmFused16kEnc2, kAsmFused16kFmaFwd, kAsmFused16kFmsInv, kAsmFused16kFmaInv,  // ... of 16384 words
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -371,7 +373,9 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_row8_u32_asm", "nflhip_row8_ntt_u32_asm", "nflhip_row8_fwd_u32_asm", "nflhip_row8_inv_u32_asm",
     "nflhip_row128_u16_asm", "nflhip_row128_ntt_u16_asm", "nflhip_row128_fwd_u16_asm", "nflhip_row128_inv_u16_asm",
     "nflhip_fused_enc2_4096_asm", "nflhip_fused_fma_fwd4096_asm", "nflhip_fused_fms_inv4096_asm", "nflhip_fused_fma_inv4096_asm",
-    "nflhip_polymul_pipe65536ntb_asm"};
+    "nflhip_polymul_pipe65536ntb_asm",
+    "nflhip_fused_enc2_8192_asm", "nflhip_fused_fma_fwd8192_asm", "nflhip_fused_fms_inv8192_asm", "nflhip_fused_fma_inv8192_asm",
+    "nflhip_fused_enc2_16384_asm", "nflhip_fused_fma_fwd16384_asm", "nflhip_fused_fms_inv16384_asm", "nflhip_fused_fma_inv16384_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -458,11 +462,14 @@ extern "C" void nflhip_debug_fused_grid(int mode) { g_fused_grid.store(mode); } 
 hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, uint64_t *out0, uint64_t *out1,
                                 const void *const *x, const unsigned *xstride, const int *xfmt, const void *const *k,
                                 const unsigned *kstride, size_t batch, hipStream_t st) {
-  if (s.limb_bits != 64 || s.logn != kLogN || s.compiled_only || !s.small_delta || s.nm > 65535 || kind < 0 || kind > 3)
+  if (s.limb_bits != 64 || s.logn < kLogN || s.logn > kLogN + 2 || s.compiled_only || !s.small_delta || s.nm > 65535 || kind < 0 || kind > 3)
     return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
   if (batch > 0x7fffffffull) return hipErrorInvalidValue;
-  hipFunction_t fn = asm_fn((AsmKind)(kAsmFusedEnc2 + kind));
+  // rows of 4096 words: 256 threads on the pair-mode map; 8192 / 16384: the row-resident ring-mode map, 512 / 1024 threads,
+  // lane-major twiddle copy
+  const int rows_log = s.logn - kLogN;
+  hipFunction_t fn = asm_fn((AsmKind)((rows_log == 0 ? kAsmFusedEnc2 : rows_log == 1 ? kAsmFused8kEnc2 : kAsmFused16kEnc2) + kind));
   if (!fn) return hipErrorNotSupported;
   const int nx = kind == 0 ? 3 : 2, nk = kind == 0 ? 2 : 1;
   struct {
@@ -486,7 +493,7 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
     args.k[i] = k[i];
     args.sk[i] = kstride[i];
   }
-  args.psi = t.psi;
+  args.psi = rows_log ? PSI_LM(t) : t.psi;
   args.mc = t.mc;
   args.nm = (int)s.nm;
   args.logn = s.logn;
@@ -496,12 +503,12 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
   const size_t groups = (batch + 7) / 8, wgs = groups * 8 * s.nm;
   const int forced = g_fused_grid.load(std::memory_order_relaxed);
   const bool fits = wgs <= 0x7fffffffull && groups * s.nm < (0xffffffffull / s.nm);
-  const bool remap = fits && forced != 1 && (forced == 2 || (kind < 2 && s.nm > 1 && args.fmt != 0));
+  const bool remap = rows_log == 0 && fits && forced != 1 && (forced == 2 || (kind < 2 && s.nm > 1 && args.fmt != 0));
   args.magic = remap ? (unsigned)(0x100000000ull / s.nm + 1) : 0u;
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   if (remap) return hipModuleLaunchKernel(fn, (unsigned)wgs, 1, 1, kThreads, 1, 1, 0, st, nullptr, extra);
-  return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+  return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, (unsigned)(kThreads << rows_log), 1, 1, 0, st, nullptr, extra);
 }
 
 // n = 65536: one launch of the three-role kernel (tools/gen_polymul_asm.py build_pipe): fused block products of `cnt_v`

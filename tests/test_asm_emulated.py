@@ -173,6 +173,38 @@ def test_emulated_u64_transform_fused_multiply_subtract_inverse(nm, batch, gener
     assert np.array_equal(got[0], o.intt(o.pointwise(0, x1, prod)))
 
 
+@pytest.mark.parametrize("n,nm,batch,fmt", [(8192, 2, 2, np.int8), (8192, 1, 1, np.uint64), (16384, 1, 1, np.int16), (16384, 2, 1, np.uint64)])
+def test_emulated_u64_transform_fused_pipelines_on_row_resident_kernels(n, nm, batch, fmt, generated, oracle_factory):
+    """the same four pipelines for rows of 8192 / 16384 words (tools/gen_polymul_asm.py build_fused_rows: ring-mode register
+    map, the key row in the empty ring's registers): both forward kernels and both inverse kernels against the oracle"""
+    o = oracle_factory(64, n, nm)
+    prm, ka, kb = operands(o, 64, n, nm, 1, 41)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    rng = np.random.default_rng(42)
+    if fmt is np.uint64:
+        _, x0, x1 = operands(o, 64, n, nm, batch, 43)
+        _, x2, _ = operands(o, 64, n, nm, batch, 44)
+        xs = w = [x0, x1, x2]
+    else:
+        info = np.iinfo(fmt)
+        xs = [rng.integers(info.min, info.max, size=(batch, n), endpoint=True).astype(fmt) for _ in range(3)]
+        w = [_signed_rows(x, P) for x in xs]
+    f = [o.ntt(x) for x in w]
+    KA, KB = (np.ascontiguousarray(np.broadcast_to(k_, f[0].shape)) for k_ in (ka, kb))
+    want0 = o.pointwise(0, o.pointwise(2, f[0], KA), f[1])
+    want1 = o.pointwise(0, o.pointwise(2, f[0], KB), f[2])
+    G = n // 4096
+    got = asm_emu.run_fused_kernel(generated("fused_enc2_%d" % n), n, nm, prm, xs, [ka, kb], batch, 2, groups=G)
+    assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1)
+    got = asm_emu.run_fused_kernel(generated("fused_fma_fwd%d" % n), n, nm, prm, xs[:2], [ka], batch, 1, groups=G)
+    assert np.array_equal(got[0], want0)
+    prod = o.pointwise(2, want0, KB)
+    got = asm_emu.run_fused_kernel(generated("fused_fms_inv%d" % n), n, nm, prm, [want0, want1], [kb], batch, 1, groups=G)
+    assert np.array_equal(got[0], o.intt(o.pointwise(1, want1, prod)))
+    got = asm_emu.run_fused_kernel(generated("fused_fma_inv%d" % n), n, nm, prm, [want0, want1], [kb], batch, 1, groups=G)
+    assert np.array_equal(got[0], o.intt(o.pointwise(0, want1, prod)))
+
+
 @pytest.mark.parametrize("n,nm,batch", [(16384, 2, 3), (8192, 3, 4), (8192, 1, 1)])
 def test_emulated_u64_two_rows_per_workgroup_forward_transform_of_long_rows(n, nm, batch, generated, oracle_factory):
     """stand-alone forward transform at n = 16384 / 8192: two polynomials of one modulus per workgroup on shared twiddle

@@ -5,8 +5,8 @@ decrypt() bodies (reference tests/nfllib_demo_main_op.cpp:26-58) as ONE device p
   * the engine's own unfused sequence (nflhip_ntt_fwd_dev / nflhip_eval_dev / nflhip_ntt_inv_dev), and
   * the context created under NFLHIP_VARIANT=hipcc, which composes the same result from the compiled kernels,
 
-bit for bit.  u64 / 4096 runs the generated gfx950 kernels (tools/gen_polymul_asm.py build_fused); every other shape the
-composed plan behind the same entry points.
+bit for bit.  u64 / 4096, 8192 and 16384 run the generated gfx950 kernels (tools/gen_polymul_asm.py build_fused /
+build_fused_rows); every other shape the composed plan behind the same entry points.
 """
 import os
 
@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 KEY = bytes(range(32))
 EXPR_ADD, EXPR_SUB, EXPR_MUL = 0x10, 0x11, 0x12
-SHAPES = [(64, 4096, 4), (64, 4096, 1), (64, 4096, 3), (64, 1024, 2), (64, 8192, 2), (32, 1024, 1), (32, 4096, 2), (16, 128, 1)]
+SHAPES = [(64, 4096, 4), (64, 4096, 1), (64, 4096, 3), (64, 1024, 2), (64, 8192, 2), (64, 8192, 1), (64, 16384, 8), (64, 16384, 1),
+          (64, 32768, 2), (32, 1024, 1), (32, 4096, 2), (16, 128, 1)]
 
 
 def _words(o, batch, seed, operand=0):

@@ -3576,6 +3576,372 @@ def inverse_half(em, vm, tw_seq, first_stage=None):
     epilogue_inverse(em, vm, last_plain)
 
 
+# ------------------------------------------------------------------ transform-fused pipelines, rows of 8192 / 16384 words
+# The same four pipelines on the row-resident register map of build_row16k (ring mode: 128 VGPRs, one butterfly at a time,
+# twiddle records streaming through the 9-slot ring; ROW_G sub-groups of 256 threads, one outer radix-ROW_G pass F0 / I0
+# around the 4096-word passes).  One workgroup per (batch element, modulus) row of exactly 4096 ROW_G words.  The ring is
+# empty between a transform and the next one, so the 32 registers of a key row's 16 words live in ITS slots: the key is
+# loaded behind the last forward record, the multiply-add lands in the key's registers (x' stays for the second result), and
+# the next transform's ring is primed once the result's stores have been issued.  The exchanges are the plain ones of
+# build_row16k (write, barrier, read): the split-phase schedules of the product kernels are tied to their two-operand shape.
+# kernarg as ARGS_FUSED (the grid is always (batch, nm): magic is ignored).
+S_X2ROW16 = "s[52:53]"     # (stream 1's borrow pair: idle in single-stream mode)
+
+
+def build_fused_rows(kind):
+    """kind: enc2 | fma_fwd | fms_inv | fma_inv -- over one 4096 * ROW_G-word row per workgroup (configure("ring", ROW_G))"""
+    assert SINGLE_STREAM and ROW_G in (1, 2, 4)      # (1: a 4096-word row on the ring-mode map -- 128 VGPRs, four workgroups per CU)
+    em = Emitter()
+    vm = VmCounter(em)
+    R = em.raw
+    fwd = kind in ("enc2", "fma_fwd")
+    passes = {"F0": (S_K0["F0"], None, False), "F1": (S_K["F1"], None, False), "F2": (S_K["F2"], V_BIDX, False),
+              "F3": (S_K["F3"], V_TID, False), "I1": (S_K["I1"], V_TID, True), "I2": (S_K["I2"], V_BIDX, True),
+              "I3": (S_K["I3"], None, True), "I0": (S_K0["I0"], None, True)}
+    order = {"F0": tuple(range(ROW_LG)), "F1": (0, 1, 2, 3), "F2": (0, 1, 2, 3), "F3": (0, 1, 2, 3), "I1": (3, 2, 1, 0),
+             "I2": (3, 2, 1, 0), "I3": (3, 2, 1, 0) if ROW_G > 1 else (3, 2, 1), "I0": tuple(range(ROW_LG - 1, 0, -1))}
+    per = 16 // ROW_G
+    AX = T(0, 0)
+    V_K = V_TW
+    row_bytes_log = 15 + ROW_LG
+
+    # ---------------- prologue: thread map of prologue16k, operands of prologue_fused
+    R("s_load_dwordx16 s[56:71], s[0:1], 0x0")           # out0 out1 x0 x1 x2 k0 k1 psi
+    R("s_load_dwordx2 s[12:13], s[0:1], 0x40")           # mc
+    R("s_load_dwordx2 s[72:73], s[0:1], 0x48")           # nm, logn
+    R("s_load_dwordx8 s[76:83], s[0:1], 0x50")           # fmt, strides x0 x1 x2 k0 k1, count, magic
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_OFF8, V_TID))                      # tid*8
+    em.valu("v_mov_b32_e32 v%d, v%d" % (V_TWA, V_TID))                              # the workgroup-wide thread index (compact inputs)
+    em.valu("v_lshrrev_b32_e32 v%d, 8, v%d" % (V_BIDX, V_TID))                      # q (wave-uniform)
+    R("s_nop 1")
+    R("v_readfirstlane_b32 %s, v%d" % (S_Q, V_BIDX))
+    R("s_nop 1")
+    em.valu("v_and_b32_e32 v%d, 0xff, v%d" % (V_TID, V_TID))                        # t = tid & 255
+    R("s_mul_i32 %s, %s, 0x%x" % (S_SLAB, S_Q, SLAB_BYTES))
+    em.valu("v_lshrrev_b32_e32 v%d, 4, v%d" % (V_BIDX, V_TID))                      # B = t >> 4
+    em.valu("v_add_u32_e32 v%d, v%d, v%d" % (V_L1W, V_TID, V_BIDX))
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1W, V_L1W))                       # (t + B)*8
+    em.valu("v_and_b32_e32 v%d, 15, v%d" % (V_L1R, V_TID))                          # r
+    em.valu("v_mov_b32_e32 v%d, 0x110" % (V_L2R,))                                  # 272
+    em.valu("v_mad_u32_u24 v%d, v%d, v%d, v%d" % (V_L1R, V_BIDX, V_L2R, V_L1R))     # 272*B + r
+    em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (V_L1R, V_L1R))
+    em.valu("v_mov_b32_e32 v%d, 0x88" % (V_L2R,))                                   # 17*8
+    em.valu("v_mul_u32_u24_e32 v%d, v%d, v%d" % (V_L2R, V_TID, V_L2R))              # 17*t*8
+    for reg in (V_L1W, V_L1R, V_L2R):
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (reg, S_SLAB, reg))                  # inside the sub-group's slab
+    for t_ in sorted(set(V_T)):
+        em.valu("v_mov_b32_e32 v%d, 0" % (t_ + 15,))                                # the persistent zero of ZP
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b32 s14, s72")                              # nm
+    R("s_sub_u32 s88, s73, 12")                          # r = ROW_LG: rows of exactly 4096 ROW_G words
+    R("s_mov_b32 %s, s76" % S_FMT)
+    R("s_mov_b64 s[10:11], s[70:71]")                    # psi (the lane-major copy)
+
+    def word_row(dst, base, stride):
+        R("s_mul_i32 s42, s2, s%d" % stride if stride is not None else "s_mov_b32 s42, s2")
+        R("s_mul_hi_u32 s43, s42, s14")
+        R("s_mul_i32 s42, s42, s14")
+        R("s_add_u32 s42, s42, s3")
+        R("s_addc_u32 s43, s43, 0")
+        R("s_lshl_b64 s[42:43], s[42:43], %d" % row_bytes_log)
+        R("s_add_u32 s%d, s%d, s42" % (dst, base))
+        R("s_addc_u32 s%d, s%d, s43" % (dst + 1, base + 1))
+
+    def x_row(dst, base, stride, k):
+        if not fwd:
+            return word_row(dst, base, stride)
+        R("s_bfe_u32 %s, %s, 0x%x" % (S_F, S_FMT, (4 << 16) | (4 * k)))
+        R("s_mul_i32 s42, s2, s%d" % stride)
+        R("s_mul_hi_u32 s45, s42, s14")
+        R("s_mul_i32 s44, s42, s14")
+        R("s_add_u32 s44, s44, s3")
+        R("s_addc_u32 s45, s45, 0")
+        R("s_lshl_b64 s[44:45], s[44:45], %d" % row_bytes_log)
+        R("s_add_u32 s87, %s, %d" % (S_F, 11 + ROW_LG))      # compact: (x * stride) << (log2 n + f - 1)
+        R("s_mov_b32 s43, 0")
+        R("s_lshl_b64 s[42:43], s[42:43], s87")
+        R("s_cmp_eq_u32 %s, 0" % S_F)
+        R("s_cselect_b64 s[42:43], s[44:45], s[42:43]")
+        R("s_add_u32 s%d, s%d, s42" % (dst, base))
+        R("s_addc_u32 s%d, s%d, s43" % (dst + 1, base + 1))
+
+    x_row(16, 60, 77, 0)
+    x_row(18, 62, 78, 1)
+    word_row(20, 56, None)
+    word_row(96, 66, 80)                                 # k0
+    if kind == "enc2":
+        x_row(52, 64, 79, 2)                             # x2
+        word_row(98, 68, 81)                             # k1
+        word_row(100, 58, None)                          # out1
+    # tw = psi + (cm << (logn + 4)); pass constants of the row's only block group (blkG = 0) and of block q
+    R("s_add_u32 s43, s88, 16")
+    R("s_lshl_b32 s42, s3, s43")
+    R("s_add_u32 s22, s10, s42")
+    R("s_addc_u32 s23, s11, 0")
+    R("s_mov_b32 %s, 1" % (S_K0["F0"],))
+    R("s_mov_b32 %s, 2" % (S_K0["I0"],))
+    R("s_mov_b32 s89, %s" % (S_Q,))                      # blk = q
+    R("s_lshl_b32 s90, 1, s88")
+    R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
+    R("s_lshl_b32 s91, s90, 4")
+    R("s_lshl_b32 s92, s90, 8")
+    R("s_lshl_b32 s93, 0x200, s88")
+    R("s_lshl_b32 s42, s89, 8")
+    R("s_sub_u32 s93, s93, s42")                         # (512<<r) - 256*blk
+    R("s_lshl_b32 s94, 32, s88")
+    R("s_lshl_b32 s42, s89, 4")
+    R("s_sub_u32 s94, s94, s42")                         # (32<<r) - 16*blk
+    R("s_lshl_b32 s95, 2, s88")
+    R("s_sub_u32 s95, s95, s89")                         # (2<<r) - blk
+    R("s_mul_i32 s42, s3, 0x70")
+    R("s_add_u32 s42, s12, s42")
+    R("s_addc_u32 s43, s13, 0")
+    R("s_load_dwordx16 s[56:71], s[42:43], 0x0")          # the ModConst record (the kernarg copies are spent)
+    R("s_load_dwordx8 s[72:79], s[42:43], 0x40")
+    R("s_load_dwordx4 s[80:83], s[42:43], 0x60")
+
+    def x_loads(dst, srow, k, tag):
+        """x[tid + 256 G j] -> register pair j (the layout F0 starts from): word rows or compact; 16 loads on every path"""
+        step = 256 * ROW_G
+        R("s_bfe_u32 %s, %s, 0x%x" % (S_F, S_FMT, (4 << 16) | (4 * k)))
+        R("s_mov_b64 s[86:87], %s" % (srow,))
+        R("s_cmp_eq_u32 %s, 0" % S_F)
+        R("s_cbranch_scc0 .L%s_compact" % tag)
+        seq = 0
+        for j in range(16):
+            seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] nt" % (vp(dst + 2 * j), V_OFF8))
+            if j < 15:
+                R("s_add_u32 s86, s86, 0x%x" % (8 * step,))
+                R("s_addc_u32 s87, s87, 0")
+        R("s_branch .L%s_issued" % tag)
+        em.lines.append(".L%s_compact:" % tag)
+        for f, (es, op) in enumerate(((1, "global_load_sbyte"), (2, "global_load_sshort"), (4, "global_load_dword")), 1):
+            if f < 3:
+                R("s_cmp_eq_u32 %s, %d" % (S_F, f))
+                R("s_cbranch_scc0 .L%s_f%d" % (tag, f + 1))
+            if es > 1:
+                em.valu("v_lshlrev_b32_e32 v%d, %d, v%d" % (AX, es.bit_length() - 1, V_TWA))
+            for j in range(16):
+                R("%s v%d, v%d, s[86:87]" % (op, dst + 2 * j, V_TWA if es == 1 else AX))
+                if j < 15:
+                    R("s_add_u32 s86, s86, 0x%x" % (es * step,))
+                    R("s_addc_u32 s87, s87, 0")
+            if f < 3:
+                R("s_branch .L%s_issued" % tag)
+                em.lines.append(".L%s_f%d:" % (tag, f + 1))
+        em.lines.append(".L%s_issued:" % tag)
+        return seq
+
+    def block_base(srow):                                 # s[86:87] = first word of this sub-group's 4096-word block
+        lo, hi = srow[2:-1].split(":")
+        R("s_lshl_b32 s42, %s, 15" % (S_Q,))
+        R("s_add_u32 s86, s%s, s42" % lo)
+        R("s_addc_u32 s87, s%s, 0" % hi)
+
+    def lane_loads(dst, srow, stream=True):
+        block_base(srow)
+        g, _ = lane_contig_setup(em)
+        seqs = []
+        for j in range(16):
+            seqs.append(vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d%s" % (vp(dst + 2 * j), g, (j & 7) * 512, " nt" if stream else "")))
+            if j == 7:
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+        return seqs
+
+    if fwd:
+        x_loads(V_A, S_AROW, 0, "x0")
+        seq_x = x_loads(V_B, S_BROW, 1, "x1")
+    else:
+        lane_loads(V_A, S_AROW)
+        seq_k = lane_loads(V_K, S_K0ROW, stream=False)[-1]
+        seq_b = lane_loads(V_B, S_BROW)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b64 s[24:25], s[56:57]")                    # p
+    R("s_mov_b64 s[26:27], s[58:59]")                    # 2p
+    R("s_add_u32 s28, s58, s56")                         # 3p
+    R("s_addc_u32 s29, s59, s57")
+    R("s_mov_b32 s30, s80")                              # delta
+    R("s_mov_b32 s31, 0x3fffffff")
+    R("s_mov_b32 s15, 0xc0000000")
+    R("s_mov_b64 s[32:33], s[82:83]")                    # mu2
+    R("s_mov_b64 s[34:35], s[62:63]")                    # ninv
+    R("s_mov_b64 s[36:37], s[64:65]")                    # ninv_sh
+    R("s_mov_b64 s[38:39], s[66:67]")                    # w1ninv
+    R("s_mov_b64 s[40:41], s[68:69]")                    # w1ninv_sh
+    em.valu("v_mov_b32_e32 v%d, s25" % (V_PHI,))
+
+    def make_ring(names):
+        uses = [(name, s_, g) for name in names for s_ in order[name] for g in range(1 << s_)]
+        ring = Ring(em, vm, RING_SLOTS, uses, passes)
+        ring.prime()
+        return ring
+
+    def forward(bases, first):
+        """F0 X0 F1 E1 F2 E2 F3 over `bases` on shared twiddle records (the plain exchanges of build_row16k)"""
+        ring = make_ring(["F0", "F1", "F2", "F3"])
+
+        def fwd_pass(name):
+            em.comment("%s" % name)
+            for s_ in order[name]:
+                half = 8 >> s_
+                for g in range(1 << s_):
+                    tw = ring.get((name, s_, g))
+                    jobs = []
+                    for h in range(half):
+                        i0 = g * 2 * half + h
+                        for base in bases:
+                            jobs.append(ct_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
+                    run_pairs(em, jobs)
+                    ring.done((name, s_, g))
+        fwd_pass("F0")
+        for i, base in enumerate(bases if ROW_G > 1 else ()):
+            em.comment("X0: thread (q, t) slot per*qq + j  ->  sub-group qq, thread t, slot q + G*j")
+            if i or not first:
+                R("s_barrier")       # WAR: the slabs are still being read (previous operand / the first result's store transposes)
+            em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * SLAB_BYTES, V_OFF8))
+            for k in range(16):
+                qq, j = k // per, k % per
+                R("ds_write_b64 v%d, %s offset:%d" % (V_OFF8 if qq < 2 else AX, vp(base + 2 * k), (qq & 1) * SLAB_BYTES + j * 2048 * ROW_G))
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+            em.valu("v_add_u32_e32 v%d, %s, v%d" % (AX, S_SLAB, AX))
+            for k in range(16):
+                R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * k), AX, 2048 * k))
+            R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F1")
+        for base in bases:
+            em.comment("E1")
+            R("s_barrier")           # WAR against the previous exchange through this slab
+            lds_write(em, V_L1W, base, 2176)
+            R("s_waitcnt lgkmcnt(0)")
+            R("s_barrier")
+            lds_read(em, V_L1R, base, 136)
+            R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F2")
+        em.comment("E2: wave-local 16-lane transposes (LDS is in order per wave)")
+        for base in bases:
+            lds_write(em, V_L1R, base, 136)
+            lds_read(em, V_L2R, base, 8)
+        R("s_waitcnt lgkmcnt(0)")
+        fwd_pass("F3")
+
+    def x_expand(dst, k, tag):
+        fused_x_expand(em, dst, k, tag)
+
+    def fma_store(xb, fold_a, k_row, dst_row, early=None):
+        """V_K = canonical(key * V_A + xb) -> dst_row; the key's 16 words go into the (empty) ring's registers"""
+        em.comment("the key row's block: words 16t .. 16t+15 of block q")
+        block_base(k_row)
+        em.valu("v_lshlrev_b32_e32 v%d, 7, v%d" % (AX, V_TID))
+        kseq = [vm.load("global_load_dwordx4 v[%d:%d], v%d, s[86:87] offset:%d" % (V_K + 4 * i, V_K + 4 * i + 3, AX, 16 * i)) for i in range(8)]
+        for i in range(8):
+            vm.wait(kseq[i])
+            run_pairs(em, [fma_job(V_K + 4 * i, V_A + 4 * i, xb + 4 * i, fold_a), fma_job(V_K + 4 * i + 2, V_A + 4 * i + 2, xb + 4 * i + 2, fold_a)])
+        if early is not None:
+            early()
+        lds_write(em, V_L2R, V_K, 8)
+        g, l = lane_contig_setup(em)
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (l, S_SLAB, l))
+        for j in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_K + 2 * j), l, 544 * j))
+        R("s_waitcnt lgkmcnt(0)")
+        block_base(dst_row)
+        for j in range(16):
+            vm.load("global_store_dwordx2 v%d, %s, s[86:87] offset:%d nt" % (g, vp(V_K + 2 * j), (j & 7) * 512))
+            if j == 7:
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+
+    if fwd:
+        vm.wait(seq_x)
+        x_expand(V_A, 0, "e0")
+        x_expand(V_B, 1, "e1")
+        forward([V_A, V_B], True)
+        if kind == "fma_fwd":
+            fma_store(V_B, True, S_K0ROW, S_CROW)
+            R("s_endpgm")
+            return em
+        state = {}
+
+        def early():
+            state["x2"] = x_loads(V_B, S_X2ROW16, 2, "x2")
+        fma_store(V_B, True, S_K0ROW, S_CROW, early)
+        em.comment("second half: x2 alone, x0' stays in V_A")
+        vm.wait(state["x2"])
+        x_expand(V_B, 2, "e2")
+        forward([V_B], False)
+        fma_store(V_B, False, S_K1ROW, S_O1ROW)
+        R("s_endpgm")
+        return em
+
+    # ---- fms_inv / fma_inv
+    vm.wait(seq_k)
+    em.comment("x1 -+ x0 * k0 in the loaded (lane-contiguous) layout; x1 is consumed as it lands")
+    for i in range(0, 16, 2):
+        vm.wait(seq_b[i + 1])
+        run_pairs(em, [fms_job(V_A + 2 * j, V_K + 2 * j, V_B + 2 * j, kind == "fms_inv") for j in (i, i + 1)])
+    ring = make_ring(["I1", "I2", "I3", "I0"])
+    em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
+    _, l = lane_contig_setup(em)
+    em.valu("v_add_u32_e32 v%d, %s, v%d" % (l, S_SLAB, l))
+    for j in range(16):
+        R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
+    lds_read(em, V_L2R, V_A, 8)
+    R("s_waitcnt lgkmcnt(0)")
+
+    def inv_pass(name, stages):
+        em.comment(name)
+        for s_ in stages:
+            half = 8 >> s_
+            for g in range(1 << s_):
+                tw = ring.get((name, s_, g))
+                run_pairs(em, [gs_bfly(V_A + 2 * (g * 2 * half + h), V_A + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
+                ring.done((name, s_, g))
+    inv_pass("I1", (3, 2, 1, 0))
+    em.comment("E2'")
+    lds_write(em, V_L2R, V_A, 8)
+    lds_read(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I2", (3, 2, 1, 0))
+    em.comment("E1'")
+    lds_write(em, V_L1R, V_A, 136)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_barrier")
+    lds_read(em, V_L1W, V_A, 2176)
+    R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I3", (3, 2, 1, 0) if ROW_G > 1 else (3, 2, 1))
+    if ROW_G > 1:
+        em.comment("X0': thread (q, t) slot g + G*j  ->  thread (g, t) slot per*q + j, reader-major layout [slot][tid]")
+        R("s_barrier")               # every wave is done reading E1'
+        R("s_lshl_b32 s86, %s, 15" % (S_Q,))
+        em.valu("v_lshlrev_b32_e32 v%d, 3, v%d" % (AX, V_TID))
+        em.valu("v_add_u32_e32 v%d, s86, v%d" % (AX, AX))                              # q*32768 + t*8
+        for k in range(16):
+            g_, j = k % ROW_G, k // ROW_G
+            R("ds_write_b64 v%d, %s offset:%d" % (AX, vp(V_A + 2 * k), j * 2048 * ROW_G + g_ * 2048))
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_barrier")
+        rstep = 2048 * ROW_G
+        em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 8 * rstep, V_OFF8))
+        for k in range(16):
+            R("ds_read_b64 %s, v%d offset:%d" % (vp(V_A + 2 * k), V_OFF8 if k < 8 else AX, (k & 7) * rstep))
+        R("s_waitcnt lgkmcnt(0)")
+    inv_pass("I0", order["I0"])
+    em.comment("stage 0 with n^-1 folded in")
+    R("s_waitcnt vmcnt(0)")
+    run_pairs(em, [final_bfly(V_A + 2 * h, V_A + 2 * (h + 8)) for h in range(8)])
+    R("s_mov_b64 s[86:87], %s" % (S_CROW,))
+    for k in range(16):
+        R("global_store_dwordx2 v%d, %s, s[86:87] nt" % (V_OFF8, vp(V_A + 2 * k)))
+        if k < 15:
+            R("s_add_u32 s86, s86, 0x%x" % (2048 * ROW_G,))
+            R("s_addc_u32 s87, s87, 0")
+    R("s_endpgm")
+    return em
+
+
 KERNELS_FUSED = {
     "enc2": ("fused_enc2_4096", "nflhip_fused_enc2_4096_asm"),
     "fma_fwd": ("fused_fma_fwd4096", "nflhip_fused_fma_fwd4096_asm"),
@@ -3757,6 +4123,22 @@ def main():
         g.update(NEXT_SGPR=102)
         emit_file(os.path.join(outdir, "polymul8192p_gfx950.s"), "nflhip_polymul8192p_asm", build_row16k_loop(),
                   args=ARGS_STD + [("i32", 48), ("i32", 52)])
+    # experiment (nflhip_debug_fused_grid(3)): the inverse pipelines of a 4096-word row on the ring-mode map (128 VGPRs: four
+    # workgroups per CU instead of three, one butterfly at a time)
+    configure("ring", 1)
+    g.update(NEXT_SGPR=102, LDS_BYTES=SLAB_BYTES)
+    for kind in ("fms_inv", "fma_inv"):
+        stem, kname = KERNELS_FUSED[kind]
+        emit_file(os.path.join(outdir, stem + "r_gfx950.s"), kname.replace("_asm", "r_asm"), build_fused_rows(kind), args=ARGS_FUSED)
+    g.update(NEXT_SGPR=96)
+    # transform-fused pipelines on the row-resident map: rows of 16384 and 8192 words
+    for groups, words in ((4, 16384), (2, 8192)):
+        configure("ring", groups)
+        g.update(NEXT_SGPR=102)
+        for kind, (stem, kname) in KERNELS_FUSED.items():
+            emit_file(os.path.join(outdir, stem.replace("4096", str(words)).replace("_%d" % words, "_%d" % words) + "_gfx950.s"),
+                      kname.replace("4096", str(words)), build_fused_rows(kind), args=ARGS_FUSED)
+        g.update(NEXT_SGPR=96)
     configure(ring, 4)
     # 32768-word rows: one operand register-resident in a 1024-thread workgroup (4 sub-groups x 2 blocks)
     g = globals()
