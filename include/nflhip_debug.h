@@ -23,9 +23,10 @@ void nflhip_debug_gauss_tie_shift(int shift);
 struct nflhip_ctx;
 void nflhip_debug_host_pipe_seconds(const struct nflhip_ctx *ctx, double out[4]);
 
-/* grid of the transform-fused kernels (u64, degree 4096): 0 = the library's policy (forward entries with compact inputs and
- * more than one modulus deal the nm rows of a batch element to one XCD; everything else one workgroup per (element, modulus)
- * in a 2-D grid), 1 = always the 2-D grid, 2 = always the XCD-dealt 1-D grid.  Same results either way. */
+/* variants of the transform-fused kernels: 0 = the library's policy (forward entries with compact inputs and more than one
+ * modulus deal the nm rows of a batch element to one XCD, everything else runs one workgroup per (element, modulus) in a
+ * 2-D grid; at degree 4096 the inverse entries run on the ring-mode register map, the forward ones on the pair-mode map),
+ * 1 = always the 2-D grid, 2 = always the XCD-dealt 1-D grid, 3 = the other register map at degree 4096.  Same results. */
 void nflhip_debug_fused_grid(int mode);
 
 #ifdef __cplusplus

@@ -353,6 +353,7 @@ enum AsmKind {
   kAsmPipe64kB,                                                      // n = 65536, operand b already transformed (build_pipe b_ntt)
   kAsmFused8kEnc2, kAsmFused8kFmaFwd, kAsmFused8kFmsInv, kAsmFused8kFmaInv,      // transform-fused pipelines, rows of 8192 words (build_fused_rows)
   kAsmFused16kEnc2, kAsmFused16kFmaFwd, kAsmFused16kFmsInv, kAsmFused16kFmaInv,  // ... of 16384 words
+  kAsmFusedEnc2R, kAsmFusedFmaFwdR, kAsmFusedFmsInvR, kAsmFusedFmaInvR,  // ... of 4096 words on the ring-mode map (128 VGPRs, four workgroups per CU)
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -375,7 +376,8 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_fused_enc2_4096_asm", "nflhip_fused_fma_fwd4096_asm", "nflhip_fused_fms_inv4096_asm", "nflhip_fused_fma_inv4096_asm",
     "nflhip_polymul_pipe65536ntb_asm",
     "nflhip_fused_enc2_8192_asm", "nflhip_fused_fma_fwd8192_asm", "nflhip_fused_fms_inv8192_asm", "nflhip_fused_fma_inv8192_asm",
-    "nflhip_fused_enc2_16384_asm", "nflhip_fused_fma_fwd16384_asm", "nflhip_fused_fms_inv16384_asm", "nflhip_fused_fma_inv16384_asm"};
+    "nflhip_fused_enc2_16384_asm", "nflhip_fused_fma_fwd16384_asm", "nflhip_fused_fms_inv16384_asm", "nflhip_fused_fma_inv16384_asm",
+    "nflhip_fused_enc2_4096r_asm", "nflhip_fused_fma_fwd4096r_asm", "nflhip_fused_fms_inv4096r_asm", "nflhip_fused_fma_inv4096r_asm"};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -469,7 +471,14 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
   // rows of 4096 words: 256 threads on the pair-mode map; 8192 / 16384: the row-resident ring-mode map, 512 / 1024 threads,
   // lane-major twiddle copy
   const int rows_log = s.logn - kLogN;
-  hipFunction_t fn = asm_fn((AsmKind)((rows_log == 0 ? kAsmFusedEnc2 : rows_log == 1 ? kAsmFused8kEnc2 : kAsmFused16kEnc2) + kind));
+  const int forced = g_fused_grid.load(std::memory_order_relaxed);
+  // rows of 4096 words have two register maps: pair mode (168 VGPRs, two interleaved butterflies, three workgroups per CU)
+  // and ring mode (128 VGPRs, one butterfly at a time, four per CU).  Measured same-box (profiles/r04_ring_vs_pair_4096.txt):
+  // the inverse pipelines -- 70 % VALU, the rest exposed operand latency -- gain 4 % from the fourth workgroup; the forward
+  // ones are VALU-bound and keep pair mode.  Mode 3 of the debug hook swaps the choice (A/B runs).
+  const bool ring4k = rows_log == 0 && ((kind >= 2) != (forced == 3));
+  hipFunction_t fn = ring4k ? asm_fn((AsmKind)(kAsmFusedEnc2R + kind))
+                            : asm_fn((AsmKind)((rows_log == 0 ? kAsmFusedEnc2 : rows_log == 1 ? kAsmFused8kEnc2 : kAsmFused16kEnc2) + kind));
   if (!fn) return hipErrorNotSupported;
   const int nx = kind == 0 ? 3 : 2, nk = kind == 0 ? 2 : 1;
   struct {
@@ -493,7 +502,7 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
     args.k[i] = k[i];
     args.sk[i] = kstride[i];
   }
-  args.psi = rows_log ? PSI_LM(t) : t.psi;
+  args.psi = rows_log || ring4k ? PSI_LM(t) : t.psi;
   args.mc = t.mc;
   args.nm = (int)s.nm;
   args.logn = s.logn;
@@ -501,13 +510,14 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
   // forward kinds with more than one modulus: the nm rows of a batch element back to back on one XCD (1-D grid, the kernel
   // deals the workgroups itself), so that compact inputs -- one copy for all moduli -- come from HBM once
   const size_t groups = (batch + 7) / 8, wgs = groups * 8 * s.nm;
-  const int forced = g_fused_grid.load(std::memory_order_relaxed);
   const bool fits = wgs <= 0x7fffffffull && groups * s.nm < (0xffffffffull / s.nm);
-  const bool remap = rows_log == 0 && fits && forced != 1 && (forced == 2 || (kind < 2 && s.nm > 1 && args.fmt != 0));
+  // (rows of 8192 / 16384 words keep the 2-D grid by default: with the nm rows of an element on one XCD that L2 holds nm
+  // twiddle tables and the key rows of nm moduli at once -- measured at 16384 x 8: encrypt traffic 1.24x -> 1.32x)
+  const bool remap = fits && forced != 1 && (forced == 2 || (rows_log == 0 && kind < 2 && s.nm > 1 && args.fmt != 0));
   args.magic = remap ? (unsigned)(0x100000000ull / s.nm + 1) : 0u;
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  if (remap) return hipModuleLaunchKernel(fn, (unsigned)wgs, 1, 1, kThreads, 1, 1, 0, st, nullptr, extra);
+  if (remap) return hipModuleLaunchKernel(fn, (unsigned)wgs, 1, 1, (unsigned)(kThreads << rows_log), 1, 1, 0, st, nullptr, extra);
   return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, (unsigned)(kThreads << rows_log), 1, 1, 0, st, nullptr, extra);
 }
 

@@ -1108,7 +1108,7 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts, remap=False, groups=1):
+def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts, remap=False, groups=1, lane_major=None):
     """the transform-fused kernels of tools/gen_polymul_asm.py build_fused (kernarg ARGS_FUSED: out0 out1 x0 x1 x2 k0 k1 psi
     mc | nm logn fmt | strides x0 x1 x2 k0 k1 | count magic; grid (batch, nm), or -- remap -- the 1-D grid whose workgroups
     the kernel deals to (batch element, modulus) itself, the nm rows of an element back to back on one XCD).  xs: up to three forward inputs / inverse
@@ -1117,7 +1117,8 @@ def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts, remap=False, gr
     -> list of `nouts` result arrays (batch, nm, n)"""
     import struct
     mem = Memory()
-    psi, mc = device_tables(64, n, nm, prm, lane_major=groups > 1)   # (rows of 8192 / 16384 words: the ring-mode kernels, groups = n / 4096)
+    # (rows of 8192 / 16384 words -- groups = n / 4096 -- and the ring-mode experiment at 4096 read the lane-major twiddle copy)
+    psi, mc = device_tables(64, n, nm, prm, lane_major=groups > 1 if lane_major is None else lane_major)
     outs = [np.zeros((batch, nm, n), dtype=np.uint64) for _ in range(nouts)]
     fmt_of = {np.dtype(np.uint64): 0, np.dtype(np.int8): 1, np.dtype(np.int16): 2, np.dtype(np.int32): 3}
     px, sx, fmt = [0, 0, 0], [0, 0, 0], 0

@@ -156,6 +156,11 @@ def test_emulated_u64_transform_fused_forward_multiply_add(fmt, nm, batch, gener
     if fmt is np.int8:   # the 1-D grid that keeps the nm rows of an element on one XCD (padding workgroups exit at once)
         got = asm_emu.run_fused_kernel(generated("fused_enc2_4096"), n, nm, prm, xs, [ka, kb], batch, 2, remap=True)
         assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1)
+        # ... and the ring-mode variants of the two forward kernels (lane-major twiddle copy), both grids
+        got = asm_emu.run_fused_kernel(generated("fused_enc2_4096r"), n, nm, prm, xs, [ka, kb], batch, 2, remap=True, lane_major=True)
+        assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1)
+        got = asm_emu.run_fused_kernel(generated("fused_fma_fwd4096r"), n, nm, prm, xs[:2], [ka], batch, 1, lane_major=True)
+        assert np.array_equal(got[0], want0)
 
 
 @pytest.mark.parametrize("nm,batch", [(2, 2), (1, 1)])
@@ -170,6 +175,11 @@ def test_emulated_u64_transform_fused_multiply_subtract_inverse(nm, batch, gener
     got = asm_emu.run_fused_kernel(generated("fused_fms_inv4096"), n, nm, prm, [x0, x1], [k], batch, 1)
     assert np.array_equal(got[0], o.intt(o.pointwise(1, x1, prod)))
     got = asm_emu.run_fused_kernel(generated("fused_fma_inv4096"), n, nm, prm, [x0, x1], [k], batch, 1)
+    assert np.array_equal(got[0], o.intt(o.pointwise(0, x1, prod)))
+    # the ring-mode variants of the same two kernels (one butterfly at a time, 128 VGPRs, lane-major twiddle copy)
+    got = asm_emu.run_fused_kernel(generated("fused_fms_inv4096r"), n, nm, prm, [x0, x1], [k], batch, 1, lane_major=True)
+    assert np.array_equal(got[0], o.intt(o.pointwise(1, x1, prod)))
+    got = asm_emu.run_fused_kernel(generated("fused_fma_inv4096r"), n, nm, prm, [x0, x1], [k], batch, 1, lane_major=True)
     assert np.array_equal(got[0], o.intt(o.pointwise(0, x1, prod)))
 
 

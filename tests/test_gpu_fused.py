@@ -197,7 +197,7 @@ def test_both_grids_of_the_fused_kernels_give_the_same_words(engine_factory):
             w = e.fill_uniform(e.empty(batch), 5, 0)
             k0, k1 = e.fill_uniform(e.empty(1), 6, 0), e.fill_uniform(e.empty(batch), 6, 1)
             got = []
-            for mode in (1, 2, 0):
+            for mode in (1, 2, 3, 0):
                 _lib.lib.nflhip_debug_fused_grid(mode)
                 a0, a1 = e.fwd_fma2(x, k0, w, k1, x)
                 got.append((a0, a1, e.fwd_fma(w, k1, x), e.fma_inv(a0, k0, a1, subtract=True), e.fma_inv(a0, k1, a1)))

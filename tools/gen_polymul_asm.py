@@ -3584,7 +3584,7 @@ def inverse_half(em, vm, tw_seq, first_stage=None):
 # loaded behind the last forward record, the multiply-add lands in the key's registers (x' stays for the second result), and
 # the next transform's ring is primed once the result's stores have been issued.  The exchanges are the plain ones of
 # build_row16k (write, barrier, read): the split-phase schedules of the product kernels are tied to their two-operand shape.
-# kernarg as ARGS_FUSED (the grid is always (batch, nm): magic is ignored).
+# kernarg as ARGS_FUSED; both grids of prologue_fused.
 S_X2ROW16 = "s[52:53]"     # (stream 1's borrow pair: idle in single-stream mode)
 
 
@@ -3633,6 +3633,20 @@ def build_fused_rows(kind):
         em.valu("v_mov_b32_e32 v%d, 0" % (t_ + 15,))                                # the persistent zero of ZP
     R("s_waitcnt lgkmcnt(0)")
     R("s_mov_b32 s14, s72")                              # nm
+    # magic != 0: the 1-D grid of prologue_fused (the nm rows of a batch element back to back on one XCD)
+    R("s_cmp_eq_u32 s83, 0")
+    R("s_cbranch_scc1 .Lplain_grid")
+    R("s_and_b32 s42, s2, 7")                            # xcd
+    R("s_lshr_b32 s43, s2, 3")                           # q
+    R("s_mul_hi_u32 s44, s43, s83")                      # j
+    R("s_mul_i32 s45, s44, s14")
+    R("s_sub_u32 s3, s43, s45")                          # cm
+    R("s_lshl_b32 s44, s44, 3")
+    R("s_add_u32 s2, s44, s42")                          # element
+    R("s_cmp_lt_u32 s2, s82")
+    R("s_cbranch_scc1 .Lplain_grid")
+    R("s_endpgm")                                        # padding of the last group of eight
+    em.lines.append(".Lplain_grid:")
     R("s_sub_u32 s88, s73, 12")                          # r = ROW_LG: rows of exactly 4096 ROW_G words
     R("s_mov_b32 %s, s76" % S_FMT)
     R("s_mov_b64 s[10:11], s[70:71]")                    # psi (the lane-major copy)
@@ -4127,8 +4141,7 @@ def main():
     # workgroups per CU instead of three, one butterfly at a time)
     configure("ring", 1)
     g.update(NEXT_SGPR=102, LDS_BYTES=SLAB_BYTES)
-    for kind in ("fms_inv", "fma_inv"):
-        stem, kname = KERNELS_FUSED[kind]
+    for kind, (stem, kname) in KERNELS_FUSED.items():
         emit_file(os.path.join(outdir, stem + "r_gfx950.s"), kname.replace("_asm", "r_asm"), build_fused_rows(kind), args=ARGS_FUSED)
     g.update(NEXT_SGPR=96)
     # transform-fused pipelines on the row-resident map: rows of 16384 and 8192 words
