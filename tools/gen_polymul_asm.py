@@ -3589,12 +3589,13 @@ S_X2ROW16 = "s[52:53]"     # (stream 1's borrow pair: idle in single-stream mode
 
 
 def build_fused_rows(kind):
-    """kind: enc2 | fma_fwd | fms_inv | fma_inv -- over one 4096 * ROW_G-word row per workgroup (configure("ring", ROW_G))"""
+    """kind: enc2 | fma_fwd | fms_inv | fma_inv -- over one 4096 * ROW_G-word row per workgroup (configure("ring", ROW_G));
+    polymul (experiment, ROW_G = 1): out0 = INTT(NTT(x0) (.) NTT(x1)), the metric product on the ring-mode map"""
     assert SINGLE_STREAM and ROW_G in (1, 2, 4)      # (1: a 4096-word row on the ring-mode map -- 128 VGPRs, four workgroups per CU)
     em = Emitter()
     vm = VmCounter(em)
     R = em.raw
-    fwd = kind in ("enc2", "fma_fwd")
+    fwd = kind in ("enc2", "fma_fwd", "polymul")
     passes = {"F0": (S_K0["F0"], None, False), "F1": (S_K["F1"], None, False), "F2": (S_K["F2"], V_BIDX, False),
               "F3": (S_K["F3"], V_TID, False), "I1": (S_K["I1"], V_TID, True), "I2": (S_K["I2"], V_BIDX, True),
               "I3": (S_K["I3"], None, True), "I0": (S_K0["I0"], None, True)}
@@ -3873,6 +3874,11 @@ def build_fused_rows(kind):
         x_expand(V_A, 0, "e0")
         x_expand(V_B, 1, "e1")
         forward([V_A, V_B], True)
+    if kind == "polymul":
+        ring = make_ring(["I1", "I2", "I3", "I0"])       # (the inverse passes' first records fly under the product)
+        em.comment("point-wise product (thread t of sub-group q holds words 16t..16t+15 of block q of both operands)")
+        run_pairs(em, [pointwise(V_A + 2 * i, V_B + 2 * i, True, True) for i in range(16)])
+    elif fwd:
         if kind == "fma_fwd":
             fma_store(V_B, True, S_K0ROW, S_CROW)
             R("s_endpgm")
@@ -3890,20 +3896,21 @@ def build_fused_rows(kind):
         R("s_endpgm")
         return em
 
-    # ---- fms_inv / fma_inv
-    vm.wait(seq_k)
-    em.comment("x1 -+ x0 * k0 in the loaded (lane-contiguous) layout; x1 is consumed as it lands")
-    for i in range(0, 16, 2):
-        vm.wait(seq_b[i + 1])
-        run_pairs(em, [fms_job(V_A + 2 * j, V_K + 2 * j, V_B + 2 * j, kind == "fms_inv") for j in (i, i + 1)])
-    ring = make_ring(["I1", "I2", "I3", "I0"])
-    em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
-    _, l = lane_contig_setup(em)
-    em.valu("v_add_u32_e32 v%d, %s, v%d" % (l, S_SLAB, l))
-    for j in range(16):
-        R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
-    lds_read(em, V_L2R, V_A, 8)
-    R("s_waitcnt lgkmcnt(0)")
+    # ---- fms_inv / fma_inv (and the second half of the product)
+    if kind != "polymul":
+        vm.wait(seq_k)
+        em.comment("x1 -+ x0 * k0 in the loaded (lane-contiguous) layout; x1 is consumed as it lands")
+        for i in range(0, 16, 2):
+            vm.wait(seq_b[i + 1])
+            run_pairs(em, [fms_job(V_A + 2 * j, V_K + 2 * j, V_B + 2 * j, kind == "fms_inv") for j in (i, i + 1)])
+        ring = make_ring(["I1", "I2", "I3", "I0"])
+        em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
+        _, l = lane_contig_setup(em)
+        em.valu("v_add_u32_e32 v%d, %s, v%d" % (l, S_SLAB, l))
+        for j in range(16):
+            R("ds_write_b64 v%d, %s offset:%d" % (l, vp(V_A + 2 * j), 544 * j))
+        lds_read(em, V_L2R, V_A, 8)
+        R("s_waitcnt lgkmcnt(0)")
 
     def inv_pass(name, stages):
         em.comment(name)
@@ -4143,6 +4150,11 @@ def main():
     g.update(NEXT_SGPR=102, LDS_BYTES=SLAB_BYTES)
     for kind, (stem, kname) in KERNELS_FUSED.items():
         emit_file(os.path.join(outdir, stem + "r_gfx950.s"), kname.replace("_asm", "r_asm"), build_fused_rows(kind), args=ARGS_FUSED)
+    # ... and the metric product itself on that map: measured same-box against nflhip_polymul4096nt_asm (profiles/
+    # r04_ring_vs_pair_4096.txt): 2.89 ms per 16 384 products either way -- the product is bound by its arithmetic, a fourth
+    # workgroup per CU buys nothing.  Only emitted with NFL_GEN_EXPERIMENTS=1.
+    if experiments:
+        emit_file(os.path.join(outdir, "fused_polymul4096r_gfx950.s"), "nflhip_fused_polymul4096r_asm", build_fused_rows("polymul"), args=ARGS_FUSED)
     g.update(NEXT_SGPR=96)
     # transform-fused pipelines on the row-resident map: rows of 16384 and 8192 words
     for groups, words in ((4, 16384), (2, 8192)):
