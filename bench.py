@@ -566,6 +566,27 @@ def main():
             "note": "GB/s are algorithmic bytes (SURVEY.md 8(d)) / event time; polys per second over the same batch",
         }
         del bn, limbs
+        # what callers run AROUND the transforms: the reference's LWE demo (tests/nfllib_demo_main_op.cpp:26-58) on this
+        # workload's ring, operator by operator and through the transform-fused pipelines -- same
+        # keystreams, so the two plans must produce the same ciphertexts (digests compared)
+        if lb == 64 and n in (4096, 8192, 16384):
+            try:
+                import types
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import lwe_demo
+                lw = {}
+                for plan in ("unfused", "fused"):
+                    la = types.SimpleNamespace(degree=n, nmoduli=nm, batch=min(batch, 8192), sigma=3.19, reps=5, plan=plan, grid=0, fixed_key=True)
+                    r, okl = lwe_demo.run(la)
+                    lw[plan] = {"encryptions_per_s": r["encryptions_per_s"], "decryptions_per_s": r["decryptions_per_s"],
+                                "decrypts_to_zero": okl, "digest": r["digest"]}
+                lw["same_ciphertexts"] = lw["fused"]["digest"] == lw["unfused"]["digest"]
+                lw["batch"] = min(batch, 8192)
+                lw["what"] = ("encrypt: 3 Gaussian polynomials, 3 forward transforms, 2 multiply-adds against the public key; decrypt: "
+                              "multiply-subtract against the secret key + inverse transform; fused = nflhip_fwd_fma2_dev / nflhip_fma_inv_dev")
+                extras["lwe"] = lw
+            except Exception as ex:   # secondary figure: never takes the bench down
+                extras["lwe"] = {"error": repr(ex)}
         # the other single-GPU BASELINE configs, timed inside this same run (driver-visible, not builder-only): configs[2]
         # (C) and configs[4] (E: "CRT lift + poly-mul"); the headline's own tensors are released first
         if args.workload == "B" and not args.no_side_configs:

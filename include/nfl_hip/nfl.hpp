@@ -628,6 +628,67 @@ static constexpr int dist_flags = 0;
 
 template <class P> struct lazy;
 
+// Handle payloads come and go at the rate of the caller's temporaries (three per encryption of the LWE demo loop), and a
+// general-purpose malloc / free pair per payload was the largest single item of the per-polynomial host cost (tools/hostprof:
+// ~115 ns of ~185 per temporary).  std::allocate_shared with this allocator takes the control block + payload from a
+// per-thread free list of fixed-size blocks instead; blocks freed on another thread simply join that thread's list.
+template <class U> struct block_pool_alloc {
+  typedef U value_type;
+  block_pool_alloc() noexcept {}
+  template <class V> block_pool_alloc(const block_pool_alloc<V> &) noexcept {}
+  template <class V> struct rebind { typedef block_pool_alloc<V> other; };
+  struct node { node *next; };
+  struct list_t {
+    node *head;
+    size_t count;
+    list_t() : head(nullptr), count(0) {}
+    ~list_t() {
+      gone() = true;   // (payloads released later in this thread's teardown -- static destructors -- go straight back to the heap)
+      while (head) {
+        node *n = head;
+        head = n->next;
+        ::operator delete(static_cast<void *>(n));
+      }
+      count = 0;
+    }
+  };
+  static bool &gone() {   // trivially destructible, so it outlives the list it guards
+    static thread_local bool g = false;
+    return g;
+  }
+  static list_t &list() {
+    static thread_local list_t l;
+    return l;
+  }
+  U *allocate(size_t n) {
+    if (n == 1 && sizeof(U) >= sizeof(node) && !gone()) {
+      list_t &l = list();
+      if (l.head) {
+        node *x = l.head;
+        l.head = x->next;
+        --l.count;
+        return reinterpret_cast<U *>(x);
+      }
+    }
+    return static_cast<U *>(::operator new(n * sizeof(U)));
+  }
+  void deallocate(U *p, size_t n) noexcept {
+    if (n == 1 && sizeof(U) >= sizeof(node) && !gone()) {
+      list_t &l = list();
+      if (l.count < (size_t(1) << 16)) {   // (bounded: a burst of 65 536 dead temporaries is kept, the rest goes back)
+        node *x = reinterpret_cast<node *>(p);
+        x->next = l.head;
+        l.head = x;
+        ++l.count;
+        return;
+      }
+    }
+    ::operator delete(static_cast<void *>(p));
+  }
+  template <class V> bool operator==(const block_pool_alloc<V> &) const noexcept { return true; }
+  template <class V> bool operator!=(const block_pool_alloc<V> &) const noexcept { return false; }
+};
+
 // The shared payload of a poly_p handle (poly_p.hpp:11-204 keeps a std::shared_ptr<poly>): one polynomial that lives
 // in HBM (`dev`), on the host (`host`), or both.  host_valid / dev_valid say which image holds the current value;
 // neither valid = the zero polynomial (what poly_p() is) with nothing allocated yet.  Every device-side operation is
@@ -2212,7 +2273,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   typedef std::shared_ptr<payload_type> ptr_type;
   mutable ptr_type _p;
 
-  static ptr_type fresh() { return std::make_shared<payload_type>(); }
+  static ptr_type fresh() { return std::allocate_shared<payload_type>(detail::block_pool_alloc<payload_type>()); }
   // constructors: the zero polynomial and the random tags never touch the host; everything else builds the host image
   // with poly's own constructor (same argument meaning, same exceptions)
   static ptr_type make_pointer() { return fresh(); }
@@ -2257,7 +2318,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     return p.use_count() - p->qrefs - extra > 1;
   }
   void detach() const {
-    if (shared(_p)) _p = std::make_shared<payload_type>(*_p);  // (device-to-device when the value lives in HBM)
+    if (shared(_p)) _p = std::allocate_shared<payload_type>(detail::block_pool_alloc<payload_type>(), *_p);  // (device-to-device when the value lives in HBM)
   }
   void detach_for_overwrite() {
     if (shared(_p)) _p = fresh();

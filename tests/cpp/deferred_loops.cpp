@@ -134,6 +134,7 @@ int main(int argc, char **argv) {
   const size_t reps = argc > 1 ? size_t(std::atol(argv[1])) : 300;
   try {
     if (!run<uint64_t, 4096, 4>(reps)) return 1;
+    if (!run<uint64_t, 8192, 2>(reps / 4 + 8)) return 1;      // (the fused entries' row-resident kernels on the GPU)
     if (!run<uint32_t, 1024, 2>(reps)) return 1;
     if (!run<uint16_t, 128, 1>(reps)) return 1;
     std::printf("deferred == immediate on the loop shapes, %zu iterations per ring\nall checks passed\n", reps);

@@ -129,6 +129,10 @@ def test_headline_line_carries_sustained_independent_secondary_and_side_configs(
     sec = d["roofline"]["secondary"]
     assert sec["peak"] == 1228.8 and abs(sec["frac"] - sec["achieved"] / sec["peak"]) < 1e-3
     assert sec["model"]["kind"] == "fitted" and "peak_at_measured_clock" in sec["model"] and sec["opcode_grid"]["clock_GHz"] == 2.4
+    lwe = d["extras"]["lwe"]
+    assert "error" not in lwe and lwe["same_ciphertexts"] is True and lwe["fused"]["decrypts_to_zero"] is True
+    assert lwe["fused"]["encryptions_per_s"] > 1.3 * lwe["unfused"]["encryptions_per_s"]
+    assert lwe["fused"]["decryptions_per_s"] > 1.3 * lwe["unfused"]["decryptions_per_s"]
     cfg = d["extras"]["configs"]
     for wl in ("C", "E"):
         c = cfg[wl]

@@ -3,7 +3,7 @@
 # in the same run, and cpu_baseline) and the rocprofv3 kernel summaries of the same commands.
 # Usage: bash tools/final_profiles.sh <tag>   -> gpurun_out/<tag>_bench_<W>.json, gpurun_out/<tag>_kernel_stats_<W>.csv, ...
 set -u
-tag=${1:-r03_final}
+tag=${1:-r04_final}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
@@ -28,9 +28,21 @@ done
 rm -rf /tmp/prof_t
 tests/cpp/resident_test | head -1 > $out/${tag}_lwe_poly_p.json
 NFL_LWE_REPS=16384 tests/cpp/resident_test | head -1 >> $out/${tag}_lwe_poly_p.json   # long loop: queue runs overlap recording
-python tools/lwe_demo.py 2>/dev/null > $out/${tag}_lwe.jsonl
-python tools/lwe_demo.py --degree 16384 --nmoduli 8 --batch 512 2>/dev/null >> $out/${tag}_lwe.jsonl
-python tools/lwe_demo.py --degree 1024 --nmoduli 2 --batch 65536 2>/dev/null >> $out/${tag}_lwe.jsonl
+NFL_HIP_NO_FUSION=1 NFL_LWE_REPS=16384 tests/cpp/resident_test | head -1 > $out/${tag}_lwe_poly_p_nofusion.json
+# the LWE demo on resident batches: operator by operator and through the transform-fused pipelines (same keystreams)
+rm -f $out/${tag}_lwe.jsonl
+for shape in "4096 4 16384" "8192 2 8192" "16384 8 1024" "1024 2 65536"; do
+  set -- $shape
+  for plan in unfused fused; do
+    python tools/lwe_demo.py --degree $1 --nmoduli $2 --batch $3 --plan $plan --reps 10 --fixed-key 2>/dev/null >> $out/${tag}_lwe.jsonl
+  done
+done
+python tools/lwe_demo.py --batch 8192 --reps 10 --traffic --fixed-key 2>/dev/null > $out/${tag}_lwe_traffic.json
+rm -rf /tmp/prof_lwe
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lwe -- python $here/tools/lwe_demo.py --batch 8192 --reps 10 --fixed-key > /dev/null 2>&1)
+f=$(find /tmp/prof_lwe -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats_lwe_fused.csv
+rm -rf /tmp/prof_lwe
 # effective clock and power under the product kernels: GRBM_GUI_ACTIVE per launch (cycles, summed over the 8 XCDs) and
 # rocm-smi sampled during a long run
 for wl in B A C F; do
@@ -41,8 +53,8 @@ for wl in B A C F; do
   rm -rf /tmp/pmc_clk_$wl
 done
 smi() { for i in $(seq 1 $2); do rocm-smi -P -c --json 2>/dev/null | tr -d '\n'; echo; sleep 0.25; done > $out/${tag}_smi_$1.jsonl; }
-for wl in C F E; do
-  steps=$([ $wl = E ] && echo 150 || echo 3000)
+for wl in B C F E; do
+  steps=$([ $wl = E ] && echo 60 || echo 3000)
   (smi $wl 36 &) ; timeout 120 python bench.py --workload $wl --steps $steps --warmup 10 --no-cpu-baseline --no-traffic --no-extras > $out/${tag}_bench_${wl}_long.json 2>/dev/null; sleep 1.5
 done
 ls -la $out | tail -25
