@@ -161,6 +161,12 @@ static Big big_shl(const Big &a, int k, size_t limbs) {
   return r;
 }
 
+// fewest moduli for which the lift runs as an int8 GEMM on the matrix cores (kernels_crt_mfma.hip); below it the VALU
+// kernels of kernels_crt.hip are closer to the memory system than the GEMM's fixed 32-modulus tile
+#ifndef NFLHIP_CRT_MFMA_MIN_NM
+#define NFLHIP_CRT_MFMA_MIN_NM 12
+#endif
+
 template <typename T>
 static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const void *invkv, int kmax_log2) {
   const T *P = (const T *)Pv, *roots = (const T *)rootsv, *invk = (const T *)invkv;
@@ -254,6 +260,38 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
         cur = mulmod_h(cur, two32, p);
       }
     }
+  }
+
+  // the lift as an int8 GEMM (kernels_crt_mfma.hip): balanced base-256 digits of Q/p_cm, laid out as the B operand of
+  // v_mfma_i32_32x32x32_i8 -- K-step s, N-tile t, lane (column j = lane & 31, half h = lane >> 5), byte e:
+  // modulus slot cm = 4 s + 2 h + (e >> 3), digit of y a = e & 7, column k = 8 j + t  ->  digit k - a of Q/p_cm.
+  // Slot 31 is the quotient row: the digits of Q itself against the single digit "-floor(S / Q)" (a = 0).
+  std::vector<int8_t> bfrag;
+  if (wb == 64 && crt_ok && nm >= NFLHIP_CRT_MFMA_MIN_NM && nm <= 31 && c->shape.crt_L >= 4 && c->shape.crt_L <= 31) {
+    const size_t ND = 264;
+    std::vector<int8_t> dig(32 * ND, 0);
+    for (size_t cm = 0; cm < 32; ++cm) {
+      Big quot;
+      if (cm < nm) big_divrem_u64(Q, P[cm], &quot);
+      else if (cm == 31) quot = Q;
+      else continue;
+      int carry = 0;
+      for (size_t k = 0; k < ND; ++k) {
+        const size_t w = k / 8;
+        int v = (w < quot.size() ? (int)((quot[w] >> (8 * (k % 8))) & 0xff) : 0) + carry;
+        carry = 0;
+        if (v >= 128) { v -= 256; carry = 1; }
+        dig[cm * ND + k] = (int8_t)v;
+      }
+    }
+    bfrag.assign((size_t)8 * 8 * 64 * 16, 0);
+    for (int st = 0; st < 8; ++st)
+      for (int t = 0; t < 8; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 16; ++e) {
+            const int cm = 4 * st + 2 * (lane >> 5) + (e >> 3), a = e & 7, k = 8 * (lane & 31) + t;
+            if (k >= a && (cm < 31 || a == 0)) bfrag[(((size_t)st * 8 + t) * 64 + lane) * 16 + e] = dig[cm * ND + (k - a)];
+          }
   }
 
   // twiddles + per-modulus constants
@@ -353,6 +391,11 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     for (size_t k = L; k-- > 0;) qt = qt * 18446744073709551616.0L + (long double)Q[k];
     for (long w = 0; w < 2 * (long)L - 3; ++w) qt /= 4294967296.0L;
     c->tabs.inv_qtop = (double)(1.0L / qt);
+  }
+  c->tabs.crt_bfrag = nullptr;
+  if (!bfrag.empty()) {
+    HIPCHK(nullptr, hipMalloc(&c->tabs.crt_bfrag, bfrag.size()));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.crt_bfrag, bfrag.data(), bfrag.size(), hipMemcpyHostToDevice));
   }
   c->tabs.qhat_w = nullptr;
   c->tabs.qsh_w = nullptr;
@@ -700,6 +743,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->tabs.qhat) (void)hipFree(ctx->tabs.qhat);
   if (ctx->tabs.qsh) (void)hipFree(ctx->tabs.qsh);
   if (ctx->tabs.qparts) (void)hipFree(ctx->tabs.qparts);
+  if (ctx->tabs.crt_bfrag) (void)hipFree(ctx->tabs.crt_bfrag);
   if (ctx->tabs.bparts) (void)hipFree(ctx->tabs.bparts);
   if (ctx->tabs.flag) (void)hipFree(ctx->tabs.flag);
   if (ctx->tabs.qhat_w) (void)hipFree(ctx->tabs.qhat_w);

@@ -62,6 +62,8 @@ struct DevTables {
   uint64_t *qhat_w; // [nm][crt_Lw]   Q/p_cm, little-endian limbs, or nullptr when the fast tables cover the shape
   uint64_t *qsh_w;  // [crt_nsh][crt_Lw]  Q << k
   int crt_Lw, crt_nsh;
+  // CRT lift on the matrix cores (kernels_crt_mfma.hip): 64-bit limbs, many moduli
+  void *crt_bfrag;  // [8 K-steps][8 N-tiles][64 lanes][16] int8: balanced base-256 digits of Q/p_cm in B-fragment order, or nullptr
 };
 
 // ---- launchers (kernels_generic.hip) ----
@@ -198,6 +200,9 @@ hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint
 
 // register-resident CRT kernels for 64-bit limbs (kernels_crt.hip); hipErrorNotSupported otherwise
 hipError_t launch_crt_lift_fast_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,
+                                    hipStream_t st);
+// the lift as an int8 GEMM on v_mfma_i32_32x32x32_i8 (kernels_crt_mfma.hip): many moduli, batch * n a multiple of 64
+hipError_t launch_crt_lift_mfma_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,
                                     hipStream_t st);
 hipError_t launch_crt_project_fast_u64(const Shape &s, const DevTables &t, uint64_t *d, const uint64_t *limbs, size_t L_in,
                                        size_t batch, hipStream_t st);

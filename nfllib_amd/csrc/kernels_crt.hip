@@ -273,6 +273,10 @@ hipError_t launch_crt_lift_fast_u64(const Shape &s, const DevTables &t, uint64_t
   if (s.limb_bits != 64 || !s.small_delta || s.nm > 32 || (int)s.crt_Lacc > 33) return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
   const size_t ncoef = batch * s.n;
+  if (t.crt_bfrag && ncoef % 64 == 0) {  // many moduli: the sum is a GEMM (kernels_crt_mfma.hip)
+    const hipError_t e = launch_crt_lift_mfma_u64(s, t, limbs, d, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   int rounds = 0;
   while ((1u << rounds) < s.nm) ++rounds;
   const dim3 g((unsigned)((ncoef + 255) / 256)), b(256);

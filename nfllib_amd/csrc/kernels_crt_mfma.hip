@@ -1,0 +1,274 @@
+// kernels_crt_mfma.hip -- CRT lift (GMP::poly2mpz, gmp.hpp:183-209) for MANY 62-bit moduli on the matrix cores.
+//
+// The transforms and point-wise operators of this engine are scans of independent words: no contraction, no MFMA
+// (BASELINE.json north_star).  The CRT lift is the one place where the reference's own formula IS a dense contraction:
+//     X_i = sum_cm (Q/p_cm) * y_(cm,i),     y_(cm,i) = x_(cm,i) * (Q/p_cm)^-1 mod p_cm,     then mod Q
+// -- for every coefficient i a vector of nm residues against a fixed nm x (L words) matrix of constants.  With 30 moduli
+// (BASELINE configs[4], the XPIR-scale ring) that is 900 word products per coefficient; kernels_crt.hip runs them as 5 400
+// 21-bit x 32-bit multiply-adds on the vector ALU and is bound by them (profiles/r03_crt_kernels.txt).  Here the same sum is an
+// int8 GEMM on v_mfma_i32_32x32x32_i8:
+//   * y (62 bits) is written in BALANCED base-256 digits, y = sum_a z_a 256^a with z_a in [-128, 127]: the bytes of
+//     (y + 0x8080808080808080) ^ 0x8080808080808080 read as int8 (two VALU instructions per residue);
+//   * Q/p_cm is written in balanced base-256 digits d_(cm,b) on the host, once per context;
+//   * column k of the product, c_k = sum_cm sum_a z_(cm,a) d_(cm,k-a), is a dot product of length 8 nm <= 256 of int8
+//     values: |c_k| <= 256 * 2^14 = 2^22, exact in the int32 accumulators; S = sum_k c_k 256^k;
+//   * the reduction mod Q rides along: S / Q = sum_cm y_cm / p_cm EXACTLY, so t = floor(sum_cm y_cm / p_cm - 2^-20) (double
+//     precision, error far below the margin) is floor(S / Q) or one less, and row 31 of the GEMM is "-t times the digits of
+//     Q": the product comes out as S - t Q, in [0, 2Q), and one conditional subtraction of Q is all that is left.
+// GEMM shape per coefficient: K = 8 * 32 (31 moduli at most + the quotient row, zero padded) = 256, N = 256 columns
+// (k <= 8 L for L <= 31 words): 65 536 int8 multiply-adds on the matrix cores instead of 5 400 32-bit ones on the VALU.
+//
+// Mapping (one 256-thread workgroup works on 64 consecutive coefficients per iteration; persistent, grid-stride; the next
+// tile's residues are in flight while this one is worked on):
+//   P1  thread (c = lane, g = wave) computes y for coefficient c and the moduli g, g+4, g+8, ... (the modulus is
+//       wave-uniform: its constants are scalar loads), stores z into LDS in the A-fragment order and its share of
+//       sum y / p next to it;
+//   P2  wave (u = w & 1, m = w >> 1): the 32 x 128 block "coefficients of half m, columns of half u" = 4 N-tiles x 8
+//       K-steps = 32 MFMAs.  The wave's 32 B fragments (128 VGPRs) are loaded ONCE per kernel; A comes from LDS (one
+//       ds_read_b128 per 4 MFMAs; the quotient row is patched into the last K-step's registers).  Column map: N-tile t,
+//       lane column j <-> k = 8 j + t, so the four tiles of a wave are the four bytes of ONE 32-bit digit position
+//       2 j + u: X = c_0 + c_1 2^8 + c_2 2^16 + c_3 2^24 (signed, < 2^47) is formed in the lane and parked in LDS;
+//   P3  thread (c = lane, r = wave) owns the 16 positions 16 r .. 16 r + 15 of coefficient c: local carry chain, the
+//       carries between the four parts resolved through LDS (a part passes a carry on only when its upper 15 digits are
+//       all zeros / all ones: published as two flags), then the same scheme for the borrow of "- Q";
+//   P4  the 64 x L result words are contiguous in HBM: coalesced stores from the LDS stage.
+// The K index of an MFMA operand is only ever used symmetrically (the same (lane half, byte) slot of A and B carries
+// the same (modulus, digit) pair), so the kernel depends on the instruction's row / column maps only: A row = lane & 31,
+// B column = lane & 31, C (column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
+//
+// Phase costs measured by removing one phase's arithmetic at a time: profiles/r04_crt_mfma.txt.
+#include "modarith64.h"
+
+namespace nflhip {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+static constexpr int kMfmaCoef = 64;              // coefficients per workgroup iteration
+static constexpr int kXStride = 65;               // u64 slots per coefficient in the X array: 64 digits, odd stride (bank spread)
+static constexpr int kStStride = 33;              // u64 slots per coefficient in the result stage: 32 limbs, odd stride
+static constexpr u64 kBias = 0x8080808080808080ull;
+
+__global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d, const MC64 *__restrict__ mc,
+                                                          const uint4 *__restrict__ bfrag, const u32 *__restrict__ qdig,
+                                                          int logn, int nm, int L, size_t ncoef) {
+  __shared__ uint4 a_frag[2 * 8 * 64];                     // 16 KiB: [M-tile][K-step][lane] x 16 bytes
+  __shared__ long long xs[kMfmaCoef * kXStride];           // 33 KiB: [coefficient][32-bit digit position] signed partial sums
+  __shared__ u64 stage[kMfmaCoef * kStStride];             // 17 KiB: [coefficient][limb] results
+  __shared__ double fpart[4 * 64];                         // [wave][coefficient] shares of sum y / p
+  __shared__ double invp[32];
+  __shared__ int ex_co[4 * 64];                            // P3: carry out of a part, its lowest digit, "upper digits all 0 / all 1"
+  __shared__ u32 ex_d0[4 * 64];
+  __shared__ int ex_fl[4 * 64];
+  __shared__ int ex_b[4 * 64];                             // borrow out of a part of S - Q, "the part's difference is 0"
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the constants of "its" moduli are scalar loads
+  const int u = w & 1, m = w >> 1;
+  if (tid < 32) invp[tid] = tid < nm ? 1.0 / (double)mc[tid].p : 0.0;
+  // the wave's B fragments: K-step s, N-tile 4u + tt
+  v4i breg[8][4];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const uint4 v = bfrag[(s * 8 + 4 * u + tt) * 64 + lane];
+      breg[s][tt] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+  u64 *a_words = reinterpret_cast<u64 *>(a_frag);
+  const size_t ngroups = ncoef / kMfmaCoef;
+  const size_t nmask = (((size_t)1) << logn) - 1;
+  u64 xv[8];
+  auto fetch = [&](size_t grp) {
+    const size_t gid = grp * kMfmaCoef + (size_t)lane;
+    const size_t b = gid >> logn, i = gid & nmask;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cm = w + 4 * q;
+      xv[q] = d[((b * (size_t)nm + (size_t)(cm < nm ? cm : 0)) << logn) + i];
+    }
+  };
+  if (blockIdx.x < ngroups) fetch(blockIdx.x);
+  __syncthreads();
+  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // ---- P1: residues -> y -> balanced digits in A-fragment order; this thread's share of sum y / p
+    {
+      const int mt = lane >> 5, row = lane & 31;
+      double f = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int cm = w + 4 * q;
+        u64 z = 0;
+        if (cm < nm) {
+          const u64 p = mc[cm].p, yi = mc[cm].yinv, yis = mc[cm].yinv_sh;
+          const u64 y = mul_shoup<u64>(xv[q], yi, yis, p);
+          f += (double)y * invp[cm];
+          z = (y + kBias) ^ kBias;
+        }
+        const int s = cm >> 2, h = (cm >> 1) & 1, e = cm & 1;
+        a_words[(((mt * 8 + s) * 64) + row + 32 * h) * 2 + e] = z;
+      }
+      fpart[w * 64 + lane] = f;
+      if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x);   // the next tile's residues: in flight until the next P1
+    }
+    __syncthreads();
+    // ---- P2: 32 MFMAs per wave
+    v16i acc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tt][r] = 0;
+    {
+      // the quotient row: modulus slot 31 = (K-step 7, lane half 1, second word), digit 0 only
+      const int c = 32 * m + (lane & 31);
+      const double f = ((fpart[c] + fpart[64 + c]) + fpart[128 + c]) + fpart[192 + c];
+      int tq = (int)floor(f - 0x1p-20);
+      tq = tq < 0 ? 0 : tq;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const uint4 av = a_frag[(m * 8 + s) * 64 + lane];
+        v4i a = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+        if (s == 7 && lane >= 32) a[2] = (-tq) & 0xff;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[s][tt], acc[tt], 0, 0, 0);
+      }
+    }
+    // four neighbouring byte columns of one 32-bit digit position -> one signed sum (|c| <= 2^22: the pairs fit 32 bits)
+    {
+      const int j = lane & 31, hh = lane >> 5;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int t01 = acc[0][r] + (acc[1][r] << 8), t23 = acc[2][r] + (acc[3][r] << 8);
+        xs[(m * 32 + row) * kXStride + 2 * j + u] = (long long)t01 + ((long long)t23 << 16);
+      }
+    }
+    __syncthreads();
+    // ---- P3: thread (coefficient = lane, part = wave): 16 of the 64 digit positions
+    {
+      const int r = w;
+      const long long *xc = xs + lane * kXStride + 16 * r;
+      u32 dg[16];
+      {
+        long long carry = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const long long t = xc[k] + carry;
+          dg[k] = (u32)t;
+          carry = t >> 32;
+        }
+        u32 orv = 0, andv = ~0u;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+          orv |= dg[k];
+          andv &= dg[k];
+        }
+        ex_co[r * 64 + lane] = (int)carry;
+        ex_d0[r * 64 + lane] = dg[0];
+        ex_fl[r * 64 + lane] = (orv == 0 ? 1 : 0) | (andv == ~0u ? 2 : 0);
+      }
+      __syncthreads();
+      {
+        // carry into this part: a lower part passes its own carry out, plus or minus one when the carry INTO it runs
+        // through all of its digits
+        int cin = 0;
+        for (int rr = 0; rr < r; ++rr) {
+          const long long t = (long long)ex_d0[rr * 64 + lane] + (long long)cin;
+          const int fl = ex_fl[rr * 64 + lane];
+          int ext = 0;
+          if ((fl & 2) && t >= (1LL << 32)) ext = 1;
+          if ((fl & 1) && t < 0) ext = -1;
+          cin = ex_co[rr * 64 + lane] + ext;
+        }
+        const long long t0 = (long long)dg[0] + (long long)cin;
+        dg[0] = (u32)t0;
+        long long carry = t0 >> 32;
+        if (__builtin_amdgcn_ballot_w64(carry != 0) != 0) {   // rare (|cin| < 2^17 against a 32-bit digit)
+#pragma unroll
+          for (int k = 1; k < 16; ++k) {
+            const long long t = (long long)dg[k] + carry;
+            dg[k] = (u32)t;
+            carry = t >> 32;
+          }
+        }
+      }
+      // S - Q on this part
+      const u32 *qd = qdig + 16 * r;
+      u32 D[16];
+      {
+        unsigned bw = 0;
+        u32 orD = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          D[k] = __builtin_subc(dg[k], qd[k], bw, &bw);
+          orD |= D[k];
+        }
+        ex_b[r * 64 + lane] = (int)bw | (orD == 0 ? 2 : 0);
+      }
+      __syncthreads();
+      {
+        unsigned b = 0, bin = 0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const unsigned v = (unsigned)ex_b[rr * 64 + lane];
+          if (rr == r) bin = b;
+          b = (v & 1u) | ((v >> 1) & b);
+        }
+        const bool ge = b == 0;   // S >= Q: take the difference
+        unsigned brw = D[0] < bin ? 1u : 0u;
+        D[0] -= bin;
+        if (__builtin_amdgcn_ballot_w64(brw != 0 && ge) != 0) {   // rare: the part's lowest digit of S - Q is 0
+#pragma unroll
+          for (int k = 1; k < 16; ++k) {
+            const unsigned nb = D[k] < brw ? 1u : 0u;
+            D[k] -= brw;
+            brw = nb;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const u32 lo = ge ? D[2 * k] : dg[2 * k], hi = ge ? D[2 * k + 1] : dg[2 * k + 1];
+          stage[lane * kStStride + 8 * r + k] = (u64)lo | ((u64)hi << 32);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- P4: the 64 x L result words are contiguous in HBM: 32 lanes per coefficient, 8 coefficients per pass
+    {
+      u64 *o = out + grp * (size_t)kMfmaCoef * (size_t)L;
+      const int k = tid & 31;
+      if (k < L) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int c = (tid >> 5) + 8 * r;
+          o[c * L + k] = stage[c * kStStride + k];
+        }
+      }
+    }
+    // (reuse across iterations is ordered by the five barriers: a_frag / fpart are rewritten after barrier 5 and were last
+    //  read before barrier 2; xs is rewritten after the next barrier 1; the exchange arrays and the stage two barriers on)
+  }
+}
+
+// `bfrag` / `qdig`: DevTables::crt_bfrag (api.hip build_tables; its modulus slot 31 holds the digits of Q itself), row 0 of
+// DevTables::qsh (Q as 32-bit digits, zero padded to 72).  hipErrorNotSupported when the shape has no table (few moduli: the
+// VALU kernels are on the memory system there; 32 moduli: no free slot for the quotient row) or the batch is not a multiple
+// of the tile.
+hipError_t launch_crt_lift_mfma_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,
+                                    hipStream_t st) {
+  if (s.limb_bits != 64 || !t.crt_bfrag || s.nm > 31 || (batch * s.n) % kMfmaCoef != 0 || s.crt_L < 4 || s.crt_L > 31)
+    return hipErrorNotSupported;
+  if (batch == 0) return hipSuccess;
+  const size_t ncoef = batch * s.n;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  size_t blocks = (size_t)cus * 2;
+  if (blocks > ncoef / kMfmaCoef) blocks = ncoef / kMfmaCoef;
+  hipLaunchKernelGGL(k_crt_lift_mfma, dim3((unsigned)blocks), dim3(256), 0, st, limbs, d, (const MC64 *)t.mc,
+                     (const uint4 *)t.crt_bfrag, (const u32 *)t.qsh, s.logn, (int)s.nm, (int)s.crt_L, ncoef);
+  return hipGetLastError();
+}
+
+}  // namespace nflhip

@@ -625,6 +625,34 @@ def test_degrees_beyond_the_baseline_shapes(lb, n, m, batch, oracle_factory, eng
     assert np.array_equal(e.to_host(e.polymul(da, e.ntt_(db.clone()), b_is_ntt=True)), want)
 
 
+@pytest.mark.parametrize("n,m,batch", [(256, 12, 3), (64, 16, 1), (128, 17, 2), (32, 29, 2), (256, 31, 1), (64, 32, 5),
+                                       (4096, 16, 40), (65536, 30, 2)])
+def test_crt_lift_on_the_matrix_cores(n, m, batch, oracle_factory, engine_factory):
+    """GMP::poly2mpz (gmp.hpp:183-209) with 12 and more 62-bit moduli runs as an int8 GEMM (kernels_crt_mfma.hip): extreme
+    residues (X = Q - 1, 0, 1, one residue set), every modulus count's zero padding, more tiles than workgroups."""
+    o, e = oracle_factory(64, n, m), engine_factory(64, n, m)
+    a = o.fill_uniform(batch, SEED, 0)
+    P = np.asarray(o.P[:m], dtype=a.dtype)
+    a[0, :, 0] = P - 1
+    a[0, :, 1] = 0
+    a[0, :, 2] = 1
+    a[0, :, 3] = 0; a[0, m - 1, 3] = P[m - 1] - 1
+    a[0, :, 4] = P - 1; a[0, 0, 4] = 0
+    a[0, :, 5] = P >> 1
+    limbs = e.crt_lift(e.to_device(a))
+    got = e.to_host(limbs).view(np.uint64)
+    if n <= 4096:
+        assert np.array_equal(got, o.crt_lift(a)), "poly2mpz differs"
+    else:                                            # the oracle's big integers on a sample; everything through the round trip
+        o2 = oracle_factory(64, 512, m)              # the lift is per coefficient: a 512-coefficient oracle on a sample
+        assert o2.P[:m] == o.P[:m]
+        assert np.array_equal(got[:, :512], o2.crt_lift(np.ascontiguousarray(a[:, :, :512])))
+    Q = o.crt_modulus()
+    assert int.from_bytes(got[0, 0].tobytes(), "little") == Q - 1
+    assert int.from_bytes(got[0, 1].tobytes(), "little") == 0 and int.from_bytes(got[0, 2].tobytes(), "little") == 1
+    assert np.array_equal(e.to_host(e.crt_project(limbs)), a)
+
+
 @pytest.mark.parametrize("lb,n,m,batch", [(64, 64, 33, 2), (64, 256, 40, 1), (64, 16, 100, 2), (32, 64, 64, 2), (32, 32, 291, 1),
                                           (64, 8, 1000, 1)])
 def test_crt_beyond_32_moduli(lb, n, m, batch, oracle_factory, engine_factory):
