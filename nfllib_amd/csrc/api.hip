@@ -161,10 +161,12 @@ static Big big_shl(const Big &a, int k, size_t limbs) {
   return r;
 }
 
-// fewest moduli for which the lift runs as an int8 GEMM on the matrix cores (kernels_crt_mfma.hip); below it the VALU
-// kernels of kernels_crt.hip are closer to the memory system than the GEMM's fixed 32-modulus tile
+// fewest moduli for which the lift runs as an int8 GEMM on the matrix cores (kernels_crt_mfma.hip).  Its cost hardly depends on
+// the modulus count (the tile is always 32 modulus slots x 256 columns: 0.48 ms at 12 moduli, 0.75 ms at 30 for 4 Mi
+// coefficients), the VALU kernels of kernels_crt.hip grow with its square (0.24 ms at 12, 0.56 at 20, 0.76 at 24, 1.19 at 30):
+// they cross between 20 and 21 (profiles/r04_crt_mfma.txt)
 #ifndef NFLHIP_CRT_MFMA_MIN_NM
-#define NFLHIP_CRT_MFMA_MIN_NM 12
+#define NFLHIP_CRT_MFMA_MIN_NM 21
 #endif
 
 template <typename T>

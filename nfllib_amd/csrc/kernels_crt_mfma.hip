@@ -22,16 +22,18 @@
 // tile's residues are in flight while this one is worked on):
 //   P1  thread (c = lane, g = wave) computes y for coefficient c and the moduli g, g+4, g+8, ... (the modulus is
 //       wave-uniform: its constants are scalar loads), stores z into LDS in the A-fragment order and its share of
-//       sum y / p next to it;
+//       sum y / p next to it (from the top 32 bits of y: 2^-32 per term, far inside the 2^-20 margin);
 //   P2  wave (u = w & 1, m = w >> 1): the 32 x 128 block "coefficients of half m, columns of half u" = 4 N-tiles x 8
 //       K-steps = 32 MFMAs.  The wave's 32 B fragments (128 VGPRs) are loaded ONCE per kernel; A comes from LDS (one
 //       ds_read_b128 per 4 MFMAs; the quotient row is patched into the last K-step's registers).  Column map: N-tile t,
 //       lane column j <-> k = 8 j + t, so the four tiles of a wave are the four bytes of ONE 32-bit digit position
 //       2 j + u: X = c_0 + c_1 2^8 + c_2 2^16 + c_3 2^24 (signed, < 2^47) is formed in the lane and parked in LDS;
-//   P3  thread (c = lane, r = wave) owns the 16 positions 16 r .. 16 r + 15 of coefficient c: local carry chain, the
-//       carries between the four parts resolved through LDS (a part passes a carry on only when its upper 15 digits are
-//       all zeros / all ones: published as two flags), then the same scheme for the borrow of "- Q";
-//   P4  the 64 x L result words are contiguous in HBM: coalesced stores from the LDS stage.
+//   P3  from here on wave w owns coefficients 16 w .. 16 w + 15 and no barrier is needed any more: lane (c = lane & 15,
+//       part r = lane >> 4) takes the 16 positions 16 r .. 16 r + 15: local carry chain, then the carries between the four
+//       parts by lane permutes (a part passes a carry on only when its upper 15 digits are all zeros / all ones: two flag
+//       bits travel with its carry out), then the same scheme for the borrow of "- Q";
+//   P4  the wave's 16 x L result words are contiguous in HBM: coalesced stores from its rows of the LDS stage.
+// Two workgroup barriers per tile (A fragments ready, digit positions ready).
 // The K index of an MFMA operand is only ever used symmetrically (the same (lane half, byte) slot of A and B carries
 // the same (modulus, digit) pair), so the kernel depends on the instruction's row / column maps only: A row = lane & 31,
 // B column = lane & 31, C (column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
@@ -56,15 +58,13 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
   __shared__ long long xs[kMfmaCoef * kXStride];           // 33 KiB: [coefficient][32-bit digit position] signed partial sums
   __shared__ u64 stage[kMfmaCoef * kStStride];             // 17 KiB: [coefficient][limb] results
   __shared__ double fpart[4 * 64];                         // [wave][coefficient] shares of sum y / p
-  __shared__ double invp[32];
-  __shared__ int ex_co[4 * 64];                            // P3: carry out of a part, its lowest digit, "upper digits all 0 / all 1"
-  __shared__ u32 ex_d0[4 * 64];
-  __shared__ int ex_fl[4 * 64];
-  __shared__ int ex_b[4 * 64];                             // borrow out of a part of S - Q, "the part's difference is 0"
+  __shared__ double invp[32];                              // 2^30 / p
+  __shared__ u32 qs[64];                                   // Q as 32-bit digits
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the constants of "its" moduli are scalar loads
   const int u = w & 1, m = w >> 1;
-  if (tid < 32) invp[tid] = tid < nm ? 1.0 / (double)mc[tid].p : 0.0;
+  if (tid < 32) invp[tid] = tid < nm ? 0x1p30 / (double)mc[tid].p : 0.0;
+  if (tid >= 64 && tid < 128) qs[tid - 64] = qdig[tid - 64];
   // the wave's B fragments: K-step s, N-tile 4u + tt
   v4i breg[8][4];
 #pragma unroll
@@ -89,6 +89,12 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
   };
   if (blockIdx.x < ngroups) fetch(blockIdx.x);
   __syncthreads();
+#ifdef NFLHIP_CRT_MFMA_STAMP
+  unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime(), st_n = 0;
+#define NFLHIP_STAMP(i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); st_acc[i] += now - st_t; st_t = now; }
+#else
+#define NFLHIP_STAMP(i)
+#endif
   for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     // ---- P1: residues -> y -> balanced digits in A-fragment order; this thread's share of sum y / p
     {
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
         if (cm < nm) {
           const u64 p = mc[cm].p, yi = mc[cm].yinv, yis = mc[cm].yinv_sh;
           const u64 y = mul_shoup<u64>(xv[q], yi, yis, p);
-          f += (double)y * invp[cm];
+          f += (double)(u32)(y >> 30) * invp[cm];
           z = (y + kBias) ^ kBias;
         }
         const int s = cm >> 2, h = (cm >> 1) & 1, e = cm & 1;
@@ -110,7 +116,9 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
       fpart[w * 64 + lane] = f;
       if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x);   // the next tile's residues: in flight until the next P1
     }
+    NFLHIP_STAMP(0)
     __syncthreads();
+    NFLHIP_STAMP(1)
     // ---- P2: 32 MFMAs per wave
     v16i acc[4];
 #pragma unroll
@@ -142,74 +150,71 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
         xs[(m * 32 + row) * kXStride + 2 * j + u] = (long long)t01 + ((long long)t23 << 16);
       }
     }
+    NFLHIP_STAMP(2)
     __syncthreads();
-    // ---- P3: thread (coefficient = lane, part = wave): 16 of the 64 digit positions
+    NFLHIP_STAMP(3)
+    // ---- P3: wave w owns coefficients 16 w .. 16 w + 15 from here on -- lane (c = lane & 15, part r = lane >> 4) has the
+    //      16 digit positions 16 r .. 16 r + 15; everything between the parts goes through lane permutes: no barrier
     {
-      const int r = w;
-      const long long *xc = xs + lane * kXStride + 16 * r;
+      const int cl = lane & 15, r = lane >> 4, c = 16 * w + cl;
+      const long long *xc = xs + c * kXStride + 16 * r;
       u32 dg[16];
-      {
-        long long carry = 0;
+      long long carry = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const long long t = xc[k] + carry;
-          dg[k] = (u32)t;
-          carry = t >> 32;
-        }
-        u32 orv = 0, andv = ~0u;
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-          orv |= dg[k];
-          andv &= dg[k];
-        }
-        ex_co[r * 64 + lane] = (int)carry;
-        ex_d0[r * 64 + lane] = dg[0];
-        ex_fl[r * 64 + lane] = (orv == 0 ? 1 : 0) | (andv == ~0u ? 2 : 0);
+      for (int k = 0; k < 16; ++k) {
+        const long long t = xc[k] + carry;
+        dg[k] = (u32)t;
+        carry = t >> 32;
       }
-      __syncthreads();
+      u32 orv = 0, andv = ~0u;
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        orv |= dg[k];
+        andv &= dg[k];
+      }
       {
         // carry into this part: a lower part passes its own carry out, plus or minus one when the carry INTO it runs
-        // through all of its digits
-        int cin = 0;
-        for (int rr = 0; rr < r; ++rr) {
-          const long long t = (long long)ex_d0[rr * 64 + lane] + (long long)cin;
-          const int fl = ex_fl[rr * 64 + lane];
+        // through all of its digits (upper 15 digits all ones / all zeros)
+        const int info = (int)carry * 4 + ((orv == 0 ? 1 : 0) | (andv == ~0u ? 2 : 0));   // |carry| < 2^17
+        int cin = 0, mine = 0;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const int oi = __shfl(info, cl + 16 * rr, 64);
+          const u32 od = (u32)__shfl((int)dg[0], cl + 16 * rr, 64);
+          const long long t = (long long)od + (long long)cin;
           int ext = 0;
-          if ((fl & 2) && t >= (1LL << 32)) ext = 1;
-          if ((fl & 1) && t < 0) ext = -1;
-          cin = ex_co[rr * 64 + lane] + ext;
+          if ((oi & 2) && t >= (1LL << 32)) ext = 1;
+          if ((oi & 1) && t < 0) ext = -1;
+          cin = (oi >> 2) + ext;
+          if (r == rr + 1) mine = cin;
         }
-        const long long t0 = (long long)dg[0] + (long long)cin;
+        const long long t0 = (long long)dg[0] + (long long)mine;
         dg[0] = (u32)t0;
-        long long carry = t0 >> 32;
-        if (__builtin_amdgcn_ballot_w64(carry != 0) != 0) {   // rare (|cin| < 2^17 against a 32-bit digit)
+        long long cy = t0 >> 32;
+        if (__builtin_amdgcn_ballot_w64(cy != 0) != 0) {   // rare (|cin| < 2^17 against a 32-bit digit)
 #pragma unroll
           for (int k = 1; k < 16; ++k) {
-            const long long t = (long long)dg[k] + carry;
+            const long long t = (long long)dg[k] + cy;
             dg[k] = (u32)t;
-            carry = t >> 32;
+            cy = t >> 32;
           }
         }
       }
-      // S - Q on this part
-      const u32 *qd = qdig + 16 * r;
+      // S - Q on this part, then the borrows between the parts the same way
       u32 D[16];
-      {
-        unsigned bw = 0;
-        u32 orD = 0;
+      unsigned bw = 0;
+      u32 orD = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          D[k] = __builtin_subc(dg[k], qd[k], bw, &bw);
-          orD |= D[k];
-        }
-        ex_b[r * 64 + lane] = (int)bw | (orD == 0 ? 2 : 0);
+      for (int k = 0; k < 16; ++k) {
+        D[k] = __builtin_subc(dg[k], qs[16 * r + k], bw, &bw);
+        orD |= D[k];
       }
-      __syncthreads();
       {
+        const int info = (int)bw | (orD == 0 ? 2 : 0);   // borrow out, "the part's difference is 0" (a borrow in runs through)
         unsigned b = 0, bin = 0;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const unsigned v = (unsigned)ex_b[rr * 64 + lane];
+          const unsigned v = (unsigned)__shfl(info, cl + 16 * rr, 64);
           if (rr == r) bin = b;
           b = (v & 1u) | ((v >> 1) & b);
         }
@@ -227,26 +232,42 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const u32 lo = ge ? D[2 * k] : dg[2 * k], hi = ge ? D[2 * k + 1] : dg[2 * k + 1];
-          stage[lane * kStStride + 8 * r + k] = (u64)lo | ((u64)hi << 32);
+          stage[c * kStStride + 8 * r + k] = (u64)lo | ((u64)hi << 32);
         }
       }
     }
-    __syncthreads();
-    // ---- P4: the 64 x L result words are contiguous in HBM: 32 lanes per coefficient, 8 coefficients per pass
+    NFLHIP_STAMP(4)
+    // ---- P4: the wave's 16 x L result words are contiguous in HBM: 32 lanes per coefficient, 2 coefficients per pass.
+    //      The stage rows were written by this wave: LDS operations of one wave complete in order, no barrier.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-      u64 *o = out + grp * (size_t)kMfmaCoef * (size_t)L;
-      const int k = tid & 31;
+      // (the lane's offsets are recomputed per tile on purpose: hoisted out of the loop they are ten more live registers
+      //  next to the 128 of the B fragments, and their spill reloads wait on EVERY outstanding load and store)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int k = ln & 31;
+      u64 *o = out + (grp * (size_t)kMfmaCoef + 16 * w + (ln >> 5)) * (size_t)L + k;
+      const u64 *sp = stage + (16 * w + (ln >> 5)) * kStStride + k;
       if (k < L) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int c = (tid >> 5) + 8 * r;
-          o[c * L + k] = stage[c * kStStride + k];
-        }
+        for (int rr = 0; rr < 8; ++rr) o[(size_t)(2 * rr) * (size_t)L] = sp[2 * rr * kStStride];
       }
     }
-    // (reuse across iterations is ordered by the five barriers: a_frag / fpart are rewritten after barrier 5 and were last
-    //  read before barrier 2; xs is rewritten after the next barrier 1; the exchange arrays and the stage two barriers on)
+    NFLHIP_STAMP(5)
+#ifdef NFLHIP_CRT_MFMA_STAMP
+    ++st_n;
+#endif
+    // (reuse across iterations: a_frag / fpart are rewritten after this wave's P4 and were last read before barrier 2 by
+    //  every wave; xs is rewritten after the next barrier 1, which every wave reaches after its P3; the stage rows are
+    //  private to the wave)
   }
+#ifdef NFLHIP_CRT_MFMA_STAMP
+  if (blockIdx.x == 3 && lane == 0)
+    printf("wave %d tiles %llu cycles/tile: P1 %llu  barrier1 %llu  P2 %llu  barrier2 %llu  P3 %llu  P4 %llu\n", w, st_n, st_acc[0] / st_n,
+           st_acc[1] / st_n, st_acc[2] / st_n, st_acc[3] / st_n, st_acc[4] / st_n, st_acc[5] / st_n);
+#endif
 }
 
 // `bfrag` / `qdig`: DevTables::crt_bfrag (api.hip build_tables; its modulus slot 31 holds the digits of Q itself), row 0 of

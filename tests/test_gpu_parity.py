@@ -625,11 +625,12 @@ def test_degrees_beyond_the_baseline_shapes(lb, n, m, batch, oracle_factory, eng
     assert np.array_equal(e.to_host(e.polymul(da, e.ntt_(db.clone()), b_is_ntt=True)), want)
 
 
-@pytest.mark.parametrize("n,m,batch", [(256, 12, 3), (64, 16, 1), (128, 17, 2), (32, 29, 2), (256, 31, 1), (64, 32, 5),
-                                       (4096, 16, 40), (65536, 30, 2)])
+@pytest.mark.parametrize("n,m,batch", [(256, 21, 3), (64, 22, 1), (128, 25, 2), (32, 29, 2), (256, 31, 1), (64, 30, 5),
+                                       (4096, 23, 40), (65536, 30, 2), (64, 20, 2), (64, 32, 1)])
 def test_crt_lift_on_the_matrix_cores(n, m, batch, oracle_factory, engine_factory):
-    """GMP::poly2mpz (gmp.hpp:183-209) with 12 and more 62-bit moduli runs as an int8 GEMM (kernels_crt_mfma.hip): extreme
-    residues (X = Q - 1, 0, 1, one residue set), every modulus count's zero padding, more tiles than workgroups."""
+    """GMP::poly2mpz (gmp.hpp:183-209) with 21 .. 31 62-bit moduli runs as an int8 GEMM (kernels_crt_mfma.hip): extreme
+    residues (X = Q - 1, 0, 1, one residue set), several modulus counts' zero padding, more tiles than workgroups; 20 and 32
+    moduli are the VALU kernels either side of it."""
     o, e = oracle_factory(64, n, m), engine_factory(64, n, m)
     a = o.fill_uniform(batch, SEED, 0)
     P = np.asarray(o.P[:m], dtype=a.dtype)
