@@ -227,7 +227,21 @@ def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False):
                                "achieved_GBs": round(crt_bytes * batch / (msl * 1e-3) / 1e9, 1),
                                "frac": round(crt_bytes * batch / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "algorithmic_bytes_per_poly": crt_bytes, "limbs_per_coefficient": L}
-            del limbs
+            # and the way back, GMP::mpz2poly (gmp.hpp:211-219): the lifted coefficients projected onto the moduli again
+            back = eng.crt_project(limbs)
+            ok_rt = not eng.any_neq(back, c)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                eng.crt_project(limbs)
+            e1.record()
+            torch.cuda.synchronize()
+            msp = e0.elapsed_time(e1) / steps
+            out["crt_project"] = {"value": round(batch / (msp * 1e-3), 1), "unit": "polys/s", "ms_per_step": round(msp, 4),
+                                  "achieved_GBs": round(crt_bytes * batch / (msp * 1e-3) / 1e9, 1),
+                                  "frac": round(crt_bytes * batch / (msp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "round_trip_check": bool(ok_rt)}
+            del limbs, back
         del a, b, c
     finally:
         eng.close()

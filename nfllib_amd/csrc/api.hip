@@ -168,6 +168,9 @@ static Big big_shl(const Big &a, int k, size_t limbs) {
 #ifndef NFLHIP_CRT_MFMA_MIN_NM
 #define NFLHIP_CRT_MFMA_MIN_NM 21
 #endif
+#ifndef NFLHIP_CRT_MFMA_PROJ_MIN_NM
+#define NFLHIP_CRT_MFMA_PROJ_MIN_NM 13
+#endif
 
 template <typename T>
 static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const void *invkv, int kmax_log2) {
@@ -296,6 +299,45 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
           }
   }
 
+  // the projection as an int8 GEMM (kernels_crt_mfma.hip): balanced base-256 digits of 256^k mod p_cm, k < 256, as the B
+  // operand -- K-step s, N-tile t = digit, lane (cm = lane & 31, half h = lane >> 5), byte e: k = 32 s + 16 h + e -- and the
+  // per-residue constant 2^18 p + 128 sum_k (256^k mod p) (the input bytes enter as a - 128; the sum is made non-negative)
+  std::vector<int8_t> bproj;
+  std::vector<uint64_t> coff;
+  if (wb == 64 && c->shape.small_delta && nm >= NFLHIP_CRT_MFMA_PROJ_MIN_NM && nm <= 32) {
+    std::vector<int8_t> dig((size_t)32 * 256 * 8, 0);   // [cm][k][digit]
+    coff.assign(32 * 2, 0);
+    for (size_t cm = 0; cm < nm; ++cm) {
+      const uint64_t p = P[cm];
+      uint64_t cur = 1 % p;
+      __int128 colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < 256; ++k) {
+        int carry = 0;
+        for (int b = 0; b < 8; ++b) {
+          int v = (int)((cur >> (8 * b)) & 0xff) + carry;
+          carry = 0;
+          if (v >= 128 && b < 7) { v -= 256; carry = 1; }   // (the top digit of a 62-bit value is below 65: no carry out)
+          dig[(cm * 256 + k) * 8 + b] = (int8_t)v;
+          colsum[b] += 128 * v;
+        }
+        cur = mulmod_h(cur, 256 % p, p);
+      }
+      __int128 off = (__int128)p << 18;
+      for (int b = 0; b < 8; ++b) off += colsum[b] * ((__int128)1 << (8 * b));
+      coff[2 * cm] = (uint64_t)off;
+      coff[2 * cm + 1] = (uint64_t)((unsigned __int128)off >> 64);
+    }
+    bproj.assign((size_t)8 * 8 * 64 * 16, 0);
+    for (int st = 0; st < 8; ++st)
+      for (int t = 0; t < 8; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 16; ++e) {
+            const size_t cm = lane & 31;
+            const int k = 32 * st + 16 * (lane >> 5) + e;
+            if (cm < nm) bproj[(((size_t)st * 8 + t) * 64 + lane) * 16 + e] = dig[(cm * 256 + k) * 8 + t];
+          }
+  }
+
   // twiddles + per-modulus constants
   std::vector<Tw<T>> psi(nm * n);
   std::vector<ModConst<T>> mc(nm);
@@ -395,6 +437,14 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     c->tabs.inv_qtop = (double)(1.0L / qt);
   }
   c->tabs.crt_bfrag = nullptr;
+  c->tabs.crt_bproj = nullptr;
+  c->tabs.crt_coff = nullptr;
+  if (!bproj.empty()) {
+    HIPCHK(nullptr, hipMalloc(&c->tabs.crt_bproj, bproj.size()));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.crt_bproj, bproj.data(), bproj.size(), hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMalloc((void **)&c->tabs.crt_coff, coff.size() * sizeof(uint64_t)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.crt_coff, coff.data(), coff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
   if (!bfrag.empty()) {
     HIPCHK(nullptr, hipMalloc(&c->tabs.crt_bfrag, bfrag.size()));
     HIPCHK(nullptr, hipMemcpy(c->tabs.crt_bfrag, bfrag.data(), bfrag.size(), hipMemcpyHostToDevice));
@@ -746,6 +796,8 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->tabs.qsh) (void)hipFree(ctx->tabs.qsh);
   if (ctx->tabs.qparts) (void)hipFree(ctx->tabs.qparts);
   if (ctx->tabs.crt_bfrag) (void)hipFree(ctx->tabs.crt_bfrag);
+  if (ctx->tabs.crt_bproj) (void)hipFree(ctx->tabs.crt_bproj);
+  if (ctx->tabs.crt_coff) (void)hipFree(ctx->tabs.crt_coff);
   if (ctx->tabs.bparts) (void)hipFree(ctx->tabs.bparts);
   if (ctx->tabs.flag) (void)hipFree(ctx->tabs.flag);
   if (ctx->tabs.qhat_w) (void)hipFree(ctx->tabs.qhat_w);

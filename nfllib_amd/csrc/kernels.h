@@ -64,6 +64,8 @@ struct DevTables {
   int crt_Lw, crt_nsh;
   // CRT lift on the matrix cores (kernels_crt_mfma.hip): 64-bit limbs, many moduli
   void *crt_bfrag;  // [8 K-steps][8 N-tiles][64 lanes][16] int8: balanced base-256 digits of Q/p_cm in B-fragment order, or nullptr
+  void *crt_bproj;  // the same for the projection: digit t of 256^k mod p_cm, k = 32 s + 16 (lane >> 5) + byte, cm = lane & 31, or nullptr
+  uint64_t *crt_coff; // [32][2] 2^18 p_cm + 128 sum_k (256^k mod p_cm in those digits), 128 bits: what the projection adds before reducing
 };
 
 // ---- launchers (kernels_generic.hip) ----
@@ -204,6 +206,8 @@ hipError_t launch_crt_lift_fast_u64(const Shape &s, const DevTables &t, uint64_t
 // the lift as an int8 GEMM on v_mfma_i32_32x32x32_i8 (kernels_crt_mfma.hip): many moduli, batch * n a multiple of 64
 hipError_t launch_crt_lift_mfma_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,
                                     hipStream_t st);
+hipError_t launch_crt_project_mfma_u64(const Shape &s, const DevTables &t, uint64_t *d, const uint64_t *limbs, size_t L_in,
+                                       size_t batch, hipStream_t st);
 hipError_t launch_crt_project_fast_u64(const Shape &s, const DevTables &t, uint64_t *d, const uint64_t *limbs, size_t L_in,
                                        size_t batch, hipStream_t st);
 

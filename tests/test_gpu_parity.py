@@ -652,6 +652,20 @@ def test_crt_lift_on_the_matrix_cores(n, m, batch, oracle_factory, engine_factor
     assert int.from_bytes(got[0, 0].tobytes(), "little") == Q - 1
     assert int.from_bytes(got[0, 1].tobytes(), "little") == 0 and int.from_bytes(got[0, 2].tobytes(), "little") == 1
     assert np.array_equal(e.to_host(e.crt_project(limbs)), a)
+    # mpz2poly of wide non-negative integers (tests/poly_mpz.cpp:44-64) is the same GEMM the other way round, 5 .. 32 words
+    import torch
+    rng = np.random.default_rng(1)
+    nn = min(n, 512)
+    o2 = o if n == nn else oracle_factory(64, nn, m)
+    for lin in (5, e.crt_limbs, 32):
+        wide = rng.integers(0, 2**63, size=(batch, n, lin), dtype=np.uint64) * np.uint64(2) + rng.integers(
+            0, 2, size=(batch, n, lin), dtype=np.uint64)
+        wide[0, 0, :] = np.uint64(0xFFFFFFFFFFFFFFFF)   # every byte 255: the accumulators' worst case
+        wide[0, 1, :] = 0
+        wide[0, 2, :] = np.uint64(0x8080808080808080)   # every byte the bias itself
+        dw = torch.from_numpy(wide.view(np.int64)).to(limbs.device)
+        got_p = e.to_host(e.crt_project(dw))
+        assert np.array_equal(got_p[:, :, :nn], o2.crt_project(np.ascontiguousarray(wide[:, :nn]))), "L_in = %d" % lin
 
 
 @pytest.mark.parametrize("lb,n,m,batch", [(64, 64, 33, 2), (64, 256, 40, 1), (64, 16, 100, 2), (32, 64, 64, 2), (32, 32, 291, 1),

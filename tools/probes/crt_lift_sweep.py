@@ -17,5 +17,13 @@ for nm in (8, 10, 12, 14, 16, 20, 24, 28, 30, 31, 32):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     L = e.crt_limbs
-    print("%-8s nm %2d L %2d  %8.3f ms  %7.1f GB/s algorithmic" % (tag, nm, L, dt * 1e3, batch * n * 8 * (nm + L) / dt / 1e9))
+    limbs = e.crt_lift(a)
+    e.crt_project(limbs); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        e.crt_project(limbs)
+    torch.cuda.synchronize()
+    dp = (time.perf_counter() - t0) / 10
+    print("%-8s nm %2d L %2d  lift %8.3f ms  %7.1f GB/s   project %8.3f ms  %7.1f GB/s (algorithmic)" % (
+        tag, nm, L, dt * 1e3, batch * n * 8 * (nm + L) / dt / 1e9, dp * 1e3, batch * n * 8 * (nm + L) / dp / 1e9))
     e.close()
