@@ -164,12 +164,13 @@ static Big big_shl(const Big &a, int k, size_t limbs) {
 // fewest moduli for which the lift runs as an int8 GEMM on the matrix cores (kernels_crt_mfma.hip).  Its cost hardly depends on
 // the modulus count (the tile is always 32 modulus slots x 256 columns: 0.48 ms at 12 moduli, 0.75 ms at 30 for 4 Mi
 // coefficients), the VALU kernels of kernels_crt.hip grow with its square (0.24 ms at 12, 0.56 at 20, 0.76 at 24, 1.19 at 30):
-// they cross between 20 and 21 (profiles/r04_crt_mfma.txt)
+// they cross between 20 and 21.  The projection's VALU kernels take a second launch beyond 16 residues: 0.40 ms at 16, 0.61 at 18
+// against the GEMM's 0.40 / 0.43 -- it takes over at 17 (same-box sweeps in profiles/r04_crt_mfma.txt)
 #ifndef NFLHIP_CRT_MFMA_MIN_NM
 #define NFLHIP_CRT_MFMA_MIN_NM 21
 #endif
 #ifndef NFLHIP_CRT_MFMA_PROJ_MIN_NM
-#define NFLHIP_CRT_MFMA_PROJ_MIN_NM 13
+#define NFLHIP_CRT_MFMA_PROJ_MIN_NM 17
 #endif
 
 template <typename T>
