@@ -640,15 +640,26 @@ def test_crt_lift_on_the_matrix_cores(n, m, batch, oracle_factory, engine_factor
     a[0, :, 3] = 0; a[0, m - 1, 3] = P[m - 1] - 1
     a[0, :, 4] = P - 1; a[0, 0, 4] = 0
     a[0, :, 5] = P >> 1
+    # lifted values that put runs of all-ones / all-zero digits against the boundaries of the kernel's four 512-bit parts
+    # (the carry / borrow that runs THROUGH a part is a ballot-guarded slow path random residues never take); small X also
+    # makes the quotient estimate land one below the floor, so both S - tQ = X and X + Q come by
+    Q = o.crt_modulus()
+    adv = [(1 << (32 * j)) - 1 for j in range(1, 2 * o.crt_limbs)] + [1 << (512 * k) for k in (1, 2, 3)]
+    adv += [(1 << (512 * k)) + 1 for k in (1, 2, 3)] + [Q - (1 << (512 * k)) for k in (1, 2, 3)] + [Q - 2, Q >> 1, (Q >> 1) + 1]
+    adv += [((1 << 512) - 1) << 512, ((1 << 512) - 1) << 1024, (1 << 1024) - (1 << 512)]
+    adv = [x for x in adv if 0 <= x < Q][: max(0, n - 6)]
+    for idx, x in enumerate(adv):
+        a[0, :, 6 + idx] = [x % int(p) for p in o.P[:m]]
     limbs = e.crt_lift(e.to_device(a))
     got = e.to_host(limbs).view(np.uint64)
+    for idx, x in enumerate(adv):
+        assert int.from_bytes(got[0, 6 + idx].tobytes(), "little") == x, "adversarial value %d (%d bits)" % (idx, x.bit_length())
     if n <= 4096:
         assert np.array_equal(got, o.crt_lift(a)), "poly2mpz differs"
     else:                                            # the oracle's big integers on a sample; everything through the round trip
         o2 = oracle_factory(64, 512, m)              # the lift is per coefficient: a 512-coefficient oracle on a sample
         assert o2.P[:m] == o.P[:m]
         assert np.array_equal(got[:, :512], o2.crt_lift(np.ascontiguousarray(a[:, :, :512])))
-    Q = o.crt_modulus()
     assert int.from_bytes(got[0, 0].tobytes(), "little") == Q - 1
     assert int.from_bytes(got[0, 1].tobytes(), "little") == 0 and int.from_bytes(got[0, 2].tobytes(), "little") == 1
     assert np.array_equal(e.to_host(e.crt_project(limbs)), a)
