@@ -43,6 +43,22 @@ rm -rf /tmp/prof_lwe
 f=$(find /tmp/prof_lwe -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats_lwe_fused.csv
 rm -rf /tmp/prof_lwe
+# CRT both ways (tools/crt_bench.py: B, C on the VALU kernels, E on the matrix cores): rates, kernel summary, and the HBM
+# traffic of the two GEMM kernels per launch of 16 polynomials (503 316 480 algorithmic bytes) from separate counter passes
+python tools/crt_bench.py 2>/dev/null > $out/${tag}_crt_bench.txt
+rm -rf /tmp/prof_crt
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_crt -- python $here/tools/crt_bench.py > /dev/null 2>&1)
+f=$(find /tmp/prof_crt -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats_crt.csv
+rm -rf /tmp/prof_crt
+dirs=""
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_crt_$c
+  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_crt_$c -- python $here/tools/crt_bench.py > /dev/null 2>&1)
+  dirs="$dirs /tmp/pmc_crt_$c"
+done
+{ echo "# mean per launch (u64/65536/30 x 16): FETCH_SIZE in KiB, to be doubled on gfx950; WRITE_SIZE in KiB"; python tools/pmc_sq.py k_crt_lift_mfma $dirs | sed 's/^/lift    /'; python tools/pmc_sq.py k_crt_project_mfma $dirs | sed 's/^/project /'; } > $out/${tag}_crt_traffic.txt
+rm -rf /tmp/pmc_crt_FETCH_SIZE /tmp/pmc_crt_WRITE_SIZE
 # effective clock and power under the product kernels: GRBM_GUI_ACTIVE per launch (cycles, summed over the 8 XCDs) and
 # rocm-smi sampled during a long run
 for wl in B A C F; do
