@@ -105,3 +105,39 @@ def test_the_walk_was_wide():
     assert len(_RAN) >= 100
     assert {lb for lb, _, _ in _RAN} == {16, 32, 64}
     assert min(l for _, l, _ in _RAN) <= 3 and max(l for _, l, _ in _RAN) >= 11 and max(m for _, _, m in _RAN) >= 16
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_crt_matrix_core_kernels_every_modulus_count_and_width(seed, oracle_factory, engine_factory):
+    """GMP::poly2mpz / mpz2poly (gmp.hpp:183-219) on the matrix cores (kernels_crt_mfma.hip): every modulus count they serve
+    (lift 21 .. 31, projection 17 .. 32), every input width of the projection (5 .. 32 words), random residues plus lifted
+    values whose digits are runs of ones / zeros placed at random (the carry / borrow paths between the kernel's parts)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    for m in range(17, 33):
+        n, batch = 256, 3
+        o, e = oracle_factory(64, n, m), engine_factory(64, n, m)
+        Q = o.crt_modulus()
+        a = o.fill_uniform(batch, int(rng.integers(1, 2**40)), 0)
+        adv = [int(rng.integers(0, 2**62)) << int(rng.integers(0, 64 * o.crt_limbs)) for _ in range(60)]
+        adv += [(1 << int(rng.integers(1, Q.bit_length()))) - 1 for _ in range(60)]
+        adv += [Q - 1 - ((1 << int(rng.integers(1, Q.bit_length() - 1))) - 1) for _ in range(60)]
+        adv += [((1 << 512) - 1) << (32 * int(rng.integers(0, 2 * o.crt_limbs - 16))) for _ in range(40)]
+        adv = [x % Q for x in adv][:n]
+        for idx, x in enumerate(adv):
+            a[0, :, idx] = [x % int(p) for p in o.P[:m]]
+        limbs = e.crt_lift(e.to_device(a))
+        got = e.to_host(limbs).view(np.uint64)
+        assert np.array_equal(got, o.crt_lift(a)), "lift, %d moduli" % m
+        for idx, x in enumerate(adv):
+            assert int.from_bytes(got[0, idx].tobytes(), "little") == x
+        assert np.array_equal(e.to_host(e.crt_project(limbs)), a), "round trip, %d moduli" % m
+        for lin in range(5, 33):
+            wide = rng.integers(0, 2**63, size=(1, n, lin), dtype=np.uint64) * np.uint64(2) + rng.integers(
+                0, 2, size=(1, n, lin), dtype=np.uint64)
+            wide[0, 0, :] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            wide[0, 1, :] = 0
+            wide[0, 2, :] = np.uint64(0x8080808080808080)
+            wide[0, 3, :] = np.uint64(0x7F7F7F7F7F7F7F7F)
+            dw = torch.from_numpy(wide.view(np.int64)).to(limbs.device)
+            assert np.array_equal(e.to_host(e.crt_project(dw)), o.crt_project(wide)), "project, %d moduli, %d words" % (m, lin)
