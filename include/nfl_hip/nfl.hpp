@@ -53,6 +53,7 @@
 #include <array>
 #include <atomic>
 #include <cassert>
+#include <chrono>
 #include <cinttypes>
 #include <climits>
 #include <cmath>
@@ -75,6 +76,7 @@
 #include <stdexcept>
 #include <string>
 #include <strings.h>
+#include <thread>
 #include <tuple>
 #include <type_traits>
 #include <unordered_map>
@@ -282,6 +284,41 @@ inline unsigned strict_exempt(const unsigned char *code, size_t len) {
   return as_companion & ~as_value;
 }
 
+// The lock of the recording path (detail::lazy<P>::mu, the buffer pool of detail::context): recursive, ONE atomic operation per
+// outermost acquisition and a plain release store -- a std::recursive_mutex costs a locked instruction each way plus two
+// calls into libc, and the LWE demo's loop takes the queue's lock sixteen times per encryption: a third of its host time
+// inside a process that has other threads at all (the HIP runtime's), where glibc's single-thread shortcuts are off.
+// Waiters spin, then yield, then sleep (a queue run may hold the lock for hundreds of microseconds).
+class light_lock {
+  std::atomic<const void *> owner_;
+  unsigned depth_;
+  static const void *me() {
+    static thread_local char tag;
+    return &tag;
+  }
+ public:
+  light_lock() : owner_(nullptr), depth_(0) {}
+  light_lock(const light_lock &) = delete;
+  light_lock &operator=(const light_lock &) = delete;
+  void lock() {
+    const void *self = me();
+    if (owner_.load(std::memory_order_relaxed) == self) {
+      ++depth_;
+      return;
+    }
+    const void *expected = nullptr;
+    for (unsigned spins = 0; !owner_.compare_exchange_weak(expected, self, std::memory_order_acquire, std::memory_order_relaxed); ++spins) {
+      expected = nullptr;
+      if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      else if (spins > 64) std::this_thread::yield();
+    }
+    depth_ = 1;
+  }
+  void unlock() {
+    if (--depth_ == 0) owner_.store(nullptr, std::memory_order_release);
+  }
+};
+
 // Every ring type whose per-polynomial operations can be deferred (detail::lazy<P> below) registers the function that
 // runs its queue.  Whoever is about to invalidate something recorded operations refer to -- a FastGaussianNoise that
 // dies (its device tables), nfl::set_sampler_key (the key recorded draws will be made with) -- runs all queues first.
@@ -349,7 +386,7 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   nflhip_ctx *ctx;
   void *stream;
   int device;
-  std::mutex mu;
+  light_lock mu;
   static constexpr size_t poly_bytes = Degree * NbModuli * sizeof(T);
   static constexpr size_t chunk_bytes = (poly_bytes + 255) / 256 * 256;          // device buffers are 256-byte aligned
   // Device buffers of the resident handles: slabs (256 MiB first, doubling up to 2 GiB -- the device has 288 GB) carved
@@ -460,12 +497,12 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   }
   static void acquire_many(size_t cnt, void **out) {
     context &c = inst();
-    std::lock_guard<std::mutex> lk(c.mu);
+    std::lock_guard<light_lock> lk(c.mu);
     c.acquire_many_locked(cnt, out);
   }
   static void *acquire() {
     context &c = inst();
-    std::lock_guard<std::mutex> lk(c.mu);
+    std::lock_guard<light_lock> lk(c.mu);
     for (auto &kv : c.slabs)
       if (!kv.second.free.empty()) {
         void *p = kv.second.free.back();
@@ -480,7 +517,7 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
   static void release(void *p) {
     if (!p || !alive()) return;  // (after teardown the runtime reclaims it)
     context &c = inst();
-    std::lock_guard<std::mutex> lk(c.mu);
+    std::lock_guard<light_lock> lk(c.mu);
     slab *hit = c.last_released;  // (neighbouring handles die together: the slab of the previous release, usually)
     if (!hit || static_cast<char *>(p) < hit->base || static_cast<char *>(p) >= hit->base + hit->chunks * chunk_bytes) {
       auto it = c.slabs.upper_bound(static_cast<char *>(p));
@@ -709,10 +746,14 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   int wlev, rlev;
   int fw;  // scratch of lazy<P>::fuse (valid when `epoch` is the current flush): the recorded operation that last wrote this value
   unsigned pin_at;  // where the queue's reference to this payload sits in its pin list (valid while qrefs is set / during that run)
+  // recording scratch of lazy<P>::record (valid when `rec_run` is the queue's current recording run): index of the last
+  // recorded operation that writes / reads this value -- what lets a transform join the operation that produced its operand
+  unsigned rec_run;
+  int rec_w, rec_r;
 
-  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0) {}
+  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0), rec_run(0), rec_w(-1), rec_r(-1) {}
   payload(const payload &o) : std::enable_shared_from_this<payload<P>>(), host(nullptr), dev(nullptr), host_valid(false),
-                              dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0) {
+                              dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0), rec_run(0), rec_w(-1), rec_r(-1) {
     pending();
     o.usable();
     if (o.dev_valid) {  // stays on the device
@@ -860,11 +901,14 @@ template <class P> struct lazy {
       } f;          // K_FWD_FMA
     };
     unsigned char kind, nin, len;
+    unsigned char post;   // 0, or K_NTT_FWD / K_NTT_INV: the result is transformed in place right after (a transform recorded on
+                          // a value nothing had read since this operation produced it joins the operation instead of becoming a record)
   };
-  std::recursive_mutex mu;
+  light_lock mu;
   std::vector<op> q, running;  // recorded operations; the ones a queue run is working on (two buffers that swap: no regrowth)
   std::vector<ptr_t> pins, pins_running;  // the payloads they name, one reference each
   size_t launches, coalesced;  // statistics: launches issued / operations they carried
+  unsigned rec_run_;           // the recording run: bumped whenever the queue is handed to a queue run (payload::rec_run)
   // records after which the queue runs by itself: long enough for wide launches, short enough that the device works on
   // one part of a loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments).  Measured on the
   // LWE demo loop (profiles/r02_late_queue_limit.txt): 2 048 iterations 614 k / 738 k / 1.04 M / 861 k encryptions/s with
@@ -881,7 +925,7 @@ template <class P> struct lazy {
     static const bool v = getenv("NFL_HIP_EARLY_RUN") && atoi(getenv("NFL_HIP_EARLY_RUN")) != 0;
     return v;
   }
-  lazy() : launches(0), coalesced(0), small_(nullptr), small_cap_(0), fused_fwd(0), fused_inv(0) {
+  lazy() : launches(0), coalesced(0), rec_run_(1), small_(nullptr), small_cap_(0), fused_fwd(0), fused_inv(0) {
     ctx_t::inst();  // (the context is constructed first, so it is destroyed last)
     alive() = true;
     queue_registry::get().add(&lazy::run_if_alive);
@@ -903,7 +947,7 @@ template <class P> struct lazy {
   }
   // whether two recorded operations may share a launch: everything a launch takes from its first member
   static bool same_signature(const op &a, const op &b) {
-    if (a.kind != b.kind) return false;
+    if (a.kind != b.kind || a.post != b.post) return false;
     if (a.kind == K_EVAL) return a.len == b.len && a.nin == b.nin && std::memcmp(a.e.code, b.e.code, a.len) == 0;
     if (a.kind == K_SAMPLE || a.kind == K_GAUSS) return a.s.dist == b.s.dist && a.s.p0 == b.s.p0 && a.s.p1 == b.s.p1 && a.s.tab == b.s.tab;
     if (a.kind == K_FILL) return a.s.sid == b.s.sid;
@@ -1009,8 +1053,8 @@ template <class P> struct lazy {
       prev[size_t(i)] = o.out->fw;
       if ((o.kind == K_NTT_FWD || o.kind == K_NTT_INV) && o.out->fw >= 0) ++uses[size_t(o.out->fw)];
       o.out->fw = i;
-      any_fwd |= o.kind == K_NTT_FWD;
-      any_inv |= o.kind == K_NTT_INV;
+      any_fwd |= o.kind == K_NTT_FWD || o.post == K_NTT_FWD;
+      any_inv |= o.kind == K_NTT_INV || o.post == K_NTT_INV;
     }
     // the value an operation wrote is still its payload's at the end of the run: only fusable away when no handle is left
     auto dead_after = [&](int d) {
@@ -1019,6 +1063,11 @@ template <class P> struct lazy {
     };
     // a sampled-and-transformed polynomial nobody else sees: -> index of its K_GAUSS record, or -1
     auto gauss_chain = [&](int dn, int want_uses) {
+      if (dn >= 0 && ops[size_t(dn)].kind == K_GAUSS && ops[size_t(dn)].post == K_NTT_FWD) {   // the transform joined its constructor's record
+        const op &g = ops[size_t(dn)];
+        if (uses[size_t(dn)] != want_uses || !dead_after(dn) || (g.s.p1 >> 32) != 0) return -1;
+        return small_format(g.s.tab, uint32_t(g.s.p1)) > NFLHIP_FMT_I32 ? -1 : dn;
+      }
       if (dn < 0 || ops[size_t(dn)].kind != K_NTT_FWD || uses[size_t(dn)] != want_uses || !dead_after(dn)) return -1;
       const int g = prev[size_t(dn)];
       if (g < 0 || ops[size_t(g)].kind != K_GAUSS || uses[size_t(g)] != 1 || (ops[size_t(g)].s.p1 >> 32) != 0) return -1;
@@ -1028,6 +1077,22 @@ template <class P> struct lazy {
     if (any_inv)
       for (int i = 0; i < n; ++i) {
         op &t = ops[size_t(i)];
+        if (t.kind == K_EVAL && t.post == K_NTT_INV) {   // the transform joined the expression's record: rewrite in place
+          int a, b, c;
+          bool sub;
+          if (!parse_fma(t, a, b, c, sub)) continue;
+          pay_t *pc = t.e.in[c], *pa = t.e.in[a], *pb = t.e.in[b];
+          t.kind = K_FMA_INV;
+          t.post = 0;
+          t.nin = 3;
+          t.len = 1;
+          t.e.in[0] = pc;
+          t.e.in[1] = pa;
+          t.e.in[2] = pb;
+          t.e.code[0] = sub ? 1 : 0;
+          ++fused_inv;
+          continue;
+        }
         if (t.kind != K_NTT_INV) continue;
         const int d = prev[size_t(i)];
         int a, b, c;
@@ -1145,13 +1210,39 @@ template <class P> struct lazy {
       p->qrefs = 1;
     }
   }
+  pay_t *rec_tag(pay_t *p) {
+    if (p->rec_run != rec_run_) {
+      p->rec_run = rec_run_;
+      p->rec_w = p->rec_r = -1;
+    }
+    return p;
+  }
+  // A transform recorded on a value that a Gaussian constructor or an expression of THIS recording run produced and that
+  // nothing has read since does not become a record of its own: the producing operation notes "then transform in place"
+  // (op::post).  The reference's loops are written that way -- poly_p u{gaussian}; u.ntt_pow_phi();  out = rb - ra * s;
+  // out.invntt_pow_invphi(); -- and every record costs the host the same whatever it stands for.  Results are those of the
+  // separate records; NFL_HIP_NO_FUSION=1 switches this off together with the transform fusion.
+  static bool joining_on() {
+    static const bool v = !getenv("NFL_HIP_NO_FUSION");
+    return v;
+  }
+  bool join_transform(pay_t *p, int kind) {
+    if (!joining_on()) return false;
+    std::lock_guard<light_lock> lk(mu);
+    if (p->rec_run != rec_run_ || p->rec_w < 0 || p->rec_r > p->rec_w || p->poisoned) return false;
+    op &t = q[size_t(p->rec_w)];
+    if (t.post || t.out != p || !((t.kind == K_GAUSS && kind == K_NTT_FWD) || t.kind == K_EVAL)) return false;
+    t.post = static_cast<unsigned char>(kind);
+    return true;
+  }
   // `fill(op &)` writes the record in place, in the queue; the payloads it names are pinned here
   template <class F> void record(F fill) {
-    std::lock_guard<std::recursive_mutex> lk(mu);
+    std::lock_guard<light_lock> lk(mu);
     q.emplace_back();
     op &o = q.back();
     o.nin = 0;
     o.len = 0;
+    o.post = 0;
     try {  // inputs must hold a device value (or be produced by the queue) before the operation counts as recorded
       fill(o);
       for (int j = 0; j < o.nin; ++j) o.e.in[j]->dev_ro_nf();
@@ -1162,6 +1253,9 @@ template <class P> struct lazy {
       q.pop_back();
       throw;
     }
+    const int at = int(q.size()) - 1;
+    for (int j = 0; j < o.nin; ++j) rec_tag(o.e.in[j])->rec_r = at;
+    rec_tag(o.out)->rec_w = at;
     o.out->queued = true;
     o.out->dev_valid = true;
     o.out->host_valid = false;
@@ -1174,7 +1268,7 @@ template <class P> struct lazy {
     }
   }
   void flush() {
-    std::lock_guard<std::recursive_mutex> lk(mu);
+    std::lock_guard<light_lock> lk(mu);
     if (q.empty()) return;
     std::vector<op> local;  // (a queue run started from inside another one: cannot happen today, costs nothing to allow)
     std::vector<ptr_t> local_pins;
@@ -1183,6 +1277,7 @@ template <class P> struct lazy {
     std::vector<ptr_t> &held = outer ? pins_running : local_pins;
     ops.swap(q);
     held.swap(pins);
+    ++rec_run_;   // (what is recorded from now on cannot join operations of this run)
     if (q.capacity() < ops.capacity()) q.reserve(ops.capacity());
     for (auto &p : held) p->qrefs = 0;  // (operations recorded from now on belong to the next run and pin again)
     std::vector<unsigned char> launched(ops.size(), 0);
@@ -1252,7 +1347,7 @@ template <class P> struct lazy {
     for (size_t i = 0; i < ops.size(); ++i) {
       const op &o = ops[i];
       if (o.kind == K_NOP) continue;
-      uint64_t h = mix(0xcbf29ce484222325ull, uint64_t(o.kind));
+      uint64_t h = mix(0xcbf29ce484222325ull, uint64_t(o.kind) | (uint64_t(o.post) << 8));
       if (o.kind == K_FWD_FMA) {
         h = mix(mix(mix(h, uint64_t(reinterpret_cast<uintptr_t>(o.f.tab))), (uint64_t(o.f.amp[0]) << 32) | o.f.amp[1]), (uint64_t(o.f.amp[2]) << 8) | o.nin);
       } else if (o.kind == K_FMA_INV) {
@@ -1284,6 +1379,30 @@ template <class P> struct lazy {
     struct { unsigned char key[32]; } smp;  // the key as it is NOW: set_sampler_key runs the queues before it changes it
     detail::sampler::get().copy_key(smp.key);
     static const bool trace = getenv("NFL_HIP_TRACE_DEFERRED") != nullptr;
+    // in-place transforms of the results of `idx` (mutually independent): by address, so that neighbours become one dense batch
+    auto launch_transforms = [&](const std::vector<size_t> &idx, int tkind) {
+      std::vector<char *> ptr;
+      ptr.reserve(idx.size());
+      for (size_t i : idx) ptr.push_back(static_cast<char *>(ops[i].out->dev));
+      sort_interleaved(ptr);
+      for (size_t a = 0; a < ptr.size();) {
+        size_t b = a + 1;
+        while (b < ptr.size() && ptr[b] == ptr[b - 1] + ctx_t::chunk_bytes) ++b;
+        check(ctx, tkind == K_NTT_FWD ? nflhip_ntt_fwd_dev(ctx, ptr[a], b - a, st) : nflhip_ntt_inv_dev(ctx, ptr[a], b - a, st),
+              "deferred transform");
+        ++launches;
+        coalesced += b - a;
+        a = b;
+      }
+    };
+    // (operations that carry a joined transform count as launched only once it has been issued)
+    auto finish_post = [&](const std::vector<size_t> &idx) {
+      const int post = ops[idx[0]].post;
+      if (!post) return;
+      for (size_t i : idx) launched[i] = 0;
+      launch_transforms(idx, post);
+      for (size_t i : idx) launched[i] = 1;
+    };
     for (size_t gi : order) {
       std::vector<size_t> &idx = members[gi];
       const int kind = ops[idx[0]].kind;
@@ -1333,20 +1452,7 @@ template <class P> struct lazy {
         }
       }
       if (kind == K_NTT_FWD || kind == K_NTT_INV) {
-        // in place, mutually independent: any order -- by address, so that neighbours become one dense batch
-        std::vector<char *> ptr;
-        ptr.reserve(idx.size());
-        for (size_t i : idx) ptr.push_back(static_cast<char *>(ops[i].out->dev));
-        sort_interleaved(ptr);
-        for (size_t a = 0; a < ptr.size();) {
-          size_t b = a + 1;
-          while (b < ptr.size() && ptr[b] == ptr[b - 1] + ctx_t::chunk_bytes) ++b;
-          check(ctx, kind == K_NTT_FWD ? nflhip_ntt_fwd_dev(ctx, ptr[a], b - a, st) : nflhip_ntt_inv_dev(ctx, ptr[a], b - a, st),
-                "deferred transform");
-          ++launches;
-          coalesced += b - a;
-          a = b;
-        }
+        launch_transforms(idx, kind);
         for (size_t i : idx) launched[i] = 1;
         continue;
       }
@@ -1387,6 +1493,7 @@ template <class P> struct lazy {
           coalesced += cnt;
           a = b;
         }
+        finish_post(idx);
         continue;
       }
       // ---- K_EVAL (and the fused kinds, whose operands sit in the same slots): operands that are one polynomial for
@@ -1537,6 +1644,7 @@ template <class P> struct lazy {
           a = b;
         }
       }
+      finish_post(idx);
     }
     guard.complete = true;
   }
@@ -2314,7 +2422,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
     if (p.use_count() - extra <= 1) return false;  // nobody else at all
     // The queue's reference and the flag that discounts it change together under the queue's lock -- also when a queue
     // run started by ANOTHER thread retires this handle's operations -- so they are read under it.
-    std::lock_guard<std::recursive_mutex> lk(lazy_t::inst().mu);
+    std::lock_guard<detail::light_lock> lk(lazy_t::inst().mu);
     return p.use_count() - p->qrefs - extra > 1;
   }
   void detach() const {
@@ -2335,12 +2443,18 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
   static bool defer_sample(payload_type &p, int kind, int dist, uint64_t p0, uint64_t p1, uint64_t sid, const nflhip_gauss *tab) {
     if (!lazy_t::usable()) return false;
     if (kind != lazy_t::K_FILL) {
-      // (validated once per distinct argument tuple in a row: loops repeat the same constructor)
-      struct last_t { int dist; uint64_t p0, p1; const nflhip_gauss *tab; bool any; };
-      static thread_local last_t last = {0, 0, 0, nullptr, false};
-      if (!last.any || last.dist != dist || last.p0 != p0 || last.p1 != p1 || last.tab != tab) {
+      // (validated once per distinct argument tuple: loops repeat a handful of constructors -- the LWE demo's alternate between two
+      //  amplifiers, so remembering only the last one made two validating C-ABI calls per encryption, more than all the recording)
+      struct seen_t { int dist; uint64_t p0, p1; const nflhip_gauss *tab; };
+      static thread_local seen_t seen[8];
+      static thread_local unsigned nseen = 0, victim = 0;
+      bool known = false;
+      for (unsigned k = 0; k < nseen && !known; ++k)
+        known = seen[k].dist == dist && seen[k].p0 == p0 && seen[k].p1 == p1 && seen[k].tab == tab;
+      if (!known) {
         check_sample_args(dist, p0, p1, tab);
-        last = last_t{dist, p0, p1, tab, true};
+        const unsigned at = nseen < 8 ? nseen++ : victim++ % 8;
+        seen[at] = seen_t{dist, p0, p1, tab};
       }
     }
     lazy_t::inst().record([&](typename lazy_t::op &o) {
@@ -2479,10 +2593,21 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
 
  private:
   void transform(int kind) {
+    bool tried = false;
+    if (lazy_t::usable() && !detail::strictmod && _p.use_count() > 1) {
+      // queued values carry the queue's reference: the copy-on-write test and the attempt to join the producing record need
+      // the queue's lock both -- taken once here instead of twice
+      std::lock_guard<detail::light_lock> lk(lazy_t::inst().mu);
+      if (_p.use_count() - _p->qrefs <= 1) {
+        tried = true;
+        if (lazy_t::inst().join_transform(_p.get(), kind)) return;
+      }
+    }
     detach();
     if (detail::strictmod)
       detail::strict_dev(ctx_t::get(), _p->dev_ro(), 1, ctx_t::queue(), kind == lazy_t::K_NTT_FWD ? "ntt_pow_phi" : "invntt_pow_invphi");
     if (lazy_t::usable()) {
+      if (!tried && lazy_t::inst().join_transform(_p.get(), kind)) return;
       lazy_t::inst().record([&](typename lazy_t::op &o) {
         o.kind = static_cast<unsigned char>(kind);
         o.out = _p.get();

@@ -11,7 +11,11 @@
 //   4. the sequences the transform fusion rewrites (sample, transform, multiply-add; multiply-add, inverse transform) in
 //      every operand order, next to look-alikes it must leave alone: a third reader of a transformed temporary, a
 //      temporary whose handle survives, a key rewritten between two results, a result feeding the next, a sum that is
-//      read before it is transformed back.
+//      read before it is transformed back;
+//   5. transforms that join the record of the operation that produced their operand (detail::lazy::join_transform) next
+//      to the ones that must stay records of their own: a reader between the two, two transforms in a row, a transform
+//      after a queue run, a constructor / transform pair of the wrong kinds, a value written twice, a fused
+//      multiply-add transformed back at once.
 // Usage: deferred_loops [reps].  Exit code 0 = identical.  Runs against the real library (GPU) and against the toy
 // arithmetic of tests/cpp/mock (CPU: tests/test_host_logic.py).
 #include <nfl.hpp>
@@ -117,6 +121,29 @@ template <class T, size_t Degree, size_t NbModuli> static bool run(size_t reps) 
         if (i % 6 == 1) save(r2[i]);
       }
       for (auto &a : alive) save(a);
+    }
+    {  // 5. shapes around the joined transforms
+      poly_p k1{nfl::uniform()}, k2{nfl::uniform()}, c0{nfl::uniform()};
+      const size_t m = reps / 4 + 5;
+      std::vector<poly_p> r0(m), r1(m);
+      for (size_t i = 0; i < m; ++i) {
+        poly_p u{G(&fg)}, e1{G(&fg, 2)};
+        switch (i % 9) {
+          case 0: r1[i] = u + k1; u.ntt_pow_phi(); r0[i] = u; break;                                    // u is read before its transform
+          case 1: u.ntt_pow_phi(); u.invntt_pow_invphi(); r0[i] = u; r1[i] = e1; break;                 // two transforms in a row
+          case 2: r0[i] = u + e1; r0[i].ntt_pow_phi(); r1[i] = r0[i] * k1; r1[i].ntt_pow_phi(); r1[i].ntt_pow_phi(); break;   // expression, then forward (twice)
+          case 3: r0[i] = k1 * k2 + c0; r0[i] = r0[i] * k2 + u; r0[i].invntt_pow_invphi(); r1[i] = r0[i] + e1; break;   // written twice, in place
+          case 4: u.ntt_pow_phi(); e1.ntt_pow_phi(); r0[i] = u * k1 + e1; r0[i].invntt_pow_invphi(); r1[i] = r0[i]; break;   // fused, back at once
+          case 5: if (i % 2) poly_p::synchronize(); u.ntt_pow_phi(); r0[i] = u; r1[i] = e1; break;      // (sometimes) after a queue run
+          case 6: u.invntt_pow_invphi(); r0[i] = u; { poly_p w{nfl::uniform()}; w.ntt_pow_phi(); r1[i] = w; } break;   // wrong kinds
+          case 7: { poly_p c = u; u.ntt_pow_phi(); r0[i] = u; r1[i] = c; } break;                       // a copy shares the value
+          default: r0[i] = c0 - k1 * k2; r1[i] = r0[i] + u; r0[i].invntt_pow_invphi(); break;           // the difference is read first
+        }
+      }
+      for (size_t i = 0; i < m; ++i) {
+        save(r0[i]);
+        save(r1[i]);
+      }
     }
     poly_p::synchronize();
   }

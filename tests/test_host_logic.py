@@ -125,6 +125,23 @@ def test_the_harness_notices_a_broken_fusion(mock, tmp_path):
         assert r.returncode != 0 and "all checks passed" not in r.stdout
 
 
+def test_the_harness_notices_a_transform_joined_too_eagerly(mock, tmp_path):
+    """a header whose transforms join the producing record although the value was read in between, or although that record
+    already carries a transform, must fail the loop comparison (section 5 of deferred_loops.cpp)"""
+    good = {"p->rec_r > p->rec_w || ": "", "if (t.post || t.out != p || ": "if (t.out != p || "}
+    for k, (old, new) in enumerate(good.items()):
+        inc = tmp_path / ("include%d" % k)
+        shutil.copytree(os.path.join(ROOT, "include"), inc)
+        hdr = inc / "nfl_hip" / "nfl.hpp"
+        text = hdr.read_text()
+        assert old in text
+        hdr.write_text(text.replace(old, new))
+        exe = str(tmp_path / ("join_mutant%d" % k))
+        build_program("deferred_loops.cpp", exe, include=str(inc))
+        r = run(exe, 60)
+        assert r.returncode != 0 and "all checks passed" not in r.stdout
+
+
 def test_random_programs_under_address_and_undefined_behaviour_sanitizers(mock, tmp_path):
     """the same random programs with ASan + UBSan + leak detection: handles dying while queued, the queue's raw payload
     pointers and its one-reference-per-run pins, the buffer pool's free lists"""
