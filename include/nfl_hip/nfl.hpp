@@ -598,7 +598,7 @@ inline void randombytes(unsigned char *x, unsigned long long xlen) {
 template <class in_class, class out_class, unsigned _lu_depth> class FastGaussianNoise {
  public:
   FastGaussianNoise(double sigma, unsigned int security, unsigned int samples, double center_d = 0, bool /*verbose*/ = false)
-      : sigma_(sigma), security_(security), samples_(samples), center_(center_d) {
+      : sigma_(sigma), security_(security), samples_(samples), center_(center_d), last_(nullptr) {
     static_assert(_lu_depth == 1 || _lu_depth == 2, "_lu_depth must be 1 or 2 (FastGaussianNoise.hpp:214)");
   }
   FastGaussianNoise(FastGaussianNoise const &) = delete;
@@ -612,13 +612,19 @@ template <class in_class, class out_class, unsigned _lu_depth> class FastGaussia
     for (auto &kv : tables_) nflhip_gauss_destroy(nullptr, kv.second);
   }
   const nflhip_gauss *table(nflhip_ctx *ctx) {
+    // (every random constructor of a loop comes through here: the context used last is answered from one atomic pointer to
+    //  its map node -- node addresses are stable -- instead of a mutex and a map lookup per polynomial)
+    const std::pair<nflhip_ctx *const, nflhip_gauss *> *hit = last_.load(std::memory_order_acquire);
+    if (hit && hit->first == ctx) return hit->second;
     std::lock_guard<std::mutex> lk(mu_);
     auto it = tables_.find(ctx);
-    if (it != tables_.end()) return it->second;
-    nflhip_gauss *g = nullptr;
-    detail::check(ctx, nflhip_gauss_create(ctx, &g, sigma_, security_, samples_, center_), "FastGaussianNoise");
-    tables_[ctx] = g;
-    return g;
+    if (it == tables_.end()) {
+      nflhip_gauss *g = nullptr;
+      detail::check(ctx, nflhip_gauss_create(ctx, &g, sigma_, security_, samples_, center_), "FastGaussianNoise");
+      it = tables_.emplace(ctx, g).first;
+    }
+    last_.store(&*it, std::memory_order_release);
+    return it->second;
   }
   double sigma() const { return sigma_; }
   // FastGaussianNoise.hpp:477-595: rlen raw samples, negative values wrap into out_class exactly like the reference's
@@ -637,6 +643,7 @@ template <class in_class, class out_class, unsigned _lu_depth> class FastGaussia
   double center_;
   std::mutex mu_;
   std::map<nflhip_ctx *, nflhip_gauss *> tables_;
+  std::atomic<const std::pair<nflhip_ctx *const, nflhip_gauss *> *> last_;
 };
 
 template <class in_class, class out_class, unsigned _lu_depth> struct gaussian {
@@ -1295,7 +1302,12 @@ template <class P> struct lazy {
               o[i].out->poisoned = true;
             }
         o.clear();
-        h.clear();
+        if (ctx_t::alive()) {   // the temporaries' buffers go back to the pool one by one: its lock is taken once for all of them
+          std::lock_guard<light_lock> pool(ctx_t::inst().mu);
+          h.clear();
+        } else {
+          h.clear();
+        }
       }
     } guard{ops, held, launched, false};
     // ---- 1. levels (the last writing / reading level of a value is kept in its payload, tagged with this flush's epoch)
