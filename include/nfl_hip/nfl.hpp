@@ -2735,10 +2735,17 @@ template <class P> class device_batch {
     detail::check(ctx(), nflhip_malloc(ctx(), &d_, bytes()), "device_batch");
   }
   device_batch(const P *host, size_t count) : device_batch(count) { upload(host); }
-  ~device_batch() { if (d_) nflhip_free(ctx(), d_); }
+  ~device_batch() {
+    if (small_) nflhip_free(ctx(), small_);
+    if (d_) nflhip_free(ctx(), d_);
+  }
   device_batch(const device_batch &) = delete;
   device_batch &operator=(const device_batch &) = delete;
-  device_batch(device_batch &&o) noexcept : n_(o.n_), d_(o.d_), c_(o.c_) { o.d_ = nullptr; }
+  device_batch(device_batch &&o) noexcept : n_(o.n_), d_(o.d_), c_(o.c_), small_(o.small_), small_cap_(o.small_cap_) {
+    o.d_ = nullptr;
+    o.small_ = nullptr;
+    o.small_cap_ = 0;
+  }
 
   size_t size() const { return n_; }
   size_t bytes() const { return n_ * sizeof(P); }
@@ -2855,6 +2862,28 @@ template <class P> class device_batch {
     detail::check(ctx(), nflhip_sample_gauss_dev(ctx(), d_, first_poly, n_, m.fg_prng->table(ctx()), m.amplifier, s.key,
                                                  stream_id, queue()), "set(gaussian)");
   }
+  // ---- the transform-fused pipelines over a resident batch (include/nflhip.h "transform-fused pipelines"; what the
+  // reference's LWE demo does around its transforms, tests/nfllib_demo_main_op.cpp:26-58).  `k` operands are in NTT form
+  // and hold either one polynomial (a key shared by the whole batch) or one per element.  Results are bit-identical to
+  //     X.set(x); E.set(e); X.ntt_pow_phi(); E.ntt_pow_phi(); *this = X * k + E;          (stream ids taken in that order)
+  //     *this = b -+ a * k; this->invntt_pow_invphi();
+  // -- the Gaussian polynomials only ever exist as one signed integer per coefficient, the transformed ones not at all.
+  template <class Gx, class Ge> void assign_gaussian_fma(Gx const &x, const device_batch &k, Ge const &e) {
+    gaussian_fma(nullptr, x, k, e, nullptr, e);
+  }
+  // *this = NTT(x) * k0 + NTT(e0), out1 = NTT(x) * k1 + NTT(e1): x is drawn and transformed once
+  template <class Gx, class G0, class G1>
+  void assign_gaussian_fma2(device_batch &out1, Gx const &x, const device_batch &k0, G0 const &e0, const device_batch &k1, G1 const &e1) {
+    same_size(out1);
+    gaussian_fma(&out1, x, k0, e0, &k1, e1);
+  }
+  // *this = INTT(b - a * k) (subtract) or INTT(b + a * k); a, b, k in NTT form; *this may be a or b
+  void assign_fma_inv(const device_batch &a, const device_batch &k, const device_batch &b, bool subtract) {
+    same_size(a);
+    same_size(b);
+    nflhip_operand oa = {a.d_, 1, NFLHIP_FMT_WORDS}, ok = key_operand(k), ob = {b.d_, 1, NFLHIP_FMT_WORDS};
+    detail::check(ctx(), nflhip_fma_inv_dev(ctx(), d_, &oa, &ok, &ob, subtract ? 1 : 0, n_, queue()), "multiply-add + inverse transform");
+  }
   // replicate one polynomial over the batch (a key shared by every ciphertext, ...)
   void fill(const P &one) {  // one upload + one broadcast kernel
     void *tmp = nullptr;
@@ -2908,9 +2937,84 @@ template <class P> class device_batch {
                                  : nflhip_any_neq_dev(ctx(), d_, o.d_, n_, &r, queue()), "compare");
     return r != 0;
   }
+  nflhip_operand key_operand(const device_batch &k) const {
+    if (k.c_ != c_) throw std::runtime_error("nfl(hip): the batches of one operation must live on one device");
+    if (k.n_ != 1 && k.n_ != n_) throw std::runtime_error("nfl(hip): a key operand holds one polynomial or one per element");
+    nflhip_operand o = {k.d_, size_t(k.n_ == 1 ? 0 : 1), NFLHIP_FMT_WORDS};
+    return o;
+  }
+  // compact Gaussian polynomials of one call: a grow-only buffer of this batch (its consumers are on the batch's stream)
+  void *small_buffer(size_t bytes) {
+    if (bytes > small_cap_) {
+      if (small_) {
+        sync();
+        nflhip_free(ctx(), small_);
+        small_ = nullptr;
+        small_cap_ = 0;
+      }
+      detail::check(ctx(), nflhip_malloc(ctx(), &small_, bytes), "compact sampler buffer");
+      small_cap_ = bytes;
+    }
+    return small_;
+  }
+  template <class Gx, class G0, class G1>
+  void gaussian_fma(device_batch *out1, Gx const &x, const device_batch &k0, G0 const &e0, const device_batch *k1, G1 const &e1) {
+    typedef detail::lazy<P> lazy_t;
+    detail::sampler &s = detail::sampler::get();
+    const nflhip_gauss *tab[3] = {x.fg_prng->table(ctx()), e0.fg_prng->table(ctx()), out1 ? e1.fg_prng->table(ctx()) : nullptr};
+    const uint64_t amp[3] = {x.amplifier, e0.amplifier, out1 ? e1.amplifier : 0};
+    const int nx = out1 ? 3 : 2;
+    int fmt = NFLHIP_FMT_I8;
+    for (int j = 0; j < nx; ++j) fmt = std::max(fmt, (amp[j] >> 32) ? 99 : lazy_t::small_format(tab[j], uint32_t(amp[j])));
+    if (fmt > NFLHIP_FMT_I32) {   // samples too wide for a compact format: the operator sequence itself
+      const unsigned char fma[] = {0, 1, NFLHIP_EXPR_MUL, 2, NFLHIP_EXPR_ADD};
+      device_batch X(n_, c_->device), E(n_, c_->device), K(n_, c_->device);
+      X.set(x);
+      E.set(e0);
+      X.ntt_pow_phi();
+      E.ntt_pow_phi();
+      const device_batch *kk[2] = {&k0, k1};
+      device_batch *oo[2] = {this, out1};
+      for (int r = 0; r < (out1 ? 2 : 1); ++r) {
+        if (r) {
+          E.set(e1);
+          E.ntt_pow_phi();
+        }
+        const device_batch *key = kk[r];
+        if (key->n_ == 1) {   // (the expression entry takes dense operands: replicate the key)
+          nflhip_operand src = {key->d_, 0, NFLHIP_FMT_WORDS};
+          detail::check(ctx(), nflhip_expand_small_dev(ctx(), K.d_, &src, n_, queue()), "key broadcast");
+          key = &K;
+        }
+        const device_batch *ops[] = {&X, key, &E};
+        oo[r]->assign_program(fma, sizeof(fma), ops, 3);
+      }
+      sync();   // (the temporaries die here)
+      return;
+    }
+    const size_t es = fmt == NFLHIP_FMT_I8 ? 1 : fmt == NFLHIP_FMT_I16 ? 2 : 4, each = (n_ * P::degree * es + 255) / 256 * 256;
+    char *buf = static_cast<char *>(small_buffer(each * size_t(nx)));
+    nflhip_operand xo[3];
+    for (int j = 0; j < nx; ++j) {
+      detail::check(ctx(), nflhip_sample_gauss_small_dev(ctx(), buf + each * size_t(j), fmt, 0, n_, tab[j], amp[j], s.key, s.next++, queue()),
+                    "set(gaussian), compact");
+      xo[j].ptr = buf + each * size_t(j);
+      xo[j].stride = 1;
+      xo[j].format = fmt;
+    }
+    nflhip_operand ka = key_operand(k0);
+    if (out1) {
+      nflhip_operand kb = key_operand(*k1);
+      detail::check(ctx(), nflhip_fwd_fma2_dev(ctx(), d_, out1->d_, &xo[0], &ka, &xo[1], &kb, &xo[2], n_, queue()), "transform + multiply-add");
+    } else {
+      detail::check(ctx(), nflhip_fwd_fma_dev(ctx(), d_, &xo[0], &ka, &xo[1], n_, queue()), "transform + multiply-add");
+    }
+  }
   size_t n_;
   void *d_;
   context_type *c_;
+  void *small_ = nullptr;
+  size_t small_cap_ = 0;
 };
 
 // ---------------------------------------------------------------- batches split over the GPUs of one node

@@ -183,7 +183,8 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_deferred_sema
 
 // the reference's LWE demo with plain poly_p operators (tests/nfllib_demo_main_op.cpp:26-58, 260-332)
 template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *enc_per_s, double *dec_per_s, double *batch_enc_per_s,
-                                                                       double *batch_dec_per_s, size_t *launches, size_t *operations) {
+                                                                       double *batch_dec_per_s, size_t *launches, size_t *operations,
+                                                                       double *fused_enc_per_s, double *fused_dec_per_s) {
   using poly_t = nfl::poly<T, Degree, NbModuli>;
   using poly_p = nfl::poly_p<T, Degree, NbModuli>;
   using G = nfl::gaussian<uint8_t, T, 2>;
@@ -263,6 +264,46 @@ template <class T, size_t Degree, size_t NbModuli> static bool run_lwe(double *e
     DEC.invntt_pow_invphi();
   };
   batch_enc(); batch_dec(); S.sync();
+  {
+    // the same through the batch's fused pipelines (device_batch::assign_gaussian_fma2 / assign_fma_inv): identical words when
+    // the samplers start from the same stream id; keys as ONE polynomial each (stride 0) and as one per element
+    unsigned char key[32];
+    for (int i = 0; i < 32; i++) key[i] = (unsigned char)(7 * i + 3);
+    batch_t S1(1), PKA1(1), PKB1(1), RA2(B), RB2(B), DEC2(B);
+    S1.fill(s);
+    PKA1.fill(pka);
+    PKB1.fill(pkb);
+    nfl::set_sampler_key(key, 1000);
+    batch_enc();
+    batch_dec();
+    nfl::set_sampler_key(key, 1000);
+    RA2.assign_gaussian_fma2(RB2, G(&g_prng), PKA1, G(&g_prng, 2), PKB1, G(&g_prng, 2));
+    DEC2.assign_fma_inv(RA2, S1, RB2, true);
+    CHECK(!RA2.any_differs(RA) && !RB2.any_differs(RB) && !DEC2.any_differs(DEC));
+    nfl::set_sampler_key(key, 1000);
+    RA2.assign_gaussian_fma(G(&g_prng), PKA, G(&g_prng, 2));       // one result, keys per element; e2's stream id is skipped ...
+    CHECK(!RA2.any_differs(RA));
+    DEC2.assign_fma_inv(RA, S, RB, true);
+    CHECK(!DEC2.any_differs(DEC));
+    DEC2.assign_fma_inv(RA, S1, RB, false);                        // ... and the sum: INTT(rb + ra * s)
+    const batch_t *o[] = {&RB, &RA, &S};
+    const unsigned char sum[] = {0, 1, 2, NFLHIP_EXPR_MUL, NFLHIP_EXPR_ADD};
+    RB2.assign_program(sum, sizeof(sum), o, 3);
+    RB2.invntt_pow_invphi();
+    CHECK(!DEC2.any_differs(RB2));
+    auto fused_enc = [&]() { RA2.assign_gaussian_fma2(RB2, G(&g_prng), PKA1, G(&g_prng, 2), PKB1, G(&g_prng, 2)); };
+    auto fused_dec = [&]() { DEC2.assign_fma_inv(RA2, S1, RB2, true); };
+    fused_enc(); fused_dec(); S.sync();
+    auto f0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < 4; k++) fused_enc();
+    S.sync();
+    auto f1 = std::chrono::steady_clock::now();
+    for (int k = 0; k < 4; k++) fused_dec();
+    S.sync();
+    auto f2 = std::chrono::steady_clock::now();
+    *fused_enc_per_s = 4 * B / std::chrono::duration<double>(f1 - f0).count();
+    *fused_dec_per_s = 4 * B / std::chrono::duration<double>(f2 - f1).count();
+  }
   t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < 4; k++) batch_enc();
   S.sync();
@@ -285,20 +326,21 @@ int main() {
     if (!run_deferred_semantics<uint64_t, 4096, 4>()) return 1;
     if (!run_deferred_semantics<uint32_t, 1024, 2>()) return 1;
     if (!run_deferred_semantics<uint64_t, 1024, 1>()) return 1;
-    double e = 0, d = 0, be = 0, bd = 0;
+    double e = 0, d = 0, be = 0, bd = 0, fe = 0, fd = 0, fx = 0, fy = 0;
     size_t nl = 0, no = 0;
-    if (!run_lwe<uint64_t, 4096, 4>(&e, &d, &be, &bd, &nl, &no)) return 1;
+    if (!run_lwe<uint64_t, 4096, 4>(&e, &d, &be, &bd, &nl, &no, &fe, &fd)) return 1;
     // the same loops with every operation launched when it is called (no deferral): what a per-polynomial API costs
     nfl::poly_p<uint64_t, 4096, 4>::synchronize();
     nfl::set_deferred(false);
     double ee = 0, ed = 0, x0 = 0, x1 = 0;
     size_t y0 = 0, y1 = 0;
-    if (!run_lwe<uint64_t, 4096, 4>(&ee, &ed, &x0, &x1, &y0, &y1)) return 1;
+    if (!run_lwe<uint64_t, 4096, 4>(&ee, &ed, &x0, &x1, &y0, &y1, &fx, &fy)) return 1;
     nfl::set_deferred(true);
     std::printf("{\"lwe_u64_4096_4\": {\"poly_p_encryptions_per_s\": %.1f, \"poly_p_decryptions_per_s\": %.1f, "
                 "\"device_batch_encryptions_per_s\": %.1f, \"device_batch_decryptions_per_s\": %.1f, "
+                "\"device_batch_fused_encryptions_per_s\": %.1f, \"device_batch_fused_decryptions_per_s\": %.1f, "
                 "\"poly_p_eager_encryptions_per_s\": %.1f, \"poly_p_eager_decryptions_per_s\": %.1f, "
-                "\"deferred_operations\": %zu, \"launches_they_became\": %zu}}\n", e, d, be, bd, ee, ed, no, nl);
+                "\"deferred_operations\": %zu, \"launches_they_became\": %zu}}\n", e, d, be, bd, fe, fd, ee, ed, no, nl);
     std::printf("all checks passed\n");
     return 0;
   } catch (const std::exception &ex) {
