@@ -290,7 +290,7 @@ def _picker(kind):
 @pytest.mark.parametrize("stem,n,nm,batch,dlog,rlog,pooled,wgs,order", [
     ("polymul_xcd32768", 32768, 1, 8, 0, 3, 0, 40, "round-robin"),  # five workgroups per XCD
     ("polymul_xcd32768", 32768, 2, 5, 0, 2, 0, 8, "highest"),       # two moduli, batch not a power of two, one workgroup per XCD
-    ("polymul_xcd32768", 32768, 1, 8, 1, 1, 0, 24, "random"),       # two scheduling domains per XCD
+    ("polymul_xcd32768", 32768, 1, 16, 1, 1, 0, 24, "random"),      # two scheduling domains per XCD (needs 16 rows)
     # n = 65536 (same generator, 16 block products and radix-16 streaming roles per row): 50 s on the interpreter, so only
     # with NFL_EMU_FULL=1; its three roles run in every suite through test_emulated_u64_three_role_kernel
     pytest.param("polymul_xcd65536", 65536, 1, 8, 0, 1, 0, 16, "random",
