@@ -273,13 +273,13 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   // modulus slot cm = 4 s + 2 h + (e >> 3), digit of y a = e & 7, column k = 8 j + t  ->  digit k - a of Q/p_cm.
   // Slot 31 is the quotient row: the digits of Q itself against the single digit "-floor(S / Q)" (a = 0).
   std::vector<int8_t> bfrag;
-  if (wb == 64 && crt_ok && nm >= NFLHIP_CRT_MFMA_MIN_NM && nm <= 31 && c->shape.crt_L >= 4 && c->shape.crt_L <= 31) {
+  if (wb == 64 && crt_ok && nm >= NFLHIP_CRT_MFMA_MIN_NM && nm <= 32 && c->shape.crt_L >= 4 && c->shape.crt_L <= 31) {
     const size_t ND = 264;
     std::vector<int8_t> dig(32 * ND, 0);
     for (size_t cm = 0; cm < 32; ++cm) {
       Big quot;
       if (cm < nm) big_divrem_u64(Q, P[cm], &quot);
-      else if (cm == 31) quot = Q;
+      else if (cm == 31) quot = Q;   // (with 32 moduli the slot is the 32nd modulus's and the kernel subtracts the quotient itself)
       else continue;
       int carry = 0;
       for (size_t k = 0; k < ND; ++k) {
@@ -296,7 +296,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
         for (int lane = 0; lane < 64; ++lane)
           for (int e = 0; e < 16; ++e) {
             const int cm = 4 * st + 2 * (lane >> 5) + (e >> 3), a = e & 7, k = 8 * (lane & 31) + t;
-            if (k >= a && (cm < 31 || a == 0)) bfrag[(((size_t)st * 8 + t) * 64 + lane) * 16 + e] = dig[cm * ND + (k - a)];
+            if (k >= a && ((size_t)cm < nm || a == 0)) bfrag[(((size_t)st * 8 + t) * 64 + lane) * 16 + e] = dig[cm * ND + (k - a)];
           }
   }
 

@@ -15,7 +15,7 @@
 //   * the reduction mod Q rides along: S / Q = sum_cm y_cm / p_cm EXACTLY, so t = floor(sum_cm y_cm / p_cm - 2^-20) (double
 //     precision, error far below the margin) is floor(S / Q) or one less, and row 31 of the GEMM is "-t times the digits of
 //     Q": the product comes out as S - t Q, in [0, 2Q), and one conditional subtraction of Q is all that is left.
-// GEMM shape per coefficient: K = 8 * 32 (31 moduli at most + the quotient row, zero padded) = 256, N = 256 columns
+// GEMM shape per coefficient: K = 8 * 32 (up to 31 moduli + the quotient row, zero padded; 32 moduli: P3 subtracts t Q) = 256, N = 256 columns
 // (k <= 8 L for L <= 31 words): 65 536 int8 multiply-adds on the matrix cores instead of 5 400 32-bit ones on the VALU.
 //
 // Mapping (one 256-thread workgroup works on 64 consecutive coefficients per iteration; persistent, grid-stride; the next
@@ -51,6 +51,9 @@ static constexpr int kXStride = 65;               // u64 slots per coefficient i
 static constexpr int kStStride = 33;              // u64 slots per coefficient in the result stage: 32 limbs, odd stride
 static constexpr u64 kBias = 0x8080808080808080ull;
 
+// QROW: the quotient row rides in modulus slot 31 (up to 31 moduli); with 32 moduli every slot is taken and P3 subtracts t Q from
+// its 16 positions instead (one multiply-add per position more)
+template <bool QROW>
 __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d, const MC64 *__restrict__ mc,
                                                           const uint4 *__restrict__ bfrag, const u32 *__restrict__ qdig,
                                                           int logn, int nm, int L, size_t ncoef) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
       for (int s = 0; s < 8; ++s) {
         const uint4 av = a_frag[(m * 8 + s) * 64 + lane];
         v4i a = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
-        if (s == 7 && lane >= 32) a[2] = (-tq) & 0xff;
+        if (QROW && s == 7 && lane >= 32) a[2] = (-tq) & 0xff;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[s][tt], acc[tt], 0, 0, 0);
       }
@@ -158,11 +161,17 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
     {
       const int cl = lane & 15, r = lane >> 4, c = 16 * w + cl;
       const long long *xc = xs + c * kXStride + 16 * r;
+      long long tqq = 0;   // 32 moduli: the quotient estimate again (the same sum in the same order as P2's), to be subtracted here
+      if (!QROW) {
+        const double f = ((fpart[c] + fpart[64 + c]) + fpart[128 + c]) + fpart[192 + c];
+        const int t = (int)floor(f - 0x1p-20);
+        tqq = t < 0 ? 0 : t;
+      }
       u32 dg[16];
       long long carry = 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const long long t = xc[k] + carry;
+        const long long t = xc[k] - (QROW ? 0 : tqq * (long long)qs[16 * r + k]) + carry;
         dg[k] = (u32)t;
         carry = t >> 32;
       }
@@ -272,11 +281,11 @@ __global__ __launch_bounds__(256, 2) void k_crt_lift_mfma(u64 *out, const u64 *d
 
 // `bfrag` / `qdig`: DevTables::crt_bfrag (api.hip build_tables; its modulus slot 31 holds the digits of Q itself), row 0 of
 // DevTables::qsh (Q as 32-bit digits, zero padded to 72).  hipErrorNotSupported when the shape has no table (few moduli: the
-// VALU kernels are on the memory system there; 32 moduli: no free slot for the quotient row) or the batch is not a multiple
+// VALU kernels are on the memory system there) or the batch is not a multiple
 // of the tile.
 hipError_t launch_crt_lift_mfma_u64(const Shape &s, const DevTables &t, uint64_t *limbs, const uint64_t *d, size_t batch,
                                     hipStream_t st) {
-  if (s.limb_bits != 64 || !t.crt_bfrag || s.nm > 31 || (batch * s.n) % kMfmaCoef != 0 || s.crt_L < 4 || s.crt_L > 31)
+  if (s.limb_bits != 64 || !t.crt_bfrag || s.nm > 32 || (batch * s.n) % kMfmaCoef != 0 || s.crt_L < 4 || s.crt_L > 31)
     return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
   const size_t ncoef = batch * s.n;
@@ -287,8 +296,12 @@ hipError_t launch_crt_lift_mfma_u64(const Shape &s, const DevTables &t, uint64_t
   }
   size_t blocks = (size_t)cus * 2;
   if (blocks > ncoef / kMfmaCoef) blocks = ncoef / kMfmaCoef;
-  hipLaunchKernelGGL(k_crt_lift_mfma, dim3((unsigned)blocks), dim3(256), 0, st, limbs, d, (const MC64 *)t.mc,
-                     (const uint4 *)t.crt_bfrag, (const u32 *)t.qsh, s.logn, (int)s.nm, (int)s.crt_L, ncoef);
+  if (s.nm < 32)
+    hipLaunchKernelGGL(k_crt_lift_mfma<true>, dim3((unsigned)blocks), dim3(256), 0, st, limbs, d, (const MC64 *)t.mc,
+                       (const uint4 *)t.crt_bfrag, (const u32 *)t.qsh, s.logn, (int)s.nm, (int)s.crt_L, ncoef);
+  else
+    hipLaunchKernelGGL(k_crt_lift_mfma<false>, dim3((unsigned)blocks), dim3(256), 0, st, limbs, d, (const MC64 *)t.mc,
+                       (const uint4 *)t.crt_bfrag, (const u32 *)t.qsh, s.logn, (int)s.nm, (int)s.crt_L, ncoef);
   return hipGetLastError();
 }
 

@@ -110,7 +110,7 @@ def test_the_walk_was_wide():
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_crt_matrix_core_kernels_every_modulus_count_and_width(seed, oracle_factory, engine_factory):
     """GMP::poly2mpz / mpz2poly (gmp.hpp:183-219) on the matrix cores (kernels_crt_mfma.hip): every modulus count they serve
-    (lift 21 .. 31, projection 17 .. 32), every input width of the projection (5 .. 32 words), random residues plus lifted
+    (lift 21 .. 32, projection 17 .. 32), every input width of the projection (5 .. 32 words), random residues plus lifted
     values whose digits are runs of ones / zeros placed at random (the carry / borrow paths between the kernel's parts)."""
     import torch
     rng = np.random.default_rng(seed)

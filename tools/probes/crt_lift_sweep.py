@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from nfllib_amd import Engine
 tag = sys.argv[1] if len(sys.argv) > 1 else "default"
-for nm in (10, 12, 14, 16, 18, 20, 21, 22, 24, 30):
+for nm in (10, 12, 14, 16, 18, 20, 21, 22, 24, 30, 31, 32):
     n, batch = 4096, 1024
     e = Engine(64, n, nm)
     a = e.fill_uniform(e.empty(batch), 1, 0)
