@@ -628,9 +628,9 @@ def test_degrees_beyond_the_baseline_shapes(lb, n, m, batch, oracle_factory, eng
 @pytest.mark.parametrize("n,m,batch", [(256, 21, 3), (64, 22, 1), (128, 25, 2), (32, 29, 2), (256, 31, 1), (64, 30, 5),
                                        (4096, 23, 40), (65536, 30, 2), (64, 20, 2), (64, 32, 1)])
 def test_crt_lift_on_the_matrix_cores(n, m, batch, oracle_factory, engine_factory):
-    """GMP::poly2mpz (gmp.hpp:183-209) with 21 .. 31 62-bit moduli runs as an int8 GEMM (kernels_crt_mfma.hip): extreme
-    residues (X = Q - 1, 0, 1, one residue set), several modulus counts' zero padding, more tiles than workgroups; 20 and 32
-    moduli are the VALU kernels either side of it."""
+    """GMP::poly2mpz (gmp.hpp:183-209) with 21 .. 32 62-bit moduli runs as an int8 GEMM (kernels_crt_mfma.hip): extreme
+    residues (X = Q - 1, 0, 1, one residue set), several modulus counts' zero padding, more tiles than workgroups; 32 moduli
+    take the instantiation without a quotient row, 20 the VALU kernel below the range."""
     o, e = oracle_factory(64, n, m), engine_factory(64, n, m)
     a = o.fill_uniform(batch, SEED, 0)
     P = np.asarray(o.P[:m], dtype=a.dtype)
