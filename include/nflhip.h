@@ -265,7 +265,7 @@ int nflhip_check_range(const nflhip_ctx *ctx, const void *h_data, size_t batch, 
  * project: GMP::mpz2poly gmp.hpp:211-219 / poly::set_mpz gmp.hpp:73-108 --
  *          x(cm,i) = X_i mod p_cm for non-negative X_i given as L_in limbs.
  * Any number of moduli.  With 62-bit moduli the lift runs on the matrix cores (an int8 GEMM over balanced base-256 digits,
- * nfllib_amd/csrc/kernels_crt_mfma.hip) for 21..32 of them, the projection for 17..32 and inputs of 5..32 limbs, when
+ * nfllib_amd/csrc/kernels_crt_mfma.hip) for 21..32 of them, the projection for 17..32 and inputs of 5..64 limbs, when
  * batch * degree is a multiple of 64; register-resident VALU kernels up to 32 moduli otherwise, a limb-serial kernel
  * beyond.  The results do not depend on which kernel ran. */
 int nflhip_crt_lift_dev(nflhip_ctx *ctx, uint64_t *d_limbs, const void *d_data, size_t batch, void *stream);

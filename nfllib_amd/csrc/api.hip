@@ -304,10 +304,11 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   // operand -- K-step s, N-tile t = digit, lane (cm = lane & 31, half h = lane >> 5), byte e: k = 32 s + 16 h + e -- and the
   // per-residue constant 2^18 p + 128 sum_k (256^k mod p) (the input bytes enter as a - 128; the sum is made non-negative)
   std::vector<int8_t> bproj;
-  std::vector<uint64_t> coff;
+  std::vector<uint64_t> coff, c2048;
   if (wb == 64 && c->shape.small_delta && nm >= NFLHIP_CRT_MFMA_PROJ_MIN_NM && nm <= 32) {
     std::vector<int8_t> dig((size_t)32 * 256 * 8, 0);   // [cm][k][digit]
     coff.assign(32 * 2, 0);
+    c2048.assign(32 * 2, 0);
     for (size_t cm = 0; cm < nm; ++cm) {
       const uint64_t p = P[cm];
       uint64_t cur = 1 % p;
@@ -327,6 +328,8 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
       for (int b = 0; b < 8; ++b) off += colsum[b] * ((__int128)1 << (8 * b));
       coff[2 * cm] = (uint64_t)off;
       coff[2 * cm + 1] = (uint64_t)((unsigned __int128)off >> 64);
+      c2048[2 * cm] = powmod_h(2 % p, 2048, p);
+      c2048[2 * cm + 1] = shoup_h(c2048[2 * cm], p, 64);
     }
     bproj.assign((size_t)8 * 8 * 64 * 16, 0);
     for (int st = 0; st < 8; ++st)
@@ -440,11 +443,14 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   c->tabs.crt_bfrag = nullptr;
   c->tabs.crt_bproj = nullptr;
   c->tabs.crt_coff = nullptr;
+  c->tabs.crt_c2048 = nullptr;
   if (!bproj.empty()) {
     HIPCHK(nullptr, hipMalloc(&c->tabs.crt_bproj, bproj.size()));
     HIPCHK(nullptr, hipMemcpy(c->tabs.crt_bproj, bproj.data(), bproj.size(), hipMemcpyHostToDevice));
     HIPCHK(nullptr, hipMalloc((void **)&c->tabs.crt_coff, coff.size() * sizeof(uint64_t)));
     HIPCHK(nullptr, hipMemcpy(c->tabs.crt_coff, coff.data(), coff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMalloc((void **)&c->tabs.crt_c2048, c2048.size() * sizeof(uint64_t)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.crt_c2048, c2048.data(), c2048.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
   if (!bfrag.empty()) {
     HIPCHK(nullptr, hipMalloc(&c->tabs.crt_bfrag, bfrag.size()));
@@ -799,6 +805,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->tabs.crt_bfrag) (void)hipFree(ctx->tabs.crt_bfrag);
   if (ctx->tabs.crt_bproj) (void)hipFree(ctx->tabs.crt_bproj);
   if (ctx->tabs.crt_coff) (void)hipFree(ctx->tabs.crt_coff);
+  if (ctx->tabs.crt_c2048) (void)hipFree(ctx->tabs.crt_c2048);
   if (ctx->tabs.bparts) (void)hipFree(ctx->tabs.bparts);
   if (ctx->tabs.flag) (void)hipFree(ctx->tabs.flag);
   if (ctx->tabs.qhat_w) (void)hipFree(ctx->tabs.qhat_w);

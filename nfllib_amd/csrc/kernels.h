@@ -65,6 +65,7 @@ struct DevTables {
   // CRT lift on the matrix cores (kernels_crt_mfma.hip): 64-bit limbs, many moduli
   void *crt_bfrag;  // [8 K-steps][8 N-tiles][64 lanes][16] int8: balanced base-256 digits of Q/p_cm in B-fragment order, or nullptr
   void *crt_bproj;  // the same for the projection: digit t of 256^k mod p_cm, k = 32 s + 16 (lane >> 5) + byte, cm = lane & 31, or nullptr
+  uint64_t *crt_c2048; // [32][2] 2^2048 mod p_cm and its Shoup companion: how the residue of an input's upper 32 words joins the lower words'
   uint64_t *crt_coff; // [32][2] 2^18 p_cm + 128 sum_k (256^k mod p_cm in those digits), 128 bits: what the projection adds before reducing
 };
 

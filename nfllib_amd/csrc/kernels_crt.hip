@@ -315,7 +315,7 @@ hipError_t launch_crt_project_fast_u64(const Shape &s, const DevTables &t, uint6
   if (s.limb_bits != 64 || !s.small_delta || s.nm > 32) return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
   const size_t ncoef = batch * s.n;
-  if (t.crt_bproj && L_in > 4 && L_in <= 32 && ncoef % 64 == 0) {  // many moduli: the sum is a GEMM (kernels_crt_mfma.hip)
+  if (t.crt_bproj && L_in > 4 && L_in <= 64 && ncoef % 64 == 0) {  // many moduli: the sum is a GEMM (kernels_crt_mfma.hip)
     const hipError_t e = launch_crt_project_mfma_u64(s, t, d, limbs, L_in, batch, st);
     if (e != hipErrorNotSupported) return e;
   }

@@ -322,11 +322,16 @@ hipError_t launch_crt_lift_mfma_u64(const Shape &s, const DevTables &t, uint64_t
 //   P3  thread (c = lane, cm = wave + 4 q): the two halves from LDS, the reduction with wave-uniform constants, a coalesced store.
 static constexpr int kPjHalf = 528 / 16;          // uint4 slots per (M-tile, K-step, lane half): 32 rows + one slot of padding
 
+// NP = 1: inputs of up to 32 words.  NP = 2: up to 64 (what poly::set_mpz meets when it reduces a product of two lifted values):
+// the upper 32 words go through the same GEMM first, their residues wait in LDS, and the lower words' residues take them along
+// as r_lo + r_hi * (2^2048 mod p) -- one more Shoup product per residue.
+template <int NP>
 __global__ __launch_bounds__(256, 2) void k_crt_project_mfma(u64 *d, const u64 *limbs, const MC64 *__restrict__ mc,
                                                              const uint4 *__restrict__ bproj, const u64 *__restrict__ coff,
-                                                             int logn, int nm, int Lin, size_t ncoef) {
+                                                             const u64 *__restrict__ c2048, int logn, int nm, int Lin, size_t ncoef) {
   __shared__ uint4 a_frag[2 * 8 * 2 * kPjHalf];            // 16.5 KiB: [M-tile][K-step][lane half][32 rows + pad] x 16 bytes
   __shared__ long long xs[kMfmaCoef * kXStride];           // 33 KiB: [coefficient][2 cm + half] signed partial sums
+  __shared__ u64 rhi[NP > 1 ? 8 * 256 : 1];                // 16 KiB (NP = 2): the upper words' residues, [q][thread]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int u = w & 1, m = w >> 1;
@@ -342,81 +347,91 @@ __global__ __launch_bounds__(256, 2) void k_crt_project_mfma(u64 *d, const u64 *
   const size_t ngroups = ncoef / kMfmaCoef;
   const size_t nmask = (((size_t)1) << logn) - 1;
   u64 xv[8];
-  auto fetch = [&](size_t grp) {
+  auto fetch = [&](size_t grp, int ps) {   // words 32 ps .. 32 ps + 31 of the tile's coefficients
     int ln = lane;
     asm volatile("" : "+v"(ln));   // (recomputed per tile: see the lift's P4)
-    const int k = ln & 31;
+    const int k = (ln & 31) + 32 * ps;
     const u64 *src = limbs + (grp * (size_t)kMfmaCoef + 16 * w + (ln >> 5)) * (size_t)Lin + k;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) xv[rr] = k < Lin ? src[(size_t)(2 * rr) * (size_t)Lin] : 0;
   };
-  if (blockIdx.x < ngroups) fetch(blockIdx.x);
+  if (blockIdx.x < ngroups) fetch(blockIdx.x, NP - 1);
   for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    // (every lane-dependent offset below is recomputed per tile from an opaque copy of the lane number: hoisted out of the loop
-    //  they are some forty live registers next to the 128 of the B fragments -- see the lift's P4)
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    // ---- P1: word k of coefficient c -> K bytes 8 k .. 8 k + 7 of row c
-    {
-      const int k = ln & 31, s = k >> 2, h = (k >> 1) & 1, e = k & 1;
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int c = 16 * w + 2 * rr + (ln >> 5), mt = c >> 5, row = c & 31;
-        a_words[((((mt * 8 + s) * 2 + h) * kPjHalf) + row) * 2 + e] = xv[rr] ^ kBias;
+    for (int ps = NP - 1; ps >= 0; --ps) {
+      // (every lane-dependent offset below is recomputed per tile from an opaque copy of the lane number: hoisted out of the
+      //  loop they are some forty live registers next to the 128 of the B fragments -- see the lift's P4)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      // ---- P1: word k of coefficient c -> K bytes 8 k .. 8 k + 7 of row c
+      {
+        const int k = ln & 31, s = k >> 2, h = (k >> 1) & 1, e = k & 1;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int c = 16 * w + 2 * rr + (ln >> 5), mt = c >> 5, row = c & 31;
+          a_words[((((mt * 8 + s) * 2 + h) * kPjHalf) + row) * 2 + e] = xv[rr] ^ kBias;
+        }
+        // the next words: this tile's lower half, or the next tile's first pass -- in flight during everything below
+        if (ps > 0) fetch(grp, ps - 1);
+        else if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x, NP - 1);
       }
-      if (grp + gridDim.x < ngroups) fetch(grp + gridDim.x);
-    }
-    __syncthreads();
-    // ---- P2: 32 MFMAs per wave
-    v16i acc[4];
+      __syncthreads();
+      // ---- P2: 32 MFMAs per wave
+      v16i acc[4];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tt][r] = 0;
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const uint4 av = a_frag[((m * 8 + s) * 2 + (ln >> 5)) * kPjHalf + (ln & 31)];
-      const v4i a = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+      for (int s = 0; s < 8; ++s) {
+        const uint4 av = a_frag[((m * 8 + s) * 2 + (ln >> 5)) * kPjHalf + (ln & 31)];
+        const v4i a = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[s][tt], acc[tt], 0, 0, 0);
-    }
-    {
-      const int j = ln & 31, hh = ln >> 5;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int t01 = acc[0][r] + (acc[1][r] << 8), t23 = acc[2][r] + (acc[3][r] << 8);
-        xs[(m * 32 + row) * kXStride + 2 * j + u] = (long long)t01 + ((long long)t23 << 16);
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[s][tt], acc[tt], 0, 0, 0);
       }
-    }
-    __syncthreads();
-    // ---- P3: R = X_0 + X_1 2^32 + 2^18 p, then R mod p
-    {
-      const size_t gid = grp * kMfmaCoef + (size_t)ln;
-      const size_t b = gid >> logn, i = gid & nmask;
-      const long long *xc = xs + ln * kXStride;
+      {
+        const int j = ln & 31, hh = ln >> 5;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int cm = w + 4 * q;
-        if (cm < nm) {
-          const MC64 c = mc[cm];
-          const Mod md = make_mod(c);
-          const unsigned __int128 off = (unsigned __int128)coff[2 * cm] | ((unsigned __int128)coff[2 * cm + 1] << 64);
-          const unsigned __int128 T = (unsigned __int128)((__int128)xc[2 * cm] + ((__int128)xc[2 * cm + 1] << 32)) + off;
-          const u64 r = shoup_acc<true>((u64)(T >> 64), Tw64{c.beta, c.beta_sh}, fold2((u64)T, md), md);
-          d[((b * (size_t)nm + (size_t)cm) << logn) + i] = csub<u64>(fold2(r, md), md.p);
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int t01 = acc[0][r] + (acc[1][r] << 8), t23 = acc[2][r] + (acc[3][r] << 8);
+          xs[(m * 32 + row) * kXStride + 2 * j + u] = (long long)t01 + ((long long)t23 << 16);
         }
       }
+      __syncthreads();
+      // ---- P3: R = X_0 + X_1 2^32 + 2^18 p, then R mod p
+      {
+        const size_t gid = grp * kMfmaCoef + (size_t)ln;
+        const size_t b = gid >> logn, i = gid & nmask;
+        const long long *xc = xs + ln * kXStride;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int cm = w + 4 * q;
+          if (cm < nm) {
+            const MC64 c = mc[cm];
+            const Mod md = make_mod(c);
+            const unsigned __int128 off = (unsigned __int128)coff[2 * cm] | ((unsigned __int128)coff[2 * cm + 1] << 64);
+            const unsigned __int128 T = (unsigned __int128)((__int128)xc[2 * cm] + ((__int128)xc[2 * cm + 1] << 32)) + off;
+            u64 r = fold2(shoup_acc<true>((u64)(T >> 64), Tw64{c.beta, c.beta_sh}, fold2((u64)T, md), md), md);   // < p + 4 delta
+            if (NP > 1 && ps > 0) {
+              rhi[q * 256 + tid] = r;   // (this thread reads it back: no barrier)
+            } else {
+              if (NP > 1) r = fold2(shoup_acc<true>(rhi[q * 256 + tid], Tw64{c2048[2 * cm], c2048[2 * cm + 1]}, r, md), md);
+              d[((b * (size_t)nm + (size_t)cm) << logn) + i] = csub<u64>(r, md.p);
+            }
+          }
+        }
+      }
+      // (a_frag is rewritten after this wave's P3 and was last read before barrier 2; xs is rewritten after the next barrier 1)
     }
-    // (a_frag is rewritten after this wave's P3 and was last read before barrier 2; xs is rewritten after the next barrier 1)
   }
 }
 
-// `bproj` / `coff`: DevTables::crt_bproj / crt_coff (api.hip build_tables).  hipErrorNotSupported when the shape has no table
-// (few moduli), the input is wider than 32 words or the batch is not a multiple of the tile.
+// `bproj` / `coff` / `c2048`: DevTables::crt_bproj / crt_coff / crt_c2048 (api.hip build_tables).  hipErrorNotSupported when the
+// shape has no table (few moduli), the input is wider than 64 words or the batch is not a multiple of the tile.
 hipError_t launch_crt_project_mfma_u64(const Shape &s, const DevTables &t, uint64_t *d, const uint64_t *limbs, size_t L_in,
                                        size_t batch, hipStream_t st) {
-  if (s.limb_bits != 64 || !s.small_delta || !t.crt_bproj || s.nm > 32 || L_in == 0 || L_in > 32 || (batch * s.n) % kMfmaCoef != 0)
+  if (s.limb_bits != 64 || !s.small_delta || !t.crt_bproj || s.nm > 32 || L_in == 0 || L_in > 64 || (batch * s.n) % kMfmaCoef != 0)
     return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
   const size_t ncoef = batch * s.n;
@@ -427,8 +442,12 @@ hipError_t launch_crt_project_mfma_u64(const Shape &s, const DevTables &t, uint6
   }
   size_t blocks = (size_t)cus * 2;
   if (blocks > ncoef / kMfmaCoef) blocks = ncoef / kMfmaCoef;
-  hipLaunchKernelGGL(k_crt_project_mfma, dim3((unsigned)blocks), dim3(256), 0, st, d, limbs, (const MC64 *)t.mc,
-                     (const uint4 *)t.crt_bproj, (const u64 *)t.crt_coff, s.logn, (int)s.nm, (int)L_in, ncoef);
+  if (L_in <= 32)
+    hipLaunchKernelGGL(k_crt_project_mfma<1>, dim3((unsigned)blocks), dim3(256), 0, st, d, limbs, (const MC64 *)t.mc,
+                       (const uint4 *)t.crt_bproj, (const u64 *)t.crt_coff, (const u64 *)t.crt_c2048, s.logn, (int)s.nm, (int)L_in, ncoef);
+  else
+    hipLaunchKernelGGL(k_crt_project_mfma<2>, dim3((unsigned)blocks), dim3(256), 0, st, d, limbs, (const MC64 *)t.mc,
+                       (const uint4 *)t.crt_bproj, (const u64 *)t.crt_coff, (const u64 *)t.crt_c2048, s.logn, (int)s.nm, (int)L_in, ncoef);
   return hipGetLastError();
 }
 

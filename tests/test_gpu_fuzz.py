@@ -110,7 +110,7 @@ def test_the_walk_was_wide():
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_crt_matrix_core_kernels_every_modulus_count_and_width(seed, oracle_factory, engine_factory):
     """GMP::poly2mpz / mpz2poly (gmp.hpp:183-219) on the matrix cores (kernels_crt_mfma.hip): every modulus count they serve
-    (lift 21 .. 32, projection 17 .. 32), every input width of the projection (5 .. 32 words), random residues plus lifted
+    (lift 21 .. 32, projection 17 .. 32), every input width of the projection (5 .. 64 words: one GEMM pass up to 32, two beyond), random residues plus lifted
     values whose digits are runs of ones / zeros placed at random (the carry / borrow paths between the kernel's parts)."""
     import torch
     rng = np.random.default_rng(seed)
@@ -132,7 +132,7 @@ def test_crt_matrix_core_kernels_every_modulus_count_and_width(seed, oracle_fact
         for idx, x in enumerate(adv):
             assert int.from_bytes(got[0, idx].tobytes(), "little") == x
         assert np.array_equal(e.to_host(e.crt_project(limbs)), a), "round trip, %d moduli" % m
-        for lin in range(5, 33):
+        for lin in range(5, 65):
             wide = rng.integers(0, 2**63, size=(1, n, lin), dtype=np.uint64) * np.uint64(2) + rng.integers(
                 0, 2, size=(1, n, lin), dtype=np.uint64)
             wide[0, 0, :] = np.uint64(0xFFFFFFFFFFFFFFFF)

@@ -663,12 +663,12 @@ def test_crt_lift_on_the_matrix_cores(n, m, batch, oracle_factory, engine_factor
     assert int.from_bytes(got[0, 0].tobytes(), "little") == Q - 1
     assert int.from_bytes(got[0, 1].tobytes(), "little") == 0 and int.from_bytes(got[0, 2].tobytes(), "little") == 1
     assert np.array_equal(e.to_host(e.crt_project(limbs)), a)
-    # mpz2poly of wide non-negative integers (tests/poly_mpz.cpp:44-64) is the same GEMM the other way round, 5 .. 32 words
+    # mpz2poly of wide non-negative integers (tests/poly_mpz.cpp:44-64) is the same GEMM the other way round, 5 .. 64 words
     import torch
     rng = np.random.default_rng(1)
     nn = min(n, 512)
     o2 = o if n == nn else oracle_factory(64, nn, m)
-    for lin in (5, e.crt_limbs, 32):
+    for lin in (5, e.crt_limbs, 32, 33, 2 * e.crt_limbs, 64):      # (33 .. 64 words: two GEMM passes)
         wide = rng.integers(0, 2**63, size=(batch, n, lin), dtype=np.uint64) * np.uint64(2) + rng.integers(
             0, 2, size=(batch, n, lin), dtype=np.uint64)
         wide[0, 0, :] = np.uint64(0xFFFFFFFFFFFFFFFF)   # every byte 255: the accumulators' worst case
