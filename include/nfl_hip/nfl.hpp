@@ -478,15 +478,21 @@ template <class T, size_t Degree, size_t NbModuli> struct context {
       for (auto &kv : slabs)
         if (kv.second.bump < kv.second.chunks && (!best || kv.second.chunks - kv.second.bump > best->chunks - best->bump)) best = &kv.second;
       if (!best) {
-        for (auto &kv : slabs) {  // recycle before growing without bound
-          slab &sl = kv.second;
-          while (got < cnt && !sl.free.empty()) {
-            out[got++] = sl.free.back();
-            sl.free.pop_back();
-            ++sl.live;
+        // recycle before growing without bound -- but only when the recycled chunks cover what is still missing: a few
+        // scattered chunks in front of a fresh slab cut a loop's dense result arrays into as many launches
+        size_t recyclable = 0;
+        for (auto &kv : slabs) recyclable += kv.second.free.size();
+        if (recyclable >= cnt - got) {
+          for (auto &kv : slabs) {
+            slab &sl = kv.second;
+            while (got < cnt && !sl.free.empty()) {
+              out[got++] = sl.free.back();
+              sl.free.pop_back();
+              ++sl.live;
+            }
           }
+          return;
         }
-        if (got == cnt) return;
         best = &grow(cnt - got);
       }
       while (got < cnt && best->bump < best->chunks) {
