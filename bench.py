@@ -16,6 +16,7 @@ data-path collective (weak scaling: per-GPU batch fixed).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -601,6 +602,28 @@ def main():
                 extras["lwe"] = lw
             except Exception as ex:   # secondary figure: never takes the bench down
                 extras["lwe"] = {"error": repr(ex)}
+            # ... and the same demo as the reference's callers write it: plain nfl::poly_p operators through the drop-in header
+            # (deferred queue, transform fusion) and nfl::device_batch -- tests/cpp/resident_main.cpp, u64/4096/4, 16 384 iterations
+            if (n, nm) == (4096, 4) and isinstance(extras.get("lwe"), dict) and "error" not in extras["lwe"]:
+                try:
+                    exe = os.path.join(ROOT, "tests", "cpp", "resident_test")
+                    if not os.path.exists(exe):
+                        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "resident_test"], check=True, timeout=300,
+                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    torch.cuda.synchronize()
+                    r = subprocess.run([exe], capture_output=True, text=True, timeout=240, env=dict(os.environ, NFL_LWE_REPS="16384"))
+                    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    if r.returncode != 0 or not line:
+                        raise RuntimeError("resident_test rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+                    cpp = json.loads(line[0])["lwe_u64_4096_4"]
+                    extras["lwe"]["cpp_header"] = {k: cpp[k] for k in (
+                        "poly_p_encryptions_per_s", "poly_p_decryptions_per_s", "device_batch_encryptions_per_s", "device_batch_decryptions_per_s",
+                        "device_batch_fused_encryptions_per_s", "device_batch_fused_decryptions_per_s", "poly_p_eager_encryptions_per_s",
+                        "poly_p_eager_decryptions_per_s", "deferred_operations", "launches_they_became") if k in cpp}
+                    extras["lwe"]["cpp_header"]["what"] = ("tests/cpp/resident_test, 16 384 iterations: the demo written with nfl::poly_p operators (deferred queue) "
+                                                           "and on nfl::device_batch (operator by operator / its fused methods); all checks passed")
+                except Exception as ex:
+                    extras["lwe"]["cpp_header"] = {"error": repr(ex)}
         # the other single-GPU BASELINE configs, timed inside this same run (driver-visible, not builder-only): configs[2]
         # (C) and configs[4] (E: "CRT lift + poly-mul"); the headline's own tensors are released first
         if args.workload == "B" and not args.no_side_configs:

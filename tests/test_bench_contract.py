@@ -133,6 +133,9 @@ def test_headline_line_carries_sustained_independent_secondary_and_side_configs(
     assert "error" not in lwe and lwe["same_ciphertexts"] is True and lwe["fused"]["decrypts_to_zero"] is True
     assert lwe["fused"]["encryptions_per_s"] > 1.3 * lwe["unfused"]["encryptions_per_s"]
     assert lwe["fused"]["decryptions_per_s"] > 1.3 * lwe["unfused"]["decryptions_per_s"]
+    hdr = lwe["cpp_header"]      # the same demo through the drop-in header: plain poly_p operators and device_batch's fused methods
+    assert "error" not in hdr and hdr["poly_p_encryptions_per_s"] > 20 * hdr["poly_p_eager_encryptions_per_s"]
+    assert hdr["device_batch_fused_encryptions_per_s"] > 1.3 * hdr["device_batch_encryptions_per_s"]
     cfg = d["extras"]["configs"]
     for wl in ("C", "E"):
         c = cfg[wl]
