@@ -39,7 +39,7 @@ def run(args):
     from nfllib_amd._lib import FMT_I8
     EXPR_ADD, EXPR_SUB, EXPR_MUL = 0x10, 0x11, 0x12                 # NFLHIP_EXPR_* (include/nflhip.h)
 
-    e = Engine(64, args.degree, args.nmoduli)
+    e = Engine(getattr(args, "limb_bits", 64), args.degree, args.nmoduli)
     if args.grid:
         from nfllib_amd import _lib
         _lib.lib.nflhip_debug_fused_grid(args.grid)
@@ -104,7 +104,7 @@ def run(args):
     bits = np.where(v < P[0] // 2, v % 2, 1 - v % 2)
     ok = bool((bits == 0).all())
     noise = np.where(v < P[0] // 2, v, v - P[0]).astype(np.float64)
-    out = {"demo": "LWE-like symmetric encryption of 0 (tests/nfllib_demo_main_op.cpp)", "plan": args.plan, "grid": args.grid, "degree": args.degree,
+    out = {"demo": "LWE-like symmetric encryption of 0 (tests/nfllib_demo_main_op.cpp)", "plan": args.plan, "grid": args.grid, "limb_bits": getattr(args, "limb_bits", 64), "degree": args.degree,
            "nmoduli": args.nmoduli, "batch": B, "encrypt_us_per_ciphertext": round(t_enc / B * 1e6, 4),
            "decrypt_us_per_ciphertext": round(t_dec / B * 1e6, 4), "encryptions_per_s": round(B / t_enc, 1),
            "decryptions_per_s": round(B / t_dec, 1), "decrypts_to_zero": ok,
@@ -144,6 +144,7 @@ def measure_traffic(args, launches):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--limb-bits", type=int, default=64, choices=(16, 32, 64), dest="limb_bits")
     ap.add_argument("--degree", type=int, default=4096)
     ap.add_argument("--nmoduli", type=int, default=4)
     ap.add_argument("--batch", type=int, default=4096)
