@@ -354,6 +354,7 @@ enum AsmKind {
   kAsmFused8kEnc2, kAsmFused8kFmaFwd, kAsmFused8kFmsInv, kAsmFused8kFmaInv,      // transform-fused pipelines, rows of 8192 words (build_fused_rows)
   kAsmFused16kEnc2, kAsmFused16kFmaFwd, kAsmFused16kFmsInv, kAsmFused16kFmaInv,  // ... of 16384 words
   kAsmFusedEnc2R, kAsmFusedFmaFwdR, kAsmFusedFmsInvR, kAsmFusedFmaInvR,  // ... of 4096 words on the ring-mode map (128 VGPRs, four workgroups per CU)
+  kAsmFused32kFmsInv, kAsmFused32kFmaInv,                            // the inverse pipelines of a 32768-word row (build_row32k fms_inv / fma_inv)
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -377,7 +378,9 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul_pipe65536ntb_asm",
     "nflhip_fused_enc2_8192_asm", "nflhip_fused_fma_fwd8192_asm", "nflhip_fused_fms_inv8192_asm", "nflhip_fused_fma_inv8192_asm",
     "nflhip_fused_enc2_16384_asm", "nflhip_fused_fma_fwd16384_asm", "nflhip_fused_fms_inv16384_asm", "nflhip_fused_fma_inv16384_asm",
-    "nflhip_fused_enc2_4096r_asm", "nflhip_fused_fma_fwd4096r_asm", "nflhip_fused_fms_inv4096r_asm", "nflhip_fused_fma_inv4096r_asm"};
+    "nflhip_fused_enc2_4096r_asm", "nflhip_fused_fma_fwd4096r_asm", "nflhip_fused_fms_inv4096r_asm", "nflhip_fused_fma_inv4096r_asm",
+    "nflhip_fused_fms_inv32768_asm", "nflhip_fused_fma_inv32768_asm",
+};
 struct AsmKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kAsmCount] = {};
@@ -464,10 +467,28 @@ extern "C" void nflhip_debug_fused_grid(int mode) { g_fused_grid.store(mode); } 
 hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, uint64_t *out0, uint64_t *out1,
                                 const void *const *x, const unsigned *xstride, const int *xfmt, const void *const *k,
                                 const unsigned *kstride, size_t batch, hipStream_t st) {
-  if (s.limb_bits != 64 || s.logn < kLogN || s.logn > kLogN + 2 || s.compiled_only || !s.small_delta || s.nm > 65535 || kind < 0 || kind > 3)
+  if (s.limb_bits != 64 || s.logn < kLogN || s.logn > kLogN + 3 || s.compiled_only || !s.small_delta || s.nm > 65535 || kind < 0 || kind > 3)
     return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
   if (batch > 0x7fffffffull) return hipErrorInvalidValue;
+  if (s.logn == kLogN + 3) {
+    // rows of 32768 words: the inverse pipelines only (one operand register-resident, b and the key streamed through the idle
+    // twiddle ring: build_row32k), dense a / b, the key one polynomial for the batch or one per element
+    if (kind < 2 || xstride[0] != 1 || xstride[1] != 1 || kstride[0] > 1 || xfmt[0] || xfmt[1]) return hipErrorNotSupported;
+    hipFunction_t fn32 = asm_fn(kind == 2 ? kAsmFused32kFmsInv : kAsmFused32kFmaInv);
+    if (!fn32) return hipErrorNotSupported;
+    struct {
+      void *c;
+      const void *a, *b, *psi, *mc;
+      int nm, logn;
+      const void *k;
+      int kstride, pad;
+    } a32 = {out0, x[0], x[1], PSI_LM(t), t.mc, (int)s.nm, s.logn, k[0], (int)kstride[0], 0};
+    static_assert(sizeof(a32) == 64, "kernarg layout of nflhip_fused_*_inv32768_asm (ARGS_STD + key pointer + stride flag)");
+    size_t size32 = 60;
+    void *extra32[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a32, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size32, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(fn32, (unsigned)batch, (unsigned)s.nm, 1, 1024, 1, 1, 0, st, nullptr, extra32);
+  }
   // rows of 4096 words: 256 threads on the pair-mode map; 8192 / 16384: the row-resident ring-mode map, 512 / 1024 threads,
   // lane-major twiddle copy
   const int rows_log = s.logn - kLogN;

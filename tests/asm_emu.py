@@ -1083,7 +1083,7 @@ def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magi
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16, grid_x=None):
+def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16, grid_x=None, key=None):
     """the 64-bit block kernels of tools/gen_polymul_asm.py (kernarg: dst, a, b, psi, mc, nm, logn[, count]; grid =
     (blocks of the batch, nm); 2^block_log words per workgroup, 16 per thread).  count (the two-rows-per-workgroup
     transforms) = number of polynomials"""
@@ -1097,6 +1097,9 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     kernarg = struct.pack("<5Q3i", pc, pa, pb, ppsi, pmc, nm, logn, count if count is not None else 0)
     if grid_x is not None:   # persistent row kernels: workgroup (x, cm) of a (grid_x, nm) grid walks polynomials x, x + grid_x, ...
         kernarg = struct.pack("<5Q4i", pc, pa, pb, ppsi, pmc, nm, logn, batch, grid_x)
+    if key is not None:      # the fused inverse kinds of build_row32k: a third input row, one polynomial (stride 0) or one per element
+        pk = mem.add(key.copy())
+        kernarg = struct.pack("<5Q2iQi", pc, pa, pb, ppsi, pmc, nm, logn, pk, 0 if key.shape[0] == 1 else 1)
     with open(asm_path) as f:
         text = f.read()
     lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))

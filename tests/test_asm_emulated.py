@@ -244,6 +244,22 @@ def test_emulated_u64_register_resident_32768_word_rows(nm, batch, generated, or
     assert np.array_equal(run("polymul_ntt32768s", a, scratch), o.polymul(a, b))
 
 
+@pytest.mark.parametrize("nm,batch,shared_key,subtract", [(1, 1, True, True), (2, 2, False, False)])
+def test_emulated_u64_fused_inverse_pipeline_of_32768_word_rows(nm, batch, shared_key, subtract, generated, oracle_factory):
+    """n = 32768: INTT(b - a k) / INTT(b + a k) in ONE register-resident kernel (the decryption of the reference's demo at its
+    largest test configuration, tests/nfllib_demo_main_op.cpp:51-57): b and the key stream through the idle twiddle ring"""
+    n = 32768
+    o = oracle_factory(64, n, nm)
+    prm, a, b = operands(o, 64, n, nm, batch, 23)
+    _, k, _ = operands(o, 64, n, nm, 1 if shared_key else batch, 29)
+    K = np.ascontiguousarray(np.broadcast_to(k, a.shape)) if shared_key else k
+    prod = o.pointwise(2, a, K)
+    want = o.intt(o.pointwise(1 if subtract else 0, b, prod))
+    got = asm_emu.run_block_kernel(generated("fused_fms_inv32768" if subtract else "fused_fma_inv32768"), n, nm, prm, a, b, 15,
+                                   words_per_thread=32, key=k)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("nt", ["nt"])
 @pytest.mark.parametrize("nm,batch", [(1, 3), (2, 2)])
 def test_emulated_u64_two_rows_per_workgroup_transforms(nt, nm, batch, generated, oracle_factory):

@@ -6,7 +6,7 @@ decrypt() bodies (reference tests/nfllib_demo_main_op.cpp:26-58) as ONE device p
   * the context created under NFLHIP_VARIANT=hipcc, which composes the same result from the compiled kernels,
 
 bit for bit.  u64 / 4096, 8192 and 16384 run the generated gfx950 kernels (tools/gen_polymul_asm.py build_fused /
-build_fused_rows); every other shape the composed plan behind the same entry points.
+build_fused_rows), u64 / 32768 the inverse pipelines' (build_row32k); every other shape the composed plan behind the same entry points.
 """
 import os
 
@@ -109,6 +109,10 @@ def test_multiply_subtract_inverse_pipeline(lb, n, nm, engine_factory, compiled_
         alias = db.clone()
         e.fma_inv(da, ds, alias, subtract=True, out=alias)
         assert torch.equal(alias, got)
+        kk = _words(o, batch, 7, 1)                                   # a key per element (stride 1), result over the first operand
+        alias_a = da.clone()
+        e.fma_inv(alias_a, e.to_device(kk), db, subtract=False, out=alias_a)
+        assert np.array_equal(e.to_host(alias_a), o.intt(o.pointwise(0, b, o.pointwise(2, a, kk))))
 
 
 @pytest.mark.parametrize("lb,n,nm", [(64, 4096, 4), (64, 1024, 2), (32, 1024, 1)])

@@ -990,7 +990,7 @@ def configure(mode, groups=4):
         g.update(V_ZERO=g["V_T"][0] + 15)
 
 
-def prologue16k(em, vm, stop=None, kind="polymul"):
+def prologue16k(em, vm, stop=None, kind="polymul", key_row=False):
     """1024 threads; v0 = tid on entry.  Leaves V_TID = tid & 255 (the thread's index inside its sub-group),
     V_OFF8 = tid*8, the LDS addresses of the sub-group's slab, all pass constants, and the row loads issued."""
     R = em.raw
@@ -1043,6 +1043,22 @@ def prologue16k(em, vm, stop=None, kind="polymul"):
     for base, row in ((6, 16), (8, 18), (4, 20)):
         R("s_add_u32 s%d, s%d, s42" % (row, base))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    if key_row:
+        # a third input row (the fused inverse kinds of build_row32k): its base at kernarg 0x30, and at 0x38 whether it advances
+        # with the batch (1) or is ONE polynomial for every element (0: a key) -> s[98:99]
+        R("s_load_dwordx2 s[98:99], s[0:1], 0x30")
+        R("s_load_dword s100, s[0:1], 0x38")
+        R("s_lshr_b32 s42, s2, s86")                     # poly
+        R("s_waitcnt lgkmcnt(0)")
+        R("s_mul_i32 s42, s42, s100")                    # ... or 0
+        R("s_mul_i32 s42, s42, s14")
+        R("s_add_u32 s42, s42, s3")                      # row
+        R("s_lshl_b32 s42, s42, s86")
+        R("s_add_u32 s42, s42, s87")                     # block index
+        R("s_lshr_b32 s43, s42, %d" % (32 - 15 - ROW_LG,))
+        R("s_lshl_b32 s42, s42, %d" % (15 + ROW_LG,))
+        R("s_add_u32 s98, s98, s42")
+        R("s_addc_u32 s99, s99, s43")
     if kind == "fwd2":
         # the second polynomial (same modulus: nm rows further), or the first one again for the odd one out at the end of
         # the batch (transformed twice, stored twice to the same place): source s[18:19], destination s[96:97]
@@ -1822,7 +1838,8 @@ def build_row32k(kind="fwd"):
         return load
     passes["Ba"], passes["Bb"] = bprime_loader(0), bprime_loader(4)
 
-    has_fwd, has_inv = kind != "inv", kind != "fwd"
+    fused_inv = kind in ("fms_inv", "fma_inv")       # INTT(b - a k) / INTT(b + a k): a at S_AROW, b at S_BROW, the key row at s[98:99]
+    has_fwd, has_inv = kind != "inv" and not fused_inv, kind != "fwd"
     uses = []
     if has_fwd:
         uses += [("F0", s_, g) for s_ in range(3) for g in range(1 << s_)]
@@ -1838,7 +1855,7 @@ def build_row32k(kind="fwd"):
                 uses += [(name + "ab"[f], s_, g) for s_ in (3, 2, 1, 0) for g in range(1 << s_)]
         uses += [("I0", s_, g) for s_ in (2, 1, 0) for g in range(1 << s_)]
     ring = Ring(em, vm, RING_SLOTS, uses, passes)
-    prologue16k(em, vm, None, "none")
+    prologue16k(em, vm, None, "none", key_row=fused_inv)
     AX = T(0, 0)   # exchange address scratch (the butterfly temporaries are idle during exchanges)
 
     def block_base(srow, boff):                           # s[86:87] = first word of block q + boff of the row at srow
@@ -1868,6 +1885,22 @@ def build_row32k(kind="fwd"):
                 if j == 7:
                     R("s_add_u32 s86, s86, 0x1000")
                     R("s_addc_u32 s87, s87, 0")
+    if fused_inv:
+        em.comment("a <- fold(b -+ a k) word by word, in the load layout (the operation is element-wise): b and the key stream through"
+                   " the twiddle ring's registers, eight words of each at a time, before the ring is primed")
+        for f, (base, boff) in enumerate(FILES):
+            for half in range(2):
+                g_, _ = lane_contig_setup(em)
+                seq = None
+                for srow, dst0 in ((S_BROW, V_TW), ("s[98:99]", V_TW + 16)):
+                    block_base(srow, boff)
+                    if half:
+                        R("s_add_u32 s86, s86, 0x1000")
+                        R("s_addc_u32 s87, s87, 0")
+                    for jj in range(8):
+                        seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d%s" % (vp(dst0 + 2 * jj), g_, jj * 512, " nt" if srow == S_BROW else ""))
+                vm.wait(seq)
+                run_pairs(em, [fms_job(base + 2 * (8 * half + jj), V_TW + 16 + 2 * jj, V_TW + 2 * jj, kind == "fms_inv") for jj in range(8)])
     n_row_loads = vm.issued
     ring.prime()
 
@@ -4171,6 +4204,12 @@ def main():
     for kind, stem in (("fwd", "ntt_fwd32768"), ("inv", "ntt_inv32768"), ("polymul_ntt", "polymul_ntt32768"),
                        ("fwd_s", "ntt_fwd32768s"), ("polymul_s", "polymul_ntt32768s")):
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind))
+    # ... and the fused inverse pipelines of such a row: INTT(b -+ a k), the key row's base and stride flag behind the standard arguments
+    g.update(NEXT_SGPR=102)
+    for kind in ("fms_inv", "fma_inv"):
+        emit_file(os.path.join(outdir, "fused_%s32768_gfx950.s" % kind), "nflhip_fused_%s32768_asm" % kind, build_row32k(kind),
+                  args=ARGS_STD + [("ptr", 48), ("i32", 56)])
+    g.update(NEXT_SGPR=98)
     configure("ring", 4)
     if os.environ.get("NFL_DEBUG16K"):   # checkpoint variants for bisecting a fault: kernel ends after phase n
         kind = os.environ["NFL_DEBUG16K"]
