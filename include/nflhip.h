@@ -210,7 +210,8 @@ int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const vo
  * below every modulus) -- what the samplers produce before they spread a value over the moduli (core.hpp:230-277); see
  * nflhip_sample_gauss_small_dev.  k operands and the operands of nflhip_fma_inv_dev are words in NTT form (canonical,
  * ops.hpp:131,211).  Results are dense; a result may alias a dense input of the same call.  u64 limbs at degree 4096,
- * 8192 and 16384 run one generated gfx950 kernel per call (at degree 32768 nflhip_fma_inv_dev does, for dense a / b); every other shape composes the same result from the plain kernels through
+ * 8192 and 16384 run one generated gfx950 kernel per call (at degree 32768 nflhip_fma_inv_dev does for dense a / b, and the forward
+ * entries run three for int8 polynomials with keys of stride 0); every other shape composes the same result from the plain kernels through
  * the context's scratch (calls on different streams of one context are then ordered by events, as for nflhip_polymul_dev). */
 #define NFLHIP_FMT_WORDS 0
 #define NFLHIP_FMT_I8 1
@@ -228,8 +229,9 @@ int nflhip_fwd_fma2_dev(nflhip_ctx *ctx, void *d_out0, void *d_out1, const nflhi
                         void *stream);
 int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, const nflhip_operand *k,
                        const nflhip_operand *b, int subtract, size_t batch, void *stream);
-/* 1 when the three entries above run as ONE generated kernel each on this context (u64 limbs, degree 4096 / 8192 / 16384,
- * the default kernel variant), 0 when they compose the result from the plain kernels: what a caller that can choose between its own
+/* 1 when the three entries above run as generated kernels on this context (u64 limbs, the default kernel variant: ONE kernel each
+ * at degree 4096 / 8192 / 16384; at degree 32768 one kernel for nflhip_fma_inv_dev and, for int8 polynomials with keys shared by the
+ * batch, one per noise polynomial + one for the results), 0 when they compose the result from the plain kernels: what a caller that can choose between its own
  * operator sequence and these entries asks (the header's deferred queue only rewrites sequences when it gains a pass) */
 int nflhip_has_fused_kernels(const nflhip_ctx *ctx);
 /* compact polynomial(s) -> residue words: d_data[b][cm][i] = v < 0 ? p_cm + v : v, v = element i of src's polynomial

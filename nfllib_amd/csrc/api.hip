@@ -1105,6 +1105,28 @@ static int fused_fwd_composed(nflhip_ctx *ctx, void *out0, void *out1, const nfl
     for (int j = 0; j < 2; ++j) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[j], 0));
   void *s0 = ctx->scratch, *s1 = (char *)ctx->scratch + bytes;
   static const unsigned char prog[5] = {0, 1, NFLHIP_EXPR_MUL, 2, NFLHIP_EXPR_ADD};
+  // rows of 32768 words with int8 polynomials and keys shared by the batch (the LWE demo at the reference's largest configuration):
+  // the noise polynomials go from their bytes straight to NTT words in the scratch, then ONE kernel transforms x in registers and
+  // writes X k + e' for both results -- 6 polynomial passes over HBM instead of 17
+  if (ctx->shape.limb_bits == 64 && ctx->shape.logn == 15 && x->format == NFLHIP_FMT_I8 && e0->format == NFLHIP_FMT_I8 &&
+      (!out1 || e1->format == NFLHIP_FMT_I8) && x->stride == 1 && e0->stride == 1 && (!out1 || e1->stride == 1) && k0->stride == 0 &&
+      (!out1 || k1->stride == 0)) {
+    hipError_t e5 = launch_row32k_fwd_i8_u64(ctx->shape, ctx->tabs, (uint64_t *)s0, e0->ptr, batch, st);
+    if (e5 == hipSuccess && out1) e5 = launch_row32k_fwd_i8_u64(ctx->shape, ctx->tabs, (uint64_t *)s1, e1->ptr, batch, st);
+    if (e5 == hipSuccess)
+      e5 = launch_row32k_fwd_fma_i8_u64(ctx->shape, ctx->tabs, (uint64_t *)out0, (uint64_t *)out1, x->ptr, (const uint64_t *)k0->ptr,
+                                        (const uint64_t *)s0, out1 ? (const uint64_t *)k1->ptr : nullptr, (const uint64_t *)s1, batch, st);
+    if (e5 != hipErrorNotSupported) {
+      if (e5 != hipSuccess) return hipfail(ctx, e5, "fwd_fma: 32768-word row kernels");
+      if (!cap) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
+        ctx->ev_scratch_valid = true;
+        for (int j = 0; j < 2; ++j)
+          if (ctx->aux[j]) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[j], ctx->ev_scratch, 0));
+      }
+      return NFLHIP_OK;
+    }
+  }
   hipError_t e = expand_any(ctx, s0, x, batch, st);
   if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
   rc = nflhip_ntt_fwd_dev(ctx, s0, batch, st);
@@ -1198,7 +1220,7 @@ int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, co
 }
 
 int nflhip_has_fused_kernels(const nflhip_ctx *ctx) {
-  return ctx && ctx->shape.limb_bits == 64 && ctx->shape.logn >= 12 && ctx->shape.logn <= 14 && !ctx->shape.compiled_only && ctx->shape.small_delta &&
+  return ctx && ctx->shape.limb_bits == 64 && ctx->shape.logn >= 12 && ctx->shape.logn <= 15 && !ctx->shape.compiled_only && ctx->shape.small_delta &&
          ctx->shape.nm <= 65535 && !ctx->cyclic;
 }
 

@@ -138,6 +138,11 @@ hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const
 // transform-fused pipelines at n = 4096, 64-bit limbs (tools/gen_polymul_asm.py build_fused): kind 0 enc2 | 1 fma_fwd |
 // 2 fms_inv | 3 fma_inv; x: up to three operands with their formats (forward kinds) and strides, k: key rows with strides.
 // hipErrorNotSupported for other shapes / the compiled-only variant (api.hip composes the same result from the plain kernels)
+// rows of 32768 words from a compact (int8) Gaussian polynomial: its forward transform, and NTT(x) k0 + e0' [, NTT(x) k1 + e1'] (e' words)
+hipError_t launch_row32k_fwd_i8_u64(const Shape &s, const DevTables &t, uint64_t *dst, const void *x8, size_t batch, hipStream_t st);
+hipError_t launch_row32k_fwd_fma_i8_u64(const Shape &s, const DevTables &t, uint64_t *out0, uint64_t *out1, const void *x8,
+                                        const uint64_t *k0, const uint64_t *e0p, const uint64_t *k1, const uint64_t *e1p, size_t batch,
+                                        hipStream_t st);
 hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, uint64_t *out0, uint64_t *out1,
                                 const void *const *x, const unsigned *xstride, const int *xfmt, const void *const *k,
                                 const unsigned *kstride, size_t batch, hipStream_t st);

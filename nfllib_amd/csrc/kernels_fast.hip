@@ -355,6 +355,7 @@ enum AsmKind {
   kAsmFused16kEnc2, kAsmFused16kFmaFwd, kAsmFused16kFmsInv, kAsmFused16kFmaInv,  // ... of 16384 words
   kAsmFusedEnc2R, kAsmFusedFmaFwdR, kAsmFusedFmsInvR, kAsmFusedFmaInvR,  // ... of 4096 words on the ring-mode map (128 VGPRs, four workgroups per CU)
   kAsmFused32kFmsInv, kAsmFused32kFmaInv,                            // the inverse pipelines of a 32768-word row (build_row32k fms_inv / fma_inv)
+  kAsmFwd32kI8, kAsmFused32kFmaFwdI8, kAsmFused32kEnc2I8,            // ... its forward transform / forward pipelines from a compact (int8) polynomial
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -380,6 +381,7 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_fused_enc2_16384_asm", "nflhip_fused_fma_fwd16384_asm", "nflhip_fused_fms_inv16384_asm", "nflhip_fused_fma_inv16384_asm",
     "nflhip_fused_enc2_4096r_asm", "nflhip_fused_fma_fwd4096r_asm", "nflhip_fused_fms_inv4096r_asm", "nflhip_fused_fma_inv4096r_asm",
     "nflhip_fused_fms_inv32768_asm", "nflhip_fused_fma_inv32768_asm",
+    "nflhip_ntt_fwd32768i8_asm", "nflhip_fused_fma_fwd32768i8_asm", "nflhip_fused_enc2_32768i8_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -540,6 +542,45 @@ hipError_t launch_fused_asm_u64(const Shape &s, const DevTables &t, int kind, ui
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   if (remap) return hipModuleLaunchKernel(fn, (unsigned)wgs, 1, 1, (unsigned)(kThreads << rows_log), 1, 1, 0, st, nullptr, extra);
   return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, (unsigned)(kThreads << rows_log), 1, 1, 0, st, nullptr, extra);
+}
+
+// rows of 32768 words, forward side (tools/gen_polymul_asm.py build_row32k fwd_i8 / fma_fwd_i8 / enc2_i8): a compact Gaussian
+// polynomial (one signed byte per coefficient) -> the NTT words of every modulus; and out0 = NTT(x) k0 + e0' [, out1 = NTT(x) k1 +
+// e1'] with x compact, the keys one polynomial each (NTT form) and e' ALREADY transformed words (what the first kernel wrote)
+hipError_t launch_row32k_fwd_i8_u64(const Shape &s, const DevTables &t, uint64_t *dst, const void *x8, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn != kLogN + 3 || s.compiled_only || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+  if (batch == 0) return hipSuccess;
+  if (batch > 0x7fffffffull) return hipErrorInvalidValue;
+  hipFunction_t fn = asm_fn(kAsmFwd32kI8);
+  if (!fn) return hipErrorNotSupported;
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    int nm, logn;
+  } args = {dst, x8, nullptr, PSI_LM(t), t.mc, (int)s.nm, s.logn};
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, 1024, 1, 1, 0, st, nullptr, extra);
+}
+hipError_t launch_row32k_fwd_fma_i8_u64(const Shape &s, const DevTables &t, uint64_t *out0, uint64_t *out1, const void *x8,
+                                        const uint64_t *k0, const uint64_t *e0p, const uint64_t *k1, const uint64_t *e1p, size_t batch,
+                                        hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn != kLogN + 3 || s.compiled_only || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+  if (batch == 0) return hipSuccess;
+  if (batch > 0x7fffffffull) return hipErrorInvalidValue;
+  hipFunction_t fn = asm_fn(out1 ? kAsmFused32kEnc2I8 : kAsmFused32kFmaFwdI8);
+  if (!fn) return hipErrorNotSupported;
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    int nm, logn;
+    const void *k0, *k1, *e1p;
+    void *out1;
+  } args = {out0, x8, e0p, PSI_LM(t), t.mc, (int)s.nm, s.logn, k0, out1 ? k1 : k0, out1 ? e1p : e0p, out1 ? out1 : out0};
+  static_assert(sizeof(args) == 80, "kernarg layout of nflhip_fused_{fma_fwd,enc2_}32768i8_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)batch, (unsigned)s.nm, 1, 1024, 1, 1, 0, st, nullptr, extra);
 }
 
 // n = 65536: one launch of the three-role kernel (tools/gen_polymul_asm.py build_pipe): fused block products of `cnt_v`

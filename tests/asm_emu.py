@@ -512,6 +512,8 @@ def _sload(n):
             w.mem.cached_read(w.mem.k1, range(addr >> 7, ((addr + 4 * n - 1) >> 7) + 1), vector=False)
         data = np.frombuffer(w.mem.read(addr, 4 * n), dtype=np.uint32)
         lo = ops[0][1]
+        if lo % min(n, 4):   # (the assembler rejects it too: destination groups of 2 are even, of 4 and more multiples of 4)
+            raise RuntimeError("s_load_dwordx%d into s%d: misaligned destination" % (n, lo))
         w.def_s(lo, n)
         for k in range(n):
             w.s[lo + k] = int(data[k])
@@ -1083,7 +1085,7 @@ def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magi
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16, grid_x=None, key=None):
+def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16, grid_x=None, key=None, compact=None):
     """the 64-bit block kernels of tools/gen_polymul_asm.py (kernarg: dst, a, b, psi, mc, nm, logn[, count]; grid =
     (blocks of the batch, nm); 2^block_log words per workgroup, 16 per thread).  count (the two-rows-per-workgroup
     transforms) = number of polynomials"""
@@ -1092,6 +1094,8 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     psi, mc = device_tables(64, n, nm, prm, lane_major=block_log >= 13)   # (the ring-mode kernels: tw_base_lm)
     c = np.zeros_like(a)
     pa, pb, pc, ppsi, pmc = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(psi), mem.add(mc)
+    if compact is not None:   # operand a as one signed byte per coefficient, shared by the moduli: (batch, n) int8
+        pa = mem.add(compact.copy())
     logn = n.bit_length() - 1
     batch = a.shape[0]
     kernarg = struct.pack("<5Q3i", pc, pa, pb, ppsi, pmc, nm, logn, count if count is not None else 0)
@@ -1109,6 +1113,31 @@ def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_pe
     run_kernel(text, mem, kernarg, (gx, nm), lds, waves_per_wg=(1 << block_log) // words_per_thread // 64)
     out, _ = mem.find(pc, c.nbytes)
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
+
+
+def run_row32k_forward_pipeline(asm_path, nm, prm, x8, k0, e0p, k1=None, e1p=None):
+    """nflhip_fused_{fma_fwd,enc2_}32768i8_asm (build_row32k): x8 (batch, n) int8; k0 / k1 (1, nm, n) key rows in NTT form; e0p / e1p
+    (batch, nm, n) noise rows in NTT form -> out0 [, out1] = NTT(x) k + e'"""
+    import struct
+    n = 32768
+    mem = Memory()
+    psi, mc = device_tables(64, n, nm, prm, lane_major=True)
+    batch = x8.shape[0]
+    o0, o1 = np.zeros_like(e0p), np.zeros_like(e0p)
+    two = k1 is not None
+    px, pe0, po0, ppsi, pmc = mem.add(x8.copy()), mem.add(e0p.copy()), mem.add(o0), mem.add(psi), mem.add(mc)
+    pk0, pk1 = mem.add(k0.copy()), mem.add((k1 if two else k0).copy())
+    pe1, po1 = mem.add((e1p if two else e0p).copy()), mem.add(o1)
+    kernarg = struct.pack("<5Q2i4Q", po0, px, pe0, ppsi, pmc, nm, 15, pk0, pk1, pe1, po1)
+    with open(asm_path) as f:
+        text = f.read()
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
+    run_kernel(text, mem, kernarg, (batch, nm), lds, waves_per_wg=16)
+    out = []
+    for ptr, arr in ((po0, o0), (po1, o1))[:2 if two else 1]:
+        buf, _ = mem.find(ptr, arr.nbytes)
+        out.append(buf[:arr.nbytes].view(arr.dtype).reshape(arr.shape).copy())
+    return out
 
 
 def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts, remap=False, groups=1, lane_major=None):

@@ -162,6 +162,7 @@ int main(int argc, char **argv) {
   try {
     if (!run<uint64_t, 4096, 4>(reps)) return 1;
     if (!run<uint64_t, 8192, 2>(reps / 4 + 8)) return 1;      // (the fused entries' row-resident kernels on the GPU)
+    if (!run<uint64_t, 32768, 2>(reps / 16 + 6)) return 1;    // (... and the 32768-word rows' pipelines)
     if (!run<uint32_t, 1024, 2>(reps)) return 1;
     if (!run<uint16_t, 128, 1>(reps)) return 1;
     std::printf("deferred == immediate on the loop shapes, %zu iterations per ring\nall checks passed\n", reps);

@@ -244,6 +244,48 @@ def test_emulated_u64_register_resident_32768_word_rows(nm, batch, generated, or
     assert np.array_equal(run("polymul_ntt32768s", a, scratch), o.polymul(a, b))
 
 
+@pytest.mark.parametrize("nm,batch", [(2, 2)])
+def test_emulated_u64_forward_transform_of_a_compact_32768_word_row(nm, batch, generated, oracle_factory):
+    """n = 32768: a compact Gaussian polynomial (one signed byte per coefficient, the same for every modulus) in, the NTT words
+    of every modulus out -- the expansion v < 0 -> p + v happens in the registers the transform starts from"""
+    n = 32768
+    o = oracle_factory(64, n, nm)
+    prm, a, _ = operands(o, 64, n, nm, batch, 31)
+    rng = np.random.default_rng(5)
+    x = rng.integers(-128, 127, size=(batch, n), endpoint=True).astype(np.int8)
+    x[0, :4] = (-128, 127, 0, -1)
+    P = np.asarray(o.P[:nm], dtype=np.uint64)
+    words = np.where(x[:, None, :] < 0, (P[None, :, None].astype(np.int64) + x[:, None, :].astype(np.int64)).astype(np.uint64),
+                     x[:, None, :].astype(np.int64).astype(np.uint64))
+    got = asm_emu.run_block_kernel(generated("ntt_fwd32768i8"), n, nm, prm, a, a, 15, words_per_thread=32, compact=x)
+    assert np.array_equal(got, o.ntt(np.ascontiguousarray(words)))
+
+
+@pytest.mark.parametrize("nm,batch,two", [(2, 2, True), (1, 1, False)])
+def test_emulated_u64_fused_forward_pipelines_of_32768_word_rows(nm, batch, two, generated, oracle_factory):
+    """n = 32768: out0 = NTT(x) k0 + e0' [, out1 = NTT(x) k1 + e1'] with x one signed byte per coefficient, transformed once and
+    kept in registers; the keys (one polynomial for the batch) and the transformed noise rows stream through the idle twiddle ring"""
+    n = 32768
+    o = oracle_factory(64, n, nm)
+    prm, e0p, e1p = operands(o, 64, n, nm, batch, 37)
+    _, k0, k1 = operands(o, 64, n, nm, 1, 41)
+    rng = np.random.default_rng(9)
+    x = rng.integers(-128, 127, size=(batch, n), endpoint=True).astype(np.int8)
+    P = np.asarray(o.P[:nm], dtype=np.uint64)
+    words = np.where(x[:, None, :] < 0, (P[None, :, None].astype(np.int64) + x[:, None, :].astype(np.int64)).astype(np.uint64),
+                     x[:, None, :].astype(np.int64).astype(np.uint64))
+    X = o.ntt(np.ascontiguousarray(words))
+    bc = lambda k: np.ascontiguousarray(np.broadcast_to(k, X.shape))
+    want0 = o.pointwise(0, o.pointwise(2, X, bc(k0)), e0p)
+    if two:
+        got = asm_emu.run_row32k_forward_pipeline(generated("fused_enc2_32768i8"), nm, prm, x, k0, e0p, k1, e1p)
+        assert np.array_equal(got[0], want0)
+        assert np.array_equal(got[1], o.pointwise(0, o.pointwise(2, X, bc(k1)), e1p))
+    else:
+        got = asm_emu.run_row32k_forward_pipeline(generated("fused_fma_fwd32768i8"), nm, prm, x, k0, e0p)
+        assert np.array_equal(got[0], want0)
+
+
 @pytest.mark.parametrize("nm,batch,shared_key,subtract", [(1, 1, True, True), (2, 2, False, False)])
 def test_emulated_u64_fused_inverse_pipeline_of_32768_word_rows(nm, batch, shared_key, subtract, generated, oracle_factory):
     """n = 32768: INTT(b - a k) / INTT(b + a k) in ONE register-resident kernel (the decryption of the reference's demo at its

@@ -990,7 +990,7 @@ def configure(mode, groups=4):
         g.update(V_ZERO=g["V_T"][0] + 15)
 
 
-def prologue16k(em, vm, stop=None, kind="polymul", key_row=False):
+def prologue16k(em, vm, stop=None, kind="polymul", key_row=False, compact_x=False):
     """1024 threads; v0 = tid on entry.  Leaves V_TID = tid & 255 (the thread's index inside its sub-group),
     V_OFF8 = tid*8, the LDS addresses of the sub-group's slab, all pass constants, and the row loads issued."""
     R = em.raw
@@ -1043,6 +1043,14 @@ def prologue16k(em, vm, stop=None, kind="polymul", key_row=False):
     for base, row in ((6, 16), (8, 18), (4, 20)):
         R("s_add_u32 s%d, s%d, s42" % (row, base))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+    if compact_x:
+        # operand a is ONE signed byte per coefficient (the samplers' compact output), the same for every modulus: row = a + poly * n
+        R("s_lshr_b32 s42, s2, s86")                     # poly
+        R("s_mov_b32 s43, 0")
+        R("s_add_u32 s16, s88, 12")                      # logn
+        R("s_lshl_b64 s[42:43], s[42:43], s16")
+        R("s_add_u32 s16, s6, s42")
+        R("s_addc_u32 s17, s7, s43")
     if key_row:
         # a third input row (the fused inverse kinds of build_row32k): its base at kernarg 0x30, and at 0x38 whether it advances
         # with the batch (1) or is ONE polynomial for every element (0: a key) -> s[98:99]
@@ -1838,6 +1846,12 @@ def build_row32k(kind="fwd"):
         return load
     passes["Ba"], passes["Bb"] = bprime_loader(0), bprime_loader(4)
 
+    compact_x = kind in ("fwd_i8", "fma_fwd_i8", "enc2_i8")   # the row arrives as one signed byte per coefficient (a compact Gaussian polynomial)
+    # fma_fwd_i8 / enc2_i8: the transformed row X never leaves the registers -- out0 = X k0 + e0' [, out1 = X k1 + e1'] with the key rows
+    # (one polynomial for the batch) and the already transformed noise rows e' streamed through the ring's registers in the store layout
+    enc_res = {"fma_fwd_i8": 1, "enc2_i8": 2}.get(kind, 0)
+    if compact_x:
+        kind = "fwd"
     fused_inv = kind in ("fms_inv", "fma_inv")       # INTT(b - a k) / INTT(b + a k): a at S_AROW, b at S_BROW, the key row at s[98:99]
     has_fwd, has_inv = kind != "inv" and not fused_inv, kind != "fwd"
     uses = []
@@ -1855,7 +1869,7 @@ def build_row32k(kind="fwd"):
                 uses += [(name + "ab"[f], s_, g) for s_ in (3, 2, 1, 0) for g in range(1 << s_)]
         uses += [("I0", s_, g) for s_ in (2, 1, 0) for g in range(1 << s_)]
     ring = Ring(em, vm, RING_SLOTS, uses, passes)
-    prologue16k(em, vm, None, "none", key_row=fused_inv)
+    prologue16k(em, vm, None, "none", key_row=fused_inv, compact_x=compact_x)
     AX = T(0, 0)   # exchange address scratch (the butterfly temporaries are idle during exchanges)
 
     def block_base(srow, boff):                           # s[86:87] = first word of block q + boff of the row at srow
@@ -1870,7 +1884,24 @@ def build_row32k(kind="fwd"):
     if has_fwd:
         em.comment("the row: x[tid + 1024 k] -> slot k (8 KiB contiguous per workgroup load)")
         R("s_mov_b64 s[86:87], %s" % (S_AROW,))
-        for k in range(32):
+        if compact_x:
+            em.valu("v_lshrrev_b32_e32 v%d, 3, v%d" % (T(0, 0), V_OFF8))        # tid (V_TID is the index inside the sub-group)
+            seq = None
+            for k in range(32):
+                seq = vm.load("global_load_sbyte v%d, v%d, s[86:87]" % (V_A + 2 * k, T(0, 0)))
+                if k < 31:
+                    R("s_add_u32 s86, s86, 0x400")
+                    R("s_addc_u32 s87, s87, 0")
+            vm.wait(seq)
+            em.comment("x >= 0 stays, x < 0 becomes p + x: any word congruent to the coefficient is a legal input of the first butterfly")
+            t = T(0, 4)
+            for k in range(32):
+                x = V_A + 2 * k
+                em.valu("v_ashrrev_i32_e32 v%d, 31, v%d" % (x + 1, x))
+                em.valu("v_and_b32_e32 v%d, s24, v%d" % (t, x + 1))
+                em.valu("v_and_b32_e32 v%d, s25, v%d" % (t + 1, x + 1))
+                em.valu("v_lshl_add_u64 %s, %s, 0, %s" % (vp(x), vp(x), vp(t)))
+        for k in range(32 if not compact_x else 0):
             vm.load("global_load_dwordx2 %s, v%d, s[86:87] nt" % (vp(V_A + 2 * k), V_OFF8))
             if k < 31:
                 R("s_add_u32 s86, s86, 0x2000")
@@ -2022,6 +2053,57 @@ def build_row32k(kind="fwd"):
                     if i < 7:
                         R("s_add_u32 s86, s86, 0x1000")
                         R("s_addc_u32 s87, s87, 0")
+            R("s_endpgm")
+            return True
+        if kind == "fwd" and enc_res:
+            em.comment("X in the store layout (a wave-local LDS transpose per file), then per result: key and noise words in, X k + e' out")
+            R("s_load_dwordx8 s[88:95], s[0:1], 0x30")                      # k0 k1 e1' out1 (an aligned group of eight)
+            R("s_sub_u32 s42, s20, s4")                                     # the dense rows' offset (this element, this modulus)
+            R("s_subb_u32 s43, s21, s5")
+            R("s_mov_b32 s96, s3")                                          # the key rows' offset: modulus cm of ONE polynomial (n = 32768)
+            R("s_mov_b32 s97, 0")
+            R("s_lshl_b64 s[96:97], s[96:97], 18")
+            R("s_waitcnt lgkmcnt(0)")
+            for lo in (88, 90):
+                R("s_add_u32 s%d, s%d, s96" % (lo, lo))
+                R("s_addc_u32 s%d, s%d, s97" % (lo + 1, lo + 1))
+            for lo in (92, 94):
+                R("s_add_u32 s%d, s%d, s42" % (lo, lo))
+                R("s_addc_u32 s%d, s%d, s43" % (lo + 1, lo + 1))
+            def transposes(base):
+                lds_write(em, V_L2R, base, 8)
+                _, l_ = lane_contig_setup(em)
+                em.valu("v_add_u32_e32 v%d, %s, v%d" % (l_, S_SLAB, l_))
+                for j in range(16):
+                    R("ds_read_b64 %s, v%d offset:%d" % (vp(base + 2 * j), l_, 544 * j))
+            def fma_stores(base, boff):
+                for res in range(enc_res):
+                    krow, erow, orow = (("s[88:89]", S_BROW, S_CROW), ("s[90:91]", "s[92:93]", "s[94:95]"))[res]
+                    for half in range(2):
+                        g_, _ = lane_contig_setup(em)
+                        seq = None
+                        for srow, dst0, nt_ in ((krow, V_TW, ""), (erow, V_TW + 16, " nt")):
+                            block_base(srow, boff)
+                            if half:
+                                R("s_add_u32 s86, s86, 0x1000")
+                                R("s_addc_u32 s87, s87, 0")
+                            for jj in range(8):
+                                seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d%s" % (vp(dst0 + 2 * jj), g_, jj * 512, nt_))
+                        vm.wait(seq)
+                        run_pairs(em, [fma_job(V_TW + 2 * jj, base + 2 * (8 * half + jj), V_TW + 16 + 2 * jj, res == 0) for jj in range(8)])
+                        g_, _ = lane_contig_setup(em)
+                        block_base(orow, boff)
+                        if half:
+                            R("s_add_u32 s86, s86, 0x1000")
+                            R("s_addc_u32 s87, s87, 0")
+                        for jj in range(8):
+                            R("global_store_dwordx2 v%d, %s, s[86:87] offset:%d nt" % (g_, vp(V_TW + 2 * jj), jj * 512))
+            transposes(A_)
+            R(W0)
+            transposes(B_)
+            fma_stores(A_, FILES[0][1])
+            R(W0)
+            fma_stores(B_, FILES[1][1])
             R("s_endpgm")
             return True
         if kind == "fwd":
@@ -4205,6 +4287,11 @@ def main():
                        ("fwd_s", "ntt_fwd32768s"), ("polymul_s", "polymul_ntt32768s")):
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind))
     # ... and the fused inverse pipelines of such a row: INTT(b -+ a k), the key row's base and stride flag behind the standard arguments
+    # ... the forward transform of a compact (int8) Gaussian polynomial: one byte per coefficient in, NTT words of every modulus out
+    emit_file(os.path.join(outdir, "ntt_fwd32768i8_gfx950.s"), "nflhip_ntt_fwd32768i8_asm", build_row32k("fwd_i8"))
+    for kind, stem in (("fma_fwd_i8", "fused_fma_fwd32768i8"), ("enc2_i8", "fused_enc2_32768i8")):   # ... and the forward pipelines on such a polynomial: out0 = NTT(x) k0 + e0' [, out1 = NTT(x) k1 + e1']
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind),
+                  args=ARGS_STD + [("ptr", 48), ("ptr", 56), ("ptr", 64), ("ptr", 72)])
     g.update(NEXT_SGPR=102)
     for kind in ("fms_inv", "fma_inv"):
         emit_file(os.path.join(outdir, "fused_%s32768_gfx950.s" % kind), "nflhip_fused_%s32768_asm" % kind, build_row32k(kind),
