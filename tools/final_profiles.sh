@@ -31,7 +31,7 @@ NFL_LWE_REPS=16384 tests/cpp/resident_test | head -1 >> $out/${tag}_lwe_poly_p.j
 NFL_HIP_NO_FUSION=1 NFL_LWE_REPS=16384 tests/cpp/resident_test | head -1 > $out/${tag}_lwe_poly_p_nofusion.json
 # the LWE demo on resident batches: operator by operator and through the transform-fused pipelines (same keystreams)
 rm -f $out/${tag}_lwe.jsonl
-for shape in "4096 4 16384" "8192 2 8192" "16384 8 1024" "1024 2 65536"; do
+for shape in "4096 4 16384" "8192 2 8192" "16384 8 1024" "32768 2 1024" "1024 2 65536"; do
   set -- $shape
   for plan in unfused fused; do
     python tools/lwe_demo.py --degree $1 --nmoduli $2 --batch $3 --plan $plan --reps 10 --fixed-key 2>/dev/null >> $out/${tag}_lwe.jsonl
