@@ -1210,6 +1210,19 @@ int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, co
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "fma_inv(fused)");
   }
+  // short rows (1024 / 2048 words; 4096 for 32-bit limbs): the wave-per-row kernels multiply-subtract in the registers their
+  // inverse transform starts from (kernels_wave.hip k_row_fma_inv)
+  if (a->stride == 1 && b->stride == 1 && k->stride <= 1 && !ctx->cyclic) {
+    hipError_t e = hipErrorNotSupported;
+    if (ctx->shape.limb_bits == 32)
+      e = launch_row_fma_inv_u32(ctx->shape, ctx->tabs, subtract, (uint32_t *)d_out, (const uint32_t *)a->ptr, (const uint32_t *)k->ptr,
+                                 (int)k->stride, (const uint32_t *)b->ptr, batch, st);
+    else if (ctx->shape.limb_bits == 64)
+      e = launch_row_fma_inv_u64(ctx->shape, ctx->tabs, subtract, (uint64_t *)d_out, (const uint64_t *)a->ptr, (const uint64_t *)k->ptr,
+                                 (int)k->stride, (const uint64_t *)b->ptr, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "fma_inv(rows)");
+  }
   // composed: one fused multiply-add / -subtract pass into the result, inverse transform in place
   const unsigned char prog[5] = {0, 1, 2, NFLHIP_EXPR_MUL, (unsigned char)(subtract ? NFLHIP_EXPR_SUB : NFLHIP_EXPR_ADD)};
   const void *ops[3] = {b->ptr, a->ptr, k->ptr};

@@ -138,6 +138,11 @@ hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const
 // transform-fused pipelines at n = 4096, 64-bit limbs (tools/gen_polymul_asm.py build_fused): kind 0 enc2 | 1 fma_fwd |
 // 2 fms_inv | 3 fma_inv; x: up to three operands with their formats (forward kinds) and strides, k: key rows with strides.
 // hipErrorNotSupported for other shapes / the compiled-only variant (api.hip composes the same result from the plain kernels)
+// INTT(b -+ a (.) key) in one pass on the wave-per-row kernels (kernels_wave.hip): rows of 1024 / 2048 words, 4096 for 32-bit limbs
+hipError_t launch_row_fma_inv_u32(const Shape &s, const DevTables &t, int subtract, uint32_t *c, const uint32_t *a, const uint32_t *key,
+                                  int kstride, const uint32_t *b, size_t batch, hipStream_t st);
+hipError_t launch_row_fma_inv_u64(const Shape &s, const DevTables &t, int subtract, uint64_t *c, const uint64_t *a, const uint64_t *key,
+                                  int kstride, const uint64_t *b, size_t batch, hipStream_t st);
 // rows of 32768 words from a compact (int8) Gaussian polynomial: its forward transform, and NTT(x) k0 + e0' [, NTT(x) k1 + e1'] (e' words)
 hipError_t launch_row32k_fwd_i8_u64(const Shape &s, const DevTables &t, uint64_t *dst, const void *x8, size_t batch, hipStream_t st);
 hipError_t launch_row32k_fwd_fma_i8_u64(const Shape &s, const DevTables &t, uint64_t *out0, uint64_t *out1, const void *x8,

@@ -102,6 +102,8 @@ template <bool MAD> struct Pol32T {
     u = mul_shoup<u32>(s, c.ninv, c.ninv_sh, k.p);
     x = mul_shoup<u32>(d, c.w1ninv, c.w1ninv_sh, k.p);
   }
+  // b -+ m for canonical b and a product m of mul(): what the inverse butterflies take (< 2p)
+  __device__ __forceinline__ static T addsub(T b, T m, bool sub, const K &k) { return sub ? b + k.p - m : b + m; }
 };
 typedef Pol32T<false> Pol32;
 typedef Pol32T<NFLHIP_U32_MAD != 0> Pol32M;
@@ -123,6 +125,7 @@ struct Pol64 {
   __device__ __forceinline__ static T canon(T x, const K &k) { return nflhip::canon<3>(x, k.m); }
   __device__ __forceinline__ static T prep(T b, const K &k) { return fold2(b, k.m); }
   __device__ __forceinline__ static T mul(T a, T b, const K &k) { return mul_lazy(fold2(a, k.m), b, k.mu2, k.m); }  // < 2p
+  __device__ __forceinline__ static T addsub(T b, T m, bool sub, const K &k) { return fold2(sub ? b + k.m.p2 - m : b + m, k.m); }
   __device__ __forceinline__ static void last(T &u, T &x, const MC &c, const K &k) {
     const T s = u + x, d = x - u + k.m.p2;
     u = mul_shoup<u64>(s, c.ninv, c.ninv_sh, k.m.p);
@@ -390,6 +393,69 @@ __global__ __launch_bounds__(256) void k_row1024_lds(typename P::T *c, const typ
     row_body<P, MODE, 4>(c, a, b, row, slab[wave], table[cm], mc[cm], lane, true);
     wave_sync();  // the slab is reused by the next row
   }
+}
+
+// c = INTT(b - a (.) key) (SUB) or INTT(b + a (.) key), all in NTT form: the decryption of the reference's demo
+// (tests/nfllib_demo_main_op.cpp:51-57) as ONE pass -- the multiply-subtract happens in the registers the inverse transform
+// starts from.  key: one polynomial for the batch (kstride 0) or one per element (1).
+template <class P, int SUB, int LB>
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : 2)) void k_row_fma_inv(
+    typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::T *key, int kstride,
+    const typename P::TW *__restrict__ psi, const typename P::MC *__restrict__ mc, int nm, size_t rows) {
+  typedef typename P::T T;
+  constexpr int W = 16 * LB, RPB = 256 / W, LOGN = LB == 4 ? 10 : (LB == 8 ? 11 : 12);
+  __shared__ T slab[RPB][kSlabWords * (W / 64)];
+  const int sub = threadIdx.x / W, t = threadIdx.x % W;
+  size_t row = (size_t)blockIdx.x * RPB + sub;
+  const bool live = row < rows;
+  if (!live) {
+    if (LB == 4) return;
+    row = rows - 1;
+  }
+  const int cm = (int)(row % (size_t)nm);
+  const typename P::MC &mcr = mc[cm];
+  const typename P::K k = P::make(mcr);
+  const T *ar = a + (row << LOGN) + 16 * t, *br = b + (row << LOGN) + 16 * t;
+  const T *kr = key + ((kstride ? row : (size_t)cm) << LOGN) + 16 * t;
+  T ra[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) ra[q] = P::addsub(br[q], P::mul(ar[q], kr[q], k), SUB != 0, k);
+  inv_row<P, LB>(ra, slab[sub], psi + ((size_t)cm << LOGN), mcr, k, t, 2u, false);
+  T *cr = c + (row << LOGN);
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cr[t + W * j] = ra[j];
+  }
+}
+template <class P, int LB>
+static hipError_t launch_fma_inv_rows(const Shape &s, const DevTables &t, int subtract, typename P::T *c, const typename P::T *a,
+                                      const typename P::T *key, int kstride, const typename P::T *b, size_t batch, hipStream_t st) {
+  const size_t rows = batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  constexpr int RPB = 256 / (16 * LB);
+  const size_t blocks = (rows + RPB - 1) / RPB;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const typename P::TW *psi = (const typename P::TW *)t.psi;
+  const typename P::MC *mc = (const typename P::MC *)t.mc;
+  if (subtract) hipLaunchKernelGGL((k_row_fma_inv<P, 1, LB>), dim3((unsigned)blocks), dim3(256), 0, st, c, a, b, key, kstride, psi, mc, (int)s.nm, rows);
+  else hipLaunchKernelGGL((k_row_fma_inv<P, 0, LB>), dim3((unsigned)blocks), dim3(256), 0, st, c, a, b, key, kstride, psi, mc, (int)s.nm, rows);
+  return hipGetLastError();
+}
+// rows of 1024 / 2048 words (and 4096 for 32-bit limbs): dense a / b, the key with stride 0 or 1; hipErrorNotSupported otherwise
+hipError_t launch_row_fma_inv_u32(const Shape &s, const DevTables &t, int subtract, uint32_t *c, const uint32_t *a, const uint32_t *key,
+                                  int kstride, const uint32_t *b, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 32) return hipErrorNotSupported;
+  if (s.logn == 10) return launch_fma_inv_rows<Pol32, 4>(s, t, subtract, c, a, key, kstride, b, batch, st);
+  if (s.logn == 11) return launch_fma_inv_rows<Pol32, 8>(s, t, subtract, c, a, key, kstride, b, batch, st);
+  if (s.logn == 12) return launch_fma_inv_rows<Pol32M, 16>(s, t, subtract, c, a, key, kstride, b, batch, st);
+  return hipErrorNotSupported;
+}
+hipError_t launch_row_fma_inv_u64(const Shape &s, const DevTables &t, int subtract, uint64_t *c, const uint64_t *a, const uint64_t *key,
+                                  int kstride, const uint64_t *b, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || !s.small_delta) return hipErrorNotSupported;
+  if (s.logn == 10) return launch_fma_inv_rows<Pol64, 4>(s, t, subtract, c, a, key, kstride, b, batch, st);
+  if (s.logn == 11) return launch_fma_inv_rows<Pol64, 8>(s, t, subtract, c, a, key, kstride, b, batch, st);
+  return hipErrorNotSupported;
 }
 
 template <class P, int LB>
