@@ -983,9 +983,12 @@ template <class P> struct lazy {
     static const bool v = !getenv("NFL_HIP_NO_FUSION") && nflhip_has_fused_kernels(ctx_t::get()) != 0;
     return v;
   }
-  // c +- a * b as a 5-byte postfix program over three distinct operands: {a, b, c, subtract}, or false
-  static bool parse_fma(const op &o, int &a, int &b, int &c, bool &sub) {
-    if (o.kind != K_EVAL || o.len != 5 || o.nin != 3) return false;
+  // c +- a * b as a 5-byte postfix program over three distinct operands: {a, b, c, subtract}, or false.  A record that
+  // carries a joined transform (op::post, join_transform below) is NOT that expression: its result is the transformed
+  // value, and a rewrite that took only the expression would drop the transform.  The one place that models a joined
+  // transform -- the expression followed by its own inverse transform -- asks for it by name (`joined`).
+  static bool parse_fma(const op &o, int &a, int &b, int &c, bool &sub, unsigned char joined = 0) {
+    if (o.kind != K_EVAL || o.len != 5 || o.nin != 3 || o.post != joined) return false;
     const unsigned char *q = o.e.code;
     if (q[0] < 3 && q[1] < 3 && q[2] == NFLHIP_EXPR_MUL && q[3] < 3 && q[4] == NFLHIP_EXPR_ADD) {            // a b * c +
       a = q[0]; b = q[1]; c = q[3]; sub = false;
@@ -1083,7 +1086,8 @@ template <class P> struct lazy {
       }
       if (dn < 0 || ops[size_t(dn)].kind != K_NTT_FWD || uses[size_t(dn)] != want_uses || !dead_after(dn)) return -1;
       const int g = prev[size_t(dn)];
-      if (g < 0 || ops[size_t(g)].kind != K_GAUSS || uses[size_t(g)] != 1 || (ops[size_t(g)].s.p1 >> 32) != 0) return -1;
+      if (g < 0 || ops[size_t(g)].kind != K_GAUSS || ops[size_t(g)].post != 0 || uses[size_t(g)] != 1 || (ops[size_t(g)].s.p1 >> 32) != 0)
+        return -1;   // (post: the constructor's record already carries one transform; this would be the second)
       if (small_format(ops[size_t(g)].s.tab, uint32_t(ops[size_t(g)].s.p1)) > NFLHIP_FMT_I32) return -1;
       return g;
     };
@@ -1093,7 +1097,7 @@ template <class P> struct lazy {
         if (t.kind == K_EVAL && t.post == K_NTT_INV) {   // the transform joined the expression's record: rewrite in place
           int a, b, c;
           bool sub;
-          if (!parse_fma(t, a, b, c, sub)) continue;
+          if (!parse_fma(t, a, b, c, sub, K_NTT_INV)) continue;
           pay_t *pc = t.e.in[c], *pa = t.e.in[a], *pb = t.e.in[b];
           t.kind = K_FMA_INV;
           t.post = 0;

@@ -209,7 +209,7 @@ int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const vo
  * one SIGNED integer per coefficient shared by all moduli (int8 / int16 / int32; v < 0 stands for p + v; |v| must be
  * below every modulus) -- what the samplers produce before they spread a value over the moduli (core.hpp:230-277); see
  * nflhip_sample_gauss_small_dev.  k operands and the operands of nflhip_fma_inv_dev are words in NTT form (canonical,
- * ops.hpp:131,211).  Results are dense; a result may alias a dense input of the same call.  u64 limbs at degree 4096,
+ * ops.hpp:131,211).  Results are dense; a result may alias any input of the same call (x, either e, either k).  u64 limbs at degree 4096,
  * 8192 and 16384 run one generated gfx950 kernel per call (at degree 32768 nflhip_fma_inv_dev does for dense a / b, and the forward
  * entries run three for int8 polynomials with keys of stride 0; rows of 1024 / 2048 words -- 4096 for 32-bit limbs -- run
  * nflhip_fma_inv_dev as one pass of the wave-per-row kernels); every other shape composes the same result from the plain kernels through

@@ -1090,6 +1090,14 @@ static hipError_t expand_any(nflhip_ctx *ctx, void *dst, const nflhip_operand *s
                     launch_expand_small<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)dst, src->ptr, src->format, (unsigned)src->stride, batch, st));
 }
 
+// out0 of a two-result call lies over (part of) an input of the SECOND result (k1 or e1): the one aliasing in which a plan that
+// stores the first result before it has read the second one's inputs would change them under its own feet
+static bool first_result_overlaps(nflhip_ctx *ctx, const void *out0, const nflhip_operand *in, size_t batch) {
+  const size_t per = in->format == NFLHIP_FMT_WORDS ? poly_bytes(ctx, 1) : ctx->shape.n << (in->format - NFLHIP_FMT_I8);
+  const char *o = (const char *)out0, *k = (const char *)in->ptr;
+  return o < k + ((batch - 1) * in->stride + 1) * per && k < o + poly_bytes(ctx, batch);
+}
+
 static int fused_fwd_composed(nflhip_ctx *ctx, void *out0, void *out1, const nflhip_operand *x, const nflhip_operand *k0,
                               const nflhip_operand *e0, const nflhip_operand *k1, const nflhip_operand *e1, size_t batch,
                               hipStream_t st) {
@@ -1098,12 +1106,12 @@ static int fused_fwd_composed(nflhip_ctx *ctx, void *out0, void *out1, const nfl
   const size_t bytes = poly_bytes(ctx, batch);
   std::unique_lock<std::mutex> lk(ctx->scratch_mu);
   const bool cap = is_capturing(st);
-  int rc = ensure_scratch(ctx, 2 * bytes);
+  int rc = ensure_scratch(ctx, (out1 ? 3 : 2) * bytes);
   if (rc) return rc;
   if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
   if (!cap && ctx->ev_prev_valid)
     for (int j = 0; j < 2; ++j) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[j], 0));
-  void *s0 = ctx->scratch, *s1 = (char *)ctx->scratch + bytes;
+  void *s0 = ctx->scratch, *s1 = (char *)ctx->scratch + bytes, *s2 = (char *)ctx->scratch + 2 * bytes;
   static const unsigned char prog[5] = {0, 1, NFLHIP_EXPR_MUL, 2, NFLHIP_EXPR_ADD};
   // rows of 32768 words with int8 polynomials and keys shared by the batch (the LWE demo at the reference's largest configuration):
   // the noise polynomials go from their bytes straight to NTT words in the scratch, then ONE kernel transforms x in registers and
@@ -1131,17 +1139,27 @@ static int fused_fwd_composed(nflhip_ctx *ctx, void *out0, void *out1, const nfl
   if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
   rc = nflhip_ntt_fwd_dev(ctx, s0, batch, st);
   if (rc) return rc;
+  // a result may alias a dense input of the same call (nflhip.h): every input polynomial is read into the scratch BEFORE the
+  // first result is stored (e1 may be out0), and when out0 overlaps a per-element k1 the first result waits in the scratch
+  // until the second has been computed -- the generated kernels read a whole row of every operand before they store, the
+  // composed plan gives the same guarantee
   for (int h = 0; h < (out1 ? 2 : 1); ++h) {
-    const nflhip_operand *kk = h ? k1 : k0, *ee = h ? e1 : e0;
-    e = expand_any(ctx, s1, ee, batch, st);
+    void *sh = h ? s2 : s1;
+    e = expand_any(ctx, sh, h ? e1 : e0, batch, st);
     if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
-    rc = nflhip_ntt_fwd_dev(ctx, s1, batch, st);
-    if (rc) return rc;
-    const void *ops[3] = {s0, kk->ptr, s1};
-    const unsigned sd[3] = {1, (unsigned)kk->stride, 1};
-    rc = eval_dev(ctx, h ? out1 : out0, ops, 3, prog, sizeof(prog), batch, st, sd, 1);
+    rc = nflhip_ntt_fwd_dev(ctx, sh, batch, st);
     if (rc) return rc;
   }
+  const bool hold0 = out1 && first_result_overlaps(ctx, out0, k1, batch);
+  for (int h = 0; h < (out1 ? 2 : 1); ++h) {
+    const nflhip_operand *kk = h ? k1 : k0;
+    void *sh = h ? s2 : s1;
+    const void *ops[3] = {s0, kk->ptr, sh};
+    const unsigned sd[3] = {1, (unsigned)kk->stride, 1};
+    rc = eval_dev(ctx, h ? out1 : (hold0 ? s1 : out0), ops, 3, prog, sizeof(prog), batch, st, sd, 1);
+    if (rc) return rc;
+  }
+  if (hold0) HIPCHK(ctx, hipMemcpyAsync(out0, s1, bytes, hipMemcpyDeviceToDevice, st));
   if (!cap) {  // the scratch is reused by the next call on any stream: order it after this one
     HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
     ctx->ev_scratch_valid = true;
@@ -1165,7 +1183,10 @@ static int fused_fwd_any(nflhip_ctx *ctx, void *out0, void *out1, const nflhip_o
   if (rc) return rc;
   if (batch == 0) return NFLHIP_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (ctx->shape.limb_bits == 64) {
+  // (the generated two-result kernels store a row of out0 before they load that row of k1 and, the row-resident ones, of e1: a
+  // first result laid over an input of the second -- legal, nflhip.h -- takes the composed plan, which reads every polynomial
+  // before it stores and holds out0 back when it must)
+  if (ctx->shape.limb_bits == 64 && !(two && (first_result_overlaps(ctx, out0, k1, batch) || first_result_overlaps(ctx, out0, e1, batch)))) {
     const void *xs[3] = {x->ptr, e0->ptr, two ? e1->ptr : nullptr};
     const unsigned xstr[3] = {(unsigned)x->stride, (unsigned)e0->stride, two ? (unsigned)e1->stride : 0u};
     const int xf[3] = {x->format, e0->format, two ? e1->format : 0};

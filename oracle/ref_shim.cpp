@@ -263,6 +263,8 @@ struct ops_for {
   X(uint64_t, 32768, 2)    \
   X(uint64_t, 16, 40)      \
   X(uint32_t, 32, 64)      \
+  X(uint64_t, 64, 96)      \
+  X(uint64_t, 1024, 94)    \
   X(uint64_t, 65536, 30)
 #endif
 

@@ -128,7 +128,7 @@ template <class T, size_t Degree, size_t NbModuli> static bool run(size_t reps) 
       std::vector<poly_p> r0(m), r1(m);
       for (size_t i = 0; i < m; ++i) {
         poly_p u{G(&fg)}, e1{G(&fg, 2)};
-        switch (i % 9) {
+        switch (i % 13) {
           case 0: r1[i] = u + k1; u.ntt_pow_phi(); r0[i] = u; break;                                    // u is read before its transform
           case 1: u.ntt_pow_phi(); u.invntt_pow_invphi(); r0[i] = u; r1[i] = e1; break;                 // two transforms in a row
           case 2: r0[i] = u + e1; r0[i].ntt_pow_phi(); r1[i] = r0[i] * k1; r1[i].ntt_pow_phi(); r1[i].ntt_pow_phi(); break;   // expression, then forward (twice)
@@ -137,7 +137,13 @@ template <class T, size_t Degree, size_t NbModuli> static bool run(size_t reps) 
           case 5: if (i % 2) poly_p::synchronize(); u.ntt_pow_phi(); r0[i] = u; r1[i] = e1; break;      // (sometimes) after a queue run
           case 6: u.invntt_pow_invphi(); r0[i] = u; { poly_p w{nfl::uniform()}; w.ntt_pow_phi(); r1[i] = w; } break;   // wrong kinds
           case 7: { poly_p c = u; u.ntt_pow_phi(); r0[i] = u; r1[i] = c; } break;                       // a copy shares the value
-          default: r0[i] = c0 - k1 * k2; r1[i] = r0[i] + u; r0[i].invntt_pow_invphi(); break;           // the difference is read first
+          case 8: r0[i] = c0 - k1 * k2; r1[i] = r0[i] + u; r0[i].invntt_pow_invphi(); break;            // the difference is read first
+          case 9: r0[i] = k1 * k2 + c0; r0[i].ntt_pow_phi(); r0[i].invntt_pow_invphi(); r1[i] = r0[i] + e1; break;   // c + a*b, forward (joined), then inverse: NOT c + a*b -> inverse
+          case 10: u.ntt_pow_phi(); u.ntt_pow_phi(); e1.ntt_pow_phi(); r0[i] = u * k1 + e1; r1[i] = k2; break;   // sampled, transformed TWICE, multiplied
+          case 11: { poly_p e2{G(&fg, 2)}; u.ntt_pow_phi(); e1.ntt_pow_phi(); e2.ntt_pow_phi();       // both results, a transform joined to the FIRST
+                     r0[i] = u * k1 + e1; r0[i].ntt_pow_phi(); r1[i] = u * k2 + e2; } break;
+          default: { poly_p e2{G(&fg, 2)}; u.ntt_pow_phi(); e1.ntt_pow_phi(); e2.ntt_pow_phi();       // ... to the SECOND
+                     r0[i] = u * k1 + e1; r1[i] = u * k2 + e2; r1[i].invntt_pow_invphi(); } break;
         }
       }
       for (size_t i = 0; i < m; ++i) {

@@ -88,6 +88,15 @@ def test_forward_multiply_add_pipelines(lb, n, nm, fmt, engine_factory, compiled
             alias = xs_d[1].clone()
             e.fwd_fma(xs_d[0], dka, alias, out=alias)
             assert torch.equal(alias, got0)
+            # ... including an input of the OTHER result: out0 over e1's array and out1 over e0's,
+            e0c, e1c = xs_d[1].clone(), xs_d[2].clone()
+            e.fwd_fma2(xs_d[0], dka, e0c, dkb, e1c, out0=e1c, out1=e0c)
+            assert torch.equal(e1c, got0) and torch.equal(e0c, got1)
+            # ... and out0 over a per-element k1 (the composed plan holds the first result back until the second is done)
+            k1d = dense_k.clone()
+            want1d = o.pointwise(0, o.pointwise(2, f[0], e.to_host(dense_k)), f[2])
+            _, o1 = e.fwd_fma2(xs_d[0], dka, xs_d[1], k1d, xs_d[2], out0=k1d)
+            assert torch.equal(k1d, got0) and np.array_equal(e.to_host(o1), want1d)
 
 
 @pytest.mark.parametrize("lb,n,nm", SHAPES)

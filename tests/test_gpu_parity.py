@@ -514,13 +514,15 @@ def test_adversarial_coefficient_values(lb, n, m, oracle_factory, engine_factory
 
 @pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 65536])
 def test_every_mirrored_62_bit_modulus_runs_the_delta_form_kernels(n, oracle_factory, engine_factory):
-    """All 64 mirrored 62-bit moduli in one context.  From the 46th on 2^62 - p needs the full 32 bits (c >= 1024 in
+    """The first 92 mirrored 62-bit moduli in one context: every prime whose 2^62 - p still fits 32 bits (the 93rd on run the
+    general-modulus kernels, tests/test_gpu_big_delta.py).  From the 46th on 2^62 - p needs the full 32 bits (c >= 1024 in
     params.hpp:94-97's c*2^21 - 1), which is the widest delta the multiply-add butterflies accept: uniform words and
     the extreme ones (p-1 everywhere: largest products, folds and quotients) must still match the oracle bit for bit
     on the wave, block, row-resident and pipeline kernels.  (CRT needs <= 32 moduli and is covered elsewhere.)"""
-    lb, m, batch = 64, 64, 3
+    from nfllib_amd.params import params
+    lb, m, batch = 64, 92, 3 if n < 65536 else 2
     o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
-    assert (1 << 62) - int(o.P[45]) >= (1 << 31) and (1 << 62) - int(o.P[63]) < (1 << 32)
+    assert (1 << 62) - int(o.P[45]) >= (1 << 31) and (1 << 62) - int(o.P[91]) < (1 << 32) <= (1 << 62) - int(params(64).P[92])
     a, b = _inputs(o, batch)
     pm1 = (np.array([int(p) for p in o.P], dtype=np.uint64) - 1).astype(o.dtype)[:, None]
     a[0], b[0] = pm1, pm1

@@ -53,7 +53,7 @@ def test_oracle_crt_matches_reference(key, oracle_factory):
     c = ent["crt"]
     assert o.crt_bits == c["bits"] and o.crt_shift == c["shift"] and o.crt_limbs == c["limbs"]
     assert hex(o.crt_modulus()) == c["modulus"] and hex(o.crt_modulus_shoup()) == c["modulus_shoup"]
-    lh = hashlib.sha256(b"".join(o.crt_lifting(cm).to_bytes(8 * 40, "little") for cm in range(m))).hexdigest()
+    lh = hashlib.sha256(b"".join(o.crt_lifting(cm).to_bytes(8 * (40 if m <= 32 else 100), "little") for cm in range(m))).hexdigest()
     assert lh == c["lifting_sha256"]
     a = o.fill_uniform(1, SEED, 0)
     lifted = o.crt_lift(a)
