@@ -253,6 +253,60 @@ def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False):
     return out
 
 
+D_SHARD = 1 << 17   # BASELINE configs[3]: 2^20 polynomials over 8 GPUs
+
+
+def shard_config_d(torch, eng, rank, world, steps, barrier, gather_u64, max_over_ranks):
+    """extras.configs.D -- one shard of BASELINE configs[3] per GPU on the headline's engine (same ring, same kernel): `steps`
+    products over 2^17 resident polynomials per rank, barrier + synchronize on both sides, MAX over ranks, and a checksum of
+    checksums over the logical global batch of world x 2^17.  NFLHIP_BENCH_D_SHARD shrinks the shard (tests on a shared device);
+    the block then says that it is not config 4."""
+    shard = int(os.environ.get("NFLHIP_BENCH_D_SHARD", D_SHARD))
+    first = rank * shard
+    a = eng.fill_uniform(eng.empty(shard), SEED, 0, first_poly=first)
+    b = eng.fill_uniform(eng.empty(shard), SEED, 1, first_poly=first)
+    c = eng.empty(shard)
+    steps = max(1, min(steps, 10))
+    for _ in range(2):
+        eng.polymul(a, b, out=c)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        eng.polymul(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    kernel_ms = max_over_ranks(e0.elapsed_time(e1) / steps)
+    commutes = not eng.any_neq(c, eng.polymul(b, a))
+    own = gather_u64(eng.digest(c, first_poly=first))
+    nxt = (rank + 1) % world
+    eng.fill_uniform(a, SEED, 0, first_poly=nxt * shard)
+    eng.fill_uniform(b, SEED, 1, first_poly=nxt * shard)
+    eng.polymul(a, b, out=c)
+    cross = gather_u64(eng.digest(c, first_poly=nxt * shard))
+    cross = [cross[(r - 1) % world] for r in range(world)]
+    del a, b, c
+    torch.cuda.empty_cache()
+    from nfllib_amd import sharding
+    alg = 3 * eng.nmoduli * eng.degree * 8
+    ach = alg * shard / (kernel_ms * 1e-3) / 1e9
+    return {"workload": "nfl::poly<uint64_t,4096,4> batch=2^20 sharded across 8 GPUs (BASELINE configs D): 2^17 polynomials per GPU",
+            "batch_per_gpu": shard, "n_gpus": world, "global_batch": shard * world,
+            "is_baseline_config_4": bool(shard == D_SHARD and world == 8), "shard_is_baseline_shard": bool(shard == D_SHARD),
+            "steps": steps, "value": round(world * shard * steps / dt, 1), "unit": "polymul/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "kernel_ms": round(kernel_ms, 4), "achieved_GBs_per_gpu": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+            "resident_GiB_per_gpu": round(3 * shard * eng.nmoduli * eng.degree * 8 / 2.0**30, 2), "scaling": "weak",
+            "self_check": bool(commutes and own == cross),
+            "checksum_of_checksums": {"ok": bool(own == cross), "sum_of_shard_digests": "%016x" % sharding.combine_digests(own),
+                                      "recomputed_on_the_neighbouring_gpu": "%016x" % sharding.combine_digests(cross), "shards": world},
+            "how": "value = world x shard x steps / max-over-ranks wall time between barriers; no data-path collective"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -627,7 +681,7 @@ def main():
         # the other single-GPU BASELINE configs, timed inside this same run (driver-visible, not builder-only): configs[2]
         # (C) and configs[4] (E: "CRT lift + poly-mul"); the headline's own tensors are released first
         if args.workload == "B" and not args.no_side_configs:
-            del a, b, c
+            a = b = c = None
             torch.cuda.empty_cache()
             side = {}
             for wl, sb, st_, crt in (("C", 1024, 20, False), ("E", 64, 20, True)):
@@ -636,6 +690,24 @@ def main():
                 except Exception as ex:   # reported, never fatal
                     side[wl] = {"error": repr(ex)}
             extras["configs"] = side
+
+    # BASELINE configs[3] (D): "nfl::poly<uint64_t, 4096, 4> batch=2^20 sharded across 8 GPUs" -- 2^17 polynomials per GPU, so the
+    # driver's `--gpus 8` line carries config 4 itself (global batch N x 2^17 = 2^20 at N = 8) beside the weak-scaling `value` on
+    # workload B's per-GPU batch; the N = 1 line carries the same block for ONE shard (3 x 16 GiB resident).  Collective: every
+    # rank runs it, same barriers and max-over-ranks clock as the headline, its own checksum of checksums.
+    config_d = None
+    if args.workload == "B" and not args.no_side_configs:
+        a = b = c = None
+        torch.cuda.empty_cache()
+        try:
+            config_d = shard_config_d(torch, eng, rank, world, args.steps, barrier, gather_u64,
+                                      (lambda v: sharding.allreduce_max(v, dist, device=red_dev)) if use_dist else (lambda v: v))
+        except Exception as ex:   # reported, never fatal (every rank fails or succeeds alike: allocation sizes are the same)
+            config_d = {"error": repr(ex)}
+        if rank == 0:
+            if extras is None:
+                extras = {}
+            extras.setdefault("configs", {})["D"] = config_d
 
     result = {
         "metric": "poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli" if args.workload == "B"
@@ -657,12 +729,24 @@ def main():
                                 "G": "nflhip_polymul8192_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
+    # what actually binds the metric kernel: not HBM -- `bound` / `frac` above stay as SURVEY.md 8(d)
+    # defines them -- but wave64 VALU issue at the package power limit.  `ceiling_frac_no_memory` is the measured rate of the same
+    # kernel with every HBM, twiddle and LDS access removed (only the butterflies' arithmetic left), as a fraction of the same
+    # 8 TB/s: the most this instruction stream can reach on this part whatever the memory system does.
+    if kwl == "B":
+        ceil = 0.32
+        result["roofline"].update({
+            "binding": "valu-issue at the package power limit",
+            "ceiling_frac_no_memory": ceil,
+            "ceiling_source": "profiles/r03_power_ablation.txt: the metric kernel with HBM, twiddle and LDS traffic removed runs 6.56 M polymul/s "
+                              "(x 393 216 B = 2.58 TB/s = 0.32 of 8 TB/s) at 1 290-1 395 W of the 1 400 W package limit, sclk ~2.07 GHz",
+            "frac_of_ceiling": round(achieved / HBM_PEAK_GBS / ceil, 4)})
     # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  `peak` / `frac` are the
     # HARDWARE ceiling and do not depend on this kernel or this run: one wave64 VALU instruction per SIMD every 2 cycles
     # (MI355X_MICROARCH.md) at the nominal 2.4 GHz, 256 CUs x 4 SIMDs = 1 228.8 G wave-instructions/s.  Two tighter, still
     # kernel-independent prices ride along: `opcode_grid` = the isolated issue costs of tools/ubench_issue.hip (multiply /
     # carry / VOP3 opcodes 4.2 cycles, plain VOP2 2.5: the 62-bit butterfly's 10 + 8 mix = 62 cycles per 18 instructions) at
-    # 2.4 GHz; and `model` = the FITTED figure of earlier rounds (3.86 cycles per instruction, the butterfly stream's own
+    # 2.4 GHz; and `fitted` = the FITTED figure of earlier rounds (3.86 cycles per instruction, the butterfly stream's own
     # measured cost, at the clock this run got under the 1 400 W package limit) -- by construction close to 1, kept only as
     # a consistency check of the instruction counts.
     # Instructions per product: dynamic counts of the generated kernels on the interpreter of tests/asm_emu.py
@@ -687,7 +771,7 @@ def main():
         if power and power.get("sclk_MHz"):
             clock_ghz = round(power["sclk_MHz"] / 1000.0, 3)    # the clock THIS run's kernel got (sampled above)
         peak_fit = 256 * 4 * clock_ghz / cyc_per_inst
-        sec["model"] = {"kind": "fitted", "peak_at_measured_clock": round(peak_fit, 1), "frac": round(ach_gi / peak_fit, 4),
+        sec["fitted"] = {"kind": "fitted", "peak_at_measured_clock": round(peak_fit, 1), "frac": round(ach_gi / peak_fit, 4),
                         "clock_GHz": clock_ghz, "cycles_per_instruction": cyc_per_inst,
                         "source": model + ", profiles/r03_ubench_issue.txt, profiles/r03_power_clock.txt, profiles/r03_operand_ab.txt"}
         sec["power"] = power

@@ -184,12 +184,18 @@ class Engine:
         t = _torch()
         if not ten.is_contiguous():
             raise ValueError("operands must be contiguous tensors")
-        fmt = {t.int8: FMT_I8, t.int16: FMT_I16, t.int32: FMT_I32}.get(ten.dtype, FMT_WORDS)
-        if ten.dtype == self.torch_dtype and ten.dim() == 3:
+        # the shape names the format (torch has no unsigned 16 / 32-bit types, so a u16 / u32 ring's words share int16 / int32
+        # with the compact formats): limb words are 3-D [count][nmoduli][degree], compact polynomials 2-D [count][degree];
+        # anything else is ambiguous and refused
+        compact = {t.int8: FMT_I8, t.int16: FMT_I16, t.int32: FMT_I32}.get(ten.dtype)
+        if ten.dim() == 3 and ten.dtype == self.torch_dtype and tuple(ten.shape[1:]) == (self.nmoduli, self.degree):
             fmt = FMT_WORDS
+        elif ten.dim() == 2 and compact is not None and ten.shape[1] == self.degree and not words_only:
+            fmt = compact
+        else:
+            raise ValueError("operand shape / dtype: limb words are [count][nmoduli][degree] of the ring's word type, compact "
+                             "polynomials [count][degree] int8 / int16 / int32")
         per = self.degree if fmt != FMT_WORDS else self.words_per_poly
-        if (fmt == FMT_WORDS and ten.dtype != self.torch_dtype) or ten.numel() % per or (words_only and fmt != FMT_WORDS):
-            raise ValueError("operand shape / dtype")
         count = ten.numel() // per
         return _lib.Operand(ten.data_ptr(), 0 if count == 1 else 1, fmt), count
 

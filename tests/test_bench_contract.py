@@ -74,7 +74,7 @@ def test_two_rank_launch_line_of_the_driver():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, NFLHIP_BENCH_BACKEND="gloo", NFLHIP_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, NFLHIP_BENCH_BACKEND="gloo", NFLHIP_BENCH_ONE_DEVICE="1", NFLHIP_BENCH_D_SHARD="1024")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
                         "--warmup", "1", "--batch", "512", "--scatter-gather"], capture_output=True, text=True, timeout=900, env=env)
@@ -84,7 +84,14 @@ def test_two_rank_launch_line_of_the_driver():
     d = json.loads(lines[0])
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 1024
     assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.2
-    assert "cpu_baseline" not in d and "extras" not in d            # rank 0 at N = 1 only
+    assert "cpu_baseline" not in d and set(d["extras"]) == {"configs"} and set(d["extras"]["configs"]) == {"D"}   # the rest: rank 0 at N = 1 only
+    # BASELINE configs[3] in the N > 1 line: global batch = N x shard (2^17 per GPU on a real node; shrunk here, two ranks share a device)
+    dd = d["extras"]["configs"]["D"]
+    assert "error" not in dd, dd
+    assert dd["n_gpus"] == 2 and dd["batch_per_gpu"] == 1024 and dd["global_batch"] == 2 * dd["batch_per_gpu"]
+    assert dd["shard_is_baseline_shard"] is False and dd["is_baseline_config_4"] is False
+    assert dd["self_check"] is True and dd["checksum_of_checksums"]["ok"] is True and dd["checksum_of_checksums"]["shards"] == 2
+    assert abs(dd["value"] - dd["global_batch"] / (dd["ms_per_step"] * 1e-3)) / dd["value"] < 0.05
     sg = d["scatter_gather"]
     assert sg["polymul_per_s_incl_scatter_gather"] > 0 and sg["bytes_moved"] == 3 * 512 * 4 * 4096 * 8
     assert d["config"]["self_check"] is True
@@ -96,7 +103,7 @@ def test_plain_gpus_n_launches_n_ranks_itself_or_refuses():
     127.0.0.1) and reports n_gpus 2 -- here on one device through the test knobs; without the knob, on a box with fewer
     than N devices, it exits non-zero instead of printing an n_gpus the run did not have"""
     import torch
-    env = dict(os.environ, NFLHIP_BENCH_BACKEND="gloo", NFLHIP_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, NFLHIP_BENCH_BACKEND="gloo", NFLHIP_BENCH_ONE_DEVICE="1", NFLHIP_BENCH_D_SHARD="1024")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512"],
@@ -128,7 +135,17 @@ def test_headline_line_carries_sustained_independent_secondary_and_side_configs(
     assert sus["unit"] == "polymul/s" and sus["seconds"] > 1.5 and 0 < sus["frac"] < 1 and sus["value"] > 0
     sec = d["roofline"]["secondary"]
     assert sec["peak"] == 1228.8 and abs(sec["frac"] - sec["achieved"] / sec["peak"]) < 1e-3
-    assert sec["model"]["kind"] == "fitted" and "peak_at_measured_clock" in sec["model"] and sec["opcode_grid"]["clock_GHz"] == 2.4
+    assert "model" not in sec and sec["fitted"]["kind"] == "fitted" and "peak_at_measured_clock" in sec["fitted"] and sec["opcode_grid"]["clock_GHz"] == 2.4
+    # what binds, said in the line: HBM stays the declared roofline; the kernel is VALU-issue / power bound
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and "valu-issue" in rf["binding"] and rf["ceiling_frac_no_memory"] == 0.32 and "profiles/" in rf["ceiling_source"]
+    assert abs(rf["frac_of_ceiling"] - rf["frac"] / rf["ceiling_frac_no_memory"]) < 2e-3 and rf["frac_of_ceiling"] < 1
+    # BASELINE configs[3] for ONE shard: 2^17 polynomials resident on this GPU, its own clock and checksum of checksums
+    dd = d["extras"]["configs"]["D"]
+    assert "error" not in dd, dd
+    assert dd["batch_per_gpu"] == 1 << 17 and dd["n_gpus"] == 1 and dd["global_batch"] == 1 << 17 and dd["shard_is_baseline_shard"] is True
+    assert dd["is_baseline_config_4"] is False and dd["self_check"] is True and dd["checksum_of_checksums"]["ok"] is True
+    assert dd["value"] > 0 and abs(dd["value"] - dd["global_batch"] / (dd["ms_per_step"] * 1e-3)) / dd["value"] < 0.05
     lwe = d["extras"]["lwe"]
     assert "error" not in lwe and lwe["same_ciphertexts"] is True and lwe["fused"]["decrypts_to_zero"] is True
     assert lwe["fused"]["encryptions_per_s"] > 1.3 * lwe["unfused"]["encryptions_per_s"]

@@ -219,3 +219,20 @@ def test_both_grids_of_the_fused_kernels_give_the_same_words(engine_factory):
     finally:
         _lib.lib.nflhip_debug_fused_grid(0)
         e.gauss_destroy(g)
+
+
+def test_ambiguous_operand_shapes_are_refused(engine_factory):
+    """torch has no unsigned 16 / 32-bit types: a u32 ring's words and the compact int32 format share a dtype, so the shape
+    must name the format -- [count][nmoduli][degree] words, [count][degree] compact -- and anything else raises."""
+    import torch
+    e = engine_factory(32, 1024, 2)
+    w, k = e.empty(4), e.empty(1)
+    good = e.fwd_fma(w, k, w.clone())
+    assert good.shape == w.shape
+    compact = torch.zeros((4, 1024), dtype=torch.int32, device=w.device)
+    e.fwd_fma(compact, k, compact)                                    # 2-D int32: one signed integer per coefficient
+    for bad in (w.view(-1), w.view(4, 2048), w.view(8, 1024), w.view(4, 2, 32, 32), compact.view(-1), compact.view(4, 2, 512)):
+        with pytest.raises(ValueError):
+            e.fwd_fma(bad, k, w)
+    with pytest.raises(ValueError):
+        e.fwd_fma(w, compact, w)                                       # keys are words
