@@ -143,7 +143,7 @@ def measure_traffic(workload, batch):
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", str(steps),
-                   "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline", "--no-traffic", "--no-rccl"]
+                   "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline", "--no-traffic", "--no-rccl", "--no-side-configs"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)

