@@ -598,16 +598,27 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     // pipeline: launch L = forward pass of chunk L, block products of chunk L-1, inverse pass of chunk L-2.
     const size_t pw = ctx->shape.nm * ctx->shape.n;
     size_t nchunk = (size_t)kPipeChunks;
+#ifdef NFLHIP_ABLATION_KNOBS   // experiment builds only (tools/sessions/gpu_round5_a.sh): chunk count at run time
+    if (const char *ev = getenv("NFLHIP_PIPE_CHUNKS_RT")) nchunk = (size_t)atoi(ev) > 0 ? (size_t)atoi(ev) : nchunk;
+    static const bool alias_chunks = getenv("NFLHIP_ABLATE_PIPE_ALIAS") != nullptr;
+#endif
     if (nchunk * 2 > batch) nchunk = batch >= 2 ? batch / 2 : 1;
     auto lo_of = [&](size_t ch) { return batch * ch / nchunk; };
+#ifdef NFLHIP_ABLATION_KNOBS   // ... and every chunk laid over chunk 0's memory (WRONG results by construction: the roles of
+    // neighbouring launches then share one window of a, b, c and the scratch that fits the 256 MiB Infinity Cache -- what
+    // the plan would run at if none of its passes reached HBM)
+    auto at_of = [&](size_t ch) { return alias_chunks ? (size_t)0 : lo_of(ch); };
+#else
+    auto at_of = lo_of;
+#endif
     bool supported = true;
     if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));  // a previous call on another stream
     if (!cap && ctx->ev_prev_valid)  // ... or a helper-stream plan (polymul_ntt_dev at this shape) still reading s0
       for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
     for (size_t L = 0; L < nchunk + 2 && supported; ++L) {
       const bool hf = L < nchunk, hv = L >= 1 && L - 1 < nchunk, hi = L >= 2 && L - 2 < nchunk;
-      const size_t f0 = hf ? lo_of(L) : 0, v0 = hv ? lo_of(L - 1) : 0, i0 = hi ? lo_of(L - 2) : 0;
-      const int cf = hf ? (int)(lo_of(L + 1) - f0) : 0, cv = hv ? (int)(lo_of(L) - v0) : 0, ci = hi ? (int)(lo_of(L - 1) - i0) : 0;
+      const size_t f0 = hf ? at_of(L) : 0, v0 = hv ? at_of(L - 1) : 0, i0 = hi ? at_of(L - 2) : 0;
+      const int cf = hf ? (int)(lo_of(L + 1) - lo_of(L)) : 0, cv = hv ? (int)(lo_of(L) - lo_of(L - 1)) : 0, ci = hi ? (int)(lo_of(L - 1) - lo_of(L - 2)) : 0;
       // (b already transformed: its blocks are read from the caller's array by the block products, no forward pass, no scratch)
       e = launch_polymul_pipe64k_u64(ctx->shape, ctx->tabs, (uint64_t *)c + v0 * pw, (const uint64_t *)s0 + v0 * pw,
                                      (b_is_ntt ? (const uint64_t *)b : (const uint64_t *)s1) + v0 * pw, cv, (const uint64_t *)a + f0 * pw,

@@ -85,6 +85,14 @@ def sp(pair):
 #   nobar  the workgroup barriers are dropped as well
 #   nobfly the butterflies of the register passes are dropped (memory, LDS and the point-wise step remain)
 ABLATE = set(filter(None, os.environ.get("NFL_GEN_ABLATE", "").split(",")))
+# scratchN (N a power of two): the n = 65536 pipeline's scratch rows a', b' of the WHOLE batch aliased onto N rows, i.e. the
+# forward pass's writes and the block products' reads served by the on-die caches instead of HBM (round 5: what is the
+# prize of a plan whose scratch never leaves the chip?)
+SCRATCH_ALIAS = next((int(x[7:]) for x in ABLATE if x.startswith("scratch")), 0)
+# bprimeN: the same question for rows of 32768 words (workload F): b' = NTT(b) makes a round trip through the context's
+# scratch between the two launches of the composed product -- here over N row blocks instead of one per row
+BPRIME_ALIAS = next((int(x[6:]) for x in ABLATE if x.startswith("bprime")), 0)
+ALIAS_ROWS = ()   # set by build_row32k for its "_s" kinds: which of the row pointers s16 / s18 / s20 prologue16k aliases
 
 
 class Emitter:
@@ -1040,7 +1048,15 @@ def prologue16k(em, vm, stop=None, kind="polymul", key_row=False, compact_x=Fals
         R("s_and_b32 s42, s42, 3")
     R("s_lshr_b32 s43, s42, %d" % (32 - 15 - ROW_LG,))
     R("s_lshl_b32 s42, s42, %d" % (15 + ROW_LG,))        # * 4096 G words * 8 bytes
+    if ALIAS_ROWS:   # ablation "bprimeN": the scratch operand of the composed 32768-word product laid over N row blocks (cache-resident)
+        R("s_lshr_b32 s44, s42, %d" % (15 + ROW_LG,))
+        R("s_and_b32 s44, s44, %d" % (BPRIME_ALIAS - 1,))
+        R("s_lshl_b32 s44, s44, %d" % (15 + ROW_LG,))
     for base, row in ((6, 16), (8, 18), (4, 20)):
+        if row in ALIAS_ROWS:
+            R("s_add_u32 s%d, s%d, s44" % (row, base))
+            R("s_addc_u32 s%d, s%d, 0" % (row + 1, base + 1))
+            continue
         R("s_add_u32 s%d, s%d, s42" % (row, base))
         R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
     if compact_x:
@@ -1869,7 +1885,11 @@ def build_row32k(kind="fwd"):
                 uses += [(name + "ab"[f], s_, g) for s_ in (3, 2, 1, 0) for g in range(1 << s_)]
         uses += [("I0", s_, g) for s_ in (2, 1, 0) for g in range(1 << s_)]
     ring = Ring(em, vm, RING_SLOTS, uses, passes)
+    global ALIAS_ROWS
+    if BPRIME_ALIAS and scratch_layout:   # fwd_s writes b' through s20, polymul_ntt_s reads it through s18
+        ALIAS_ROWS = (20,) if kind == "fwd" else (18,)
     prologue16k(em, vm, None, "none", key_row=fused_inv, compact_x=compact_x)
+    ALIAS_ROWS = ()
     AX = T(0, 0)   # exchange address scratch (the butterfly temporaries are idle during exchanges)
 
     def block_base(srow, boff):                           # s[86:87] = first word of block q + boff of the row at srow
@@ -3183,9 +3203,18 @@ def build_pipe(logn=None, fused=False, b_ntt=False):
         R("s_lshl_b32 s42, s87, %d" % (PIPE_LOGN + 3,))      # row * n * 8
         R("s_lshl_b32 s86, s89, %d" % CG_LOG)
         R("s_add_u32 s42, s42, s86")                         # + the bytes of q column groups (no carry: the low bits were zero)
-        for row in (16, 20):
-            R("s_add_u32 s%d, s%d, s42" % (row, row))
-            R("s_addc_u32 s%d, s%d, s43" % (row + 1, row + 1))
+        if SCRATCH_ALIAS:   # ablation: the scratch rows of the whole batch laid over a window of SCRATCH_ALIAS rows (cache-resident)
+            R("s_add_u32 s16, s16, s42")
+            R("s_addc_u32 s17, s17, s43")
+            R("s_and_b32 s44, s87, %d" % (SCRATCH_ALIAS - 1,))
+            R("s_lshl_b32 s44, s44, %d" % (PIPE_LOGN + 3,))
+            R("s_add_u32 s44, s44, s86")
+            R("s_add_u32 s20, s20, s44")
+            R("s_addc_u32 s21, s21, 0")
+        else:
+            for row in (16, 20):
+                R("s_add_u32 s%d, s%d, s42" % (row, row))
+                R("s_addc_u32 s%d, s%d, s43" % (row + 1, row + 1))
         R("s_mov_b32 s90, 1")                                # K_F1 of the row's first four stages
     emit_mc_load(em)
     mark = len(em.lines)
@@ -3228,9 +3257,20 @@ def build_pipe(logn=None, fused=False, b_ntt=False):
         R("s_add_u32 s42, s42, s89")                         # block index = row * (n / 4096) + blk
         R("s_lshr_b32 s43, s42, 17")
         R("s_lshl_b32 s42, s42, 15")
-        for base, row in ((6, 16), (8, 18), (4, 20)):
-            R("s_add_u32 s%d, s%d, s42" % (row, base))
-            R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
+        if SCRATCH_ALIAS and not b_ntt:
+            R("s_and_b32 s44, s87, %d" % (SCRATCH_ALIAS - 1,))
+            R("s_lshl_b32 s44, s44, %d" % RL)
+            R("s_add_u32 s44, s44, s89")
+            R("s_lshl_b32 s44, s44, 15")
+            for base, row in ((6, 16), (8, 18)):
+                R("s_add_u32 s%d, s%d, s44" % (row, base))
+                R("s_addc_u32 s%d, s%d, 0" % (row + 1, base + 1))
+            R("s_add_u32 s20, s4, s42")
+            R("s_addc_u32 s21, s5, s43")
+        else:
+            for base, row in ((6, 16), (8, 18), (4, 20)):
+                R("s_add_u32 s%d, s%d, s42" % (row, base))
+                R("s_addc_u32 s%d, s%d, s43" % (row + 1, base + 1))
     R("s_mov_b32 s88, %d" % (PIPE_LOGN - 12,))
     R("s_lshl_b32 s90, 1, s88")
     R("s_add_u32 s90, s90, s89")                         # Kf = 2^r + blk
