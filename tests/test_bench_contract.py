@@ -159,3 +159,6 @@ def test_headline_line_carries_sustained_independent_secondary_and_side_configs(
         assert "error" not in c, c
         assert c["self_check"] is True and c["value"] > 0 and 0 < c["frac"] < 1 and c["traffic_ratio"] is not None and c["traffic_ratio"] > 0.98
     assert cfg["E"]["crt_lift"]["value"] > 0 and cfg["E"]["crt_lift"]["limbs_per_coefficient"] == 30
+    one = cfg["E"]["polymul_plus_crt_lift"]     # BASELINE configs[4] as ONE figure: slower than either part, faster than their serial sum allows
+    assert one["unit"] == "polys/s" and 0 < one["value"] < min(cfg["E"]["value"], cfg["E"]["crt_lift"]["value"])
+    assert one["ms_per_step"] < 1.15 * (cfg["E"]["ms_per_step"] + cfg["E"]["crt_lift"]["ms_per_step"])
