@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NFLHIP_ABI_VERSION 4
+#define NFLHIP_ABI_VERSION 5
 
 typedef struct nflhip_ctx nflhip_ctx;
 
@@ -306,7 +306,14 @@ enum {
   /* OR into NFLHIP_DIST_ZO / NFLHIP_DIST_HWT: store +1 exactly as the reference does, as the non-canonical word
    * p + 1 (`pm + (rnd & 2)`, core.hpp:341,387), so that raw _data images diff clean against the CPU library.
    * Default (flag absent): the canonical 1, which the engine's own operators require (ops.hpp:131,148). */
-  NFLHIP_DIST_REFERENCE_WORDS = 0x100
+  NFLHIP_DIST_REFERENCE_WORDS = 0x100,
+  /* OR into NFLHIP_DIST_UNIFORM: the NARROW draw -- residue word g reads the limb-width LANE g of the keystream (bytes
+   * [g w, (g + 1) w), little endian, w = limb bytes) instead of one 64-bit word, in a keystream domain of its own.  Same map
+   * from the lane to the residue (mask, one conditional subtraction), so the distribution is the reference's; a u16 / u32
+   * polynomial costs a quarter / half of the ChaCha20 rounds (measured: profiles/r05_sampler_rates.txt).  The values differ
+   * from the wide rule's for the same (key, stream_id) -- a different domain, by design: what the wide rule produces, and
+   * every digest recorded from it, keeps its meaning. */
+  NFLHIP_DIST_NARROW = 0x200
 };
 /* KEYSTREAM DISCIPLINE.  A (key, stream_id, distribution) triple names one keystream: two calls that share all
  * three produce the same values.  Different distributions never share keystream words even for the same
@@ -339,6 +346,15 @@ typedef struct nflhip_gauss nflhip_gauss;
 int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsigned security, unsigned samples,
                         double center);
 int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g);
+/* DRAW WIDTH of every sampler that takes this table: 64 (default, the rule above) or 32 -- the narrow draw: the top 32 bits
+ * of coefficient g's uniform number are the 32-bit lane g of the stream (key, stream_id) in the Gaussian samplers' narrow
+ * domain, the next 32 bits lane g of a second domain that is only generated when the first lane ties with the top half of
+ * a table entry the search meets (~entries x 2^-32 per sample), the lower words as above.  The sample is still EXACTLY the
+ * full-precision inversion of that number; it costs half the ChaCha20 rounds and 32-bit compares.  Values differ from the
+ * 64-bit draw's for the same (key, stream_id): other keystream domains.  Sequence forms then need degree >= 16.  Set it
+ * before the table is used by concurrent calls (it is a plain field). */
+int nflhip_gauss_set_draw_bits(nflhip_gauss *g, int bits);
+int nflhip_gauss_draw_bits(const nflhip_gauss *g);
 /* the same table without a device (host arithmetic only: what nflhip_gauss_create uploads); h_table may be NULL to
  * query the sizes first, cap_words = capacity of h_table in 64-bit words */
 int nflhip_gauss_table(double sigma, unsigned security, unsigned samples, double center, long long *x_min, size_t *entries,

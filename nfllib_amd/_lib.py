@@ -16,7 +16,8 @@ TAB_PSI, TAB_MODULUS, TAB_INVDEGREE = range(3)
 TAB_PHIS, TAB_SHOUPPHIS, TAB_INVPOLY_INVPHIS, TAB_SHOUPINVPOLY_INVPHIS, TAB_OMEGAS, TAB_INVOMEGAS = range(3, 9)
 ROW_INVERSE_TABLES, ROW_BITREV_IO = 1, 2
 DIST_REFERENCE_WORDS = 0x100
-ABI_VERSION = 4
+DIST_NARROW = 0x200
+ABI_VERSION = 5
 FMT_WORDS, FMT_I8, FMT_I16, FMT_I32 = range(4)
 
 # every symbol include/nflhip.h declares: (name, restype, argtypes)
@@ -70,6 +71,8 @@ SYMBOLS = [
     ("nflhip_random_words_dev", _i, [_vp, _vp, _u64, _sz, _vp, _u64, _vp]),
     ("nflhip_gauss_create", _i, [_vp, C.POINTER(_vp), C.c_double, C.c_uint, C.c_uint, C.c_double]),
     ("nflhip_gauss_destroy", _i, [_vp, _vp]),
+    ("nflhip_gauss_set_draw_bits", _i, [_vp, _i]),
+    ("nflhip_gauss_draw_bits", _i, [_vp]),
     ("nflhip_gauss_table", _i, [C.c_double, C.c_uint, C.c_uint, C.c_double, C.POINTER(C.c_longlong), C.POINTER(_sz), C.POINTER(_i),
                                C.POINTER(C.c_uint), C.POINTER(C.c_double), _vp, _sz]),
     ("nflhip_gauss_info", _i, [_vp, C.POINTER(C.c_longlong), C.POINTER(_sz), C.POINTER(_i), C.POINTER(C.c_uint),

@@ -598,9 +598,8 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     // pipeline: launch L = forward pass of chunk L, block products of chunk L-1, inverse pass of chunk L-2.
     const size_t pw = ctx->shape.nm * ctx->shape.n;
     size_t nchunk = (size_t)kPipeChunks;
-#ifdef NFLHIP_ABLATION_KNOBS   // experiment builds only (tools/sessions/gpu_round5_a.sh): chunk count at run time
-    if (const char *ev = getenv("NFLHIP_PIPE_CHUNKS_RT")) nchunk = (size_t)atoi(ev) > 0 ? (size_t)atoi(ev) : nchunk;
-    static const bool alias_chunks = getenv("NFLHIP_ABLATE_PIPE_ALIAS") != nullptr;
+#ifdef NFLHIP_ABLATION_KNOBS   // experiment builds only (tools/sessions/gpu_round5_a.sh): chunk count at run time, chunk aliasing
+#include "ablation_knobs.inc"
 #endif
     if (nchunk * 2 > batch) nchunk = batch >= 2 ? batch / 2 : 1;
     auto lo_of = [&](size_t ch) { return batch * ch / nchunk; };
@@ -1393,7 +1392,9 @@ struct nflhip_gauss {
   GaussTable tab;
   uint64_t *d_cdt = nullptr;
   int device = 0;
+  int draw_bits = 64;   // keystream bits a sample normally consumes (nflhip_gauss_set_draw_bits): 64, or 32 = the narrow draw
 };
+static inline int gauss_narrow(const nflhip_gauss *g) { return g->draw_bits == 32 ? 1 : 0; }
 
 int nflhip_random_words_dev(nflhip_ctx *ctx, uint64_t *d_out, uint64_t first_word, size_t nwords, const unsigned char *key,
                             uint64_t stream_id, void *stream) {
@@ -1409,8 +1410,10 @@ int nflhip_sample_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t batch,
   CHECK_CTX(ctx);
   if (!key || (batch && !d)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
   const int dist_in = dist;
-  dist &= ~NFLHIP_DIST_REFERENCE_WORDS;
+  dist &= ~(NFLHIP_DIST_REFERENCE_WORDS | NFLHIP_DIST_NARROW);
   if (dist < NFLHIP_DIST_UNIFORM || dist > NFLHIP_DIST_HWT) return fail(ctx, NFLHIP_ERR_INVALID, "unknown distribution");
+  if ((dist_in & NFLHIP_DIST_NARROW) && dist != NFLHIP_DIST_UNIFORM)
+    return fail(ctx, NFLHIP_ERR_INVALID, "the narrow draw applies to the uniform rule only (the others read one word per coefficient)");
   if (dist == NFLHIP_DIST_BOUNDED) {
     if (p0 == 0 || p0 >= (((uint64_t)1) << 62)) return fail(ctx, NFLHIP_ERR_INVALID, "upper_bound out of range");
     for (uint64_t p : ctx->h_P)  // core.hpp:205-210
@@ -1456,10 +1459,10 @@ int nflhip_sample_gauss_seq_dev(nflhip_ctx *ctx, void *d, size_t batch, const nf
   const long long x0 = g->tab.x_min;
   hipError_t e = DISPATCH_T(
       ctx,
-      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride),
-      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride),
-      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride));
-  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8");
+      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g)),
+      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g)),
+      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g)));
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8 (>= 16 under the 32-bit draw)");
   if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss_seq");
   return NFLHIP_OK;
 }
@@ -1509,6 +1512,13 @@ int nflhip_gauss_table(double sigma, unsigned security, unsigned samples, double
   return NFLHIP_OK;
 }
 
+int nflhip_gauss_set_draw_bits(nflhip_gauss *g, int bits) {
+  if (!g || (bits != 64 && bits != 32)) return NFLHIP_ERR_INVALID;
+  g->draw_bits = bits;
+  return NFLHIP_OK;
+}
+int nflhip_gauss_draw_bits(const nflhip_gauss *g) { return g ? g->draw_bits : 0; }
+
 int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g) {
   if (!g) return NFLHIP_OK;
   (void)ctx;  // never dereferenced: a FastGaussianNoise with static storage may outlive the context that built its table
@@ -1541,9 +1551,9 @@ int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t 
   const long long x0 = g->tab.x_min;
   hipError_t e = DISPATCH_T(
       ctx,
-      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st),
-      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st),
-      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st));
+      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g)),
+      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g)),
+      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g)));
   if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss");
   return NFLHIP_OK;
 }
@@ -1564,8 +1574,8 @@ static int gauss_small_any(nflhip_ctx *ctx, void *d_out, int format, size_t firs
   for (uint64_t p : ctx->h_P)
     if (mag * amplifier >= p) return fail(ctx, NFLHIP_ERR_INVALID, "the samples are not below the modulus");
   hipError_t e = launch_gauss_small(ctx->shape, d_out, format, first_poly, batch, g->d_cdt, g->tab.words, (int)g->tab.entries,
-                                    g->tab.x_min, amplifier, key, stream_id, (hipStream_t)stream, seq_on, seq_stride);
-  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8");
+                                    g->tab.x_min, amplifier, key, stream_id, (hipStream_t)stream, seq_on, seq_stride, gauss_narrow(g));
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8 (>= 16 under the 32-bit draw)");
   if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss_small");
   return NFLHIP_OK;
 }
@@ -1588,7 +1598,7 @@ int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sampl
   if (!key || !g || (count && !d_out)) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
   if (g->device != ctx->device) return fail(ctx, NFLHIP_ERR_INVALID, "gaussian table lives on another device");
   hipError_t e = launch_gauss_noise((long long *)d_out, first_sample, count, g->d_cdt, g->tab.words, (int)g->tab.entries,
-                                    g->tab.x_min, key, stream_id, (hipStream_t)stream);
+                                    g->tab.x_min, key, stream_id, (hipStream_t)stream, gauss_narrow(g));
   if (e != hipSuccess) return hipfail(ctx, e, "gauss_noise");
   return NFLHIP_OK;
 }

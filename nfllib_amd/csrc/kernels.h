@@ -109,7 +109,8 @@ hipError_t launch_crt_lift_wide(const Shape &s, const DevTables &t, uint64_t *li
 void set_gauss_tie_shift(int shift);  // debug entry point nflhip_debug_gauss_tie_shift (include/nflhip_debug.h)
 hipError_t launch_random_words(uint64_t *out, uint64_t first_word, size_t nwords, const unsigned char *key32,
                                uint64_t stream_id, hipStream_t st);
-// dist: 0 uniform | 1 bounded (p0 = upper bound, p1 = amplifier) | 2 zero/one (p0 = rho) | 3 hamming weight (p0 = h)
+// dist: 0 uniform | 1 bounded (p0 = upper bound, p1 = amplifier) | 2 zero/one (p0 = rho) | 3 hamming weight (p0 = h);
+// | 0x100 reference words (zero/one, hamming weight) | 0x200 narrow draw (uniform: keystream lanes of the limb width)
 template <typename T>
 hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, int dist, uint64_t p0,
                          uint64_t p1, const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on = 0,
@@ -118,19 +119,21 @@ hipError_t launch_inner_fwd_fast_u32(const Shape &s, const DevTables &t, const u
                                      hipStream_t st);
 hipError_t launch_inner_inv_fast_u32(const Shape &s, const DevTables &t, const uint32_t *src, const uint32_t *mul,
                                      uint32_t *dst, size_t rows, hipStream_t st);
+// narrow (every Gaussian launcher): the table's draw width is 32 bits (nflhip_gauss_set_draw_bits) -- domains 7 / 8 of the keystream
 hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *cdt, int words,
-                              int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st);
+                              int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st,
+                              int narrow = 0);
 template <typename T>
 hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
                                const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
                                const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on = 0,
-                               uint64_t seq_stride = 0);
+                               uint64_t seq_stride = 0, int narrow = 0);
 
 // compact Gaussian polynomials (one signed integer x * amp per coefficient; format 1 int8 | 2 int16 | 3 int32) and their
 // expansion into residue words (format 0 = word rows: a strided gather); stride in polynomials, 0 = shared
 hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_poly, size_t batch, const uint64_t *cdt,
                               int words, int entries, long long x_min, uint64_t amp, const unsigned char *key32,
-                              uint64_t stream_id, hipStream_t st, int seq_on = 0, uint64_t seq_stride = 0);
+                              uint64_t stream_id, hipStream_t st, int seq_on = 0, uint64_t seq_stride = 0, int narrow = 0);
 template <typename T>
 hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const void *src, int format, unsigned stride,
                                size_t batch, hipStream_t st);

@@ -31,6 +31,16 @@ struct ChaChaKey {
 };
 // tags: NFLHIP_DIST_* + 1; 0 = the raw words of nflhip_random_words_dev, kDomGauss for both Gaussian entry points
 static constexpr int kDomRaw = 0, kDomGauss = 5;
+// NARROW DRAWS (round 5): the wide rules above spend one 64-bit keystream word per value whatever the limb width, so a u16 /
+// u32 polynomial pays 4x / 2x the ChaCha20 rounds it needs, and a Gaussian sample -- decided by its first few bits in all
+// but ~entries x 2^-32 of the cases -- as many as a uniform 62-bit residue.  Under the narrow rules a value reads a LANE of
+// the keystream: residue word g of poly(uniform) the limb-width lane g (bytes [g w, (g + 1) w) of the stream, little
+// endian), Gaussian coefficient g the 32-bit lane g.  They live in their OWN domains, so what the wide rules produce for a
+// (key, stream id) -- and every digest recorded from them -- keeps its meaning:
+//   6  poly(uniform), lanes of the limb width (NFLHIP_DIST_UNIFORM | NFLHIP_DIST_NARROW)
+//   7  Gaussian, 32-bit draw: lane g of this stream is the TOP half of coefficient g's first word
+//   8  ... and lane g of this one its lower half, read only when the top half ties with a table entry's
+static constexpr int kDomUniformNarrow = 6, kDomGauss32 = 7, kDomGauss32Ref = 8;
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
@@ -167,6 +177,69 @@ __global__ void __launch_bounds__(256) k_sample_uniform8(T *d, const ModConst<T>
     for (int k = 0; k < 8; ++k) {
       const size_t idx = (tile << 9) + (size_t)(k * 64 + lane);
       if (idx < total) d[idx] = (T)o[k];
+    }
+  }
+}
+
+// ---- poly(uniform), narrow draw: residue word g reads the limb-width lane g of the stream.  One keystream block per thread =
+// L = 64 / sizeof(T) consecutive residue words = 64 contiguous bytes of the row, masked, reduced and stored by the thread
+// itself.  Needs rows of at least L words (a block never straddles a row) and, in sequence mode, nothing else.
+template <typename T> __device__ __forceinline__ uint64_t uniform_lanes(uint64_t x, T mask, T p) {
+  uint64_t r = 0;
+#pragma unroll
+  for (int l = 0; l < (int)(8 / sizeof(T)); ++l) {
+    T v = (T)((T)(x >> (8 * sizeof(T) * l)) & mask);
+    if (v >= p) v = (T)(v - p);
+    r |= (uint64_t)v << (8 * sizeof(T) * l);
+  }
+  return r;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_sample_uniform_narrow(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm,
+                                                               uint64_t first_word, size_t total, ChaChaKey key, uint64_t nonce) {
+  constexpr int LG = sizeof(T) == 2 ? 5 : sizeof(T) == 4 ? 4 : 3;   // log2 of the lanes per block
+  const uint64_t fb = first_word >> LG;                             // first_word and total are multiples of the row length
+  const size_t nblk = total >> LG;
+  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (size_t)gridDim.x * blockDim.x) {
+    uint64_t w[8];
+    const uint64_t row = (fb + b) >> (logn - LG);
+    const int cm = (row >> 32) == 0 ? (int)((uint32_t)row % (uint32_t)nm) : (int)(row % (uint64_t)nm);
+    if (key.seq_on) {
+      const uint64_t poly = row / (uint64_t)nm;
+      chacha20_block(key, (fb + b) - ((poly * (uint64_t)nm) << (logn - LG)), nonce + poly * key.seq_stride, w);
+    } else {
+      chacha20_block(key, fb + b, nonce, w);
+    }
+    const ModConst<T> c = mc[cm];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = uniform_lanes<T>(w[j], c.mask, c.p);
+    uint4 *dst = reinterpret_cast<uint4 *>(d + (b << LG));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dst[q] = make_uint4((uint32_t)w[2 * q], (uint32_t)(w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)(w[2 * q + 1] >> 32));
+  }
+}
+// any row length, any alignment: the lane's modulus is looked up lane by lane (rows shorter than a keystream block)
+template <typename T>
+__global__ void k_sample_uniform_narrow_any(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_word,
+                                            size_t total, ChaChaKey key, uint64_t nonce) {
+  constexpr int L = 64 / sizeof(T);
+  const uint64_t per = key.seq_on ? ((uint64_t)nm << logn) : total;     // lanes of one stream (sequence mode: one polynomial)
+  const uint64_t base = key.seq_on ? 0 : first_word;                    // ... and the lane its first value reads
+  const uint64_t fb = base / L, bps = (base + per + L - 1) / L - fb;    // blocks per stream
+  const uint64_t nstreams = key.seq_on ? total / per : 1;
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nstreams * bps; idx += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t sidx = idx / bps, blk = fb + idx % bps;
+    uint64_t w[8];
+    chacha20_block(key, blk, nonce + (key.seq_on ? sidx * key.seq_stride : 0), w);
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const uint64_t g = blk * L + j;
+      if (g < base || g >= base + per) continue;
+      const ModConst<T> c = mc[(int)((g >> logn) % (uint64_t)nm)];
+      T v = (T)((T)(w[j / (L / 8)] >> (8 * sizeof(T) * (j % (L / 8)))) & c.mask);
+      if (v >= c.p) v = (T)(v - c.p);
+      d[sidx * per + (g - base)] = v;
     }
   }
 }
@@ -369,16 +442,181 @@ __device__ __forceinline__ void stage_gauss_top(uint64_t *top, const uint64_t *_
   __syncthreads();
 }
 
+// ---- the 32-bit draw (nflhip_gauss_set_draw_bits(g, 32)).  Coefficient g's uniform number is
+//   ( lane g of stream 7 , lane g of stream 8 , secondary words as above )       (32 + 32 + 64 (W - 1) bits, most significant first)
+// and the sample is its full-precision inversion, exactly as under the 64-bit draw.  The search runs on the 32-bit lane
+// against the table's top halves; only when the lane EQUALS a top half it meets (probability ~entries x 2^-32 per sample)
+// is the lower half fetched (one more keystream block) and the sample redone by the exact search.  Half the ChaCha20 rounds
+// per sample, and 32-bit compares instead of 64-bit ones.
+__device__ __forceinline__ uint32_t lane32_of(const uint64_t (&w)[8], unsigned j) {   // (no dynamic register indexing)
+  uint64_t x = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x = (int)(j >> 1) == q ? w[q] : x;
+  return (uint32_t)(x >> (32 * (j & 1)));
+}
+__device__ __noinline__ uint64_t gauss32_first_word(uint32_t top, uint64_t g, const ChaChaKey &key, uint64_t nonce) {
+  ChaChaKey kr = key;
+  kr.dom = ((uint64_t)kDomGauss32Ref) << 56;
+  uint64_t blk[8];
+  chacha20_block(kr, g >> 4, nonce, blk);
+  return ((uint64_t)top << 32) | (uint64_t)lane32_of(blk, (unsigned)(g & 15));
+}
+// the first word of coefficient g in full (both halves): the per-sample paths
+__device__ __forceinline__ uint64_t gauss32_word(uint64_t g, const ChaChaKey &key, uint64_t nonce) {
+  uint64_t blk[8];
+  chacha20_block(key, g >> 4, nonce, blk);
+  return gauss32_first_word(lane32_of(blk, (unsigned)(g & 15)), g, key, nonce);
+}
+// sixteen searches side by side over the table's top halves in LDS (`top`, one 32-bit word per entry)
+template <int W>
+__device__ __forceinline__ void gauss_search16(const uint64_t (&w)[8], uint64_t g0, const uint32_t *top,
+                                               const uint64_t *__restrict__ cdt, int entries, int iters, int tie_shift,
+                                               const ChaChaKey &key, uint64_t nc, int (&out)[16]) {
+  int lo[16], hi[16];
+  uint32_t r[16];
+  unsigned tied = 0;
+  const int ts = tie_shift > 31 ? 31 : tie_shift;   // (the test hook widens the ties of this stage too)
+#pragma unroll
+  for (int c = 0; c < 16; ++c) lo[c] = 0, hi[c] = entries - 1, r[c] = (uint32_t)(w[c >> 1] >> (32 * (c & 1)));
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int mid = (lo[c] + hi[c]) >> 1;
+      const uint32_t es = top[mid] >> ts, rs = r[c] >> ts;
+      const bool open = lo[c] < hi[c], less = rs < es;
+      tied |= (open && rs == es) ? (1u << c) : 0u;    // the lower half always matters on a tie, one-word tables included
+      hi[c] = (open && less) ? mid : hi[c];
+      lo[c] = (open && !less) ? mid + 1 : lo[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) out[c] = lo[c];
+  if (tied) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (tied & (1u << c)) out[c] = gauss_search<W>(gauss32_first_word(r[c], g0 + c, key, nc), g0 + c, cdt, entries, tie_shift, key, nc);
+  }
+}
+__device__ __forceinline__ void stage_gauss_top32(uint32_t *top, const uint64_t *__restrict__ cdt, int entries, int W) {
+  for (int k = threadIdx.x; k < entries; k += blockDim.x) top[k] = (uint32_t)(cdt[(size_t)k * W] >> 32);
+  __syncthreads();
+}
+// sixteen consecutive coefficients of one keystream block -> their table indices (iters = 0: the table does not fit LDS)
+template <int W>
+__device__ __forceinline__ void gauss_block16(uint64_t g0, const uint32_t *top, const uint64_t *__restrict__ cdt, int entries, int iters,
+                                              int tie_shift, const ChaChaKey &key, uint64_t nc, int (&r)[16]) {
+  uint64_t w[8];
+  chacha20_block(key, g0 >> 4, nc, w);
+  if (iters) {
+    gauss_search16<W>(w, g0, top, cdt, entries, iters, tie_shift, key, nc, r);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      r[c] = gauss_search<W>(gauss32_first_word((uint32_t)(w[c >> 1] >> (32 * (c & 1))), g0 + c, key, nc), g0 + c, cdt, entries, tie_shift, key, nc);
+  }
+}
+
+// compact polynomials, 32-bit draw, n >= 16: a thread's block = 16 consecutive coefficients = 16 / 32 / 64 contiguous bytes
+template <typename S, int W>
+__global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t first_coef, size_t ncoef,
+                                                       const uint64_t *__restrict__ cdt, int entries, long long x_min,
+                                                       long long amp, ChaChaKey key, uint64_t nonce, int tie_shift, int iters) {
+  extern __shared__ uint32_t gtop32[];
+  if (iters) stage_gauss_top32(gtop32, cdt, entries, W);
+  const uint64_t n = ((uint64_t)1) << logn;
+  const size_t ngroups = ncoef >> 4;  // first_coef and ncoef are multiples of 16 (n >= 16)
+  for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += (size_t)gridDim.x * blockDim.x) {
+    uint64_t g0 = first_coef + (grp << 4), nc = nonce;
+    if (key.seq_on) {
+      nc += (g0 >> logn) * key.seq_stride;
+      g0 &= n - 1;
+    }
+    int r[16];
+    gauss_block16<W>(g0, gtop32, cdt, entries, iters, tie_shift, key, nc, r);
+    uint32_t v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = (uint32_t)(int32_t)(S)((x_min + r[c]) * amp);
+    S *dst = d + (grp << 4);
+    if (sizeof(S) == 1) {
+      uint4 pk;
+      pk.x = (v[0] & 0xff) | ((v[1] & 0xff) << 8) | ((v[2] & 0xff) << 16) | (v[3] << 24);
+      pk.y = (v[4] & 0xff) | ((v[5] & 0xff) << 8) | ((v[6] & 0xff) << 16) | (v[7] << 24);
+      pk.z = (v[8] & 0xff) | ((v[9] & 0xff) << 8) | ((v[10] & 0xff) << 16) | (v[11] << 24);
+      pk.w = (v[12] & 0xff) | ((v[13] & 0xff) << 8) | ((v[14] & 0xff) << 16) | (v[15] << 24);
+      *reinterpret_cast<uint4 *>(dst) = pk;
+    } else if (sizeof(S) == 2) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        reinterpret_cast<uint4 *>(dst)[q] = make_uint4((v[8 * q] & 0xffff) | (v[8 * q + 1] << 16), (v[8 * q + 2] & 0xffff) | (v[8 * q + 3] << 16),
+                                                       (v[8 * q + 4] & 0xffff) | (v[8 * q + 5] << 16), (v[8 * q + 6] & 0xffff) | (v[8 * q + 7] << 16));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+  }
+}
+
+// residue words over the moduli, 32-bit draw, n >= 16: a wave's 1024 results through the wave-local LDS transpose
+template <typename T, int W>
+__global__ void __launch_bounds__(256) k_sample_gauss16(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm,
+                                                        uint64_t first_coef, size_t ncoef, const uint64_t *__restrict__ cdt,
+                                                        int entries, long long x_min, uint64_t amp, ChaChaKey key, uint64_t nonce,
+                                                        int tie_shift, int iters) {
+  constexpr int S = kTS;
+  __shared__ int xs[4][16 * S];
+  extern __shared__ uint32_t gtop32[];
+  if (iters) stage_gauss_top32(gtop32, cdt, entries, W);
+  const uint64_t n = ((uint64_t)1) << logn;
+  const size_t ngroups = ncoef >> 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t nwt = (ngroups + 63) >> 6;  // wave tiles of 64 groups = 1024 coefficients
+  for (size_t tile = (size_t)blockIdx.x * 4 + wv; tile < nwt; tile += (size_t)gridDim.x * 4) {
+    const size_t grp = (tile << 6) + lane;
+    if (grp < ngroups) {
+      uint64_t g0 = first_coef + (grp << 4), nc = nonce;
+      if (key.seq_on) {
+        nc += (g0 >> logn) * key.seq_stride;
+        g0 &= n - 1;
+      }
+      int r[16];
+      gauss_block16<W>(g0, gtop32, cdt, entries, iters, tie_shift, key, nc, r);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xs[wv][c * S + lane] = r[c];
+    }
+    wave_sync_lds();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int t = k * 64 + lane;               // coefficient of the tile: produced by lane t >> 4 as its result t & 15
+      const size_t idx = (tile << 10) + (size_t)t;
+      if (idx < ncoef) {
+        const long long x = x_min + xs[wv][(t & 15) * S + (t >> 4)];
+        const bool neg = x < 0;
+        const uint64_t mag = (uint64_t)(neg ? -x : x);
+        const uint64_t poly = idx >> logn, i = idx & (n - 1);
+        T *col = d + ((poly * (uint64_t)nm) << logn) + i;
+        for (int cm = 0; cm < nm; ++cm) col[(uint64_t)cm << logn] = signed_residue<T>(neg, mag, amp, (uint64_t)mc[cm].p);
+      }
+    }
+    wave_sync_lds();
+  }
+}
+
+// the first word of coefficient g's uniform number, either draw (the per-sample paths)
+__device__ __forceinline__ uint64_t gauss_word(uint64_t g, const ChaChaKey &key, uint64_t nonce, int narrow) {
+  if (narrow) return gauss32_word(g, key, nonce);
+  uint64_t blk[8];
+  chacha20_block(key, g >> 3, nonce, blk);
+  return blk[g & 7];
+}
+
 template <typename T, int W>
 __global__ void k_sample_gauss(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, uint64_t first_coef,
                                size_t ncoef, const uint64_t *__restrict__ cdt, int entries, long long x_min, uint64_t amp,
-                               ChaChaKey key, uint64_t nonce, int tie_shift) {
+                               ChaChaKey key, uint64_t nonce, int tie_shift, int narrow) {
   const uint64_t n = ((uint64_t)1) << logn;
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t g = first_coef + idx;
-    uint64_t blk[8];
-    chacha20_block(key, g >> 3, nonce, blk);
-    const long long x = x_min + gauss_search<W>(blk[g & 7], g, cdt, entries, tie_shift, key, nonce);
+    const long long x = x_min + gauss_search<W>(gauss_word(g, key, nonce, narrow), g, cdt, entries, tie_shift, key, nonce);
     const bool neg = x < 0;
     const uint64_t mag = (uint64_t)(neg ? -x : x);
     const uint64_t poly = idx >> logn, i = idx & (n - 1);
@@ -503,12 +741,10 @@ __global__ void __launch_bounds__(256) k_gauss_small8(S *d, int logn, uint64_t f
 
 template <typename S, int W>
 __global__ void k_gauss_small(S *d, uint64_t first_coef, size_t ncoef, const uint64_t *__restrict__ cdt, int entries,
-                              long long x_min, long long amp, ChaChaKey key, uint64_t nonce, int tie_shift) {
+                              long long x_min, long long amp, ChaChaKey key, uint64_t nonce, int tie_shift, int narrow) {
   for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ncoef; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t g = first_coef + idx;
-    uint64_t blk[8];
-    chacha20_block(key, g >> 3, nonce, blk);
-    d[idx] = (S)((x_min + gauss_search<W>(blk[g & 7], g, cdt, entries, tie_shift, key, nonce)) * amp);
+    d[idx] = (S)((x_min + gauss_search<W>(gauss_word(g, key, nonce, narrow), g, cdt, entries, tie_shift, key, nonce)) * amp);
   }
 }
 
@@ -536,7 +772,14 @@ __global__ void k_expand_small(T *dst, const S *src, const ModConst<T> *__restri
 // coefficient first_sample + j of a polynomial batch would get from the same (key, stream_id)
 template <int W>
 __global__ void k_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *__restrict__ cdt,
-                              int entries, long long x_min, ChaChaKey key, uint64_t nonce, int tie_shift) {
+                              int entries, long long x_min, ChaChaKey key, uint64_t nonce, int tie_shift, int narrow) {
+  if (narrow) {   // 32-bit draw: one sample per thread (this entry point is a test / inspection path, not a hot one)
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
+      const uint64_t g = first_sample + j;
+      out[j] = x_min + gauss_search<W>(gauss32_word(g, key, nonce), g, cdt, entries, tie_shift, key, nonce);
+    }
+    return;
+  }
   const uint64_t fb = first_sample >> 3, nb = ((first_sample + count + 7) >> 3) - fb;
   for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t w[8];
@@ -632,9 +875,20 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
   if (seq_on && (s.n < 8 || first_poly != 0)) return hipErrorNotSupported;  // (keystream blocks must not straddle polynomials)
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
   const int refw = dist & 0x100;   // NFLHIP_DIST_REFERENCE_WORDS
+  const int narrow = dist & 0x200; // NFLHIP_DIST_NARROW
   dist &= 0xff;
-  const ChaChaKey key = load_key(key32, dist + 1, seq_on, seq_stride);
+  if (narrow && dist != 0) return hipErrorInvalidValue;
+  const ChaChaKey key = load_key(key32, narrow ? kDomUniformNarrow : dist + 1, seq_on, seq_stride);
   const size_t ncoef = batch * s.n, total = ncoef * s.nm;
+  if (narrow && sizeof(T) < 8) {   // (64-bit limbs: a lane IS a stream word -- the kernels below, in the narrow domain)
+    if (s.n >= 64 / sizeof(T))
+      hipLaunchKernelGGL((k_sample_uniform_narrow<T>), dim3(grid_for(total * sizeof(T) / 64)), dim3(256), 0, st, d, mc, s.logn, (int)s.nm,
+                         (uint64_t)first_poly * s.nm * s.n, total, key, stream_id);
+    else
+      hipLaunchKernelGGL((k_sample_uniform_narrow_any<T>), dim3(grid_for(total * sizeof(T) / 64 + batch + 2)), dim3(256), 0, st, d, mc, s.logn,
+                         (int)s.nm, (uint64_t)first_poly * s.nm * s.n, total, key, stream_id);
+    return hipGetLastError();
+  }
   switch (dist) {
     case 0:
       if (s.n >= 8)
@@ -681,18 +935,19 @@ static int gauss_lds_iters(int entries) {
 }
 
 hipError_t launch_gauss_noise(long long *out, uint64_t first_sample, size_t count, const uint64_t *cdt, int words,
-                              int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st) {
+                              int entries, long long x_min, const unsigned char *key32, uint64_t stream_id, hipStream_t st,
+                              int narrow) {
   if (count == 0) return hipSuccess;
-  const ChaChaKey key = load_key(key32, kDomGauss);
-  const dim3 g(grid_for(count / 8 + 2)), b(256);
+  const ChaChaKey key = load_key(key32, narrow ? kDomGauss32 : kDomGauss);
+  const dim3 g(grid_for(narrow ? count : count / 8 + 2)), b(256);
   const int ts = gauss_tie_shift();
   switch (words) {
-    case 1: hipLaunchKernelGGL((k_gauss_noise<1>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
-    case 2: hipLaunchKernelGGL((k_gauss_noise<2>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
-    case 3: hipLaunchKernelGGL((k_gauss_noise<3>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
-    case 4: hipLaunchKernelGGL((k_gauss_noise<4>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
-    case 5: hipLaunchKernelGGL((k_gauss_noise<5>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
-    case 6: hipLaunchKernelGGL((k_gauss_noise<6>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts); break;
+    case 1: hipLaunchKernelGGL((k_gauss_noise<1>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts, narrow); break;
+    case 2: hipLaunchKernelGGL((k_gauss_noise<2>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts, narrow); break;
+    case 3: hipLaunchKernelGGL((k_gauss_noise<3>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts, narrow); break;
+    case 4: hipLaunchKernelGGL((k_gauss_noise<4>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts, narrow); break;
+    case 5: hipLaunchKernelGGL((k_gauss_noise<5>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts, narrow); break;
+    case 6: hipLaunchKernelGGL((k_gauss_noise<6>), g, b, 0, st, out, first_sample, count, cdt, entries, x_min, key, stream_id, ts, narrow); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -702,15 +957,30 @@ template <typename T>
 hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
                                const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
                                const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on,
-                               uint64_t seq_stride) {
+                               uint64_t seq_stride, int narrow) {
   if (batch == 0) return hipSuccess;
-  if (seq_on && (s.n < 8 || first_poly != 0)) return hipErrorNotSupported;
+  if (seq_on && (s.n < (narrow ? 16u : 8u) || first_poly != 0)) return hipErrorNotSupported;
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
-  const ChaChaKey key = load_key(key32, kDomGauss, seq_on, seq_stride);
+  const ChaChaKey key = load_key(key32, narrow ? kDomGauss32 : kDomGauss, seq_on, seq_stride);
   const size_t ncoef = batch * s.n;
   const uint64_t fc = (uint64_t)first_poly * s.n;
   const int tie_shift = gauss_tie_shift();
-  if (s.n >= 8) {  // eight coefficients per thread
+  if (narrow && s.n >= 16) {  // sixteen coefficients per thread
+    const dim3 g(grid_for(ncoef / 16)), b(256);
+    const int iters = gauss_lds_iters(entries);
+    const size_t lds = iters ? (size_t)entries * 4 : 0;
+    switch (words) {
+      case 1: hipLaunchKernelGGL((k_sample_gauss16<T, 1>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 2: hipLaunchKernelGGL((k_sample_gauss16<T, 2>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 3: hipLaunchKernelGGL((k_sample_gauss16<T, 3>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 4: hipLaunchKernelGGL((k_sample_gauss16<T, 4>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 5: hipLaunchKernelGGL((k_sample_gauss16<T, 5>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 6: hipLaunchKernelGGL((k_sample_gauss16<T, 6>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
+  if (!narrow && s.n >= 8) {  // eight coefficients per thread
     const dim3 g(grid_for(ncoef / 8)), b(256);
     const int iters = gauss_lds_iters(entries);
     const size_t lds = iters ? (size_t)entries * 8 : 0;
@@ -727,12 +997,12 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
   }
   const dim3 g(grid_for(ncoef)), b(256);
   switch (words) {
-    case 1: hipLaunchKernelGGL((k_sample_gauss<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-    case 2: hipLaunchKernelGGL((k_sample_gauss<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-    case 3: hipLaunchKernelGGL((k_sample_gauss<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-    case 4: hipLaunchKernelGGL((k_sample_gauss<T, 4>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-    case 5: hipLaunchKernelGGL((k_sample_gauss<T, 5>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
-    case 6: hipLaunchKernelGGL((k_sample_gauss<T, 6>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift); break;
+    case 1: hipLaunchKernelGGL((k_sample_gauss<T, 1>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, narrow); break;
+    case 2: hipLaunchKernelGGL((k_sample_gauss<T, 2>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, narrow); break;
+    case 3: hipLaunchKernelGGL((k_sample_gauss<T, 3>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, narrow); break;
+    case 4: hipLaunchKernelGGL((k_sample_gauss<T, 4>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, narrow); break;
+    case 5: hipLaunchKernelGGL((k_sample_gauss<T, 5>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, narrow); break;
+    case 6: hipLaunchKernelGGL((k_sample_gauss<T, 6>), g, b, 0, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, narrow); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -741,25 +1011,28 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
 // format: 1 int8 | 2 int16 | 3 int32 (NFLHIP_FMT_*)
 hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_poly, size_t batch, const uint64_t *cdt,
                               int words, int entries, long long x_min, uint64_t amp, const unsigned char *key32,
-                              uint64_t stream_id, hipStream_t st, int seq_on, uint64_t seq_stride) {
+                              uint64_t stream_id, hipStream_t st, int seq_on, uint64_t seq_stride, int narrow) {
   if (batch == 0) return hipSuccess;
-  if (seq_on && (s.n < 8 || first_poly != 0)) return hipErrorNotSupported;
+  if (seq_on && (s.n < (narrow ? 16u : 8u) || first_poly != 0)) return hipErrorNotSupported;
   if (words < 1 || words > 6 || format < 1 || format > 3) return hipErrorInvalidValue;
-  const ChaChaKey key = load_key(key32, kDomGauss, seq_on, seq_stride);
+  const ChaChaKey key = load_key(key32, narrow ? kDomGauss32 : kDomGauss, seq_on, seq_stride);
   const size_t ncoef = batch * s.n;
   const uint64_t fc = (uint64_t)first_poly * s.n;
   const int tie_shift = gauss_tie_shift();
   const long long a = (long long)amp;
   const int iters = gauss_lds_iters(entries);
-  const size_t lds = iters ? (size_t)entries * 8 : 0;
+  const size_t lds = iters ? (size_t)entries * (narrow ? 4 : 8) : 0;
 #define NFLHIP_GS(S, W)                                                                                                              \
   do {                                                                                                                               \
-    if (s.n >= 8)                                                                                                                    \
+    if (narrow && s.n >= 16)                                                                                                         \
+      hipLaunchKernelGGL((k_gauss_small16<S, W>), dim3(grid_for(ncoef / 16)), dim3(256), lds, st, (S *)d, s.logn, fc, ncoef, cdt,  \
+                         entries, x_min, a, key, stream_id, tie_shift, iters);                                                       \
+    else if (!narrow && s.n >= 8)                                                                                                    \
       hipLaunchKernelGGL((k_gauss_small8<S, W>), dim3(grid_for(ncoef / 8)), dim3(256), lds, st, (S *)d, s.logn, fc, ncoef, cdt,    \
                          entries, x_min, a, key, stream_id, tie_shift, iters);                                                       \
     else                                                                                                                             \
       hipLaunchKernelGGL((k_gauss_small<S, W>), dim3(grid_for(ncoef)), dim3(256), 0, st, (S *)d, fc, ncoef, cdt, entries, x_min, a, \
-                         key, stream_id, tie_shift);                                                                                 \
+                         key, stream_id, tie_shift, narrow);                                                                         \
   } while (0)
 #define NFLHIP_GSW(S)                    \
   switch (words) {                       \
@@ -798,7 +1071,7 @@ hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const
                                        const unsigned char *, uint64_t, hipStream_t, int, uint64_t);                     \
   template hipError_t launch_sample_gauss<T>(const Shape &, const DevTables &, T *, size_t, size_t, const uint64_t *, int, \
                                              int, long long, uint64_t, const unsigned char *, uint64_t, hipStream_t, int,  \
-                                             uint64_t);                                                                    \
+                                             uint64_t, int);                                                               \
   template hipError_t launch_expand_small<T>(const Shape &, const DevTables &, T *, const void *, int, unsigned, size_t, hipStream_t);
 NFLHIP_INST(uint16_t)
 NFLHIP_INST(uint32_t)

@@ -299,15 +299,19 @@ class Engine:
             self._next_stream += 1
         return stream_id
 
-    def sample(self, d, dist, key, stream_id=None, param0=0, param1=1, first_poly=0, stream=None):
+    NARROW = True   # this engine knows the narrow draws (DIST_NARROW, gauss_create(draw_bits=32))
+
+    def sample(self, d, dist, key, stream_id=None, param0=0, param1=1, first_poly=0, stream=None, narrow=False):
         """dist: DIST_UNIFORM | DIST_BOUNDED (param0 = upper bound, param1 = amplifier) | DIST_ZO (param0 = rho)
-        | DIST_HWT (param0 = hamming weight)"""
+        | DIST_HWT (param0 = hamming weight); narrow (uniform only): keystream lanes of the limb width (NFLHIP_DIST_NARROW)"""
+        dist |= _lib.DIST_NARROW if narrow else 0
         self._chk(self.lib.nflhip_sample_dev(self.ctx, _vp(d), first_poly, self._batch(d), dist, param0, param1,
                                              self._key(key), self._sid(stream_id), self._stream(stream)))
         return d
 
-    def sample_seq(self, d, dist, key, first_stream_id, stream_id_stride=1, param0=0, param1=1, stream=None):
+    def sample_seq(self, d, dist, key, first_stream_id, stream_id_stride=1, param0=0, param1=1, stream=None, narrow=False):
         """polynomial b = sample(one polynomial, stream id first_stream_id + b*stride) (nflhip_sample_seq_dev)"""
+        dist |= _lib.DIST_NARROW if narrow else 0
         self._chk(self.lib.nflhip_sample_seq_dev(self.ctx, _vp(d), self._batch(d), dist, param0, param1, self._key(key),
                                                  first_stream_id, stream_id_stride, self._stream(stream)))
         return d
@@ -324,11 +328,16 @@ class Engine:
                                                    self._stream(stream)))
         return out
 
-    def gauss_create(self, sigma, security=128, samples=None, center=0.0):
-        """FastGaussianNoise(sigma, security, samples, center): returns a handle for sample_gauss / gauss_info"""
+    def gauss_create(self, sigma, security=128, samples=None, center=0.0, draw_bits=64):
+        """FastGaussianNoise(sigma, security, samples, center): returns a handle for sample_gauss / gauss_info;
+        draw_bits = 32: the narrow draw (nflhip_gauss_set_draw_bits)"""
         h = C.c_void_p()
         self._chk(self.lib.nflhip_gauss_create(self.ctx, C.byref(h), float(sigma), int(security),
                                                int(samples if samples is not None else self.degree), float(center)))
+        if draw_bits != 64:
+            if self.lib.nflhip_gauss_set_draw_bits(h, int(draw_bits)) != 0:
+                self.lib.nflhip_gauss_destroy(self.ctx, h)
+                raise ValueError("draw_bits must be 64 or 32")
         return h
 
     def gauss_destroy(self, g):

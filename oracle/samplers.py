@@ -76,7 +76,9 @@ def centered(data, P):
 SECONDARY_COUNTER = 1 << 63   # first block counter of the secondary stream (kernels_sample.hip, lazy-precision Gaussian)
 # domain separation (kernels_sample.hip, ChaChaKey::dom): bits 56..62 of the block counter carry the distribution's tag,
 # so calls of different distributions that share (key, stream_id) never read the same keystream word
-DOMAIN = {"raw": 0, "uniform": 1, "bounded": 2, "zo": 3, "hwt": 4, "gauss": 5}
+DOMAIN = {"raw": 0, "uniform": 1, "bounded": 2, "zo": 3, "hwt": 4, "gauss": 5,
+          # the narrow draws (kernels_sample.hip "NARROW DRAWS"): a value reads a LANE of the keystream, in a domain of its own
+          "uniform_narrow": 6, "gauss32": 7, "gauss32_ref": 8}
 
 
 def domain_base(name):
@@ -121,6 +123,22 @@ def chacha20_words(key32, stream_id, first_word, nwords, counter_base=0):
     return words[off:off + nwords].copy()
 
 
+def chacha20_lanes(key32, stream_id, first_lane, nlanes, lane_bytes, counter_base=0):
+    """lanes [first_lane, first_lane + nlanes) of the keystream read as little-endian integers of lane_bytes bytes each
+    (lane g = bytes [g * lane_bytes, (g + 1) * lane_bytes) of the stream): what the narrow draws consume"""
+    per = 8 // lane_bytes
+    fw, lw = first_lane // per, (first_lane + nlanes + per - 1) // per
+    words = chacha20_words(key32, stream_id, fw, lw - fw, counter_base=counter_base)
+    lanes = words.view({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[lane_bytes])   # (little-endian host)
+    off = first_lane - fw * per
+    return lanes[off:off + nlanes].copy()
+
+
+def uniform_narrow_words(key32, stream_id, first_word, nwords, limb_bits):
+    """the random lanes poly(uniform) consumes under NFLHIP_DIST_NARROW: residue word g reads the limb-width lane g"""
+    return chacha20_lanes(key32, stream_id, first_word, nwords, limb_bits // 8, counter_base=domain_base("uniform_narrow"))
+
+
 def gaussian_pmf(sigma, center, x_min, entries):
     """P(X = x) of the tail-cut discrete Gaussian on [x_min, x_min + entries) (FastGaussianNoise.hpp:296-330)"""
     x = np.arange(x_min, x_min + entries, dtype=np.float64)
@@ -137,6 +155,21 @@ def gaussian_words(key32, stream_id, first_coef, ncoef, W):
     if W > 1:
         r[:, 1:] = chacha20_words(key32, stream_id, (W - 1) * first_coef, (W - 1) * ncoef,
                                   counter_base=SECONDARY_COUNTER | domain_base("gauss")).reshape(ncoef, W - 1)
+    return r
+
+
+def gaussian_words_narrow(key32, stream_id, first_coef, ncoef, W):
+    """The W-word uniform number of coefficient g under the 32-bit draw (nflhip_gauss_set_draw_bits(g, 32)): word 0 =
+    (32-bit lane g of stream "gauss32") << 32 | 32-bit lane g of stream "gauss32_ref" (the device reads the second lane only
+    when the first ties with the top half of a table entry); words k >= 1 as under the 64-bit draw, from the secondary stream of
+    the "gauss32" domain."""
+    r = np.empty((ncoef, W), dtype=np.uint64)
+    hi = chacha20_lanes(key32, stream_id, first_coef, ncoef, 4, counter_base=domain_base("gauss32")).astype(np.uint64)
+    lo = chacha20_lanes(key32, stream_id, first_coef, ncoef, 4, counter_base=domain_base("gauss32_ref")).astype(np.uint64)
+    r[:, 0] = (hi << _U64(32)) | lo
+    if W > 1:
+        r[:, 1:] = chacha20_words(key32, stream_id, (W - 1) * first_coef, (W - 1) * ncoef,
+                                  counter_base=SECONDARY_COUNTER | domain_base("gauss32")).reshape(ncoef, W - 1)
     return r
 
 

@@ -231,3 +231,131 @@ def test_gaussian_beyond_192_bits(sigma, security, words, engine_factory):
     raw = e.gauss_noise(g, 2048, KEY, stream_id=31).cpu().numpy()
     assert np.array_equal(raw, flatv[:2048])
     e.gauss_destroy(g)
+
+
+# ---- the narrow draws (NFLHIP_DIST_NARROW, nflhip_gauss_set_draw_bits(g, 32)): keystream lanes instead of 64-bit words ----------
+NARROW_SHAPES = [(64, 4096, 4, 3), (64, 4, 3, 7), (32, 1024, 2, 3), (32, 8, 2, 5), (32, 16, 3, 4), (16, 128, 1, 4), (16, 16, 2, 9),
+                 (16, 32, 3, 5), (16, 4096, 2, 2), (32, 32768, 1, 1)]
+
+
+@pytest.mark.parametrize("lb,n,m,batch", NARROW_SHAPES, ids=["u%d-n%d-m%d" % s[:3] for s in NARROW_SHAPES])
+def test_narrow_uniform_is_the_reference_rule_on_keystream_lanes(lb, n, m, batch, engine_factory):
+    """poly(uniform) (core.hpp:152-188: mask to floor(log2 p) + 1 bits, one conditional subtraction) applied to the limb-width
+    LANE g of the keystream instead of the 64-bit word g: exact against the numpy restatement of the lanes, for rows longer
+    and shorter than a keystream block (the per-thread-block kernel and the lane-by-lane one), shards and the sequence form."""
+    e = engine_factory(lb, n, m)
+    P, dt = _P(e), e.np_dtype
+    got = e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, KEY, stream_id=1, narrow=True))
+    lanes = S.uniform_narrow_words(KEY, 1, 0, batch * m * n, lb).reshape(batch, m, n)
+    assert np.array_equal(got, S.uniform(lanes, P))
+    assert all((got[:, cm] < P[cm]).all() for cm in range(m))
+    wide = e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, KEY, stream_id=1))
+    assert not np.array_equal(wide, got), "its own keystream domain: the wide rule's values keep their meaning"
+    # any split of the batch gives the same words
+    lo = e.sample(e.empty(2), DIST_UNIFORM, KEY, stream_id=1, first_poly=0, narrow=True)
+    hi = e.sample(e.empty(batch - 2), DIST_UNIFORM, KEY, stream_id=1, first_poly=2, narrow=True)
+    assert np.array_equal(np.concatenate([e.to_host(lo), e.to_host(hi)]), got)
+    # sequence form: polynomial b = a one-polynomial call with stream id first + b * stride
+    if n >= 8:
+        seq = e.to_host(e.sample_seq(e.empty(batch), DIST_UNIFORM, KEY, 100, 3, narrow=True))
+        for b in range(batch):
+            one = S.uniform_narrow_words(KEY, 100 + 3 * b, 0, m * n, lb).reshape(1, m, n)
+            assert np.array_equal(seq[b:b + 1], S.uniform(one, P)), b
+    # the flag belongs to the uniform rule only
+    for dist, p0 in ((DIST_BOUNDED, 5), (DIST_ZO, 100), (DIST_HWT, 1)):
+        with pytest.raises(NflHipError, match="narrow draw"):
+            e.sample(e.empty(1), dist, KEY, param0=p0, narrow=True)
+    # statistics of the lanes: every residue row uniform on [0, p)
+    if batch * n >= 4096:
+        for cm in range(m):
+            x = got[:, cm].astype(np.float64).reshape(-1) / P[cm]
+            assert abs(x.mean() - 0.5) < 5 / np.sqrt(12 * x.size) and abs(x.var() - 1 / 12) < 0.01
+
+
+_NARROW_TIE_CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+from nfllib_amd import Engine
+from oracle import samplers as S
+import ctypes
+from nfllib_amd import _lib
+_lib.lib.nflhip_debug_gauss_tie_shift.argtypes = [ctypes.c_int]
+_lib.lib.nflhip_debug_gauss_tie_shift.restype = None
+_lib.lib.nflhip_debug_gauss_tie_shift(int(sys.argv[1]))
+KEY = bytes(range(32))
+for lb, n, m, batch, sigma, sec, first in ((64, 1024, 2, 3, 3.2, 128, 0), (64, 64, 1, 13, 20.0, 128, 5), (32, 256, 1, 5, 3.2, 64, 2),
+                                          (64, 4, 1, 9, 3.2, 128, 3), (64, 8, 2, 5, 3.2, 128, 1), (16, 128, 1, 7, 2.0, 20, 0),
+                                          (64, 4096, 1, 2, 215.0, 100, 1), (64, 16, 1, 6, 3.19, 128, 0)):
+    e = Engine(lb, n, m)
+    P = [int(e.table(1, cm)[0]) for cm in range(m)]
+    g = e.gauss_create(sigma, security=sec, samples=1024, draw_bits=32)
+    info = e.gauss_info(g)
+    d = e.to_host(e.sample_gauss(e.empty(batch), g, KEY, stream_id=21, first_poly=first))
+    v = S.centered(d, P)[:, 0].reshape(-1)
+    r = S.gaussian_words_narrow(KEY, 21, first * n, batch * n, info["words"])
+    want = S.gaussian_from_table(r, info["table"], info["x_min"])
+    assert np.array_equal(v, want), ("words", lb, n, m, sigma, sec, int((v != want).sum()))
+    # the compact form and the raw samples read the same lanes
+    amp = 2 if sigma < 10 else 1
+    fmt = torch.int8 if sigma < 10 else torch.int32
+    sm = e.sample_gauss_small(torch.empty((batch, n), dtype=fmt, device="cuda:0"), g, KEY, stream_id=21, amplifier=amp, first_poly=first)
+    assert np.array_equal(sm.cpu().numpy().reshape(-1).astype(np.int64), amp * want), ("compact", lb, n, sigma)
+    raw = e.gauss_noise(g, batch * n - 3, KEY, stream_id=21, first_sample=first * n + 1).cpu().numpy()
+    assert np.array_equal(raw, want[1:batch * n - 2]), ("noise", lb, n)
+    if n >= 16:   # sequence forms: one keystream per polynomial
+        seq = e.to_host(e.sample_gauss_seq(e.empty(batch), g, KEY, 500, 7))
+        sms = e.sample_gauss_small_seq(torch.empty((batch, n), dtype=fmt, device="cuda:0"), g, KEY, 500, 7, amplifier=amp).cpu().numpy()
+        for b in range(batch):
+            rb = S.gaussian_words_narrow(KEY, 500 + 7 * b, 0, n, info["words"])
+            wb = S.gaussian_from_table(rb, info["table"], info["x_min"])
+            assert np.array_equal(S.centered(seq[b:b + 1], P)[0, 0], wb) and np.array_equal(sms[b].astype(np.int64), amp * wb), ("seq", lb, n, b)
+    e.gauss_destroy(g)
+print("TIE_OK")
+"""
+
+
+@pytest.mark.parametrize("tie_shift", ["0", "20", "31", "56", "63"])
+def test_narrow_gaussian_equals_full_precision_inversion(tie_shift):
+    """The 32-bit draw: a sample is decided by the 32-bit lane g of its stream unless that lane equals the top half of a table
+    entry the search meets; then the lower half (a second domain) and, on a further tie, the secondary words are read.  The
+    value is exactly the oracle's full-precision inversion of (lane, lower lane, secondary words) for every table width, the
+    16-per-thread kernels and the per-coefficient ones, residue words, compact polynomials, raw samples, shards and the
+    sequence forms -- with the debug tie shift (never set in production) widening what counts as a tie at BOTH stages so that
+    the refinement paths run (20: one 32-bit tie in 4096 comparisons; 31 / 63: nearly every comparison)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _NARROW_TIE_CHILD % {"root": root}, tie_shift], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "TIE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_narrow_gaussian_statistics_and_arguments(engine_factory):
+    e = engine_factory(64, 1024, 2)
+    P = _P(e)
+    sigma = 3.2
+    g = e.gauss_create(sigma, security=128, samples=1024, draw_bits=32)
+    assert e.lib.nflhip_gauss_draw_bits(g) == 32
+    v = S.centered(e.to_host(e.sample_gauss(e.empty(200), g, KEY, stream_id=9)), P)[:, 0].reshape(-1)
+    assert abs(v.mean()) < 5 * sigma / np.sqrt(v.size) and abs(v.var() / sigma ** 2 - 1) < 0.02
+    rh, rlo = GOLD["gauss_%g/hist" % sigma], int(GOLD["gauss_%g/lo" % sigma])
+    lo, hi = min(rlo, int(v.min())), max(rlo + rh.size - 1, int(v.max()))
+    a = np.bincount(v - lo, minlength=hi - lo + 1)
+    b = np.zeros(hi - lo + 1, dtype=np.int64)
+    b[rlo - lo:rlo - lo + rh.size] = rh
+    assert _chi2_two_sample(a, b) < 1.5, "two-sample test against the real reference's samples"
+    g64 = e.gauss_create(sigma, security=128, samples=1024)
+    assert e.lib.nflhip_gauss_draw_bits(g64) == 64
+    v64 = S.centered(e.to_host(e.sample_gauss(e.empty(200), g64, KEY, stream_id=9)), P)[:, 0].reshape(-1)
+    assert not np.array_equal(v, v64), "other keystream domains: the 64-bit draw's values keep their meaning"
+    assert e.lib.nflhip_gauss_set_draw_bits(g64, 16) != 0 and e.lib.nflhip_gauss_set_draw_bits(g64, 32) == 0
+    assert np.array_equal(S.centered(e.to_host(e.sample_gauss(e.empty(200), g64, KEY, stream_id=9)), P)[:, 0].reshape(-1), v)
+    e8 = engine_factory(64, 8, 2)
+    g8 = e8.gauss_create(sigma, security=128, samples=8, draw_bits=32)
+    with pytest.raises(NflHipError, match="degree >= 8"):
+        e8.sample_gauss_seq(e8.empty(2), g8, KEY, 1)
+    for h in (g, g64):
+        e.gauss_destroy(h)
+    e8.gauss_destroy(g8)
