@@ -596,6 +596,17 @@ inline void randombytes(unsigned char *x, unsigned long long xlen) {
   if (!f.read(reinterpret_cast<char *>(x), std::streamsize(xlen))) throw std::runtime_error("nfl(hip): /dev/urandom unreadable");
 }
 
+namespace detail {
+// NARROW DRAWS (nflhip.h NFLHIP_DIST_NARROW, nflhip_gauss_set_draw_bits): poly(uniform) reads keystream lanes of the limb
+// width and the Gaussian constructors 32-bit lanes -- the reference's maps from random bits to coefficients, the same
+// distributions, at 1/4 - 1/2 of the ChaCha20 rounds.  NFL_HIP_WIDE_DRAWS=1 (read once) keeps the one-word-per-value rules.
+inline bool narrow_draws() {
+  static const bool v = !std::getenv("NFL_HIP_WIDE_DRAWS");
+  return v;
+}
+inline int uniform_rule() { return narrow_draws() ? (NFLHIP_DIST_UNIFORM | NFLHIP_DIST_NARROW) : NFLHIP_DIST_UNIFORM; }
+}  // namespace detail
+
 /* FastGaussianNoise<in_class, out_class, _lu_depth>(sigma, security, samples, center) -- same constructor as
  * FastGaussianNoise.hpp:163-204.  The reference builds byte-indexed lookup tables over MPFR barriers; here the object
  * only carries the parameters and owns one cumulative table per device context (built on first use with the
@@ -627,6 +638,9 @@ template <class in_class, class out_class, unsigned _lu_depth> class FastGaussia
     if (it == tables_.end()) {
       nflhip_gauss *g = nullptr;
       detail::check(ctx, nflhip_gauss_create(ctx, &g, sigma_, security_, samples_, center_), "FastGaussianNoise");
+      // the narrow draw (32 keystream bits per sample, the rest read lazily: nflhip.h nflhip_gauss_set_draw_bits) wherever the
+      // sequence forms accept it -- the same exact inversion at half the ChaCha20 rounds
+      if (detail::narrow_draws() && nflhip_degree(ctx) >= 16) nflhip_gauss_set_draw_bits(g, 32);
       it = tables_.emplace(ctx, g).first;
     }
     last_.store(&*it, std::memory_order_release);
@@ -1996,7 +2010,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly {
   // counter stream for `uniform(seed)`
   void set(uniform const &u) {
     if (!u.seeded) {
-      sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+      sample(detail::uniform_rule(), 0, 1, "set(uniform)");
       return;
     }
     for (size_t cm = 0; cm < nmoduli; cm++) {
@@ -2501,7 +2515,7 @@ template <class T, size_t Degree, size_t NbModuli> class poly_p {
       if (defer_sample(p, lazy_t::K_FILL, 0, 0, 0, u.seed, nullptr)) return;
       detail::check(ctx_t::get(), nflhip_fill_uniform_dev(ctx_t::get(), p.dev_wo(), 0, 1, u.seed, 0, ctx_t::queue()), "set(uniform)");
     } else {
-      sample_dist(p, NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)");
+      sample_dist(p, detail::uniform_rule(), 0, 1, "set(uniform)");
     }
   }
   static void sample_into(payload_type &p, non_uniform const &m) { sample_dist(p, NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)"); }
@@ -2854,7 +2868,7 @@ template <class P> class device_batch {
   // polynomial first_poly + k of the keystream, so that the shards of a batch equal the batch drawn on one device.
   void set(uniform const &u, size_t first_poly = 0) {
     if (u.seeded) detail::check(ctx(), nflhip_fill_uniform_dev(ctx(), d_, first_poly, n_, u.seed, 0, queue()), "set(uniform)");
-    else sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)", first_poly, detail::sampler::get().next++);
+    else sample(detail::uniform_rule(), 0, 1, "set(uniform)", first_poly, detail::sampler::get().next++);
   }
   void set(non_uniform const &m) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)", 0, detail::sampler::get().next++); }
   void set(ZO_dist const &m) { sample(NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)", 0, detail::sampler::get().next++); }
@@ -2862,7 +2876,7 @@ template <class P> class device_batch {
   template <class in_class, unsigned _lu_depth> void set(gaussian<in_class, value_type, _lu_depth> const &m) {
     set_at(m, 0, detail::sampler::get().next++);
   }
-  void set_at(uniform const &, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_UNIFORM, 0, 1, "set(uniform)", first_poly, stream_id); }
+  void set_at(uniform const &, size_t first_poly, uint64_t stream_id) { sample(detail::uniform_rule(), 0, 1, "set(uniform)", first_poly, stream_id); }
   void set_at(non_uniform const &m, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_BOUNDED, m.upper_bound, m.amplifier, "set(non_uniform)", first_poly, stream_id); }
   void set_at(ZO_dist const &m, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_ZO | detail::dist_flags, m.rho, 1, "set(ZO_dist)", first_poly, stream_id); }
   void set_at(hwt_dist const &m, size_t first_poly, uint64_t stream_id) { sample(NFLHIP_DIST_HWT | detail::dist_flags, m.hwt, 1, "set(hwt_dist)", first_poly, stream_id); }

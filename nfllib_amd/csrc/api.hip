@@ -1393,6 +1393,7 @@ struct nflhip_gauss {
   uint64_t *d_cdt = nullptr;
   int device = 0;
   int draw_bits = 64;   // keystream bits a sample normally consumes (nflhip_gauss_set_draw_bits): 64, or 32 = the narrow draw
+  uint16_t *d_lut = nullptr;   // the narrow draw's bucket table (kernels_sample.hip gauss_bucket_table); NULL: table too long for LDS
 };
 static inline int gauss_narrow(const nflhip_gauss *g) { return g->draw_bits == 32 ? 1 : 0; }
 
@@ -1459,9 +1460,9 @@ int nflhip_sample_gauss_seq_dev(nflhip_ctx *ctx, void *d, size_t batch, const nf
   const long long x0 = g->tab.x_min;
   hipError_t e = DISPATCH_T(
       ctx,
-      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g)),
-      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g)),
-      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g)));
+      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g), g->d_lut),
+      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g), g->d_lut),
+      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, 0, batch, g->d_cdt, w, en, x0, amplifier, key, first_stream_id, st, 1, stream_id_stride, gauss_narrow(g), g->d_lut));
   if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8 (>= 16 under the 32-bit draw)");
   if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss_seq");
   return NFLHIP_OK;
@@ -1486,6 +1487,16 @@ int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsig
   if (e != hipSuccess) {
     (void)hipFree(g->d_cdt);
     return hipfail(ctx, e, "gauss table upload");
+  }
+  const std::vector<uint16_t> lut = gauss_bucket_table(g->tab.cdt.data(), g->tab.words, g->tab.entries);
+  if (!lut.empty()) {
+    e = hipMalloc((void **)&g->d_lut, lut.size() * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(g->d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(g->d_cdt);
+      if (g->d_lut) (void)hipFree(g->d_lut);
+      return hipfail(ctx, e, "gauss bucket table upload");
+    }
   }
   *out = g.release();
   return NFLHIP_OK;
@@ -1524,6 +1535,7 @@ int nflhip_gauss_destroy(nflhip_ctx *ctx, nflhip_gauss *g) {
   (void)ctx;  // never dereferenced: a FastGaussianNoise with static storage may outlive the context that built its table
   (void)hipSetDevice(g->device);
   if (g->d_cdt) (void)hipFree(g->d_cdt);
+  if (g->d_lut) (void)hipFree(g->d_lut);
   delete g;
   return NFLHIP_OK;
 }
@@ -1551,9 +1563,9 @@ int nflhip_sample_gauss_dev(nflhip_ctx *ctx, void *d, size_t first_poly, size_t 
   const long long x0 = g->tab.x_min;
   hipError_t e = DISPATCH_T(
       ctx,
-      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g)),
-      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g)),
-      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g)));
+      launch_sample_gauss<uint16_t>(ctx->shape, ctx->tabs, (uint16_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g), g->d_lut),
+      launch_sample_gauss<uint32_t>(ctx->shape, ctx->tabs, (uint32_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g), g->d_lut),
+      launch_sample_gauss<uint64_t>(ctx->shape, ctx->tabs, (uint64_t *)d, first_poly, batch, g->d_cdt, w, en, x0, amplifier, key, stream_id, st, 0, 0, gauss_narrow(g), g->d_lut));
   if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss");
   return NFLHIP_OK;
 }
@@ -1574,7 +1586,7 @@ static int gauss_small_any(nflhip_ctx *ctx, void *d_out, int format, size_t firs
   for (uint64_t p : ctx->h_P)
     if (mag * amplifier >= p) return fail(ctx, NFLHIP_ERR_INVALID, "the samples are not below the modulus");
   hipError_t e = launch_gauss_small(ctx->shape, d_out, format, first_poly, batch, g->d_cdt, g->tab.words, (int)g->tab.entries,
-                                    g->tab.x_min, amplifier, key, stream_id, (hipStream_t)stream, seq_on, seq_stride, gauss_narrow(g));
+                                    g->tab.x_min, amplifier, key, stream_id, (hipStream_t)stream, seq_on, seq_stride, gauss_narrow(g), g->d_lut);
   if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8 (>= 16 under the 32-bit draw)");
   if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss_small");
   return NFLHIP_OK;

@@ -127,13 +127,16 @@ template <typename T>
 hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
                                const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
                                const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on = 0,
-                               uint64_t seq_stride = 0, int narrow = 0);
+                               uint64_t seq_stride = 0, int narrow = 0, const uint16_t *lut = nullptr);
+// the narrow draw's bucket table (device copy passed as `lut` above and below; empty = the table does not fit LDS)
+std::vector<uint16_t> gauss_bucket_table(const uint64_t *cdt, int words, size_t entries);
 
 // compact Gaussian polynomials (one signed integer x * amp per coefficient; format 1 int8 | 2 int16 | 3 int32) and their
 // expansion into residue words (format 0 = word rows: a strided gather); stride in polynomials, 0 = shared
 hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_poly, size_t batch, const uint64_t *cdt,
                               int words, int entries, long long x_min, uint64_t amp, const unsigned char *key32,
-                              uint64_t stream_id, hipStream_t st, int seq_on = 0, uint64_t seq_stride = 0, int narrow = 0);
+                              uint64_t stream_id, hipStream_t st, int seq_on = 0, uint64_t seq_stride = 0, int narrow = 0,
+                              const uint16_t *lut = nullptr);
 template <typename T>
 hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const void *src, int format, unsigned stride,
                                size_t batch, hipStream_t st);

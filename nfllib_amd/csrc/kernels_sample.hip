@@ -8,6 +8,7 @@
 // The map from random words to values is the reference's, statement for statement (cited per kernel); the tests feed
 // the same words through a numpy restatement that is pinned against the real reference.
 #include <atomic>
+#include <vector>
 
 #include "kernels.h"
 #include <type_traits>
@@ -467,48 +468,83 @@ __device__ __forceinline__ uint64_t gauss32_word(uint64_t g, const ChaChaKey &ke
   chacha20_block(key, g >> 4, nonce, blk);
   return gauss32_first_word(lane32_of(blk, (unsigned)(g & 15)), g, key, nonce);
 }
-// sixteen searches side by side over the table's top halves in LDS (`top`, one 32-bit word per entry)
+// Sixteen searches side by side over the table's top halves in LDS (`top`, one 32-bit word per entry), each STARTED by a
+// bucket table (`lut`, kGaussBuckets entries, built on the host with the table, gauss_bucket_table below): the lane's top 12
+// bits name a bucket; lut[b] = (number of entries whose top half lies below the bucket) | min(entries inside it, 15) << 12.
+// The answer is then known up to the entries inside the bucket -- none or one almost everywhere, so kGaussLutSteps = 2
+// branch-free steps close every bucket of at most 3 entries.  A sample in a denser bucket (the far tails, where dozens of
+// entries share their top 12 bits: ~2^-11 per sample) or one that ties with a top half is redone alone: the plain search over
+// the whole table and, on a tie, the exact one with the lower half of its first word.  Same value either way.
+constexpr int kGaussBucketBits = 12, kGaussBuckets = 1 << kGaussBucketBits, kGaussLutSteps = 2;
 template <int W>
-__device__ __forceinline__ void gauss_search16(const uint64_t (&w)[8], uint64_t g0, const uint32_t *top,
-                                               const uint64_t *__restrict__ cdt, int entries, int iters, int tie_shift,
+__device__ __noinline__ int gauss_search32_one(uint32_t r, uint64_t g, const uint32_t *top, const uint64_t *__restrict__ cdt, int entries,
+                                               int tie_shift, const ChaChaKey &key, uint64_t nc) {
+  const int ts = tie_shift > 31 ? 31 : tie_shift;
+  int lo = 0, hi = entries - 1;
+  bool tie = false;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const uint32_t es = top[mid] >> ts, rs = r >> ts;
+    tie |= rs == es;
+    if (rs < es) hi = mid; else lo = mid + 1;
+  }
+  return tie ? gauss_search<W>(gauss32_first_word(r, g, key, nc), g, cdt, entries, tie_shift, key, nc) : lo;
+}
+template <int W>
+__device__ __forceinline__ void gauss_search16(const uint64_t (&w)[8], uint64_t g0, const uint32_t *top, const uint16_t *lut,
+                                               const uint64_t *__restrict__ cdt, int entries, int tie_shift,
                                                const ChaChaKey &key, uint64_t nc, int (&out)[16]) {
   int lo[16], hi[16];
   uint32_t r[16];
-  unsigned tied = 0;
+  unsigned redo = 0;
   const int ts = tie_shift > 31 ? 31 : tie_shift;   // (the test hook widens the ties of this stage too)
 #pragma unroll
-  for (int c = 0; c < 16; ++c) lo[c] = 0, hi[c] = entries - 1, r[c] = (uint32_t)(w[c >> 1] >> (32 * (c & 1)));
-  for (int it = 0; it < iters; ++it) {
+  for (int c = 0; c < 16; ++c) {
+    r[c] = (uint32_t)(w[c >> 1] >> (32 * (c & 1)));
+    const unsigned e = lut[r[c] >> (32 - kGaussBucketBits)];
+    const int inside = (int)(e >> kGaussBucketBits);
+    lo[c] = (int)(e & (kGaussBuckets - 1));
+    hi[c] = min(lo[c] + inside, entries - 1);
+    redo |= inside >= (1 << kGaussLutSteps) ? (1u << c) : 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < kGaussLutSteps; ++it) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int mid = (lo[c] + hi[c]) >> 1;
       const uint32_t es = top[mid] >> ts, rs = r[c] >> ts;
       const bool open = lo[c] < hi[c], less = rs < es;
-      tied |= (open && rs == es) ? (1u << c) : 0u;    // the lower half always matters on a tie, one-word tables included
+      redo |= (open && rs == es) ? (1u << c) : 0u;    // the lower half always matters on a tie, one-word tables included
       hi[c] = (open && less) ? mid : hi[c];
       lo[c] = (open && !less) ? mid + 1 : lo[c];
     }
   }
 #pragma unroll
   for (int c = 0; c < 16; ++c) out[c] = lo[c];
-  if (tied) {
+  if (redo) {
 #pragma unroll
     for (int c = 0; c < 16; ++c)
-      if (tied & (1u << c)) out[c] = gauss_search<W>(gauss32_first_word(r[c], g0 + c, key, nc), g0 + c, cdt, entries, tie_shift, key, nc);
+      if (redo & (1u << c)) out[c] = gauss_search32_one<W>(r[c], g0 + c, top, cdt, entries, tie_shift, key, nc);
   }
 }
-__device__ __forceinline__ void stage_gauss_top32(uint32_t *top, const uint64_t *__restrict__ cdt, int entries, int W) {
+// LDS image of a narrow-draw kernel: top halves [entries, rounded up to even], then the bucket table
+__device__ __forceinline__ const uint16_t *stage_gauss_top32(uint32_t *top, const uint64_t *__restrict__ cdt, const uint16_t *__restrict__ lut_g,
+                                                             int entries, int W) {
+  uint16_t *lut = reinterpret_cast<uint16_t *>(top + ((entries + 1) & ~1));
   for (int k = threadIdx.x; k < entries; k += blockDim.x) top[k] = (uint32_t)(cdt[(size_t)k * W] >> 32);
+  for (int k = threadIdx.x; k < kGaussBuckets / 8; k += blockDim.x)
+    reinterpret_cast<uint4 *>(lut)[k] = reinterpret_cast<const uint4 *>(lut_g)[k];
   __syncthreads();
+  return lut;
 }
-// sixteen consecutive coefficients of one keystream block -> their table indices (iters = 0: the table does not fit LDS)
+// sixteen consecutive coefficients of one keystream block -> their table indices (lut == nullptr: the table does not fit LDS)
 template <int W>
-__device__ __forceinline__ void gauss_block16(uint64_t g0, const uint32_t *top, const uint64_t *__restrict__ cdt, int entries, int iters,
-                                              int tie_shift, const ChaChaKey &key, uint64_t nc, int (&r)[16]) {
+__device__ __forceinline__ void gauss_block16(uint64_t g0, const uint32_t *top, const uint16_t *lut, const uint64_t *__restrict__ cdt,
+                                              int entries, int tie_shift, const ChaChaKey &key, uint64_t nc, int (&r)[16]) {
   uint64_t w[8];
   chacha20_block(key, g0 >> 4, nc, w);
-  if (iters) {
-    gauss_search16<W>(w, g0, top, cdt, entries, iters, tie_shift, key, nc, r);
+  if (lut) {
+    gauss_search16<W>(w, g0, top, lut, cdt, entries, tie_shift, key, nc, r);
   } else {
 #pragma unroll
     for (int c = 0; c < 16; ++c)
@@ -520,9 +556,10 @@ __device__ __forceinline__ void gauss_block16(uint64_t g0, const uint32_t *top, 
 template <typename S, int W>
 __global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t first_coef, size_t ncoef,
                                                        const uint64_t *__restrict__ cdt, int entries, long long x_min,
-                                                       long long amp, ChaChaKey key, uint64_t nonce, int tie_shift, int iters) {
+                                                       long long amp, ChaChaKey key, uint64_t nonce, int tie_shift,
+                                                       const uint16_t *__restrict__ lut_g) {
   extern __shared__ uint32_t gtop32[];
-  if (iters) stage_gauss_top32(gtop32, cdt, entries, W);
+  const uint16_t *lut = lut_g ? stage_gauss_top32(gtop32, cdt, lut_g, entries, W) : nullptr;
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 4;  // first_coef and ncoef are multiples of 16 (n >= 16)
   for (size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups; grp += (size_t)gridDim.x * blockDim.x) {
@@ -532,7 +569,7 @@ __global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t 
       g0 &= n - 1;
     }
     int r[16];
-    gauss_block16<W>(g0, gtop32, cdt, entries, iters, tie_shift, key, nc, r);
+    gauss_block16<W>(g0, gtop32, lut, cdt, entries, tie_shift, key, nc, r);
     uint32_t v[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) v[c] = (uint32_t)(int32_t)(S)((x_min + r[c]) * amp);
@@ -561,11 +598,11 @@ template <typename T, int W>
 __global__ void __launch_bounds__(256) k_sample_gauss16(T *d, const ModConst<T> *__restrict__ mc, int logn, int nm,
                                                         uint64_t first_coef, size_t ncoef, const uint64_t *__restrict__ cdt,
                                                         int entries, long long x_min, uint64_t amp, ChaChaKey key, uint64_t nonce,
-                                                        int tie_shift, int iters) {
+                                                        int tie_shift, const uint16_t *__restrict__ lut_g) {
   constexpr int S = kTS;
   __shared__ int xs[4][16 * S];
   extern __shared__ uint32_t gtop32[];
-  if (iters) stage_gauss_top32(gtop32, cdt, entries, W);
+  const uint16_t *lut = lut_g ? stage_gauss_top32(gtop32, cdt, lut_g, entries, W) : nullptr;
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 4;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -579,7 +616,7 @@ __global__ void __launch_bounds__(256) k_sample_gauss16(T *d, const ModConst<T> 
         g0 &= n - 1;
       }
       int r[16];
-      gauss_block16<W>(g0, gtop32, cdt, entries, iters, tie_shift, key, nc, r);
+      gauss_block16<W>(g0, gtop32, lut, cdt, entries, tie_shift, key, nc, r);
 #pragma unroll
       for (int c = 0; c < 16; ++c) xs[wv][c * S + lane] = r[c];
     }
@@ -926,6 +963,21 @@ hipError_t launch_sample(const Shape &s, const DevTables &t, T *d, size_t first_
 static std::atomic<int> g_gauss_tie_shift{0};
 void set_gauss_tie_shift(int shift) { g_gauss_tie_shift.store(shift < 0 ? 0 : (shift > 63 ? 63 : shift)); }
 static int gauss_tie_shift() { return g_gauss_tie_shift.load(std::memory_order_relaxed); }
+// the bucket table of the narrow draw's search (gauss_search16), from the table's first words; empty when the table does not fit LDS
+std::vector<uint16_t> gauss_bucket_table(const uint64_t *cdt, int words, size_t entries) {
+  std::vector<uint16_t> lut;
+  if (entries < 2 || entries > (size_t)kGaussLdsEntries) return lut;
+  lut.resize(kGaussBuckets);
+  size_t k = 0;
+  for (unsigned b = 0; b < (unsigned)kGaussBuckets; ++b) {
+    while (k < entries && (cdt[k * words] >> (64 - kGaussBucketBits)) < b) ++k;       // entries whose top half lies below the bucket
+    size_t in = 0;
+    while (k + in < entries && (cdt[(k + in) * words] >> (64 - kGaussBucketBits)) == b) ++in;
+    lut[b] = (uint16_t)((k > (size_t)kGaussBuckets - 1 ? (size_t)kGaussBuckets - 1 : k) | ((in > 15 ? 15 : in) << kGaussBucketBits));
+  }
+  return lut;
+}
+static size_t gauss_narrow_lds(int entries) { return (size_t)((entries + 1) & ~1) * 4 + (size_t)kGaussBuckets * 2; }
 // steps of the LDS-resident search (gauss_search8), 0 = the table is too long for LDS: the per-sample search over global memory
 static int gauss_lds_iters(int entries) {
   if (entries < 2 || entries > kGaussLdsEntries) return 0;
@@ -957,7 +1009,7 @@ template <typename T>
 hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch,
                                const uint64_t *cdt, int words, int entries, long long x_min, uint64_t amp,
                                const unsigned char *key32, uint64_t stream_id, hipStream_t st, int seq_on,
-                               uint64_t seq_stride, int narrow) {
+                               uint64_t seq_stride, int narrow, const uint16_t *lut) {
   if (batch == 0) return hipSuccess;
   if (seq_on && (s.n < (narrow ? 16u : 8u) || first_poly != 0)) return hipErrorNotSupported;
   const ModConst<T> *mc = (const ModConst<T> *)t.mc;
@@ -967,15 +1019,14 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
   const int tie_shift = gauss_tie_shift();
   if (narrow && s.n >= 16) {  // sixteen coefficients per thread
     const dim3 g(grid_for(ncoef / 16)), b(256);
-    const int iters = gauss_lds_iters(entries);
-    const size_t lds = iters ? (size_t)entries * 4 : 0;
+    const size_t lds = lut ? gauss_narrow_lds(entries) : 0;
     switch (words) {
-      case 1: hipLaunchKernelGGL((k_sample_gauss16<T, 1>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
-      case 2: hipLaunchKernelGGL((k_sample_gauss16<T, 2>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
-      case 3: hipLaunchKernelGGL((k_sample_gauss16<T, 3>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
-      case 4: hipLaunchKernelGGL((k_sample_gauss16<T, 4>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
-      case 5: hipLaunchKernelGGL((k_sample_gauss16<T, 5>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
-      case 6: hipLaunchKernelGGL((k_sample_gauss16<T, 6>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, iters); break;
+      case 1: hipLaunchKernelGGL((k_sample_gauss16<T, 1>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, lut); break;
+      case 2: hipLaunchKernelGGL((k_sample_gauss16<T, 2>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, lut); break;
+      case 3: hipLaunchKernelGGL((k_sample_gauss16<T, 3>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, lut); break;
+      case 4: hipLaunchKernelGGL((k_sample_gauss16<T, 4>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, lut); break;
+      case 5: hipLaunchKernelGGL((k_sample_gauss16<T, 5>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, lut); break;
+      case 6: hipLaunchKernelGGL((k_sample_gauss16<T, 6>), g, b, lds, st, d, mc, s.logn, (int)s.nm, fc, ncoef, cdt, entries, x_min, amp, key, stream_id, tie_shift, lut); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1011,7 +1062,7 @@ hipError_t launch_sample_gauss(const Shape &s, const DevTables &t, T *d, size_t 
 // format: 1 int8 | 2 int16 | 3 int32 (NFLHIP_FMT_*)
 hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_poly, size_t batch, const uint64_t *cdt,
                               int words, int entries, long long x_min, uint64_t amp, const unsigned char *key32,
-                              uint64_t stream_id, hipStream_t st, int seq_on, uint64_t seq_stride, int narrow) {
+                              uint64_t stream_id, hipStream_t st, int seq_on, uint64_t seq_stride, int narrow, const uint16_t *lut) {
   if (batch == 0) return hipSuccess;
   if (seq_on && (s.n < (narrow ? 16u : 8u) || first_poly != 0)) return hipErrorNotSupported;
   if (words < 1 || words > 6 || format < 1 || format > 3) return hipErrorInvalidValue;
@@ -1021,12 +1072,12 @@ hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_
   const int tie_shift = gauss_tie_shift();
   const long long a = (long long)amp;
   const int iters = gauss_lds_iters(entries);
-  const size_t lds = iters ? (size_t)entries * (narrow ? 4 : 8) : 0;
+  const size_t lds = narrow ? (lut ? gauss_narrow_lds(entries) : 0) : (iters ? (size_t)entries * 8 : 0);
 #define NFLHIP_GS(S, W)                                                                                                              \
   do {                                                                                                                               \
     if (narrow && s.n >= 16)                                                                                                         \
       hipLaunchKernelGGL((k_gauss_small16<S, W>), dim3(grid_for(ncoef / 16)), dim3(256), lds, st, (S *)d, s.logn, fc, ncoef, cdt,  \
-                         entries, x_min, a, key, stream_id, tie_shift, iters);                                                       \
+                         entries, x_min, a, key, stream_id, tie_shift, lut);                                                         \
     else if (!narrow && s.n >= 8)                                                                                                    \
       hipLaunchKernelGGL((k_gauss_small8<S, W>), dim3(grid_for(ncoef / 8)), dim3(256), lds, st, (S *)d, s.logn, fc, ncoef, cdt,    \
                          entries, x_min, a, key, stream_id, tie_shift, iters);                                                       \
@@ -1071,7 +1122,7 @@ hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const
                                        const unsigned char *, uint64_t, hipStream_t, int, uint64_t);                     \
   template hipError_t launch_sample_gauss<T>(const Shape &, const DevTables &, T *, size_t, size_t, const uint64_t *, int, \
                                              int, long long, uint64_t, const unsigned char *, uint64_t, hipStream_t, int,  \
-                                             uint64_t, int);                                                               \
+                                             uint64_t, int, const uint16_t *);                                             \
   template hipError_t launch_expand_small<T>(const Shape &, const DevTables &, T *, const void *, int, unsigned, size_t, hipStream_t);
 NFLHIP_INST(uint16_t)
 NFLHIP_INST(uint32_t)

@@ -45,7 +45,10 @@ def run(args):
         _lib.lib.nflhip_debug_fused_grid(args.grid)
     key = bytes(range(1, 33)) if args.fixed_key else os.urandom(32)
     B = args.batch
-    g = e.gauss_create(args.sigma, 128, 1 << 10)                    # FastGaussianNoise(SIGMA, 128, 1<<10), line 271
+    # FastGaussianNoise(SIGMA, 128, 1<<10), line 271; draw_bits 32 = the narrow draw (what include/nfl_hip/nfl.hpp's generator sets)
+    draw_bits = getattr(args, "draw_bits", 32)
+    g = e.gauss_create(args.sigma, 128, 1 << 10, draw_bits=draw_bits if args.degree >= 16 else 64)
+    narrow = draw_bits == 32
     sid = [0]
 
     def stream():
@@ -54,7 +57,7 @@ def run(args):
 
     # secret key s (NTT form), public key (pka uniform, pkb = 2e + pka*s): ONE polynomial each, shared by the batch
     s = e.ntt_(e.sample_gauss(e.empty(1), g, key, stream()))
-    pka = e.sample(e.empty(1), DIST_UNIFORM, key, stream())
+    pka = e.sample(e.empty(1), DIST_UNIFORM, key, stream(), narrow=narrow)
     pkb = e.ntt_(e.sample_gauss(e.empty(1), g, key, stream(), amplifier=2))
     pkb = e.eval(bytes([0, 1, 2, EXPR_MUL, EXPR_ADD]), [pkb, pka, s])                  # pkb + pka*s   (lines 281-283)
     resa, resb, dec = e.empty(B), e.empty(B), e.empty(B)
@@ -105,7 +108,7 @@ def run(args):
     ok = bool((bits == 0).all())
     noise = np.where(v < P[0] // 2, v, v - P[0]).astype(np.float64)
     out = {"demo": "LWE-like symmetric encryption of 0 (tests/nfllib_demo_main_op.cpp)", "plan": args.plan, "grid": args.grid, "limb_bits": getattr(args, "limb_bits", 64), "degree": args.degree,
-           "nmoduli": args.nmoduli, "batch": B, "encrypt_us_per_ciphertext": round(t_enc / B * 1e6, 4),
+           "nmoduli": args.nmoduli, "batch": B, "draw_bits": draw_bits, "encrypt_us_per_ciphertext": round(t_enc / B * 1e6, 4),
            "decrypt_us_per_ciphertext": round(t_dec / B * 1e6, 4), "encryptions_per_s": round(B / t_enc, 1),
            "decryptions_per_s": round(B / t_dec, 1), "decrypts_to_zero": ok,
            "noise_rms": round(float(np.sqrt((noise ** 2).mean())), 1),
@@ -151,6 +154,8 @@ def main():
     ap.add_argument("--sigma", type=float, default=3.19)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--plan", choices=("fused", "unfused"), default="fused")
+    ap.add_argument("--draw-bits", type=int, default=32, choices=(32, 64), dest="draw_bits",
+                    help="keystream bits a Gaussian sample consumes: 32 = the narrow draw (and narrow uniform lanes), 64 = one word per value")
     ap.add_argument("--traffic", action="store_true")
     ap.add_argument("--fixed-key", action="store_true", help="a fixed sampler key (reproducible digests)")
     ap.add_argument("--grid", type=int, default=0, help="experiment: 1 / 2 force the 2-D / the XCD-dealt 1-D grid of the fused kernels (nflhip_debug_fused_grid)")
