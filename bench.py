@@ -614,6 +614,14 @@ def main():
         t_su = rate(lambda: eng.sample(c, 0, skey, stream_id=1), 5)
         t_sg = rate(lambda: eng.sample_gauss(c, gs, skey, stream_id=2), 5)
         eng.gauss_destroy(gs)
+        # the narrow draws (include/nflhip.h NFLHIP_DIST_NARROW, nflhip_gauss_set_draw_bits): keystream lanes instead of 64-bit words
+        gs32 = eng.gauss_create(3.19, 128, n, draw_bits=32 if n >= 16 else 64)
+        t_sun = rate(lambda: eng.sample(c, 0, skey, stream_id=1, narrow=True), 5)
+        t_sgn = rate(lambda: eng.sample_gauss(c, gs32, skey, stream_id=2), 5)
+        small = eng.empty_small(batch)
+        t_sgc = rate(lambda: eng.sample_gauss_small(small, gs32, skey, stream_id=3), 5)
+        del small
+        eng.gauss_destroy(gs32)
         # the host-pointer entry point (nflhip_polymul: pageable host buffers in and out, PCIe included) -- never `value`
         hb = min(batch, max(1, (256 << 20) // (nm * n * w)))
         ha, hbb = eng.to_host(a[:hb]), eng.to_host(b[:hb])
@@ -648,6 +656,10 @@ def main():
             "crt_project_per_s": round(sub / t_p, 1), "crt_project_GBs": round(crt_bytes / t_p / 1e9, 1),
             "sample_uniform_per_s": round(batch / t_su, 1), "sample_uniform_GBs": round(batch * nm * n * w / t_su / 1e9, 1),
             "sample_gaussian_per_s": round(batch / t_sg, 1),
+            "narrow_draws": {"sample_uniform_per_s": round(batch / t_sun, 1), "sample_uniform_GBs": round(batch * nm * n * w / t_sun / 1e9, 1),
+                             "sample_gaussian_per_s": round(batch / t_sgn, 1), "sample_gaussian_compact_per_s": round(batch / t_sgc, 1),
+                             "sample_gaussian_compact_G_coefficients_per_s": round(batch * n / t_sgc / 1e9, 1),
+                             "what": "limb-width / 32-bit keystream lanes per value instead of one 64-bit word (profiles/r05_sampler_rates.txt)"},
             "host_pointer_polymul_per_s": round(hb / t_host, 1),
             **row_extra,
             "note": "GB/s are algorithmic bytes (SURVEY.md 8(d)) / event time; polys per second over the same batch",
