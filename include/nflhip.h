@@ -211,9 +211,10 @@ int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const vo
  * nflhip_sample_gauss_small_dev.  k operands and the operands of nflhip_fma_inv_dev are words in NTT form (canonical,
  * ops.hpp:131,211).  Results are dense; a result may alias any input of the same call (x, either e, either k).  u64 limbs at degree 4096,
  * 8192 and 16384 run one generated gfx950 kernel per call (at degree 32768 nflhip_fma_inv_dev does for dense a / b, and the forward
- * entries run three for int8 polynomials with keys of stride 0; rows of 1024 / 2048 words -- 4096 for 32-bit limbs -- run
- * nflhip_fma_inv_dev as one pass of the wave-per-row kernels); every other shape composes the same result from the plain kernels through
- * the context's scratch (calls on different streams of one context are then ordered by events, as for nflhip_polymul_dev). */
+ * entries run three for int8 polynomials with keys of stride 0); rows of 1024 / 2048 words -- 4096 for 32-bit limbs -- run every
+ * entry as ONE pass of the wave-per-row kernels (forward: inputs of one format, strides 0 / 1); every other shape composes the same
+ * result from the plain kernels through the context's scratch (calls on different streams of one context are then ordered by
+ * events, as for nflhip_polymul_dev). */
 #define NFLHIP_FMT_WORDS 0
 #define NFLHIP_FMT_I8 1
 #define NFLHIP_FMT_I16 2
@@ -230,10 +231,12 @@ int nflhip_fwd_fma2_dev(nflhip_ctx *ctx, void *d_out0, void *d_out1, const nflhi
                         void *stream);
 int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, const nflhip_operand *k,
                        const nflhip_operand *b, int subtract, size_t batch, void *stream);
-/* 1 when the three entries above run as generated kernels on this context (u64 limbs, the default kernel variant: ONE kernel each
- * at degree 4096 / 8192 / 16384; at degree 32768 one kernel for nflhip_fma_inv_dev and, for int8 polynomials with keys shared by the
- * batch, one per noise polynomial + one for the results), 0 when they compose the result from the plain kernels: what a caller that can choose between its own
- * operator sequence and these entries asks (the header's deferred queue only rewrites sequences when it gains a pass) */
+/* 1 when the three entries above run as one-pass kernels on this context (the default kernel variant; u64 limbs: ONE kernel each
+ * at degree 1024 / 2048 -- the wave-per-row kernels -- and 4096 / 8192 / 16384 -- generated; at degree 32768 one kernel for
+ * nflhip_fma_inv_dev and, for int8 polynomials with keys shared by the batch, one per noise polynomial + one for the results;
+ * u32 limbs: ONE kernel each at degree 1024 / 2048 / 4096), 0 when they compose the result from the plain kernels: what a caller
+ * that can choose between its own operator sequence and these entries asks (the header's deferred queue only rewrites sequences
+ * when it gains a pass) */
 int nflhip_has_fused_kernels(const nflhip_ctx *ctx);
 /* compact polynomial(s) -> residue words: d_data[b][cm][i] = v < 0 ? p_cm + v : v, v = element i of src's polynomial
  * b * stride (format NFLHIP_FMT_WORDS: a strided gather of word rows) */

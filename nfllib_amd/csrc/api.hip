@@ -1207,6 +1207,23 @@ static int fused_fwd_any(nflhip_ctx *ctx, void *out0, void *out1, const nflhip_o
     if (e == hipSuccess) return NFLHIP_OK;
     if (e != hipErrorNotSupported) return hipfail(ctx, e, "fwd_fma(fused)");
   }
+  // short rows (1024 / 2048 words; 4096 for 32-bit limbs): the wave-per-row kernels transform x once, keep it in registers and
+  // multiply-add each transformed noise row in place (kernels_wave.hip k_row_fwd_fma) -- operands of one format, strides 0 / 1
+  const bool aliased = two && (first_result_overlaps(ctx, out0, k1, batch) || first_result_overlaps(ctx, out0, e1, batch));
+  if (!aliased && !ctx->cyclic && !ctx->shape.compiled_only && x->format == e0->format && (!two || e1->format == x->format) && x->stride <= 1 &&
+      e0->stride <= 1 && k0->stride <= 1 && (!two || (e1->stride <= 1 && k1->stride <= 1))) {
+    hipError_t e = hipErrorNotSupported;
+    if (ctx->shape.limb_bits == 32)
+      e = launch_row_fwd_fma_u32(ctx->shape, ctx->tabs, x->format, (uint32_t *)out0, (uint32_t *)out1, x->ptr, (unsigned)x->stride,
+                                 (const uint32_t *)k0->ptr, (unsigned)k0->stride, e0->ptr, (unsigned)e0->stride, two ? (const uint32_t *)k1->ptr : nullptr,
+                                 two ? (unsigned)k1->stride : 0u, two ? e1->ptr : nullptr, two ? (unsigned)e1->stride : 0u, batch, st);
+    else if (ctx->shape.limb_bits == 64)
+      e = launch_row_fwd_fma_u64(ctx->shape, ctx->tabs, x->format, (uint64_t *)out0, (uint64_t *)out1, x->ptr, (unsigned)x->stride,
+                                 (const uint64_t *)k0->ptr, (unsigned)k0->stride, e0->ptr, (unsigned)e0->stride, two ? (const uint64_t *)k1->ptr : nullptr,
+                                 two ? (unsigned)k1->stride : 0u, two ? e1->ptr : nullptr, two ? (unsigned)e1->stride : 0u, batch, st);
+    if (e == hipSuccess) return NFLHIP_OK;
+    if (e != hipErrorNotSupported) return hipfail(ctx, e, "fwd_fma(rows)");
+  }
   return fused_fwd_composed(ctx, out0, out1, x, k0, e0, k1, e1, batch, st);
 }
 
@@ -1264,8 +1281,10 @@ int nflhip_fma_inv_dev(nflhip_ctx *ctx, void *d_out, const nflhip_operand *a, co
 }
 
 int nflhip_has_fused_kernels(const nflhip_ctx *ctx) {
-  return ctx && ctx->shape.limb_bits == 64 && ctx->shape.logn >= 12 && ctx->shape.logn <= 15 && !ctx->shape.compiled_only && ctx->shape.small_delta &&
-         ctx->shape.nm <= 65535 && !ctx->cyclic;
+  if (!ctx || ctx->shape.compiled_only || ctx->cyclic || ctx->shape.nm > 65535) return 0;
+  const Shape &s = ctx->shape;
+  if (s.limb_bits == 64) return s.small_delta && s.logn >= 10 && s.logn <= 15;    // 1024 / 2048: the wave-per-row kernels; 4096 ... 32768: generated
+  return s.limb_bits == 32 && s.logn >= 10 && s.logn <= 12;                       // the wave-per-row kernels
 }
 
 int nflhip_expand_small_dev(nflhip_ctx *ctx, void *d_data, const nflhip_operand *src, size_t batch, void *stream) {

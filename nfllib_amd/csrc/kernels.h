@@ -145,6 +145,14 @@ hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const
 // 2 fms_inv | 3 fma_inv; x: up to three operands with their formats (forward kinds) and strides, k: key rows with strides.
 // hipErrorNotSupported for other shapes / the compiled-only variant (api.hip composes the same result from the plain kernels)
 // INTT(b -+ a (.) key) in one pass on the wave-per-row kernels (kernels_wave.hip): rows of 1024 / 2048 words, 4096 for 32-bit limbs
+// out0 = NTT(x) k0 + NTT(e0) [, out1 = NTT(x) k1 + NTT(e1)] on the wave-per-row kernels (kernels_wave.hip k_row_fwd_fma): rows of 1024 /
+// 2048 words (4096 for 32-bit limbs), x / e0 / e1 of one format, strides 0 or 1; hipErrorNotSupported otherwise
+hipError_t launch_row_fwd_fma_u32(const Shape &s, const DevTables &t, int format, uint32_t *out0, uint32_t *out1, const void *x, unsigned xs,
+                                  const uint32_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint32_t *k1, unsigned k1s, const void *e1,
+                                  unsigned e1s, size_t batch, hipStream_t st);
+hipError_t launch_row_fwd_fma_u64(const Shape &s, const DevTables &t, int format, uint64_t *out0, uint64_t *out1, const void *x, unsigned xs,
+                                  const uint64_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint64_t *k1, unsigned k1s, const void *e1,
+                                  unsigned e1s, size_t batch, hipStream_t st);
 hipError_t launch_row_fma_inv_u32(const Shape &s, const DevTables &t, int subtract, uint32_t *c, const uint32_t *a, const uint32_t *key,
                                   int kstride, const uint32_t *b, size_t batch, hipStream_t st);
 hipError_t launch_row_fma_inv_u64(const Shape &s, const DevTables &t, int subtract, uint64_t *c, const uint64_t *a, const uint64_t *key,

@@ -13,6 +13,7 @@
 // butterflies of the 4096-word kernels (modarith64.h), so u64 rows of 1024 words (tests/ntt_perfs.cpp's shape) get a
 // fused product too.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 #include "modarith.h"
@@ -427,6 +428,132 @@ __global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : 2)) void k_r
     for (int j = 0; j < 16; ++j) cr[t + W * j] = ra[j];
   }
 }
+// out0 = NTT(x) (.) k0 + NTT(e0) [, out1 = NTT(x) (.) k1 + NTT(e1)]: the encryption of the reference's demo
+// (tests/nfllib_demo_main_op.cpp:26-46) as ONE pass over rows this short -- x is transformed once and stays in registers, each
+// noise row is transformed in the same wave(s) and the multiply-add happens in the registers the transform leaves (NTT word
+// 16 t + q), against the key row read in that layout.  S = the operands' format: int8_t / int16_t / int32_t = ONE signed
+// integer per coefficient shared by the moduli (v < 0 stands for p + v), or T = residue words.
+// Compact rows are NOT read lane by lane (round 4 tried that: a wave instruction then moves 64 or 128 bytes and the kernel
+// lost to the composed plan): every lane fetches 16 contiguous bytes -- one instruction per wave covers a whole int8 row of
+// 1024 coefficients -- into the row's LDS slab, and the lane map of the first pass (x[t + W q]) is read back from there.
+template <class P, typename S, int LB>
+__device__ __forceinline__ void load_row_small(typename P::T (&r)[16], const S *src, typename P::T *lds, int t, typename P::T p) {
+  typedef typename P::T T;
+  constexpr int W = 16 * LB;
+  if constexpr (sizeof(S) >= 4) {   // 32-bit integers (or words): a wave load is already 256 contiguous bytes
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const S v = src[t + W * q];
+      r[q] = std::is_signed<S>::value ? (T)((long long)v < 0 ? (long long)p + (long long)v : (long long)v) : (T)v;
+    }
+  } else {
+    uint4 *stage = reinterpret_cast<uint4 *>(lds);
+    const uint4 *g = reinterpret_cast<const uint4 *>(src);
+    stage[t] = g[t];                                        // 16 W bytes per step: an int8 row is one step, an int16 row two
+    if constexpr (sizeof(S) == 2) stage[t + W] = g[t + W];
+    row_sync<LB>();
+    const S *l = reinterpret_cast<const S *>(lds);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int v = (int)l[t + W * q];
+      r[q] = (T)(v < 0 ? p + (T)(long long)v : (T)v);
+    }
+    row_sync<LB>();   // (the slab is the transform's exchange buffer next)
+  }
+}
+template <class P, typename S, int TWO, int LB>
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 4 : 2)) void k_row_fwd_fma(
+    typename P::T *out0, typename P::T *out1, const S *x, unsigned xs, const typename P::T *k0, unsigned k0s, const S *e0, unsigned e0s,
+    const typename P::T *k1, unsigned k1s, const S *e1, unsigned e1s, const typename P::TW *__restrict__ psi,
+    const typename P::MC *__restrict__ mc, int nm, size_t rows) {
+  typedef typename P::T T;
+  constexpr int W = 16 * LB, RPB = 256 / W, LOGN = LB == 4 ? 10 : (LB == 8 ? 11 : 12);
+  constexpr bool words = !std::is_signed<S>::value;
+  __shared__ T slab[RPB][kSlabWords * (W / 64)];
+  const int sub = threadIdx.x / W, t = threadIdx.x % W;
+  size_t row = (size_t)blockIdx.x * RPB + sub;
+  const bool live = row < rows;
+  if (!live) {
+    if (LB == 4) return;
+    row = rows - 1;
+  }
+  const size_t el = row / (size_t)nm;
+  const int cm = (int)(row - el * (size_t)nm);
+  const typename P::MC &mcr = mc[cm];
+  const typename P::K k = P::make(mcr);
+  const typename P::TW *tw = psi + ((size_t)cm << LOGN);
+  // a compact polynomial is one row of n integers per element; a word polynomial nm rows of n words
+  auto in_row = [&](const S *base, unsigned stride) { return base + ((((size_t)stride * el * (words ? (size_t)nm : 1)) + (words ? (size_t)cm : 0)) << LOGN); };
+  T rx[16], re[16];
+  load_row_small<P, S, LB>(rx, in_row(x, xs), slab[sub], t, (T)mcr.p);
+  fwd_row<P, LB>(rx, slab[sub], tw, t, k);
+  for (int h = 0; h < (TWO ? 2 : 1); ++h) {   // (left to the compiler: the body holds workgroup barriers for rows of several waves)
+    row_sync<LB>();   // the slab is reused
+    load_row_small<P, S, LB>(re, in_row(h ? e1 : e0, h ? e1s : e0s), slab[sub], t, (T)mcr.p);
+    fwd_row<P, LB>(re, slab[sub], tw, t, k);
+    const unsigned ks = h ? k1s : k0s;
+    const T *kr = (h ? k1 : k0) + ((((size_t)ks * el) * (size_t)nm + (size_t)cm) << LOGN) + 16 * t;
+    T *o = (h ? out1 : out0) + (row << LOGN) + 16 * t;
+    T res[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) res[q] = P::canon(P::mul(rx[q], kr[q], k) + P::canon(re[q], k), k);
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[q] = res[q];
+    }
+  }
+}
+template <class P, typename S, int LB>
+static hipError_t launch_fwd_fma_rows_fmt(const Shape &s, const DevTables &t, typename P::T *out0, typename P::T *out1, const void *x, unsigned xs,
+                                          const typename P::T *k0, unsigned k0s, const void *e0, unsigned e0s, const typename P::T *k1, unsigned k1s,
+                                          const void *e1, unsigned e1s, size_t batch, hipStream_t st) {
+  const size_t rows = batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  constexpr int RPB = 256 / (16 * LB);
+  const size_t blocks = (rows + RPB - 1) / RPB;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const typename P::TW *psi = (const typename P::TW *)t.psi;
+  const typename P::MC *mc = (const typename P::MC *)t.mc;
+  if (out1)
+    hipLaunchKernelGGL((k_row_fwd_fma<P, S, 1, LB>), dim3((unsigned)blocks), dim3(256), 0, st, out0, out1, (const S *)x, xs, k0, k0s, (const S *)e0, e0s,
+                       k1, k1s, (const S *)e1, e1s, psi, mc, (int)s.nm, rows);
+  else
+    hipLaunchKernelGGL((k_row_fwd_fma<P, S, 0, LB>), dim3((unsigned)blocks), dim3(256), 0, st, out0, out1, (const S *)x, xs, k0, k0s, (const S *)e0, e0s,
+                       k0, k0s, (const S *)e0, e0s, psi, mc, (int)s.nm, rows);
+  return hipGetLastError();
+}
+template <class P, int LB>
+static hipError_t launch_fwd_fma_rows(const Shape &s, const DevTables &t, int format, typename P::T *out0, typename P::T *out1, const void *x, unsigned xs,
+                                      const typename P::T *k0, unsigned k0s, const void *e0, unsigned e0s, const typename P::T *k1, unsigned k1s,
+                                      const void *e1, unsigned e1s, size_t batch, hipStream_t st) {
+  switch (format) {
+    case 0: return launch_fwd_fma_rows_fmt<P, typename P::T, LB>(s, t, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+    case 1: return launch_fwd_fma_rows_fmt<P, int8_t, LB>(s, t, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+    case 2: return launch_fwd_fma_rows_fmt<P, int16_t, LB>(s, t, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+    case 3: return launch_fwd_fma_rows_fmt<P, int32_t, LB>(s, t, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+    default: return hipErrorNotSupported;
+  }
+}
+// rows of 1024 / 2048 words (and 4096 for 32-bit limbs); x, e0, e1 of ONE format (NFLHIP_FMT_*), every stride 0 or 1; out1 == nullptr:
+// one result.  hipErrorNotSupported otherwise (api.hip composes the same result from the plain kernels)
+hipError_t launch_row_fwd_fma_u32(const Shape &s, const DevTables &t, int format, uint32_t *out0, uint32_t *out1, const void *x, unsigned xs,
+                                  const uint32_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint32_t *k1, unsigned k1s, const void *e1,
+                                  unsigned e1s, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 32) return hipErrorNotSupported;
+  if (s.logn == 10) return launch_fwd_fma_rows<Pol32, 4>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+  if (s.logn == 11) return launch_fwd_fma_rows<Pol32, 8>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+  if (s.logn == 12) return launch_fwd_fma_rows<Pol32M, 16>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+  return hipErrorNotSupported;
+}
+hipError_t launch_row_fwd_fma_u64(const Shape &s, const DevTables &t, int format, uint64_t *out0, uint64_t *out1, const void *x, unsigned xs,
+                                  const uint64_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint64_t *k1, unsigned k1s, const void *e1,
+                                  unsigned e1s, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || !s.small_delta) return hipErrorNotSupported;
+  if (s.logn == 10) return launch_fwd_fma_rows<Pol64, 4>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+  if (s.logn == 11) return launch_fwd_fma_rows<Pol64, 8>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+  return hipErrorNotSupported;
+}
+
 template <class P, int LB>
 static hipError_t launch_fma_inv_rows(const Shape &s, const DevTables &t, int subtract, typename P::T *c, const typename P::T *a,
                                       const typename P::T *key, int kstride, const typename P::T *b, size_t batch, hipStream_t st) {

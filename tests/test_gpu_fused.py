@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 KEY = bytes(range(32))
 EXPR_ADD, EXPR_SUB, EXPR_MUL = 0x10, 0x11, 0x12
 SHAPES = [(64, 4096, 4), (64, 4096, 1), (64, 4096, 3), (64, 1024, 2), (64, 8192, 2), (64, 8192, 1), (64, 16384, 8), (64, 16384, 1),
-          (64, 32768, 2), (32, 1024, 1), (32, 4096, 2), (16, 128, 1)]
+          (64, 32768, 2), (32, 1024, 1), (32, 4096, 2), (16, 128, 1), (64, 2048, 3), (32, 2048, 2), (32, 1024, 2)]
 
 
 def _words(o, batch, seed, operand=0):

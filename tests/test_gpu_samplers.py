@@ -235,7 +235,7 @@ def test_gaussian_beyond_192_bits(sigma, security, words, engine_factory):
 
 # ---- the narrow draws (NFLHIP_DIST_NARROW, nflhip_gauss_set_draw_bits(g, 32)): keystream lanes instead of 64-bit words ----------
 NARROW_SHAPES = [(64, 4096, 4, 3), (64, 4, 3, 7), (32, 1024, 2, 3), (32, 8, 2, 5), (32, 16, 3, 4), (16, 128, 1, 4), (16, 16, 2, 9),
-                 (16, 32, 2, 5), (16, 2048, 2, 2), (32, 32768, 1, 1)]
+                 (16, 32, 2, 5), (16, 512, 2, 2), (32, 32768, 1, 1)]
 
 
 @pytest.mark.parametrize("lb,n,m,batch", NARROW_SHAPES, ids=["u%d-n%d-m%d" % s[:3] for s in NARROW_SHAPES])
