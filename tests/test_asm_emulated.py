@@ -27,7 +27,9 @@ def generated():
 
     def get(stem):
         path = os.path.join(CSRC, stem + "_gfx950.s")
-        newest = max(os.path.getmtime(os.path.join(ROOT, "tools", g)) for g in GENERATORS)
+        srcs = [os.path.join(ROOT, "tools", g) for g in GENERATORS]
+        srcs += [os.path.join(ROOT, "tools", "asmgen", f) for f in os.listdir(os.path.join(ROOT, "tools", "asmgen")) if f.endswith(".py")]
+        newest = max(os.path.getmtime(f) for f in srcs)
         if not state["ran"] and (not os.path.exists(path) or os.path.getmtime(path) < newest):
             for g in GENERATORS:
                 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", g)], stdout=subprocess.DEVNULL)

@@ -9,6 +9,7 @@ for v in ${ABLATIONS:-tw0 nolds row0 nobfly tw0,nolds,row0}; do
   cp -r nfllib_amd/csrc $d/nfllib_amd/
   cp -r include $d/
   cp tools/gen_*.py $d/tools/
+  cp -r tools/asmgen $d/tools/
   touch $d/tools/gen_polymul_asm.py
   (cd $d/nfllib_amd/csrc && NFL_GEN_ABLATE=$v make -s -j4 > make.log 2>&1 && echo "$v built" || echo "$v FAILED") &
 done
