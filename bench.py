@@ -666,7 +666,7 @@ def main():
         }
         del bn, limbs
         # what callers run AROUND the transforms: the reference's LWE demo (tests/nfllib_demo_main_op.cpp:26-58) on this
-        # workload's ring, operator by operator and through the transform-fused pipelines (DESIGN.md section 10) -- same
+        # workload's ring, operator by operator and through the transform-fused pipelines (DESIGN.md section 5.5) -- same
         # keystreams, so the two plans must produce the same ciphertexts (digests compared)
         if lb == 64 and n in (4096, 8192, 16384, 32768):
             try:
