@@ -143,7 +143,7 @@ def measure_traffic(workload, batch):
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", str(steps),
-                   "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline", "--no-traffic", "--no-rccl", "--no-side-configs"]
+                   "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline", "--no-traffic", "--no-rccl", "--no-side-configs", "--prewarm", "0"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="polys per GPU (default: workload default)")
     ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
+    ap.add_argument("--prewarm", type=float, default=1.0, help="seconds of untimed launches before the W warm-up steps (clock ramp after idle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel secondary rates")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -426,6 +427,15 @@ def main():
             comm = None
             rccl = {"initialised": world > 1, "world_size": world, "backend": backend, "error": "nflhip_comm: " + repr(e)}
 
+    # device warm-up BY TIME before the W warm-up steps: after an idle period the part needs a few hundred milliseconds of work to
+    # reach the clock it then holds under its power limit -- the first launches of the metric kernel run ~6 % slower than the held
+    # rate (profiles/r03_power_clock.txt: 3.24 ms first, 3.04 ms held per 16 384 products), and W = 5 steps are 15 ms.  Untimed,
+    # like the W steps; `sustained` below (the same launch held for 2.5 s) is the figure this makes the headline agree with.
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.prewarm:
+        for _ in range(8):
+            eng.polymul(a, b, out=c)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         eng.polymul(a, b, out=c)
     torch.cuda.synchronize()
