@@ -18,7 +18,7 @@ FUZZ = os.path.join(CPP, "deferred_fuzz")
 
 
 def _build():
-    subprocess.check_call(["make", "-s", "-C", CPP, "surface_test", "resident_test", "deferred_fuzz", "serialize_archive", "strictmod_test"])
+    subprocess.check_call(["make", "-s", "-j5", "-C", CPP, "surface_test", "resident_test", "deferred_fuzz", "serialize_archive", "strictmod_test"])
     assert os.path.exists(BIN) and os.path.exists(RES) and os.path.exists(FUZZ)
 
 
