@@ -13,7 +13,7 @@ done
 here=$(pwd)
 for wl in B A C E F; do
   rm -rf /tmp/prof_$wl
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python $here/bench.py --workload $wl --steps 20 --warmup 3 --no-extras --no-cpu-baseline --no-traffic > $here/$out/${tag}_bench_${wl}_under_rocprof.json 2>/dev/null)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python $here/bench.py --workload $wl --steps 20 --warmup 3 --no-extras --no-cpu-baseline --no-traffic --no-side-configs > $here/$out/${tag}_bench_${wl}_under_rocprof.json 2>/dev/null)
   f=$(find /tmp/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats_${wl}.csv
   rm -rf /tmp/prof_$wl
