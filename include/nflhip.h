@@ -312,7 +312,9 @@ enum {
   NFLHIP_DIST_REFERENCE_WORDS = 0x100,
   /* OR into NFLHIP_DIST_UNIFORM: the NARROW draw -- residue word g reads the limb-width LANE g of the keystream (bytes
    * [g w, (g + 1) w), little endian, w = limb bytes) instead of one 64-bit word, in a keystream domain of its own.  Same map
-   * from the lane to the residue (mask, one conditional subtraction), so the distribution is the reference's; a u16 / u32
+   * from the lane to the residue (mask, one conditional subtraction), so the distribution is the reference's -- and so is the
+   * consumption: the reference fills _data with fastrandombytes and reduces every limb-width word in place (core.hpp:152-188),
+   * i.e. residue word g is made from bytes [g w, (g + 1) w) of ITS stream (tests/test_samplers_cpu.py pins exactly that); a u16 / u32
    * polynomial costs a quarter / half of the ChaCha20 rounds (measured: profiles/r05_sampler_rates.txt).  The values differ
    * from the wide rule's for the same (key, stream_id) -- a different domain, by design: what the wide rule produces, and
    * every digest recorded from it, keeps its meaning. */

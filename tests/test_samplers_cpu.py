@@ -173,3 +173,62 @@ def test_gaussian_fixtures_from_the_real_reference():
             r = np.array([[int.from_bytes((p + pad * (8 * W - len(p)))[8 * j:8 * j + 8], "big") for j in range(W)] for p in prefixes],
                          dtype=np.uint64)
             assert np.array_equal(S.gaussian_from_table(r, t["table"], t["x_min"]), got)
+
+
+# ---- the narrow draws (oracle/samplers.py chacha20_lanes / uniform_narrow_words / gaussian_words_narrow) -----------------------
+KEY = bytes((7 * i + 3) & 0xFF for i in range(32))
+
+
+def test_keystream_lanes_are_the_little_endian_bytes_of_the_words():
+    w = S.chacha20_words(KEY, 5, 3, 40, counter_base=S.domain_base("uniform_narrow"))
+    raw = w.tobytes()
+    for lane_bytes, dt in ((1, np.uint8), (2, np.uint16), (4, np.uint32), (8, np.uint64)):
+        per = 8 // lane_bytes
+        lanes = S.chacha20_lanes(KEY, 5, 3 * per, 40 * per, lane_bytes, counter_base=S.domain_base("uniform_narrow"))
+        assert lanes.tobytes() == raw and lanes.dtype == dt
+        # any window, aligned or not
+        part = S.chacha20_lanes(KEY, 5, 3 * per + 5, 17, lane_bytes, counter_base=S.domain_base("uniform_narrow"))
+        assert np.array_equal(part, lanes[5:22])
+
+
+@pytest.mark.parametrize("tag", _shapes())
+def test_the_narrow_uniform_rule_is_the_references_rule_on_its_own_byte_stream(tag):
+    """The reference's poly(uniform) fills _data with fastrandombytes and reduces every limb-width word in place (core.hpp:152-188):
+    residue word g is made from bytes [g w, (g + 1) w) of the stream.  That IS the narrow rule; the fixture captured from the real
+    reference (raw bytes, resulting polynomial) pins S.uniform on exactly that reading of the bytes."""
+    lb, n, m, P = _moduli(tag)
+    key = next((k for k in GOLD.files if k.startswith(tag + "/uniform") and k.endswith("/raw")), None)
+    if key is None:
+        pytest.skip("no uniform fixture for this shape")
+    raw, want = GOLD[key], GOLD[key[:-3] + "out"]
+    lanes = np.frombuffer(raw.tobytes(), dtype={16: "<u2", 32: "<u4", 64: "<u8"}[lb]).reshape(m, n)
+    assert np.array_equal(S.uniform(lanes, P), want.reshape(m, n))
+    # and the device's narrow keystream is read the same way: lane g = bytes [g w, (g + 1) w)
+    words = S.uniform_narrow_words(KEY, 9, 0, m * n, lb)
+    stream = S.chacha20_words(KEY, 9, 0, (m * n * lb // 8 + 7) // 8, counter_base=S.domain_base("uniform_narrow")).tobytes()
+    assert words.tobytes() == stream[:m * n * lb // 8]
+
+
+@pytest.mark.parametrize("sigma,security", [(3.19, 128), (20.0, 128), (2.0, 20)])
+def test_the_narrow_gaussian_draw_has_the_tables_distribution(sigma, security):
+    """(32-bit lane, 32-bit lower lane, secondary words) is a uniform W-word number, so its inversion through the table has the
+    table's distribution: chi-square against the tail-cut discrete Gaussian, and agreement with the wide draw's statistics.
+    The table is the engine's host-built one (pinned against the real reference's MPFR table above)."""
+    from nfllib_amd.engine import gauss_table
+    info = gauss_table(sigma, security, 1024)
+    N = 1 << 16
+    r = S.gaussian_words_narrow(KEY, 77, 0, N, info["words"])
+    assert r.shape == (N, info["words"]) and r.dtype == np.uint64
+    x = S.gaussian_from_table(r, info["table"], info["x_min"])
+    pmf = S.gaussian_pmf(sigma, 0.0, info["x_min"], info["entries"])
+    obs = np.bincount(x - info["x_min"], minlength=info["entries"]).astype(np.float64)
+    exp = pmf * N
+    keep = exp >= 8
+    stat = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum() + (obs[~keep].sum() - exp[~keep].sum()) ** 2 / max(exp[~keep].sum(), 1e-9)
+    dof = int(keep.sum())
+    assert stat < dof + 6 * np.sqrt(2 * dof), (stat, dof)
+    assert abs(x.mean()) < 5 * sigma / np.sqrt(N) and abs(x.var() / sigma ** 2 - 1) < 0.03
+    # first words: top half = lane g of domain 7, lower half = lane g of domain 8 -- independent streams
+    hi = S.chacha20_lanes(KEY, 77, 0, N, 4, counter_base=S.domain_base("gauss32")).astype(np.uint64)
+    lo = S.chacha20_lanes(KEY, 77, 0, N, 4, counter_base=S.domain_base("gauss32_ref")).astype(np.uint64)
+    assert np.array_equal(r[:, 0], (hi << np.uint64(32)) | lo) and not np.array_equal(hi, lo)
