@@ -944,10 +944,12 @@ template <class P> struct lazy {
     static const size_t v = getenv("NFL_HIP_QUEUE_LIMIT") ? size_t(atol(getenv("NFL_HIP_QUEUE_LIMIT"))) : 8192;
     return v ? v : 1;
   }
-  // (Round 5: a loop's first two runs at HALF that length -- so that the device starts earlier on short loops -- was measured
-  //  and dropped: LWE demo loop 2 048 iterations 1.68 -> 1.85 M encryptions/s, but 1 024: 1.60 -> 1.39 M, 4 096: 2.12 -> 2.08 M,
-  //  16 384: 2.48 -> 2.43 M.  The host records an encryption in 0.36 us and a queue run costs it ~36 us, so 2.78 M/s is the
-  //  ceiling of ANY run policy at 2 048 iterations: profiles/r05_short_loops.txt.)
+  // (Round 5 measured two run-length policies for SHORT loops and dropped both -- LWE demo loop, encryptions/s against the fixed
+  //  length: a loop's first two runs at HALF length: 2 048 iterations 1.68 -> 1.85 M, but 1 024: 1.60 -> 1.39 M, 4 096: 2.12 ->
+  //  2.08 M, 16 384: 2.48 -> 2.43 M; its first run at THREE QUARTERS: 2 048: 1.67 -> 1.88 M, 4 096: 2.10 -> 2.16 M, but 1 536:
+  //  1.67 -> 1.60 M, 3 072: 2.01 -> 1.86 M.  Any fixed threshold moves the sawtooth, it does not remove it: what a short loop
+  //  pays beyond its recording is the device work that starts when the loop ends.  The host records an encryption in 0.36 us
+  //  and a run costs it ~36 us, so 2.78 M/s is the ceiling of ANY policy at 2 048 iterations: profiles/r05_short_loops.txt.)
 
   // NFL_HIP_EARLY_RUN=1: from 1 024 records on, every 512 records the queue asks whether the stream is idle
   // (nflhip_stream_idle: one hipStreamQuery) and runs at once if it is.  Off by default: measured on the LWE demo's

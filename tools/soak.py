@@ -28,4 +28,30 @@ for lb, n, m, batch in ((64, 4096, 4, 2048), (64, 8192, 2, 1024), (64, 16384, 8,
     print("u%d/%d/%d batch %d: %d iterations, %d mismatches" % (lb, n, m, batch, iters, mism))
     bad += mism
     e.close()
+
+# round 5: the wave-per-row fused forward kernels (LDS-staged compact rows) and the narrow-draw samplers, same question
+KEY = bytes(range(32))
+for lb, n, m, batch in ((32, 1024, 2, 4099), (64, 1024, 2, 2051), (64, 2048, 3, 1025), (32, 2048, 2, 2049), (32, 4096, 2, 513)):
+    e = Engine(lb, n, m)
+    g = e.gauss_create(3.19, 128, n, draw_bits=32)
+    x, e0, e1 = (e.sample_gauss_small(e.empty_small(batch), g, KEY, stream_id=i + 1) for i in range(3))
+    k0 = e.sample(e.empty(1), 0, KEY, stream_id=9, narrow=True)
+    k1 = e.sample(e.empty(1), 0, KEY, stream_id=10, narrow=True)
+    r0, r1 = e.fwd_fma2(x, k0, e0, k1, e1)
+    r0, r1 = r0.clone(), r1.clone()
+    torch.cuda.synchronize()
+    mism = 0
+    for it in range(iters):
+        o0, o1 = e.fwd_fma2(x, k0, e0, k1, e1)
+        mism += int(e.any_neq(o0, r0)) + int(e.any_neq(o1, r1))
+        if it % 4 == 0:
+            x2 = e.sample_gauss_small(e.empty_small(batch), g, KEY, stream_id=1)
+            mism += int(not torch.equal(x2, x))
+            u2 = e.sample(e.empty(1), 0, KEY, stream_id=9, narrow=True)
+            mism += int(e.any_neq(u2, k0))
+    print("u%d/%d/%d batch %d fused forward rows + narrow samplers: %d iterations, %d mismatches" % (lb, n, m, batch, iters, mism))
+    bad += mism
+    e.gauss_destroy(g)
+    e.close()
+print("SOAK", "CLEAN" if bad == 0 else "MISMATCHES: %d" % bad)
 sys.exit(1 if bad else 0)
