@@ -1210,7 +1210,10 @@ static int fused_fwd_any(nflhip_ctx *ctx, void *out0, void *out1, const nflhip_o
   // short rows (1024 / 2048 words; 4096 for 32-bit limbs): the wave-per-row kernels transform x once, keep it in registers and
   // multiply-add each transformed noise row in place (kernels_wave.hip k_row_fwd_fma) -- operands of one format, strides 0 / 1
   const bool aliased = two && (first_result_overlaps(ctx, out0, k1, batch) || first_result_overlaps(ctx, out0, e1, batch));
-  if (!aliased && !ctx->cyclic && !ctx->shape.compiled_only && x->format == e0->format && (!two || e1->format == x->format) && x->stride <= 1 &&
+  // (compact rows are fetched 16 bytes per lane: their arrays must be 16-byte aligned -- device allocations are; a caller's odd offset
+  //  into one takes the composed plan)
+  const bool aligned16 = ((((uintptr_t)x->ptr) | ((uintptr_t)e0->ptr) | (two ? (uintptr_t)e1->ptr : 0)) & 15) == 0;
+  if (!aliased && aligned16 && !ctx->cyclic && !ctx->shape.compiled_only && x->format == e0->format && (!two || e1->format == x->format) && x->stride <= 1 &&
       e0->stride <= 1 && k0->stride <= 1 && (!two || (e1->stride <= 1 && k1->stride <= 1))) {
     hipError_t e = hipErrorNotSupported;
     if (ctx->shape.limb_bits == 32)

@@ -236,3 +236,24 @@ def test_ambiguous_operand_shapes_are_refused(engine_factory):
             e.fwd_fma(bad, k, w)
     with pytest.raises(ValueError):
         e.fwd_fma(w, compact, w)                                       # keys are words
+
+
+def test_compact_rows_at_an_odd_offset_take_the_composed_plan(engine_factory, oracle_factory):
+    """the wave-per-row forward kernels fetch compact rows 16 bytes per lane; an int8 array that starts at an odd byte is still a
+    legal operand (one signed integer per coefficient) and gives the same words through the composed plan"""
+    import torch
+    lb, n, nm, batch = 32, 1024, 2, 5
+    e, o = engine_factory(lb, n, nm), oracle_factory(lb, n, nm)
+    P = np.asarray(e.P, dtype=np.uint64)
+    rng = np.random.default_rng(3)
+    raw = [torch.from_numpy(rng.integers(-100, 100, size=batch * n + 16, dtype=np.int8)).to("cuda:0") for _ in range(3)]
+    odd = [r[3:3 + batch * n].view(batch, n) for r in raw]              # storage offset 3 bytes
+    assert all(t.data_ptr() % 16 == 3 and t.is_contiguous() for t in odd)
+    even = [t.clone() for t in odd]
+    ka, kb = e.to_device(o.fill_uniform(1, 7, 0)), e.to_device(o.fill_uniform(1, 7, 1))
+    g0, g1 = e.fwd_fma2(odd[0], ka, odd[1], kb, odd[2])
+    w0, w1 = e.fwd_fma2(even[0], ka, even[1], kb, even[2])
+    assert torch.equal(g0, w0) and torch.equal(g1, w1)
+    w = [_signed_rows(t.cpu().numpy(), P, e.np_dtype) for t in even]
+    f = [o.ntt(x) for x in w]
+    assert np.array_equal(e.to_host(g0), o.pointwise(0, o.pointwise(2, f[0], _bc(e.to_host(ka), f[0])), f[1]))
