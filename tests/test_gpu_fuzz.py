@@ -100,6 +100,100 @@ def test_random_sampler_calls(shape, batch, first, sid, ub, amp, rho, key, sigma
     e.gauss_destroy(g)
 
 
+_fused_shape = st.one_of(
+    st.tuples(st.just(32), st.integers(10, 12), st.integers(1, 4)),     # the wave-per-row kernels (u32: 1024 / 2048 / 4096 words)
+    st.tuples(st.just(64), st.integers(10, 11), st.integers(1, 5)),     # ... u64: 1024 / 2048
+    st.tuples(st.just(64), st.integers(12, 13), st.integers(1, 3)),     # the generated kernels (4096 / 8192)
+    st.tuples(st.just(32), st.integers(5, 9), st.integers(1, 3)),       # composed plans
+    st.tuples(st.just(16), st.integers(5, 9), st.integers(1, 2)),
+)
+
+
+@settings(max_examples=90, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(shape=_fused_shape, batch=st.integers(1, 9), seed=st.integers(0, 2**31), fmt=st.sampled_from(["words", "i8", "i16", "i32"]),
+       xs=st.integers(0, 1), es=st.integers(0, 1), ks=st.integers(0, 1), two=st.booleans(), alias=st.integers(0, 3), sub=st.booleans())
+def test_random_fused_pipeline_calls(shape, batch, seed, fmt, xs, es, ks, two, alias, sub, oracle_factory, engine_factory):
+    """nflhip_fwd_fma[2]_dev / nflhip_fma_inv_dev on random shapes, batches, operand formats, strides (0 = one polynomial for the batch)
+    and result aliasing, against the oracle run operator by operator: the one-pass kernels of every row family and the composed
+    plan must agree with it bit for bit."""
+    import torch
+    lb, logn, m = shape
+    n = 1 << logn
+    o, e = oracle_factory(lb, n, m), engine_factory(lb, n, m)
+    P = np.asarray(e.P, dtype=np.uint64)
+    rng = np.random.default_rng(seed)
+
+    def operand(count, which):
+        if fmt == "words":
+            h = o.fill_uniform(count, seed + which, which & 1)
+            return h, e.to_device(h)
+        np_fmt = {"i8": np.int8, "i16": np.int16, "i32": np.int32}[fmt]
+        bound = min(int(P.min()) - 1, np.iinfo(np_fmt).max)
+        c = rng.integers(-bound, bound, size=(count, n), endpoint=True).astype(np_fmt)
+        v = c.astype(np.int64)[:, None, :]
+        return np.where(v < 0, P[None, :, None].astype(np.int64) + v, v).astype(e.np_dtype), torch.from_numpy(c).to("cuda:0")
+
+    bc = lambda h: np.ascontiguousarray(np.broadcast_to(h, (batch,) + h.shape[1:]))
+    xh, xd = operand(batch if xs else 1, 0)
+    e0h, e0d = operand(batch if es else 1, 1)
+    e1h, e1d = operand(batch if es else 1, 2)
+    k0h, k1h = o.fill_uniform(batch if ks else 1, seed + 7, 0), o.fill_uniform(batch if ks else 1, seed + 7, 1)
+    k0d, k1d = e.to_device(k0h), e.to_device(k1h)
+    fx = o.ntt(bc(xh))
+    want0 = o.pointwise(0, o.pointwise(2, fx, bc(k0h)), o.ntt(bc(e0h)))
+    want1 = o.pointwise(0, o.pointwise(2, fx, bc(k1h)), o.ntt(bc(e1h)))
+    # a result over a dense word input of its own result (legal aliasing), or fresh
+    out0 = out1 = None
+    if fmt == "words" and alias == 1 and es:
+        e0d = e0d.clone(); out0 = e0d
+    if fmt == "words" and alias == 2 and xs and not two:
+        xd = xd.clone(); out0 = xd
+    if fmt == "words" and alias == 3 and ks and two:
+        k1d = k1d.clone(); out1 = k1d
+    if two:
+        g0, g1 = e.fwd_fma2(xd, k0d, e0d, k1d, e1d, out0=out0, out1=out1, batch=batch)
+        assert np.array_equal(e.to_host(g0), want0) and np.array_equal(e.to_host(g1), want1)
+    else:
+        g0 = e.fwd_fma(xd, k0d, e0d, out=out0, batch=batch)
+        assert np.array_equal(e.to_host(g0), want0)
+    # the inverse entry on the same operands (NTT-form words): INTT(b -+ a k)
+    ah, bh = o.fill_uniform(batch, seed + 11, 0), o.fill_uniform(batch, seed + 11, 1)
+    prod = o.pointwise(2, ah, bc(k0h))
+    wanti = o.intt(o.pointwise(1 if sub else 0, bh, prod))
+    ad, bd = e.to_device(ah), e.to_device(bh)
+    outi = bd if alias == 1 else (ad if alias == 2 else None)
+    assert np.array_equal(e.to_host(e.fma_inv(ad, k0d, bd, subtract=sub, out=outi, batch=batch)), wanti)
+
+
+@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(shape=_shape, batch=st.integers(1, 6), first=st.integers(0, 1000), sid=st.integers(0, 2**64 - 1), key=st.binary(min_size=32, max_size=32),
+       sigma=st.sampled_from([2.0, 3.19, 20.0]), sec=st.sampled_from([20, 64, 100]), amp=st.integers(1, 3))
+def test_random_narrow_draw_calls(shape, batch, first, sid, key, sigma, sec, amp, engine_factory):
+    """the narrow draws (NFLHIP_DIST_NARROW, nflhip_gauss_set_draw_bits(g, 32)) on random shapes, shards, stream ids and keys against
+    the restated rules fed with the very keystream lanes"""
+    import torch
+    from nfllib_amd import DIST_UNIFORM
+    from oracle import samplers as S
+    lb, logn, m = shape
+    n = 1 << logn
+    e = engine_factory(lb, n, m)
+    P = [int(e.table(1, cm)[0]) for cm in range(m)]
+    lanes = S.uniform_narrow_words(key, sid, first * m * n, batch * m * n, lb).reshape(batch, m, n)
+    got = e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, key, stream_id=sid, first_poly=first, narrow=True))
+    assert np.array_equal(got, S.uniform(lanes, P))
+    if lb == 16 and sigma > 3.2:
+        return
+    g = e.gauss_create(sigma, security=sec, samples=1024, draw_bits=32)
+    info = e.gauss_info(g)
+    want = S.gaussian_from_table(S.gaussian_words_narrow(key, sid, first * n, batch * n, info["words"]), info["table"], info["x_min"])
+    v = S.centered(e.to_host(e.sample_gauss(e.empty(batch), g, key, stream_id=sid, first_poly=first)), P)[:, 0].reshape(-1)
+    assert np.array_equal(v, want)
+    if amp * max(abs(info["x_min"]), info["x_min"] + info["entries"] - 1) < min(min(P), 1 << 31):
+        sm = e.sample_gauss_small(torch.empty((batch, n), dtype=torch.int32, device="cuda:0"), g, key, stream_id=sid, amplifier=amp, first_poly=first)
+        assert np.array_equal(sm.cpu().numpy().reshape(-1).astype(np.int64), amp * want)
+    e.gauss_destroy(g)
+
+
 def test_the_walk_was_wide():
     """(runs after the fuzz above) every limb width and both ends of the degree range were visited"""
     assert len(_RAN) >= 100
