@@ -186,7 +186,7 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False):
+def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False, round_trip=False):
     """One more BASELINE config timed inside the driver's run (extras.configs): `steps` products over a resident batch,
     HIP events on the launch stream, in-run counter traffic -- the same quantities as the headline, for the shapes the
     driver does not time itself."""
@@ -216,6 +216,25 @@ def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False):
                "steps": steps, "value": round(batch / (ms * 1e-3), 1), "unit": "polymul/s", "ms_per_step": round(ms, 4),
                "achieved_GBs": round(alg * batch / (ms * 1e-3) / 1e9, 1), "frac": round(alg * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "algorithmic_bytes_per_polymul": alg, "self_check": bool(ok)}
+        if round_trip:
+            # BASELINE configs[0] is the NTT + INTT round trip of tests/ntt_perfs.cpp on this shape (there: CPU only)
+            rt = a.clone()
+            for _ in range(4):
+                eng.intt_(eng.ntt_(rt))
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                eng.intt_(eng.ntt_(rt))
+            e1.record()
+            torch.cuda.synchronize()
+            msr = e0.elapsed_time(e1) / steps
+            rt_bytes = 4 * nm * n * (lb // 8)          # two in-place transforms: 2 x (read + write)
+            out["ntt_intt_round_trip"] = {"value": round(batch / (msr * 1e-3), 1), "unit": "round trips/s", "ms_per_step": round(msr, 4),
+                                          "achieved_GBs": round(rt_bytes * batch / (msr * 1e-3) / 1e9, 1),
+                                          "frac": round(rt_bytes * batch / (msr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "returns_the_input": bool(not eng.any_neq(rt, a)),
+                                          "reference": "tests/ntt_perfs.cpp: 50 000 round trips of poly<uint32_t,1024,1> on one core"}
+            del rt
         if with_crt:
             # BASELINE configs[4] is "CRT lift + poly-mul": GMP::poly2mpz (gmp.hpp:183-209) of the product, all coefficients
             L = eng.crt_limbs
@@ -338,7 +357,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.traffic)")
     ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: skip the world-size-1 RCCL initialisation")
-    ap.add_argument("--no-side-configs", action="store_true", help="workload B only: skip extras.configs (configs C and E timed in the same run)")
+    ap.add_argument("--no-side-configs", action="store_true", help="workload B only: skip extras.configs (configs A, C, D and E timed in the same run)")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1 only: also time one step whose operands start on rank 0 and whose product returns there "
                          "(grouped RCCL send/recv of contiguous shards, SURVEY.md 8(e)); reported beside `value`, never in it")
@@ -724,9 +743,9 @@ def main():
             a = b = c = None
             torch.cuda.empty_cache()
             side = {}
-            for wl, sb, st_, crt in (("C", 1024, 20, False), ("E", 64, 20, True)):
+            for wl, sb, st_, crt in (("A", 1 << 19, 20, False), ("C", 1024, 20, False), ("E", 64, 20, True)):
                 try:
-                    side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt)
+                    side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt, round_trip=wl == "A")
                 except Exception as ex:   # reported, never fatal
                     side[wl] = {"error": repr(ex)}
             extras["configs"] = side

@@ -154,7 +154,9 @@ def test_headline_line_carries_sustained_independent_secondary_and_side_configs(
     assert "error" not in hdr and hdr["poly_p_encryptions_per_s"] > 20 * hdr["poly_p_eager_encryptions_per_s"]
     assert hdr["device_batch_fused_encryptions_per_s"] > 1.3 * hdr["device_batch_encryptions_per_s"]
     cfg = d["extras"]["configs"]
-    for wl in ("C", "E"):
+    rt = cfg["A"]["ntt_intt_round_trip"]        # BASELINE configs[0]'s operation on the device
+    assert rt["value"] > 0 and rt["returns_the_input"] is True and "uint32_t,1024,1" in cfg["A"]["workload"]
+    for wl in ("A", "C", "E"):
         c = cfg[wl]
         assert "error" not in c, c
         assert c["self_check"] is True and c["value"] > 0 and 0 < c["frac"] < 1 and c["traffic_ratio"] is not None and c["traffic_ratio"] > 0.98
