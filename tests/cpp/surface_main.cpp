@@ -500,6 +500,7 @@ int main() {
     ok &= run<uint16_t, 128, 1>();      // 128,14,uint16_t
     ok &= run<uint32_t, 1024, 2>();     // 1024,60,uint32_t
     ok &= run<uint64_t, 64, 3>();
+    ok &= run<uint64_t, 64, 94>();      // moduli past the 92nd (2^62 - p >= 2^32: the general-modulus kernels), schoolbook-checked
     ok &= run<uint64_t, 4096, 4>();     // BASELINE configs[1]
     ok &= run<uint64_t, 8192, 2>();     // 8192,124,uint64_t
     ok &= run_samplers<uint64_t, 4096, 4>();
