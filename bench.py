@@ -743,7 +743,7 @@ def main():
             a = b = c = None
             torch.cuda.empty_cache()
             side = {}
-            for wl, sb, st_, crt in (("A", 1 << 19, 20, False), ("C", 1024, 20, False), ("E", 64, 20, True)):
+            for wl, sb, st_, crt in (("A", 1 << 19, 20, False), ("C", 2048, 20, False), ("E", 128, 20, True)):
                 try:
                     side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt, round_trip=wl == "A")
                 except Exception as ex:   # reported, never fatal
