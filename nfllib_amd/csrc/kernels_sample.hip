@@ -545,10 +545,16 @@ __device__ __forceinline__ void gauss_block16(uint64_t g0, const uint32_t *top, 
   chacha20_block(key, g0 >> 4, nc, w);
   if (lut) {
     gauss_search16<W>(w, g0, top, lut, cdt, entries, tie_shift, key, nc, r);
-  } else {
+  } else {   // (tables beyond kGaussLdsEntries: the exact search per sample; the sixteen lower halves are ONE block of the second domain)
+    ChaChaKey kr = key;
+    kr.dom = ((uint64_t)kDomGauss32Ref) << 56;
+    uint64_t lo[8];
+    chacha20_block(kr, g0 >> 4, nc, lo);
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      r[c] = gauss_search<W>(gauss32_first_word((uint32_t)(w[c >> 1] >> (32 * (c & 1))), g0 + c, key, nc), g0 + c, cdt, entries, tie_shift, key, nc);
+    for (int c = 0; c < 16; ++c) {
+      const uint64_t r0 = ((uint64_t)(uint32_t)(w[c >> 1] >> (32 * (c & 1))) << 32) | (uint64_t)(uint32_t)(lo[c >> 1] >> (32 * (c & 1)));
+      r[c] = gauss_search<W>(r0, g0 + c, cdt, entries, tie_shift, key, nc);
+    }
   }
 }
 
