@@ -357,7 +357,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.traffic)")
     ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: skip the world-size-1 RCCL initialisation")
-    ap.add_argument("--no-side-configs", action="store_true", help="workload B only: skip extras.configs (configs A, C, D and E timed in the same run)")
+    ap.add_argument("--no-side-configs", action="store_true", help="workload B only: skip extras.configs (configs A, C, D, E and the reference's largest test shape F timed in the same run)")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1 only: also time one step whose operands start on rank 0 and whose product returns there "
                          "(grouped RCCL send/recv of contiguous shards, SURVEY.md 8(e)); reported beside `value`, never in it")
@@ -743,7 +743,7 @@ def main():
             a = b = c = None
             torch.cuda.empty_cache()
             side = {}
-            for wl, sb, st_, crt in (("A", 1 << 19, 20, False), ("C", 2048, 20, False), ("E", 128, 20, True)):
+            for wl, sb, st_, crt in (("A", 1 << 19, 20, False), ("C", 2048, 20, False), ("F", 2048, 20, False), ("E", 128, 20, True)):
                 try:
                     side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt, round_trip=wl == "A")
                 except Exception as ex:   # reported, never fatal
