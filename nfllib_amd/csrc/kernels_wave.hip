@@ -24,6 +24,12 @@ namespace nflhip {
 typedef Tw<u32> Tw32;
 typedef ModConst<u32> MC32;
 
+// workgroups of 256 threads per CU the 64-bit row kernels are compiled for (register budget 512 / (2 x this) VGPRs per thread).
+// Measured (round 5, same box, u64/1024/2 and u64/2048/2 products per second): 2: 38.8 M / 16.8 M; 3: 27.0 M / 16.9 M; 4: 21.4 M /
+// 13.4 M -- the fused product keeps two rows of 16 words in registers and spills beyond two workgroups per CU
+#ifndef NFLHIP_W64_OCC
+#define NFLHIP_W64_OCC 2
+#endif
 static constexpr int kSlabWords = 1088;  // LDS words per 1024 row words (padding of either exchange layout included)
 
 __device__ __forceinline__ u32 lazy2(u32 x, u32 p2) { return min(x, x - p2); }  // [0,4p) -> [0,2p)
@@ -345,7 +351,7 @@ __device__ __forceinline__ void row_body(typename P::T *c, const typename P::T *
 template <class P, int MODE, int LB>
 // 32-bit limbs: 4 waves per SIMD for the fused products (measured round 2, u32/1024/1: 3, 4, 5 waves 198, 201, 193 M
 // products/s, 6 and 8 (spills) 169 and 152 -- the kernel is bound by VALU issue, not by latency), 5 for the transforms
-__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? (MODE == 0 || (LB == 16 && MODE == 1) ? 4 : 5) : 2)) void k_row(
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? (MODE == 0 || (LB == 16 && MODE == 1) ? 4 : 5) : NFLHIP_W64_OCC)) void k_row(
     typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::TW *__restrict__ psi,
     const typename P::MC *__restrict__ mc, int nm, size_t rows) {
   constexpr int W = 16 * LB, RPB = 256 / W, LOGN = LB == 4 ? 10 : (LB == 8 ? 11 : 12);  // rows per 256-thread block: 4, 2, 1
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256) void k_row1024_lds(typename P::T *c, const typ
 // (tests/nfllib_demo_main_op.cpp:51-57) as ONE pass -- the multiply-subtract happens in the registers the inverse transform
 // starts from.  key: one polynomial for the batch (kstride 0) or one per element (1).
 template <class P, int SUB, int LB>
-__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : 2)) void k_row_fma_inv(
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 5 : NFLHIP_W64_OCC)) void k_row_fma_inv(
     typename P::T *c, const typename P::T *a, const typename P::T *b, const typename P::T *key, int kstride,
     const typename P::TW *__restrict__ psi, const typename P::MC *__restrict__ mc, int nm, size_t rows) {
   typedef typename P::T T;
@@ -462,7 +468,7 @@ __device__ __forceinline__ void load_row_small(typename P::T (&r)[16], const S *
   }
 }
 template <class P, typename S, int TWO, int LB>
-__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 4 : 2)) void k_row_fwd_fma(
+__global__ __launch_bounds__(256, (sizeof(typename P::T) == 4 ? 4 : NFLHIP_W64_OCC)) void k_row_fwd_fma(
     typename P::T *out0, typename P::T *out1, const S *x, unsigned xs, const typename P::T *k0, unsigned k0s, const S *e0, unsigned e0s,
     const typename P::T *k1, unsigned k1s, const S *e1, unsigned e1s, const typename P::TW *__restrict__ psi,
     const typename P::MC *__restrict__ mc, int nm, size_t rows) {
