@@ -182,3 +182,25 @@ def test_same_rows_as_a_small_delta_context(oracle_factory, engine_factory):
     a92, b92 = np.ascontiguousarray(a[:, :92]), np.ascontiguousarray(b[:, :92])
     got92 = e92.to_host(e92.polymul(e92.to_device(a92), e92.to_device(b92)))
     assert np.array_equal(got95[:, :92], got92)
+
+
+def test_samplers_on_the_late_moduli(oracle_factory, engine_factory):
+    """the random constructors are modulus-generic (mask, one conditional subtraction; v < 0 -> p + v): wide and narrow draws on a
+    94-modulus context against the restated rules fed with the very keystream words"""
+    from nfllib_amd import DIST_UNIFORM
+    from oracle import samplers as S
+    n, m, batch = 1024, 94, 2
+    o, e = _ctx(n, m, oracle_factory, engine_factory)
+    P = [int(p) for p in o.P]
+    key = bytes(range(32))
+    words = S.chacha20_words(key, 3, 0, batch * m * n, counter_base=S.domain_base("uniform")).reshape(batch, m, n)
+    assert np.array_equal(e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, key, stream_id=3)), S.uniform(words, P))
+    lanes = S.uniform_narrow_words(key, 3, 0, batch * m * n, 64).reshape(batch, m, n)
+    assert np.array_equal(e.to_host(e.sample(e.empty(batch), DIST_UNIFORM, key, stream_id=3, narrow=True)), S.uniform(lanes, P))
+    for bits, rule in ((64, S.gaussian_words), (32, S.gaussian_words_narrow)):
+        g = e.gauss_create(3.19, 128, n, draw_bits=bits)
+        info = e.gauss_info(g)
+        want = S.gaussian_from_table(rule(key, 5, 0, batch * n, info["words"]), info["table"], info["x_min"])
+        got = S.centered(e.to_host(e.sample_gauss(e.empty(batch), g, key, stream_id=5)), P)
+        assert all(np.array_equal(got[:, cm].reshape(-1), want) for cm in (0, 91, 92, m - 1)), bits
+        e.gauss_destroy(g)
