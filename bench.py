@@ -122,6 +122,46 @@ def cpu_baseline(limb_bits, degree, nmoduli, budget_s=12.0, check=None):
     return out
 
 
+_ORACLES = {}
+
+
+def oracle_for(limb_bits, degree, nmoduli):
+    """the CPU checker (oracle/nfl_oracle.c rebuilt -march=native under gpurun_out/ when possible), one instance per shape.
+    Test infrastructure: used OUTSIDE every timed region, to check sampled polynomials of the products the blocks time."""
+    key = (limb_bits, degree, nmoduli)
+    if key not in _ORACLES:
+        from nfllib_amd.params import params
+        from oracle import oracle as O
+        libpath = None
+        try:
+            native_dir = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(native_dir, exist_ok=True)
+            O.build(native_out=native_dir)
+            libpath = os.path.join(native_dir, "libnfloracle_native.so")
+        except Exception:
+            libpath = None
+        _ORACLES[key] = O.Oracle(limb_bits, degree, nmoduli, params(limb_bits), libpath=libpath)
+    return _ORACLES[key]
+
+
+def oracle_samples(eng, a, b, c, idx, limbs=None):
+    """Copy the polynomials `idx` of a timed product's operands and result to the host, recompute the products with the CPU
+    oracle and compare bit for bit (and, given the device's lifted coefficients, the CRT lift of those results against
+    oracle.crt_lift).  Returns the keys every bench block carries: parity_sample_ok, parity_sample[, crt_parity_sample_ok]."""
+    import numpy as np
+    o = oracle_for(eng.limb_bits, eng.degree, eng.nmoduli)
+    idx = sorted(set(int(i) for i in idx))
+    ha, hb, hc = (np.concatenate([eng.to_host(t[i:i + 1]) for i in idx]) for t in (a, b, c))
+    t0 = time.perf_counter()
+    out = {"parity_sample_ok": bool(np.array_equal(o.polymul(ha, hb), hc)),
+           "parity_sample": "polynomials %s of the timed batch recomputed by the CPU oracle, bit-exact compare" % (idx,)}
+    if limbs is not None:
+        hl = np.concatenate([limbs[i:i + 1].detach().cpu().contiguous().numpy().view(np.uint64) for i in idx])
+        out["crt_parity_sample_ok"] = bool(np.array_equal(np.asarray(o.crt_lift(hc)).reshape(hl.shape), hl))
+    out["parity_sample_seconds"] = round(time.perf_counter() - t0, 2)
+    return out
+
+
 def measure_traffic(workload, batch):
     """HBM bytes one step moves, measured IN THIS RUN: two short re-runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domains, as MI355X_MICROARCH.md's HBM
@@ -211,12 +251,20 @@ def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False, roun
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
         ok = not eng.any_neq(c, eng.polymul(b, a))
+        # ... and against the CPU oracle: the first polynomial, one inside, the first of the LAST chunk of the long-row plans
+        # (n = 65536: the pipeline works through the batch in 4 chunks) and the last one
+        try:
+            parity = oracle_samples(eng, a, b, c, {0, batch // 3, batch - max(1, batch // 4), batch - 1} if n < 65536
+                                    else {0, batch - batch // 4, batch - 1})
+        except Exception as ex:   # reported (as a failed check), never fatal
+            parity = {"parity_sample_ok": None, "parity_sample": "failed: %r" % (ex,)}
         alg = 3 * nm * n * (lb // 8)
         what = "BASELINE configs %s" % workload if workload != "F" else "the reference's largest test configuration, tests/CMakeLists.txt (32768, 124, uint64_t)"
         out = {"workload": "nfl::poly<uint%d_t,%d,%d> batched polymul (%s)" % (lb, n, nm, what), "batch": batch,
                "steps": steps, "value": round(batch / (ms * 1e-3), 1), "unit": "polymul/s", "ms_per_step": round(ms, 4),
                "achieved_GBs": round(alg * batch / (ms * 1e-3) / 1e9, 1), "frac": round(alg * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "algorithmic_bytes_per_polymul": alg, "self_check": bool(ok)}
+        out.update(parity)
         if round_trip:
             # BASELINE configs[0] is the NTT + INTT round trip of tests/ntt_perfs.cpp on this shape (there: CPU only)
             rt = a.clone()
@@ -241,6 +289,13 @@ def side_config(torch, Engine, workload, batch, steps, dev, with_crt=False, roun
             L = eng.crt_limbs
             limbs = eng.crt_lift(c)
             torch.cuda.synchronize()
+            try:
+                cp = oracle_samples(eng, a, b, c, {0, batch - 1}, limbs=limbs)
+                out["crt_parity_sample_ok"] = cp["crt_parity_sample_ok"] and cp["parity_sample_ok"]
+                out["crt_parity_sample"] = "GMP::poly2mpz of polynomials 0 and %d of the product against oracle.crt_lift, bit-exact limbs" % (batch - 1)
+            except Exception as ex:
+                out["crt_parity_sample_ok"] = None
+                out["crt_parity_sample"] = "failed: %r" % (ex,)
             e0.record()
             for _ in range(steps):
                 eng.crt_lift(c)
@@ -301,6 +356,14 @@ def shard_config_d(torch, eng, rank, world, steps, barrier, gather_u64, max_over
     the block then says that it is not config 4."""
     shard = int(os.environ.get("NFLHIP_BENCH_D_SHARD", D_SHARD))
     first = rank * shard
+    # pre-flight: three resident tensors of the shard (48 GiB at 2^17) + the commutativity check's fourth + head room must fit in
+    # the device's FREE memory; every rank takes the same decision (the smallest free figure over the ranks decides)
+    need = 4 * shard * eng.nmoduli * eng.degree * 8 + (1 << 30)
+    free = -max_over_ranks(-float(torch.cuda.mem_get_info()[0]))
+    preflight = {"ok": bool(need <= free), "needed_GiB": round(need / 2.0**30, 2), "free_GiB": round(free / 2.0**30, 2)}
+    if not preflight["ok"]:
+        raise RuntimeError("pre-flight: a shard of %d polynomials needs %.1f GiB resident, %.1f GiB are free on the fullest device"
+                           % (shard, preflight["needed_GiB"], preflight["free_GiB"]))
     a = eng.fill_uniform(eng.empty(shard), SEED, 0, first_poly=first)
     b = eng.fill_uniform(eng.empty(shard), SEED, 1, first_poly=first)
     c = eng.empty(shard)
@@ -321,6 +384,10 @@ def shard_config_d(torch, eng, rank, world, steps, barrier, gather_u64, max_over
     dt = max_over_ranks(time.perf_counter() - t0)
     kernel_ms = max_over_ranks(e0.elapsed_time(e1) / steps)
     commutes = not eng.any_neq(c, eng.polymul(b, a))
+    try:
+        parity = oracle_samples(eng, a, b, c, {0, shard // 2, shard - 1}) if rank == 0 else {}
+    except Exception as ex:
+        parity = {"parity_sample_ok": None, "parity_sample": "failed: %r" % (ex,)}
     own = gather_u64(eng.digest(c, first_poly=first))
     nxt = (rank + 1) % world
     eng.fill_uniform(a, SEED, 0, first_poly=nxt * shard)
@@ -339,7 +406,7 @@ def shard_config_d(torch, eng, rank, world, steps, barrier, gather_u64, max_over
             "steps": steps, "value": round(world * shard * steps / dt, 1), "unit": "polymul/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "kernel_ms": round(kernel_ms, 4), "achieved_GBs_per_gpu": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
             "resident_GiB_per_gpu": round(3 * shard * eng.nmoduli * eng.degree * 8 / 2.0**30, 2), "scaling": "weak",
-            "self_check": bool(commutes and own == cross),
+            "self_check": bool(commutes and own == cross), **parity, "preflight": preflight,
             "checksum_of_checksums": {"ok": bool(own == cross), "sum_of_shard_digests": "%016x" % sharding.combine_digests(own),
                                       "recomputed_on_the_neighbouring_gpu": "%016x" % sharding.combine_digests(cross), "shards": world},
             "how": "value = world x shard x steps / max-over-ranks wall time between barriers; no data-path collective"}
@@ -773,7 +840,7 @@ def main():
         "metric": "poly-mults/sec (NTT+pointwise+INTT), n=4096, 4x62-bit moduli" if args.workload == "B"
                   else "poly-mults/sec (NTT+pointwise+INTT), n=%d, %dx%d-bit moduli" % (n, nm, lb - 2),
         "value": round(value, 1), "unit": "polymul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "prewarm_s": args.prewarm, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u%d" % lb, "data": "synthetic",
         "config": {"workload": "nfl::poly<uint%d_t,%d,%d> batched polymul (BASELINE configs %s)" % (lb, n, nm, args.workload),
                    "degree": n, "nmoduli": nm, "limb_bits": lb, "batch_per_gpu": batch, "global_batch": batch * world,
@@ -798,6 +865,7 @@ def main():
         result["roofline"].update({
             "binding": "valu-issue at the package power limit",
             "ceiling_frac_no_memory": ceil,
+            "ceiling_measured": "round 3 (not re-measured in this run)",
             "ceiling_source": "profiles/r03_power_ablation.txt: the metric kernel with HBM, twiddle and LDS traffic removed runs 6.56 M polymul/s "
                               "(x 393 216 B = 2.58 TB/s = 0.32 of 8 TB/s) at 1 290-1 395 W of the 1 400 W package limit, sclk ~2.07 GHz",
             "frac_of_ceiling": round(achieved / HBM_PEAK_GBS / ceil, 4)})

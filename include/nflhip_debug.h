@@ -29,6 +29,12 @@ void nflhip_debug_host_pipe_seconds(const struct nflhip_ctx *ctx, double out[4])
  * 1 = always the 2-D grid, 2 = always the XCD-dealt 1-D grid, 3 = the other register map at degree 4096.  Same results. */
 void nflhip_debug_fused_grid(int mode);
 
+/* which kernel serves nflhip_polymul[_dev] at 64-bit limbs, degree 4096, coefficient-form operands: 0 = complete transforms,
+ * 1 / 2 = the forward transforms stop that many stages early, the products are taken modulo X^2 / X^4 -+ zeta and the inverse
+ * starts as many stages late (tools/asmgen/incomplete.py).  Same words out.  Returns the previous setting; a negative level
+ * only reads it.  Process-wide. */
+int nflhip_debug_polymul_level(int level);
+
 #ifdef __cplusplus
 }
 #endif

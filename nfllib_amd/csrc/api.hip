@@ -420,6 +420,27 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   }
   HIPCHK(nullptr, hipMalloc(&c->tabs.mc, mc.size() * sizeof(ModConst<T>)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.mc, mc.data(), mc.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
+  c->tabs.mc_inc[0] = c->tabs.mc_inc[1] = nullptr;
+  if (sizeof(T) == 8 && n == 4096 && !c->cyclic && c->shape.small_delta) {
+    // the metric product on incomplete transforms (nflhip_polymul4096i{1,2}_asm): the inverse undoes 12 - level stages, so the
+    // scale folded into its last stage is (n / 2^level)^-1; the base multiplication reduces sums below 2^127 with
+    // floor(2^127 / p) = 2^65 + m, m < 2^35 (delta < 2^32), handed over in the mu2 field
+    for (int level = 1; level <= 2; ++level) {
+      std::vector<ModConst<T>> mi(mc);
+      for (size_t cm = 0; cm < nm; ++cm) {
+        const uint64_t p = P[cm];
+        const uint64_t ng = mulmod_h((uint64_t)mc[cm].ninv, (uint64_t)1 << level, p);
+        const uint64_t wg = mulmod_h((uint64_t)mc[cm].w1ninv, (uint64_t)1 << level, p);
+        mi[cm].ninv = (T)ng;
+        mi[cm].ninv_sh = (T)shoup_h(ng, p, wb);
+        mi[cm].w1ninv = (T)wg;
+        mi[cm].w1ninv_sh = (T)shoup_h(wg, p, wb);
+        mi[cm].mu2 = (T)(uint64_t)(((((u128)1) << 127) / p) - (((u128)1) << 65));
+      }
+      HIPCHK(nullptr, hipMalloc(&c->tabs.mc_inc[level - 1], mi.size() * sizeof(ModConst<T>)));
+      HIPCHK(nullptr, hipMemcpy(c->tabs.mc_inc[level - 1], mi.data(), mi.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
+    }
+  }
   HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qhat, qhat.size() * sizeof(uint64_t)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.qhat, qhat.data(), qhat.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qsh, qsh.size() * sizeof(uint64_t)));
@@ -809,6 +830,8 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->tabs.psi) (void)hipFree(ctx->tabs.psi);
   if (ctx->tabs.psi_lm) (void)hipFree(ctx->tabs.psi_lm);
   if (ctx->tabs.mc) (void)hipFree(ctx->tabs.mc);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->tabs.mc_inc[i]) (void)hipFree(ctx->tabs.mc_inc[i]);
   if (ctx->tabs.qhat) (void)hipFree(ctx->tabs.qhat);
   if (ctx->tabs.qsh) (void)hipFree(ctx->tabs.qsh);
   if (ctx->tabs.qparts) (void)hipFree(ctx->tabs.qparts);

@@ -51,6 +51,8 @@ struct DevTables {
   void *psi;        // [nm][n] Tw<T>
   void *psi_lm;     // 64-bit limbs, n >= 4096: the same with the last four stages lane-major (what the generated kernels read)
   void *mc;         // [nm] ModConst<T>
+  void *mc_inc[2];  // 64-bit limbs, n = 4096, delta-form moduli: the records the incomplete-transform products read (level 1, 2:
+                    // (n / 2^level)^-1 in the n^-1 fields, floor(2^127 / p) - 2^65 in mu2; tools/asmgen/incomplete.py), or nullptr
   uint64_t *qhat;   // [nm][crt_Lacc]  Q/p_cm, little-endian limbs
   uint64_t *qsh;    // [6][crt_Lacc]   Q << k, k = 0..5
   uint32_t *qparts; // [nm][3][72]     32-bit digits of (Q/p_cm) << 21 j   (carry-free lift), or nullptr

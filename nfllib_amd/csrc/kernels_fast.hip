@@ -356,6 +356,7 @@ enum AsmKind {
   kAsmFusedEnc2R, kAsmFusedFmaFwdR, kAsmFusedFmsInvR, kAsmFusedFmaInvR,  // ... of 4096 words on the ring-mode map (128 VGPRs, four workgroups per CU)
   kAsmFused32kFmsInv, kAsmFused32kFmaInv,                            // the inverse pipelines of a 32768-word row (build_row32k fms_inv / fma_inv)
   kAsmFwd32kI8, kAsmFused32kFmaFwdI8, kAsmFused32kEnc2I8,            // ... its forward transform / forward pipelines from a compact (int8) polynomial
+  kAsmPolymulI1, kAsmPolymulI2,                                      // the n = 4096 product on incomplete transforms (1 / 2 stages dropped, incomplete.py)
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
@@ -382,6 +383,7 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_fused_enc2_4096r_asm", "nflhip_fused_fma_fwd4096r_asm", "nflhip_fused_fms_inv4096r_asm", "nflhip_fused_fma_inv4096r_asm",
     "nflhip_fused_fms_inv32768_asm", "nflhip_fused_fma_inv32768_asm",
     "nflhip_ntt_fwd32768i8_asm", "nflhip_fused_fma_fwd32768i8_asm", "nflhip_fused_enc2_32768i8_asm",
+    "nflhip_polymul4096i1_asm", "nflhip_polymul4096i2_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -430,6 +432,10 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
     const void *a, *b, *psi, *mc;
     int nm, logn;
   } args = {c, a, b, is8k(kind) || is16k(kind) || is32k(kind) ? PSI_LM(t) : t.psi, t.mc, (int)s.nm, s.logn};
+  if (kind == kAsmPolymulI1 || kind == kAsmPolymulI2) {   // (their own ModConst records: scale of the shorter inverse, 2^127 Barrett constant)
+    args.mc = t.mc_inc[kind - kAsmPolymulI1];
+    if (!args.mc || s.logn != kLogN) return hipErrorNotSupported;
+  }
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   // one 256-thread workgroup per 4096-word block, or one 1024-thread workgroup per 16384-word block
@@ -784,6 +790,18 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
   return hipGetLastError();
 }
 
+// which n = 4096 product serves coefficient-form operands: 0 = complete transforms (nflhip_polymul4096nt_asm), 1 / 2 = that many
+// stages dropped each way.  Default chosen by measurement (profiles/r06_incomplete_ab.txt); the test hook switches it per process.
+#ifndef NFLHIP_POLYMUL_LEVEL
+#define NFLHIP_POLYMUL_LEVEL 2
+#endif
+static std::atomic<int> g_polymul_level{NFLHIP_POLYMUL_LEVEL};
+extern "C" int nflhip_debug_polymul_level(int level) {   // include/nflhip_debug.h; returns the previous setting; level < 0 only reads
+  const int old = g_polymul_level.load();
+  if (level >= 0 && level <= 2) g_polymul_level.store(level);
+  return old;
+}
+
 static inline bool row16k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 2; }
 static inline bool row8k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 1; }
 // 32768-word rows: one operand register-resident in a 1024-thread workgroup (tools/gen_polymul_asm.py build_row32k).
@@ -808,6 +826,14 @@ hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t 
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
+  if (!b_is_ntt && s.logn == kLogN) {
+    // coefficient form in AND out: the transforms may stay incomplete (tools/asmgen/incomplete.py) -- same words out
+    const int level = g_polymul_level.load();
+    if (level == 1 || level == 2) {
+      const hipError_t e = launch_asm(level == 1 ? kAsmPolymulI1 : kAsmPolymulI2, s, t, c, a, b, batch, st);
+      if (e != hipErrorNotSupported) return e;
+    }
+  }
   {
     const hipError_t e = launch_asm(b_is_ntt ? kAsmPolymulNtt : kAsmPolymul, s, t, c, a, b, batch, st);
     if (e != hipErrorNotSupported) return e;

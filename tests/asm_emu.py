@@ -703,6 +703,11 @@ def _(w, ops, mods):
     w.wr32(ops[0], w.rd32(ops[1]))
 
 
+@op("v_not_b32_e32")
+def _(w, ops, mods):
+    w.wr32(ops[0], w.rd32(ops[1]) ^ U(0xFFFFFFFF))
+
+
 @op("v_mad_u64_u32")
 def _(w, ops, mods):
     prod = w.rd32(ops[2]) * w.rd32(ops[3])
@@ -1030,7 +1035,7 @@ def run_kernel(asm_text, mem, kernarg, grid, lds_bytes, waves_per_wg=4, concurre
                 raise RuntimeError("emulated launch is stuck: %d workgroups poll and nothing changes" % len(gens))
 
 
-def device_tables(limb_bits, n, nm, prm, lane_major=False):
+def device_tables(limb_bits, n, nm, prm, lane_major=False, incomplete=0):
     """the twiddle table (Tw<T>: {psi^bitrev(k), Shoup companion}) and the ModConst<T> records exactly as
     nfllib_amd/csrc/api.hip build_tables lays them out on the device (negacyclic case), from params<T>.
     lane_major: DevTables::psi_lm, what the ring-mode 64-bit kernels (rows of 8192 words and up) are handed -- the last four stages (indices n/16 .. n-1)
@@ -1056,6 +1061,15 @@ def device_tables(limb_bits, n, nm, prm, lane_major=False):
         bits = p.bit_length()
         rec = [p, 2 * p, (1 << (2 * wb - 4)) // p, ninv, (ninv << wb) // p, w1n, (w1n << wb) // p, beta, (beta << wb) // p,
                0, 0, (1 << bits) - 1, (1 << (wb - 2)) - p, (1 << (2 * wb - 3)) // p]   # (yinv: CRT only, unused by the row kernels)
+        if incomplete:
+            # DevTables::mc_inc (api.hip build_tables): the records of the incomplete-transform product (tools/asmgen/incomplete.py) --
+            # (n / G)^-1 in the n^-1 fields, floor(2^127 / p) - 2^65 in the mu2 field
+            g = 1 << incomplete
+            ninv_g = ninv * g % p
+            w1n_g = w1n * g % p
+            rec[3:7] = [ninv_g, (ninv_g << wb) // p, w1n_g, (w1n_g << wb) // p]
+            rec[13] = (1 << 127) // p - (1 << 65)
+            assert 0 <= rec[13] < (1 << 35)
         mc[cm] = [r & ((1 << wb) - 1) for r in rec]
     if lane_major:
         assert logn >= 12
@@ -1085,13 +1099,14 @@ def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magi
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16, grid_x=None, key=None, compact=None):
+def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16, grid_x=None, key=None, compact=None,
+                     incomplete=0):
     """the 64-bit block kernels of tools/gen_polymul_asm.py (kernarg: dst, a, b, psi, mc, nm, logn[, count]; grid =
     (blocks of the batch, nm); 2^block_log words per workgroup, 16 per thread).  count (the two-rows-per-workgroup
     transforms) = number of polynomials"""
     import struct
     mem = Memory()
-    psi, mc = device_tables(64, n, nm, prm, lane_major=block_log >= 13)   # (the ring-mode kernels: tw_base_lm)
+    psi, mc = device_tables(64, n, nm, prm, lane_major=block_log >= 13, incomplete=incomplete)   # (the ring-mode kernels: tw_base_lm)
     c = np.zeros_like(a)
     pa, pb, pc, ppsi, pmc = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(psi), mem.add(mc)
     if compact is not None:   # operand a as one signed byte per coefficient, shared by the moduli: (batch, n) int8

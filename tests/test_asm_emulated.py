@@ -105,6 +105,60 @@ def test_emulated_u64_block_product(stem, n, block_log, nm, batch, generated, or
     assert np.array_equal(got, o.polymul(a, b))
 
 
+@pytest.mark.parametrize("level", [1, 2])
+def test_emulated_u64_product_on_incomplete_transforms(level, generated, oracle_factory):
+    """nflhip_polymul4096i{1,2}_asm (tools/asmgen/incomplete.py): forward transforms stop `level` stages early, base
+    multiplication mod X^(2^level) -+ zeta on lazily accumulated 128-bit sums, inverse starts `level` stages late -- the words
+    out are the complete kernel's.  Random operands with the boundary values of operands(), all-(p-1) rows (the largest sums
+    the 2^127 Barrett step sees) and unit impulses (X^(n-1) * X^(n-1): the negacyclic sign through the base multiplication)."""
+    nm = 2
+    o = oracle_factory(64, 4096, nm)
+    prm, a, b = operands(o, 64, 4096, nm, 3, 20 + level)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    a[1], b[1] = (P - 1)[:, None], (P - 1)[:, None]
+    a[2], b[2] = 0, 0
+    a[2, :, 4095], b[2, :, 4095] = 1, 1
+    b[2, :, 1] = P - 1
+    stem = generated("polymul4096i%d" % level)
+    got = asm_emu.run_block_kernel(stem, 4096, nm, prm, a, b, 12, incomplete=level)
+    assert np.array_equal(got, o.polymul(a, b))
+    # the records matter: with the complete kernel's ModConst (n^-1, mu2) the same listing must NOT produce the product
+    bad = asm_emu.run_block_kernel(stem, 4096, nm, prm, a[:1], b[:1], 12, incomplete=0)
+    assert not np.array_equal(bad, got[:1])
+
+
+def test_barrett_step_of_the_base_multiplication_in_integers():
+    """the reduction incomplete.py emits for sums T < 2^127 of products of folded words, restated on Python integers:
+    th = T >> 63, q^ = 2 th + floor(th m / 2^64) with m = floor(2^127 / p) - 2^65, r = T - q^ p must lie in [0, 2^64) with
+    q - q^ <= 3 -- at the largest operands the two-bit fold can leave (2^62 + 3 delta - 1) and at random ones, for the first and
+    the last delta-form moduli (delta up to 2^32)"""
+    from nfllib_amd.params import params
+    prm = params(64)
+    rng = np.random.default_rng(99)
+    for ci in (0, 1, 29, 63, 91):
+        p = int(prm.P[ci])
+        d = (1 << 62) - p
+        m = (1 << 127) // p - (1 << 65)
+        assert 0 <= m < (1 << 35)
+        m0, m1 = m & 0xFFFFFFFF, m >> 32
+        hi = (1 << 62) + 3 * d - 1
+        cases = [([hi] * 4, [hi] * 4), ([p - 1] * 4, [p - 1] * 4), ([0] * 4, [hi] * 4), ([hi, 0, 0, 0], [hi, 0, 0, 0])]
+        cases += [([int(x) % (hi + 1) for x in rng.integers(0, 1 << 63, 4)], [int(x) % (hi + 1) for x in rng.integers(0, 1 << 63, 4)])
+                  for _ in range(400)]
+        for xs, ys in cases:
+            T = sum(x * y for x, y in zip(xs, ys))
+            th = T >> 63
+            tl, thh = th & 0xFFFFFFFF, th >> 32
+            H = thh * m0 + ((tl * m0) >> 32)
+            H += tl * m1
+            assert H < (1 << 64)
+            q = 2 * th + thh * m1 + (H >> 32)
+            r = T - q * p
+            assert 0 <= T // p - q <= 3 and 0 <= r < (1 << 64)
+            f = (r & ((1 << 62) - 1)) + (r >> 62) * d
+            assert f % p == T % p and f <= hi
+
+
 @pytest.mark.parametrize("suffix,n,block_log", [("4096", 4096, 12), ("8192", 8192, 13), ("16384", 16384, 14)])
 def test_emulated_u64_block_transforms(suffix, n, block_log, generated, oracle_factory):
     """stand-alone forward / inverse, the product with b already in NTT form, and (4096) the inverse with a fused

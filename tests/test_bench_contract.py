@@ -98,6 +98,52 @@ def test_two_rank_launch_line_of_the_driver():
 
 
 @pytest.mark.gpu
+def test_eight_rank_rehearsal_of_the_scale_line():
+    """The SCALE line the driver will launch on an 8-GPU node (--gpus 8 under torch.distributed.run), rehearsed with eight
+    ranks on ONE device (gloo control plane, reduced shards): n_gpus 8, world size 8, configs[3]'s block with
+    global batch = 8 x shard and a checksum of checksums over 8 shards -- so the first real 8-GPU run is not spent on a
+    launch-line bug.  No rate is asserted: eight ranks share one GPU here."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NFLHIP_BENCH_BACKEND="gloo", NFLHIP_BENCH_ONE_DEVICE="1", NFLHIP_BENCH_D_SHARD="256")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3",
+                        "--warmup", "1", "--batch", "256", "--prewarm", "0.1"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the JSON line"
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 * 256
+    assert d["config"]["rccl"]["world_size"] == 8
+    assert d["config"]["self_check"] is True and d["config"]["checksum_of_checksums"]["ok"] is True
+    assert d["config"]["checksum_of_checksums"]["shards"] == 8
+    assert abs(d["value"] - 8 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.2
+    dd = d["extras"]["configs"]["D"]
+    assert "error" not in dd, dd
+    assert dd["n_gpus"] == 8 and dd["batch_per_gpu"] == 256 and dd["global_batch"] == 8 * dd["batch_per_gpu"]
+    assert dd["shard_is_baseline_shard"] is False and dd["is_baseline_config_4"] is False   # (the real shard is 2^17: 48 GiB per GPU)
+    assert dd["self_check"] is True and dd["checksum_of_checksums"]["ok"] is True and dd["checksum_of_checksums"]["shards"] == 8
+    assert dd["parity_sample_ok"] is True
+    assert dd["preflight"]["ok"] is True and dd["preflight"]["needed_GiB"] < dd["preflight"]["free_GiB"]
+
+
+@pytest.mark.gpu
+def test_config_d_preflight_refuses_a_shard_that_does_not_fit():
+    """the pre-flight of extras.configs.D: a shard whose three resident tensors exceed the device's free memory is refused
+    with a reason in the block (the headline still prints), instead of an out-of-memory fault mid-run"""
+    env = dict(os.environ, NFLHIP_BENCH_D_SHARD=str(1 << 22))      # 3 x 512 GiB
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "256", "--no-extras",
+                        "--no-cpu-baseline", "--no-traffic", "--prewarm", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    dd = d["extras"]["configs"]["D"]
+    assert "error" in dd and "pre-flight" in dd["error"] and d["value"] > 0
+
+
+@pytest.mark.gpu
 def test_plain_gpus_n_launches_n_ranks_itself_or_refuses():
     """`python bench.py --gpus 2` with NO launcher around it spawns the two ranks itself (torch.distributed.run on
     127.0.0.1) and reports n_gpus 2 -- here on one device through the test knobs; without the knob, on a box with fewer
@@ -160,6 +206,10 @@ def test_headline_line_carries_sustained_independent_secondary_and_side_configs(
         c = cfg[wl]
         assert "error" not in c, c
         assert c["self_check"] is True and c["value"] > 0 and 0 < c["frac"] < 1 and c["traffic_ratio"] is not None and c["traffic_ratio"] > 0.98
+        # every block carries polynomials of ITS timed product recomputed by the CPU oracle (not only the headline)
+        assert c["parity_sample_ok"] is True and "CPU oracle" in c["parity_sample"], c.get("parity_sample")
+    assert dd["parity_sample_ok"] is True
+    assert cfg["E"]["crt_parity_sample_ok"] is True and "oracle.crt_lift" in cfg["E"]["crt_parity_sample"]
     assert cfg["E"]["crt_lift"]["value"] > 0 and cfg["E"]["crt_lift"]["limbs_per_coefficient"] == 30
     one = cfg["E"]["polymul_plus_crt_lift"]     # BASELINE configs[4] as ONE figure: slower than either part, faster than their serial sum allows
     assert one["unit"] == "polys/s" and 0 < one["value"] < min(cfg["E"]["value"], cfg["E"]["crt_lift"]["value"])

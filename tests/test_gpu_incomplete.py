@@ -1,0 +1,77 @@
+"""-m gpu: the metric product on INCOMPLETE transforms (nflhip_polymul4096i{1,2}_asm, tools/asmgen/incomplete.py) through the
+C ABI against the CPU oracle, bit-exact -- the same words as the complete kernel: nflhip_polymul_dev with
+nflhip_debug_polymul_level 1 / 2 (the level the library ships with is whichever measured faster; all three must agree).
+Semantics matched: a.ntt_pow_phi(); b.ntt_pow_phi(); c = a * b; c.invntt_pow_invphi() (poly.hpp:167-168, 350;
+core.hpp:594-614)."""
+import numpy as np
+import pytest
+
+from conftest import SEED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def level():
+    from nfllib_amd import _lib
+    saved = _lib.lib.nflhip_debug_polymul_level(-1)
+
+    def set_level(v):
+        _lib.lib.nflhip_debug_polymul_level(v)
+    yield set_level
+    _lib.lib.nflhip_debug_polymul_level(saved)
+
+
+@pytest.mark.parametrize("nm,batch", [(1, 1), (4, 6), (30, 3), (92, 2)])
+def test_incomplete_products_equal_the_oracle(nm, batch, level, oracle_factory, engine_factory):
+    o, e = oracle_factory(64, 4096, nm), engine_factory(64, 4096, nm)
+    a, b = o.fill_uniform(batch, SEED, 0), o.fill_uniform(batch, SEED, 1)
+    want = o.polymul(a, b)
+    da, db = e.to_device(a), e.to_device(b)
+    for lv in (0, 1, 2):
+        level(lv)
+        assert np.array_equal(e.to_host(e.polymul(da, db)), want), "level %d" % lv
+
+
+@pytest.mark.parametrize("lv", [1, 2])
+def test_incomplete_products_at_the_boundaries(lv, level, oracle_factory, engine_factory):
+    """all-(p-1) rows (the largest 128-bit sums), zeros, unit impulses at 0 and n-1 (negacyclic wrap through the base
+    multiplication), alternating 0 / p-1, operands aliased with the result"""
+    nm = 4
+    o, e = oracle_factory(64, 4096, nm), engine_factory(64, 4096, nm)
+    P = np.asarray(e.params.P[:nm], dtype=np.uint64)
+    a = np.zeros((6, nm, 4096), dtype=np.uint64)
+    b = np.zeros_like(a)
+    a[0], b[0] = (P - 1)[:, None], (P - 1)[:, None]
+    a[1, :, 4095], b[1, :, 4095] = 1, 1
+    a[2, :, 0], b[2] = 1, o.fill_uniform(1, SEED, 1)[0]
+    a[3, :, ::2], b[3, :, 1::2] = (P - 1)[:, None], (P - 1)[:, None]
+    a[4], b[4] = o.fill_uniform(1, 7, 0)[0], 0
+    a[5, :, 4095], b[5, :, 1] = (P - 1), (P - 1)
+    want = o.polymul(a, b)
+    level(lv)
+    da, db = e.to_device(a), e.to_device(b)
+    assert np.array_equal(e.to_host(e.polymul(da, db)), want)
+    assert np.array_equal(e.to_host(e.polymul(da, db, out=da)), want)      # c over a
+    da = e.to_device(a)
+    assert np.array_equal(e.to_host(e.polymul(da, db, out=db)), want)      # c over b
+    sq = e.to_device(a)
+    assert np.array_equal(e.to_host(e.polymul(sq, sq)), o.polymul(a, a))   # a * a (both operands one buffer)
+
+
+@pytest.mark.parametrize("lv", [1, 2])
+def test_incomplete_products_at_full_batch(lv, level, engine_factory, oracle_factory):
+    """BASELINE configs[1] at its bench batch: digest equal to the complete kernel's, commutes, sampled polynomials vs the oracle"""
+    e = engine_factory(64, 4096, 4)
+    batch = 16384
+    a = e.fill_uniform(e.empty(batch), SEED, 0)
+    b = e.fill_uniform(e.empty(batch), SEED, 1)
+    level(0)
+    ref = e.digest(e.polymul(a, b))
+    level(lv)
+    c = e.polymul(a, b)
+    assert e.digest(c) == ref
+    assert not e.any_neq(c, e.polymul(b, a))
+    o = oracle_factory(64, 4096, 4)
+    for i in (0, 5461, batch - 1):
+        assert np.array_equal(e.to_host(c[i:i + 1]), o.polymul(e.to_host(a[i:i + 1]), e.to_host(b[i:i + 1])))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B of the metric kernel between two builds of the library, through the few C entry points both have
-(raw ctypes, no version check): python tools/ab_probe.py LIB.so [seconds]"""
+(raw ctypes, no version check): python tools/ab_probe.py LIB.so [seconds [level]]"""
 import ctypes as C
 import sys
 import time
@@ -10,6 +10,9 @@ from nfllib_amd.params import params as limb_params
 
 lib = C.CDLL(sys.argv[1])
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+level = int(sys.argv[3]) if len(sys.argv) > 3 else -1     # nflhip_debug_polymul_level: 0 complete transforms, 1 / 2 incomplete
+if level >= 0:
+    lib.nflhip_debug_polymul_level(level)
 n, nm, batch = 4096, 4, 16384
 pr = limb_params(64)
 import numpy as np
@@ -31,4 +34,4 @@ while time.time() - t0 < seconds:
     assert lib.nflhip_time_polymul_dev(h, ptr[0], ptr[1], ptr[2], batch, 20, None, C.byref(ms)) == 0
     out.append(ms.value)
 third = out[-len(out) // 3:]
-print("%s: %.4f ms per launch of %d (last third of %.0f s; first %.4f), checksum %d" % (sys.argv[1], sum(third) / len(third), batch, seconds, out[0], int(bufs[0][:4096].sum().item()) & 0xffffffff))
+print("%s%s: %.4f ms per launch of %d (last third of %.0f s; first %.4f), checksum %d" % (sys.argv[1], "" if level < 0 else " level %d" % level, sum(third) / len(third), batch, seconds, out[0], int(bufs[0][:4096].sum().item()) & 0xffffffff))

@@ -60,9 +60,10 @@ def case(name, workload, nm_workload, run, products):
                  per.get("lds", 0) * nm_workload, bound, m))
 
 
-def block(stem, n, block_log, workload, nm_w):
+def block(stem, n, block_log, workload, nm_w, incomplete=0):
     prm, a = operands(64, n, 1, 1)
-    case(stem, workload, nm_w, lambda: asm_emu.run_block_kernel(os.path.join(CSRC, stem + "_gfx950.s"), n, 1, prm, a, a, block_log), 1)
+    case(stem, workload, nm_w, lambda: asm_emu.run_block_kernel(os.path.join(CSRC, stem + "_gfx950.s"), n, 1, prm, a, a, block_log,
+                                                                incomplete=incomplete), 1)
 
 
 def row(stem, bits, n, rows_per_wg, magic, workload, nm_w, batch):
@@ -76,6 +77,8 @@ def pipe(stem, n, workload, nm_w):
 
 
 block("polymul4096nt", 4096, 12, "B", 4)
+block("polymul4096i1", 4096, 12, "B", 4, incomplete=1)   # round 6: 1 / 2 stages dropped each way, base multiplication mod X^2 / X^4 -+ zeta
+block("polymul4096i2", 4096, 12, "B", 4, incomplete=2)
 block("polymul8192", 8192, 13, "G", 2)
 block("polymul16384", 16384, 14, "C", 8)
 def rows32k(workload, nm_w):   # b' = NTT(b), then c = INTT(NTT(a) (.) b'): the two register-resident row kernels of n = 32768

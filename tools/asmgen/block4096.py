@@ -119,6 +119,15 @@ def prologue(em, vm, kind="polymul"):
     def row_loads(dst_base, srow):
         seq = 0
         R("s_mov_b64 s[86:87], %s" % (srow,))
+        if "x4" in cfg.ABLATE:
+            # timing ablation (round 6, wrong results by construction): the same 32 KiB row fetched as 8 x 16 bytes per thread
+            # (word pairs 2t, 2t+1 of each 512-word slice) instead of 16 x 8 bytes -- does the fetch WIDTH matter to the product?
+            em.valu("v_lshlrev_b32_e32 v%d, 4, v%d" % (T(1, 0), cfg.V_TID))
+            for k in range(8):
+                seq = vm.load("global_load_dwordx4 v[%d:%d], v%d, s[86:87] offset:%d nt" % (dst_base + 4 * k, dst_base + 4 * k + 3, T(1, 0), 0))
+                R("s_add_u32 s86, s86, 0x1000")
+                R("s_addc_u32 s87, s87, 0")
+            return seq
         for k in range(16):
             seq = vm.load("global_load_dwordx2 %s, v%d, s[86:87] offset:%d" % (vp(dst_base + 2 * k), cfg.V_OFF8, (k & 1) * 2048))
             if k & 1:
@@ -191,6 +200,13 @@ def strided_rows(em, vm, base, srow, stride, store=False, offset=0, nwords=16):
     R = em.raw
     seq = 0
     R("s_mov_b64 s[86:87], %s" % (srow,))
+    if "x4" in cfg.ABLATE and store and stride == 2048 and nwords == 16 and not offset:
+        em.valu("v_lshlrev_b32_e32 v%d, 4, v%d" % (T(1, 0), cfg.V_TID))
+        for k in range(8):
+            R("global_store_dwordx4 v%d, v[%d:%d], s[86:87] nt" % (T(1, 0), base + 4 * k, base + 4 * k + 3))
+            R("s_add_u32 s86, s86, 0x1000")
+            R("s_addc_u32 s87, s87, 0")
+        return seq
     if offset:
         R("s_add_u32 s86, s86, 0x%x" % offset)
         R("s_addc_u32 s87, s87, 0")
@@ -264,7 +280,12 @@ def build(kind="polymul"):
     return build_body(em, vm, kind, tw_seq)
 
 
-def build_body(em, vm, kind, tw_seq, suffix=""):
+def build_body(em, vm, kind, tw_seq, suffix="", level=0):
+    """level (kind "polymul" only): 1 / 2 = the product on incomplete transforms (incomplete.py)"""
+    if level:
+        assert kind == "polymul"
+        from .incomplete import body_incomplete
+        return body_incomplete(em, vm, tw_seq, suffix, level)
     R = em.raw
     has_fwd = kind in ("polymul", "polymul_ntt", "fwd", "fwd2")
     has_inv = kind not in ("fwd", "fwd2")

@@ -3,6 +3,7 @@ import os
 
 from . import state as cfg
 from .block4096 import build
+from .incomplete import build_incomplete
 from .fused import build_fused, build_fused_rows
 from .rows import build_row16k, build_row16k_loop
 from .rows32k import build_row32k
@@ -51,6 +52,12 @@ def main():
             if not experiments:
                 continue
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build(kind), args=args)
+    # the metric product on incomplete transforms (round 6, incomplete.py): 1 or 2 stages dropped each way, base multiplication
+    # mod X^2 / X^4 -+ zeta; same arguments, the host passes the ModConst records with (n / G)^-1 and the 2^127 Barrett constant
+    for level in (1, 2):
+        emi = build_incomplete(level)
+        emi.lines = nt(emi)
+        emit_file(os.path.join(outdir, "polymul4096i%d_gfx950.s" % level), "nflhip_polymul4096i%d_asm" % level, emi)
     # transform-fused pipelines (n = 4096): word-row streams `nt`, key rows and compact inputs through the caches
     cfg.set(NEXT_SGPR=102)
     for kind, (stem, kname) in KERNELS_FUSED.items():

@@ -16,13 +16,13 @@ def tw_slot(s, g):
     return (1 << s) - 1 + g          # 15 records: sub-stage s (0..3), group g (0..2^s-1)
 
 
-def ct_stage(em, bases, s):
+def ct_stage(em, bases, s, slot=tw_slot):
     if "nobfly" in cfg.ABLATE:
         return
     half = 8 >> s
     jobs = []
     for g in range(1 << s):
-        tw = twreg(tw_slot(s, g))
+        tw = twreg(slot(s, g))
         for h in range(half):
             i0 = g * 2 * half + h
             for base in bases:
@@ -30,13 +30,13 @@ def ct_stage(em, bases, s):
     run_pairs(em, jobs)
 
 
-def gs_stage(em, base, s):
+def gs_stage(em, base, s, slot=tw_slot):
     if "nobfly" in cfg.ABLATE:
         return
     half = 8 >> s
     jobs = []
     for g in range(1 << s):
-        tw = twreg(tw_slot(s, g))
+        tw = twreg(slot(s, g))
         for h in range(half):
             i0 = g * 2 * half + h
             jobs.append(gs_bfly(base + 2 * i0, base + 2 * (i0 + half), tw))
@@ -90,7 +90,7 @@ def tw_uniform_stage(em, vm, s, kreg, descending):
     return seq
 
 
-def tw_lane_stage(em, vm, s, vidx, kreg, descending, groups=None):
+def tw_lane_stage(em, vm, s, vidx, kreg, descending, groups=None, slot=tw_slot):
     """Per-lane twiddle records of sub-stage s.  Ascending (forward): index = (K << s) + (vidx << s) + g.
     Descending (inverse, mirrored): index = (K << s) - 1 - (vidx << s) - g.  vidx: VGPR with B or t.
     groups: only these g (default: all 2^s)"""
@@ -102,7 +102,7 @@ def tw_lane_stage(em, vm, s, vidx, kreg, descending, groups=None):
         em.valu("v_mov_b32_e32 v%d, 0" % (cfg.V_TWO,))
     if not descending:
         for g in groups:
-            r = cfg.V_TW + 4 * tw_slot(s, g)
+            r = cfg.V_TW + 4 * slot(s, g)
             seq = vm.load("global_load_dwordx4 v[%d:%d], v%d, %s offset:%d" % (r, r + 3, cfg.V_TWO, cfg.S_BASE2, g * 16))
     else:
         em.valu("v_mov_b32_e32 v%d, s84" % (cfg.V_TWA,))
@@ -110,7 +110,7 @@ def tw_lane_stage(em, vm, s, vidx, kreg, descending, groups=None):
         em.valu("v_sub_co_u32_e32 v%d, vcc, v%d, v%d" % (cfg.V_TWA, cfg.V_TWA, cfg.V_TWO), "vcc", None)
         em.valu("v_subbrev_co_u32_e32 v%d, vcc, 0, v%d, vcc" % (cfg.V_TWA + 1, cfg.V_TWA + 1), "vcc", "vcc")
         for g in groups:
-            r = cfg.V_TW + 4 * tw_slot(s, g)
+            r = cfg.V_TW + 4 * slot(s, g)
             seq = vm.load("global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (r, r + 3, vp(cfg.V_TWA), -g * 16))
     return seq
 
