@@ -421,7 +421,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   HIPCHK(nullptr, hipMalloc(&c->tabs.mc, mc.size() * sizeof(ModConst<T>)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.mc, mc.data(), mc.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
   c->tabs.mc_inc[0] = c->tabs.mc_inc[1] = nullptr;
-  if (sizeof(T) == 8 && n == 4096 && !c->cyclic && c->shape.small_delta) {
+  if (sizeof(T) == 8 && n >= 4096 && !c->cyclic && c->shape.small_delta) {
     // the metric product on incomplete transforms (nflhip_polymul4096i{1,2}_asm): the inverse undoes 12 - level stages, so the
     // scale folded into its last stage is (n / 2^level)^-1; the base multiplication reduces sums below 2^127 with
     // floor(2^127 / p) = 2^65 + m, m < 2^35 (delta < 2^32), handed over in the mu2 field
@@ -597,7 +597,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       if (!cap && ctx->ev_prev_valid)
         for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
       e = launch_polymul_xcd_u64(ctx->shape, ctx->tabs, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)b, batch,
-                                 ctx->scratch, st);
+                                 ctx->scratch, st, polymul_level());
       if (e == hipSuccess) {
         if (!cap) {
           HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
@@ -632,6 +632,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     auto at_of = lo_of;
 #endif
     bool supported = true;
+    const int level = b_is_ntt ? 0 : polymul_level();   // read once: the three roles of a chunk run in different launches
     if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));  // a previous call on another stream
     if (!cap && ctx->ev_prev_valid)  // ... or a helper-stream plan (polymul_ntt_dev at this shape) still reading s0
       for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
@@ -643,7 +644,7 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
       e = launch_polymul_pipe64k_u64(ctx->shape, ctx->tabs, (uint64_t *)c + v0 * pw, (const uint64_t *)s0 + v0 * pw,
                                      (b_is_ntt ? (const uint64_t *)b : (const uint64_t *)s1) + v0 * pw, cv, (const uint64_t *)a + f0 * pw,
                                      (uint64_t *)s0 + f0 * pw, b_is_ntt ? nullptr : (const uint64_t *)b + f0 * pw,
-                                     b_is_ntt ? nullptr : (uint64_t *)s1 + f0 * pw, cf, (uint64_t *)c + i0 * pw, ci, st, b_is_ntt != 0);
+                                     b_is_ntt ? nullptr : (uint64_t *)s1 + f0 * pw, cf, (uint64_t *)c + i0 * pw, ci, st, b_is_ntt != 0, level);
       if (e == hipErrorNotSupported && L == 0) { supported = false; break; }
       if (e != hipSuccess) return hipfail(ctx, e, "polymul: pipeline kernel");
     }

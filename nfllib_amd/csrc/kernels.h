@@ -214,11 +214,12 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
 // is not covered.  `work`: device memory of that many bytes, initialised by the call on `st`.
 size_t xcd_plan_bytes(const Shape &s, size_t batch);
 hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
-                                  size_t batch, void *work, hipStream_t st);
+                                  size_t batch, void *work, hipStream_t st, int level = 0);
+int polymul_level();   // 0 / 1 / 2: transforms of the coefficient-form products complete / incomplete (kernels_fast.hip, nflhip_debug_polymul_level)
 hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
-                                      hipStream_t st, bool b_is_ntt = false);
+                                      hipStream_t st, bool b_is_ntt = false, int level = 0);
 
 // n = 1024, 32- and 64-bit limbs: one wave per row (kernels_wave.hip).  mode 0: c = INTT(NTT(a)(.)NTT(b)); 1: b already in
 // NTT form; 2: c = NTT(a); 3: c = INTT(a).  hipErrorNotSupported for other shapes.

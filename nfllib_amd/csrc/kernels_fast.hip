@@ -357,10 +357,12 @@ enum AsmKind {
   kAsmFused32kFmsInv, kAsmFused32kFmaInv,                            // the inverse pipelines of a 32768-word row (build_row32k fms_inv / fma_inv)
   kAsmFwd32kI8, kAsmFused32kFmaFwdI8, kAsmFused32kEnc2I8,            // ... its forward transform / forward pipelines from a compact (int8) polynomial
   kAsmPolymulI1, kAsmPolymulI2,                                      // the n = 4096 product on incomplete transforms (1 / 2 stages dropped, incomplete.py)
+  kAsmPipe64kI2, kAsmXcd64kI2, kAsmXcd32kI2,                         // ... the long-row plans with their block products on incomplete transforms (level 2)
+  kAsmPolymul8kI2, kAsmPolymul16kI2,                                 // ... the row-resident products (rows.py build_row16k level 2)
   kAsmCount
 };
-static inline bool is8k(AsmKind k) { return k >= kAsmPolymul8k && k <= kAsmInv8k; }
-static inline bool is16k(AsmKind k) { return k >= kAsmPolymul16k && k <= kAsmInv16k; }
+static inline bool is8k(AsmKind k) { return (k >= kAsmPolymul8k && k <= kAsmInv8k) || k == kAsmPolymul8kI2; }
+static inline bool is16k(AsmKind k) { return (k >= kAsmPolymul16k && k <= kAsmInv16k) || k == kAsmPolymul16kI2; }
 static inline bool is32k(AsmKind k) { return k >= kAsmFwd32k && k <= kAsmPolymulNtt32kS; }
 static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul4096nt_asm", "nflhip_polymul_ntt4096_asm", "nflhip_ntt_fwd4096_asm", "nflhip_ntt_inv4096_asm", "nflhip_ntt_inv_mul4096_asm",
@@ -384,6 +386,8 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_fused_fms_inv32768_asm", "nflhip_fused_fma_inv32768_asm",
     "nflhip_ntt_fwd32768i8_asm", "nflhip_fused_fma_fwd32768i8_asm", "nflhip_fused_enc2_32768i8_asm",
     "nflhip_polymul4096i1_asm", "nflhip_polymul4096i2_asm",
+    "nflhip_polymul_pipe65536nti2_asm", "nflhip_polymul_xcd65536i2_asm", "nflhip_polymul_xcd32768i2_asm",
+    "nflhip_polymul8192i2_asm", "nflhip_polymul16384i2_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -421,6 +425,19 @@ static hipFunction_t asm_fn(AsmKind kind) {
 #define PSI_LM(t) ((t).psi_lm)
 #endif
 
+// which n = 4096 product serves coefficient-form operands: 0 = complete transforms (nflhip_polymul4096nt_asm), 1 / 2 = that many
+// stages dropped each way.  Default chosen by measurement (profiles/r06_incomplete_ab.txt); the test hook switches it per process.
+#ifndef NFLHIP_POLYMUL_LEVEL
+#define NFLHIP_POLYMUL_LEVEL 2
+#endif
+static std::atomic<int> g_polymul_level{NFLHIP_POLYMUL_LEVEL};
+int polymul_level() { return g_polymul_level.load(); }   // (api.hip reads it ONCE per product: the launches of a chunked plan must agree)
+extern "C" int nflhip_debug_polymul_level(int level) {   // include/nflhip_debug.h; returns the previous setting; level < 0 only reads
+  const int old = g_polymul_level.load();
+  if (level >= 0 && level <= 2) g_polymul_level.store(level);
+  return old;
+}
+
 // every generated kernel takes (dst, src_a, src_b, psi, mc, nm, logn) and one workgroup per block of its size
 static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a,
                              const uint64_t *b, size_t batch, hipStream_t st) {
@@ -435,6 +452,10 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   if (kind == kAsmPolymulI1 || kind == kAsmPolymulI2) {   // (their own ModConst records: scale of the shorter inverse, 2^127 Barrett constant)
     args.mc = t.mc_inc[kind - kAsmPolymulI1];
     if (!args.mc || s.logn != kLogN) return hipErrorNotSupported;
+  }
+  if (kind == kAsmPolymul8kI2 || kind == kAsmPolymul16kI2) {
+    args.mc = t.mc_inc[1];
+    if (!args.mc || s.logn != (kind == kAsmPolymul8kI2 ? kLogN + 1 : kLogN + 2)) return hipErrorNotSupported;   // whole rows only: the scale is the row's
   }
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -596,11 +617,14 @@ hipError_t launch_row32k_fwd_fma_i8_u64(const Shape &s, const DevTables &t, uint
 hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,
                                       const uint64_t *fb_src, uint64_t *fb_dst, int cnt_f, uint64_t *inv, int cnt_i,
-                                      hipStream_t st, bool b_is_ntt) {
+                                      hipStream_t st, bool b_is_ntt, int level) {
   if (s.limb_bits != 64 || s.logn != 16 || s.compiled_only || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
   // (coefficient loads / stores carry `nt`: they pass through the L2 once, the twiddle tables stay resident: measured +3 %)
   // b_is_ntt: b_v is the caller's transformed operand (canonical words), read block-wise as it lies; no forward role for it
-  hipFunction_t fn = asm_fn(b_is_ntt ? kAsmPipe64kB : kAsmPipe64k);
+  // level 2 (coefficient-form operands only): the block products run on incomplete transforms, and the streaming inverse role
+  // folds in (n / 4)^-1 from the level-2 records -- every launch of one product takes the same level
+  const bool inc = level == 2 && !b_is_ntt && t.mc_inc[1];
+  hipFunction_t fn = asm_fn(b_is_ntt ? kAsmPipe64kB : inc ? kAsmPipe64kI2 : kAsmPipe64k);
   if (!fn) return hipErrorNotSupported;
   const int mx = cnt_v > cnt_f ? (cnt_v > cnt_i ? cnt_v : cnt_i) : (cnt_f > cnt_i ? cnt_f : cnt_i);
   if (mx <= 0) return hipSuccess;
@@ -614,7 +638,7 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
     const void *fb_src;
     void *fb_dst, *inv;
     unsigned remap_per, remap_magic;
-  } args = {c_v, a_v, b_v, t.psi, t.mc, (int)s.nm, s.logn, cnt_v, cnt_f, cnt_i, 0, fa_src, fa_dst, fb_src, fb_dst, inv, 0u, 0u};
+  } args = {c_v, a_v, b_v, t.psi, inc ? t.mc_inc[1] : t.mc, (int)s.nm, s.logn, cnt_v, cnt_f, cnt_i, 0, fa_src, fa_dst, fb_src, fb_dst, inv, 0u, 0u};
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_pipe65536_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -677,10 +701,11 @@ size_t xcd_plan_bytes(const Shape &s, size_t batch) {
   return xcd_plan(s, batch, &p) ? p.total : 0;
 }
 hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
-                                  size_t batch, void *work, hipStream_t st) {
+                                  size_t batch, void *work, hipStream_t st, int level) {
   XcdPlan p;
   if (!xcd_plan(s, batch, &p)) return hipErrorNotSupported;
-  hipFunction_t fn = asm_fn(s.logn == 16 ? kAsmXcd64k : kAsmXcd32k);
+  const bool inc = level == 2 && t.mc_inc[1];
+  hipFunction_t fn = asm_fn(s.logn == 16 ? (inc ? kAsmXcd64kI2 : kAsmXcd64k) : (inc ? kAsmXcd32kI2 : kAsmXcd32k));
   if (!fn) return hipErrorNotSupported;
   // fresh counters: word block 0 (workgroups that joined, per XCD) and the first KiB of every domain's record
   hipLaunchKernelGGL(k_xcd_reset, dim3((8u << p.dlog) + 1), dim3(128), 0, st, (uint4 *)work);
@@ -695,7 +720,7 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
     unsigned magic;
     int d, rlog, jmax, spin, inv;
     void *scr_a, *scr_b, *ctl, *trace;
-  } args = {c, a, b, t.psi, t.mc, (int)s.nm, s.logn, (int)(batch * s.nm), (int)batch, p.magic, p.dlog, p.rlog, 0,
+  } args = {c, a, b, t.psi, inc ? t.mc_inc[1] : t.mc, (int)s.nm, s.logn, (int)(batch * s.nm), (int)batch, p.magic, p.dlog, p.rlog, 0,
             1 << 22, 0, w + p.ctl_bytes, w + p.ctl_bytes + p.slot_bytes, w, nullptr};
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_xcd*_asm");
   size_t size = sizeof(args);
@@ -790,18 +815,6 @@ static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t 
   return hipGetLastError();
 }
 
-// which n = 4096 product serves coefficient-form operands: 0 = complete transforms (nflhip_polymul4096nt_asm), 1 / 2 = that many
-// stages dropped each way.  Default chosen by measurement (profiles/r06_incomplete_ab.txt); the test hook switches it per process.
-#ifndef NFLHIP_POLYMUL_LEVEL
-#define NFLHIP_POLYMUL_LEVEL 2
-#endif
-static std::atomic<int> g_polymul_level{NFLHIP_POLYMUL_LEVEL};
-extern "C" int nflhip_debug_polymul_level(int level) {   // include/nflhip_debug.h; returns the previous setting; level < 0 only reads
-  const int old = g_polymul_level.load();
-  if (level >= 0 && level <= 2) g_polymul_level.store(level);
-  return old;
-}
-
 static inline bool row16k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 2; }
 static inline bool row8k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 1; }
 // 32768-word rows: one operand register-resident in a 1024-thread workgroup (tools/gen_polymul_asm.py build_row32k).
@@ -817,10 +830,11 @@ hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint6
 
 hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                    int b_is_ntt, size_t batch, hipStream_t st) {
+  const bool inc2 = !b_is_ntt && g_polymul_level.load() == 2 && t.mc_inc[1];   // coefficient form in and out: incomplete transforms
   if (row16k_shape(s))  // a 16384-word row fits one CU: the whole product is a single launch
-    return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt16k : kAsmPolymul16k, s, t, c, a, b, batch, st);
+    return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt16k : inc2 ? kAsmPolymul16kI2 : kAsmPolymul16k, s, t, c, a, b, batch, st);
   if (row8k_shape(s))   // 8192-word rows: 512 threads, two rows per CU
-    return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt8k : kAsmPolymul8k, s, t, c, a, b, batch, st);
+    return batch == 0 ? hipSuccess : launch_asm(b_is_ntt ? kAsmPolymulNtt8k : inc2 ? kAsmPolymul8kI2 : kAsmPolymul8k, s, t, c, a, b, batch, st);
   if (row32k_shape(s) && b_is_ntt) return launch_row32k_u64(s, t, 1, c, a, b, batch, st);
   if (!fast_shape(s)) return hipErrorNotSupported;
   const size_t rows = batch * s.nm;

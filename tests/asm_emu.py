@@ -1192,13 +1192,13 @@ def run_fused_kernel(asm_path, n, nm, prm, xs, ks, batch, nouts, remap=False, gr
     return res
 
 
-def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=False, b_ntt=False):
+def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=False, b_ntt=False, incomplete=0):
     """n = 32768 / 65536: the three-role kernel of tools/gen_polymul_asm.py build_pipe (kernarg as
     launch_polymul_pipe64k_u64 packs it) driven the way the composed product does: forward streaming pass of both
     operands, fused block products, inverse streaming pass in place -- three launches of the same kernel"""
     import struct
     mem = Memory()
-    psi, mc = device_tables(64, n, nm, prm)
+    psi, mc = device_tables(64, n, nm, prm, incomplete=incomplete)
     logn = n.bit_length() - 1
     batch = a.shape[0]
     c, sa, sb = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)
@@ -1224,13 +1224,13 @@ def run_pipe_product(asm_path, n, nm, prm, a, b, one_launch_roles=False, remap=F
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_xcd_product(asm_path, n, nm, prm, a, b, dlog, rlog, pooled, wgs, pick, spin=20000, free_mask=0xFF):
+def run_xcd_product(asm_path, n, nm, prm, a, b, dlog, rlog, pooled, wgs, pick, spin=20000, free_mask=0xFF, incomplete=0):
     """n = 32768 / 65536, the whole batch in ONE launch of persistent workgroups (tools/gen_polymul_asm.py fused_header;
     kernarg and work area as launch_polymul_xcd_u64 / k_xcd_reset lay them out).  Workgroup i runs on XCD i mod 8 (the
     hardware's round-robin); `pick` chooses which workgroup continues whenever one sleeps in a poll."""
     import struct
     mem = Memory()
-    psi, mc = device_tables(64, n, nm, prm)
+    psi, mc = device_tables(64, n, nm, prm, incomplete=incomplete)
     logn = n.bit_length() - 1
     batch = a.shape[0]
     rows = batch * nm
@@ -1258,13 +1258,13 @@ def run_xcd_product(asm_path, n, nm, prm, a, b, dlog, rlog, pooled, wgs, pick, s
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_pipe_product_pipelined(asm_path, n, nm, prm, a, b):
+def run_pipe_product_pipelined(asm_path, n, nm, prm, a, b, incomplete=0):
     """the same three-role kernel driven as the chunked plan drives it: launch t runs the forward pass of polynomial t, the
     block products of polynomial t - 1 and the inverse pass of polynomial t - 2 TOGETHER (all three roles in one launch,
     on different rows), batch + 2 launches in all"""
     import struct
     mem = Memory()
-    psi, mc = device_tables(64, n, nm, prm)
+    psi, mc = device_tables(64, n, nm, prm, incomplete=incomplete)
     logn = n.bit_length() - 1
     batch = a.shape[0]
     c, sa, sb = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)

@@ -127,6 +127,18 @@ def test_emulated_u64_product_on_incomplete_transforms(level, generated, oracle_
     assert not np.array_equal(bad, got[:1])
 
 
+@pytest.mark.parametrize("n,block_log", [(8192, 13), (16384, 14)])
+def test_emulated_u64_row_products_on_incomplete_transforms(n, block_log, generated, oracle_factory):
+    """the row-resident products (ring-mode register map: one butterfly at a time, every register taken -- the base
+    multiplication's scratch is three reserved slots of the twiddle ring) with 2 stages dropped each way"""
+    o = oracle_factory(64, n, 1)
+    prm, a, b = operands(o, 64, n, 1, 2, 25)
+    P = np.asarray(prm.P[:1], dtype=np.uint64)
+    a[1], b[1] = (P - 1)[:, None], (P - 1)[:, None]
+    got = asm_emu.run_block_kernel(generated("polymul%di2" % n), n, 1, prm, a, b, block_log, incomplete=2)
+    assert np.array_equal(got, o.polymul(a, b))
+
+
 def test_barrett_step_of_the_base_multiplication_in_integers():
     """the reduction incomplete.py emits for sums T < 2^127 of products of folded words, restated on Python integers:
     th = T >> 63, q^ = 2 th + floor(th m / 2^64) with m = floor(2^127 / p) - 2^65, r = T - q^ p must lie in [0, 2^64) with
@@ -384,6 +396,27 @@ def test_emulated_u64_three_role_kernel(stem, n, generated, oracle_factory):
     # operand b already transformed: the variant without a forward role for it (24 workgroups per row), b' read block-wise
     fb = o2.ntt(b)
     assert np.array_equal(asm_emu.run_pipe_product(generated(stem + "b"), n, 2, prm, a, fb, remap=True, b_ntt=True), o2.polymul(a, b))
+
+
+def test_emulated_u64_three_role_kernel_on_incomplete_transforms(generated, oracle_factory):
+    """workload E with its block products on incomplete transforms (role V = incomplete.body_incomplete at r = 4, the scale
+    (n / 4)^-1 folded in by the streaming inverse role from the level-2 ModConst records), two moduli, XCD remap, and the same
+    kernel driven as the chunked pipeline drives it (all three roles in one launch)"""
+    n = 65536
+    o2 = oracle_factory(64, n, 2)
+    prm, a, b = operands(o2, 64, n, 2, 1, 23)
+    stem = generated("polymul_pipe65536nti2")
+    want = o2.polymul(a, b)
+    assert np.array_equal(asm_emu.run_pipe_product(stem, n, 2, prm, a, b, remap=True, incomplete=2), want)
+    assert np.array_equal(asm_emu.run_pipe_product_pipelined(stem, n, 2, prm, a, b, incomplete=2), want)
+
+
+def test_emulated_one_launch_plan_on_incomplete_transforms(generated, oracle_factory):
+    """the persistent one-launch plan (rows of 32768 words) with its block products on incomplete transforms"""
+    o = oracle_factory(64, 32768, 1)
+    prm, a, b = operands(o, 64, 32768, 1, 8, 24)
+    got = asm_emu.run_xcd_product(generated("polymul_xcd32768i2"), 32768, 1, prm, a, b, 0, 3, 0, 40, _picker("round-robin"), incomplete=2)
+    assert np.array_equal(got, o.polymul(a, b))
 
 
 def _picker(kind):

@@ -75,3 +75,39 @@ def test_incomplete_products_at_full_batch(lv, level, engine_factory, oracle_fac
     o = oracle_factory(64, 4096, 4)
     for i in (0, 5461, batch - 1):
         assert np.array_equal(e.to_host(c[i:i + 1]), o.polymul(e.to_host(a[i:i + 1]), e.to_host(b[i:i + 1])))
+
+
+@pytest.mark.parametrize("n,m,batch,xcd", [(65536, 3, 11, False), (65536, 3, 11, True), (65536, 30, 2, False), (32768, 2, 37, True)])
+def test_long_row_plans_on_incomplete_block_products(n, m, batch, xcd, level, oracle_factory):
+    """rows of 65536 / 32768 words: the chunked three-role pipeline and the one-launch plan with their 4096-word block
+    products on incomplete transforms (level 2; the streaming inverse role folds in (n / 4)^-1) -- the complete plans' words,
+    the oracle's on the first and the last polynomial, in place"""
+    from test_gpu_xcd import _engine
+    o, e = oracle_factory(64, n, m), _engine(n, m, xcd)
+    a = e.fill_uniform(e.empty(batch), SEED, 0)
+    b = e.fill_uniform(e.empty(batch), SEED, 1)
+    level(0)
+    want = e.to_host(e.polymul(a, b))
+    level(2)
+    got = e.to_host(e.polymul(a, b))
+    assert np.array_equal(got, want)
+    for i in (0, batch - 1):
+        assert np.array_equal(got[i:i + 1], o.polymul(e.to_host(a[i:i + 1]), e.to_host(b[i:i + 1])))
+    a2 = a.clone()
+    e.polymul(a2, b, out=a2)
+    assert np.array_equal(e.to_host(a2), want)
+
+
+@pytest.mark.parametrize("n,m,batch", [(8192, 2, 5), (16384, 8, 3), (16384, 1, 1)])
+def test_row_resident_products_on_incomplete_transforms(n, m, batch, level, oracle_factory, engine_factory):
+    """rows of 8192 / 16384 words (nflhip_polymul{8192,16384}i2_asm): the oracle's words at level 2 and 0, all-(p-1) rows, in place"""
+    o, e = oracle_factory(64, n, m), engine_factory(64, n, m)
+    a, b = o.fill_uniform(batch, SEED, 0), o.fill_uniform(batch, SEED, 1)
+    P = np.asarray(e.params.P[:m], dtype=np.uint64)
+    a[batch - 1], b[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    want = o.polymul(a, b)
+    for lv in (0, 2):
+        level(lv)
+        da, db = e.to_device(a), e.to_device(b)
+        assert np.array_equal(e.to_host(e.polymul(da, db)), want), "level %d" % lv
+        assert np.array_equal(e.to_host(e.polymul(da, db, out=da)), want), "level %d in place" % lv

@@ -95,7 +95,7 @@ def base_mul(a0, b0, G, tw, negate, rtmp, negtmp):
         for k in range(G - 1, -1, -1):
             ys = [b[k - i] if k - i >= 0 else b[k - i + G] for i in range(G)]   # (b[j] for j > k already holds zeta b_j)
             yield from dot(s, a, ys)
-            dst = T(s, 16) if k == 0 else rtmp[s] + 2 * (k - 1)
+            dst = T(s, 16) if k == 0 else (rtmp[s][k - 1] if isinstance(rtmp[s], (list, tuple)) else rtmp[s] + 2 * (k - 1))
             yield from barrett127(s, dst)
             res[k] = dst
             if k:

@@ -73,6 +73,9 @@ def main():
     em_b = build_pipe(b_ntt=True)     # operand b already transformed: two streaming roles per row, b' read block-wise as it lies
     em_b.lines = nt(em_b)
     emit_file(os.path.join(outdir, "polymul_pipe65536ntb_gfx950.s"), "nflhip_polymul_pipe65536ntb_asm", em_b, args=ARGS_PIPE)
+    em_i = build_pipe(level=2)        # ... its block products on incomplete transforms (round 6)
+    em_i.lines = nt(em_i)
+    emit_file(os.path.join(outdir, "polymul_pipe65536nti2_gfx950.s"), "nflhip_polymul_pipe65536nti2_asm", em_i, args=ARGS_PIPE)
     if experiments:
         emit_file(os.path.join(outdir, "polymul_pipe65536_gfx950.s"), "nflhip_polymul_pipe65536_asm", build_pipe(), args=ARGS_PIPE)
         em15 = build_pipe(15)     # n = 32768 on the same kernel with radix-8 streaming roles (superseded by build_row32k)
@@ -87,11 +90,17 @@ def main():
         emit_file(os.path.join(outdir, "polymul_xcd%d%s_gfx950.s" % (1 << lg, sfx)), "nflhip_polymul_xcd%d%s_asm" % (1 << lg, sfx), emf,
                   args=ARGS_PIPE, lds=cfg.LDS_BYTES + 64)
     cfg.FUSED_LIFO = False
+    for lg in (16, 15):               # ... and on incomplete transforms
+        cfg.FUSED_LOADS = ""
+        emf = build_pipe(lg, fused=True, level=2)
+        emit_file(os.path.join(outdir, "polymul_xcd%di2_gfx950.s" % (1 << lg)), "nflhip_polymul_xcd%di2_asm" % (1 << lg), emf,
+                  args=ARGS_PIPE, lds=cfg.LDS_BYTES + 64)
     build_pipe(16)   # (leave the module-level PIPE_LOGN as it was)
     ring = "ringpair" if os.environ.get("NFL_GEN_RINGPAIR") else "ring"
     cfg.configure(ring, 4)
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), kname, build_row16k(kind))
+    emit_file(os.path.join(outdir, "polymul16384i2_gfx950.s"), "nflhip_polymul16384i2_asm", build_row16k("polymul", level=2))   # incomplete transforms (round 6)
     cfg.set(NEXT_SGPR=98)     # two rows of one modulus per workgroup on shared twiddle records (stand-alone forward transform)
     emit_file(os.path.join(outdir, "ntt_fwd16384x2_gfx950.s"), "nflhip_ntt_fwd16384x2_asm", build_row16k("fwd2"), args=ARGS_STD + [("i32", 48)])
     cfg.set(NEXT_SGPR=96)
@@ -103,6 +112,7 @@ def main():
     for kind, (stem, kname) in KERNELS16K.items():
         emit_file(os.path.join(outdir, stem.replace("16384", "8192") + "_gfx950.s"), kname.replace("16384", "8192"),
                   build_row16k(kind))
+    emit_file(os.path.join(outdir, "polymul8192i2_gfx950.s"), "nflhip_polymul8192i2_asm", build_row16k("polymul", level=2))
     cfg.set(NEXT_SGPR=98)
     emit_file(os.path.join(outdir, "ntt_fwd8192x2_gfx950.s"), "nflhip_ntt_fwd8192x2_asm", build_row16k("fwd2"), args=ARGS_STD + [("i32", 48)])
     cfg.set(NEXT_SGPR=96)

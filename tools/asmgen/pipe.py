@@ -69,7 +69,7 @@ def legacy_role_map(em, PER_ROW, NV, NSW, b_ntt=False):
     R("s_cbranch_scc1 .Lrole_i")
 
 
-def build_pipe(logn=None, fused=False, b_ntt=False):
+def build_pipe(logn=None, fused=False, b_ntt=False, level=0):
     """n = 65536 (logn 16): radix-16 streaming roles, 16 + 3 x 4 = 28 workgroups per row.
     n = 32768 (logn 15): radix-8 streaming roles (a thread's 16 registers hold two columns of 8 words), 8 + 3 x 2 = 14.
     fused: ONE launch of persistent workgroups for the whole batch; the three roles of a row run on ONE XCD, ordered by
@@ -89,6 +89,8 @@ def build_pipe(logn=None, fused=False, b_ntt=False):
     NSW = 4 if RL == 4 else 2                             # streaming workgroups per row and operand
     PER_ROW = NV + (2 if b_ntt else 3) * NSW
     assert not (fused and b_ntt)
+    assert not (level and b_ntt)                          # level: the block products run on incomplete transforms (incomplete.py);
+                                                          # the host then passes the records with (n / 2^level)^-1 for role I
     CG_LOG = 11 if RL == 4 else 12                        # bytes (log2) of one column group: 256 columns x (16 / RADIX) x 8 B
     stride = n_words // RADIX * 8                         # bytes between x[o + k n/RADIX]
     R("s_load_dwordx8 s[4:11], s[0:1], 0x0")             # c_v, a_v, b_v, psi
@@ -311,7 +313,7 @@ def build_pipe(logn=None, fused=False, b_ntt=False):
         tw_seq[("F1", st)] = PASS_TW["F1"](em, vm, st)
     emit_consts(em)
     mark = len(em.lines)
-    build_body(em, vm, "polymul_ntt" if b_ntt else "polymul", tw_seq, "_v")
+    build_body(em, vm, "polymul_ntt" if b_ntt else "polymul", tw_seq, "_v", level=level)
     if fused:
         mod = " nt" if cfg.FUSED_LIFO else cfg.FUSED_LOADS
         em.lines[mark_v:mark] = [l + mod if "global_load_dwordx2" in l else l for l in em.lines[mark_v:mark]]

@@ -200,8 +200,12 @@ def prologue16k(em, vm, stop=None, kind="polymul", key_row=False, compact_x=Fals
         em.valu("v_mov_b32_e32 v%d, 0x3fffffff" % (v_mask(),))
 
 
-def build_row16k(kind="polymul", stop=None):
-    """kind: polymul | polymul_ntt (b already in NTT form) | fwd | inv -- over one 16384-word block per workgroup"""
+def build_row16k(kind="polymul", stop=None, level=0):
+    """kind: polymul | polymul_ntt (b already in NTT form) | fwd | inv -- over one 16384-word block per workgroup
+    level (kind polymul, split schedules only): 1 / 2 = the product on incomplete transforms (incomplete.py): F3 and I1 keep
+    their first 4 - level sub-stages, the point-wise step is the base multiplication mod X^(2^level) -+ zeta; the host passes
+    the ModConst records with (n / 2^level)^-1"""
+    assert not level or (kind == "polymul" and cfg.SPLIT32K and cfg.SINGLE_STREAM)
     em = Emitter()
     vm = VmCounter(em)
     R = em.raw
@@ -214,7 +218,15 @@ def build_row16k(kind="polymul", stop=None):
     has_fwd = kind != "inv"
     has_inv = kind not in ("fwd", "fwd2")
     names = (["F0", "F1", "F2", "F3"] if has_fwd else []) + (["I1", "I2", "I3", "I0"] if has_inv else [])
-    uses = [(name, s, g) for name in names for s in order[name] for g in range(1 << s)]
+    keep_last = None               # level: (pass, sub-stage) whose records stay in the ring through the base multiplication (zeta)
+    if level:
+        keep = 4 - level
+        order["F3"], order["I1"] = tuple(range(keep)), tuple(range(keep - 1, -1, -1))
+        keep_last = ("F3", keep - 1)
+        passes["TMP"] = None       # three reserved ring slots: the base multiplication's scratch (every register of the 128 is taken)
+        names = ["F0", "F1", "F2", "F3", "TMP", "I1", "I2", "I3", "I0"]
+        order["TMP"] = (0,)
+    uses = [(name, s, g) for name in names for s in order[name] for g in (range(3) if name == "TMP" else range(1 << s))]
     ring = Ring(em, vm, cfg.RING_SLOTS, uses, passes)
     fwd_bases = (cfg.V_A, cfg.V_B) if kind in ("polymul", "fwd2") else (cfg.V_A,)
     prologue16k(em, vm, stop, kind)
@@ -269,7 +281,8 @@ def build_row16k(kind="polymul", stop=None):
     def then_b(name, s_):
         for g in range(1 << s_):
             run_pairs(em, bflys(cfg.V_B, s_, g, ring.regs((name, s_, g))))
-            ring.done((name, s_, g))
+            if (name, s_) != keep_last:
+                ring.done((name, s_, g))
 
     def both(name, s_):
         for g in range(1 << s_):
@@ -278,7 +291,8 @@ def build_row16k(kind="polymul", stop=None):
             for ja, jb in zip(bflys(cfg.V_A, s_, g, tw), bflys(cfg.V_B, s_, g, tw)):
                 jobs += [ja, jb]
             run_pairs(em, jobs)
-            ring.done((name, s_, g))
+            if (name, s_) != keep_last:
+                ring.done((name, s_, g))
 
     def x0_w(base):
         em.valu("v_add_u32_e32 v%d, 0x%x, v%d" % (AX, 2 * cfg.SLAB_BYTES, cfg.V_OFF8))
@@ -297,9 +311,8 @@ def build_row16k(kind="polymul", stop=None):
         exch = {"F0": (x0_w, x0_r, True),
                 "F1": (lambda b_: lds_write(em, cfg.V_L1W, b_, 2176), lambda b_: lds_read(em, cfg.V_L1R, b_, 136), True),
                 "F2": (lambda b_: lds_write(em, cfg.V_L1R, b_, 136), lambda b_: lds_read(em, cfg.V_L2R, b_, 8), False)}   # E2: wave-local
-        names = ["F0", "F1", "F2", "F3"]
         pending = None          # exchange of operand b still to be finished inside the next pass
-        for name in names:
+        for name in ["F0", "F1", "F2", "F3"]:
             stages = list(order[name])
             em.comment("%s (operands share the twiddle records; exchanges under the arithmetic)" % name)
             k = 0
@@ -498,7 +511,25 @@ def build_row16k(kind="polymul", stop=None):
         em.comment("point-wise product (thread t of sub-group q holds words 16t..16t+15 of block q of both operands)")
         if kind == "polymul_ntt":
             R("s_waitcnt vmcnt(%d)" % (vm.issued - n_before_ring))    # b's loads (issued before the ring's) have landed
-        run_pairs(em, [pointwise(cfg.V_A + 2 * i, cfg.V_B + 2 * i, True, kind == "polymul") for i in range(16)])
+        if level:
+            from .incomplete import base_mul
+            G = 1 << level
+            em.comment("base multiplication mod X^%d -+ zeta; scratch = three reserved ring slots" % G)
+            tmp = [int(ring.get(("TMP", 0, k))[0][1:]) for k in range(3)]          # first register of each reserved slot
+            assert tmp[0] % 2 == 0
+            rt = [tmp[0], tmp[0] + 2, tmp[1]][:G - 1] if G == 4 else [tmp[0]]
+            # (base_mul addresses its G - 1 result pairs as rtmp + 2 (k - 1): hand it a contiguous-looking map)
+            jobs = []
+            for g in range(16 // G):
+                tw = ring.regs((keep_last[0], keep_last[1], g // 2))
+                jobs.append(base_mul(cfg.V_A + 2 * G * g, cfg.V_B + 2 * G * g, G, tw, bool(g & 1), [rt, rt], [tmp[2], tmp[2]]))
+            run_pairs(em, jobs)
+            for g in range(1 << keep_last[1]):
+                ring.done((keep_last[0], keep_last[1], g))
+            for k in range(3):
+                ring.done(("TMP", 0, k))
+        else:
+            run_pairs(em, [pointwise(cfg.V_A + 2 * i, cfg.V_B + 2 * i, True, kind == "polymul") for i in range(16)])
     else:
         R("s_waitcnt vmcnt(%d)" % (vm.issued - n_before_ring))        # the block loads have landed
         em.comment("lane-contiguous -> thread-contiguous through the wave's own LDS region")
@@ -536,7 +567,7 @@ def build_row16k(kind="polymul", stop=None):
 
         AXP = cfg.V_TWA                                          # (idle in the uniform pass I3 and in I0)
         rstep = 2048 * cfg.ROW_G                                 # bytes between a reader's consecutive slots
-        for s_ in (3, 2, 1):
+        for s_ in order["I1"][:-1]:
             inv_stage("I1", s_)
         em.comment("E2' (wave-local): written word by word out of I1's last stage, read in I2's order")
         inv_stage("I1", 0, post=lambda k: R("ds_write_b64 v%d, %s offset:%d" % (cfg.V_L2R, vp(cfg.V_A + 2 * k), 8 * k)))

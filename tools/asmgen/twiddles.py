@@ -164,6 +164,9 @@ class Ring:
         self.slot_of[use] = slot
         name, s, g = use
         em, r = self.em, cfg.V_TW + 4 * slot
+        if self.passes[name] is None:     # a RESERVED slot: four scratch registers handed out in ring order, nothing is loaded
+            self.seq_of[use] = self.vm.issued
+            return
         if callable(self.passes[name]):   # not a twiddle record: the pass supplies the load (row32k streams b' this way)
             text = self.passes[name](em, r, s, g, self.cur != (name, s))
             self.cur = (name, s)

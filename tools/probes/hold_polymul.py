@@ -3,6 +3,7 @@
 (rocm-smi sampled while the launches are queued): `python tools/probes/hold_polymul.py DEGREE NMODULI BATCH [SECONDS]`.
 PYTHONPATH selects the library (ablated builds live under build/abl_*)."""
 import json
+import os
 import subprocess
 import sys
 import time
@@ -13,6 +14,8 @@ from nfllib_amd import Engine
 n, nm, batch = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 secs = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
 e = Engine(64, n, nm)
+if os.environ.get("NFL_POLYMUL_LEVEL"):      # probe knob (not read by the library): nflhip_debug_polymul_level, include/nflhip_debug.h
+    e.lib.nflhip_debug_polymul_level(int(os.environ["NFL_POLYMUL_LEVEL"]))
 a = e.fill_uniform(e.empty(batch), 1, 0)
 b = e.fill_uniform(e.empty(batch), 1, 1)
 c = e.empty(batch)
