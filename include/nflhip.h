@@ -209,7 +209,9 @@ int nflhip_polymul_ntt_dev(nflhip_ctx *ctx, void *d_c, const void *d_a, const vo
  * one SIGNED integer per coefficient shared by all moduli (int8 / int16 / int32; v < 0 stands for p + v; |v| must be
  * below every modulus) -- what the samplers produce before they spread a value over the moduli (core.hpp:230-277); see
  * nflhip_sample_gauss_small_dev.  k operands and the operands of nflhip_fma_inv_dev are words in NTT form (canonical,
- * ops.hpp:131,211).  Results are dense; a result may alias any input of the same call (x, either e, either k).  u64 limbs at degree 4096,
+ * ops.hpp:131,211).  Results are dense; a result may alias a DENSE (stride 1) input of the same call
+ * exactly (same first byte), or lie over one in any way when it is out0 over e1 / k1 (then a plan that reads every input before it
+ * stores is taken); a result that overlaps an operand shared by the batch (stride 0, batch > 1) is refused with NFLHIP_ERR_INVALID.  u64 limbs at degree 4096,
  * 8192 and 16384 run one generated gfx950 kernel per call (at degree 32768 nflhip_fma_inv_dev does for dense a / b, and the forward
  * entries run three for int8 polynomials with keys of stride 0); rows of 1024 / 2048 words -- 4096 for 32-bit limbs -- run every
  * entry as ONE pass of the wave-per-row kernels (forward: inputs of one format, strides 0 / 1); every other shape composes the same

@@ -1140,7 +1140,10 @@ static int fused_fwd_composed(nflhip_ctx *ctx, void *out0, void *out1, const nfl
   const size_t bytes = poly_bytes(ctx, batch);
   std::unique_lock<std::mutex> lk(ctx->scratch_mu);
   const bool cap = is_capturing(st);
-  int rc = ensure_scratch(ctx, (out1 ? 3 : 2) * bytes);
+  // three polynomials of scratch per batch element only when the first result lies over an input of the second one (then every
+  // input is read before anything is stored); otherwise two: e1 is transformed into e0's place after the first result is out
+  const bool overlap = out1 && (first_result_overlaps(ctx, out0, e1, batch) || first_result_overlaps(ctx, out0, k1, batch));
+  int rc = ensure_scratch(ctx, (overlap ? 3 : 2) * bytes);
   if (rc) return rc;
   if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
   if (!cap && ctx->ev_prev_valid)
@@ -1177,23 +1180,37 @@ static int fused_fwd_composed(nflhip_ctx *ctx, void *out0, void *out1, const nfl
   // first result is stored (e1 may be out0), and when out0 overlaps a per-element k1 the first result waits in the scratch
   // until the second has been computed -- the generated kernels read a whole row of every operand before they store, the
   // composed plan gives the same guarantee
-  for (int h = 0; h < (out1 ? 2 : 1); ++h) {
-    void *sh = h ? s2 : s1;
-    e = expand_any(ctx, sh, h ? e1 : e0, batch, st);
-    if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
-    rc = nflhip_ntt_fwd_dev(ctx, sh, batch, st);
-    if (rc) return rc;
+  if (!overlap) {
+    for (int h = 0; h < (out1 ? 2 : 1); ++h) {
+      e = expand_any(ctx, s1, h ? e1 : e0, batch, st);
+      if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
+      rc = nflhip_ntt_fwd_dev(ctx, s1, batch, st);
+      if (rc) return rc;
+      const nflhip_operand *kk = h ? k1 : k0;
+      const void *ops[3] = {s0, kk->ptr, s1};
+      const unsigned sd[3] = {1, (unsigned)kk->stride, 1};
+      rc = eval_dev(ctx, h ? out1 : out0, ops, 3, prog, sizeof(prog), batch, st, sd, 1);
+      if (rc) return rc;
+    }
+  } else {
+    for (int h = 0; h < 2; ++h) {
+      void *sh = h ? s2 : s1;
+      e = expand_any(ctx, sh, h ? e1 : e0, batch, st);
+      if (e != hipSuccess) return hipfail(ctx, e, "fwd_fma: expand");
+      rc = nflhip_ntt_fwd_dev(ctx, sh, batch, st);
+      if (rc) return rc;
+    }
+    const bool hold0 = first_result_overlaps(ctx, out0, k1, batch);
+    for (int h = 0; h < 2; ++h) {
+      const nflhip_operand *kk = h ? k1 : k0;
+      void *sh = h ? s2 : s1;
+      const void *ops[3] = {s0, kk->ptr, sh};
+      const unsigned sd[3] = {1, (unsigned)kk->stride, 1};
+      rc = eval_dev(ctx, h ? out1 : (hold0 ? s1 : out0), ops, 3, prog, sizeof(prog), batch, st, sd, 1);
+      if (rc) return rc;
+    }
+    if (hold0) HIPCHK(ctx, hipMemcpyAsync(out0, s1, bytes, hipMemcpyDeviceToDevice, st));
   }
-  const bool hold0 = out1 && first_result_overlaps(ctx, out0, k1, batch);
-  for (int h = 0; h < (out1 ? 2 : 1); ++h) {
-    const nflhip_operand *kk = h ? k1 : k0;
-    void *sh = h ? s2 : s1;
-    const void *ops[3] = {s0, kk->ptr, sh};
-    const unsigned sd[3] = {1, (unsigned)kk->stride, 1};
-    rc = eval_dev(ctx, h ? out1 : (hold0 ? s1 : out0), ops, 3, prog, sizeof(prog), batch, st, sd, 1);
-    if (rc) return rc;
-  }
-  if (hold0) HIPCHK(ctx, hipMemcpyAsync(out0, s1, bytes, hipMemcpyDeviceToDevice, st));
   if (!cap) {  // the scratch is reused by the next call on any stream: order it after this one
     HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));
     ctx->ev_scratch_valid = true;
@@ -1216,6 +1233,16 @@ static int fused_fwd_any(nflhip_ctx *ctx, void *out0, void *out1, const nflhip_o
   if (!rc && two) rc = check_operand(ctx, e1, batch, false, "e1");
   if (rc) return rc;
   if (batch == 0) return NFLHIP_OK;
+  // a result may lie over a DENSE input (nflhip.h); over an operand the whole batch shares (stride 0, batch > 1) it would be
+  // written by one batch element while the others still read it: refused, not raced
+  if (batch > 1) {
+    const nflhip_operand *ins[5] = {x, k0, e0, k1, e1};
+    void *outs[2] = {out0, two ? out1 : nullptr};
+    for (const nflhip_operand *in : ins)
+      for (void *o : outs)
+        if (in && o && in->stride == 0 && first_result_overlaps(ctx, o, in, batch))
+          return fail(ctx, NFLHIP_ERR_INVALID, "a result overlaps an operand shared by the batch (stride 0)");
+  }
   hipStream_t st = (hipStream_t)stream;
   // (the generated two-result kernels store a row of out0 before they load that row of k1 and, the row-resident ones, of e1: a
   // first result laid over an input of the second -- legal, nflhip.h -- takes the composed plan, which reads every polynomial

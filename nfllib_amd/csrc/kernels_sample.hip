@@ -527,10 +527,11 @@ __device__ __forceinline__ void gauss_search16(const uint64_t (&w)[8], uint64_t 
       if (redo & (1u << c)) out[c] = gauss_search32_one<W>(r[c], g0 + c, top, cdt, entries, tie_shift, key, nc);
   }
 }
-// LDS image of a narrow-draw kernel: top halves [entries, rounded up to even], then the bucket table
+// LDS image of a narrow-draw kernel: top halves [entries, rounded up to a multiple of FOUR words], then the bucket table -- the
+// table is copied with 16-byte LDS stores, so its offset and the dynamic-LDS base (alignas(16) below) keep it 16-byte aligned
 __device__ __forceinline__ const uint16_t *stage_gauss_top32(uint32_t *top, const uint64_t *__restrict__ cdt, const uint16_t *__restrict__ lut_g,
                                                              int entries, int W) {
-  uint16_t *lut = reinterpret_cast<uint16_t *>(top + ((entries + 1) & ~1));
+  uint16_t *lut = reinterpret_cast<uint16_t *>(top + ((entries + 3) & ~3));
   for (int k = threadIdx.x; k < entries; k += blockDim.x) top[k] = (uint32_t)(cdt[(size_t)k * W] >> 32);
   for (int k = threadIdx.x; k < kGaussBuckets / 8; k += blockDim.x)
     reinterpret_cast<uint4 *>(lut)[k] = reinterpret_cast<const uint4 *>(lut_g)[k];
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t 
                                                        const uint64_t *__restrict__ cdt, int entries, long long x_min,
                                                        long long amp, ChaChaKey key, uint64_t nonce, int tie_shift,
                                                        const uint16_t *__restrict__ lut_g) {
-  extern __shared__ uint32_t gtop32[];
+  extern __shared__ alignas(16) uint32_t gtop32[];
   const uint16_t *lut = lut_g ? stage_gauss_top32(gtop32, cdt, lut_g, entries, W) : nullptr;
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 4;  // first_coef and ncoef are multiples of 16 (n >= 16)
@@ -607,7 +608,7 @@ __global__ void __launch_bounds__(256) k_sample_gauss16(T *d, const ModConst<T> 
                                                         int tie_shift, const uint16_t *__restrict__ lut_g) {
   constexpr int S = kTS;
   __shared__ int xs[4][16 * S];
-  extern __shared__ uint32_t gtop32[];
+  extern __shared__ alignas(16) uint32_t gtop32[];
   const uint16_t *lut = lut_g ? stage_gauss_top32(gtop32, cdt, lut_g, entries, W) : nullptr;
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 4;
@@ -983,7 +984,7 @@ std::vector<uint16_t> gauss_bucket_table(const uint64_t *cdt, int words, size_t 
   }
   return lut;
 }
-static size_t gauss_narrow_lds(int entries) { return (size_t)((entries + 1) & ~1) * 4 + (size_t)kGaussBuckets * 2; }
+static size_t gauss_narrow_lds(int entries) { return (size_t)((entries + 3) & ~3) * 4 + (size_t)kGaussBuckets * 2; }
 // steps of the LDS-resident search (gauss_search8), 0 = the table is too long for LDS: the per-sample search over global memory
 static int gauss_lds_iters(int entries) {
   if (entries < 2 || entries > kGaussLdsEntries) return 0;
