@@ -805,6 +805,29 @@ def main():
                                                            "and on nfl::device_batch (operator by operator / its fused methods); all checks passed")
                 except Exception as ex:
                     extras["lwe"]["cpp_header"] = {"error": repr(ex)}
+        # what an UNCHANGED caller of the reference gains (north_star: "drops into existing callers"): one of the reference's own
+        # timing programs, same source, real NFLlib on this host's CPU against the drop-in header on this GPU
+        # (tools/reference_programs.py; the full table of all 11 programs: profiles/r06_reference_programs.txt)
+        if args.workload == "B" and not args.no_side_configs:
+            try:
+                tool = os.path.join(ROOT, "tools", "reference_programs.py")
+                rp_json = os.path.join(ROOT, "gpurun_out", "reference_programs_bench.json")
+                os.makedirs(os.path.dirname(rp_json), exist_ok=True)
+                torch.cuda.synchronize()
+                r = subprocess.run([sys.executable, tool, "--reps", "1", "--only", "nfllib_demo_main_op__8192_124_uint64_t", "--json", rp_json],
+                                   capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    raise RuntimeError((r.stdout + r.stderr)[-300:])
+                rp = json.load(open(rp_json))
+                prog = rp["programs"]["nfllib_demo_main_op__8192_124_uint64_t"]
+                extras["reference_programs"] = {
+                    "program": "tests/nfllib_demo_main_op.cpp, CONFIG 8192, 124, uint64_t -- unchanged source, built twice",
+                    "cpu": rp["summary"]["cpu"], "ops_us": {k: [v["cpu_us"], v["gpu_us"]] for k, v in prog["ops"].items()},
+                    "columns": "[real NFLlib on one host core, drop-in header on the MI355X] microseconds per polynomial",
+                    "note": "nfl::poly is a host array: every device call carries its PCIe round trip; resident nfl::poly_p is the fast path",
+                    "full_table": "profiles/r06_reference_programs.txt"}
+            except Exception as ex:   # secondary figure: never takes the bench down
+                extras["reference_programs"] = {"error": repr(ex)}
         # the other single-GPU BASELINE configs, timed inside this same run (driver-visible, not builder-only): configs[2]
         # (C) and configs[4] (E: "CRT lift + poly-mul"); the headline's own tensors are released first
         if args.workload == "B" and not args.no_side_configs:

@@ -188,6 +188,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     c->h_roots.push_back(roots[cm]);
     c->h_invk.push_back(invk[cm]);
     if (((((uint64_t)1) << (wb - 2)) - p) >> 32) c->shape.small_delta = 0;
+    if (c->shape.small_delta) c->shape.nm_small = (int)cm + 1;
   }
   c->kmax_log2 = kmax_log2;
   // CRT constants
@@ -421,7 +422,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   HIPCHK(nullptr, hipMalloc(&c->tabs.mc, mc.size() * sizeof(ModConst<T>)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.mc, mc.data(), mc.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
   c->tabs.mc_inc[0] = c->tabs.mc_inc[1] = nullptr;
-  if (sizeof(T) == 8 && n >= 4096 && !c->cyclic && c->shape.small_delta) {
+  if (sizeof(T) == 8 && n >= 4096 && !c->cyclic && (c->shape.small_delta || (n == 4096 && c->shape.nm_small > 0))) {
     // the metric product on incomplete transforms (nflhip_polymul4096i{1,2}_asm): the inverse undoes 12 - level stages, so the
     // scale folded into its last stage is (n / 2^level)^-1; the base multiplication reduces sums below 2^127 with
     // floor(2^127 / p) = 2^65 + m, m < 2^35 (delta < 2^32), handed over in the mu2 field
@@ -770,6 +771,7 @@ static int ctx_create_mode(nflhip_ctx **out, int device, int limb_bits, size_t d
   c->shape.n = degree;
   c->shape.nm = nmoduli;
   c->shape.small_delta = 1;
+  c->shape.nm_small = 0;
   // the environment is read HERE, once per context (include/nflhip.h "environment")
   {
     const char *v = getenv("NFLHIP_VARIANT");

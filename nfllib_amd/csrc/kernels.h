@@ -39,6 +39,8 @@ struct Shape {
   size_t crt_Lacc;   // limbs of the accumulator (L+1)
   uint64_t crt_Q0;   // the moduli product when it is below 2^64 (crt_L == 1), else its low word
   int small_delta;   // every modulus is 2^(W-2) - delta with delta < 2^32 (delta-form butterflies)
+  int nm_small;      // length of the PREFIX of moduli with delta < 2^32 (== nm when small_delta): at degree 4096 these rows keep the
+                     // delta-form kernels in a context whose later moduli need the general family (params.hpp:82-119: #92 on)
   // configuration, read ONCE when the context is created (include/nflhip.h "environment"):
   int compiled_only; // NFLHIP_VARIANT=hipcc: the compiled (hipcc) kernels serve every call -- the independent cross-check
                      // of the generated assembly kernels (bit-identical results, tests/test_gpu_variants.py)

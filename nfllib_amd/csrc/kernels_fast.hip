@@ -196,9 +196,8 @@ __device__ __forceinline__ void inv_core(u64 (&v)[16], u64 *sm, const Tw64 *__re
 
 template <bool B_IS_NTT, int ARITH>
 __device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, const u64 *b, const Tw64 *__restrict__ psi,
-                                             const MC64 *__restrict__ mc, int nm) {
+                                             const MC64 *__restrict__ mc, int nm, size_t row) {
   const int t = threadIdx.x;
-  const size_t row = blockIdx.x;
   const int cm = (int)(row % (size_t)nm);
   const MC64 mcc = mc[cm];
   const Mod k = make_mod(mcc);
@@ -245,12 +244,21 @@ __device__ __forceinline__ void polymul_body(u64 *sm, u64 *c, const u64 *a, cons
   for (int i = 0; i < 16; ++i) c[off + t + 256 * i] = va[i];
 }
 
+// a launch over the moduli [cm0, cm0 + cmcnt) of every polynomial only (cmcnt > 0): logical block L -> block index in the batch.
+// Contexts whose moduli beyond a prefix need the general arithmetic send the prefix to the generated kernels and the rest here.
+__device__ __forceinline__ size_t block_of(unsigned L, int nm, int r, int cm0, int cmcnt) {
+  if (cmcnt <= 0) return L;
+  const unsigned rs = L >> r, bl = L & ((1u << r) - 1u);
+  const size_t row = (size_t)(rs / (unsigned)cmcnt) * (size_t)nm + (size_t)cm0 + rs % (unsigned)cmcnt;
+  return (row << r) | bl;
+}
+
 template <bool B_IS_NTT, int ARITH, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void k_polymul4096(u64 *c, const u64 *a, const u64 *b,
                                                                 const Tw64 *__restrict__ psi,
-                                                                const MC64 *__restrict__ mc, int nm) {
+                                                                const MC64 *__restrict__ mc, int nm, int cm0, int cmcnt) {
   __shared__ u64 sm[kLdsWords];
-  polymul_body<B_IS_NTT, ARITH>(sm, c, a, b, psi, mc, nm);
+  polymul_body<B_IS_NTT, ARITH>(sm, c, a, b, psi, mc, nm, block_of(blockIdx.x, nm, 0, cm0, cmcnt));
 }
 
 // ---- stand-alone transforms (in place or out of place) --------------------------------
@@ -258,16 +266,17 @@ __global__ __launch_bounds__(kThreads, MINW) void k_polymul4096(u64 *c, const u6
 // logn > 12 the streaming outer passes run before (forward) / after (inverse) these.
 template <int ARITH>
 __global__ __launch_bounds__(kThreads) void k_ntt_fwd4096(const u64 *src, u64 *dst, const Tw64 *__restrict__ psi,
-                                                          const MC64 *__restrict__ mc, int nm, int logn) {
+                                                          const MC64 *__restrict__ mc, int nm, int logn, int cm0, int cmcnt) {
   __shared__ u64 sm[kLdsWords];
   const int t = threadIdx.x;
   const int r = logn - kLogN;
-  const size_t row = (size_t)blockIdx.x >> r;
-  const Blk bk{r, blockIdx.x & ((1u << r) - 1u)};
+  const size_t blk = block_of(blockIdx.x, nm, r, cm0, cmcnt);
+  const size_t row = blk >> r;
+  const Blk bk{r, (unsigned)(blk & ((1u << r) - 1u))};
   const int cm = (int)(row % (size_t)nm);
   const Mod k = make_mod(mc[cm]);
   const Tw64 *tw = psi + ((size_t)cm << logn);
-  const size_t off = (size_t)blockIdx.x << kLogN;
+  const size_t off = blk << kLogN;
   u64 v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = src[off + t + 256 * i];
@@ -293,17 +302,18 @@ __global__ __launch_bounds__(kThreads) void k_ntt_fwd4096(const u64 *src, u64 *d
 template <int ARITH, bool MUL>
 __global__ __launch_bounds__(kThreads) void k_ntt_inv4096(const u64 *src, const u64 *mul, u64 *dst,
                                                           const Tw64 *__restrict__ psi, const MC64 *__restrict__ mc,
-                                                          int nm, int logn) {
+                                                          int nm, int logn, int cm0, int cmcnt) {
   __shared__ u64 sm[kLdsWords];
   const int t = threadIdx.x;
   const int r = logn - kLogN;
-  const size_t row = (size_t)blockIdx.x >> r;
-  const Blk bk{r, blockIdx.x & ((1u << r) - 1u)};
+  const size_t blk = block_of(blockIdx.x, nm, r, cm0, cmcnt);
+  const size_t row = blk >> r;
+  const Blk bk{r, (unsigned)(blk & ((1u << r) - 1u))};
   const int cm = (int)(row % (size_t)nm);
   const MC64 mcc = mc[cm];
   const Mod k = make_mod(mcc);
   const Tw64 *tw = psi + ((size_t)cm << logn);
-  const size_t off = (size_t)blockIdx.x << kLogN;
+  const size_t off = blk << kLogN;
   const int w = t >> 6, l = t & 63;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -440,8 +450,10 @@ extern "C" int nflhip_debug_polymul_level(int level) {   // include/nflhip_debug
 
 // every generated kernel takes (dst, src_a, src_b, psi, mc, nm, logn) and one workgroup per block of its size
 static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a,
-                             const uint64_t *b, size_t batch, hipStream_t st) {
-  if (s.compiled_only || !s.small_delta || s.nm > 65535) return hipErrorNotSupported;
+                             const uint64_t *b, size_t batch, hipStream_t st, int ny = 0) {
+  // ny > 0: only the moduli [0, ny) of every polynomial (grid.y; rows stay nm apart) -- the delta-form prefix of a context whose
+  // later moduli take the general family
+  if (s.compiled_only || (!s.small_delta && !(ny > 0 && ny <= s.nm_small)) || s.nm > 65535) return hipErrorNotSupported;
   hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
   struct {
@@ -464,17 +476,17 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   if (s.logn < blog) return hipErrorNotSupported;
   const size_t gx = batch << (s.logn - blog);
   if (gx > 0x7fffffffull) return hipErrorInvalidValue;
-  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)s.nm, 1, is16k(kind) || is32k(kind) ? 1024 : (is8k(kind) ? 512 : kThreads), 1, 1, 0, st,
+  return hipModuleLaunchKernel(fn, (unsigned)gx, (unsigned)(ny > 0 ? ny : s.nm), 1, is16k(kind) || is32k(kind) ? 1024 : (is8k(kind) ? 512 : kThreads), 1, 1, 0, st,
                                nullptr, extra);
 }
 
 // n = 4096 stand-alone transforms of a batch: two polynomials (same modulus) per workgroup, like the a / b operands of the
 // fused product -- twice the bytes in flight per workgroup and one set of twiddle loads for both rows.
 static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t, uint64_t *dst, const uint64_t *src,
-                                size_t batch, hipStream_t st) {
+                                size_t batch, hipStream_t st, int ny = 0) {
   // (the same for rows of 16384 / 8192 words: the forward half of their fused products without the product)
   const bool k16 = kind == kAsmFwd16kX2, k8 = kind == kAsmFwd8kX2;
-  if (s.compiled_only || !s.small_delta || s.logn != (k16 ? kLogN + 2 : k8 ? kLogN + 1 : kLogN) || s.nm > 65535) return hipErrorNotSupported;
+  if (s.compiled_only || (!s.small_delta && !(ny > 0 && ny <= s.nm_small)) || s.logn != (k16 ? kLogN + 2 : k8 ? kLogN + 1 : kLogN) || s.nm > 65535) return hipErrorNotSupported;
   if (batch < 2 || batch > 0x7fffffffull) return hipErrorNotSupported;
   hipFunction_t fn = asm_fn(kind);
   if (!fn) return hipErrorNotSupported;
@@ -485,7 +497,7 @@ static hipError_t launch_asm_x2(AsmKind kind, const Shape &s, const DevTables &t
   } args = {dst, src, nullptr, k16 || k8 ? PSI_LM(t) : t.psi, t.mc, (int)s.nm, s.logn, (int)batch};
   size_t size = 52;
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), (unsigned)s.nm, 1, k16 ? 1024 : k8 ? 512 : kThreads, 1, 1, 0, st, nullptr, extra);
+  return hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), (unsigned)(ny > 0 ? ny : s.nm), 1, k16 ? 1024 : k8 ? 512 : kThreads, 1, 1, 0, st, nullptr, extra);
 }
 
 // transform-fused pipelines (tools/gen_polymul_asm.py build_fused, kernarg ARGS_FUSED): one 256-thread workgroup per
@@ -804,15 +816,23 @@ hipError_t launch_polymul_blocks_asm_u64(const Shape &s, const DevTables &t, uin
 
 template <bool B_IS_NTT>
 static hipError_t launch_polymul_v(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
-                                   unsigned rows, hipStream_t st) {
+                                   unsigned rows, hipStream_t st, int cm0 = 0, int cmcnt = 0) {
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
   const int nm = (int)s.nm;
   // delta-form arithmetic (two-bit fold, one-off quotient: the assembly kernel's formulation) needs delta < 2^32; any other
-  // modulus takes the Harvey ranges with the generic Shoup product
-  if (s.small_delta) hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, 3, 2>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);
-  else hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, 0, 2>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm);
+  // modulus takes the Harvey ranges with the generic Shoup product.  cmcnt > 0: `rows` counts only the moduli [cm0, cm0 + cmcnt)
+  if (s.small_delta) hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, 3, 2>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm, cm0, cmcnt);
+  else hipLaunchKernelGGL((k_polymul4096<B_IS_NTT, 0, 2>), dim3(rows), dim3(kThreads), 0, st, c, a, b, psi, mc, nm, cm0, cmcnt);
   return hipGetLastError();
+}
+
+// A context whose moduli beyond a prefix have delta >= 2^32 (the reference's table from its 93rd 62-bit prime on, params.hpp:82-119):
+// at degree 4096 the prefix rows keep the generated delta-form kernels (grid restricted to those moduli), the others take the
+// general-modulus kernels -- two launches on the stream, disjoint rows.
+static inline bool split_families(const Shape &s, size_t batch) {
+  return s.limb_bits == 64 && s.logn == kLogN && !s.small_delta && s.nm_small > 0 && !s.compiled_only && batch > 0 &&
+         batch * (s.nm - (size_t)s.nm_small) <= 0x7fffffffull;
 }
 
 static inline bool row16k_shape(const Shape &s) { return s.limb_bits == 64 && s.logn == kLogN + 2; }
@@ -840,6 +860,18 @@ hipError_t launch_polymul_fast_u64(const Shape &s, const DevTables &t, uint64_t 
   const size_t rows = batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows > 0x7fffffffull) return hipErrorInvalidValue;
+  if (split_families(s, batch)) {
+    const int ns = s.nm_small, level = b_is_ntt ? 0 : g_polymul_level.load();
+    hipError_t e = hipErrorNotSupported;
+    if (level == 1 || level == 2) e = launch_asm(level == 1 ? kAsmPolymulI1 : kAsmPolymulI2, s, t, c, a, b, batch, st, ns);
+    if (e == hipErrorNotSupported) e = launch_asm(b_is_ntt ? kAsmPolymulNtt : kAsmPolymul, s, t, c, a, b, batch, st, ns);
+    if (e == hipSuccess) {
+      const unsigned rest = (unsigned)(batch * (s.nm - (size_t)ns));
+      return b_is_ntt ? launch_polymul_v<true>(s, t, c, a, b, rest, st, ns, (int)s.nm - ns)
+                      : launch_polymul_v<false>(s, t, c, a, b, rest, st, ns, (int)s.nm - ns);
+    }
+    if (e != hipErrorNotSupported) return e;
+  }
   if (!b_is_ntt && s.logn == kLogN) {
     // coefficient form in AND out: the transforms may stay incomplete (tools/asmgen/incomplete.py) -- same words out
     const int level = g_polymul_level.load();
@@ -871,9 +903,20 @@ hipError_t launch_inner_fwd_fast_u64(const Shape &s, const DevTables &t, const u
   }
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
+  if (rows % s.nm == 0 && split_families(s, rows / s.nm)) {
+    const int ns = s.nm_small;
+    hipError_t e = launch_asm_x2(kAsmFwd2, s, t, dst, src, rows / s.nm, st, ns);
+    if (e == hipErrorNotSupported) e = launch_asm(kAsmFwd, s, t, dst, src, nullptr, rows / s.nm, st, ns);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_ntt_fwd4096<0>, dim3((unsigned)(rows / s.nm * (s.nm - (size_t)ns))), dim3(kThreads), 0, st, src, dst, psi, mc,
+                         (int)s.nm, s.logn, ns, (int)s.nm - ns);
+      return hipGetLastError();
+    }
+    if (e != hipErrorNotSupported) return e;
+  }
   const dim3 g((unsigned)blocks), b(kThreads);
-  if (s.small_delta) hipLaunchKernelGGL(k_ntt_fwd4096<3>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
-  else hipLaunchKernelGGL(k_ntt_fwd4096<0>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn);
+  if (s.small_delta) hipLaunchKernelGGL(k_ntt_fwd4096<3>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn, 0, 0);
+  else hipLaunchKernelGGL(k_ntt_fwd4096<0>, g, b, 0, st, src, dst, psi, mc, (int)s.nm, s.logn, 0, 0);
   return hipGetLastError();
 }
 
@@ -890,10 +933,22 @@ hipError_t launch_inner_inv_fast_u64(const Shape &s, const DevTables &t, const u
   }
   const Tw64 *psi = (const Tw64 *)t.psi;
   const MC64 *mc = (const MC64 *)t.mc;
-  const dim3 g((unsigned)blocks), b(kThreads);
+  dim3 g((unsigned)blocks), b(kThreads);
+  int cm0 = 0, cmcnt = 0;
+  if (rows % s.nm == 0 && split_families(s, rows / s.nm)) {
+    const int ns = s.nm_small;
+    hipError_t e = mul ? hipErrorNotSupported : launch_asm_x2(kAsmInv2, s, t, dst, src, rows / s.nm, st, ns);
+    if (e == hipErrorNotSupported) e = launch_asm(mul ? kAsmInvMul : kAsmInv, s, t, dst, src, mul, rows / s.nm, st, ns);
+    if (e == hipSuccess) {
+      cm0 = ns, cmcnt = (int)s.nm - ns;
+      g = dim3((unsigned)(rows / s.nm * (size_t)cmcnt));
+    } else if (e != hipErrorNotSupported) {
+      return e;
+    }
+  }
 #define NFLHIP_INV(A)                                                                                                  \
-  if (mul) hipLaunchKernelGGL((k_ntt_inv4096<A, true>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);      \
-  else hipLaunchKernelGGL((k_ntt_inv4096<A, false>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn);
+  if (mul) hipLaunchKernelGGL((k_ntt_inv4096<A, true>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn, cm0, cmcnt);      \
+  else hipLaunchKernelGGL((k_ntt_inv4096<A, false>), g, b, 0, st, src, mul, dst, psi, mc, (int)s.nm, s.logn, cm0, cmcnt);
   if (s.small_delta) { NFLHIP_INV(2) }
   else { NFLHIP_INV(0) }
 #undef NFLHIP_INV

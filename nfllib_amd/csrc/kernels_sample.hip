@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t 
                                                        const uint64_t *__restrict__ cdt, int entries, long long x_min,
                                                        long long amp, ChaChaKey key, uint64_t nonce, int tie_shift,
                                                        const uint16_t *__restrict__ lut_g) {
-  extern __shared__ alignas(16) uint32_t gtop32[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t gtop32[];
   const uint16_t *lut = lut_g ? stage_gauss_top32(gtop32, cdt, lut_g, entries, W) : nullptr;
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 4;  // first_coef and ncoef are multiples of 16 (n >= 16)
@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(256) k_sample_gauss16(T *d, const ModConst<T> 
                                                         int tie_shift, const uint16_t *__restrict__ lut_g) {
   constexpr int S = kTS;
   __shared__ int xs[4][16 * S];
-  extern __shared__ alignas(16) uint32_t gtop32[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t gtop32[];
   const uint16_t *lut = lut_g ? stage_gauss_top32(gtop32, cdt, lut_g, entries, W) : nullptr;
   const uint64_t n = ((uint64_t)1) << logn;
   const size_t ngroups = ncoef >> 4;

@@ -10,6 +10,41 @@ if ROOT not in sys.path:
 SEED = 0x4E464C6C6962  # "NFLlib": the primary seed of SURVEY.md 8(d)
 
 
+def fuzz_seed():
+    """the seed of every randomised test (tests/cpp/deferred_fuzz, tests/test_gpu_fuzz.py): NFL_FUZZ_SEED when set, otherwise
+    derived from the tree under test (the commit hash where there is a .git, else a digest of the product sources: the GPU
+    box gets a snapshot without history) -- a new tree explores new programs, one tree always the same ones.  Failing tests
+    print it; NFL_FUZZ_SEED=<that> reproduces them."""
+    v = os.environ.get("NFL_FUZZ_SEED")
+    if v:
+        return int(v, 0) & 0x7FFFFFFF
+    import hashlib
+    import subprocess
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10)
+        if head.returncode == 0 and head.stdout.strip():
+            return int(head.stdout.strip()[:8], 16) & 0x7FFFFFFF
+    except Exception:
+        pass
+    h = hashlib.sha256()
+    for rel in ("include/nflhip.h", "nfllib_amd/csrc/api.hip", "nfllib_amd/csrc/kernels_fast.hip", "nfllib_amd/csrc/kernels_generic.hip"):
+        try:
+            h.update(open(os.path.join(ROOT, rel), "rb").read())
+        except OSError:
+            pass
+    for d in ("include/nfl_hip",):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            h.update(open(os.path.join(ROOT, d, f), "rb").read())
+    return int(h.hexdigest()[:8], 16) & 0x7FFFFFFF
+
+
+FUZZ_SEED = fuzz_seed()
+
+
+def pytest_report_header(config):
+    return "NFL_FUZZ_SEED=%d (randomised tests; set the variable to reproduce a run)" % FUZZ_SEED
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,9 +1,12 @@
-"""Shape / batch / operation fuzz of the C ABI against the oracle (derandomised hypothesis: the same examples every run).
+"""Shape / batch / operation fuzz of the C ABI against the oracle (hypothesis seeded with conftest.FUZZ_SEED: NFL_FUZZ_SEED, or a
+value derived from the tree under test -- the same examples for one tree, new ones for the next; printed in the pytest header).
 The parametrised parity tests pin the shapes of BASELINE.json; this one walks the space between them -- every limb width,
 degrees 4 .. 8192, 1 .. 32 moduli, ragged batches, random expression programs, aliasing of the destination."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, given, seed as hyp_seed, settings, strategies as st
+
+from conftest import FUZZ_SEED
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +30,8 @@ def _program(draw_ops, noperands):
     return prog
 
 
-@settings(max_examples=300, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=300, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+@hyp_seed(FUZZ_SEED)
 @given(shape=_shape, batch=st.integers(1, 7), seed=st.integers(0, 2**31), ops=st.lists(st.sampled_from([ADD, SUB, MUL]), min_size=1, max_size=6),
        alias=st.integers(0, 2))
 def test_random_shapes_and_operations(shape, batch, seed, ops, alias, oracle_factory, engine_factory):
@@ -65,7 +69,8 @@ def test_random_shapes_and_operations(shape, batch, seed, ops, alias, oracle_fac
         assert np.array_equal(e.to_host(e.crt_project(e.crt_lift(da))), a)
 
 
-@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=120, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+@hyp_seed(FUZZ_SEED)
 @given(shape=_shape, batch=st.integers(1, 6), first=st.integers(0, 1000), sid=st.integers(0, 2**64 - 1), ub=st.integers(1, 1 << 13),
        amp=st.integers(1, 4), rho=st.integers(0, 255), key=st.binary(min_size=32, max_size=32), sigma=st.sampled_from([2.0, 3.19, 20.0]),
        sec=st.sampled_from([20, 64, 100]))
@@ -109,7 +114,8 @@ _fused_shape = st.one_of(
 )
 
 
-@settings(max_examples=90, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=90, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+@hyp_seed(FUZZ_SEED)
 @given(shape=_fused_shape, batch=st.integers(1, 9), seed=st.integers(0, 2**31), fmt=st.sampled_from(["words", "i8", "i16", "i32"]),
        xs=st.integers(0, 1), es=st.integers(0, 1), ks=st.integers(0, 1), two=st.booleans(), alias=st.integers(0, 3), sub=st.booleans())
 def test_random_fused_pipeline_calls(shape, batch, seed, fmt, xs, es, ks, two, alias, sub, oracle_factory, engine_factory):
@@ -165,7 +171,8 @@ def test_random_fused_pipeline_calls(shape, batch, seed, fmt, xs, es, ks, two, a
     assert np.array_equal(e.to_host(e.fma_inv(ad, k0d, bd, subtract=sub, out=outi, batch=batch)), wanti)
 
 
-@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=60, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+@hyp_seed(FUZZ_SEED)
 @given(shape=_shape, batch=st.integers(1, 6), first=st.integers(0, 1000), sid=st.integers(0, 2**64 - 1), key=st.binary(min_size=32, max_size=32),
        sigma=st.sampled_from([2.0, 3.19, 20.0]), sec=st.sampled_from([20, 64, 100]), amp=st.integers(1, 3))
 def test_random_narrow_draw_calls(shape, batch, first, sid, key, sigma, sec, amp, engine_factory):

@@ -41,8 +41,10 @@ def run(exe, *args, env=None):
 
 
 def test_random_programs_deferred_equals_immediate(mock):
-    r = run(os.path.join(mock, "deferred_fuzz"), 60, 2024)
-    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+    from conftest import FUZZ_SEED
+    for seed in (2024, FUZZ_SEED):      # the historical seed as a regression run + the tree's own (conftest.fuzz_seed)
+        r = run(os.path.join(mock, "deferred_fuzz"), 60, seed)
+        assert r.returncode == 0 and "all checks passed" in r.stdout, "NFL_FUZZ_SEED=%d\n" % seed + r.stdout + r.stderr
 
 
 def test_the_archive_hook_writes_the_manual_image(mock):
