@@ -82,6 +82,10 @@
 #include <unordered_map>
 #include <utility>
 #include <vector>
+#if defined(__linux__)
+#include <sys/syscall.h>   // membarrier(2): the asymmetric barrier of detail::light_lock
+#include <unistd.h>
+#endif
 
 #include "../nflhip.h"
 #include "../nflhip_params.h"
@@ -290,18 +294,44 @@ inline unsigned strict_exempt(const unsigned char *code, size_t len) {
 // inside a process that has other threads at all (the HIP runtime's), where glibc's single-thread shortcuts are off.
 // Waiters spin, then yield, then sleep (a queue run may hold the lock for hundreds of microseconds).
 class light_lock {
+  // ---- the plain lock: what every thread but the bias holder takes (and every thread once the bias is gone)
   std::atomic<const void *> owner_;
   unsigned depth_;
+  // ---- the bias (round 6): the FIRST thread that takes this lock keeps a claim on it and from then on enters with two plain
+  // stores and two plain loads -- no locked instruction, no fence: 11 acquisitions per recorded LWE encryption were a sixth of
+  // the host's time.  Another thread that wants the lock takes the plain lock, raises revoke_, issues
+  // membarrier(PRIVATE_EXPEDITED) -- a full barrier on every running thread of the process, so the holder's "bias_depth_ = 1;
+  // load revoke_" cannot both slip past it -- and waits for bias_depth_ == 0; the holder, seeing revoke_, backs off and
+  // waits for it to clear.  After kMaxRevocations of these (a program that records from several threads) the bias is withdrawn for
+  // good and the lock is the plain one.  No membarrier in the kernel / sandbox (or NFL_HIP_NO_BIASED_LOCK set): never biased.
+  std::atomic<const void *> bias_owner_;
+  std::atomic<unsigned> bias_depth_;    // written by the bias holder only
+  std::atomic<unsigned> revoke_;        // 1 while a thread that holds the plain lock keeps the bias holder out
+  std::atomic<unsigned> revocations_;
+  bool revoking_;                       // (plain-lock holder's note: it raised revoke_ at its outermost acquisition)
+  enum { kMaxRevocations = 16 };
   static const void *me() {
     static thread_local char tag;
     return &tag;
   }
- public:
-  light_lock() : owner_(nullptr), depth_(0) {}
-  light_lock(const light_lock &) = delete;
-  light_lock &operator=(const light_lock &) = delete;
-  void lock() {
-    const void *self = me();
+  static const void *no_bias() {        // sentinel: the bias was withdrawn (or never available)
+    static char tag;
+    return &tag;
+  }
+  static bool asymmetric_barrier_available() {
+#if defined(__linux__) && defined(__NR_membarrier)
+    static const bool ok = !std::getenv("NFL_HIP_NO_BIASED_LOCK") && syscall(__NR_membarrier, 16 /* REGISTER_PRIVATE_EXPEDITED */, 0, 0) == 0;
+    return ok;
+#else
+    return false;
+#endif
+  }
+  static void barrier_all_threads() {
+#if defined(__linux__) && defined(__NR_membarrier)
+    if (syscall(__NR_membarrier, 8 /* PRIVATE_EXPEDITED */, 0, 0) != 0) std::abort();   // (registered above: cannot fail)
+#endif
+  }
+  void lock_plain(const void *self) {
     if (owner_.load(std::memory_order_relaxed) == self) {
       ++depth_;
       return;
@@ -313,9 +343,80 @@ class light_lock {
       else if (spins > 64) std::this_thread::yield();
     }
     depth_ = 1;
+    // outermost acquisition of the plain lock: keep a bias holder (another thread) out for as long as we hold it
+    const void *b = bias_owner_.load(std::memory_order_acquire);
+    revoking_ = false;
+    if (b != nullptr && b != no_bias() && b != self) {
+      revoke_.store(1, std::memory_order_seq_cst);
+      barrier_all_threads();
+      for (unsigned spins = 0; bias_depth_.load(std::memory_order_acquire) != 0; ++spins) {
+        if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else if (spins > 64) std::this_thread::yield();
+      }
+      revoking_ = true;
+      if (revocations_.fetch_add(1, std::memory_order_relaxed) + 1 >= kMaxRevocations)
+        bias_owner_.store(no_bias(), std::memory_order_release);   // (the holder is outside and kept out: it re-reads this when it retries)
+    }
+  }
+ public:
+  light_lock() : owner_(nullptr), depth_(0), bias_owner_(nullptr), bias_depth_(0), revoke_(0), revocations_(0), revoking_(false) {}
+  light_lock(const light_lock &) = delete;
+  light_lock &operator=(const light_lock &) = delete;
+  void lock() {
+    const void *self = me();
+    for (;;) {
+      const void *b = bias_owner_.load(std::memory_order_relaxed);
+      if (b == self) {
+        const unsigned d = bias_depth_.load(std::memory_order_relaxed);
+        if (d) {                                           // recursive acquisition by the holder
+          bias_depth_.store(d + 1, std::memory_order_relaxed);
+          return;
+        }
+        bias_depth_.store(1, std::memory_order_relaxed);
+        std::atomic_signal_fence(std::memory_order_seq_cst);   // compiler barrier; the revoker's membarrier is the hardware one
+        if (!revoke_.load(std::memory_order_acquire)) return;  // FAST PATH
+        bias_depth_.store(0, std::memory_order_release);       // somebody holds the plain lock and wants us out: wait, then retry
+        for (unsigned spins = 0; revoke_.load(std::memory_order_acquire) != 0; ++spins) {
+          if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
+          else if (spins > 64) std::this_thread::yield();
+        }
+        continue;
+      }
+      if (b == nullptr && asymmetric_barrier_available()) {   // nobody has the bias yet: the first thread claims it
+        const void *none = nullptr;
+        if (bias_owner_.compare_exchange_strong(none, self, std::memory_order_acq_rel)) {
+          // (a thread may be inside the plain lock right now -- it read bias_owner_ == nullptr before our claim: wait for it once)
+          for (unsigned spins = 0; owner_.load(std::memory_order_acquire) != nullptr; ++spins) {
+            if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            else if (spins > 64) std::this_thread::yield();
+          }
+        }
+        continue;
+      }
+      if (b == nullptr) {                                      // no asymmetric barrier on this system: plain lock for everybody
+        const void *none = nullptr;
+        bias_owner_.compare_exchange_strong(none, no_bias(), std::memory_order_acq_rel);
+        continue;
+      }
+      lock_plain(self);
+      return;
+    }
   }
   void unlock() {
-    if (--depth_ == 0) owner_.store(nullptr, std::memory_order_release);
+    if (bias_owner_.load(std::memory_order_relaxed) == me()) {
+      const unsigned d = bias_depth_.load(std::memory_order_relaxed);
+      if (d) {
+        bias_depth_.store(d - 1, std::memory_order_release);
+        return;
+      }
+    }
+    if (--depth_ == 0) {
+      if (revoking_) {
+        revoking_ = false;
+        revoke_.store(0, std::memory_order_release);
+      }
+      owner_.store(nullptr, std::memory_order_release);
+    }
   }
 };
 

@@ -422,7 +422,7 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   HIPCHK(nullptr, hipMalloc(&c->tabs.mc, mc.size() * sizeof(ModConst<T>)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.mc, mc.data(), mc.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
   c->tabs.mc_inc[0] = c->tabs.mc_inc[1] = nullptr;
-  if (sizeof(T) == 8 && n >= 4096 && !c->cyclic && (c->shape.small_delta || (n == 4096 && c->shape.nm_small > 0))) {
+  if (sizeof(T) == 8 && n >= 1024 && !c->cyclic && (c->shape.small_delta || (n == 4096 && c->shape.nm_small > 0))) {
     // the metric product on incomplete transforms (nflhip_polymul4096i{1,2}_asm): the inverse undoes 12 - level stages, so the
     // scale folded into its last stage is (n / 2^level)^-1; the base multiplication reduces sums below 2^127 with
     // floor(2^127 / p) = 2^65 + m, m < 2^35 (delta < 2^32), handed over in the mu2 field

@@ -213,6 +213,9 @@ hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, u
 // 32-bit limbs, n = 1024, fused product: the generated gfx950 assembly kernel (hipErrorNotSupported: use k_row)
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                                   const uint32_t *b, size_t batch, hipStream_t st);
+// 64-bit limbs, n = 1024 / 2048: the generated twins (modes 0, 2, 3; hipErrorNotSupported: use k_row)
+hipError_t launch_row1024_u64_asm(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
+                                  const uint64_t *b, size_t batch, hipStream_t st);
 // is not covered.  `work`: device memory of that many bytes, initialised by the call on `st`.
 size_t xcd_plan_bytes(const Shape &s, size_t batch);
 hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,

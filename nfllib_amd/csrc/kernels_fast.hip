@@ -369,6 +369,8 @@ enum AsmKind {
   kAsmPolymulI1, kAsmPolymulI2,                                      // the n = 4096 product on incomplete transforms (1 / 2 stages dropped, incomplete.py)
   kAsmPipe64kI2, kAsmXcd64kI2, kAsmXcd32kI2,                         // ... the long-row plans with their block products on incomplete transforms (level 2)
   kAsmPolymul8kI2, kAsmPolymul16kI2,                                 // ... the row-resident products (rows.py build_row16k level 2)
+  kAsmRow1024U64, kAsmRow2048U64, kAsmRow1024L0U64, kAsmRow2048L0U64,                                    // 64-bit limbs, one / two waves per row (rows1k.py):
+  kAsmRowFwd1024U64, kAsmRowFwd2048U64, kAsmRowInv1024U64, kAsmRowInv2048U64,                            //   product (incomplete / complete transforms), transforms
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return (k >= kAsmPolymul8k && k <= kAsmInv8k) || k == kAsmPolymul8kI2; }
@@ -398,6 +400,8 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul4096i1_asm", "nflhip_polymul4096i2_asm",
     "nflhip_polymul_pipe65536nti2_asm", "nflhip_polymul_xcd65536i2_asm", "nflhip_polymul_xcd32768i2_asm",
     "nflhip_polymul8192i2_asm", "nflhip_polymul16384i2_asm",
+    "nflhip_row1024_u64_asm", "nflhip_row2048_u64_asm", "nflhip_row1024_l0_u64_asm", "nflhip_row2048_l0_u64_asm",
+    "nflhip_row1024_fwd_u64_asm", "nflhip_row2048_fwd_u64_asm", "nflhip_row1024_inv_u64_asm", "nflhip_row2048_inv_u64_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -778,6 +782,32 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
     unsigned long long rows;
   } args = {c, a, b, t.psi, t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows};
   static_assert(sizeof(args) == 56, "kernarg layout of nflhip_row1024_u32_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
+}
+
+// 64-bit limbs, n = 1024 / 2048: the fused product (on incomplete transforms unless nflhip_debug_polymul_level says 0) and the
+// stand-alone transforms, one wave / two waves per row (tools/asmgen/rows1k.py); hipErrorNotSupported: the compiled k_row<Pol64, ...>
+hipError_t launch_row1024_u64_asm(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
+                                  const uint64_t *b, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn < 10 || s.logn > 11 || s.compiled_only || !s.small_delta || (mode != 0 && mode != 2 && mode != 3))
+    return hipErrorNotSupported;
+  const unsigned long long rows = (unsigned long long)batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;  // (row mod nm is one multiply in the kernel)
+  const bool inc = mode == 0 && g_polymul_level.load() == 2 && t.mc_inc[1];
+  const int first = mode == 0 ? (inc ? kAsmRow1024U64 : kAsmRow1024L0U64) : (mode == 2 ? kAsmRowFwd1024U64 : kAsmRowInv1024U64);
+  hipFunction_t fn = asm_fn((AsmKind)(first + (s.logn - 10)));
+  if (!fn) return hipErrorNotSupported;
+  const unsigned rpb = 4u >> (s.logn - 10);  // rows per 256-thread workgroup
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    unsigned nm, magic;
+    unsigned long long rows;
+  } args = {c, a, b, t.psi, inc ? t.mc_inc[1] : t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows};
+  static_assert(sizeof(args) == 56, "kernarg layout of nflhip_row1024_u64_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);

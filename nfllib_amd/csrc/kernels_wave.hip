@@ -675,6 +675,12 @@ hipError_t launch_inner_inv_fast_u32(const Shape &s, const DevTables &t, const u
 hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
                               const uint64_t *b, size_t batch, hipStream_t st) {
   if (s.limb_bits != 64 || !s.small_delta) return hipErrorNotSupported;
+  // the generated kernels of the fused product and the stand-alone transforms (tools/asmgen/rows1k.py; Shape::compiled_only = the
+  // compiled template below instead)
+  if (!s.compiled_only && (s.logn == 10 || s.logn == 11) && (mode == 0 || mode == 2 || mode == 3)) {
+    const hipError_t e = launch_row1024_u64_asm(s, t, mode, c, a, b, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (s.logn == 10) return launch_rows<Pol64, 4>(s, t, mode, c, a, b, batch, st);
   if (s.logn == 11) return launch_rows<Pol64, 8>(s, t, mode, c, a, b, batch, st);
   return hipErrorNotSupported;

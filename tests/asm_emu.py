@@ -1081,11 +1081,11 @@ def device_tables(limb_bits, n, nm, prm, lane_major=False, incomplete=0):
     return psi, mc
 
 
-def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magic):
+def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magic, incomplete=0):
     """a, b: (batch, nm, n) arrays -> the kernel's output array (same shape)"""
     import struct
     mem = Memory()
-    psi, mc = device_tables(limb_bits, n, nm, prm)
+    psi, mc = device_tables(limb_bits, n, nm, prm, incomplete=incomplete)
     c = np.zeros_like(a)
     pa, pb, pc, ppsi, pmc = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(psi), mem.add(mc)
     rows = a.shape[0] * nm

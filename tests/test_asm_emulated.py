@@ -139,6 +139,24 @@ def test_emulated_u64_row_products_on_incomplete_transforms(n, block_log, genera
     assert np.array_equal(got, o.polymul(a, b))
 
 
+@pytest.mark.parametrize("n,nm,batch", [(1024, 3, 3), (2048, 2, 2)])
+def test_emulated_u64_wave_per_row_kernels(n, nm, batch, generated, oracle_factory):
+    """tools/asmgen/rows1k.py: 64-bit rows of 1024 words (one wave per row, no workgroup barrier) and 2048 (two waves): the
+    product on incomplete transforms (level 2: at 1024 the third pass of either transform is gone), the product on complete
+    transforms, and the stand-alone transforms; odd row counts leave surplus waves / rows in the last workgroup"""
+    o = oracle_factory(64, n, nm)
+    prm, a, b = operands(o, 64, n, nm, batch, 26)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    a[batch - 1], b[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    rpw = 4096 // n
+    want = o.polymul(a, b)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row%d_u64" % n), 64, n, nm, prm, a, b, rpw, True, incomplete=2), want)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row%d_l0_u64" % n), 64, n, nm, prm, a, b, rpw, True), want)
+    fa = o.ntt(a)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row%d_fwd_u64" % n), 64, n, nm, prm, a, a, rpw, True), fa)
+    assert np.array_equal(asm_emu.run_row_kernel(generated("row%d_inv_u64" % n), 64, n, nm, prm, fa, fa, rpw, True), a)
+
+
 def test_barrett_step_of_the_base_multiplication_in_integers():
     """the reduction incomplete.py emits for sums T < 2^127 of products of folded words, restated on Python integers:
     th = T >> 63, q^ = 2 th + floor(th m / 2^64) with m = floor(2^127 / p) - 2^65, r = T - q^ p must lie in [0, 2^64) with

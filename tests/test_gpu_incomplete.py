@@ -111,3 +111,23 @@ def test_row_resident_products_on_incomplete_transforms(n, m, batch, level, orac
         da, db = e.to_device(a), e.to_device(b)
         assert np.array_equal(e.to_host(e.polymul(da, db)), want), "level %d" % lv
         assert np.array_equal(e.to_host(e.polymul(da, db, out=da)), want), "level %d in place" % lv
+
+
+@pytest.mark.parametrize("n,m,batch", [(1024, 2, 5), (1024, 1, 1), (2048, 3, 3), (2048, 2, 64), (1024, 30, 7)])
+def test_wave_per_row_u64_kernels(n, m, batch, level, oracle_factory, engine_factory, compiled_engine_factory):
+    """64-bit rows of 1024 / 2048 words on the generated kernels (tools/asmgen/rows1k.py): product at level 2 and 0, forward, inverse,
+    in place -- the oracle's words and the compiled template's (NFLHIP_VARIANT=hipcc contexts)"""
+    o, e, ec = oracle_factory(64, n, m), engine_factory(64, n, m), compiled_engine_factory(64, n, m)
+    a, b = o.fill_uniform(batch, SEED, 0), o.fill_uniform(batch, SEED, 1)
+    P = np.asarray(e.params.P[:m], dtype=np.uint64)
+    a[batch - 1], b[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    want = o.polymul(a, b)
+    for lv in (0, 2):
+        level(lv)
+        da, db = e.to_device(a), e.to_device(b)
+        assert np.array_equal(e.to_host(e.polymul(da, db)), want), "level %d" % lv
+        assert np.array_equal(e.to_host(e.polymul(da, db, out=da)), want), "level %d in place" % lv
+    assert np.array_equal(ec.to_host(ec.polymul(ec.to_device(a), ec.to_device(b))), want)
+    fa = e.to_host(e.ntt_(e.to_device(a)))
+    assert np.array_equal(fa, o.ntt(a)) and np.array_equal(fa, ec.to_host(ec.ntt_(ec.to_device(a))))
+    assert np.array_equal(e.to_host(e.intt_(e.to_device(fa))), a)

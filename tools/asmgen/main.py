@@ -4,6 +4,7 @@ import os
 from . import state as cfg
 from .block4096 import build
 from .incomplete import build_incomplete
+from .rows1k import ARGS_ROW, build_row1k
 from .fused import build_fused, build_fused_rows
 from .rows import build_row16k, build_row16k_loop
 from .rows32k import build_row32k
@@ -58,6 +59,12 @@ def main():
         emi = build_incomplete(level)
         emi.lines = nt(emi)
         emit_file(os.path.join(outdir, "polymul4096i%d_gfx950.s" % level), "nflhip_polymul4096i%d_asm" % level, emi)
+    # 64-bit rows of 1024 / 2048 words, one wave / two waves per row (rows1k.py, round 6): product on incomplete transforms,
+    # stand-alone transforms; "l0" = the product on complete transforms (the A/B partner and the cross-check)
+    for LB, words in ((4, 1024), (8, 2048)):
+        for mode, level, sfx in (("polymul", 2, ""), ("polymul", 0, "_l0"), ("fwd", 0, "_fwd"), ("inv", 0, "_inv")):
+            emit_file(os.path.join(outdir, "row%d%s_u64_gfx950.s" % (words, sfx)), "nflhip_row%d%s_u64_asm" % (words, sfx),
+                      build_row1k(LB, mode, level), args=ARGS_ROW)
     # transform-fused pipelines (n = 4096): word-row streams `nt`, key rows and compact inputs through the caches
     cfg.set(NEXT_SGPR=102)
     for kind, (stem, kname) in KERNELS_FUSED.items():

@@ -39,7 +39,8 @@ int main(int argc, char **argv) {
 #ifdef HOSTPROF_PCSAMPLE
   pcsample_start();
 #endif
-  for (int round = 0; round < 6; ++round) {
+  const int ROUNDS = getenv("HOSTPROF_ROUNDS") ? atoi(getenv("HOSTPROF_ROUNDS")) : 6;
+  for (int round = 0; round < ROUNDS; ++round) {
     auto t0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < REPS; i++) encrypt(resa[i], resb[i]);
     auto tr = std::chrono::steady_clock::now();
