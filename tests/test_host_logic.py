@@ -99,7 +99,7 @@ def test_the_harness_notices_a_broken_queue(mock, tmp_path):
     commute): proof that the mock keeps what the queue's correctness depends on"""
     inc = tmp_path / "include"
     shutil.copytree(os.path.join(ROOT, "include"), inc)
-    hdr = inc / "nfl_hip" / "nfl.hpp"
+    hdr = inc / "nfl_hip" / "queue.hpp"      # (the deferred queue's part of the split header)
     text = hdr.read_text()
     good = "L = std::max(L, std::max(o.out->wlev, o.out->rlev) + 1);"
     assert good in text
@@ -118,7 +118,7 @@ def test_the_harness_notices_a_broken_fusion(mock, tmp_path):
     for k, (old, new) in enumerate(good.items()):
         inc = tmp_path / ("include%d" % k)
         shutil.copytree(os.path.join(ROOT, "include"), inc)
-        hdr = inc / "nfl_hip" / "nfl.hpp"
+        hdr = inc / "nfl_hip" / "queue.hpp"      # (the deferred queue's part of the split header)
         text = hdr.read_text()
         assert old in text
         hdr.write_text(text.replace(old, new).replace("if (ux != 1 && ux != 2) continue;", "if (ux < 1) continue;") if k else text.replace(old, new))
@@ -135,7 +135,7 @@ def test_the_harness_notices_a_transform_joined_too_eagerly(mock, tmp_path):
     for k, (old, new) in enumerate(good.items()):
         inc = tmp_path / ("include%d" % k)
         shutil.copytree(os.path.join(ROOT, "include"), inc)
-        hdr = inc / "nfl_hip" / "nfl.hpp"
+        hdr = inc / "nfl_hip" / "queue.hpp"      # (the deferred queue's part of the split header)
         text = hdr.read_text()
         assert old in text
         hdr.write_text(text.replace(old, new))

@@ -69,7 +69,7 @@ def test_the_virtual_devices_notice_a_broken_split(tmp_path, good, bad):
     """mutants of the header must fail: proof that the CPU stand-in keeps what the split's correctness depends on"""
     inc = tmp_path / "include"
     shutil.copytree(os.path.join(ROOT, "include"), inc)
-    hdr = inc / "nfl_hip" / "nfl.hpp"
+    hdr = inc / "nfl_hip" / "batch.hpp"      # (nfl::sharded_batch lives in the batch part of the split header)
     text = hdr.read_text()
     assert good in text
     hdr.write_text(text.replace(good, bad))
