@@ -528,10 +528,7 @@ static int ensure_scratch(nflhip_ctx *ctx, size_t bytes) {
 #define NFLHIP_PIPE_CHUNKS 4
 #endif
 static constexpr int kPipeChunks = NFLHIP_PIPE_CHUNKS;
-#ifndef NFLHIP_PIPE_EDGE_DIV
-#define NFLHIP_PIPE_EDGE_DIV 0
-#endif
-static constexpr size_t kPipeEdgeDiv = NFLHIP_PIPE_EDGE_DIV;   // 0: uniform chunks
+
 
 // Rows of 65536 / 32768 words in ONE launch of persistent workgroups (kernels_fast.hip launch_polymul_xcd_u64) instead
 // of the chunked pipeline / the register-resident row kernels: by default for SMALL batches, where the other plans'
@@ -628,11 +625,10 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
 #include "ablation_knobs.inc"
 #endif
     if (nchunk * 2 > batch) nchunk = batch >= 2 ? batch / 2 : 1;
-    // chunk boundaries: uniform, except that the FIRST and the LAST chunk may be shorter (edge polynomials each): the first launch
-    // (forward role alone) and the last (inverse role alone) run one role against HBM with nothing to overlap, so what they carry is
-    // the pipeline's fill and drain -- kPipeEdgeDiv (measured, profiles/r06_E_edge_chunks.txt) sets edge = batch / kPipeEdgeDiv
+    // chunk boundaries: uniform.  (Round 6 tried SHORT first / last chunks -- the first launch runs the forward role alone and the last
+    // the inverse role alone, the pipeline's fill and drain -- through the experiment knob below: nothing beyond noise at batch 128,
+    // +0.8 % for eight chunks at batch 256: profiles/r06_E_edge_chunks.txt.)
     size_t edge = 0;
-    if (kPipeEdgeDiv > 0 && nchunk >= 4 && batch / kPipeEdgeDiv >= 1 && 2 * (batch / kPipeEdgeDiv) + (nchunk - 2) <= batch) edge = batch / kPipeEdgeDiv;
 #ifdef NFLHIP_ABLATION_KNOBS
     if (const char *ee = getenv("NFLHIP_PIPE_EDGE_RT")) {
       edge = (size_t)atoi(ee);

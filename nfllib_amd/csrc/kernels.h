@@ -213,6 +213,12 @@ hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, u
 // 32-bit limbs, n = 1024, fused product: the generated gfx950 assembly kernel (hipErrorNotSupported: use k_row)
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                                   const uint32_t *b, size_t batch, hipStream_t st);
+// ... their transform-fused pipelines (formats words / int8, strides 0 / 1; hipErrorNotSupported: the compiled kernels)
+hipError_t launch_row_fwd_fma_u64_asm(const Shape &s, const DevTables &t, int format, uint64_t *out0, uint64_t *out1, const void *x, unsigned xs,
+                                      const uint64_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint64_t *k1, unsigned k1s,
+                                      const void *e1, unsigned e1s, size_t batch, hipStream_t st);
+hipError_t launch_row_fma_inv_u64_asm(const Shape &s, const DevTables &t, int subtract, uint64_t *c, const uint64_t *a, const uint64_t *key,
+                                      int kstride, const uint64_t *b, size_t batch, hipStream_t st);
 // 64-bit limbs, n = 1024 / 2048: the generated twins (modes 0, 2, 3; hipErrorNotSupported: use k_row)
 hipError_t launch_row1024_u64_asm(const Shape &s, const DevTables &t, int mode, uint64_t *c, const uint64_t *a,
                                   const uint64_t *b, size_t batch, hipStream_t st);

@@ -371,6 +371,9 @@ enum AsmKind {
   kAsmPolymul8kI2, kAsmPolymul16kI2,                                 // ... the row-resident products (rows.py build_row16k level 2)
   kAsmRow1024U64, kAsmRow2048U64, kAsmRow1024L0U64, kAsmRow2048L0U64,                                    // 64-bit limbs, one / two waves per row (rows1k.py):
   kAsmRowFwd1024U64, kAsmRowFwd2048U64, kAsmRowInv1024U64, kAsmRowInv2048U64,                            //   product (incomplete / complete transforms), transforms
+  kAsmRowFmsInv1024U64, kAsmRowFmsInv2048U64, kAsmRowFmaInv1024U64, kAsmRowFmaInv2048U64,                //   INTT(b -+ a k)
+  kAsmRowEnc2W1024U64, kAsmRowEnc2W2048U64, kAsmRowEnc2I81024U64, kAsmRowEnc2I82048U64,                  //   NTT(x) k + NTT(e), two results; words / int8 inputs
+  kAsmRowFmaFwdW1024U64, kAsmRowFmaFwdW2048U64, kAsmRowFmaFwdI81024U64, kAsmRowFmaFwdI82048U64,          //   ... one result
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return (k >= kAsmPolymul8k && k <= kAsmInv8k) || k == kAsmPolymul8kI2; }
@@ -402,6 +405,9 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul8192i2_asm", "nflhip_polymul16384i2_asm",
     "nflhip_row1024_u64_asm", "nflhip_row2048_u64_asm", "nflhip_row1024_l0_u64_asm", "nflhip_row2048_l0_u64_asm",
     "nflhip_row1024_fwd_u64_asm", "nflhip_row2048_fwd_u64_asm", "nflhip_row1024_inv_u64_asm", "nflhip_row2048_inv_u64_asm",
+    "nflhip_row1024_fmsinv_u64_asm", "nflhip_row2048_fmsinv_u64_asm", "nflhip_row1024_fmainv_u64_asm", "nflhip_row2048_fmainv_u64_asm",
+    "nflhip_row1024_enc2w_u64_asm", "nflhip_row2048_enc2w_u64_asm", "nflhip_row1024_enc2i8_u64_asm", "nflhip_row2048_enc2i8_u64_asm",
+    "nflhip_row1024_fmafwdw_u64_asm", "nflhip_row2048_fmafwdw_u64_asm", "nflhip_row1024_fmafwdi8_u64_asm", "nflhip_row2048_fmafwdi8_u64_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -808,6 +814,57 @@ hipError_t launch_row1024_u64_asm(const Shape &s, const DevTables &t, int mode, 
     unsigned long long rows;
   } args = {c, a, b, t.psi, inc ? t.mc_inc[1] : t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows};
   static_assert(sizeof(args) == 56, "kernarg layout of nflhip_row1024_u64_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
+}
+
+// ... and the transform-fused pipelines on those rows (rows1k.py build_row1k_fwd_fma / build_row1k_fma_inv): operands of format words
+// or int8, strides 0 / 1; hipErrorNotSupported: the compiled k_row_fwd_fma / k_row_fma_inv (kernels_wave.hip)
+hipError_t launch_row_fwd_fma_u64_asm(const Shape &s, const DevTables &t, int format, uint64_t *out0, uint64_t *out1, const void *x, unsigned xs,
+                                      const uint64_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint64_t *k1, unsigned k1s,
+                                      const void *e1, unsigned e1s, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn < 10 || s.logn > 11 || s.compiled_only || !s.small_delta || (format != 0 && format != 1)) return hipErrorNotSupported;
+  if (xs > 1 || k0s > 1 || e0s > 1 || (out1 && (k1s > 1 || e1s > 1))) return hipErrorNotSupported;
+  const unsigned long long rows = (unsigned long long)batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;
+  const int first = out1 ? (format == 0 ? kAsmRowEnc2W1024U64 : kAsmRowEnc2I81024U64) : (format == 0 ? kAsmRowFmaFwdW1024U64 : kAsmRowFmaFwdI81024U64);
+  hipFunction_t fn = asm_fn((AsmKind)(first + (s.logn - 10)));
+  if (!fn) return hipErrorNotSupported;
+  const unsigned rpb = 4u >> (s.logn - 10);
+  struct {
+    void *out0, *out1;
+    const void *x, *psi, *mc;
+    unsigned nm, magic;
+    const void *k0, *e0, *k1, *e1;
+    unsigned long long rows;
+    unsigned xs, k0s, e0s, k1s, e1s, pad;
+  } args = {out0, out1, x, t.psi, t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), k0, e0, out1 ? k1 : k0, out1 ? e1 : e0,
+            rows, xs, k0s, e0s, out1 ? k1s : 0u, out1 ? e1s : 0u, 0u};
+  static_assert(sizeof(args) == 112, "kernarg layout of nflhip_row*_enc2*_u64_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
+}
+hipError_t launch_row_fma_inv_u64_asm(const Shape &s, const DevTables &t, int subtract, uint64_t *c, const uint64_t *a, const uint64_t *key,
+                                      int kstride, const uint64_t *b, size_t batch, hipStream_t st) {
+  if (s.limb_bits != 64 || s.logn < 10 || s.logn > 11 || s.compiled_only || !s.small_delta || kstride < 0 || kstride > 1) return hipErrorNotSupported;
+  const unsigned long long rows = (unsigned long long)batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;
+  hipFunction_t fn = asm_fn((AsmKind)((subtract ? kAsmRowFmsInv1024U64 : kAsmRowFmaInv1024U64) + (s.logn - 10)));
+  if (!fn) return hipErrorNotSupported;
+  const unsigned rpb = 4u >> (s.logn - 10);
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    unsigned nm, magic;
+    unsigned long long rows;
+    const void *key;
+    unsigned kstride, pad;
+  } args = {c, a, b, t.psi, t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows, key, (unsigned)kstride, 0u};
+  static_assert(sizeof(args) == 72, "kernarg layout of nflhip_row*_fm?inv_u64_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);

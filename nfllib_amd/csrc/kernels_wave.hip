@@ -555,6 +555,10 @@ hipError_t launch_row_fwd_fma_u64(const Shape &s, const DevTables &t, int format
                                   const uint64_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint64_t *k1, unsigned k1s, const void *e1,
                                   unsigned e1s, size_t batch, hipStream_t st) {
   if (s.limb_bits != 64 || !s.small_delta) return hipErrorNotSupported;
+  {  // the generated kernels (tools/asmgen/rows1k.py) where they cover the call
+    const hipError_t e = launch_row_fwd_fma_u64_asm(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (s.logn == 10) return launch_fwd_fma_rows<Pol64, 4>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
   if (s.logn == 11) return launch_fwd_fma_rows<Pol64, 8>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
   return hipErrorNotSupported;
@@ -586,6 +590,10 @@ hipError_t launch_row_fma_inv_u32(const Shape &s, const DevTables &t, int subtra
 hipError_t launch_row_fma_inv_u64(const Shape &s, const DevTables &t, int subtract, uint64_t *c, const uint64_t *a, const uint64_t *key,
                                   int kstride, const uint64_t *b, size_t batch, hipStream_t st) {
   if (s.limb_bits != 64 || !s.small_delta) return hipErrorNotSupported;
+  {
+    const hipError_t e = launch_row_fma_inv_u64_asm(s, t, subtract, c, a, key, kstride, b, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (s.logn == 10) return launch_fma_inv_rows<Pol64, 4>(s, t, subtract, c, a, key, kstride, b, batch, st);
   if (s.logn == 11) return launch_fma_inv_rows<Pol64, 8>(s, t, subtract, c, a, key, kstride, b, batch, st);
   return hipErrorNotSupported;

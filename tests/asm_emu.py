@@ -739,6 +739,16 @@ def _(w, ops, mods):
     w.wr64(ops[0], (w.rd64(ops[1]) << (w.rd32(ops[2]) & U(63))) + w.rd64(ops[3]))
 
 
+@op("v_bfe_i32")
+def _(w, ops, mods):
+    x = np.asarray(w.rd32(ops[1]), dtype=np.uint64).astype(np.int64)
+    off = np.asarray(w.rd32(ops[2]), dtype=np.uint64).astype(np.int64) & 31
+    width = int(np.asarray(w.rd32(ops[3]), dtype=np.uint64).reshape(-1)[0]) & 31
+    f = (x >> off) & ((1 << width) - 1)
+    f = np.where(f >> (width - 1), f - (1 << width), f) if width else f * 0
+    w.wr32(ops[0], (f & M32).astype(np.uint64) + np.zeros(64, dtype=np.uint64))
+
+
 @op("v_alignbit_b32")
 def _(w, ops, mods):
     w.wr32(ops[0], ((w.rd32(ops[1]) << U(32)) | w.rd32(ops[2])) >> (w.rd32(ops[3]) & U(31)))
@@ -1097,6 +1107,50 @@ def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magi
     run_kernel(text, mem, kernarg, (rows + rows_per_wg - 1) // rows_per_wg, lds)
     out, _ = mem.find(pc, c.nbytes)
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
+
+
+def run_row_fused(asm_path, n, nm, prm, rows_per_wg, kind, **kw):
+    """the transform-fused wave-per-row kernels of tools/asmgen/rows1k.py (64-bit limbs, rows of 1024 / 2048 words).
+    kind "inv": c = INTT(b -+ a k): kw a, b (batch, nm, n) words, key (1 or batch, nm, n) -> c
+    kind "fwd": out0 = NTT(x) k0 + NTT(e0) [, out1 = NTT(x) k1 + NTT(e1)]: kw x, e0[, e1]: (B, nm, n) words or (B, n) int8 with B = 1
+    (shared by the batch) or batch; k0[, k1] (1 or batch, nm, n) -> out0[, out1]"""
+    import struct
+    mem = Memory()
+    psi, mc = device_tables(64, n, nm, prm)
+    ppsi, pmc = mem.add(psi), mem.add(mc)
+    magic = lambda: 0 if nm == 1 else ((1 << 32) // nm + 1)
+    with open(asm_path) as f:
+        text = f.read()
+    lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", text).group(1))
+    if kind == "inv":
+        a, b, key = kw["a"], kw["b"], kw["key"]
+        batch = a.shape[0]
+        rows = batch * nm
+        c = np.zeros_like(a)
+        pa, pb, pc, pk = mem.add(a.copy()), mem.add(b.copy()), mem.add(c), mem.add(key.copy())
+        kernarg = struct.pack("<5Q2IQQ2I", pc, pa, pb, ppsi, pmc, nm, magic(), rows, pk, 0 if key.shape[0] == 1 else 1, 0)
+        run_kernel(text, mem, kernarg, (rows + rows_per_wg - 1) // rows_per_wg, lds)
+        out, _ = mem.find(pc, c.nbytes)
+        return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
+    x, e0, k0 = kw["x"], kw["e0"], kw["k0"]
+    e1, k1 = kw.get("e1"), kw.get("k1")
+    batch = kw["batch"]
+    rows = batch * nm
+    o0 = np.zeros((batch, nm, n), dtype=np.uint64)
+    o1 = np.zeros_like(o0)
+    stride = lambda arr: 0 if arr.shape[0] == 1 and batch > 1 else 1
+    px, pe0, pk0, po0, po1 = mem.add(x.copy()), mem.add(e0.copy()), mem.add(k0.copy()), mem.add(o0), mem.add(o1)
+    pe1 = mem.add(e1.copy()) if e1 is not None else pe0
+    pk1 = mem.add(k1.copy()) if k1 is not None else pk0
+    kernarg = struct.pack("<5Q2I4QQ5I", po0, po1, px, ppsi, pmc, nm, magic(), pk0, pe0, pk1, pe1, rows, stride(x), stride(k0), stride(e0),
+                          stride(k1) if k1 is not None else 0, stride(e1) if e1 is not None else 0)
+    kernarg += b"\0" * (112 - len(kernarg))
+    run_kernel(text, mem, kernarg, (rows + rows_per_wg - 1) // rows_per_wg, lds)
+    res = []
+    for ptr, arr in ((po0, o0), (po1, o1))[:2 if k1 is not None else 1]:
+        buf, _ = mem.find(ptr, arr.nbytes)
+        res.append(buf[:arr.nbytes].view(np.uint64).reshape(arr.shape).copy())
+    return res
 
 
 def run_block_kernel(asm_path, n, nm, prm, a, b, block_log, count=None, words_per_thread=16, grid_x=None, key=None, compact=None,

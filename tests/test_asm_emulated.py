@@ -157,6 +157,47 @@ def test_emulated_u64_wave_per_row_kernels(n, nm, batch, generated, oracle_facto
     assert np.array_equal(asm_emu.run_row_kernel(generated("row%d_inv_u64" % n), 64, n, nm, prm, fa, fa, rpw, True), a)
 
 
+@pytest.mark.parametrize("n,nm,batch", [(1024, 3, 3), (2048, 2, 2)])
+def test_emulated_u64_wave_per_row_fused_pipelines(n, nm, batch, generated, oracle_factory):
+    """tools/asmgen/rows1k.py build_row1k_fwd_fma / build_row1k_fma_inv: out0 = NTT(x) k0 + NTT(e0) [, out1 = NTT(x) k1 + NTT(e1)] with
+    word and int8 operands, shared (stride 0) and dense keys / x, and INTT(b -+ a k) -- against the operator-by-operator oracle"""
+    ADD, SUB, MUL = 0, 1, 2
+    o = oracle_factory(64, n, nm)
+    from nfllib_amd.params import params
+    prm = params(64)
+    rng = np.random.default_rng(31)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    rnd = lambda B: (rng.integers(0, 1 << 62, size=(B, nm, n), dtype=np.uint64) % P[None, :, None])
+    small = lambda B: rng.integers(-128, 128, size=(B, n)).astype(np.int8)
+    expand = lambda v: np.where(v.astype(np.int64)[:, None, :] < 0, P.astype(np.int64)[None, :, None] + v.astype(np.int64)[:, None, :],
+                                v.astype(np.int64)[:, None, :]).astype(np.uint64)
+    rpw = 4096 // n
+    a, b = rnd(batch), rnd(batch)
+    for key in (rnd(1), rnd(batch)):
+        kk = np.broadcast_to(key, (batch, nm, n)).copy()
+        for sub, stem in ((True, "fmsinv"), (False, "fmainv")):
+            want = o.intt(o.pointwise(SUB if sub else ADD, b, o.pointwise(MUL, a, kk)))
+            got = asm_emu.run_row_fused(generated("row%d_%s_u64" % (n, stem)), n, nm, prm, rpw, "inv", a=a, b=b, key=key)
+            assert np.array_equal(got, want), (stem, key.shape)
+    for fmt in ("w", "i8"):
+        for two, xb in ((True, 1), (False, batch)):
+            if fmt == "w":
+                x, e0, e1 = rnd(xb), rnd(batch), rnd(batch)
+                X, E0, E1 = x, e0, e1
+            else:
+                x, e0, e1 = small(xb), small(batch), small(batch)
+                X, E0, E1 = expand(x), expand(e0), expand(e1)
+            Xb = np.broadcast_to(X, (batch, nm, n)).copy()
+            k0, k1 = rnd(1), rnd(batch)
+            K0 = np.broadcast_to(k0, (batch, nm, n)).copy()
+            w0 = o.pointwise(ADD, o.pointwise(MUL, o.ntt(Xb), K0), o.ntt(E0))
+            w1 = o.pointwise(ADD, o.pointwise(MUL, o.ntt(Xb), k1), o.ntt(E1))
+            stem = ("enc2" if two else "fmafwd") + fmt
+            r = asm_emu.run_row_fused(generated("row%d_%s_u64" % (n, stem)), n, nm, prm, rpw, "fwd", x=x, e0=e0, k0=k0,
+                                      e1=e1 if two else None, k1=k1 if two else None, batch=batch)
+            assert np.array_equal(r[0], w0) and (not two or np.array_equal(r[1], w1)), stem
+
+
 def test_barrett_step_of_the_base_multiplication_in_integers():
     """the reduction incomplete.py emits for sums T < 2^127 of products of folded words, restated on Python integers:
     th = T >> 63, q^ = 2 th + floor(th m / 2^64) with m = floor(2^127 / p) - 2^65, r = T - q^ p must lie in [0, 2^64) with

@@ -4,7 +4,7 @@ import os
 from . import state as cfg
 from .block4096 import build
 from .incomplete import build_incomplete
-from .rows1k import ARGS_ROW, build_row1k
+from .rows1k import ARGS_ROW, ARGS_ROW_FWD, ARGS_ROW_INV, build_row1k, build_row1k_fma_inv, build_row1k_fwd_fma
 from .fused import build_fused, build_fused_rows
 from .rows import build_row16k, build_row16k_loop
 from .rows32k import build_row32k
@@ -65,6 +65,17 @@ def main():
         for mode, level, sfx in (("polymul", 2, ""), ("polymul", 0, "_l0"), ("fwd", 0, "_fwd"), ("inv", 0, "_inv")):
             emit_file(os.path.join(outdir, "row%d%s_u64_gfx950.s" % (words, sfx)), "nflhip_row%d%s_u64_asm" % (words, sfx),
                       build_row1k(LB, mode, level), args=ARGS_ROW)
+    # ... and the transform-fused pipelines on those rows (the LWE demo's bodies, one wave(s) per row)
+    cfg.set(NEXT_SGPR=102)
+    for LB, words in ((4, 1024), (8, 2048)):
+        for sub, nm_ in ((True, "fmsinv"), (False, "fmainv")):
+            emit_file(os.path.join(outdir, "row%d_%s_u64_gfx950.s" % (words, nm_)), "nflhip_row%d_%s_u64_asm" % (words, nm_),
+                      build_row1k_fma_inv(LB, sub), args=ARGS_ROW_INV)
+        for two, nm_ in ((True, "enc2"), (False, "fmafwd")):
+            for fmt in ("w", "i8"):
+                emit_file(os.path.join(outdir, "row%d_%s%s_u64_gfx950.s" % (words, nm_, fmt)), "nflhip_row%d_%s%s_u64_asm" % (words, nm_, fmt),
+                          build_row1k_fwd_fma(LB, two, fmt), args=ARGS_ROW_FWD)
+    cfg.set(NEXT_SGPR=96)
     # transform-fused pipelines (n = 4096): word-row streams `nt`, key rows and compact inputs through the caches
     cfg.set(NEXT_SGPR=102)
     for kind, (stem, kname) in KERNELS_FUSED.items():
