@@ -66,21 +66,24 @@ def block(stem, n, block_log, workload, nm_w, incomplete=0):
                                                                 incomplete=incomplete), 1)
 
 
-def row(stem, bits, n, rows_per_wg, magic, workload, nm_w, batch):
+def row(stem, bits, n, rows_per_wg, magic, workload, nm_w, batch, incomplete=0):
     prm, a = operands(bits, n, 1, batch)
-    case(stem, workload, nm_w, lambda: asm_emu.run_row_kernel(os.path.join(CSRC, stem + "_gfx950.s"), bits, n, 1, prm, a, a, rows_per_wg, magic), batch)
+    case(stem, workload, nm_w, lambda: asm_emu.run_row_kernel(os.path.join(CSRC, stem + "_gfx950.s"), bits, n, 1, prm, a, a, rows_per_wg, magic,
+                                                              incomplete=incomplete), batch)
 
 
-def pipe(stem, n, workload, nm_w):
+def pipe(stem, n, workload, nm_w, incomplete=0):
     prm, a = operands(64, n, 1, 1)
-    case(stem, workload, nm_w, lambda: asm_emu.run_pipe_product(os.path.join(CSRC, stem + "_gfx950.s"), n, 1, prm, a, a), 1)
+    case(stem, workload, nm_w, lambda: asm_emu.run_pipe_product(os.path.join(CSRC, stem + "_gfx950.s"), n, 1, prm, a, a, incomplete=incomplete), 1)
 
 
 block("polymul4096nt", 4096, 12, "B", 4)
 block("polymul4096i1", 4096, 12, "B", 4, incomplete=1)   # round 6: 1 / 2 stages dropped each way, base multiplication mod X^2 / X^4 -+ zeta
 block("polymul4096i2", 4096, 12, "B", 4, incomplete=2)
 block("polymul8192", 8192, 13, "G", 2)
+block("polymul8192i2", 8192, 13, "G", 2, incomplete=2)
 block("polymul16384", 16384, 14, "C", 8)
+block("polymul16384i2", 16384, 14, "C", 8, incomplete=2)
 def rows32k(workload, nm_w):   # b' = NTT(b), then c = INTT(NTT(a) (.) b'): the two register-resident row kernels of n = 32768
     prm, a = operands(64, 32768, 1, 1)
     k = lambda stem: asm_emu.run_block_kernel(os.path.join(CSRC, stem + "_gfx950.s"), 32768, 1, prm, a, a, 15, words_per_thread=32)
@@ -89,7 +92,12 @@ def rows32k(workload, nm_w):   # b' = NTT(b), then c = INTT(NTT(a) (.) b'): the 
 
 rows32k("F", 2)
 pipe("polymul_pipe65536nt", 65536, "E", 30)
+pipe("polymul_pipe65536nti2", 65536, "E", 30, incomplete=2)
 row("row1024_u32", 32, 1024, 4, True, "A", 1, 4)
+row("row1024_l0_u64", 64, 1024, 4, True, "-", 2, 4)                   # round 6: 64-bit rows of 1024 / 2048 words, one / two waves per row
+row("row1024_u64", 64, 1024, 4, True, "-", 2, 4, incomplete=2)
+row("row2048_l0_u64", 64, 2048, 2, True, "-", 2, 2)
+row("row2048_u64", 64, 2048, 2, True, "-", 2, 2, incomplete=2)
 row("row128_u16", 16, 128, 32, False, "H", 1, 32)
 row("row8_u32", 32, 8, 256, True, "T", 2, 256)
 
