@@ -871,12 +871,13 @@ def main():
                    "checksum_of_checksums": checksum, "rccl": rccl},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096nt_asm", "C": "nflhip_polymul16384_asm",
-                                "E": "nflhip_polymul_pipe65536nt_asm (block products + streaming passes, 6 launches per step)",
+                     "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096i2_asm (2 stages dropped each way, base multiplication mod X^4 -+ zeta)",
+                                "C": "nflhip_polymul16384i2_asm",
+                                "E": "nflhip_polymul_pipe65536nti2_asm (block products on incomplete transforms + streaming passes, 6 launches per step)",
                                 "F": "nflhip_ntt_fwd32768s_asm (b -> scratch, layout [block][pair][thread]) + nflhip_polymul_ntt32768s_asm (a, b' streamed): "
                                      "register-resident 32768-word rows, 2 launches per step" if batch * nm >= 256 else
                                      "nflhip_polymul_xcd32768_asm (one launch of persistent workgroups; fewer than 256 rows)",
-                                "G": "nflhip_polymul8192_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
+                                "G": "nflhip_polymul8192i2_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},
     }
     # what actually binds the metric kernel: not HBM -- `bound` / `frac` above stay as SURVEY.md 8(d)
@@ -902,9 +903,9 @@ def main():
     # a consistency check of the instruction counts.
     # Instructions per product: dynamic counts of the generated kernels on the interpreter of tests/asm_emu.py
     # (tools/asm_cost.py -> profiles/r03_valu_issue_model.txt; B and A agree with their SQ counter passes).
-    model = "profiles/r03_valu_issue_model.txt"
-    valu = {"B": (96464, 1), "A": (2081, nm), "G": (103856, 1), "C": (888192, 1), "F": (478144, 1),
-            "E": (15115680, 1), "H": (227, 1), "T": (13, 1)}.get(kwl)
+    model = "profiles/r06_valu_issue_model.txt"
+    valu = {"B": (90064, 1), "A": (2081, nm), "G": (97312, 1), "C": (835840, 1), "F": (477248, 1),
+            "E": (14347680, 1), "H": (227, 1), "T": (13, 1)}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]
         nominal_ghz = 2.4

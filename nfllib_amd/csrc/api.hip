@@ -621,20 +621,15 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     // pipeline: launch L = forward pass of chunk L, block products of chunk L-1, inverse pass of chunk L-2.
     const size_t pw = ctx->shape.nm * ctx->shape.n;
     size_t nchunk = (size_t)kPipeChunks;
-#ifdef NFLHIP_ABLATION_KNOBS   // experiment builds only (tools/sessions/gpu_round5_a.sh): chunk count at run time, chunk aliasing
+    size_t edge = 0;   // polynomials in the first and in the last chunk when they are shorter than the others (experiment knob only)
+#ifdef NFLHIP_ABLATION_KNOBS   // experiment builds only (tools/sessions/gpu_round5_a.sh, gpu_round6_g.sh): chunk count / edge chunks at run time, chunk aliasing
 #include "ablation_knobs.inc"
 #endif
     if (nchunk * 2 > batch) nchunk = batch >= 2 ? batch / 2 : 1;
     // chunk boundaries: uniform.  (Round 6 tried SHORT first / last chunks -- the first launch runs the forward role alone and the last
     // the inverse role alone, the pipeline's fill and drain -- through the experiment knob below: nothing beyond noise at batch 128,
     // +0.8 % for eight chunks at batch 256: profiles/r06_E_edge_chunks.txt.)
-    size_t edge = 0;
-#ifdef NFLHIP_ABLATION_KNOBS
-    if (const char *ee = getenv("NFLHIP_PIPE_EDGE_RT")) {
-      edge = (size_t)atoi(ee);
-      if (nchunk < 3 || 2 * edge + (nchunk - 2) > batch) edge = 0;
-    }
-#endif
+    if (nchunk < 3 || 2 * edge + (nchunk - 2) > batch) edge = 0;
     auto lo_of = [&](size_t ch) -> size_t {
       if (!edge) return batch * ch / nchunk;
       if (ch == 0) return 0;

@@ -198,6 +198,68 @@ def test_emulated_u64_wave_per_row_fused_pipelines(n, nm, batch, generated, orac
             assert np.array_equal(r[0], w0) and (not two or np.array_equal(r[1], w1)), stem
 
 
+@pytest.mark.parametrize("level", [1, 2])
+def test_incomplete_transform_algebra_in_integers(level):
+    """what tools/asmgen/incomplete.py relies on, on Python integers at n = 64: after S = log2(n) - level stages of the merged
+    Cooley-Tukey network over psi_br[k] = phi^bitrev(k), group g of 2^level consecutive words is the residue modulo
+    X^(2^level) - zeta_g with zeta_g = +psi_br[2^(S-1) + g / 2] for even g and its negative for odd g; multiplying residues group by
+    group and running the mirrored inverse over S stages (scale 2^-S) gives the negacyclic product"""
+    import random
+    from nfllib_amd.params import params
+    prm = params(64)
+    n, logn = 64, 6
+    p, phi = int(prm.P[0]), int(prm.primitive_roots[0])
+    for _ in range(prm.kmax_log2 - logn):
+        phi = phi * phi % p
+    br = lambda k: int(format(k, "0%db" % logn)[::-1], 2)
+    psi = [pow(phi, br(k), p) for k in range(n)]
+
+    def fwd(a, stages):
+        a, t, m = a[:], n, 1
+        for _ in range(stages):
+            t //= 2
+            for i in range(m):
+                for j in range(i * 2 * t, i * 2 * t + t):
+                    u, v = a[j], a[j + t] * psi[m + i] % p
+                    a[j], a[j + t] = (u + v) % p, (u - v) % p
+            m *= 2
+        return a
+
+    def inv(a, stages):
+        a, m, t = a[:], 1 << stages, n >> stages
+        for _ in range(stages):
+            m //= 2
+            for i in range(m):
+                w = pow(psi[m + i], p - 2, p)
+                for j in range(i * 2 * t, i * 2 * t + t):
+                    u, v = a[j], a[j + t]
+                    a[j], a[j + t] = (u + v) % p, (u - v) * w % p
+            t *= 2
+        sc = pow(1 << stages, p - 2, p)
+        return [x * sc % p for x in a]
+
+    rnd = random.Random(3)
+    a, b = [rnd.randrange(p) for _ in range(n)], [rnd.randrange(p) for _ in range(n)]
+    want = [0] * n
+    for i in range(n):
+        for j in range(n):
+            k = i + j
+            if k < n:
+                want[k] = (want[k] + a[i] * b[j]) % p
+            else:
+                want[k - n] = (want[k - n] - a[i] * b[j]) % p
+    S, G = logn - level, 1 << level
+    fa, fb, out = fwd(a, S), fwd(b, S), [0] * n
+    for g in range(n // G):
+        w = psi[(1 << (S - 1)) + g // 2]
+        zeta = w if g % 2 == 0 else p - w
+        A, B = fa[g * G:(g + 1) * G], fb[g * G:(g + 1) * G]
+        for k in range(G):
+            acc = sum(A[i] * B[k - i] for i in range(k + 1)) + zeta * sum(A[i] * B[k + G - i] for i in range(k + 1, G))
+            out[g * G + k] = acc % p
+    assert inv(out, S) == want
+
+
 def test_barrett_step_of_the_base_multiplication_in_integers():
     """the reduction incomplete.py emits for sums T < 2^127 of products of folded words, restated on Python integers:
     th = T >> 63, q^ = 2 th + floor(th m / 2^64) with m = floor(2^127 / p) - 2^65, r = T - q^ p must lie in [0, 2^64) with

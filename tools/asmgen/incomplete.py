@@ -4,7 +4,8 @@ late.  Coefficient form in and out, so the result is bit-identical to the comple
 
 After global stage S - 1 (S = 12 - L) thread q holds, in register pairs G g .. G g + G - 1 (G = 2^L), the residue of its
 operand modulo X^G - zeta_g, coefficients in natural order, with zeta_g = +w for even g and -w for odd g, w = the twiddle
-of the last retained stage that produced the pair of groups (tests: the same algebra in Python, /tests/test_asm_emulated.py).
+of the last retained stage that produced the pair of groups (the same algebra on Python integers:
+tests/test_asm_emulated.py::test_incomplete_transform_algebra_in_integers).
 Base multiplication, per group (c_k = sum_{i+j=k} a_i b_j + zeta sum_{i+j=k+G} a_i b_j):
   * the 2 G inputs are folded (< 2^62 + 3 delta); bz_j = fold(zeta b_j) by one Shoup product (one-off quotient), IN PLACE, as soon
     as the raw b_j has been used for the last time (c_k is computed for k = G-1 .. 0);
