@@ -422,6 +422,22 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
   HIPCHK(nullptr, hipMalloc(&c->tabs.mc, mc.size() * sizeof(ModConst<T>)));
   HIPCHK(nullptr, hipMemcpy(c->tabs.mc, mc.data(), mc.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
   c->tabs.mc_inc[0] = c->tabs.mc_inc[1] = nullptr;
+  if (sizeof(T) == 4 && n >= 1024 && n <= 4096 && !c->cyclic) {
+    // 32-bit limbs, rows of 1024 / 2048 / 4096 words: the product on incomplete transforms (tools/gen_row1024_u32_asm.py base_mul,
+    // level 2 only) reads (n / 4)^-1 in the n^-1 fields and floor(2^62 / p) - 2^32 in the mu field
+    std::vector<ModConst<T>> mi(mc);
+    for (size_t cm = 0; cm < nm; ++cm) {
+      const uint64_t p = P[cm];
+      const uint64_t ng = mulmod_h((uint64_t)mc[cm].ninv, 4, p), wg = mulmod_h((uint64_t)mc[cm].w1ninv, 4, p);
+      mi[cm].ninv = (T)ng;
+      mi[cm].ninv_sh = (T)shoup_h(ng, p, wb);
+      mi[cm].w1ninv = (T)wg;
+      mi[cm].w1ninv_sh = (T)shoup_h(wg, p, wb);
+      mi[cm].mu = (T)(uint64_t)(((((u128)1) << 62) / p) - (((u128)1) << 32));
+    }
+    HIPCHK(nullptr, hipMalloc(&c->tabs.mc_inc[1], mi.size() * sizeof(ModConst<T>)));
+    HIPCHK(nullptr, hipMemcpy(c->tabs.mc_inc[1], mi.data(), mi.size() * sizeof(ModConst<T>), hipMemcpyHostToDevice));
+  }
   if (sizeof(T) == 8 && n >= 1024 && !c->cyclic && (c->shape.small_delta || (n == 4096 && c->shape.nm_small > 0))) {
     // the metric product on incomplete transforms (nflhip_polymul4096i{1,2}_asm): the inverse undoes 12 - level stages, so the
     // scale folded into its last stage is (n / 2^level)^-1; the base multiplication reduces sums below 2^127 with

@@ -374,6 +374,7 @@ enum AsmKind {
   kAsmRowFmsInv1024U64, kAsmRowFmsInv2048U64, kAsmRowFmaInv1024U64, kAsmRowFmaInv2048U64,                //   INTT(b -+ a k)
   kAsmRowEnc2W1024U64, kAsmRowEnc2W2048U64, kAsmRowEnc2I81024U64, kAsmRowEnc2I82048U64,                  //   NTT(x) k + NTT(e), two results; words / int8 inputs
   kAsmRowFmaFwdW1024U64, kAsmRowFmaFwdW2048U64, kAsmRowFmaFwdI81024U64, kAsmRowFmaFwdI82048U64,          //   ... one result
+  kAsmRow1024I2U32, kAsmRow2048I2U32, kAsmRow4096I2U32,                                                  // 32-bit limbs: the product on incomplete transforms
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return (k >= kAsmPolymul8k && k <= kAsmInv8k) || k == kAsmPolymul8kI2; }
@@ -408,6 +409,7 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_row1024_fmsinv_u64_asm", "nflhip_row2048_fmsinv_u64_asm", "nflhip_row1024_fmainv_u64_asm", "nflhip_row2048_fmainv_u64_asm",
     "nflhip_row1024_enc2w_u64_asm", "nflhip_row2048_enc2w_u64_asm", "nflhip_row1024_enc2i8_u64_asm", "nflhip_row2048_enc2i8_u64_asm",
     "nflhip_row1024_fmafwdw_u64_asm", "nflhip_row2048_fmafwdw_u64_asm", "nflhip_row1024_fmafwdi8_u64_asm", "nflhip_row2048_fmafwdi8_u64_asm",
+    "nflhip_row1024_i2_u32_asm", "nflhip_row2048_i2_u32_asm", "nflhip_row4096_i2_u32_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -777,7 +779,8 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
   if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;  // (row mod nm is one multiply in the kernel)
-  const int first = mode == 0 ? kAsmRow1024U32 : (mode == 2 ? kAsmRowFwd1024U32 : kAsmRowInv1024U32);
+  const bool inc = mode == 0 && g_polymul_level.load() == 2 && t.mc_inc[1];   // coefficient form in and out: incomplete transforms
+  const int first = mode == 0 ? (inc ? kAsmRow1024I2U32 : kAsmRow1024U32) : (mode == 2 ? kAsmRowFwd1024U32 : kAsmRowInv1024U32);
   hipFunction_t fn = asm_fn((AsmKind)(first + (s.logn - 10)));
   const unsigned rpb = 4u >> (s.logn - 10);  // rows per 256-thread workgroup
   if (!fn) return hipErrorNotSupported;
@@ -786,7 +789,7 @@ hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, 
     const void *a, *b, *psi, *mc;
     unsigned nm, magic;
     unsigned long long rows;
-  } args = {c, a, b, t.psi, t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows};
+  } args = {c, a, b, t.psi, inc ? t.mc_inc[1] : t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows};
   static_assert(sizeof(args) == 56, "kernarg layout of nflhip_row1024_u32_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

@@ -1078,8 +1078,12 @@ def device_tables(limb_bits, n, nm, prm, lane_major=False, incomplete=0):
             ninv_g = ninv * g % p
             w1n_g = w1n * g % p
             rec[3:7] = [ninv_g, (ninv_g << wb) // p, w1n_g, (w1n_g << wb) // p]
-            rec[13] = (1 << 127) // p - (1 << 65)
-            assert 0 <= rec[13] < (1 << 35)
+            if wb == 64:
+                rec[13] = (1 << 127) // p - (1 << 65)
+                assert 0 <= rec[13] < (1 << 35)
+            elif wb == 32:       # the 32-bit kernels read their Barrett constant from `mu`: floor(2^62 / p) - 2^32 (gen_row1024_u32_asm.py base_mul)
+                rec[2] = (1 << 62) // p - (1 << 32)
+                assert 0 <= rec[2] < (1 << 32)
         mc[cm] = [r & ((1 << wb) - 1) for r in rec]
     if lane_major:
         assert logn >= 12

@@ -72,6 +72,18 @@ def test_emulated_u32_product(n, nm, batch, generated, oracle_factory):
     assert np.array_equal(got, o.polymul(a, b))
 
 
+@pytest.mark.parametrize("n,nm,batch", [(1024, 3, 3), (2048, 2, 2), (4096, 1, 2)])
+def test_emulated_u32_product_on_incomplete_transforms(n, nm, batch, generated, oracle_factory):
+    """32-bit limbs (tools/gen_row1024_u32_asm.py base_mul): two stages dropped each way, four-term sums of canonical 30-bit residues in
+    ONE carry-free 64-bit chain, Barrett with floor(2^62 / p) = 2^32 + m; all-(p-1) rows are the largest sums"""
+    o = oracle_factory(32, n, nm)
+    prm, a, b = operands(o, 32, n, nm, batch, 27)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64).astype(prm.dtype)
+    a[batch - 1], b[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    got = asm_emu.run_row_kernel(generated("row%d_i2_u32" % n), 32, n, nm, prm, a, b, 4096 // n, True, incomplete=2)
+    assert np.array_equal(got, o.polymul(a, b))
+
+
 @pytest.mark.parametrize("n,nm,batch", [(1024, 2, 3), (2048, 1, 1), (4096, 2, 1)])
 def test_emulated_u32_transforms(n, nm, batch, generated, oracle_factory):
     o = oracle_factory(32, n, nm)

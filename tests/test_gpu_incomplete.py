@@ -131,3 +131,18 @@ def test_wave_per_row_u64_kernels(n, m, batch, level, oracle_factory, engine_fac
     fa = e.to_host(e.ntt_(e.to_device(a)))
     assert np.array_equal(fa, o.ntt(a)) and np.array_equal(fa, ec.to_host(ec.ntt_(ec.to_device(a))))
     assert np.array_equal(e.to_host(e.intt_(e.to_device(fa))), a)
+
+
+@pytest.mark.parametrize("n,m,batch", [(1024, 1, 5), (1024, 2, 3), (2048, 2, 5), (4096, 3, 3)])
+def test_u32_products_on_incomplete_transforms(n, m, batch, level, oracle_factory, engine_factory):
+    """32-bit limbs, rows of 1024 / 2048 / 4096 words (nflhip_row*_i2_u32_asm): the oracle's words at level 2 and 0, all-(p-1) rows, in place"""
+    o, e = oracle_factory(32, n, m), engine_factory(32, n, m)
+    a, b = o.fill_uniform(batch, SEED, 0), o.fill_uniform(batch, SEED, 1)
+    P = np.asarray(e.params.P[:m], dtype=np.uint64).astype(a.dtype)
+    a[batch - 1], b[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    want = o.polymul(a, b)
+    for lv in (0, 2):
+        level(lv)
+        da, db = e.to_device(a), e.to_device(b)
+        assert np.array_equal(e.to_host(e.polymul(da, db)), want), "level %d" % lv
+        assert np.array_equal(e.to_host(e.polymul(da, db, out=da)), want), "level %d in place" % lv

@@ -149,6 +149,46 @@ def last(u, x):
     return gen
 
 
+def base_mul(g4, rec, negate):
+    """Round 6, products on INCOMPLETE transforms (see tools/asmgen/incomplete.py for the 64-bit twin): the four words 4 g4 .. 4 g4 + 3
+    of either operand are a residue modulo X^4 - zeta (zeta = +w, or -w when `negate`; rec = the VGPR record (w, w') of the last
+    retained stage).  c_k = sum_{i+j=k} a_i b_j + zeta sum_{i+j=k+4} a_i b_j: canonical operands (< p < 2^30) make every four-term
+    sum < 2^62 -- it accumulates in ONE 64-bit chain of v_mad_u64_u32 without carries -- and one Barrett step reduces it:
+    th = T >> 30, mu = floor(2^62 / p) = 2^32 + m, q^ = th + mulhi(th, m) (q - q^ <= 3, r < 4p < 2^32), then one conditional
+    subtraction (< 2p, what the inverse butterflies take).  zeta b_j replaces b_j once its raw value is dead.  The results wait in
+    the HIGH halves of a's register pairs (scratch in this kernel): the first inverse stage / exchange reads them from there."""
+    w, wp = rec
+
+    def gen(s):
+        T0, Q, TH, NW = V_S[s], V_S[s] + 1, V_S[s] + 2, V_S[s] + 3
+        P0 = V_PW + 2 * s
+        a = [V_A + 2 * (4 * g4 + i) for i in range(4)]
+        b = [V_B + 2 * (4 * g4 + i) for i in range(4)]
+        zw, zwp = w, wp
+        if negate:   # -w = p - w, its companion floor((p - w) 2^32 / p) = ~w'; the high half of b0's pair is free scratch
+            yield "v_sub_u32_e32 v%d, s%d, %s" % (NW, S_P, w), None, None
+            yield "v_not_b32_e32 v%d, %s" % (b[0] + 1, wp), None, None
+            zw, zwp = "v%d" % NW, "v%d" % (b[0] + 1)
+        for r in a + b:
+            yield from csub(r, r, S_2P, s)
+            yield from csub(r, r, S_P, s)
+        for k in (3, 2, 1, 0):
+            ys = [b[k - i] if k - i >= 0 else b[k - i + 4] for i in range(4)]
+            for i in range(4):
+                yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (pair(P0), S_DUMMY, a[i], ys[i], "0" if i == 0 else pair(P0)), None, None
+            yield "v_alignbit_b32 v%d, v%d, v%d, 30" % (TH, P0 + 1, P0), None, None
+            yield "v_mul_hi_u32 v%d, v%d, s%d" % (Q, TH, S_MU), None, None
+            yield "v_add_u32_e32 v%d, v%d, v%d" % (Q, Q, TH), None, None
+            yield "v_mad_u64_u32 %s, %s, v%d, s%d, %s" % (pair(P0), S_DUMMY, Q, S_NEGP, pair(P0)), None, None
+            yield from csub(P0, a[k] + 1, S_2P, s)
+            if k:   # b_k <- zeta b_k (canonical)
+                yield "v_mul_hi_u32 v%d, v%d, %s" % (Q, b[k], zwp), None, None
+                yield "v_mad_u64_u32 %s, %s, v%d, s%d, 0" % (pair(P0), S_DUMMY, Q, S_NEGP), None, None
+                yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (pair(P0), S_DUMMY, b[k], zw, pair(P0)), None, None
+                yield from csub(P0, b[k], S_P, s)
+    return gen
+
+
 def run(em, jobs):
     for i in range(0, len(jobs), 2):
         gens = [jobs[i](0)]
@@ -157,12 +197,16 @@ def run(em, jobs):
         G.interleave(em, gens)
 
 
-def build(LB=4, mode="polymul"):
-    """mode: polymul (c = INTT(NTT(a) (.) NTT(b))) | fwd (c = NTT(a), canonical) | inv (c = INTT(a))"""
+def build(LB=4, mode="polymul", level=0):
+    """mode: polymul (c = INTT(NTT(a) (.) NTT(b))) | fwd (c = NTT(a), canonical) | inv (c = INTT(a));
+    level 2 (polymul): both forward transforms stop two stages early, base multiplication mod X^4 -+ zeta, the inverse starts two
+    stages late (the host passes ModConst records with (n / 4)^-1 and floor(2^62 / p) - 2^32 in the mu field)"""
+    assert level in (0, 2) and (not level or mode == "polymul")
     W = 16 * LB                       # lanes per row
     LG = LB.bit_length() - 1          # log2 LB
     LOGN = 8 + LG
     NS3 = LG                          # stages of the last pass: 2, 3, 4
+    KEEP3 = NS3 - level               # ... that remain when the transforms are incomplete
     WAVES = W // 64                   # waves per row
     em = G.Emitter()
     R = em.raw
@@ -295,6 +339,10 @@ def build(LB=4, mode="polymul"):
                 V("v_add_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 256 << i, V_LANE))
         return f
 
+    def idx_zeta():     # incomplete transforms, no stage of the last pass left: zeta = -+ tw[2^(LOGN - 3) + 2 t + g], g < 2
+        V("v_lshlrev_b32_e32 v%d, 1, v%d" % (V_TWO, V_LANE))
+        V("v_add_u32_e32 v%d, 0x%x, v%d" % (V_TWO, 1 << (LOGN - 3), V_TWO))
+
     def idx_inv1(i):    # tw[(512 << i) - 1 - (G t + g)], g < G: the block [(512 << i) - G (t + 1), +G)
         lgG = 3 - (NS3 - 1 - i)
         def f():
@@ -328,7 +376,7 @@ def build(LB=4, mode="polymul"):
             R("s_waitcnt lgkmcnt(0)")
             R("s_barrier")
 
-    def exchange(bases, waddr, woff, raddr, roff, sync_between=False, sync_before=False):
+    def exchange(bases, waddr, woff, raddr, roff, sync_between=False, sync_before=False, src_off=0):
         """LDS exchange of the listed operands, one after the other.  sync_between: writers and readers are different
         waves of the row (workgroup barrier when the row has more than one wave); sync_before: the slab's previous readers
         were other waves too"""
@@ -336,7 +384,7 @@ def build(LB=4, mode="polymul"):
             if sync_before or (n and sync_between):
                 row_sync()
             for q in range(16):
-                R("ds_write_b32 v%d, v%d offset:%d" % (waddr, b + 2 * q, woff(q)))
+                R("ds_write_b32 v%d, v%d offset:%d" % (waddr, b + 2 * q + src_off, woff(q)))
             if sync_between:
                 row_sync()
             for q in range(16):
@@ -361,19 +409,21 @@ def build(LB=4, mode="polymul"):
             cur, cur_seq = bufs[s & 1], seq
             if s < 3:
                 seq = lane_tw(bufs[(s + 1) & 1], idx_pass2(s + 1), 2 << s)
-            else:
+            elif KEEP3 > 0:
                 seq = lane_tw(bufs[(s + 1) & 1], idx_pass3(0), 8 >> (NS3 - 1))
+            else:
+                seq = lane_tw(bufs[(s + 1) & 1], idx_zeta, 2)
             wait(cur_seq)
             stage16(both, s, lambda g, cur=cur: vrec(cur, g), ct)
         exchange(both, V_A2, e2_blk, V_A3, e2_thr, sync_before=True)
         # the last NS3 stages on the lane's 16 consecutive words: stage i has d = 1 << (NS3 - 1 - i), G = 8 / d groups
-        for i in range(NS3):
+        for i in range(KEEP3):
             d = 1 << (NS3 - 1 - i)
             Gn = 8 // d
             cur, cur_seq = bufs[i & 1], seq
-            if i + 1 < NS3:
+            if i + 1 < KEEP3:
                 seq = lane_tw(bufs[(i + 1) & 1], idx_pass3(i + 1), 8 // (d // 2))
-            elif mode == "polymul":
+            elif mode == "polymul" and not level:
                 seq = lane_tw(bufs[(i + 1) & 1], idx_inv1(NS3 - 1), 8)   # (first inverse stage, descending)
             wait(cur_seq)
             jobs = []
@@ -399,23 +449,38 @@ def build(LB=4, mode="polymul"):
         L(".Ldone:")
         R("s_endpgm")
         return em, 4 * SLAB
-    if mode == "polymul":
+    inv1 = list(range(NS3 - 1, -1, -1))           # stages of the inverse's first pass
+    from_high = False                             # the inverse's first reader takes its inputs from the high halves of a's pairs
+    if mode == "polymul" and level:
+        # ------------------------------------------------------------ base multiplication mod X^4 -+ zeta (see base_mul)
+        zb = (KEEP3 - 1) & 1 if KEEP3 else 0      # the buffer that holds zeta: the last retained stage's records
+        zeta_seq = seq
+        inv1 = list(range(KEEP3 - 1, -1, -1))
+        first_buf = zb ^ 1
+        if inv1:
+            seq = lane_tw(bufs[first_buf], idx_inv1(KEEP3 - 1), 8 // (1 << (NS3 - KEEP3)))
+        else:
+            seq = lane_tw(bufs[first_buf], idx_inv2(3), 8)
+        wait(zeta_seq)
+        run(em, [base_mul(g4, vrec(bufs[zb], g4 // 2), bool(g4 & 1)) for g4 in range(4)])
+        from_high = True
+    elif mode == "polymul":
         # ------------------------------------------------------------ point-wise product -> a, in [0, 2p)
         run(em, [pointwise(V_A + 2 * q, V_B + 2 * q) for q in range(16)])
-        k0 = NS3
+        first_buf = NS3 & 1
     else:
         seq = lane_tw(bufs[0], idx_inv1(NS3 - 1), 8)
         R("s_waitcnt lgkmcnt(0)")
-        k0 = 0
+        first_buf = 0
     # ---------------------------------------------------------------- inverse (one operand)
-    for k, i in enumerate(range(NS3 - 1, -1, -1)):
+    for k, i in enumerate(inv1):
         d = 1 << (NS3 - 1 - i)
         Gn = 8 // d
-        cur, cur_seq = bufs[(k0 + k) & 1], seq
+        cur, cur_seq = bufs[(first_buf + k) & 1], seq
         if i > 0:
-            seq = lane_tw(bufs[(k0 + k + 1) & 1], idx_inv1(i - 1), Gn // 2)
+            seq = lane_tw(bufs[(first_buf + k + 1) & 1], idx_inv1(i - 1), Gn // 2)
         else:
-            seq = lane_tw(bufs[(k0 + k + 1) & 1], idx_inv2(3), 8)
+            seq = lane_tw(bufs[(first_buf + k + 1) & 1], idx_inv2(3), 8)
         wait(cur_seq)
         jobs = []
         for g in range(Gn):
@@ -423,11 +488,13 @@ def build(LB=4, mode="polymul"):
                 x, y = 2 * d * g + h, 2 * d * g + h + d
                 if mode == "inv" and k == 0:   # the loaded words sit in the consecutive block
                     jobs.append(gs(V_A + 2 * x, V_A + 2 * y, vrec(cur, Gn - 1 - g), xsrc=V_B + x, ysrc=V_B + y))
+                elif from_high and k == 0:     # the base multiplication's results
+                    jobs.append(gs(V_A + 2 * x, V_A + 2 * y, vrec(cur, Gn - 1 - g), xsrc=V_A + 2 * x + 1, ysrc=V_A + 2 * y + 1))
                 else:
                     jobs.append(gs(V_A + 2 * x, V_A + 2 * y, vrec(cur, Gn - 1 - g)))
         run(em, jobs)
-    exchange(one, V_A3, e2_thr, V_A2, e2_blk)
-    base_k = k0 + NS3
+    exchange(one, V_A3, e2_thr, V_A2, e2_blk, src_off=1 if (from_high and not inv1) else 0)
+    base_k = first_buf + len(inv1)
     for k, s in enumerate((3, 2, 1, 0)):
         cur, cur_seq = bufs[(base_k + k) & 1], seq
         n = 1 << s
@@ -452,9 +519,10 @@ ARGS = [("ptr", 0), ("ptr", 8), ("ptr", 16), ("ptr", 24), ("ptr", 32), ("i32", 4
 
 
 def main():
-    for LB, n, mode in [(LB, n, mode) for LB, n in sorted(SHAPES.items()) for mode in ("polymul", "fwd", "inv")]:
-        em, lds = build(LB, mode)
-        sfx = "" if mode == "polymul" else "_" + mode
+    for LB, n, mode in [(LB, n, mode) for LB, n in sorted(SHAPES.items()) for mode in ("polymul", "polymul_i2", "fwd", "inv")]:
+        # "polymul_i2": the product on incomplete transforms (round 6); the complete product stays the cross-check and the A/B partner
+        em, lds = build(LB, "polymul" if mode == "polymul_i2" else mode, 2 if mode == "polymul_i2" else 0)
+        sfx = {"polymul": "", "polymul_i2": "_i2"}.get(mode, "_" + mode)
         kname = "nflhip_row%d%s_u32_asm" % (n, sfx)
         out = os.path.join(G.ROOT, "nfllib_amd", "csrc", "row%d%s_u32_gfx950.s" % (n, sfx))
         karg = 56

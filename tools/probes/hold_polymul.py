@@ -13,7 +13,8 @@ from nfllib_amd import Engine
 
 n, nm, batch = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 secs = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
-e = Engine(64, n, nm)
+LB = int(os.environ.get("NFL_LIMB_BITS", "64"))     # probe knob: 64 (default) / 32 / 16-bit limbs
+e = Engine(LB, n, nm)
 if os.environ.get("NFL_POLYMUL_LEVEL"):      # probe knob (not read by the library): nflhip_debug_polymul_level, include/nflhip_debug.h
     e.lib.nflhip_debug_polymul_level(int(os.environ["NFL_POLYMUL_LEVEL"]))
 a = e.fill_uniform(e.empty(batch), 1, 0)
@@ -48,7 +49,7 @@ while time.perf_counter() < t_end:
 torch.cuda.synchronize()
 ms_held = e0.elapsed_time(e1) / iters
 busy = [s for s in samples[1:] if s[0] > 0.6 * max(x[0] for x in samples)] or samples
-alg = 3 * nm * n * 8
+alg = 3 * nm * n * (LB // 8)
 print(json.dumps({"n": n, "nm": nm, "batch": batch, "first_ms": round(ms, 4), "held_ms": round(ms_held, 4), "polymul_per_s": round(batch / ms_held * 1e3, 1),
                   "frac": round(batch / ms_held * 1e3 * alg / 8e12, 4), "package_W": round(sum(s[0] for s in busy) / len(busy), 1),
                   "sclk_MHz": round(sum(s[1] for s in busy) / len(busy)), "samples": len(busy)}))
