@@ -871,7 +871,7 @@ def main():
                    "checksum_of_checksums": checksum, "rccl": rccl},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": {"A": "nflhip_row1024_u32_asm", "B": "nflhip_polymul4096i2_asm (2 stages dropped each way, base multiplication mod X^4 -+ zeta)",
+                     "kernel": {"A": "nflhip_row1024_i2_u32_asm", "B": "nflhip_polymul4096i2_asm (2 stages dropped each way, base multiplication mod X^4 -+ zeta)",
                                 "C": "nflhip_polymul16384i2_asm",
                                 "E": "nflhip_polymul_pipe65536nti2_asm (block products on incomplete transforms + streaming passes, 6 launches per step)",
                                 "F": "nflhip_ntt_fwd32768s_asm (b -> scratch, layout [block][pair][thread]) + nflhip_polymul_ntt32768s_asm (a, b' streamed): "
@@ -904,7 +904,7 @@ def main():
     # Instructions per product: dynamic counts of the generated kernels on the interpreter of tests/asm_emu.py
     # (tools/asm_cost.py -> profiles/r03_valu_issue_model.txt; B and A agree with their SQ counter passes).
     model = "profiles/r06_valu_issue_model.txt"
-    valu = {"B": (90064, 1), "A": (2081, nm), "G": (97312, 1), "C": (835840, 1), "F": (477248, 1),
+    valu = {"B": (90064, 1), "A": (1846, nm), "G": (97312, 1), "C": (835840, 1), "F": (477248, 1),
             "E": (14347680, 1), "H": (227, 1), "T": (13, 1)}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]
