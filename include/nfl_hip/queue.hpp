@@ -90,30 +90,31 @@ template <class U> struct block_pool_alloc {
 // in HBM (`dev`), on the host (`host`), or both.  host_valid / dev_valid say which image holds the current value;
 // neither valid = the zero polynomial (what poly_p() is) with nothing allocated yet.  Every device-side operation is
 // enqueued on the context's stream, so the only synchronisation points are the device-to-host copies below.
-// `queued`: the value is the result of operations that are still in the deferred queue (lazy<P> below); every access
-// other than enqueueing more work runs the queue first (pending()).
+// queued(): the value is the result of operations that are still in the deferred queue (lazy<P> below: recorded, or handed to
+// a queue run that has not been retired yet); every access other than enqueueing more work runs the queue first (pending()).
+// A queue run (lazy<P>::execute, possibly on the queue's own thread) never touches a payload: take() copies what it needs into
+// per-run arrays and retire() writes the buffers it assigned back.  Every field belongs to the recording threads (under the
+// queue's lock), which in turn leave `dev` of a queued value alone until its run is retired.
 template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   typedef typename P::value_type T;
   typedef context<T, P::degree, P::nmoduli> ctx_t;
   static constexpr size_t bytes = sizeof(T) * P::degree * P::nmoduli;
   P *host;
   void *dev;
-  bool host_valid, dev_valid, queued;
+  bool host_valid, dev_valid;
+  unsigned qrun;  // the recording run of the last deferred operation that writes this value (0: none); see queued()
   bool poisoned;  // the deferred operation that was to produce this value never ran (an earlier launch of its queue run failed)
-  long qrefs;  // 1 while the deferred queue holds its (single) reference to this value, else 0: copy-on-write decisions look past it
-  // levelling scratch of lazy<P>::flush (valid when `epoch` is the current flush): last level that writes / reads this value
-  unsigned epoch;
-  int wlev, rlev;
-  int fw;  // scratch of lazy<P>::fuse (valid when `epoch` is the current flush): the recorded operation that last wrote this value
-  unsigned pin_at;  // where the queue's reference to this payload sits in its pin list (valid while qrefs is set / during that run)
+  long qrefs;  // references the deferred queue holds to this value (one per queue run that mentions it: the one being recorded, the
+              // one in flight): copy-on-write decisions look past them
+  unsigned pin_at;  // where the recording run's reference to this payload sits in its pin list (valid while rec_run is the current one)
   // recording scratch of lazy<P>::record (valid when `rec_run` is the queue's current recording run): index of the last
   // recorded operation that writes / reads this value -- what lets a transform join the operation that produced its operand
   unsigned rec_run;
   int rec_w, rec_r;
 
-  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0), rec_run(0), rec_w(-1), rec_r(-1) {}
+  payload() : host(nullptr), dev(nullptr), host_valid(false), dev_valid(false), qrun(0), poisoned(false), qrefs(0), pin_at(0), rec_run(0), rec_w(-1), rec_r(-1) {}
   payload(const payload &o) : std::enable_shared_from_this<payload<P>>(), host(nullptr), dev(nullptr), host_valid(false),
-                              dev_valid(false), queued(false), poisoned(false), qrefs(0), epoch(0), wlev(-1), rlev(-1), fw(-1), pin_at(0), rec_run(0), rec_w(-1), rec_r(-1) {
+                              dev_valid(false), qrun(0), poisoned(false), qrefs(0), pin_at(0), rec_run(0), rec_w(-1), rec_r(-1) {
     pending();
     o.usable();
     if (o.dev_valid) {  // stays on the device
@@ -134,6 +135,7 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
   }
   static nflhip_ctx *ctx() { return ctx_t::get(); }
   static void pending() { lazy<P>::inst().flush(); }  // run whatever is still deferred
+  bool queued() const { return qrun != 0 && qrun > lazy<P>::inst().done_run_; }  // (read under the queue's lock, or after pending())
   void usable() const {  // reading a value whose producing operation never ran is an error, not stale HBM
     if (poisoned) throw std::runtime_error("nfl(hip): this polynomial's deferred operation did not run (an earlier operation of its queue failed)");
   }
@@ -181,7 +183,7 @@ template <class P> struct payload : std::enable_shared_from_this<payload<P>> {
     return dev_ro_nf();
   }
   const void *dev_ro_nf() {  // (the queue's own form: never runs the queue)
-    if (queued) return dev;  // produced by a deferred operation; its buffer is assigned when the queue runs
+    if (queued()) return nullptr;  // produced by a deferred operation; its buffer is assigned when the queue runs (and is the run's until then)
     usable();
     if (!dev) dev = ctx_t::acquire();
     if (!dev_valid) {
@@ -237,7 +239,7 @@ template <class P> struct lazy {
   typedef std::shared_ptr<pay_t> ptr_t;
   // K_FWD_FMA / K_FMA_INV / K_NOP are never recorded: a queue run rewrites recorded sequences into them (fuse())
   enum kind_t { K_EVAL = 0, K_NTT_FWD, K_NTT_INV, K_SAMPLE, K_GAUSS, K_FILL, K_FWD_FMA, K_FMA_INV, K_NOP };
-  // One recorded operation: 72 bytes, trivially destructible.  The payloads it names are kept alive by ONE reference per
+  // One recorded operation: 120 bytes, trivially destructible.  The payloads it names are kept alive by ONE reference per
   // payload and queue run (`pins`), not one per mention -- a loop's temporaries are mentioned three times each.
   static constexpr int max_in = 4;  // expressions with more distinct handle operands are launched at once, not recorded
   struct op {
@@ -257,24 +259,90 @@ template <class P> struct lazy {
         pay_t *out2;           // second result (out1 = NTT(x) * k1 + NTT(e1)), or nullptr
         uint64_t sid[3];       // stream ids of the Gaussian polynomials x, e0, e1
         uint32_t amp[3];       // their amplifiers
+        unsigned out2_pin;
         const nflhip_gauss *tab;
       } f;          // K_FWD_FMA
     };
     unsigned char kind, nin, len;
     unsigned char post;   // 0, or K_NTT_FWD / K_NTT_INV: the result is transformed in place right after (a transform recorded on
                           // a value nothing had read since this operation produced it joins the operation instead of becoming a record)
+    // Where the run's references to `out` and to the inputs sit in its pin list.  A queue run works on THESE: whatever it keeps
+    // per value (buffer, levels, last writer) lives in arrays of its own, indexed by pin -- it never touches a payload, whose
+    // cache lines stay with the recording thread (the first version of the queue's thread wrote its levelling scratch into the
+    // payloads: the recording thread then fetched every line back from the other core when it retired the run, 1.5 us per LWE
+    // encryption, 2.5 times slower than no thread at all).
+    unsigned out_pin, in_pin[max_in];
   };
-  light_lock mu;
-  std::vector<op> q, running;  // recorded operations; the ones a queue run is working on (two buffers that swap: no regrowth)
-  std::vector<ptr_t> pins, pins_running;  // the payloads they name, one reference each
-  size_t launches, coalesced;  // statistics: launches issued / operations they carried
+  // ---- the recording side (under mu).  The three groups below sit on cache lines of their own: the queue's thread polls `st` and
+  // writes its statistics while the recording thread appends to q with every operation -- on one line that costs the recorder a
+  // cross-core transfer per record (measured: the LWE loop recorded 2.5 times SLOWER with the groups interleaved).
+  alignas(64) light_lock mu;
+  std::vector<op> q;           // recorded operations
+  std::vector<ptr_t> pins;     // the payloads they name, one reference each
   unsigned rec_run_;           // the recording run: bumped whenever the queue is handed to a queue run (payload::rec_run)
+  std::atomic<unsigned> done_run_;  // the last recording run that has been retired (payload::queued)
+  size_t next_run_;            // records at which the next run is handed to the queue's thread
+  std::thread *th;             // the queue's thread, created by the first hand-over (leaked in a forked child, which has no such thread)
+  long th_pid;
+  bool th_failed;
+  // ---- the handshake
+  alignas(64) std::atomic<int> st;   // 0: no run in flight; 1: `fly` is with the queue's thread; 2: it is done with it (retire() is due)
+  std::atomic<bool> w_sleeping, u_sleeping, quit;
+  alignas(64) std::mutex wm;
+  std::condition_variable wcv, ucv;
+  // ---- the executing side
+  // The queue run in flight: the records and pins of one recording run (their vectors swap with q / pins: no regrowth), from
+  // take() to retire().  Between post() and the moment `st` turns 2 it belongs to the queue's thread; otherwise to whoever
+  // holds `mu`.
+  struct alignas(64) run_t {
+    std::vector<op> ops, work;
+    bool remote;               // executed by the queue's thread
+    std::vector<ptr_t> held;
+    std::vector<unsigned char> launched;
+    // per pin, filled by take() (recording thread; nothing is in flight then, so every payload's `dev` is final): the value's
+    // buffer (nullptr: none yet -- the run assigns one to its results and retire() writes it back) and whether the run's pin is
+    // the LAST reference (no handle left: what the transform fusion needs to know before it lets a temporary never exist)
+    std::vector<void *> dev;
+    std::vector<unsigned char> dead;
+    std::vector<int> wlev, rlev, fw;   // the run's levelling scratch, per pin
+    unsigned char key[32];     // the sampler key as it was when the run was taken: set_sampler_key runs the queues before it changes it
+    unsigned id;               // its recording run (payload::qrun)
+    bool complete;
+    std::exception_ptr error;  // what stopped it (rethrown by retire())
+    run_t() : remote(false), id(0), complete(false) {}
+  } fly;
+  std::atomic<size_t> launches, coalesced;  // statistics: launches issued / operations they carried
+  std::atomic<size_t> fused_fwd, fused_inv;  // statistics: sequences rewritten so far
+  // compact Gaussian polynomials of a fused run live in ONE grow-only device buffer (every consumer is on the queue's stream)
+  void *small_;
+  size_t small_cap_;
+  alignas(64) char pad_[64];
   // records after which the queue runs by itself: long enough for wide launches, short enough that the device works on
   // one part of a loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments).  Measured on the
   // LWE demo loop (profiles/r02_late_queue_limit.txt): 2 048 iterations 614 k / 738 k / 1.04 M / 861 k encryptions/s with
   // 2 048 / 4 096 / 8 192 / 16 384 records, 16 384 iterations 1.09 M / 1.21 M / 1.16 M / 1.16 M with 4 096 ... 32 768.
   static size_t max_queue() {
     static const size_t v = getenv("NFL_HIP_QUEUE_LIMIT") ? size_t(atol(getenv("NFL_HIP_QUEUE_LIMIT"))) : 8192;
+    return v ? v : 1;
+  }
+  // ---- the queue's own thread (round 6).  Preparing a queue run -- fusing, levelling, grouping, finding the stride runs -- and
+  // issuing its launches cost the recording thread as much as the recording itself (tools/hostprof: 0.2 us of 0.43 us per LWE
+  // encryption).  A run that starts because the queue is long enough is therefore handed to a thread of the queue's own:
+  // the recording thread swaps in the other pair of vectors and goes on recording while that thread works.  ONE run is in flight
+  // at most; the recording thread retires it (drops the pins, rethrows what stopped it) when it hands over the next one or when
+  // anything needs the queue empty.  A run that somebody WAITS for (flush(): a value is read on the host, synchronize()) is
+  // executed by the waiting thread itself once the one in flight is retired: no hand-over latency on short programs.
+  // With a thread to hand runs to, the queue does not wait for max_queue() records either: from min_run() records on it hands
+  // over as soon as the thread is idle, so the device starts on a loop's first part while the host is still recording
+  // (the 2 048-iteration LWE loop used to leave the device idle for four fifths of its recording).
+  // NFL_HIP_QUEUE_THREAD=0 (or a machine with one hardware thread, or a thread that cannot be created): every run is executed by
+  // the thread that starts it, as before.  Results are identical either way (tests/cpp: deferred == immediate under both).
+  static bool threaded() {
+    static const bool v = getenv("NFL_HIP_QUEUE_THREAD") ? atoi(getenv("NFL_HIP_QUEUE_THREAD")) != 0 : std::thread::hardware_concurrency() > 1;
+    return v;
+  }
+  static size_t min_run() {
+    static const size_t v = getenv("NFL_HIP_QUEUE_MIN") ? size_t(atol(getenv("NFL_HIP_QUEUE_MIN"))) : 1024;
     return v ? v : 1;
   }
   // (Round 5 measured two run-length policies for SHORT loops and dropped both -- LWE demo loop, encryptions/s against the fixed
@@ -291,13 +359,28 @@ template <class P> struct lazy {
     static const bool v = getenv("NFL_HIP_EARLY_RUN") && atoi(getenv("NFL_HIP_EARLY_RUN")) != 0;
     return v;
   }
-  lazy() : launches(0), coalesced(0), rec_run_(1), small_(nullptr), small_cap_(0), fused_fwd(0), fused_inv(0) {
+  lazy() : rec_run_(1), done_run_(0), next_run_(std::min(min_run(), max_queue())), th(nullptr), th_pid(0), th_failed(false), st(0), w_sleeping(false), u_sleeping(false), quit(false),
+           launches(0), coalesced(0), fused_fwd(0), fused_inv(0), small_(nullptr), small_cap_(0) {
     ctx_t::inst();  // (the context is constructed first, so it is destroyed last)
     alive() = true;
     queue_registry::get().add(&lazy::run_if_alive);
   }
   ~lazy() {
     alive() = false;
+    if (th && th_pid == long(getpid())) {
+      try {   // the run in flight holds raw pointers into this object: see it out (what it reports has nobody to go to)
+        std::lock_guard<light_lock> lk(mu);
+        collect();
+      } catch (...) {
+      }
+      {
+        std::lock_guard<std::mutex> lk(wm);
+        quit.store(true);
+        wcv.notify_all();
+      }
+      th->join();
+      delete th;
+    }
     if (small_ && ctx_t::alive()) nflhip_free(ctx_t::get(), small_);
   }
   static bool &alive() {
@@ -352,17 +435,14 @@ template <class P> struct lazy {
     }
     return a != b && a != c && b != c;
   }
-  static bool mentions(const op &o, const pay_t *p) {
+  static bool mentions(const op &o, unsigned pin) {
     if (o.kind == K_NOP) return false;
-    if (o.out == p || (o.kind == K_FWD_FMA && o.f.out2 == p)) return true;
+    if (o.out_pin == pin || (o.kind == K_FWD_FMA && o.f.out2 && o.f.out2_pin == pin)) return true;
     if (o.kind == K_EVAL || o.kind == K_FWD_FMA || o.kind == K_FMA_INV)
       for (int j = 0; j < o.nin; ++j)
-        if (o.e.in[j] == p) return true;
+        if (o.in_pin[j] == pin) return true;
     return false;
   }
-  // compact Gaussian polynomials of a fused run live in ONE grow-only device buffer (every consumer is on the queue's stream)
-  void *small_;
-  size_t small_cap_;
   void *small_buffer(size_t bytes) {
     if (bytes > small_cap_) {
       nflhip_ctx *c = ctx_t::get();
@@ -394,41 +474,33 @@ template <class P> struct lazy {
     const uint64_t v = last.mag * uint64_t(amp);
     return v <= 127 ? NFLHIP_FMT_I8 : v <= 32767 ? NFLHIP_FMT_I16 : v <= 2147483647ull ? NFLHIP_FMT_I32 : 99;
   }
-  size_t fused_fwd, fused_inv;  // statistics: sequences rewritten so far
-  void fuse(std::vector<op> &ops, const std::vector<ptr_t> &held, unsigned ep) {
+  void fuse(run_t &r, std::vector<op> &ops) {
     const int n = int(ops.size());
     if (n < 2 || !fusion_on()) return;
     // definitions: prev[i] = the operation that wrote ops[i].out before i (what an in-place transform reads), def[i][j] =
     // the one that wrote input j of an expression; uses[d] = reads of the value operation d wrote; -1 = from before this run
     std::vector<int> prev(size_t(n), -1), uses(size_t(n), 0), def(size_t(n) * 3, -1);
-    auto touch = [ep](pay_t *p) {
-      if (p->epoch != ep) {
-        p->epoch = ep;
-        p->wlev = p->rlev = -1;
-        p->fw = -1;
-      }
-    };
+    std::vector<int> &fw = r.fw;   // per pin: the recorded operation that last wrote the value
+    fw.assign(r.held.size(), -1);
     bool any_fwd = false, any_inv = false;
     for (int i = 0; i < n; ++i) {
       op &o = ops[size_t(i)];
       if (o.kind == K_EVAL)
         for (int j = 0; j < o.nin; ++j) {
-          touch(o.e.in[j]);
-          const int d = o.e.in[j]->fw;
+          const int d = fw[o.in_pin[j]];
           if (j < 3) def[size_t(i) * 3 + size_t(j)] = d;
           if (d >= 0) ++uses[size_t(d)];
         }
-      touch(o.out);
-      prev[size_t(i)] = o.out->fw;
-      if ((o.kind == K_NTT_FWD || o.kind == K_NTT_INV) && o.out->fw >= 0) ++uses[size_t(o.out->fw)];
-      o.out->fw = i;
+      prev[size_t(i)] = fw[o.out_pin];
+      if ((o.kind == K_NTT_FWD || o.kind == K_NTT_INV) && fw[o.out_pin] >= 0) ++uses[size_t(fw[o.out_pin])];
+      fw[o.out_pin] = i;
       any_fwd |= o.kind == K_NTT_FWD || o.post == K_NTT_FWD;
       any_inv |= o.kind == K_NTT_INV || o.post == K_NTT_INV;
     }
     // the value an operation wrote is still its payload's at the end of the run: only fusable away when no handle is left
     auto dead_after = [&](int d) {
-      pay_t *p = ops[size_t(d)].out;
-      return p->fw != d || held[p->pin_at].use_count() == 1;   // (the queue's pin is the last reference)
+      const unsigned k = ops[size_t(d)].out_pin;
+      return fw[k] != d || r.dead[k] != 0;   // (this run's pin was the last reference when the run was taken: no handle, no later record)
     };
     // a sampled-and-transformed polynomial nobody else sees: -> index of its K_GAUSS record, or -1
     auto gauss_chain = [&](int dn, int want_uses) {
@@ -452,6 +524,7 @@ template <class P> struct lazy {
           bool sub;
           if (!parse_fma(t, a, b, c, sub, K_NTT_INV)) continue;
           pay_t *pc = t.e.in[c], *pa = t.e.in[a], *pb = t.e.in[b];
+          const unsigned kc = t.in_pin[c], ka = t.in_pin[a], kb = t.in_pin[b];
           t.kind = K_FMA_INV;
           t.post = 0;
           t.nin = 3;
@@ -459,6 +532,9 @@ template <class P> struct lazy {
           t.e.in[0] = pc;
           t.e.in[1] = pa;
           t.e.in[2] = pb;
+          t.in_pin[0] = kc;
+          t.in_pin[1] = ka;
+          t.in_pin[2] = kb;
           t.e.code[0] = sub ? 1 : 0;
           ++fused_inv;
           continue;
@@ -471,7 +547,7 @@ template <class P> struct lazy {
         op &e = ops[size_t(d)];
         bool clean = true;   // nothing between the two rewrites an operand (the fused operation reads them at i, not at d)
         for (int k = d + 1; k < i && clean; ++k)
-          clean = ops[size_t(k)].kind == K_NOP || (ops[size_t(k)].out != e.e.in[0] && ops[size_t(k)].out != e.e.in[1] && ops[size_t(k)].out != e.e.in[2]);
+          clean = ops[size_t(k)].kind == K_NOP || (ops[size_t(k)].out_pin != e.in_pin[0] && ops[size_t(k)].out_pin != e.in_pin[1] && ops[size_t(k)].out_pin != e.in_pin[2]);
         if (!clean) continue;
         pay_t *pc = e.e.in[c], *pa = e.e.in[a], *pb = e.e.in[b];
         t.kind = K_FMA_INV;
@@ -480,6 +556,9 @@ template <class P> struct lazy {
         t.e.in[0] = pc;
         t.e.in[1] = pa;
         t.e.in[2] = pb;
+        t.in_pin[0] = e.in_pin[c];
+        t.in_pin[1] = e.in_pin[a];
+        t.in_pin[2] = e.in_pin[b];
         t.e.code[0] = sub ? 1 : 0;
         e.kind = K_NOP;
         ++fused_inv;
@@ -514,9 +593,9 @@ template <class P> struct lazy {
           if (cands[r].i >= 0 && def[size_t(cands[r].i) * 3 + size_t(cands[r].xs)] == dx) c1 = &cands[r];
         if (!c1 || c1->i - c0.i > 4) continue;
         const op &e0 = ops[size_t(c0.i)], &e1 = ops[size_t(c1->i)];
-        bool clean = e1.e.in[c1->ks] != e0.out && e1.out != e0.out;   // (the fused operation writes both results at e1's place)
+        bool clean = e1.in_pin[c1->ks] != e0.out_pin && e1.out_pin != e0.out_pin;   // (the fused operation writes both results at e1's place)
         for (int k = c0.i + 1; k < c1->i && clean; ++k)
-          clean = !mentions(ops[size_t(k)], e0.out) && (ops[size_t(k)].kind == K_NOP || ops[size_t(k)].out != e0.e.in[c0.ks]);
+          clean = !mentions(ops[size_t(k)], e0.out_pin) && (ops[size_t(k)].kind == K_NOP || ops[size_t(k)].out_pin != e0.in_pin[c0.ks]);
         if (!clean) continue;
       }
       const op e0 = ops[size_t(c0.i)];
@@ -525,12 +604,16 @@ template <class P> struct lazy {
       const op &gx = ops[size_t(c0.gx)], &g0 = ops[size_t(c0.ge)];
       t.kind = K_FWD_FMA;
       t.out = e0.out;
+      t.out_pin = e0.out_pin;
       t.nin = c1 ? 2 : 1;
       t.len = 0;
       t.f.in[0] = e0.e.in[c0.ks];
       t.f.in[1] = c1 ? e1.e.in[c1->ks] : nullptr;
       t.f.in[2] = t.f.in[3] = nullptr;
+      t.in_pin[0] = e0.in_pin[c0.ks];
+      t.in_pin[1] = c1 ? e1.in_pin[c1->ks] : 0;
       t.f.out2 = c1 ? e1.out : nullptr;
+      t.f.out2_pin = c1 ? e1.out_pin : 0;
       t.f.tab = gx.s.tab;
       t.f.sid[0] = gx.s.sid;
       t.f.amp[0] = uint32_t(gx.s.p1);
@@ -572,18 +655,15 @@ template <class P> struct lazy {
     }
     std::sort(v.begin(), v.end());
   }
-  // the queue's reference to a payload (taken the first time a queue run's operations mention it)
-  void pin(pay_t *p) {
-    if (!p->qrefs) {
-      p->pin_at = unsigned(pins.size());
-      pins.push_back(p->shared_from_this());
-      p->qrefs = 1;
-    }
-  }
-  pay_t *rec_tag(pay_t *p) {
+  // the recording run's reference to a payload, taken the first time one of its operations mentions it (the recording scratch
+  // is tagged with the run at the same moment: "mentioned in this run" and "pinned by this run" are one fact)
+  pay_t *pin(pay_t *p) {
     if (p->rec_run != rec_run_) {
       p->rec_run = rec_run_;
       p->rec_w = p->rec_r = -1;
+      p->pin_at = unsigned(pins.size());
+      pins.push_back(p->shared_from_this());
+      ++p->qrefs;
     }
     return p;
   }
@@ -610,6 +690,14 @@ template <class P> struct lazy {
     std::lock_guard<light_lock> lk(mu);
     q.emplace_back();
     op &o = q.back();
+#if defined(__x86_64__)
+    // the vector's storage was last read by the queue's thread (another core, often another L3): ask for the lines this loop will
+    // write a dozen records from now in exclusive state NOW, so that the stores do not each wait for the invalidation
+    if (q.size() + 16 <= q.capacity()) {
+      const char *ahead = reinterpret_cast<const char *>(&o + 16);
+      __asm__ volatile("prefetchw %0\n\tprefetchw %1" : : "m"(*ahead), "m"(*(ahead + 64)));
+    }
+#endif
     o.nin = 0;
     o.len = 0;
     o.post = 0;
@@ -617,72 +705,266 @@ template <class P> struct lazy {
       fill(o);
       for (int j = 0; j < o.nin; ++j) o.e.in[j]->dev_ro_nf();
       if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) o.out->dev_ro_nf();
-      pin(o.out);
-      for (int j = 0; j < o.nin; ++j) pin(o.e.in[j]);
     } catch (...) {
       q.pop_back();
       throw;
     }
     const int at = int(q.size()) - 1;
-    for (int j = 0; j < o.nin; ++j) rec_tag(o.e.in[j])->rec_r = at;
-    rec_tag(o.out)->rec_w = at;
-    o.out->queued = true;
+    for (int j = 0; j < o.nin; ++j) {
+      pin(o.e.in[j])->rec_r = at;
+      o.in_pin[j] = o.e.in[j]->pin_at;
+    }
+    pin(o.out)->rec_w = at;
+    o.out_pin = o.out->pin_at;
+    o.out->qrun = rec_run_;
     o.out->dev_valid = true;
     o.out->host_valid = false;
     if (o.kind != K_NTT_FWD && o.kind != K_NTT_INV) o.out->poisoned = false;  // overwritten entirely
-    if (q.size() >= max_queue()) flush();
-    else if (early_run() && q.size() >= 1024 && q.size() % 512 == 0) {
+    const size_t n = q.size();
+    if (!threaded()) {
+      if (n >= max_queue()) hand_over();
+    } else if (n >= next_run_ && (n >= 2 * max_queue() || (n % 64 == 0 && st.load(std::memory_order_relaxed) != 1)) && have_thread()) {
+      // Run lengths of a loop grow geometrically (min_run(), twice that, ... up to max_queue()): the device starts on the loop's
+      // first few hundred iterations while the host is still recording, and the later runs are long enough for the device's
+      // best rate (per run it pays three sampler launches and the drain of the fused kernel, whatever the length).  A run waits
+      // for the queue's thread only at twice the full length; flush() -- somebody waited: the loop is over -- starts anew.
+      hand_over();
+      next_run_ = std::min(next_run_ * 2, max_queue());
+    } else if (n >= 2 * max_queue()) {
+      hand_over();   // (no thread after all)
+    } else if (early_run() && n >= 1024 && n % 512 == 0) {
       // a loop shorter than the queue: do not let the device sit idle until the loop's end
       int idle = 0;
-      if (nflhip_stream_idle(ctx_t::get(), ctx_t::queue(), &idle) == NFLHIP_OK && idle) flush();
+      if (nflhip_stream_idle(ctx_t::get(), ctx_t::queue(), &idle) == NFLHIP_OK && idle) hand_over();
     }
   }
+  // everything recorded so far has been launched (or has failed: rethrown here) when this returns
   void flush() {
     std::lock_guard<light_lock> lk(mu);
+    next_run_ = std::min(min_run(), max_queue());
+    collect();
     if (q.empty()) return;
-    std::vector<op> local;  // (a queue run started from inside another one: cannot happen today, costs nothing to allow)
-    std::vector<ptr_t> local_pins;
-    const bool outer = running.empty() && pins_running.empty();
-    std::vector<op> &ops = outer ? running : local;
-    std::vector<ptr_t> &held = outer ? pins_running : local_pins;
-    ops.swap(q);
-    held.swap(pins);
-    ++rec_run_;   // (what is recorded from now on cannot join operations of this run)
-    if (q.capacity() < ops.capacity()) q.reserve(ops.capacity());
-    for (auto &p : held) p->qrefs = 0;  // (operations recorded from now on belong to the next run and pin again)
-    std::vector<unsigned char> launched(ops.size(), 0);
-    struct done_guard {  // whatever happens, the payloads stop claiming a queued value, and the run's references go
-      std::vector<op> &o;
-      std::vector<ptr_t> &h;
-      std::vector<unsigned char> &launched;
-      bool complete;
-      ~done_guard() {
-        for (auto &x : o) x.out->queued = false;
-        if (!complete)  // a launch failed: what was never launched holds no value -- later accesses throw (payload::usable)
-          for (size_t i = 0; i < o.size(); ++i)
-            if (!launched[i]) {
-              o[i].out->dev_valid = false;
-              o[i].out->poisoned = true;
-            }
-        o.clear();
-        if (ctx_t::alive()) {   // the temporaries' buffers go back to the pool one by one: its lock is taken once for all of them
-          std::lock_guard<light_lock> pool(ctx_t::inst().mu);
-          h.clear();
-        } else {
-          h.clear();
+    take();
+    execute(fly);   // somebody waits for it: no hand-over
+    retire();
+  }
+  // the records so far become the run in flight (the previous one is retired first): on the queue's thread if there is one
+  void hand_over() {
+    collect();
+    if (q.empty()) return;
+    take(clean_cut());
+    if (have_thread()) {
+      fly.remote = true;
+      post();
+    } else {
+      execute(fly);
+      retire();
+    }
+  }
+  bool have_thread() {   // (under mu)
+    if (!threaded() || th_failed) return false;
+    const long pid = long(getpid());
+    if (th && th_pid == pid) return true;
+    if (th) return false;   // a forked child: the thread stayed with the parent; runs are executed by their callers here
+    try {
+      th_pid = pid;
+      th = new std::thread([this] { worker(); });
+    } catch (...) {
+      th = nullptr;
+      th_failed = true;
+      return false;
+    }
+    return true;
+  }
+  // Where to cut the queue when a run starts by itself in the middle of a loop.  The iteration that is being recorded right now has
+  // sampled its temporaries but not consumed them yet (poly_p u{gaussian}; u.ntt_pow_phi(); ra = u * pka + e1; | rb = u * pkb + e2;):
+  // a run that takes its first half cannot fuse it -- u has a handle and another reader to come -- and launches nine small
+  // kernels for that one iteration instead (a fifth of the device's time per run, rocprofv3 timeline of the LWE loop).  So the
+  // records from the first one that mentions a Gaussian temporary of the last few records whose HANDLE IS STILL ALIVE stay in
+  // the queue for the next run.  -> number of records the run takes (all of them when there is no such temporary).
+  size_t clean_cut() const {
+    const size_t n = q.size(), window = 32;
+    const size_t from = n > window ? n - window : 0;
+    unsigned open_pin[8];
+    int nopen = 0;
+    for (size_t i = from; i < n && nopen < 8; ++i) {
+      const op &o = q[i];
+      if (o.kind == K_GAUSS && pins[o.out_pin].use_count() - o.out->qrefs >= 1) open_pin[nopen++] = o.out_pin;
+    }
+    if (!nopen) return n;
+    for (size_t i = from; i < n; ++i)
+      for (int k = 0; k < nopen; ++k)
+        if (mentions(q[i], open_pin[k])) return i ? i : n;   // (nothing in front of it: take everything)
+    return n;
+  }
+  void take(size_t cut = size_t(-1)) {   // (under mu, nothing in flight); records from `cut` on stay in the queue
+    op rest[32];
+    size_t nrest = 0;
+    if (cut < q.size()) {
+      nrest = q.size() - cut;
+      std::copy(q.begin() + ptrdiff_t(cut), q.end(), rest);
+      q.resize(cut);
+    }
+    fly.ops.swap(q);
+    fly.held.swap(pins);
+    if (q.capacity() < fly.ops.capacity()) q.reserve(fly.ops.capacity());
+    fly.id = rec_run_++;   // (what is recorded from now on cannot join operations of this run, and pins again)
+    for (size_t i = 0; i < nrest; ++i) {   // the records that stay: recorded again, in the new recording run
+      q.push_back(rest[i]);
+      op &o = q.back();
+      const int at = int(q.size()) - 1;
+      const bool two = o.kind == K_FWD_FMA && o.f.out2;   // (never recorded; kept for completeness)
+      for (int j = 0; j < o.nin; ++j) {
+        pin(o.e.in[j])->rec_r = at;
+        o.in_pin[j] = o.e.in[j]->pin_at;
+      }
+      pin(o.out)->rec_w = at;
+      o.out_pin = o.out->pin_at;
+      o.out->qrun = rec_run_;
+      if (two) {
+        pin(o.f.out2)->rec_w = at;
+        o.f.out2_pin = o.f.out2->pin_at;
+        o.f.out2->qrun = rec_run_;
+      }
+    }
+    fly.launched.assign(fly.ops.size(), 0);
+    const size_t np = fly.held.size();
+    fly.dev.resize(np);
+    fly.dead.resize(np);
+    for (size_t k = 0; k < np; ++k) {
+      fly.dev[k] = fly.held[k]->dev;
+      fly.dead[k] = fly.held[k].use_count() == 1;
+    }
+    fly.complete = false;
+    fly.error = nullptr;
+    fly.remote = false;
+    detail::sampler::get().copy_key(fly.key);
+  }
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+  void post() {
+    st.store(1, std::memory_order_seq_cst);
+    if (w_sleeping.load(std::memory_order_seq_cst)) {
+      std::lock_guard<std::mutex> lk(wm);
+      wcv.notify_one();
+    }
+  }
+  void worker() {
+    for (;;) {
+      unsigned spins = 0;
+      while (st.load(std::memory_order_acquire) != 1 && !quit.load(std::memory_order_relaxed)) {
+        if (++spins < 20000) {   // (a loop hands over the next run within a fraction of a millisecond: worth a short spin)
+          cpu_relax();
+          continue;
         }
+        std::unique_lock<std::mutex> lk(wm);
+        w_sleeping.store(true, std::memory_order_seq_cst);
+        wcv.wait(lk, [this] { return st.load(std::memory_order_seq_cst) == 1 || quit.load(); });
+        w_sleeping.store(false, std::memory_order_seq_cst);
       }
-    } guard{ops, held, launched, false};
-    // ---- 1. levels (the last writing / reading level of a value is kept in its payload, tagged with this flush's epoch)
-    static unsigned epoch_counter = 0;
-    const unsigned ep = ++epoch_counter;
-    auto touch = [ep](pay_t *p) {
-      if (p->epoch != ep) {
-        p->epoch = ep;
-        p->wlev = p->rlev = -1;
+      if (st.load(std::memory_order_acquire) != 1) return;   // quit
+      execute(fly);
+      st.store(2, std::memory_order_seq_cst);
+      if (u_sleeping.load(std::memory_order_seq_cst)) {
+        std::lock_guard<std::mutex> lk(wm);
+        ucv.notify_all();
       }
-    };
-    fuse(ops, held, ep);   // (tags the payloads it sees with this flush's epoch: wlev / rlev start at -1 either way)
+    }
+  }
+  // wait for the run in flight, if any, and retire it (under mu)
+  void collect() {
+    int s = st.load(std::memory_order_acquire);
+    if (s == 0) return;
+    for (unsigned spins = 0; s != 2; s = st.load(std::memory_order_acquire)) {
+      if (++spins < 20000) {
+        cpu_relax();
+        continue;
+      }
+      std::unique_lock<std::mutex> lk(wm);
+      u_sleeping.store(true, std::memory_order_seq_cst);
+      ucv.wait(lk, [this] { return st.load(std::memory_order_seq_cst) == 2; });
+      u_sleeping.store(false, std::memory_order_seq_cst);
+    }
+    retire();
+  }
+  // the run in flight is over (under mu; executed here, or by the queue's thread which has set st = 2): its values stop being
+  // queued, its references go; if a launch failed, what was never launched holds no value -- later accesses throw
+  // (payload::usable) -- and so does everything recorded since (it was recorded on top of values that do not exist): rethrown
+  void retire() {
+    st.store(0, std::memory_order_relaxed);
+    done_run_.store(fly.id, std::memory_order_relaxed);
+    const bool failed = !fly.complete;
+    if (failed)
+      for (size_t i = 0; i < fly.ops.size(); ++i)
+        if (!fly.launched[i]) {
+          fly.ops[i].out->dev_valid = false;
+          fly.ops[i].out->poisoned = true;
+        }
+    fly.ops.clear();
+    for (size_t k = 0; k < fly.held.size(); ++k) {
+      pay_t *p = fly.held[k].get();
+      p->dev = fly.dev[k];   // (results that had no buffer got theirs from the run)
+      --p->qrefs;
+    }
+    if (failed && !q.empty()) {
+      for (auto &o : q) {
+        o.out->dev_valid = false;
+        o.out->poisoned = true;
+      }
+      q.clear();
+      for (auto &p : pins) --p->qrefs;
+      fly.held.insert(fly.held.end(), pins.begin(), pins.end());
+      pins.clear();
+      done_run_.store(rec_run_++, std::memory_order_relaxed);
+    }
+    if (ctx_t::alive()) {   // the temporaries' buffers go back to the pool one by one: its lock is taken once for all of them
+      std::lock_guard<light_lock> pool(ctx_t::inst().mu);
+      fly.held.clear();
+    } else {
+      fly.held.clear();
+    }
+    if (failed) {
+      std::exception_ptr e = fly.error;
+      fly.error = nullptr;
+      if (e) std::rethrow_exception(e);
+      throw std::runtime_error("nfl(hip): a deferred operation failed");
+    }
+  }
+  // One queue run: fuse, level, group, launch.  Runs on the queue's thread or on the thread that waits for it; touches nothing
+  // of the recording state (see payload: `dev` of results without a buffer, and the levelling scratch).  Never throws: what
+  // stops it is kept in r.error, r.launched says which operations were issued.
+  void execute(run_t &r) {
+    static const bool stats = getenv("NFL_HIP_TRACE_DEFERRED") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t nops = r.ops.size();
+    try {
+      execute_body(r);
+      r.complete = true;
+    } catch (...) {
+      r.error = std::current_exception();
+    }
+    if (stats) {
+      const double us = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6;
+      std::fprintf(stderr, "nfl(hip) queue run: %zu records in %.1f us (%s)\n", nops, us, r.remote ? "the queue's thread" : "the calling thread");
+    }
+  }
+  void execute_body(run_t &r) {
+    // The queue's thread works on a COPY of the records: it rewrites them (fusion), and lines it has written would have to come
+    // back from its cache, one by one, when the recording thread fills the same vector again two runs later.
+    if (r.remote) r.work.assign(r.ops.begin(), r.ops.end());
+    std::vector<op> &ops = r.remote ? r.work : r.ops;
+    std::vector<unsigned char> &launched = r.launched;
+    std::vector<void *> &D = r.dev;   // per pin: the value's buffer
+    fuse(r, ops);
+    // ---- 1. levels (per pin: the last level that writes / reads the value)
+    std::vector<int> &wlev = r.wlev, &rlev = r.rlev;
+    wlev.assign(r.held.size(), -1);
+    rlev.assign(r.held.size(), -1);
     std::vector<int> lvl(ops.size(), 0);
     for (size_t i = 0; i < ops.size(); ++i) {
       op &o = ops[i];
@@ -692,22 +974,15 @@ template <class P> struct lazy {
         continue;
       }
       int L = 0;
-      for (int j = 0; j < o.nin; ++j) {
-        touch(o.e.in[j]);
-        L = std::max(L, o.e.in[j]->wlev + 1);
-      }
-      touch(o.out);
-      L = std::max(L, std::max(o.out->wlev, o.out->rlev) + 1);
-      pay_t *out2 = o.kind == K_FWD_FMA ? o.f.out2 : nullptr;
-      if (out2) {
-        touch(out2);
-        L = std::max(L, std::max(out2->wlev, out2->rlev) + 1);
-      }
+      for (int j = 0; j < o.nin; ++j) L = std::max(L, wlev[o.in_pin[j]] + 1);
+      L = std::max(L, std::max(wlev[o.out_pin], rlev[o.out_pin]) + 1);
+      const bool two_results = o.kind == K_FWD_FMA && o.f.out2;
+      if (two_results) L = std::max(L, std::max(wlev[o.f.out2_pin], rlev[o.f.out2_pin]) + 1);
       lvl[i] = L;
-      o.out->wlev = L;
-      if (out2) out2->wlev = L;
-      for (int j = 0; j < o.nin; ++j) o.e.in[j]->rlev = std::max(o.e.in[j]->rlev, L);
-      if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) o.out->rlev = std::max(o.out->rlev, L);
+      wlev[o.out_pin] = L;
+      if (two_results) wlev[o.f.out2_pin] = L;
+      for (int j = 0; j < o.nin; ++j) rlev[o.in_pin[j]] = std::max(rlev[o.in_pin[j]], L);
+      if (o.kind == K_NTT_FWD || o.kind == K_NTT_INV) rlev[o.out_pin] = std::max(rlev[o.out_pin], L);
     }
     // ---- 2. groups: (level, signature) -> operations in program order.  A loop produces a handful of distinct
     // signatures, so a linear table of the ones seen (64-bit FNV-1a of the fields, plus the level) beats a map.
@@ -751,14 +1026,13 @@ template <class P> struct lazy {
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return keys[x].level < keys[y].level; });
     nflhip_ctx *ctx = ctx_t::get();
     void *st = ctx_t::queue();
-    struct { unsigned char key[32]; } smp;  // the key as it is NOW: set_sampler_key runs the queues before it changes it
-    detail::sampler::get().copy_key(smp.key);
+    struct { const unsigned char *key; } smp = {r.key};  // the key as it was when the run was taken
     static const bool trace = getenv("NFL_HIP_TRACE_DEFERRED") != nullptr;
     // in-place transforms of the results of `idx` (mutually independent): by address, so that neighbours become one dense batch
     auto launch_transforms = [&](const std::vector<size_t> &idx, int tkind) {
       std::vector<char *> ptr;
       ptr.reserve(idx.size());
-      for (size_t i : idx) ptr.push_back(static_cast<char *>(ops[i].out->dev));
+      for (size_t i : idx) ptr.push_back(static_cast<char *>(D[ops[i].out_pin]));
       sort_interleaved(ptr);
       for (size_t a = 0; a < ptr.size();) {
         size_t b = a + 1;
@@ -783,8 +1057,8 @@ template <class P> struct lazy {
       const int kind = ops[idx[0]].kind;
       const size_t launches_before = launches;
       struct tracer {
-        bool on; int level, kind; size_t n; const size_t &now; size_t before;
-        ~tracer() { if (on) std::fprintf(stderr, "nfl(hip) deferred: level %d kind %d: %zu operations -> %zu launches\n", level, kind, n, now - before); }
+        bool on; int level, kind; size_t n; const std::atomic<size_t> &now; size_t before;
+        ~tracer() { if (on) std::fprintf(stderr, "nfl(hip) deferred: level %d kind %d: %zu operations -> %zu launches\n", level, kind, n, now.load() - before); }
       } tr{trace, keys[gi].level, kind, idx.size(), launches, launches_before};
       if ((kind == K_SAMPLE || kind == K_GAUSS) && idx.size() >= 4) {
         // A loop body that draws several polynomials of one distribution (e1, e2 of an encryption) interleaves their
@@ -810,20 +1084,20 @@ template <class P> struct lazy {
       // ---- 3. buffers for results that have none yet: consecutive, in program order
       std::vector<size_t> need;
       for (size_t i : idx)
-        if (!ops[i].out->dev) need.push_back(i);
+        if (!D[ops[i].out_pin]) need.push_back(i);
       if (!need.empty()) {
         std::vector<void *> bufs(need.size());
         ctx_t::acquire_many(need.size(), bufs.data());
-        for (size_t k = 0; k < need.size(); ++k) ops[need[k]].out->dev = bufs[k];
+        for (size_t k = 0; k < need.size(); ++k) D[ops[need[k]].out_pin] = bufs[k];
       }
       if (kind == K_FWD_FMA) {   // the second results: a dense array of their own
         need.clear();
         for (size_t i : idx)
-          if (ops[i].f.out2 && !ops[i].f.out2->dev) need.push_back(i);
+          if (ops[i].f.out2 && !D[ops[i].f.out2_pin]) need.push_back(i);
         if (!need.empty()) {
           std::vector<void *> bufs(need.size());
           ctx_t::acquire_many(need.size(), bufs.data());
-          for (size_t k = 0; k < need.size(); ++k) ops[need[k]].f.out2->dev = bufs[k];
+          for (size_t k = 0; k < need.size(); ++k) D[ops[need[k]].f.out2_pin] = bufs[k];
         }
       }
       if (kind == K_NTT_FWD || kind == K_NTT_INV) {
@@ -833,7 +1107,7 @@ template <class P> struct lazy {
       }
       if (kind == K_FILL) {
         for (size_t i : idx) {
-          check(ctx, nflhip_fill_uniform_dev(ctx, ops[i].out->dev, 0, 1, ops[i].s.sid, 0, st), "deferred set(uniform)");
+          check(ctx, nflhip_fill_uniform_dev(ctx, D[ops[i].out_pin], 0, 1, ops[i].s.sid, 0, st), "deferred set(uniform)");
           launched[i] = 1;
           ++launches;
           ++coalesced;
@@ -848,7 +1122,7 @@ template <class P> struct lazy {
           uint64_t stride = 0;
           while (b < idx.size()) {
             const op &prev = ops[idx[b - 1]], &cur = ops[idx[b]];
-            if (static_cast<char *>(cur.out->dev) != static_cast<char *>(prev.out->dev) + ctx_t::chunk_bytes) break;
+            if (static_cast<char *>(D[cur.out_pin]) != static_cast<char *>(D[prev.out_pin]) + ctx_t::chunk_bytes) break;
             const uint64_t d = cur.s.sid - prev.s.sid;
             if (b == a + 1) stride = d;
             else if (d != stride) break;
@@ -856,12 +1130,12 @@ template <class P> struct lazy {
           }
           const size_t cnt = b - a;
           if (kind == K_SAMPLE)
-            check(ctx, cnt == 1 ? nflhip_sample_dev(ctx, o0.out->dev, 0, 1, o0.s.dist, o0.s.p0, o0.s.p1, smp.key, o0.s.sid, st)
-                                : nflhip_sample_seq_dev(ctx, o0.out->dev, cnt, o0.s.dist, o0.s.p0, o0.s.p1, smp.key, o0.s.sid, stride, st),
+            check(ctx, cnt == 1 ? nflhip_sample_dev(ctx, D[o0.out_pin], 0, 1, o0.s.dist, o0.s.p0, o0.s.p1, smp.key, o0.s.sid, st)
+                                : nflhip_sample_seq_dev(ctx, D[o0.out_pin], cnt, o0.s.dist, o0.s.p0, o0.s.p1, smp.key, o0.s.sid, stride, st),
                   "deferred random constructor");
           else
-            check(ctx, cnt == 1 ? nflhip_sample_gauss_dev(ctx, o0.out->dev, 0, 1, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, st)
-                                : nflhip_sample_gauss_seq_dev(ctx, o0.out->dev, cnt, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, stride, st),
+            check(ctx, cnt == 1 ? nflhip_sample_gauss_dev(ctx, D[o0.out_pin], 0, 1, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, st)
+                                : nflhip_sample_gauss_seq_dev(ctx, D[o0.out_pin], cnt, o0.s.tab, o0.s.p1, smp.key, o0.s.sid, stride, st),
                   "deferred set(gaussian)");
           for (size_t k = a; k < b; ++k) launched[idx[k]] = 1;
           ++launches;
@@ -876,18 +1150,18 @@ template <class P> struct lazy {
       const int nin = ops[idx[0]].nin;
       // a "key" slot holds one of a few polynomials throughout the group (at most 8, and at most every eighth operation a
       // new one); each combination of keys becomes its own sub-group, whose other operands then advance by strides
-      struct subgroup { const pay_t *key[NFLHIP_EXPR_MAX_OPERANDS]; std::vector<size_t> idx; };
+      struct subgroup { unsigned key[NFLHIP_EXPR_MAX_OPERANDS]; std::vector<size_t> idx; };   // (keys by pin; ~0u: not a key slot)
       std::vector<subgroup> sub;
       {
         bool keyslot[NFLHIP_EXPR_MAX_OPERANDS];
         const size_t cap = std::min<size_t>(idx.size() / 8 + 1, 8);
         for (int j = 0; j < nin; ++j) {
-          const pay_t *seen[8];
+          unsigned seen[8];
           size_t ns = 0;
           bool few = idx.size() >= 2;
           for (size_t i : idx) {
             if (!few) break;
-            const pay_t *p = ops[i].e.in[j];
+            const unsigned p = ops[i].in_pin[j];
             size_t k = ns;
             while (k-- > 0 && seen[k] != p) {}
             if (k == size_t(-1)) {
@@ -898,8 +1172,8 @@ template <class P> struct lazy {
           keyslot[j] = few && ns < idx.size();
         }
         for (size_t i : idx) {
-          const pay_t *key[NFLHIP_EXPR_MAX_OPERANDS];
-          for (int j = 0; j < nin; ++j) key[j] = keyslot[j] ? ops[i].e.in[j] : nullptr;
+          unsigned key[NFLHIP_EXPR_MAX_OPERANDS];
+          for (int j = 0; j < nin; ++j) key[j] = keyslot[j] ? ops[i].in_pin[j] : ~0u;
           size_t g = sub.size();
           for (size_t k = sub.size(); k-- > 0;)
             if (std::equal(key, key + nin, sub[k].key)) { g = k; break; }
@@ -924,10 +1198,10 @@ template <class P> struct lazy {
             size_t b = a + 1;
             while (b < sidx.size()) {
               const op &prev = ops[sidx[b - 1]], &cur = ops[sidx[b]];
-              bool ok = static_cast<char *>(cur.out->dev) == static_cast<char *>(prev.out->dev) + ctx_t::chunk_bytes &&
-                        (!two || static_cast<char *>(cur.f.out2->dev) == static_cast<char *>(prev.f.out2->dev) + ctx_t::chunk_bytes);
+              bool ok = static_cast<char *>(D[cur.out_pin]) == static_cast<char *>(D[prev.out_pin]) + ctx_t::chunk_bytes &&
+                        (!two || static_cast<char *>(D[cur.f.out2_pin]) == static_cast<char *>(D[prev.f.out2_pin]) + ctx_t::chunk_bytes);
               for (int j = 0; j < nin && ok; ++j) {
-                const ptrdiff_t d = static_cast<char *>(cur.f.in[j]->dev) - static_cast<char *>(prev.f.in[j]->dev);
+                const ptrdiff_t d = static_cast<char *>(D[cur.in_pin[j]]) - static_cast<char *>(D[prev.in_pin[j]]);
                 if (d < 0 || d % ptrdiff_t(ctx_t::chunk_bytes)) ok = false;
                 else if (b == a + 1) kstride[j] = size_t(d) / ctx_t::chunk_bytes;
                 else if (size_t(d) != kstride[j] * ctx_t::chunk_bytes) ok = false;
@@ -955,12 +1229,12 @@ template <class P> struct lazy {
               ++launches;
             }
             for (int j = 0; j < nin; ++j) {
-              k[j].ptr = o0.f.in[j]->dev;
+              k[j].ptr = D[o0.in_pin[j]];
               k[j].stride = cnt > 1 ? kstride[j] : 0;
               k[j].format = NFLHIP_FMT_WORDS;
             }
-            check(ctx, two ? nflhip_fwd_fma2_dev(ctx, o0.out->dev, o0.f.out2->dev, &x[0], &k[0], &x[1], &k[1], &x[2], cnt, st)
-                           : nflhip_fwd_fma_dev(ctx, o0.out->dev, &x[0], &k[0], &x[1], cnt, st),
+            check(ctx, two ? nflhip_fwd_fma2_dev(ctx, D[o0.out_pin], D[o0.f.out2_pin], &x[0], &k[0], &x[1], &k[1], &x[2], cnt, st)
+                           : nflhip_fwd_fma_dev(ctx, D[o0.out_pin], &x[0], &k[0], &x[1], cnt, st),
                   "deferred transform + multiply-add");
             for (size_t q = a; q < b; ++q) launched[sidx[q]] = 1;
             ++launches;
@@ -971,8 +1245,8 @@ template <class P> struct lazy {
         }
         {  // by destination address (program order among equals); a loop's results already are in that order
           bool sorted = true;
-          for (size_t k = 1; k < sidx.size() && sorted; ++k) sorted = !(ops[sidx[k]].out->dev < ops[sidx[k - 1]].out->dev);
-          if (!sorted) std::stable_sort(sidx.begin(), sidx.end(), [&](size_t x, size_t y) { return ops[x].out->dev < ops[y].out->dev; });
+          for (size_t k = 1; k < sidx.size() && sorted; ++k) sorted = !(D[ops[sidx[k]].out_pin] < D[ops[sidx[k - 1]].out_pin]);
+          if (!sorted) std::stable_sort(sidx.begin(), sidx.end(), [&](size_t x, size_t y) { return D[ops[x].out_pin] < D[ops[y].out_pin]; });
         }
         for (size_t a = 0; a < sidx.size();) {
           const op &o0 = ops[sidx[a]];
@@ -981,13 +1255,13 @@ template <class P> struct lazy {
           while (b < sidx.size()) {
             const op &prev = ops[sidx[b - 1]], &cur = ops[sidx[b]];
             bool ok = true;
-            const ptrdiff_t od = static_cast<char *>(cur.out->dev) - static_cast<char *>(prev.out->dev);
+            const ptrdiff_t od = static_cast<char *>(D[cur.out_pin]) - static_cast<char *>(D[prev.out_pin]);
             if (od <= 0 || od % ptrdiff_t(ctx_t::chunk_bytes)) break;
             if (kind == K_FMA_INV && size_t(od) != ctx_t::chunk_bytes) break;   // (the fused entry writes dense results)
             if (b == a + 1) ostride = size_t(od) / ctx_t::chunk_bytes;
             else if (size_t(od) != ostride * ctx_t::chunk_bytes) break;
             for (int j = 0; j < nin && ok; ++j) {
-              const ptrdiff_t d = static_cast<char *>(cur.e.in[j]->dev) - static_cast<char *>(prev.e.in[j]->dev);
+              const ptrdiff_t d = static_cast<char *>(D[cur.in_pin[j]]) - static_cast<char *>(D[prev.in_pin[j]]);
               if (d < 0 || d % ptrdiff_t(ctx_t::chunk_bytes)) ok = false;
               else if (b == a + 1) stride[j] = size_t(d) / ctx_t::chunk_bytes;
               else if (size_t(d) != stride[j] * ctx_t::chunk_bytes) ok = false;
@@ -997,7 +1271,7 @@ template <class P> struct lazy {
           }
           const size_t cnt = b - a;
           const void *d[NFLHIP_EXPR_MAX_OPERANDS];
-          for (int j = 0; j < nin; ++j) d[j] = o0.e.in[j]->dev;
+          for (int j = 0; j < nin; ++j) d[j] = D[o0.in_pin[j]];
           if (kind == K_FMA_INV) {   // in[0] +- in[1] * in[2], then the inverse transform: one launch
             nflhip_operand w[3];
             for (int j = 0; j < 3; ++j) {
@@ -1005,12 +1279,12 @@ template <class P> struct lazy {
               w[j].stride = cnt > 1 ? stride[j] : 0;
               w[j].format = NFLHIP_FMT_WORDS;
             }
-            check(ctx, nflhip_fma_inv_dev(ctx, o0.out->dev, &w[1], &w[2], &w[0], o0.e.code[0], cnt, st), "deferred multiply-add + inverse transform");
+            check(ctx, nflhip_fma_inv_dev(ctx, D[o0.out_pin], &w[1], &w[2], &w[0], o0.e.code[0], cnt, st), "deferred multiply-add + inverse transform");
             coalesced += cnt;   // (two recorded operations per member)
           } else if (cnt == 1) {
-            check(ctx, nflhip_eval_dev(ctx, o0.out->dev, d, size_t(nin), o0.e.code, size_t(o0.len), 1, st), "deferred operator=(expr)");
+            check(ctx, nflhip_eval_dev(ctx, D[o0.out_pin], d, size_t(nin), o0.e.code, size_t(o0.len), 1, st), "deferred operator=(expr)");
           } else {
-            check(ctx, nflhip_eval_strided_dev(ctx, o0.out->dev, ostride, d, stride, size_t(nin), o0.e.code, size_t(o0.len), cnt, st),
+            check(ctx, nflhip_eval_strided_dev(ctx, D[o0.out_pin], ostride, d, stride, size_t(nin), o0.e.code, size_t(o0.len), cnt, st),
                   "deferred operator=(expr)");
           }
           for (size_t k = a; k < b; ++k) launched[sidx[k]] = 1;
@@ -1021,7 +1295,6 @@ template <class P> struct lazy {
       }
       finish_post(idx);
     }
-    guard.complete = true;
   }
 };
 }  // namespace detail

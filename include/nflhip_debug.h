@@ -35,6 +35,12 @@ void nflhip_debug_fused_grid(int mode);
  * only reads it.  Process-wide. */
 int nflhip_debug_polymul_level(int level);
 
+/* role trace of the one-launch plan (rows of 32768 / 65536 words, NFLHIP_XCD): device memory of 32 x 65536 x 16 bytes, zeroed by the
+ * caller; every role of the following products stores {ticket | kind << 28, t0, t1, t2} = when its workgroup became free, when the
+ * role's inputs were ready, when it was done (low words of s_memtime) at record (domain << 16 | sequence number in the domain).
+ * NULL switches the trace off.  tools/xcd_trace.py turns a launch into the table of profiles/r06_E_role_stamps.txt. */
+void nflhip_debug_xcd_trace(void *device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

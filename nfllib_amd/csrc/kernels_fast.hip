@@ -687,6 +687,10 @@ hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64
 // least xcd_plan_bytes(); it is (re)initialised here, on `st`.
 static std::atomic<unsigned long long> g_xcd_launches{0};
 extern "C" unsigned long long nflhip_debug_xcd_launches(void) { return g_xcd_launches.load(); }  // include/nflhip_debug.h
+// test / profiling hook: a device buffer (32 domains x 65536 records x 16 bytes) into which every role of the NEXT one-launch
+// products writes {ticket | kind << 28, t0 = workgroup free, t1 = inputs ready, t2 = done} (low words of s_memtime); nullptr = off
+static std::atomic<void *> g_xcd_trace{nullptr};
+extern "C" void nflhip_debug_xcd_trace(void *device_buffer) { g_xcd_trace.store(device_buffer); }
 __global__ void k_xcd_reset(uint4 *ctl) {   // block 0: the header; block d + 1: record d at byte 4096 + 69632 d (2 KiB each)
   uint4 *p = blockIdx.x == 0 ? ctl : ctl + (4096 + (size_t)(blockIdx.x - 1) * 0x11000) / 16;
   p[threadIdx.x] = make_uint4(0, 0, 0, 0);
@@ -745,7 +749,7 @@ hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *
     int d, rlog, jmax, spin, inv;
     void *scr_a, *scr_b, *ctl, *trace;
   } args = {c, a, b, t.psi, inc ? t.mc_inc[1] : t.mc, (int)s.nm, s.logn, (int)(batch * s.nm), (int)batch, p.magic, p.dlog, p.rlog, 0,
-            1 << 22, 0, w + p.ctl_bytes, w + p.ctl_bytes + p.slot_bytes, w, nullptr};
+            1 << 22, 0, w + p.ctl_bytes, w + p.ctl_bytes + p.slot_bytes, w, g_xcd_trace.load()};
   static_assert(sizeof(args) == 112, "kernarg layout of nflhip_polymul_xcd*_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

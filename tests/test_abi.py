@@ -40,7 +40,7 @@ def test_the_library_exports_exactly_what_its_two_headers_declare():
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and not l.split()[-1].startswith("_Z")}
     exported = {e for e in exported if e not in ("_init", "_fini")}
     assert exported == set(_declared()) | debug, sorted(exported ^ (set(_declared()) | debug))
-    assert len(debug) <= 5     # (round 6: + nflhip_debug_polymul_level)
+    assert len(debug) <= 6     # (round 6: + nflhip_debug_polymul_level, nflhip_debug_xcd_trace)
 
 
 def test_the_library_reads_three_environment_variables():

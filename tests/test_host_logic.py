@@ -55,13 +55,38 @@ def test_the_archive_hook_writes_the_manual_image(mock):
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("limit", [None, 97, 1])
-def test_loop_shapes_deferred_equals_immediate(mock, limit):
+@pytest.mark.parametrize("limit,thread,min_run", [(None, 1, None), (97, 1, None), (1, 1, None), (None, 0, None), (97, 0, None), (None, 1, 16), (50, 1, 7)])
+def test_loop_shapes_deferred_equals_immediate(mock, limit, thread, min_run):
     """the LWE loop, strided / reversed / chained loops, handles dying queued; with the default queue length, with a queue
-    that runs by itself every 97 records (in the middle of groups) and with one that holds a single record"""
-    r = run(os.path.join(mock, "deferred_loops"), 300 if limit != 1 else 40,
-            env=None if limit is None else {"NFL_HIP_QUEUE_LIMIT": str(limit)})
+    that runs by itself every 97 records (in the middle of groups) and with one that holds a single record; runs executed by
+    the queue's own thread (the default: a run that starts by itself is handed over and the program goes on recording) or by
+    the recording thread (NFL_HIP_QUEUE_THREAD=0); hand-overs from 16 / 7 records on (NFL_HIP_QUEUE_MIN: the run lengths of a
+    loop grow geometrically from there)"""
+    env = {"NFL_HIP_QUEUE_THREAD": str(thread)}
+    if limit is not None:
+        env["NFL_HIP_QUEUE_LIMIT"] = str(limit)
+    if min_run is not None:
+        env["NFL_HIP_QUEUE_MIN"] = str(min_run)
+    r = run(os.path.join(mock, "deferred_loops"), 300 if limit != 1 else 40, env=env)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+    if thread and limit == 97:      # the run was really handed over (NFL_HIP_TRACE_DEFERRED names the executing thread)
+        r = run(os.path.join(mock, "deferred_loops"), 60, env=dict(env, NFL_HIP_TRACE_DEFERRED="1"))
+        assert "(the queue's thread)" in r.stderr and "all checks passed" in r.stdout
+
+
+def test_runs_that_start_inside_an_iteration_leave_it_whole(mock):
+    """lazy::clean_cut: a run that starts by itself while an iteration's Gaussian temporaries still have their handles leaves
+    that iteration's records in the queue -- so every sample / transform / multiply-add sequence the one-run queue fuses is
+    still fused when runs start every 97 or 61 records, on either thread"""
+    def fused(env):
+        r = run(os.path.join(mock, "deferred_loops"), 300, env=dict(env, NFL_HIP_TRACE_DEFERRED="1"))
+        assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+        return sum(int(l.split(":")[2].split()[0]) for l in r.stderr.splitlines() if l.startswith("nfl(hip) deferred:") and " kind 6:" in l)
+    whole = fused({"NFL_HIP_QUEUE_THREAD": "0", "NFL_HIP_QUEUE_LIMIT": "1000000"})
+    assert whole >= 300
+    for env in ({"NFL_HIP_QUEUE_THREAD": "0", "NFL_HIP_QUEUE_LIMIT": "97"}, {"NFL_HIP_QUEUE_THREAD": "1", "NFL_HIP_QUEUE_LIMIT": "97", "NFL_HIP_QUEUE_MIN": "16"},
+                {"NFL_HIP_QUEUE_THREAD": "0", "NFL_HIP_QUEUE_LIMIT": "61"}):
+        assert fused(env) == whole, env
 
 
 def test_early_queue_runs_do_not_change_results(mock):
@@ -76,15 +101,16 @@ def test_the_loops_are_coalesced(mock):
     """what deferral is for: the LWE loop's 300 x 10 operations leave as a handful of launches -- with the transform fusion
     (the default where the context has the fused kernels: the toy device says it does) as 300 forward multiply-adds in
     four launches (three compact sampler launches + the fused one) and 300 multiply-subtract-inverse operations in one;
-    without it (NFL_HIP_NO_FUSION=1) operator by operator, as recorded"""
-    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1", "NFL_HIP_NO_FUSION": "1"})
+    without it (NFL_HIP_NO_FUSION=1) operator by operator, as recorded.  (One queue run for the whole loop: the queue's own thread,
+    which would start on the loop's first 2 048 records while the rest is being recorded, is switched off.)"""
+    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1", "NFL_HIP_NO_FUSION": "1", "NFL_HIP_QUEUE_THREAD": "0"})
     assert r.returncode == 0
     lines = [l for l in r.stderr.splitlines() if l.startswith("nfl(hip) deferred:")]
     first_ring = lines[:7]      # level 0: gaussians (3 groups), level 1: transforms, 2: products, 3: decryption, 4: inverse
     ops = sum(int(l.split(":")[2].split()[0]) for l in first_ring)
     launches = sum(int(l.split("->")[1].split()[0]) for l in first_ring)
     assert ops >= 300 * 10 and launches <= 12, first_ring
-    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1"})
+    r = run(os.path.join(mock, "deferred_loops"), 300, env={"NFL_HIP_TRACE_DEFERRED": "1", "NFL_HIP_QUEUE_THREAD": "0"})
     assert r.returncode == 0 and "all checks passed" in r.stdout
     lines = [l for l in r.stderr.splitlines() if l.startswith("nfl(hip) deferred:")]
     fused = [l for l in lines[:6] if " kind 6:" in l or " kind 7:" in l]       # K_FWD_FMA, K_FMA_INV
@@ -101,9 +127,9 @@ def test_the_harness_notices_a_broken_queue(mock, tmp_path):
     shutil.copytree(os.path.join(ROOT, "include"), inc)
     hdr = inc / "nfl_hip" / "queue.hpp"      # (the deferred queue's part of the split header)
     text = hdr.read_text()
-    good = "L = std::max(L, std::max(o.out->wlev, o.out->rlev) + 1);"
+    good = "L = std::max(L, std::max(wlev[o.out_pin], rlev[o.out_pin]) + 1);"
     assert good in text
-    hdr.write_text(text.replace(good, "L = std::max(L, o.out->wlev + 1);"))
+    hdr.write_text(text.replace(good, "L = std::max(L, wlev[o.out_pin] + 1);"))
     exe = str(tmp_path / "fuzz_mutant")
     build_program("deferred_fuzz.cpp", exe, include=str(inc))
     r = run(exe, 40, 1)
@@ -113,7 +139,7 @@ def test_the_harness_notices_a_broken_queue(mock, tmp_path):
 def test_the_harness_notices_a_broken_fusion(mock, tmp_path):
     """a header whose transform fusion forgets that a sampled-and-transformed temporary may still have a handle (or another
     reader) must fail the loop comparison: proof that the look-alike shapes of deferred_loops.cpp bite"""
-    good = {"      return p->fw != d || held[p->pin_at].use_count() == 1;": "      return true;",
+    good = {"      return fw[k] != d || r.dead[k] != 0;": "      return true;",
             "uses[size_t(dn)] != want_uses || ": ""}
     for k, (old, new) in enumerate(good.items()):
         inc = tmp_path / ("include%d" % k)
@@ -154,6 +180,23 @@ def test_random_programs_under_address_and_undefined_behaviour_sanitizers(mock, 
                            os.path.join(ROOT, "tests", "cpp", "deferred_fuzz.cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
     r = run(exe, 12, 99, env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "NFL_HIP_QUEUE_LIMIT": "61"})
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_the_queue_thread_and_one_recording_thread_under_thread_sanitizer(mock, tmp_path):
+    """the hand-over protocol of the queue's own thread (lazy::take / post / execute / collect / retire) under ThreadSanitizer:
+    one recording thread, runs handed over every few records (NFL_HIP_QUEUE_MIN=5, limit 40), random programs and the loop
+    shapes: no data race -- a run works on the per-run arrays take() filled and never touches a payload -- and deferred ==
+    immediate.  (NFL_HIP_NO_BIASED_LOCK: the buffer pool's lock is taken by both threads; its membarrier-based bias is not
+    something ThreadSanitizer can see through.)"""
+    for name, args in (("deferred_fuzz", (25, 31)), ("deferred_loops", (120,))):
+        exe = str(tmp_path / (name + "_tsan"))
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                               "-DNFL_HIP_NO_GMP", "-o", exe, os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
+                               "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+        r = run(exe, *args, env={"NFL_HIP_QUEUE_THREAD": "1", "NFL_HIP_QUEUE_MIN": "5", "NFL_HIP_QUEUE_LIMIT": "40", "NFL_HIP_NO_BIASED_LOCK": "1",
+                                 "TSAN_OPTIONS": "halt_on_error=0"})
+        assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[:4000]
 
 
 def test_threads_with_their_own_handles_share_the_queue_safely(mock, tmp_path):

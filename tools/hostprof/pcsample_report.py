@@ -11,7 +11,7 @@ frames = []
 def flush():
     if frames:
         for fn, loc in frames:
-            if "nfl.hpp" in loc:
+            if "nfl_hip/" in loc:
                 outer[loc.split("/")[-1].split(" ")[0]] += 1
                 break
         else:

@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 6, session m: the queue's own thread (include/nfl_hip/queue.hpp: hand_over / execute) against runs executed by the recording
+# thread: tests/cpp/resident_test (the LWE demo with plain poly_p operators), 16 384 / 2 048 / 1 024 / 4 096 iterations
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out
+make -s -C tests/cpp resident_test deferred_loops deferred_fuzz deferred_threads deferred_edges 2>&1 | tail -3
+{
+echo "# encryptions/s, decryptions/s of the poly_p loop (tests/cpp/resident_test): queue thread on / off, minimum run length (records)"
+for reps in 16384 2048 1024 4096; do
+  for cfg in "0 2048" "1 1024" "1 2048" "1 4096" "1 100000"; do
+    set -- $cfg
+    for rep in 1 2 3; do
+      NFL_HIP_QUEUE_THREAD=$1 NFL_HIP_QUEUE_MIN=$2 NFL_LWE_REPS=$reps timeout 300 tests/cpp/resident_test 2>/dev/null | head -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())['lwe_u64_4096_4']
+print('reps $reps thread $1 min_run $2: poly_p %.3f M enc/s %.3f M dec/s; batch fused %.3f M enc/s; launches %s for %s operations' % (d['poly_p_encryptions_per_s'] / 1e6, d['poly_p_decryptions_per_s'] / 1e6, d['device_batch_fused_encryptions_per_s'] / 1e6, d.get('launches_they_became'), d.get('deferred_operations')))"
+    done
+  done
+done
+echo "# correctness on the real library, queue thread on (default): deferred_loops 300 / deferred_fuzz 40 / deferred_threads / deferred_edges"
+tests/cpp/deferred_loops 300 | tail -1
+NFL_HIP_QUEUE_MIN=64 tests/cpp/deferred_loops 300 | tail -1
+tests/cpp/deferred_fuzz 40 2024 | tail -1
+NFL_HIP_QUEUE_MIN=32 tests/cpp/deferred_fuzz 40 7 | tail -1
+NFL_HIP_QUEUE_LIMIT=37 tests/cpp/deferred_threads 6 400 | tail -1
+tests/cpp/deferred_edges | tail -1
+} > gpurun_out/r06_queue_thread.txt 2>&1
+cat gpurun_out/r06_queue_thread.txt
