@@ -188,11 +188,15 @@ def test_the_queue_thread_and_one_recording_thread_under_thread_sanitizer(mock, 
     shapes: no data race -- a run works on the per-run arrays take() filled and never touches a payload -- and deferred ==
     immediate.  (NFL_HIP_NO_BIASED_LOCK: the buffer pool's lock is taken by both threads; its membarrier-based bias is not
     something ThreadSanitizer can see through.)"""
-    for name, args in (("deferred_fuzz", (25, 31)), ("deferred_loops", (120,))):
+    programs = (("deferred_fuzz", (25, 31)), ("deferred_loops", (120,)))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:      # (the two compilations side by side)
+        list(pool.map(lambda name: subprocess.check_call(
+            ["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o",
+             str(tmp_path / (name + "_tsan")), os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK]),
+            [n for n, _ in programs]))
+    for name, args in programs:
         exe = str(tmp_path / (name + "_tsan"))
-        subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"),
-                               "-DNFL_HIP_NO_GMP", "-o", exe, os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
-                               "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
         r = run(exe, *args, env={"NFL_HIP_QUEUE_THREAD": "1", "NFL_HIP_QUEUE_MIN": "5", "NFL_HIP_QUEUE_LIMIT": "40", "NFL_HIP_NO_BIASED_LOCK": "1",
                                  "TSAN_OPTIONS": "halt_on_error=0"})
         assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
