@@ -303,12 +303,23 @@ template <class P> class device_batch {
     const size_t es = fmt == NFLHIP_FMT_I8 ? 1 : fmt == NFLHIP_FMT_I16 ? 2 : 4, each = (n_ * P::degree * es + 255) / 256 * 256;
     char *buf = static_cast<char *>(small_buffer(each * size_t(nx)));
     nflhip_operand xo[3];
+    void *dst[3];
+    uint64_t sid[3];
+    bool one_table = true;
     for (int j = 0; j < nx; ++j) {
-      detail::check(ctx(), nflhip_sample_gauss_small_dev(ctx(), buf + each * size_t(j), fmt, 0, n_, tab[j], amp[j], s.key, s.next++, queue()),
-                    "set(gaussian), compact");
-      xo[j].ptr = buf + each * size_t(j);
+      dst[j] = buf + each * size_t(j);
+      sid[j] = s.next++;
+      one_table &= tab[j] == tab[0];
+      xo[j].ptr = dst[j];
       xo[j].stride = 1;
       xo[j].format = fmt;
+    }
+    if (one_table) {   // the draws of one generator: one launch
+      detail::check(ctx(), nflhip_sample_gauss_small_multi_dev(ctx(), dst, size_t(nx), fmt, n_, tab[0], amp, s.key, sid, nullptr, queue()),
+                    "set(gaussian), compact");
+    } else {
+      for (int j = 0; j < nx; ++j)
+        detail::check(ctx(), nflhip_sample_gauss_small_dev(ctx(), dst[j], fmt, 0, n_, tab[j], amp[j], s.key, sid[j], queue()), "set(gaussian), compact");
     }
     nflhip_operand ka = key_operand(k0);
     if (out1) {

@@ -1220,14 +1220,19 @@ template <class P> struct lazy {
             const size_t es = fmt == NFLHIP_FMT_I8 ? 1 : fmt == NFLHIP_FMT_I16 ? 2 : 4, each = (cnt * P::degree * es + 255) / 256 * 256;
             char *buf = static_cast<char *>(small_buffer(each * size_t(nx)));
             nflhip_operand x[3], k[2];
+            void *dst[3];
+            uint64_t amp[3];
             for (int j = 0; j < nx; ++j) {
-              check(ctx, nflhip_sample_gauss_small_seq_dev(ctx, buf + each * size_t(j), fmt, cnt, o0.f.tab, o0.f.amp[j], smp.key, o0.f.sid[j],
-                                                           sstride[j], st), "deferred set(gaussian), compact");
-              x[j].ptr = buf + each * size_t(j);
+              dst[j] = buf + each * size_t(j);
+              amp[j] = o0.f.amp[j];
+              x[j].ptr = dst[j];
               x[j].stride = 1;
               x[j].format = fmt;
-              ++launches;
             }
+            // (x, e0, e1 of a fused record are draws of ONE table: one launch for the three)
+            check(ctx, nflhip_sample_gauss_small_multi_dev(ctx, dst, size_t(nx), fmt, cnt, o0.f.tab, amp, smp.key, o0.f.sid, sstride, st),
+                  "deferred set(gaussian), compact");
+            ++launches;
             for (int j = 0; j < nin; ++j) {
               k[j].ptr = D[o0.in_pin[j]];
               k[j].stride = cnt > 1 ? kstride[j] : 0;

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NFLHIP_ABI_VERSION 5
+#define NFLHIP_ABI_VERSION 6
 
 typedef struct nflhip_ctx nflhip_ctx;
 
@@ -389,6 +389,14 @@ int nflhip_sample_gauss_small_dev(nflhip_ctx *ctx, void *d_out, int format, size
 int nflhip_sample_gauss_small_seq_dev(nflhip_ctx *ctx, void *d_out, int format, size_t batch, const nflhip_gauss *g,
                                       uint64_t amplifier, const unsigned char key[32], uint64_t first_stream_id,
                                       uint64_t stream_id_stride, void *stream);
+/* `count` (1..4) compact draws from ONE table in ONE launch: draw j writes `batch` polynomials to d_out[j] with amplifier[j] and is,
+ * byte for byte, nflhip_sample_gauss_small_seq_dev(..., stream_id[j], stream_id_stride[j], ...) when stream_id_stride is given and
+ * nflhip_sample_gauss_small_dev(..., first_poly 0, ..., stream_id[j], ...) when it is NULL.  What an LWE encryption draws per
+ * ciphertext (FastGaussianNoise.hpp:477-595 through tests/nfllib_demo_main_op.cpp:33-35: x, e0, e1 with their own amplifiers):
+ * three launches of a few hundred polynomials each leave wave slots empty in their last round and pay three ramps. */
+int nflhip_sample_gauss_small_multi_dev(nflhip_ctx *ctx, void *const *d_out, size_t count, int format, size_t batch,
+                                        const nflhip_gauss *g, const uint64_t *amplifier, const unsigned char key[32],
+                                        const uint64_t *stream_id, const uint64_t *stream_id_stride, void *stream);
 /* FastGaussianNoise::getNoise(out, rlen) (FastGaussianNoise.hpp:477-595): `count` raw signed samples; sample j is the
  * integer that coefficient first_sample + j of a polynomial batch gets from the same (key, stream_id) */
 int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sample, size_t count, const nflhip_gauss *g,

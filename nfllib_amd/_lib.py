@@ -17,7 +17,7 @@ TAB_PHIS, TAB_SHOUPPHIS, TAB_INVPOLY_INVPHIS, TAB_SHOUPINVPOLY_INVPHIS, TAB_OMEG
 ROW_INVERSE_TABLES, ROW_BITREV_IO = 1, 2
 DIST_REFERENCE_WORDS = 0x100
 DIST_NARROW = 0x200
-ABI_VERSION = 5
+ABI_VERSION = 6
 FMT_WORDS, FMT_I8, FMT_I16, FMT_I32 = range(4)
 
 # every symbol include/nflhip.h declares: (name, restype, argtypes)
@@ -81,6 +81,7 @@ SYMBOLS = [
     ("nflhip_sample_gauss", _i, [_vp, _vp, _sz, _vp, _u64, _vp, _u64]),
     ("nflhip_sample_gauss_small_dev", _i, [_vp, _vp, _i, _sz, _sz, _vp, _u64, _vp, _u64, _vp]),
     ("nflhip_sample_gauss_small_seq_dev", _i, [_vp, _vp, _i, _sz, _vp, _u64, _vp, _u64, _u64, _vp]),
+    ("nflhip_sample_gauss_small_multi_dev", _i, [_vp, _vp, _sz, _i, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("nflhip_gauss_noise_dev", _i, [_vp, _vp, _u64, _sz, _vp, _vp, _u64, _vp]),
     ("nflhip_gauss_noise", _i, [_vp, _vp, _sz, _vp, _vp, _u64]),
     ("nflhip_malloc", _i, [_vp, C.POINTER(_vp), _sz]),

@@ -1706,6 +1706,31 @@ int nflhip_sample_gauss_small_seq_dev(nflhip_ctx *ctx, void *d_out, int format, 
   return gauss_small_any(ctx, d_out, format, 0, batch, g, amplifier, key, first_stream_id, stream, 1, stream_id_stride);
 }
 
+int nflhip_sample_gauss_small_multi_dev(nflhip_ctx *ctx, void *const *d_out, size_t count, int format, size_t batch, const nflhip_gauss *g,
+                                        const uint64_t *amplifier, const unsigned char *key, const uint64_t *stream_id,
+                                        const uint64_t *stream_id_stride, void *stream) {
+  CHECK_CTX(ctx);
+  if (!key || !g || !d_out || !amplifier || !stream_id) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+  if (count < 1 || count > 4) return fail(ctx, NFLHIP_ERR_INVALID, "one to four draws per call");
+  if (g->device != ctx->device) return fail(ctx, NFLHIP_ERR_INVALID, "gaussian table lives on another device");
+  if (format < NFLHIP_FMT_I8 || format > NFLHIP_FMT_I32) return fail(ctx, NFLHIP_ERR_INVALID, "the compact format is int8, int16 or int32");
+  const long long lo = g->tab.x_min, hi = g->tab.x_min + (long long)g->tab.entries - 1;
+  const uint64_t mag = (uint64_t)std::max(lo < 0 ? -lo : lo, hi < 0 ? -hi : hi);
+  const uint64_t cap = format == NFLHIP_FMT_I8 ? 127u : format == NFLHIP_FMT_I16 ? 32767u : 2147483647u;
+  for (size_t j = 0; j < count; ++j) {   // (the checks of gauss_small_any, per draw)
+    if (batch && !d_out[j]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
+    if (amplifier[j] == 0) return fail(ctx, NFLHIP_ERR_INVALID, "amplifier must be positive");
+    if (amplifier[j] > cap || mag > cap / amplifier[j]) return fail(ctx, NFLHIP_ERR_INVALID, "the samples do not fit the compact format");
+    for (uint64_t p : ctx->h_P)
+      if (mag * amplifier[j] >= p) return fail(ctx, NFLHIP_ERR_INVALID, "the samples are not below the modulus");
+  }
+  hipError_t e = launch_gauss_small_multi(ctx->shape, d_out, count, format, batch, g->d_cdt, g->tab.words, (int)g->tab.entries, g->tab.x_min,
+                                          amplifier, key, stream_id, stream_id_stride, (hipStream_t)stream, gauss_narrow(g), g->d_lut);
+  if (e == hipErrorNotSupported) return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "sequence mode needs degree >= 8 (>= 16 under the 32-bit draw)");
+  if (e != hipSuccess) return hipfail(ctx, e, "sample_gauss_small_multi");
+  return NFLHIP_OK;
+}
+
 int nflhip_gauss_noise_dev(nflhip_ctx *ctx, int64_t *d_out, uint64_t first_sample, size_t count, const nflhip_gauss *g,
                            const unsigned char *key, uint64_t stream_id, void *stream) {
   CHECK_CTX(ctx);

@@ -141,6 +141,9 @@ hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_
                               int words, int entries, long long x_min, uint64_t amp, const unsigned char *key32,
                               uint64_t stream_id, hipStream_t st, int seq_on = 0, uint64_t seq_stride = 0, int narrow = 0,
                               const uint16_t *lut = nullptr);
+hipError_t launch_gauss_small_multi(const Shape &s, void *const *d, size_t count, int format, size_t batch, const uint64_t *cdt, int words,
+                                    int entries, long long x_min, const uint64_t *amp, const unsigned char *key32, const uint64_t *stream_id,
+                                    const uint64_t *seq_stride, hipStream_t st, int narrow, const uint16_t *lut);
 template <typename T>
 hipError_t launch_expand_small(const Shape &s, const DevTables &t, T *dst, const void *src, int format, unsigned stride,
                                size_t batch, hipStream_t st);

@@ -561,10 +561,9 @@ __device__ __forceinline__ void gauss_block16(uint64_t g0, const uint32_t *top, 
 
 // compact polynomials, 32-bit draw, n >= 16: a thread's block = 16 consecutive coefficients = 16 / 32 / 64 contiguous bytes
 template <typename S, int W>
-__global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t first_coef, size_t ncoef,
-                                                       const uint64_t *__restrict__ cdt, int entries, long long x_min,
-                                                       long long amp, ChaChaKey key, uint64_t nonce, int tie_shift,
-                                                       const uint16_t *__restrict__ lut_g) {
+__device__ __forceinline__ void gauss_small16_body(S *d, int logn, uint64_t first_coef, size_t ncoef, const uint64_t *__restrict__ cdt, int entries,
+                                                   long long x_min, long long amp, const ChaChaKey &key, uint64_t nonce, int tie_shift,
+                                                   const uint16_t *__restrict__ lut_g) {
   extern __shared__ __attribute__((aligned(16))) uint32_t gtop32[];
   const uint16_t *lut = lut_g ? stage_gauss_top32(gtop32, cdt, lut_g, entries, W) : nullptr;
   const uint64_t n = ((uint64_t)1) << logn;
@@ -598,6 +597,35 @@ __global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t 
       for (int q = 0; q < 4; ++q) reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
   }
+}
+template <typename S, int W>
+__global__ void __launch_bounds__(256) k_gauss_small16(S *d, int logn, uint64_t first_coef, size_t ncoef,
+                                                       const uint64_t *__restrict__ cdt, int entries, long long x_min,
+                                                       long long amp, ChaChaKey key, uint64_t nonce, int tie_shift,
+                                                       const uint16_t *__restrict__ lut_g) {
+  gauss_small16_body<S, W>(d, logn, first_coef, ncoef, cdt, entries, x_min, amp, key, nonce, tie_shift, lut_g);
+}
+// up to four compact draws of one table in ONE launch (blockIdx.y = the draw): an LWE encryption samples x, e0, e1 with their own
+// amplifiers and stream ids, and three launches of a few hundred polynomials each leave a third of the wave slots empty in their
+// last round (1 638 polynomials = 2.1 rounds of the 3 072 slots; three draws together = 6.4)
+struct GaussMulti {
+  void *d[4];
+  long long amp[4];
+  uint64_t nonce[4], stride[4];
+};
+template <typename S, int W>
+__global__ void __launch_bounds__(256) k_gauss_small16_multi(GaussMulti m, int logn, size_t ncoef, const uint64_t *__restrict__ cdt,
+                                                             int entries, long long x_min, ChaChaKey key, int tie_shift,
+                                                             const uint16_t *__restrict__ lut_g) {
+  const unsigned j = blockIdx.y;
+  S *d = nullptr;
+  long long amp = 0;
+  uint64_t nonce = 0, stride = 0;
+#pragma unroll
+  for (unsigned q = 0; q < 4; ++q)   // (no dynamic indexing of the kernel argument)
+    if (q == j) d = static_cast<S *>(m.d[q]), amp = m.amp[q], nonce = m.nonce[q], stride = m.stride[q];
+  key.seq_stride = stride;
+  gauss_small16_body<S, W>(d, logn, 0, ncoef, cdt, entries, x_min, amp, key, nonce, tie_shift, lut_g);
 }
 
 // residue words over the moduli, 32-bit draw, n >= 16: a wave's 1024 results through the wave-local LDS transpose
@@ -1104,6 +1132,49 @@ hipError_t launch_gauss_small(const Shape &s, void *d, int format, size_t first_
   if (format == 1) { NFLHIP_GSW(int8_t) } else if (format == 2) { NFLHIP_GSW(int16_t) } else { NFLHIP_GSW(int32_t) }
 #undef NFLHIP_GSW
 #undef NFLHIP_GS
+  return hipGetLastError();
+}
+
+// `count` compact draws of one table: one launch where the sixteen-per-thread kernel applies (32-bit draw, n >= 16), else one per draw
+hipError_t launch_gauss_small_multi(const Shape &s, void *const *d, size_t count, int format, size_t batch, const uint64_t *cdt, int words,
+                                    int entries, long long x_min, const uint64_t *amp, const unsigned char *key32, const uint64_t *stream_id,
+                                    const uint64_t *seq_stride, hipStream_t st, int narrow, const uint16_t *lut) {
+  if (batch == 0 || count == 0) return hipSuccess;
+  if (count > 4 || words < 1 || words > 6 || format < 1 || format > 3) return hipErrorInvalidValue;
+  const int seq_on = seq_stride != nullptr;
+  if (!(narrow && s.n >= 16) || count == 1) {
+    for (size_t j = 0; j < count; ++j) {
+      hipError_t e = launch_gauss_small(s, d[j], format, 0, batch, cdt, words, entries, x_min, amp[j], key32, stream_id[j], st, seq_on,
+                                        seq_on ? seq_stride[j] : 0, narrow, lut);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  const ChaChaKey key = load_key(key32, kDomGauss32, seq_on, 0);
+  const size_t ncoef = batch * s.n;
+  GaussMulti m = {};
+  for (size_t j = 0; j < count; ++j) {
+    m.d[j] = d[j];
+    m.amp[j] = (long long)amp[j];
+    m.nonce[j] = stream_id[j];
+    m.stride[j] = seq_on ? seq_stride[j] : 0;
+  }
+  const int tie_shift = gauss_tie_shift();
+  const size_t lds = lut ? gauss_narrow_lds(entries) : 0;
+  const dim3 g(grid_for(ncoef / 16), (unsigned)count), b(256);
+#define NFLHIP_GM(S, W) hipLaunchKernelGGL((k_gauss_small16_multi<S, W>), g, b, lds, st, m, s.logn, ncoef, cdt, entries, x_min, key, tie_shift, lut)
+#define NFLHIP_GMW(S)                \
+  switch (words) {                   \
+    case 1: NFLHIP_GM(S, 1); break;  \
+    case 2: NFLHIP_GM(S, 2); break;  \
+    case 3: NFLHIP_GM(S, 3); break;  \
+    case 4: NFLHIP_GM(S, 4); break;  \
+    case 5: NFLHIP_GM(S, 5); break;  \
+    default: NFLHIP_GM(S, 6); break; \
+  }
+  if (format == 1) { NFLHIP_GMW(int8_t) } else if (format == 2) { NFLHIP_GMW(int16_t) } else { NFLHIP_GMW(int32_t) }
+#undef NFLHIP_GMW
+#undef NFLHIP_GM
   return hipGetLastError();
 }
 

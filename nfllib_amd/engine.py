@@ -252,6 +252,21 @@ class Engine:
                                                              first_stream_id, stream_id_stride, self._stream(stream)))
         return d
 
+    def sample_gauss_small_multi(self, ds, g, key, stream_ids, stream_id_strides=None, amplifiers=None, stream=None):
+        """up to four compact draws of one table in ONE launch (nflhip_sample_gauss_small_multi_dev): draw j fills ds[j] exactly as
+        sample_gauss_small_seq(ds[j], g, key, stream_ids[j], stream_id_strides[j], amplifiers[j]) would -- or, without strides, as
+        sample_gauss_small(ds[j], g, key, stream_ids[j], amplifiers[j])"""
+        cnt = len(ds)
+        o, n = self._operand(ds[0])
+        amplifiers = list(amplifiers) if amplifiers is not None else [1] * cnt
+        ptrs = (C.c_void_p * cnt)(*[d.data_ptr() for d in ds])
+        amps = (C.c_uint64 * cnt)(*amplifiers)
+        sids = (C.c_uint64 * cnt)(*stream_ids)
+        strides = (C.c_uint64 * cnt)(*stream_id_strides) if stream_id_strides is not None else None
+        self._chk(self.lib.nflhip_sample_gauss_small_multi_dev(self.ctx, ptrs, cnt, o.format, n, g, amps, self._key(key), sids, strides,
+                                                               self._stream(stream)))
+        return ds
+
     def check_range(self, d, stream=None):
         """CHECK_STRICTMOD's assertion over a resident batch: True iff some word is >= its row's modulus"""
         r = C.c_int(0)

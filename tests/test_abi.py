@@ -25,7 +25,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), "libnflhip.so does not export %s" % n
     bound = {s[0] for s in _lib.SYMBOLS}
     assert bound == set(names), (bound ^ set(names))
-    assert lib.nflhip_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.nflhip_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_the_library_exports_exactly_what_its_two_headers_declare():

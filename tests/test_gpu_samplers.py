@@ -361,3 +361,34 @@ def test_narrow_gaussian_statistics_and_arguments(engine_factory):
     for h in (g, g64):
         e.gauss_destroy(h)
     e8.gauss_destroy(g8)
+
+
+@pytest.mark.parametrize("lb,n,m,draw_bits", [(64, 4096, 4, 32), (64, 1024, 2, 32), (32, 1024, 2, 32), (64, 16, 2, 32), (64, 8, 2, 64), (64, 2048, 2, 64)],
+                         ids=["u64-4096", "u64-1024", "u32-1024", "u64-16", "u64-8-wide", "u64-2048-wide"])
+def test_several_compact_draws_in_one_launch_are_the_single_draws(lb, n, m, draw_bits, engine_factory):
+    """nflhip_sample_gauss_small_multi_dev (what an LWE encryption's x, e0, e1 become): draw j is, byte for byte, the single
+    sequence call (per-polynomial stream ids first + i * stride) -- or, without strides, the single batch call -- with draw j's
+    amplifier and stream id; one to four draws, int8 / int16 / int32, also where the one-launch kernel does not apply (64-bit
+    draw, degree < 16: the library loops) and at a batch that does not fill the grid evenly"""
+    import torch
+    e = engine_factory(lb, n, m)
+    g = e.gauss_create(3.2, security=128, samples=n, draw_bits=draw_bits)
+    for batch in (1, 37):
+        for fmt, amps in ((torch.int8, [1, 2, 2, 1]), (torch.int16, [100, 1, 250, 7]), (torch.int32, [1 << 20, 5, 1, 12345])):
+            for count in (1, 2, 3, 4):
+                sids, strides = [500, 501, 77, 1 << 40][:count], [3, 3, 0, 11][:count]
+                if n >= 16 or draw_bits == 64 and n >= 8:      # sequence form
+                    got = e.sample_gauss_small_multi([torch.zeros((batch, n), dtype=fmt, device="cuda:0") for _ in range(count)], g, KEY, sids, strides,
+                                                     amps[:count])
+                    for j in range(count):
+                        want = e.sample_gauss_small_seq(torch.zeros((batch, n), dtype=fmt, device="cuda:0"), g, KEY, sids[j], strides[j], amplifier=amps[j])
+                        assert torch.equal(got[j], want), ("seq", batch, fmt, count, j)
+                got = e.sample_gauss_small_multi([torch.zeros((batch, n), dtype=fmt, device="cuda:0") for _ in range(count)], g, KEY, sids, None, amps[:count])
+                for j in range(count):
+                    want = e.sample_gauss_small(torch.zeros((batch, n), dtype=fmt, device="cuda:0"), g, KEY, stream_id=sids[j], amplifier=amps[j])
+                    assert torch.equal(got[j], want), ("batch", batch, fmt, count, j)
+    with pytest.raises(NflHipError, match="one to four"):
+        e.sample_gauss_small_multi([torch.zeros((1, n), dtype=torch.int8, device="cuda:0")] * 5, g, KEY, [1] * 5, None, [1] * 5)
+    with pytest.raises(NflHipError, match="do not fit"):
+        e.sample_gauss_small_multi([torch.zeros((1, n), dtype=torch.int8, device="cuda:0")] * 2, g, KEY, [1, 2], None, [1, 120])
+    e.gauss_destroy(g)

@@ -136,39 +136,44 @@ def test_the_harness_notices_a_broken_queue(mock, tmp_path):
     assert r.returncode != 0 and "all checks passed" not in r.stdout
 
 
-def test_the_harness_notices_a_broken_fusion(mock, tmp_path):
-    """a header whose transform fusion forgets that a sampled-and-transformed temporary may still have a handle (or another
-    reader) must fail the loop comparison: proof that the look-alike shapes of deferred_loops.cpp bite"""
-    good = {"      return fw[k] != d || r.dead[k] != 0;": "      return true;",
-            "uses[size_t(dn)] != want_uses || ": ""}
-    for k, (old, new) in enumerate(good.items()):
+def _mutants_fail(tmp_path, edits, tag, also=None):
+    """builds deferred_loops.cpp against copies of include/ with ONE line of queue.hpp changed each (side by side) and expects
+    every one of them to fail the loop comparison"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def build(k):
+        old, new = edits[k]
         inc = tmp_path / ("include%d" % k)
         shutil.copytree(os.path.join(ROOT, "include"), inc)
         hdr = inc / "nfl_hip" / "queue.hpp"      # (the deferred queue's part of the split header)
         text = hdr.read_text()
         assert old in text
-        hdr.write_text(text.replace(old, new).replace("if (ux != 1 && ux != 2) continue;", "if (ux < 1) continue;") if k else text.replace(old, new))
-        exe = str(tmp_path / ("loops_mutant%d" % k))
+        text = text.replace(old, new)
+        if also and k in also:
+            assert also[k][0] in text
+            text = text.replace(*also[k])
+        hdr.write_text(text)
+        exe = str(tmp_path / ("%s_mutant%d" % (tag, k)))
         build_program("deferred_loops.cpp", exe, include=str(inc))
+        return exe
+    with ThreadPoolExecutor(2) as pool:
+        exes = list(pool.map(build, range(len(edits))))
+    for exe in exes:
         r = run(exe, 60)
-        assert r.returncode != 0 and "all checks passed" not in r.stdout
+        assert r.returncode != 0 and "all checks passed" not in r.stdout, exe
+
+
+def test_the_harness_notices_a_broken_fusion(mock, tmp_path):
+    """a header whose transform fusion forgets that a sampled-and-transformed temporary may still have a handle (or another
+    reader) must fail the loop comparison: proof that the look-alike shapes of deferred_loops.cpp bite"""
+    _mutants_fail(tmp_path, [("      return fw[k] != d || r.dead[k] != 0;", "      return true;"), ("uses[size_t(dn)] != want_uses || ", "")], "loops",
+                  also={1: ("if (ux != 1 && ux != 2) continue;", "if (ux < 1) continue;")})
 
 
 def test_the_harness_notices_a_transform_joined_too_eagerly(mock, tmp_path):
     """a header whose transforms join the producing record although the value was read in between, or although that record
     already carries a transform, must fail the loop comparison (section 5 of deferred_loops.cpp)"""
-    good = {"p->rec_r > p->rec_w || ": "", "if (t.post || t.out != p || ": "if (t.out != p || "}
-    for k, (old, new) in enumerate(good.items()):
-        inc = tmp_path / ("include%d" % k)
-        shutil.copytree(os.path.join(ROOT, "include"), inc)
-        hdr = inc / "nfl_hip" / "queue.hpp"      # (the deferred queue's part of the split header)
-        text = hdr.read_text()
-        assert old in text
-        hdr.write_text(text.replace(old, new))
-        exe = str(tmp_path / ("join_mutant%d" % k))
-        build_program("deferred_loops.cpp", exe, include=str(inc))
-        r = run(exe, 60)
-        assert r.returncode != 0 and "all checks passed" not in r.stdout
+    _mutants_fail(tmp_path, [("p->rec_r > p->rec_w || ", ""), ("if (t.post || t.out != p || ", "if (t.out != p || ")], "join")
 
 
 def test_random_programs_under_address_and_undefined_behaviour_sanitizers(mock, tmp_path):
