@@ -87,6 +87,7 @@
 #if defined(__linux__)
 #include <sys/syscall.h>   // membarrier(2): the asymmetric barrier of detail::light_lock
 #include <unistd.h>
+#include <pthread.h>
 #endif
 
 #include "../nflhip.h"

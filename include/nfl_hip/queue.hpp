@@ -855,6 +855,9 @@ template <class P> struct lazy {
     }
   }
   void worker() {
+#if defined(__linux__) && defined(__GLIBC__)
+    pthread_setname_np(pthread_self(), "nflhip-queue");
+#endif
     for (;;) {
       unsigned spins = 0;
       while (st.load(std::memory_order_acquire) != 1 && !quit.load(std::memory_order_relaxed)) {
@@ -880,6 +883,12 @@ template <class P> struct lazy {
   void collect() {
     int s = st.load(std::memory_order_acquire);
     if (s == 0) return;
+    if (s == 1 && th_pid != long(getpid())) {   // a forked child: the run in flight stayed with the parent's thread
+      fly.complete = false;
+      fly.error = std::make_exception_ptr(std::runtime_error("nfl(hip): the process forked while a queue run was in flight"));
+      retire();
+      return;
+    }
     for (unsigned spins = 0; s != 2; s = st.load(std::memory_order_acquire)) {
       if (++spins < 20000) {
         cpu_relax();

@@ -7,11 +7,15 @@
 //   3. a launch that fails in the middle of a queue run: what ran holds its value, what never ran THROWS on access
 //      instead of handing out uninitialised HBM, and overwriting such a handle makes it usable again.  (Needs the CPU
 //      stand-in's failure injection, tests/cpp/mock: skipped against the real library.)
+//   4. the same inside a run that started by itself (on the queue's own thread): everything recorded since is poisoned too;
+//   5. fork() while the queue's thread exists: the child executes its runs itself.  (4 and 5: CPU stand-in only.)
 // Usage: deferred_edges.  Exit code 0 = all checks passed.
 #include <nfl.hpp>
 
 #include <cstdio>
 #include <vector>
+#include <sys/wait.h>
+#include <unistd.h>
 
 extern "C" void mock_fail_after(long) __attribute__((weak));   // only the CPU stand-in defines it
 
@@ -93,6 +97,53 @@ template <class T, size_t Degree, size_t NbModuli> struct ring {
       t = x + y;                                      // overwritten entirely: usable again
       CHECK(words(t) == sv, "a handle that is overwritten entirely is usable again");
       poly_p::synchronize();
+
+      // 4. a launch that fails inside a run that started BY ITSELF (executed by the queue's own thread unless
+      //    NFL_HIP_QUEUE_THREAD=0): the error surfaces at a later record or at the next access, what the run never launched
+      //    throws on access -- and so does what was recorded on top of it while the run was in flight
+      const std::vector<T> sum = words(poly_p(x + y));
+      std::vector<poly_p> v(3000);
+      mock_fail_after(0);                             // the next launch fails: the first launch of the loop's first run
+      size_t threw_at = v.size();
+      for (size_t i = 0; i < v.size(); ++i) {
+        try { v[i] = x + y; } catch (const std::runtime_error &) { threw_at = i; mock_fail_after(-1); break; }
+      }
+      if (threw_at == v.size()) {                     // (a queue longer than the loop: the failure surfaces at the first access)
+        threw = false;
+        try { (void)words(v[0]); } catch (const std::runtime_error &) { threw = true; }
+        mock_fail_after(-1);
+        CHECK(threw, "the failure of a run surfaces at the next access");
+      } else {
+        CHECK(threw_at > 0, "the failure of a run that started by itself surfaces at a later record");
+      }
+      bad_t = false;
+      try { (void)words(v[0]); } catch (const std::runtime_error &) { bad_t = true; }
+      CHECK(bad_t, "what the failed run never launched throws on access");
+      if (threw_at > 1 && threw_at < v.size()) {
+        bad_w = false;
+        try { (void)words(v[threw_at - 1]); } catch (const std::runtime_error &) { bad_w = true; }
+        CHECK(bad_w, "what was recorded while the failed run was in flight throws on access");
+      }
+      for (size_t i = 0; i < v.size(); ++i) v[i] = x + y;   // overwritten entirely: usable again, and the queue works as before
+      CHECK(words(v[0]) == sum && words(v[v.size() - 1]) == sum && words(v[v.size() / 2]) == sum, "the queue works again after a failed run");
+      poly_p::synchronize();
+
+      // 5. fork() with the queue's thread alive: the child has no such thread and executes its runs itself
+      const pid_t pid = fork();
+      if (pid == 0) {
+        bool ok = true;
+        try {
+          std::vector<poly_p> c(2500);
+          for (size_t i = 0; i < c.size(); ++i) c[i] = x + y;
+          ok = words(c[0]) == sum && words(c[c.size() - 1]) == sum;
+        } catch (...) {
+          ok = false;
+        }
+        _exit(ok ? 0 : 3);
+      }
+      int status = -1;
+      CHECK(pid > 0 && waitpid(pid, &status, 0) == pid && WIFEXITED(status) && WEXITSTATUS(status) == 0,
+            "a forked child records and runs its queue without the parent's thread");
     }
   }
 };

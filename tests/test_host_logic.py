@@ -227,7 +227,9 @@ def test_generators_that_die_early_key_changes_and_failing_launches(mock, tmp_pa
     """tests/cpp/deferred_edges.cpp under ASan + UBSan: a FastGaussianNoise destroyed before the polynomials built from it
     are used (its device table must outlive the recorded draws), nfl::set_sampler_key between a random constructor and the
     queue run (deferred == immediate), and a launch that fails in the middle of a queue run (injected by the CPU stand-in):
-    what ran keeps its value, what never ran throws on access, an overwritten handle is usable again"""
+    what ran keeps its value, what never ran throws on access, an overwritten handle is usable again; the same inside a run
+    that started by itself on the queue's own thread (what was recorded while it was in flight is poisoned too, the queue works
+    again afterwards), and fork() with that thread alive (the child runs its queue itself)"""
     exe = str(tmp_path / "edges_asan")
     subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o", exe,
