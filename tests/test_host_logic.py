@@ -29,8 +29,20 @@ def mock():
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o",
                            os.path.join(MOCK, "libnflhip.so"), c, "-lpthread"])
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(3) as pool:   # (the header is the slow part of each: compile the three programs side by side)
-        list(pool.map(lambda name: build_program(name + ".cpp", os.path.join(MOCK, name)), ("deferred_fuzz", "deferred_loops", "serialize_archive")))
+    asan = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    tsan = ["-O1", "-g", "-fsanitize=thread", "-pthread"]
+    jobs = [("deferred_fuzz", "deferred_fuzz", None), ("deferred_loops", "deferred_loops", None), ("serialize_archive", "serialize_archive", None),
+            ("deferred_fuzz", "fuzz_asan", asan), ("deferred_edges", "edges_asan", asan), ("deferred_fuzz", "deferred_fuzz_tsan", tsan),
+            ("deferred_loops", "deferred_loops_tsan", tsan), ("deferred_threads", "threads_tsan", tsan)]
+
+    def build(job):     # (the header is the slow part of each: the programs and their sanitizer builds compile side by side)
+        src, out, flags = job
+        if flags is None:
+            return build_program(src + ".cpp", os.path.join(MOCK, out))
+        subprocess.check_call(["g++", "-std=c++11"] + flags + ["-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o", os.path.join(MOCK, out),
+                               os.path.join(ROOT, "tests", "cpp", src + ".cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+    with ThreadPoolExecutor(6) as pool:
+        list(pool.map(build, jobs))
     return MOCK
 
 
@@ -179,10 +191,7 @@ def test_the_harness_notices_a_transform_joined_too_eagerly(mock, tmp_path):
 def test_random_programs_under_address_and_undefined_behaviour_sanitizers(mock, tmp_path):
     """the same random programs with ASan + UBSan + leak detection: handles dying while queued, the queue's raw payload
     pointers and its one-reference-per-run pins, the buffer pool's free lists"""
-    exe = str(tmp_path / "fuzz_asan")
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                           "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o", exe,
-                           os.path.join(ROOT, "tests", "cpp", "deferred_fuzz.cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+    exe = os.path.join(mock, "fuzz_asan")       # (built by the fixture, beside the others)
     r = run(exe, 12, 99, env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "NFL_HIP_QUEUE_LIMIT": "61"})
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
@@ -194,14 +203,8 @@ def test_the_queue_thread_and_one_recording_thread_under_thread_sanitizer(mock, 
     immediate.  (NFL_HIP_NO_BIASED_LOCK: the buffer pool's lock is taken by both threads; its membarrier-based bias is not
     something ThreadSanitizer can see through.)"""
     programs = (("deferred_fuzz", (25, 31)), ("deferred_loops", (120,)))
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(2) as pool:      # (the two compilations side by side)
-        list(pool.map(lambda name: subprocess.check_call(
-            ["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o",
-             str(tmp_path / (name + "_tsan")), os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK]),
-            [n for n, _ in programs]))
     for name, args in programs:
-        exe = str(tmp_path / (name + "_tsan"))
+        exe = os.path.join(mock, name + "_tsan")
         r = run(exe, *args, env={"NFL_HIP_QUEUE_THREAD": "1", "NFL_HIP_QUEUE_MIN": "5", "NFL_HIP_QUEUE_LIMIT": "40", "NFL_HIP_NO_BIASED_LOCK": "1",
                                  "TSAN_OPTIONS": "halt_on_error=0"})
         assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
@@ -213,10 +216,7 @@ def test_threads_with_their_own_handles_share_the_queue_safely(mock, tmp_path):
     run started by one thread retires the others' operations.  Under ThreadSanitizer, with a queue that runs by itself
     every 37 records: no data race (the copy-on-write test reads the queue's reference and its flag under the queue's
     lock) and every thread's results equal those of the same program run alone."""
-    exe = str(tmp_path / "threads_tsan")
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"),
-                           "-DNFL_HIP_NO_GMP", "-o", exe, os.path.join(ROOT, "tests", "cpp", "deferred_threads.cpp"),
-                           "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+    exe = os.path.join(mock, "threads_tsan")
     for _ in range(3):
         r = run(exe, 6, 400, env={"NFL_HIP_QUEUE_LIMIT": "37", "TSAN_OPTIONS": "halt_on_error=0"})
         assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
@@ -230,10 +230,7 @@ def test_generators_that_die_early_key_changes_and_failing_launches(mock, tmp_pa
     what ran keeps its value, what never ran throws on access, an overwritten handle is usable again; the same inside a run
     that started by itself on the queue's own thread (what was recorded while it was in flight is poisoned too, the queue works
     again afterwards), and fork() with that thread alive (the child runs its queue itself)"""
-    exe = str(tmp_path / "edges_asan")
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                           "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-DNFL_HIP_NO_GMP", "-o", exe,
-                           os.path.join(ROOT, "tests", "cpp", "deferred_edges.cpp"), "-L" + MOCK, "-lnflhip", "-Wl,-rpath," + MOCK])
+    exe = os.path.join(mock, "edges_asan")
     for limit in (None, "64"):
         r = run(exe, env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", **({"NFL_HIP_QUEUE_LIMIT": limit} if limit else {})})
         assert r.returncode == 0 and "with failure injection" in r.stdout and "all checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
