@@ -316,7 +316,7 @@ template <class P> struct lazy {
   // compact Gaussian polynomials of a fused run live in ONE grow-only device buffer (every consumer is on the queue's stream)
   void *small_;
   size_t small_cap_;
-  alignas(64) char pad_[64];
+  alignas(64) char pad_[64];   // (the executing side ends on a line of its own: whatever follows this object is not ours to slow down)
   // records after which the queue runs by itself: long enough for wide launches, short enough that the device works on
   // one part of a loop while the host records the next (NFL_HIP_QUEUE_LIMIT overrides, for experiments).  Measured on the
   // LWE demo loop (profiles/r02_late_queue_limit.txt): 2 048 iterations 614 k / 738 k / 1.04 M / 861 k encryptions/s with
