@@ -885,13 +885,14 @@ def main():
     # kernel with every HBM, twiddle and LDS access removed (only the butterflies' arithmetic left), as a fraction of the same
     # 8 TB/s: the most this instruction stream can reach on this part whatever the memory system does.
     if kwl == "B":
-        ceil = 0.32
+        ceil = 0.351
         result["roofline"].update({
             "binding": "valu-issue at the package power limit",
             "ceiling_frac_no_memory": ceil,
-            "ceiling_measured": "round 3 (not re-measured in this run)",
-            "ceiling_source": "profiles/r03_power_ablation.txt: the metric kernel with HBM, twiddle and LDS traffic removed runs 6.56 M polymul/s "
-                              "(x 393 216 B = 2.58 TB/s = 0.32 of 8 TB/s) at 1 290-1 395 W of the 1 400 W package limit, sclk ~2.07 GHz",
+            "ceiling_measured": "round 6, session v, on the shipped incomplete-transform kernel (not re-measured in this run)",
+            "ceiling_source": "profiles/r06_power_ablation.txt: nflhip_polymul4096i2_asm with HBM, twiddle and LDS traffic removed runs 7.15 M polymul/s "
+                              "(x 393 216 B = 2.81 TB/s = 0.351 of 8 TB/s) at 1 293 W, sclk 2.39 GHz; shipped, same box, same 6 s hold: 6.05 M/s at "
+                              "1 333-1 374 W, sclk 2.11-2.17 GHz (operands in the L2 alone: 7.07 M/s at 2.35 GHz -- what HBM traffic costs is clock)",
             "frac_of_ceiling": round(achieved / HBM_PEAK_GBS / ceil, 4)})
     # secondary ceiling (BASELINE.md section 4 asks for it beside the HBM roofline): VALU issue.  `peak` / `frac` are the
     # HARDWARE ceiling and do not depend on this kernel or this run: one wave64 VALU instruction per SIMD every 2 cycles
