@@ -26,7 +26,9 @@ void nflhip_debug_host_pipe_seconds(const struct nflhip_ctx *ctx, double out[4])
 /* variants of the transform-fused kernels: 0 = the library's policy (forward entries with compact inputs and more than one
  * modulus deal the nm rows of a batch element to one XCD, everything else runs one workgroup per (element, modulus) in a
  * 2-D grid; at degree 4096 the inverse entries run on the ring-mode register map, the forward ones on the pair-mode map),
- * 1 = always the 2-D grid, 2 = always the XCD-dealt 1-D grid, 3 = the other register map at degree 4096.  Same results. */
+ * 1 = always the 2-D grid, 2 = always the XCD-dealt 1-D grid, 3 = the other register map at degree 4096, 4 = rows of 1024 / 2048 (/ 4096
+ * at 32-bit limbs) words run the compiled one-pass template (kernels_wave.hip k_row_fwd_fma / k_row_fma_inv) instead of the generated
+ * wave-per-row kernels: their same-box A/B partner.  Same results. */
 void nflhip_debug_fused_grid(int mode);
 
 /* which kernel serves nflhip_polymul[_dev] at 64-bit limbs, degree 4096, coefficient-form operands: 0 = complete transforms,

@@ -217,6 +217,11 @@ hipError_t launch_row128_u16_asm(const Shape &s, const DevTables &t, int mode, u
 hipError_t launch_row1024_u32_asm(const Shape &s, const DevTables &t, int mode, uint32_t *c, const uint32_t *a,
                                   const uint32_t *b, size_t batch, hipStream_t st);
 // ... their transform-fused pipelines (formats words / int8, strides 0 / 1; hipErrorNotSupported: the compiled kernels)
+hipError_t launch_row_fwd_fma_u32_asm(const Shape &s, const DevTables &t, int format, uint32_t *out0, uint32_t *out1, const void *x, unsigned xs,
+                                      const uint32_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint32_t *k1, unsigned k1s,
+                                      const void *e1, unsigned e1s, size_t batch, hipStream_t st);
+hipError_t launch_row_fma_inv_u32_asm(const Shape &s, const DevTables &t, int subtract, uint32_t *c, const uint32_t *a, const uint32_t *key,
+                                      int kstride, const uint32_t *b, size_t batch, hipStream_t st);
 hipError_t launch_row_fwd_fma_u64_asm(const Shape &s, const DevTables &t, int format, uint64_t *out0, uint64_t *out1, const void *x, unsigned xs,
                                       const uint64_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint64_t *k1, unsigned k1s,
                                       const void *e1, unsigned e1s, size_t batch, hipStream_t st);

@@ -375,6 +375,9 @@ enum AsmKind {
   kAsmRowEnc2W1024U64, kAsmRowEnc2W2048U64, kAsmRowEnc2I81024U64, kAsmRowEnc2I82048U64,                  //   NTT(x) k + NTT(e), two results; words / int8 inputs
   kAsmRowFmaFwdW1024U64, kAsmRowFmaFwdW2048U64, kAsmRowFmaFwdI81024U64, kAsmRowFmaFwdI82048U64,          //   ... one result
   kAsmRow1024I2U32, kAsmRow2048I2U32, kAsmRow4096I2U32,                                                  // 32-bit limbs: the product on incomplete transforms
+  kAsmRowFmsInv1024U32, kAsmRowFmsInv2048U32, kAsmRowFmsInv4096U32, kAsmRowFmaInv1024U32, kAsmRowFmaInv2048U32, kAsmRowFmaInv4096U32,   // 32-bit limbs: INTT(b -+ a k)
+  kAsmRowEnc2W1024U32, kAsmRowEnc2W2048U32, kAsmRowEnc2W4096U32, kAsmRowEnc2I81024U32, kAsmRowEnc2I82048U32, kAsmRowEnc2I84096U32,     //   NTT(x) k + NTT(e), two results; words / int8
+  kAsmRowFmaFwdW1024U32, kAsmRowFmaFwdW2048U32, kAsmRowFmaFwdW4096U32, kAsmRowFmaFwdI81024U32, kAsmRowFmaFwdI82048U32, kAsmRowFmaFwdI84096U32,   //   ... one result
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return (k >= kAsmPolymul8k && k <= kAsmInv8k) || k == kAsmPolymul8kI2; }
@@ -410,6 +413,12 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_row1024_enc2w_u64_asm", "nflhip_row2048_enc2w_u64_asm", "nflhip_row1024_enc2i8_u64_asm", "nflhip_row2048_enc2i8_u64_asm",
     "nflhip_row1024_fmafwdw_u64_asm", "nflhip_row2048_fmafwdw_u64_asm", "nflhip_row1024_fmafwdi8_u64_asm", "nflhip_row2048_fmafwdi8_u64_asm",
     "nflhip_row1024_i2_u32_asm", "nflhip_row2048_i2_u32_asm", "nflhip_row4096_i2_u32_asm",
+    "nflhip_row1024_fmsinv_u32_asm", "nflhip_row2048_fmsinv_u32_asm", "nflhip_row4096_fmsinv_u32_asm",
+    "nflhip_row1024_fmainv_u32_asm", "nflhip_row2048_fmainv_u32_asm", "nflhip_row4096_fmainv_u32_asm",
+    "nflhip_row1024_enc2w_u32_asm", "nflhip_row2048_enc2w_u32_asm", "nflhip_row4096_enc2w_u32_asm",
+    "nflhip_row1024_enc2i8_u32_asm", "nflhip_row2048_enc2i8_u32_asm", "nflhip_row4096_enc2i8_u32_asm",
+    "nflhip_row1024_fmafwdw_u32_asm", "nflhip_row2048_fmafwdw_u32_asm", "nflhip_row4096_fmafwdw_u32_asm",
+    "nflhip_row1024_fmafwdi8_u32_asm", "nflhip_row2048_fmafwdi8_u32_asm", "nflhip_row4096_fmafwdi8_u32_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -831,6 +840,7 @@ hipError_t launch_row1024_u64_asm(const Shape &s, const DevTables &t, int mode, 
 hipError_t launch_row_fwd_fma_u64_asm(const Shape &s, const DevTables &t, int format, uint64_t *out0, uint64_t *out1, const void *x, unsigned xs,
                                       const uint64_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint64_t *k1, unsigned k1s,
                                       const void *e1, unsigned e1s, size_t batch, hipStream_t st) {
+  if (g_fused_grid.load(std::memory_order_relaxed) == 4) return hipErrorNotSupported;   // (nflhip_debug_fused_grid: the compiled one-pass template instead)
   if (s.limb_bits != 64 || s.logn < 10 || s.logn > 11 || s.compiled_only || !s.small_delta || (format != 0 && format != 1)) return hipErrorNotSupported;
   if (xs > 1 || k0s > 1 || e0s > 1 || (out1 && (k1s > 1 || e1s > 1))) return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
@@ -856,6 +866,7 @@ hipError_t launch_row_fwd_fma_u64_asm(const Shape &s, const DevTables &t, int fo
 }
 hipError_t launch_row_fma_inv_u64_asm(const Shape &s, const DevTables &t, int subtract, uint64_t *c, const uint64_t *a, const uint64_t *key,
                                       int kstride, const uint64_t *b, size_t batch, hipStream_t st) {
+  if (g_fused_grid.load(std::memory_order_relaxed) == 4) return hipErrorNotSupported;   // (nflhip_debug_fused_grid: the compiled one-pass template instead)
   if (s.limb_bits != 64 || s.logn < 10 || s.logn > 11 || s.compiled_only || !s.small_delta || kstride < 0 || kstride > 1) return hipErrorNotSupported;
   const unsigned long long rows = (unsigned long long)batch * s.nm;
   if (rows == 0) return hipSuccess;
@@ -872,6 +883,60 @@ hipError_t launch_row_fma_inv_u64_asm(const Shape &s, const DevTables &t, int su
     unsigned kstride, pad;
   } args = {c, a, b, t.psi, t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows, key, (unsigned)kstride, 0u};
   static_assert(sizeof(args) == 72, "kernarg layout of nflhip_row*_fm?inv_u64_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
+}
+
+// 32-bit limbs, n = 1024 / 2048 / 4096: the transform-fused pipelines (tools/gen_row1024_u32_asm.py build_fwd_fma / build_fma_inv): operands
+// of format words or int8, strides 0 / 1; hipErrorNotSupported: the compiled k_row_fwd_fma / k_row_fma_inv (kernels_wave.hip).  The forward
+// kinds reduce x k + e (lazily reduced x, e) with the base multiplication's Barrett step: they read the level-2 records
+hipError_t launch_row_fwd_fma_u32_asm(const Shape &s, const DevTables &t, int format, uint32_t *out0, uint32_t *out1, const void *x, unsigned xs,
+                                      const uint32_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint32_t *k1, unsigned k1s,
+                                      const void *e1, unsigned e1s, size_t batch, hipStream_t st) {
+  if (g_fused_grid.load(std::memory_order_relaxed) == 4) return hipErrorNotSupported;   // (nflhip_debug_fused_grid: the compiled one-pass template instead)
+  if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || s.compiled_only || !t.mc_inc[1] || (format != 0 && format != 1)) return hipErrorNotSupported;
+  if (xs > 1 || k0s > 1 || e0s > 1 || (out1 && (k1s > 1 || e1s > 1))) return hipErrorNotSupported;
+  const unsigned long long rows = (unsigned long long)batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;
+  const int first = out1 ? (format == 0 ? kAsmRowEnc2W1024U32 : kAsmRowEnc2I81024U32) : (format == 0 ? kAsmRowFmaFwdW1024U32 : kAsmRowFmaFwdI81024U32);
+  hipFunction_t fn = asm_fn((AsmKind)(first + (s.logn - 10)));
+  if (!fn) return hipErrorNotSupported;
+  const unsigned rpb = 4u >> (s.logn - 10);
+  struct {
+    void *out0, *out1;
+    const void *x, *psi, *mc;
+    unsigned nm, magic;
+    const void *k0, *e0, *k1, *e1;
+    unsigned long long rows;
+    unsigned xs, k0s, e0s, k1s, e1s, pad;
+  } args = {out0, out1, x, t.psi, t.mc_inc[1], (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), k0, e0, out1 ? k1 : k0,
+            out1 ? e1 : e0, rows, xs, k0s, e0s, out1 ? k1s : 0u, out1 ? e1s : 0u, 0u};
+  static_assert(sizeof(args) == 112, "kernarg layout of nflhip_row*_enc2*_u32_asm");
+  size_t size = sizeof(args);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);
+}
+hipError_t launch_row_fma_inv_u32_asm(const Shape &s, const DevTables &t, int subtract, uint32_t *c, const uint32_t *a, const uint32_t *key,
+                                      int kstride, const uint32_t *b, size_t batch, hipStream_t st) {
+  if (g_fused_grid.load(std::memory_order_relaxed) == 4) return hipErrorNotSupported;   // (nflhip_debug_fused_grid: the compiled one-pass template instead)
+  if (s.limb_bits != 32 || s.logn < 10 || s.logn > 12 || s.compiled_only || kstride < 0 || kstride > 1) return hipErrorNotSupported;
+  const unsigned long long rows = (unsigned long long)batch * s.nm;
+  if (rows == 0) return hipSuccess;
+  if (rows * s.nm >= (1ull << 32)) return hipErrorNotSupported;
+  hipFunction_t fn = asm_fn((AsmKind)((subtract ? kAsmRowFmsInv1024U32 : kAsmRowFmaInv1024U32) + (s.logn - 10)));
+  if (!fn) return hipErrorNotSupported;
+  const unsigned rpb = 4u >> (s.logn - 10);
+  struct {
+    void *c;
+    const void *a, *b, *psi, *mc;
+    unsigned nm, magic;
+    unsigned long long rows;
+    const void *key;
+    unsigned kstride, pad;
+  } args = {c, a, b, t.psi, t.mc, (unsigned)s.nm, s.nm == 1 ? 0u : (unsigned)((1ull << 32) / s.nm + 1), rows, key, (unsigned)kstride, 0u};
+  static_assert(sizeof(args) == 72, "kernarg layout of nflhip_row*_fm?inv_u32_asm");
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   return hipModuleLaunchKernel(fn, (unsigned)((rows + rpb - 1) / rpb), 1, 1, 256, 1, 1, 0, st, nullptr, extra);

@@ -546,6 +546,10 @@ hipError_t launch_row_fwd_fma_u32(const Shape &s, const DevTables &t, int format
                                   const uint32_t *k0, unsigned k0s, const void *e0, unsigned e0s, const uint32_t *k1, unsigned k1s, const void *e1,
                                   unsigned e1s, size_t batch, hipStream_t st) {
   if (s.limb_bits != 32) return hipErrorNotSupported;
+  {  // the generated kernels (tools/gen_row1024_u32_asm.py build_fwd_fma) where they cover the call
+    const hipError_t e = launch_row_fwd_fma_u32_asm(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (s.logn == 10) return launch_fwd_fma_rows<Pol32, 4>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
   if (s.logn == 11) return launch_fwd_fma_rows<Pol32, 8>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
   if (s.logn == 12) return launch_fwd_fma_rows<Pol32M, 16>(s, t, format, out0, out1, x, xs, k0, k0s, e0, e0s, k1, k1s, e1, e1s, batch, st);
@@ -582,6 +586,10 @@ static hipError_t launch_fma_inv_rows(const Shape &s, const DevTables &t, int su
 hipError_t launch_row_fma_inv_u32(const Shape &s, const DevTables &t, int subtract, uint32_t *c, const uint32_t *a, const uint32_t *key,
                                   int kstride, const uint32_t *b, size_t batch, hipStream_t st) {
   if (s.limb_bits != 32) return hipErrorNotSupported;
+  {
+    const hipError_t e = launch_row_fma_inv_u32_asm(s, t, subtract, c, a, key, kstride, b, batch, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (s.logn == 10) return launch_fma_inv_rows<Pol32, 4>(s, t, subtract, c, a, key, kstride, b, batch, st);
   if (s.logn == 11) return launch_fma_inv_rows<Pol32, 8>(s, t, subtract, c, a, key, kstride, b, batch, st);
   if (s.logn == 12) return launch_fma_inv_rows<Pol32M, 16>(s, t, subtract, c, a, key, kstride, b, batch, st);

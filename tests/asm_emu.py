@@ -976,6 +976,23 @@ for _name, _nw in (("b32", 1), ("b64", 2), ("b128", 4)):
     HANDLERS["ds_read_" + _name] = _ds(_nw, False)
 
 
+def _ds_read_i8(w, ops, mods):
+    """one byte per lane, sign-extended (the compact rows of tools/gen_row1024_u32_asm.py build_fwd_fma)"""
+    imm = mods.get("offset", 0)
+    w.use_v(ops[1][1])
+    w.def_v(ops[0][1], 1)
+    if w.exec:
+        addr = _get(w, ops[1][1]).astype(np.int64) + imm
+        idx = addr >> 2
+        w.lds_touch(idx, False)
+        byte = (w.lds[idx].astype(np.uint64) >> ((addr & 3) << 3).astype(np.uint64)) & np.uint64(0xff)
+        _put(w, ops[0][1], np.where(byte >= 128, byte | np.uint64(0xffffff00), byte).astype(np.uint64))
+    w.issue(w.lgkm_q, range(ops[0][1], ops[0][1] + 1))
+
+
+HANDLERS["ds_read_i8"] = _ds_read_i8
+
+
 def _workgroup(waves):
     """generator over one workgroup: its waves advance from barrier to barrier in turn; yields at every s_sleep"""
     nw = len(waves[0].lds)
@@ -1113,14 +1130,15 @@ def run_row_kernel(asm_path, limb_bits, n, nm, prm, a, b, rows_per_wg, with_magi
     return out[:c.nbytes].view(a.dtype).reshape(a.shape).copy()
 
 
-def run_row_fused(asm_path, n, nm, prm, rows_per_wg, kind, **kw):
-    """the transform-fused wave-per-row kernels of tools/asmgen/rows1k.py (64-bit limbs, rows of 1024 / 2048 words).
+def run_row_fused(asm_path, n, nm, prm, rows_per_wg, kind, limb_bits=64, incomplete=0, **kw):
+    """the transform-fused wave-per-row kernels of tools/asmgen/rows1k.py (64-bit limbs, rows of 1024 / 2048 words) and of
+    tools/gen_row1024_u32_asm.py (32-bit limbs, 1024 / 2048 / 4096 words; their forward kinds read the level-2 records: incomplete=2).
     kind "inv": c = INTT(b -+ a k): kw a, b (batch, nm, n) words, key (1 or batch, nm, n) -> c
     kind "fwd": out0 = NTT(x) k0 + NTT(e0) [, out1 = NTT(x) k1 + NTT(e1)]: kw x, e0[, e1]: (B, nm, n) words or (B, n) int8 with B = 1
     (shared by the batch) or batch; k0[, k1] (1 or batch, nm, n) -> out0[, out1]"""
     import struct
     mem = Memory()
-    psi, mc = device_tables(64, n, nm, prm)
+    psi, mc = device_tables(limb_bits, n, nm, prm, incomplete=incomplete)
     ppsi, pmc = mem.add(psi), mem.add(mc)
     magic = lambda: 0 if nm == 1 else ((1 << 32) // nm + 1)
     with open(asm_path) as f:
@@ -1140,7 +1158,8 @@ def run_row_fused(asm_path, n, nm, prm, rows_per_wg, kind, **kw):
     e1, k1 = kw.get("e1"), kw.get("k1")
     batch = kw["batch"]
     rows = batch * nm
-    o0 = np.zeros((batch, nm, n), dtype=np.uint64)
+    wdt = np.uint64 if limb_bits == 64 else np.uint32
+    o0 = np.zeros((batch, nm, n), dtype=wdt)
     o1 = np.zeros_like(o0)
     stride = lambda arr: 0 if arr.shape[0] == 1 and batch > 1 else 1
     px, pe0, pk0, po0, po1 = mem.add(x.copy()), mem.add(e0.copy()), mem.add(k0.copy()), mem.add(o0), mem.add(o1)
@@ -1153,7 +1172,7 @@ def run_row_fused(asm_path, n, nm, prm, rows_per_wg, kind, **kw):
     res = []
     for ptr, arr in ((po0, o0), (po1, o1))[:2 if k1 is not None else 1]:
         buf, _ = mem.find(ptr, arr.nbytes)
-        res.append(buf[:arr.nbytes].view(np.uint64).reshape(arr.shape).copy())
+        res.append(buf[:arr.nbytes].view(wdt).reshape(arr.shape).copy())
     return res
 
 

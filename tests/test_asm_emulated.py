@@ -210,6 +210,54 @@ def test_emulated_u64_wave_per_row_fused_pipelines(n, nm, batch, generated, orac
             assert np.array_equal(r[0], w0) and (not two or np.array_equal(r[1], w1)), stem
 
 
+@pytest.mark.parametrize("n,nm,batch", [(1024, 3, 3), (2048, 2, 2), (4096, 1, 2)])
+def test_emulated_u32_wave_per_row_fused_pipelines(n, nm, batch, generated, oracle_factory):
+    """tools/gen_row1024_u32_asm.py build_fwd_fma / build_fma_inv (32-bit limbs, one / two / four waves per row): out0 = NTT(x) k0 +
+    NTT(e0) [, out1 = NTT(x) k1 + NTT(e1)] with word and int8 operands (extreme bytes included), shared (stride 0) and dense keys / x,
+    and INTT(b -+ a k) -- against the operator-by-operator oracle; odd row counts leave surplus waves / rows in the last workgroup"""
+    ADD, SUB, MUL = 0, 1, 2
+    o = oracle_factory(32, n, nm)
+    from nfllib_amd.params import params
+    prm = params(32)
+    rng = np.random.default_rng(47)
+    P = np.asarray(prm.P[:nm], dtype=np.uint32)
+    rnd = lambda B: (rng.integers(0, 1 << 30, size=(B, nm, n), dtype=np.uint32) % P[None, :, None])
+    def small(B):
+        v = rng.integers(-128, 128, size=(B, n)).astype(np.int8)
+        v[:, :4] = (-128, 127, -1, 0)
+        return v
+    expand = lambda v: np.where(v.astype(np.int64)[:, None, :] < 0, P.astype(np.int64)[None, :, None] + v.astype(np.int64)[:, None, :],
+                                v.astype(np.int64)[:, None, :]).astype(np.uint32)
+    rpw = 4096 // n
+    a, b = rnd(batch), rnd(batch)
+    a[batch - 1], b[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    for key in (rnd(1), rnd(batch)):
+        key[0, :, :2] = (P - 1)[:, None]
+        kk = np.broadcast_to(key, (batch, nm, n)).copy()
+        for sub, stem in ((True, "fmsinv"), (False, "fmainv")):
+            want = o.intt(o.pointwise(SUB if sub else ADD, b, o.pointwise(MUL, a, kk)))
+            got = asm_emu.run_row_fused(generated("row%d_%s_u32" % (n, stem)), n, nm, prm, rpw, "inv", limb_bits=32, a=a, b=b, key=key)
+            assert np.array_equal(got, want), (stem, key.shape)
+    for fmt in ("w", "i8"):
+        for two, xb in ((True, 1), (False, batch)):
+            if fmt == "w":
+                x, e0, e1 = rnd(xb), rnd(batch), rnd(batch)
+                X, E0, E1 = x, e0, e1
+            else:
+                x, e0, e1 = small(xb), small(batch), small(batch)
+                X, E0, E1 = expand(x), expand(e0), expand(e1)
+            Xb = np.broadcast_to(X, (batch, nm, n)).copy()
+            k0, k1 = rnd(1), rnd(batch)
+            k0[0, :, :2] = (P - 1)[:, None]
+            K0 = np.broadcast_to(k0, (batch, nm, n)).copy()
+            w0 = o.pointwise(ADD, o.pointwise(MUL, o.ntt(Xb), K0), o.ntt(E0))
+            w1 = o.pointwise(ADD, o.pointwise(MUL, o.ntt(Xb), k1), o.ntt(E1))
+            stem = ("enc2" if two else "fmafwd") + fmt
+            r = asm_emu.run_row_fused(generated("row%d_%s_u32" % (n, stem)), n, nm, prm, rpw, "fwd", limb_bits=32, incomplete=2, x=x, e0=e0, k0=k0,
+                                      e1=e1 if two else None, k1=k1 if two else None, batch=batch)
+            assert np.array_equal(r[0], w0) and (not two or np.array_equal(r[1], w1)), stem
+
+
 @pytest.mark.parametrize("level", [1, 2])
 def test_incomplete_transform_algebra_in_integers(level):
     """what tools/asmgen/incomplete.py relies on, on Python integers at n = 64: after S = log2(n) - level stages of the merged

@@ -221,6 +221,34 @@ def test_both_grids_of_the_fused_kernels_give_the_same_words(engine_factory):
         e.gauss_destroy(g)
 
 
+@pytest.mark.parametrize("lb,n,nm", [(32, 1024, 2), (32, 2048, 3), (32, 4096, 2), (64, 1024, 2), (64, 2048, 1)])
+def test_generated_and_compiled_wave_per_row_pipelines_give_the_same_words(lb, n, nm, engine_factory):
+    """rows of 1024 / 2048 (/ 4096 at 32-bit limbs) words: the generated fused kernels (tools/gen_row1024_u32_asm.py build_fwd_fma /
+    build_fma_inv, tools/asmgen/rows1k.py) and the compiled one-pass template they replace (nflhip_debug_fused_grid(4)), int8 and word
+    operands, shared and dense keys, ragged batches (surplus waves / rows in the last workgroup)"""
+    import torch
+    from nfllib_amd import _lib
+    from nfllib_amd._lib import FMT_I8
+    e = engine_factory(lb, n, nm)
+    g = e.gauss_create(3.19, 128, 1 << 10)
+    try:
+        for batch in (1, 3, 10, 65):
+            xs = [e.sample_gauss_small(e.empty_small(batch, FMT_I8), g, KEY, 40 + i, amplifier=3) for i in range(3)]
+            ws = [e.fill_uniform(e.empty(batch), 5, i) for i in range(3)]
+            k0, k1 = e.fill_uniform(e.empty(1), 6, 0), e.fill_uniform(e.empty(batch), 6, 1)
+            got = []
+            for mode in (4, 0):
+                _lib.lib.nflhip_debug_fused_grid(mode)
+                a0, a1 = e.fwd_fma2(xs[0], k0, xs[1], k1, xs[2])
+                b0, b1 = e.fwd_fma2(ws[0], k1, ws[1], k0, ws[2])
+                got.append((a0, a1, b0, b1, e.fwd_fma(xs[2], k1, xs[0]), e.fwd_fma(ws[1], k0, ws[0]),
+                            e.fma_inv(a0, k0, a1, subtract=True), e.fma_inv(b0, k1, b1, subtract=False)))
+            assert all(torch.equal(p, q) for p, q in zip(got[0], got[1])), batch
+    finally:
+        _lib.lib.nflhip_debug_fused_grid(0)
+        e.gauss_destroy(g)
+
+
 def test_ambiguous_operand_shapes_are_refused(engine_factory):
     """torch has no unsigned 16 / 32-bit types: a u32 ring's words and the compact int32 format share a dtype, so the shape
     must name the format -- [count][nmoduli][degree] words, [count][degree] compact -- and anything else raises."""
