@@ -874,8 +874,8 @@ def main():
                      "kernel": {"A": "nflhip_row1024_i2_u32_asm", "B": "nflhip_polymul4096i2_asm (2 stages dropped each way, base multiplication mod X^4 -+ zeta)",
                                 "C": "nflhip_polymul16384i2_asm",
                                 "E": "nflhip_polymul_pipe65536nti2_asm (block products on incomplete transforms + streaming passes, 6 launches per step)",
-                                "F": "nflhip_ntt_fwd32768s_asm (b -> scratch, layout [block][pair][thread]) + nflhip_polymul_ntt32768s_asm (a, b' streamed): "
-                                     "register-resident 32768-word rows, 2 launches per step" if batch * nm >= 256 else
+                                "F": "nflhip_ntt_fwd32768si2_asm (b -> scratch two stages short, layout [block][pair][thread]) + nflhip_polymul_ntt32768si2_asm "
+                                     "(a, b' streamed, base multiplication mod X^4 -+ zeta): register-resident 32768-word rows, 2 launches per step" if batch * nm >= 256 else
                                      "nflhip_polymul_xcd32768_asm (one launch of persistent workgroups; fewer than 256 rows)",
                                 "G": "nflhip_polymul8192i2_asm", "H": "nflhip_row128_u16_asm", "T": "nflhip_row8_u32_asm"}[kwl],
                      "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": launch_bytes},

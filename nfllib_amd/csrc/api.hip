@@ -591,9 +591,11 @@ static int polymul_composed(nflhip_ctx *ctx, T *c, const T *a, const T *b, int b
     if (!cap && ctx->ev_scratch_valid) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
     if (!cap && ctx->ev_prev_valid)
       for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_done[k], 0));
-    e = launch_row32k_u64(ctx->shape, ctx->tabs, 4, (uint64_t *)ctx->scratch, (const uint64_t *)b, nullptr, batch, st);
+    // (the level is read ONCE per product: both launches must agree on what b' is)
+    const int pair = polymul_level() == 2 && ctx->tabs.mc_inc[1] ? 6 : 4;
+    e = launch_row32k_u64(ctx->shape, ctx->tabs, pair, (uint64_t *)ctx->scratch, (const uint64_t *)b, nullptr, batch, st);
     if (e == hipSuccess)
-      e = launch_row32k_u64(ctx->shape, ctx->tabs, 5, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)ctx->scratch, batch, st);
+      e = launch_row32k_u64(ctx->shape, ctx->tabs, pair + 1, (uint64_t *)c, (const uint64_t *)a, (const uint64_t *)ctx->scratch, batch, st);
     if (e == hipSuccess) {
       if (!cap) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_scratch, st));

@@ -378,11 +378,12 @@ enum AsmKind {
   kAsmRowFmsInv1024U32, kAsmRowFmsInv2048U32, kAsmRowFmsInv4096U32, kAsmRowFmaInv1024U32, kAsmRowFmaInv2048U32, kAsmRowFmaInv4096U32,   // 32-bit limbs: INTT(b -+ a k)
   kAsmRowEnc2W1024U32, kAsmRowEnc2W2048U32, kAsmRowEnc2W4096U32, kAsmRowEnc2I81024U32, kAsmRowEnc2I82048U32, kAsmRowEnc2I84096U32,     //   NTT(x) k + NTT(e), two results; words / int8
   kAsmRowFmaFwdW1024U32, kAsmRowFmaFwdW2048U32, kAsmRowFmaFwdW4096U32, kAsmRowFmaFwdI81024U32, kAsmRowFmaFwdI82048U32, kAsmRowFmaFwdI84096U32,   //   ... one result
+  kAsmFwd32kSI2, kAsmPolymulNtt32kSI2,                               // 32768-word rows: the composed product's pair on incomplete transforms (b' stored two stages short)
   kAsmCount
 };
 static inline bool is8k(AsmKind k) { return (k >= kAsmPolymul8k && k <= kAsmInv8k) || k == kAsmPolymul8kI2; }
 static inline bool is16k(AsmKind k) { return (k >= kAsmPolymul16k && k <= kAsmInv16k) || k == kAsmPolymul16kI2; }
-static inline bool is32k(AsmKind k) { return k >= kAsmFwd32k && k <= kAsmPolymulNtt32kS; }
+static inline bool is32k(AsmKind k) { return (k >= kAsmFwd32k && k <= kAsmPolymulNtt32kS) || k == kAsmFwd32kSI2 || k == kAsmPolymulNtt32kSI2; }
 static const char *const kAsmNames[kAsmCount] = {
     "nflhip_polymul4096nt_asm", "nflhip_polymul_ntt4096_asm", "nflhip_ntt_fwd4096_asm", "nflhip_ntt_inv4096_asm", "nflhip_ntt_inv_mul4096_asm",
     "nflhip_ntt_fwd4096x2nt_asm", "nflhip_ntt_inv4096x2nt_asm",
@@ -419,6 +420,7 @@ static const char *const kAsmNames[kAsmCount] = {
     "nflhip_row1024_enc2i8_u32_asm", "nflhip_row2048_enc2i8_u32_asm", "nflhip_row4096_enc2i8_u32_asm",
     "nflhip_row1024_fmafwdw_u32_asm", "nflhip_row2048_fmafwdw_u32_asm", "nflhip_row4096_fmafwdw_u32_asm",
     "nflhip_row1024_fmafwdi8_u32_asm", "nflhip_row2048_fmafwdi8_u32_asm", "nflhip_row4096_fmafwdi8_u32_asm",
+    "nflhip_ntt_fwd32768si2_asm", "nflhip_polymul_ntt32768si2_asm",
 };
 struct AsmKernel {
   hipModule_t mod = nullptr;
@@ -489,6 +491,10 @@ static hipError_t launch_asm(AsmKind kind, const Shape &s, const DevTables &t, u
   if (kind == kAsmPolymul8kI2 || kind == kAsmPolymul16kI2) {
     args.mc = t.mc_inc[1];
     if (!args.mc || s.logn != (kind == kAsmPolymul8kI2 ? kLogN + 1 : kLogN + 2)) return hipErrorNotSupported;   // whole rows only: the scale is the row's
+  }
+  if (kind == kAsmFwd32kSI2 || kind == kAsmPolymulNtt32kSI2) {
+    args.mc = t.mc_inc[1];
+    if (!args.mc || s.logn != kLogN + 3) return hipErrorNotSupported;
   }
   size_t size = sizeof(args);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -1002,8 +1008,10 @@ hipError_t launch_row32k_u64(const Shape &s, const DevTables &t, int mode, uint6
                              size_t batch, hipStream_t st) {
   if (!row32k_shape(s)) return hipErrorNotSupported;
   if (batch == 0) return hipSuccess;
-  // modes 4 / 5: the two halves of the composed product -- b' goes through the context's scratch in a layout only these two share
-  const AsmKind k = mode == 1 ? kAsmPolymulNtt32k : mode == 2 ? kAsmFwd32k : mode == 3 ? kAsmInv32k : mode == 4 ? kAsmFwd32kS : kAsmPolymulNtt32kS;
+  // modes 4 / 5: the two halves of the composed product -- b' goes through the context's scratch in a layout only these two share;
+  // 6 / 7: the same pair on incomplete transforms (b' two stages short and unreduced; BOTH launches of a product take the same pair)
+  const AsmKind k = mode == 1 ? kAsmPolymulNtt32k : mode == 2 ? kAsmFwd32k : mode == 3 ? kAsmInv32k : mode == 4 ? kAsmFwd32kS :
+                    mode == 6 ? kAsmFwd32kSI2 : mode == 7 ? kAsmPolymulNtt32kSI2 : kAsmPolymulNtt32kS;
   return launch_asm(k, s, t, c, a, b, batch, st);
 }
 

@@ -491,6 +491,14 @@ def test_emulated_u64_register_resident_32768_word_rows(nm, batch, generated, or
     scratch = run("ntt_fwd32768s", b, b)
     assert np.array_equal(scratch.reshape(batch, nm, 8, 8, 256, 2), fb.reshape(batch, nm, 8, 256, 8, 2).transpose(0, 1, 2, 4, 3, 5))
     assert np.array_equal(run("polymul_ntt32768s", a, scratch), o.polymul(a, b))
+    # ... and the same pair on incomplete transforms (level 2: b' is stored two stages short and unreduced, the point-wise step is the
+    # base multiplication mod X^4 -+ zeta against the streamed groups, the inverse starts two stages late; all-(p - 1) rows included)
+    P = np.asarray(prm.P[:nm], dtype=np.uint64)
+    a2, b2 = a.copy(), b.copy()
+    a2[batch - 1], b2[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    run2 = lambda stem, x, y: asm_emu.run_block_kernel(generated(stem), n, nm, prm, x, y, 15, words_per_thread=32, incomplete=2)
+    scratch2 = run2("ntt_fwd32768si2", b2, b2)
+    assert np.array_equal(run2("polymul_ntt32768si2", a2, scratch2), o.polymul(a2, b2))
 
 
 @pytest.mark.parametrize("nm,batch", [(2, 2)])

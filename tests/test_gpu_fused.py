@@ -233,7 +233,7 @@ def test_generated_and_compiled_wave_per_row_pipelines_give_the_same_words(lb, n
     g = e.gauss_create(3.19, 128, 1 << 10)
     try:
         for batch in (1, 3, 10, 65):
-            xs = [e.sample_gauss_small(e.empty_small(batch, FMT_I8), g, KEY, 40 + i, amplifier=3) for i in range(3)]
+            xs = [e.sample_gauss_small(e.empty_small(batch, FMT_I8), g, KEY, 40 + i) for i in range(3)]
             ws = [e.fill_uniform(e.empty(batch), 5, i) for i in range(3)]
             k0, k1 = e.fill_uniform(e.empty(1), 6, 0), e.fill_uniform(e.empty(batch), 6, 1)
             got = []

@@ -113,6 +113,27 @@ def test_row_resident_products_on_incomplete_transforms(n, m, batch, level, orac
         assert np.array_equal(e.to_host(e.polymul(da, db, out=da)), want), "level %d in place" % lv
 
 
+@pytest.mark.parametrize("m,batch", [(2, 5), (1, 3)])
+def test_register_resident_32768_word_rows_on_incomplete_transforms(m, batch, level, oracle_factory):
+    """rows of 32768 words, the composed product (nflhip_ntt_fwd32768s[i2]_asm -> scratch -> nflhip_polymul_ntt32768s[i2]_asm): at level 2
+    b' is stored two stages short and unreduced and meets a' in a base multiplication mod X^4 -+ zeta -- the oracle's words at level 2
+    and 0, all-(p-1) rows, result over a and over b"""
+    from test_gpu_xcd import _engine
+    n = 32768
+    o, e = oracle_factory(64, n, m), _engine(n, m, False)
+    a, b = o.fill_uniform(batch, SEED, 0), o.fill_uniform(batch, SEED, 1)
+    P = np.asarray(e.params.P[:m], dtype=np.uint64)
+    a[batch - 1], b[batch - 1] = (P - 1)[:, None], (P - 1)[:, None]
+    want = o.polymul(a, b)
+    for lv in (0, 2, 0, 2):
+        level(lv)
+        da, db = e.to_device(a), e.to_device(b)
+        assert np.array_equal(e.to_host(e.polymul(da, db)), want), "level %d" % lv
+        assert np.array_equal(e.to_host(e.polymul(da, db, out=da)), want), "level %d, result over a" % lv
+        da = e.to_device(a)
+        assert np.array_equal(e.to_host(e.polymul(da, db, out=db)), want), "level %d, result over b" % lv
+
+
 @pytest.mark.parametrize("n,m,batch", [(1024, 2, 5), (1024, 1, 1), (2048, 3, 3), (2048, 2, 64), (1024, 30, 7)])
 def test_wave_per_row_u64_kernels(n, m, batch, level, oracle_factory, engine_factory, compiled_engine_factory):
     """64-bit rows of 1024 / 2048 words on the generated kernels (tools/asmgen/rows1k.py): product at level 2 and 0, forward, inverse,

@@ -79,8 +79,9 @@ def base_mul(a0, b0, G, tw, negate, rtmp, negtmp):
     """one group: pairs a0 .. a0 + 2G - 2 and b0 ..; tw = the VGPR record (w0, w1, w'0, w'1) of +zeta; negate: zeta = -w;
     rtmp: G - 1 spare register pairs per stream; negtmp: 4 spare registers per stream"""
     def gen(s):
-        a = [a0 + 2 * i for i in range(G)]
-        b = [b0 + 2 * i for i in range(G)]
+        # (a0 / b0: the first of G consecutive register pairs, or the list of the G pairs -- rows32k streams b through ring slots)
+        a = list(a0) if isinstance(a0, (list, tuple)) else [a0 + 2 * i for i in range(G)]
+        b = list(b0) if isinstance(b0, (list, tuple)) else [b0 + 2 * i for i in range(G)]
         z = tw
         if negate:
             nt = negtmp[s]

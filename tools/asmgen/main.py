@@ -164,6 +164,8 @@ def main():
     for kind, stem in (("fwd", "ntt_fwd32768"), ("inv", "ntt_inv32768"), ("polymul_ntt", "polymul_ntt32768"),
                        ("fwd_s", "ntt_fwd32768s"), ("polymul_s", "polymul_ntt32768s")):
         emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind))
+    for kind, stem in (("fwd_s", "ntt_fwd32768si2"), ("polymul_s", "polymul_ntt32768si2")):   # the composed product's pair on incomplete transforms (round 6)
+        emit_file(os.path.join(outdir, stem + "_gfx950.s"), "nflhip_%s_asm" % stem, build_row32k(kind, level=2))
     # ... and the fused inverse pipelines of such a row: INTT(b -+ a k), the key row's base and stride flag behind the standard arguments
     # ... the forward transform of a compact (int8) Gaussian polynomial: one byte per coefficient in, NTT words of every modulus out
     emit_file(os.path.join(outdir, "ntt_fwd32768i8_gfx950.s"), "nflhip_ntt_fwd32768i8_asm", build_row32k("fwd_i8"))

@@ -25,7 +25,7 @@ from .rows import prologue16k
 # kinds: fwd (canonical NTT-form words out), inv, polymul_ntt: c = INTT(NTT(a) (.) b') with b' (already transformed,
 # canonical) STREAMED through the twiddle ring during the point-wise step -- the large-row product is then
 # b' = fwd(b) (read + write) followed by polymul_ntt(a, b') (two reads + one write): 5 operand passes instead of 9.
-def build_row32k(kind="fwd"):
+def build_row32k(kind="fwd", level=0):
     assert cfg.ROW_G == 4 and cfg.ROW_LG == 3 and cfg.NEXT_VGPR == 128
     em = Emitter()
     vm = VmCounter(em)
@@ -48,6 +48,15 @@ def build_row32k(kind="fwd"):
     kind = kind[:-2] if scratch_layout else kind
     if scratch_layout:
         kind = {"polymul": "polymul_ntt"}.get(kind, kind)
+    # level 2 (the "_s" pair only -- b' is OURS, so it may be stored incomplete): both forward transforms stop two stages early (F3 keeps
+    # its sub-stages 0 and 1; fwd_s stores the words as the butterflies leave them, no canonical step), the point-wise step becomes the
+    # base multiplication mod X^4 -+ zeta (incomplete.py) on a's registers and the streamed b' -- a group of four words is two ring slots,
+    # zeta the two records of F3's sub-stage 1, which stay in the ring through the group products of their file, the scratch three
+    # RESERVED slots: 2 + 3 + two groups of b' in flight = the nine slots -- and the inverse starts two stages late (I1 runs its
+    # sub-stages 1 and 0).  The host hands both kernels of the pair the level-2 ModConst records ((n / 4)^-1, the mu2 field).
+    assert level in (0, 2) and (not level or (scratch_layout and kind in ("fwd", "polymul_ntt") and cfg.SPLIT32K and cfg.SINGLE_STREAM))
+    f3_stages = (0, 1) if level else (0, 1, 2, 3)
+    i1_stages = (1, 0) if level else (3, 2, 1, 0)
 
     def bprime_loader(boff):
         def load(em_, r, s_, i, first):               # words 16t + 2i, 16t + 2i + 1 of block q + boff of b' -> one ring slot
@@ -79,15 +88,19 @@ def build_row32k(kind="fwd"):
         uses += [("F0", s_, g) for s_ in range(3) for g in range(1 << s_)]
         for name in ("F1", "F2", "F3"):
             for f in range(2):
-                uses += [(name + "ab"[f], s_, g) for s_ in range(4) for g in range(1 << s_)]
-    if kind == "polymul_ntt":
+                uses += [(name + "ab"[f], s_, g) for s_ in (f3_stages if name == "F3" else range(4)) for g in range(1 << s_)]
+                if name == "F3" and level and kind == "polymul_ntt":     # the file's group products follow its F3 at once
+                    uses += [("TMP", f, k) for k in range(3)] + [("B" + "ab"[f], 0, i) for i in range(8)]
+    if kind == "polymul_ntt" and not level:
         for f in range(2):
             uses += [("B" + "ab"[f], 0, i) for i in range(8)]
     if has_inv:
         for name in ("I1", "I2", "I3"):
             for f in range(2):
-                uses += [(name + "ab"[f], s_, g) for s_ in (3, 2, 1, 0) for g in range(1 << s_)]
+                uses += [(name + "ab"[f], s_, g) for s_ in (i1_stages if name == "I1" else (3, 2, 1, 0)) for g in range(1 << s_)]
         uses += [("I0", s_, g) for s_ in (2, 1, 0) for g in range(1 << s_)]
+    if level:
+        passes["TMP"] = None           # reserved ring slots: four scratch registers each, nothing is loaded
     ring = Ring(em, vm, cfg.RING_SLOTS, uses, passes)
     if cfg.BPRIME_ALIAS and scratch_layout:   # fwd_s writes b' through s20, polymul_ntt_s reads it through s18
         cfg.ALIAS_ROWS = (20,) if kind == "fwd" else (18,)
@@ -194,7 +207,31 @@ def build_row32k(kind="fwd"):
             for g in range(1 << s_):
                 tw = ring.get((nm_, s_, g))
                 run_pairs(em, [ct_bfly(base + 2 * (g * 2 * half + h), base + 2 * (g * 2 * half + h + half), tw) for h in range(half)])
-                ring.done((nm_, s_, g))
+                if not (level and kind == "polymul_ntt" and name == "F3" and s_ == 1):    # (zeta: released by group_products)
+                    ring.done((nm_, s_, g))
+
+    def group_products(f):
+        """level 2, the product kernel: file f = a' (four groups of four words per thread) times the streamed b' modulo X^4 -+ zeta"""
+        if not (level and kind == "polymul_ntt"):
+            return
+        from .incomplete import base_mul
+        base = FILES[f][0]
+        em.comment("base multiplication mod X^4 -+ zeta, file %s: b' streams through the ring two slots per group; scratch = three reserved slots" % "AB"[f])
+        tmp = [int(ring.get(("TMP", f, k))[0][1:]) for k in range(3)]
+        rt = [tmp[0], tmp[0] + 2, tmp[1]]
+        for g4 in range(4):
+            u0, u1 = ("B" + "ab"[f], 0, 2 * g4), ("B" + "ab"[f], 0, 2 * g4 + 1)
+            ring.get(u0)
+            ring.get(u1)
+            r0, r1 = cfg.V_TW + 4 * ring.slot_of[u0], cfg.V_TW + 4 * ring.slot_of[u1]
+            tw = ring.regs(("F3" + "ab"[f], 1, g4 // 2))
+            run_pairs(em, [base_mul([base + 8 * g4 + 2 * i for i in range(4)], [r0, r0 + 2, r1, r1 + 2], 4, tw, bool(g4 & 1), [rt, rt], [tmp[2], tmp[2]])])
+            ring.done(u0)
+            ring.done(u1)
+        for g in range(2):
+            ring.done(("F3" + "ab"[f], 1, g))
+        for k in range(3):
+            ring.done(("TMP", f, k))
 
     def inv_stages(f, name, stages):
         base, nm_ = FILES[f][0], name + "ab"[f]
@@ -263,13 +300,14 @@ def build_row32k(kind="fwd"):
                 lambda: lds_read(em, cfg.V_L1R, B_, 136), lambda: fwd_stages(0, "F2", (2, 3)), W0,
                 # E2 is wave-local (LDS is in order per wave): file A's transposes run under F2 of file B, B's under F3 of A
                 lambda: lds_write(em, cfg.V_L1R, A_, 136), lambda: lds_read(em, cfg.V_L2R, A_, 8), lambda: fwd_stages(1, "F2", (0, 1, 2, 3)), W0,
-                lambda: lds_write(em, cfg.V_L1R, B_, 136), lambda: lds_read(em, cfg.V_L2R, B_, 8), lambda: fwd_stages(0, "F3", (0, 1, 2, 3)), W0,
-                lambda: fwd_stages(1, "F3", (0, 1, 2, 3)))
+                lambda: lds_write(em, cfg.V_L1R, B_, 136), lambda: lds_read(em, cfg.V_L2R, B_, 8), lambda: fwd_stages(0, "F3", f3_stages),
+                lambda: group_products(0), W0, lambda: fwd_stages(1, "F3", f3_stages), lambda: group_products(1))
         if kind == "fwd" and scratch_layout:
             em.comment("canonical words straight into the product's scratch layout [block][pair i][thread]: no transposes")
             em.valu("v_lshlrev_b32_e32 v%d, 4, v%d" % (cfg.V_TWO, cfg.V_TID))
             for base, boff in FILES:
-                run_pairs(em, [canon(base + 2 * i) for i in range(16)])
+                if not level:          # (level 2: the product's base multiplication folds whatever word it is handed)
+                    run_pairs(em, [canon(base + 2 * i) for i in range(16)])
                 block_base(cfg.S_CROW, boff)
                 for i in range(8):
                     R("global_store_dwordx4 v%d, v[%d:%d], s[86:87] nt" % (cfg.V_TWO, base + 4 * i, base + 4 * i + 3))
@@ -356,7 +394,9 @@ def build_row32k(kind="fwd"):
             stores(B_, FILES[1][1])
             R("s_endpgm")
             return True
-        if kind == "polymul_ntt":
+        if kind == "polymul_ntt" and level:
+            seq(lambda: inv_stages(0, "I1", i1_stages))
+        elif kind == "polymul_ntt":
             em.comment("point-wise product with b' streamed through the ring: slot i of a file = words 16t + 2i, 16t + 2i + 1 of its block")
             for f, (base, _) in enumerate(FILES):
                 for i in range(8):
@@ -377,7 +417,7 @@ def build_row32k(kind="fwd"):
                 lds_read(em, cfg.V_L2R, base, 8)
             seq(lambda: to_threads(A_), W0, lambda: to_threads(B_), lambda: inv_stages(0, "I1", (3, 2, 1, 0)), W0)
         seq(# E2' is wave-local: file A's under I1 of file B, file B's under I2 of file A
-            lambda: lds_write(em, cfg.V_L2R, A_, 8), lambda: lds_read(em, cfg.V_L1R, A_, 136), lambda: inv_stages(1, "I1", (3, 2, 1, 0)), W0,
+            lambda: lds_write(em, cfg.V_L2R, A_, 8), lambda: lds_read(em, cfg.V_L1R, A_, 136), lambda: inv_stages(1, "I1", i1_stages), W0,
             lambda: lds_write(em, cfg.V_L2R, B_, 8), lambda: lds_read(em, cfg.V_L1R, B_, 136), lambda: inv_stages(0, "I2", (3, 2, 1, 0)), W0,
             lambda: lds_write(em, cfg.V_L1R, A_, 136), lambda: inv_stages(1, "I2", (3, 2)), W0, BAR,
             lambda: lds_read(em, cfg.V_L1W, A_, 2176), lambda: inv_stages(1, "I2", (1, 0)), W0, BAR,
