@@ -185,7 +185,11 @@ def test_emulated_u64_wave_per_row_fused_pipelines(n, nm, batch, generated, orac
                                 v.astype(np.int64)[:, None, :]).astype(np.uint64)
     rpw = 4096 // n
     a, b = rnd(batch), rnd(batch)
+    # the extreme words of the one-chain multiply-add (tools/asmgen/fused.py mac128): a = 0 (p - a = p), a = b = k = p - 1
+    a[0, :, 0], a[0, :, 1], a[0, :, 2], a[0, :, 3] = 0, P - 1, P - 1, 0
+    b[0, :, 0], b[0, :, 1], b[0, :, 2], b[0, :, 3] = P - 1, P - 1, 0, 0
     for key in (rnd(1), rnd(batch)):
+        key[0, :, :4] = (P - 1)[:, None]
         kk = np.broadcast_to(key, (batch, nm, n)).copy()
         for sub, stem in ((True, "fmsinv"), (False, "fmainv")):
             want = o.intt(o.pointwise(SUB if sub else ADD, b, o.pointwise(MUL, a, kk)))
@@ -201,6 +205,7 @@ def test_emulated_u64_wave_per_row_fused_pipelines(n, nm, batch, generated, orac
                 X, E0, E1 = expand(x), expand(e0), expand(e1)
             Xb = np.broadcast_to(X, (batch, nm, n)).copy()
             k0, k1 = rnd(1), rnd(batch)
+            k0[0, :, :8], k1[0, :, :8] = (P - 1)[:, None], (P - 1)[:, None]
             K0 = np.broadcast_to(k0, (batch, nm, n)).copy()
             w0 = o.pointwise(ADD, o.pointwise(MUL, o.ntt(Xb), K0), o.ntt(E0))
             w1 = o.pointwise(ADD, o.pointwise(MUL, o.ntt(Xb), k1), o.ntt(E1))

@@ -223,29 +223,55 @@ def fused_lane_loads(em, vm, dst, srow, stream=True):
     return seqs
 
 
+def mac128(s, x, y, addend, dst):
+    """dst = fold(x * y + addend) < p + 4 delta: ONE 128-bit chain.  x < 2^62 (canonical, or p - canonical), y folded or canonical
+    (< 2^62 + 3 delta), addend ANY 64-bit word: it is the addend of the low product, whose carry (weight 2^64) joins the cross sum's
+    high dword -- the cross sum stays below 2^63.1, so neither that addition nor the sum itself can overflow; T = x y + addend < 2^124.1
+    takes the point-wise product's Barrett step (T < 2^125: arith.pointwise), r < 4p, then the two-bit fold"""
+    mu0, mu1 = "s%d" % cfg.S_MU2[0], "s%d" % cfg.S_MU2[1]
+    L, A, P, Q, H, E, ZP, D = T(s, 16), T(s, 6), T(s, 2), T(s, 8), T(s, 10), T(s, 12), T(s, 14), T(s, 4)
+    # T as four dwords: T0 = L.lo, T1 = A.lo, T2 = E.lo, T3 = E.hi
+    yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(L), cfg.S_BORROW[s], x, y, vp(addend)), cfg.S_BORROW[s], None
+    yield "v_mov_b32_e32 v%d, v%d" % (ZP, L + 1), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(A), cfg.S_DUMMY, x, y + 1, vp(ZP)), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(A), cfg.S_DUMMY, x + 1, y, vp(A)), None, None
+    yield "v_addc_co_u32_e64 v%d, %s, v%d, 0, %s" % (ZP, cfg.S_DUMMY, A + 1, cfg.S_BORROW[s]), None, cfg.S_BORROW[s]
+    yield "v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(E), cfg.S_DUMMY, x + 1, y + 1, vp(ZP)), None, None
+    # th = T >> 61; q ~ floor(th*mu2/2^64), one-off allowed; r = lo64(T) + q*delta - (q << 62)
+    yield "v_alignbit_b32 v%d, v%d, v%d, 29" % (D, E, A), None, None
+    yield "v_alignbit_b32 v%d, v%d, v%d, 29" % (D + 1, E + 1, E), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, 0" % (vp(H), cfg.S_DUMMY, D + 1, mu0), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), cfg.S_CARRY[s], D, mu1, vp(H)), cfg.S_CARRY[s], None
+    yield "v_mov_b32_e32 v%d, v%d" % (P, H + 1), None, None
+    yield "v_addc_co_u32_e64 v%d, %s, 0, 0, %s" % (P + 1, cfg.S_DUMMY, cfg.S_CARRY[s]), None, cfg.S_CARRY[s]
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(Q), cfg.S_DUMMY, D + 1, mu1, vp(P)), None, None
+    yield "v_mov_b32_e32 v%d, v%d" % (L + 1, A), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(L), cfg.S_DUMMY, Q, cfg.S_DELTA, vp(L)), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, 0" % (vp(H), cfg.S_DUMMY, Q + 1, cfg.S_DELTA), None, None
+    yield "v_mad_u64_u32 %s, %s, v%d, %s, %s" % (vp(H), cfg.S_DUMMY, Q, cfg.S_C0, vp(H)), None, None
+    yield "v_add_u32_e32 v%d, v%d, v%d" % (L + 1, L + 1, H), None, None
+    yield from fold2(s, dst, L)
+
+
 def fma_job(k, a, b, fold_a):
-    """k = canonical(k * a + b): k a canonical key word, a / b lazily reduced words (a is folded in place the first time)"""
+    """k = canonical(k * a + b): k a canonical key word, a a lazily reduced word (folded in place the first time), b ANY 64-bit word:
+    27 instructions where product, fold, add, fold, conditional subtraction took 33"""
     def gen(s):
-        yield from pointwise(k, a, False, fold_a)(s)
-        yield from fold2(s, b, b)
-        yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(k), vp(k), vp(b)), None, None
-        yield from fold2(s, k, k)
+        if fold_a:
+            yield from fold2(s, a, a)
+        yield from mac128(s, k, a, b, k)
         yield from csub_p(s, k)
     return gen
 
 
 def fms_job(a, k, b, subtract):
-    """a = fold(b -+ a * k) < p + 4 delta, all inputs canonical (the contract of the reference's operators, ops.hpp:131,211)"""
+    """a = fold(b -+ a * k) < p + 4 delta, all inputs canonical (the contract of the reference's operators, ops.hpp:131,211): b - a k is
+    (p - a) k + b, one chain"""
     def gen(s):
-        yield from pointwise(a, k, False, False)(s)
         if subtract:
-            E = T(s, 12)
-            yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(b), cfg.S_P2), None, None
-            yield "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (a, cfg.S_BORROW[s], E, a), cfg.S_BORROW[s], None
-            yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (a + 1, cfg.S_DUMMY, E + 1, a + 1, cfg.S_BORROW[s]), None, cfg.S_BORROW[s]
-        else:
-            yield "v_lshl_add_u64 %s, %s, 0, %s" % (vp(a), vp(a), vp(b)), None, None
-        yield from fold2(s, a, a)
+            yield "v_sub_co_u32_e64 v%d, %s, s24, v%d" % (a, cfg.S_BORROW[s], a), cfg.S_BORROW[s], None
+            yield "v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (a + 1, cfg.S_DUMMY, cfg.V_PHI, a + 1, cfg.S_BORROW[s]), None, cfg.S_BORROW[s]
+        yield from mac128(s, a, k, b, a)
     return gen
 
 
