@@ -84,13 +84,14 @@ block("polymul8192", 8192, 13, "G", 2)
 block("polymul8192i2", 8192, 13, "G", 2, incomplete=2)
 block("polymul16384", 16384, 14, "C", 8)
 block("polymul16384i2", 16384, 14, "C", 8, incomplete=2)
-def rows32k(workload, nm_w):   # b' = NTT(b), then c = INTT(NTT(a) (.) b'): the two register-resident row kernels of n = 32768
+def rows32k(workload, nm_w, sfx="s", incomplete=0):   # b' = NTT(b) into the scratch, then c = INTT(NTT(a) (.) b'): the register-resident pair of n = 32768
     prm, a = operands(64, 32768, 1, 1)
-    k = lambda stem: asm_emu.run_block_kernel(os.path.join(CSRC, stem + "_gfx950.s"), 32768, 1, prm, a, a, 15, words_per_thread=32)
-    case("ntt_fwd32768 + polymul_ntt32768", workload, nm_w, lambda: (k("ntt_fwd32768"), k("polymul_ntt32768")), 1)
+    k = lambda stem: asm_emu.run_block_kernel(os.path.join(CSRC, stem + "_gfx950.s"), 32768, 1, prm, a, a, 15, words_per_thread=32, incomplete=incomplete)
+    case("fwd32768%s + polymul_ntt32768%s" % (sfx, sfx), workload, nm_w, lambda: (k("ntt_fwd32768" + sfx), k("polymul_ntt32768" + sfx)), 1)
 
 
 rows32k("F", 2)
+rows32k("F", 2, "si2", 2)                                  # round 6, third session: the pair on incomplete transforms
 pipe("polymul_pipe65536nt", 65536, "E", 30)
 pipe("polymul_pipe65536nti2", 65536, "E", 30, incomplete=2)
 row("row1024_u32", 32, 1024, 4, True, "A", 1, 4)
