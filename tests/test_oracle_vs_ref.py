@@ -51,10 +51,14 @@ def test_cpu_port_not_slower_than_reference(oracle_factory):
     o, r = oracle_factory(64, 4096, 4), O.Reference(64, 4096, 4)
     a, b = o.fill_uniform(16, 1, 0), o.fill_uniform(16, 1, 1)
 
-    def best(fn):
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter(); fn(a, b); ts.append(time.perf_counter() - t0)
-        return min(ts)
-    tp, tr = best(o.polymul), best(r.polymul)
+    def once(fn):
+        t0 = time.perf_counter(); fn(a, b); return time.perf_counter() - t0
+    # the two are timed ALTERNATELY and compared by their minima, in up to three attempts: a busy host (other test processes, a build)
+    # slows whichever runs at that moment, not the port
+    for attempt in range(3):
+        tp = tr = float("inf")
+        for _ in range(8):
+            tp, tr = min(tp, once(o.polymul)), min(tr, once(r.polymul))
+        if tp < 1.25 * tr:
+            break
     assert tp < 1.25 * tr, (tp, tr)
