@@ -53,5 +53,20 @@ for lb, n, m, batch in ((32, 1024, 2, 4099), (64, 1024, 2, 2051), (64, 2048, 3, 
     bad += mism
     e.gauss_destroy(g)
     e.close()
+# round 6, third session: the fused inverse pipeline on those rows (generated kernels at both limb widths) and the 32768-word composed
+# product at a batch that takes the register-resident pair
+for lb, n, m, batch in ((32, 1024, 2, 4099), (32, 4096, 2, 513), (64, 2048, 2, 1025)):
+    e = Engine(lb, n, m)
+    a = e.fill_uniform(e.empty(batch), 21, 0)
+    b = e.fill_uniform(e.empty(batch), 21, 1)
+    k = e.fill_uniform(e.empty(1), 22, 0)
+    r = e.fma_inv(a, k, b, subtract=True).clone()
+    torch.cuda.synchronize()
+    mism = 0
+    for it in range(iters):
+        mism += int(e.any_neq(e.fma_inv(a, k, b, subtract=True), r))
+    print("u%d/%d/%d batch %d fused inverse rows: %d iterations, %d mismatches" % (lb, n, m, batch, iters, mism))
+    bad += mism
+    e.close()
 print("SOAK", "CLEAN" if bad == 0 else "MISMATCHES: %d" % bad)
 sys.exit(1 if bad else 0)
