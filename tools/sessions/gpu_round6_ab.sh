@@ -10,7 +10,7 @@ for reps in 2048 16384 65536; do
     for r in 1 2 3; do
       NFL_HIP_QUEUE_LIMIT=$lim NFL_LWE_REPS=$reps timeout 300 tests/cpp/resident_test 2>/dev/null | head -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read())
+d = list(json.loads(sys.stdin.read()).values())[0]
 print('reps $reps limit $lim: poly_p %.3f M enc/s %.3f M dec/s; batch fused %.3f M enc/s; launches %s for %s operations' % (d['poly_p_encryptions_per_s'] / 1e6, d['poly_p_decryptions_per_s'] / 1e6, d['device_batch_fused_encryptions_per_s'] / 1e6, d.get('launches_they_became'), d.get('deferred_operations')))"
     done
   done
