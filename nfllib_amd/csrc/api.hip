@@ -773,6 +773,32 @@ int nflhip_device_count(int *count) {
   return NFLHIP_OK;
 }
 
+// First-use costs paid ONCE per device when its first context is created instead of inside whichever call comes first (measured,
+// profiles/r06_first_use.txt: the first element-wise call 3.2 ms, the first transform 5.4 - 6.6 ms, the first CRT call 1.3 ms against
+// 35 - 60 us afterwards -- the runtime loads a translation unit's code object at the first launch of any of its kernels, the generated
+// kernels' module at its first use): one empty launch per translation unit, the module, and -- per context -- the three device staging
+// buffers of the host-pointer entry points at one polynomial's size: + 20 ms on the first context of a process, nothing afterwards.
+static int warm_up_device(nflhip_ctx *c) {
+  static std::once_flag once[16];
+  if (c->device >= 0 && c->device < 16) {
+    hipError_t e = hipSuccess;
+    std::call_once(once[c->device], [&] {
+      hipStream_t st = c->hstream;
+      hipError_t (*const tus[])(hipStream_t) = {nflhip::warm_generic, nflhip::warm_fast, nflhip::warm_crt, nflhip::warm_crt_mfma,
+                                                nflhip::warm_sample, nflhip::warm_wave};
+      for (auto f : tus)
+        if (e == hipSuccess) e = f(st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+    });
+    if (e != hipSuccess) return hipfail(nullptr, e, "first-use warm-up");
+  }
+  for (int slot = 0; slot < 3; ++slot) {
+    int rc = ensure_stage(c, slot, c->shape.n * c->shape.nm * c->word);
+    if (rc) return rc;
+  }
+  return NFLHIP_OK;
+}
+
 static int ctx_create_mode(nflhip_ctx **out, int device, int limb_bits, size_t degree, size_t nmoduli, const void *P,
                            const void *primitive_roots, const void *invkmax, int kmax_log2, int cyclic) {
   if (!out) return fail(nullptr, NFLHIP_ERR_INVALID, "out is NULL");
@@ -830,6 +856,7 @@ static int ctx_create_mode(nflhip_ctx **out, int device, int limb_bits, size_t d
     if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming);
     if (se != hipSuccess) rc = hipfail(nullptr, se, "hipStreamCreate");
   }
+  if (rc == NFLHIP_OK) rc = warm_up_device(c);
   if (rc != NFLHIP_OK) {
     nflhip_ctx_destroy(c);
     return rc;

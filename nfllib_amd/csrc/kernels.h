@@ -234,6 +234,13 @@ hipError_t launch_row1024_u64_asm(const Shape &s, const DevTables &t, int mode, 
 size_t xcd_plan_bytes(const Shape &s, size_t batch);
 hipError_t launch_polymul_xcd_u64(const Shape &s, const DevTables &t, uint64_t *c, const uint64_t *a, const uint64_t *b,
                                   size_t batch, void *work, hipStream_t st, int level = 0);
+// one empty launch per translation unit (+ the generated kernels' module): api.hip warm_up_device
+hipError_t warm_generic(hipStream_t st);
+hipError_t warm_fast(hipStream_t st);
+hipError_t warm_crt(hipStream_t st);
+hipError_t warm_crt_mfma(hipStream_t st);
+hipError_t warm_sample(hipStream_t st);
+hipError_t warm_wave(hipStream_t st);
 int polymul_level();   // 0 / 1 / 2: transforms of the coefficient-form products complete / incomplete (kernels_fast.hip, nflhip_debug_polymul_level)
 hipError_t launch_polymul_pipe64k_u64(const Shape &s, const DevTables &t, uint64_t *c_v, const uint64_t *a_v,
                                       const uint64_t *b_v, int cnt_v, const uint64_t *fa_src, uint64_t *fa_dst,

@@ -344,4 +344,11 @@ hipError_t launch_crt_project_fast_u64(const Shape &s, const DevTables &t, uint6
   return hipGetLastError();
 }
 
+// first-use warm-up (api.hip warm_up_device): the runtime loads a translation unit's code object at the first launch of ANY of its kernels
+__global__ void k_warm_crt() {}
+hipError_t warm_crt(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_crt, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}
+
 }  // namespace nflhip

@@ -451,4 +451,11 @@ hipError_t launch_crt_project_mfma_u64(const Shape &s, const DevTables &t, uint6
   return hipGetLastError();
 }
 
+// first-use warm-up (api.hip warm_up_device): the runtime loads a translation unit's code object at the first launch of ANY of its kernels
+__global__ void k_warm_crt_mfma() {}
+hipError_t warm_crt_mfma(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_crt_mfma, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}
+
 }  // namespace nflhip

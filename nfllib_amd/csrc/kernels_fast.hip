@@ -1144,4 +1144,12 @@ hipError_t launch_ntt_inv_fast_u64(const Shape &s, const DevTables &t, const uin
   return launch_inner_inv_fast_u64(s, t, src, nullptr, dst, batch * s.nm, st);
 }
 
+// first-use warm-up (api.hip warm_up_device): the runtime loads a translation unit's code object at the first launch of ANY of its kernels
+__global__ void k_warm_fast() {}
+hipError_t warm_fast(hipStream_t st) {
+  (void)asm_fn(kAsmPolymul);   // ... and the module of the generated kernels (hipModuleLoadData + its function table)
+  hipLaunchKernelGGL(k_warm_fast, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}
+
 }  // namespace nflhip

@@ -997,4 +997,11 @@ NFLHIP_INST(uint16_t)
 NFLHIP_INST(uint32_t)
 NFLHIP_INST(uint64_t)
 
+// first-use warm-up (api.hip warm_up_device): the runtime loads a translation unit's code object at the first launch of ANY of its kernels
+__global__ void k_warm_generic() {}
+hipError_t warm_generic(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_generic, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}
+
 }  // namespace nflhip

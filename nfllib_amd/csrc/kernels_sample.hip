@@ -1207,4 +1207,11 @@ NFLHIP_INST(uint32_t)
 NFLHIP_INST(uint64_t)
 #undef NFLHIP_INST
 
+// first-use warm-up (api.hip warm_up_device): the runtime loads a translation unit's code object at the first launch of ANY of its kernels
+__global__ void k_warm_sample() {}
+hipError_t warm_sample(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_sample, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}
+
 }  // namespace nflhip

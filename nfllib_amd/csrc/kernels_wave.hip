@@ -702,4 +702,11 @@ hipError_t launch_row1024_u64(const Shape &s, const DevTables &t, int mode, uint
   return hipErrorNotSupported;
 }
 
+// first-use warm-up (api.hip warm_up_device): the runtime loads a translation unit's code object at the first launch of ANY of its kernels
+__global__ void k_warm_wave() {}
+hipError_t warm_wave(hipStream_t st) {
+  hipLaunchKernelGGL(k_warm_wave, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}
+
 }  // namespace nflhip
