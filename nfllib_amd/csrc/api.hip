@@ -39,6 +39,10 @@ struct nflhip_ctx {
   hipStream_t hstream = nullptr;
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
+  // a staging buffer of up to kStageHostMax bytes is PINNED HOST memory the kernels read and write directly (one polynomial per call, the
+  // nfl::poly surface: a 128 KiB operand crosses PCIe inside the kernel in less time than a copy engine needs to start); larger ones are device
+  // memory filled by copies
+  bool stage_host[4] = {false, false, false, false};
   // large host-pointer calls: a three-slot pipeline of pinned staging chunks (HostPipe below), created on first use
   struct HostPipe *pipe = nullptr;
   // scratch for the composed (non-fused) polymul path, per stream use is serialised by the caller
@@ -520,12 +524,22 @@ static int set_device(const nflhip_ctx *ctx) {
 }
 static size_t poly_bytes(const nflhip_ctx *ctx, size_t batch) { return batch * ctx->shape.nm * ctx->shape.n * ctx->word; }
 
-static int ensure_stage(nflhip_ctx *ctx, int slot, size_t bytes) {
-  if (ctx->stage_bytes[slot] >= bytes) return NFLHIP_OK;
-  if (ctx->stage[slot]) HIPCHK(ctx, hipFree(ctx->stage[slot]));
+static constexpr size_t kStageHostMax = (size_t)1 << 20;
+static void free_stage(nflhip_ctx *ctx, int slot) {
+  if (ctx->stage[slot]) (void)(ctx->stage_host[slot] ? hipHostFree(ctx->stage[slot]) : hipFree(ctx->stage[slot]));
   ctx->stage[slot] = nullptr;
   ctx->stage_bytes[slot] = 0;
-  HIPCHK(ctx, hipMalloc(&ctx->stage[slot], bytes));
+  ctx->stage_host[slot] = false;
+}
+static int ensure_stage(nflhip_ctx *ctx, int slot, size_t bytes) {
+  if (ctx->stage_bytes[slot] >= bytes) return NFLHIP_OK;
+  free_stage(ctx, slot);
+  if (bytes <= kStageHostMax) {
+    HIPCHK(ctx, hipHostMalloc(&ctx->stage[slot], bytes, hipHostMallocDefault));
+    ctx->stage_host[slot] = true;
+  } else {
+    HIPCHK(ctx, hipMalloc(&ctx->stage[slot], bytes));
+  }
   ctx->stage_bytes[slot] = bytes;
   return NFLHIP_OK;
 }
@@ -883,8 +897,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_scratch) (void)hipEventDestroy(ctx->ev_scratch);
   pipe_destroy(ctx);
-  for (int i = 0; i < 4; ++i)
-    if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+  for (int i = 0; i < 4; ++i) free_stage(ctx, i);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->tabs.psi) (void)hipFree(ctx->tabs.psi);
   if (ctx->tabs.psi_lm) (void)hipFree(ctx->tabs.psi_lm);
@@ -2188,12 +2201,14 @@ struct Staged {
   int in(int slot, const void *h, size_t bytes) {
     int rc = ensure_stage(ctx, slot, bytes);
     if (rc) return rc;
-    if (h) HIPCHK(ctx, hipMemcpyAsync(ctx->stage[slot], h, bytes, hipMemcpyHostToDevice, ctx->hstream));
+    if (h && ctx->stage_host[slot]) std::memcpy(ctx->stage[slot], h, bytes);   // (the stream is idle: every host-pointer call ends synchronised)
+    else if (h) HIPCHK(ctx, hipMemcpyAsync(ctx->stage[slot], h, bytes, hipMemcpyHostToDevice, ctx->hstream));
     return NFLHIP_OK;
   }
   int out(void *h, int slot, size_t bytes) {
-    HIPCHK(ctx, hipMemcpyAsync(h, ctx->stage[slot], bytes, hipMemcpyDeviceToHost, ctx->hstream));
+    if (!ctx->stage_host[slot]) HIPCHK(ctx, hipMemcpyAsync(h, ctx->stage[slot], bytes, hipMemcpyDeviceToHost, ctx->hstream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->hstream));
+    if (ctx->stage_host[slot]) std::memcpy(h, ctx->stage[slot], bytes);
     return NFLHIP_OK;
   }
 };
