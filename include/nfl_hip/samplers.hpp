@@ -72,6 +72,9 @@ template <class in_class, class out_class, unsigned _lu_depth> class FastGaussia
   FastGaussianNoise(double sigma, unsigned int security, unsigned int samples, double center_d = 0, bool /*verbose*/ = false)
       : sigma_(sigma), security_(security), samples_(samples), center_(center_d), last_(nullptr) {
     static_assert(_lu_depth == 1 || _lu_depth == 2, "_lu_depth must be 1 or 2 (FastGaussianNoise.hpp:214)");
+    // the reference computes its table HERE (FastGaussianNoise.hpp:214-300); so does this one -- on the host, once per parameter set and
+    // process, kept by the library -- and the first polynomial drawn in a context only uploads it.  (A parameter error surfaces at that draw.)
+    (void)nflhip_gauss_table(sigma_, security_, samples_, center_, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   }
   FastGaussianNoise(FastGaussianNoise const &) = delete;
   FastGaussianNoise &operator=(FastGaussianNoise const &) = delete;

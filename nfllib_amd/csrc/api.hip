@@ -11,7 +11,9 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <tuple>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -1612,6 +1614,26 @@ int nflhip_sample_gauss_seq_dev(nflhip_ctx *ctx, void *d, size_t batch, const nf
   return NFLHIP_OK;
 }
 
+// The table of a parameter set is computed once per process (448-bit fixed point on the host: milliseconds) and shared by every context's
+// generator: the header's FastGaussianNoise asks for it when it is CONSTRUCTED (nflhip_gauss_table with no output buffer) -- where the
+// reference builds its MPFR table -- so that the first polynomial drawn from it does not carry the construction
+static int cached_gauss_table(double sigma, unsigned security, unsigned samples, double center, GaussTable *out, std::string *err) {
+  typedef std::tuple<double, unsigned, unsigned, double> Key;
+  static std::mutex mu;
+  static std::map<Key, std::shared_ptr<const GaussTable>> cache;
+  const Key key(sigma, security, samples, center);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::shared_ptr<GaussTable> t = std::make_shared<GaussTable>();
+    if (build_gauss_table(sigma, security, samples, center, t.get(), err)) return 1;
+    if (cache.size() >= 64) cache.clear();
+    it = cache.emplace(key, t).first;
+  }
+  *out = *it->second;
+  return 0;
+}
+
 int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsigned security, unsigned samples,
                         double center) {
   CHECK_CTX(ctx);
@@ -1620,7 +1642,7 @@ int nflhip_gauss_create(nflhip_ctx *ctx, nflhip_gauss **out, double sigma, unsig
   if (!g) return fail(ctx, NFLHIP_ERR_NOMEM, "out of host memory");
   std::string err;
   try {
-    if (build_gauss_table(sigma, security, samples, center, &g->tab, &err)) return fail(ctx, NFLHIP_ERR_INVALID, err);
+    if (cached_gauss_table(sigma, security, samples, center, &g->tab, &err)) return fail(ctx, NFLHIP_ERR_INVALID, err);
   } catch (const std::bad_alloc &) {
     return fail(ctx, NFLHIP_ERR_NOMEM, "out of host memory while building the gaussian table");
   }
@@ -1651,7 +1673,7 @@ int nflhip_gauss_table(double sigma, unsigned security, unsigned samples, double
   GaussTable tab;
   std::string err;
   try {
-    if (build_gauss_table(sigma, security, samples, center, &tab, &err)) return fail(nullptr, NFLHIP_ERR_INVALID, err);
+    if (cached_gauss_table(sigma, security, samples, center, &tab, &err)) return fail(nullptr, NFLHIP_ERR_INVALID, err);
   } catch (const std::bad_alloc &) {
     return fail(nullptr, NFLHIP_ERR_NOMEM, "out of host memory while building the gaussian table");
   }
