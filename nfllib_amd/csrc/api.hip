@@ -536,10 +536,11 @@ static void free_stage(nflhip_ctx *ctx, int slot) {
 static int ensure_stage(nflhip_ctx *ctx, int slot, size_t bytes) {
   if (ctx->stage_bytes[slot] >= bytes) return NFLHIP_OK;
   free_stage(ctx, slot);
-  if (bytes <= kStageHostMax) {
-    HIPCHK(ctx, hipHostMalloc(&ctx->stage[slot], bytes, hipHostMallocDefault));
+  if (bytes <= kStageHostMax && hipHostMalloc(&ctx->stage[slot], bytes, hipHostMallocDefault) == hipSuccess) {
     ctx->stage_host[slot] = true;
-  } else {
+  } else {   // (also when the pinned allocation is refused -- a locked-memory limit: the copies take over)
+    (void)hipGetLastError();
+    ctx->stage[slot] = nullptr;
     HIPCHK(ctx, hipMalloc(&ctx->stage[slot], bytes));
   }
   ctx->stage_bytes[slot] = bytes;
