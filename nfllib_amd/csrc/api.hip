@@ -45,6 +45,7 @@ struct nflhip_ctx {
   // nfl::poly surface: a 128 KiB operand crosses PCIe inside the kernel in less time than a copy engine needs to start); larger ones are device
   // memory filled by copies
   bool stage_host[4] = {false, false, false, false};
+  bool flag_host = false;          // tabs.flag is pinned host memory
   // large host-pointer calls: a three-slot pipeline of pinned staging chunks (HostPipe below), created on first use
   struct HostPipe *pipe = nullptr;
   // scratch for the composed (non-fused) polymul path, per stream use is serialised by the caller
@@ -62,6 +63,7 @@ struct nflhip_ctx {
   // threads comparing on distinct streams never share a flag
   static constexpr int kCmpSlots = 32;
   std::mutex cmp_mu[kCmpSlots];
+  int cmp_token[kCmpSlots] = {};   // the token of the slot's latest comparison (under its mutex)
   std::atomic<unsigned> cmp_next{0};
   // host copies for introspection
   std::vector<uint64_t> h_Q;                     // moduli_product limbs
@@ -510,7 +512,17 @@ static int build_tables(nflhip_ctx *c, const void *Pv, const void *rootsv, const
     HIPCHK(nullptr, hipMalloc((void **)&c->tabs.qsh_w, qsh_w.size() * sizeof(uint64_t)));
     HIPCHK(nullptr, hipMemcpy(c->tabs.qsh_w, qsh_w.data(), qsh_w.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
-  HIPCHK(nullptr, hipMalloc((void **)&c->tabs.flag, nflhip_ctx::kCmpSlots * sizeof(int)));
+  // the comparison flags: pinned host memory the kernels store into and the caller reads once the stream has drained (device memory +
+  // a copy when the pinned allocation is refused); a hit stores the call's TOKEN, so nothing has to be cleared in front of a launch
+  if (hipHostMalloc((void **)&c->tabs.flag, nflhip_ctx::kCmpSlots * sizeof(int), hipHostMallocDefault) == hipSuccess) {
+    c->flag_host = true;
+    std::memset(c->tabs.flag, 0, nflhip_ctx::kCmpSlots * sizeof(int));
+  } else {
+    (void)hipGetLastError();
+    c->tabs.flag = nullptr;
+    HIPCHK(nullptr, hipMalloc((void **)&c->tabs.flag, nflhip_ctx::kCmpSlots * sizeof(int)));
+    HIPCHK(nullptr, hipMemset(c->tabs.flag, 0, nflhip_ctx::kCmpSlots * sizeof(int)));
+  }
   return NFLHIP_OK;
 }
 
@@ -915,7 +927,7 @@ int nflhip_ctx_destroy(nflhip_ctx *ctx) {
   if (ctx->tabs.crt_coff) (void)hipFree(ctx->tabs.crt_coff);
   if (ctx->tabs.crt_c2048) (void)hipFree(ctx->tabs.crt_c2048);
   if (ctx->tabs.bparts) (void)hipFree(ctx->tabs.bparts);
-  if (ctx->tabs.flag) (void)hipFree(ctx->tabs.flag);
+  if (ctx->tabs.flag) (void)(ctx->flag_host ? hipHostFree(ctx->tabs.flag) : hipFree(ctx->tabs.flag));
   if (ctx->tabs.qhat_w) (void)hipFree(ctx->tabs.qhat_w);
   if (ctx->tabs.qsh_w) (void)hipFree(ctx->tabs.qsh_w);
   delete ctx;
@@ -1425,6 +1437,25 @@ int nflhip_expand_small_dev(nflhip_ctx *ctx, void *d_data, const nflhip_operand 
   return NFLHIP_OK;
 }
 
+// the token of the next comparison on a slot (its mutex held): 1, 2, ... -- never the value the flag holds from an earlier call
+static int next_cmp_token(nflhip_ctx *ctx, unsigned slot, hipStream_t st) {
+  int &tok = ctx->cmp_token[slot];
+  if (tok == 0x7fffffff) {   // wrap: clear the flag once, start over
+    tok = 0;
+    if (ctx->flag_host) ctx->tabs.flag[slot] = 0;
+    else (void)hipMemsetAsync(ctx->tabs.flag + slot, 0, sizeof(int), st);
+  }
+  return ++tok;
+}
+static int read_cmp_flag(nflhip_ctx *ctx, unsigned slot, int token, hipStream_t st, int *hit) {
+  int flag = 0;
+  if (!ctx->flag_host) HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->tabs.flag + slot, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  if (ctx->flag_host) flag = *(volatile int *)(ctx->tabs.flag + slot);
+  *hit = flag == token ? 1 : 0;
+  return NFLHIP_OK;
+}
+
 static int any_cmp_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t batch, int want_eq, int *result, void *stream) {
   CHECK_CTX(ctx);
   if (!result || (batch && (!a || !b))) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
@@ -1432,16 +1463,13 @@ static int any_cmp_dev(nflhip_ctx *ctx, const void *a, const void *b, size_t bat
   const unsigned slot = ctx->cmp_next.fetch_add(1, std::memory_order_relaxed) % nflhip_ctx::kCmpSlots;
   std::lock_guard<std::mutex> lk(ctx->cmp_mu[slot]);  // held until the readback below has completed
   int *dflag = ctx->tabs.flag + slot;
+  const int token = next_cmp_token(ctx, slot, st);
   hipError_t e = DISPATCH_T(
-      ctx, launch_any_cmp<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)a, (const uint16_t *)b, batch, want_eq, dflag, st),
-      launch_any_cmp<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)a, (const uint32_t *)b, batch, want_eq, dflag, st),
-      launch_any_cmp<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)a, (const uint64_t *)b, batch, want_eq, dflag, st));
+      ctx, launch_any_cmp<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)a, (const uint16_t *)b, batch, want_eq, dflag, token, st),
+      launch_any_cmp<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)a, (const uint32_t *)b, batch, want_eq, dflag, token, st),
+      launch_any_cmp<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)a, (const uint64_t *)b, batch, want_eq, dflag, token, st));
   if (e != hipSuccess) return hipfail(ctx, e, "any_cmp");
-  int flag = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  *result = flag ? 1 : 0;
-  return NFLHIP_OK;
+  return read_cmp_flag(ctx, slot, token, st, result);
 }
 int nflhip_check_range_dev(nflhip_ctx *ctx, const void *d_data, size_t batch, int *bad, void *stream) {
   CHECK_CTX(ctx);
@@ -1450,15 +1478,12 @@ int nflhip_check_range_dev(nflhip_ctx *ctx, const void *d_data, size_t batch, in
   const unsigned slot = ctx->cmp_next.fetch_add(1, std::memory_order_relaxed) % nflhip_ctx::kCmpSlots;
   std::lock_guard<std::mutex> lk(ctx->cmp_mu[slot]);  // held until the readback below has completed
   int *dflag = ctx->tabs.flag + slot;
-  hipError_t e = DISPATCH_T(ctx, launch_check_range<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d_data, batch, dflag, st),
-                            launch_check_range<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)d_data, batch, dflag, st),
-                            launch_check_range<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)d_data, batch, dflag, st));
+  const int token = next_cmp_token(ctx, slot, st);
+  hipError_t e = DISPATCH_T(ctx, launch_check_range<uint16_t>(ctx->shape, ctx->tabs, (const uint16_t *)d_data, batch, dflag, token, st),
+                            launch_check_range<uint32_t>(ctx->shape, ctx->tabs, (const uint32_t *)d_data, batch, dflag, token, st),
+                            launch_check_range<uint64_t>(ctx->shape, ctx->tabs, (const uint64_t *)d_data, batch, dflag, token, st));
   if (e != hipSuccess) return hipfail(ctx, e, "check_range");
-  int flag = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  *bad = flag ? 1 : 0;
-  return NFLHIP_OK;
+  return read_cmp_flag(ctx, slot, token, st, bad);
 }
 
 int nflhip_check_range(const nflhip_ctx *ctx, const void *h_data, size_t batch, int *bad) {

@@ -90,9 +90,9 @@ hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const vo
                             const unsigned *strides = nullptr, unsigned out_stride = 1);  // strides in polynomials (0 = shared)
 template <typename T>
 hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
-                          int *flag, hipStream_t st);
+                          int *flag, int token, hipStream_t st);   // a hit stores `token` into *flag (no clearing, no atomic)
 template <typename T>
-hipError_t launch_check_range(const Shape &s, const DevTables &t, const T *d, size_t batch, int *flag, hipStream_t st);
+hipError_t launch_check_range(const Shape &s, const DevTables &t, const T *d, size_t batch, int *flag, int token, hipStream_t st);
 template <typename T>
 hipError_t launch_fill_uniform(const Shape &s, const DevTables &t, T *d, size_t first_poly, size_t batch, uint64_t seed,
                                int operand, hipStream_t st);

@@ -553,45 +553,45 @@ hipError_t launch_eval_expr(const Shape &s, const DevTables &t, T *out, const vo
 
 // expr::operator bool over eqmod / neqmod (ops.hpp:81-117): "any word" semantics
 template <typename T>
-__global__ void k_any_cmp(const T *a, const T *b, size_t total, int want_eq, int *flag) {
+__global__ void k_any_cmp(const T *a, const T *b, size_t total, int want_eq, int *flag, int token) {
   int hit = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
     hit |= ((a[i] == b[i]) == (want_eq != 0)) ? 1 : 0;
   if (__any(hit)) {
-    if ((threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    // every wave that saw a hit stores the SAME word: the call's token (no clearing pass in front of the kernel, no atomic -- the flag may
+    // live in pinned host memory, where the caller reads it after the stream has drained)
+    if ((threadIdx.x & 63) == 0) *flag = token;
   }
 }
 
 template <typename T>
 hipError_t launch_any_cmp(const Shape &s, const DevTables &t, const T *a, const T *b, size_t batch, int want_eq,
-                          int *flag, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
-  if (e != hipSuccess || batch == 0) return e;
+                          int *flag, int token, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
   const size_t total = batch * s.nm * s.n;
   const size_t blocks = stream_blocks(total, 2048);
-  hipLaunchKernelGGL((k_any_cmp<T>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, total, want_eq, flag);
+  hipLaunchKernelGGL((k_any_cmp<T>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, total, want_eq, flag, token);
   return hipGetLastError();
 }
 
 // CHECK_STRICTMOD (debug.hpp:33-37; the asserts of ops.hpp:131,148,211,235 and core.hpp:457-462): any word that is not the
 // canonical representative of its row's modulus
 template <typename T>
-__global__ void k_check_range(const T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t total, int *flag) {
+__global__ void k_check_range(const T *d, const ModConst<T> *__restrict__ mc, int logn, int nm, size_t total, int *flag, int token) {
   int hit = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
     hit |= d[i] >= mc[(int)((i >> logn) % (size_t)nm)].p ? 1 : 0;
   if (__any(hit)) {
-    if ((threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    if ((threadIdx.x & 63) == 0) *flag = token;   // (see k_any_cmp)
   }
 }
 
 template <typename T>
-hipError_t launch_check_range(const Shape &s, const DevTables &t, const T *d, size_t batch, int *flag, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
-  if (e != hipSuccess || batch == 0) return e;
+hipError_t launch_check_range(const Shape &s, const DevTables &t, const T *d, size_t batch, int *flag, int token, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
   const size_t total = batch * s.nm * s.n;
   hipLaunchKernelGGL((k_check_range<T>), dim3((unsigned)stream_blocks(total, 2048)), dim3(256), 0, st, d, (const ModConst<T> *)t.mc,
-                     s.logn, (int)s.nm, total, flag);
+                     s.logn, (int)s.nm, total, flag, token);
   return hipGetLastError();
 }
 
@@ -981,9 +981,9 @@ hipError_t launch_broadcast(void *dst, const void *one, size_t bytes_per_poly, s
   template hipError_t launch_eval_expr<T>(const Shape &, const DevTables &, T *, const void *const *, int,           \
                                           const unsigned char *, int, size_t, hipStream_t, const unsigned *,         \
                                           unsigned);                                                                 \
-  template hipError_t launch_check_range<T>(const Shape &, const DevTables &, const T *, size_t, int *, hipStream_t); \
+  template hipError_t launch_check_range<T>(const Shape &, const DevTables &, const T *, size_t, int *, int, hipStream_t); \
   template hipError_t launch_any_cmp<T>(const Shape &, const DevTables &, const T *, const T *, size_t, int, int *,  \
-                                        hipStream_t);                                                                \
+                                        int, hipStream_t);                                                           \
   template hipError_t launch_fill_uniform<T>(const Shape &, const DevTables &, T *, size_t, size_t, uint64_t, int,   \
                                              hipStream_t);                                                           \
   template hipError_t launch_bitrev_rows<T>(const Shape &, T *, size_t, hipStream_t);                                \
