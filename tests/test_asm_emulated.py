@@ -215,7 +215,7 @@ def test_emulated_u64_wave_per_row_fused_pipelines(n, nm, batch, generated, orac
             assert np.array_equal(r[0], w0) and (not two or np.array_equal(r[1], w1)), stem
 
 
-@pytest.mark.parametrize("n,nm,batch", [(1024, 3, 3), (2048, 2, 2), (4096, 1, 2)])
+@pytest.mark.parametrize("n,nm,batch", [(1024, 3, 3), (2048, 3, 3), (4096, 1, 2)])
 def test_emulated_u32_wave_per_row_fused_pipelines(n, nm, batch, generated, oracle_factory):
     """tools/gen_row1024_u32_asm.py build_fwd_fma / build_fma_inv (32-bit limbs, one / two / four waves per row): out0 = NTT(x) k0 +
     NTT(e0) [, out1 = NTT(x) k1 + NTT(e1)] with word and int8 operands (extreme bytes included), shared (stride 0) and dense keys / x,
