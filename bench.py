@@ -834,7 +834,7 @@ def main():
             a = b = c = None
             torch.cuda.empty_cache()
             side = {}
-            for wl, sb, st_, crt in (("A", 1 << 19, 20, False), ("C", 2048, 20, False), ("F", 2048, 20, False), ("E", 128, 20, True)):
+            for wl, sb, st_, crt in (("A", 1 << 19, 20, False), ("G", 8192, 20, False), ("C", 2048, 20, False), ("F", 2048, 20, False), ("E", 128, 20, True)):
                 try:
                     side[wl] = side_config(torch, Engine, wl, sb, st_, dev, with_crt=crt, round_trip=wl == "A")
                 except Exception as ex:   # reported, never fatal
@@ -905,7 +905,7 @@ def main():
     # Instructions per product: dynamic counts of the generated kernels on the interpreter of tests/asm_emu.py
     # (tools/asm_cost.py -> profiles/r03_valu_issue_model.txt; B and A agree with their SQ counter passes).
     model = "profiles/r06_valu_issue_model.txt"
-    valu = {"B": (90064, 1), "A": (1846, nm), "G": (97312, 1), "C": (835840, 1), "F": (477248, 1),
+    valu = {"B": (90064, 1), "A": (1846, nm), "G": (97312, 1), "C": (835840, 1), "F": (447008, 1),
             "E": (14347680, 1), "H": (227, 1), "T": (13, 1)}.get(kwl)
     if valu:
         inst_per_poly = valu[0] * valu[1]

@@ -202,7 +202,7 @@ def test_headline_line_carries_sustained_independent_secondary_and_side_configs(
     cfg = d["extras"]["configs"]
     rt = cfg["A"]["ntt_intt_round_trip"]        # BASELINE configs[0]'s operation on the device
     assert rt["value"] > 0 and rt["returns_the_input"] is True and "uint32_t,1024,1" in cfg["A"]["workload"]
-    for wl in ("A", "C", "F", "E"):
+    for wl in ("A", "G", "C", "F", "E"):   # (G = the reference's own test configuration (8192, 124, uint64_t))
         c = cfg[wl]
         assert "error" not in c, c
         assert c["self_check"] is True and c["value"] > 0 and 0 < c["frac"] < 1 and c["traffic_ratio"] is not None and c["traffic_ratio"] > 0.98
