@@ -93,12 +93,12 @@ template <class Op, class... Args> struct expr {
   using p = params<value_type>;
 
   // evaluate this node into the host polynomial `out`: the whole tree in ONE fused device pass when it fits the
-  // host-pointer program limits (<= 3 distinct leaves, stack depth <= 4), else one pass per node
+  // host-pointer program limits (<= 4 distinct leaves, stack depth <= 4), else one pass per node
   void eval(poly_type &out) const {
     program pr;
     lower(pr);
-    if (pr.ok && opcode<Op>::value >= 0 && pr.noperands <= 3) {
-      const void *h[3] = {nullptr, nullptr, nullptr};
+    if (pr.ok && opcode<Op>::value >= 0 && pr.noperands <= 4) {
+      const void *h[4] = {nullptr, nullptr, nullptr, nullptr};
       for (size_t k = 0; k < pr.noperands; ++k)
         h[k] = pr.pay[k] ? static_cast<payload_type *>(pr.pay[k])->host_ro().cdata() : pr.host[k];
       if (out.apply_program(pr, h)) return;

@@ -155,7 +155,7 @@ int nflhip_pointwise(nflhip_ctx *ctx, int op, void *h_out, const void *h_a, cons
  * (`x op y` with y on top); NFLHIP_EXPR_MUL_SHOUP pops b', b, a and pushes mulmod_shoup(a,b,b');
  * NFLHIP_EXPR_COMPUTE_SHOUP replaces the top.  At most 8 operands, 24 program bytes, stack depth 4;
  * exactly one value must remain.  `out` may alias any operand.  The host-pointer variant stages at
- * most 3 distinct operands. */
+ * most 4 distinct operands (4: `c = c + shoup(a * b, b')`, the result is formed over the first one's staging buffer). */
 #define NFLHIP_EXPR_ADD 0x10
 #define NFLHIP_EXPR_SUB 0x11
 #define NFLHIP_EXPR_MUL 0x12

@@ -2334,32 +2334,35 @@ int nflhip_eval(nflhip_ctx *ctx, void *h_out, const void *const *h_operands, siz
                 size_t proglen, size_t batch) {
   CHECK_CTX(ctx);
   if (!program || !h_operands) return fail(ctx, NFLHIP_ERR_INVALID, "NULL argument");
-  if (noperands == 0 || noperands > 3 || proglen == 0 || proglen > NFLHIP_EXPR_MAX_LEN)
-    return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "host-pointer eval takes at most 3 distinct operands");
+  if (noperands == 0 || noperands > 4 || proglen == 0 || proglen > NFLHIP_EXPR_MAX_LEN)
+    return fail(ctx, NFLHIP_ERR_UNSUPPORTED, "host-pointer eval takes at most 4 distinct operands");
   if (batch == 0) return NFLHIP_OK;
   if (!h_out) return fail(ctx, NFLHIP_ERR_INVALID, "NULL output");
   Staged s(ctx);
   const size_t bytes = poly_bytes(ctx, batch);
   for (size_t i = 0; i < noperands; ++i)
     if (!h_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
-  {
+  if (noperands <= 3) {   // (the pipeline's slots hold three inputs and the result)
     int prc = run_pipelined(ctx, batch, h_operands, (int)noperands, h_out, [&](const void *const *d, void *out, size_t cnt, void *st) {
       return eval_dev(ctx, out, d, noperands, program, proglen, cnt, st);
     });
     if (prc != NFLHIP_ERR_UNSUPPORTED) return prc;
   }
-  const void *dops[3] = {nullptr, nullptr, nullptr};
+  const void *dops[4] = {nullptr, nullptr, nullptr, nullptr};
   for (size_t i = 0; i < noperands; ++i) {
     if (!h_operands[i]) return fail(ctx, NFLHIP_ERR_INVALID, "NULL operand");
     int rc = s.in((int)i, h_operands[i], bytes);
     if (rc) return rc;
     dops[i] = ctx->stage[i];
   }
-  int rc = s.in(3, nullptr, bytes);
+  // four operands (c = c + shoup(a * b, b'): the reference's FMA with a precomputed companion) fill the four staging buffers: the result
+  // is written over the first one -- the evaluation is element-wise, `out` may alias an input
+  const int oslot = noperands == 4 ? 0 : 3;
+  int rc = s.in(oslot, nullptr, bytes);
   if (rc) return rc;
-  rc = eval_dev(ctx, ctx->stage[3], dops, noperands, program, proglen, batch, ctx->hstream);
+  rc = eval_dev(ctx, ctx->stage[oslot], dops, noperands, program, proglen, batch, ctx->hstream);
   if (rc) return rc;
-  return s.out(h_out, 3, bytes);
+  return s.out(h_out, oslot, bytes);
 }
 
 int nflhip_polymul(nflhip_ctx *ctx, void *c, const void *a, const void *b, size_t batch) {

@@ -275,6 +275,13 @@ def test_fused_expression_trees(lb, n, m, oracle_factory, engine_factory):
     assert np.array_equal(e.to_host(e.eval([0, 1, 1, CSH, MSH, 2, ADD], [da, db, dc])), want)
     # host-pointer variant
     assert np.array_equal(e.h_eval([0, 1, 2, MUL, ADD], [a, b, c]), o.pointwise(OP_ADD, a, o.pointwise(OP_MUL, b, c)))
+    # ... with four distinct operands: c + shoup(a * b, b') (tests/nfllib_demo_main_op.cpp:254; the result is formed over the first
+    # operand's staging buffer), at one polynomial (pinned staging) and at a batch past it
+    bp = o.pointwise(OP_COMPUTE_SHOUP, b)
+    assert np.array_equal(e.h_eval([0, 1, 2, 3, MSH, ADD], [c, a, b, bp]), o.pointwise(OP_ADD, c, o.pointwise(OP_MUL, a, b)))
+    assert np.array_equal(e.h_eval([0, 1, 2, 3, MSH, ADD], [c[:1], a[:1], b[:1], bp[:1]]), o.pointwise(OP_ADD, c[:1], o.pointwise(OP_MUL, a[:1], b[:1])))
+    with pytest.raises(NflHipError):
+        e.h_eval([0, 1, ADD, 2, ADD, 3, ADD, 4, ADD], [a, b, c, bp, a.copy()])     # five distinct operands: the host-pointer variant declines
     # malformed programs are rejected, not executed
     for bad in ([0, ADD], [0, 1], [0, 1, 2, 0, 1, ADD], [9, 0, ADD], [0, 1, 0x7f]):
         with pytest.raises(NflHipError):
