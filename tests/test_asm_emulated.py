@@ -489,13 +489,14 @@ def test_emulated_u64_register_resident_32768_word_rows(nm, batch, generated, or
     fa, fb = o.ntt(a), o.ntt(b)
     run = lambda stem, x, y: asm_emu.run_block_kernel(generated(stem), n, nm, prm, x, y, 15, words_per_thread=32)
     assert np.array_equal(run("ntt_fwd32768", a, a), fa)
-    assert np.array_equal(run("ntt_inv32768", fa, fa), a)
-    assert np.array_equal(run("polymul_ntt32768", a, fb), o.polymul(a, b))
-    # the pair of the composed product: b' travels through the scratch as [block][slot pair i][thread] x 16 bytes (coalesced
-    # on both sides), not in the reference's order
-    scratch = run("ntt_fwd32768s", b, b)
-    assert np.array_equal(scratch.reshape(batch, nm, 8, 8, 256, 2), fb.reshape(batch, nm, 8, 256, 8, 2).transpose(0, 1, 2, 4, 3, 5))
-    assert np.array_equal(run("polymul_ntt32768s", a, scratch), o.polymul(a, b))
+    if batch == 1:   # (the second parameter set spends its time on the shipped pair below)
+        assert np.array_equal(run("ntt_inv32768", fa, fa), a)
+        assert np.array_equal(run("polymul_ntt32768", a, fb), o.polymul(a, b))
+        # the pair of the composed product: b' travels through the scratch as [block][slot pair i][thread] x 16 bytes (coalesced
+        # on both sides), not in the reference's order
+        scratch = run("ntt_fwd32768s", b, b)
+        assert np.array_equal(scratch.reshape(batch, nm, 8, 8, 256, 2), fb.reshape(batch, nm, 8, 256, 8, 2).transpose(0, 1, 2, 4, 3, 5))
+        assert np.array_equal(run("polymul_ntt32768s", a, scratch), o.polymul(a, b))
     # ... and the same pair on incomplete transforms (level 2: b' is stored two stages short and unreduced, the point-wise step is the
     # base multiplication mod X^4 -+ zeta against the streamed groups, the inverse starts two stages late; all-(p - 1) rows included)
     P = np.asarray(prm.P[:nm], dtype=np.uint64)
