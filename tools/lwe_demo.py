@@ -66,9 +66,13 @@ def run(args):
         u, e1, e2 = (e.empty_small(B, FMT_I8) for _ in range(3))
 
         def encrypt():
-            e.sample_gauss_small(u, g, key, stream())                                  # u
-            e.sample_gauss_small(e1, g, key, stream(), amplifier=2)                    # 2*e_1
-            e.sample_gauss_small(e2, g, key, stream(), amplifier=2)                    # 2*e_2
+            if getattr(args, "multi_draw", True) and hasattr(e, "sample_gauss_small_multi"):
+                # u, 2*e_1, 2*e_2: one launch, byte for byte the three single draws (nflhip_sample_gauss_small_multi_dev, ABI 6)
+                e.sample_gauss_small_multi([u, e1, e2], g, key, [stream(), stream(), stream()], amplifiers=[1, 2, 2])
+            else:
+                e.sample_gauss_small(u, g, key, stream())                                  # u
+                e.sample_gauss_small(e1, g, key, stream(), amplifier=2)                    # 2*e_1
+                e.sample_gauss_small(e2, g, key, stream(), amplifier=2)                    # 2*e_2
             e.fwd_fma2(u, pka, e1, pkb, e2, out0=resa, out1=resb)                      # resa = u*pka + 2e_1, resb = u*pkb + 2e_2
 
         def decrypt():
@@ -158,6 +162,7 @@ def main():
                     help="keystream bits a Gaussian sample consumes: 32 = the narrow draw (and narrow uniform lanes), 64 = one word per value")
     ap.add_argument("--traffic", action="store_true")
     ap.add_argument("--fixed-key", action="store_true", help="a fixed sampler key (reproducible digests)")
+    ap.add_argument("--single-draws", action="store_false", dest="multi_draw", help="fused plan: three sampler launches per encryption instead of one")
     ap.add_argument("--grid", type=int, default=0, help="experiment: 1 / 2 force the 2-D / the XCD-dealt 1-D grid of the fused kernels (nflhip_debug_fused_grid)")
     args = ap.parse_args()
     out, ok = run(args)
